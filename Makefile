@@ -1,0 +1,23 @@
+# Builds the C-ABI HIP library (gfx950 only) and the oracle-side helpers.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH  ?= gfx950
+SRC   := avlen_amd/csrc
+OBJ   := build/obj
+LIB   := avlen_amd/lib/libavlen_hip.so
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Iinclude -Wall -Wno-unused-function -ffp-contract=off
+SRCS  := $(wildcard $(SRC)/*.hip)
+OBJS  := $(patsubst $(SRC)/%.hip,$(OBJ)/%.o,$(SRCS))
+
+all: $(LIB)
+
+$(OBJ)/%.o: $(SRC)/%.hip $(SRC)/common.h include/avlen_hip.h
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB): $(OBJS)
+	@mkdir -p $(dir $(LIB))
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+clean:
+	rm -rf build $(LIB)
+.PHONY: all clean

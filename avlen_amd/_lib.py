@@ -1,0 +1,175 @@
+"""ctypes binding of libavlen_hip.so (C ABI declared in include/avlen_hip.h).
+
+There is NO fallback: if the HIP library is missing this module raises at import, and every call
+checks the library's status code.  PyTorch only supplies device memory (``tensor.data_ptr()``) and the
+current HIP stream.
+"""
+import ctypes as C
+import os
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libavlen_hip.so")
+
+PREC_FP32, PREC_BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_QUICKGELU = 0, 1, 2
+
+_ERR = {1: "bad argument", 2: "kernel launch failed", 3: "workspace too small / missing"}
+
+
+class AvlenHipError(RuntimeError):
+    pass
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build it with `make` (hipcc --offload-arch=gfx950) or "
+        "`python -c 'import __graft_entry__ as g; g.build()'`. avlen_amd has no CPU/PyTorch fallback.")
+
+lib = C.CDLL(LIB_PATH)
+
+f32p = C.c_void_p
+vp = C.c_void_p
+
+
+class Linear(C.Structure):
+    _fields_ = [("w", f32p), ("b", f32p), ("out_f", C.c_int), ("in_f", C.c_int)]
+
+
+class Conv(C.Structure):
+    _fields_ = [("w", f32p), ("b", f32p), ("cin", C.c_int), ("cout", C.c_int), ("kh", C.c_int), ("kw", C.c_int),
+                ("stride", C.c_int), ("pad", C.c_int)]
+
+
+class Affine(C.Structure):
+    _fields_ = [("g", f32p), ("b", f32p)]
+
+
+class ResBlock(C.Structure):
+    _fields_ = [("conv1", Conv), ("conv2", Conv), ("down", Conv), ("bn1", Affine), ("bn2", Affine), ("bnd", Affine),
+                ("has_down", C.c_int)]
+
+
+class ResNet18(C.Structure):
+    _fields_ = [("conv1", Conv), ("bn1", Affine), ("block", ResBlock * 8), ("fc", Linear)]
+
+
+class Cnn3(C.Structure):
+    _fields_ = [("conv", Conv * 3), ("fc", Linear)]
+
+
+class Mha(C.Structure):
+    _fields_ = [("in_proj", Linear), ("out_proj", Linear)]
+
+
+class EncLayer(C.Structure):
+    _fields_ = [("self_attn", Mha), ("lin1", Linear), ("lin2", Linear), ("norm1", Affine), ("norm2", Affine)]
+
+
+class DecLayer(C.Structure):
+    _fields_ = [("self_attn", Mha), ("cross_attn", Mha), ("lin1", Linear), ("lin2", Linear), ("norm1", Affine),
+                ("norm2", Affine), ("norm3", Affine)]
+
+
+class Transformer(C.Structure):
+    _fields_ = [("enc", EncLayer), ("enc_norm", Affine), ("dec", DecLayer), ("dec_norm", Affine), ("d", C.c_int),
+                ("nhead", C.c_int)]
+
+
+class Smt(C.Structure):
+    _fields_ = [("pose", Linear), ("fus0", Linear), ("fus2", Linear), ("tr", Transformer)]
+
+
+class Dialog(C.Structure):
+    _fields_ = [("fus0", Linear), ("fus2", Linear), ("tr", Transformer), ("pe", f32p), ("pe_len", C.c_int)]
+
+
+class ClipBlock(C.Structure):
+    _fields_ = [("ln1", Affine), ("ln2", Affine), ("attn", Mha), ("fc", Linear), ("proj", Linear)]
+
+
+class ClipText(C.Structure):
+    _fields_ = [("tok_emb", f32p), ("pos_emb", f32p), ("block", ClipBlock * 12), ("ln_final", Affine),
+                ("text_proj", f32p), ("vocab", C.c_int), ("ctx", C.c_int), ("width", C.c_int), ("heads", C.c_int),
+                ("layers", C.c_int), ("out_dim", C.c_int)]
+
+
+class Gru(C.Structure):
+    _fields_ = [("w_ih", f32p), ("w_hh", f32p), ("b_ih", f32p), ("b_hh", f32p), ("in_f", C.c_int), ("hidden", C.c_int)]
+
+
+class Heads(C.Structure):
+    _fields_ = [("action", Linear), ("critic", Linear), ("unct", Linear), ("has_unct", C.c_int)]
+
+
+i32, f32, sz = C.c_int, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); every symbol declared in include/avlen_hip.h
+SIGNATURES = {
+    "avlen_gemm": (i32, [vp, i32, i32, vp, i32, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, sz, vp]),
+    "avlen_gemm_workspace_bytes": (sz, [i32, i32, i32, i32]),
+    "avlen_gemm_pick_splitk": (i32, [i32, i32, i32]),
+    "avlen_conv2d_nhwc": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "avlen_pack_conv_weight": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "avlen_pack_fc_after_flatten": (i32, [vp, vp, i32, i32, i32, vp]),
+    "avlen_groupnorm_nhwc": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp]),
+    "avlen_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp]),
+    "avlen_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "avlen_attention_fwd": (i32, [vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp]),
+    "avlen_attention_bwd": (i32, [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, i32, vp, i32,
+                                  i32, i32, i32, i32, i32, i32, f32, vp]),
+    "avlen_preprocess_image": (i32, [vp, vp, i32, i32, i32, f32, vp]),
+    "avlen_rgbd_concat": (i32, [vp, vp, vp, i32, i32, vp]),
+    "avlen_feature_assemble": (i32, [vp, i32, C.POINTER(Linear), vp, i32, vp, i32, vp, i32, vp, i32, i32, vp, vp, vp,
+                                     i32, i32, vp]),
+    "avlen_concat_rows": (i32, [vp, i32, i32, vp, i32, i32, vp, i32, i32, vp]),
+    "avlen_resnet18_workspace_bytes": (sz, [i32]),
+    "avlen_resnet18_fwd": (i32, [C.POINTER(ResNet18), vp, i32, i32, i32, f32, vp, i32, i32, vp, sz, vp]),
+    "avlen_cnn3_workspace_bytes": (sz, [C.POINTER(Cnn3), i32, i32, i32]),
+    "avlen_cnn3_fwd": (i32, [C.POINTER(Cnn3), vp, i32, i32, i32, vp, i32, i32, vp, sz, vp]),
+    "avlen_smt_workspace_bytes": (sz, [C.POINTER(Smt), i32, i32, i32, i32]),
+    "avlen_smt_fwd": (i32, [C.POINTER(Smt), vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "avlen_smt_bwd": (i32, [C.POINTER(Smt), C.POINTER(Smt), vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "avlen_dialog_workspace_bytes": (sz, [C.POINTER(Dialog), i32, i32]),
+    "avlen_dialog_fwd": (i32, [C.POINTER(Dialog), vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, sz, vp]),
+    "avlen_clip_text_workspace_bytes": (sz, [C.POINTER(ClipText), i32]),
+    "avlen_clip_text_fwd": (i32, [C.POINTER(ClipText), vp, vp, i32, i32, vp, sz, vp]),
+    "avlen_gru_workspace_bytes": (sz, [C.POINTER(Gru), i32, i32]),
+    "avlen_gru_fwd": (i32, [C.POINTER(Gru), vp, vp, vp, vp, vp, i32, i32, i32, vp, sz, vp]),
+    "avlen_heads_fwd": (i32, [C.POINTER(Heads), vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "avlen_ppo_loss_heads_bwd": (i32, [C.POINTER(Heads), C.POINTER(Heads), vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp,
+                                       f32, f32, f32, f32, vp, vp, i32, vp]),
+    "avlen_rl_mask_norm": (i32, [vp, i32, vp, vp]),
+    "avlen_gae_scan": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, vp]),
+    "avlen_grad_sumsq": (i32, [vp, sz, vp, vp]),
+    "avlen_adam_step": (i32, [vp, vp, vp, vp, sz, f32, f32, f32, f32, i32, f32, vp, vp]),
+    "avlen_extmem_insert": (i32, [vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "avlen_minibatch_gather": (i32, [vp, vp, vp, i32, i32, i32, sz, i32, vp]),
+    "avlen_copy_rows": (i32, [vp, i32, vp, i32, i32, i32, vp]),
+    "avlen_build_info": (C.c_char_p, []),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)            # AttributeError here == missing export: fail loudly
+    _fn.restype, _fn.argtypes = _res, _args
+
+
+def stream():
+    """The current torch HIP stream as a raw hipStream_t."""
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "avlen_hip needs contiguous device tensors"
+    return C.c_void_p(t.data_ptr())
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise AvlenHipError(f"avlen_hip call failed ({what}): {_ERR.get(rc, rc)}")
+
+
+def call(name, *args):
+    check(getattr(lib, name)(*args), name)

@@ -1,0 +1,264 @@
+// Multi-head attention core (softmax(QK^T)V) for short sequences (S <= ~512, head dim 32/64), gfx950.
+//
+// The sequences on this path are tiny by GPU standards (scene memory 301 tokens, CLIP text 77,
+// dialog memory 4), so one wavefront owns 64 query rows of one (sample, head): a lane keeps its q row
+// and output accumulator in registers, keys/values stream through LDS in chunks of 64 with the
+// PADDED KEYS COMPACTED AWAY while staging (wave ballot + prefix popcount), so an external memory that
+// is half empty costs half the work.  Softmax is the online (running max / sum) form, rescaled once
+// per 8 keys.  fp32 throughout (VALU): this is <20 % of the SMT block's FLOPs.
+#include "common.h"
+#include "../../include/avlen_hip.h"
+
+namespace {
+
+constexpr int CH = 64;      // keys per LDS chunk (= wave width: lane j stages key j)
+
+template <int D>
+__global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ K,
+                                                      int ldk, const float* __restrict__ V, int ldv,
+                                                      float* __restrict__ O, int ldo, const float* __restrict__ key_mask,
+                                                      float* __restrict__ lse, int H, int Sq, int Sk, int causal,
+                                                      float scale) {
+  __shared__ __attribute__((aligned(16))) float ks[CH * D];
+  __shared__ __attribute__((aligned(16))) float vs[CH * D];
+  __shared__ int kidx[CH];
+  const int lane = threadIdx.x;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int i = blockIdx.x * 64 + lane;                 // this lane's query row
+  const bool qok = i < Sq;
+  float q[D], o[D];
+#pragma unroll
+  for (int d = 0; d < D; d++) { q[d] = 0.f; o[d] = 0.f; }
+  if (qok) {
+    const float4* qp = reinterpret_cast<const float4*>(Q + ((long)b * Sq + i) * ldq + h * D);
+#pragma unroll
+    for (int d4 = 0; d4 < D / 4; d4++) {
+      float4 t = qp[d4];
+      q[d4 * 4] = t.x * scale; q[d4 * 4 + 1] = t.y * scale; q[d4 * 4 + 2] = t.z * scale; q[d4 * 4 + 3] = t.w * scale;
+    }
+  }
+  float m = -INFINITY, l = 0.f;
+  // causal: keys beyond the last query row of this block are never needed
+  const int sk_end = causal ? min(Sk, blockIdx.x * 64 + 64) : Sk;
+  for (int j0 = 0; j0 < sk_end; j0 += CH) {
+    const int j = j0 + lane;
+    bool valid = j < sk_end && (key_mask == nullptr || key_mask[(long)b * Sk + j] != 0.f);
+    unsigned long long bal = __ballot(valid);
+    int nvalid = __popcll(bal);
+    int pos = __popcll(bal & ((1ull << lane) - 1ull));
+    __syncthreads();                                   // previous chunk fully consumed
+    if (valid) {
+      const float4* kp = reinterpret_cast<const float4*>(K + ((long)b * Sk + j) * ldk + h * D);
+      const float4* vp = reinterpret_cast<const float4*>(V + ((long)b * Sk + j) * ldv + h * D);
+      float4* kd = reinterpret_cast<float4*>(&ks[pos * D]);
+      float4* vd = reinterpret_cast<float4*>(&vs[pos * D]);
+#pragma unroll
+      for (int d4 = 0; d4 < D / 4; d4++) { kd[d4] = kp[d4]; vd[d4] = vp[d4]; }
+      kidx[pos] = j;
+    }
+    __syncthreads();
+    for (int g0 = 0; g0 < nvalid; g0 += 8) {
+      float s[8];
+      float mg = -INFINITY;
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        int jj = g0 + u;
+        float acc = -INFINITY;
+        if (jj < nvalid) {                              // wave-uniform
+          const float4* kr = reinterpret_cast<const float4*>(&ks[jj * D]);
+          float a = 0.f;
+#pragma unroll
+          for (int d4 = 0; d4 < D / 4; d4++) {
+            float4 t = kr[d4];
+            a += q[d4 * 4] * t.x + q[d4 * 4 + 1] * t.y + q[d4 * 4 + 2] * t.z + q[d4 * 4 + 3] * t.w;
+          }
+          acc = (causal && kidx[jj] > i) ? -INFINITY : a;
+        }
+        s[u] = acc;
+        mg = fmaxf(mg, acc);
+      }
+      float mn = fmaxf(m, mg);
+      float corr = (m == -INFINITY) ? 0.f : __expf(m - mn);
+      l *= corr;
+#pragma unroll
+      for (int d = 0; d < D; d++) o[d] *= corr;
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        int jj = g0 + u;
+        if (jj < nvalid) {
+          float p = (s[u] == -INFINITY) ? 0.f : __expf(s[u] - mn);
+          l += p;
+          const float4* vr = reinterpret_cast<const float4*>(&vs[jj * D]);
+#pragma unroll
+          for (int d4 = 0; d4 < D / 4; d4++) {
+            float4 t = vr[d4];
+            o[d4 * 4] += p * t.x; o[d4 * 4 + 1] += p * t.y; o[d4 * 4 + 2] += p * t.z; o[d4 * 4 + 3] += p * t.w;
+          }
+        }
+      }
+      m = mn;
+    }
+  }
+  if (qok) {
+    float inv = l > 0.f ? 1.f / l : 0.f;
+    float4* op = reinterpret_cast<float4*>(O + ((long)b * Sq + i) * ldo + h * D);
+#pragma unroll
+    for (int d4 = 0; d4 < D / 4; d4++)
+      op[d4] = make_float4(o[d4 * 4] * inv, o[d4 * 4 + 1] * inv, o[d4 * 4 + 2] * inv, o[d4 * 4 + 3] * inv);
+    if (lse) lse[((long)b * H + h) * Sq + i] = m + __logf(l);
+  }
+}
+
+// dQ: lane per query (same streaming structure as forward).  Also writes delta = rowsum(dO * O).
+template <int D>
+__global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ K,
+                                                         int ldk, const float* __restrict__ V, int ldv,
+                                                         const float* __restrict__ O, int ldo,
+                                                         const float* __restrict__ dO, int lddo,
+                                                         const float* __restrict__ key_mask, const float* __restrict__ lse,
+                                                         float* __restrict__ delta, float* __restrict__ dQ, int lddq,
+                                                         int H, int Sq, int Sk, int causal, float scale) {
+  __shared__ __attribute__((aligned(16))) float ks[CH * D];
+  __shared__ __attribute__((aligned(16))) float vs[CH * D];
+  __shared__ int kidx[CH];
+  const int lane = threadIdx.x, b = blockIdx.z, h = blockIdx.y;
+  const int i = blockIdx.x * 64 + lane;
+  const bool qok = i < Sq;
+  float q[D], go[D], dq[D];
+  float dl = 0.f, ls = 0.f;
+#pragma unroll
+  for (int d = 0; d < D; d++) { q[d] = 0.f; go[d] = 0.f; dq[d] = 0.f; }
+  if (qok) {
+    const float* qp = Q + ((long)b * Sq + i) * ldq + h * D;
+    const float* gp = dO + ((long)b * Sq + i) * lddo + h * D;
+    const float* op = O + ((long)b * Sq + i) * ldo + h * D;
+#pragma unroll
+    for (int d = 0; d < D; d++) { q[d] = qp[d] * scale; go[d] = gp[d]; dl += gp[d] * op[d]; }
+    ls = lse[((long)b * H + h) * Sq + i];
+    delta[((long)b * H + h) * Sq + i] = dl;
+  }
+  const int sk_end = causal ? min(Sk, blockIdx.x * 64 + 64) : Sk;
+  for (int j0 = 0; j0 < sk_end; j0 += CH) {
+    const int j = j0 + lane;
+    bool valid = j < sk_end && (key_mask == nullptr || key_mask[(long)b * Sk + j] != 0.f);
+    unsigned long long bal = __ballot(valid);
+    int nvalid = __popcll(bal);
+    int pos = __popcll(bal & ((1ull << lane) - 1ull));
+    __syncthreads();
+    if (valid) {
+      const float4* kp = reinterpret_cast<const float4*>(K + ((long)b * Sk + j) * ldk + h * D);
+      const float4* vp = reinterpret_cast<const float4*>(V + ((long)b * Sk + j) * ldv + h * D);
+      float4* kd = reinterpret_cast<float4*>(&ks[pos * D]);
+      float4* vd = reinterpret_cast<float4*>(&vs[pos * D]);
+#pragma unroll
+      for (int d4 = 0; d4 < D / 4; d4++) { kd[d4] = kp[d4]; vd[d4] = vp[d4]; }
+      kidx[pos] = j;
+    }
+    __syncthreads();
+    for (int jj = 0; jj < nvalid; jj++) {
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < D; d++) { s += q[d] * ks[jj * D + d]; dp += go[d] * vs[jj * D + d]; }
+      float p = (causal && kidx[jj] > i) ? 0.f : __expf(s - ls);
+      float ds = p * (dp - dl) * scale;
+#pragma unroll
+      for (int d = 0; d < D; d++) dq[d] += ds * ks[jj * D + d];
+    }
+  }
+  if (qok) {
+    float* o = dQ + ((long)b * Sq + i) * lddq + h * D;
+#pragma unroll
+    for (int d = 0; d < D; d++) o[d] = dq[d];
+  }
+}
+
+// dK/dV: lane per key; queries (q, dO, lse, delta) stream through LDS in chunks of 64.
+template <int D>
+__global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ K,
+                                                          int ldk, const float* __restrict__ V, int ldv,
+                                                          const float* __restrict__ dO, int lddo,
+                                                          const float* __restrict__ key_mask, const float* __restrict__ lse,
+                                                          const float* __restrict__ delta, float* __restrict__ dK, int lddk,
+                                                          float* __restrict__ dV, int lddv, int H, int Sq, int Sk,
+                                                          int causal, float scale) {
+  __shared__ __attribute__((aligned(16))) float qs[CH * D];
+  __shared__ __attribute__((aligned(16))) float gs[CH * D];
+  __shared__ float s_lse[CH], s_del[CH];
+  const int lane = threadIdx.x, b = blockIdx.z, h = blockIdx.y;
+  const int j = blockIdx.x * 64 + lane;
+  const bool kok = j < Sk;
+  const bool kvalid = kok && (key_mask == nullptr || key_mask[(long)b * Sk + j] != 0.f);
+  float k[D], v[D], dk[D], dv[D];
+#pragma unroll
+  for (int d = 0; d < D; d++) { k[d] = 0.f; v[d] = 0.f; dk[d] = 0.f; dv[d] = 0.f; }
+  if (kok) {
+    const float* kp = K + ((long)b * Sk + j) * ldk + h * D;
+    const float* vp = V + ((long)b * Sk + j) * ldv + h * D;
+#pragma unroll
+    for (int d = 0; d < D; d++) { k[d] = kp[d]; v[d] = vp[d]; }
+  }
+  const int i_beg = causal ? blockIdx.x * 64 : 0;       // queries before this block's first key see none of its keys
+  for (int i0 = i_beg; i0 < Sq; i0 += CH) {
+    const int i = i0 + lane;
+    __syncthreads();
+    if (i < Sq) {
+      const float4* qp = reinterpret_cast<const float4*>(Q + ((long)b * Sq + i) * ldq + h * D);
+      const float4* gp = reinterpret_cast<const float4*>(dO + ((long)b * Sq + i) * lddo + h * D);
+      float4* qd = reinterpret_cast<float4*>(&qs[lane * D]);
+      float4* gd = reinterpret_cast<float4*>(&gs[lane * D]);
+#pragma unroll
+      for (int d4 = 0; d4 < D / 4; d4++) { qd[d4] = qp[d4]; gd[d4] = gp[d4]; }
+      s_lse[lane] = lse[((long)b * H + h) * Sq + i];
+      s_del[lane] = delta[((long)b * H + h) * Sq + i];
+    }
+    __syncthreads();
+    const int nq = min(CH, Sq - i0);
+    for (int ii = 0; ii < nq; ii++) {
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < D; d++) { s += qs[ii * D + d] * k[d]; dp += gs[ii * D + d] * v[d]; }
+      float p = (!kvalid || (causal && j > i0 + ii)) ? 0.f : __expf(s * scale - s_lse[ii]);
+      float ds = p * (dp - s_del[ii]) * scale;
+#pragma unroll
+      for (int d = 0; d < D; d++) { dv[d] += p * gs[ii * D + d]; dk[d] += ds * qs[ii * D + d]; }
+    }
+  }
+  if (kok) {
+    float* ok = dK + ((long)b * Sk + j) * lddk + h * D;
+    float* ov = dV + ((long)b * Sk + j) * lddv + h * D;
+#pragma unroll
+    for (int d = 0; d < D; d++) { ok[d] = dk[d]; ov[d] = dv[d]; }
+  }
+}
+
+}  // namespace
+
+extern "C" int avlen_attention_fwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O,
+                                   int ldo, const float* key_mask, float* lse, int B, int H, int Sq, int Sk, int D,
+                                   int causal, float scale, hipStream_t stream) {
+  if (B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0 || (ldq | ldk | ldv | ldo) % 4) return AVLEN_ERR_ARG;
+  dim3 grid(ceil_div(Sq, 64), H, B), block(64);
+  if (D == 32)
+    hipLaunchKernelGGL((attn_fwd_kernel<32>), grid, block, 0, stream, Q, ldq, K, ldk, V, ldv, O, ldo, key_mask, lse, H, Sq, Sk, causal, scale);
+  else if (D == 64)
+    hipLaunchKernelGGL((attn_fwd_kernel<64>), grid, block, 0, stream, Q, ldq, K, ldk, V, ldv, O, ldo, key_mask, lse, H, Sq, Sk, causal, scale);
+  else return AVLEN_ERR_ARG;
+  return avlen_launch_status();
+}
+
+extern "C" int avlen_attention_bwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
+                                   const float* O, int ldo, const float* dO, int lddo, const float* key_mask,
+                                   const float* lse, float* delta, float* dQ, int lddq, float* dK, int lddk, float* dV,
+                                   int lddv, int B, int H, int Sq, int Sk, int D, int causal, float scale,
+                                   hipStream_t stream) {
+  if (B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0 || (ldq | ldk | ldv | lddo) % 4) return AVLEN_ERR_ARG;
+  dim3 gq(ceil_div(Sq, 64), H, B), gk(ceil_div(Sk, 64), H, B), block(64);
+  if (D == 32) {
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<32>), gq, block, 0, stream, Q, ldq, K, ldk, V, ldv, O, ldo, dO, lddo, key_mask, lse, delta, dQ, lddq, H, Sq, Sk, causal, scale);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<32>), gk, block, 0, stream, Q, ldq, K, ldk, V, ldv, dO, lddo, key_mask, lse, delta, dK, lddk, dV, lddv, H, Sq, Sk, causal, scale);
+  } else if (D == 64) {
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<64>), gq, block, 0, stream, Q, ldq, K, ldk, V, ldv, O, ldo, dO, lddo, key_mask, lse, delta, dQ, lddq, H, Sq, Sk, causal, scale);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<64>), gk, block, 0, stream, Q, ldq, K, ldk, V, ldv, dO, lddo, key_mask, lse, delta, dK, lddk, dV, lddv, H, Sq, Sk, causal, scale);
+  } else return AVLEN_ERR_ARG;
+  return avlen_launch_status();
+}

@@ -1,0 +1,171 @@
+// Small HBM-bound kernels: sensor preprocessing, feature-column assembly, weight packing, row copies.
+#include "common.h"
+#include "../../include/avlen_hip.h"
+
+namespace {
+
+// (B,S,S,C) -> (B,64,64,C), y = scale * mean over k x k blocks (k = S/64).  One thread per output
+// pixel-channel; a wave reads k contiguous runs of k*C floats per output row => coalesced.
+__global__ void preprocess_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int S, int C, int k,
+                                  float scale) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long tot = (long)B * 64 * 64 * C;
+  if (idx >= tot) return;
+  int c = (int)(idx % C);
+  long p = idx / C;
+  int ox = (int)(p % 64), oy = (int)((p / 64) % 64), b = (int)(p / 4096);
+  const float* src = x + (((long)b * S + oy * k) * S + ox * k) * C + c;
+  float s = 0.f;
+  for (int dy = 0; dy < k; dy++)
+    for (int dx = 0; dx < k; dx++) s += src[((long)dy * S + dx) * C];
+  // torch: (x/255) then area-mean.  Keep that order of roundings: scale each tap, then average.
+  y[idx] = s * scale / (float)(k * k);
+}
+
+__global__ void preprocess_exact_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int S, int C, int k,
+                                        float div) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long tot = (long)B * 64 * 64 * C;
+  if (idx >= tot) return;
+  int c = (int)(idx % C);
+  long p = idx / C;
+  int ox = (int)(p % 64), oy = (int)((p / 64) % 64), b = (int)(p / 4096);
+  const float* src = x + (((long)b * S + oy * k) * S + ox * k) * C + c;
+  float s = 0.f;
+  for (int dy = 0; dy < k; dy++)
+    for (int dx = 0; dx < k; dx++) s += src[((long)dy * S + dx) * C] / div;   // same rounding as x/255 then mean
+  y[idx] = s / (float)(k * k);
+}
+
+__global__ void rgbd_concat_kernel(const float* __restrict__ rgb, const float* __restrict__ depth,
+                                   float* __restrict__ y, long npix) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix) return;
+  float4 o;
+  o.x = rgb[i * 3] / 255.0f; o.y = rgb[i * 3 + 1] / 255.0f; o.z = rgb[i * 3 + 2] / 255.0f; o.w = depth[i];
+  reinterpret_cast<float4*>(y)[i] = o;
+}
+
+__global__ void assemble_kernel(float* __restrict__ feats, int ldf, const float* __restrict__ aw,
+                                const float* __restrict__ ab, int n_act_out, int n_act_in,
+                                const int64_t* __restrict__ prev_actions, int col_action,
+                                const float* __restrict__ category, int col_cat, const float* __restrict__ pose,
+                                int col_pose, const float* __restrict__ extra, int n_extra, int col_extra,
+                                const float* __restrict__ cbel, const float* __restrict__ lbel, float* __restrict__ goal,
+                                int d_goal, int B) {
+  int b = blockIdx.x, t = threadIdx.x;
+  if (b >= B) return;
+  float* f = feats + (long)b * ldf;
+  if (aw && t < n_act_out) {
+    long a = prev_actions[b];
+    float v = ab[t];
+    if (a >= 0 && a < n_act_in) v += aw[(long)t * n_act_in + a];
+    f[col_action + t] = v;
+  }
+  if (category && t < 21) f[col_cat + t] = category[(long)b * 21 + t];
+  if (pose && t < 4) f[col_pose + t] = pose[(long)b * 4 + t];
+  if (extra) for (int i = t; i < n_extra; i += blockDim.x) f[col_extra + i] = extra[(long)b * n_extra + i];
+  if (goal) {
+    for (int i = t; i < d_goal; i += blockDim.x) {
+      float v = 0.f;
+      if (i < 21) v = cbel[(long)b * 21 + i];
+      else if (i < 23) v = lbel[(long)b * 2 + (i - 21)];
+      goal[(long)b * d_goal + i] = v;
+    }
+  }
+}
+
+__global__ void concat_rows_kernel(const float* __restrict__ a, int lda, int na, const float* __restrict__ b, int ldb,
+                                   int nb, float* __restrict__ out, int ldo, int B) {
+  int r = blockIdx.x;
+  for (int i = threadIdx.x; i < na + nb; i += blockDim.x)
+    out[(long)r * ldo + i] = i < na ? a[(long)r * lda + i] : b[(long)r * ldb + (i - na)];
+}
+
+__global__ void pack_conv_kernel(const float* __restrict__ w, float* __restrict__ o, int O, int I, int KH, int KW) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long tot = (long)O * I * KH * KW;
+  if (idx >= tot) return;
+  int ci = (int)(idx % I);
+  long r = idx / I;
+  int kx = (int)(r % KW); r /= KW;
+  int ky = (int)(r % KH);
+  int oc = (int)(r / KH);
+  o[idx] = w[(((long)oc * I + ci) * KH + ky) * KW + kx];
+}
+
+__global__ void pack_fc_kernel(const float* __restrict__ w, float* __restrict__ o, int O, int C, int HW) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long tot = (long)O * C * HW;
+  if (idx >= tot) return;
+  int c = (int)(idx % C);
+  long r = idx / C;
+  int p = (int)(r % HW);
+  int oc = (int)(r / HW);
+  o[idx] = w[((long)oc * C + c) * HW + p];
+}
+
+__global__ void copy_rows_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd, int rows,
+                                 int cols) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)rows * cols) return;
+  int r = (int)(idx / cols), c = (int)(idx % cols);
+  dst[(long)r * ldd + c] = src[(long)r * lds + c];
+}
+
+}  // namespace
+
+static inline dim3 grid1d(long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
+
+extern "C" int avlen_preprocess_image(const float* x, float* y, int B, int S, int C, float divisor, hipStream_t stream) {
+  if (S % 64 || B <= 0) return AVLEN_ERR_ARG;
+  long tot = (long)B * 4096 * C;
+  if (divisor == 1.0f)
+    hipLaunchKernelGGL(preprocess_kernel, grid1d(tot), dim3(256), 0, stream, x, y, B, S, C, S / 64, 1.0f);
+  else
+    hipLaunchKernelGGL(preprocess_exact_kernel, grid1d(tot), dim3(256), 0, stream, x, y, B, S, C, S / 64, divisor);
+  return avlen_launch_status();
+}
+
+extern "C" int avlen_rgbd_concat(const float* rgb, const float* depth, float* y, int B, int HW, hipStream_t stream) {
+  long npix = (long)B * HW;
+  hipLaunchKernelGGL(rgbd_concat_kernel, grid1d(npix), dim3(256), 0, stream, rgb, depth, y, npix);
+  return avlen_launch_status();
+}
+
+extern "C" int avlen_feature_assemble(float* feats, int ldf, const avlen_linear* act, const int64_t* prev_actions,
+                                      int col_action, const float* category, int col_cat, const float* pose,
+                                      int col_pose, const float* extra, int n_extra, int col_extra,
+                                      const float* category_belief, const float* location_belief, float* goal,
+                                      int d_goal, int B, hipStream_t stream) {
+  if (B <= 0) return AVLEN_ERR_ARG;
+  if (act && (act->out_f > 64 || !prev_actions)) return AVLEN_ERR_ARG;
+  hipLaunchKernelGGL(assemble_kernel, dim3(B), dim3(64), 0, stream, feats, ldf, act ? act->w : nullptr,
+                     act ? act->b : nullptr, act ? act->out_f : 0, act ? act->in_f : 0, prev_actions, col_action,
+                     category, col_cat, pose, col_pose, extra, n_extra, col_extra, category_belief, location_belief,
+                     goal, d_goal, B);
+  return avlen_launch_status();
+}
+
+extern "C" int avlen_concat_rows(const float* a, int lda, int na, const float* b, int ldb, int nb, float* out, int ldo,
+                                 int B, hipStream_t stream) {
+  hipLaunchKernelGGL(concat_rows_kernel, dim3(B), dim3(128), 0, stream, a, lda, na, b, ldb, nb, out, ldo, B);
+  return avlen_launch_status();
+}
+
+extern "C" int avlen_pack_conv_weight(const float* w, float* o, int O, int I, int KH, int KW, hipStream_t stream) {
+  hipLaunchKernelGGL(pack_conv_kernel, grid1d((long)O * I * KH * KW), dim3(256), 0, stream, w, o, O, I, KH, KW);
+  return avlen_launch_status();
+}
+
+extern "C" int avlen_pack_fc_after_flatten(const float* w, float* o, int O, int C, int HW, hipStream_t stream) {
+  hipLaunchKernelGGL(pack_fc_kernel, grid1d((long)O * C * HW), dim3(256), 0, stream, w, o, O, C, HW);
+  return avlen_launch_status();
+}
+
+extern "C" int avlen_copy_rows(const float* src, int lds, float* dst, int ldd, int rows, int cols, hipStream_t stream) {
+  hipLaunchKernelGGL(copy_rows_kernel, grid1d((long)rows * cols), dim3(256), 0, stream, src, lds, dst, ldd, rows, cols);
+  return avlen_launch_status();
+}
+
+extern "C" const char* avlen_build_info(void) { return "avlen_hip gfx950 (CDNA4) " __DATE__ " " __TIME__; }

@@ -1,0 +1,665 @@
+// Module-level compositions of the avlen_hip kernels: the reference's nn.Modules on this path, each as
+// ONE C entry point that enqueues its whole launch sequence on the caller's stream using caller scratch.
+//   avlen_resnet18_fwd   <- SMTCNN tower        (smt_cnn.py:78-115, smt_resnet.py:132-146)
+//   avlen_cnn3_fwd       <- AudioCNN/VisualCNN  (audio_cnn.py:136-151, visual_cnn.py:165-190)
+//   avlen_smt_fwd/_bwd   <- SMTStateEncoder     (smt_state_encoder.py:109-276) + nn.Transformer
+//   avlen_dialog_fwd     <- DialogStateEncoder  (dialog_state_encoder.py:114-155)
+//   avlen_clip_text_fwd  <- CLIP.encode_text    (third party; call site policy.py:847-849)
+//   avlen_gru_fwd        <- RNNStateEncoder     (av_nav/models/rnn_state_encoder.py:80-143)
+#include "common.h"
+#include "../../include/avlen_hip.h"
+#include <math.h>
+
+int avlen_groupnorm_nhwc_ws(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+                            int B, int HW, int C, int G, int relu, float eps, float* part, hipStream_t stream);
+extern "C" size_t avlen_groupnorm_workspace_bytes(int B, int C);
+
+#define TRY(x) do { int _rc = (x); if (_rc != AVLEN_OK) return _rc; } while (0)
+
+namespace {
+
+constexpr size_t GEMM_SCRATCH = 96u << 20;       // split-K / accumulate slabs shared by one module call
+
+struct Ctx { hipStream_t st; int prec; void* gws; size_t gws_bytes; };
+
+// Y[M, out_f] (ldy) = act(X[M, in_f] (ldx) * W^T + b) + res
+int linear(const Ctx& c, const avlen_linear& L, const float* X, int ldx, float* Y, int ldy, int M, int act,
+           const float* res, int ldr) {
+  int sk = avlen_gemm_pick_splitk(M, L.out_f, L.in_f);
+  if (avlen_gemm_workspace_bytes(M, L.out_f, L.in_f, sk) > c.gws_bytes) sk = 1;
+  return avlen_gemm(X, ldx, 0, L.w, L.in_f, 0, Y, ldy, L.b, res, ldr, M, L.out_f, L.in_f, act, c.prec, sk, 0.f,
+                    c.gws, c.gws_bytes, c.st);
+}
+// Y = act(X * W[r0:r0+n, :]^T + b[r0:r0+n])   (a row-slice of a packed projection, e.g. the V third of in_proj)
+int linear_rows(const Ctx& c, const avlen_linear& L, int r0, int n, const float* X, int ldx, float* Y, int ldy, int M,
+                int act, const float* res, int ldr) {
+  avlen_linear S = L;
+  S.w = L.w + (size_t)r0 * L.in_f; S.b = L.b ? L.b + r0 : nullptr; S.out_f = n;
+  return linear(c, S, X, ldx, Y, ldy, M, act, res, ldr);
+}
+// dX[M, in_f] = dY[M, out_f] * W (+ add)     add==dX allowed (in-place accumulate)
+int linear_dx(const Ctx& c, const avlen_linear& L, const float* dY, int ldy, float* dX, int ldx, int M, const float* add,
+              int ldadd) {
+  return avlen_gemm(dY, ldy, 0, L.w, L.in_f, 1, dX, ldx, nullptr, add, ldadd, M, L.in_f, L.out_f, 0, c.prec, 1, 0.f,
+                    c.gws, c.gws_bytes, c.st);
+}
+// dW[out_f, in_f] += dY^T X   (reduction over the M rows, split over the chip)
+int linear_dw(const Ctx& c, const avlen_linear& G, const float* dY, int ldy, const float* X, int ldx, int M) {
+  int sk = avlen_gemm_pick_splitk(G.out_f, G.in_f, M);
+  while (sk > 1 && avlen_gemm_workspace_bytes(G.out_f, G.in_f, M, sk) > c.gws_bytes) sk /= 2;
+  return avlen_gemm(dY, ldy, 1, X, ldx, 1, G.w, G.in_f, nullptr, nullptr, 0, G.out_f, G.in_f, M, 0, c.prec, sk, 1.f,
+                    c.gws, c.gws_bytes, c.st);
+}
+
+// ---------------------------------------------------------------- small kernels used by the modules
+__global__ void colsum_acc_kernel(const float* __restrict__ dY, int ld, float* __restrict__ out, int rows, int N,
+                                  int rows_per_block) {
+  __shared__ float sh[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float s = 0.f;
+  if (col < N) for (int r = r0 + w; r < r1; r += 4) s += dY[(long)r * ld + col];
+  sh[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && col < N) atomicAdd(&out[col], sh[0][lane] + sh[1][lane] + sh[2][lane] + sh[3][lane]);
+}
+int colsum_acc(const Ctx& c, const float* dY, int ld, float* out, int rows, int N) {
+  if (!out) return AVLEN_OK;
+  int rpb = rows >= 65536 ? 1024 : rows >= 2048 ? 128 : 32;
+  hipLaunchKernelGGL(colsum_acc_kernel, dim3(ceil_div(N, 64), ceil_div(rows, rpb)), dim3(256), 0, c.st, dY, ld, out,
+                     rows, N, rpb);
+  return avlen_launch_status();
+}
+
+__global__ void relu_bwd_kernel(float* __restrict__ dx, const float* __restrict__ y, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && y[i] <= 0.f) dx[i] = 0.f;
+}
+int relu_bwd(const Ctx& c, float* dx, const float* y, long n) {
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.st, dx, y, n);
+  return avlen_launch_status();
+}
+
+// SMT fusion input.  Row (b, s): src = s < M ? memory[s, b, :] : x[b, :]
+//   XF[row] = [ src[0:pc] | pose_encoder(format(relative_pose(x_pose[b] -> src_pose))) (16) | src[pc+4:F] ]
+//   FMT[row] = formatted 5-vector (kept for the pose-encoder gradient)
+//   maskx[b, s] = s < M ? (pretraining ? 0 : masks[b, s]) : 1
+// cto (current token only): S = 1 and only the s = M row is produced.
+__global__ void smt_build_kernel(const float* __restrict__ x, const float* __restrict__ memory,
+                                 const float* __restrict__ masks, const float* __restrict__ pw,
+                                 const float* __restrict__ pb, float* __restrict__ XF, int ldxf, float* __restrict__ FMT,
+                                 float* __restrict__ maskx, int B, int M, int F, int pc, int cto) {
+  const int S = cto ? 1 : M + 1;
+  const int row = blockIdx.x;                 // b * S + s
+  const int b = row / S, s = cto ? M : row % S;
+  const float* src = (s < M) ? memory + ((long)s * B + b) * F : x + (long)b * F;
+  const float* xp = x + (long)b * F + pc;
+  __shared__ float fmt[5];
+  const int t = threadIdx.x;
+  if (t == 0) {
+    float ax = xp[0], ay = xp[1], ah = xp[2];
+    float bx = src[pc], by = src[pc + 1], bh = src[pc + 2], bt = src[pc + 3];
+    float heading_a = -ah, heading_b = -bh;
+    float dx = bx - ax, dy = by - ay;
+    float r = sqrtf(dx * dx + dy * dy);
+    float phi = atan2f(dy, dx) - heading_a;
+    float x_ab = r * cosf(phi), y_ab = r * sinf(phi);
+    float dh = heading_b - heading_a;
+    dh = -atan2f(sinf(dh), cosf(dh));
+    fmt[0] = x_ab; fmt[1] = y_ab; fmt[2] = cosf(dh); fmt[3] = sinf(dh); fmt[4] = expf(-bt);
+    if (maskx) maskx[(long)b * S + (cto ? 0 : s)] = (s < M) ? masks[(long)b * M + s] : 1.f;
+  }
+  __syncthreads();
+  float* o = XF + (long)row * ldxf;
+  for (int i = t; i < F + 12; i += blockDim.x) {
+    float v;
+    if (i < pc) v = src[i];
+    else if (i < pc + 16) {
+      int j = i - pc;
+      v = pb[j];
+#pragma unroll
+      for (int k = 0; k < 5; k++) v += pw[j * 5 + k] * fmt[k];
+    } else v = src[i - 12];
+    o[i] = v;
+  }
+  if (FMT && t < 5) FMT[(long)row * 8 + t] = fmt[t];
+}
+
+// dW_pose[16][5] += dPE^T FMT ; db_pose[16] += colsum(dPE)    (dPE: [R,16], FMT: [R,8])
+__global__ void pose_grad_kernel(const float* __restrict__ dPE, const float* __restrict__ FMT, float* __restrict__ gw,
+                                 float* __restrict__ gb, long R, int rows_per_block) {
+  __shared__ float acc[96];
+  const int t = threadIdx.x;            // 96 threads: t<80 -> (j=t/5,k=t%5) weight grads, t>=80 -> bias j=t-80
+  long r0 = (long)blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
+  float s = 0.f;
+  if (t < 80) { int j = t / 5, k = t % 5; for (long r = r0; r < r1; r++) s += dPE[r * 16 + j] * FMT[r * 8 + k]; }
+  else if (t < 96) { int j = t - 80; for (long r = r0; r < r1; r++) s += dPE[r * 16 + j]; }
+  (void)acc;
+  if (t < 80) atomicAdd(&gw[t], s); else if (t < 96) atomicAdd(&gb[t - 80], s);
+}
+
+// dialog sequence rows: seq[b, s, :] = [ (s<M ? memory_state[s,b,:] : x_att[b,:]) | d_emb[b,:] (optional) ]
+__global__ void dialog_build_kernel(const float* __restrict__ x_att, const float* __restrict__ mem,
+                                    const float* __restrict__ masks, const float* __restrict__ d_emb,
+                                    float* __restrict__ seq, int ldseq, float* __restrict__ maskx, int B, int M, int d) {
+  const int S = M + 1, row = blockIdx.x, b = row / S, s = row % S;
+  const float* src = s < M ? mem + ((long)s * B + b) * d : x_att + (long)b * d;
+  float* o = seq + (long)row * ldseq;
+  for (int i = threadIdx.x; i < d; i += blockDim.x) {
+    o[i] = src[i];
+    if (d_emb) o[d + i] = d_emb[(long)b * d + i];
+  }
+  if (threadIdx.x == 0) maskx[(long)b * S + s] = s < M ? masks[(long)b * M + s] : 1.f;
+}
+// seq[b, s, :] += pe[int(agent_step[b]), :]
+__global__ void add_pe_kernel(float* __restrict__ seq, const float* __restrict__ pe, const float* __restrict__ step,
+                              int S, int d, int pe_len) {
+  const int row = blockIdx.x, b = row / S;
+  int idx = (int)step[b];
+  idx = idx < 0 ? 0 : (idx >= pe_len ? pe_len - 1 : idx);
+  for (int i = threadIdx.x; i < d; i += blockDim.x) seq[(long)row * d + i] += pe[(long)idx * d + i];
+}
+
+// CLIP: x[b, t, :] = tok_emb[tokens[b,t]] + pos_emb[t]; eot[b] = argmax_t tokens[b, t]
+__global__ void clip_embed_kernel(const int64_t* __restrict__ tokens, const float* __restrict__ tok_emb,
+                                  const float* __restrict__ pos_emb, float* __restrict__ x, int ctx, int width, int vocab) {
+  const int row = blockIdx.x, t = row % ctx;
+  long id = tokens[row];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const float4* e = reinterpret_cast<const float4*>(tok_emb + id * width);
+  const float4* p = reinterpret_cast<const float4*>(pos_emb + (long)t * width);
+  float4* o = reinterpret_cast<float4*>(x + (long)row * width);
+  for (int i = threadIdx.x; i < width / 4; i += blockDim.x) {
+    float4 a = e[i], c = p[i];
+    o[i] = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
+  }
+}
+__global__ void clip_gather_eot_kernel(const int64_t* __restrict__ tokens, const float* __restrict__ x,
+                                       float* __restrict__ out, int ctx, int width) {
+  const int b = blockIdx.x;
+  __shared__ int s_eot;
+  if (threadIdx.x == 0) {
+    long best = tokens[(long)b * ctx]; int bi = 0;
+    for (int t = 1; t < ctx; t++) { long v = tokens[(long)b * ctx + t]; if (v > best) { best = v; bi = t; } }
+    s_eot = bi;
+  }
+  __syncthreads();
+  const float* src = x + ((long)b * ctx + s_eot) * width;
+  for (int i = threadIdx.x; i < width; i += blockDim.x) out[(long)b * width + i] = src[i];
+}
+
+// GRU gates (rnn_state_encoder.py via nn.GRU): r,z,n ordering; h' = (1-z)*n + z*h
+__global__ void gru_mask_kernel(const float* __restrict__ h, const float* __restrict__ mask, float* __restrict__ hm, int N, int H) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (long)N * H) hm[i] = h[i] * mask[i / H];
+}
+__global__ void gru_gate_kernel(const float* __restrict__ gi, const float* __restrict__ gh, const float* __restrict__ hm,
+                                float* __restrict__ hout, float* __restrict__ out, int N, int H) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)N * H) return;
+  int n = (int)(i / H), j = (int)(i % H);
+  const float* a = gi + (long)n * 3 * H; const float* b = gh + (long)n * 3 * H;
+  float r = 1.f / (1.f + expf(-(a[j] + b[j])));
+  float z = 1.f / (1.f + expf(-(a[H + j] + b[H + j])));
+  float nn = tanhf(a[2 * H + j] + r * b[2 * H + j]);
+  float hv = (1.f - z) * nn + z * hm[i];
+  hout[i] = hv; out[i] = hv;
+}
+
+}  // namespace
+
+// =====================================================================================================
+// ResNet-18 tower
+// =====================================================================================================
+extern "C" size_t avlen_resnet18_workspace_bytes(int B) {
+  size_t act = (size_t)B * 64 * 64 * 16 * sizeof(float);
+  return 5 * (act + 256) + avlen_groupnorm_workspace_bytes(B, 128) + GEMM_SCRATCH + 4096;
+}
+
+extern "C" int avlen_resnet18_fwd(const avlen_resnet18* net, const float* img, int B, int S, int C, float divisor,
+                                  float* out, int ld_out, int prec, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!net || B <= 0 || ws_bytes < avlen_resnet18_workspace_bytes(B)) return AVLEN_ERR_WS;
+  WsBump w(ws, ws_bytes);
+  size_t act = (size_t)B * 64 * 64 * 16;
+  float* x0 = w.take<float>(act);
+  float* buf[4];
+  for (int i = 0; i < 4; i++) buf[i] = w.take<float>(act);
+  float* part = w.take<float>(avlen_groupnorm_workspace_bytes(B, 128) / sizeof(float));
+  void* gws = w.take<char>(GEMM_SCRATCH);
+  Ctx c{st, prec, gws, GEMM_SCRATCH};
+
+  TRY(avlen_preprocess_image(img, x0, B, S, C, divisor, st));
+  const avlen_conv& c1 = net->conv1;
+  TRY(avlen_conv2d_nhwc(x0, c1.w, nullptr, nullptr, buf[0], B, 64, 64, c1.cin, c1.cout, c1.kh, c1.kw, c1.stride, c1.pad,
+                        0, prec, st));
+  TRY(avlen_groupnorm_nhwc_ws(buf[0], net->bn1.g, net->bn1.b, nullptr, buf[0], B, 4096, 16, 16, 1, 1e-5f, part, st));
+  float* cur = buf[0]; float* t1 = buf[1]; float* t2 = buf[2]; float* t3 = buf[3];
+  int H = 64, Cc = 16;
+  for (int i = 0; i < 8; i++) {
+    const avlen_resblock& k = net->block[i];
+    int s = k.conv1.stride, OH = (H + 2 - 3) / s + 1, Co = k.conv1.cout;
+    TRY(avlen_conv2d_nhwc(cur, k.conv1.w, nullptr, nullptr, t1, B, H, H, Cc, Co, 3, 3, s, 1, 0, prec, st));
+    TRY(avlen_groupnorm_nhwc_ws(t1, k.bn1.g, k.bn1.b, nullptr, t1, B, OH * OH, Co, 16, 1, 1e-5f, part, st));
+    TRY(avlen_conv2d_nhwc(t1, k.conv2.w, nullptr, nullptr, t2, B, OH, OH, Co, Co, 3, 3, 1, 1, 0, prec, st));
+    const float* idt = cur;
+    if (k.has_down) {
+      TRY(avlen_conv2d_nhwc(cur, k.down.w, nullptr, nullptr, t3, B, H, H, Cc, Co, 1, 1, s, 0, 0, prec, st));
+      TRY(avlen_groupnorm_nhwc_ws(t3, k.bnd.g, k.bnd.b, nullptr, t3, B, OH * OH, Co, 16, 0, 1e-5f, part, st));
+      idt = t3;
+    }
+    TRY(avlen_groupnorm_nhwc_ws(t2, k.bn2.g, k.bn2.b, idt, t2, B, OH * OH, Co, 16, 1, 1e-5f, part, st));
+    float* old = cur; cur = t2; t2 = old;
+    H = OH; Cc = Co;
+  }
+  // flatten (NHWC order; fc.w was packed to match) + fc
+  return linear(c, net->fc, cur, H * H * Cc, out, ld_out, B, 0, nullptr, 0);
+}
+
+// =====================================================================================================
+// 3-conv CNNs
+// =====================================================================================================
+static void cnn3_dims(const avlen_cnn3* n, int H, int W, int oh[3], int ow[3]) {
+  for (int i = 0; i < 3; i++) {
+    oh[i] = (H - n->conv[i].kh) / n->conv[i].stride + 1;
+    ow[i] = (W - n->conv[i].kw) / n->conv[i].stride + 1;
+    H = oh[i]; W = ow[i];
+  }
+}
+extern "C" size_t avlen_cnn3_workspace_bytes(const avlen_cnn3* n, int B, int H, int W) {
+  int oh[3], ow[3]; cnn3_dims(n, H, W, oh, ow);
+  size_t tot = 0;
+  for (int i = 0; i < 3; i++) tot += (size_t)B * oh[i] * ow[i] * n->conv[i].cout * sizeof(float) + 256;
+  return tot + GEMM_SCRATCH + 1024;
+}
+extern "C" int avlen_cnn3_fwd(const avlen_cnn3* n, const float* x, int B, int H, int W, float* out, int ld_out,
+                              int prec, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!n || B <= 0 || ws_bytes < avlen_cnn3_workspace_bytes(n, B, H, W)) return AVLEN_ERR_WS;
+  int oh[3], ow[3]; cnn3_dims(n, H, W, oh, ow);
+  if (oh[2] <= 0 || ow[2] <= 0 || n->fc.in_f != oh[2] * ow[2] * n->conv[2].cout) return AVLEN_ERR_ARG;
+  WsBump w(ws, ws_bytes);
+  float* a[3];
+  for (int i = 0; i < 3; i++) a[i] = w.take<float>((size_t)B * oh[i] * ow[i] * n->conv[i].cout);
+  void* gws = w.take<char>(GEMM_SCRATCH);
+  Ctx c{st, prec, gws, GEMM_SCRATCH};
+  const float* cur = x; int h = H, wd = W;
+  for (int i = 0; i < 3; i++) {
+    const avlen_conv& k = n->conv[i];
+    TRY(avlen_conv2d_nhwc(cur, k.w, k.b, nullptr, a[i], B, h, wd, k.cin, k.cout, k.kh, k.kw, k.stride, 0,
+                          i < 2 ? AVLEN_ACT_RELU : AVLEN_ACT_NONE, prec, st));
+    cur = a[i]; h = oh[i]; wd = ow[i];
+  }
+  return linear(c, n->fc, cur, n->fc.in_f, out, ld_out, B, AVLEN_ACT_RELU, nullptr, 0);
+}
+
+// =====================================================================================================
+// Transformer (1 enc + 1 dec layer, post-norm) over batch-major rows
+// =====================================================================================================
+namespace {
+
+struct TrWs {          // forward activations kept for backward (R = B*S rows, d model dim)
+  float *QKV, *AO, *LSE, *T1, *X1, *F1, *T2, *X2, *MEM;
+  float *m1, *r1, *m2, *r2, *me, *re;
+  float *V0, *U1, *Y1, *Qc, *KVc, *AOc, *LSEc, *U2, *Y2, *G1, *U3, *Y3;
+  float *md1, *rd1, *md2, *rd2, *md3, *rd3, *mf, *rf;
+};
+
+void tr_layout(WsBump& w, TrWs& t, long B, long S, int d, int H, bool cto) {
+  long R = B * S;
+  t.QKV = w.take<float>(R * (cto ? d : 3 * d));
+  t.AO = cto ? t.QKV : w.take<float>(R * d);
+  t.LSE = w.take<float>(B * H * S);
+  t.T1 = w.take<float>(R * d); t.X1 = w.take<float>(R * d); t.F1 = w.take<float>(R * d);
+  t.T2 = w.take<float>(R * d); t.X2 = w.take<float>(R * d); t.MEM = w.take<float>(R * d);
+  t.m1 = w.take<float>(R); t.r1 = w.take<float>(R); t.m2 = w.take<float>(R); t.r2 = w.take<float>(R);
+  t.me = w.take<float>(R); t.re = w.take<float>(R);
+  t.V0 = w.take<float>(B * d); t.U1 = w.take<float>(B * d); t.Y1 = w.take<float>(B * d); t.Qc = w.take<float>(B * d);
+  t.KVc = w.take<float>(R * (cto ? d : 2 * d));
+  t.AOc = cto ? t.KVc : w.take<float>(B * d);
+  t.LSEc = w.take<float>(B * H);
+  t.U2 = w.take<float>(B * d); t.Y2 = w.take<float>(B * d); t.G1 = w.take<float>(B * d);
+  t.U3 = w.take<float>(B * d); t.Y3 = w.take<float>(B * d);
+  t.md1 = w.take<float>(B); t.rd1 = w.take<float>(B); t.md2 = w.take<float>(B); t.rd2 = w.take<float>(B);
+  t.md3 = w.take<float>(B); t.rd3 = w.take<float>(B); t.mf = w.take<float>(B); t.rf = w.take<float>(B);
+}
+
+// Z: [R, d] encoder input (batch-major), maskx: [B, S] (1 = valid), tgt: [B, d]; out: [B, d]
+int transformer_fwd(const Ctx& c, const avlen_transformer& tr, TrWs& t, const float* Z, const float* maskx,
+                    const float* tgt, float* out, int B, int S, bool cto) {
+  const int d = tr.d, H = tr.nhead, D = d / H;
+  const long R = (long)B * S;
+  const float scale = 1.0f / sqrtf((float)D);
+  const avlen_enc_layer& e = tr.enc;
+  // ---- encoder layer
+  if (cto) {      // single valid key: softmax == 1, attention output == V(token)
+    TRY(linear_rows(c, e.self_attn.in_proj, 2 * d, d, Z, d, t.QKV, d, (int)R, 0, nullptr, 0));
+  } else {
+    TRY(linear(c, e.self_attn.in_proj, Z, d, t.QKV, 3 * d, (int)R, 0, nullptr, 0));
+    TRY(avlen_attention_fwd(t.QKV, 3 * d, t.QKV + d, 3 * d, t.QKV + 2 * d, 3 * d, t.AO, d, maskx, t.LSE, B, H, S, S, D,
+                            0, scale, c.st));
+  }
+  TRY(linear(c, e.self_attn.out_proj, t.AO, d, t.T1, d, (int)R, 0, Z, d));
+  TRY(avlen_layernorm_fwd(t.T1, nullptr, e.norm1.g, e.norm1.b, t.X1, t.m1, t.r1, (int)R, d, 1e-5f, c.st));
+  TRY(linear(c, e.lin1, t.X1, d, t.F1, e.lin1.out_f, (int)R, AVLEN_ACT_RELU, nullptr, 0));
+  TRY(linear(c, e.lin2, t.F1, e.lin1.out_f, t.T2, d, (int)R, 0, t.X1, d));
+  TRY(avlen_layernorm_fwd(t.T2, nullptr, e.norm2.g, e.norm2.b, t.X2, t.m2, t.r2, (int)R, d, 1e-5f, c.st));
+  TRY(avlen_layernorm_fwd(t.X2, nullptr, tr.enc_norm.g, tr.enc_norm.b, t.MEM, t.me, t.re, (int)R, d, 1e-5f, c.st));
+  // ---- decoder layer (one target token per sample)
+  const avlen_dec_layer& q = tr.dec;
+  TRY(linear_rows(c, q.self_attn.in_proj, 2 * d, d, tgt, d, t.V0, d, B, 0, nullptr, 0));       // self-attn over 1 token
+  TRY(linear(c, q.self_attn.out_proj, t.V0, d, t.U1, d, B, 0, tgt, d));
+  TRY(avlen_layernorm_fwd(t.U1, nullptr, q.norm1.g, q.norm1.b, t.Y1, t.md1, t.rd1, B, d, 1e-5f, c.st));
+  if (cto) {
+    TRY(linear_rows(c, q.cross_attn.in_proj, 2 * d, d, t.MEM, d, t.KVc, d, (int)R, 0, nullptr, 0));   // V only
+  } else {
+    TRY(linear_rows(c, q.cross_attn.in_proj, 0, d, t.Y1, d, t.Qc, d, B, 0, nullptr, 0));
+    TRY(linear_rows(c, q.cross_attn.in_proj, d, 2 * d, t.MEM, d, t.KVc, 2 * d, (int)R, 0, nullptr, 0));
+    TRY(avlen_attention_fwd(t.Qc, d, t.KVc, 2 * d, t.KVc + d, 2 * d, t.AOc, d, maskx, t.LSEc, B, H, 1, S, D, 0, scale,
+                            c.st));
+  }
+  TRY(linear(c, q.cross_attn.out_proj, t.AOc, d, t.U2, d, B, 0, t.Y1, d));
+  TRY(avlen_layernorm_fwd(t.U2, nullptr, q.norm2.g, q.norm2.b, t.Y2, t.md2, t.rd2, B, d, 1e-5f, c.st));
+  TRY(linear(c, q.lin1, t.Y2, d, t.G1, q.lin1.out_f, B, AVLEN_ACT_RELU, nullptr, 0));
+  TRY(linear(c, q.lin2, t.G1, q.lin1.out_f, t.U3, d, B, 0, t.Y2, d));
+  TRY(avlen_layernorm_fwd(t.U3, nullptr, q.norm3.g, q.norm3.b, t.Y3, t.md3, t.rd3, B, d, 1e-5f, c.st));
+  TRY(avlen_layernorm_fwd(t.Y3, nullptr, tr.dec_norm.g, tr.dec_norm.b, out, t.mf, t.rf, B, d, 1e-5f, c.st));
+  return AVLEN_OK;
+}
+
+struct TrBwdWs { float *dA, *dB, *dC, *dD, *dE, *delta; };     // dA: [R,3d]; dB..dE: [R,d]
+
+void trb_layout(WsBump& w, TrBwdWs& b, long B, long S, int d, int H) {
+  long R = B * S;
+  b.dA = w.take<float>(R * 3 * d); b.dB = w.take<float>(R * d); b.dC = w.take<float>(R * d);
+  b.dD = w.take<float>(R * d); b.dE = w.take<float>(R * d); b.delta = w.take<float>(B * H * S);
+}
+
+// Gradients w.r.t. the transformer parameters (accumulated into g) and w.r.t. Z (written to dZ [R,d]).
+int transformer_bwd(const Ctx& c, const avlen_transformer& tr, const avlen_transformer& g, TrWs& t, TrBwdWs& s,
+                    const float* Z, const float* maskx, const float* tgt, const float* d_out, float* dZ, int B, int S,
+                    bool cto) {
+  const int d = tr.d, H = tr.nhead, D = d / H;
+  const long R = (long)B * S;
+  const float scale = 1.0f / sqrtf((float)D);
+  const avlen_dec_layer& q = tr.dec; const avlen_dec_layer& gq = g.dec;
+  float* dY3 = s.dB; float* dU3 = s.dC;
+  // ---- decoder: final LN, norm3, FFN
+  TRY(avlen_layernorm_bwd(d_out, t.Y3, tr.dec_norm.g, t.mf, t.rf, dY3, g.dec_norm.g, g.dec_norm.b, B, d, c.st));
+  TRY(avlen_layernorm_bwd(dY3, t.U3, q.norm3.g, t.md3, t.rd3, dU3, gq.norm3.g, gq.norm3.b, B, d, c.st));
+  float* dG1 = s.dD; float* dY2 = s.dE;
+  TRY(linear_dw(c, gq.lin2, dU3, d, t.G1, q.lin1.out_f, B));
+  TRY(colsum_acc(c, dU3, d, gq.lin2.b, B, d));
+  TRY(linear_dx(c, q.lin2, dU3, d, dG1, q.lin1.out_f, B, nullptr, 0));
+  TRY(relu_bwd(c, dG1, t.G1, (long)B * q.lin1.out_f));
+  TRY(linear_dw(c, gq.lin1, dG1, q.lin1.out_f, t.Y2, d, B));
+  TRY(colsum_acc(c, dG1, q.lin1.out_f, gq.lin1.b, B, q.lin1.out_f));
+  TRY(linear_dx(c, q.lin1, dG1, q.lin1.out_f, dY2, d, B, dU3, d));               // dY2 = dU3 + dG1 W1
+  // ---- decoder: norm2, cross attention
+  float* dU2 = s.dB;
+  TRY(avlen_layernorm_bwd(dY2, t.U2, q.norm2.g, t.md2, t.rd2, dU2, gq.norm2.g, gq.norm2.b, B, d, c.st));
+  float* dAOc = s.dC;
+  TRY(linear_dw(c, gq.cross_attn.out_proj, dU2, d, t.AOc, d, B));
+  TRY(colsum_acc(c, dU2, d, gq.cross_attn.out_proj.b, B, d));
+  TRY(linear_dx(c, q.cross_attn.out_proj, dU2, d, dAOc, d, B, nullptr, 0));
+  float* dMEM = s.dD;                    // [R, d]
+  float* dY1 = s.dE;                     // [B, d]
+  avlen_linear gin = gq.cross_attn.in_proj; const avlen_linear& win = q.cross_attn.in_proj;
+  if (cto) {
+    // AOc == Vc(MEM): dVc = dAOc ; q,k projections get exactly zero gradient (softmax over one key)
+    avlen_linear gv = gin; gv.w = gin.w + (size_t)2 * d * d; gv.b = gin.b + 2 * d; gv.out_f = d;
+    avlen_linear wv = win; wv.w = win.w + (size_t)2 * d * d; wv.out_f = d;
+    TRY(linear_dw(c, gv, dAOc, d, t.MEM, d, (int)R));
+    TRY(colsum_acc(c, dAOc, d, gv.b, (int)R, d));
+    TRY(linear_dx(c, wv, dAOc, d, dMEM, d, (int)R, nullptr, 0));
+    TRY(avlen_copy_rows(dU2, d, dY1, d, B, d, c.st));                          // dY1 = dU2 (residual)
+  } else {
+    float* dQc = s.dA;                   // [B, d]
+    float* dKVc = s.dA + (size_t)B * d;   // [R, 2d]
+    TRY(avlen_attention_bwd(t.Qc, d, t.KVc, 2 * d, t.KVc + d, 2 * d, t.AOc, d, dAOc, d, maskx, t.LSEc, s.delta, dQc, d,
+                            dKVc, 2 * d, dKVc + d, 2 * d, B, H, 1, S, D, 0, scale, c.st));
+    avlen_linear gqp = gin; gqp.out_f = d;
+    avlen_linear wqp = win; wqp.out_f = d;
+    TRY(linear_dw(c, gqp, dQc, d, t.Y1, d, B));
+    TRY(colsum_acc(c, dQc, d, gqp.b, B, d));
+    TRY(linear_dx(c, wqp, dQc, d, dY1, d, B, dU2, d));                         // dY1 = dU2 + dQc Wq
+    avlen_linear gkv = gin; gkv.w = gin.w + (size_t)d * d; gkv.b = gin.b + d; gkv.out_f = 2 * d;
+    avlen_linear wkv = win; wkv.w = win.w + (size_t)d * d; wkv.out_f = 2 * d;
+    TRY(linear_dw(c, gkv, dKVc, 2 * d, t.MEM, d, (int)R));
+    TRY(colsum_acc(c, dKVc, 2 * d, gkv.b, (int)R, 2 * d));
+    TRY(linear_dx(c, wkv, dKVc, 2 * d, dMEM, d, (int)R, nullptr, 0));
+  }
+  // ---- decoder: norm1, self attention over the single target token
+  float* dU1 = s.dB;
+  TRY(avlen_layernorm_bwd(dY1, t.U1, q.norm1.g, t.md1, t.rd1, dU1, gq.norm1.g, gq.norm1.b, B, d, c.st));
+  float* dV0 = s.dC;
+  TRY(linear_dw(c, gq.self_attn.out_proj, dU1, d, t.V0, d, B));
+  TRY(colsum_acc(c, dU1, d, gq.self_attn.out_proj.b, B, d));
+  TRY(linear_dx(c, q.self_attn.out_proj, dU1, d, dV0, d, B, nullptr, 0));
+  {
+    avlen_linear gv = gq.self_attn.in_proj; gv.w += (size_t)2 * d * d; gv.b += 2 * d; gv.out_f = d;
+    TRY(linear_dw(c, gv, dV0, d, tgt, d, B));
+    TRY(colsum_acc(c, dV0, d, gv.b, B, d));
+  }
+  // ---- encoder: final norm, norm2, FFN
+  const avlen_enc_layer& e = tr.enc; const avlen_enc_layer& ge = g.enc;
+  float* dX2 = s.dB; float* dT2 = s.dC;
+  TRY(avlen_layernorm_bwd(dMEM, t.X2, tr.enc_norm.g, t.me, t.re, dX2, g.enc_norm.g, g.enc_norm.b, (int)R, d, c.st));
+  TRY(avlen_layernorm_bwd(dX2, t.T2, e.norm2.g, t.m2, t.r2, dT2, ge.norm2.g, ge.norm2.b, (int)R, d, c.st));
+  float* dF1 = s.dD; float* dX1 = s.dE;
+  TRY(linear_dw(c, ge.lin2, dT2, d, t.F1, e.lin1.out_f, (int)R));
+  TRY(colsum_acc(c, dT2, d, ge.lin2.b, (int)R, d));
+  TRY(linear_dx(c, e.lin2, dT2, d, dF1, e.lin1.out_f, (int)R, nullptr, 0));
+  TRY(relu_bwd(c, dF1, t.F1, R * e.lin1.out_f));
+  TRY(linear_dw(c, ge.lin1, dF1, e.lin1.out_f, t.X1, d, (int)R));
+  TRY(colsum_acc(c, dF1, e.lin1.out_f, ge.lin1.b, (int)R, e.lin1.out_f));
+  TRY(linear_dx(c, e.lin1, dF1, e.lin1.out_f, dX1, d, (int)R, dT2, d));          // dX1 = dT2 + dF1 W1
+  // ---- encoder: norm1, self attention
+  float* dT1 = s.dB;
+  TRY(avlen_layernorm_bwd(dX1, t.T1, e.norm1.g, t.m1, t.r1, dT1, ge.norm1.g, ge.norm1.b, (int)R, d, c.st));
+  float* dAO = s.dC;
+  TRY(linear_dw(c, ge.self_attn.out_proj, dT1, d, t.AO, d, (int)R));
+  TRY(colsum_acc(c, dT1, d, ge.self_attn.out_proj.b, (int)R, d));
+  TRY(linear_dx(c, e.self_attn.out_proj, dT1, d, dAO, d, (int)R, nullptr, 0));
+  if (cto) {
+    avlen_linear gv = ge.self_attn.in_proj; gv.w += (size_t)2 * d * d; gv.b += 2 * d; gv.out_f = d;
+    avlen_linear wv = e.self_attn.in_proj; wv.w += (size_t)2 * d * d; wv.out_f = d;
+    TRY(linear_dw(c, gv, dAO, d, Z, d, (int)R));
+    TRY(colsum_acc(c, dAO, d, gv.b, (int)R, d));
+    TRY(linear_dx(c, wv, dAO, d, dZ, d, (int)R, dT1, d));                         // dZ = dT1 + dV Wv
+  } else {
+    float* dQKV = s.dA;
+    TRY(avlen_attention_bwd(t.QKV, 3 * d, t.QKV + d, 3 * d, t.QKV + 2 * d, 3 * d, t.AO, d, dAO, d, maskx, t.LSE, s.delta,
+                            dQKV, 3 * d, dQKV + d, 3 * d, dQKV + 2 * d, 3 * d, B, H, S, S, D, 0, scale, c.st));
+    TRY(linear_dw(c, ge.self_attn.in_proj, dQKV, 3 * d, Z, d, (int)R));
+    TRY(colsum_acc(c, dQKV, 3 * d, ge.self_attn.in_proj.b, (int)R, 3 * d));
+    TRY(linear_dx(c, e.self_attn.in_proj, dQKV, 3 * d, dZ, d, (int)R, dT1, d));   // dZ = dT1 + dQKV Win
+  }
+  return AVLEN_OK;
+}
+
+struct SmtWs { float *XF, *FMT, *maskx, *H1, *Z; TrWs tr; TrBwdWs tb; float *dZ, *dH1, *dPE; void* gws; int ldxf; };
+
+void smt_layout(WsBump& w, SmtWs& s, const avlen_smt* p, long B, long M, int F, bool cto) {
+  long S = cto ? 1 : M + 1, R = B * S;
+  int d = p->tr.d;
+  s.ldxf = (int)align_up(F + 12, 4);
+  s.XF = w.take<float>(R * s.ldxf); s.FMT = w.take<float>(R * 8); s.maskx = w.take<float>(B * S);
+  s.H1 = w.take<float>(R * d); s.Z = w.take<float>(R * d);
+  tr_layout(w, s.tr, B, S, d, p->tr.nhead, cto);
+  trb_layout(w, s.tb, B, S, d, p->tr.nhead);
+  s.dZ = w.take<float>(R * d); s.dH1 = w.take<float>(R * d); s.dPE = w.take<float>(R * 16);
+  s.gws = w.take<char>(GEMM_SCRATCH);
+}
+
+}  // namespace
+
+extern "C" size_t avlen_smt_workspace_bytes(const avlen_smt* p, int B, int M, int F, int cto) {
+  WsBump w(nullptr, 0); SmtWs s;
+  smt_layout(w, s, p, B, M, F, cto != 0);
+  return w.off + 4096;
+}
+
+extern "C" int avlen_smt_fwd(const avlen_smt* p, const float* x, const float* memory, const float* masks,
+                             const float* goal, float* out, int B, int M, int F, int pose_col, int cto, int prec,
+                             void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!p || B <= 0 || M < 0 || p->fus0.in_f != F + 12 || p->pose.in_f != 5 || p->pose.out_f != 16) return AVLEN_ERR_ARG;
+  if (!cto && M > 0 && (!memory || !masks)) return AVLEN_ERR_ARG;
+  if (ws_bytes < avlen_smt_workspace_bytes(p, B, M, F, cto)) return AVLEN_ERR_WS;
+  WsBump w(ws, ws_bytes); SmtWs s;
+  smt_layout(w, s, p, B, M, F, cto != 0);
+  Ctx c{st, prec, s.gws, GEMM_SCRATCH};
+  const int S = cto ? 1 : M + 1, d = p->tr.d;
+  const long R = (long)B * S;
+  hipLaunchKernelGGL(smt_build_kernel, dim3((unsigned)R), dim3(128), 0, st, x, memory, masks, p->pose.w, p->pose.b, s.XF,
+                     s.ldxf, s.FMT, s.maskx, B, M, F, pose_col, cto);
+  TRY(avlen_launch_status());
+  TRY(linear(c, p->fus0, s.XF, s.ldxf, s.H1, d, (int)R, AVLEN_ACT_RELU, nullptr, 0));
+  TRY(linear(c, p->fus2, s.H1, d, s.Z, d, (int)R, 0, nullptr, 0));
+  return transformer_fwd(c, p->tr, s.tr, s.Z, s.maskx, goal, out, B, S, cto != 0);
+}
+
+extern "C" int avlen_smt_bwd(const avlen_smt* p, const avlen_smt* g, const float* x, const float* memory,
+                             const float* masks, const float* goal, const float* d_out, int B, int M, int F,
+                             int pose_col, int cto, int prec, void* ws, size_t ws_bytes, hipStream_t st) {
+  (void)x; (void)memory; (void)masks;
+  if (!p || !g || ws_bytes < avlen_smt_workspace_bytes(p, B, M, F, cto)) return AVLEN_ERR_WS;
+  WsBump w(ws, ws_bytes); SmtWs s;
+  smt_layout(w, s, p, B, M, F, cto != 0);
+  Ctx c{st, prec, s.gws, GEMM_SCRATCH};
+  const int S = cto ? 1 : M + 1, d = p->tr.d;
+  const long R = (long)B * S;
+  TRY(transformer_bwd(c, p->tr, g->tr, s.tr, s.tb, s.Z, s.maskx, goal, d_out, s.dZ, B, S, cto != 0));
+  // fusion MLP
+  TRY(linear_dw(c, g->fus2, s.dZ, d, s.H1, d, (int)R));
+  TRY(colsum_acc(c, s.dZ, d, g->fus2.b, (int)R, d));
+  TRY(linear_dx(c, p->fus2, s.dZ, d, s.dH1, d, (int)R, nullptr, 0));
+  TRY(relu_bwd(c, s.dH1, s.H1, R * d));
+  {
+    avlen_linear g0 = g->fus0;            // dW0[d][F+12] += dH1^T XF  (XF rows are ldxf apart)
+    int sk = avlen_gemm_pick_splitk(g0.out_f, g0.in_f, (int)R);
+    while (sk > 1 && avlen_gemm_workspace_bytes(g0.out_f, g0.in_f, (int)R, sk) > GEMM_SCRATCH) sk /= 2;
+    TRY(avlen_gemm(s.dH1, d, 1, s.XF, s.ldxf, 1, g0.w, g0.in_f, nullptr, nullptr, 0, g0.out_f, g0.in_f, (int)R, 0, prec,
+                   sk, 1.f, s.gws, GEMM_SCRATCH, st));
+    TRY(colsum_acc(c, s.dH1, d, g0.b, (int)R, d));
+  }
+  // pose encoder: dPE[R,16] = dH1 * W0[:, pc:pc+16]
+  TRY(avlen_gemm(s.dH1, d, 0, p->fus0.w + pose_col, p->fus0.in_f, 1, s.dPE, 16, nullptr, nullptr, 0, (int)R, 16, d, 0,
+                 prec, 1, 0.f, s.gws, GEMM_SCRATCH, st));
+  int rpb = R >= 65536 ? 2048 : 256;
+  hipLaunchKernelGGL(pose_grad_kernel, dim3((unsigned)((R + rpb - 1) / rpb)), dim3(96), 0, st, s.dPE, s.FMT, g->pose.w,
+                     g->pose.b, R, rpb);
+  return avlen_launch_status();
+}
+
+// =====================================================================================================
+// Dialog state encoder
+// =====================================================================================================
+namespace {
+struct DlgWs { float *SEQ, *maskx, *H1, *Z; TrWs tr; void* gws; };
+void dlg_layout(WsBump& w, DlgWs& s, const avlen_dialog* p, long B, long M) {
+  long S = M + 1, R = B * S; int d = p->tr.d;
+  s.SEQ = w.take<float>(R * 2 * d); s.maskx = w.take<float>(B * S);
+  s.H1 = w.take<float>(R * d); s.Z = w.take<float>(R * d);
+  tr_layout(w, s.tr, B, S, d, p->tr.nhead, false);
+  s.gws = w.take<char>(GEMM_SCRATCH);
+}
+}  // namespace
+
+extern "C" size_t avlen_dialog_workspace_bytes(const avlen_dialog* p, int B, int M) {
+  WsBump w(nullptr, 0); DlgWs s; dlg_layout(w, s, p, B, M); return w.off + 4096;
+}
+
+extern "C" int avlen_dialog_fwd(const avlen_dialog* p, const float* x_att, const float* memory_state,
+                                const float* masks, const float* d_emb, const float* agent_step, const float* goal,
+                                float* out, int B, int M, int prec, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!p || B <= 0 || ws_bytes < avlen_dialog_workspace_bytes(p, B, M)) return AVLEN_ERR_WS;
+  WsBump w(ws, ws_bytes); DlgWs s; dlg_layout(w, s, p, B, M);
+  Ctx c{st, prec, s.gws, GEMM_SCRATCH};
+  const int S = M + 1, d = p->tr.d; const long R = (long)B * S;
+  const int ldseq = d_emb ? 2 * d : d;
+  float* seq = d_emb ? s.SEQ : s.Z;
+  hipLaunchKernelGGL(dialog_build_kernel, dim3((unsigned)R), dim3(128), 0, st, x_att, memory_state, masks, d_emb, seq,
+                     ldseq, s.maskx, B, M, d);
+  TRY(avlen_launch_status());
+  if (d_emb) {
+    TRY(linear(c, p->fus0, s.SEQ, 2 * d, s.H1, d, (int)R, AVLEN_ACT_RELU, nullptr, 0));
+    TRY(linear(c, p->fus2, s.H1, d, s.Z, d, (int)R, 0, nullptr, 0));
+  }
+  hipLaunchKernelGGL(add_pe_kernel, dim3((unsigned)R), dim3(128), 0, st, s.Z, p->pe, agent_step, S, d, p->pe_len);
+  TRY(avlen_launch_status());
+  return transformer_fwd(c, p->tr, s.tr, s.Z, s.maskx, goal, out, B, S, false);
+}
+
+// =====================================================================================================
+// CLIP text tower
+// =====================================================================================================
+extern "C" size_t avlen_clip_text_workspace_bytes(const avlen_clip_text* p, int B) {
+  size_t R = (size_t)B * p->ctx, wd = p->width;
+  return (R * (wd * 3 + 3 * wd + 4 * wd) + (size_t)B * wd * 2) * sizeof(float) + GEMM_SCRATCH + 8192;
+}
+
+extern "C" int avlen_clip_text_fwd(const avlen_clip_text* p, const int64_t* tokens, float* out, int B, int prec,
+                                   void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!p || B <= 0 || p->width % p->heads || ws_bytes < avlen_clip_text_workspace_bytes(p, B)) return AVLEN_ERR_WS;
+  const int wd = p->width, H = p->heads, D = wd / H, ctx = p->ctx;
+  const long R = (long)B * ctx;
+  WsBump w(ws, ws_bytes);
+  float* X = w.take<float>(R * wd); float* Hn = w.take<float>(R * wd); float* AO = w.take<float>(R * wd);
+  float* QKV = w.take<float>(R * 3 * wd); float* Fh = w.take<float>(R * 4 * wd);
+  float* E = w.take<float>((size_t)B * wd); float* E2 = w.take<float>((size_t)B * wd);
+  void* gws = w.take<char>(GEMM_SCRATCH);
+  Ctx c{st, prec, gws, GEMM_SCRATCH};
+  const float scale = 1.0f / sqrtf((float)D);
+  hipLaunchKernelGGL(clip_embed_kernel, dim3((unsigned)R), dim3(128), 0, st, tokens, p->tok_emb, p->pos_emb, X, ctx, wd,
+                     p->vocab);
+  TRY(avlen_launch_status());
+  for (int l = 0; l < p->layers; l++) {
+    const avlen_clip_block& b = p->block[l];
+    TRY(avlen_layernorm_fwd(X, nullptr, b.ln1.g, b.ln1.b, Hn, nullptr, nullptr, (int)R, wd, 1e-5f, st));
+    TRY(linear(c, b.attn.in_proj, Hn, wd, QKV, 3 * wd, (int)R, 0, nullptr, 0));
+    TRY(avlen_attention_fwd(QKV, 3 * wd, QKV + wd, 3 * wd, QKV + 2 * wd, 3 * wd, AO, wd, nullptr, nullptr, B, H, ctx, ctx,
+                            D, 1, scale, st));
+    TRY(linear(c, b.attn.out_proj, AO, wd, X, wd, (int)R, 0, X, wd));                 // x += attn
+    TRY(avlen_layernorm_fwd(X, nullptr, b.ln2.g, b.ln2.b, Hn, nullptr, nullptr, (int)R, wd, 1e-5f, st));
+    TRY(linear(c, b.fc, Hn, wd, Fh, b.fc.out_f, (int)R, AVLEN_ACT_QUICKGELU, nullptr, 0));
+    TRY(linear(c, b.proj, Fh, b.fc.out_f, X, wd, (int)R, 0, X, wd));                  // x += mlp
+  }
+  hipLaunchKernelGGL(clip_gather_eot_kernel, dim3(B), dim3(128), 0, st, tokens, X, E, ctx, wd);
+  TRY(avlen_launch_status());
+  TRY(avlen_layernorm_fwd(E, nullptr, p->ln_final.g, p->ln_final.b, E2, nullptr, nullptr, B, wd, 1e-5f, st));
+  // out = E2 @ text_proj   (text_proj stored [width][out_dim])
+  return avlen_gemm(E2, wd, 0, p->text_proj, p->out_dim, 1, out, p->out_dim, nullptr, nullptr, 0, B, p->out_dim, wd, 0,
+                    prec, 1, 0.f, gws, GEMM_SCRATCH, st);
+}
+
+// =====================================================================================================
+// GRU
+// =====================================================================================================
+extern "C" size_t avlen_gru_workspace_bytes(const avlen_gru* p, int T, int N) {
+  size_t H = p->hidden;
+  return ((size_t)T * N * 3 * H + (size_t)N * 3 * H + 2 * (size_t)N * H) * sizeof(float) + GEMM_SCRATCH + 4096;
+}
+
+extern "C" int avlen_gru_fwd(const avlen_gru* p, const float* x, const float* h0, const float* masks, float* out,
+                             float* h_out, int T, int N, int prec, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!p || T <= 0 || N <= 0 || ws_bytes < avlen_gru_workspace_bytes(p, T, N)) return AVLEN_ERR_WS;
+  const int H = p->hidden;
+  WsBump w(ws, ws_bytes);
+  float* GI = w.take<float>((size_t)T * N * 3 * H); float* GH = w.take<float>((size_t)N * 3 * H);
+  float* hm = w.take<float>((size_t)N * H); float* hc = w.take<float>((size_t)N * H);
+  void* gws = w.take<char>(GEMM_SCRATCH);
+  Ctx c{st, prec, gws, GEMM_SCRATCH};
+  avlen_linear ih{p->w_ih, p->b_ih, 3 * H, p->in_f}, hh{p->w_hh, p->b_hh, 3 * H, H};
+  TRY(linear(c, ih, x, p->in_f, GI, 3 * H, T * N, 0, nullptr, 0));
+  const float* hprev = h0;
+  dim3 g((unsigned)(((long)N * H + 255) / 256));
+  for (int t = 0; t < T; t++) {
+    hipLaunchKernelGGL(gru_mask_kernel, g, dim3(256), 0, st, hprev, masks + (size_t)t * N, hm, N, H);
+    TRY(linear(c, hh, hm, H, GH, 3 * H, N, 0, nullptr, 0));
+    hipLaunchKernelGGL(gru_gate_kernel, g, dim3(256), 0, st, GI + (size_t)t * N * 3 * H, GH, hm, hc,
+                       out + (size_t)t * N * H, N, H);
+    hprev = hc;
+  }
+  TRY(avlen_launch_status());
+  return avlen_copy_rows(hc, H, h_out, H, N, H, st);
+}

@@ -1,0 +1,275 @@
+// GroupNorm (NHWC, fused ReLU / residual) and LayerNorm forward/backward for gfx950.
+// Both are HBM/L2-bound streaming kernels: 16-byte loads, wave(64)-level reductions, no re-reads
+// from HBM (a sample's activations -- <= 256 KB -- stay in the XCD's L2 between the two passes).
+#include "common.h"
+#include "../../include/avlen_hip.h"
+
+namespace {
+
+// One block per (sample, spatial split).  C <= 128, C % 4 == 0, blockDim*4 % C == 0, so every
+// thread always touches the same 4 channels and keeps 4 running sums in registers.
+// Two-kernel form so that small batches still fill the chip:
+//   gn_stats:  partial sum / sumsq per (sample, split, channel)  -> stats[B][S][2][C]
+//   gn_apply:  combine partials -> per-group mean / rstd; y = relu(xhat*g + b + res)
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, float* __restrict__ part,
+                                                       int HW, int C, int splits) {
+  __shared__ float s_sum[128], s_sq[128];
+  const int b = blockIdx.x / splits, sp = blockIdx.x % splits;
+  const int tid = threadIdx.x;
+  if (tid < C) { s_sum[tid] = 0.f; s_sq[tid] = 0.f; }
+  __syncthreads();
+  const long n4 = (long)HW * C / 4;                         // float4 per sample
+  const long per = (n4 + splits - 1) / splits;
+  const long beg = sp * per, end = min(n4, beg + per);
+  const float4* xp = reinterpret_cast<const float4*>(x + (long)b * HW * C);
+  float4 s = make_float4(0, 0, 0, 0), q = make_float4(0, 0, 0, 0);
+  // per*4 % C == 0 is guaranteed by the launcher (per is a multiple of C/4 * 256 / gcd) -> fixed channels
+  for (long f = beg + tid; f < end; f += 256) {
+    float4 v = xp[f];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
+  }
+  const int c0 = (int)(((beg + tid) * 4) % C);
+  atomicAdd(&s_sum[c0], s.x); atomicAdd(&s_sum[c0 + 1], s.y); atomicAdd(&s_sum[c0 + 2], s.z); atomicAdd(&s_sum[c0 + 3], s.w);
+  atomicAdd(&s_sq[c0], q.x); atomicAdd(&s_sq[c0 + 1], q.y); atomicAdd(&s_sq[c0 + 2], q.z); atomicAdd(&s_sq[c0 + 3], q.w);
+  __syncthreads();
+  if (tid < C) {
+    float* o = part + ((long)(b * splits + sp) * 2) * C;
+    o[tid] = s_sum[tid];
+    o[C + tid] = s_sq[tid];
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ part,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ res, float* __restrict__ y, int HW,
+                                                       int C, int G, int splits, int relu, float eps) {
+  __shared__ float s_scale[128], s_shift[128];
+  const int b = blockIdx.x / splits, sp = blockIdx.x % splits;
+  const int tid = threadIdx.x;
+  const int cg = C / G;
+  if (tid < G) {
+    double sum = 0.0, sq = 0.0;
+    for (int s = 0; s < splits; s++) {
+      const float* o = part + ((long)(b * splits + s) * 2) * C;
+      for (int c = tid * cg; c < (tid + 1) * cg; c++) { sum += o[c]; sq += o[C + c]; }
+    }
+    double n = (double)HW * cg;
+    double mean = sum / n;
+    double var = sq / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    for (int c = tid * cg; c < (tid + 1) * cg; c++) {
+      float sc = gamma[c] * rstd;
+      s_scale[c] = sc;
+      s_shift[c] = beta[c] - (float)mean * sc;
+    }
+  }
+  __syncthreads();
+  const long n4 = (long)HW * C / 4;
+  const long per = (n4 + splits - 1) / splits;
+  const long beg = sp * per, end = min(n4, beg + per);
+  const long base = (long)b * HW * C;
+  const float4* xp = reinterpret_cast<const float4*>(x + base);
+  const float4* rp = res ? reinterpret_cast<const float4*>(res + base) : nullptr;
+  float4* yp = reinterpret_cast<float4*>(y + base);
+  const int c0 = (int)(((beg + tid) * 4) % C);
+  const float a0 = s_scale[c0], a1 = s_scale[c0 + 1], a2 = s_scale[c0 + 2], a3 = s_scale[c0 + 3];
+  const float h0 = s_shift[c0], h1 = s_shift[c0 + 1], h2 = s_shift[c0 + 2], h3 = s_shift[c0 + 3];
+  for (long f = beg + tid; f < end; f += 256) {
+    float4 v = xp[f];
+    v.x = v.x * a0 + h0; v.y = v.y * a1 + h1; v.z = v.z * a2 + h2; v.w = v.w * a3 + h3;
+    if (rp) { float4 r = rp[f]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    yp[f] = v;
+  }
+}
+
+// LayerNorm: one wave per row, d = 64 * VPL * ... handled as d/64 values per lane (d <= 1024).
+template <int NV>   // NV = d / 64 values per lane, strided so loads are coalesced
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float* __restrict__ y, float* __restrict__ mean_o,
+                                                     float* __restrict__ rstd_o, int rows, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  constexpr int d = NV * 64;
+  const float* xr = x + (long)row * d;
+  float v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    v[i] = xr[lane + i * 64];
+    if (res) v[i] += res[(long)row * d + lane + i * 64];
+    s += v[i];
+  }
+  float mean = wave_sum(s) * (1.f / d);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; i++) { float t = v[i] - mean; q += t * t; }
+  float rstd = rsqrtf(wave_sum(q) * (1.f / d) + eps);
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    int c = lane + i * 64;
+    y[(long)row * d + c] = (v[i] - mean) * rstd * gamma[c] + beta[c];
+  }
+  if (mean_o && lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+}
+
+// Backward.  Each block handles ROWS_PER_BLOCK rows (one wave per row at a time) and accumulates
+// dgamma/dbeta for its rows in registers, then one atomicAdd per column per block.
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ xsum,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, float* __restrict__ dx,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int rows,
+                                                     int rows_per_block) {
+  constexpr int d = NV * 64;
+  __shared__ float sg[4][d], sb[4][d];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float ag[NV], ab[NV];
+#pragma unroll
+  for (int i = 0; i < NV; i++) { ag[i] = 0.f; ab[i] = 0.f; }
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(rows, r0 + rows_per_block);
+  for (int row = r0 + w; row < r1; row += 4) {
+    float m = mean[row], rs = rstd[row];
+    float g[NV], xh[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      int c = lane + i * 64;
+      float dyv = dy[(long)row * d + c];
+      xh[i] = (xsum[(long)row * d + c] - m) * rs;
+      g[i] = dyv * gamma[c];
+      s1 += g[i]; s2 += g[i] * xh[i];
+      ag[i] += dyv * xh[i]; ab[i] += dyv;
+    }
+    s1 = wave_sum(s1) * (1.f / d); s2 = wave_sum(s2) * (1.f / d);
+#pragma unroll
+    for (int i = 0; i < NV; i++) dx[(long)row * d + lane + i * 64] = rs * (g[i] - s1 - xh[i] * s2);
+  }
+  if (dgamma) {
+#pragma unroll
+    for (int i = 0; i < NV; i++) { sg[w][lane + i * 64] = ag[i]; sb[w][lane + i * 64] = ab[i]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += 256) {
+      atomicAdd(&dgamma[c], sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c]);
+      atomicAdd(&dbeta[c], sb[0][c] + sb[1][c] + sb[2][c] + sb[3][c]);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" size_t avlen_groupnorm_workspace_bytes(int B, int C) {
+  return (size_t)B * 16 * 2 * C * sizeof(float) + 256;           // up to 16 spatial splits
+}
+
+static int gn_pick_splits(int B, int HW, int C) {
+  // fill >= ~512 blocks; each split must cover a multiple of 256 float4 (so thread->channel is fixed)
+  long n4 = (long)HW * C / 4;
+  int s = 1;
+  while (s < 16 && (long)B * s < 512 && (n4 / (s * 2)) >= 256 && (n4 % ((long)s * 2 * 256)) == 0) s *= 2;
+  return s;
+}
+
+// ws may be NULL only when the internal static scratch is not needed -> we always need partials, so the
+// public entry point below carries its own tiny scratch inside `y`'s tail?  No: use a dedicated arg-free
+// scheme: partial stats live in a caller workspace for module calls; the primitive entry uses splits=1 and
+// a small static device buffer is avoided by folding stats+apply into one launch.
+__global__ __launch_bounds__(256) void gn_fused_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ res,
+                                                       float* __restrict__ y, int HW, int C, int G, int relu, float eps) {
+  __shared__ float s_sum[128], s_sq[128], s_scale[128], s_shift[128];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid < C) { s_sum[tid] = 0.f; s_sq[tid] = 0.f; }
+  __syncthreads();
+  const long n4 = (long)HW * C / 4;
+  const long base = (long)b * HW * C;
+  const float4* xp = reinterpret_cast<const float4*>(x + base);
+  float4 s = make_float4(0, 0, 0, 0), q = make_float4(0, 0, 0, 0);
+  for (long f = tid; f < n4; f += 256) {
+    float4 v = xp[f];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
+  }
+  const int c0 = (tid * 4) % C;
+  atomicAdd(&s_sum[c0], s.x); atomicAdd(&s_sum[c0 + 1], s.y); atomicAdd(&s_sum[c0 + 2], s.z); atomicAdd(&s_sum[c0 + 3], s.w);
+  atomicAdd(&s_sq[c0], q.x); atomicAdd(&s_sq[c0 + 1], q.y); atomicAdd(&s_sq[c0 + 2], q.z); atomicAdd(&s_sq[c0 + 3], q.w);
+  __syncthreads();
+  const int cg = C / G;
+  if (tid < G) {
+    double sum = 0.0, sq = 0.0;
+    for (int c = tid * cg; c < (tid + 1) * cg; c++) { sum += s_sum[c]; sq += s_sq[c]; }
+    double n = (double)HW * cg, mean = sum / n, var = sq / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    for (int c = tid * cg; c < (tid + 1) * cg; c++) {
+      float sc = gamma[c] * rstd;
+      s_scale[c] = sc; s_shift[c] = beta[c] - (float)mean * sc;
+    }
+  }
+  __syncthreads();
+  const float4* rp = res ? reinterpret_cast<const float4*>(res + base) : nullptr;
+  float4* yp = reinterpret_cast<float4*>(y + base);
+  const float a0 = s_scale[c0], a1 = s_scale[c0 + 1], a2 = s_scale[c0 + 2], a3 = s_scale[c0 + 3];
+  const float h0 = s_shift[c0], h1 = s_shift[c0 + 1], h2 = s_shift[c0 + 2], h3 = s_shift[c0 + 3];
+  for (long f = tid; f < n4; f += 256) {
+    float4 v = xp[f];
+    v.x = v.x * a0 + h0; v.y = v.y * a1 + h1; v.z = v.z * a2 + h2; v.w = v.w * a3 + h3;
+    if (rp) { float4 r = rp[f]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    yp[f] = v;
+  }
+}
+
+// Internal (module-level) form with spatial splits and a caller-provided partials buffer.
+int avlen_groupnorm_nhwc_ws(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+                            int B, int HW, int C, int G, int relu, float eps, float* part, hipStream_t stream) {
+  if (C > 128 || C % 4 || 1024 % C || C % G || ((long)HW * C) % 4) return AVLEN_ERR_ARG;
+  int splits = part ? gn_pick_splits(B, HW, C) : 1;
+  if (splits == 1) {
+    hipLaunchKernelGGL(gn_fused_kernel, dim3(B), dim3(256), 0, stream, x, gamma, beta, residual, y, HW, C, G, relu, eps);
+    return avlen_launch_status();
+  }
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(B * splits), dim3(256), 0, stream, x, part, HW, C, splits);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(B * splits), dim3(256), 0, stream, x, part, gamma, beta, residual, y, HW, C,
+                     G, splits, relu, eps);
+  return avlen_launch_status();
+}
+
+extern "C" int avlen_groupnorm_nhwc(const float* x, const float* gamma, const float* beta, const float* residual,
+                                    float* y, int B, int HW, int C, int G, int relu, float eps, hipStream_t stream) {
+  return avlen_groupnorm_nhwc_ws(x, gamma, beta, residual, y, B, HW, C, G, relu, eps, nullptr, stream);
+}
+
+extern "C" int avlen_layernorm_fwd(const float* x, const float* residual, const float* gamma, const float* beta,
+                                   float* y, float* mean, float* rstd, int rows, int d, float eps,
+                                   hipStream_t stream) {
+  if (rows <= 0) return AVLEN_ERR_ARG;
+  dim3 grid(ceil_div(rows, 4)), block(256);
+  switch (d) {
+    case 256: hipLaunchKernelGGL((ln_fwd_kernel<4>), grid, block, 0, stream, x, residual, gamma, beta, y, mean, rstd, rows, eps); break;
+    case 512: hipLaunchKernelGGL((ln_fwd_kernel<8>), grid, block, 0, stream, x, residual, gamma, beta, y, mean, rstd, rows, eps); break;
+    case 128: hipLaunchKernelGGL((ln_fwd_kernel<2>), grid, block, 0, stream, x, residual, gamma, beta, y, mean, rstd, rows, eps); break;
+    case 64: hipLaunchKernelGGL((ln_fwd_kernel<1>), grid, block, 0, stream, x, residual, gamma, beta, y, mean, rstd, rows, eps); break;
+    default: return AVLEN_ERR_ARG;
+  }
+  return avlen_launch_status();
+}
+
+extern "C" int avlen_layernorm_bwd(const float* dy, const float* xsum, const float* gamma, const float* mean,
+                                   const float* rstd, float* dx, float* dgamma, float* dbeta, int rows, int d,
+                                   hipStream_t stream) {
+  if (rows <= 0) return AVLEN_ERR_ARG;
+  int rpb = rows >= 65536 ? 256 : rows >= 4096 ? 64 : 16;
+  dim3 grid(ceil_div(rows, rpb)), block(256);
+  switch (d) {
+    case 256: hipLaunchKernelGGL((ln_bwd_kernel<4>), grid, block, 0, stream, dy, xsum, gamma, mean, rstd, dx, dgamma, dbeta, rows, rpb); break;
+    case 512: hipLaunchKernelGGL((ln_bwd_kernel<8>), grid, block, 0, stream, dy, xsum, gamma, mean, rstd, dx, dgamma, dbeta, rows, rpb); break;
+    default: return AVLEN_ERR_ARG;
+  }
+  return avlen_launch_status();
+}

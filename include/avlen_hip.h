@@ -1,0 +1,227 @@
+/* avlen_hip.h -- C ABI of libavlen_hip.so: the MI355X (gfx950) implementation of the SAVi/AVLEN
+ * PPO rollout-and-update hot path.
+ *
+ * The reference (merlresearch/avlen) has no FFI on this path: its boundary is the Python class API
+ * of ss_baselines/savi/ppo/policy.py (Policy.act* / evaluate_actions*), ss_baselines/savi/ppo/ppo.py
+ * (PPO.update) and ss_baselines/savi/models/rollout_storage.py.  Each entry point below names the
+ * reference code whose arithmetic it replaces (paths relative to the reference root).  The Python
+ * classes in avlen_amd/ keep the reference's names/signatures and call these through ctypes.
+ *
+ * Conventions: every pointer is a DEVICE pointer unless named host_*; fp32 storage; images are NHWC;
+ * sequences are batch-major [B][S][d]; functions enqueue work on `stream` and return immediately
+ * (never allocate, never synchronise; graph-capturable); return AVLEN_OK (0) or an AVLEN_ERR_* code.
+ * `prec` selects the MFMA operand type of the dense products: AVLEN_PREC_FP32 (exact fp32 MFMA,
+ * the parity mode) or AVLEN_PREC_BF16 (bf16 operands, fp32 accumulate).  Scratch comes from the
+ * caller: ask the matching *_workspace_bytes() first.
+ */
+#ifndef AVLEN_HIP_H
+#define AVLEN_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* avlen_stream_t;        /* == hipStream_t */
+
+#define AVLEN_PREC_FP32 0
+#define AVLEN_PREC_BF16 1
+#define AVLEN_ACT_NONE 0
+#define AVLEN_ACT_RELU 1
+#define AVLEN_ACT_QUICKGELU 2
+
+/* ------------------------------------------------------------------ parameter views ---------- */
+typedef struct { float* w; float* b; int out_f; int in_f; } avlen_linear;          /* w[out_f][in_f] */
+typedef struct { float* w; float* b; int cin, cout, kh, kw, stride, pad; } avlen_conv; /* w packed [cout][kh][kw][cin] */
+typedef struct { float* g; float* b; } avlen_affine;                               /* norm scale / shift */
+typedef struct { avlen_conv conv1, conv2, down; avlen_affine bn1, bn2, bnd; int has_down; } avlen_resblock;
+/* CustomResNet (smt_resnet.py:56-149): conv7x7 + GroupNorm(16) + 8 basic blocks + fc(8192->64).
+ * fc.w is packed so that its columns follow the NHWC flatten order (h,w,c). */
+typedef struct { avlen_conv conv1; avlen_affine bn1; avlen_resblock block[8]; avlen_linear fc; } avlen_resnet18;
+/* AudioCNN / VisualCNN (audio_cnn.py:62-94, visual_cnn.py:82-107): 3 convs (+bias, ReLU after the
+ * first two) + fc + ReLU.  fc.w packed to the NHWC flatten order. */
+typedef struct { avlen_conv conv[3]; avlen_linear fc; } avlen_cnn3;
+typedef struct { avlen_linear in_proj, out_proj; } avlen_mha;                      /* packed q|k|v rows */
+typedef struct { avlen_mha self_attn; avlen_linear lin1, lin2; avlen_affine norm1, norm2; } avlen_enc_layer;
+typedef struct { avlen_mha self_attn, cross_attn; avlen_linear lin1, lin2; avlen_affine norm1, norm2, norm3; } avlen_dec_layer;
+/* torch.nn.Transformer(d, nhead, 1 enc, 1 dec, ff, relu, post-norm) + final enc/dec LayerNorms
+ * (smt_state_encoder.py:88-96). */
+typedef struct { avlen_enc_layer enc; avlen_affine enc_norm; avlen_dec_layer dec; avlen_affine dec_norm; int d, nhead; } avlen_transformer;
+/* SMTStateEncoder (smt_state_encoder.py:23-96): pose Linear(5,16), fusion MLP, transformer. */
+typedef struct { avlen_linear pose, fus0, fus2; avlen_transformer tr; } avlen_smt;
+/* DialogStateEncoder (dialog_state_encoder.py:42-99): fusion MLP(512->256->256), transformer, pe[100][256]. */
+typedef struct { avlen_linear fus0, fus2; avlen_transformer tr; float* pe; int pe_len; } avlen_dialog;
+typedef struct { avlen_affine ln1, ln2; avlen_mha attn; avlen_linear fc, proj; } avlen_clip_block;
+/* CLIP ViT-B/32 text tower (third party; call site policy.py:847-849). text_proj is [width][out]. */
+typedef struct { float* tok_emb; float* pos_emb; avlen_clip_block block[12]; avlen_affine ln_final;
+                 float* text_proj; int vocab, ctx, width, heads, layers, out_dim; } avlen_clip_text;
+/* nn.GRU(in, H, 1 layer) (av_nav/models/rnn_state_encoder.py:36-40): w_ih[3H][in], w_hh[3H][H], r|z|n. */
+typedef struct { float* w_ih; float* w_hh; float* b_ih; float* b_hh; int in_f, hidden; } avlen_gru;
+/* CategoricalNet + CriticHead (+ CriticHead2) of one policy (policy.py:46-61, 279-297). */
+typedef struct { avlen_linear action, critic, unct; int has_unct; } avlen_heads;
+
+/* ------------------------------------------------------------------ dense primitives ---------- */
+/* C[M][N] = act(A * Wt^T + bias) + residual.  A(m,k)=A[m*lda+k] (transA: A[k*lda+m]); Wt(n,k)=B[n*ldb+k]
+ * (transB: B[k*ldb+n]).  splitk>1 or beta!=0 route through slabs in `ws` (C = beta*C + ...).
+ * Replaces torch.nn.functional.linear and its two backward products. */
+int avlen_gemm(const float* A, int lda, int transA, const float* B, int ldb, int transB, float* C, int ldc,
+               const float* bias, const float* residual, int ldr, int M, int N, int K, int act, int prec,
+               int splitk, float beta, void* ws, size_t ws_bytes, avlen_stream_t stream);
+size_t avlen_gemm_workspace_bytes(int M, int N, int K, int splitk);
+int avlen_gemm_pick_splitk(int M, int N, int K);
+/* NHWC convolution as implicit GEMM; Wp packed [Cout][KH][KW][Cin].  Replaces nn.Conv2d forward
+ * (smt_resnet.py:29-34,77-78,116-119; audio_cnn.py:62-83; visual_cnn.py:82-103). */
+int avlen_conv2d_nhwc(const float* X, const float* Wp, const float* bias, const float* residual, float* Y,
+                      int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int act,
+                      int prec, avlen_stream_t stream);
+/* OIHW -> [O][KH][KW][I] (conv) and (O, C*H*W) -> (O, H*W*C) (fc after an NCHW flatten). */
+int avlen_pack_conv_weight(const float* w_oihw, float* w_packed, int O, int I, int KH, int KW, avlen_stream_t stream);
+int avlen_pack_fc_after_flatten(const float* w, float* w_packed, int O, int C, int HW, avlen_stream_t stream);
+
+/* ------------------------------------------------------------------ normalisation ------------- */
+/* y = [relu]( GroupNorm_G(x)*g + b [+ residual] ), x NHWC (B,HW,C).  smt_resnet.py:30-33,40-51,79. */
+int avlen_groupnorm_nhwc(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+                         int B, int HW, int C, int G, int relu, float eps, avlen_stream_t stream);
+/* y = LayerNorm(x [+ residual]) over the last dim d (d % 64 == 0, d <= 1024); saves mean/rstd when non-NULL. */
+int avlen_layernorm_fwd(const float* x, const float* residual, const float* gamma, const float* beta, float* y,
+                        float* mean, float* rstd, int rows, int d, float eps, avlen_stream_t stream);
+/* dx = LN backward (also the gradient of the residual input); dgamma/dbeta += (atomic fp32). xhat is
+ * recomputed from y: xhat = (y - beta)/gamma is avoided -- pass the saved pre-norm sum `xsum` = x+residual. */
+int avlen_layernorm_bwd(const float* dy, const float* xsum, const float* gamma, const float* mean,
+                        const float* rstd, float* dx, float* dgamma, float* dbeta, int rows, int d,
+                        avlen_stream_t stream);
+
+/* ------------------------------------------------------------------ attention ------------------ */
+/* Multi-head attention core, batch-major.  Q[b][i] at Q + (b*Sq+i)*ldq + h*D, same for K,V (Sk rows),
+ * O (Sq rows).  key_mask[b][j] (1 = valid, 0 = padded) may be NULL; causal masks j>i.  scale multiplies
+ * q.k.  lse[b][h][i] (log-sum-exp of the scaled scores) is saved when non-NULL.  D in {32, 64}.
+ * Replaces the softmax(QK^T)V core of nn.MultiheadAttention (smt_state_encoder.py:160-166). */
+int avlen_attention_fwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O,
+                        int ldo, const float* key_mask, float* lse, int B, int H, int Sq, int Sk, int D,
+                        int causal, float scale, avlen_stream_t stream);
+/* Gradients of the same; dQ/dK/dV are overwritten.  delta is a (B*H*Sq) scratch. */
+int avlen_attention_bwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
+                        const float* O, int ldo, const float* dO, int lddo, const float* key_mask,
+                        const float* lse, float* delta, float* dQ, int lddq, float* dK, int lddk, float* dV,
+                        int lddv, int B, int H, int Sq, int Sk, int D, int causal, float scale,
+                        avlen_stream_t stream);
+
+/* ------------------------------------------------------------------ small fused kernels -------- */
+/* (B,S,S,C) NHWC fp32 -> (x / divisor) -> kxk block mean -> (B,64,64,C).  K1+K2: smt_cnn.py:83-93 +
+ * common/utils.py:467-557 (area resize to 64, identity crop).  divisor = 255 for rgb, 1 for depth. */
+int avlen_preprocess_image(const float* x, float* y, int B, int S, int C, float divisor, avlen_stream_t stream);
+/* VisualCNN input (visual_cnn.py:165-183): y[b,h,w,:] = [rgb/255 (3), depth (1)]. */
+int avlen_rgbd_concat(const float* rgb, const float* depth, float* y, int B, int HW, avlen_stream_t stream);
+/* Non-CNN feature columns (policy.py:662-674, 1035-1036, 1062-1063): for each row b
+ *   feats[b, col_action .. +16)   = action_encoder.w[:, prev_action[b]] + b      (one-hot x Linear)
+ *   feats[b, col_cat .. +21)      = category[b]              (only if category != NULL)
+ *   feats[b, col_pose .. +4)      = pose[b]
+ *   feats[b, col_extra .. +n_extra) = extra[b]               (query_state; only if extra != NULL)
+ * and the belief/goal vector (policy.py:605-618): goal[b] = [category_belief(21) | location_belief(2) | 0...]. */
+int avlen_feature_assemble(float* feats, int ldf, const avlen_linear* action_encoder, const int64_t* prev_actions,
+                           int col_action, const float* category, int col_cat, const float* pose, int col_pose,
+                           const float* extra, int n_extra, int col_extra, const float* category_belief,
+                           const float* location_belief, float* goal, int d_goal, int B, avlen_stream_t stream);
+/* rows[b] = [feats[b, 0:n_keep) | tail[b]]: the external-memory row of pi_q (policy.py:1062-1063). */
+int avlen_concat_rows(const float* a, int lda, int na, const float* b, int ldb, int nb, float* out, int ldo, int B,
+                      avlen_stream_t stream);
+
+/* ------------------------------------------------------------------ encoders (module level) ---- */
+size_t avlen_resnet18_workspace_bytes(int B);
+/* SMTCNN tower (smt_cnn.py:78-115 + smt_resnet.py:132-146) on one modality: img (B,S,S,C) raw sensor,
+ * divisor = 255 for rgb, 1 for depth; writes 64 features to out[b*ld_out + 0..63]. */
+int avlen_resnet18_fwd(const avlen_resnet18* net, const float* img, int B, int S, int C, float divisor, float* out,
+                       int ld_out, int prec, void* ws, size_t ws_bytes, avlen_stream_t stream);
+size_t avlen_cnn3_workspace_bytes(const avlen_cnn3* net, int B, int H, int W);
+/* AudioCNN.forward (audio_cnn.py:136-151) / VisualCNN.cnn: x NHWC (B,H,W,conv[0].cin) -> out[b*ld_out + 0..fc.out_f). */
+int avlen_cnn3_fwd(const avlen_cnn3* net, const float* x, int B, int H, int W, float* out, int ld_out, int prec,
+                   void* ws, size_t ws_bytes, avlen_stream_t stream);
+
+/* ------------------------------------------------------------------ SMT / dialog / CLIP -------- */
+/* SMTStateEncoder.single_forward (smt_state_encoder.py:109-188).
+ *   x      (B, F)         current features [.. | pose(4) at pose_col | ..]
+ *   memory (M, B, F)      external memory rows, reference layout (slot-major)
+ *   masks  (B, M)         1 = valid slot
+ *   goal   (B, d)         decoder target (belief vector)
+ *   out    (B, d)
+ * current_token_only=1 is the `pretraining=True` configuration (:126-129): every memory key is masked,
+ * so only the current token is computed (bit-for-bit the same function, 200x fewer FLOPs).
+ * When `save` != 0 the workspace keeps what avlen_smt_bwd needs. */
+size_t avlen_smt_workspace_bytes(const avlen_smt* p, int B, int M, int F, int current_token_only);
+int avlen_smt_fwd(const avlen_smt* p, const float* x, const float* memory, const float* masks, const float* goal,
+                  float* out, int B, int M, int F, int pose_col, int current_token_only, int prec, void* ws,
+                  size_t ws_bytes, avlen_stream_t stream);
+/* Backward of avlen_smt_fwd w.r.t. the parameters only (x, memory and goal carry no gradient on this
+ * path: policy.py:1035-1036).  `ws` must be the forward's workspace, untouched.  Gradients are
+ * ACCUMULATED into `g` (same layout as p). */
+int avlen_smt_bwd(const avlen_smt* p, const avlen_smt* g, const float* x, const float* memory, const float* masks,
+                  const float* goal, const float* d_out, int B, int M, int F, int pose_col,
+                  int current_token_only, int prec, void* ws, size_t ws_bytes, avlen_stream_t stream);
+/* DialogStateEncoder.single_forward (dialog_state_encoder.py:114-155): x_att (B,d), memory_state (M,B,d),
+ * masks (B,M), d_emb (B,d) or NULL, agent_step (B) float, goal (B,d) -> out (B,d). */
+size_t avlen_dialog_workspace_bytes(const avlen_dialog* p, int B, int M);
+int avlen_dialog_fwd(const avlen_dialog* p, const float* x_att, const float* memory_state, const float* masks,
+                     const float* d_emb, const float* agent_step, const float* goal, float* out, int B, int M,
+                     int prec, void* ws, size_t ws_bytes, avlen_stream_t stream);
+/* CLIP.encode_text (frozen): tokens (B,ctx) int64 -> out (B,out_dim). */
+size_t avlen_clip_text_workspace_bytes(const avlen_clip_text* p, int B);
+int avlen_clip_text_fwd(const avlen_clip_text* p, const int64_t* tokens, float* out, int B, int prec, void* ws,
+                        size_t ws_bytes, avlen_stream_t stream);
+
+/* ------------------------------------------------------------------ GRU ------------------------ */
+/* RNNStateEncoder (rnn_state_encoder.py:80-143).  T==1: single_forward; T>1: seq_forward with x (T*N,in)
+ * T-major, masks (T*N).  h0 (N,H) -> out (T*N,H), h_out (N,H).  h is multiplied by masks[t] before step t. */
+size_t avlen_gru_workspace_bytes(const avlen_gru* p, int T, int N);
+int avlen_gru_fwd(const avlen_gru* p, const float* x, const float* h0, const float* masks, float* out, float* h_out,
+                  int T, int N, int prec, void* ws, size_t ws_bytes, avlen_stream_t stream);
+
+/* ------------------------------------------------------------------ heads / PPO ---------------- */
+/* CategoricalNet + critics forward (common/utils.py:44-72, policy.py:86-96): feats (B,d) ->
+ * logits/probs/logp (B,A), value (B), unct (B,2) (if has_unct), and, when actions != NULL,
+ * log_prob[b] = logp[b, actions[b]] and entropy[b] (per row). Any output pointer may be NULL. */
+int avlen_heads_fwd(const avlen_heads* h, const float* feats, int d, int A, float* logits, float* probs,
+                    float* value, float* unct, const int64_t* actions, float* log_prob, float* entropy, int B,
+                    avlen_stream_t stream);
+/* PPO loss (ppo.py:219-262) fused with its backward through the heads.  Row-wise inputs as in the
+ * reference minibatch; norm = {1/sum(rl_masks), 1/R} read from device (2 floats, see avlen_rl_mask_norm).
+ * Outputs: loss_sums[6] += {value_loss, action_loss, entropy, values_mean, returns_mean, unct_loss}
+ * contributions (already normalised); d_feats (B,d) overwritten; head gradients accumulated into g. */
+int avlen_ppo_loss_heads_bwd(const avlen_heads* h, const avlen_heads* g, const float* feats, int d, int A,
+                             const int64_t* actions, const float* old_log_probs, const float* adv,
+                             const int64_t* rl_masks, const float* value_preds, const float* returns,
+                             const int64_t* unct_gt, const float* norm, float clip, float value_coef,
+                             float entropy_coef, float unct_coef, float* loss_sums, float* d_feats, int B,
+                             avlen_stream_t stream);
+/* norm[0] = 1/sum(rl_masks[0..R)), norm[1] = 1/R. */
+int avlen_rl_mask_norm(const int64_t* rl_masks, int R, float* norm, avlen_stream_t stream);
+/* GAE backward scan (rollout_storage.py:394-405): values[T_used] <- next_value first.  rewards (T,N),
+ * values (T+1,N), masks (T+1,N), returns (T+1,N) out, advantages (T,N) out (= returns - values). */
+int avlen_gae_scan(const float* rewards, float* values, const float* masks, const float* next_value, float* returns,
+                   float* advantages, int T_used, int N, float gamma, float tau, avlen_stream_t stream);
+/* clip_grad_norm_ + Adam (ppo.py:297-300, torch.optim.Adam): norm_sq is a device double accumulated by
+ * avlen_grad_sumsq over every trained segment, then each segment is stepped. */
+int avlen_grad_sumsq(const float* grad, size_t n, double* norm_sq, avlen_stream_t stream);
+int avlen_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr,
+                    float beta1, float beta2, float eps, int step, float max_grad_norm, const double* norm_sq,
+                    avlen_stream_t stream);
+
+/* ------------------------------------------------------------------ rollout storage ------------ */
+/* ExternalMemory.insert (rollout_storage.py:930-941) on ONE copy of the ring: memory (total,N,dim),
+ * masks (N,total).  Also snapshots the new masks to masks_out (N,total) when non-NULL. */
+int avlen_extmem_insert(float* memory, float* masks, const float* feats, int ld_feats, const float* not_done,
+                        float* masks_out, int idx, int total, int capacity, int N, int dim, avlen_stream_t stream);
+/* recurrent_generator's gather (rollout_storage.py:649-782): dst[(t*n_mb + j), :] = src[t, env[j], :]
+ * for t < T; src is (T_alloc, N, D) fp32 (elem_bytes=4) or int64 (elem_bytes=8). */
+int avlen_minibatch_gather(const void* src, void* dst, const int64_t* env, int T, int N, int n_mb, size_t D,
+                           int elem_bytes, avlen_stream_t stream);
+/* out[i] = a[i] (fp32 copy on stream; strided rows) -- storage insert helper. */
+int avlen_copy_rows(const float* src, int lds, float* dst, int ldd, int rows, int cols, avlen_stream_t stream);
+
+/* build / device info */
+const char* avlen_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
