@@ -128,8 +128,8 @@ SIGNATURES = {
     "avlen_cnn3_workspace_bytes": (sz, [C.POINTER(Cnn3), i32, i32, i32]),
     "avlen_cnn3_fwd": (i32, [C.POINTER(Cnn3), vp, i32, i32, i32, vp, i32, i32, vp, sz, vp]),
     "avlen_smt_workspace_bytes": (sz, [C.POINTER(Smt), i32, i32, i32, i32]),
-    "avlen_smt_fwd": (i32, [C.POINTER(Smt), vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
-    "avlen_smt_bwd": (i32, [C.POINTER(Smt), C.POINTER(Smt), vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "avlen_smt_fwd": (i32, [C.POINTER(Smt), vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "avlen_smt_bwd": (i32, [C.POINTER(Smt), C.POINTER(Smt), vp, vp, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     "avlen_dialog_workspace_bytes": (sz, [C.POINTER(Dialog), i32, i32]),
     "avlen_dialog_fwd": (i32, [C.POINTER(Dialog), vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, sz, vp]),
     "avlen_clip_text_workspace_bytes": (sz, [C.POINTER(ClipText), i32]),

@@ -87,13 +87,14 @@ int relu_bwd(const Ctx& c, float* dx, const float* y, long n) {
 //   maskx[b, s] = s < M ? (pretraining ? 0 : masks[b, s]) : 1
 // cto (current token only): S = 1 and only the s = M row is produced.
 __global__ void smt_build_kernel(const float* __restrict__ x, const float* __restrict__ memory,
-                                 const float* __restrict__ masks, const float* __restrict__ pw,
+                                 const int32_t* __restrict__ mem_index, int NC, const float* __restrict__ masks, const float* __restrict__ pw,
                                  const float* __restrict__ pb, float* __restrict__ XF, int ldxf, float* __restrict__ FMT,
                                  float* __restrict__ maskx, int B, int M, int F, int pc, int cto) {
   const int S = cto ? 1 : M + 1;
   const int row = blockIdx.x;                 // b * S + s
   const int b = row / S, s = cto ? M : row % S;
-  const float* src = (s < M) ? memory + ((long)s * B + b) * F : x + (long)b * F;
+  const int col = mem_index ? mem_index[b] : b;
+  const float* src = (s < M) ? memory + ((long)s * NC + col) * F : x + (long)b * F;
   const float* xp = x + (long)b * F + pc;
   __shared__ float fmt[5];
   const int t = threadIdx.x;
@@ -499,9 +500,9 @@ extern "C" size_t avlen_smt_workspace_bytes(const avlen_smt* p, int B, int M, in
   return w.off + 4096;
 }
 
-extern "C" int avlen_smt_fwd(const avlen_smt* p, const float* x, const float* memory, const float* masks,
-                             const float* goal, float* out, int B, int M, int F, int pose_col, int cto, int prec,
-                             void* ws, size_t ws_bytes, hipStream_t st) {
+extern "C" int avlen_smt_fwd(const avlen_smt* p, const float* x, const float* memory, const int32_t* mem_index, int NC,
+                             const float* masks, const float* goal, float* out, int B, int M, int F, int pose_col,
+                             int cto, int prec, void* ws, size_t ws_bytes, hipStream_t st) {
   if (!p || B <= 0 || M < 0 || p->fus0.in_f != F + 12 || p->pose.in_f != 5 || p->pose.out_f != 16) return AVLEN_ERR_ARG;
   if (!cto && M > 0 && (!memory || !masks)) return AVLEN_ERR_ARG;
   if (ws_bytes < avlen_smt_workspace_bytes(p, B, M, F, cto)) return AVLEN_ERR_WS;
@@ -510,7 +511,8 @@ extern "C" int avlen_smt_fwd(const avlen_smt* p, const float* x, const float* me
   Ctx c{st, prec, s.gws, GEMM_SCRATCH};
   const int S = cto ? 1 : M + 1, d = p->tr.d;
   const long R = (long)B * S;
-  hipLaunchKernelGGL(smt_build_kernel, dim3((unsigned)R), dim3(128), 0, st, x, memory, masks, p->pose.w, p->pose.b, s.XF,
+  if (!mem_index) NC = B;
+  hipLaunchKernelGGL(smt_build_kernel, dim3((unsigned)R), dim3(128), 0, st, x, memory, mem_index, NC, masks, p->pose.w, p->pose.b, s.XF,
                      s.ldxf, s.FMT, s.maskx, B, M, F, pose_col, cto);
   TRY(avlen_launch_status());
   TRY(linear(c, p->fus0, s.XF, s.ldxf, s.H1, d, (int)R, AVLEN_ACT_RELU, nullptr, 0));
@@ -518,10 +520,8 @@ extern "C" int avlen_smt_fwd(const avlen_smt* p, const float* x, const float* me
   return transformer_fwd(c, p->tr, s.tr, s.Z, s.maskx, goal, out, B, S, cto != 0);
 }
 
-extern "C" int avlen_smt_bwd(const avlen_smt* p, const avlen_smt* g, const float* x, const float* memory,
-                             const float* masks, const float* goal, const float* d_out, int B, int M, int F,
-                             int pose_col, int cto, int prec, void* ws, size_t ws_bytes, hipStream_t st) {
-  (void)x; (void)memory; (void)masks;
+extern "C" int avlen_smt_bwd(const avlen_smt* p, const avlen_smt* g, const float* goal, const float* d_out, int B, int M,
+                             int F, int pose_col, int cto, int prec, void* ws, size_t ws_bytes, hipStream_t st) {
   if (!p || !g || ws_bytes < avlen_smt_workspace_bytes(p, B, M, F, cto)) return AVLEN_ERR_WS;
   WsBump w(ws, ws_bytes); SmtWs s;
   smt_layout(w, s, p, B, M, F, cto != 0);

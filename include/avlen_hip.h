@@ -141,7 +141,10 @@ int avlen_cnn3_fwd(const avlen_cnn3* net, const float* x, int B, int H, int W, f
 /* ------------------------------------------------------------------ SMT / dialog / CLIP -------- */
 /* SMTStateEncoder.single_forward (smt_state_encoder.py:109-188).
  *   x      (B, F)         current features [.. | pose(4) at pose_col | ..]
- *   memory (M, B, F)      external memory rows, reference layout (slot-major)
+ *   memory (M, NC, F)     external memory rows, reference layout (slot-major); sample b reads column
+ *                         mem_index[b] (int32), or column b when mem_index == NULL (then NC == B).  The
+ *                         index form lets a (T*N_mb)-row PPO minibatch read the N-column ring in place
+ *                         instead of materialising the reference's (300, T*N_mb, F) copy (K21).
  *   masks  (B, M)         1 = valid slot
  *   goal   (B, d)         decoder target (belief vector)
  *   out    (B, d)
@@ -149,15 +152,14 @@ int avlen_cnn3_fwd(const avlen_cnn3* net, const float* x, int B, int H, int W, f
  * so only the current token is computed (bit-for-bit the same function, 200x fewer FLOPs).
  * When `save` != 0 the workspace keeps what avlen_smt_bwd needs. */
 size_t avlen_smt_workspace_bytes(const avlen_smt* p, int B, int M, int F, int current_token_only);
-int avlen_smt_fwd(const avlen_smt* p, const float* x, const float* memory, const float* masks, const float* goal,
-                  float* out, int B, int M, int F, int pose_col, int current_token_only, int prec, void* ws,
-                  size_t ws_bytes, avlen_stream_t stream);
+int avlen_smt_fwd(const avlen_smt* p, const float* x, const float* memory, const int32_t* mem_index, int NC,
+                  const float* masks, const float* goal, float* out, int B, int M, int F, int pose_col,
+                  int current_token_only, int prec, void* ws, size_t ws_bytes, avlen_stream_t stream);
 /* Backward of avlen_smt_fwd w.r.t. the parameters only (x, memory and goal carry no gradient on this
  * path: policy.py:1035-1036).  `ws` must be the forward's workspace, untouched.  Gradients are
  * ACCUMULATED into `g` (same layout as p). */
-int avlen_smt_bwd(const avlen_smt* p, const avlen_smt* g, const float* x, const float* memory, const float* masks,
-                  const float* goal, const float* d_out, int B, int M, int F, int pose_col,
-                  int current_token_only, int prec, void* ws, size_t ws_bytes, avlen_stream_t stream);
+int avlen_smt_bwd(const avlen_smt* p, const avlen_smt* g, const float* goal, const float* d_out, int B, int M, int F,
+                  int pose_col, int current_token_only, int prec, void* ws, size_t ws_bytes, avlen_stream_t stream);
 /* DialogStateEncoder.single_forward (dialog_state_encoder.py:114-155): x_att (B,d), memory_state (M,B,d),
  * masks (B,M), d_emb (B,d) or NULL, agent_step (B) float, goal (B,d) -> out (B,d). */
 size_t avlen_dialog_workspace_bytes(const avlen_dialog* p, int B, int M);

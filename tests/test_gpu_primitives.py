@@ -16,8 +16,18 @@ def L():
     return _lib
 
 
+_KEEP = []
+
+
 def dev(t):
-    return t.cuda().contiguous()
+    """Device copy that stays alive for the whole test (a temporary could be freed and its block re-used by the
+    next allocation before the asynchronous kernel has run)."""
+    d = t.cuda().contiguous()
+    _KEEP.append(d)
+    if len(_KEEP) > 64:
+        torch.cuda.synchronize()
+        del _KEEP[:32]
+    return d
 
 
 def rel_err(a, b):
