@@ -1,0 +1,244 @@
+"""Host-side engine shared by the policies: flat parameter storage, packed weights, C-struct views of
+the parameters, workspaces.  PyTorch is used for device memory only."""
+import ctypes as C
+import torch
+
+from . import _lib as L
+
+ALIGN = 64          # floats
+
+
+def _align(n):
+    return (n + ALIGN - 1) // ALIGN * ALIGN
+
+
+class FlatParams:
+    """All parameters of a policy live in ONE fp32 device buffer (trained ones first, so gradient
+    clipping, Adam and the RCCL all-reduce each touch one contiguous range); nn.Parameters keep their
+    reference names but become views into it."""
+
+    def __init__(self, module, trained_prefixes):
+        named = [(n, p) for n, p in module.named_parameters()]
+        tr = [(n, p) for n, p in named if n.startswith(tuple(trained_prefixes))]
+        rest = [(n, p) for n, p in named if not n.startswith(tuple(trained_prefixes))]
+        dev = named[0][1].device
+        off, self.offsets = 0, {}
+        for n, p in tr:
+            self.offsets[n] = (off, p.numel())
+            off += _align(p.numel())
+        self.n_trained = off
+        for n, p in rest:
+            self.offsets[n] = (off, p.numel())
+            off += _align(p.numel())
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(self.n_trained, dtype=torch.float32, device=dev)
+        self.trained_names = [n for n, _ in tr]
+        with torch.no_grad():
+            for n, p in tr + rest:
+                o, k = self.offsets[n]
+                view = self.flat[o:o + k].view(p.shape)
+                view.copy_(p.data.to(torch.float32))
+                p.data = view
+            for n, p in tr:                      # torch-side tools see the HIP-written gradients
+                p.grad = self.grad_view(n, p.shape)
+        self.device = dev
+        self._ptrs = {n: p.data_ptr() for n, p in named}
+
+    def intact(self, module):
+        for n, p in module.named_parameters():
+            if self._ptrs.get(n) != p.data_ptr():
+                return False
+        return True
+
+    def grad_view(self, name, shape):
+        o, k = self.offsets[name]
+        return self.grad[o:o + k].view(shape)
+
+    def grad_ptr(self, name):
+        o, _ = self.offsets[name]
+        return self.grad.data_ptr() + 4 * o
+
+
+class Workspaces:
+    def __init__(self):
+        self._bufs = {}
+
+    def get(self, key, nbytes, device):
+        b = self._bufs.get(key)
+        if b is None or b.numel() < nbytes or b.device != device:
+            b = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            self._bufs[key] = b
+        return b
+
+    def clear(self):
+        self._bufs.clear()
+
+
+def P(t, off_floats=0):
+    """raw device pointer of tensor t (+ offset in floats)"""
+    return C.c_void_p(t.data_ptr() + 4 * off_floats)
+
+
+def linear_view(w, b):
+    return L.Linear(P(w), P(b) if b is not None else None, w.shape[0], w.shape[1])
+
+
+def affine_view(m):
+    return L.Affine(P(m.weight), P(m.bias))
+
+
+class Packed:
+    """Conv / post-flatten fc weights re-laid out for the NHWC implicit-GEMM kernels.  The packed copies
+    are derived data: rebuilt (by HIP kernels) whenever the canonical parameters may have changed."""
+
+    def __init__(self, device):
+        self.device, self.bufs, self.jobs = device, [], []
+
+    def conv(self, conv, has_bias):
+        O, I, KH, KW = conv.weight.shape
+        buf = torch.empty(O * KH * KW * I, dtype=torch.float32, device=self.device)
+        self.bufs.append(buf)
+        self.jobs.append(("conv", conv.weight, buf, (O, I, KH, KW)))
+        return L.Conv(P(buf), P(conv.bias) if has_bias else None, I, O, KH, KW, conv.stride[0], conv.padding[0])
+
+    def fc_after_flatten(self, lin, C_, HW):
+        O = lin.weight.shape[0]
+        buf = torch.empty(O * C_ * HW, dtype=torch.float32, device=self.device)
+        self.bufs.append(buf)
+        self.jobs.append(("fc", lin.weight, buf, (O, C_, HW)))
+        return L.Linear(P(buf), P(lin.bias), O, C_ * HW)
+
+    def refresh(self):
+        st = L.stream()
+        for kind, w, buf, dims in self.jobs:
+            if kind == "conv":
+                L.call("avlen_pack_conv_weight", P(w), P(buf), *dims, st)
+            else:
+                L.call("avlen_pack_fc_after_flatten", P(w), P(buf), *dims, st)
+
+
+def resnet18_view(net, packed):
+    s = L.ResNet18()
+    s.conv1 = packed.conv(net.conv1, False)
+    s.bn1 = affine_view(net.bn1)
+    i = 0
+    for layer in (net.layer1, net.layer2, net.layer3, net.layer4):
+        for blk in layer:
+            b = s.block[i]
+            b.conv1 = packed.conv(blk.conv1, False)
+            b.conv2 = packed.conv(blk.conv2, False)
+            b.bn1, b.bn2 = affine_view(blk.bn1), affine_view(blk.bn2)
+            if blk.downsample is not None:
+                b.down = packed.conv(blk.downsample[0], False)
+                b.bnd = affine_view(blk.downsample[1])
+                b.has_down = 1
+            else:
+                b.has_down = 0
+            i += 1
+    s.fc = packed.fc_after_flatten(net.fc, 128, 64)
+    return s
+
+
+def cnn3_view(net, packed):
+    s = L.Cnn3()
+    for i, idx in enumerate((0, 2, 4)):
+        s.conv[i] = packed.conv(net.cnn[idx], True)
+    h, w = net.out_hw
+    s.fc = packed.fc_after_flatten(net.cnn[6], 64, h * w)
+    return s
+
+
+def mha_view(m):
+    return L.Mha(L.Linear(P(m.in_proj_weight), P(m.in_proj_bias), m.in_proj_weight.shape[0], m.in_proj_weight.shape[1]),
+                 linear_view(m.out_proj.weight, m.out_proj.bias))
+
+
+def transformer_view(t, d, nhead):
+    s = L.Transformer()
+    e, q = t.encoder.layers[0], t.decoder.layers[0]
+    s.enc = L.EncLayer(mha_view(e.self_attn), linear_view(e.linear1.weight, e.linear1.bias),
+                       linear_view(e.linear2.weight, e.linear2.bias), affine_view(e.norm1), affine_view(e.norm2))
+    s.enc_norm = affine_view(t.encoder.norm)
+    s.dec = L.DecLayer(mha_view(q.self_attn), mha_view(q.multihead_attn), linear_view(q.linear1.weight, q.linear1.bias),
+                       linear_view(q.linear2.weight, q.linear2.bias), affine_view(q.norm1), affine_view(q.norm2),
+                       affine_view(q.norm3))
+    s.dec_norm = affine_view(t.decoder.norm)
+    s.d, s.nhead = d, nhead
+    return s
+
+
+def smt_view(enc):
+    s = L.Smt()
+    s.pose = linear_view(enc.pose_encoder.weight, enc.pose_encoder.bias)
+    s.fus0 = linear_view(enc.fusion_encoder[0].weight, enc.fusion_encoder[0].bias)
+    s.fus2 = linear_view(enc.fusion_encoder[2].weight, enc.fusion_encoder[2].bias)
+    s.tr = transformer_view(enc.transformer, enc._dim_feedforward, enc._nhead)
+    return s
+
+
+def dialog_view(enc):
+    s = L.Dialog()
+    s.fus0 = linear_view(enc.fusion_encoder[0].weight, enc.fusion_encoder[0].bias)
+    s.fus2 = linear_view(enc.fusion_encoder[2].weight, enc.fusion_encoder[2].bias)
+    s.tr = transformer_view(enc.dialog_transformer, enc._dim_feedforward, enc._nhead)
+    s.pe = P(enc.pos_encode.pe)
+    s.pe_len = enc.pos_encode.pe.shape[0]
+    return s
+
+
+def clip_view(clip):
+    s = L.ClipText()
+    s.tok_emb, s.pos_emb = P(clip.token_embedding.weight), P(clip.positional_embedding)
+    for i, blk in enumerate(clip.transformer.resblocks):
+        b = s.block[i]
+        b.ln1, b.ln2 = affine_view(blk.ln_1), affine_view(blk.ln_2)
+        b.attn = mha_view(blk.attn)
+        b.fc = linear_view(blk.mlp.c_fc.weight, blk.mlp.c_fc.bias)
+        b.proj = linear_view(blk.mlp.c_proj.weight, blk.mlp.c_proj.bias)
+    s.ln_final = affine_view(clip.ln_final)
+    s.text_proj = P(clip.text_projection)
+    s.vocab, s.ctx = clip.vocab_size, clip.context_length
+    s.width, s.heads, s.layers = clip.transformer.width, clip.heads, clip.transformer.layers
+    s.out_dim = clip.text_projection.shape[1]
+    return s
+
+
+def gru_view(rnn):
+    return L.Gru(P(rnn.weight_ih_l0), P(rnn.weight_hh_l0), P(rnn.bias_ih_l0), P(rnn.bias_hh_l0),
+                 rnn.weight_ih_l0.shape[1], rnn.weight_hh_l0.shape[1])
+
+
+def heads_view(action_lin, critic_lin, unct_lin=None):
+    h = L.Heads()
+    h.action = linear_view(action_lin.weight, action_lin.bias)
+    h.critic = linear_view(critic_lin.weight, critic_lin.bias)
+    if unct_lin is not None:
+        h.unct = linear_view(unct_lin.weight, unct_lin.bias)
+        h.has_unct = 1
+    else:
+        h.has_unct = 0
+    return h
+
+
+def grad_struct_like(view, name_of_ptr, flat):
+    """Build a struct of the same ctypes type whose pointers address the matching ranges of flat.grad.
+    `name_of_ptr`: {param data_ptr -> name}.  Pointers into a packed projection (row slices) are not
+    needed here: every view above points at the start of a parameter tensor."""
+    out = type(view)()
+    for fname, ftype in view._fields_:
+        val = getattr(view, fname)
+        if isinstance(val, C.Structure):
+            setattr(out, fname, grad_struct_like(val, name_of_ptr, flat))
+        elif isinstance(val, C.Array):
+            arr = getattr(out, fname)
+            for i in range(len(val)):
+                arr[i] = grad_struct_like(val[i], name_of_ptr, flat)
+        elif ftype is C.c_void_p:
+            if val is None:
+                setattr(out, fname, None)
+            else:
+                name = name_of_ptr.get(val)
+                setattr(out, fname, C.c_void_p(flat.grad_ptr(name)) if name in flat.trained_names else None)
+        else:
+            setattr(out, fname, val)
+    return out

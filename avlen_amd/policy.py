@@ -1,0 +1,583 @@
+"""Drop-in mirror of ss_baselines/savi/ppo/policy.py on the MI355X HIP library.
+
+Same class names, constructor keywords, method signatures, return tuples and parameter names as the
+reference (policy.py:39-276 Policy API; :299-356 policy classes; :379-1114 nets), so
+`ss_baselines/savi/ddppo/algo/ddppo_trainer.py:301-512` can construct these instead.  Every tensor
+operation below `act* / evaluate_actions* / get_value*` is a HIP kernel launched through the C ABI
+(include/avlen_hip.h); PyTorch provides device memory, the stream and the host RNG.
+
+Sampling: `Categorical.sample()` of the reference CPU path consumes the torch CPU generator
+(SURVEY App. B).  With sampling="host" (default) the (B,A) probabilities are brought to the host and the
+action is drawn from that generator in the same order -> bit-exact actions for a fixed seed;
+sampling="device" keeps everything on the GPU (like the reference would on a CUDA device).
+"""
+import ctypes as C
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import engine as E
+from . import nets as N
+
+DUAL_GOAL_DELIMITER = ","
+_PREC = {"fp32": L.PREC_FP32, "bf16": L.PREC_BF16}
+
+POSE, SPECTROGRAM, LOCATION_BELIEF, CATEGORY_BELIEF, CATEGORY = "pose", "spectrogram", "location_belief", \
+    "category_belief", "category"     # soundspaces/tasks/nav.py cls_uuid values
+
+
+def _f32(t):
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _i64(t):
+    if t.dtype != torch.int64:
+        t = t.long()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class _Dist:
+    """What the trainer reads off the reference's CustomFixedCategorical."""
+    def __init__(self, logits, probs):
+        self.logits, self.probs = logits, probs
+
+
+class Policy(nn.Module):
+    """policy.py:39-276."""
+
+    def __init__(self, net, dim_actions, dim_actions_option=2, precision="fp32", sampling="host"):
+        super().__init__()
+        self.net = net
+        self.dim_actions, self.dim_actions_option = dim_actions, dim_actions_option
+        d = self.net.output_size
+        self.action_distribution_option = N.CategoricalNetParams(d, dim_actions_option)
+        self.action_distribution_goal = N.CategoricalNetParams(d, dim_actions)
+        self.action_distribution_vln = N.CategoricalNetParams(d, dim_actions)
+        self.critic_goal = N.CriticHeadParams(d)
+        self.critic_option = N.CriticHeadParams(d)
+        self.uncertainty_option = N.CriticHeadParams(d, 2)
+        self.critic_vln = N.CriticHeadParams(d)
+        self.precision, self.sampling = precision, sampling
+        self._eng = None
+        self._ws = E.Workspaces()
+        self._dirty = True
+        for m in self.modules():
+            m.register_load_state_dict_post_hook(lambda mod, keys, p=self: p.mark_params_changed())
+
+    # ------------------------------------------------------------------ engine state
+    TRAINED_PREFIXES = ()
+
+    def forward(self, *x):
+        raise NotImplementedError
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._eng = None
+        return r
+
+    def mark_params_changed(self):
+        """Call after modifying encoder weights in place (load_state_dict does it automatically)."""
+        self._dirty = True
+
+    @property
+    def prec(self):
+        return _PREC[self.precision]
+
+    def _engine(self):
+        p0 = next(self.parameters())
+        if not p0.is_cuda:
+            raise RuntimeError("avlen_amd policies run on an MI355X only: move the policy to a HIP device "
+                               "(there is no CPU fallback)")
+        if self._eng is None:
+            flat = E.FlatParams(self, self.TRAINED_PREFIXES)
+            packed = E.Packed(flat.device)
+            eng = {"flat": flat, "packed": packed}
+            self._build_views(eng, packed)
+            ptr2name = {p.data_ptr(): n for n, p in self.named_parameters()}
+            eng["ptr2name"] = ptr2name
+            self._eng = eng
+            self._dirty = True
+            self._ws.clear()
+        if self._dirty:
+            self._eng["packed"].refresh()
+            self._dirty = False
+        return self._eng
+
+    def _build_views(self, eng, packed):
+        raise NotImplementedError
+
+    def _heads(self, which):
+        eng = self._engine()
+        key = "heads_" + which
+        if key not in eng:
+            act = getattr(self, "action_distribution_" + which).linear
+            cr = getattr(self, "critic_" + which).fc
+            un = self.uncertainty_option.fc if which == "option" else None
+            eng[key] = E.heads_view(act, cr, un)
+        return eng[key]
+
+    # ------------------------------------------------------------------ heads + sampling
+    def _run_heads(self, which, feats, action=None, deterministic=False, need_sample=True):
+        B, d = feats.shape
+        A = self.dim_actions_option if which == "option" else self.dim_actions
+        dev = feats.device
+        h = self._heads(which)
+        logits = torch.empty(B, A, device=dev)
+        probs = torch.empty(B, A, device=dev)
+        value = torch.empty(B, 1, device=dev)
+        unct = torch.empty(B, 2, device=dev) if which == "option" else None
+        st = L.stream()
+        L.call("avlen_heads_fwd", C.byref(h), E.P(feats), d, A, E.P(logits), E.P(probs), E.P(value),
+               E.P(unct) if unct is not None else None, None, None, None, B, st)
+        out = {"logits": logits, "probs": probs, "value": value, "unct": unct}
+        if action is None and need_sample:
+            if deterministic:
+                action = probs.argmax(dim=-1, keepdim=True)
+            elif self.sampling == "host":
+                pc = probs.cpu()                                        # sync; (B,A) floats
+                q = torch.empty_like(pc).exponential_(1)                # == torch.multinomial's race
+                action = (pc / q).argmax(-1, keepdim=True).to(dev)
+            else:
+                q = torch.empty_like(probs).exponential_(1)
+                action = (probs / q).argmax(-1, keepdim=True)
+        if action is not None:
+            action = _i64(action.view(B, 1))
+            logp = torch.empty(B, 1, device=dev)
+            ent = torch.empty(B, device=dev)
+            L.call("avlen_heads_fwd", C.byref(h), E.P(feats), d, A, None, None, None, None, E.P(action), E.P(logp),
+                   E.P(ent), B, st)
+            out.update(action=action, log_prob=logp, entropy_rows=ent)
+        return out
+
+    # ------------------------------------------------------------------ reference API
+    def act(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks,
+            deterministic=False):
+        features, rnn_hidden_states, ext_memory_feats = self.net.run(
+            self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks)
+        h = self._run_heads("goal", features, deterministic=deterministic)
+        return h["value"], h["action"], h["log_prob"], rnn_hidden_states, ext_memory_feats, h["probs"]
+
+    def act_option(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks,
+                   query_state, last_query_info, deterministic=False):
+        features, rnn_hidden_states, ext_memory_feats = self.net.run(
+            self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks, query_state,
+            last_query_info)
+        h = self._run_heads("option", features, deterministic=deterministic)
+        return (h["value"], h["unct"], h["action"], h["log_prob"], rnn_hidden_states, ext_memory_feats, h["probs"])
+
+    def act_dialog(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_dialog,
+                   ext_memory_masks, all_dialog, agent_step, deterministic=False, without_dialog=False):
+        if without_dialog:
+            all_dialog = None
+        features, rnn_hidden_states, ext_memory_feats, ext_memory_dialog_feats = self.net.run(
+            self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_dialog,
+            ext_memory_masks, all_dialog, agent_step)
+        h = self._run_heads("vln", features, deterministic=deterministic)
+        return (h["value"], h["action"], h["log_prob"], rnn_hidden_states, ext_memory_feats,
+                ext_memory_dialog_feats, h["probs"])
+
+    def get_value(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks):
+        features, _, _ = self.net.run(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory,
+                                      ext_memory_masks)
+        return self._run_heads("goal", features, need_sample=False)["value"]
+
+    def get_value_option(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks,
+                         query_state, last_query_info):
+        features, _, _ = self.net.run(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory,
+                                      ext_memory_masks, query_state, last_query_info)
+        return self._run_heads("option", features, need_sample=False)["value"]
+
+    def evaluate_actions(self, observations, rnn_hidden_states, prev_actions, masks, action, ext_memory,
+                         ext_memory_masks):
+        features, rnn_hidden_states, ext_memory_feats = self.net.run(
+            self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks)
+        h = self._run_heads("goal", features, action=action)
+        return h["value"], h["log_prob"], h["entropy_rows"].mean(), rnn_hidden_states, ext_memory_feats
+
+    def evaluate_actions_option(self, observations, rnn_hidden_states, prev_actions, masks, action, ext_memory,
+                                ext_memory_masks, query_state, last_query_info):
+        """Values only (no autograd graph): training goes through avlen_amd.ppo.PPO.update, which runs the
+        fused HIP loss/backward (ppo.py:207-262)."""
+        features, rnn_hidden_states, ext_memory_feats = self.net.run(
+            self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks, query_state,
+            last_query_info)
+        h = self._run_heads("option", features, action=action)
+        return (h["value"], h["unct"], h["log_prob"], h["entropy_rows"].mean(), rnn_hidden_states, ext_memory_feats,
+                h["probs"])
+
+    def evaluate_actions_dialog(self, observations, rnn_hidden_states, prev_actions, masks, action, ext_memory,
+                                ext_memory_dialog, ext_memory_masks, all_dialog, agent_step, without_dialog=False):
+        if without_dialog:
+            all_dialog = None
+        features, rnn_hidden_states, ext_memory_feats, ext_memory_dialog_feats = self.net.run(
+            self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_dialog,
+            ext_memory_masks, all_dialog, agent_step)
+        h = self._run_heads("vln", features, action=action)
+        return (None, h["log_prob"], h["entropy_rows"].mean(), rnn_hidden_states, ext_memory_feats,
+                ext_memory_dialog_feats, h["logits"])
+
+
+# =========================================================================================================
+# nets
+# =========================================================================================================
+class Net(N._Holder):
+    @property
+    def is_blind(self):
+        return False
+
+
+class _SMTBase(Net):
+    """Shared by AudioNavSMTNet / AudioNavDialogNet / AudioNavOptionNet (policy.py:501-1114)."""
+
+    def _init_encoders(self, observation_space, action_space, hidden_size, use_category_input, extra_dims, smt_kwargs):
+        self._hidden_size = hidden_size
+        self._action_size = action_space.n
+        self._use_category_input = use_category_input
+        assert SPECTROGRAM in observation_space.spaces and POSE in observation_space.spaces
+        sh, sw, sc = observation_space.spaces[SPECTROGRAM].shape
+        self.goal_encoder = N.Cnn3Params(sc, (sh, sw), N.audio_geometry(sh, sw), 128)
+        self.visual_encoder = N.SMTCNNParams(observation_space)
+        self.action_encoder = N._no_fwd(nn.Linear(self._action_size, 16))
+        nfeats = self.visual_encoder.feature_dims + 16 + 128
+        self._col_cat = nfeats
+        if use_category_input:
+            nfeats += 21
+        pose_dims = observation_space.spaces[POSE].shape[0]
+        pose_indices = (nfeats, nfeats + pose_dims)
+        nfeats += pose_dims
+        self._x_dims = nfeats                     # [visual | action | audio | (category) | pose]
+        nfeats += extra_dims
+        self._feature_size = nfeats
+        self._img = observation_space.spaces["rgb"].shape[0]
+        self.smt_state_encoder = N.SMTStateEncoderParams(nfeats, dim_feedforward=hidden_size,
+                                                         pose_indices=pose_indices, **smt_kwargs)
+
+    @property
+    def memory_dim(self):
+        return self._feature_size
+
+    @property
+    def output_size(self):
+        return self.smt_state_encoder.hidden_state_size
+
+    @property
+    def num_recurrent_layers(self):
+        return -1
+
+    def freeze_encoders(self):
+        for m in (self.goal_encoder, self.visual_encoder, self.action_encoder):
+            for p in m.parameters():
+                p.requires_grad = False
+
+    def set_eval_encoders(self):
+        self.goal_encoder.eval()
+        self.visual_encoder.eval()
+
+    def pretrained_initialization(self, path):
+        sd = torch.load(path, map_location="cpu")["state_dict"]
+        self.load_state_dict({k[len("actor_critic.net."):]: v for k, v in sd.items() if "actor_critic.net." in k},
+                             strict=False)
+
+    # ---- engine
+    def build_views(self, eng, packed):
+        eng["rgb"] = E.resnet18_view(self.visual_encoder.rgb_encoder, packed)
+        eng["depth"] = E.resnet18_view(self.visual_encoder.depth_encoder, packed)
+        eng["audio"] = E.cnn3_view(self.goal_encoder, packed)
+        eng["action"] = E.linear_view(self.action_encoder.weight, self.action_encoder.bias)
+        eng["smt"] = E.smt_view(self.smt_state_encoder)
+
+    def features(self, pol, obs, prev_actions, extra=None):
+        """-> feats (B, F) = [visual 128 | action 16 | audio 128 | (category 21) | pose 4 | (extra)], goal (B,d)."""
+        eng = pol._engine()
+        rgb, depth, spec = _f32(obs["rgb"]), _f32(obs["depth"]), _f32(obs[SPECTROGRAM])
+        B = rgb.shape[0]
+        dev = rgb.device
+        F = self._feature_size
+        feats = torch.empty(B, F, device=dev)
+        goal = torch.empty(B, self._hidden_size, device=dev)
+        st = L.stream()
+        prec = pol.prec
+        nb = L.lib.avlen_resnet18_workspace_bytes(B)
+        ws = pol._ws.get("resnet", nb, dev)
+        S = rgb.shape[1]
+        L.call("avlen_resnet18_fwd", C.byref(eng["rgb"]), E.P(rgb), B, S, rgb.shape[3], 255.0, E.P(feats, 0), F, prec,
+               E.P(ws), nb, st)
+        L.call("avlen_resnet18_fwd", C.byref(eng["depth"]), E.P(depth), B, S, depth.shape[3], 1.0, E.P(feats, 64), F,
+               prec, E.P(ws), nb, st)
+        H, W = spec.shape[1], spec.shape[2]
+        nb2 = L.lib.avlen_cnn3_workspace_bytes(C.byref(eng["audio"]), B, H, W)
+        ws2 = pol._ws.get("audio", nb2, dev)
+        L.call("avlen_cnn3_fwd", C.byref(eng["audio"]), E.P(spec), B, H, W, E.P(feats, 144), F, prec, E.P(ws2), nb2, st)
+        pa = _i64(prev_actions.view(B, -1)[:, :1])
+        cat = _f32(obs[CATEGORY]) if self._use_category_input else None
+        pose = _f32(obs[POSE])
+        cb, lb = _f32(obs[CATEGORY_BELIEF]), _f32(obs[LOCATION_BELIEF])
+        ex = _f32(extra) if extra is not None else None
+        pose_col = self._x_dims - 4
+        L.call("avlen_feature_assemble", E.P(feats), F, C.byref(eng["action"]), E.P(pa), 128,
+               E.P(cat) if cat is not None else None, self._col_cat, E.P(pose), pose_col,
+               E.P(ex) if ex is not None else None, ex.shape[1] if ex is not None else 0, self._x_dims, E.P(cb), E.P(lb),
+               E.P(goal), self._hidden_size, B, st)
+        return feats, goal
+
+    def smt(self, pol, feats, goal, ext_memory, ext_memory_masks, save_key="smt", mem_index=None):
+        eng = pol._engine()
+        B, F = feats.shape
+        dev = feats.device
+        cto = 1 if self.smt_state_encoder._pretraining else 0
+        mem = _f32(ext_memory) if ext_memory is not None else None
+        M = mem.shape[0] if mem is not None else 0
+        NC = mem.shape[1] if mem is not None else B
+        masks = _f32(ext_memory_masks) if ext_memory_masks is not None else None
+        if not cto:
+            assert mem is not None and mem.shape[2] == F and masks.shape == (B, M), "ext memory/mask shape"
+            assert mem_index is not None or NC == B
+        out = torch.empty(B, self._hidden_size, device=dev)
+        nb = L.lib.avlen_smt_workspace_bytes(C.byref(eng["smt"]), B, M, F, cto)
+        ws = pol._ws.get(save_key, nb, dev)
+        L.call("avlen_smt_fwd", C.byref(eng["smt"]), E.P(feats), E.P(mem) if mem is not None else None,
+               E.P(mem_index) if mem_index is not None else None, NC, E.P(masks) if masks is not None else None,
+               E.P(goal), E.P(out), B, M, F, self._x_dims - 4, cto, pol.prec, E.P(ws), nb, L.stream())
+        return out, (ws, nb, B, M, F, cto)
+
+
+class AudioNavSMTNet(_SMTBase):
+    """policy.py:501-674 (pi_g)."""
+
+    def __init__(self, observation_space, action_space, hidden_size=128, use_pretrained=False, pretrained_path="",
+                 use_belief_as_goal=True, use_label_belief=True, use_location_belief=True, use_belief_encoding=False,
+                 normalize_category_distribution=False, use_category_input=False, **kwargs):
+        super().__init__()
+        assert use_belief_as_goal and use_label_belief and use_location_belief and not use_belief_encoding \
+            and not normalize_category_distribution, "only the AVLEN yaml configuration is implemented"
+        self._init_encoders(observation_space, action_space, hidden_size, use_category_input, 0, kwargs)
+        if use_pretrained:
+            self.pretrained_initialization(pretrained_path)
+        self.train()
+
+    def run(self, pol, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks):
+        feats, goal = self.features(pol, observations, prev_actions)
+        x_att, _ = self.smt(pol, feats, goal, ext_memory, ext_memory_masks)
+        return x_att, rnn_hidden_states, feats
+
+
+class AudioNavOptionNet(_SMTBase):
+    """policy.py:919-1114 (pi_q)."""
+
+    def __init__(self, observation_space, action_space, hidden_size=128, use_pretrained=False, pretrained_path="",
+                 use_belief_as_goal=True, use_label_belief=True, use_location_belief=True, use_belief_encoding=False,
+                 normalize_category_distribution=False, use_category_input=False, query_count_emb_size=32, **kwargs):
+        super().__init__()
+        assert use_belief_as_goal and use_label_belief and use_location_belief and not use_belief_encoding \
+            and not normalize_category_distribution, "only the AVLEN yaml configuration is implemented"
+        self._query_count_emb_size = query_count_emb_size
+        kwargs.pop("use_query_count", None)
+        self._init_encoders(observation_space, action_space, hidden_size, use_category_input, query_count_emb_size,
+                            kwargs)
+        self.policy_selector = N._no_fwd(nn.Linear(self.smt_state_encoder.hidden_state_size, 2))   # unused in fwd
+        self._qcnt_emb = N._no_fwd(nn.Embedding(2, query_count_emb_size))                          # unused in fwd
+        if use_pretrained:
+            self.pretrained_initialization(pretrained_path)
+        self.train()
+
+    @property
+    def qcnt_emb(self):
+        return self._qcnt_emb
+
+    def run(self, pol, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks,
+            query_state, last_query_info, mem_index=None, save_key="smt"):
+        feats, goal = self.features(pol, observations, prev_actions, extra=query_state)      # [x | query_state]
+        x_att, saved = self.smt(pol, feats, goal, ext_memory, ext_memory_masks, save_key, mem_index)
+        B = feats.shape[0]
+        lqi = _f32(last_query_info)
+        row = torch.empty(B, self._feature_size, device=feats.device)                          # [x | last_query_info]
+        L.call("avlen_concat_rows", E.P(feats), feats.shape[1], self._x_dims, E.P(lqi), lqi.shape[1], lqi.shape[1],
+               E.P(row), row.shape[1], B, L.stream())
+        self._last = (feats, goal, saved)
+        return x_att, rnn_hidden_states, row
+
+
+class AudioNavDialogNet(_SMTBase):
+    """policy.py:679-916 (pi_l)."""
+
+    def __init__(self, observation_space, action_space, hidden_size=128, use_pretrained=False, pretrained_path="",
+                 use_belief_as_goal=True, use_label_belief=True, use_location_belief=True, use_belief_encoding=False,
+                 normalize_category_distribution=False, use_category_input=False, num_steps=5, **kwargs):
+        super().__init__()
+        assert use_belief_as_goal and use_label_belief and use_location_belief and not use_belief_encoding \
+            and not normalize_category_distribution, "only the AVLEN yaml configuration is implemented"
+        self._num_steps = num_steps
+        # policy.py:728-732: the category input is NOT appended for pi_l
+        self._init_encoders(observation_space, action_space, hidden_size, False, 0, kwargs)
+        self.clip = N.ClipTextParams()
+        self.dialog_layer = N._no_fwd(nn.Linear(self.clip.transformer.width, hidden_size))
+        self.dialog_state_encoder = N.DialogStateEncoderParams(hidden_size + hidden_size, dim_feedforward=hidden_size,
+                                                               **kwargs)
+        if use_pretrained:
+            self.pretrained_initialization(pretrained_path)
+        self.train()
+
+    def build_views(self, eng, packed):
+        super().build_views(eng, packed)
+        eng["clip"] = E.clip_view(self.clip)
+        eng["dialog_layer"] = E.linear_view(self.dialog_layer.weight, self.dialog_layer.bias)
+        eng["dialog"] = E.dialog_view(self.dialog_state_encoder)
+
+    def encode_text(self, pol, tokens):
+        eng = pol._engine()
+        tok = _i64(tokens)
+        B = tok.shape[0]
+        out = torch.empty(B, self.clip.text_projection.shape[1], device=tok.device)
+        nb = L.lib.avlen_clip_text_workspace_bytes(C.byref(eng["clip"]), B)
+        ws = pol._ws.get("clip", nb, tok.device)
+        L.call("avlen_clip_text_fwd", C.byref(eng["clip"]), E.P(tok), E.P(out), B, pol.prec, E.P(ws), nb, L.stream())
+        return out
+
+    text_encoder_override = None      # tests: callable(tokens)->(B,512) replacing the CLIP tower (unpinned)
+
+    def run(self, pol, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_dialog,
+            ext_memory_masks, all_dialog, agent_step):
+        eng = pol._engine()
+        feats, goal = self.features(pol, observations, prev_actions)
+        x_att, _ = self.smt(pol, feats, goal, ext_memory, ext_memory_masks)
+        B, d = x_att.shape
+        dev = x_att.device
+        st = L.stream()
+        d_emb = None
+        if all_dialog is not None:
+            e = (self.text_encoder_override(all_dialog) if self.text_encoder_override is not None
+                 else self.encode_text(pol, all_dialog))
+            e = _f32(e)
+            d_emb = torch.empty(B, d, device=dev)
+            dl = eng["dialog_layer"]
+            nbg = L.lib.avlen_gemm_workspace_bytes(B, d, e.shape[1], 1)
+            wsg = pol._ws.get("dlg_gemm", nbg, dev)
+            L.call("avlen_gemm", E.P(e), e.shape[1], 0, dl.w, dl.in_f, 0, E.P(d_emb), d, dl.b, None, 0, B, d, e.shape[1],
+                   0, pol.prec, 1, 0.0, E.P(wsg), nbg, st)
+        memd = _f32(ext_memory_dialog)
+        mk = _f32(ext_memory_masks)
+        M = memd.shape[0]
+        step = _f32(agent_step.view(-1))
+        out = torch.empty(B, d, device=dev)
+        nb = L.lib.avlen_dialog_workspace_bytes(C.byref(eng["dialog"]), B, M)
+        ws = pol._ws.get("dialog", nb, dev)
+        L.call("avlen_dialog_fwd", C.byref(eng["dialog"]), E.P(x_att), E.P(memd), E.P(mk),
+               E.P(d_emb) if d_emb is not None else None, E.P(step), E.P(goal), E.P(out), B, M, pol.prec, E.P(ws), nb, st)
+        return out, rnn_hidden_states, feats, out
+
+
+class AudioNavBaselineNet(Net):
+    """policy.py:379-498: [AudioCNN 512 | VisualCNN 512 | category 21] -> masked GRU (config 2)."""
+
+    def __init__(self, observation_space, hidden_size, goal_sensor_uuid, extra_rgb=False, use_mlp_state_encoder=False):
+        super().__init__()
+        assert goal_sensor_uuid == SPECTROGRAM and not extra_rgb and not use_mlp_state_encoder, \
+            "avlen_amd implements the spectrogram-goal GRU baseline"
+        self.goal_sensor_uuid, self._hidden_size = goal_sensor_uuid, hidden_size
+        self._label = CATEGORY in observation_space.spaces
+        H, W, _ = observation_space.spaces["rgb"].shape
+        self.visual_encoder = N.Cnn3Params(4, (H, W), N.VISUAL_GEOMETRY, hidden_size)
+        sh, sw, sc = observation_space.spaces[SPECTROGRAM].shape
+        self.audio_encoder = N.Cnn3Params(sc, (sh, sw), N.audio_geometry(sh, sw), hidden_size)
+        self._rnn_in = 2 * hidden_size + (observation_space.spaces[CATEGORY].shape[0] if self._label else 0)
+        self.state_encoder = N.RNNStateEncoderParams(self._rnn_in, hidden_size)
+        self.train()
+
+    @property
+    def output_size(self):
+        return self._hidden_size
+
+    @property
+    def num_recurrent_layers(self):
+        return 1
+
+    def build_views(self, eng, packed):
+        eng["visual"] = E.cnn3_view(self.visual_encoder, packed)
+        eng["audio"] = E.cnn3_view(self.audio_encoder, packed)
+        eng["gru"] = E.gru_view(self.state_encoder.rnn)
+
+    def run(self, pol, observations, rnn_hidden_states, prev_actions, masks, ext_memory=None, ext_memory_masks=None):
+        eng = pol._engine()
+        rgb, depth, spec = _f32(observations["rgb"]), _f32(observations["depth"]), _f32(observations[SPECTROGRAM])
+        R = rgb.shape[0]
+        dev = rgb.device
+        st = L.stream()
+        F = self._rnn_in
+        x = torch.empty(R, F, device=dev)
+        H, W = spec.shape[1], spec.shape[2]
+        nb = L.lib.avlen_cnn3_workspace_bytes(C.byref(eng["audio"]), R, H, W)
+        ws = pol._ws.get("audio", nb, dev)
+        L.call("avlen_cnn3_fwd", C.byref(eng["audio"]), E.P(spec), R, H, W, E.P(x, 0), F, pol.prec, E.P(ws), nb, st)
+        S = rgb.shape[1]
+        rgbd = torch.empty(R, S, S, 4, device=dev)
+        L.call("avlen_rgbd_concat", E.P(rgb), E.P(depth), E.P(rgbd), R, S * S, st)
+        nb2 = L.lib.avlen_cnn3_workspace_bytes(C.byref(eng["visual"]), R, S, S)
+        ws2 = pol._ws.get("visual", nb2, dev)
+        L.call("avlen_cnn3_fwd", C.byref(eng["visual"]), E.P(rgbd), R, S, S, E.P(x, self._hidden_size), F, pol.prec,
+               E.P(ws2), nb2, st)
+        if self._label:
+            cat = _f32(observations[CATEGORY])
+            L.call("avlen_copy_rows", E.P(cat), cat.shape[1], E.P(x, 2 * self._hidden_size), F, R, cat.shape[1], st)
+        h0 = _f32(rnn_hidden_states)
+        Nn = h0.shape[1]
+        T = R // Nn
+        mk = _f32(masks.view(-1))
+        out = torch.empty(R, self._hidden_size, device=dev)
+        h_out = torch.empty(1, Nn, self._hidden_size, device=dev)
+        nb3 = L.lib.avlen_gru_workspace_bytes(C.byref(eng["gru"]), T, Nn)
+        ws3 = pol._ws.get("gru", nb3, dev)
+        L.call("avlen_gru_fwd", C.byref(eng["gru"]), E.P(x), E.P(h0), E.P(mk), E.P(out), E.P(h_out), T, Nn, pol.prec,
+               E.P(ws3), nb3, st)
+        return out, h_out, None
+
+
+# =========================================================================================================
+# policies (policy.py:299-356)
+# =========================================================================================================
+class _NetPolicy(Policy):
+    def _build_views(self, eng, packed):
+        self.net.build_views(eng, packed)
+
+
+class AudioNavBaselinePolicy(_NetPolicy):
+    TRAINED_PREFIXES = ("net.", "action_distribution_goal.", "critic_goal.")
+
+    def __init__(self, observation_space, action_space, goal_sensor_uuid, hidden_size=512, extra_rgb=False,
+                 use_mlp_state_encoder=False, **eng_kw):
+        super().__init__(AudioNavBaselineNet(observation_space=observation_space, hidden_size=hidden_size,
+                                             goal_sensor_uuid=goal_sensor_uuid, extra_rgb=extra_rgb,
+                                             use_mlp_state_encoder=use_mlp_state_encoder), action_space.n, **eng_kw)
+
+
+def _split_engine_kwargs(kwargs):
+    return {k: kwargs.pop(k) for k in ("precision", "sampling") if k in kwargs}
+
+
+class AudioNavSMTPolicy(_NetPolicy):
+    TRAINED_PREFIXES = ()                      # pi_g is frozen on this path (ddppo_trainer.py:417-419)
+
+    def __init__(self, observation_space, action_space, hidden_size=128, **kwargs):
+        ek = _split_engine_kwargs(kwargs)
+        super().__init__(AudioNavSMTNet(observation_space, action_space, hidden_size=hidden_size, **kwargs),
+                         action_space.n, **ek)
+
+
+class AudioNavDialogPolicy(_NetPolicy):
+    TRAINED_PREFIXES = ()
+
+    def __init__(self, observation_space, action_space, hidden_size=128, **kwargs):
+        ek = _split_engine_kwargs(kwargs)
+        super().__init__(AudioNavDialogNet(observation_space, action_space, hidden_size=hidden_size, **kwargs),
+                         action_space.n, **ek)
+
+
+class AudioNavOptionPolicy(_NetPolicy):
+    # parameters reached by the gradient of PPO.update (policy.py:1035-1036 detaches the encoders)
+    TRAINED_PREFIXES = ("net.smt_state_encoder.", "action_distribution_option.", "critic_option.",
+                        "uncertainty_option.")
+
+    def __init__(self, observation_space, action_space, hidden_size=128, **kwargs):
+        ek = _split_engine_kwargs(kwargs)
+        super().__init__(AudioNavOptionNet(observation_space, action_space, hidden_size=hidden_size, **kwargs), 2, **ek)

@@ -1,0 +1,253 @@
+"""Device-resident mirror of ss_baselines/savi/models/rollout_storage.py (RolloutStorage :16-905,
+ExternalMemory :907-960).
+
+Same constructor, `insert` (22 arguments), `compute_returns`, `after_update`, `recurrent_generator`
+(22-tuple) and `external_memory_*` accessors as the reference, with two MI355X-first changes that do
+not alter any value the trainer can observe:
+
+* the reference keeps T+1 IDENTICAL copies of every external memory (rollout_storage.py:924,933 --
+  3.6 GB per memory at N=64); here there is ONE copy (total, N, dim) plus the per-step masks: a slot that
+  is visible at step t is never overwritten before the rollout ends (total = capacity + T);
+* GAE, the ring insert and the minibatch gather are HIP kernels (avlen_gae_scan, avlen_extmem_insert,
+  avlen_minibatch_gather); `gather_minibatch` hands avlen_amd.ppo.PPO an index into the ring instead of
+  the (300, T*N_mb, dim) tensor the reference materialises per minibatch (K21).
+"""
+from collections import defaultdict
+import torch
+
+from . import _lib as L
+from .engine import P
+
+
+class _CopyAxis:
+    """`memory[:, step]` of the reference's (total, copies, N, dim) tensor: every copy is the same."""
+    def __init__(self, em):
+        self._em = em
+
+    def __getitem__(self, idx):
+        if isinstance(idx, tuple) and len(idx) == 2 and idx[0] == slice(None):
+            return self._em.memory
+        raise IndexError("external memory is stored once: index it as memory[:, step]")
+
+    @property
+    def shape(self):
+        m = self._em.memory
+        return (m.shape[0], self._em.num_copies, m.shape[1], m.shape[2])
+
+
+class ExternalMemory:
+    def __init__(self, num_envs, total_size, capacity, dim, num_copies=1, num_steps=150, device="cpu"):
+        self.num_envs, self.total_size, self.capacity, self.dim = num_envs, total_size, capacity, dim
+        self.num_copies, self.num_steps = num_copies, num_steps
+        self.masks = torch.zeros(num_envs, total_size, device=device)
+        self.memory = torch.zeros(total_size, num_envs, dim, device=device)
+        self.idx = 0
+
+    def insert(self, em_features, not_done_masks, masks_out=None):
+        f = em_features if em_features.is_contiguous() else em_features.contiguous()
+        nd = not_done_masks.float().contiguous()
+        L.call("avlen_extmem_insert", P(self.memory), P(self.masks), P(f), f.shape[1], P(nd),
+               P(masks_out) if masks_out is not None else None, self.idx, self.total_size, self.capacity,
+               self.num_envs, self.dim, L.stream())
+        self.idx = (self.idx + 1) % self.total_size
+
+    def to(self, device):
+        self.masks, self.memory = self.masks.to(device), self.memory.to(device)
+
+
+class RolloutStorage:
+    def __init__(self, num_steps, num_envs, observation_space, action_space, recurrent_hidden_state_size,
+                 use_external_memory, external_memory_size, external_memory_capacity, external_memory_option_size,
+                 external_memory_option_capacity, external_memory_vln_size, external_memory_vln_capacity,
+                 external_memory_dim_goal, external_memory_dim_vln, external_memory_dim_option,
+                 external_memory_dim_dialog, num_recurrent_layers=1, max_dialog_len=20, query_count_emb_size=32,
+                 use_state_memory=False, device="cuda", skip_sensors=()):
+        T, N, dev = num_steps, num_envs, torch.device(device)
+        z = lambda *s, **k: torch.zeros(*s, device=dev, **k)
+        self.num_steps, self.num_envs, self.device = T, N, dev
+        # `skip_sensors`: sensors no network reads (e.g. raw `audiogoal`) need not live in HBM
+        self.observations = {k: z(T + 1, N, *sp.shape) for k, sp in observation_space.spaces.items()
+                             if k not in skip_sensors}
+        if num_recurrent_layers < 1:
+            num_recurrent_layers = 1
+        self.recurrent_hidden_states = z(T + 1, num_recurrent_layers, N, recurrent_hidden_state_size)
+        self.all_dialog = z(T, N, max_dialog_len, dtype=torch.long)
+        self.query_state, self.last_query_info = z(T, N, query_count_emb_size), z(T, N, query_count_emb_size)
+        self.agent_step = z(T, N)
+        self.rewards, self.value_preds, self.returns = z(T, N, 1), z(T + 1, N, 1), z(T + 1, N, 1)
+        self.advantages = z(T, N, 1)
+        self.action_log_probs = z(T, N, 1)
+        discrete = action_space.__class__.__name__ == "ActionSpace"
+        ashape = 1 if discrete else action_space.shape[0]
+        adt = torch.long if discrete else torch.float32
+        self.actions, self.actions_option = z(T, N, ashape, dtype=adt), z(T, N, ashape, dtype=adt)
+        self.prev_actions = z(T + 1, N, ashape, dtype=adt)
+        self.masks, self.masks_vln = z(T + 1, N, 1), z(T + 1, N, 1)
+        self.o_actions = z(T, N)
+        self.o_masks, self.ucnt_gt, self.rl_masks = (z(T, N, dtype=torch.long) for _ in range(3))
+        self.action_probs = z(T, N, 4)
+        self.use_external_memory, self.use_state_memory = use_external_memory, use_state_memory
+        self.em_size, self.em_capacity = external_memory_size, external_memory_capacity
+        self.em_option_size, self.em_option_capacity = external_memory_option_size, external_memory_option_capacity
+        self.em_vln_size, self.em_vln_capacity = external_memory_vln_size, external_memory_vln_capacity
+        self.em_dim_goal, self.em_dim_vln = external_memory_dim_goal, external_memory_dim_vln
+        self.em_dim_dialog, self.em_dim_option = external_memory_dim_dialog, external_memory_dim_option
+        self.em_masks, self.em_vln_masks = z(T + 1, N, self.em_size), z(T + 1, N, self.em_vln_size)
+        mk = lambda size, cap, dim: ExternalMemory(N, size, cap, dim, num_copies=T + 1, num_steps=T, device=dev)
+        self.em = self.em_option = self.em_vln = self.em_vln_dialog = None
+        if use_external_memory:
+            self.em = mk(self.em_size, self.em_capacity, self.em_dim_goal)
+            self.em_option = mk(self.em_option_size, self.em_option_capacity, self.em_dim_option)
+            self.em_vln = mk(self.em_vln_size, self.em_vln_capacity, self.em_dim_vln)
+        if use_state_memory:
+            self.em_vln_dialog = mk(self.em_vln_size, self.em_vln_capacity, self.em_dim_dialog)
+        self.step = 0
+
+    def to(self, device):
+        dev = torch.device(device)
+        for k, v in list(self.__dict__.items()):
+            if torch.is_tensor(v):
+                setattr(self, k, v.to(dev))
+        self.observations = {k: v.to(dev) for k, v in self.observations.items()}
+        for em in (self.em, self.em_option, self.em_vln, self.em_vln_dialog):
+            if em is not None:
+                em.to(dev)
+        self.device = dev
+
+    # ---------------------------------------------------------------- insert (rollout_storage.py:214-297)
+    def insert(self, observations, recurrent_hidden_states, actions, actions_option, action_log_probs, value_preds,
+               rewards, not_done_masks, not_done_masks_vln, em_features, em_features_option, em_features_vln,
+               em_features_dialog, all_dialog, o_action, o_mask, rl_masks, ucnt_gt, action_prob, query_state,
+               last_query_info, agent_step):
+        s = self.step
+        dev = self.device
+        as_t = lambda x, dt=None: (x if torch.is_tensor(x) else torch.as_tensor(x)).to(dev, dtype=dt, non_blocking=True)
+        for sensor in self.observations:
+            self.observations[sensor][s + 1].copy_(observations[sensor], non_blocking=True)
+        self.recurrent_hidden_states[s + 1].copy_(recurrent_hidden_states)
+        self.all_dialog[s].copy_(all_dialog)
+        self.query_state[s].copy_(query_state)
+        self.last_query_info[s].copy_(last_query_info)
+        self.agent_step[s].copy_(as_t(agent_step).view(-1))
+        if o_action is not None:
+            self.o_masks[s].copy_(as_t(o_mask).view(-1))
+            self.ucnt_gt[s].copy_(as_t(ucnt_gt).view(-1))
+            self.rl_masks[s].copy_(as_t(rl_masks).view(-1))
+            self.o_actions[s].copy_(as_t(o_action).view(-1))
+            self.action_probs[s].copy_(action_prob)
+        self.actions[s].copy_(actions)
+        if actions_option is not None:
+            self.actions_option[s].copy_(actions_option)
+        self.prev_actions[s + 1].copy_(actions)
+        self.action_log_probs[s].copy_(action_log_probs)
+        self.value_preds[s].copy_(value_preds)
+        self.rewards[s].copy_(rewards)
+        self.masks[s + 1].copy_(not_done_masks)
+        self.masks_vln[s + 1].copy_(not_done_masks_vln)
+        nd, ndv = self.masks[s + 1], self.masks_vln[s + 1]
+        if self.use_external_memory:
+            self.em.insert(em_features, nd, self.em_masks[s + 1])
+            self.em_option.insert(em_features_option, nd)
+            self.em_vln.insert(em_features_vln, ndv, self.em_vln_masks[s + 1])
+        if self.use_state_memory:
+            self.em_vln_dialog.insert(em_features_dialog, ndv)
+            if not self.use_external_memory:
+                self.em_vln_masks[s + 1].copy_(self.em_vln_dialog.masks)
+        self.step = s + 1
+
+    def after_update(self):
+        s = self.step
+        for sensor in self.observations:
+            self.observations[sensor][0].copy_(self.observations[sensor][s])
+        self.recurrent_hidden_states[0].copy_(self.recurrent_hidden_states[s])
+        for buf in (self.masks, self.masks_vln, self.prev_actions, self.em_masks, self.em_vln_masks):
+            buf[0].copy_(buf[s])
+        self.step = 0
+
+    # ---------------------------------------------------------------- GAE (rollout_storage.py:394-412)
+    def compute_returns(self, next_value, use_gae, gamma, tau):
+        if not use_gae:
+            raise NotImplementedError("avlen_amd implements the GAE branch (use_gae: True in every AVLEN yaml)")
+        nv = next_value.detach().float().contiguous()
+        L.call("avlen_gae_scan", P(self.rewards), P(self.value_preds), P(self.masks), P(nv), P(self.returns),
+               P(self.advantages), self.step, self.num_envs, float(gamma), float(tau), L.stream())
+
+    # ---------------------------------------------------------------- accessors used by the trainer
+    @property
+    def external_memory_goal(self):
+        return _CopyAxis(self.em)
+
+    @property
+    def external_memory_option(self):
+        return _CopyAxis(self.em_option)
+
+    @property
+    def external_memory_vln(self):
+        return _CopyAxis(self.em_vln)
+
+    @property
+    def external_memory_vln_dialog(self):
+        return _CopyAxis(self.em_vln_dialog)
+
+    @property
+    def external_memory_masks(self):
+        return self.em_masks
+
+    @property
+    def external_memory_vln_masks(self):
+        return self.em_vln_masks
+
+    # ---------------------------------------------------------------- minibatches
+    def _gather(self, src, env, T):
+        """src (T_alloc, N, ...) -> (T*n_mb, ...) rows ordered t-major, like _flatten_helper."""
+        n_mb = env.numel()
+        D = 1
+        for d in src.shape[2:]:
+            D *= d
+        dst = torch.empty((T * n_mb,) + tuple(src.shape[2:]), dtype=src.dtype, device=src.device)
+        L.call("avlen_minibatch_gather", P(src), P(dst), P(env), T, self.num_envs, n_mb, D, src.element_size(),
+               L.stream())
+        return dst
+
+    def gather_minibatch(self, env, advantages=None):
+        """The tensors PPO.update needs for the env subset `env` (int64, device), WITHOUT materialising the
+        (em_size, T*n_mb, dim) memory: rows index the ring through `mem_index`."""
+        T = self.step
+        g = lambda x: self._gather(x, env, T)
+        adv = self.advantages if advantages is None else advantages
+        n_mb = env.numel()
+        mem_index = env.to(torch.int32).repeat(T).contiguous()            # row t*n_mb+j reads ring column env[j]
+        return {
+            "obs": {k: g(v) for k, v in self.observations.items()},
+            "actions_option": g(self.actions_option), "prev_actions": g(self.prev_actions),
+            "value_preds": g(self.value_preds), "returns": g(self.returns), "masks": g(self.masks),
+            "old_log_probs": g(self.action_log_probs), "adv": g(adv), "rl_masks": g(self.rl_masks),
+            "ucnt_gt": g(self.ucnt_gt), "em_masks": g(self.em_masks), "query_state": g(self.query_state),
+            "last_query_info": g(self.last_query_info), "mem_index": mem_index, "T": T, "n_mb": n_mb,
+        }
+
+    def recurrent_generator(self, advantages, num_mini_batch):
+        """API-compatible generator (rollout_storage.py:591-810): yields the reference's 22-tuple, including the
+        materialised (em_size, T*n_mb, dim) memories."""
+        N = self.rewards.size(1)
+        assert N >= num_mini_batch, (
+            "Trainer requires the number of processes ({}) to be greater than or equal to the number of "
+            "trainer mini batches ({}).".format(N, num_mini_batch))
+        per = N // num_mini_batch
+        perm = torch.randperm(N)
+        T = self.step
+        for start in range(0, N, per):
+            env = perm[start:start + per].to(self.device)
+            n_mb = env.numel()
+            g = lambda x: self._gather(x, env, T)
+            obs = defaultdict(list)
+            for k, v in self.observations.items():
+                obs[k] = g(v)
+            rec = self.recurrent_hidden_states[0][:, env]
+            mem = lambda em: (em.memory[:, env].unsqueeze(1).expand(-1, T, -1, -1).reshape(em.total_size, T * n_mb, em.dim)
+                              if em is not None else None)
+            yield (obs, rec, g(self.actions), g(self.actions_option), g(self.prev_actions), g(self.value_preds),
+                   g(self.returns), g(self.masks), g(self.action_log_probs), g(advantages), g(self.rl_masks),
+                   g(self.ucnt_gt), mem(self.em), mem(self.em_option), mem(self.em_vln), mem(self.em_vln_dialog),
+                   g(self.em_masks), g(self.em_vln_masks), g(self.all_dialog), g(self.query_state),
+                   g(self.last_query_info), g(self.agent_step))

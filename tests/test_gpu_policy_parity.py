@@ -1,0 +1,345 @@
+"""The product (avlen_amd Policy / RolloutStorage / PPO on the HIP library) against
+ (1) golden vectors produced by the REFERENCE's own modules, and (2) the CPU oracle on the same inputs.
+fp32 mode: logits/values within 1e-3 (north_star tolerance), sampled actions bit-exact for fixed seeds.
+bf16 mode: tolerance stated per assertion."""
+import json
+import os
+import numpy as np
+import pytest
+import torch
+
+import fixtures as fx
+import restate as R
+import cycle as cyc
+from conftest import golden, GOLDEN, param_specs
+from avlen_amd import policy as P
+from avlen_amd.ppo import DDPPO
+from avlen_amd.rollout_storage import RolloutStorage
+from avlen_amd.spaces import savi_observation_space, ActionSpace, SMT_KW
+
+pytestmark = pytest.mark.gpu
+TOL = dict(rtol=1e-3, atol=1e-3)
+
+
+def cu(x):
+    if isinstance(x, dict):
+        return {k: v.cuda() for k, v in x.items()}
+    return x.cuda() if x is not None else None
+
+
+def build(kind, precision="fp32", **kw):
+    spec = kw.pop("spectrogram", (65, 26, 2))
+    osp, asp = savi_observation_space(spec), ActionSpace(4)
+    if kind == "option":
+        pol = P.AudioNavOptionPolicy(osp, asp, pretraining=kw.get("pretraining", False), precision=precision,
+                                     use_category_input=kw.get("distractor", False), query_count_emb_size=32, **SMT_KW)
+    elif kind == "goal":
+        pol = P.AudioNavSMTPolicy(osp, asp, pretraining=False, use_category_input=False, precision=precision, **SMT_KW)
+    elif kind == "dialog":
+        pol = P.AudioNavDialogPolicy(osp, asp, pretraining=False, use_category_input=False, num_steps=3,
+                                     precision=precision, **SMT_KW)
+    else:
+        pol = P.AudioNavBaselinePolicy(osp, asp, "spectrogram", hidden_size=512, precision=precision)
+    return pol
+
+
+def load_fixture(pol, spec_key, specs):
+    sd = fx.state_dict_for({k: tuple(v) for k, v in specs[spec_key].items()})
+    missing = pol.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys
+    return sd
+
+
+def close(a, b, **kw):
+    tol = dict(TOL); tol.update(kw)
+    np.testing.assert_allclose(a.detach().float().cpu().numpy() if torch.is_tensor(a) else a, b, **tol)
+
+
+@pytest.fixture(scope="module")
+def specs():
+    return param_specs()
+
+
+def test_encoders_match_reference(specs):
+    pol = build("option")
+    load_fixture(pol, "option", specs)
+    pol.cuda()
+    obs = cu(fx.observations("enc", 2))
+    feats, goal = pol.net.features(pol, obs, torch.zeros(2, 1, dtype=torch.long, device="cuda"),
+                                   extra=torch.zeros(2, 32, device="cuda"))
+    torch.cuda.synchronize()
+    close(feats[:, :128], golden("enc_visual")["out"])
+    close(feats[:, 144:272], golden("enc_audio_65")["out"])
+    pol2 = build("option", spectrogram=(257, 101, 2))
+    load_fixture(pol2, "option_257", specs)
+    pol2.cuda()
+    obs2 = cu(fx.observations("enc", 2, (257, 101)))
+    f2, _ = pol2.net.features(pol2, obs2, torch.zeros(2, 1, dtype=torch.long, device="cuda"),
+                              extra=torch.zeros(2, 32, device="cuda"))
+    close(f2[:, 144:272], golden("enc_audio_257")["out"])
+
+
+@pytest.mark.parametrize("pre", [True, False])
+@pytest.mark.parametrize("M", [4, 300])
+def test_option_policy_matches_reference(specs, pre, M):
+    B = 3
+    pol = build("option", pretraining=pre)
+    load_fixture(pol, "option", specs)
+    pol.cuda()
+    tag = f"opt_p{int(pre)}_m{M}"
+    g = golden("policy_" + tag)
+    obs = cu(fx.observations(tag, B))
+    mem, mk = fx.memory(tag, M, B, 308, 272).cuda(), fx.mask_patterns(tag, B, M).cuda()
+    qs, lqi = fx.sym(tag + ".qs", (B, 32)).cuda(), fx.sym(tag + ".lqi", (B, 32)).cuda()
+    pa, act = fx.ints(tag + ".pa", (B, 1), 4).cuda(), fx.ints(tag + ".a", (B, 1), 2).cuda()
+    h0, ones = torch.zeros(1, B, 512, device="cuda"), torch.ones(B, 1, device="cuda")
+    v, u, lp, ent, _, row, probs = pol.evaluate_actions_option(obs, h0, pa, ones, act, mem, mk, qs, lqi)
+    close(v, g["value"]); close(u, g["unct"]); close(lp, g["log_prob"]); close(ent, g["entropy"])
+    close(probs, g["probs"]); close(row, g["row"])
+    torch.manual_seed(1234)
+    v2, u2, a2, lp2, _, row2, probs2 = pol.act_option(obs, h0, pa, ones, mem, mk, qs, lqi)
+    assert np.array_equal(a2.cpu().numpy(), g["sampled"])            # bit-exact sampling for the fixed seed
+    close(lp2, g["sampled_log_prob"])
+    det = pol.act_option(obs, h0, pa, ones, mem, mk, qs, lqi, deterministic=True)[2]
+    assert np.array_equal(det.cpu().numpy(), g["mode"])
+    close(pol.get_value_option(obs, h0, pa, ones, mem, mk, qs, lqi), g["get_value"])
+
+
+def test_option_policy_bf16_tolerance(specs):
+    """bf16 operands (fp32 accumulate): report and bound the deviation from the fp32 reference."""
+    B, M, pre = 3, 300, False
+    pol = build("option", precision="bf16", pretraining=pre)
+    load_fixture(pol, "option", specs)
+    pol.cuda()
+    tag = f"opt_p{int(pre)}_m{M}"
+    g = golden("policy_" + tag)
+    obs = cu(fx.observations(tag, B))
+    mem, mk = fx.memory(tag, M, B, 308, 272).cuda(), fx.mask_patterns(tag, B, M).cuda()
+    qs, lqi = fx.sym(tag + ".qs", (B, 32)).cuda(), fx.sym(tag + ".lqi", (B, 32)).cuda()
+    pa, act = fx.ints(tag + ".pa", (B, 1), 4).cuda(), fx.ints(tag + ".a", (B, 1), 2).cuda()
+    v, u, lp, ent, _, row, probs = pol.evaluate_actions_option(obs, torch.zeros(1, B, 512, device="cuda"), pa,
+                                                               torch.ones(B, 1, device="cuda"), act, mem, mk, qs, lqi)
+    err_v = float(np.abs(v.cpu().numpy() - g["value"]).max())
+    err_p = float(np.abs(probs.cpu().numpy() - g["probs"]).max())
+    print(f"bf16 max |value err| = {err_v:.4g}, max |prob err| = {err_p:.4g}")
+    assert err_v < 5e-2 and err_p < 2e-2
+
+
+def test_option_distractor(specs):
+    B, M = 3, 6
+    pol = build("option", distractor=True)
+    load_fixture(pol, "option_distractor", specs)
+    pol.cuda()
+    tag = "opt_dis"
+    g = golden("policy_" + tag)
+    obs = cu(fx.observations(tag, B))
+    mem, mk = fx.memory(tag, M, B, 329, 293).cuda(), fx.mask_patterns(tag, B, M).cuda()
+    qs, lqi = fx.sym(tag + ".qs", (B, 32)).cuda(), fx.sym(tag + ".lqi", (B, 32)).cuda()
+    pa, act = fx.ints(tag + ".pa", (B, 1), 4).cuda(), fx.ints(tag + ".a", (B, 1), 2).cuda()
+    v, u, lp, ent, _, row, probs = pol.evaluate_actions_option(obs, torch.zeros(1, B, 512, device="cuda"), pa,
+                                                               torch.ones(B, 1, device="cuda"), act, mem, mk, qs, lqi)
+    close(v, g["value"]); close(probs, g["probs"]); close(row, g["row"]); close(lp, g["log_prob"]); close(u, g["unct"])
+
+
+@pytest.mark.parametrize("M", [4, 300])
+def test_goal_policy_matches_reference(specs, M):
+    B = 3
+    pol = build("goal")
+    load_fixture(pol, "goal", specs)
+    pol.cuda()
+    tag = f"goal_m{M}"
+    g = golden("policy_" + tag)
+    obs = cu(fx.observations(tag, B))
+    mem, mk = fx.memory(tag, M, B, 276, 272).cuda(), fx.mask_patterns(tag, B, M).cuda()
+    pa, act = fx.ints(tag + ".pa", (B, 1), 4).cuda(), fx.ints(tag + ".a", (B, 1), 4).cuda()
+    h0, ones = torch.zeros(1, B, 512, device="cuda"), torch.ones(B, 1, device="cuda")
+    v, lp, ent, _, row = pol.evaluate_actions(obs, h0, pa, ones, act, mem, mk)
+    close(v, g["value"]); close(lp, g["log_prob"]); close(ent, g["entropy"]); close(row, g["row"])
+    torch.manual_seed(77)
+    v2, a2, lp2, _, row2, probs = pol.act(obs, h0, pa, ones, mem, mk)
+    close(probs, g["probs"])
+    assert np.array_equal(a2.cpu().numpy(), g["sampled"])
+
+
+@pytest.mark.parametrize("with_dialog", [True, False])
+def test_dialog_policy_matches_reference(specs, with_dialog):
+    """pi_l with the CLIP tower replaced by the same stub embedding the reference golden used."""
+    B, M = 3, 3
+    pol = build("dialog")
+    load_fixture(pol, "dialog", specs)
+    pol.cuda()
+    pol.net.text_encoder_override = lambda t: fx.stub_text_embedding(t.cpu()).cuda()
+    tag = "dlg"
+    g = golden("policy_dlg" if with_dialog else "policy_dlg_nodialog")
+    obs = cu(fx.observations(tag, B))
+    mem, memd = fx.memory(tag, M, B, 276, 272).cuda(), fx.sym(tag + ".memd", (M, B, 256)).cuda()
+    mk = fx.mask_patterns(tag, B, M).cuda()
+    pa, act = fx.ints(tag + ".pa", (B, 1), 4).cuda(), fx.ints(tag + ".a", (B, 1), 4).cuda()
+    toks = fx.dialog_tokens(tag, B).cuda()
+    astep = fx.ints(tag + ".as", (B,), 3).float().cuda()
+    h0, ones = torch.zeros(1, B, 512, device="cuda"), torch.ones(B, 1, device="cuda")
+    _, lp, ent, _, row, xd, logits = pol.evaluate_actions_dialog(obs, h0, pa, ones, act, mem, memd, mk, toks, astep,
+                                                                 without_dialog=not with_dialog)
+    close(xd, g["xd"]); close(row, g["row"]); close(logits, g["logits"]); close(lp, g["log_prob"])
+    close(ent, g["entropy"])
+    torch.manual_seed(5)
+    v, a2, lp2, _, _, _, probs = pol.act_dialog(obs, h0, pa, ones, mem, memd, mk, toks, astep,
+                                                without_dialog=not with_dialog)
+    close(v, g["value"]); close(probs, g["probs"])
+    assert np.array_equal(a2.cpu().numpy(), g["sampled"])
+
+
+def test_clip_text_tower_vs_oracle():
+    """CLIP text encoder (parity unpinned against the reference: third-party, absent) vs the oracle's
+    restatement of CLIP's public definition, random weights, 2 layers' worth checked at full depth."""
+    torch.manual_seed(0)
+    pol = build("dialog")
+    sd = {k: v.clone() for k, v in pol.state_dict().items() if k.startswith("net.clip.")}
+    for k in sd:                                 # non-trivial norms / biases
+        if k.endswith("bias"):
+            sd[k] = torch.randn_like(sd[k]) * 0.02
+    pol.load_state_dict(sd, strict=False)
+    toks = fx.dialog_tokens("clip", 3)
+    ref = R.clip_encode_text({k: v for k, v in sd.items()}, "net.clip", toks)
+    pol.cuda()
+    out = pol.net.encode_text(pol, toks.cuda())
+    close(out, ref.numpy(), rtol=2e-3, atol=2e-3)
+
+
+def test_baseline_policy_matches_reference(specs):
+    pol = build("baseline")
+    load_fixture(pol, "baseline", specs)
+    pol.cuda()
+    g = golden("policy_base")
+    N, T = 3, 5
+    obs = cu(fx.observations("base", N))
+    h0 = fx.sym("base.h0", (1, N, 512), 0.5).cuda()
+    m1 = torch.tensor([[1.0], [0.0], [1.0]]).cuda()
+    torch.manual_seed(9)
+    v, a, lp, h1, _, probs = pol.act(obs, h0, None, m1, None, None)
+    close(v, g["value"]); close(probs, g["probs"]); close(h1, g["hidden"])
+    assert np.array_equal(a.cpu().numpy(), g["sampled"])
+    obs_seq = cu(fx.observations("base.seq", T * N))
+    ms = torch.from_numpy((fx.unit("base.m", T * N) >= 0.3).astype("float32")).view(T * N, 1).cuda()
+    act = fx.ints("base.a", (T * N, 1), 4).cuda()
+    v2, lp2, ent2, h2, _ = pol.evaluate_actions(obs_seq, h0, None, ms, act, None, None)
+    close(v2, g["seq_value"]); close(lp2, g["seq_log_prob"]); close(ent2, g["seq_entropy"]); close(h2, g["seq_hidden"])
+
+
+@pytest.mark.parametrize("pre", [True, False])
+def test_full_cycle_matches_reference(specs, pre):
+    """T rollout steps -> insert -> get_value -> GAE -> PPO.update (2 epochs x 2 minibatches): sampled
+    actions, returns, the 6-tuple and the post-step parameters vs the reference's PPO/RolloutStorage."""
+    g = golden(f"cycle_p{int(pre)}")
+    keys = json.load(open(os.path.join(GOLDEN, f"cycle_p{int(pre)}_keys.json")))
+    T, N, EMS, EMC = 6, 4, 12, 6
+    pol = build("option", pretraining=pre)
+    load_fixture(pol, "option", specs)
+    pol.cuda()
+    agent = DDPPO(pol, 0.2, 2, 2, 0.5, 0.05, lr=2.5e-4, eps=1e-5, max_grad_norm=0.2, use_normalized_advantage=False)
+    st = RolloutStorage(T, N, savi_observation_space(), ActionSpace(4), 512, True, EMS, EMC, EMS, EMC, 3, 3, 276, 276,
+                        308, 256, num_recurrent_layers=-1, max_dialog_len=77, use_state_memory=True, device="cuda")
+    o0 = cyc.first_obs(N)
+    for k in st.observations:
+        st.observations[k][0].copy_(o0[k])
+    torch.manual_seed(2024)
+    for t in range(T):
+        si = cyc.step_inputs(t, N)
+        st.query_state[st.step].copy_(si["query_state"])
+        st.last_query_info[st.step].copy_(si["last_query_info"])
+        so = {k: v[st.step] for k, v in st.observations.items()}
+        v, u, ao, lp, h, row, probs = pol.act_option(
+            so, st.recurrent_hidden_states[st.step], st.prev_actions[st.step], st.masks[st.step],
+            st.external_memory_option[:, st.step].contiguous(), st.external_memory_masks[st.step],
+            st.query_state[st.step], st.last_query_info[st.step])
+        close(v, g["value"][t]); close(probs, g["probs"][t])
+        assert np.array_equal(ao.cpu().numpy(), g["action_option"][t])
+        z = torch.zeros
+        st.insert(cu(si["next_obs"]), h, si["actions"].cuda(), ao, lp, v, si["rewards"].cuda(), si["not_done"].cuda(),
+                  si["not_done"].cuda(), row[:, :276].contiguous(), row, row[:, :276].contiguous(),
+                  z(N, 256, device="cuda"), z(N, 77, dtype=torch.long, device="cuda"), z(N), torch.ones(N, dtype=torch.long),
+                  si["rl_masks"], si["ucnt_gt"], z(N, 4, device="cuda"), si["query_state"].cuda(),
+                  si["last_query_info"].cuda(), si["agent_step"])
+    lo = {k: v[-1] for k, v in st.observations.items()}
+    nv = pol.get_value_option(lo, st.recurrent_hidden_states[st.step], st.prev_actions[st.step], st.masks[st.step],
+                              st.external_memory_option[:, st.step].contiguous(), st.external_memory_masks[st.step],
+                              st.query_state[st.step - 1], st.last_query_info[st.step - 1])
+    close(nv, g["next_value"])
+    st.compute_returns(nv, True, 0.99, 0.95)
+    close(st.returns[:T], g["returns"][:T])
+    out = agent.update(st)
+    st.after_update()
+    torch.cuda.synchronize()
+    assert np.array_equal(st.em_masks.cpu().numpy(), g["em_masks"])
+    np.testing.assert_allclose(np.array(out), g["update"], rtol=2e-3, atol=2e-4)
+    sd = {k: v.detach().cpu() for k, v in pol.state_dict().items()}
+    pabs = np.array([float(sd[k].double().abs().sum()) for k in keys])
+    np.testing.assert_allclose(pabs, g["param_abs"], rtol=2e-5)
+    close(sd["net.smt_state_encoder.fusion_encoder.2.weight"][:4, :8], g["fusion2_w"], rtol=2e-3, atol=2e-5)
+    close(sd["critic_option.fc.weight"], g["critic_w"], rtol=2e-3, atol=2e-5)
+    # the update moved the trained parameters by ~lr per step: compare the DELTAS with the reference's
+    sd0 = fx.state_dict_for({k: tuple(v) for k, v in specs["option"].items()})
+    for name, gold in (("net.smt_state_encoder.fusion_encoder.2.weight", g["fusion2_w"]),):
+        d_ours = (sd[name][:4, :8] - sd0[name][:4, :8]).numpy()
+        d_ref = gold - sd0[name][:4, :8].numpy()
+        np.testing.assert_allclose(d_ours, d_ref, rtol=5e-2, atol=2e-5)
+
+
+def test_gradients_match_oracle_autograd(specs):
+    """Full-memory (pretraining=False) gradient of the PPO loss w.r.t. every trained parameter: HIP backward
+    (heads + transformer incl. masked attention + fusion MLP + pose encoder) vs torch autograd on the oracle."""
+    import flow
+    B, M = 6, 9
+    pre = False
+    pol = build("option", pretraining=pre)
+    sd = load_fixture(pol, "option", specs)
+    pol.cuda()
+    tag = "grad"
+    obs = fx.observations(tag, B)
+    mem, mk = fx.memory(tag, M, B, 308, 272), fx.mask_patterns(tag, B, M)
+    qs, lqi = fx.sym(tag + ".qs", (B, 32)), fx.sym(tag + ".lqi", (B, 32))
+    pa, act = fx.ints(tag + ".pa", (B, 1), 4), fx.ints(tag + ".a", (B, 1), 2)
+    old_lp, adv = -0.7 + fx.sym(tag + ".olp", (B, 1), 0.2), fx.sym(tag + ".adv", (B, 1), 1.0)
+    rl = torch.tensor([1, 0, 1, 1, 1, 0]); ug = fx.ints(tag + ".ug", (B,), 2)
+    vp, ret = fx.sym(tag + ".vp", (B, 1), 1.0), fx.sym(tag + ".ret", (B, 1), 1.0)
+    # oracle
+    osd = {k: v.clone() for k, v in sd.items()}
+    tr = [k for k in osd if k.startswith(flow.TRAINED_PREFIXES)]
+    for k in tr:
+        osd[k].requires_grad_(True)
+    feats, _ = R.option_net(osd, obs, pa, mem, mk, qs, lqi, pretraining=pre)
+    h = R.heads(osd, "option", feats, action=act)
+    vl, al, ul, _, _ = R.ppo_losses(h["value"], h["unct"], h["log_prob"], h["entropy"], old_lp, adv, rl, vp, ret, ug)
+    R.total_loss(vl, al, h["entropy"], ul).backward()
+    # product
+    import ctypes as C
+    from avlen_amd import _lib as L, engine as E
+    agent = DDPPO(pol, 0.2, 1, 1, 0.5, 0.05, lr=2.5e-4, eps=1e-5, max_grad_norm=0.2, use_normalized_advantage=False)
+    eng = pol._engine()
+    flat = eng["flat"]
+    smt_g, heads_g = agent._grad_views(eng)
+    flat.grad.zero_()
+    x_att, _, _ = pol.net.run(pol, cu(obs), None, pa.cuda(), None, mem.cuda(), mk.cuda(), qs.cuda(), lqi.cuda(),
+                              save_key="smt_train")
+    _, goal, (ws, nb, Bq, Mq, F, cto) = pol.net._last
+    norm, d_feats, loss = torch.empty(2, device="cuda"), torch.empty(B, 256, device="cuda"), torch.zeros(6, device="cuda")
+    tens = [t.cuda().contiguous() for t in (act, old_lp, adv, rl, vp, ret, ug)]
+    L.call("avlen_rl_mask_norm", E.P(tens[3]), B, E.P(norm), L.stream())
+    hv = pol._heads("option")
+    L.call("avlen_ppo_loss_heads_bwd", C.byref(hv), C.byref(heads_g), E.P(x_att), 256, 2, E.P(tens[0]), E.P(tens[1]),
+           E.P(tens[2]), E.P(tens[3]), E.P(tens[4]), E.P(tens[5]), E.P(tens[6]), E.P(norm), 0.2, 0.5, 0.05, 0.5,
+           E.P(loss), E.P(d_feats), B, L.stream())
+    L.call("avlen_smt_bwd", C.byref(eng["smt"]), C.byref(smt_g), E.P(goal), E.P(d_feats), Bq, Mq, F, 272, cto, pol.prec,
+           E.P(ws), nb, L.stream())
+    torch.cuda.synchronize()
+    lossv = loss.cpu().numpy()
+    np.testing.assert_allclose(lossv[[0, 1, 2, 5]], [float(vl), float(al), float(h["entropy"]), float(ul)], rtol=1e-3,
+                               atol=1e-5)
+    worst = 0.0
+    for k in tr:
+        ours = flat.grad_view(k, osd[k].shape).cpu().double()
+        ref = osd[k].grad.double()
+        err = float((ours - ref).abs().max() / (ref.abs().max() + 1e-8))
+        worst = max(worst, err)
+        assert err < 2e-3, (k, err)
+    print("max relative gradient error over trained params:", worst)
