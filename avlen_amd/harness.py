@@ -1,0 +1,137 @@
+"""Synthetic-observation driver that reproduces the reference trainer's call pattern on the hot path
+(ss_baselines/savi/ppo/ppo_trainer.py:323-897 `_collect_rollout_step`, :1045-1093 `_update_agent`) without
+the simulator: pi_q.act_option -> pi_g.act -> pi_l.act_dialog -> RolloutStorage.insert per step, then
+get_value_option -> compute_returns (GAE) -> DDPPO.update -> after_update per cycle.
+
+Used by bench.py and __graft_entry__.smoke().  Observations follow SURVEY.md §8(d): 128x128 RGB-D,
+binaural spectrogram, pose, beliefs, 77-token dialog; everything is generated once and is resident in
+HBM before timing starts ("simulator output").
+"""
+import math
+import torch
+
+from . import policy as P
+from .ppo import DDPPO
+from .rollout_storage import RolloutStorage
+from .spaces import savi_observation_space, ActionSpace, SMT_KW
+
+
+def sinusoid_table(n, d):
+    pos = torch.arange(n).unsqueeze(1)
+    div = torch.exp(torch.arange(0, d, 2) * (-math.log(10000.0) / d))
+    pe = torch.zeros(n, d)
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    return pe
+
+
+class Workload:
+    def __init__(self, num_envs, num_steps=150, spectrogram=(257, 101, 2), precision="bf16", pretraining=True,
+                 em_capacity=150, ppo_epoch=2, num_mini_batch=2, device="cuda", seed=0, sampling="host",
+                 with_dialog_policy=True, with_goal_policy=True):
+        self.N, self.T, self.dev = num_envs, num_steps, torch.device(device)
+        self.spec = spectrogram
+        osp, asp = savi_observation_space(spectrogram), ActionSpace(4)
+        torch.manual_seed(seed)
+        kw = dict(SMT_KW, precision=precision, sampling=sampling)
+        self.pi_q = P.AudioNavOptionPolicy(osp, asp, pretraining=pretraining, use_category_input=False,
+                                           query_count_emb_size=32, **kw).to(self.dev)
+        self.pi_g = (P.AudioNavSMTPolicy(osp, asp, pretraining=False, use_category_input=False, **kw).to(self.dev)
+                     if with_goal_policy else None)
+        self.pi_l = (P.AudioNavDialogPolicy(osp, asp, pretraining=False, use_category_input=False, num_steps=3,
+                                            **kw).to(self.dev) if with_dialog_policy else None)
+        self.agent = DDPPO(self.pi_q, clip_param=0.2, ppo_epoch=ppo_epoch, num_mini_batch=num_mini_batch,
+                           value_loss_coef=0.5, entropy_coef=0.05, lr=2.5e-4, eps=1e-5, max_grad_norm=0.2,
+                           use_normalized_advantage=False)
+        self.agent.init_distributed(find_unused_params=True)
+        T, N = self.T, self.N
+        ems = em_capacity + T                       # ddppo_trainer.py:649-669: size = capacity + num_steps
+        self.rollouts = RolloutStorage(T, N, osp, asp, 512, True, ems, em_capacity, ems, em_capacity, 3, 3, 276, 276,
+                                       308, 256, num_recurrent_layers=-1, max_dialog_len=77, use_state_memory=True,
+                                       device=self.dev)
+        self._make_simulator_output(seed)
+
+    # -- what the CPU simulator + trainer bookkeeping would have produced, resident in HBM ------------------
+    def _make_simulator_output(self, seed):
+        T, N, dev = self.T, self.N, self.dev
+        g = torch.Generator(device="cpu").manual_seed(1000 + seed)
+        H, W, _ = self.spec
+        r = lambda *s: torch.rand(*s, generator=g)
+        self.sim = {
+            "rgb": torch.randint(0, 256, (T + 1, N, 128, 128, 3), generator=g, dtype=torch.uint8).to(dev).float(),
+            "depth": r(T + 1, N, 128, 128, 1).to(dev),
+            "spectrogram": torch.log1p(3.0 * torch.randn(T + 1, N, H, W, 2, generator=g).abs()).to(dev),
+            "category": torch.nn.functional.one_hot(torch.randint(0, 21, (T + 1, N), generator=g), 21).float().to(dev),
+            "category_belief": torch.softmax(torch.randn(T + 1, N, 21, generator=g), -1).to(dev),
+            "location_belief": (3.0 * torch.randn(T + 1, N, 2, generator=g)).to(dev),
+        }
+        pose = torch.stack([r(T + 1, N) * 20 - 10, r(T + 1, N) * 20 - 10, r(T + 1, N) * 2 * math.pi - math.pi,
+                            torch.arange(T + 1).float().view(-1, 1).expand(-1, N)], -1)
+        self.sim["pose"] = pose.to(dev)
+        self.rewards = torch.randn(T, N, 1, generator=g).to(dev)
+        self.not_done = (r(T, N, 1) >= 1.0 / 150).float().to(dev)
+        pe = sinusoid_table(1000, 32)
+        self.query_state = pe[torch.randint(0, 4, (T, N), generator=g)].to(dev)
+        self.last_query_info = pe[torch.randint(0, 150, (T, N), generator=g)].to(dev)
+        self.agent_step = torch.randint(0, 3, (T, N), generator=g).float().to(dev)
+        toks = torch.zeros(T, N, 77, dtype=torch.long)
+        ln = torch.randint(2, 73, (T, N), generator=g)
+        body = torch.randint(1, 49406, (T, N, 77), generator=g)
+        ar = torch.arange(77).view(1, 1, 77)
+        toks = torch.where(ar < ln.unsqueeze(-1), body, toks)
+        toks[..., 0] = 49406
+        toks.scatter_(-1, ln.unsqueeze(-1), 49407)
+        self.dialog = toks.to(dev)
+        self.rl_masks = (r(T, N) < 0.7).long().to(dev)
+        self.rl_masks[:, 0] = 1
+        self.ucnt_gt = torch.randint(0, 2, (T, N), generator=g).to(dev)
+        self.o_action = torch.zeros(N, device=dev)
+        self.o_mask = torch.ones(N, dtype=torch.long, device=dev)
+        self.zero_dialog_feats = torch.zeros(N, 256, device=dev)
+        for k in self.rollouts.observations:
+            self.rollouts.observations[k][0].copy_(self.sim[k][0])
+
+    # -- one rollout step (ppo_trainer.py:375-391, 449, 608-636, 864-888) -----------------------------------
+    def rollout_step(self):
+        ro, t = self.rollouts, self.rollouts.step
+        obs = {k: v[t] for k, v in ro.observations.items()}
+        ro.query_state[t].copy_(self.query_state[t])
+        ro.last_query_info[t].copy_(self.last_query_info[t])
+        h = ro.recurrent_hidden_states[t]
+        em_masks = ro.external_memory_masks[t]
+        values, unct, a_opt, lp_opt, h, row_opt, probs_opt = self.pi_q.act_option(
+            obs, h, ro.prev_actions[t], ro.masks[t], ro.external_memory_option[:, t], em_masks, ro.query_state[t],
+            ro.last_query_info[t])
+        actions, row_goal, row_vln, row_dlg, probs_vln = a_opt, row_opt[:, :276], row_opt[:, :276], self.zero_dialog_feats, None
+        if self.pi_g is not None:
+            _, a_goal, _, _, row_goal, _ = self.pi_g.act(obs, h, ro.prev_actions[t], ro.masks[t],
+                                                           ro.external_memory_goal[:, t], em_masks)
+            actions = a_goal
+        if self.pi_l is not None:
+            _, a_vln, _, _, row_vln, row_dlg, probs_vln = self.pi_l.act_dialog(
+                obs, h, ro.prev_actions[t], ro.masks_vln[t], ro.external_memory_vln[:, t],
+                ro.external_memory_vln_dialog[:, t], ro.external_memory_vln_masks[t], self.dialog[t], self.agent_step[t])
+            actions = torch.where(a_opt == 1, a_vln, actions)           # queried envs follow pi_l
+        if probs_vln is None:
+            probs_vln = torch.zeros(self.N, 4, device=self.dev)
+        nxt = {k: self.sim[k][t + 1] for k in ro.observations}
+        ro.insert(nxt, h, actions, a_opt, lp_opt, values, self.rewards[t], self.not_done[t], self.not_done[t],
+                  row_goal, row_opt, row_vln, row_dlg, self.dialog[t], self.o_action, self.o_mask, self.rl_masks[t],
+                  self.ucnt_gt[t], probs_vln, self.query_state[t], self.last_query_info[t], self.agent_step[t])
+
+    # -- _update_agent (ppo_trainer.py:1045-1093) -------------------------------------------------------------
+    def update(self):
+        ro, s = self.rollouts, self.rollouts.step
+        last = {k: v[s] for k, v in ro.observations.items()}
+        nv = self.pi_q.get_value_option(last, ro.recurrent_hidden_states[s], ro.prev_actions[s], ro.masks[s],
+                                        ro.external_memory_option[:, s], ro.external_memory_masks[s],
+                                        ro.query_state[s - 1], ro.last_query_info[s - 1])
+        ro.compute_returns(nv, True, 0.99, 0.95)
+        out = self.agent.update(ro)
+        ro.after_update()
+        return out
+
+    def cycle(self, steps=None):
+        for _ in range(steps or self.T):
+            self.rollout_step()
+        return self.update()
