@@ -160,7 +160,7 @@ class OptionAgent:
                 for k in self.trained:
                     self.sd[k].requires_grad_(False)
                 for i, x in enumerate((vl, al, h["entropy"], vm, rm, ul)):
-                    acc[i] += float(x)
+                    acc[i] += float(x.detach())
         n = self.epochs * self.mb
         st.after_update()
         return acc[0] / n, acc[1] / n, acc[2] / n, acc[3], acc[4], acc[5] / n
@@ -168,3 +168,69 @@ class OptionAgent:
 
 def sinus_pe(n, d=32):
     return R.sinusoid_table(n, d)
+
+
+# --------------------------------------------------------------------------------------------------
+# CPU baseline for bench.py ("port"): the three-policy rollout + pi_q update, reference call order
+# --------------------------------------------------------------------------------------------------
+def clip_text_spec(width=512, layers=12, ctx=77, vocab=49408, out=512, prefix="net.clip."):
+    s = {prefix + "token_embedding.weight": (vocab, width), prefix + "positional_embedding": (ctx, width),
+         prefix + "ln_final.weight": (width,), prefix + "ln_final.bias": (width,),
+         prefix + "text_projection": (width, out)}
+    for i in range(layers):
+        b = f"{prefix}transformer.resblocks.{i}."
+        s.update({b + "attn.in_proj_weight": (3 * width, width), b + "attn.in_proj_bias": (3 * width,),
+                  b + "attn.out_proj.weight": (width, width), b + "attn.out_proj.bias": (width,),
+                  b + "ln_1.weight": (width,), b + "ln_1.bias": (width,), b + "ln_2.weight": (width,),
+                  b + "ln_2.bias": (width,), b + "mlp.c_fc.weight": (4 * width, width), b + "mlp.c_fc.bias": (4 * width,),
+                  b + "mlp.c_proj.weight": (width, 4 * width), b + "mlp.c_proj.bias": (width,)})
+    return s
+
+
+def cpu_baseline(specs, N=16, T=4, spectrogram=(257, 101), pretraining=True, em_size=300, threads=None):
+    """Time ONE bounded rollout(T steps, 3 policies incl. CLIP text) + pi_q update (2 epochs x 2 minibatches)
+    of the oracle on the host cores.  Returns (env_steps_per_second, seconds, threads)."""
+    import time
+    import fixtures as fx
+    if threads:
+        torch.set_num_threads(threads)
+    key = "option_257" if spectrogram[0] >= 30 and spectrogram[1] >= 30 else "option"
+    mk = lambda spec: fx.state_dict_for({k: tuple(v) for k, v in spec.items()})
+    sd_q = mk(specs[key])
+    # pi_g / pi_l share the encoder shapes of the chosen spectrogram size: swap in the audio FC shape
+    fcw = tuple(specs[key]["net.goal_encoder.cnn.6.weight"])
+    conv_keys = [k for k in specs[key] if k.startswith("net.goal_encoder.")]
+    def with_audio(base):
+        s = dict(base)
+        for k in conv_keys:
+            s[k] = specs[key][k]
+        return s
+    sd_g = mk(with_audio(specs["goal"]))
+    sl = with_audio(specs["dialog"])
+    sl.update(clip_text_spec())
+    sd_l = mk(sl)
+    agent = OptionAgent(sd_q, pretraining=pretraining)
+    obs0 = fx.observations("cpu.obs0", N, spectrogram)
+    st = Storage(T, N, obs0, em_size, em_size // 2)
+    pe = sinus_pe(1000)
+    toks = fx.dialog_tokens("cpu.tok", N)
+    zeros = torch.zeros
+    t0 = time.perf_counter()
+    for t in range(T):
+        so = {k: v[st.step] for k, v in st.obs.items()}
+        qs, lqi = pe[fx.ints(f"cpu.qc{t}", (N,), 4)], pe[fx.ints(f"cpu.lq{t}", (N,), 150)]
+        h, row = agent.act(so, st.prev_actions[st.step], st.em_option.memory, st.em_masks[st.step], qs, lqi)
+        with torch.no_grad():
+            fg, xg = R.smt_net(sd_g, so, st.prev_actions[st.step], st.em.memory, st.em_masks[st.step])
+            hg = R.heads(sd_g, "goal", fg)
+            fl, xl = R.dialog_net(sd_l, so, st.prev_actions[st.step], st.em_vln.memory, st.em_vln_dialog.memory,
+                                  st.em_vln_masks[st.step], toks, fx.ints(f"cpu.as{t}", (N,), 3).float())
+            hl = R.heads(sd_l, "vln", fl)
+        actions = torch.where(h["action"] == 1, hl["action"], hg["action"])
+        nd = torch.from_numpy((fx.unit(f"cpu.nd{t}", N) >= 1 / 150).astype("float32")).view(N, 1)
+        st.insert(fx.observations(f"cpu.obs{t + 1}", N, spectrogram, step=t + 1), actions, h["action"], h["log_prob"],
+                  h["value"], fx.sym(f"cpu.r{t}", (N, 1)), nd, nd, xg, row, xl, fl, toks,
+                  torch.ones(N, dtype=torch.long), fx.ints(f"cpu.ug{t}", (N,), 2), qs, lqi, zeros(N))
+    agent.update(st)
+    dt = time.perf_counter() - t0
+    return N * T / dt, dt, torch.get_num_threads()
