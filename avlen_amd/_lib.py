@@ -33,12 +33,12 @@ vp = C.c_void_p
 
 
 class Linear(C.Structure):
-    _fields_ = [("w", f32p), ("b", f32p), ("out_f", C.c_int), ("in_f", C.c_int)]
+    _fields_ = [("w", f32p), ("b", f32p), ("out_f", C.c_int), ("in_f", C.c_int), ("w16", vp), ("ld16", C.c_int)]
 
 
 class Conv(C.Structure):
     _fields_ = [("w", f32p), ("b", f32p), ("cin", C.c_int), ("cout", C.c_int), ("kh", C.c_int), ("kw", C.c_int),
-                ("stride", C.c_int), ("pad", C.c_int)]
+                ("stride", C.c_int), ("pad", C.c_int), ("w16", vp), ("cin16", C.c_int)]
 
 
 class Affine(C.Structure):
@@ -110,6 +110,12 @@ SIGNATURES = {
     "avlen_gemm_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "avlen_gemm_pick_splitk": (i32, [i32, i32, i32]),
     "avlen_conv2d_nhwc": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "avlen_gemm_bf16": (i32, [vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "avlen_gemm_bf16_workspace_bytes": (sz, [i32, i32]),
+    "avlen_conv2d_nhwc_bf16": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "avlen_cast_bf16": (i32, [vp, i32, vp, i32, C.c_long, i32, vp]),
+    "avlen_pack_conv_weight_bf16": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "avlen_pack_fc_after_flatten_bf16": (i32, [vp, vp, i32, i32, i32, vp]),
     "avlen_pack_conv_weight": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "avlen_pack_fc_after_flatten": (i32, [vp, vp, i32, i32, i32, vp]),
     "avlen_groupnorm_nhwc": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp]),
@@ -128,7 +134,7 @@ SIGNATURES = {
     "avlen_cnn3_workspace_bytes": (sz, [C.POINTER(Cnn3), i32, i32, i32]),
     "avlen_cnn3_fwd": (i32, [C.POINTER(Cnn3), vp, i32, i32, i32, vp, i32, i32, vp, sz, vp]),
     "avlen_smt_workspace_bytes": (sz, [C.POINTER(Smt), i32, i32, i32, i32]),
-    "avlen_smt_fwd": (i32, [C.POINTER(Smt), vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "avlen_smt_fwd": (i32, [C.POINTER(Smt), vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     "avlen_smt_bwd": (i32, [C.POINTER(Smt), C.POINTER(Smt), vp, vp, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     "avlen_dialog_workspace_bytes": (sz, [C.POINTER(Dialog), i32, i32]),
     "avlen_dialog_fwd": (i32, [C.POINTER(Dialog), vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, sz, vp]),

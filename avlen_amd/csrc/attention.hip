@@ -8,6 +8,7 @@
 // per 8 keys.  fp32 throughout (VALU): this is <20 % of the SMT block's FLOPs.
 #include "common.h"
 #include "../../include/avlen_hip.h"
+#include "internal.h"
 
 namespace {
 
@@ -16,9 +17,9 @@ constexpr int CH = 64;      // keys per LDS chunk (= wave width: lane j stages k
 template <int D>
 __global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ K,
                                                       int ldk, const float* __restrict__ V, int ldv,
-                                                      float* __restrict__ O, int ldo, const float* __restrict__ key_mask,
-                                                      float* __restrict__ lse, int H, int Sq, int Sk, int causal,
-                                                      float scale) {
+                                                      float* __restrict__ O, int ldo, __bf16* __restrict__ O16, int ldo16,
+                                                      const float* __restrict__ key_mask, float* __restrict__ lse, int H,
+                                                      int Sq, int Sk, int causal, float scale) {
   __shared__ __attribute__((aligned(16))) float ks[CH * D];
   __shared__ __attribute__((aligned(16))) float vs[CH * D];
   __shared__ int kidx[CH];
@@ -101,10 +102,17 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ 
   }
   if (qok) {
     float inv = l > 0.f ? 1.f / l : 0.f;
-    float4* op = reinterpret_cast<float4*>(O + ((long)b * Sq + i) * ldo + h * D);
+    if (O) {
+      float4* op = reinterpret_cast<float4*>(O + ((long)b * Sq + i) * ldo + h * D);
 #pragma unroll
-    for (int d4 = 0; d4 < D / 4; d4++)
-      op[d4] = make_float4(o[d4 * 4] * inv, o[d4 * 4 + 1] * inv, o[d4 * 4 + 2] * inv, o[d4 * 4 + 3] * inv);
+      for (int d4 = 0; d4 < D / 4; d4++)
+        op[d4] = make_float4(o[d4 * 4] * inv, o[d4 * 4 + 1] * inv, o[d4 * 4 + 2] * inv, o[d4 * 4 + 3] * inv);
+    }
+    if (O16) {
+      __bf16* oh = O16 + ((long)b * Sq + i) * ldo16 + h * D;
+#pragma unroll
+      for (int d = 0; d < D; d++) oh[d] = (__bf16)(o[d] * inv);
+    }
     if (lse) lse[((long)b * H + h) * Sq + i] = m + __logf(l);
   }
 }
@@ -233,17 +241,24 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(const float* __restric
 
 }  // namespace
 
+int avlen_attention_fwd16(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+                          void* O16, int ldo16, const float* key_mask, float* lse, int B, int H, int Sq, int Sk, int D,
+                          int causal, float scale, hipStream_t stream) {
+  if (B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0 || (ldq | ldk | ldv | ldo) % 4) return AVLEN_ERR_ARG;
+  dim3 grid(ceil_div(Sq, 64), H, B), block(64);
+  __bf16* oh = (__bf16*)O16;
+  if (D == 32)
+    hipLaunchKernelGGL((attn_fwd_kernel<32>), grid, block, 0, stream, Q, ldq, K, ldk, V, ldv, O, ldo, oh, ldo16, key_mask, lse, H, Sq, Sk, causal, scale);
+  else if (D == 64)
+    hipLaunchKernelGGL((attn_fwd_kernel<64>), grid, block, 0, stream, Q, ldq, K, ldk, V, ldv, O, ldo, oh, ldo16, key_mask, lse, H, Sq, Sk, causal, scale);
+  else return AVLEN_ERR_ARG;
+  return avlen_launch_status();
+}
+
 extern "C" int avlen_attention_fwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O,
                                    int ldo, const float* key_mask, float* lse, int B, int H, int Sq, int Sk, int D,
                                    int causal, float scale, hipStream_t stream) {
-  if (B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0 || (ldq | ldk | ldv | ldo) % 4) return AVLEN_ERR_ARG;
-  dim3 grid(ceil_div(Sq, 64), H, B), block(64);
-  if (D == 32)
-    hipLaunchKernelGGL((attn_fwd_kernel<32>), grid, block, 0, stream, Q, ldq, K, ldk, V, ldv, O, ldo, key_mask, lse, H, Sq, Sk, causal, scale);
-  else if (D == 64)
-    hipLaunchKernelGGL((attn_fwd_kernel<64>), grid, block, 0, stream, Q, ldq, K, ldk, V, ldv, O, ldo, key_mask, lse, H, Sq, Sk, causal, scale);
-  else return AVLEN_ERR_ARG;
-  return avlen_launch_status();
+  return avlen_attention_fwd16(Q, ldq, K, ldk, V, ldv, O, ldo, nullptr, 0, key_mask, lse, B, H, Sq, Sk, D, causal, scale, stream);
 }
 
 extern "C" int avlen_attention_bwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,

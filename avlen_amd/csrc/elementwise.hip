@@ -1,8 +1,30 @@
 // Small HBM-bound kernels: sensor preprocessing, feature-column assembly, weight packing, row copies.
 #include "common.h"
 #include "../../include/avlen_hip.h"
+#include "internal.h"
 
 namespace {
+
+// (B,S,S,C) fp32 -> (x/div, kxk mean) -> (B,64,64,8) bf16, channels >= C zero.  One thread per output pixel.
+__global__ void preprocess_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ y, int B, int S, int C, int k, float div) {
+  long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= (long)B * 4096) return;
+  int ox = (int)(pix % 64), oy = (int)((pix / 64) % 64), b = (int)(pix / 4096);
+  const float* src = x + (((long)b * S + oy * k) * S + ox * k) * C;
+  typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8v;
+  bf16x8v o;
+#pragma unroll
+  for (int c = 0; c < 8; c++) {
+    float s = 0.f;
+    if (c < C) {
+      for (int dy = 0; dy < k; dy++)
+        for (int dx = 0; dx < k; dx++) s += src[((long)dy * S + dx) * C + c] / div;
+      s /= (float)(k * k);
+    }
+    o[c] = (__bf16)s;
+  }
+  *reinterpret_cast<bf16x8v*>(y + pix * 8) = o;
+}
 
 // (B,S,S,C) -> (B,64,64,C), y = scale * mean over k x k blocks (k = S/64).  One thread per output
 // pixel-channel; a wave reads k contiguous runs of k*C floats per output row => coalesced.
@@ -124,6 +146,13 @@ extern "C" int avlen_preprocess_image(const float* x, float* y, int B, int S, in
     hipLaunchKernelGGL(preprocess_kernel, grid1d(tot), dim3(256), 0, stream, x, y, B, S, C, S / 64, 1.0f);
   else
     hipLaunchKernelGGL(preprocess_exact_kernel, grid1d(tot), dim3(256), 0, stream, x, y, B, S, C, S / 64, divisor);
+  return avlen_launch_status();
+}
+
+int avlen_preprocess_image_bf16(const float* x, void* y16, int B, int S, int C, float divisor, hipStream_t stream) {
+  if (S % 64 || B <= 0 || C > 8) return AVLEN_ERR_ARG;
+  long tot = (long)B * 4096;
+  hipLaunchKernelGGL(preprocess_bf16_kernel, grid1d(tot), dim3(256), 0, stream, x, (__bf16*)y16, B, S, C, S / 64, divisor);
   return avlen_launch_status();
 }
 

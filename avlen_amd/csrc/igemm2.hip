@@ -1,0 +1,352 @@
+// bf16-in-HBM MFMA GEMM / implicit-GEMM convolution for gfx950 (the rollout "perf mode" kernel).
+//
+//   C[m, n] = epilogue( sum_k A(m, k) * W(n, k) ),   A, W bf16 (K contiguous), accumulate fp32
+//
+// What differs from igemm.hip (fp32 operands, register staging):
+//  * operands are already bf16 in HBM (producers emit bf16 copies), so tiles go HBM -> LDS with
+//    `global_load_lds_dwordx4` (16 B per lane, no VGPR round trip, no conversion, no ds_write);
+//  * BK = 64 (128-byte LDS rows), double-buffered LDS, ONE barrier per K-step: the loads of tile k+1 are in
+//    flight while tile k is multiplied;
+//  * the LDS image is lane-linear (a glds requirement), so the bank-conflict swizzle is applied to the per-lane
+//    SOURCE address and undone on the fragment read: 16-byte chunk c of row r is stored at chunk c ^ ((r>>1)&7);
+//  * wave tile 64x64 (BN=128: waves 2x2) -> 32 MFMA per 16 ds_read_b128 per K-step;
+//  * implicit-GEMM conv: the per-lane source address IS the gather (NHWC, Cin % 8 == 0, one 16-byte chunk = 8
+//    channels of one tap); padding taps and K/M tails read a 16-byte zero page;
+//  * small grids split K across blockIdx.z into fp32 slabs (deterministic reduce, no atomics).
+#include "common.h"
+#include "../../include/avlen_hip.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero_page[4] = {0, 0, 0, 0};
+
+namespace {
+
+constexpr int BK = 64;
+constexpr int NT = 256;
+
+struct G2 {
+  const bf16* A; const bf16* B; float* C32; bf16* C16; const float* bias; const float* residual;
+  int M, N, K;
+  int lda, ldb, ldc32, ldc16, ldr;
+  int act;
+  int conv, H, W, Cin, cin_log2, OH, OW, KH, KW, kw_magic, stride, pad;
+  int splitk, ksteps_per_split;
+  float* slab;
+  float* stats; int ohw;      // optional GroupNorm statistics: stats[sample][0|1][N] += sum / sum of squares of C
+};
+
+__device__ __forceinline__ float act2(float v, int act) {
+  if (act == 1) return fmaxf(v, 0.f);
+  if (act == 2) return v / (1.f + __expf(-1.702f * v));
+  return v;
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(NT) void g2_kernel(G2 p) {
+  constexpr int WTM = BM / WM, WTN = BN / WN;       // wave tile
+  constexpr int MI = WTM / 16, NI = WTN / 16;
+  constexpr int A_ROUNDS = BM * 8 / NT;              // 16-byte chunks per thread for the A tile
+  constexpr int B_SLOTS = BN * 8;
+  constexpr int B_ROUNDS = (B_SLOTS + NT - 1) / NT;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+  extern __shared__ __attribute__((aligned(16))) char lds[];       // [2][A_BYTES + B_BYTES]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n_tiles = (p.N + BN - 1) / BN;
+  const int m0 = (blockIdx.x / n_tiles) * BM, n0 = (blockIdx.x % n_tiles) * BN;
+  const int nk_total = (p.K + BK - 1) / BK;
+  const int kt_beg = blockIdx.z * p.ksteps_per_split;
+  const int kt_end = min(nk_total, kt_beg + p.ksteps_per_split);
+
+  // ---- per-thread source descriptors (fixed across K-steps) ----
+  const char* a_src[A_ROUNDS]; int a_iy0[A_ROUNDS], a_ix0[A_ROUNDS], a_sw[A_ROUNDS]; bool a_ok[A_ROUNDS];
+#pragma unroll
+  for (int r = 0; r < A_ROUNDS; r++) {
+    int slot = r * NT + tid, row = slot >> 3;
+    a_sw[r] = ((slot & 7) ^ ((row >> 1) & 7)) * 8;           // logical k offset (elements) of this lane's chunk
+    int m = m0 + row;
+    a_ok[r] = m < p.M;
+    if (p.conv) {
+      int ohw = p.OH * p.OW;
+      int mm = a_ok[r] ? m : 0;
+      int b = mm / ohw, rr = mm - b * ohw;
+      int oy = rr / p.OW, ox = rr - oy * p.OW;
+      a_src[r] = (const char*)(p.A + (long)b * p.H * p.W * p.Cin);
+      a_iy0[r] = oy * p.stride - p.pad; a_ix0[r] = ox * p.stride - p.pad;
+    } else {
+      a_src[r] = (const char*)(p.A + (long)min(m, p.M - 1) * p.lda);
+      a_iy0[r] = 0; a_ix0[r] = 0;
+    }
+  }
+  const char* b_src[B_ROUNDS]; int b_sw[B_ROUNDS];
+#pragma unroll
+  for (int r = 0; r < B_ROUNDS; r++) {
+    int slot = r * NT + tid, row = (slot >> 3) % BN;
+    b_sw[r] = ((slot & 7) ^ ((row >> 1) & 7)) * 8;
+    b_src[r] = (const char*)(p.B + (long)min(n0 + row, p.N - 1) * p.ldb);
+  }
+  const char* zero = (const char*)g_zero_page;
+
+  auto issue = [&](int kt, int buf) {
+    char* abase = lds + buf * (A_BYTES + B_BYTES);
+    char* bbase = abase + A_BYTES;
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int r = 0; r < A_ROUNDS; r++) {
+      int k = k0 + a_sw[r];
+      const char* src = zero;
+      if (p.conv) {
+        int tap = k >> p.cin_log2, ci = k & (p.Cin - 1);
+        int ky = (tap * p.kw_magic) >> 16, kx = tap - ky * p.KW;
+        int iy = a_iy0[r] + ky, ix = a_ix0[r] + kx;
+        if (a_ok[r] && k < p.K && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+          src = a_src[r] + (((long)iy * p.W + ix) * p.Cin + ci) * 2;
+      } else if (k < p.K) {
+        src = a_src[r] + (long)k * 2;
+      }
+      __builtin_amdgcn_global_load_lds((const void*)src,
+          (__attribute__((address_space(3))) void*)(abase + (r * NT + wave * 64) * 16), 16, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < B_ROUNDS; r++) {
+      if (B_SLOTS >= NT || (r * NT + wave * 64) < B_SLOTS) {      // wave-uniform
+        int k = k0 + b_sw[r];
+        const char* src = (k < p.K) ? b_src[r] + (long)k * 2 : zero;
+        __builtin_amdgcn_global_load_lds((const void*)src,
+            (__attribute__((address_space(3))) void*)(bbase + (r * NT + wave * 64) * 16), 16, 0, 0);
+      }
+    }
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; i++)
+#pragma unroll
+    for (int j = 0; j < NI; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int wm = wave / WN, wn = wave % WN;
+  const int r16 = lane & 15, q = lane >> 4;
+
+  if (kt_beg < kt_end) issue(kt_beg, 0);
+  for (int kt = kt_beg; kt < kt_end; kt++) {
+    const int buf = (kt - kt_beg) & 1;
+    __syncthreads();                 // s_waitcnt vmcnt(0): tile kt landed; everyone left buffer buf^1
+    if (kt + 1 < kt_end) issue(kt + 1, buf ^ 1);
+    const char* abase = lds + buf * (A_BYTES + B_BYTES);
+    const char* bbase = abase + A_BYTES;
+#pragma unroll
+    for (int kh = 0; kh < 2; kh++) {
+      bf16x8 af[MI], bfr[NI];
+      const int cc = kh * 4 + q;
+#pragma unroll
+      for (int i = 0; i < MI; i++) {
+        int row = wm * WTM + i * 16 + r16;
+        af[i] = *reinterpret_cast<const bf16x8*>(abase + row * 128 + ((cc ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < NI; j++) {
+        int row = wn * WTN + j * 16 + r16;
+        bfr[j] = *reinterpret_cast<const bf16x8*>(bbase + row * 128 + ((cc ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int j = 0; j < NI; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- fused GroupNorm statistics: per (sample, channel) sum and sum of squares of the raw conv output.
+  // A wave tile (WTM rows) never straddles two samples (ohw % WTM == 0, checked on the host); rows >= M are zero.
+  if (p.stats) {
+    const int sample = (m0 + wm * WTM) / p.ohw;
+    if (m0 + wm * WTM < p.M) {
+#pragma unroll
+      for (int j = 0; j < NI; j++) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; i++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) { float v = acc[i][j][r]; s1 += v; s2 += v * v; }
+        s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+        int col = n0 + wn * WTN + j * 16 + r16;
+        if (q == 0 && col < p.N) {
+          atomicAdd(&p.stats[((long)sample * 2) * p.N + col], s1);
+          atomicAdd(&p.stats[((long)sample * 2 + 1) * p.N + col], s2);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue ----
+#pragma unroll
+  for (int i = 0; i < MI; i++) {
+#pragma unroll
+    for (int j = 0; j < NI; j++) {
+      int col = n0 + wn * WTN + j * 16 + r16;
+      if (col >= p.N) continue;
+      float bv = (p.bias && p.splitk == 1) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        int row = m0 + wm * WTM + i * 16 + q * 4 + r;
+        if (row >= p.M) continue;
+        float v = acc[i][j][r];
+        if (p.splitk > 1) {
+          p.slab[((long)blockIdx.z * p.M + row) * p.N + col] = v;
+        } else {
+          v = act2(v + bv, p.act);
+          if (p.residual) v += p.residual[(long)row * p.ldr + col];
+          if (p.C32) p.C32[(long)row * p.ldc32 + col] = v;
+          if (p.C16) p.C16[(long)row * p.ldc16 + col] = (bf16)v;
+        }
+      }
+    }
+  }
+}
+
+__global__ void g2_reduce_kernel(const float* __restrict__ slab, float* __restrict__ C32, bf16* __restrict__ C16,
+                                 const float* __restrict__ bias, const float* __restrict__ residual, int M, int N,
+                                 int ldc32, int ldc16, int ldr, int splits, int act) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long tot = (long)M * N;
+  if (i >= tot) return;
+  int row = (int)(i / N), col = (int)(i - (long)row * N);
+  float s = 0.f;
+  for (int z = 0; z < splits; z++) s += slab[(long)z * tot + i];
+  if (bias) s += bias[col];
+  s = act2(s, act);
+  if (residual) s += residual[(long)row * ldr + col];
+  if (C32) C32[(long)row * ldc32 + col] = s;
+  if (C16) C16[(long)row * ldc16 + col] = (bf16)s;
+}
+
+// fp32 -> bf16 with row padding (pad columns zero-filled)
+__global__ void cast_rows_kernel(const float* __restrict__ src, int lds_, bf16* __restrict__ dst, int ldd, long rows, int cols) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * ldd) return;
+  long r = i / ldd; int c = (int)(i - r * ldd);
+  dst[i] = c < cols ? (bf16)src[r * lds_ + c] : (bf16)0.f;
+}
+
+// OIHW fp32 -> [O][KH][KW][Cp] bf16 (channels zero-padded to Cp)
+__global__ void pack_conv_bf16_kernel(const float* __restrict__ w, bf16* __restrict__ o, int O, int I, int KH, int KW, int Cp) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long tot = (long)O * KH * KW * Cp;
+  if (idx >= tot) return;
+  int ci = (int)(idx % Cp); long r = idx / Cp;
+  int kx = (int)(r % KW); r /= KW;
+  int ky = (int)(r % KH); int oc = (int)(r / KH);
+  o[idx] = ci < I ? (bf16)w[(((long)oc * I + ci) * KH + ky) * KW + kx] : (bf16)0.f;
+}
+// (O, C*HW) fp32 (NCHW flatten) -> (O, HW*C) bf16 (NHWC flatten)
+__global__ void pack_fc_bf16_kernel(const float* __restrict__ w, bf16* __restrict__ o, int O, int C, int HW) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long tot = (long)O * C * HW;
+  if (idx >= tot) return;
+  int c = (int)(idx % C); long r = idx / C; int pp = (int)(r % HW); int oc = (int)(r / HW);
+  o[idx] = (bf16)w[((long)oc * C + c) * HW + pp];
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch(const G2& p, int m_tiles, int n_tiles, hipStream_t st) {
+  size_t lds = 2 * (size_t)(BM * 128 + BN * 128);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&g2_kernel<BM, BN, WM, WN>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((g2_kernel<BM, BN, WM, WN>), dim3(m_tiles * n_tiles, 1, p.splitk), dim3(NT), lds, st, p);
+  return avlen_launch_status();
+}
+
+int run_g2(G2 p, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K & 7) || (p.lda & 7) || (p.ldb & 7)) return AVLEN_ERR_ARG;
+  int bn = p.N <= 16 ? 16 : p.N <= 32 ? 32 : p.N <= 64 ? 64 : 128;
+  int m_tiles = ceil_div(p.M, 128), n_tiles = ceil_div(p.N, bn);
+  int nk = ceil_div(p.K, BK);
+  long tiles = (long)m_tiles * n_tiles;
+  int split = 1;
+  if (tiles < 192 && nk >= 4 && !p.stats) {
+    split = (int)min((long)(nk / 2), (384 + tiles - 1) / tiles);
+    if (split < 1) split = 1;
+    if (split > 32) split = 32;
+    if (!ws || (size_t)split * p.M * p.N * sizeof(float) > ws_bytes) split = 1;
+  }
+  p.ksteps_per_split = ceil_div(nk, split);
+  p.splitk = ceil_div(nk, p.ksteps_per_split);
+  p.slab = (float*)ws;
+  int rc;
+  switch (bn) {
+    case 16: rc = launch<128, 16, 4, 1>(p, m_tiles, n_tiles, st); break;
+    case 32: rc = launch<128, 32, 4, 1>(p, m_tiles, n_tiles, st); break;
+    case 64: rc = launch<128, 64, 2, 2>(p, m_tiles, n_tiles, st); break;
+    default: rc = launch<128, 128, 2, 2>(p, m_tiles, n_tiles, st); break;
+  }
+  if (rc != AVLEN_OK) return rc;
+  if (p.splitk > 1) {
+    long tot = (long)p.M * p.N;
+    hipLaunchKernelGGL(g2_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, p.slab, p.C32, p.C16, p.bias,
+                       p.residual, p.M, p.N, p.ldc32, p.ldc16, p.ldr, p.splitk, p.act);
+    return avlen_launch_status();
+  }
+  return AVLEN_OK;
+}
+
+}  // namespace
+
+extern "C" size_t avlen_gemm_bf16_workspace_bytes(int M, int N) { return (size_t)32 * M * N * sizeof(float) + 256; }
+
+extern "C" int avlen_gemm_bf16(const void* A, int lda, const void* B, int ldb, float* C32, int ldc32, void* C16,
+                               int ldc16, const float* bias, const float* residual, int ldr, int M, int N, int K,
+                               int act, void* ws, size_t ws_bytes, hipStream_t stream) {
+  G2 p = {};
+  p.A = (const bf16*)A; p.B = (const bf16*)B; p.C32 = C32; p.C16 = (bf16*)C16; p.bias = bias; p.residual = residual;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc32 = ldc32; p.ldc16 = ldc16; p.ldr = ldr; p.act = act;
+  return run_g2(p, ws, ws_bytes, stream);
+}
+
+extern "C" int avlen_conv2d_nhwc_bf16(const void* X, const void* Wp, const float* bias, const float* residual,
+                                      float* Y32, void* Y16, float* gn_stats, int Bn, int H, int W, int Cin, int Cout,
+                                      int KH, int KW, int stride, int pad, int act, void* ws, size_t ws_bytes,
+                                      hipStream_t stream) {
+  if (Cin < 8 || (Cin & (Cin - 1))) return AVLEN_ERR_ARG;       // power of two >= 8 (conv1 input is channel-padded)
+  int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+  if (OH <= 0 || OW <= 0) return AVLEN_ERR_ARG;
+  G2 p = {};
+  p.A = (const bf16*)X; p.B = (const bf16*)Wp; p.C32 = Y32; p.C16 = (bf16*)Y16; p.bias = bias; p.residual = residual;
+  p.M = Bn * OH * OW; p.N = Cout; p.K = KH * KW * Cin; p.lda = 8; p.ldb = p.K; p.ldc32 = Cout; p.ldc16 = Cout; p.ldr = Cout;
+  p.act = act; p.conv = 1; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.KH = KH; p.KW = KW;
+  p.stride = stride; p.pad = pad;
+  if (gn_stats) {
+    if ((OH * OW) % 64 || bias) return AVLEN_ERR_ARG;      // wave tiles (32 or 64 rows) must not straddle samples
+    p.stats = gn_stats; p.ohw = OH * OW;
+  }
+  int l2 = 0; while ((1 << l2) < Cin) l2++;
+  p.cin_log2 = l2; p.kw_magic = (65536 + KW - 1) / KW;
+  return run_g2(p, ws, ws_bytes, stream);
+}
+
+extern "C" int avlen_cast_bf16(const float* src, int ld_src, void* dst, int ld_dst, long rows, int cols, hipStream_t stream) {
+  long tot = rows * ld_dst;
+  if (tot <= 0) return AVLEN_ERR_ARG;
+  hipLaunchKernelGGL(cast_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, src, ld_src, (bf16*)dst, ld_dst, rows, cols);
+  return avlen_launch_status();
+}
+
+extern "C" int avlen_pack_conv_weight_bf16(const float* w_oihw, void* w_packed, int O, int I, int KH, int KW, int Cpad,
+                                           hipStream_t stream) {
+  long tot = (long)O * KH * KW * Cpad;
+  hipLaunchKernelGGL(pack_conv_bf16_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, w_oihw, (bf16*)w_packed, O, I, KH, KW, Cpad);
+  return avlen_launch_status();
+}
+
+extern "C" int avlen_pack_fc_after_flatten_bf16(const float* w, void* w_packed, int O, int C, int HW, hipStream_t stream) {
+  long tot = (long)O * C * HW;
+  hipLaunchKernelGGL(pack_fc_bf16_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, w, (bf16*)w_packed, O, C, HW);
+  return avlen_launch_status();
+}

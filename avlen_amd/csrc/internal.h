@@ -1,0 +1,16 @@
+// Internal (non-ABI) entry points shared between the .hip translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+int avlen_groupnorm_nhwc_ws(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+                            int B, int HW, int C, int G, int relu, float eps, float* part, hipStream_t stream);
+extern "C" size_t avlen_groupnorm_workspace_bytes(int B, int C);
+int avlen_groupnorm_apply_bf16(const float* x, const float* stats, const float* gamma, const float* beta, const void* res16,
+                               void* y16, int B, int HW, int C, int G, int relu, float eps, hipStream_t stream);
+int avlen_layernorm_fwd16(const float* x, const float* residual, const float* gamma, const float* beta, float* y,
+                          void* y16, float* mean, float* rstd, int rows, int d, float eps, hipStream_t stream);
+int avlen_attention_fwd16(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+                          void* O16, int ldo16, const float* key_mask, float* lse, int B, int H, int Sq, int Sk, int D,
+                          int causal, float scale, hipStream_t stream);
+int avlen_preprocess_image_bf16(const float* x, void* y16, int B, int S, int C, float divisor, hipStream_t stream);

@@ -10,9 +10,7 @@
 #include "../../include/avlen_hip.h"
 #include <math.h>
 
-int avlen_groupnorm_nhwc_ws(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
-                            int B, int HW, int C, int G, int relu, float eps, float* part, hipStream_t stream);
-extern "C" size_t avlen_groupnorm_workspace_bytes(int B, int C);
+#include "internal.h"
 
 #define TRY(x) do { int _rc = (x); if (_rc != AVLEN_OK) return _rc; } while (0)
 
@@ -211,16 +209,195 @@ __global__ void gru_gate_kernel(const float* __restrict__ gi, const float* __res
 }  // namespace
 
 // =====================================================================================================
+// bf16 fast path (rollout "perf mode"): activations that feed a GEMM are kept in bf16, weights come from the
+// bf16 shadows (w16), tiles are staged with global_load_lds (igemm2.hip), GroupNorm statistics are produced by
+// the conv epilogue.  Same math as the fp32-staged path with prec = BF16 (operands rounded to bf16, fp32
+// accumulate); inference only (nothing is kept for backward).
+// =====================================================================================================
+namespace {
+
+typedef __bf16 bf16;
+
+bool lin16_ok(const avlen_linear& L) { return L.w16 != nullptr && (L.ld16 % 8) == 0; }
+
+// Y = act(X16 * W16^T + b) + res  -> fp32 (Y32) and/or bf16 (Y16)
+int linear16(const Ctx& c, const avlen_linear& L, const bf16* X16, int ldx, float* Y32, int ld32, bf16* Y16, int ld16, int M,
+             int act, const float* res, int ldr) {
+  return avlen_gemm_bf16(X16, ldx, L.w16, L.ld16, Y32, ld32, Y16, ld16, L.b, res, ldr, M, L.out_f, L.ld16, act, c.gws,
+                         c.gws_bytes, c.st);
+}
+int linear16_rows(const Ctx& c, const avlen_linear& L, int r0, int n, const bf16* X16, int ldx, float* Y32, int ld32,
+                  bf16* Y16, int ld16, int M, int act) {
+  avlen_linear S = L;
+  S.w16 = (char*)L.w16 + (size_t)r0 * L.ld16 * 2; S.b = L.b ? L.b + r0 : nullptr; S.out_f = n;
+  return linear16(c, S, X16, ldx, Y32, ld32, Y16, ld16, M, act, nullptr, 0);
+}
+
+__global__ void smt_build16_kernel(const float* __restrict__ x, const float* __restrict__ memory,
+                                   const int32_t* __restrict__ mem_index, int NC, const float* __restrict__ masks,
+                                   const float* __restrict__ pw, const float* __restrict__ pb, bf16* __restrict__ XF, int ldxf,
+                                   float* __restrict__ maskx, int B, int M, int F, int pc) {
+  const int S = M + 1;
+  const int row = blockIdx.x, b = row / S, s = row % S;
+  const int col = mem_index ? mem_index[b] : b;
+  const float* src = (s < M) ? memory + ((long)s * NC + col) * F : x + (long)b * F;
+  const float* xp = x + (long)b * F + pc;
+  __shared__ float fmt[5];
+  const int t = threadIdx.x;
+  if (t == 0) {
+    float ax = xp[0], ay = xp[1], ah = xp[2];
+    float bx = src[pc], by = src[pc + 1], bh = src[pc + 2], bt = src[pc + 3];
+    float heading_a = -ah, heading_b = -bh;
+    float dx = bx - ax, dy = by - ay;
+    float r = sqrtf(dx * dx + dy * dy);
+    float phi = atan2f(dy, dx) - heading_a;
+    float dh = heading_b - heading_a;
+    dh = -atan2f(sinf(dh), cosf(dh));
+    fmt[0] = r * cosf(phi); fmt[1] = r * sinf(phi); fmt[2] = cosf(dh); fmt[3] = sinf(dh); fmt[4] = expf(-bt);
+    maskx[(long)b * S + s] = (s < M) ? masks[(long)b * M + s] : 1.f;
+  }
+  __syncthreads();
+  bf16* o = XF + (long)row * ldxf;
+  for (int i = t; i < ldxf; i += blockDim.x) {
+    float v = 0.f;
+    if (i < pc) v = src[i];
+    else if (i < pc + 16) {
+      int j = i - pc;
+      v = pb[j];
+#pragma unroll
+      for (int k = 0; k < 5; k++) v += pw[j * 5 + k] * fmt[k];
+    } else if (i < F + 12) v = src[i - 12];
+    o[i] = (bf16)v;
+  }
+}
+
+// ---- ResNet-18 tower ----
+size_t resnet18_ws_bf16(int B) {
+  size_t px = (size_t)B * 4096;
+  return px * 8 * 2 + 3 * (px * 16 * 4 + 256) + 4 * (px * 16 * 2 + 256) + 21 * ((size_t)B * 2 * 128 * 4 + 256) +
+         avlen_gemm_bf16_workspace_bytes(B, 64) + 8192;
+}
+
+bool resnet18_has16(const avlen_resnet18* n) {
+  if (!n->conv1.w16 || !n->fc.w16) return false;
+  for (int i = 0; i < 8; i++) {
+    if (!n->block[i].conv1.w16 || !n->block[i].conv2.w16) return false;
+    if (n->block[i].has_down && !n->block[i].down.w16) return false;
+  }
+  return true;
+}
+
+int conv16(const avlen_conv& k, const bf16* x, float* raw, float* stats, int B, int H, int W, void* gws, size_t gwsb,
+           hipStream_t st) {
+  return avlen_conv2d_nhwc_bf16(x, k.w16, nullptr, nullptr, raw, nullptr, stats, B, H, W, k.cin16, k.cout, k.kh, k.kw,
+                                k.stride, k.pad, 0, gws, gwsb, st);
+}
+
+int resnet18_fwd_bf16(const avlen_resnet18* net, const float* img, int B, int S, int C, float divisor, float* out,
+                      int ld_out, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (ws_bytes < resnet18_ws_bf16(B)) return AVLEN_ERR_WS;
+  WsBump w(ws, ws_bytes);
+  size_t px = (size_t)B * 4096;
+  bf16* x0 = w.take<bf16>(px * 8);
+  float* raw[3]; for (int i = 0; i < 3; i++) raw[i] = w.take<float>(px * 16);
+  bf16* act[4]; for (int i = 0; i < 4; i++) act[i] = w.take<bf16>(px * 16);
+  size_t stat_stride = align_up((size_t)B * 2 * 128, 64);
+  float* stats = w.take<float>(21 * stat_stride);
+  size_t gwsb = avlen_gemm_bf16_workspace_bytes(B, 64);
+  void* gws = w.take<char>(gwsb);
+  if (hipMemsetAsync(stats, 0, 21 * stat_stride * sizeof(float), st) != hipSuccess) return AVLEN_ERR_LAUNCH;
+  int si = 0;
+  auto next_stats = [&]() { return stats + (size_t)(si++) * stat_stride; };
+
+  TRY(avlen_preprocess_image_bf16(img, x0, B, S, C, divisor, st));
+  float* s0 = next_stats();
+  TRY(conv16(net->conv1, x0, raw[0], s0, B, 64, 64, gws, gwsb, st));
+  TRY(avlen_groupnorm_apply_bf16(raw[0], s0, net->bn1.g, net->bn1.b, nullptr, act[0], B, 4096, 16, 16, 1, 1e-5f, st));
+  bf16* cur = act[0]; bf16* a1 = act[1]; bf16* idt = act[2]; bf16* nxt = act[3];
+  int H = 64, Cc = 16;
+  for (int i = 0; i < 8; i++) {
+    const avlen_resblock& k = net->block[i];
+    int s = k.conv1.stride, OH = (H + 2 - 3) / s + 1, Co = k.conv1.cout;
+    float* st1 = next_stats(); float* st2 = next_stats();
+    TRY(conv16(k.conv1, cur, raw[0], st1, B, H, H, gws, gwsb, st));
+    TRY(avlen_groupnorm_apply_bf16(raw[0], st1, k.bn1.g, k.bn1.b, nullptr, a1, B, OH * OH, Co, 16, 1, 1e-5f, st));
+    TRY(conv16(k.conv2, a1, raw[1], st2, B, OH, OH, gws, gwsb, st));
+    const bf16* identity = cur;
+    if (k.has_down) {
+      float* st3 = next_stats();
+      TRY(conv16(k.down, cur, raw[2], st3, B, H, H, gws, gwsb, st));
+      TRY(avlen_groupnorm_apply_bf16(raw[2], st3, k.bnd.g, k.bnd.b, nullptr, idt, B, OH * OH, Co, 16, 0, 1e-5f, st));
+      identity = idt;
+    }
+    TRY(avlen_groupnorm_apply_bf16(raw[1], st2, k.bn2.g, k.bn2.b, identity, nxt, B, OH * OH, Co, 16, 1, 1e-5f, st));
+    bf16* old = cur; cur = nxt; nxt = old;
+    H = OH; Cc = Co;
+  }
+  (void)Cc;
+  return avlen_gemm_bf16(cur, net->fc.ld16, net->fc.w16, net->fc.ld16, out, ld_out, nullptr, 0, net->fc.b, nullptr, 0, B,
+                         net->fc.out_f, net->fc.ld16, 0, gws, gwsb, st);
+}
+
+// ---- 3-conv CNNs ----
+void cnn3_dims2(const avlen_cnn3* n, int H, int W, int oh[3], int ow[3]) {
+  for (int i = 0; i < 3; i++) {
+    oh[i] = (H - n->conv[i].kh) / n->conv[i].stride + 1;
+    ow[i] = (W - n->conv[i].kw) / n->conv[i].stride + 1;
+    H = oh[i]; W = ow[i];
+  }
+}
+bool cnn3_has16(const avlen_cnn3* n) { return n->conv[0].w16 && n->conv[1].w16 && n->conv[2].w16 && n->fc.w16; }
+size_t cnn3_ws_bf16(const avlen_cnn3* n, int B, int H, int W) {
+  int oh[3], ow[3]; cnn3_dims2(n, H, W, oh, ow);
+  size_t tot = (size_t)B * H * W * 8 * 2 + 256;
+  size_t mx = 0;
+  for (int i = 0; i < 3; i++) {
+    tot += (size_t)B * oh[i] * ow[i] * n->conv[i].cout * 2 + 256;
+    mx = max(mx, avlen_gemm_bf16_workspace_bytes(B * oh[i] * ow[i], n->conv[i].cout));
+  }
+  return tot + max(mx, avlen_gemm_bf16_workspace_bytes(B, n->fc.out_f)) + 4096;
+}
+int cnn3_fwd_bf16(const avlen_cnn3* n, const float* x, int B, int H, int W, float* out, int ld_out, void* ws,
+                  size_t ws_bytes, hipStream_t st) {
+  if (ws_bytes < cnn3_ws_bf16(n, B, H, W)) return AVLEN_ERR_WS;
+  int oh[3], ow[3]; cnn3_dims2(n, H, W, oh, ow);
+  WsBump w(ws, ws_bytes);
+  bf16* x16 = w.take<bf16>((size_t)B * H * W * 8);
+  bf16* a[3];
+  size_t mx = avlen_gemm_bf16_workspace_bytes(B, n->fc.out_f);
+  for (int i = 0; i < 3; i++) {
+    a[i] = w.take<bf16>((size_t)B * oh[i] * ow[i] * n->conv[i].cout);
+    mx = max(mx, avlen_gemm_bf16_workspace_bytes(B * oh[i] * ow[i], n->conv[i].cout));
+  }
+  void* gws = w.take<char>(mx);
+  TRY(avlen_cast_bf16(x, n->conv[0].cin, x16, 8, (long)B * H * W, n->conv[0].cin, st));     // channel-pad to 8
+  const bf16* cur = x16; int h = H, wd = W;
+  for (int i = 0; i < 3; i++) {
+    const avlen_conv& k = n->conv[i];
+    TRY(avlen_conv2d_nhwc_bf16(cur, k.w16, k.b, nullptr, nullptr, a[i], nullptr, B, h, wd, k.cin16, k.cout, k.kh, k.kw,
+                               k.stride, 0, i < 2 ? AVLEN_ACT_RELU : AVLEN_ACT_NONE, gws, mx, st));
+    cur = a[i]; h = oh[i]; wd = ow[i];
+  }
+  return avlen_gemm_bf16(cur, n->fc.ld16, n->fc.w16, n->fc.ld16, out, ld_out, nullptr, 0, n->fc.b, nullptr, 0, B,
+                         n->fc.out_f, n->fc.ld16, AVLEN_ACT_RELU, gws, mx, st);
+}
+
+}  // namespace
+
+// =====================================================================================================
 // ResNet-18 tower
 // =====================================================================================================
 extern "C" size_t avlen_resnet18_workspace_bytes(int B) {
   size_t act = (size_t)B * 64 * 64 * 16 * sizeof(float);
-  return 5 * (act + 256) + avlen_groupnorm_workspace_bytes(B, 128) + GEMM_SCRATCH + 4096;
+  size_t v1 = 5 * (act + 256) + avlen_groupnorm_workspace_bytes(B, 128) + GEMM_SCRATCH + 4096;
+  return max(v1, resnet18_ws_bf16(B));
 }
 
 extern "C" int avlen_resnet18_fwd(const avlen_resnet18* net, const float* img, int B, int S, int C, float divisor,
                                   float* out, int ld_out, int prec, void* ws, size_t ws_bytes, hipStream_t st) {
   if (!net || B <= 0 || ws_bytes < avlen_resnet18_workspace_bytes(B)) return AVLEN_ERR_WS;
+  if (prec == AVLEN_PREC_BF16 && resnet18_has16(net) && C <= 8)
+    return resnet18_fwd_bf16(net, img, B, S, C, divisor, out, ld_out, ws, ws_bytes, st);
   WsBump w(ws, ws_bytes);
   size_t act = (size_t)B * 64 * 64 * 16;
   float* x0 = w.take<float>(act);
@@ -271,13 +448,15 @@ extern "C" size_t avlen_cnn3_workspace_bytes(const avlen_cnn3* n, int B, int H, 
   int oh[3], ow[3]; cnn3_dims(n, H, W, oh, ow);
   size_t tot = 0;
   for (int i = 0; i < 3; i++) tot += (size_t)B * oh[i] * ow[i] * n->conv[i].cout * sizeof(float) + 256;
-  return tot + GEMM_SCRATCH + 1024;
+  return max(tot + GEMM_SCRATCH + 1024, cnn3_ws_bf16(n, B, H, W));
 }
 extern "C" int avlen_cnn3_fwd(const avlen_cnn3* n, const float* x, int B, int H, int W, float* out, int ld_out,
                               int prec, void* ws, size_t ws_bytes, hipStream_t st) {
   if (!n || B <= 0 || ws_bytes < avlen_cnn3_workspace_bytes(n, B, H, W)) return AVLEN_ERR_WS;
   int oh[3], ow[3]; cnn3_dims(n, H, W, oh, ow);
   if (oh[2] <= 0 || ow[2] <= 0 || n->fc.in_f != oh[2] * ow[2] * n->conv[2].cout) return AVLEN_ERR_ARG;
+  if (prec == AVLEN_PREC_BF16 && cnn3_has16(n) && n->conv[0].cin <= 8)
+    return cnn3_fwd_bf16(n, x, B, H, W, out, ld_out, ws, ws_bytes, st);
   WsBump w(ws, ws_bytes);
   float* a[3];
   for (int i = 0; i < 3; i++) a[i] = w.take<float>((size_t)B * oh[i] * ow[i] * n->conv[i].cout);
@@ -324,14 +503,14 @@ void tr_layout(WsBump& w, TrWs& t, long B, long S, int d, int H, bool cto) {
   t.md3 = w.take<float>(B); t.rd3 = w.take<float>(B); t.mf = w.take<float>(B); t.rf = w.take<float>(B);
 }
 
-// Z: [R, d] encoder input (batch-major), maskx: [B, S] (1 = valid), tgt: [B, d]; out: [B, d]
-int transformer_fwd(const Ctx& c, const avlen_transformer& tr, TrWs& t, const float* Z, const float* maskx,
-                    const float* tgt, float* out, int B, int S, bool cto) {
+// Encoder layer + final encoder norm (fp32-staged kernels; keeps every activation for backward).
+// Z: [R, d] encoder input (batch-major), maskx: [B, S] (1 = valid)
+int enc_fwd(const Ctx& c, const avlen_transformer& tr, TrWs& t, const float* Z, const float* maskx, int B, int S,
+            bool cto) {
   const int d = tr.d, H = tr.nhead, D = d / H;
   const long R = (long)B * S;
   const float scale = 1.0f / sqrtf((float)D);
   const avlen_enc_layer& e = tr.enc;
-  // ---- encoder layer
   if (cto) {      // single valid key: softmax == 1, attention output == V(token)
     TRY(linear_rows(c, e.self_attn.in_proj, 2 * d, d, Z, d, t.QKV, d, (int)R, 0, nullptr, 0));
   } else {
@@ -345,16 +524,23 @@ int transformer_fwd(const Ctx& c, const avlen_transformer& tr, TrWs& t, const fl
   TRY(linear(c, e.lin2, t.F1, e.lin1.out_f, t.T2, d, (int)R, 0, t.X1, d));
   TRY(avlen_layernorm_fwd(t.T2, nullptr, e.norm2.g, e.norm2.b, t.X2, t.m2, t.r2, (int)R, d, 1e-5f, c.st));
   TRY(avlen_layernorm_fwd(t.X2, nullptr, tr.enc_norm.g, tr.enc_norm.b, t.MEM, t.me, t.re, (int)R, d, 1e-5f, c.st));
-  // ---- decoder layer (one target token per sample)
+  // K/V (cto: V only) projections of the encoder memory for the decoder's cross attention
+  const avlen_dec_layer& q = tr.dec;
+  if (cto) return linear_rows(c, q.cross_attn.in_proj, 2 * d, d, t.MEM, d, t.KVc, d, (int)R, 0, nullptr, 0);
+  return linear_rows(c, q.cross_attn.in_proj, d, 2 * d, t.MEM, d, t.KVc, 2 * d, (int)R, 0, nullptr, 0);
+}
+
+// Decoder layer over ONE target token per sample, given t.KVc (K|V projections of the encoder memory).
+int dec_fwd(const Ctx& c, const avlen_transformer& tr, TrWs& t, const float* maskx, const float* tgt, float* out, int B,
+            int S, bool cto) {
+  const int d = tr.d, H = tr.nhead, D = d / H;
+  const float scale = 1.0f / sqrtf((float)D);
   const avlen_dec_layer& q = tr.dec;
   TRY(linear_rows(c, q.self_attn.in_proj, 2 * d, d, tgt, d, t.V0, d, B, 0, nullptr, 0));       // self-attn over 1 token
   TRY(linear(c, q.self_attn.out_proj, t.V0, d, t.U1, d, B, 0, tgt, d));
   TRY(avlen_layernorm_fwd(t.U1, nullptr, q.norm1.g, q.norm1.b, t.Y1, t.md1, t.rd1, B, d, 1e-5f, c.st));
-  if (cto) {
-    TRY(linear_rows(c, q.cross_attn.in_proj, 2 * d, d, t.MEM, d, t.KVc, d, (int)R, 0, nullptr, 0));   // V only
-  } else {
+  if (!cto) {
     TRY(linear_rows(c, q.cross_attn.in_proj, 0, d, t.Y1, d, t.Qc, d, B, 0, nullptr, 0));
-    TRY(linear_rows(c, q.cross_attn.in_proj, d, 2 * d, t.MEM, d, t.KVc, 2 * d, (int)R, 0, nullptr, 0));
     TRY(avlen_attention_fwd(t.Qc, d, t.KVc, 2 * d, t.KVc + d, 2 * d, t.AOc, d, maskx, t.LSEc, B, H, 1, S, D, 0, scale,
                             c.st));
   }
@@ -365,6 +551,12 @@ int transformer_fwd(const Ctx& c, const avlen_transformer& tr, TrWs& t, const fl
   TRY(avlen_layernorm_fwd(t.U3, nullptr, q.norm3.g, q.norm3.b, t.Y3, t.md3, t.rd3, B, d, 1e-5f, c.st));
   TRY(avlen_layernorm_fwd(t.Y3, nullptr, tr.dec_norm.g, tr.dec_norm.b, out, t.mf, t.rf, B, d, 1e-5f, c.st));
   return AVLEN_OK;
+}
+
+int transformer_fwd(const Ctx& c, const avlen_transformer& tr, TrWs& t, const float* Z, const float* maskx,
+                    const float* tgt, float* out, int B, int S, bool cto) {
+  TRY(enc_fwd(c, tr, t, Z, maskx, B, S, cto));
+  return dec_fwd(c, tr, t, maskx, tgt, out, B, S, cto);
 }
 
 struct TrBwdWs { float *dA, *dB, *dC, *dD, *dE, *delta; };     // dA: [R,3d]; dB..dE: [R,d]
@@ -494,18 +686,87 @@ void smt_layout(WsBump& w, SmtWs& s, const avlen_smt* p, long B, long M, int F, 
 
 }  // namespace
 
+namespace {
+
+bool smt_has16(const avlen_smt* p) {
+  const avlen_transformer& t = p->tr;
+  return lin16_ok(p->fus0) && lin16_ok(p->fus2) && lin16_ok(t.enc.self_attn.in_proj) && lin16_ok(t.enc.self_attn.out_proj) &&
+         lin16_ok(t.enc.lin1) && lin16_ok(t.enc.lin2) && lin16_ok(t.dec.cross_attn.in_proj);
+}
+
+struct Smt16Ws { bf16 *XF, *H1, *Z16, *AO16, *X116, *F116, *MEM16; float *Z, *QKV, *T1, *X1, *T2, *X2, *maskx; TrWs tr; void* gws; size_t gwsb; int ldxf; };
+
+void smt16_layout(WsBump& w, Smt16Ws& s, const avlen_smt* p, long B, long M, int F) {
+  long S = M + 1, R = B * S; int d = p->tr.d;
+  s.ldxf = p->fus0.ld16;
+  s.XF = w.take<bf16>(R * s.ldxf); s.H1 = w.take<bf16>(R * d); s.Z16 = w.take<bf16>(R * d); s.AO16 = w.take<bf16>(R * d);
+  s.X116 = w.take<bf16>(R * d); s.F116 = w.take<bf16>(R * d); s.MEM16 = w.take<bf16>(R * d);
+  s.Z = w.take<float>(R * d); s.QKV = w.take<float>(R * 3 * d); s.T1 = w.take<float>(R * d); s.X1 = w.take<float>(R * d);
+  s.T2 = w.take<float>(R * d); s.X2 = w.take<float>(R * d); s.maskx = w.take<float>(B * S);
+  // decoder scratch: reuse TrWs with only the decoder-side buffers populated
+  TrWs& t = s.tr;
+  t.KVc = w.take<float>(R * 2 * d); t.LSEc = w.take<float>(B * p->tr.nhead);
+  t.V0 = w.take<float>(B * d); t.U1 = w.take<float>(B * d); t.Y1 = w.take<float>(B * d); t.Qc = w.take<float>(B * d);
+  t.AOc = w.take<float>(B * d); t.U2 = w.take<float>(B * d); t.Y2 = w.take<float>(B * d); t.G1 = w.take<float>(B * d);
+  t.U3 = w.take<float>(B * d); t.Y3 = w.take<float>(B * d);
+  t.md1 = w.take<float>(B); t.rd1 = w.take<float>(B); t.md2 = w.take<float>(B); t.rd2 = w.take<float>(B);
+  t.md3 = w.take<float>(B); t.rd3 = w.take<float>(B); t.mf = w.take<float>(B); t.rf = w.take<float>(B);
+  s.gwsb = max((size_t)GEMM_SCRATCH, avlen_gemm_bf16_workspace_bytes(128, 768));
+  s.gws = w.take<char>(s.gwsb);
+}
+
+size_t smt16_ws_bytes(const avlen_smt* p, int B, int M, int F) {
+  WsBump w(nullptr, 0); Smt16Ws s; smt16_layout(w, s, p, B, M, F); return w.off + 4096;
+}
+
+// SMTStateEncoder forward, inference only, full memory, bf16 operands (pi_g / pi_l / 2nd-stage pi_q rollouts)
+int smt_fwd_infer_bf16(const avlen_smt* p, const float* x, const float* memory, const int32_t* mem_index, int NC,
+                       const float* masks, const float* goal, float* out, int B, int M, int F, int pose_col, void* ws,
+                       size_t ws_bytes, hipStream_t st) {
+  if (ws_bytes < smt16_ws_bytes(p, B, M, F)) return AVLEN_ERR_WS;
+  WsBump w(ws, ws_bytes); Smt16Ws s; smt16_layout(w, s, p, B, M, F);
+  Ctx c{st, AVLEN_PREC_BF16, s.gws, s.gwsb};
+  const avlen_transformer& tr = p->tr;
+  const int S = M + 1, d = tr.d, H = tr.nhead, D = d / H;
+  const long R = (long)B * S;
+  const float scale = 1.0f / sqrtf((float)D);
+  if (!mem_index) NC = B;
+  hipLaunchKernelGGL(smt_build16_kernel, dim3((unsigned)R), dim3(128), 0, st, x, memory, mem_index, NC, masks, p->pose.w,
+                     p->pose.b, s.XF, s.ldxf, s.maskx, B, M, F, pose_col);
+  TRY(avlen_launch_status());
+  TRY(linear16(c, p->fus0, s.XF, s.ldxf, nullptr, 0, s.H1, d, (int)R, AVLEN_ACT_RELU, nullptr, 0));
+  TRY(linear16(c, p->fus2, s.H1, d, s.Z, d, s.Z16, d, (int)R, 0, nullptr, 0));
+  const avlen_enc_layer& e = tr.enc;
+  TRY(linear16(c, e.self_attn.in_proj, s.Z16, d, s.QKV, 3 * d, nullptr, 0, (int)R, 0, nullptr, 0));
+  TRY(avlen_attention_fwd16(s.QKV, 3 * d, s.QKV + d, 3 * d, s.QKV + 2 * d, 3 * d, nullptr, 0, s.AO16, d, s.maskx, nullptr, B,
+                            H, S, S, D, 0, scale, st));
+  TRY(linear16(c, e.self_attn.out_proj, s.AO16, d, s.T1, d, nullptr, 0, (int)R, 0, s.Z, d));
+  TRY(avlen_layernorm_fwd16(s.T1, nullptr, e.norm1.g, e.norm1.b, s.X1, s.X116, nullptr, nullptr, (int)R, d, 1e-5f, st));
+  TRY(linear16(c, e.lin1, s.X116, d, nullptr, 0, s.F116, d, (int)R, AVLEN_ACT_RELU, nullptr, 0));
+  TRY(linear16(c, e.lin2, s.F116, d, s.T2, d, nullptr, 0, (int)R, 0, s.X1, d));
+  TRY(avlen_layernorm_fwd16(s.T2, nullptr, e.norm2.g, e.norm2.b, s.X2, nullptr, nullptr, nullptr, (int)R, d, 1e-5f, st));
+  TRY(avlen_layernorm_fwd16(s.X2, nullptr, tr.enc_norm.g, tr.enc_norm.b, nullptr, s.MEM16, nullptr, nullptr, (int)R, d, 1e-5f, st));
+  TRY(linear16_rows(c, tr.dec.cross_attn.in_proj, d, 2 * d, s.MEM16, d, s.tr.KVc, 2 * d, nullptr, 0, (int)R, 0));
+  return dec_fwd(c, tr, s.tr, s.maskx, goal, out, B, S, false);
+}
+
+}  // namespace
+
 extern "C" size_t avlen_smt_workspace_bytes(const avlen_smt* p, int B, int M, int F, int cto) {
   WsBump w(nullptr, 0); SmtWs s;
   smt_layout(w, s, p, B, M, F, cto != 0);
-  return w.off + 4096;
+  size_t v1 = w.off + 4096;
+  return (!cto && smt_has16(p)) ? max(v1, smt16_ws_bytes(p, B, M, F)) : v1;
 }
 
 extern "C" int avlen_smt_fwd(const avlen_smt* p, const float* x, const float* memory, const int32_t* mem_index, int NC,
                              const float* masks, const float* goal, float* out, int B, int M, int F, int pose_col,
-                             int cto, int prec, void* ws, size_t ws_bytes, hipStream_t st) {
+                             int cto, int save_for_backward, int prec, void* ws, size_t ws_bytes, hipStream_t st) {
   if (!p || B <= 0 || M < 0 || p->fus0.in_f != F + 12 || p->pose.in_f != 5 || p->pose.out_f != 16) return AVLEN_ERR_ARG;
   if (!cto && M > 0 && (!memory || !masks)) return AVLEN_ERR_ARG;
   if (ws_bytes < avlen_smt_workspace_bytes(p, B, M, F, cto)) return AVLEN_ERR_WS;
+  if (prec == AVLEN_PREC_BF16 && !cto && !save_for_backward && M > 0 && smt_has16(p))
+    return smt_fwd_infer_bf16(p, x, memory, mem_index, NC, masks, goal, out, B, M, F, pose_col, ws, ws_bytes, st);
   WsBump w(ws, ws_bytes); SmtWs s;
   smt_layout(w, s, p, B, M, F, cto != 0);
   Ctx c{st, prec, s.gws, GEMM_SCRATCH};
@@ -613,6 +874,25 @@ extern "C" int avlen_clip_text_fwd(const avlen_clip_text* p, const int64_t* toke
   hipLaunchKernelGGL(clip_embed_kernel, dim3((unsigned)R), dim3(128), 0, st, tokens, p->tok_emb, p->pos_emb, X, ctx, wd,
                      p->vocab);
   TRY(avlen_launch_status());
+  bool fast = prec == AVLEN_PREC_BF16;
+  for (int l = 0; l < p->layers && fast; l++) {
+    const avlen_clip_block& b = p->block[l];
+    fast = lin16_ok(b.attn.in_proj) && lin16_ok(b.attn.out_proj) && lin16_ok(b.fc) && lin16_ok(b.proj);
+  }
+  if (fast) {      // bf16 operands from HBM: Hn / AO / F live in bf16, the residual stream X stays fp32
+    bf16* Hn16 = (bf16*)Hn; bf16* AO16 = (bf16*)AO; bf16* F16 = (bf16*)Fh;
+    for (int l = 0; l < p->layers; l++) {
+      const avlen_clip_block& b = p->block[l];
+      TRY(avlen_layernorm_fwd16(X, nullptr, b.ln1.g, b.ln1.b, nullptr, Hn16, nullptr, nullptr, (int)R, wd, 1e-5f, st));
+      TRY(linear16(c, b.attn.in_proj, Hn16, wd, QKV, 3 * wd, nullptr, 0, (int)R, 0, nullptr, 0));
+      TRY(avlen_attention_fwd16(QKV, 3 * wd, QKV + wd, 3 * wd, QKV + 2 * wd, 3 * wd, nullptr, 0, AO16, wd, nullptr, nullptr, B,
+                                H, ctx, ctx, D, 1, scale, st));
+      TRY(linear16(c, b.attn.out_proj, AO16, wd, X, wd, nullptr, 0, (int)R, 0, X, wd));
+      TRY(avlen_layernorm_fwd16(X, nullptr, b.ln2.g, b.ln2.b, nullptr, Hn16, nullptr, nullptr, (int)R, wd, 1e-5f, st));
+      TRY(linear16(c, b.fc, Hn16, wd, nullptr, 0, F16, b.fc.out_f, (int)R, AVLEN_ACT_QUICKGELU, nullptr, 0));
+      TRY(linear16(c, b.proj, F16, b.fc.out_f, X, wd, nullptr, 0, (int)R, 0, X, wd));
+    }
+  } else
   for (int l = 0; l < p->layers; l++) {
     const avlen_clip_block& b = p->block[l];
     TRY(avlen_layernorm_fwd(X, nullptr, b.ln1.g, b.ln1.b, Hn, nullptr, nullptr, (int)R, wd, 1e-5f, st));

@@ -3,8 +3,60 @@
 // from HBM (a sample's activations -- <= 256 KB -- stay in the XCD's L2 between the two passes).
 #include "common.h"
 #include "../../include/avlen_hip.h"
+#include "internal.h"
 
 namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8v;
+
+// GroupNorm apply for the bf16 fast path: x = raw fp32 conv output, statistics (per sample/channel sum, sumsq) come
+// from the conv epilogue; y (bf16) = [relu](xhat*g + b [+ res (bf16)]).  8 channels (16 B out) per thread-iteration.
+__global__ __launch_bounds__(256) void gn_apply_bf16_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const __bf16* __restrict__ res, __bf16* __restrict__ y, int HW,
+                                                            int C, int G, int splits, int relu, float eps) {
+  __shared__ float s_scale[128], s_shift[128];
+  const int b = blockIdx.x / splits, sp = blockIdx.x % splits, tid = threadIdx.x;
+  const int cg = C / G;
+  if (tid < G) {
+    const float* st = stats + (long)b * 2 * C;
+    double sum = 0.0, sq = 0.0;
+    for (int c = tid * cg; c < (tid + 1) * cg; c++) { sum += st[c]; sq += st[C + c]; }
+    double n = (double)HW * cg, mean = sum / n, var = sq / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    for (int c = tid * cg; c < (tid + 1) * cg; c++) {
+      float sc = gamma[c] * rstd;
+      s_scale[c] = sc; s_shift[c] = beta[c] - (float)mean * sc;
+    }
+  }
+  __syncthreads();
+  const long n8 = (long)HW * C / 8;
+  const long per = (n8 + splits - 1) / splits;
+  const long beg = sp * per, end = min(n8, beg + per);
+  const long base = (long)b * HW * C;
+  const int c0 = (int)(((beg + tid) * 8) % C);          // 256*8 % C == 0 -> fixed channels per thread
+  float sc[8], sh[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) { sc[i] = s_scale[c0 + i]; sh[i] = s_shift[c0 + i]; }
+  for (long f = beg + tid; f < end; f += 256) {
+    const float4* xp = reinterpret_cast<const float4*>(x + base + f * 8);
+    float4 a = xp[0], c = xp[1];
+    float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+    if (res) {
+      bf16x8v r = *reinterpret_cast<const bf16x8v*>(res + base + f * 8);
+#pragma unroll
+      for (int i = 0; i < 8; i++) v[i] = v[i] * sc[i] + sh[i] + (float)r[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; i++) v[i] = v[i] * sc[i] + sh[i];
+    }
+    bf16x8v o;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o[i] = (__bf16)(relu ? fmaxf(v[i], 0.f) : v[i]);
+    *reinterpret_cast<bf16x8v*>(y + base + f * 8) = o;
+  }
+}
 
 // One block per (sample, spatial split).  C <= 128, C % 4 == 0, blockDim*4 % C == 0, so every
 // thread always touches the same 4 channels and keeps 4 running sums in registers.
@@ -89,8 +141,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
 template <int NV>   // NV = d / 64 values per lane, strided so loads are coalesced
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     float* __restrict__ y, float* __restrict__ mean_o,
-                                                     float* __restrict__ rstd_o, int rows, float eps) {
+                                                     float* __restrict__ y, __bf16* __restrict__ y16,
+                                                     float* __restrict__ mean_o, float* __restrict__ rstd_o, int rows,
+                                                     float eps) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -112,7 +165,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 #pragma unroll
   for (int i = 0; i < NV; i++) {
     int c = lane + i * 64;
-    y[(long)row * d + c] = (v[i] - mean) * rstd * gamma[c] + beta[c];
+    float o = (v[i] - mean) * rstd * gamma[c] + beta[c];
+    if (y) y[(long)row * d + c] = o;
+    if (y16) y16[(long)row * d + c] = (__bf16)o;
   }
   if (mean_o && lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
 }
@@ -245,18 +300,35 @@ extern "C" int avlen_groupnorm_nhwc(const float* x, const float* gamma, const fl
   return avlen_groupnorm_nhwc_ws(x, gamma, beta, residual, y, B, HW, C, G, relu, eps, nullptr, stream);
 }
 
+int avlen_layernorm_fwd16(const float* x, const float* residual, const float* gamma, const float* beta, float* y,
+                          void* y16, float* mean, float* rstd, int rows, int d, float eps, hipStream_t stream) {
+  if (rows <= 0) return AVLEN_ERR_ARG;
+  dim3 grid(ceil_div(rows, 4)), block(256);
+  __bf16* h = (__bf16*)y16;
+  switch (d) {
+    case 256: hipLaunchKernelGGL((ln_fwd_kernel<4>), grid, block, 0, stream, x, residual, gamma, beta, y, h, mean, rstd, rows, eps); break;
+    case 512: hipLaunchKernelGGL((ln_fwd_kernel<8>), grid, block, 0, stream, x, residual, gamma, beta, y, h, mean, rstd, rows, eps); break;
+    case 128: hipLaunchKernelGGL((ln_fwd_kernel<2>), grid, block, 0, stream, x, residual, gamma, beta, y, h, mean, rstd, rows, eps); break;
+    case 64: hipLaunchKernelGGL((ln_fwd_kernel<1>), grid, block, 0, stream, x, residual, gamma, beta, y, h, mean, rstd, rows, eps); break;
+    default: return AVLEN_ERR_ARG;
+  }
+  return avlen_launch_status();
+}
+
 extern "C" int avlen_layernorm_fwd(const float* x, const float* residual, const float* gamma, const float* beta,
                                    float* y, float* mean, float* rstd, int rows, int d, float eps,
                                    hipStream_t stream) {
-  if (rows <= 0) return AVLEN_ERR_ARG;
-  dim3 grid(ceil_div(rows, 4)), block(256);
-  switch (d) {
-    case 256: hipLaunchKernelGGL((ln_fwd_kernel<4>), grid, block, 0, stream, x, residual, gamma, beta, y, mean, rstd, rows, eps); break;
-    case 512: hipLaunchKernelGGL((ln_fwd_kernel<8>), grid, block, 0, stream, x, residual, gamma, beta, y, mean, rstd, rows, eps); break;
-    case 128: hipLaunchKernelGGL((ln_fwd_kernel<2>), grid, block, 0, stream, x, residual, gamma, beta, y, mean, rstd, rows, eps); break;
-    case 64: hipLaunchKernelGGL((ln_fwd_kernel<1>), grid, block, 0, stream, x, residual, gamma, beta, y, mean, rstd, rows, eps); break;
-    default: return AVLEN_ERR_ARG;
-  }
+  return avlen_layernorm_fwd16(x, residual, gamma, beta, y, nullptr, mean, rstd, rows, d, eps, stream);
+}
+
+int avlen_groupnorm_apply_bf16(const float* x, const float* stats, const float* gamma, const float* beta, const void* res16,
+                               void* y16, int B, int HW, int C, int G, int relu, float eps, hipStream_t stream) {
+  if (C > 128 || C % 8 || 2048 % C || C % G) return AVLEN_ERR_ARG;
+  long n8 = (long)HW * C / 8;
+  int splits = 1;
+  while (splits < 16 && (long)B * splits < 512 && n8 / (splits * 2) >= 256) splits *= 2;
+  hipLaunchKernelGGL(gn_apply_bf16_kernel, dim3(B * splits), dim3(256), 0, stream, x, stats, gamma, beta, (const __bf16*)res16,
+                     (__bf16*)y16, HW, C, G, splits, relu, eps);
   return avlen_launch_status();
 }
 

@@ -43,6 +43,20 @@ class FlatParams:
                 p.grad = self.grad_view(n, p.shape)
         self.device = dev
         self._ptrs = {n: p.data_ptr() for n, p in named}
+        # bf16 shadow of the whole buffer (same offsets): the w16 operands of the bf16 fast path
+        self.flat16 = torch.zeros(off, dtype=torch.bfloat16, device=dev)
+
+    def refresh16(self, trained_only=False):
+        n = self.n_trained if trained_only else self.flat.numel()
+        if n:
+            L.call("avlen_cast_bf16", P(self.flat), n, P(self.flat16), n, 1, n, L.stream())
+
+    def shadow_ptr(self, t):
+        """bf16 shadow address of parameter tensor t (a view into flat), or None."""
+        off = (t.data_ptr() - self.flat.data_ptr()) // 4
+        if off < 0 or off >= self.flat.numel():
+            return None
+        return C.c_void_p(self.flat16.data_ptr() + 2 * off)
 
     def intact(self, module):
         for n, p in module.named_parameters():
@@ -79,8 +93,11 @@ def P(t, off_floats=0):
     return C.c_void_p(t.data_ptr() + 4 * off_floats)
 
 
-def linear_view(w, b):
-    return L.Linear(P(w), P(b) if b is not None else None, w.shape[0], w.shape[1])
+def linear_view(w, b, flat=None):
+    v = L.Linear(P(w), P(b) if b is not None else None, w.shape[0], w.shape[1])
+    if flat is not None and w.shape[1] % 8 == 0:
+        v.w16, v.ld16 = flat.shadow_ptr(w), w.shape[1]
+    return v
 
 
 def affine_view(m):
@@ -91,30 +108,42 @@ class Packed:
     """Conv / post-flatten fc weights re-laid out for the NHWC implicit-GEMM kernels.  The packed copies
     are derived data: rebuilt (by HIP kernels) whenever the canonical parameters may have changed."""
 
-    def __init__(self, device):
-        self.device, self.bufs, self.jobs = device, [], []
+    def __init__(self, device, flat=None):
+        self.device, self.bufs, self.jobs, self.flat = device, [], [], flat
 
     def conv(self, conv, has_bias):
         O, I, KH, KW = conv.weight.shape
         buf = torch.empty(O * KH * KW * I, dtype=torch.float32, device=self.device)
-        self.bufs.append(buf)
-        self.jobs.append(("conv", conv.weight, buf, (O, I, KH, KW)))
-        return L.Conv(P(buf), P(conv.bias) if has_bias else None, I, O, KH, KW, conv.stride[0], conv.padding[0])
+        c16 = max(8, I)
+        assert c16 & (c16 - 1) == 0, "bf16 conv path needs a power-of-two channel count"
+        buf16 = torch.empty(O * KH * KW * c16, dtype=torch.bfloat16, device=self.device)
+        self.bufs += [buf, buf16]
+        self.jobs.append(("conv", conv.weight, buf, buf16, (O, I, KH, KW), c16))
+        v = L.Conv(P(buf), P(conv.bias) if has_bias else None, I, O, KH, KW, conv.stride[0], conv.padding[0])
+        v.w16, v.cin16 = P(buf16), c16
+        return v
 
     def fc_after_flatten(self, lin, C_, HW):
         O = lin.weight.shape[0]
         buf = torch.empty(O * C_ * HW, dtype=torch.float32, device=self.device)
-        self.bufs.append(buf)
-        self.jobs.append(("fc", lin.weight, buf, (O, C_, HW)))
-        return L.Linear(P(buf), P(lin.bias), O, C_ * HW)
+        buf16 = torch.empty(O * C_ * HW, dtype=torch.bfloat16, device=self.device)
+        self.bufs += [buf, buf16]
+        self.jobs.append(("fc", lin.weight, buf, buf16, (O, C_, HW), 0))
+        v = L.Linear(P(buf), P(lin.bias), O, C_ * HW)
+        v.w16, v.ld16 = P(buf16), C_ * HW
+        return v
 
     def refresh(self):
         st = L.stream()
-        for kind, w, buf, dims in self.jobs:
+        for kind, w, buf, buf16, dims, c16 in self.jobs:
             if kind == "conv":
                 L.call("avlen_pack_conv_weight", P(w), P(buf), *dims, st)
+                L.call("avlen_pack_conv_weight_bf16", P(w), P(buf16), *dims, c16, st)
             else:
                 L.call("avlen_pack_fc_after_flatten", P(w), P(buf), *dims, st)
+                L.call("avlen_pack_fc_after_flatten_bf16", P(w), P(buf16), *dims, st)
+        if self.flat is not None:
+            self.flat.refresh16()
 
 
 def resnet18_view(net, packed):
@@ -148,53 +177,51 @@ def cnn3_view(net, packed):
     return s
 
 
-def mha_view(m):
-    return L.Mha(L.Linear(P(m.in_proj_weight), P(m.in_proj_bias), m.in_proj_weight.shape[0], m.in_proj_weight.shape[1]),
-                 linear_view(m.out_proj.weight, m.out_proj.bias))
+def mha_view(m, flat=None):
+    return L.Mha(linear_view(m.in_proj_weight, m.in_proj_bias, flat), linear_view(m.out_proj.weight, m.out_proj.bias, flat))
 
 
-def transformer_view(t, d, nhead):
+def transformer_view(t, d, nhead, flat=None):
     s = L.Transformer()
     e, q = t.encoder.layers[0], t.decoder.layers[0]
-    s.enc = L.EncLayer(mha_view(e.self_attn), linear_view(e.linear1.weight, e.linear1.bias),
-                       linear_view(e.linear2.weight, e.linear2.bias), affine_view(e.norm1), affine_view(e.norm2))
+    lv = lambda m: linear_view(m.weight, m.bias, flat)
+    s.enc = L.EncLayer(mha_view(e.self_attn, flat), lv(e.linear1), lv(e.linear2), affine_view(e.norm1), affine_view(e.norm2))
     s.enc_norm = affine_view(t.encoder.norm)
-    s.dec = L.DecLayer(mha_view(q.self_attn), mha_view(q.multihead_attn), linear_view(q.linear1.weight, q.linear1.bias),
-                       linear_view(q.linear2.weight, q.linear2.bias), affine_view(q.norm1), affine_view(q.norm2),
-                       affine_view(q.norm3))
+    s.dec = L.DecLayer(mha_view(q.self_attn, flat), mha_view(q.multihead_attn, flat), lv(q.linear1), lv(q.linear2),
+                       affine_view(q.norm1), affine_view(q.norm2), affine_view(q.norm3))
     s.dec_norm = affine_view(t.decoder.norm)
     s.d, s.nhead = d, nhead
     return s
 
 
-def smt_view(enc):
+def smt_view(enc, flat=None):
     s = L.Smt()
     s.pose = linear_view(enc.pose_encoder.weight, enc.pose_encoder.bias)
-    s.fus0 = linear_view(enc.fusion_encoder[0].weight, enc.fusion_encoder[0].bias)
-    s.fus2 = linear_view(enc.fusion_encoder[2].weight, enc.fusion_encoder[2].bias)
-    s.tr = transformer_view(enc.transformer, enc._dim_feedforward, enc._nhead)
+    s.fus0 = linear_view(enc.fusion_encoder[0].weight, enc.fusion_encoder[0].bias, flat)
+    s.fus2 = linear_view(enc.fusion_encoder[2].weight, enc.fusion_encoder[2].bias, flat)
+    s.tr = transformer_view(enc.transformer, enc._dim_feedforward, enc._nhead, flat)
     return s
 
 
-def dialog_view(enc):
+def dialog_view(enc, flat=None):
     s = L.Dialog()
-    s.fus0 = linear_view(enc.fusion_encoder[0].weight, enc.fusion_encoder[0].bias)
-    s.fus2 = linear_view(enc.fusion_encoder[2].weight, enc.fusion_encoder[2].bias)
-    s.tr = transformer_view(enc.dialog_transformer, enc._dim_feedforward, enc._nhead)
+    s.fus0 = linear_view(enc.fusion_encoder[0].weight, enc.fusion_encoder[0].bias, flat)
+    s.fus2 = linear_view(enc.fusion_encoder[2].weight, enc.fusion_encoder[2].bias, flat)
+    s.tr = transformer_view(enc.dialog_transformer, enc._dim_feedforward, enc._nhead, flat)
     s.pe = P(enc.pos_encode.pe)
     s.pe_len = enc.pos_encode.pe.shape[0]
     return s
 
 
-def clip_view(clip):
+def clip_view(clip, flat=None):
     s = L.ClipText()
     s.tok_emb, s.pos_emb = P(clip.token_embedding.weight), P(clip.positional_embedding)
     for i, blk in enumerate(clip.transformer.resblocks):
         b = s.block[i]
         b.ln1, b.ln2 = affine_view(blk.ln_1), affine_view(blk.ln_2)
-        b.attn = mha_view(blk.attn)
-        b.fc = linear_view(blk.mlp.c_fc.weight, blk.mlp.c_fc.bias)
-        b.proj = linear_view(blk.mlp.c_proj.weight, blk.mlp.c_proj.bias)
+        b.attn = mha_view(blk.attn, flat)
+        b.fc = linear_view(blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, flat)
+        b.proj = linear_view(blk.mlp.c_proj.weight, blk.mlp.c_proj.bias, flat)
     s.ln_final = affine_view(clip.ln_final)
     s.text_proj = P(clip.text_projection)
     s.vocab, s.ctx = clip.vocab_size, clip.context_length

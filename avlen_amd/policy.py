@@ -92,7 +92,7 @@ class Policy(nn.Module):
                                "(there is no CPU fallback)")
         if self._eng is None:
             flat = E.FlatParams(self, self.TRAINED_PREFIXES)
-            packed = E.Packed(flat.device)
+            packed = E.Packed(flat.device, flat)
             eng = {"flat": flat, "packed": packed}
             self._build_views(eng, packed)
             ptr2name = {p.data_ptr(): n for n, p in self.named_parameters()}
@@ -286,7 +286,7 @@ class _SMTBase(Net):
         eng["depth"] = E.resnet18_view(self.visual_encoder.depth_encoder, packed)
         eng["audio"] = E.cnn3_view(self.goal_encoder, packed)
         eng["action"] = E.linear_view(self.action_encoder.weight, self.action_encoder.bias)
-        eng["smt"] = E.smt_view(self.smt_state_encoder)
+        eng["smt"] = E.smt_view(self.smt_state_encoder, eng["flat"])
 
     def features(self, pol, obs, prev_actions, extra=None):
         """-> feats (B, F) = [visual 128 | action 16 | audio 128 | (category 21) | pose 4 | (extra)], goal (B,d)."""
@@ -322,7 +322,7 @@ class _SMTBase(Net):
                E.P(goal), self._hidden_size, B, st)
         return feats, goal
 
-    def smt(self, pol, feats, goal, ext_memory, ext_memory_masks, save_key="smt", mem_index=None):
+    def smt(self, pol, feats, goal, ext_memory, ext_memory_masks, save_key="smt", mem_index=None, save=False):
         eng = pol._engine()
         B, F = feats.shape
         dev = feats.device
@@ -339,7 +339,7 @@ class _SMTBase(Net):
         ws = pol._ws.get(save_key, nb, dev)
         L.call("avlen_smt_fwd", C.byref(eng["smt"]), E.P(feats), E.P(mem) if mem is not None else None,
                E.P(mem_index) if mem_index is not None else None, NC, E.P(masks) if masks is not None else None,
-               E.P(goal), E.P(out), B, M, F, self._x_dims - 4, cto, pol.prec, E.P(ws), nb, L.stream())
+               E.P(goal), E.P(out), B, M, F, self._x_dims - 4, cto, 1 if save else 0, pol.prec, E.P(ws), nb, L.stream())
         return out, (ws, nb, B, M, F, cto)
 
 
@@ -387,9 +387,9 @@ class AudioNavOptionNet(_SMTBase):
         return self._qcnt_emb
 
     def run(self, pol, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks,
-            query_state, last_query_info, mem_index=None, save_key="smt"):
+            query_state, last_query_info, mem_index=None, save_key="smt", save=False):
         feats, goal = self.features(pol, observations, prev_actions, extra=query_state)      # [x | query_state]
-        x_att, saved = self.smt(pol, feats, goal, ext_memory, ext_memory_masks, save_key, mem_index)
+        x_att, saved = self.smt(pol, feats, goal, ext_memory, ext_memory_masks, save_key, mem_index, save)
         B = feats.shape[0]
         lqi = _f32(last_query_info)
         row = torch.empty(B, self._feature_size, device=feats.device)                          # [x | last_query_info]
@@ -421,7 +421,7 @@ class AudioNavDialogNet(_SMTBase):
 
     def build_views(self, eng, packed):
         super().build_views(eng, packed)
-        eng["clip"] = E.clip_view(self.clip)
+        eng["clip"] = E.clip_view(self.clip, eng["flat"])
         eng["dialog_layer"] = E.linear_view(self.dialog_layer.weight, self.dialog_layer.bias)
         eng["dialog"] = E.dialog_view(self.dialog_state_encoder)
 

@@ -82,7 +82,7 @@ class PPO(nn.Module):
         flat.grad.zero_()
         x_att, _, _ = net.run(pol, b["obs"], None, b["prev_actions"], b["masks"], rollouts.em_option.memory,
                               b["em_masks"], b["query_state"], b["last_query_info"], mem_index=b["mem_index"],
-                              save_key="smt_train")
+                              save_key="smt_train", save=True)
         feats, goal, (ws, nb, B, M, F, cto) = net._last
         R, d = x_att.shape
         dev = x_att.device
@@ -106,6 +106,7 @@ class PPO(nn.Module):
         L.call("avlen_grad_sumsq", E.P(flat.grad), flat.n_trained, E.P(ad["norm_sq"]), st)
         L.call("avlen_adam_step", E.P(flat.flat), E.P(flat.grad), E.P(ad["m"]), E.P(ad["v"]), flat.n_trained, float(lr),
                0.9, 0.999, float(eps), ad["step"], float(self.max_grad_norm), E.P(ad["norm_sq"]), st)
+        flat.refresh16(trained_only=True)                 # bf16 shadows of the updated weights (rollout fast path)
 
     def update(self, rollouts):
         advantages = self.get_advantages(rollouts).contiguous()

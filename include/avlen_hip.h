@@ -32,8 +32,11 @@ typedef struct ihipStream_t* avlen_stream_t;        /* == hipStream_t */
 #define AVLEN_ACT_QUICKGELU 2
 
 /* ------------------------------------------------------------------ parameter views ---------- */
-typedef struct { float* w; float* b; int out_f; int in_f; } avlen_linear;          /* w[out_f][in_f] */
-typedef struct { float* w; float* b; int cin, cout, kh, kw, stride, pad; } avlen_conv; /* w packed [cout][kh][kw][cin] */
+/* w[out_f][in_f] fp32 (canonical).  w16: optional bf16 shadow of the same matrix, row stride ld16 (multiple of 8,
+ * padding zero) used by the bf16 fast path; NULL -> that layer runs on the fp32-staged kernel. */
+typedef struct { float* w; float* b; int out_f; int in_f; void* w16; int ld16; } avlen_linear;
+/* w packed [cout][kh][kw][cin] fp32; w16: bf16 [cout][kh][kw][cin16] with cin16 = max(8, cin) zero-padded. */
+typedef struct { float* w; float* b; int cin, cout, kh, kw, stride, pad; void* w16; int cin16; } avlen_conv;
 typedef struct { float* g; float* b; } avlen_affine;                               /* norm scale / shift */
 typedef struct { avlen_conv conv1, conv2, down; avlen_affine bn1, bn2, bnd; int has_down; } avlen_resblock;
 /* CustomResNet (smt_resnet.py:56-149): conv7x7 + GroupNorm(16) + 8 basic blocks + fc(8192->64).
@@ -78,6 +81,24 @@ int avlen_conv2d_nhwc(const float* X, const float* Wp, const float* bias, const 
 /* OIHW -> [O][KH][KW][I] (conv) and (O, C*H*W) -> (O, H*W*C) (fc after an NCHW flatten). */
 int avlen_pack_conv_weight(const float* w_oihw, float* w_packed, int O, int I, int KH, int KW, avlen_stream_t stream);
 int avlen_pack_fc_after_flatten(const float* w, float* w_packed, int O, int C, int HW, avlen_stream_t stream);
+
+/* ---- bf16-operand fast path (rollout "perf mode"): A, W already bf16 in HBM (leading dims multiples of 8,
+ * padding zero-filled), tiles staged HBM->LDS with global_load_lds, BK=64, double-buffered; outputs fp32
+ * (C32) and/or bf16 (C16), either may be NULL.  Same math as avlen_gemm / avlen_conv2d_nhwc with prec=BF16. */
+int avlen_gemm_bf16(const void* A, int lda, const void* B, int ldb, float* C32, int ldc32, void* C16, int ldc16,
+                    const float* bias, const float* residual, int ldr, int M, int N, int K, int act, void* ws,
+                    size_t ws_bytes, avlen_stream_t stream);
+size_t avlen_gemm_bf16_workspace_bytes(int M, int N);
+/* X NHWC bf16 with Cin a power of two >= 8 (conv1's 3/1 input channels are zero-padded to 8); Wp bf16
+ * [Cout][KH][KW][Cin].  gn_stats (optional, pre-zeroed, [B][2][Cout]): the epilogue adds each sample's
+ * per-channel sum and sum of squares of the raw output, so GroupNorm needs no separate statistics pass. */
+int avlen_conv2d_nhwc_bf16(const void* X, const void* Wp, const float* bias, const float* residual, float* Y32,
+                           void* Y16, float* gn_stats, int B, int H, int W, int Cin, int Cout, int KH, int KW,
+                           int stride, int pad, int act, void* ws, size_t ws_bytes, avlen_stream_t stream);
+int avlen_cast_bf16(const float* src, int ld_src, void* dst, int ld_dst, long rows, int cols, avlen_stream_t stream);
+int avlen_pack_conv_weight_bf16(const float* w_oihw, void* w_packed, int O, int I, int KH, int KW, int Cpad,
+                                avlen_stream_t stream);
+int avlen_pack_fc_after_flatten_bf16(const float* w, void* w_packed, int O, int C, int HW, avlen_stream_t stream);
 
 /* ------------------------------------------------------------------ normalisation ------------- */
 /* y = [relu]( GroupNorm_G(x)*g + b [+ residual] ), x NHWC (B,HW,C).  smt_resnet.py:30-33,40-51,79. */
@@ -150,11 +171,13 @@ int avlen_cnn3_fwd(const avlen_cnn3* net, const float* x, int B, int H, int W, f
  *   out    (B, d)
  * current_token_only=1 is the `pretraining=True` configuration (:126-129): every memory key is masked,
  * so only the current token is computed (bit-for-bit the same function, 200x fewer FLOPs).
- * When `save` != 0 the workspace keeps what avlen_smt_bwd needs. */
+ * save_for_backward != 0: the workspace keeps what avlen_smt_bwd needs (fp32-staged kernels); == 0 with
+ * prec = BF16 and full memory takes the bf16 fast path (inference only). */
 size_t avlen_smt_workspace_bytes(const avlen_smt* p, int B, int M, int F, int current_token_only);
 int avlen_smt_fwd(const avlen_smt* p, const float* x, const float* memory, const int32_t* mem_index, int NC,
                   const float* masks, const float* goal, float* out, int B, int M, int F, int pose_col,
-                  int current_token_only, int prec, void* ws, size_t ws_bytes, avlen_stream_t stream);
+                  int current_token_only, int save_for_backward, int prec, void* ws, size_t ws_bytes,
+                  avlen_stream_t stream);
 /* Backward of avlen_smt_fwd w.r.t. the parameters only (x, memory and goal carry no gradient on this
  * path: policy.py:1035-1036).  `ws` must be the forward's workspace, untouched.  Gradients are
  * ACCUMULATED into `g` (same layout as p). */

@@ -125,6 +125,36 @@ def test_option_policy_bf16_tolerance(specs):
     assert err_v < 5e-2 and err_p < 2e-2
 
 
+@pytest.mark.parametrize("kind", ["goal", "dialog"])
+def test_bf16_fast_path_policies(specs, kind):
+    """pi_g (full 300-slot memory) and pi_l (CLIP text + dialog) on the bf16 fast path (bf16 activations, glds GEMM,
+    fused GN statistics) vs the fp32 reference goldens / oracle; tolerances are the measured bf16 envelope."""
+    B = 3
+    pol = build(kind, precision="bf16")
+    if kind == "goal":
+        load_fixture(pol, "goal", specs); pol.cuda()
+        tag, M = "goal_m300", 300
+        g = golden("policy_" + tag)
+        obs = cu(fx.observations(tag, B))
+        mem, mk = fx.memory(tag, M, B, 276, 272).cuda(), fx.mask_patterns(tag, B, M).cuda()
+        pa, act = fx.ints(tag + ".pa", (B, 1), 4).cuda(), fx.ints(tag + ".a", (B, 1), 4).cuda()
+        v, lp, ent, _, row = pol.evaluate_actions(obs, torch.zeros(1, B, 512, device="cuda"), pa,
+                                                  torch.ones(B, 1, device="cuda"), act, mem, mk)
+        ev, er = float(np.abs(v.cpu().numpy() - g["value"]).max()), float(np.abs(row.cpu().numpy() - g["row"]).max())
+        print(f"pi_g bf16 fast path: max |value err| {ev:.4g}, max |feature err| {er:.4g}")
+        assert ev < 5e-2 and er < 8e-2
+    else:
+        torch.manual_seed(0)
+        sd = {k: v.clone() for k, v in pol.state_dict().items() if k.startswith("net.clip.")}
+        toks = fx.dialog_tokens("clip", B)
+        ref = R.clip_encode_text(sd, "net.clip", toks)
+        pol.cuda()
+        out = pol.net.encode_text(pol, toks.cuda())
+        e = float((out.cpu() - ref).abs().max() / ref.abs().max())
+        print(f"CLIP text bf16 fast path: max rel err {e:.4g}")
+        assert e < 3e-2
+
+
 def test_option_distractor(specs):
     B, M = 3, 6
     pol = build("option", distractor=True)
@@ -320,7 +350,7 @@ def test_gradients_match_oracle_autograd(specs):
     smt_g, heads_g = agent._grad_views(eng)
     flat.grad.zero_()
     x_att, _, _ = pol.net.run(pol, cu(obs), None, pa.cuda(), None, mem.cuda(), mk.cuda(), qs.cuda(), lqi.cuda(),
-                              save_key="smt_train")
+                              save_key="smt_train", save=True)
     _, goal, (ws, nb, Bq, Mq, F, cto) = pol.net._last
     norm, d_feats, loss = torch.empty(2, device="cuda"), torch.empty(B, 256, device="cuda"), torch.zeros(6, device="cuda")
     tens = [t.cuda().contiguous() for t in (act, old_lp, adv, rl, vp, ret, ug)]

@@ -270,3 +270,51 @@ def test_gae_adam_extmem(L):
                L.ptr(ns), L.stream())
     torch.cuda.synchronize()
     assert rel_err(pd, p) < 1e-6 and rel_err(md_, mm) < 1e-5
+
+
+# ------------------------------------------------------------------ bf16 fast path (igemm2.hip)
+@pytest.mark.parametrize("M,N,K,act", [(4928, 2048, 512, 2), (4928, 512, 2048, 0), (300, 256, 320, 1), (64, 64, 8192, 0),
+                                       (130, 21, 72, 0), (19264, 768, 256, 0), (257, 130, 200, 0)])
+def test_gemm_bf16_fast_path(L, M, N, K, act):
+    torch.manual_seed(10)
+    A, W = torch.randn(M, K), torch.randn(N, K) / math.sqrt(K)
+    b, r = torch.randn(N), torch.randn(M, N)
+    A16, W16 = dev(A.bfloat16()), dev(W.bfloat16())
+    ref = A16.float().cpu() @ W16.float().cpu().t() + b
+    ref = torch.relu(ref) if act == 1 else (ref * torch.sigmoid(1.702 * ref) if act == 2 else ref)
+    ref = ref + r
+    C32 = torch.empty(M, N, device="cuda"); C16 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    nb = L.lib.avlen_gemm_bf16_workspace_bytes(M, N); ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    L.call("avlen_gemm_bf16", L.ptr(A16), K, L.ptr(W16), K, L.ptr(C32), N, L.ptr(C16), N, L.ptr(dev(b)), L.ptr(dev(r)), N, M,
+           N, K, act, L.ptr(ws), nb, L.stream())
+    torch.cuda.synchronize()
+    assert rel_err(C32, ref) < 1e-5                 # same bf16 operands, fp32 accumulate
+    assert rel_err(C16.float(), ref) < 1e-2
+
+
+@pytest.mark.parametrize("cfg", [(2, 64, 3, 16, 7, 1, 3), (2, 64, 16, 16, 3, 1, 1), (3, 64, 16, 32, 3, 2, 1),
+                                 (2, 32, 16, 32, 1, 2, 0), (64, 8, 128, 128, 3, 1, 1), (5, 16, 64, 128, 3, 2, 1)])
+def test_conv_bf16_with_fused_groupnorm_stats(L, cfg):
+    """bf16 implicit-GEMM conv (zero-padded channels) + GroupNorm statistics from its epilogue + bf16 GN apply,
+    against conv2d + group_norm in fp32 on the bf16-rounded operands."""
+    B, H, Cin, Cout, k, s, p = cfg
+    torch.manual_seed(11)
+    x = torch.randn(B, H, H, Cin); w = torch.randn(Cout, Cin, k, k) / math.sqrt(Cin * k * k)
+    g, be = torch.rand(Cout) + 0.5, torch.randn(Cout)
+    Cp = max(8, Cin)
+    x16 = torch.zeros(B, H, H, Cp, dtype=torch.bfloat16); x16[..., :Cin] = x.bfloat16()
+    OH = (H + 2 * p - k) // s + 1
+    res = torch.randn(B, OH, OH, Cout).bfloat16()
+    raw_ref = F.conv2d(x.bfloat16().float().permute(0, 3, 1, 2), w.bfloat16().float(), None, stride=s, padding=p)
+    y_ref = torch.relu(F.group_norm(raw_ref, 16, g, be, 1e-5).permute(0, 2, 3, 1) + res.float())
+    wp16 = torch.empty(Cout, k, k, Cp, device="cuda", dtype=torch.bfloat16)
+    L.call("avlen_pack_conv_weight_bf16", L.ptr(dev(w)), L.ptr(wp16), Cout, Cin, k, k, Cp, L.stream())
+    raw = torch.empty(B, OH, OH, Cout, device="cuda"); stats = torch.zeros(B, 2, Cout, device="cuda")
+    nb = L.lib.avlen_gemm_bf16_workspace_bytes(B * OH * OH, Cout); ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    L.call("avlen_conv2d_nhwc_bf16", L.ptr(dev(x16)), L.ptr(wp16), None, None, L.ptr(raw), None, L.ptr(stats), B, H, H, Cp,
+           Cout, k, k, s, p, 0, L.ptr(ws), nb, L.stream())
+    torch.cuda.synchronize()
+    assert rel_err(raw, raw_ref.permute(0, 2, 3, 1)) < 1e-5
+    sums = raw_ref.sum(dim=(2, 3)); sq = (raw_ref ** 2).sum(dim=(2, 3))
+    assert rel_err(stats[:, 0], sums) < 1e-4 and rel_err(stats[:, 1], sq) < 1e-4
+    # bf16 GN-apply through the module-level tower is covered by the policy tests; here check the stats only
