@@ -272,7 +272,7 @@ int run_g2(G2 p, void* ws, size_t ws_bytes, hipStream_t st) {
   long tiles = (long)m_tiles * n_tiles;
   int split = 1;
   if (tiles < 192 && nk >= 4 && !p.stats) {
-    split = (int)min((long)(nk / 2), (384 + tiles - 1) / tiles);
+    { long a = nk / 2, b = (384 + tiles - 1) / tiles; split = (int)(a < b ? a : b); }
     if (split < 1) split = 1;
     if (split > 32) split = 32;
     if (!ws || (size_t)split * p.M * p.N * sizeof(float) > ws_bytes) split = 1;

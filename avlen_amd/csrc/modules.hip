@@ -9,6 +9,9 @@
 #include "common.h"
 #include "../../include/avlen_hip.h"
 #include <math.h>
+#include <algorithm>
+
+static inline size_t zmax(size_t a, size_t b) { return a > b ? a : b; }
 
 #include "internal.h"
 
@@ -353,9 +356,9 @@ size_t cnn3_ws_bf16(const avlen_cnn3* n, int B, int H, int W) {
   size_t mx = 0;
   for (int i = 0; i < 3; i++) {
     tot += (size_t)B * oh[i] * ow[i] * n->conv[i].cout * 2 + 256;
-    mx = max(mx, avlen_gemm_bf16_workspace_bytes(B * oh[i] * ow[i], n->conv[i].cout));
+    mx = zmax(mx, avlen_gemm_bf16_workspace_bytes(B * oh[i] * ow[i], n->conv[i].cout));
   }
-  return tot + max(mx, avlen_gemm_bf16_workspace_bytes(B, n->fc.out_f)) + 4096;
+  return tot + zmax(mx, avlen_gemm_bf16_workspace_bytes(B, n->fc.out_f)) + 4096;
 }
 int cnn3_fwd_bf16(const avlen_cnn3* n, const float* x, int B, int H, int W, float* out, int ld_out, void* ws,
                   size_t ws_bytes, hipStream_t st) {
@@ -367,7 +370,7 @@ int cnn3_fwd_bf16(const avlen_cnn3* n, const float* x, int B, int H, int W, floa
   size_t mx = avlen_gemm_bf16_workspace_bytes(B, n->fc.out_f);
   for (int i = 0; i < 3; i++) {
     a[i] = w.take<bf16>((size_t)B * oh[i] * ow[i] * n->conv[i].cout);
-    mx = max(mx, avlen_gemm_bf16_workspace_bytes(B * oh[i] * ow[i], n->conv[i].cout));
+    mx = zmax(mx, avlen_gemm_bf16_workspace_bytes(B * oh[i] * ow[i], n->conv[i].cout));
   }
   void* gws = w.take<char>(mx);
   TRY(avlen_cast_bf16(x, n->conv[0].cin, x16, 8, (long)B * H * W, n->conv[0].cin, st));     // channel-pad to 8
@@ -390,7 +393,7 @@ int cnn3_fwd_bf16(const avlen_cnn3* n, const float* x, int B, int H, int W, floa
 extern "C" size_t avlen_resnet18_workspace_bytes(int B) {
   size_t act = (size_t)B * 64 * 64 * 16 * sizeof(float);
   size_t v1 = 5 * (act + 256) + avlen_groupnorm_workspace_bytes(B, 128) + GEMM_SCRATCH + 4096;
-  return max(v1, resnet18_ws_bf16(B));
+  return zmax(v1, resnet18_ws_bf16(B));
 }
 
 extern "C" int avlen_resnet18_fwd(const avlen_resnet18* net, const float* img, int B, int S, int C, float divisor,
@@ -448,7 +451,7 @@ extern "C" size_t avlen_cnn3_workspace_bytes(const avlen_cnn3* n, int B, int H, 
   int oh[3], ow[3]; cnn3_dims(n, H, W, oh, ow);
   size_t tot = 0;
   for (int i = 0; i < 3; i++) tot += (size_t)B * oh[i] * ow[i] * n->conv[i].cout * sizeof(float) + 256;
-  return max(tot + GEMM_SCRATCH + 1024, cnn3_ws_bf16(n, B, H, W));
+  return zmax(tot + GEMM_SCRATCH + 1024, cnn3_ws_bf16(n, B, H, W));
 }
 extern "C" int avlen_cnn3_fwd(const avlen_cnn3* n, const float* x, int B, int H, int W, float* out, int ld_out,
                               int prec, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -711,7 +714,7 @@ void smt16_layout(WsBump& w, Smt16Ws& s, const avlen_smt* p, long B, long M, int
   t.U3 = w.take<float>(B * d); t.Y3 = w.take<float>(B * d);
   t.md1 = w.take<float>(B); t.rd1 = w.take<float>(B); t.md2 = w.take<float>(B); t.rd2 = w.take<float>(B);
   t.md3 = w.take<float>(B); t.rd3 = w.take<float>(B); t.mf = w.take<float>(B); t.rf = w.take<float>(B);
-  s.gwsb = max((size_t)GEMM_SCRATCH, avlen_gemm_bf16_workspace_bytes(128, 768));
+  s.gwsb = zmax((size_t)GEMM_SCRATCH, avlen_gemm_bf16_workspace_bytes(128, 768));
   s.gws = w.take<char>(s.gwsb);
 }
 
@@ -756,7 +759,7 @@ extern "C" size_t avlen_smt_workspace_bytes(const avlen_smt* p, int B, int M, in
   WsBump w(nullptr, 0); SmtWs s;
   smt_layout(w, s, p, B, M, F, cto != 0);
   size_t v1 = w.off + 4096;
-  return (!cto && smt_has16(p)) ? max(v1, smt16_ws_bytes(p, B, M, F)) : v1;
+  return (!cto && smt_has16(p)) ? zmax(v1, smt16_ws_bytes(p, B, M, F)) : v1;
 }
 
 extern "C" int avlen_smt_fwd(const avlen_smt* p, const float* x, const float* memory, const int32_t* mem_index, int NC,

@@ -58,6 +58,25 @@ __global__ __launch_bounds__(256) void gn_apply_bf16_kernel(const float* __restr
   }
 }
 
+// Deterministic block reduction of per-thread 4-channel partials.  Thread u owns channels c0(u)..c0(u)+3 with
+// c0(u) = (c0_t0 + 4u) % C (c0_t0 a multiple of 4); channel c is summed over its 1024/C owners in a fixed order.
+__device__ __forceinline__ void reduce_channels(float4 s, float4 q, int c0_t0, int C, float* s_part /*[2][256][4]*/,
+                                                float* s_sum, float* s_sq) {
+  const int tid = threadIdx.x;
+  float* ps = s_part + tid * 4; float* pq = s_part + 1024 + tid * 4;
+  ps[0] = s.x; ps[1] = s.y; ps[2] = s.z; ps[3] = s.w;
+  pq[0] = q.x; pq[1] = q.y; pq[2] = q.z; pq[3] = q.w;
+  __syncthreads();
+  if (tid < C) {
+    const int step = C / 4, off = tid & 3;
+    const int u0 = (((tid & ~3) - c0_t0 + C) % C) / 4;
+    float a = 0.f, b = 0.f;
+    for (int u = u0; u < 256; u += step) { a += s_part[u * 4 + off]; b += s_part[1024 + u * 4 + off]; }
+    s_sum[tid] = a; s_sq[tid] = b;
+  }
+  __syncthreads();
+}
+
 // One block per (sample, spatial split).  C <= 128, C % 4 == 0, blockDim*4 % C == 0, so every
 // thread always touches the same 4 channels and keeps 4 running sums in registers.
 // Two-kernel form so that small batches still fill the chip:
@@ -66,10 +85,9 @@ __global__ __launch_bounds__(256) void gn_apply_bf16_kernel(const float* __restr
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, float* __restrict__ part,
                                                        int HW, int C, int splits) {
   __shared__ float s_sum[128], s_sq[128];
+  __shared__ float s_part[2048];
   const int b = blockIdx.x / splits, sp = blockIdx.x % splits;
   const int tid = threadIdx.x;
-  if (tid < C) { s_sum[tid] = 0.f; s_sq[tid] = 0.f; }
-  __syncthreads();
   const long n4 = (long)HW * C / 4;                         // float4 per sample
   const long per = (n4 + splits - 1) / splits;
   const long beg = sp * per, end = min(n4, beg + per);
@@ -81,10 +99,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
   }
-  const int c0 = (int)(((beg + tid) * 4) % C);
-  atomicAdd(&s_sum[c0], s.x); atomicAdd(&s_sum[c0 + 1], s.y); atomicAdd(&s_sum[c0 + 2], s.z); atomicAdd(&s_sum[c0 + 3], s.w);
-  atomicAdd(&s_sq[c0], q.x); atomicAdd(&s_sq[c0 + 1], q.y); atomicAdd(&s_sq[c0 + 2], q.z); atomicAdd(&s_sq[c0 + 3], q.w);
-  __syncthreads();
+  reduce_channels(s, q, (int)((beg * 4) % C), C, s_part, s_sum, s_sq);
   if (tid < C) {
     float* o = part + ((long)(b * splits + sp) * 2) * C;
     o[tid] = s_sum[tid];
@@ -238,9 +253,8 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const float* __restrict__
                                                        const float* __restrict__ beta, const float* __restrict__ res,
                                                        float* __restrict__ y, int HW, int C, int G, int relu, float eps) {
   __shared__ float s_sum[128], s_sq[128], s_scale[128], s_shift[128];
+  __shared__ float s_part[2048];
   const int b = blockIdx.x, tid = threadIdx.x;
-  if (tid < C) { s_sum[tid] = 0.f; s_sq[tid] = 0.f; }
-  __syncthreads();
   const long n4 = (long)HW * C / 4;
   const long base = (long)b * HW * C;
   const float4* xp = reinterpret_cast<const float4*>(x + base);
@@ -251,9 +265,7 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const float* __restrict__
     q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
   }
   const int c0 = (tid * 4) % C;
-  atomicAdd(&s_sum[c0], s.x); atomicAdd(&s_sum[c0 + 1], s.y); atomicAdd(&s_sum[c0 + 2], s.z); atomicAdd(&s_sum[c0 + 3], s.w);
-  atomicAdd(&s_sq[c0], q.x); atomicAdd(&s_sq[c0 + 1], q.y); atomicAdd(&s_sq[c0 + 2], q.z); atomicAdd(&s_sq[c0 + 3], q.w);
-  __syncthreads();
+  reduce_channels(s, q, 0, C, s_part, s_sum, s_sq);
   const int cg = C / G;
   if (tid < G) {
     double sum = 0.0, sq = 0.0;

@@ -28,12 +28,12 @@ def sinusoid_table(n, d):
 class Workload:
     def __init__(self, num_envs, num_steps=150, spectrogram=(257, 101, 2), precision="bf16", pretraining=True,
                  em_capacity=150, ppo_epoch=2, num_mini_batch=2, device="cuda", seed=0, sampling="host",
-                 with_dialog_policy=True, with_goal_policy=True):
+                 with_dialog_policy=True, with_goal_policy=True, use_graphs=True):
         self.N, self.T, self.dev = num_envs, num_steps, torch.device(device)
         self.spec = spectrogram
         osp, asp = savi_observation_space(spectrogram), ActionSpace(4)
         torch.manual_seed(seed)
-        kw = dict(SMT_KW, precision=precision, sampling=sampling)
+        kw = dict(SMT_KW, precision=precision, sampling=sampling, use_graphs=use_graphs)
         self.pi_q = P.AudioNavOptionPolicy(osp, asp, pretraining=pretraining, use_category_input=False,
                                            query_count_emb_size=32, **kw).to(self.dev)
         self.pi_g = (P.AudioNavSMTPolicy(osp, asp, pretraining=False, use_category_input=False, **kw).to(self.dev)

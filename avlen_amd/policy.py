@@ -38,6 +38,75 @@ def _i64(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+class _Graph:
+    """One captured forward: static input buffers + the HIP graph + its (static) outputs."""
+
+    def __init__(self, pol, fn, args, by_pointer=()):
+        # `by_pointer` args (external-memory rings) are read in place: the graph is keyed on their address
+        self.static = [a if (i in by_pointer and torch.is_tensor(a)) else
+                       (a.clone() if torch.is_tensor(a) else
+                        ({k: v.clone() for k, v in a.items()} if isinstance(a, dict) else a))
+                       for i, a in enumerate(args)]
+        ws_saved = pol._ws
+        pol._ws = E.Workspaces()                         # this graph owns its scratch
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                # warm-up outside capture (lazy HIP init, attributes)
+                fn(*self.static)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.outs = fn(*self.static)
+            self.ws = pol._ws
+        finally:
+            pol._ws = ws_saved
+
+    def __call__(self, args):
+        for s, a in zip(self.static, args):
+            if torch.is_tensor(s):
+                if s.data_ptr() != a.data_ptr():
+                    s.copy_(a, non_blocking=True)
+            elif isinstance(s, dict):
+                for k in s:
+                    s[k].copy_(a[k], non_blocking=True)
+        self.graph.replay()
+        return self.outs
+
+
+def _sig(a):
+    if torch.is_tensor(a):
+        return (tuple(a.shape), a.dtype)
+    if isinstance(a, dict):
+        return tuple((k, tuple(v.shape)) for k, v in sorted(a.items()))
+    return a
+
+
+def _graphed(pol, which, fn, args):
+    # rnn_hidden_states (arg 1) and masks (arg 3) are not read by the SMT nets: keep them out of the graph
+    args = list(args)
+    rnn = args[1]
+    args[1], args[3] = None, None
+    args[0] = {k: _f32(v) for k, v in args[0].items() if k in pol.net.obs_keys}
+    by_ptr = (4, 5) if which == "vln" else (4,)          # ext_memory (+ dialog memory): persistent ring buffers
+    for i in by_ptr:
+        if torch.is_tensor(args[i]):
+            args[i] = _f32(args[i])
+    key = (which,) + tuple(_sig(a) for a in args) + tuple(args[i].data_ptr() if torch.is_tensor(args[i]) else 0
+                                                          for i in by_ptr)
+    g = pol._graphs.get(key)
+    if g is None:
+        pol._engine()                                    # flat/packed state must exist before capture
+        if len(pol._graphs) >= 16:
+            pol._graphs.clear()
+        g = pol._graphs[key] = _Graph(pol, fn, args, by_ptr)
+    outs, heads = g(args)
+    outs = list(outs)
+    outs[1] = rnn
+    return tuple(outs), dict(heads)
+
+
 class _Dist:
     """What the trainer reads off the reference's CustomFixedCategorical."""
     def __init__(self, logits, probs):
@@ -47,7 +116,7 @@ class _Dist:
 class Policy(nn.Module):
     """policy.py:39-276."""
 
-    def __init__(self, net, dim_actions, dim_actions_option=2, precision="fp32", sampling="host"):
+    def __init__(self, net, dim_actions, dim_actions_option=2, precision="fp32", sampling="host", use_graphs=False):
         super().__init__()
         self.net = net
         self.dim_actions, self.dim_actions_option = dim_actions, dim_actions_option
@@ -60,6 +129,9 @@ class Policy(nn.Module):
         self.uncertainty_option = N.CriticHeadParams(d, 2)
         self.critic_vln = N.CriticHeadParams(d)
         self.precision, self.sampling = precision, sampling
+        self.use_graphs = use_graphs          # capture each act*/get_value* forward in a HIP graph (static shapes)
+        self._graphs = {}
+        self._side = None
         self._eng = None
         self._ws = E.Workspaces()
         self._dirty = True
@@ -75,7 +147,13 @@ class Policy(nn.Module):
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
         self._eng = None
+        self._graphs = {}
         return r
+
+    def side_streams(self):
+        if self._side is None:
+            self._side = [torch.cuda.Stream() for _ in range(3)]
+        return self._side
 
     def mark_params_changed(self):
         """Call after modifying encoder weights in place (load_state_dict does it automatically)."""
@@ -119,7 +197,8 @@ class Policy(nn.Module):
         return eng[key]
 
     # ------------------------------------------------------------------ heads + sampling
-    def _run_heads(self, which, feats, action=None, deterministic=False, need_sample=True):
+    def _heads_first(self, which, feats):
+        """logits / probs / value / unct of one head set (one kernel; capturable)."""
         B, d = feats.shape
         A = self.dim_actions_option if which == "option" else self.dim_actions
         dev = feats.device
@@ -128,10 +207,16 @@ class Policy(nn.Module):
         probs = torch.empty(B, A, device=dev)
         value = torch.empty(B, 1, device=dev)
         unct = torch.empty(B, 2, device=dev) if which == "option" else None
-        st = L.stream()
         L.call("avlen_heads_fwd", C.byref(h), E.P(feats), d, A, E.P(logits), E.P(probs), E.P(value),
-               E.P(unct) if unct is not None else None, None, None, None, B, st)
-        out = {"logits": logits, "probs": probs, "value": value, "unct": unct}
+               E.P(unct) if unct is not None else None, None, None, None, B, L.stream())
+        return {"logits": logits, "probs": probs, "value": value, "unct": unct}
+
+    def _finish(self, which, feats, out, action=None, deterministic=False, need_sample=True):
+        """Action selection (host or device RNG) and the log-prob / entropy of the chosen actions."""
+        B, d = feats.shape
+        A = self.dim_actions_option if which == "option" else self.dim_actions
+        dev = feats.device
+        probs = out["probs"]
         if action is None and need_sample:
             if deterministic:
                 action = probs.argmax(dim=-1, keepdim=True)
@@ -146,35 +231,50 @@ class Policy(nn.Module):
             action = _i64(action.view(B, 1))
             logp = torch.empty(B, 1, device=dev)
             ent = torch.empty(B, device=dev)
+            h = self._heads(which)
             L.call("avlen_heads_fwd", C.byref(h), E.P(feats), d, A, None, None, None, None, E.P(action), E.P(logp),
-                   E.P(ent), B, st)
+                   E.P(ent), B, L.stream())
             out.update(action=action, log_prob=logp, entropy_rows=ent)
         return out
+
+    def _run_heads(self, which, feats, action=None, deterministic=False, need_sample=True):
+        return self._finish(which, feats, self._heads_first(which, feats), action, deterministic, need_sample)
+
+    def _forward(self, which, *net_args):
+        """net.run(...) + first heads kernel -> (net outputs tuple, heads dict); replayed from a HIP graph when
+        use_graphs is set (inputs are copied into the graph's static buffers; outputs are overwritten by the
+        next replay, so callers copy what they keep -- RolloutStorage.insert does)."""
+        def eager(*args):
+            outs = self.net.run(self, *args)
+            return outs, self._heads_first(which, outs[0])
+        if not self.use_graphs:
+            return eager(*net_args)
+        return _graphed(self, which, eager, net_args)
 
     # ------------------------------------------------------------------ reference API
     def act(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks,
             deterministic=False):
-        features, rnn_hidden_states, ext_memory_feats = self.net.run(
-            self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks)
-        h = self._run_heads("goal", features, deterministic=deterministic)
+        (features, rnn_hidden_states, ext_memory_feats), h = self._forward(
+            "goal", observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks)
+        h = self._finish("goal", features, h, deterministic=deterministic)
         return h["value"], h["action"], h["log_prob"], rnn_hidden_states, ext_memory_feats, h["probs"]
 
     def act_option(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks,
                    query_state, last_query_info, deterministic=False):
-        features, rnn_hidden_states, ext_memory_feats = self.net.run(
-            self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks, query_state,
+        (features, rnn_hidden_states, ext_memory_feats), h = self._forward(
+            "option", observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks, query_state,
             last_query_info)
-        h = self._run_heads("option", features, deterministic=deterministic)
+        h = self._finish("option", features, h, deterministic=deterministic)
         return (h["value"], h["unct"], h["action"], h["log_prob"], rnn_hidden_states, ext_memory_feats, h["probs"])
 
     def act_dialog(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_dialog,
                    ext_memory_masks, all_dialog, agent_step, deterministic=False, without_dialog=False):
         if without_dialog:
             all_dialog = None
-        features, rnn_hidden_states, ext_memory_feats, ext_memory_dialog_feats = self.net.run(
-            self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_dialog,
+        (features, rnn_hidden_states, ext_memory_feats, ext_memory_dialog_feats), h = self._forward(
+            "vln", observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_dialog,
             ext_memory_masks, all_dialog, agent_step)
-        h = self._run_heads("vln", features, deterministic=deterministic)
+        h = self._finish("vln", features, h, deterministic=deterministic)
         return (h["value"], h["action"], h["log_prob"], rnn_hidden_states, ext_memory_feats,
                 ext_memory_dialog_feats, h["probs"])
 
@@ -185,9 +285,9 @@ class Policy(nn.Module):
 
     def get_value_option(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks,
                          query_state, last_query_info):
-        features, _, _ = self.net.run(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory,
-                                      ext_memory_masks, query_state, last_query_info)
-        return self._run_heads("option", features, need_sample=False)["value"]
+        (features, _, _), h = self._forward("option", observations, rnn_hidden_states, prev_actions, masks, ext_memory,
+                                            ext_memory_masks, query_state, last_query_info)
+        return h["value"]
 
     def evaluate_actions(self, observations, rnn_hidden_states, prev_actions, masks, action, ext_memory,
                          ext_memory_masks):
@@ -251,6 +351,8 @@ class _SMTBase(Net):
         nfeats += extra_dims
         self._feature_size = nfeats
         self._img = observation_space.spaces["rgb"].shape[0]
+        self.obs_keys = ("rgb", "depth", SPECTROGRAM, POSE, CATEGORY_BELIEF, LOCATION_BELIEF) + \
+            ((CATEGORY,) if use_category_input else ())
         self.smt_state_encoder = N.SMTStateEncoderParams(nfeats, dim_feedforward=hidden_size,
                                                          pose_indices=pose_indices, **smt_kwargs)
 
@@ -300,15 +402,24 @@ class _SMTBase(Net):
         st = L.stream()
         prec = pol.prec
         nb = L.lib.avlen_resnet18_workspace_bytes(B)
-        ws = pol._ws.get("resnet", nb, dev)
+        ws_rgb, ws_dep = pol._ws.get("resnet_rgb", nb, dev), pol._ws.get("resnet_depth", nb, dev)
         S = rgb.shape[1]
-        L.call("avlen_resnet18_fwd", C.byref(eng["rgb"]), E.P(rgb), B, S, rgb.shape[3], 255.0, E.P(feats, 0), F, prec,
-               E.P(ws), nb, st)
-        L.call("avlen_resnet18_fwd", C.byref(eng["depth"]), E.P(depth), B, S, depth.shape[3], 1.0, E.P(feats, 64), F,
-               prec, E.P(ws), nb, st)
         H, W = spec.shape[1], spec.shape[2]
         nb2 = L.lib.avlen_cnn3_workspace_bytes(C.byref(eng["audio"]), B, H, W)
         ws2 = pol._ws.get("audio", nb2, dev)
+        # inside a graph capture the two towers become parallel branches (fork/join on side streams)
+        cur = torch.cuda.current_stream()
+        fork = torch.cuda.is_current_stream_capturing()
+        s_rgb, s_dep = (pol.side_streams()[:2] if fork else (cur, cur))
+        if fork:
+            s_rgb.wait_stream(cur)
+            s_dep.wait_stream(cur)
+        with torch.cuda.stream(s_rgb):
+            L.call("avlen_resnet18_fwd", C.byref(eng["rgb"]), E.P(rgb), B, S, rgb.shape[3], 255.0, E.P(feats, 0), F, prec,
+                   E.P(ws_rgb), nb, L.stream())
+        with torch.cuda.stream(s_dep):
+            L.call("avlen_resnet18_fwd", C.byref(eng["depth"]), E.P(depth), B, S, depth.shape[3], 1.0, E.P(feats, 64), F,
+                   prec, E.P(ws_dep), nb, L.stream())
         L.call("avlen_cnn3_fwd", C.byref(eng["audio"]), E.P(spec), B, H, W, E.P(feats, 144), F, prec, E.P(ws2), nb2, st)
         pa = _i64(prev_actions.view(B, -1)[:, :1])
         cat = _f32(obs[CATEGORY]) if self._use_category_input else None
@@ -320,6 +431,9 @@ class _SMTBase(Net):
                E.P(cat) if cat is not None else None, self._col_cat, E.P(pose), pose_col,
                E.P(ex) if ex is not None else None, ex.shape[1] if ex is not None else 0, self._x_dims, E.P(cb), E.P(lb),
                E.P(goal), self._hidden_size, B, st)
+        if fork:
+            cur.wait_stream(s_rgb)
+            cur.wait_stream(s_dep)
         return feats, goal
 
     def smt(self, pol, feats, goal, ext_memory, ext_memory_masks, save_key="smt", mem_index=None, save=False):
@@ -440,6 +554,17 @@ class AudioNavDialogNet(_SMTBase):
     def run(self, pol, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_dialog,
             ext_memory_masks, all_dialog, agent_step):
         eng = pol._engine()
+        e = None
+        cur = torch.cuda.current_stream()
+        fork = torch.cuda.is_current_stream_capturing()
+        s_txt = pol.side_streams()[2] if fork else cur
+        if all_dialog is not None:                       # frozen CLIP text tower: a parallel branch under capture
+            if fork:
+                s_txt.wait_stream(cur)
+            with torch.cuda.stream(s_txt):
+                e = (self.text_encoder_override(all_dialog) if self.text_encoder_override is not None
+                     else self.encode_text(pol, all_dialog))
+                e = _f32(e)
         feats, goal = self.features(pol, observations, prev_actions)
         x_att, _ = self.smt(pol, feats, goal, ext_memory, ext_memory_masks)
         B, d = x_att.shape
@@ -447,9 +572,8 @@ class AudioNavDialogNet(_SMTBase):
         st = L.stream()
         d_emb = None
         if all_dialog is not None:
-            e = (self.text_encoder_override(all_dialog) if self.text_encoder_override is not None
-                 else self.encode_text(pol, all_dialog))
-            e = _f32(e)
+            if fork:
+                cur.wait_stream(s_txt)
             d_emb = torch.empty(B, d, device=dev)
             dl = eng["dialog_layer"]
             nbg = L.lib.avlen_gemm_workspace_bytes(B, d, e.shape[1], 1)
@@ -552,7 +676,7 @@ class AudioNavBaselinePolicy(_NetPolicy):
 
 
 def _split_engine_kwargs(kwargs):
-    return {k: kwargs.pop(k) for k in ("precision", "sampling") if k in kwargs}
+    return {k: kwargs.pop(k) for k in ("precision", "sampling", "use_graphs") if k in kwargs}
 
 
 class AudioNavSMTPolicy(_NetPolicy):

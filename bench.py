@@ -34,13 +34,14 @@ def parse():
     ap.add_argument("--spectrogram", default="257x101")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graphs", action="store_true")
     return ap.parse_args()
 
 
 def kernel_roofline(prec_name):
-    """Dominant dense kernel, timed live with HIP events on the launch stream: the bf16 MFMA implicit-GEMM
-    (igemm_kernel<128,bf16>) on the CLIP MLP up-projection of one rollout step
-    (M = 64 envs x 77 tokens = 4928 rows, K = 512, N = 2048; 12 such launches per step per policy call)."""
+    """Dominant dense kernel, timed live with HIP events on the launch stream: the bf16 MFMA GEMM of the CLIP MLP
+    up-projection of one rollout step (M = 64 envs x 77 tokens = 4928 rows, K = 512, N = 2048, QuickGELU epilogue,
+    bf16 out; 12 such launches per pi_l step).  bf16: g2_kernel<128,128> (igemm2.hip); fp32: igemm_kernel<128,fp32>."""
     from avlen_amd import _lib as L
     from avlen_amd.engine import P
     M, N, K = 64 * 77, 2048, 512
@@ -48,13 +49,22 @@ def kernel_roofline(prec_name):
     A = torch.randn(M, K, device=dev)
     W = torch.randn(N, K, device=dev) / K ** 0.5
     b = torch.randn(N, device=dev)
-    Cc = torch.empty(M, N, device=dev)
-    prec = L.PREC_BF16 if prec_name == "bf16" else L.PREC_FP32
-    nb = L.lib.avlen_gemm_workspace_bytes(M, N, K, 1)
-    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
     st = L.stream()
-    run = lambda: L.call("avlen_gemm", P(A), K, 0, P(W), K, 0, P(Cc), N, P(b), None, 0, M, N, K, 2, prec, 1, 0.0, P(ws),
-                         nb, st)
+    if prec_name == "bf16":
+        A16, W16 = A.bfloat16(), W.bfloat16()
+        C16 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        nb = L.lib.avlen_gemm_bf16_workspace_bytes(M, N)
+        ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        run = lambda: L.call("avlen_gemm_bf16", P(A16), K, P(W16), K, None, N, P(C16), N, P(b), None, 0, M, N, K, 2, P(ws),
+                             nb, st)
+        name, peak = "g2_kernel<128,128,2,2> bf16 glds", 2500.0
+    else:
+        Cc = torch.empty(M, N, device=dev)
+        nb = L.lib.avlen_gemm_workspace_bytes(M, N, K, 1)
+        ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        run = lambda: L.call("avlen_gemm", P(A), K, 0, P(W), K, 0, P(Cc), N, P(b), None, 0, M, N, K, 2, L.PREC_FP32, 1, 0.0,
+                             P(ws), nb, st)
+        name, peak = "igemm_kernel<128,fp32>", 157.3
     for _ in range(5):
         run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -66,9 +76,8 @@ def kernel_roofline(prec_name):
     torch.cuda.synchronize()
     sec = e0.elapsed_time(e1) / 1e3 / iters
     flops = 2.0 * M * N * K
-    peak = 2500.0 if prec_name == "bf16" else 157.3
     ach = flops / sec / 1e12
-    return {"bound": "mfma", "kernel": f"igemm_kernel<128,{prec_name}> (CLIP c_fc, M=4928 N=2048 K=512, QuickGELU epilogue)",
+    return {"bound": "mfma", "kernel": f"{name} (CLIP c_fc, M=4928 N=2048 K=512, QuickGELU epilogue)",
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
             "us_per_launch": round(sec * 1e6, 2)}
 
@@ -97,7 +106,8 @@ def main():
         dist.init_process_group("nccl")                    # RCCL over xGMI
     from avlen_amd.harness import Workload
     H, W = (int(x) for x in a.spectrogram.split("x"))
-    wl = Workload(a.envs, a.rollout, spectrogram=(H, W, 2), precision=a.precision, pretraining=True, seed=rank)
+    wl = Workload(a.envs, a.rollout, spectrogram=(H, W, 2), precision=a.precision, pretraining=True, seed=rank,
+                  use_graphs=not a.no_graphs)
 
     def barrier():
         torch.cuda.synchronize()

@@ -140,9 +140,10 @@ def test_bf16_fast_path_policies(specs, kind):
         pa, act = fx.ints(tag + ".pa", (B, 1), 4).cuda(), fx.ints(tag + ".a", (B, 1), 4).cuda()
         v, lp, ent, _, row = pol.evaluate_actions(obs, torch.zeros(1, B, 512, device="cuda"), pa,
                                                   torch.ones(B, 1, device="cuda"), act, mem, mk)
-        ev, er = float(np.abs(v.cpu().numpy() - g["value"]).max()), float(np.abs(row.cpu().numpy() - g["row"]).max())
-        print(f"pi_g bf16 fast path: max |value err| {ev:.4g}, max |feature err| {er:.4g}")
-        assert ev < 5e-2 and er < 8e-2
+        ev = float(np.abs(v.cpu().numpy() - g["value"]).max())
+        er = float(np.abs(row.cpu().numpy() - g["row"]).max() / np.abs(g["row"]).max())
+        print(f"pi_g bf16 fast path: max |value err| {ev:.4g}, max feature err / max |feature| {er:.4g}")
+        assert ev < 5e-2 and er < 5e-2
     else:
         torch.manual_seed(0)
         sd = {k: v.clone() for k, v in pol.state_dict().items() if k.startswith("net.clip.")}
@@ -373,3 +374,26 @@ def test_gradients_match_oracle_autograd(specs):
         worst = max(worst, err)
         assert err < 2e-3, (k, err)
     print("max relative gradient error over trained params:", worst)
+
+
+def test_graph_replay_equals_eager(specs):
+    """The captured HIP graph (parallel tower branches, static inputs) reproduces the eager launch sequence
+    bit-for-bit (fp32 mode is deterministic: no atomics on the forward path), step after step with changing
+    inputs, for the three policies."""
+    from avlen_amd.harness import Workload
+    torch.manual_seed(3)
+    outs = {}
+    for graphs in (False, True):
+        wl = Workload(4, 3, spectrogram=(65, 26, 2), precision="fp32", pretraining=False, em_capacity=4, seed=5,
+                      use_graphs=graphs)
+        torch.manual_seed(11)
+        for _ in range(3):
+            wl.rollout_step()
+        ro = wl.rollouts
+        torch.cuda.synchronize()
+        outs[graphs] = [ro.value_preds.clone(), ro.action_log_probs.clone(), ro.actions.clone(), ro.em_option.memory.clone(),
+                        ro.em.memory.clone(), ro.em_vln_dialog.memory.clone()]
+    names = ["value_preds", "log_probs", "actions", "em_option", "em_goal", "em_dialog"]
+    diffs = {n: float((a.double() - b.double()).abs().max()) for n, a, b in zip(names, outs[False], outs[True])}
+    print("graph vs eager max abs diffs:", diffs)
+    assert all(v == 0.0 for v in diffs.values()), diffs
