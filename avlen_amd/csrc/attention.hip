@@ -117,6 +117,101 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ 
   }
 }
 
+// Unmasked / causal variant (CLIP text: S = 77, D = 64): FOUR lanes per query, each owning D/4 of the head dim, so a
+// 32-query block is 128 threads and the dot products / PV updates are 4x shorter per lane (2 shuffles per key).
+template <int D>
+__global__ __launch_bounds__(128) void attn_fwd4_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ K,
+                                                        int ldk, const float* __restrict__ V, int ldv,
+                                                        float* __restrict__ O, int ldo, __bf16* __restrict__ O16, int ldo16,
+                                                        float* __restrict__ lse, int H, int Sq, int Sk, int causal,
+                                                        float scale) {
+  constexpr int DP = D / 4;                       // dims per lane
+  constexpr int KC = 32;                          // keys per LDS chunk
+  __shared__ __attribute__((aligned(16))) float ks[KC * D];
+  __shared__ __attribute__((aligned(16))) float vs[KC * D];
+  const int tid = threadIdx.x, part = tid & 3, ql = tid >> 2;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int i = blockIdx.x * 32 + ql;
+  const bool qok = i < Sq;
+  float q[DP], o[DP];
+#pragma unroll
+  for (int d = 0; d < DP; d++) { q[d] = 0.f; o[d] = 0.f; }
+  if (qok) {
+    const float* qp = Q + ((long)b * Sq + i) * ldq + h * D + part * DP;
+#pragma unroll
+    for (int d = 0; d < DP; d++) q[d] = qp[d] * scale;
+  }
+  float m = -INFINITY, l = 0.f;
+  const int sk_end = causal ? min(Sk, blockIdx.x * 32 + 32) : Sk;
+  for (int j0 = 0; j0 < sk_end; j0 += KC) {
+    __syncthreads();
+    {                                              // thread (key = tid>>2, part) stages D/4 floats of K and V
+      const int j = j0 + ql;
+      if (j < sk_end) {
+        const float4* kp = reinterpret_cast<const float4*>(K + ((long)b * Sk + j) * ldk + h * D + part * DP);
+        const float4* vp = reinterpret_cast<const float4*>(V + ((long)b * Sk + j) * ldv + h * D + part * DP);
+        float4* kd = reinterpret_cast<float4*>(&ks[ql * D + part * DP]);
+        float4* vd = reinterpret_cast<float4*>(&vs[ql * D + part * DP]);
+#pragma unroll
+        for (int d4 = 0; d4 < DP / 4; d4++) { kd[d4] = kp[d4]; vd[d4] = vp[d4]; }
+      }
+    }
+    __syncthreads();
+    const int nk = min(KC, sk_end - j0);
+    for (int g0 = 0; g0 < nk; g0 += 4) {
+      float s[4];
+      float mg = -INFINITY;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int jj = g0 + u;
+        float a = 0.f;
+        if (jj < nk) {
+          const float* kr = &ks[jj * D + part * DP];
+#pragma unroll
+          for (int d = 0; d < DP; d++) a += q[d] * kr[d];
+        }
+        a += __shfl_xor(a, 1, 64);
+        a += __shfl_xor(a, 2, 64);
+        if (jj >= nk || (causal && j0 + jj > i)) a = -INFINITY;
+        s[u] = a;
+        mg = fmaxf(mg, a);
+      }
+      const float mn = fmaxf(m, mg);
+      if (mn == -INFINITY) continue;               // nothing visible yet for this query
+      const float corr = (m == -INFINITY) ? 0.f : __expf(m - mn);
+      l *= corr;
+#pragma unroll
+      for (int d = 0; d < DP; d++) o[d] *= corr;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int jj = g0 + u;
+        if (jj < nk) {
+          const float pw = (s[u] == -INFINITY) ? 0.f : __expf(s[u] - mn);
+          l += pw;
+          const float* vr = &vs[jj * D + part * DP];
+#pragma unroll
+          for (int d = 0; d < DP; d++) o[d] += pw * vr[d];
+        }
+      }
+      m = mn;
+    }
+  }
+  if (qok) {
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    if (O) {
+      float* op = O + ((long)b * Sq + i) * ldo + h * D + part * DP;
+#pragma unroll
+      for (int d = 0; d < DP; d++) op[d] = o[d] * inv;
+    }
+    if (O16) {
+      __bf16* oh = O16 + ((long)b * Sq + i) * ldo16 + h * D + part * DP;
+#pragma unroll
+      for (int d = 0; d < DP; d++) oh[d] = (__bf16)(o[d] * inv);
+    }
+    if (lse && part == 0) lse[((long)b * H + h) * Sq + i] = m + __logf(l);
+  }
+}
+
 // dQ: lane per query (same streaming structure as forward).  Also writes delta = rowsum(dO * O).
 template <int D>
 __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ K,
@@ -245,8 +340,16 @@ int avlen_attention_fwd16(const float* Q, int ldq, const float* K, int ldk, cons
                           void* O16, int ldo16, const float* key_mask, float* lse, int B, int H, int Sq, int Sk, int D,
                           int causal, float scale, hipStream_t stream) {
   if (B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0 || (ldq | ldk | ldv | ldo) % 4) return AVLEN_ERR_ARG;
-  dim3 grid(ceil_div(Sq, 64), H, B), block(64);
   __bf16* oh = (__bf16*)O16;
+  if (!key_mask && Sq >= 16 && (D == 32 || D == 64)) {       // no padding mask: 4-lanes-per-query kernel
+    dim3 g4(ceil_div(Sq, 32), H, B), b4(128);
+    if (D == 32)
+      hipLaunchKernelGGL((attn_fwd4_kernel<32>), g4, b4, 0, stream, Q, ldq, K, ldk, V, ldv, O, ldo, oh, ldo16, lse, H, Sq, Sk, causal, scale);
+    else
+      hipLaunchKernelGGL((attn_fwd4_kernel<64>), g4, b4, 0, stream, Q, ldq, K, ldk, V, ldv, O, ldo, oh, ldo16, lse, H, Sq, Sk, causal, scale);
+    return avlen_launch_status();
+  }
+  dim3 grid(ceil_div(Sq, 64), H, B), block(64);
   if (D == 32)
     hipLaunchKernelGGL((attn_fwd_kernel<32>), grid, block, 0, stream, Q, ldq, K, ldk, V, ldv, O, ldo, oh, ldo16, key_mask, lse, H, Sq, Sk, causal, scale);
   else if (D == 64)

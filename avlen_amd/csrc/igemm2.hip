@@ -267,12 +267,19 @@ int launch(const G2& p, int m_tiles, int n_tiles, hipStream_t st) {
 int run_g2(G2 p, void* ws, size_t ws_bytes, hipStream_t st) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K & 7) || (p.lda & 7) || (p.ldb & 7)) return AVLEN_ERR_ARG;
   int bn = p.N <= 16 ? 16 : p.N <= 32 ? 32 : p.N <= 64 ? 64 : 128;
-  int m_tiles = ceil_div(p.M, 128), n_tiles = ceil_div(p.N, bn);
+  int n_tiles = ceil_div(p.N, bn);
+  // 64-row tiles when 128-row tiles would leave most of the 256 CUs idle (small rollout batches)
+  int bm = 128;
+  if (bn >= 64 && (long)ceil_div(p.M, 128) * n_tiles < 256 && p.M > 64) bm = 64;
+  // GroupNorm statistics need every wave tile inside one sample: ohw % (wave rows) == 0
+  if (p.stats && bm == 64 && (p.ohw % 32)) bm = 128;
+  int m_tiles = ceil_div(p.M, bm);
   int nk = ceil_div(p.K, BK);
   long tiles = (long)m_tiles * n_tiles;
   int split = 1;
-  if (tiles < 192 && nk >= 4 && !p.stats) {
-    { long a = nk / 2, b = (384 + tiles - 1) / tiles; split = (int)(a < b ? a : b); }
+  if (tiles < 128 && nk >= 8 && !p.stats) {
+    long a = nk / 4, b = (256 + tiles - 1) / tiles;
+    split = (int)(a < b ? a : b);
     if (split < 1) split = 1;
     if (split > 32) split = 32;
     if (!ws || (size_t)split * p.M * p.N * sizeof(float) > ws_bytes) split = 1;
@@ -281,11 +288,15 @@ int run_g2(G2 p, void* ws, size_t ws_bytes, hipStream_t st) {
   p.splitk = ceil_div(nk, p.ksteps_per_split);
   p.slab = (float*)ws;
   int rc;
-  switch (bn) {
-    case 16: rc = launch<128, 16, 4, 1>(p, m_tiles, n_tiles, st); break;
-    case 32: rc = launch<128, 32, 4, 1>(p, m_tiles, n_tiles, st); break;
-    case 64: rc = launch<128, 64, 2, 2>(p, m_tiles, n_tiles, st); break;
-    default: rc = launch<128, 128, 2, 2>(p, m_tiles, n_tiles, st); break;
+  if (bm == 64) {
+    rc = (bn == 64) ? launch<64, 64, 2, 2>(p, m_tiles, n_tiles, st) : launch<64, 128, 2, 2>(p, m_tiles, n_tiles, st);
+  } else {
+    switch (bn) {
+      case 16: rc = launch<128, 16, 4, 1>(p, m_tiles, n_tiles, st); break;
+      case 32: rc = launch<128, 32, 4, 1>(p, m_tiles, n_tiles, st); break;
+      case 64: rc = launch<128, 64, 2, 2>(p, m_tiles, n_tiles, st); break;
+      default: rc = launch<128, 128, 2, 2>(p, m_tiles, n_tiles, st); break;
+    }
   }
   if (rc != AVLEN_OK) return rc;
   if (p.splitk > 1) {

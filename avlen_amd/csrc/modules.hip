@@ -239,9 +239,9 @@ int linear16_rows(const Ctx& c, const avlen_linear& L, int r0, int n, const bf16
 __global__ void smt_build16_kernel(const float* __restrict__ x, const float* __restrict__ memory,
                                    const int32_t* __restrict__ mem_index, int NC, const float* __restrict__ masks,
                                    const float* __restrict__ pw, const float* __restrict__ pb, bf16* __restrict__ XF, int ldxf,
-                                   float* __restrict__ maskx, int B, int M, int F, int pc) {
-  const int S = M + 1;
-  const int row = blockIdx.x, b = row / S, s = row % S;
+                                   float* __restrict__ maskx, int B, int M, int F, int pc, int cto) {
+  const int S = cto ? 1 : M + 1;
+  const int row = blockIdx.x, b = row / S, s = cto ? M : row % S;
   const int col = mem_index ? mem_index[b] : b;
   const float* src = (s < M) ? memory + ((long)s * NC + col) * F : x + (long)b * F;
   const float* xp = x + (long)b * F + pc;
@@ -257,7 +257,7 @@ __global__ void smt_build16_kernel(const float* __restrict__ x, const float* __r
     float dh = heading_b - heading_a;
     dh = -atan2f(sinf(dh), cosf(dh));
     fmt[0] = r * cosf(phi); fmt[1] = r * sinf(phi); fmt[2] = cosf(dh); fmt[3] = sinf(dh); fmt[4] = expf(-bt);
-    maskx[(long)b * S + s] = (s < M) ? masks[(long)b * M + s] : 1.f;
+    maskx[(long)b * S + (cto ? 0 : s)] = (s < M) ? masks[(long)b * M + s] : 1.f;
   }
   __syncthreads();
   bf16* o = XF + (long)row * ldxf;
@@ -691,66 +691,176 @@ void smt_layout(WsBump& w, SmtWs& s, const avlen_smt* p, long B, long M, int F, 
 
 namespace {
 
-bool smt_has16(const avlen_smt* p) {
-  const avlen_transformer& t = p->tr;
-  return lin16_ok(p->fus0) && lin16_ok(p->fus2) && lin16_ok(t.enc.self_attn.in_proj) && lin16_ok(t.enc.self_attn.out_proj) &&
-         lin16_ok(t.enc.lin1) && lin16_ok(t.enc.lin2) && lin16_ok(t.dec.cross_attn.in_proj);
+
+bool tr_has16(const avlen_transformer& t) {
+  return lin16_ok(t.enc.self_attn.in_proj) && lin16_ok(t.enc.self_attn.out_proj) && lin16_ok(t.enc.lin1) &&
+         lin16_ok(t.enc.lin2) && lin16_ok(t.dec.cross_attn.in_proj) && lin16_ok(t.dec.cross_attn.out_proj) &&
+         lin16_ok(t.dec.self_attn.in_proj) && lin16_ok(t.dec.self_attn.out_proj) && lin16_ok(t.dec.lin1) &&
+         lin16_ok(t.dec.lin2);
 }
 
-struct Smt16Ws { bf16 *XF, *H1, *Z16, *AO16, *X116, *F116, *MEM16; float *Z, *QKV, *T1, *X1, *T2, *X2, *maskx; TrWs tr; void* gws; size_t gwsb; int ldxf; };
+// bf16-path transformer scratch (inference only)
+struct Tr16Ws {
+  bf16 *Z16, *AO16, *X116, *F116, *MEM16;            // [R, d]
+  float *Z, *QKV, *T1, *X1, *T2, *X2, *KVc;          // [R, d] ([R,3d] QKV, [R,2d] KVc)
+  bf16 *tgt16, *V016, *Y116, *AOc16, *Y216, *G116;   // [B, d]
+  float *U1, *Y1, *Qc, *U2, *Y2, *U3, *Y3;           // [B, d]
+};
 
-void smt16_layout(WsBump& w, Smt16Ws& s, const avlen_smt* p, long B, long M, int F) {
-  long S = M + 1, R = B * S; int d = p->tr.d;
+void tr16_layout(WsBump& w, Tr16Ws& t, long B, long S, int d, bool cto) {
+  long R = B * S;
+  t.Z16 = w.take<bf16>(R * d); t.AO16 = w.take<bf16>(R * d); t.X116 = w.take<bf16>(R * d); t.F116 = w.take<bf16>(R * d);
+  t.MEM16 = w.take<bf16>(R * d);
+  t.Z = w.take<float>(R * d); t.QKV = cto ? nullptr : w.take<float>(R * 3 * d); t.T1 = w.take<float>(R * d);
+  t.X1 = w.take<float>(R * d); t.T2 = w.take<float>(R * d); t.X2 = w.take<float>(R * d);
+  t.KVc = cto ? nullptr : w.take<float>(R * 2 * d);
+  t.tgt16 = w.take<bf16>(B * d); t.V016 = w.take<bf16>(B * d); t.Y116 = w.take<bf16>(B * d); t.AOc16 = w.take<bf16>(B * d);
+  t.Y216 = w.take<bf16>(B * d); t.G116 = w.take<bf16>(B * d);
+  t.U1 = w.take<float>(B * d); t.Y1 = w.take<float>(B * d); t.Qc = w.take<float>(B * d); t.U2 = w.take<float>(B * d);
+  t.Y2 = w.take<float>(B * d); t.U3 = w.take<float>(B * d); t.Y3 = w.take<float>(B * d);
+}
+
+// Encoder layer + final norm + K/V projection for the decoder; consumes t.Z (fp32) / t.Z16.
+int enc_fwd16(const Ctx& c, const avlen_transformer& tr, Tr16Ws& t, const float* maskx, int B, int S, bool cto) {
+  const int d = tr.d, H = tr.nhead, D = d / H;
+  const long R = (long)B * S;
+  const float scale = 1.0f / sqrtf((float)D);
+  const avlen_enc_layer& e = tr.enc;
+  if (cto) {                // one valid key: attention output == V(token)
+    TRY(linear16_rows(c, e.self_attn.in_proj, 2 * d, d, t.Z16, d, nullptr, 0, t.AO16, d, (int)R, 0));
+  } else {
+    TRY(linear16(c, e.self_attn.in_proj, t.Z16, d, t.QKV, 3 * d, nullptr, 0, (int)R, 0, nullptr, 0));
+    TRY(avlen_attention_fwd16(t.QKV, 3 * d, t.QKV + d, 3 * d, t.QKV + 2 * d, 3 * d, nullptr, 0, t.AO16, d, maskx, nullptr, B,
+                              H, S, S, D, 0, scale, c.st));
+  }
+  TRY(linear16(c, e.self_attn.out_proj, t.AO16, d, t.T1, d, nullptr, 0, (int)R, 0, t.Z, d));
+  TRY(avlen_layernorm_fwd16(t.T1, nullptr, e.norm1.g, e.norm1.b, t.X1, t.X116, nullptr, nullptr, (int)R, d, 1e-5f, c.st));
+  TRY(linear16(c, e.lin1, t.X116, d, nullptr, 0, t.F116, d, (int)R, AVLEN_ACT_RELU, nullptr, 0));
+  TRY(linear16(c, e.lin2, t.F116, d, t.T2, d, nullptr, 0, (int)R, 0, t.X1, d));
+  TRY(avlen_layernorm_fwd16(t.T2, nullptr, e.norm2.g, e.norm2.b, t.X2, nullptr, nullptr, nullptr, (int)R, d, 1e-5f, c.st));
+  TRY(avlen_layernorm_fwd16(t.X2, nullptr, tr.enc_norm.g, tr.enc_norm.b, nullptr, t.MEM16, nullptr, nullptr, (int)R, d, 1e-5f,
+                            c.st));
+  if (cto)                  // cross attention over one valid key == V projection of that token
+    return linear16_rows(c, tr.dec.cross_attn.in_proj, 2 * d, d, t.MEM16, d, nullptr, 0, t.AOc16, d, (int)R, 0);
+  return linear16_rows(c, tr.dec.cross_attn.in_proj, d, 2 * d, t.MEM16, d, t.KVc, 2 * d, nullptr, 0, (int)R, 0);
+}
+
+// Decoder layer for one target token per sample on the bf16 path.
+int dec_fwd16(const Ctx& c, const avlen_transformer& tr, Tr16Ws& t, const float* maskx, const float* tgt, float* out, int B,
+              int S, bool cto) {
+  const int d = tr.d, H = tr.nhead, D = d / H;
+  const float scale = 1.0f / sqrtf((float)D);
+  const avlen_dec_layer& q = tr.dec;
+  TRY(avlen_cast_bf16(tgt, d, t.tgt16, d, B, d, c.st));
+  TRY(linear16_rows(c, q.self_attn.in_proj, 2 * d, d, t.tgt16, d, nullptr, 0, t.V016, d, B, 0));
+  TRY(linear16(c, q.self_attn.out_proj, t.V016, d, t.U1, d, nullptr, 0, B, 0, tgt, d));
+  TRY(avlen_layernorm_fwd16(t.U1, nullptr, q.norm1.g, q.norm1.b, t.Y1, t.Y116, nullptr, nullptr, B, d, 1e-5f, c.st));
+  if (!cto) {
+    TRY(linear16_rows(c, q.cross_attn.in_proj, 0, d, t.Y116, d, t.Qc, d, nullptr, 0, B, 0));
+    TRY(avlen_attention_fwd16(t.Qc, d, t.KVc, 2 * d, t.KVc + d, 2 * d, nullptr, 0, t.AOc16, d, maskx, nullptr, B, H, 1, S, D, 0,
+                              scale, c.st));
+  }
+  TRY(linear16(c, q.cross_attn.out_proj, t.AOc16, d, t.U2, d, nullptr, 0, B, 0, t.Y1, d));
+  TRY(avlen_layernorm_fwd16(t.U2, nullptr, q.norm2.g, q.norm2.b, t.Y2, t.Y216, nullptr, nullptr, B, d, 1e-5f, c.st));
+  TRY(linear16(c, q.lin1, t.Y216, d, nullptr, 0, t.G116, d, B, AVLEN_ACT_RELU, nullptr, 0));
+  TRY(linear16(c, q.lin2, t.G116, d, t.U3, d, nullptr, 0, B, 0, t.Y2, d));
+  TRY(avlen_layernorm_fwd16(t.U3, nullptr, q.norm3.g, q.norm3.b, t.Y3, nullptr, nullptr, nullptr, B, d, 1e-5f, c.st));
+  return avlen_layernorm_fwd16(t.Y3, nullptr, tr.dec_norm.g, tr.dec_norm.b, out, nullptr, nullptr, nullptr, B, d, 1e-5f, c.st);
+}
+
+bool smt_has16(const avlen_smt* p) { return lin16_ok(p->fus0) && lin16_ok(p->fus2) && tr_has16(p->tr); }
+
+struct Smt16Ws { bf16 *XF, *H1; float* maskx; Tr16Ws tr; void* gws; size_t gwsb; int ldxf; };
+
+void smt16_layout(WsBump& w, Smt16Ws& s, const avlen_smt* p, long B, long M, int F, bool cto) {
+  long S = cto ? 1 : M + 1, R = B * S; int d = p->tr.d;
+  (void)F;
   s.ldxf = p->fus0.ld16;
-  s.XF = w.take<bf16>(R * s.ldxf); s.H1 = w.take<bf16>(R * d); s.Z16 = w.take<bf16>(R * d); s.AO16 = w.take<bf16>(R * d);
-  s.X116 = w.take<bf16>(R * d); s.F116 = w.take<bf16>(R * d); s.MEM16 = w.take<bf16>(R * d);
-  s.Z = w.take<float>(R * d); s.QKV = w.take<float>(R * 3 * d); s.T1 = w.take<float>(R * d); s.X1 = w.take<float>(R * d);
-  s.T2 = w.take<float>(R * d); s.X2 = w.take<float>(R * d); s.maskx = w.take<float>(B * S);
-  // decoder scratch: reuse TrWs with only the decoder-side buffers populated
-  TrWs& t = s.tr;
-  t.KVc = w.take<float>(R * 2 * d); t.LSEc = w.take<float>(B * p->tr.nhead);
-  t.V0 = w.take<float>(B * d); t.U1 = w.take<float>(B * d); t.Y1 = w.take<float>(B * d); t.Qc = w.take<float>(B * d);
-  t.AOc = w.take<float>(B * d); t.U2 = w.take<float>(B * d); t.Y2 = w.take<float>(B * d); t.G1 = w.take<float>(B * d);
-  t.U3 = w.take<float>(B * d); t.Y3 = w.take<float>(B * d);
-  t.md1 = w.take<float>(B); t.rd1 = w.take<float>(B); t.md2 = w.take<float>(B); t.rd2 = w.take<float>(B);
-  t.md3 = w.take<float>(B); t.rd3 = w.take<float>(B); t.mf = w.take<float>(B); t.rf = w.take<float>(B);
-  s.gwsb = zmax((size_t)GEMM_SCRATCH, avlen_gemm_bf16_workspace_bytes(128, 768));
+  s.XF = w.take<bf16>(R * s.ldxf); s.H1 = w.take<bf16>(R * d); s.maskx = w.take<float>(B * S);
+  tr16_layout(w, s.tr, B, S, d, cto);
+  s.gwsb = zmax((size_t)(32u << 20), avlen_gemm_bf16_workspace_bytes(128, 768));
   s.gws = w.take<char>(s.gwsb);
 }
 
-size_t smt16_ws_bytes(const avlen_smt* p, int B, int M, int F) {
-  WsBump w(nullptr, 0); Smt16Ws s; smt16_layout(w, s, p, B, M, F); return w.off + 4096;
+size_t smt16_ws_bytes(const avlen_smt* p, int B, int M, int F, bool cto) {
+  WsBump w(nullptr, 0); Smt16Ws s; smt16_layout(w, s, p, B, M, F, cto); return w.off + 4096;
 }
 
-// SMTStateEncoder forward, inference only, full memory, bf16 operands (pi_g / pi_l / 2nd-stage pi_q rollouts)
+// SMTStateEncoder forward, inference only, bf16 operands (all rollout calls of pi_g / pi_l / pi_q)
 int smt_fwd_infer_bf16(const avlen_smt* p, const float* x, const float* memory, const int32_t* mem_index, int NC,
-                       const float* masks, const float* goal, float* out, int B, int M, int F, int pose_col, void* ws,
-                       size_t ws_bytes, hipStream_t st) {
-  if (ws_bytes < smt16_ws_bytes(p, B, M, F)) return AVLEN_ERR_WS;
-  WsBump w(ws, ws_bytes); Smt16Ws s; smt16_layout(w, s, p, B, M, F);
+                       const float* masks, const float* goal, float* out, int B, int M, int F, int pose_col, bool cto,
+                       void* ws, size_t ws_bytes, hipStream_t st) {
+  if (ws_bytes < smt16_ws_bytes(p, B, M, F, cto)) return AVLEN_ERR_WS;
+  WsBump w(ws, ws_bytes); Smt16Ws s; smt16_layout(w, s, p, B, M, F, cto);
   Ctx c{st, AVLEN_PREC_BF16, s.gws, s.gwsb};
   const avlen_transformer& tr = p->tr;
-  const int S = M + 1, d = tr.d, H = tr.nhead, D = d / H;
+  const int S = cto ? 1 : M + 1, d = tr.d;
   const long R = (long)B * S;
-  const float scale = 1.0f / sqrtf((float)D);
   if (!mem_index) NC = B;
   hipLaunchKernelGGL(smt_build16_kernel, dim3((unsigned)R), dim3(128), 0, st, x, memory, mem_index, NC, masks, p->pose.w,
-                     p->pose.b, s.XF, s.ldxf, s.maskx, B, M, F, pose_col);
+                     p->pose.b, s.XF, s.ldxf, s.maskx, B, M, F, pose_col, cto ? 1 : 0);
   TRY(avlen_launch_status());
   TRY(linear16(c, p->fus0, s.XF, s.ldxf, nullptr, 0, s.H1, d, (int)R, AVLEN_ACT_RELU, nullptr, 0));
-  TRY(linear16(c, p->fus2, s.H1, d, s.Z, d, s.Z16, d, (int)R, 0, nullptr, 0));
-  const avlen_enc_layer& e = tr.enc;
-  TRY(linear16(c, e.self_attn.in_proj, s.Z16, d, s.QKV, 3 * d, nullptr, 0, (int)R, 0, nullptr, 0));
-  TRY(avlen_attention_fwd16(s.QKV, 3 * d, s.QKV + d, 3 * d, s.QKV + 2 * d, 3 * d, nullptr, 0, s.AO16, d, s.maskx, nullptr, B,
-                            H, S, S, D, 0, scale, st));
-  TRY(linear16(c, e.self_attn.out_proj, s.AO16, d, s.T1, d, nullptr, 0, (int)R, 0, s.Z, d));
-  TRY(avlen_layernorm_fwd16(s.T1, nullptr, e.norm1.g, e.norm1.b, s.X1, s.X116, nullptr, nullptr, (int)R, d, 1e-5f, st));
-  TRY(linear16(c, e.lin1, s.X116, d, nullptr, 0, s.F116, d, (int)R, AVLEN_ACT_RELU, nullptr, 0));
-  TRY(linear16(c, e.lin2, s.F116, d, s.T2, d, nullptr, 0, (int)R, 0, s.X1, d));
-  TRY(avlen_layernorm_fwd16(s.T2, nullptr, e.norm2.g, e.norm2.b, s.X2, nullptr, nullptr, nullptr, (int)R, d, 1e-5f, st));
-  TRY(avlen_layernorm_fwd16(s.X2, nullptr, tr.enc_norm.g, tr.enc_norm.b, nullptr, s.MEM16, nullptr, nullptr, (int)R, d, 1e-5f, st));
-  TRY(linear16_rows(c, tr.dec.cross_attn.in_proj, d, 2 * d, s.MEM16, d, s.tr.KVc, 2 * d, nullptr, 0, (int)R, 0));
-  return dec_fwd(c, tr, s.tr, s.maskx, goal, out, B, S, false);
+  TRY(linear16(c, p->fus2, s.H1, d, s.tr.Z, d, s.tr.Z16, d, (int)R, 0, nullptr, 0));
+  TRY(enc_fwd16(c, tr, s.tr, s.maskx, B, S, cto));
+  return dec_fwd16(c, tr, s.tr, s.maskx, goal, out, B, S, cto);
+}
+
+// ---- dialog state encoder on the bf16 path ----
+__global__ void dialog_build16_kernel(const float* __restrict__ x_att, const float* __restrict__ mem,
+                                      const float* __restrict__ masks, const float* __restrict__ d_emb,
+                                      bf16* __restrict__ seq16, float* __restrict__ seq32, int ldseq, float* __restrict__ maskx,
+                                      int B, int M, int d) {
+  const int S = M + 1, row = blockIdx.x, b = row / S, s = row % S;
+  const float* src = s < M ? mem + ((long)s * B + b) * d : x_att + (long)b * d;
+  for (int i = threadIdx.x; i < d; i += blockDim.x) {
+    if (seq16) { seq16[(long)row * ldseq + i] = (bf16)src[i]; if (d_emb) seq16[(long)row * ldseq + d + i] = (bf16)d_emb[(long)b * d + i]; }
+    if (seq32) seq32[(long)row * d + i] = src[i];
+  }
+  if (threadIdx.x == 0) maskx[(long)b * S + s] = s < M ? masks[(long)b * M + s] : 1.f;
+}
+// z[row] += pe[step[b]]  ->  fp32 (in place) and bf16 copy
+__global__ void add_pe16_kernel(float* __restrict__ z, bf16* __restrict__ z16, const float* __restrict__ pe,
+                                const float* __restrict__ step, int S, int d, int pe_len) {
+  const int row = blockIdx.x, b = row / S;
+  int idx = (int)step[b];
+  idx = idx < 0 ? 0 : (idx >= pe_len ? pe_len - 1 : idx);
+  for (int i = threadIdx.x; i < d; i += blockDim.x) {
+    float v = z[(long)row * d + i] + pe[(long)idx * d + i];
+    z[(long)row * d + i] = v; z16[(long)row * d + i] = (bf16)v;
+  }
+}
+
+struct Dlg16Ws { bf16 *SEQ16, *H1; float* maskx; Tr16Ws tr; void* gws; size_t gwsb; };
+void dlg16_layout(WsBump& w, Dlg16Ws& s, const avlen_dialog* p, long B, long M) {
+  long S = M + 1, R = B * S; int d = p->tr.d;
+  s.SEQ16 = w.take<bf16>(R * 2 * d); s.H1 = w.take<bf16>(R * d); s.maskx = w.take<float>(B * S);
+  tr16_layout(w, s.tr, B, S, d, false);
+  s.gwsb = 32u << 20; s.gws = w.take<char>(s.gwsb);
+}
+size_t dlg16_ws_bytes(const avlen_dialog* p, int B, int M) { WsBump w(nullptr, 0); Dlg16Ws s; dlg16_layout(w, s, p, B, M); return w.off + 4096; }
+bool dlg_has16(const avlen_dialog* p) { return lin16_ok(p->fus0) && lin16_ok(p->fus2) && tr_has16(p->tr); }
+
+int dialog_fwd_bf16(const avlen_dialog* p, const float* x_att, const float* memory_state, const float* masks,
+                    const float* d_emb, const float* agent_step, const float* goal, float* out, int B, int M, void* ws,
+                    size_t ws_bytes, hipStream_t st) {
+  if (ws_bytes < dlg16_ws_bytes(p, B, M)) return AVLEN_ERR_WS;
+  WsBump w(ws, ws_bytes); Dlg16Ws s; dlg16_layout(w, s, p, B, M);
+  Ctx c{st, AVLEN_PREC_BF16, s.gws, s.gwsb};
+  const int S = M + 1, d = p->tr.d; const long R = (long)B * S;
+  if (d_emb) {
+    hipLaunchKernelGGL(dialog_build16_kernel, dim3((unsigned)R), dim3(128), 0, st, x_att, memory_state, masks, d_emb, s.SEQ16,
+                       (float*)nullptr, 2 * d, s.maskx, B, M, d);
+    TRY(linear16(c, p->fus0, s.SEQ16, 2 * d, nullptr, 0, s.H1, d, (int)R, AVLEN_ACT_RELU, nullptr, 0));
+    TRY(linear16(c, p->fus2, s.H1, d, s.tr.Z, d, nullptr, 0, (int)R, 0, nullptr, 0));
+  } else {
+    hipLaunchKernelGGL(dialog_build16_kernel, dim3((unsigned)R), dim3(128), 0, st, x_att, memory_state, masks,
+                       (const float*)nullptr, (bf16*)nullptr, s.tr.Z, d, s.maskx, B, M, d);
+  }
+  hipLaunchKernelGGL(add_pe16_kernel, dim3((unsigned)R), dim3(128), 0, st, s.tr.Z, s.tr.Z16, p->pe, agent_step, S, d, p->pe_len);
+  TRY(avlen_launch_status());
+  TRY(enc_fwd16(c, p->tr, s.tr, s.maskx, B, S, false));
+  return dec_fwd16(c, p->tr, s.tr, s.maskx, goal, out, B, S, false);
 }
 
 }  // namespace
@@ -759,7 +869,7 @@ extern "C" size_t avlen_smt_workspace_bytes(const avlen_smt* p, int B, int M, in
   WsBump w(nullptr, 0); SmtWs s;
   smt_layout(w, s, p, B, M, F, cto != 0);
   size_t v1 = w.off + 4096;
-  return (!cto && smt_has16(p)) ? zmax(v1, smt16_ws_bytes(p, B, M, F)) : v1;
+  return smt_has16(p) ? zmax(v1, smt16_ws_bytes(p, B, M, F, cto != 0)) : v1;
 }
 
 extern "C" int avlen_smt_fwd(const avlen_smt* p, const float* x, const float* memory, const int32_t* mem_index, int NC,
@@ -768,8 +878,8 @@ extern "C" int avlen_smt_fwd(const avlen_smt* p, const float* x, const float* me
   if (!p || B <= 0 || M < 0 || p->fus0.in_f != F + 12 || p->pose.in_f != 5 || p->pose.out_f != 16) return AVLEN_ERR_ARG;
   if (!cto && M > 0 && (!memory || !masks)) return AVLEN_ERR_ARG;
   if (ws_bytes < avlen_smt_workspace_bytes(p, B, M, F, cto)) return AVLEN_ERR_WS;
-  if (prec == AVLEN_PREC_BF16 && !cto && !save_for_backward && M > 0 && smt_has16(p))
-    return smt_fwd_infer_bf16(p, x, memory, mem_index, NC, masks, goal, out, B, M, F, pose_col, ws, ws_bytes, st);
+  if (prec == AVLEN_PREC_BF16 && !save_for_backward && (cto || M > 0) && smt_has16(p))
+    return smt_fwd_infer_bf16(p, x, memory, mem_index, NC, masks, goal, out, B, M, F, pose_col, cto != 0, ws, ws_bytes, st);
   WsBump w(ws, ws_bytes); SmtWs s;
   smt_layout(w, s, p, B, M, F, cto != 0);
   Ctx c{st, prec, s.gws, GEMM_SCRATCH};
@@ -830,13 +940,16 @@ void dlg_layout(WsBump& w, DlgWs& s, const avlen_dialog* p, long B, long M) {
 }  // namespace
 
 extern "C" size_t avlen_dialog_workspace_bytes(const avlen_dialog* p, int B, int M) {
-  WsBump w(nullptr, 0); DlgWs s; dlg_layout(w, s, p, B, M); return w.off + 4096;
+  WsBump w(nullptr, 0); DlgWs s; dlg_layout(w, s, p, B, M);
+  return dlg_has16(p) ? zmax(w.off + 4096, dlg16_ws_bytes(p, B, M)) : w.off + 4096;
 }
 
 extern "C" int avlen_dialog_fwd(const avlen_dialog* p, const float* x_att, const float* memory_state,
                                 const float* masks, const float* d_emb, const float* agent_step, const float* goal,
                                 float* out, int B, int M, int prec, void* ws, size_t ws_bytes, hipStream_t st) {
   if (!p || B <= 0 || ws_bytes < avlen_dialog_workspace_bytes(p, B, M)) return AVLEN_ERR_WS;
+  if (prec == AVLEN_PREC_BF16 && dlg_has16(p))
+    return dialog_fwd_bf16(p, x_att, memory_state, masks, d_emb, agent_step, goal, out, B, M, ws, ws_bytes, st);
   WsBump w(ws, ws_bytes); DlgWs s; dlg_layout(w, s, p, B, M);
   Ctx c{st, prec, s.gws, GEMM_SCRATCH};
   const int S = M + 1, d = p->tr.d; const long R = (long)B * S;

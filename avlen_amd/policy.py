@@ -536,8 +536,8 @@ class AudioNavDialogNet(_SMTBase):
     def build_views(self, eng, packed):
         super().build_views(eng, packed)
         eng["clip"] = E.clip_view(self.clip, eng["flat"])
-        eng["dialog_layer"] = E.linear_view(self.dialog_layer.weight, self.dialog_layer.bias)
-        eng["dialog"] = E.dialog_view(self.dialog_state_encoder)
+        eng["dialog_layer"] = E.linear_view(self.dialog_layer.weight, self.dialog_layer.bias, eng["flat"])
+        eng["dialog"] = E.dialog_view(self.dialog_state_encoder, eng["flat"])
 
     def encode_text(self, pol, tokens):
         eng = pol._engine()
@@ -576,10 +576,18 @@ class AudioNavDialogNet(_SMTBase):
                 cur.wait_stream(s_txt)
             d_emb = torch.empty(B, d, device=dev)
             dl = eng["dialog_layer"]
-            nbg = L.lib.avlen_gemm_workspace_bytes(B, d, e.shape[1], 1)
-            wsg = pol._ws.get("dlg_gemm", nbg, dev)
-            L.call("avlen_gemm", E.P(e), e.shape[1], 0, dl.w, dl.in_f, 0, E.P(d_emb), d, dl.b, None, 0, B, d, e.shape[1],
-                   0, pol.prec, 1, 0.0, E.P(wsg), nbg, st)
+            if pol.prec == L.PREC_BF16 and dl.w16:
+                e16 = torch.empty(B, e.shape[1], device=dev, dtype=torch.bfloat16)
+                nbg = L.lib.avlen_gemm_bf16_workspace_bytes(B, d)
+                wsg = pol._ws.get("dlg_gemm", nbg, dev)
+                L.call("avlen_cast_bf16", E.P(e), e.shape[1], E.P(e16), e.shape[1], B, e.shape[1], st)
+                L.call("avlen_gemm_bf16", E.P(e16), e.shape[1], dl.w16, dl.ld16, E.P(d_emb), d, None, 0, dl.b, None, 0, B, d,
+                       e.shape[1], 0, E.P(wsg), nbg, st)
+            else:
+                nbg = L.lib.avlen_gemm_workspace_bytes(B, d, e.shape[1], 1)
+                wsg = pol._ws.get("dlg_gemm", nbg, dev)
+                L.call("avlen_gemm", E.P(e), e.shape[1], 0, dl.w, dl.in_f, 0, E.P(d_emb), d, dl.b, None, 0, B, d,
+                       e.shape[1], 0, pol.prec, 1, 0.0, E.P(wsg), nbg, st)
         memd = _f32(ext_memory_dialog)
         mk = _f32(ext_memory_masks)
         M = memd.shape[0]

@@ -105,9 +105,10 @@ def test_option_policy_matches_reference(specs, pre, M):
     close(pol.get_value_option(obs, h0, pa, ones, mem, mk, qs, lqi), g["get_value"])
 
 
-def test_option_policy_bf16_tolerance(specs):
+@pytest.mark.parametrize("pre", [False, True])
+def test_option_policy_bf16_tolerance(specs, pre):
     """bf16 operands (fp32 accumulate): report and bound the deviation from the fp32 reference."""
-    B, M, pre = 3, 300, False
+    B, M = 3, 300
     pol = build("option", precision="bf16", pretraining=pre)
     load_fixture(pol, "option", specs)
     pol.cuda()
@@ -154,6 +155,30 @@ def test_bf16_fast_path_policies(specs, kind):
         e = float((out.cpu() - ref).abs().max() / ref.abs().max())
         print(f"CLIP text bf16 fast path: max rel err {e:.4g}")
         assert e < 3e-2
+
+
+def test_dialog_policy_bf16_tolerance(specs):
+    """pi_l (stub text embedding) entirely on the bf16 path: SMT(M=3) + dialog fusion/transformer + heads."""
+    B, M = 3, 3
+    pol = build("dialog", precision="bf16")
+    load_fixture(pol, "dialog", specs)
+    pol.cuda()
+    pol.net.text_encoder_override = lambda t: fx.stub_text_embedding(t.cpu()).cuda()
+    tag = "dlg"
+    g = golden("policy_dlg")
+    obs = cu(fx.observations(tag, B))
+    mem, memd = fx.memory(tag, M, B, 276, 272).cuda(), fx.sym(tag + ".memd", (M, B, 256)).cuda()
+    mk = fx.mask_patterns(tag, B, M).cuda()
+    pa, act = fx.ints(tag + ".pa", (B, 1), 4).cuda(), fx.ints(tag + ".a", (B, 1), 4).cuda()
+    toks = fx.dialog_tokens(tag, B).cuda()
+    astep = fx.ints(tag + ".as", (B,), 3).float().cuda()
+    _, lp, ent, _, row, xd, logits = pol.evaluate_actions_dialog(obs, torch.zeros(1, B, 512, device="cuda"), pa,
+                                                                 torch.ones(B, 1, device="cuda"), act, mem, memd, mk, toks,
+                                                                 astep)
+    e_l = float(np.abs(logits.cpu().numpy() - g["logits"]).max())
+    e_x = float(np.abs(xd.cpu().numpy() - g["xd"]).max())
+    print(f"pi_l bf16: max |logit err| {e_l:.4g}, max |state err| {e_x:.4g}")
+    assert e_l < 3e-2 and e_x < 1.5e-1
 
 
 def test_option_distractor(specs):
