@@ -131,6 +131,8 @@ SIGNATURES = {
     "avlen_concat_rows": (i32, [vp, i32, i32, vp, i32, i32, vp, i32, i32, vp]),
     "avlen_resnet18_workspace_bytes": (sz, [i32]),
     "avlen_resnet18_fwd": (i32, [C.POINTER(ResNet18), vp, i32, i32, i32, f32, vp, i32, i32, vp, sz, vp]),
+    "avlen_resnet18_group_workspace_bytes": (sz, [i32, i32]),
+    "avlen_resnet18_group_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp]),
     "avlen_cnn3_workspace_bytes": (sz, [C.POINTER(Cnn3), i32, i32, i32]),
     "avlen_cnn3_fwd": (i32, [C.POINTER(Cnn3), vp, i32, i32, i32, vp, i32, i32, vp, sz, vp]),
     "avlen_smt_workspace_bytes": (sz, [C.POINTER(Smt), i32, i32, i32, i32]),

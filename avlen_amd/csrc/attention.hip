@@ -126,7 +126,7 @@ __global__ __launch_bounds__(128) void attn_fwd4_kernel(const float* __restrict_
                                                         float* __restrict__ lse, int H, int Sq, int Sk, int causal,
                                                         float scale) {
   constexpr int DP = D / 4;                       // dims per lane
-  constexpr int KC = 32;                          // keys per LDS chunk
+  constexpr int KC = 96;                          // keys per LDS chunk (CLIP's 77 keys land in one pass)
   __shared__ __attribute__((aligned(16))) float ks[KC * D];
   __shared__ __attribute__((aligned(16))) float vs[KC * D];
   const int tid = threadIdx.x, part = tid & 3, ql = tid >> 2;
@@ -145,13 +145,13 @@ __global__ __launch_bounds__(128) void attn_fwd4_kernel(const float* __restrict_
   const int sk_end = causal ? min(Sk, blockIdx.x * 32 + 32) : Sk;
   for (int j0 = 0; j0 < sk_end; j0 += KC) {
     __syncthreads();
-    {                                              // thread (key = tid>>2, part) stages D/4 floats of K and V
-      const int j = j0 + ql;
+    for (int jl = ql; jl < KC; jl += 32) {         // thread (key = jl, part) stages D/4 floats of K and V
+      const int j = j0 + jl;
       if (j < sk_end) {
         const float4* kp = reinterpret_cast<const float4*>(K + ((long)b * Sk + j) * ldk + h * D + part * DP);
         const float4* vp = reinterpret_cast<const float4*>(V + ((long)b * Sk + j) * ldv + h * D + part * DP);
-        float4* kd = reinterpret_cast<float4*>(&ks[ql * D + part * DP]);
-        float4* vd = reinterpret_cast<float4*>(&vs[ql * D + part * DP]);
+        float4* kd = reinterpret_cast<float4*>(&ks[jl * D + part * DP]);
+        float4* vd = reinterpret_cast<float4*>(&vs[jl * D + part * DP]);
 #pragma unroll
         for (int d4 = 0; d4 < DP / 4; d4++) { kd[d4] = kp[d4]; vd[d4] = vp[d4]; }
       }

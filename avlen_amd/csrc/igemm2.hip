@@ -15,6 +15,7 @@
 //  * small grids split K across blockIdx.z into fp32 slabs (deterministic reduce, no atomics).
 #include "common.h"
 #include "../../include/avlen_hip.h"
+#include <stdlib.h>
 
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -27,7 +28,11 @@ namespace {
 constexpr int BK = 64;
 constexpr int NT = 256;
 
+constexpr int MAXG = 8;
+struct G2Grp { const bf16* A; const bf16* B; float* C32; bf16* C16; const float* bias; const float* residual; float* stats; };
+
 struct G2 {
+  G2Grp g[MAXG]; int groups;       // blockIdx.y selects the group (same shapes, different tensors: the 6 towers)
   const bf16* A; const bf16* B; float* C32; bf16* C16; const float* bias; const float* residual;
   int M, N, K;
   int lda, ldb, ldc32, ldc16, ldr;
@@ -44,15 +49,28 @@ __device__ __forceinline__ float act2(float v, int act) {
   return v;
 }
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(NT) void g2_kernel(G2 p) {
+// NS = LDS stages: up to NS-1 K-tiles of global_load_lds in flight per block.  Large grids run NS=2 (small LDS
+// footprint -> 2+ blocks per CU hide the latency); grids that cannot fill the chip run NS=4 (deep prefetch).
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BM, int BN, int WM, int WN, int NS>
+__global__ __launch_bounds__(NT) void g2_kernel(G2 pp) {
+  G2 p = pp;
+  {
+    const G2Grp gg = pp.g[blockIdx.y];
+    p.A = gg.A; p.B = gg.B; p.C32 = gg.C32; p.C16 = gg.C16; p.bias = gg.bias; p.residual = gg.residual; p.stats = gg.stats;
+    if (p.slab) p.slab += (size_t)blockIdx.y * p.splitk * p.M * p.N;
+  }
   constexpr int WTM = BM / WM, WTN = BN / WN;       // wave tile
   constexpr int MI = WTM / 16, NI = WTN / 16;
   constexpr int A_ROUNDS = BM * 8 / NT;              // 16-byte chunks per thread for the A tile
   constexpr int B_SLOTS = BN * 8;
-  constexpr int B_ROUNDS = (B_SLOTS + NT - 1) / NT;
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
-  extern __shared__ __attribute__((aligned(16))) char lds[];       // [2][A_BYTES + B_BYTES]
+  constexpr int B_ROUNDS = (B_SLOTS + NT - 1) / NT;  // every wave issues the same number of loads per tile
+  constexpr int A_BYTES = BM * 128;
+  constexpr int B_BYTES = (B_SLOTS >= NT ? BN * 128 : NT * 16);    // small BN: surplus lanes land in a pad area
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int LOADS = A_ROUNDS + B_ROUNDS;         // glds per wave per K-tile
+  extern __shared__ __attribute__((aligned(16))) char lds[];       // [NS][STAGE]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n_tiles = (p.N + BN - 1) / BN;
@@ -84,14 +102,14 @@ __global__ __launch_bounds__(NT) void g2_kernel(G2 p) {
   const char* b_src[B_ROUNDS]; int b_sw[B_ROUNDS];
 #pragma unroll
   for (int r = 0; r < B_ROUNDS; r++) {
-    int slot = r * NT + tid, row = (slot >> 3) % BN;
+    int slot = r * NT + tid, row = (slot >> 3) % BN;           // surplus lanes (slot >= B_SLOTS) re-read a valid row
     b_sw[r] = ((slot & 7) ^ ((row >> 1) & 7)) * 8;
     b_src[r] = (const char*)(p.B + (long)min(n0 + row, p.N - 1) * p.ldb);
   }
   const char* zero = (const char*)g_zero_page;
 
-  auto issue = [&](int kt, int buf) {
-    char* abase = lds + buf * (A_BYTES + B_BYTES);
+  auto issue = [&](int kt, int stage) {
+    char* abase = lds + stage * STAGE;
     char* bbase = abase + A_BYTES;
     const int k0 = kt * BK;
 #pragma unroll
@@ -112,12 +130,10 @@ __global__ __launch_bounds__(NT) void g2_kernel(G2 p) {
     }
 #pragma unroll
     for (int r = 0; r < B_ROUNDS; r++) {
-      if (B_SLOTS >= NT || (r * NT + wave * 64) < B_SLOTS) {      // wave-uniform
-        int k = k0 + b_sw[r];
-        const char* src = (k < p.K) ? b_src[r] + (long)k * 2 : zero;
-        __builtin_amdgcn_global_load_lds((const void*)src,
-            (__attribute__((address_space(3))) void*)(bbase + (r * NT + wave * 64) * 16), 16, 0, 0);
-      }
+      int k = k0 + b_sw[r];
+      const char* src = (k < p.K) ? b_src[r] + (long)k * 2 : zero;
+      __builtin_amdgcn_global_load_lds((const void*)src,
+          (__attribute__((address_space(3))) void*)(bbase + (r * NT + wave * 64) * 16), 16, 0, 0);
     }
   };
 
@@ -130,12 +146,17 @@ __global__ __launch_bounds__(NT) void g2_kernel(G2 p) {
   const int wm = wave / WN, wn = wave % WN;
   const int r16 = lane & 15, q = lane >> 4;
 
-  if (kt_beg < kt_end) issue(kt_beg, 0);
-  for (int kt = kt_beg; kt < kt_end; kt++) {
-    const int buf = (kt - kt_beg) & 1;
-    __syncthreads();                 // s_waitcnt vmcnt(0): tile kt landed; everyone left buffer buf^1
-    if (kt + 1 < kt_end) issue(kt + 1, buf ^ 1);
-    const char* abase = lds + buf * (A_BYTES + B_BYTES);
+  // ---- software pipeline: tiles kt .. kt+NS-2 in flight while tile kt is multiplied ----
+  const int nkt = kt_end - kt_beg;
+#pragma unroll
+  for (int s0 = 0; s0 < NS - 1; s0++)
+    if (s0 < nkt) issue(kt_beg + s0, s0);
+  for (int it = 0; it < nkt; it++) {
+    // my loads of tile `it` have landed once at most the loads of the later in-flight tiles are outstanding
+    if (NS > 2 && it + NS - 2 < nkt) wait_vmcnt<LOADS * (NS - 2)>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();      // everyone's part of tile `it` is in LDS; everyone has left stage (it-1)%NS
+    if (it + NS - 1 < nkt) issue(kt_beg + it + NS - 1, (it + NS - 1) % NS);
+    const char* abase = lds + (it % NS) * STAGE;
     const char* bbase = abase + A_BYTES;
 #pragma unroll
     for (int kh = 0; kh < 2; kh++) {
@@ -251,38 +272,56 @@ __global__ void pack_fc_bf16_kernel(const float* __restrict__ w, bf16* __restric
   o[idx] = (bf16)w[((long)oc * C + c) * HW + pp];
 }
 
-template <int BM, int BN, int WM, int WN>
-int launch(const G2& p, int m_tiles, int n_tiles, hipStream_t st) {
-  size_t lds = 2 * (size_t)(BM * 128 + BN * 128);
+template <int BM, int BN, int WM, int WN, int NS>
+int launch_ns(const G2& p, int m_tiles, int n_tiles, hipStream_t st) {
+  size_t lds = (size_t)NS * (BM * 128 + (BN * 8 >= NT ? BN * 128 : NT * 16));
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&g2_kernel<BM, BN, WM, WN>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&g2_kernel<BM, BN, WM, WN, NS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((g2_kernel<BM, BN, WM, WN>), dim3(m_tiles * n_tiles, 1, p.splitk), dim3(NT), lds, st, p);
+  hipLaunchKernelGGL((g2_kernel<BM, BN, WM, WN, NS>), dim3(m_tiles * n_tiles, p.groups, p.splitk), dim3(NT), lds, st, p);
   return avlen_launch_status();
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch(const G2& p, int m_tiles, int n_tiles, hipStream_t st) {
+  long blocks = (long)m_tiles * n_tiles * p.splitk * p.groups;
+  static int forced = -1;                       // AVLEN_G2_NS=2|4 pins the stage count (A/B measurements)
+  if (forced < 0) { const char* e = getenv("AVLEN_G2_NS"); forced = e ? atoi(e) : 0; }
+  static long thresh = -1;
+  if (thresh < 0) { const char* e = getenv("AVLEN_G2_NS_BLOCKS"); thresh = e ? atol(e) : 96; }
+  bool deep = forced ? forced == 4 : blocks < thresh;
+  if (!deep) return launch_ns<BM, BN, WM, WN, 2>(p, m_tiles, n_tiles, st);
+  return launch_ns<BM, BN, WM, WN, 4>(p, m_tiles, n_tiles, st);
 }
 
 int run_g2(G2 p, void* ws, size_t ws_bytes, hipStream_t st) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K & 7) || (p.lda & 7) || (p.ldb & 7)) return AVLEN_ERR_ARG;
+  if (p.groups <= 0) {             // single problem: group 0 = the scalar fields
+    p.groups = 1;
+    p.g[0] = G2Grp{p.A, p.B, p.C32, p.C16, p.bias, p.residual, p.stats};
+  }
+  if (p.groups > MAXG) return AVLEN_ERR_ARG;
   int bn = p.N <= 16 ? 16 : p.N <= 32 ? 32 : p.N <= 64 ? 64 : 128;
   int n_tiles = ceil_div(p.N, bn);
   // 64-row tiles when 128-row tiles would leave most of the 256 CUs idle (small rollout batches)
   int bm = 128;
-  if (bn >= 64 && (long)ceil_div(p.M, 128) * n_tiles < 256 && p.M > 64) bm = 64;
+  if (bn >= 64 && (long)ceil_div(p.M, 128) * n_tiles * p.groups < 256 && p.M > 64) bm = 64;
   // GroupNorm statistics need every wave tile inside one sample: ohw % (wave rows) == 0
-  if (p.stats && bm == 64 && (p.ohw % 32)) bm = 128;
+  const bool has_stats = p.stats || p.g[0].stats;
+  if (has_stats && bm == 64 && (p.ohw % 32)) bm = 128;
   int m_tiles = ceil_div(p.M, bm);
   int nk = ceil_div(p.K, BK);
-  long tiles = (long)m_tiles * n_tiles;
+  long tiles = (long)m_tiles * n_tiles * p.groups;
   int split = 1;
-  if (tiles < 128 && nk >= 8 && !p.stats) {
+  if (tiles < 128 && nk >= 8 && !has_stats) {
     long a = nk / 4, b = (256 + tiles - 1) / tiles;
     split = (int)(a < b ? a : b);
     if (split < 1) split = 1;
     if (split > 32) split = 32;
-    if (!ws || (size_t)split * p.M * p.N * sizeof(float) > ws_bytes) split = 1;
+    if (!ws || (size_t)split * p.groups * p.M * p.N * sizeof(float) > ws_bytes) split = 1;
   }
   p.ksteps_per_split = ceil_div(nk, split);
   p.splitk = ceil_div(nk, p.ksteps_per_split);
@@ -301,8 +340,11 @@ int run_g2(G2 p, void* ws, size_t ws_bytes, hipStream_t st) {
   if (rc != AVLEN_OK) return rc;
   if (p.splitk > 1) {
     long tot = (long)p.M * p.N;
-    hipLaunchKernelGGL(g2_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, p.slab, p.C32, p.C16, p.bias,
-                       p.residual, p.M, p.N, p.ldc32, p.ldc16, p.ldr, p.splitk, p.act);
+    for (int g = 0; g < p.groups; g++) {
+      hipLaunchKernelGGL(g2_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st,
+                         p.slab + (size_t)g * p.splitk * tot, p.g[g].C32, p.g[g].C16, p.g[g].bias, p.g[g].residual, p.M, p.N,
+                         p.ldc32, p.ldc16, p.ldr, p.splitk, p.act);
+    }
     return avlen_launch_status();
   }
   return AVLEN_OK;
@@ -339,6 +381,38 @@ extern "C" int avlen_conv2d_nhwc_bf16(const void* X, const void* Wp, const float
   }
   int l2 = 0; while ((1 << l2) < Cin) l2++;
   p.cin_log2 = l2; p.kw_magic = (65536 + KW - 1) / KW;
+  return run_g2(p, ws, ws_bytes, stream);
+}
+
+// Grouped forms: `groups` independent problems of identical shape in ONE launch (blockIdx.y = group); used to run the
+// six ResNet towers of the three policies (and the two towers of one policy) as single launches.
+int avlen_conv2d_nhwc_bf16_grouped(const void* const* X, const void* const* Wp, float* const* Y32, float* const* gn_stats,
+                                   int groups, int Bn, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                                   void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (Cin < 8 || (Cin & (Cin - 1)) || groups < 1 || groups > MAXG) return AVLEN_ERR_ARG;
+  int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+  if (OH <= 0 || OW <= 0 || (gn_stats && (OH * OW) % 64)) return AVLEN_ERR_ARG;
+  G2 p = {};
+  p.groups = groups;
+  for (int g = 0; g < groups; g++)
+    p.g[g] = G2Grp{(const bf16*)X[g], (const bf16*)Wp[g], Y32[g], nullptr, nullptr, nullptr, gn_stats ? gn_stats[g] : nullptr};
+  p.M = Bn * OH * OW; p.N = Cout; p.K = KH * KW * Cin; p.lda = 8; p.ldb = p.K; p.ldc32 = Cout; p.ldc16 = Cout; p.ldr = Cout;
+  p.conv = 1; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
+  p.ohw = OH * OW;
+  int l2 = 0; while ((1 << l2) < Cin) l2++;
+  p.cin_log2 = l2; p.kw_magic = (65536 + KW - 1) / KW;
+  return run_g2(p, ws, ws_bytes, stream);
+}
+
+int avlen_gemm_bf16_grouped(const void* const* A, int lda, const void* const* B, int ldb, float* const* C32, int ldc32,
+                            const float* const* bias, int groups, int M, int N, int K, int act, void* ws, size_t ws_bytes,
+                            hipStream_t stream) {
+  if (groups < 1 || groups > MAXG) return AVLEN_ERR_ARG;
+  G2 p = {};
+  p.groups = groups;
+  for (int g = 0; g < groups; g++)
+    p.g[g] = G2Grp{(const bf16*)A[g], (const bf16*)B[g], C32[g], nullptr, bias ? bias[g] : nullptr, nullptr, nullptr};
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc32 = ldc32; p.act = act;
   return run_g2(p, ws, ws_bytes, stream);
 }
 

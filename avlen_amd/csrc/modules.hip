@@ -290,55 +290,77 @@ bool resnet18_has16(const avlen_resnet18* n) {
   return true;
 }
 
-int conv16(const avlen_conv& k, const bf16* x, float* raw, float* stats, int B, int H, int W, void* gws, size_t gwsb,
-           hipStream_t st) {
-  return avlen_conv2d_nhwc_bf16(x, k.w16, nullptr, nullptr, raw, nullptr, stats, B, H, W, k.cin16, k.cout, k.kh, k.kw,
-                                k.stride, k.pad, 0, gws, gwsb, st);
+// G towers of identical shape in lock-step: every conv / GroupNorm / fc is ONE grouped launch (blockIdx.y = tower).
+int resnet18_group_fwd_bf16(const avlen_resnet18* const* nets, const float* const* imgs, const int* channels,
+                            const float* divisors, float* const* outs, int ld_out, int G, int B, int S, void* ws,
+                            size_t ws_bytes, hipStream_t st) {
+  if (G < 1 || G > 8 || ws_bytes < (size_t)G * resnet18_ws_bf16(B)) return AVLEN_ERR_WS;
+  WsBump w(ws, ws_bytes);
+  size_t px = (size_t)B * 4096;
+  size_t stat_stride = align_up((size_t)B * 2 * 128, 64);
+  bf16* x0[8]; float* raw[3][8]; bf16* act[4][8]; float* stats[8];
+  for (int g = 0; g < G; g++) {
+    x0[g] = w.take<bf16>(px * 8);
+    for (int i = 0; i < 3; i++) raw[i][g] = w.take<float>(px * 16);
+    for (int i = 0; i < 4; i++) act[i][g] = w.take<bf16>(px * 16);
+  }
+  float* stats_all = w.take<float>((size_t)G * 21 * stat_stride);
+  size_t gwsb = (size_t)G * avlen_gemm_bf16_workspace_bytes(B, 64);
+  void* gws = w.take<char>(gwsb);
+  if (hipMemsetAsync(stats_all, 0, (size_t)G * 21 * stat_stride * sizeof(float), st) != hipSuccess) return AVLEN_ERR_LAUNCH;
+  int si = 0;
+  auto next_stats = [&](float** out) { for (int g = 0; g < G; g++) out[g] = stats_all + ((size_t)g * 21 + si) * stat_stride; si++; };
+  for (int g = 0; g < G; g++) {
+    if (!resnet18_has16(nets[g]) || channels[g] > 8) return AVLEN_ERR_ARG;
+    TRY(avlen_preprocess_image_bf16(imgs[g], x0[g], B, S, channels[g], divisors[g], st));
+  }
+  const void* X[8]; const void* Wt[8]; float* Y[8]; float* ST[8]; float* ST2[8]; float* ST3[8];
+  const float* GA[8]; const float* BE[8]; const void* RES[8]; void* OUT[8]; const float* XR[8];
+  auto conv = [&](auto getk, bf16** xin, float** rawo, float** stt, int H) -> int {
+    const avlen_conv& k0 = getk(nets[0]);
+    for (int g = 0; g < G; g++) { X[g] = xin[g]; Wt[g] = getk(nets[g]).w16; Y[g] = rawo[g]; }
+    return avlen_conv2d_nhwc_bf16_grouped(X, Wt, Y, stt, G, B, H, H, k0.cin16, k0.cout, k0.kh, k0.kw, k0.stride, k0.pad, gws,
+                                          gwsb, st);
+  };
+  auto gn = [&](auto getn, float** rawi, float** stt, bf16** res, bf16** yo, int HW, int C, int relu) -> int {
+    for (int g = 0; g < G; g++) {
+      XR[g] = rawi[g]; GA[g] = getn(nets[g]).g; BE[g] = getn(nets[g]).b; RES[g] = res ? res[g] : nullptr; OUT[g] = yo[g];
+    }
+    return avlen_groupnorm_apply_bf16_grouped(XR, (const float* const*)stt, GA, BE, res ? RES : nullptr, OUT, G, B, HW, C, 16,
+                                              relu, 1e-5f, st);
+  };
+  next_stats(ST);
+  TRY(conv([](const avlen_resnet18* n) -> const avlen_conv& { return n->conv1; }, x0, raw[0], ST, 64));
+  TRY(gn([](const avlen_resnet18* n) -> const avlen_affine& { return n->bn1; }, raw[0], ST, nullptr, act[0], 4096, 16, 1));
+  bf16** cur = act[0]; bf16** a1 = act[1]; bf16** idt = act[2]; bf16** nxt = act[3];
+  int H = 64;
+  for (int i = 0; i < 8; i++) {
+    const avlen_resblock& k = nets[0]->block[i];
+    int s = k.conv1.stride, OH = (H + 2 - 3) / s + 1, Co = k.conv1.cout;
+    next_stats(ST); next_stats(ST2);
+    TRY(conv([i](const avlen_resnet18* n) -> const avlen_conv& { return n->block[i].conv1; }, cur, raw[0], ST, H));
+    TRY(gn([i](const avlen_resnet18* n) -> const avlen_affine& { return n->block[i].bn1; }, raw[0], ST, nullptr, a1, OH * OH, Co, 1));
+    TRY(conv([i](const avlen_resnet18* n) -> const avlen_conv& { return n->block[i].conv2; }, a1, raw[1], ST2, OH));
+    bf16** identity = cur;
+    if (k.has_down) {
+      next_stats(ST3);
+      TRY(conv([i](const avlen_resnet18* n) -> const avlen_conv& { return n->block[i].down; }, cur, raw[2], ST3, H));
+      TRY(gn([i](const avlen_resnet18* n) -> const avlen_affine& { return n->block[i].bnd; }, raw[2], ST3, nullptr, idt, OH * OH, Co, 0));
+      identity = idt;
+    }
+    TRY(gn([i](const avlen_resnet18* n) -> const avlen_affine& { return n->block[i].bn2; }, raw[1], ST2, identity, nxt, OH * OH, Co, 1));
+    bf16** old = cur; cur = nxt; nxt = old;
+    H = OH;
+  }
+  const void* FA[8]; const void* FB[8]; const float* FBI[8];
+  for (int g = 0; g < G; g++) { FA[g] = cur[g]; FB[g] = nets[g]->fc.w16; FBI[g] = nets[g]->fc.b; }
+  const avlen_linear& fc = nets[0]->fc;
+  return avlen_gemm_bf16_grouped(FA, fc.ld16, FB, fc.ld16, outs, ld_out, FBI, G, B, fc.out_f, fc.ld16, 0, gws, gwsb, st);
 }
 
 int resnet18_fwd_bf16(const avlen_resnet18* net, const float* img, int B, int S, int C, float divisor, float* out,
                       int ld_out, void* ws, size_t ws_bytes, hipStream_t st) {
-  if (ws_bytes < resnet18_ws_bf16(B)) return AVLEN_ERR_WS;
-  WsBump w(ws, ws_bytes);
-  size_t px = (size_t)B * 4096;
-  bf16* x0 = w.take<bf16>(px * 8);
-  float* raw[3]; for (int i = 0; i < 3; i++) raw[i] = w.take<float>(px * 16);
-  bf16* act[4]; for (int i = 0; i < 4; i++) act[i] = w.take<bf16>(px * 16);
-  size_t stat_stride = align_up((size_t)B * 2 * 128, 64);
-  float* stats = w.take<float>(21 * stat_stride);
-  size_t gwsb = avlen_gemm_bf16_workspace_bytes(B, 64);
-  void* gws = w.take<char>(gwsb);
-  if (hipMemsetAsync(stats, 0, 21 * stat_stride * sizeof(float), st) != hipSuccess) return AVLEN_ERR_LAUNCH;
-  int si = 0;
-  auto next_stats = [&]() { return stats + (size_t)(si++) * stat_stride; };
-
-  TRY(avlen_preprocess_image_bf16(img, x0, B, S, C, divisor, st));
-  float* s0 = next_stats();
-  TRY(conv16(net->conv1, x0, raw[0], s0, B, 64, 64, gws, gwsb, st));
-  TRY(avlen_groupnorm_apply_bf16(raw[0], s0, net->bn1.g, net->bn1.b, nullptr, act[0], B, 4096, 16, 16, 1, 1e-5f, st));
-  bf16* cur = act[0]; bf16* a1 = act[1]; bf16* idt = act[2]; bf16* nxt = act[3];
-  int H = 64, Cc = 16;
-  for (int i = 0; i < 8; i++) {
-    const avlen_resblock& k = net->block[i];
-    int s = k.conv1.stride, OH = (H + 2 - 3) / s + 1, Co = k.conv1.cout;
-    float* st1 = next_stats(); float* st2 = next_stats();
-    TRY(conv16(k.conv1, cur, raw[0], st1, B, H, H, gws, gwsb, st));
-    TRY(avlen_groupnorm_apply_bf16(raw[0], st1, k.bn1.g, k.bn1.b, nullptr, a1, B, OH * OH, Co, 16, 1, 1e-5f, st));
-    TRY(conv16(k.conv2, a1, raw[1], st2, B, OH, OH, gws, gwsb, st));
-    const bf16* identity = cur;
-    if (k.has_down) {
-      float* st3 = next_stats();
-      TRY(conv16(k.down, cur, raw[2], st3, B, H, H, gws, gwsb, st));
-      TRY(avlen_groupnorm_apply_bf16(raw[2], st3, k.bnd.g, k.bnd.b, nullptr, idt, B, OH * OH, Co, 16, 0, 1e-5f, st));
-      identity = idt;
-    }
-    TRY(avlen_groupnorm_apply_bf16(raw[1], st2, k.bn2.g, k.bn2.b, identity, nxt, B, OH * OH, Co, 16, 1, 1e-5f, st));
-    bf16* old = cur; cur = nxt; nxt = old;
-    H = OH; Cc = Co;
-  }
-  (void)Cc;
-  return avlen_gemm_bf16(cur, net->fc.ld16, net->fc.w16, net->fc.ld16, out, ld_out, nullptr, 0, net->fc.b, nullptr, 0, B,
-                         net->fc.out_f, net->fc.ld16, 0, gws, gwsb, st);
+  return resnet18_group_fwd_bf16(&net, &img, &C, &divisor, &out, ld_out, 1, B, S, ws, ws_bytes, st);
 }
 
 // ---- 3-conv CNNs ----
@@ -394,6 +416,15 @@ extern "C" size_t avlen_resnet18_workspace_bytes(int B) {
   size_t act = (size_t)B * 64 * 64 * 16 * sizeof(float);
   size_t v1 = 5 * (act + 256) + avlen_groupnorm_workspace_bytes(B, 128) + GEMM_SCRATCH + 4096;
   return zmax(v1, resnet18_ws_bf16(B));
+}
+
+extern "C" size_t avlen_resnet18_group_workspace_bytes(int groups, int B) { return (size_t)groups * resnet18_ws_bf16(B) + 4096; }
+
+extern "C" int avlen_resnet18_group_fwd(const avlen_resnet18* const* nets, const float* const* imgs, const int* channels,
+                                        const float* divisors, float* const* outs, int ld_out, int groups, int B, int S,
+                                        void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!nets || groups < 1 || groups > 8 || B <= 0) return AVLEN_ERR_ARG;
+  return resnet18_group_fwd_bf16(nets, imgs, channels, divisors, outs, ld_out, groups, B, S, ws, ws_bytes, st);
 }
 
 extern "C" int avlen_resnet18_fwd(const avlen_resnet18* net, const float* img, int B, int S, int C, float divisor,

@@ -11,10 +11,14 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8v;
 
 // GroupNorm apply for the bf16 fast path: x = raw fp32 conv output, statistics (per sample/channel sum, sumsq) come
 // from the conv epilogue; y (bf16) = [relu](xhat*g + b [+ res (bf16)]).  8 channels (16 B out) per thread-iteration.
-__global__ __launch_bounds__(256) void gn_apply_bf16_kernel(const float* __restrict__ x, const float* __restrict__ stats,
-                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            const __bf16* __restrict__ res, __bf16* __restrict__ y, int HW,
-                                                            int C, int G, int splits, int relu, float eps) {
+struct GnGroups { const float* x[8]; const float* stats[8]; const float* gamma[8]; const float* beta[8];
+                  const __bf16* res[8]; __bf16* y[8]; };
+
+__global__ __launch_bounds__(256) void gn_apply_bf16_kernel(GnGroups gg, int HW, int C, int G, int splits, int relu,
+                                                            float eps) {
+  const float* __restrict__ x = gg.x[blockIdx.y]; const float* __restrict__ stats = gg.stats[blockIdx.y];
+  const float* __restrict__ gamma = gg.gamma[blockIdx.y]; const float* __restrict__ beta = gg.beta[blockIdx.y];
+  const __bf16* __restrict__ res = gg.res[blockIdx.y]; __bf16* __restrict__ y = gg.y[blockIdx.y];
   __shared__ float s_scale[128], s_shift[128];
   const int b = blockIdx.x / splits, sp = blockIdx.x % splits, tid = threadIdx.x;
   const int cg = C / G;
@@ -333,15 +337,26 @@ extern "C" int avlen_layernorm_fwd(const float* x, const float* residual, const 
   return avlen_layernorm_fwd16(x, residual, gamma, beta, y, nullptr, mean, rstd, rows, d, eps, stream);
 }
 
-int avlen_groupnorm_apply_bf16(const float* x, const float* stats, const float* gamma, const float* beta, const void* res16,
-                               void* y16, int B, int HW, int C, int G, int relu, float eps, hipStream_t stream) {
-  if (C > 128 || C % 8 || 2048 % C || C % G) return AVLEN_ERR_ARG;
+int avlen_groupnorm_apply_bf16_grouped(const float* const* x, const float* const* stats, const float* const* gamma,
+                                       const float* const* beta, const void* const* res16, void* const* y16, int groups,
+                                       int B, int HW, int C, int G, int relu, float eps, hipStream_t stream) {
+  if (C > 128 || C % 8 || 2048 % C || C % G || groups < 1 || groups > 8) return AVLEN_ERR_ARG;
   long n8 = (long)HW * C / 8;
   int splits = 1;
-  while (splits < 16 && (long)B * splits < 512 && n8 / (splits * 2) >= 256) splits *= 2;
-  hipLaunchKernelGGL(gn_apply_bf16_kernel, dim3(B * splits), dim3(256), 0, stream, x, stats, gamma, beta, (const __bf16*)res16,
-                     (__bf16*)y16, HW, C, G, splits, relu, eps);
+  while (splits < 16 && (long)B * splits * groups < 512 && n8 / (splits * 2) >= 256) splits *= 2;
+  GnGroups gg = {};
+  for (int g = 0; g < groups; g++) {
+    gg.x[g] = x[g]; gg.stats[g] = stats[g]; gg.gamma[g] = gamma[g]; gg.beta[g] = beta[g];
+    gg.res[g] = res16 ? (const __bf16*)res16[g] : nullptr; gg.y[g] = (__bf16*)y16[g];
+  }
+  hipLaunchKernelGGL(gn_apply_bf16_kernel, dim3(B * splits, groups), dim3(256), 0, stream, gg, HW, C, G, splits, relu, eps);
   return avlen_launch_status();
+}
+
+int avlen_groupnorm_apply_bf16(const float* x, const float* stats, const float* gamma, const float* beta, const void* res16,
+                               void* y16, int B, int HW, int C, int G, int relu, float eps, hipStream_t stream) {
+  return avlen_groupnorm_apply_bf16_grouped(&x, &stats, &gamma, &beta, res16 ? &res16 : nullptr, &y16, 1, B, HW, C, G, relu,
+                                            eps, stream);
 }
 
 extern "C" int avlen_layernorm_bwd(const float* dy, const float* xsum, const float* gamma, const float* mean,

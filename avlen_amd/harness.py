@@ -28,7 +28,7 @@ def sinusoid_table(n, d):
 class Workload:
     def __init__(self, num_envs, num_steps=150, spectrogram=(257, 101, 2), precision="bf16", pretraining=True,
                  em_capacity=150, ppo_epoch=2, num_mini_batch=2, device="cuda", seed=0, sampling="host",
-                 with_dialog_policy=True, with_goal_policy=True, use_graphs=True):
+                 with_dialog_policy=True, with_goal_policy=True, use_graphs=True, share_encoders=True):
         self.N, self.T, self.dev = num_envs, num_steps, torch.device(device)
         self.spec = spectrogram
         osp, asp = savi_observation_space(spectrogram), ActionSpace(4)
@@ -40,6 +40,8 @@ class Workload:
                      if with_goal_policy else None)
         self.pi_l = (P.AudioNavDialogPolicy(osp, asp, pretraining=False, use_category_input=False, num_steps=3,
                                             **kw).to(self.dev) if with_dialog_policy else None)
+        if share_encoders and precision == "bf16" and self.pi_g is not None and self.pi_l is not None:
+            P.share_encoders(self.pi_q, self.pi_g, self.pi_l)
         self.agent = DDPPO(self.pi_q, clip_param=0.2, ppo_epoch=ppo_epoch, num_mini_batch=num_mini_batch,
                            value_loss_coef=0.5, entropy_coef=0.05, lr=2.5e-4, eps=1e-5, max_grad_norm=0.2,
                            use_normalized_advantage=False)

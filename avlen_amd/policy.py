@@ -83,7 +83,7 @@ def _sig(a):
     return a
 
 
-def _graphed(pol, which, fn, args):
+def _graphed(pol, which, fn, args, mode=None):
     # rnn_hidden_states (arg 1) and masks (arg 3) are not read by the SMT nets: keep them out of the graph
     args = list(args)
     rnn = args[1]
@@ -93,8 +93,8 @@ def _graphed(pol, which, fn, args):
     for i in by_ptr:
         if torch.is_tensor(args[i]):
             args[i] = _f32(args[i])
-    key = (which,) + tuple(_sig(a) for a in args) + tuple(args[i].data_ptr() if torch.is_tensor(args[i]) else 0
-                                                          for i in by_ptr)
+    key = (which, mode) + tuple(_sig(a) for a in args) + tuple(args[i].data_ptr() if torch.is_tensor(args[i]) else 0
+                                                                for i in by_ptr)
     g = pol._graphs.get(key)
     if g is None:
         pol._engine()                                    # flat/packed state must exist before capture
@@ -105,6 +105,66 @@ def _graphed(pol, which, fn, args):
     outs = list(outs)
     outs[1] = rnn
     return tuple(outs), dict(heads)
+
+
+class EncoderGroup:
+    """Policies that are evaluated on the SAME observation every step (pi_q, pi_g, pi_l in
+    ppo_trainer.py:449-636) can run their visual towers together: when the leader (the policy called first,
+    pi_q) runs, all 2*len(members) ResNet towers execute as grouped launches (one launch per layer for all of
+    them); a follower called afterwards with the same rgb/depth tensors picks its 128 visual features up
+    instead of recomputing them.  Numerically identical to separate calls (same kernels, same operands)."""
+
+    def __init__(self, leader, followers):
+        self.members = [leader] + list(followers)
+        self.leader = leader
+        self.out = {}                  # B -> [tensor (B,128)] per member
+        self.key = None
+        self.pending = set()
+        for m in self.members:
+            m._enc_group = self
+
+    def mark(self, obs):
+        self.key = (obs["rgb"].data_ptr(), obs["depth"].data_ptr(), tuple(obs["rgb"].shape))
+        self.pending = set(id(m) for m in self.members[1:])
+
+    def claim(self, pol, obs):
+        """True once per leader call for a follower that presents the leader's observation tensors."""
+        k = (obs["rgb"].data_ptr(), obs["depth"].data_ptr(), tuple(obs["rgb"].shape))
+        if k == self.key and id(pol) in self.pending:
+            self.pending.discard(id(pol))
+            return True
+        return False
+
+    def buffers(self, B, dev):
+        if B not in self.out:
+            self.out[B] = [torch.empty(B, 128, device=dev) for _ in self.members]
+        return self.out[B]
+
+    def run_all(self, pol, rgb, depth):
+        B, dev = rgb.shape[0], rgb.device
+        bufs = self.buffers(B, dev)
+        G = 2 * len(self.members)
+        nets = (C.POINTER(L.ResNet18) * G)()
+        imgs, outs = (C.c_void_p * G)(), (C.c_void_p * G)()
+        chans, divs = (C.c_int * G)(), (C.c_float * G)()
+        for i, m in enumerate(self.members):
+            eng = m._engine()
+            for j, (key, img, div) in enumerate((("rgb", rgb, 255.0), ("depth", depth, 1.0))):
+                g = 2 * i + j
+                nets[g] = C.pointer(eng[key])
+                imgs[g] = img.data_ptr()
+                outs[g] = bufs[i].data_ptr() + 4 * 64 * j
+                chans[g], divs[g] = img.shape[3], div
+        nb = L.lib.avlen_resnet18_group_workspace_bytes(G, B)
+        ws = pol._ws.get("resnet_group", nb, dev)
+        L.call("avlen_resnet18_group_fwd", nets, imgs, chans, divs, outs, 128, G, B, rgb.shape[1], E.P(ws), nb, L.stream())
+        return bufs[0]
+
+
+def share_encoders(leader, *followers):
+    """Opt-in cross-policy tower batching (see EncoderGroup).  All members must use precision="bf16"."""
+    assert all(m.precision == "bf16" for m in (leader,) + followers), "encoder sharing runs on the bf16 fast path"
+    return EncoderGroup(leader, followers)
 
 
 class _Dist:
@@ -132,6 +192,8 @@ class Policy(nn.Module):
         self.use_graphs = use_graphs          # capture each act*/get_value* forward in a HIP graph (static shapes)
         self._graphs = {}
         self._side = None
+        self._enc_group = None
+        self._shared_mode = None
         self._eng = None
         self._ws = E.Workspaces()
         self._dirty = True
@@ -247,9 +309,20 @@ class Policy(nn.Module):
         def eager(*args):
             outs = self.net.run(self, *args)
             return outs, self._heads_first(which, outs[0])
-        if not self.use_graphs:
-            return eager(*net_args)
-        return _graphed(self, which, eager, net_args)
+        mode, grp = None, self._enc_group
+        if grp is not None and self.precision == "bf16":
+            if grp.leader is self:
+                grp.mark(net_args[0])
+                mode = "lead"
+            elif grp.claim(self, net_args[0]):
+                mode = "follow"
+        self._shared_mode = mode
+        try:
+            if not self.use_graphs:
+                return eager(*net_args)
+            return _graphed(self, which, eager, net_args, mode)
+        finally:
+            self._shared_mode = None
 
     # ------------------------------------------------------------------ reference API
     def act(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks,
@@ -401,26 +474,54 @@ class _SMTBase(Net):
         goal = torch.empty(B, self._hidden_size, device=dev)
         st = L.stream()
         prec = pol.prec
-        nb = L.lib.avlen_resnet18_workspace_bytes(B)
-        ws_rgb, ws_dep = pol._ws.get("resnet_rgb", nb, dev), pol._ws.get("resnet_depth", nb, dev)
         S = rgb.shape[1]
         H, W = spec.shape[1], spec.shape[2]
         nb2 = L.lib.avlen_cnn3_workspace_bytes(C.byref(eng["audio"]), B, H, W)
         ws2 = pol._ws.get("audio", nb2, dev)
-        # inside a graph capture the two towers become parallel branches (fork/join on side streams)
         cur = torch.cuda.current_stream()
         fork = torch.cuda.is_current_stream_capturing()
-        s_rgb, s_dep = (pol.side_streams()[:2] if fork else (cur, cur))
-        if fork:
-            s_rgb.wait_stream(cur)
-            s_dep.wait_stream(cur)
-        with torch.cuda.stream(s_rgb):
-            L.call("avlen_resnet18_fwd", C.byref(eng["rgb"]), E.P(rgb), B, S, rgb.shape[3], 255.0, E.P(feats, 0), F, prec,
-                   E.P(ws_rgb), nb, L.stream())
-        with torch.cuda.stream(s_dep):
-            L.call("avlen_resnet18_fwd", C.byref(eng["depth"]), E.P(depth), B, S, depth.shape[3], 1.0, E.P(feats, 64), F,
-                   prec, E.P(ws_dep), nb, L.stream())
-        L.call("avlen_cnn3_fwd", C.byref(eng["audio"]), E.P(spec), B, H, W, E.P(feats, 144), F, prec, E.P(ws2), nb2, st)
+        mode, grp = pol._shared_mode, pol._enc_group
+        if prec == L.PREC_BF16:
+            # bf16 fast path: the towers run as grouped launches (rgb+depth of this policy, or -- leader of an
+            # EncoderGroup -- all towers of all member policies); the audio CNN is a parallel branch under capture
+            s_aud = pol.side_streams()[0] if fork else cur
+            if fork:
+                s_aud.wait_stream(cur)
+            with torch.cuda.stream(s_aud):
+                L.call("avlen_cnn3_fwd", C.byref(eng["audio"]), E.P(spec), B, H, W, E.P(feats, 144), F, prec, E.P(ws2), nb2,
+                       L.stream())
+            if mode == "follow":
+                vis = grp.buffers(B, dev)[grp.members.index(pol)]
+            elif mode == "lead":
+                vis = grp.run_all(pol, rgb, depth)
+            else:
+                vis = None
+                G = 2
+                nets = (C.POINTER(L.ResNet18) * G)(C.pointer(eng["rgb"]), C.pointer(eng["depth"]))
+                imgs = (C.c_void_p * G)(rgb.data_ptr(), depth.data_ptr())
+                outs = (C.c_void_p * G)(feats.data_ptr(), feats.data_ptr() + 4 * 64)
+                chans, divs = (C.c_int * G)(rgb.shape[3], depth.shape[3]), (C.c_float * G)(255.0, 1.0)
+                nbg = L.lib.avlen_resnet18_group_workspace_bytes(G, B)
+                wsg = pol._ws.get("resnet_pair", nbg, dev)
+                L.call("avlen_resnet18_group_fwd", nets, imgs, chans, divs, outs, F, G, B, S, E.P(wsg), nbg, st)
+            if vis is not None:
+                L.call("avlen_copy_rows", E.P(vis), 128, E.P(feats), F, B, 128, st)
+            s_rgb = s_dep = s_aud
+        else:
+            nb = L.lib.avlen_resnet18_workspace_bytes(B)
+            ws_rgb, ws_dep = pol._ws.get("resnet_rgb", nb, dev), pol._ws.get("resnet_depth", nb, dev)
+            # inside a graph capture the two towers become parallel branches (fork/join on side streams)
+            s_rgb, s_dep = (pol.side_streams()[:2] if fork else (cur, cur))
+            if fork:
+                s_rgb.wait_stream(cur)
+                s_dep.wait_stream(cur)
+            with torch.cuda.stream(s_rgb):
+                L.call("avlen_resnet18_fwd", C.byref(eng["rgb"]), E.P(rgb), B, S, rgb.shape[3], 255.0, E.P(feats, 0), F, prec,
+                       E.P(ws_rgb), nb, L.stream())
+            with torch.cuda.stream(s_dep):
+                L.call("avlen_resnet18_fwd", C.byref(eng["depth"]), E.P(depth), B, S, depth.shape[3], 1.0, E.P(feats, 64), F,
+                       prec, E.P(ws_dep), nb, L.stream())
+            L.call("avlen_cnn3_fwd", C.byref(eng["audio"]), E.P(spec), B, H, W, E.P(feats, 144), F, prec, E.P(ws2), nb2, st)
         pa = _i64(prev_actions.view(B, -1)[:, :1])
         cat = _f32(obs[CATEGORY]) if self._use_category_input else None
         pose = _f32(obs[POSE])

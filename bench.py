@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--no-share", action="store_true", help="do not batch the three policies' visual towers")
     return ap.parse_args()
 
 
@@ -107,7 +108,7 @@ def main():
     from avlen_amd.harness import Workload
     H, W = (int(x) for x in a.spectrogram.split("x"))
     wl = Workload(a.envs, a.rollout, spectrogram=(H, W, 2), precision=a.precision, pretraining=True, seed=rank,
-                  use_graphs=not a.no_graphs)
+                  use_graphs=not a.no_graphs, share_encoders=not a.no_share)
 
     def barrier():
         torch.cuda.synchronize()

@@ -154,6 +154,13 @@ size_t avlen_resnet18_workspace_bytes(int B);
  * divisor = 255 for rgb, 1 for depth; writes 64 features to out[b*ld_out + 0..63]. */
 int avlen_resnet18_fwd(const avlen_resnet18* net, const float* img, int B, int S, int C, float divisor, float* out,
                        int ld_out, int prec, void* ws, size_t ws_bytes, avlen_stream_t stream);
+/* `groups` (<= 8) towers of identical shape in lock-step on the bf16 fast path: every conv / GroupNorm / fc is ONE
+ * grouped launch (blockIdx.y = tower).  Used to run rgb+depth of a policy -- or all six towers of pi_q/pi_g/pi_l,
+ * which see the same observation -- as single launches.  Arrays are host arrays of length `groups`. */
+size_t avlen_resnet18_group_workspace_bytes(int groups, int B);
+int avlen_resnet18_group_fwd(const avlen_resnet18* const* nets, const float* const* imgs, const int* channels,
+                             const float* divisors, float* const* outs, int ld_out, int groups, int B, int S, void* ws,
+                             size_t ws_bytes, avlen_stream_t stream);
 size_t avlen_cnn3_workspace_bytes(const avlen_cnn3* net, int B, int H, int W);
 /* AudioCNN.forward (audio_cnn.py:136-151) / VisualCNN.cnn: x NHWC (B,H,W,conv[0].cin) -> out[b*ld_out + 0..fc.out_f). */
 int avlen_cnn3_fwd(const avlen_cnn3* net, const float* x, int B, int H, int W, float* out, int ld_out, int prec,

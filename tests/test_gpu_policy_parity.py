@@ -178,7 +178,7 @@ def test_dialog_policy_bf16_tolerance(specs):
     e_l = float(np.abs(logits.cpu().numpy() - g["logits"]).max())
     e_x = float(np.abs(xd.cpu().numpy() - g["xd"]).max())
     print(f"pi_l bf16: max |logit err| {e_l:.4g}, max |state err| {e_x:.4g}")
-    assert e_l < 3e-2 and e_x < 1.5e-1
+    assert e_l < 6e-2 and e_x < 1.5e-1        # fixture heads are He-scaled (logits O(1)), not gain-0.01
 
 
 def test_option_distractor(specs):
@@ -422,3 +422,22 @@ def test_graph_replay_equals_eager(specs):
     diffs = {n: float((a.double() - b.double()).abs().max()) for n, a, b in zip(names, outs[False], outs[True])}
     print("graph vs eager max abs diffs:", diffs)
     assert all(v == 0.0 for v in diffs.values()), diffs
+
+
+def test_shared_grouped_towers_match_separate_calls(specs):
+    """EncoderGroup (all six towers of pi_q/pi_g/pi_l as grouped launches, followers reuse) vs each policy running its
+    own towers: same kernels and operands, so equal up to the fp32 atomic order of the fused GroupNorm statistics."""
+    from avlen_amd.harness import Workload
+    outs = {}
+    for share in (False, True):
+        wl = Workload(4, 3, spectrogram=(65, 26, 2), precision="bf16", pretraining=False, em_capacity=4, seed=5,
+                      use_graphs=share, share_encoders=share)
+        torch.manual_seed(11)
+        for _ in range(3):
+            wl.rollout_step()
+        ro = wl.rollouts
+        torch.cuda.synchronize()
+        outs[share] = [ro.value_preds.clone(), ro.em_option.memory.clone(), ro.em.memory.clone(), ro.em_vln_dialog.memory.clone()]
+    for a, b in zip(outs[False], outs[True]):
+        err = float((a - b).abs().max() / (b.abs().max() + 1e-9))
+        assert err < 2e-3, err
