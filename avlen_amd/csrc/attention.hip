@@ -124,7 +124,15 @@ __global__ __launch_bounds__(128) void attn_fwd4_kernel(const float* __restrict_
                                                         int ldk, const float* __restrict__ V, int ldv,
                                                         float* __restrict__ O, int ldo, __bf16* __restrict__ O16, int ldo16,
                                                         float* __restrict__ lse, int H, int Sq, int Sk, int causal,
-                                                        float scale) {
+                                                        float scale, const int* __restrict__ seg_off) {
+  // seg_off (optional, ragged batches): sample b owns rows seg_off[b] .. seg_off[b+1]-1 of Q/K/V/O (Sq = Sk = its length)
+  long row0 = (long)blockIdx.z * Sq;
+  if (seg_off) {
+    row0 = seg_off[blockIdx.z];
+    Sq = Sk = seg_off[blockIdx.z + 1] - seg_off[blockIdx.z];
+    if ((int)blockIdx.x * 32 >= Sq) return;
+  }
+  const long krow0 = seg_off ? row0 : (long)blockIdx.z * Sk;
   constexpr int DP = D / 4;                       // dims per lane
   constexpr int KC = 96;                          // keys per LDS chunk (CLIP's 77 keys land in one pass)
   __shared__ __attribute__((aligned(16))) float ks[KC * D];
@@ -137,7 +145,7 @@ __global__ __launch_bounds__(128) void attn_fwd4_kernel(const float* __restrict_
 #pragma unroll
   for (int d = 0; d < DP; d++) { q[d] = 0.f; o[d] = 0.f; }
   if (qok) {
-    const float* qp = Q + ((long)b * Sq + i) * ldq + h * D + part * DP;
+    const float* qp = Q + (row0 + i) * ldq + h * D + part * DP;
 #pragma unroll
     for (int d = 0; d < DP; d++) q[d] = qp[d] * scale;
   }
@@ -148,8 +156,8 @@ __global__ __launch_bounds__(128) void attn_fwd4_kernel(const float* __restrict_
     for (int jl = ql; jl < KC; jl += 32) {         // thread (key = jl, part) stages D/4 floats of K and V
       const int j = j0 + jl;
       if (j < sk_end) {
-        const float4* kp = reinterpret_cast<const float4*>(K + ((long)b * Sk + j) * ldk + h * D + part * DP);
-        const float4* vp = reinterpret_cast<const float4*>(V + ((long)b * Sk + j) * ldv + h * D + part * DP);
+        const float4* kp = reinterpret_cast<const float4*>(K + (krow0 + j) * ldk + h * D + part * DP);
+        const float4* vp = reinterpret_cast<const float4*>(V + (krow0 + j) * ldv + h * D + part * DP);
         float4* kd = reinterpret_cast<float4*>(&ks[jl * D + part * DP]);
         float4* vd = reinterpret_cast<float4*>(&vs[jl * D + part * DP]);
 #pragma unroll
@@ -199,12 +207,12 @@ __global__ __launch_bounds__(128) void attn_fwd4_kernel(const float* __restrict_
   if (qok) {
     const float inv = l > 0.f ? 1.f / l : 0.f;
     if (O) {
-      float* op = O + ((long)b * Sq + i) * ldo + h * D + part * DP;
+      float* op = O + (row0 + i) * ldo + h * D + part * DP;
 #pragma unroll
       for (int d = 0; d < DP; d++) op[d] = o[d] * inv;
     }
     if (O16) {
-      __bf16* oh = O16 + ((long)b * Sq + i) * ldo16 + h * D + part * DP;
+      __bf16* oh = O16 + (row0 + i) * ldo16 + h * D + part * DP;
 #pragma unroll
       for (int d = 0; d < DP; d++) oh[d] = (__bf16)(o[d] * inv);
     }
@@ -339,16 +347,25 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(const float* __restric
 int avlen_attention_fwd16(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                           void* O16, int ldo16, const float* key_mask, float* lse, int B, int H, int Sq, int Sk, int D,
                           int causal, float scale, hipStream_t stream) {
+  return avlen_attention_fwd16_seg(Q, ldq, K, ldk, V, ldv, O, ldo, O16, ldo16, key_mask, lse, B, H, Sq, Sk, D, causal, scale,
+                                   nullptr, stream);
+}
+
+int avlen_attention_fwd16_seg(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+                              void* O16, int ldo16, const float* key_mask, float* lse, int B, int H, int Sq, int Sk, int D,
+                              int causal, float scale, const int* seg_off, hipStream_t stream) {
+  if (seg_off && (key_mask || lse)) return AVLEN_ERR_ARG;
   if (B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0 || (ldq | ldk | ldv | ldo) % 4) return AVLEN_ERR_ARG;
   __bf16* oh = (__bf16*)O16;
-  if (!key_mask && Sq >= 16 && (D == 32 || D == 64)) {       // no padding mask: 4-lanes-per-query kernel
+  if (!key_mask && (Sq >= 16 || seg_off) && (D == 32 || D == 64)) {       // no padding mask: 4-lanes-per-query kernel
     dim3 g4(ceil_div(Sq, 32), H, B), b4(128);
     if (D == 32)
-      hipLaunchKernelGGL((attn_fwd4_kernel<32>), g4, b4, 0, stream, Q, ldq, K, ldk, V, ldv, O, ldo, oh, ldo16, lse, H, Sq, Sk, causal, scale);
+      hipLaunchKernelGGL((attn_fwd4_kernel<32>), g4, b4, 0, stream, Q, ldq, K, ldk, V, ldv, O, ldo, oh, ldo16, lse, H, Sq, Sk, causal, scale, seg_off);
     else
-      hipLaunchKernelGGL((attn_fwd4_kernel<64>), g4, b4, 0, stream, Q, ldq, K, ldk, V, ldv, O, ldo, oh, ldo16, lse, H, Sq, Sk, causal, scale);
+      hipLaunchKernelGGL((attn_fwd4_kernel<64>), g4, b4, 0, stream, Q, ldq, K, ldk, V, ldv, O, ldo, oh, ldo16, lse, H, Sq, Sk, causal, scale, seg_off);
     return avlen_launch_status();
   }
+  if (seg_off) return AVLEN_ERR_ARG;
   dim3 grid(ceil_div(Sq, 64), H, B), block(64);
   if (D == 32)
     hipLaunchKernelGGL((attn_fwd_kernel<32>), grid, block, 0, stream, Q, ldq, K, ldk, V, ldv, O, ldo, oh, ldo16, key_mask, lse, H, Sq, Sk, causal, scale);

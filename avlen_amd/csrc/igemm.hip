@@ -287,30 +287,67 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
     }
   }
 
-  // ---- epilogue: C/D layout col = lane&15, row = (lane>>4)*4 + reg ----
+  // ---- epilogue: C/D layout col = lane&15, row = (lane>>4)*4 + reg.  Bias / residual loads are all issued before the
+  // first store so their latencies overlap (a per-tile load->use->store chain costs one round trip per tile).
   const int col_l = lane & 15, rq = lane >> 4;
+  float bv[NI];
 #pragma unroll
-  for (int mi = 0; mi < 2; mi++) {
+  for (int ni = 0; ni < NI; ni++) {
+    int col = n0 + ni * 16 + col_l;
+    bv[ni] = (p.bias && !p.to_slab && col < p.N) ? p.bias[col] : 0.f;
+  }
+  if (p.to_slab) {
+#pragma unroll
+    for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+      for (int ni = 0; ni < NI; ni++) {
+        int col = n0 + ni * 16 + col_l;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          int row = m0 + wave * 32 + mi * 16 + rq * 4 + r;
+          if (col < p.N && row < p.M) p.C[((long)blockIdx.z * p.M + row) * p.N + col] = acc[mi][ni][r];
+        }
+      }
+    return;
+  }
+  if (p.residual) {
+    float rv[2][NI][4];
+#pragma unroll
+    for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+      for (int ni = 0; ni < NI; ni++) {
+        int col = n0 + ni * 16 + col_l;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          int row = m0 + wave * 32 + mi * 16 + rq * 4 + r;
+          rv[mi][ni][r] = (col < p.N && row < p.M) ? p.residual[(long)row * p.ldr + col] : 0.f;
+        }
+      }
+#pragma unroll
+    for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+      for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[mi][ni][r] = act_apply(acc[mi][ni][r] + bv[ni], p.act) + rv[mi][ni][r];
+  } else {
+#pragma unroll
+    for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+      for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[mi][ni][r] = act_apply(acc[mi][ni][r] + bv[ni], p.act);
+  }
+#pragma unroll
+  for (int mi = 0; mi < 2; mi++)
 #pragma unroll
     for (int ni = 0; ni < NI; ni++) {
       int col = n0 + ni * 16 + col_l;
-      if (col >= p.N) continue;
-      float bv = (p.bias && !p.to_slab) ? p.bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         int row = m0 + wave * 32 + mi * 16 + rq * 4 + r;
-        if (row >= p.M) continue;
-        float v = acc[mi][ni][r];
-        if (p.to_slab) {
-          p.C[((long)blockIdx.z * p.M + row) * p.N + col] = v;
-        } else {
-          v = act_apply(v + bv, p.act);
-          if (p.residual) v += p.residual[(long)row * p.ldr + col];
-          p.C[(long)row * p.ldc + col] = v;
-        }
+        if (col < p.N && row < p.M) p.C[(long)row * p.ldc + col] = acc[mi][ni][r];
       }
     }
-  }
 }
 
 __global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, const float* bias,

@@ -21,7 +21,8 @@ typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-__device__ __attribute__((aligned(16))) unsigned int g_zero_page[4] = {0, 0, 0, 0};
+// zeros for padding taps / K tails / surplus rows: 16 KB so that the lanes of a block do not all hit one address
+__device__ __attribute__((aligned(16))) unsigned int g_zero_page[4096];
 
 namespace {
 
@@ -40,6 +41,7 @@ struct G2 {
   int conv, H, W, Cin, cin_log2, OH, OW, KH, KW, kw_magic, stride, pad;
   int splitk, ksteps_per_split;
   float* slab;
+  const int* M_dev;           // optional: the live row count (<= M) is read from device memory (ragged batches)
   float* stats; int ohw;      // optional GroupNorm statistics: stats[sample][0|1][N] += sum / sum of squares of C
 };
 
@@ -61,6 +63,8 @@ __global__ __launch_bounds__(NT) void g2_kernel(G2 pp) {
     p.A = gg.A; p.B = gg.B; p.C32 = gg.C32; p.C16 = gg.C16; p.bias = gg.bias; p.residual = gg.residual; p.stats = gg.stats;
     if (p.slab) p.slab += (size_t)blockIdx.y * p.splitk * p.M * p.N;
   }
+  const int M_alloc = p.M;                     // slab layout uses the allocated row count
+  if (p.M_dev) p.M = min(p.M, *p.M_dev);
   constexpr int WTM = BM / WM, WTN = BN / WN;       // wave tile
   constexpr int MI = WTM / 16, NI = WTN / 16;
   constexpr int A_ROUNDS = BM * 8 / NT;              // 16-byte chunks per thread for the A tile
@@ -75,6 +79,7 @@ __global__ __launch_bounds__(NT) void g2_kernel(G2 pp) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n_tiles = (p.N + BN - 1) / BN;
   const int m0 = (blockIdx.x / n_tiles) * BM, n0 = (blockIdx.x % n_tiles) * BN;
+  if (m0 >= p.M) return;                       // whole tile beyond the live rows (uniform per block)
   const int nk_total = (p.K + BK - 1) / BK;
   const int kt_beg = blockIdx.z * p.ksteps_per_split;
   const int kt_end = min(nk_total, kt_beg + p.ksteps_per_split);
@@ -95,7 +100,7 @@ __global__ __launch_bounds__(NT) void g2_kernel(G2 pp) {
       a_src[r] = (const char*)(p.A + (long)b * p.H * p.W * p.Cin);
       a_iy0[r] = oy * p.stride - p.pad; a_ix0[r] = ox * p.stride - p.pad;
     } else {
-      a_src[r] = (const char*)(p.A + (long)min(m, p.M - 1) * p.lda);
+      a_src[r] = (const char*)(p.A + (long)(m < p.M ? m : m % p.M) * p.lda);     // surplus rows re-read distinct valid rows
       a_iy0[r] = 0; a_ix0[r] = 0;
     }
   }
@@ -104,9 +109,9 @@ __global__ __launch_bounds__(NT) void g2_kernel(G2 pp) {
   for (int r = 0; r < B_ROUNDS; r++) {
     int slot = r * NT + tid, row = (slot >> 3) % BN;           // surplus lanes (slot >= B_SLOTS) re-read a valid row
     b_sw[r] = ((slot & 7) ^ ((row >> 1) & 7)) * 8;
-    b_src[r] = (const char*)(p.B + (long)min(n0 + row, p.N - 1) * p.ldb);
+    b_src[r] = (const char*)(p.B + (long)((n0 + row) < p.N ? (n0 + row) : (n0 + row) % p.N) * p.ldb);
   }
-  const char* zero = (const char*)g_zero_page;
+  const char* zero = (const char*)g_zero_page + tid * 16;          // per-thread slice of the zero page (tid*16 < 4 KB)
 
   auto issue = [&](int kt, int stage) {
     char* abase = lds + stage * STAGE;
@@ -203,39 +208,78 @@ __global__ __launch_bounds__(NT) void g2_kernel(G2 pp) {
     }
   }
 
-  // ---- epilogue ----
+  // ---- epilogue: all bias / residual loads are issued before the first store (no serialized round trips) ----
+  float bv[NI];
 #pragma unroll
-  for (int i = 0; i < MI; i++) {
+  for (int j = 0; j < NI; j++) {
+    int col = n0 + wn * WTN + j * 16 + r16;
+    bv[j] = (p.bias && p.splitk == 1 && col < p.N) ? p.bias[col] : 0.f;
+  }
+  if (p.splitk > 1) {
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+      for (int j = 0; j < NI; j++) {
+        int col = n0 + wn * WTN + j * 16 + r16;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          int row = m0 + wm * WTM + i * 16 + q * 4 + r;
+          if (col < p.N && row < p.M) p.slab[((long)blockIdx.z * M_alloc + row) * p.N + col] = acc[i][j][r];
+        }
+      }
+    return;
+  }
+  if (p.residual) {
+    float rv[MI][NI][4];
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+      for (int j = 0; j < NI; j++) {
+        int col = n0 + wn * WTN + j * 16 + r16;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          int row = m0 + wm * WTM + i * 16 + q * 4 + r;
+          rv[i][j][r] = (col < p.N && row < p.M) ? p.residual[(long)row * p.ldr + col] : 0.f;
+        }
+      }
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+      for (int j = 0; j < NI; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[i][j][r] = act2(acc[i][j][r] + bv[j], p.act) + rv[i][j][r];
+  } else {
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+      for (int j = 0; j < NI; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[i][j][r] = act2(acc[i][j][r] + bv[j], p.act);
+  }
+#pragma unroll
+  for (int i = 0; i < MI; i++)
 #pragma unroll
     for (int j = 0; j < NI; j++) {
       int col = n0 + wn * WTN + j * 16 + r16;
-      if (col >= p.N) continue;
-      float bv = (p.bias && p.splitk == 1) ? p.bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         int row = m0 + wm * WTM + i * 16 + q * 4 + r;
-        if (row >= p.M) continue;
-        float v = acc[i][j][r];
-        if (p.splitk > 1) {
-          p.slab[((long)blockIdx.z * p.M + row) * p.N + col] = v;
-        } else {
-          v = act2(v + bv, p.act);
-          if (p.residual) v += p.residual[(long)row * p.ldr + col];
-          if (p.C32) p.C32[(long)row * p.ldc32 + col] = v;
-          if (p.C16) p.C16[(long)row * p.ldc16 + col] = (bf16)v;
+        if (col < p.N && row < p.M) {
+          if (p.C32) p.C32[(long)row * p.ldc32 + col] = acc[i][j][r];
+          if (p.C16) p.C16[(long)row * p.ldc16 + col] = (bf16)acc[i][j][r];
         }
       }
     }
-  }
 }
 
 __global__ void g2_reduce_kernel(const float* __restrict__ slab, float* __restrict__ C32, bf16* __restrict__ C16,
                                  const float* __restrict__ bias, const float* __restrict__ residual, int M, int N,
-                                 int ldc32, int ldc16, int ldr, int splits, int act) {
+                                 int ldc32, int ldc16, int ldr, int splits, int act, const int* __restrict__ M_dev) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long tot = (long)M * N;
   if (i >= tot) return;
   int row = (int)(i / N), col = (int)(i - (long)row * N);
+  if (M_dev && row >= *M_dev) return;
   float s = 0.f;
   for (int z = 0; z < splits; z++) s += slab[(long)z * tot + i];
   if (bias) s += bias[col];
@@ -343,7 +387,7 @@ int run_g2(G2 p, void* ws, size_t ws_bytes, hipStream_t st) {
     for (int g = 0; g < p.groups; g++) {
       hipLaunchKernelGGL(g2_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st,
                          p.slab + (size_t)g * p.splitk * tot, p.g[g].C32, p.g[g].C16, p.g[g].bias, p.g[g].residual, p.M, p.N,
-                         p.ldc32, p.ldc16, p.ldr, p.splitk, p.act);
+                         p.ldc32, p.ldc16, p.ldr, p.splitk, p.act, p.M_dev);
     }
     return avlen_launch_status();
   }
@@ -413,6 +457,17 @@ int avlen_gemm_bf16_grouped(const void* const* A, int lda, const void* const* B,
   for (int g = 0; g < groups; g++)
     p.g[g] = G2Grp{(const bf16*)A[g], (const bf16*)B[g], C32[g], nullptr, bias ? bias[g] : nullptr, nullptr, nullptr};
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc32 = ldc32; p.act = act;
+  return run_g2(p, ws, ws_bytes, stream);
+}
+
+// Same as avlen_gemm_bf16 with the live row count taken from device memory (*M_dev <= M): tiles beyond it exit at once.
+int avlen_gemm_bf16_dyn(const void* A, int lda, const void* B, int ldb, float* C32, int ldc32, void* C16, int ldc16,
+                        const float* bias, const float* residual, int ldr, int M, const int* M_dev, int N, int K, int act,
+                        void* ws, size_t ws_bytes, hipStream_t stream) {
+  G2 p = {};
+  p.A = (const bf16*)A; p.B = (const bf16*)B; p.C32 = C32; p.C16 = (bf16*)C16; p.bias = bias; p.residual = residual;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc32 = ldc32; p.ldc16 = ldc16; p.ldr = ldr; p.act = act;
+  p.M_dev = M_dev;
   return run_g2(p, ws, ws_bytes, stream);
 }
 

@@ -177,6 +177,49 @@ __global__ void clip_embed_kernel(const int64_t* __restrict__ tokens, const floa
     o[i] = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
   }
 }
+// Ragged batch bookkeeping: causal attention + EOT pooling means tokens AFTER the EOT token can never influence the
+// output, so only the prefix [0, eot] of every dialog is computed.  seg[b] = first compact row of sample b,
+// seg[B] = number of live rows; rowmap[r] = b*ctx + t of compact row r.
+__global__ void clip_segments_kernel(const int64_t* __restrict__ tokens, int* __restrict__ seg, int* __restrict__ rowmap, int B,
+                                     int ctx) {
+  __shared__ int len[1024];
+  const int t = threadIdx.x;
+  for (int b = t; b < B; b += blockDim.x) {
+    long best = tokens[(long)b * ctx]; int bi = 0;
+    for (int k = 1; k < ctx; k++) { long v = tokens[(long)b * ctx + k]; if (v > best) { best = v; bi = k; } }
+    len[b] = bi + 1;
+  }
+  __syncthreads();
+  if (t == 0) { int acc = 0; for (int b = 0; b < B; b++) { seg[b] = acc; acc += len[b]; } seg[B] = acc; }
+  __syncthreads();
+  for (int b = 0; b < B; b++) {
+    int o = seg[b];
+    for (int k = t; k < len[b]; k += blockDim.x) rowmap[o + k] = b * ctx + k;
+  }
+}
+__global__ void clip_embed_ragged_kernel(const int64_t* __restrict__ tokens, const float* __restrict__ tok_emb,
+                                         const float* __restrict__ pos_emb, float* __restrict__ x, const int* __restrict__ seg,
+                                         const int* __restrict__ rowmap, int B, int ctx, int width, int vocab) {
+  const int row = blockIdx.x;
+  if (row >= seg[B]) return;
+  const int src = rowmap[row], t = src % ctx;
+  long id = tokens[src];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const float4* e = reinterpret_cast<const float4*>(tok_emb + id * width);
+  const float4* p = reinterpret_cast<const float4*>(pos_emb + (long)t * width);
+  float4* o = reinterpret_cast<float4*>(x + (long)row * width);
+  for (int i = threadIdx.x; i < width / 4; i += blockDim.x) {
+    float4 a = e[i], c = p[i];
+    o[i] = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
+  }
+}
+__global__ void clip_gather_last_kernel(const float* __restrict__ x, float* __restrict__ out, const int* __restrict__ seg,
+                                        int width) {
+  const int b = blockIdx.x;
+  const float* src = x + (long)(seg[b + 1] - 1) * width;
+  for (int i = threadIdx.x; i < width; i += blockDim.x) out[(long)b * width + i] = src[i];
+}
+
 __global__ void clip_gather_eot_kernel(const int64_t* __restrict__ tokens, const float* __restrict__ x,
                                        float* __restrict__ out, int ctx, int width) {
   const int b = blockIdx.x;
@@ -1018,28 +1061,45 @@ extern "C" int avlen_clip_text_fwd(const avlen_clip_text* p, const int64_t* toke
   void* gws = w.take<char>(GEMM_SCRATCH);
   Ctx c{st, prec, gws, GEMM_SCRATCH};
   const float scale = 1.0f / sqrtf((float)D);
-  hipLaunchKernelGGL(clip_embed_kernel, dim3((unsigned)R), dim3(128), 0, st, tokens, p->tok_emb, p->pos_emb, X, ctx, wd,
-                     p->vocab);
-  TRY(avlen_launch_status());
-  bool fast = prec == AVLEN_PREC_BF16;
+  bool fast = prec == AVLEN_PREC_BF16 && B <= 1024;
   for (int l = 0; l < p->layers && fast; l++) {
     const avlen_clip_block& b = p->block[l];
     fast = lin16_ok(b.attn.in_proj) && lin16_ok(b.attn.out_proj) && lin16_ok(b.fc) && lin16_ok(b.proj);
   }
-  if (fast) {      // bf16 operands from HBM: Hn / AO / F live in bf16, the residual stream X stays fp32
+  if (fast) {      // bf16 operands from HBM; ragged batch: only the tokens up to each EOT are computed
     bf16* Hn16 = (bf16*)Hn; bf16* AO16 = (bf16*)AO; bf16* F16 = (bf16*)Fh;
+    int* seg = (int*)E2;                              // [B+1] (E2 is used again only after the layers)
+    int* rowmap = (int*)QKV;                          // [R]   (consumed by the embedding, before QKV is written)
+    const int* live = seg + B;
+    hipLaunchKernelGGL(clip_segments_kernel, dim3(1), dim3(1024), 0, st, tokens, seg, rowmap, B, ctx);
+    hipLaunchKernelGGL(clip_embed_ragged_kernel, dim3((unsigned)R), dim3(128), 0, st, tokens, p->tok_emb, p->pos_emb, X, seg,
+                       rowmap, B, ctx, wd, p->vocab);
+    TRY(avlen_launch_status());
+    auto lin = [&](const avlen_linear& L, const bf16* X16, int ldx, float* Y32, int ld32, bf16* Y16, int ld16, int act,
+                   const float* res) {
+      return avlen_gemm_bf16_dyn(X16, ldx, L.w16, L.ld16, Y32, ld32, Y16, ld16, L.b, res, ld32, (int)R, live, L.out_f, L.ld16,
+                                 act, c.gws, c.gws_bytes, c.st);
+    };
     for (int l = 0; l < p->layers; l++) {
       const avlen_clip_block& b = p->block[l];
-      TRY(avlen_layernorm_fwd16(X, nullptr, b.ln1.g, b.ln1.b, nullptr, Hn16, nullptr, nullptr, (int)R, wd, 1e-5f, st));
-      TRY(linear16(c, b.attn.in_proj, Hn16, wd, QKV, 3 * wd, nullptr, 0, (int)R, 0, nullptr, 0));
-      TRY(avlen_attention_fwd16(QKV, 3 * wd, QKV + wd, 3 * wd, QKV + 2 * wd, 3 * wd, nullptr, 0, AO16, wd, nullptr, nullptr, B,
-                                H, ctx, ctx, D, 1, scale, st));
-      TRY(linear16(c, b.attn.out_proj, AO16, wd, X, wd, nullptr, 0, (int)R, 0, X, wd));
-      TRY(avlen_layernorm_fwd16(X, nullptr, b.ln2.g, b.ln2.b, nullptr, Hn16, nullptr, nullptr, (int)R, wd, 1e-5f, st));
-      TRY(linear16(c, b.fc, Hn16, wd, nullptr, 0, F16, b.fc.out_f, (int)R, AVLEN_ACT_QUICKGELU, nullptr, 0));
-      TRY(linear16(c, b.proj, F16, b.fc.out_f, X, wd, nullptr, 0, (int)R, 0, X, wd));
+      TRY(avlen_layernorm_fwd16_dyn(X, nullptr, b.ln1.g, b.ln1.b, nullptr, Hn16, nullptr, nullptr, (int)R, live, wd, 1e-5f, st));
+      TRY(lin(b.attn.in_proj, Hn16, wd, QKV, 3 * wd, nullptr, 0, 0, nullptr));
+      TRY(avlen_attention_fwd16_seg(QKV, 3 * wd, QKV + wd, 3 * wd, QKV + 2 * wd, 3 * wd, nullptr, 0, AO16, wd, nullptr, nullptr,
+                                    B, H, ctx, ctx, D, 1, scale, seg, st));
+      TRY(lin(b.attn.out_proj, AO16, wd, X, wd, nullptr, 0, 0, X));
+      TRY(avlen_layernorm_fwd16_dyn(X, nullptr, b.ln2.g, b.ln2.b, nullptr, Hn16, nullptr, nullptr, (int)R, live, wd, 1e-5f, st));
+      TRY(lin(b.fc, Hn16, wd, nullptr, 0, F16, b.fc.out_f, AVLEN_ACT_QUICKGELU, nullptr));
+      TRY(lin(b.proj, F16, b.fc.out_f, X, wd, nullptr, 0, 0, X));
     }
-  } else
+    hipLaunchKernelGGL(clip_gather_last_kernel, dim3(B), dim3(128), 0, st, X, E, seg, wd);
+    TRY(avlen_launch_status());
+    TRY(avlen_layernorm_fwd(E, nullptr, p->ln_final.g, p->ln_final.b, E2, nullptr, nullptr, B, wd, 1e-5f, st));
+    return avlen_gemm(E2, wd, 0, p->text_proj, p->out_dim, 1, out, p->out_dim, nullptr, nullptr, 0, B, p->out_dim, wd, 0,
+                      prec, 1, 0.f, gws, GEMM_SCRATCH, st);
+  }
+  hipLaunchKernelGGL(clip_embed_kernel, dim3((unsigned)R), dim3(128), 0, st, tokens, p->tok_emb, p->pos_emb, X, ctx, wd,
+                     p->vocab);
+  TRY(avlen_launch_status());
   for (int l = 0; l < p->layers; l++) {
     const avlen_clip_block& b = p->block[l];
     TRY(avlen_layernorm_fwd(X, nullptr, b.ln1.g, b.ln1.b, Hn, nullptr, nullptr, (int)R, wd, 1e-5f, st));

@@ -162,10 +162,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float* __restrict__ y, __bf16* __restrict__ y16,
                                                      float* __restrict__ mean_o, float* __restrict__ rstd_o, int rows,
-                                                     float eps) {
+                                                     float eps, const int* __restrict__ rows_dev) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  if (row >= rows || (rows_dev && row >= *rows_dev)) return;
   constexpr int d = NV * 64;
   const float* xr = x + (long)row * d;
   float v[NV];
@@ -318,14 +318,20 @@ extern "C" int avlen_groupnorm_nhwc(const float* x, const float* gamma, const fl
 
 int avlen_layernorm_fwd16(const float* x, const float* residual, const float* gamma, const float* beta, float* y,
                           void* y16, float* mean, float* rstd, int rows, int d, float eps, hipStream_t stream) {
+  return avlen_layernorm_fwd16_dyn(x, residual, gamma, beta, y, y16, mean, rstd, rows, nullptr, d, eps, stream);
+}
+
+int avlen_layernorm_fwd16_dyn(const float* x, const float* residual, const float* gamma, const float* beta, float* y,
+                              void* y16, float* mean, float* rstd, int rows, const int* rows_dev, int d, float eps,
+                              hipStream_t stream) {
   if (rows <= 0) return AVLEN_ERR_ARG;
   dim3 grid(ceil_div(rows, 4)), block(256);
   __bf16* h = (__bf16*)y16;
   switch (d) {
-    case 256: hipLaunchKernelGGL((ln_fwd_kernel<4>), grid, block, 0, stream, x, residual, gamma, beta, y, h, mean, rstd, rows, eps); break;
-    case 512: hipLaunchKernelGGL((ln_fwd_kernel<8>), grid, block, 0, stream, x, residual, gamma, beta, y, h, mean, rstd, rows, eps); break;
-    case 128: hipLaunchKernelGGL((ln_fwd_kernel<2>), grid, block, 0, stream, x, residual, gamma, beta, y, h, mean, rstd, rows, eps); break;
-    case 64: hipLaunchKernelGGL((ln_fwd_kernel<1>), grid, block, 0, stream, x, residual, gamma, beta, y, h, mean, rstd, rows, eps); break;
+    case 256: hipLaunchKernelGGL((ln_fwd_kernel<4>), grid, block, 0, stream, x, residual, gamma, beta, y, h, mean, rstd, rows, eps, rows_dev); break;
+    case 512: hipLaunchKernelGGL((ln_fwd_kernel<8>), grid, block, 0, stream, x, residual, gamma, beta, y, h, mean, rstd, rows, eps, rows_dev); break;
+    case 128: hipLaunchKernelGGL((ln_fwd_kernel<2>), grid, block, 0, stream, x, residual, gamma, beta, y, h, mean, rstd, rows, eps, rows_dev); break;
+    case 64: hipLaunchKernelGGL((ln_fwd_kernel<1>), grid, block, 0, stream, x, residual, gamma, beta, y, h, mean, rstd, rows, eps, rows_dev); break;
     default: return AVLEN_ERR_ARG;
   }
   return avlen_launch_status();
