@@ -28,11 +28,11 @@ def sinusoid_table(n, d):
 class Workload:
     def __init__(self, num_envs, num_steps=150, spectrogram=(257, 101, 2), precision="bf16", pretraining=True,
                  em_capacity=150, ppo_epoch=2, num_mini_batch=2, device="cuda", seed=0, sampling="host",
-                 with_dialog_policy=True, with_goal_policy=True, use_graphs=True, share_encoders=True):
+                 with_dialog_policy=True, with_goal_policy=True, use_graphs=True, share_encoders=True, weight_seed=0):
         self.N, self.T, self.dev = num_envs, num_steps, torch.device(device)
         self.spec = spectrogram
         osp, asp = savi_observation_space(spectrogram), ActionSpace(4)
-        torch.manual_seed(seed)
+        torch.manual_seed(weight_seed)          # identical initial weights on every rank (data-parallel replicas)
         kw = dict(SMT_KW, precision=precision, sampling=sampling, use_graphs=use_graphs)
         self.pi_q = P.AudioNavOptionPolicy(osp, asp, pretraining=pretraining, use_category_input=False,
                                            query_count_emb_size=32, **kw).to(self.dev)

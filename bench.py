@@ -40,9 +40,32 @@ def parse():
 
 
 def kernel_roofline(prec_name):
-    """Dominant dense kernel, timed live with HIP events on the launch stream: the bf16 MFMA GEMM of the CLIP MLP
-    up-projection of one rollout step (M = 64 envs x 77 tokens = 4928 rows, K = 512, N = 2048, QuickGELU epilogue,
-    bf16 out; 12 such launches per pi_l step).  bf16: g2_kernel<128,128> (igemm2.hip); fp32: igemm_kernel<128,fp32>."""
+    """Roofline of the DOMINANT kernel by GPU time (profiles/r01_rocprof_summary.md): g2_kernel<128,16,4,1,2>, the 3x3
+    16->16 implicit-GEMM conv of the ResNet towers' layer1 with fused GroupNorm statistics, as launched in a rollout step
+    (six towers x 64 envs = 384 images of 64x64x16).  HBM-bound: N=16 output channels give 36 FLOP per byte.
+    `achieved` = algorithmic bytes (bf16 activation read once + fp32 raw output written once) / duration measured live with
+    HIP events on the launch stream; `traffic` = HBM bytes per launch from the rocprofv3 PMC passes
+    (profiles/r01_pmc_traffic.json, FETCH_SIZE x2 per the gfx950 note).  The MFMA-bound GEMM of the CLIP MLP is reported
+    beside it as `mfma_gemm`."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import roofline_probe as rp
+    sec = rp.measure()
+    ab = rp.algorithmic_bytes()
+    traffic = None
+    try:
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["traffic_bytes_gfx950_corrected"]
+    except Exception:
+        pass
+    ach = ab / sec / 1e9
+    out = {"bound": "hbm", "kernel": "g2_kernel<128,16,4,1,2> (tower layer1 conv3x3 16->16 @64x64, 384 images/launch, bf16 in, "
+                                     "fp32 out, fused GN stats)", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
+           "frac": round(ach / 8000.0, 4), "traffic": traffic, "algorithmic_bytes": ab, "us_per_launch": round(sec * 1e6, 2)}
+    out["mfma_gemm"] = mfma_gemm_rate(prec_name)
+    return out
+
+
+def mfma_gemm_rate(prec_name):
+    """bf16 MFMA GEMM of the CLIP MLP up-projection (M = 64 envs x 77 tokens = 4928, K = 512, N = 2048, QuickGELU)."""
     from avlen_amd import _lib as L
     from avlen_amd.engine import P
     M, N, K = 64 * 77, 2048, 512
@@ -58,7 +81,7 @@ def kernel_roofline(prec_name):
         ws = torch.empty(nb, dtype=torch.uint8, device=dev)
         run = lambda: L.call("avlen_gemm_bf16", P(A16), K, P(W16), K, None, N, P(C16), N, P(b), None, 0, M, N, K, 2, P(ws),
                              nb, st)
-        name, peak = "g2_kernel<128,128,2,2> bf16 glds", 2500.0
+        name, peak = "g2_kernel<128,128,2,2,2> bf16 glds", 2500.0
     else:
         Cc = torch.empty(M, N, device=dev)
         nb = L.lib.avlen_gemm_workspace_bytes(M, N, K, 1)
@@ -76,11 +99,9 @@ def kernel_roofline(prec_name):
     e1.record()
     torch.cuda.synchronize()
     sec = e0.elapsed_time(e1) / 1e3 / iters
-    flops = 2.0 * M * N * K
-    ach = flops / sec / 1e12
-    return {"bound": "mfma", "kernel": f"{name} (CLIP c_fc, M=4928 N=2048 K=512, QuickGELU epilogue)",
-            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
-            "us_per_launch": round(sec * 1e6, 2)}
+    ach = 2.0 * M * N * K / sec / 1e12
+    return {"kernel": f"{name} (CLIP c_fc M=4928 N=2048 K=512)", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(ach / peak, 4), "us_per_launch": round(sec * 1e6, 2)}
 
 
 def cpu_baseline(spec_hw):
