@@ -117,18 +117,25 @@ __global__ __launch_bounds__(NT) void g2_kernel(G2 pp) {
     char* abase = lds + stage * STAGE;
     char* bbase = abase + A_BYTES;
     const int k0 = kt * BK;
+    // the swizzle term ((row>>1)&7) is the same for all of a thread's rows (they are 32 rows apart), so the k offset --
+    // and, for convolutions, the tap decode -- is computed once per K-step and shared by the A_ROUNDS gathers
+    const int ka = k0 + a_sw[0];
+    int ky = 0, kx = 0, ci = 0;
+    if (p.conv) {
+      int tap = ka >> p.cin_log2;
+      ci = ka & (p.Cin - 1);
+      ky = (tap * p.kw_magic) >> 16; kx = tap - ky * p.KW;
+    }
+    const bool k_ok = ka < p.K;
 #pragma unroll
     for (int r = 0; r < A_ROUNDS; r++) {
-      int k = k0 + a_sw[r];
       const char* src = zero;
       if (p.conv) {
-        int tap = k >> p.cin_log2, ci = k & (p.Cin - 1);
-        int ky = (tap * p.kw_magic) >> 16, kx = tap - ky * p.KW;
         int iy = a_iy0[r] + ky, ix = a_ix0[r] + kx;
-        if (a_ok[r] && k < p.K && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+        if (a_ok[r] && k_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
           src = a_src[r] + (((long)iy * p.W + ix) * p.Cin + ci) * 2;
-      } else if (k < p.K) {
-        src = a_src[r] + (long)k * 2;
+      } else if (k_ok) {
+        src = a_src[r] + (long)ka * 2;
       }
       __builtin_amdgcn_global_load_lds((const void*)src,
           (__attribute__((address_space(3))) void*)(abase + (r * NT + wave * 64) * 16), 16, 0, 0);
@@ -430,8 +437,8 @@ extern "C" int avlen_conv2d_nhwc_bf16(const void* X, const void* Wp, const float
 
 // Grouped forms: `groups` independent problems of identical shape in ONE launch (blockIdx.y = group); used to run the
 // six ResNet towers of the three policies (and the two towers of one policy) as single launches.
-int avlen_conv2d_nhwc_bf16_grouped(const void* const* X, const void* const* Wp, float* const* Y32, float* const* gn_stats,
-                                   int groups, int Bn, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+int avlen_conv2d_nhwc_bf16_grouped(const void* const* X, const void* const* Wp, float* const* Y32, void* const* Y16,
+                                   float* const* gn_stats, int groups, int Bn, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                                    void* ws, size_t ws_bytes, hipStream_t stream) {
   if (Cin < 8 || (Cin & (Cin - 1)) || groups < 1 || groups > MAXG) return AVLEN_ERR_ARG;
   int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
@@ -439,7 +446,8 @@ int avlen_conv2d_nhwc_bf16_grouped(const void* const* X, const void* const* Wp, 
   G2 p = {};
   p.groups = groups;
   for (int g = 0; g < groups; g++)
-    p.g[g] = G2Grp{(const bf16*)X[g], (const bf16*)Wp[g], Y32[g], nullptr, nullptr, nullptr, gn_stats ? gn_stats[g] : nullptr};
+    p.g[g] = G2Grp{(const bf16*)X[g], (const bf16*)Wp[g], Y32 ? Y32[g] : nullptr, Y16 ? (bf16*)Y16[g] : nullptr, nullptr,
+                   nullptr, gn_stats ? gn_stats[g] : nullptr};
   p.M = Bn * OH * OW; p.N = Cout; p.K = KH * KW * Cin; p.lda = 8; p.ldb = p.K; p.ldc32 = Cout; p.ldc16 = Cout; p.ldr = Cout;
   p.conv = 1; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
   p.ohw = OH * OW;

@@ -14,10 +14,12 @@ int avlen_attention_fwd16(const float* Q, int ldq, const float* K, int ldk, cons
                           void* O16, int ldo16, const float* key_mask, float* lse, int B, int H, int Sq, int Sk, int D,
                           int causal, float scale, hipStream_t stream);
 int avlen_preprocess_image_bf16(const float* x, void* y16, int B, int S, int C, float divisor, hipStream_t stream);
-int avlen_groupnorm_apply_bf16_grouped(const float* const* x, const float* const* stats, const float* const* gamma,
-                                       const float* const* beta, const void* const* res16, void* const* y16, int groups,
-                                       int B, int HW, int C, int G, int relu, float eps, hipStream_t stream);
-int avlen_conv2d_nhwc_bf16_grouped(const void* const* X, const void* const* Wp, float* const* Y32, float* const* gn_stats,
+int avlen_groupnorm_apply_bf16_grouped(const void* const* x, int raw16, const float* const* stats,
+                                       const float* const* gamma, const float* const* beta, const void* const* res16,
+                                       void* const* y16, int groups, int B, int HW, int C, int G, int relu, float eps,
+                                       hipStream_t stream);
+int avlen_conv2d_nhwc_bf16_grouped(const void* const* X, const void* const* Wp, float* const* Y32, void* const* Y16,
+                                   float* const* gn_stats,
                                    int groups, int Bn, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                                    void* ws, size_t ws_bytes, hipStream_t stream);
 int avlen_gemm_bf16_grouped(const void* const* A, int lda, const void* const* B, int ldb, float* const* C32, int ldc32,
@@ -32,3 +34,6 @@ int avlen_attention_fwd16_seg(const float* Q, int ldq, const float* K, int ldk, 
 int avlen_gemm_bf16_dyn(const void* A, int lda, const void* B, int ldb, float* C32, int ldc32, void* C16, int ldc16,
                         const float* bias, const float* residual, int ldr, int M, const int* M_dev, int N, int K, int act,
                         void* ws, size_t ws_bytes, hipStream_t stream);
+int avlen_dconv3x3_bf16_grouped(const void* const* X, const void* const* Wp, void* const* Y16, float* const* gn_stats,
+                                int groups, int B, int W, int C, hipStream_t stream);
+bool avlen_dconv3x3_supported(int W, int C, int KH, int KW, int stride, int pad);

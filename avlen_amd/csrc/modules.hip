@@ -341,10 +341,10 @@ int resnet18_group_fwd_bf16(const avlen_resnet18* const* nets, const float* cons
   WsBump w(ws, ws_bytes);
   size_t px = (size_t)B * 4096;
   size_t stat_stride = align_up((size_t)B * 2 * 128, 64);
-  bf16* x0[8]; float* raw[3][8]; bf16* act[4][8]; float* stats[8];
+  bf16* x0[8]; bf16* raw[3][8]; bf16* act[4][8];
   for (int g = 0; g < G; g++) {
     x0[g] = w.take<bf16>(px * 8);
-    for (int i = 0; i < 3; i++) raw[i][g] = w.take<float>(px * 16);
+    for (int i = 0; i < 3; i++) raw[i][g] = w.take<bf16>(px * 16);     // raw conv outputs kept in bf16
     for (int i = 0; i < 4; i++) act[i][g] = w.take<bf16>(px * 16);
   }
   float* stats_all = w.take<float>((size_t)G * 21 * stat_stride);
@@ -357,19 +357,21 @@ int resnet18_group_fwd_bf16(const avlen_resnet18* const* nets, const float* cons
     if (!resnet18_has16(nets[g]) || channels[g] > 8) return AVLEN_ERR_ARG;
     TRY(avlen_preprocess_image_bf16(imgs[g], x0[g], B, S, channels[g], divisors[g], st));
   }
-  const void* X[8]; const void* Wt[8]; float* Y[8]; float* ST[8]; float* ST2[8]; float* ST3[8];
-  const float* GA[8]; const float* BE[8]; const void* RES[8]; void* OUT[8]; const float* XR[8];
-  auto conv = [&](auto getk, bf16** xin, float** rawo, float** stt, int H) -> int {
+  const void* X[8]; const void* Wt[8]; void* Y[8]; float* ST[8]; float* ST2[8]; float* ST3[8];
+  const float* GA[8]; const float* BE[8]; const void* RES[8]; void* OUT[8]; const void* XR[8];
+  auto conv = [&](auto getk, bf16** xin, bf16** rawo, float** stt, int H) -> int {
     const avlen_conv& k0 = getk(nets[0]);
     for (int g = 0; g < G; g++) { X[g] = xin[g]; Wt[g] = getk(nets[g]).w16; Y[g] = rawo[g]; }
-    return avlen_conv2d_nhwc_bf16_grouped(X, Wt, Y, stt, G, B, H, H, k0.cin16, k0.cout, k0.kh, k0.kw, k0.stride, k0.pad, gws,
+    if (k0.cin16 == k0.cout && avlen_dconv3x3_supported(H, k0.cout, k0.kh, k0.kw, k0.stride, k0.pad))
+      return avlen_dconv3x3_bf16_grouped(X, Wt, Y, stt, G, B, H, k0.cout, st);      // small-channel stages: direct conv
+    return avlen_conv2d_nhwc_bf16_grouped(X, Wt, nullptr, Y, stt, G, B, H, H, k0.cin16, k0.cout, k0.kh, k0.kw, k0.stride, k0.pad, gws,
                                           gwsb, st);
   };
-  auto gn = [&](auto getn, float** rawi, float** stt, bf16** res, bf16** yo, int HW, int C, int relu) -> int {
+  auto gn = [&](auto getn, bf16** rawi, float** stt, bf16** res, bf16** yo, int HW, int C, int relu) -> int {
     for (int g = 0; g < G; g++) {
       XR[g] = rawi[g]; GA[g] = getn(nets[g]).g; BE[g] = getn(nets[g]).b; RES[g] = res ? res[g] : nullptr; OUT[g] = yo[g];
     }
-    return avlen_groupnorm_apply_bf16_grouped(XR, (const float* const*)stt, GA, BE, res ? RES : nullptr, OUT, G, B, HW, C, 16,
+    return avlen_groupnorm_apply_bf16_grouped(XR, 1, (const float* const*)stt, GA, BE, res ? RES : nullptr, OUT, G, B, HW, C, 16,
                                               relu, 1e-5f, st);
   };
   next_stats(ST);

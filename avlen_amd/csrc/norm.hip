@@ -11,12 +11,14 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8v;
 
 // GroupNorm apply for the bf16 fast path: x = raw fp32 conv output, statistics (per sample/channel sum, sumsq) come
 // from the conv epilogue; y (bf16) = [relu](xhat*g + b [+ res (bf16)]).  8 channels (16 B out) per thread-iteration.
-struct GnGroups { const float* x[8]; const float* stats[8]; const float* gamma[8]; const float* beta[8];
+struct GnGroups { const void* x[8]; const float* stats[8]; const float* gamma[8]; const float* beta[8];
                   const __bf16* res[8]; __bf16* y[8]; };
 
+template <bool RAW16>      // RAW16: the raw conv output is stored in bf16 (statistics were taken from the fp32 accumulators)
 __global__ __launch_bounds__(256) void gn_apply_bf16_kernel(GnGroups gg, int HW, int C, int G, int splits, int relu,
                                                             float eps) {
-  const float* __restrict__ x = gg.x[blockIdx.y]; const float* __restrict__ stats = gg.stats[blockIdx.y];
+  const float* __restrict__ x = (const float*)gg.x[blockIdx.y]; const float* __restrict__ stats = gg.stats[blockIdx.y];
+  const __bf16* __restrict__ x16 = (const __bf16*)gg.x[blockIdx.y];
   const float* __restrict__ gamma = gg.gamma[blockIdx.y]; const float* __restrict__ beta = gg.beta[blockIdx.y];
   const __bf16* __restrict__ res = gg.res[blockIdx.y]; __bf16* __restrict__ y = gg.y[blockIdx.y];
   __shared__ float s_scale[128], s_shift[128];
@@ -44,9 +46,16 @@ __global__ __launch_bounds__(256) void gn_apply_bf16_kernel(GnGroups gg, int HW,
 #pragma unroll
   for (int i = 0; i < 8; i++) { sc[i] = s_scale[c0 + i]; sh[i] = s_shift[c0 + i]; }
   for (long f = beg + tid; f < end; f += 256) {
-    const float4* xp = reinterpret_cast<const float4*>(x + base + f * 8);
-    float4 a = xp[0], c = xp[1];
-    float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+    float v[8];
+    if constexpr (RAW16) {
+      bf16x8v xr = *reinterpret_cast<const bf16x8v*>(x16 + base + f * 8);
+#pragma unroll
+      for (int i = 0; i < 8; i++) v[i] = (float)xr[i];
+    } else {
+      const float4* xp = reinterpret_cast<const float4*>(x + base + f * 8);
+      float4 a = xp[0], c = xp[1];
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+    }
     if (res) {
       bf16x8v r = *reinterpret_cast<const bf16x8v*>(res + base + f * 8);
 #pragma unroll
@@ -343,9 +352,10 @@ extern "C" int avlen_layernorm_fwd(const float* x, const float* residual, const 
   return avlen_layernorm_fwd16(x, residual, gamma, beta, y, nullptr, mean, rstd, rows, d, eps, stream);
 }
 
-int avlen_groupnorm_apply_bf16_grouped(const float* const* x, const float* const* stats, const float* const* gamma,
-                                       const float* const* beta, const void* const* res16, void* const* y16, int groups,
-                                       int B, int HW, int C, int G, int relu, float eps, hipStream_t stream) {
+int avlen_groupnorm_apply_bf16_grouped(const void* const* x, int raw16, const float* const* stats,
+                                       const float* const* gamma, const float* const* beta, const void* const* res16,
+                                       void* const* y16, int groups, int B, int HW, int C, int G, int relu, float eps,
+                                       hipStream_t stream) {
   if (C > 128 || C % 8 || 2048 % C || C % G || groups < 1 || groups > 8) return AVLEN_ERR_ARG;
   long n8 = (long)HW * C / 8;
   int splits = 1;
@@ -355,13 +365,17 @@ int avlen_groupnorm_apply_bf16_grouped(const float* const* x, const float* const
     gg.x[g] = x[g]; gg.stats[g] = stats[g]; gg.gamma[g] = gamma[g]; gg.beta[g] = beta[g];
     gg.res[g] = res16 ? (const __bf16*)res16[g] : nullptr; gg.y[g] = (__bf16*)y16[g];
   }
-  hipLaunchKernelGGL(gn_apply_bf16_kernel, dim3(B * splits, groups), dim3(256), 0, stream, gg, HW, C, G, splits, relu, eps);
+  if (raw16)
+    hipLaunchKernelGGL((gn_apply_bf16_kernel<true>), dim3(B * splits, groups), dim3(256), 0, stream, gg, HW, C, G, splits, relu, eps);
+  else
+    hipLaunchKernelGGL((gn_apply_bf16_kernel<false>), dim3(B * splits, groups), dim3(256), 0, stream, gg, HW, C, G, splits, relu, eps);
   return avlen_launch_status();
 }
 
 int avlen_groupnorm_apply_bf16(const float* x, const float* stats, const float* gamma, const float* beta, const void* res16,
                                void* y16, int B, int HW, int C, int G, int relu, float eps, hipStream_t stream) {
-  return avlen_groupnorm_apply_bf16_grouped(&x, &stats, &gamma, &beta, res16 ? &res16 : nullptr, &y16, 1, B, HW, C, G, relu,
+  const void* xv = x;
+  return avlen_groupnorm_apply_bf16_grouped(&xv, 0, &stats, &gamma, &beta, res16 ? &res16 : nullptr, &y16, 1, B, HW, C, G, relu,
                                             eps, stream);
 }
 
