@@ -113,6 +113,7 @@ SIGNATURES = {
     "avlen_gemm_bf16": (i32, [vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, sz, vp]),
     "avlen_gemm_bf16_workspace_bytes": (sz, [i32, i32]),
     "avlen_conv2d_nhwc_bf16": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "avlen_conv_direct_bf16": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "avlen_cast_bf16": (i32, [vp, i32, vp, i32, C.c_long, i32, vp]),
     "avlen_pack_conv_weight_bf16": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "avlen_pack_fc_after_flatten_bf16": (i32, [vp, vp, i32, i32, i32, vp]),

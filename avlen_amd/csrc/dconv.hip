@@ -24,25 +24,26 @@ namespace {
 
 struct DcGroups { const bf16* x[8]; const bf16* w[8]; bf16* y[8]; float* stats[8]; };
 
-template <int C, int W>      // C channels in = out, image W x W
+template <int C, int CO, int W, int KSZ>      // C input channels (power of two >= 8), CO output channels, image W x W, KSZ x KSZ taps
 __global__ __launch_bounds__(256) void dconv3x3_kernel(DcGroups gg, int B) {
   constexpr int TR = 8;                       // output rows per block
-  constexpr int PB = C * 2;                   // bytes per pixel
-  constexpr int ROWB = (W + 2) * PB;          // bytes per halo row
-  constexpr int NT = C / 16;                  // output-channel tiles
-  constexpr int KS = 9 * C / 32;              // MFMA k-steps (C=16: 4.5 -> 5, the tail half is zero weights)
-  constexpr int KSTEPS = (9 * C + 31) / 32;
+  constexpr int PAD = KSZ / 2;
+  constexpr int PB = C * 2;                   // bytes per input pixel
+  constexpr int ROWB = (W + 2 * PAD) * PB;    // bytes per halo row
+  constexpr int NT = CO / 16;                 // output-channel tiles
+  constexpr int KTOT = KSZ * KSZ * C;         // reduction length
+  constexpr int KSTEPS = (KTOT + 31) / 32;    // MFMA k-steps (a partial tail step multiplies zero weights)
   constexpr int MT_ROW = W / 16;              // 16-pixel tiles per image row
   constexpr int ROWS_PER_WAVE = TR / 4;
-  (void)KS;
-  __shared__ __attribute__((aligned(16))) char halo[(TR + 2) * ROWB];
+  constexpr int HR = TR + 2 * PAD;            // halo rows
+  __shared__ __attribute__((aligned(16))) char halo[HR * ROWB];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, q = lane >> 4;
   const int y0 = blockIdx.x * TR, b = blockIdx.y;
   const bf16* __restrict__ x = gg.x[blockIdx.z] + (long)b * W * W * C;
   const bf16* __restrict__ wt = gg.w[blockIdx.z];
-  bf16* __restrict__ y = gg.y[blockIdx.z] + (long)b * W * W * C;
+  bf16* __restrict__ y = gg.y[blockIdx.z] + (long)b * W * W * CO;
   float* __restrict__ stats = gg.stats[blockIdx.z];
 
   // ---- weights -> MFMA fragments in registers: lane (r16, q) holds W[cout = j*16 + r16][k = 32 s + 8 q .. +7]
@@ -52,29 +53,29 @@ __global__ __launch_bounds__(256) void dconv3x3_kernel(DcGroups gg, int B) {
 #pragma unroll
     for (int j = 0; j < NT; j++) {
       int k = 32 * s + 8 * q;
-      if (k < 9 * C) wf[s][j] = *reinterpret_cast<const bf16x8*>(wt + (long)(j * 16 + r16) * 9 * C + k);
+      if (k < KTOT) wf[s][j] = *reinterpret_cast<const bf16x8*>(wt + (long)(j * 16 + r16) * KTOT + k);
       else { bf16x8 z; for (int e = 0; e < 8; e++) z[e] = (bf16)0.f; wf[s][j] = z; }
     }
 
   // ---- halo: rows y0-1 .. y0+TR, interior columns by global_load_lds (1 KiB pieces), border columns zeroed
-  constexpr int PIECES_PER_ROW = (W * PB) / 1024 > 0 ? (W * PB) / 1024 : 1;      // C=16,W=64: 2 ; C=32,W=32: 2
-  constexpr int PIECE_B = (W * PB) / PIECES_PER_ROW;                              // bytes per piece (1024)
-  static_assert(PIECE_B == 1024, "halo rows are staged in 1 KiB wave-instructions");
-  constexpr int NPIECES = (TR + 2) * PIECES_PER_ROW;                              // 20
+  constexpr int PIECES_PER_ROW = (W * PB) / 1024;                                 // C=16,W=64: 2 ; C=32,W=32: 2 ; C=8,W=64: 1
+  static_assert(PIECES_PER_ROW >= 1 && (W * PB) % 1024 == 0, "halo rows are staged in 1 KiB wave-instructions");
+  constexpr int NPIECES = HR * PIECES_PER_ROW;
   for (int pc = wave; pc < NPIECES; pc += 4) {
     int hr = pc / PIECES_PER_ROW, part = pc % PIECES_PER_ROW;
-    int iy = y0 - 1 + hr;
+    int iy = y0 - PAD + hr;
     const char* src = (iy >= 0 && iy < W) ? (const char*)(x + (long)iy * W * C) + part * 1024 + lane * 16
                                           : (const char*)g_zero_page_dc + lane * 16;
     __builtin_amdgcn_global_load_lds((const void*)src,
-        (__attribute__((address_space(3))) void*)(halo + hr * ROWB + PB + part * 1024), 16, 0, 0);
+        (__attribute__((address_space(3))) void*)(halo + hr * ROWB + PAD * PB + part * 1024), 16, 0, 0);
   }
-  // left / right padding columns
-  for (int i = tid; i < (TR + 2) * 2 * (PB / 16); i += 256) {
-    int hr = i / (2 * (PB / 16)), rem = i % (2 * (PB / 16));
-    int side = rem / (PB / 16), ch = rem % (PB / 16);
+  // left / right padding columns (PAD pixels each side)
+  constexpr int PADCH = PAD * PB / 16;                                            // 16-byte chunks per side per row
+  for (int i = tid; i < HR * 2 * PADCH; i += 256) {
+    int hr = i / (2 * PADCH), rem = i % (2 * PADCH);
+    int side = rem / PADCH, ch = rem % PADCH;
     float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    *reinterpret_cast<float4*>(halo + hr * ROWB + (side ? (W + 1) * PB : 0) + ch * 16) = z;
+    *reinterpret_cast<float4*>(halo + hr * ROWB + (side ? (W + PAD) * PB : 0) + ch * 16) = z;
   }
   __syncthreads();                            // waits vmcnt(0): the LDS-DMA pieces have landed
 
@@ -96,8 +97,8 @@ __global__ __launch_bounds__(256) void dconv3x3_kernel(DcGroups gg, int B) {
       for (int s = 0; s < KSTEPS; s++) {
         int k = 32 * s + 8 * q;                            // this lane's 8 reduction elements: one tap, 8 channels
         int tap = k / C, ci = k % C;
-        if (tap > 8) { tap = 8; }                          // zero weights there; any finite halo data will do
-        int ky = tap / 3, kx = tap - ky * 3;
+        if (tap > KSZ * KSZ - 1) { tap = KSZ * KSZ - 1; }  // zero weights there; any finite halo data will do
+        int ky = tap / KSZ, kx = tap - ky * KSZ;
         const char* ap = halo + (ry + ky) * ROWB + (mt * 16 + r16 + kx) * PB + ci * 2;
         bf16x8 xf = *reinterpret_cast<const bf16x8*>(ap);
 #pragma unroll
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void dconv3x3_kernel(DcGroups gg, int B) {
           s1[j][r] += v; s2[j][r] += v * v;
           o[r] = (bf16)v;
         }
-        *reinterpret_cast<bf16x4*>(y + ((long)oy * W + px) * C + j * 16 + q * 4) = o;
+        *reinterpret_cast<bf16x4*>(y + ((long)oy * W + px) * CO + j * 16 + q * 4) = o;
       }
     }
   }
@@ -129,8 +130,8 @@ __global__ __launch_bounds__(256) void dconv3x3_kernel(DcGroups gg, int B) {
         for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
         if (r16 == 0) {
           int ch = j * 16 + q * 4 + r;
-          atomicAdd(&stats[((long)b * 2) * C + ch], a);
-          atomicAdd(&stats[((long)b * 2 + 1) * C + ch], c);
+          atomicAdd(&stats[((long)b * 2) * CO + ch], a);
+          atomicAdd(&stats[((long)b * 2 + 1) * CO + ch], c);
         }
       }
   }
@@ -138,24 +139,36 @@ __global__ __launch_bounds__(256) void dconv3x3_kernel(DcGroups gg, int B) {
 
 }  // namespace
 
-// X, Y: NHWC bf16 (B, W, W, C); Wp: bf16 [C][3][3][C]; stats (optional, pre-zeroed): [B][2][C] fp32.
-int avlen_dconv3x3_bf16_grouped(const void* const* X, const void* const* Wp, void* const* Y16, float* const* gn_stats,
-                                int groups, int B, int W, int C, hipStream_t stream) {
+// X: NHWC bf16 (B, W, W, Cin); Y: (B, W, W, Cout) bf16; Wp: bf16 [Cout][K][K][Cin]; stats (optional, pre-zeroed):
+// [B][2][Cout] fp32.  Stride 1, "same" padding.
+int avlen_dconv_bf16_grouped(const void* const* X, const void* const* Wp, void* const* Y16, float* const* gn_stats,
+                             int groups, int B, int W, int Cin, int Cout, int K, hipStream_t stream) {
   if (groups < 1 || groups > 8 || B <= 0) return AVLEN_ERR_ARG;
   DcGroups gg = {};
   for (int g = 0; g < groups; g++) {
     gg.x[g] = (const bf16*)X[g]; gg.w[g] = (const bf16*)Wp[g]; gg.y[g] = (bf16*)Y16[g];
     gg.stats[g] = gn_stats ? gn_stats[g] : nullptr;
   }
-  if (C == 16 && W == 64)
-    hipLaunchKernelGGL((dconv3x3_kernel<16, 64>), dim3(W / 8, B, groups), dim3(256), 0, stream, gg, B);
-  else if (C == 32 && W == 32)
-    hipLaunchKernelGGL((dconv3x3_kernel<32, 32>), dim3(W / 8, B, groups), dim3(256), 0, stream, gg, B);
+  dim3 grid(W / 8, B, groups), block(256);
+  if (Cin == 16 && Cout == 16 && W == 64 && K == 3)
+    hipLaunchKernelGGL((dconv3x3_kernel<16, 16, 64, 3>), grid, block, 0, stream, gg, B);
+  else if (Cin == 32 && Cout == 32 && W == 32 && K == 3)
+    hipLaunchKernelGGL((dconv3x3_kernel<32, 32, 32, 3>), grid, block, 0, stream, gg, B);
+  else if (Cin == 8 && Cout == 16 && W == 64 && K == 7)
+    hipLaunchKernelGGL((dconv3x3_kernel<8, 16, 64, 7>), grid, block, 0, stream, gg, B);
   else
     return AVLEN_ERR_ARG;
   return avlen_launch_status();
 }
 
-bool avlen_dconv3x3_supported(int W, int C, int KH, int KW, int stride, int pad) {
-  return KH == 3 && KW == 3 && stride == 1 && pad == 1 && ((C == 16 && W == 64) || (C == 32 && W == 32));
+bool avlen_dconv_supported(int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+  if (KH != KW || stride != 1 || pad != KH / 2) return false;
+  return (KH == 3 && Cin == 16 && Cout == 16 && W == 64) || (KH == 3 && Cin == 32 && Cout == 32 && W == 32) ||
+         (KH == 7 && Cin == 8 && Cout == 16 && W == 64);
+}
+
+extern "C" int avlen_conv_direct_bf16(const void* X, const void* Wp, void* Y16, float* gn_stats, int B, int W, int Cin,
+                                      int Cout, int K, hipStream_t stream) {
+  if (!avlen_dconv_supported(W, Cin, Cout, K, K, 1, K / 2)) return AVLEN_ERR_ARG;
+  return avlen_dconv_bf16_grouped(&X, &Wp, &Y16, gn_stats ? &gn_stats : nullptr, 1, B, W, Cin, Cout, K, stream);
 }

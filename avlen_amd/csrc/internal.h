@@ -34,6 +34,6 @@ int avlen_attention_fwd16_seg(const float* Q, int ldq, const float* K, int ldk, 
 int avlen_gemm_bf16_dyn(const void* A, int lda, const void* B, int ldb, float* C32, int ldc32, void* C16, int ldc16,
                         const float* bias, const float* residual, int ldr, int M, const int* M_dev, int N, int K, int act,
                         void* ws, size_t ws_bytes, hipStream_t stream);
-int avlen_dconv3x3_bf16_grouped(const void* const* X, const void* const* Wp, void* const* Y16, float* const* gn_stats,
-                                int groups, int B, int W, int C, hipStream_t stream);
-bool avlen_dconv3x3_supported(int W, int C, int KH, int KW, int stride, int pad);
+int avlen_dconv_bf16_grouped(const void* const* X, const void* const* Wp, void* const* Y16, float* const* gn_stats,
+                             int groups, int B, int W, int Cin, int Cout, int K, hipStream_t stream);
+bool avlen_dconv_supported(int W, int Cin, int Cout, int KH, int KW, int stride, int pad);

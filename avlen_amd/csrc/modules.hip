@@ -362,8 +362,8 @@ int resnet18_group_fwd_bf16(const avlen_resnet18* const* nets, const float* cons
   auto conv = [&](auto getk, bf16** xin, bf16** rawo, float** stt, int H) -> int {
     const avlen_conv& k0 = getk(nets[0]);
     for (int g = 0; g < G; g++) { X[g] = xin[g]; Wt[g] = getk(nets[g]).w16; Y[g] = rawo[g]; }
-    if (k0.cin16 == k0.cout && avlen_dconv3x3_supported(H, k0.cout, k0.kh, k0.kw, k0.stride, k0.pad))
-      return avlen_dconv3x3_bf16_grouped(X, Wt, Y, stt, G, B, H, k0.cout, st);      // small-channel stages: direct conv
+    if (avlen_dconv_supported(H, k0.cin16, k0.cout, k0.kh, k0.kw, k0.stride, k0.pad))      // small-channel stages: direct conv
+      return avlen_dconv_bf16_grouped(X, Wt, Y, stt, G, B, H, k0.cin16, k0.cout, k0.kh, st);
     return avlen_conv2d_nhwc_bf16_grouped(X, Wt, nullptr, Y, stt, G, B, H, H, k0.cin16, k0.cout, k0.kh, k0.kw, k0.stride, k0.pad, gws,
                                           gwsb, st);
   };

@@ -95,6 +95,10 @@ size_t avlen_gemm_bf16_workspace_bytes(int M, int N);
 int avlen_conv2d_nhwc_bf16(const void* X, const void* Wp, const float* bias, const float* residual, float* Y32,
                            void* Y16, float* gn_stats, int B, int H, int W, int Cin, int Cout, int KH, int KW,
                            int stride, int pad, int act, void* ws, size_t ws_bytes, avlen_stream_t stream);
+/* Direct stride-1 "same" convolution for the small-channel tower stages (LDS halo tile, register-resident weights):
+ * (Cin,Cout,W,K) in {(16,16,64,3), (32,32,32,3), (8,16,64,7)}; X/Y NHWC bf16; optional fused GroupNorm statistics. */
+int avlen_conv_direct_bf16(const void* X, const void* Wp, void* Y16, float* gn_stats, int B, int W, int Cin, int Cout,
+                           int K, avlen_stream_t stream);
 int avlen_cast_bf16(const float* src, int ld_src, void* dst, int ld_dst, long rows, int cols, avlen_stream_t stream);
 int avlen_pack_conv_weight_bf16(const float* w_oihw, void* w_packed, int O, int I, int KH, int KW, int Cpad,
                                 avlen_stream_t stream);
