@@ -220,6 +220,122 @@ __global__ __launch_bounds__(128) void attn_fwd4_kernel(const float* __restrict_
   }
 }
 
+// MFMA attention for short unmasked / causal sequences (CLIP text: Sk <= 96, D = 64), bf16 operands, fp32 softmax.
+// One block (4 waves) per (sample, head): Q, K and V^T are staged once in LDS as bf16; wave w owns the 16-query tiles
+// w and w+4: S = Q K^T (12 MFMA per key tile), row softmax with 4 shuffles, P -> LDS (transposes the accumulator layout
+// into an A operand), O = P V (12 MFMA per 16 output dims).  Ragged batches via seg_off (see attn_fwd4_kernel).
+typedef __attribute__((ext_vector_type(8))) __bf16 abf16x8;
+typedef __attribute__((ext_vector_type(4))) float af32x4;
+
+__global__ __launch_bounds__(256) void attn_mfma64_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ K,
+                                                          int ldk, const float* __restrict__ V, int ldv,
+                                                          __bf16* __restrict__ O16, int ldo16, int Sq, int Sk, int causal,
+                                                          float scale, const int* __restrict__ seg_off) {
+  constexpr int D = 64, SKP = 96, KR = D + 8, VR = SKP + 8;     // padded LDS rows (bytes: 144 / 208) -> fewer bank conflicts
+  __shared__ __attribute__((aligned(16))) __bf16 qs[SKP * KR];
+  __shared__ __attribute__((aligned(16))) __bf16 ks[SKP * KR];
+  __shared__ __attribute__((aligned(16))) __bf16 vt[D * VR];      // V transposed: [d][key]
+  __shared__ __attribute__((aligned(16))) __bf16 ps[4][16 * VR];  // per wave: P tile [query 16][key 96]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, q4 = lane >> 4;
+  const int h = blockIdx.x, b = blockIdx.y;
+  long row0 = (long)b * Sq, krow0 = (long)b * Sk;
+  if (seg_off) { row0 = krow0 = seg_off[b]; Sq = Sk = seg_off[b + 1] - seg_off[b]; }
+  // ---- stage (fp32 -> bf16); rows >= Sk / Sq are zero
+  for (int i = tid; i < SKP * 16; i += 256) {
+    int r = i >> 4, c4 = (i & 15) * 4;
+    float4 kv = make_float4(0, 0, 0, 0), vv = kv, qv = kv;
+    if (r < Sk) {
+      kv = *reinterpret_cast<const float4*>(K + (krow0 + r) * ldk + h * D + c4);
+      vv = *reinterpret_cast<const float4*>(V + (krow0 + r) * ldv + h * D + c4);
+    }
+    if (r < Sq) qv = *reinterpret_cast<const float4*>(Q + (row0 + r) * ldq + h * D + c4);
+    __bf16* kd = &ks[r * KR + c4]; __bf16* qd = &qs[r * KR + c4];
+    kd[0] = (__bf16)kv.x; kd[1] = (__bf16)kv.y; kd[2] = (__bf16)kv.z; kd[3] = (__bf16)kv.w;
+    qd[0] = (__bf16)(qv.x * scale); qd[1] = (__bf16)(qv.y * scale); qd[2] = (__bf16)(qv.z * scale); qd[3] = (__bf16)(qv.w * scale);
+    vt[(c4 + 0) * VR + r] = (__bf16)vv.x; vt[(c4 + 1) * VR + r] = (__bf16)vv.y;
+    vt[(c4 + 2) * VR + r] = (__bf16)vv.z; vt[(c4 + 3) * VR + r] = (__bf16)vv.w;
+  }
+  __syncthreads();
+  const int n_kt = (Sk + 15) >> 4;                 // key tiles in use (<= 6)
+  __bf16* pw = ps[wave];
+  for (int mt = wave; mt * 16 < Sq; mt += 4) {
+    // ---- S = Q K^T for 16 queries x up to 96 keys: lane holds S[query = q4*4 + r][key = nt*16 + r16]
+    af32x4 sacc[6];
+#pragma unroll
+    for (int nt = 0; nt < 6; nt++) sacc[nt] = (af32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) {
+      abf16x8 qf = *reinterpret_cast<const abf16x8*>(&qs[(mt * 16 + r16) * KR + kk * 32 + q4 * 8]);
+#pragma unroll
+      for (int nt = 0; nt < 6; nt++) {
+        if (nt < n_kt) {
+          abf16x8 kf = *reinterpret_cast<const abf16x8*>(&ks[(nt * 16 + r16) * KR + kk * 32 + q4 * 8]);
+          sacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf, sacc[nt], 0, 0, 0);
+        }
+      }
+    }
+    // ---- masked row softmax (rows live on 16 lanes with equal q4; 4 rows per lane)
+    float rmax[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, rsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nt = 0; nt < 6; nt++) {
+      const int key = nt * 16 + r16;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int qi = mt * 16 + q4 * 4 + r;
+        bool ok = nt < n_kt && key < Sk && !(causal && key > qi);
+        float v = ok ? sacc[nt][r] : -INFINITY;
+        sacc[nt][r] = v;
+        rmax[r] = fmaxf(rmax[r], v);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) rmax[r] = fmaxf(rmax[r], __shfl_xor(rmax[r], o, 64));
+#pragma unroll
+    for (int nt = 0; nt < 6; nt++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        float pv = (sacc[nt][r] == -INFINITY) ? 0.f : __expf(sacc[nt][r] - rmax[r]);
+        rsum[r] += pv;
+        pw[(q4 * 4 + r) * VR + nt * 16 + r16] = (__bf16)pv;       // P[query][key]
+      }
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) rsum[r] += __shfl_xor(rsum[r], o, 64);
+    // the P tile is private to this wave; make its LDS writes visible to the wave's own reads
+    __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    // ---- O = P V : lane holds O[query = q4*4 + r][d = dt*16 + r16]
+    af32x4 oacc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; dt++) oacc[dt] = (af32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 3; kk++) {
+      if (kk * 32 < Sk) {
+        abf16x8 pf = *reinterpret_cast<const abf16x8*>(&pw[r16 * VR + kk * 32 + q4 * 8]);
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++) {
+          abf16x8 vf = *reinterpret_cast<const abf16x8*>(&vt[(dt * 16 + r16) * VR + kk * 32 + q4 * 8]);
+          oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, oacc[dt], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int qi = mt * 16 + q4 * 4 + r;
+      if (qi < Sq) {
+        const float inv = rsum[r] > 0.f ? 1.f / rsum[r] : 0.f;
+        __bf16* op = O16 + (row0 + qi) * ldo16 + h * D + r16;
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++) op[dt * 16] = (__bf16)(oacc[dt][r] * inv);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // dQ: lane per query (same streaming structure as forward).  Also writes delta = rowsum(dO * O).
 template <int D>
 __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ K,
@@ -355,6 +471,11 @@ int avlen_attention_fwd16_seg(const float* Q, int ldq, const float* K, int ldk, 
                               void* O16, int ldo16, const float* key_mask, float* lse, int B, int H, int Sq, int Sk, int D,
                               int causal, float scale, const int* seg_off, hipStream_t stream) {
   if (seg_off && (key_mask || lse)) return AVLEN_ERR_ARG;
+  if (!key_mask && !lse && !O && O16 && D == 64 && Sk <= 96 && Sq <= 96) {       // CLIP text: bf16 MFMA attention
+    hipLaunchKernelGGL(attn_mfma64_kernel, dim3(H, B), dim3(256), 0, stream, Q, ldq, K, ldk, V, ldv, (__bf16*)O16, ldo16, Sq,
+                       Sk, causal, scale, seg_off);
+    return avlen_launch_status();
+  }
   if (B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0 || (ldq | ldk | ldv | ldo) % 4) return AVLEN_ERR_ARG;
   __bf16* oh = (__bf16*)O16;
   if (!key_mask && (Sq >= 16 || seg_off) && (D == 32 || D == 64)) {       // no padding mask: 4-lanes-per-query kernel

@@ -342,7 +342,7 @@ int launch(const G2& p, int m_tiles, int n_tiles, hipStream_t st) {
   static int forced = -1;                       // AVLEN_G2_NS=2|4 pins the stage count (A/B measurements)
   if (forced < 0) { const char* e = getenv("AVLEN_G2_NS"); forced = e ? atoi(e) : 0; }
   static long thresh = -1;
-  if (thresh < 0) { const char* e = getenv("AVLEN_G2_NS_BLOCKS"); thresh = e ? atol(e) : 96; }
+  if (thresh < 0) { const char* e = getenv("AVLEN_G2_NS_BLOCKS"); thresh = e ? atol(e) : 480; }
   bool deep = forced ? forced == 4 : blocks < thresh;
   if (!deep) return launch_ns<BM, BN, WM, WN, 2>(p, m_tiles, n_tiles, st);
   return launch_ns<BM, BN, WM, WN, 4>(p, m_tiles, n_tiles, st);
@@ -356,6 +356,9 @@ int run_g2(G2 p, void* ws, size_t ws_bytes, hipStream_t st) {
   }
   if (p.groups > MAXG) return AVLEN_ERR_ARG;
   int bn = p.N <= 16 ? 16 : p.N <= 32 ? 32 : p.N <= 64 ? 64 : 128;
+  static int small_tiles = -1;      // AVLEN_G2_SMALL=1: prefer 64x64 tiles when 64x128 tiles cannot cover the chip
+  if (small_tiles < 0) { const char* e = getenv("AVLEN_G2_SMALL"); small_tiles = e ? atoi(e) : 0; }
+  if (small_tiles && bn == 128 && (long)ceil_div(p.M, 64) * ceil_div(p.N, 128) * p.groups < 400 && p.M > 64) bn = 64;
   int n_tiles = ceil_div(p.N, bn);
   // 64-row tiles when 128-row tiles would leave most of the 256 CUs idle (small rollout batches)
   int bm = 128;
