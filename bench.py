@@ -40,68 +40,34 @@ def parse():
 
 
 def kernel_roofline(prec_name):
-    """Roofline of the DOMINANT kernel by GPU time (profiles/r01_rocprof_summary.md): g2_kernel<128,16,4,1,2>, the 3x3
-    16->16 implicit-GEMM conv of the ResNet towers' layer1 with fused GroupNorm statistics, as launched in a rollout step
-    (six towers x 64 envs = 384 images of 64x64x16).  HBM-bound: N=16 output channels give 36 FLOP per byte.
-    `achieved` = algorithmic bytes (bf16 activation read once + fp32 raw output written once) / duration measured live with
-    HIP events on the launch stream; `traffic` = HBM bytes per launch from the rocprofv3 PMC passes
-    (profiles/r01_pmc_traffic.json, FETCH_SIZE x2 per the gfx950 note).  The MFMA-bound GEMM of the CLIP MLP is reported
-    beside it as `mfma_gemm`."""
+    """Roofline of the DOMINANT kernel by GPU time in the rollout (profiles/r01_rocprof_summary.md):
+    g2_kernel<64,128,2,2,4>, the bf16 MFMA GEMM (global_load_lds staging, 4-stage LDS ring) on its heaviest call site, the
+    CLIP text MLP down-projection of one rollout step on the ragged batch (M = 2464 live rows, N = 512, K = 2048, fp32
+    residual epilogue).  `achieved` = 2*M*N*K / duration measured live with HIP events on the launch stream; `peak` = dense
+    bf16 MFMA; `traffic` = HBM bytes per launch from the rocprofv3 PMC passes (profiles/r01_pmc_traffic.json: 2 x FETCH_SIZE +
+    WRITE_SIZE, gfx950 correction).  The HBM-bound kernel class (direct 3x3 conv of the towers' layer 1) is reported beside it
+    as `hbm_conv`."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import roofline_probe as rp
-    sec = rp.measure()
-    ab = rp.algorithmic_bytes()
-    traffic = None
+    pmc = {}
     try:
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["traffic_bytes_gfx950_corrected"]
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
     except Exception:
         pass
-    ach = ab / sec / 1e9
-    out = {"bound": "hbm", "kernel": "g2_kernel<128,16,4,1,2> (tower layer1 conv3x3 16->16 @64x64, 384 images/launch, bf16 in, "
-                                     "fp32 out, fused GN stats)", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
-           "frac": round(ach / 8000.0, 4), "traffic": traffic, "algorithmic_bytes": ab, "us_per_launch": round(sec * 1e6, 2)}
-    out["mfma_gemm"] = mfma_gemm_rate(prec_name)
-    return out
-
-
-def mfma_gemm_rate(prec_name):
-    """bf16 MFMA GEMM of the CLIP MLP up-projection (M = 64 envs x 77 tokens = 4928, K = 512, N = 2048, QuickGELU)."""
-    from avlen_amd import _lib as L
-    from avlen_amd.engine import P
-    M, N, K = 64 * 77, 2048, 512
-    dev = "cuda"
-    A = torch.randn(M, K, device=dev)
-    W = torch.randn(N, K, device=dev) / K ** 0.5
-    b = torch.randn(N, device=dev)
-    st = L.stream()
-    if prec_name == "bf16":
-        A16, W16 = A.bfloat16(), W.bfloat16()
-        C16 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-        nb = L.lib.avlen_gemm_bf16_workspace_bytes(M, N)
-        ws = torch.empty(nb, dtype=torch.uint8, device=dev)
-        run = lambda: L.call("avlen_gemm_bf16", P(A16), K, P(W16), K, None, N, P(C16), N, P(b), None, 0, M, N, K, 2, P(ws),
-                             nb, st)
-        name, peak = "g2_kernel<128,128,2,2,2> bf16 glds", 2500.0
-    else:
-        Cc = torch.empty(M, N, device=dev)
-        nb = L.lib.avlen_gemm_workspace_bytes(M, N, K, 1)
-        ws = torch.empty(nb, dtype=torch.uint8, device=dev)
-        run = lambda: L.call("avlen_gemm", P(A), K, 0, P(W), K, 0, P(Cc), N, P(b), None, 0, M, N, K, 2, L.PREC_FP32, 1, 0.0,
-                             P(ws), nb, st)
-        name, peak = "igemm_kernel<128,fp32>", 157.3
-    for _ in range(5):
-        run()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    iters = 50
-    e0.record()
-    for _ in range(iters):
-        run()
-    e1.record()
-    torch.cuda.synchronize()
-    sec = e0.elapsed_time(e1) / 1e3 / iters
-    ach = 2.0 * M * N * K / sec / 1e12
-    return {"kernel": f"{name} (CLIP c_fc M=4928 N=2048 K=512)", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(ach / peak, 4), "us_per_launch": round(sec * 1e6, 2)}
+    if prec_name != "bf16":
+        return None
+    sg, sc = rp.measure(rp.make_gemm), rp.measure(rp.make_conv)
+    gw, cw = rp.gemm_work(), rp.conv_work()
+    tf = gw["flops"] / sg / 1e12
+    gb = cw["bytes"] / sc / 1e9
+    return {"bound": "mfma", "kernel": "g2_kernel<64,128,2,2,4> bf16 glds GEMM (CLIP c_proj, ragged M=2464 N=512 K=2048)",
+            "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
+            "traffic": pmc.get("gemm", {}).get("traffic_bytes"), "algorithmic_flops": gw["flops"],
+            "algorithmic_bytes": gw["bytes"], "us_per_launch": round(sg * 1e6, 2),
+            "hbm_conv": {"bound": "hbm", "kernel": "dconv3x3_kernel<16,16,64,3> (tower layer-1 conv, 384 images/launch, bf16 "
+                                                   "in/out, fused GN statistics)", "achieved": round(gb, 1), "peak": 8000.0,
+                         "unit": "GB/s", "frac": round(gb / 8000.0, 4), "traffic": pmc.get("dconv", {}).get("traffic_bytes"),
+                         "algorithmic_bytes": cw["bytes"], "us_per_launch": round(sc * 1e6, 2)}}
 
 
 def cpu_baseline(spec_hw):
@@ -168,7 +134,9 @@ def main():
     }
     if rank == 0:
         if not a.no_roofline:
-            out["roofline"] = kernel_roofline(a.precision)
+            rl = kernel_roofline(a.precision)
+            if rl is not None:
+                out["roofline"] = rl
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline((H, W))
         print(json.dumps(out), flush=True)

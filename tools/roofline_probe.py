@@ -1,36 +1,52 @@
-"""Runs ONLY the dominant kernel of the rollout (g2_kernel<128,16,4,1,2>: the 3x3 16->16 implicit-GEMM conv of the
-ResNet towers' layer1 at 64x64, six towers x 64 envs = 384 images per launch, fused GroupNorm statistics) so that
-rocprofv3 --pmc passes can attribute HBM traffic to it.  Also prints its event-timed duration and algorithmic bytes."""
+"""Runs the two kernels bench.py reports a roofline for, in isolation, so that rocprofv3 --pmc passes can attribute HBM
+traffic to them:
+  * `gemm`  : g2_kernel<64,128,2,2,4> -- the dominant kernel of the rollout by GPU time (profiles/r01_rocprof_summary.md): the
+              CLIP text MLP down-projection on the ragged batch (M = 2464 live rows = half of 64 x 77, N = 512, K = 2048),
+              bf16 operands via global_load_lds, fp32 residual epilogue.  MFMA-bound class.
+  * `dconv` : dconv3x3_kernel<16,16,64,3> -- the layer-1 3x3 convolution of the six ResNet towers (384 images of 64x64x16 per
+              launch, bf16 in / bf16 out, fused GroupNorm statistics).  HBM-bound class.
+Prints event-timed durations and algorithmic FLOPs / bytes per launch as JSON."""
 import math, sys, os, json
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from avlen_amd import _lib as L
 from avlen_amd.engine import P
 
-B, H, C = 384, 64, 16
+GEMM = dict(M=2464, N=512, K=2048)
+CONV = dict(B=384, W=64, C=16)
 
 
-def make():
-    x16 = torch.randn(B, H, H, C, device="cuda").bfloat16()
+def make_gemm():
+    M, N, K = GEMM["M"], GEMM["N"], GEMM["K"]
+    A = torch.randn(M, K, device="cuda").bfloat16(); Wt = (torch.randn(N, K, device="cuda") / math.sqrt(K)).bfloat16()
+    b = torch.randn(N, device="cuda"); X = torch.randn(M, N, device="cuda")
+    nb = L.lib.avlen_gemm_bf16_workspace_bytes(M, N); ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    fn = lambda: L.call("avlen_gemm_bf16", P(A), K, P(Wt), K, P(X), N, None, 0, P(b), P(X), N, M, N, K, 0, None, 0, L.stream())
+    return fn, (A, Wt, b, X, ws)
+
+
+def make_conv():
+    B, W, C = CONV["B"], CONV["W"], CONV["C"]
+    x16 = torch.randn(B, W, W, C, device="cuda").bfloat16()
     w = torch.randn(C, C, 3, 3, device="cuda") / math.sqrt(C * 9)
     wp16 = torch.empty(C, 3, 3, C, device="cuda", dtype=torch.bfloat16)
     L.call("avlen_pack_conv_weight_bf16", P(w), P(wp16), C, C, 3, 3, C, L.stream())
-    y = torch.empty(B, H, H, C, device="cuda")
-    stats = torch.zeros(B, 2, C, device="cuda")
-    nb = L.lib.avlen_gemm_bf16_workspace_bytes(1, 1)
-    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
-    keep = (x16, wp16, y, stats, ws)
-    fn = lambda: L.call("avlen_conv2d_nhwc_bf16", P(x16), P(wp16), None, None, P(y), None, P(stats), B, H, H, C, C, 3, 3, 1, 1, 0,
-                        P(ws), nb, L.stream())
-    return fn, keep
+    y = torch.empty(B, W, W, C, device="cuda", dtype=torch.bfloat16); stats = torch.zeros(B, 2, C, device="cuda")
+    fn = lambda: L.call("avlen_conv_direct_bf16", P(x16), P(wp16), P(y), P(stats), B, W, C, C, 3, L.stream())
+    return fn, (x16, wp16, y, stats)
 
 
-def algorithmic_bytes():
-    # read the bf16 activation once, write the fp32 raw output once (weights 4.6 KB, statistics 48 KB: negligible)
-    return B * H * H * C * 2 + B * H * H * C * 4
+def gemm_work():
+    M, N, K = GEMM["M"], GEMM["N"], GEMM["K"]
+    return {"flops": 2.0 * M * N * K, "bytes": M * K * 2 + N * K * 2 + 2 * M * N * 4}     # A + W (bf16) + residual in/out (fp32)
 
 
-def measure(iters=40):
+def conv_work():
+    B, W, C = CONV["B"], CONV["W"], CONV["C"]
+    return {"flops": 2.0 * B * W * W * C * C * 9, "bytes": B * W * W * C * 2 * 2}          # bf16 activation in + out, once each
+
+
+def measure(make, iters=40):
     fn, keep = make()
     for _ in range(5):
         fn()
@@ -44,6 +60,6 @@ def measure(iters=40):
 
 
 if __name__ == "__main__":
-    sec = measure()
-    print(json.dumps({"kernel": "g2_kernel<128,16,4,1,2>", "us_per_launch": sec * 1e6, "algorithmic_bytes": algorithmic_bytes(),
-                      "GBps": algorithmic_bytes() / sec / 1e9}))
+    sg, sc = measure(make_gemm), measure(make_conv)
+    print(json.dumps({"gemm_us": sg * 1e6, "gemm_TFLOPs": gemm_work()["flops"] / sg / 1e12, "conv_us": sc * 1e6,
+                      "conv_GBps": conv_work()["bytes"] / sc / 1e9}))
