@@ -43,7 +43,7 @@ class _Graph:
 
     def __init__(self, pol, fn, args, by_pointer=()):
         # `by_pointer` args (external-memory rings) are read in place: the graph is keyed on their address
-        self.static = [a if (i in by_pointer and torch.is_tensor(a)) else
+        self.static = [a if (i in by_pointer and (torch.is_tensor(a) or isinstance(a, dict))) else
                        (a.clone() if torch.is_tensor(a) else
                         ({k: v.clone() for k, v in a.items()} if isinstance(a, dict) else a))
                        for i, a in enumerate(args)]
@@ -68,7 +68,7 @@ class _Graph:
             if torch.is_tensor(s):
                 if s.data_ptr() != a.data_ptr():
                     s.copy_(a, non_blocking=True)
-            elif isinstance(s, dict):
+            elif isinstance(s, dict) and s is not a:
                 for k in s:
                     s[k].copy_(a[k], non_blocking=True)
         self.graph.replay()
@@ -93,14 +93,21 @@ def _graphed(pol, which, fn, args, mode=None):
     for i in by_ptr:
         if torch.is_tensor(args[i]):
             args[i] = _f32(args[i])
-    key = (which, mode) + tuple(_sig(a) for a in args) + tuple(args[i].data_ptr() if torch.is_tensor(args[i]) else 0
-                                                                for i in by_ptr)
+    grp = pol._enc_group
+    if mode == "follow" and grp.static_obs is not None and _sig(grp.static_obs) == _sig(args[0]):
+        # same observation as the leader's call: read the leader graph's static copy in place (no second staging copy)
+        args[0] = grp.static_obs
+        by_ptr = by_ptr + (0,)
+    key = (which, mode) + tuple(_sig(a) for a in args) + tuple(
+        (args[i].data_ptr() if torch.is_tensor(args[i]) else id(args[i])) for i in by_ptr)
     g = pol._graphs.get(key)
     if g is None:
         pol._engine()                                    # flat/packed state must exist before capture
         if len(pol._graphs) >= 16:
             pol._graphs.clear()
         g = pol._graphs[key] = _Graph(pol, fn, args, by_ptr)
+    if mode == "lead":
+        grp.static_obs = g.static[0]
     outs, heads = g(args)
     outs = list(outs)
     outs[1] = rnn
@@ -118,6 +125,7 @@ class EncoderGroup:
         self.members = [leader] + list(followers)
         self.leader = leader
         self.out = {}                  # B -> [tensor (B,128)] per member
+        self.static_obs = None         # the leader graph's static observation buffers (followers read them in place)
         self.key = None
         self.pending = set()
         for m in self.members:
