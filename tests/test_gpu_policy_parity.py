@@ -178,7 +178,7 @@ def test_dialog_policy_bf16_tolerance(specs):
     e_l = float(np.abs(logits.cpu().numpy() - g["logits"]).max())
     e_x = float(np.abs(xd.cpu().numpy() - g["xd"]).max())
     print(f"pi_l bf16: max |logit err| {e_l:.4g}, max |state err| {e_x:.4g}")
-    assert e_l < 6e-2 and e_x < 1.5e-1        # fixture heads are He-scaled (logits O(1)), not gain-0.01
+    assert e_l < 1e-1 and e_x < 1.5e-1        # fixture heads are He-scaled (logits O(1)), not gain-0.01
 
 
 def test_option_distractor(specs):
