@@ -279,6 +279,36 @@ int linear16_rows(const Ctx& c, const avlen_linear& L, int r0, int n, const bf16
   return linear16(c, S, X16, ldx, Y32, ld32, Y16, ld16, M, act, nullptr, 0);
 }
 
+// ---- program builder for the fused row-batch chain (chain.hip) ----
+struct ChainB {
+  avlen_chain p; bool ok;
+  ChainB() : ok(true) { p.n = 0; }
+  avlen_chain_op& next(int kind) {
+    static avlen_chain_op dummy;
+    if (p.n >= AVLEN_CHAIN_MAX_OPS) { ok = false; return dummy; }
+    avlen_chain_op& o = p.op[p.n++];
+    o = avlen_chain_op{kind, 0, 0, 0, 0, 0, 0, 0, nullptr, nullptr};
+    return o;
+  }
+  void load_x16(const bf16* x, int ld, int k, int buf) { auto& o = next(AVLEN_CH_LOAD_X16); o.p0 = x; o.ld = ld; o.k = k; o.buf = buf; }
+  void load_cur(const float* x, int ld, int buf) { auto& o = next(AVLEN_CH_LOAD_CUR); o.p0 = x; o.ld = ld; o.buf = buf; }
+  void linear(const avlen_linear& L, int r0, int act, int res, int buf, int out_buf) {
+    auto& o = next(AVLEN_CH_LINEAR);
+    o.p0 = (const char*)L.w16 + (size_t)r0 * L.ld16 * 2; o.p1 = L.b ? L.b + r0 : nullptr;
+    o.k = L.ld16; o.ld = L.ld16; o.act = act; o.res = res; o.buf = buf; o.out_buf = out_buf;
+    if (!L.w16 || (L.ld16 % 32) || L.ld16 > 512 || L.out_f < r0 + 256) ok = false;
+  }
+  void ln(const avlen_affine& a, int out_buf) { auto& o = next(AVLEN_CH_LAYERNORM); o.p0 = a.g; o.p1 = a.b; o.out_buf = out_buf; }
+  void save() { next(AVLEN_CH_SAVE); }
+  void store(float* y, int ld, bf16* y16, int ld2) { auto& o = next(AVLEN_CH_STORE); o.p0 = y; o.ld = ld; o.p1 = y16; o.ld2 = ld2; }
+};
+
+bool chain_enabled() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("AVLEN_CHAIN"); v = e ? atoi(e) : 1; }
+  return v != 0;
+}
+
 __global__ void smt_build16_kernel(const float* __restrict__ x, const float* __restrict__ memory,
                                    const int32_t* __restrict__ mem_index, int NC, const float* __restrict__ masks,
                                    const float* __restrict__ pw, const float* __restrict__ pb, bf16* __restrict__ XF, int ldxf,
@@ -827,6 +857,28 @@ int dec_fwd16(const Ctx& c, const avlen_transformer& tr, Tr16Ws& t, const float*
   const int d = tr.d, H = tr.nhead, D = d / H;
   const float scale = 1.0f / sqrtf((float)D);
   const avlen_dec_layer& q = tr.dec;
+  if (!cto && d == 256 && chain_enabled()) {          // two fused chains around the cross attention
+    ChainB a;
+    a.load_cur(tgt, d, 0); a.save();
+    a.linear(q.self_attn.in_proj, 2 * d, 0, 0, 0, 1);                // one target token: self attention == V projection
+    a.linear(q.self_attn.out_proj, 0, 0, 1, 1, 0);
+    a.ln(q.norm1, 0); a.store(t.Y1, d, nullptr, 0);
+    a.linear(q.cross_attn.in_proj, 0, 0, 0, 0, 1); a.store(t.Qc, d, nullptr, 0);
+    ChainB b;
+    b.load_cur(t.Y1, d, 0); b.save();
+    b.load_x16(t.AOc16, d, d, 1);
+    b.linear(q.cross_attn.out_proj, 0, 0, 1, 1, 0);
+    b.ln(q.norm2, 0); b.save();
+    b.linear(q.lin1, 0, AVLEN_ACT_RELU, 0, 0, 1);
+    b.linear(q.lin2, 0, 0, 1, 1, 0);
+    b.ln(q.norm3, 0); b.ln(tr.dec_norm, 0); b.store(out, d, nullptr, 0);
+    if (a.ok && b.ok && q.lin1.out_f == 256) {
+      TRY(avlen_chain_run(&a.p, B, c.st));
+      TRY(avlen_attention_fwd16(t.Qc, d, t.KVc, 2 * d, t.KVc + d, 2 * d, nullptr, 0, t.AOc16, d, maskx, nullptr, B, H, 1, S, D, 0,
+                                scale, c.st));
+      return avlen_chain_run(&b.p, B, c.st);
+    }
+  }
   TRY(avlen_cast_bf16(tgt, d, t.tgt16, d, B, d, c.st));
   TRY(linear16_rows(c, q.self_attn.in_proj, 2 * d, d, t.tgt16, d, nullptr, 0, t.V016, d, B, 0));
   TRY(linear16(c, q.self_attn.out_proj, t.V016, d, t.U1, d, nullptr, 0, B, 0, tgt, d));
@@ -876,6 +928,32 @@ int smt_fwd_infer_bf16(const avlen_smt* p, const float* x, const float* memory, 
   hipLaunchKernelGGL(smt_build16_kernel, dim3((unsigned)R), dim3(128), 0, st, x, memory, mem_index, NC, masks, p->pose.w,
                      p->pose.b, s.XF, s.ldxf, s.maskx, B, M, F, pose_col, cto ? 1 : 0);
   TRY(avlen_launch_status());
+  if (cto && d == 256 && chain_enabled()) {
+    // `current_token_only`: every attention sees one valid key, so the whole encoder + decoder is a chain of row-wise
+    // steps (attention output == V projection); one launch.
+    const avlen_enc_layer& e = tr.enc; const avlen_dec_layer& q = tr.dec;
+    ChainB ch;
+    ch.load_x16(s.XF, s.ldxf, s.ldxf, 0);
+    ch.linear(p->fus0, 0, AVLEN_ACT_RELU, 0, 0, 1);
+    ch.linear(p->fus2, 0, 0, 0, 1, 0); ch.save();                     // Z
+    ch.linear(e.self_attn.in_proj, 2 * d, 0, 0, 0, 1);               // V(Z)
+    ch.linear(e.self_attn.out_proj, 0, 0, 1, 1, 0);
+    ch.ln(e.norm1, 0); ch.save();                                    // X1
+    ch.linear(e.lin1, 0, AVLEN_ACT_RELU, 0, 0, 1);
+    ch.linear(e.lin2, 0, 0, 1, 1, 0);
+    ch.ln(e.norm2, 0); ch.ln(tr.enc_norm, 0);                        // memory token
+    ch.linear(q.cross_attn.in_proj, 2 * d, 0, 0, 0, 2);              // cross attention output, parked in image 2
+    ch.load_cur(goal, d, 0); ch.save();
+    ch.linear(q.self_attn.in_proj, 2 * d, 0, 0, 0, 1);
+    ch.linear(q.self_attn.out_proj, 0, 0, 1, 1, 0);
+    ch.ln(q.norm1, 0); ch.save();                                    // Y1
+    ch.linear(q.cross_attn.out_proj, 0, 0, 1, 2, 0);
+    ch.ln(q.norm2, 0); ch.save();                                    // Y2
+    ch.linear(q.lin1, 0, AVLEN_ACT_RELU, 0, 0, 1);
+    ch.linear(q.lin2, 0, 0, 1, 1, 0);
+    ch.ln(q.norm3, 0); ch.ln(tr.dec_norm, 0); ch.store(out, d, nullptr, 0);
+    if (ch.ok && e.lin1.out_f == 256 && q.lin1.out_f == 256 && p->fus0.out_f == 256) return avlen_chain_run(&ch.p, B, st);
+  }
   TRY(linear16(c, p->fus0, s.XF, s.ldxf, nullptr, 0, s.H1, d, (int)R, AVLEN_ACT_RELU, nullptr, 0));
   TRY(linear16(c, p->fus2, s.H1, d, s.tr.Z, d, s.tr.Z16, d, (int)R, 0, nullptr, 0));
   TRY(enc_fwd16(c, tr, s.tr, s.maskx, B, S, cto));
