@@ -16,10 +16,12 @@
 #include "common.h"
 #include "../../include/avlen_hip.h"
 #include <stdlib.h>
+#include <stdint.h>
 
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 
 // zeros for padding taps / K tails / surplus rows: 16 KB so that the lanes of a block do not all hit one address
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page[4096];
@@ -27,7 +29,6 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero_page[4096];
 namespace {
 
 constexpr int BK = 64;
-constexpr int NT = 256;
 
 constexpr int MAXG = 8;
 struct G2Grp { const bf16* A; const bf16* B; float* C32; bf16* C16; const float* bias; const float* residual; float* stats; };
@@ -40,10 +41,21 @@ struct G2 {
   int act;
   int conv, H, W, Cin, cin_log2, OH, OW, KH, KW, kw_magic, stride, pad;
   int splitk, ksteps_per_split;
+  int vec4;                   // N, ldc32, ldc16, ldr all multiples of 4: 16-byte / 8-byte epilogue accesses
   float* slab;
   const int* M_dev;           // optional: the live row count (<= M) is read from device memory (ragged batches)
   float* stats; int ohw;      // optional GroupNorm statistics: stats[sample][0|1][N] += sum / sum of squares of C
+#ifdef AVLEN_G2_LAB
+  int ablate;                 // tools/gemm_lab.hip only: 1 = no fragment reads / MFMA, 2 = no staging loads, 4 = no C stores
+#endif
 };
+#ifdef AVLEN_G2_LAB
+int g_lab_ablate = 0;
+int g_lab_cfg[5] = {0, 0, 0, 0, 0};     // bm, bn, threads, stages, split-K (0 = default)
+#define LAB(bit) (p.ablate & (bit))
+#else
+#define LAB(bit) 0
+#endif
 
 __device__ __forceinline__ float act2(float v, int act) {
   if (act == 1) return fmaxf(v, 0.f);
@@ -55,8 +67,21 @@ __device__ __forceinline__ float act2(float v, int act) {
 // footprint -> 2+ blocks per CU hide the latency); grids that cannot fill the chip run NS=4 (deep prefetch).
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int WM, int WN, int NS>
-__global__ __launch_bounds__(NT) void g2_kernel(G2 pp) {
+__device__ __forceinline__ float4 ld4(const float* base, long off, int col, int N, bool vec) {
+  if (vec) return col < N ? *reinterpret_cast<const float4*>(base + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 v;
+  v.x = col < N ? base[off] : 0.f; v.y = col + 1 < N ? base[off + 1] : 0.f;
+  v.z = col + 2 < N ? base[off + 2] : 0.f; v.w = col + 3 < N ? base[off + 3] : 0.f;
+  return v;
+}
+
+// NTH = 256: 4 waves, one per SIMD (small-N conv tiles; big grids overlap block against block).
+// NTH = 512: 8 waves, two per SIMD, in two groups that run the K-step in opposite order -- waves 0-3 multiply tile t and
+// then issue their share of the staging loads, waves 4-7 issue first and multiply after -- so that on every SIMD one wave's
+// MFMAs run under the other wave's global_load_lds issue (a 1 KiB piece holds its wave for ~60-100 cycles; measured on the
+// 4-wave kernel the two costs simply add: tools/gemm_lab.hip).
+template <int BM, int BN, int WM, int WN, int NS, int NTH>
+__global__ __launch_bounds__(NTH) void g2_kernel(G2 pp) {
   G2 p = pp;
   {
     const G2Grp gg = pp.g[blockIdx.y];
@@ -65,21 +90,34 @@ __global__ __launch_bounds__(NT) void g2_kernel(G2 pp) {
   }
   const int M_alloc = p.M;                     // slab layout uses the allocated row count
   if (p.M_dev) p.M = min(p.M, *p.M_dev);
+  static_assert(WM * WN * 64 == NTH, "wave grid must cover the block");
   constexpr int WTM = BM / WM, WTN = BN / WN;       // wave tile
   constexpr int MI = WTM / 16, NI = WTN / 16;
-  constexpr int A_ROUNDS = BM * 8 / NT;              // 16-byte chunks per thread for the A tile
+  static_assert((BM * 8) % NTH == 0, "A tile must be a whole number of block-wide rounds");
+  constexpr int A_ROUNDS = BM * 8 / NTH;             // 16-byte chunks per thread for the A tile
   constexpr int B_SLOTS = BN * 8;
-  constexpr int B_ROUNDS = (B_SLOTS + NT - 1) / NT;  // every wave issues the same number of loads per tile
+  constexpr int B_ROUNDS = (B_SLOTS + NTH - 1) / NTH;  // every wave issues the same number of loads per tile
   constexpr int A_BYTES = BM * 128;
-  constexpr int B_BYTES = (B_SLOTS >= NT ? BN * 128 : NT * 16);    // small BN: surplus lanes land in a pad area
+  constexpr int B_BYTES = (B_SLOTS >= NTH ? BN * 128 : NTH * 16);    // small BN: surplus lanes land in a pad area
   constexpr int STAGE = A_BYTES + B_BYTES;
   constexpr int LOADS = A_ROUNDS + B_ROUNDS;         // glds per wave per K-tile
   extern __shared__ __attribute__((aligned(16))) char lds[];       // [NS][STAGE]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n_tiles = (p.N + BN - 1) / BN;
-  const int m0 = (blockIdx.x / n_tiles) * BM, n0 = (blockIdx.x % n_tiles) * BN;
-  if (m0 >= p.M) return;                       // whole tile beyond the live rows (uniform per block)
+  // XCD-aware tile order: the dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs (each with its own
+  // L2); label = id % 8 names the blocks that share an XCD, and each label walks a CONTIGUOUS range of tiles (row panel
+  // major, column tile fastest) so the blocks that re-read one A panel -- or neighbouring conv halos -- share an L2.
+  // With a device-side row count only the live tiles are dealt out (dead tiles would otherwise idle whole XCDs).
+  int m0, n0;
+  {
+    const int nwg = ((p.M + BM - 1) / BM) * n_tiles;             // live tiles
+    const int bid = blockIdx.x;
+    if (bid >= nwg) return;
+    const int label = bid & 7, idx = bid >> 3, qq = nwg >> 3, rr = nwg & 7;
+    const int t = (label < rr ? label * (qq + 1) : rr * (qq + 1) + (label - rr) * qq) + idx;
+    m0 = (t / n_tiles) * BM; n0 = (t % n_tiles) * BN;
+  }
   const int nk_total = (p.K + BK - 1) / BK;
   const int kt_beg = blockIdx.z * p.ksteps_per_split;
   const int kt_end = min(nk_total, kt_beg + p.ksteps_per_split);
@@ -88,7 +126,7 @@ __global__ __launch_bounds__(NT) void g2_kernel(G2 pp) {
   const char* a_src[A_ROUNDS]; int a_iy0[A_ROUNDS], a_ix0[A_ROUNDS], a_sw[A_ROUNDS]; bool a_ok[A_ROUNDS];
 #pragma unroll
   for (int r = 0; r < A_ROUNDS; r++) {
-    int slot = r * NT + tid, row = slot >> 3;
+    int slot = r * NTH + tid, row = slot >> 3;
     a_sw[r] = ((slot & 7) ^ ((row >> 1) & 7)) * 8;           // logical k offset (elements) of this lane's chunk
     int m = m0 + row;
     a_ok[r] = m < p.M;
@@ -107,17 +145,17 @@ __global__ __launch_bounds__(NT) void g2_kernel(G2 pp) {
   const char* b_src[B_ROUNDS]; int b_sw[B_ROUNDS];
 #pragma unroll
   for (int r = 0; r < B_ROUNDS; r++) {
-    int slot = r * NT + tid, row = (slot >> 3) % BN;           // surplus lanes (slot >= B_SLOTS) re-read a valid row
+    int slot = r * NTH + tid, row = (slot >> 3) % BN;          // surplus lanes (slot >= B_SLOTS) re-read a valid row
     b_sw[r] = ((slot & 7) ^ ((row >> 1) & 7)) * 8;
     b_src[r] = (const char*)(p.B + (long)((n0 + row) < p.N ? (n0 + row) : (n0 + row) % p.N) * p.ldb);
   }
-  const char* zero = (const char*)g_zero_page + tid * 16;          // per-thread slice of the zero page (tid*16 < 4 KB)
+  const char* zero = (const char*)g_zero_page + (tid & 255) * 16;  // per-thread slice of the zero page
 
   auto issue = [&](int kt, int stage) {
     char* abase = lds + stage * STAGE;
     char* bbase = abase + A_BYTES;
     const int k0 = kt * BK;
-    // the swizzle term ((row>>1)&7) is the same for all of a thread's rows (they are 32 rows apart), so the k offset --
+    // the swizzle term ((row>>1)&7) is the same for all of a thread's rows (they are >= 32 rows apart), so the k offset --
     // and, for convolutions, the tap decode -- is computed once per K-step and shared by the A_ROUNDS gathers
     const int ka = k0 + a_sw[0];
     int ky = 0, kx = 0, ci = 0;
@@ -138,14 +176,14 @@ __global__ __launch_bounds__(NT) void g2_kernel(G2 pp) {
         src = a_src[r] + (long)ka * 2;
       }
       __builtin_amdgcn_global_load_lds((const void*)src,
-          (__attribute__((address_space(3))) void*)(abase + (r * NT + wave * 64) * 16), 16, 0, 0);
+          (__attribute__((address_space(3))) void*)(abase + (r * NTH + wave * 64) * 16), 16, 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < B_ROUNDS; r++) {
       int k = k0 + b_sw[r];
       const char* src = (k < p.K) ? b_src[r] + (long)k * 2 : zero;
       __builtin_amdgcn_global_load_lds((const void*)src,
-          (__attribute__((address_space(3))) void*)(bbase + (r * NT + wave * 64) * 16), 16, 0, 0);
+          (__attribute__((address_space(3))) void*)(bbase + (r * NTH + wave * 64) * 16), 16, 0, 0);
     }
   };
 
@@ -157,6 +195,7 @@ __global__ __launch_bounds__(NT) void g2_kernel(G2 pp) {
 
   const int wm = wave / WN, wn = wave % WN;
   const int r16 = lane & 15, q = lane >> 4;
+  const bool loads_first = NTH == 512 && wave >= 4;
 
   // ---- software pipeline: tiles kt .. kt+NS-2 in flight while tile kt is multiplied ----
   const int nkt = kt_end - kt_beg;
@@ -167,47 +206,63 @@ __global__ __launch_bounds__(NT) void g2_kernel(G2 pp) {
     // my loads of tile `it` have landed once at most the loads of the later in-flight tiles are outstanding
     if (NS > 2 && it + NS - 2 < nkt) wait_vmcnt<LOADS * (NS - 2)>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();      // everyone's part of tile `it` is in LDS; everyone has left stage (it-1)%NS
-    if (it + NS - 1 < nkt) issue(kt_beg + it + NS - 1, (it + NS - 1) % NS);
-    const char* abase = lds + (it % NS) * STAGE;
-    const char* bbase = abase + A_BYTES;
+    const bool more = it + NS - 1 < nkt && !LAB(2);
+    if (more && loads_first) issue(kt_beg + it + NS - 1, (it + NS - 1) % NS);
+    if (!LAB(1)) {
+      const char* abase = lds + (it % NS) * STAGE;
+      const char* bbase = abase + A_BYTES;
 #pragma unroll
-    for (int kh = 0; kh < 2; kh++) {
-      bf16x8 af[MI], bfr[NI];
-      const int cc = kh * 4 + q;
+      for (int kh = 0; kh < 2; kh++) {
+        bf16x8 af[MI], bfr[NI];
+        const int cc = kh * 4 + q;
 #pragma unroll
-      for (int i = 0; i < MI; i++) {
-        int row = wm * WTM + i * 16 + r16;
-        af[i] = *reinterpret_cast<const bf16x8*>(abase + row * 128 + ((cc ^ ((row >> 1) & 7)) << 4));
+        for (int i = 0; i < MI; i++) {
+          int row = wm * WTM + i * 16 + r16;
+          af[i] = *reinterpret_cast<const bf16x8*>(abase + row * 128 + ((cc ^ ((row >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < NI; j++) {
+          int row = wn * WTN + j * 16 + r16;
+          bfr[j] = *reinterpret_cast<const bf16x8*>(bbase + row * 128 + ((cc ^ ((row >> 1) & 7)) << 4));
+        }
+        // W fragment as the first operand: the result comes out transposed, lane (r16, q) holds row m = r16 and the four
+        // consecutive columns n = 4q .. 4q+3 of each 16x16 tile -> 16-byte fp32 / 8-byte bf16 stores in the epilogue
+#pragma unroll
+        for (int i = 0; i < MI; i++)
+#pragma unroll
+          for (int j = 0; j < NI; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
       }
-#pragma unroll
-      for (int j = 0; j < NI; j++) {
-        int row = wn * WTN + j * 16 + r16;
-        bfr[j] = *reinterpret_cast<const bf16x8*>(bbase + row * 128 + ((cc ^ ((row >> 1) & 7)) << 4));
-      }
-#pragma unroll
-      for (int i = 0; i < MI; i++)
-#pragma unroll
-        for (int j = 0; j < NI; j++)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
+    if (more && !loads_first) issue(kt_beg + it + NS - 1, (it + NS - 1) % NS);
   }
 
   // ---- fused GroupNorm statistics: per (sample, channel) sum and sum of squares of the raw conv output.
   // A wave tile (WTM rows) never straddles two samples (ohw % WTM == 0, checked on the host); rows >= M are zero.
+  // Reduce-scatter over the 16 row lanes: 5 cross-lane moves per 4 columns, then one atomic per column per wave.
   if (p.stats) {
     const int sample = (m0 + wm * WTM) / p.ohw;
     if (m0 + wm * WTM < p.M) {
+      const bool hi = r16 & 8, hi2 = r16 & 4;
 #pragma unroll
       for (int j = 0; j < NI; j++) {
-        float s1 = 0.f, s2 = 0.f;
+        float v1[4], v2[4];
 #pragma unroll
-        for (int i = 0; i < MI; i++)
+        for (int r = 0; r < 4; r++) {
+          float a = 0.f, b = 0.f;
 #pragma unroll
-          for (int r = 0; r < 4; r++) { float v = acc[i][j][r]; s1 += v; s2 += v * v; }
-        s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
-        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-        int col = n0 + wn * WTN + j * 16 + r16;
-        if (q == 0 && col < p.N) {
+          for (int i = 0; i < MI; i++) { float v = acc[i][j][r]; a += v; b += v * v; }
+          v1[r] = a; v2[r] = b;
+        }
+        float a0 = hi ? v1[2] : v1[0], a1 = hi ? v1[3] : v1[1], b0 = hi ? v1[0] : v1[2], b1 = hi ? v1[1] : v1[3];
+        float c0 = hi ? v2[2] : v2[0], c1 = hi ? v2[3] : v2[1], d0 = hi ? v2[0] : v2[2], d1 = hi ? v2[1] : v2[3];
+        a0 += __shfl_xor(b0, 8, 64); a1 += __shfl_xor(b1, 8, 64); c0 += __shfl_xor(d0, 8, 64); c1 += __shfl_xor(d1, 8, 64);
+        float s1 = hi2 ? a1 : a0, t1 = hi2 ? a0 : a1, s2 = hi2 ? c1 : c0, t2 = hi2 ? c0 : c1;
+        s1 += __shfl_xor(t1, 4, 64); s2 += __shfl_xor(t2, 4, 64);
+        s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
+        s1 += __shfl_xor(s1, 1, 64); s2 += __shfl_xor(s2, 1, 64);
+        int col = n0 + wn * WTN + j * 16 + q * 4 + (hi ? 2 : 0) + (hi2 ? 1 : 0);
+        if ((r16 & 3) == 0 && col < p.N) {
           atomicAdd(&p.stats[((long)sample * 2) * p.N + col], s1);
           atomicAdd(&p.stats[((long)sample * 2 + 1) * p.N + col], s2);
         }
@@ -216,65 +271,79 @@ __global__ __launch_bounds__(NT) void g2_kernel(G2 pp) {
   }
 
   // ---- epilogue: all bias / residual loads are issued before the first store (no serialized round trips) ----
-  float bv[NI];
-#pragma unroll
-  for (int j = 0; j < NI; j++) {
-    int col = n0 + wn * WTN + j * 16 + r16;
-    bv[j] = (p.bias && p.splitk == 1 && col < p.N) ? p.bias[col] : 0.f;
-  }
+  const bool vec = p.vec4 != 0;
   if (p.splitk > 1) {
 #pragma unroll
     for (int i = 0; i < MI; i++)
 #pragma unroll
       for (int j = 0; j < NI; j++) {
-        int col = n0 + wn * WTN + j * 16 + r16;
+        int col = n0 + wn * WTN + j * 16 + q * 4;
+        int row = m0 + wm * WTM + i * 16 + r16;
+        if (row >= p.M) continue;
+        float* dst = p.slab + ((long)blockIdx.z * M_alloc + row) * p.N + col;
+        if (vec) { if (col < p.N) *reinterpret_cast<float4*>(dst) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]); }
+        else {
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          int row = m0 + wm * WTM + i * 16 + q * 4 + r;
-          if (col < p.N && row < p.M) p.slab[((long)blockIdx.z * M_alloc + row) * p.N + col] = acc[i][j][r];
+          for (int r = 0; r < 4; r++) if (col + r < p.N) dst[r] = acc[i][j][r];
         }
       }
     return;
   }
+  float4 bv[NI];
+#pragma unroll
+  for (int j = 0; j < NI; j++) {
+    int col = n0 + wn * WTN + j * 16 + q * 4;
+    bv[j] = p.bias ? ld4(p.bias, col, col, p.N, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   if (p.residual) {
-    float rv[MI][NI][4];
+    float4 rv[MI][NI];
 #pragma unroll
     for (int i = 0; i < MI; i++)
 #pragma unroll
       for (int j = 0; j < NI; j++) {
-        int col = n0 + wn * WTN + j * 16 + r16;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          int row = m0 + wm * WTM + i * 16 + q * 4 + r;
-          rv[i][j][r] = (col < p.N && row < p.M) ? p.residual[(long)row * p.ldr + col] : 0.f;
-        }
+        int col = n0 + wn * WTN + j * 16 + q * 4;
+        int row = m0 + wm * WTM + i * 16 + r16;
+        rv[i][j] = row < p.M ? ld4(p.residual, (long)row * p.ldr + col, col, p.N, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
     for (int i = 0; i < MI; i++)
 #pragma unroll
-      for (int j = 0; j < NI; j++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) acc[i][j][r] = act2(acc[i][j][r] + bv[j], p.act) + rv[i][j][r];
+      for (int j = 0; j < NI; j++) {
+        acc[i][j][0] = act2(acc[i][j][0] + bv[j].x, p.act) + rv[i][j].x; acc[i][j][1] = act2(acc[i][j][1] + bv[j].y, p.act) + rv[i][j].y;
+        acc[i][j][2] = act2(acc[i][j][2] + bv[j].z, p.act) + rv[i][j].z; acc[i][j][3] = act2(acc[i][j][3] + bv[j].w, p.act) + rv[i][j].w;
+      }
   } else {
 #pragma unroll
     for (int i = 0; i < MI; i++)
 #pragma unroll
-      for (int j = 0; j < NI; j++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) acc[i][j][r] = act2(acc[i][j][r] + bv[j], p.act);
+      for (int j = 0; j < NI; j++) {
+        acc[i][j][0] = act2(acc[i][j][0] + bv[j].x, p.act); acc[i][j][1] = act2(acc[i][j][1] + bv[j].y, p.act);
+        acc[i][j][2] = act2(acc[i][j][2] + bv[j].z, p.act); acc[i][j][3] = act2(acc[i][j][3] + bv[j].w, p.act);
+      }
   }
+  if (LAB(4)) { if (acc[0][0][0] == 123.456f) p.C32[0] = 1.f; return; }
 #pragma unroll
   for (int i = 0; i < MI; i++)
 #pragma unroll
     for (int j = 0; j < NI; j++) {
-      int col = n0 + wn * WTN + j * 16 + r16;
+      int col = n0 + wn * WTN + j * 16 + q * 4;
+      int row = m0 + wm * WTM + i * 16 + r16;
+      if (row >= p.M || col >= p.N) continue;
+      if (vec) {
+        if (p.C32) *reinterpret_cast<float4*>(p.C32 + (long)row * p.ldc32 + col) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        if (p.C16) {
+          bf16x4 o;
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        int row = m0 + wm * WTM + i * 16 + q * 4 + r;
-        if (col < p.N && row < p.M) {
-          if (p.C32) p.C32[(long)row * p.ldc32 + col] = acc[i][j][r];
-          if (p.C16) p.C16[(long)row * p.ldc16 + col] = (bf16)acc[i][j][r];
+          for (int r = 0; r < 4; r++) o[r] = (bf16)acc[i][j][r];
+          *reinterpret_cast<bf16x4*>(p.C16 + (long)row * p.ldc16 + col) = o;
         }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          if (col + r < p.N) {
+            if (p.C32) p.C32[(long)row * p.ldc32 + col + r] = acc[i][j][r];
+            if (p.C16) p.C16[(long)row * p.ldc16 + col + r] = (bf16)acc[i][j][r];
+          }
       }
     }
 }
@@ -323,30 +392,33 @@ __global__ void pack_fc_bf16_kernel(const float* __restrict__ w, bf16* __restric
   o[idx] = (bf16)w[((long)oc * C + c) * HW + pp];
 }
 
-template <int BM, int BN, int WM, int WN, int NS>
+template <int BM, int BN, int WM, int WN, int NS, int NTH>
 int launch_ns(const G2& p, int m_tiles, int n_tiles, hipStream_t st) {
-  size_t lds = (size_t)NS * (BM * 128 + (BN * 8 >= NT ? BN * 128 : NT * 16));
+  size_t lds = (size_t)NS * (BM * 128 + (BN * 8 >= NTH ? BN * 128 : NTH * 16));
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&g2_kernel<BM, BN, WM, WN, NS>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&g2_kernel<BM, BN, WM, WN, NS, NTH>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((g2_kernel<BM, BN, WM, WN, NS>), dim3(m_tiles * n_tiles, p.groups, p.splitk), dim3(NT), lds, st, p);
+  hipLaunchKernelGGL((g2_kernel<BM, BN, WM, WN, NS, NTH>), dim3(m_tiles * n_tiles, p.groups, p.splitk), dim3(NTH), lds, st, p);
   return avlen_launch_status();
 }
 
+// 4-wave tiles: NS = 4 (deep prefetch, one block per CU) when the grid cannot put 2+ blocks on every CU, else NS = 2.
 template <int BM, int BN, int WM, int WN>
-int launch(const G2& p, int m_tiles, int n_tiles, hipStream_t st) {
+int launch4(const G2& p, int m_tiles, int n_tiles, hipStream_t st) {
   long blocks = (long)m_tiles * n_tiles * p.splitk * p.groups;
   static int forced = -1;                       // AVLEN_G2_NS=2|4 pins the stage count (A/B measurements)
   if (forced < 0) { const char* e = getenv("AVLEN_G2_NS"); forced = e ? atoi(e) : 0; }
   static long thresh = -1;
   if (thresh < 0) { const char* e = getenv("AVLEN_G2_NS_BLOCKS"); thresh = e ? atol(e) : 480; }
   bool deep = forced ? forced == 4 : blocks < thresh;
-  if (!deep) return launch_ns<BM, BN, WM, WN, 2>(p, m_tiles, n_tiles, st);
-  return launch_ns<BM, BN, WM, WN, 4>(p, m_tiles, n_tiles, st);
+  if (!deep) return launch_ns<BM, BN, WM, WN, 2, 256>(p, m_tiles, n_tiles, st);
+  return launch_ns<BM, BN, WM, WN, 4, 256>(p, m_tiles, n_tiles, st);
 }
+
+bool aligned_to(const void* q, size_t a) { return ((uintptr_t)q & (a - 1)) == 0; }
 
 int run_g2(G2 p, void* ws, size_t ws_bytes, hipStream_t st) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K & 7) || (p.lda & 7) || (p.ldb & 7)) return AVLEN_ERR_ARG;
@@ -355,17 +427,37 @@ int run_g2(G2 p, void* ws, size_t ws_bytes, hipStream_t st) {
     p.g[0] = G2Grp{p.A, p.B, p.C32, p.C16, p.bias, p.residual, p.stats};
   }
   if (p.groups > MAXG) return AVLEN_ERR_ARG;
+  p.vec4 = !(p.N & 3) && !(p.ldc32 & 3) && !(p.ldc16 & 3) && !(p.ldr & 3) && aligned_to(ws, 16);
+  for (int g = 0; g < p.groups; g++)
+    p.vec4 = p.vec4 && aligned_to(p.g[g].C32, 16) && aligned_to(p.g[g].C16, 8) && aligned_to(p.g[g].bias, 16) &&
+             aligned_to(p.g[g].residual, 16);
   int bn = p.N <= 16 ? 16 : p.N <= 32 ? 32 : p.N <= 64 ? 64 : 128;
-  static int small_tiles = -1;      // AVLEN_G2_SMALL=1: prefer 64x64 tiles when 64x128 tiles cannot cover the chip
-  if (small_tiles < 0) { const char* e = getenv("AVLEN_G2_SMALL"); small_tiles = e ? atoi(e) : 0; }
-  if (small_tiles && bn == 128 && (long)ceil_div(p.M, 64) * ceil_div(p.N, 128) * p.groups < 400 && p.M > 64) bn = 64;
   int n_tiles = ceil_div(p.N, bn);
-  // 64-row tiles when 128-row tiles would leave most of the 256 CUs idle (small rollout batches)
-  int bm = 128;
-  if (bn >= 64 && (long)ceil_div(p.M, 128) * n_tiles * p.groups < 256 && p.M > 64) bm = 64;
   // GroupNorm statistics need every wave tile inside one sample: ohw % (wave rows) == 0
   const bool has_stats = p.stats || p.g[0].stats;
-  if (has_stats && bm == 64 && (p.ohw % 32)) bm = 128;
+  int bm = 128, nth = 256, ns = 2;
+  if (bn == 128) {
+    // 128-column tiles run the 8-wave ping-pong kernel.  Tile height by how many tiles the problem yields (measured on
+    // MI355X, tools/gemm_lab.hip): 256 rows only when even those fill the chip several times over, 64 rows when 128-row
+    // tiles would leave CUs idle; deep prefetch (NS = 4) only for long-K problems that cannot fill the chip anyway.
+    nth = 512;
+    const int m_est = p.M_dev ? (p.M + 1) / 2 : p.M;      // ragged batches: about half the allocated rows are live
+    const long t128 = (long)ceil_div(m_est, 128) * n_tiles * p.groups;
+    const long t64 = (long)ceil_div(m_est, 64) * n_tiles * p.groups;
+    if (t128 >= 4096) { bm = 256; ns = 3; }
+    else if (t128 >= 400) { bm = 128; ns = 2; }
+    else { bm = 64; ns = (t64 < 256 && p.K >= 1024) ? 4 : 2; }
+    if (has_stats && bm == 64 && (p.ohw % 32)) { bm = 128; ns = 2; }
+    if (has_stats && (p.ohw % 64)) nth = 256;        // (not reached: the conv entry point requires ohw % 64 == 0)
+  } else {
+    // 64-row tiles when 128-row tiles would leave most of the 256 CUs idle (small rollout batches)
+    if (bn >= 64 && (long)ceil_div(p.M, 128) * n_tiles * p.groups < 256 && p.M > 64) bm = 64;
+    if (has_stats && bm == 64 && (p.ohw % 32)) bm = 128;
+  }
+#ifdef AVLEN_G2_LAB
+  if (g_lab_cfg[0]) { bm = g_lab_cfg[0]; bn = g_lab_cfg[1]; nth = g_lab_cfg[2]; n_tiles = ceil_div(p.N, bn); }
+#endif
+  if (nth == 256 && bn == 128 && bm == 256) bm = 128;
   int m_tiles = ceil_div(p.M, bm);
   int nk = ceil_div(p.K, BK);
   long tiles = (long)m_tiles * n_tiles * p.groups;
@@ -377,18 +469,32 @@ int run_g2(G2 p, void* ws, size_t ws_bytes, hipStream_t st) {
     if (split > 32) split = 32;
     if (!ws || (size_t)split * p.groups * p.M * p.N * sizeof(float) > ws_bytes) split = 1;
   }
+#ifdef AVLEN_G2_LAB
+  if (g_lab_cfg[4] && ws && (size_t)g_lab_cfg[4] * p.groups * p.M * p.N * sizeof(float) <= ws_bytes) split = g_lab_cfg[4];
+#endif
   p.ksteps_per_split = ceil_div(nk, split);
   p.splitk = ceil_div(nk, p.ksteps_per_split);
   p.slab = (float*)ws;
-  int rc;
-  if (bm == 64) {
-    rc = (bn == 64) ? launch<64, 64, 2, 2>(p, m_tiles, n_tiles, st) : launch<64, 128, 2, 2>(p, m_tiles, n_tiles, st);
+#ifdef AVLEN_G2_LAB
+  p.ablate = g_lab_ablate;
+#endif
+  int rc = AVLEN_ERR_ARG;
+  if (nth == 512) {
+#ifdef AVLEN_G2_LAB
+    if (g_lab_cfg[3]) ns = g_lab_cfg[3];
+#endif
+    if (bm == 64 && bn == 128) rc = ns == 2 ? launch_ns<64, 128, 2, 4, 2, 512>(p, m_tiles, n_tiles, st) : ns == 3 ? launch_ns<64, 128, 2, 4, 3, 512>(p, m_tiles, n_tiles, st) : launch_ns<64, 128, 2, 4, 4, 512>(p, m_tiles, n_tiles, st);
+    else if (bm == 128 && bn == 128) rc = ns == 2 ? launch_ns<128, 128, 2, 4, 2, 512>(p, m_tiles, n_tiles, st) : ns == 3 ? launch_ns<128, 128, 2, 4, 3, 512>(p, m_tiles, n_tiles, st) : launch_ns<128, 128, 2, 4, 4, 512>(p, m_tiles, n_tiles, st);
+    else if (bm == 256 && bn == 128) rc = ns == 2 ? launch_ns<256, 128, 4, 2, 2, 512>(p, m_tiles, n_tiles, st) : launch_ns<256, 128, 4, 2, 3, 512>(p, m_tiles, n_tiles, st);
+    else if (bm == 128 && bn == 64) rc = ns == 2 ? launch_ns<128, 64, 4, 2, 2, 512>(p, m_tiles, n_tiles, st) : ns == 3 ? launch_ns<128, 64, 4, 2, 3, 512>(p, m_tiles, n_tiles, st) : launch_ns<128, 64, 4, 2, 4, 512>(p, m_tiles, n_tiles, st);
+  } else if (bm == 64) {
+    rc = (bn == 64) ? launch4<64, 64, 2, 2>(p, m_tiles, n_tiles, st) : launch4<64, 128, 2, 2>(p, m_tiles, n_tiles, st);
   } else {
     switch (bn) {
-      case 16: rc = launch<128, 16, 4, 1>(p, m_tiles, n_tiles, st); break;
-      case 32: rc = launch<128, 32, 4, 1>(p, m_tiles, n_tiles, st); break;
-      case 64: rc = launch<128, 64, 2, 2>(p, m_tiles, n_tiles, st); break;
-      default: rc = launch<128, 128, 2, 2>(p, m_tiles, n_tiles, st); break;
+      case 16: rc = launch4<128, 16, 4, 1>(p, m_tiles, n_tiles, st); break;
+      case 32: rc = launch4<128, 32, 4, 1>(p, m_tiles, n_tiles, st); break;
+      case 64: rc = launch4<128, 64, 2, 2>(p, m_tiles, n_tiles, st); break;
+      default: rc = launch4<128, 128, 2, 2>(p, m_tiles, n_tiles, st); break;
     }
   }
   if (rc != AVLEN_OK) return rc;
