@@ -136,6 +136,8 @@ SIGNATURES = {
     "avlen_resnet18_group_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp]),
     "avlen_cnn3_workspace_bytes": (sz, [C.POINTER(Cnn3), i32, i32, i32]),
     "avlen_cnn3_fwd": (i32, [C.POINTER(Cnn3), vp, i32, i32, i32, vp, i32, i32, vp, sz, vp]),
+    "avlen_cnn3_group_workspace_bytes": (sz, [C.POINTER(Cnn3), i32, i32, i32, i32]),
+    "avlen_cnn3_group_fwd": (i32, [vp, vp, i32, i32, i32, i32, vp, i32, vp, sz, vp]),
     "avlen_smt_workspace_bytes": (sz, [C.POINTER(Smt), i32, i32, i32, i32]),
     "avlen_smt_fwd": (i32, [C.POINTER(Smt), vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     "avlen_smt_bwd": (i32, [C.POINTER(Smt), C.POINTER(Smt), vp, vp, i32, i32, i32, i32, i32, i32, vp, sz, vp]),

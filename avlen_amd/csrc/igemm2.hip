@@ -348,21 +348,47 @@ __global__ __launch_bounds__(NTH) void g2_kernel(G2 pp) {
     }
 }
 
-__global__ void g2_reduce_kernel(const float* __restrict__ slab, float* __restrict__ C32, bf16* __restrict__ C16,
-                                 const float* __restrict__ bias, const float* __restrict__ residual, int M, int N,
-                                 int ldc32, int ldc16, int ldr, int splits, int act, const int* __restrict__ M_dev) {
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  long tot = (long)M * N;
+// Deterministic split-K reduction + epilogue; blockIdx.y = group (all groups of a grouped launch in one pass).
+struct G2Red { G2Grp g[MAXG]; const float* slab; };
+__global__ void g2_reduce_kernel(G2Red rr, int M, int N, int ldc32, int ldc16, int ldr, int splits, int act,
+                                 const int* __restrict__ M_dev) {
+  const G2Grp g = rr.g[blockIdx.y];
+  const long tot = (long)M * N;
+  const float* __restrict__ slab = rr.slab + (size_t)blockIdx.y * splits * tot;
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= tot) return;
-  int row = (int)(i / N), col = (int)(i - (long)row * N);
-  if (M_dev && row >= *M_dev) return;
-  float s = 0.f;
-  for (int z = 0; z < splits; z++) s += slab[(long)z * tot + i];
-  if (bias) s += bias[col];
-  s = act2(s, act);
-  if (residual) s += residual[(long)row * ldr + col];
-  if (C32) C32[(long)row * ldc32 + col] = s;
-  if (C16) C16[(long)row * ldc16 + col] = (bf16)s;
+  if ((N & 3) == 0 && ((size_t)slab & 15) == 0) {   // 4 consecutive columns of one row
+    int row = (int)(i / N), col = (int)(i - (long)row * N);
+    if (M_dev && row >= *M_dev) return;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < splits; z++) {
+      float4 v = *reinterpret_cast<const float4*>(slab + (long)z * tot + i);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    float o[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      float v = o[r];
+      if (g.bias) v += g.bias[col + r];
+      v = act2(v, act);
+      if (g.residual) v += g.residual[(long)row * ldr + col + r];
+      if (g.C32) g.C32[(long)row * ldc32 + col + r] = v;
+      if (g.C16) g.C16[(long)row * ldc16 + col + r] = (bf16)v;
+    }
+    return;
+  }
+  for (int e = 0; e < 4 && i + e < tot; e++) {
+    long ii = i + e;
+    int row = (int)(ii / N), col = (int)(ii - (long)row * N);
+    if (M_dev && row >= *M_dev) return;
+    float s = 0.f;
+    for (int z = 0; z < splits; z++) s += slab[(long)z * tot + ii];
+    if (g.bias) s += g.bias[col];
+    s = act2(s, act);
+    if (g.residual) s += g.residual[(long)row * ldr + col];
+    if (g.C32) g.C32[(long)row * ldc32 + col] = s;
+    if (g.C16) g.C16[(long)row * ldc16 + col] = (bf16)s;
+  }
 }
 
 // fp32 -> bf16 with row padding (pad columns zero-filled)
@@ -500,11 +526,10 @@ int run_g2(G2 p, void* ws, size_t ws_bytes, hipStream_t st) {
   if (rc != AVLEN_OK) return rc;
   if (p.splitk > 1) {
     long tot = (long)p.M * p.N;
-    for (int g = 0; g < p.groups; g++) {
-      hipLaunchKernelGGL(g2_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st,
-                         p.slab + (size_t)g * p.splitk * tot, p.g[g].C32, p.g[g].C16, p.g[g].bias, p.g[g].residual, p.M, p.N,
-                         p.ldc32, p.ldc16, p.ldr, p.splitk, p.act, p.M_dev);
-    }
+    G2Red rr; rr.slab = p.slab;
+    for (int g = 0; g < MAXG; g++) rr.g[g] = p.g[g < p.groups ? g : 0];
+    hipLaunchKernelGGL(g2_reduce_kernel, dim3((unsigned)((tot / 4 + 256) / 256), p.groups), dim3(256), 0, st, rr, p.M, p.N,
+                       p.ldc32, p.ldc16, p.ldr, p.splitk, p.act, p.M_dev);
     return avlen_launch_status();
   }
   return AVLEN_OK;
@@ -548,15 +573,17 @@ extern "C" int avlen_conv2d_nhwc_bf16(const void* X, const void* Wp, const float
 // six ResNet towers of the three policies (and the two towers of one policy) as single launches.
 int avlen_conv2d_nhwc_bf16_grouped(const void* const* X, const void* const* Wp, float* const* Y32, void* const* Y16,
                                    float* const* gn_stats, int groups, int Bn, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
-                                   void* ws, size_t ws_bytes, hipStream_t stream) {
+                                   void* ws, size_t ws_bytes, hipStream_t stream, const float* const* bias, int act) {
   if (Cin < 8 || (Cin & (Cin - 1)) || groups < 1 || groups > MAXG) return AVLEN_ERR_ARG;
   int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
   if (OH <= 0 || OW <= 0 || (gn_stats && (OH * OW) % 64)) return AVLEN_ERR_ARG;
   G2 p = {};
   p.groups = groups;
   for (int g = 0; g < groups; g++)
-    p.g[g] = G2Grp{(const bf16*)X[g], (const bf16*)Wp[g], Y32 ? Y32[g] : nullptr, Y16 ? (bf16*)Y16[g] : nullptr, nullptr,
-                   nullptr, gn_stats ? gn_stats[g] : nullptr};
+    p.g[g] = G2Grp{(const bf16*)X[g], (const bf16*)Wp[g], Y32 ? Y32[g] : nullptr, Y16 ? (bf16*)Y16[g] : nullptr,
+                   bias ? bias[g] : nullptr, nullptr, gn_stats ? gn_stats[g] : nullptr};
+  p.act = act;
+  if (gn_stats && bias) return AVLEN_ERR_ARG;
   p.M = Bn * OH * OW; p.N = Cout; p.K = KH * KW * Cin; p.lda = 8; p.ldb = p.K; p.ldc32 = Cout; p.ldc16 = Cout; p.ldr = Cout;
   p.conv = 1; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
   p.ohw = OH * OW;

@@ -183,18 +183,26 @@ __global__ void clip_embed_kernel(const int64_t* __restrict__ tokens, const floa
 __global__ void clip_segments_kernel(const int64_t* __restrict__ tokens, int* __restrict__ seg, int* __restrict__ rowmap, int B,
                                      int ctx) {
   __shared__ int len[1024];
-  const int t = threadIdx.x;
-  for (int b = t; b < B; b += blockDim.x) {
-    long best = tokens[(long)b * ctx]; int bi = 0;
-    for (int k = 1; k < ctx; k++) { long v = tokens[(long)b * ctx + k]; if (v > best) { best = v; bi = k; } }
-    len[b] = bi + 1;
+  __shared__ int off[1025];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = blockDim.x >> 6;
+  // one wave per sample: first position of the maximum token id (torch.argmax picks the first maximum)
+  for (int b = wave; b < B; b += nw) {
+    long best = -1; int bi = 0x7fffffff;
+    for (int k = lane; k < ctx; k += 64) { long v = tokens[(long)b * ctx + k]; if (v > best) { best = v; bi = k; } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      long ob = __shfl_xor(best, o, 64); int oi = __shfl_xor(bi, o, 64);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) len[b] = bi + 1;
   }
   __syncthreads();
-  if (t == 0) { int acc = 0; for (int b = 0; b < B; b++) { seg[b] = acc; acc += len[b]; } seg[B] = acc; }
+  if (t == 0) { int acc = 0; for (int b = 0; b < B; b++) { off[b] = acc; acc += len[b]; } off[B] = acc; }
   __syncthreads();
-  for (int b = 0; b < B; b++) {
-    int o = seg[b];
-    for (int k = t; k < len[b]; k += blockDim.x) rowmap[o + k] = b * ctx + k;
+  for (int b = t; b <= B; b += blockDim.x) seg[b] = off[b];
+  for (int b = wave; b < B; b += nw) {
+    const int o = off[b];
+    for (int k = lane; k < len[b]; k += 64) rowmap[o + k] = b * ctx + k;
   }
 }
 __global__ void clip_embed_ragged_kernel(const int64_t* __restrict__ tokens, const float* __restrict__ tok_emb,
@@ -482,7 +490,61 @@ int cnn3_fwd_bf16(const avlen_cnn3* n, const float* x, int B, int H, int W, floa
                          n->fc.out_f, n->fc.ld16, AVLEN_ACT_RELU, gws, mx, st);
 }
 
+// `G` CNNs of identical architecture (the audio encoders of pi_q / pi_g / pi_l) on the SAME input: one cast, one grouped
+// launch per layer.
+int cnn3_group_fwd_bf16(const avlen_cnn3* const* nets, const float* x, int G, int B, int H, int W, float* const* outs,
+                        int ld_out, void* ws, size_t ws_bytes, hipStream_t st) {
+  const avlen_cnn3* n = nets[0];
+  if (ws_bytes < (size_t)G * cnn3_ws_bf16(n, B, H, W)) return AVLEN_ERR_WS;
+  int oh[3], ow[3]; cnn3_dims2(n, H, W, oh, ow);
+  WsBump w(ws, ws_bytes);
+  bf16* x16 = w.take<bf16>((size_t)B * H * W * 8);
+  bf16* a[3][8];
+  size_t mx = avlen_gemm_bf16_workspace_bytes(B, n->fc.out_f);
+  for (int i = 0; i < 3; i++) {
+    for (int g = 0; g < G; g++) a[i][g] = w.take<bf16>((size_t)B * oh[i] * ow[i] * n->conv[i].cout);
+    mx = zmax(mx, avlen_gemm_bf16_workspace_bytes(B * oh[i] * ow[i], n->conv[i].cout));
+  }
+  mx *= G;
+  void* gws = w.take<char>(mx);
+  if (!w.ok()) return AVLEN_ERR_WS;
+  TRY(avlen_cast_bf16(x, n->conv[0].cin, x16, 8, (long)B * H * W, n->conv[0].cin, st));     // channel-pad to 8
+  const void* X[8]; const void* Wt[8]; void* Y[8]; const float* BI[8];
+  int h = H, wd = W;
+  for (int i = 0; i < 3; i++) {
+    const avlen_conv& k = n->conv[i];
+    for (int g = 0; g < G; g++) {
+      X[g] = i == 0 ? (const void*)x16 : (const void*)a[i - 1][g];
+      Wt[g] = nets[g]->conv[i].w16; Y[g] = a[i][g]; BI[g] = nets[g]->conv[i].b;
+    }
+    TRY(avlen_conv2d_nhwc_bf16_grouped(X, Wt, nullptr, Y, nullptr, G, B, h, wd, k.cin16, k.cout, k.kh, k.kw, k.stride, 0, gws, mx,
+                                       st, BI, i < 2 ? AVLEN_ACT_RELU : AVLEN_ACT_NONE));
+    h = oh[i]; wd = ow[i];
+  }
+  const void* FA[8]; const void* FB[8]; const float* FBI[8];
+  for (int g = 0; g < G; g++) { FA[g] = a[2][g]; FB[g] = nets[g]->fc.w16; FBI[g] = nets[g]->fc.b; }
+  return avlen_gemm_bf16_grouped(FA, n->fc.ld16, FB, n->fc.ld16, outs, ld_out, FBI, G, B, n->fc.out_f, n->fc.ld16, AVLEN_ACT_RELU,
+                                 gws, mx, st);
+}
+
 }  // namespace
+
+extern "C" size_t avlen_cnn3_group_workspace_bytes(const avlen_cnn3* n, int groups, int B, int H, int W) {
+  return (size_t)groups * cnn3_ws_bf16(n, B, H, W) + 4096;
+}
+
+extern "C" int avlen_cnn3_group_fwd(const avlen_cnn3* const* nets, const float* x, int groups, int B, int H, int W,
+                                    float* const* outs, int ld_out, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!nets || groups < 1 || groups > 8 || B <= 0) return AVLEN_ERR_ARG;
+  for (int g = 0; g < groups; g++) {
+    if (!cnn3_has16(nets[g])) return AVLEN_ERR_ARG;
+    for (int i = 0; i < 3; i++) {
+      const avlen_conv &a = nets[g]->conv[i], &b = nets[0]->conv[i];
+      if (a.cin != b.cin || a.cout != b.cout || a.kh != b.kh || a.kw != b.kw || a.stride != b.stride) return AVLEN_ERR_ARG;
+    }
+  }
+  return cnn3_group_fwd_bf16(nets, x, groups, B, H, W, outs, ld_out, ws, ws_bytes, st);
+}
 
 // =====================================================================================================
 // ResNet-18 tower
@@ -1129,6 +1191,14 @@ extern "C" size_t avlen_clip_text_workspace_bytes(const avlen_clip_text* p, int 
   return (R * (wd * 3 + 3 * wd + 4 * wd) + (size_t)B * wd * 2) * sizeof(float) + GEMM_SCRATCH + 8192;
 }
 
+// out = E2 @ text_proj   (text_proj stored [width][out_dim]); a handful of row tiles -> split K over the chip
+static int clip_project(const avlen_clip_text* p, const float* E2, float* out, int B, int prec, void* gws, hipStream_t st) {
+  int sk = avlen_gemm_pick_splitk(B, p->out_dim, p->width);
+  while (sk > 1 && avlen_gemm_workspace_bytes(B, p->out_dim, p->width, sk) > GEMM_SCRATCH) sk /= 2;
+  return avlen_gemm(E2, p->width, 0, p->text_proj, p->out_dim, 1, out, p->out_dim, nullptr, nullptr, 0, B, p->out_dim, p->width,
+                    0, prec, sk, 0.f, gws, GEMM_SCRATCH, st);
+}
+
 extern "C" int avlen_clip_text_fwd(const avlen_clip_text* p, const int64_t* tokens, float* out, int B, int prec,
                                    void* ws, size_t ws_bytes, hipStream_t st) {
   if (!p || B <= 0 || p->width % p->heads || ws_bytes < avlen_clip_text_workspace_bytes(p, B)) return AVLEN_ERR_WS;
@@ -1174,8 +1244,7 @@ extern "C" int avlen_clip_text_fwd(const avlen_clip_text* p, const int64_t* toke
     hipLaunchKernelGGL(clip_gather_last_kernel, dim3(B), dim3(128), 0, st, X, E, seg, wd);
     TRY(avlen_launch_status());
     TRY(avlen_layernorm_fwd(E, nullptr, p->ln_final.g, p->ln_final.b, E2, nullptr, nullptr, B, wd, 1e-5f, st));
-    return avlen_gemm(E2, wd, 0, p->text_proj, p->out_dim, 1, out, p->out_dim, nullptr, nullptr, 0, B, p->out_dim, wd, 0,
-                      prec, 1, 0.f, gws, GEMM_SCRATCH, st);
+    return clip_project(p, E2, out, B, prec, gws, st);
   }
   hipLaunchKernelGGL(clip_embed_kernel, dim3((unsigned)R), dim3(128), 0, st, tokens, p->tok_emb, p->pos_emb, X, ctx, wd,
                      p->vocab);
@@ -1194,9 +1263,7 @@ extern "C" int avlen_clip_text_fwd(const avlen_clip_text* p, const int64_t* toke
   hipLaunchKernelGGL(clip_gather_eot_kernel, dim3(B), dim3(128), 0, st, tokens, X, E, ctx, wd);
   TRY(avlen_launch_status());
   TRY(avlen_layernorm_fwd(E, nullptr, p->ln_final.g, p->ln_final.b, E2, nullptr, nullptr, B, wd, 1e-5f, st));
-  // out = E2 @ text_proj   (text_proj stored [width][out_dim])
-  return avlen_gemm(E2, wd, 0, p->text_proj, p->out_dim, 1, out, p->out_dim, nullptr, nullptr, 0, B, p->out_dim, wd, 0,
-                    prec, 1, 0.f, gws, GEMM_SCRATCH, st);
+  return clip_project(p, E2, out, B, prec, gws, st);
 }
 
 // =====================================================================================================

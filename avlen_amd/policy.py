@@ -131,13 +131,17 @@ class EncoderGroup:
         for m in self.members:
             m._enc_group = self
 
+    @staticmethod
+    def _key(obs):
+        return (obs["rgb"].data_ptr(), obs["depth"].data_ptr(), obs[SPECTROGRAM].data_ptr(), tuple(obs["rgb"].shape))
+
     def mark(self, obs):
-        self.key = (obs["rgb"].data_ptr(), obs["depth"].data_ptr(), tuple(obs["rgb"].shape))
+        self.key = self._key(obs)
         self.pending = set(id(m) for m in self.members[1:])
 
     def claim(self, pol, obs):
         """True once per leader call for a follower that presents the leader's observation tensors."""
-        k = (obs["rgb"].data_ptr(), obs["depth"].data_ptr(), tuple(obs["rgb"].shape))
+        k = self._key(obs)
         if k == self.key and id(pol) in self.pending:
             self.pending.discard(id(pol))
             return True
@@ -147,6 +151,23 @@ class EncoderGroup:
         if B not in self.out:
             self.out[B] = [torch.empty(B, 128, device=dev) for _ in self.members]
         return self.out[B]
+
+    def audio_buffers(self, B, dev):
+        if ("a", B) not in self.out:
+            self.out[("a", B)] = [torch.empty(B, 128, device=dev) for _ in self.members]
+        return self.out[("a", B)]
+
+    def run_audio(self, pol, spec):
+        """All members' AudioCNNs on the shared spectrogram: one cast, one grouped launch per layer."""
+        B, H, W = spec.shape[0], spec.shape[1], spec.shape[2]
+        bufs = self.audio_buffers(B, spec.device)
+        G = len(self.members)
+        nets = (C.POINTER(L.Cnn3) * G)(*[C.pointer(m._engine()["audio"]) for m in self.members])
+        outs = (C.c_void_p * G)(*[b.data_ptr() for b in bufs])
+        nb = L.lib.avlen_cnn3_group_workspace_bytes(nets[0], G, B, H, W)
+        ws = pol._ws.get("audio_group", nb, spec.device)
+        L.call("avlen_cnn3_group_fwd", nets, E.P(spec), G, B, H, W, outs, 128, E.P(ws), nb, L.stream())
+        return bufs[0]
 
     def run_all(self, pol, rgb, depth):
         B, dev = rgb.shape[0], rgb.device
@@ -496,8 +517,16 @@ class _SMTBase(Net):
             if fork:
                 s_aud.wait_stream(cur)
             with torch.cuda.stream(s_aud):
-                L.call("avlen_cnn3_fwd", C.byref(eng["audio"]), E.P(spec), B, H, W, E.P(feats, 144), F, prec, E.P(ws2), nb2,
-                       L.stream())
+                if mode == "lead":
+                    aud = grp.run_audio(pol, spec)
+                elif mode == "follow":
+                    aud = grp.audio_buffers(B, dev)[grp.members.index(pol)]
+                else:
+                    aud = None
+                    L.call("avlen_cnn3_fwd", C.byref(eng["audio"]), E.P(spec), B, H, W, E.P(feats, 144), F, prec, E.P(ws2), nb2,
+                           L.stream())
+                if aud is not None:
+                    L.call("avlen_copy_rows", E.P(aud), 128, E.P(feats, 144), F, B, 128, L.stream())
             if mode == "follow":
                 vis = grp.buffers(B, dev)[grp.members.index(pol)]
             elif mode == "lead":

@@ -169,6 +169,12 @@ size_t avlen_cnn3_workspace_bytes(const avlen_cnn3* net, int B, int H, int W);
 /* AudioCNN.forward (audio_cnn.py:136-151) / VisualCNN.cnn: x NHWC (B,H,W,conv[0].cin) -> out[b*ld_out + 0..fc.out_f). */
 int avlen_cnn3_fwd(const avlen_cnn3* net, const float* x, int B, int H, int W, float* out, int ld_out, int prec,
                    void* ws, size_t ws_bytes, avlen_stream_t stream);
+/* `groups` (<= 8) AudioCNNs of identical architecture on the SAME input x (the audio encoders of pi_q / pi_g / pi_l all
+ * read the step's spectrogram, ppo_trainer.py:449-636): one bf16 cast of x, one grouped launch per layer (bf16 fast
+ * path only).  outs[g][b*ld_out + 0..fc.out_f). */
+size_t avlen_cnn3_group_workspace_bytes(const avlen_cnn3* net, int groups, int B, int H, int W);
+int avlen_cnn3_group_fwd(const avlen_cnn3* const* nets, const float* x, int groups, int B, int H, int W,
+                         float* const* outs, int ld_out, void* ws, size_t ws_bytes, avlen_stream_t stream);
 
 /* ------------------------------------------------------------------ SMT / dialog / CLIP -------- */
 /* SMTStateEncoder.single_forward (smt_state_encoder.py:109-188).

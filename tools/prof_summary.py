@@ -1,20 +1,30 @@
-"""Turn a rocprofv3 `*_kernel_stats.csv` into the markdown table kept under profiles/."""
-import csv, sys, re
+"""Summarise a rocprofv3 run (rocpd `*_results.db`, or a `*_kernel_stats.csv`) as the markdown table kept under profiles/.
+Usage: python tools/prof_summary.py <results.db|kernel_stats.csv> [title ...]"""
+import csv, re, sqlite3, sys
+
 
 def short(n):
     n = re.sub(r"\(anonymous namespace\)::", "", n)
     n = re.sub(r"^void ", "", n)
-    return n.split("(")[0][:70]
+    return n.split("(")[0][:64]
+
+
+def rows_from(path):
+    if path.endswith(".db"):
+        c = sqlite3.connect(path).cursor()
+        return [(r[0], r[1], float(r[2]), float(r[3])) for r in c.execute(
+            "select name, count(*), sum(end-start), avg(end-start) from kernels group by name")]
+    return [(r["Name"], int(r["Calls"]), float(r["TotalDurationNs"]), float(r["AverageNs"])) for r in csv.DictReader(open(path))]
+
 
 def main(path, title=""):
-    rows = list(csv.DictReader(open(path)))
-    tot = sum(float(r["TotalDurationNs"]) for r in rows)
-    print(f"# {title}\n")
-    print(f"total kernel time {tot/1e6:.1f} ms\n")
+    rows = sorted(rows_from(path), key=lambda r: -r[2])
+    tot = sum(r[2] for r in rows)
+    print(f"# {title}\n\ntotal kernel time {tot/1e6:.1f} ms over {sum(r[1] for r in rows)} launches\n")
     print("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|")
-    for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:40]:
-        t = float(r["TotalDurationNs"])
-        print(f"| `{short(r['Name'])}` | {r['Calls']} | {t/1e6:.2f} | {float(r['AverageNs'])/1e3:.1f} | {100*t/tot:.1f} |")
+    for n, calls, t, avg in rows[:45]:
+        print(f"| `{short(n)}` | {calls} | {t/1e6:.2f} | {avg/1e3:.1f} | {100*t/tot:.1f} |")
+
 
 if __name__ == "__main__":
     main(sys.argv[1], " ".join(sys.argv[2:]))
