@@ -157,6 +157,7 @@ SIGNATURES = {
     "avlen_extmem_insert": (i32, [vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
     "avlen_minibatch_gather": (i32, [vp, vp, vp, i32, i32, i32, sz, i32, vp]),
     "avlen_copy_rows": (i32, [vp, i32, vp, i32, i32, i32, vp]),
+    "avlen_multi_copy": (i32, [vp, vp, vp, i32, vp]),
     "avlen_build_info": (C.c_char_p, []),
 }
 
@@ -184,3 +185,24 @@ def check(rc, what=""):
 
 def call(name, *args):
     check(getattr(lib, name)(*args), name)
+
+
+def multi_copy(pairs):
+    """pairs: iterable of (dst, src) tensors.  Device-resident, contiguous, same-dtype, same-size pairs go out as ONE
+    `avlen_multi_copy` launch on the current stream; anything else (host tensors, dtype conversion, strided views)
+    falls back to `Tensor.copy_`."""
+    batch = []
+    for dst, src in pairs:
+        if (torch.is_tensor(src) and src.is_cuda and dst.is_cuda and src.dtype == dst.dtype and src.is_contiguous()
+                and dst.is_contiguous() and src.numel() == dst.numel()):
+            if src.data_ptr() != dst.data_ptr() and src.numel():
+                batch.append((dst, src))
+        else:
+            dst.copy_(src if torch.is_tensor(src) else torch.as_tensor(src), non_blocking=True)
+    if not batch:
+        return
+    n = len(batch)
+    srcs = (C.c_void_p * n)(*[s_.data_ptr() for _, s_ in batch])
+    dsts = (C.c_void_p * n)(*[d.data_ptr() for d, _ in batch])
+    sizes = (C.c_int64 * n)(*[d.numel() * d.element_size() for d, _ in batch])
+    call("avlen_multi_copy", srcs, dsts, sizes, n, stream())

@@ -192,6 +192,44 @@ extern "C" int avlen_pack_fc_after_flatten(const float* w, float* o, int O, int 
   return avlen_launch_status();
 }
 
+// ---- batched device-to-device copies: one launch for all of a rollout step's storage writes ----
+struct MultiCopy { const char* src[32]; char* dst[32]; long nbytes[32]; };
+__global__ void multi_copy_kernel(MultiCopy mc) {
+  const int e = blockIdx.y;
+  const char* __restrict__ s = mc.src[e]; char* __restrict__ d = mc.dst[e];
+  const long n = mc.nbytes[e];
+  const long stride = (long)gridDim.x * blockDim.x, t0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if ((((size_t)s | (size_t)d | (size_t)n) & 15) == 0) {
+    const float4* s4 = reinterpret_cast<const float4*>(s); float4* d4 = reinterpret_cast<float4*>(d);
+    for (long i = t0; i < (n >> 4); i += stride) d4[i] = s4[i];
+  } else if ((((size_t)s | (size_t)d | (size_t)n) & 3) == 0) {
+    const int* s1 = reinterpret_cast<const int*>(s); int* d1 = reinterpret_cast<int*>(d);
+    for (long i = t0; i < (n >> 2); i += stride) d1[i] = s1[i];
+  } else {
+    for (long i = t0; i < n; i += stride) d[i] = s[i];
+  }
+}
+
+extern "C" int avlen_multi_copy(const void* const* src, void* const* dst, const int64_t* nbytes, int n, hipStream_t stream) {
+  if (n < 0 || (n > 0 && (!src || !dst || !nbytes))) return AVLEN_ERR_ARG;
+  for (int base = 0; base < n; base += 32) {
+    MultiCopy mc = {};
+    const int cnt = n - base < 32 ? n - base : 32;
+    long mx = 0;
+    for (int i = 0; i < cnt; i++) {
+      if (nbytes[base + i] < 0 || (nbytes[base + i] > 0 && (!src[base + i] || !dst[base + i]))) return AVLEN_ERR_ARG;
+      mc.src[i] = (const char*)src[base + i]; mc.dst[i] = (char*)dst[base + i]; mc.nbytes[i] = nbytes[base + i];
+      if (mc.nbytes[i] > mx) mx = mc.nbytes[i];
+    }
+    if (mx == 0) continue;
+    long bx = (mx / 16 + 255) / 256;
+    if (bx < 1) bx = 1;
+    if (bx > 512) bx = 512;
+    hipLaunchKernelGGL(multi_copy_kernel, dim3((unsigned)bx, cnt), dim3(256), 0, stream, mc);
+  }
+  return avlen_launch_status();
+}
+
 extern "C" int avlen_copy_rows(const float* src, int lds, float* dst, int ldd, int rows, int cols, hipStream_t stream) {
   hipLaunchKernelGGL(copy_rows_kernel, grid1d((long)rows * cols), dim3(256), 0, stream, src, lds, dst, ldd, rows, cols);
   return avlen_launch_status();

@@ -64,13 +64,14 @@ class _Graph:
             pol._ws = ws_saved
 
     def __call__(self, args):
+        pairs = []
         for s, a in zip(self.static, args):
             if torch.is_tensor(s):
                 if s.data_ptr() != a.data_ptr():
-                    s.copy_(a, non_blocking=True)
+                    pairs.append((s, a))
             elif isinstance(s, dict) and s is not a:
-                for k in s:
-                    s[k].copy_(a[k], non_blocking=True)
+                pairs += [(s[k], a[k]) for k in s]
+        L.multi_copy(pairs)                              # one launch for all static-input refreshes
         self.graph.replay()
         return self.outs
 

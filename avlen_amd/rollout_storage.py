@@ -122,28 +122,25 @@ class RolloutStorage:
         s = self.step
         dev = self.device
         as_t = lambda x, dt=None: (x if torch.is_tensor(x) else torch.as_tensor(x)).to(dev, dtype=dt, non_blocking=True)
-        for sensor in self.observations:
-            self.observations[sensor][s + 1].copy_(observations[sensor], non_blocking=True)
-        self.recurrent_hidden_states[s + 1].copy_(recurrent_hidden_states)
-        self.all_dialog[s].copy_(all_dialog)
-        self.query_state[s].copy_(query_state)
-        self.last_query_info[s].copy_(last_query_info)
-        self.agent_step[s].copy_(as_t(agent_step).view(-1))
+        # all of the step's storage writes go out as one batched copy launch (L.multi_copy falls back to copy_ for
+        # host values / dtype conversions); shapes follow the reference's `tensor[step].copy_(value)` broadcasting
+        def fit(dst, v, dt=None):
+            v = as_t(v, dt if dt is not None else dst.dtype)
+            return (dst, v.reshape(dst.shape) if v.numel() == dst.numel() else v.expand_as(dst).contiguous())
+        pairs = [fit(self.observations[k][s + 1], observations[k]) for k in self.observations]
+        pairs += [fit(self.recurrent_hidden_states[s + 1], recurrent_hidden_states), fit(self.all_dialog[s], all_dialog),
+                  fit(self.query_state[s], query_state), fit(self.last_query_info[s], last_query_info),
+                  fit(self.agent_step[s], agent_step)]
         if o_action is not None:
-            self.o_masks[s].copy_(as_t(o_mask).view(-1))
-            self.ucnt_gt[s].copy_(as_t(ucnt_gt).view(-1))
-            self.rl_masks[s].copy_(as_t(rl_masks).view(-1))
-            self.o_actions[s].copy_(as_t(o_action).view(-1))
-            self.action_probs[s].copy_(action_prob)
-        self.actions[s].copy_(actions)
+            pairs += [fit(self.o_masks[s], o_mask), fit(self.ucnt_gt[s], ucnt_gt), fit(self.rl_masks[s], rl_masks),
+                      fit(self.o_actions[s], o_action), fit(self.action_probs[s], action_prob)]
+        pairs.append(fit(self.actions[s], actions))
         if actions_option is not None:
-            self.actions_option[s].copy_(actions_option)
-        self.prev_actions[s + 1].copy_(actions)
-        self.action_log_probs[s].copy_(action_log_probs)
-        self.value_preds[s].copy_(value_preds)
-        self.rewards[s].copy_(rewards)
-        self.masks[s + 1].copy_(not_done_masks)
-        self.masks_vln[s + 1].copy_(not_done_masks_vln)
+            pairs.append(fit(self.actions_option[s], actions_option))
+        pairs += [fit(self.prev_actions[s + 1], actions), fit(self.action_log_probs[s], action_log_probs),
+                  fit(self.value_preds[s], value_preds), fit(self.rewards[s], rewards),
+                  fit(self.masks[s + 1], not_done_masks), fit(self.masks_vln[s + 1], not_done_masks_vln)]
+        L.multi_copy(pairs)
         nd, ndv = self.masks[s + 1], self.masks_vln[s + 1]
         if self.use_external_memory:
             self.em.insert(em_features, nd, self.em_masks[s + 1])
@@ -157,11 +154,11 @@ class RolloutStorage:
 
     def after_update(self):
         s = self.step
-        for sensor in self.observations:
-            self.observations[sensor][0].copy_(self.observations[sensor][s])
-        self.recurrent_hidden_states[0].copy_(self.recurrent_hidden_states[s])
-        for buf in (self.masks, self.masks_vln, self.prev_actions, self.em_masks, self.em_vln_masks):
-            buf[0].copy_(buf[s])
+        pairs = [(v[0], v[s]) for v in self.observations.values()]
+        pairs.append((self.recurrent_hidden_states[0], self.recurrent_hidden_states[s]))
+        pairs += [(buf[0], buf[s]) for buf in (self.masks, self.masks_vln, self.prev_actions, self.em_masks,
+                                                 self.em_vln_masks)]
+        L.multi_copy(pairs)
         self.step = 0
 
     # ---------------------------------------------------------------- GAE (rollout_storage.py:394-412)
