@@ -336,6 +336,114 @@ __global__ __launch_bounds__(256) void attn_mfma64_kernel(const float* __restric
   }
 }
 
+// Self-attention straight from the packed bf16 projection [R][q | k | v] (D = 64, <= 96 tokens per sequence: CLIP text).
+// Compared with attn_mfma64_kernel: the tiles are staged with 16-byte copies (no conversion, no transposing scatter), the
+// scores are computed TRANSPOSED (S^T = K Q^T), so each lane ends up holding, for one query, four consecutive keys of every
+// key tile -- which is already the B-operand layout of the second MFMA under the key order {4q..4q+3, 16+4q..16+4q+3} per
+// 32-key step: P never leaves registers.  The matching V^T fragment is read from the row-major V tile with the hardware
+// transposing read ds_read_b64_tr_b16 (one 4-key x 16-dim block per 16-lane group).  O^T = V^T P^T comes out with four
+// consecutive output dims per lane -> 8-byte stores.  The softmax reductions are in-lane + 2 cross-lane moves.
+typedef __attribute__((ext_vector_type(4))) __bf16 abf16x4;
+
+__global__ __launch_bounds__(256) void attn_qkv16_kernel(const __bf16* __restrict__ QKV, int ld, int koff, int voff,
+                                                         __bf16* __restrict__ O16, int ldo16, int S, int causal, float scale,
+                                                         const int* __restrict__ seg_off) {
+  constexpr int D = 64, SKP = 96, KR = 80;          // 160-byte LDS rows: conflict-free for both read kinds
+  __shared__ __attribute__((aligned(16))) __bf16 qs[SKP * KR];
+  __shared__ __attribute__((aligned(16))) __bf16 ks[SKP * KR];
+  __shared__ __attribute__((aligned(16))) __bf16 vs[SKP * KR];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, q4 = lane >> 4;
+  const int h = blockIdx.x, b = blockIdx.y;
+  long row0 = (long)b * S;
+  if (seg_off) { row0 = seg_off[b]; S = seg_off[b + 1] - seg_off[b]; }
+  const int S32 = (S + 31) & ~31;                   // rows S .. S32-1 are zero (finite operands for the masked keys)
+  for (int i = tid; i < S32 * 8; i += 256) {
+    const int r = i >> 3, c = i & 7;
+    uint4 qv = make_uint4(0, 0, 0, 0), kv = qv, vv = qv;
+    if (r < S) {
+      const __bf16* base = QKV + (row0 + r) * ld + h * D + c * 8;
+      qv = *reinterpret_cast<const uint4*>(base);
+      kv = *reinterpret_cast<const uint4*>(base + koff);
+      vv = *reinterpret_cast<const uint4*>(base + voff);
+    }
+    *reinterpret_cast<uint4*>(&qs[r * KR + c * 8]) = qv;
+    *reinterpret_cast<uint4*>(&ks[r * KR + c * 8]) = kv;
+    *reinterpret_cast<uint4*>(&vs[r * KR + c * 8]) = vv;
+  }
+  __syncthreads();
+  const int n_kt = (S + 15) >> 4, n_kk = (S + 31) >> 5;
+  for (int mt = wave; mt * 16 < S; mt += 4) {
+    // ---- S^T: lane (r16, q4) holds S[query = mt*16 + r16][key = nt*16 + q4*4 + r]
+    af32x4 sacc[6];
+#pragma unroll
+    for (int nt = 0; nt < 6; nt++) sacc[nt] = (af32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) {
+      abf16x8 qf = *reinterpret_cast<const abf16x8*>(&qs[(mt * 16 + r16) * KR + kk * 32 + q4 * 8]);
+#pragma unroll
+      for (int nt = 0; nt < 6; nt++)
+        if (nt < n_kt) {
+          abf16x8 kf = *reinterpret_cast<const abf16x8*>(&ks[(nt * 16 + r16) * KR + kk * 32 + q4 * 8]);
+          sacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, sacc[nt], 0, 0, 0);
+        }
+    }
+    const int qi = mt * 16 + r16;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int nt = 0; nt < 6; nt++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int key = nt * 16 + q4 * 4 + r;
+        const bool ok = nt < n_kt && key < S && !(causal && key > qi);
+        const float v = ok ? sacc[nt][r] * scale : -INFINITY;
+        sacc[nt][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 6; nt++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const float pv = (sacc[nt][r] == -INFINITY) ? 0.f : __expf(sacc[nt][r] - mx);
+        sum += pv; sacc[nt][r] = pv;
+      }
+    sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+    // ---- O^T = V^T P^T: lane holds O[query = mt*16 + r16][d = dt*16 + q4*4 + r]
+    af32x4 oacc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; dt++) oacc[dt] = (af32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 3; kk++)
+      if (kk < n_kk) {
+        abf16x8 pf;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { pf[e] = (__bf16)sacc[2 * kk][e]; pf[4 + e] = (__bf16)sacc[2 * kk + 1][e]; }
+        const __bf16* vb = &vs[(kk * 32 + q4 * 4 + (r16 >> 2)) * KR + 4 * (r16 & 3)];
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++) {
+          abf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) abf16x4*)(vb + dt * 16));
+          abf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) abf16x4*)(vb + 16 * KR + dt * 16));
+          abf16x8 vf;
+#pragma unroll
+          for (int e = 0; e < 4; e++) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
+          oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[dt], 0, 0, 0);
+        }
+      }
+    if (qi < S) {
+      const float inv = sum > 0.f ? 1.f / sum : 0.f;
+      __bf16* op = O16 + (row0 + qi) * ldo16 + h * D + q4 * 4;
+#pragma unroll
+      for (int dt = 0; dt < 4; dt++) {
+        abf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; r++) o[r] = (__bf16)(oacc[dt][r] * inv);
+        *reinterpret_cast<abf16x4*>(op + dt * 16) = o;
+      }
+    }
+  }
+}
+
 // dQ: lane per query (same streaming structure as forward).  Also writes delta = rowsum(dO * O).
 template <int D>
 __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ K,
@@ -465,6 +573,15 @@ int avlen_attention_fwd16(const float* Q, int ldq, const float* K, int ldk, cons
                           int causal, float scale, hipStream_t stream) {
   return avlen_attention_fwd16_seg(Q, ldq, K, ldk, V, ldv, O, ldo, O16, ldo16, key_mask, lse, B, H, Sq, Sk, D, causal, scale,
                                    nullptr, stream);
+}
+
+// Packed bf16 projection [R][ld] with q | k | v at columns 0 | H*64 | 2*H*64 (head h at +64h) -> O16 [R][ldo16].
+int avlen_attention_qkv16(const void* QKV16, int ld, void* O16, int ldo16, int B, int H, int S, int causal, float scale,
+                          const int* seg_off, hipStream_t stream) {
+  if (!QKV16 || !O16 || B <= 0 || H <= 0 || S <= 0 || S > 96 || (ld & 7) || (ldo16 & 3)) return AVLEN_ERR_ARG;
+  hipLaunchKernelGGL(attn_qkv16_kernel, dim3(H, B), dim3(256), 0, stream, (const __bf16*)QKV16, ld, H * 64, 2 * H * 64,
+                     (__bf16*)O16, ldo16, S, causal, scale, seg_off);
+  return avlen_launch_status();
 }
 
 int avlen_attention_fwd16_seg(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,

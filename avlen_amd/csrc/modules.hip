@@ -1233,9 +1233,14 @@ extern "C" int avlen_clip_text_fwd(const avlen_clip_text* p, const int64_t* toke
     for (int l = 0; l < p->layers; l++) {
       const avlen_clip_block& b = p->block[l];
       TRY(avlen_layernorm_fwd16_dyn(X, nullptr, b.ln1.g, b.ln1.b, nullptr, Hn16, nullptr, nullptr, (int)R, live, wd, 1e-5f, st));
-      TRY(lin(b.attn.in_proj, Hn16, wd, QKV, 3 * wd, nullptr, 0, 0, nullptr));
-      TRY(avlen_attention_fwd16_seg(QKV, 3 * wd, QKV + wd, 3 * wd, QKV + 2 * wd, 3 * wd, nullptr, 0, AO16, wd, nullptr, nullptr,
-                                    B, H, ctx, ctx, D, 1, scale, seg, st));
+      if (D == 64 && ctx <= 96) {                      // packed bf16 q|k|v straight into the MFMA attention
+        TRY(lin(b.attn.in_proj, Hn16, wd, nullptr, 0, (bf16*)QKV, 3 * wd, 0, nullptr));
+        TRY(avlen_attention_qkv16(QKV, 3 * wd, AO16, wd, B, H, ctx, 1, scale, seg, st));
+      } else {
+        TRY(lin(b.attn.in_proj, Hn16, wd, QKV, 3 * wd, nullptr, 0, 0, nullptr));
+        TRY(avlen_attention_fwd16_seg(QKV, 3 * wd, QKV + wd, 3 * wd, QKV + 2 * wd, 3 * wd, nullptr, 0, AO16, wd, nullptr,
+                                      nullptr, B, H, ctx, ctx, D, 1, scale, seg, st));
+      }
       TRY(lin(b.attn.out_proj, AO16, wd, X, wd, nullptr, 0, 0, X));
       TRY(avlen_layernorm_fwd16_dyn(X, nullptr, b.ln2.g, b.ln2.b, nullptr, Hn16, nullptr, nullptr, (int)R, live, wd, 1e-5f, st));
       TRY(lin(b.fc, Hn16, wd, nullptr, 0, F16, b.fc.out_f, AVLEN_ACT_QUICKGELU, nullptr));

@@ -24,23 +24,39 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(avlen_heads h, const flo
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= B) return;
   const float* f = feats + (long)row * d;
+  // all MAXA + 3 dot products share one pass over the feature row: every weight load is issued before the first
+  // reduction (independent accumulators), then the wave reductions run back to back
+  constexpr int NO = MAXA + 3;
+  const float* wp[NO];
+#pragma unroll
+  for (int a = 0; a < MAXA; a++) wp[a] = h.action.w + (long)(a < A ? a : 0) * d;
+  wp[MAXA] = h.critic.w;
+  wp[MAXA + 1] = h.has_unct ? h.unct.w : h.critic.w;
+  wp[MAXA + 2] = h.has_unct ? h.unct.w + d : h.critic.w;
+  float acc[NO];
+#pragma unroll
+  for (int o = 0; o < NO; o++) acc[o] = 0.f;
+  for (int i = lane; i < d; i += 64) {
+    const float x = f[i];
+#pragma unroll
+    for (int o = 0; o < NO; o++) acc[o] += x * wp[o][i];
+  }
+#pragma unroll
+  for (int o = 0; o < NO; o++) acc[o] = wave_sum(acc[o]);
   float z[MAXA];
   float mx = -INFINITY;
 #pragma unroll
   for (int a = 0; a < MAXA; a++) {
     z[a] = -INFINITY;
-    if (a < A) { z[a] = row_dot(f, h.action.w + (long)a * d, d, lane) + h.action.b[a]; mx = fmaxf(mx, z[a]); }
+    if (a < A) { z[a] = acc[a] + h.action.b[a]; mx = fmaxf(mx, z[a]); }
   }
   float se = 0.f;
 #pragma unroll
   for (int a = 0; a < MAXA; a++) if (a < A) se += expf(z[a] - mx);
   float lse = mx + logf(se);
-  float v = row_dot(f, h.critic.w, d, lane) + h.critic.b[0];
+  float v = acc[MAXA] + h.critic.b[0];
   float u0 = 0.f, u1 = 0.f;
-  if (h.has_unct) {
-    u0 = row_dot(f, h.unct.w, d, lane) + h.unct.b[0];
-    u1 = row_dot(f, h.unct.w + d, d, lane) + h.unct.b[1];
-  }
+  if (h.has_unct) { u0 = acc[MAXA + 1] + h.unct.b[0]; u1 = acc[MAXA + 2] + h.unct.b[1]; }
   if (lane == 0) {
     float ent = 0.f;
 #pragma unroll

@@ -274,7 +274,8 @@ def test_gae_adam_extmem(L):
 
 # ------------------------------------------------------------------ bf16 fast path (igemm2.hip)
 @pytest.mark.parametrize("M,N,K,act", [(4928, 2048, 512, 2), (4928, 512, 2048, 0), (300, 256, 320, 1), (64, 64, 8192, 0),
-                                       (130, 21, 72, 0), (19264, 768, 256, 0), (257, 130, 200, 0)])
+                                       (130, 21, 72, 0), (19264, 768, 256, 0), (257, 130, 200, 0),
+                                       (16384, 4096, 128, 0), (2464, 512, 2048, 0), (8192, 1024, 192, 1)])
 def test_gemm_bf16_fast_path(L, M, N, K, act):
     torch.manual_seed(10)
     A, W = torch.randn(M, K), torch.randn(N, K) / math.sqrt(K)
@@ -336,3 +337,23 @@ def test_direct_conv_bf16(L, cfg):
     torch.cuda.synchronize()
     assert rel_err(y.float(), ref.permute(0, 2, 3, 1)) < 8e-3          # bf16 output rounding
     assert rel_err(stats[:, 0], ref.sum(dim=(2, 3))) < 1e-4 and rel_err(stats[:, 1], (ref ** 2).sum(dim=(2, 3))) < 1e-4
+
+
+def test_multi_copy(L):
+    """Batched device-to-device copies (storage inserts): mixed sizes / alignments / dtypes, > 32 pairs."""
+    torch.manual_seed(13)
+    srcs, dsts = [], []
+    for i, n in enumerate([1, 3, 4, 64, 1000, 4099, 12 * 128 * 128 * 3] + [17 + 5 * j for j in range(40)]):
+        if i % 3 == 0:
+            s_ = torch.randint(0, 1 << 40, (n,), dtype=torch.int64)
+        elif i % 3 == 1:
+            s_ = torch.randn(n)
+        else:
+            s_ = torch.randint(0, 255, (n,), dtype=torch.uint8)
+        srcs.append(dev(s_)); dsts.append(torch.zeros_like(srcs[-1]))
+    base = torch.zeros(101, device="cuda")               # a misaligned float view
+    srcs.append(dev(torch.randn(100))); dsts.append(base[1:])
+    L.multi_copy(list(zip(dsts, srcs)))
+    torch.cuda.synchronize()
+    for d, s_ in zip(dsts, srcs):
+        assert torch.equal(d, s_)
