@@ -2,14 +2,25 @@
 // (the single-target-token decoder, the collapsed `pretraining` encoder, the per-step tails of pi_q / pi_g / pi_l) in ONE
 // launch instead of ~20 launches of 5-12 us each.
 //
-// One block = 16 batch rows, 16/J waves (J = 16-feature tiles per wave; J = 1 -> 1024 threads, used when the batch is a
-// few blocks only and the chain is pure latency; J = 4 -> 256 threads).  The activation lives in registers between steps
-// (fp32, layout of the transposed MFMA result: lane (c = lane&15, q = lane>>4) of wave w holds batch row c, features
-// 16(J w + j) + 4q + r, j in 0..J-1, r in 0..3) and
-// as a bf16 copy in LDS (the B operand of the next step: X[row][k]).  Weights stream from L2 straight into registers as
-// the A operand (row = output feature), 16 B per lane per fragment; there is no LDS staging of weights and no inter-block
-// communication.  LayerNorm reduces inside the lane, across q by 2 shuffles and across the waves through 2 KB of LDS.
-// The residual operand comes from a register save slot.  The step list is a small program in the kernel arguments.
+// One block = 16 batch rows, 16 waves; wave w owns output features 16w .. 16w+15.  The activation lives in registers
+// between steps (fp32, layout of the transposed MFMA result: lane (c = lane&15, q = lane>>4) holds batch row c, features
+// 16w + 4q + r, r in 0..3) and as a bf16 image in LDS (the B operand of the next step: X[row][k]).
+//
+// Everything a step needs except its weights is on chip before the first step runs:
+//  * the program (step descriptors + the list of weight matrices) is copied from the kernel arguments into LDS -- a
+//    dynamically indexed kernarg read is a ~300-cycle scalar round trip, and the chain would pay one or more per step;
+//  * every bias / gamma / beta vector is copied into an LDS table by one cooperative pass (a global round trip per step
+//    otherwise sits on the critical path: measured 2.6k of a LayerNorm step's 2.7k cycles).
+// Weights: each step's [256][K] bf16 matrix is streamed through a 3-stage LDS ring of [256][64] tiles by
+// global_load_lds_dwordx4 (1 KiB contiguous per wave-instruction, whole 128-byte lines, XOR swizzle on the source
+// address), and the A fragments are read back with ds_read_b128.  (Fragment-shaped global loads straight to VGPRs,
+// 16 rows x 64 B per instruction, ran at 13 B/clk per CU: 4.4 us per 128 KiB step.)  The tile stream is continuous ACROSS
+// steps: while a step's epilogue / LayerNorm runs, the first tiles of the next Linear are already in flight (counted
+// s_waitcnt vmcnt, raw s_barrier -- a __syncthreads() would drain them).  LayerNorm reduces inside the lane, across q by
+// 2 shuffles and across the waves through 2 KB of LDS.  Residual operands and a parked activation live in two register
+// save slots.
+#include <stdlib.h>
+#include <string.h>
 #include "common.h"
 #include "../../include/avlen_hip.h"
 #include "internal.h"
@@ -19,160 +30,221 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+#ifdef AVLEN_CHAIN_LAB
+__device__ long long g_chain_stamps[64];     // tools/chain_lab.hip: start time of every step (block 0)
+#endif
+
 namespace {
 
-constexpr int D = 256;          // feature width of every step's output
-constexpr int KMAX = 512;       // widest input (dialog fusion: [state | text] = 512)
-constexpr int XLD = KMAX + 8;   // LDS row stride (elements) of the bf16 activation image
+constexpr int D = 256;            // feature width of every step's output
+constexpr int KMAX = 320;         // widest input (pi_q fusion: features + pose encoding = 320)
+constexpr int XLD = KMAX + 8;     // LDS row stride (elements) of the bf16 activation image
+constexpr int NTH = 1024, NW = 16;
+constexpr int TILE_BYTES = D * 128;            // one ring stage: [256 features][64 k] bf16
+constexpr int NS = 3;             // up to 2 tiles (64 KiB) in flight while one is multiplied
+constexpr int NIMG = 2;           // activation images (a third operand is parked in a register save slot)
+constexpr int XS_BYTES = NIMG * 16 * XLD * 2;
+constexpr int RED_BYTES = NW * 16 * 2 * 4;
+constexpr int MAX_LIN = 24, MAX_PAR = 36;      // Linear steps / 256-float parameter vectors per program
 
-template <int J>
-__global__ __launch_bounds__(1024 / J) void chain_kernel(avlen_chain prog, int B) {
-  constexpr int NW = 16 / J, NT = NW * 64;
-  __shared__ __attribute__((aligned(16))) bf16 xs[3][16 * XLD];
-  __shared__ float red[NW][16][2];
+// what the kernel reads: compiled from avlen_chain on the host
+struct DevOp { int kind, k, ld, ld2, act, res, buf, out_buf, par, pad; const void* p0; const void* p1; };
+struct DevLin { const char* w; int ld, nkt; };
+struct DevProg {
+  int n, n_lin, n_par, pad;
+  DevOp op[AVLEN_CHAIN_MAX_OPS];
+  DevLin lin[MAX_LIN];
+  const float* par_src[MAX_PAR];              // par_src[i] -> LDS table row i (256 floats)
+};
+constexpr int PROG_BYTES = (sizeof(DevProg) + 15) / 16 * 16;
+constexpr int PAR_BYTES = MAX_PAR * D * 4;
+constexpr int LDS_BYTES = NS * TILE_BYTES + XS_BYTES + RED_BYTES + PROG_BYTES + PAR_BYTES;
+static_assert(LDS_BYTES <= 160 * 1024, "chain kernel LDS budget");
+static_assert(sizeof(DevProg) <= 4000, "kernel argument limit");
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// LDS-only barrier: does not drain the weight tiles in flight
+__device__ __forceinline__ void bar() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
+__global__ __launch_bounds__(NTH) void chain_kernel(DevProg kprog, int B) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* ring = lds;                                                          // [NS][256][128 B]
+  bf16* xs = reinterpret_cast<bf16*>(lds + NS * TILE_BYTES);                 // [NIMG][16][XLD]
+  float* red = reinterpret_cast<float*>(lds + NS * TILE_BYTES + XS_BYTES);   // [8][16 rows][4]
+  DevProg* sp = reinterpret_cast<DevProg*>(lds + NS * TILE_BYTES + XS_BYTES + RED_BYTES);
+  float* par = reinterpret_cast<float*>(lds + NS * TILE_BYTES + XS_BYTES + RED_BYTES + PROG_BYTES);   // [MAX_PAR][256]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, q = lane >> 4;
   const int row = blockIdx.x * 16 + c;                 // this lane's batch row
   const bool rok = row < B;
-  const int n0 = wave * 16 * J;
-  float cur[J][4], sav[J][4];
-#pragma unroll
-  for (int j = 0; j < J; j++)
-#pragma unroll
-    for (int r = 0; r < 4; r++) { cur[j][r] = 0.f; sav[j][r] = 0.f; }
+  const int n0 = wave * 16;
 
-  auto publish = [&](int buf) {                        // cur -> bf16 image xs[buf][row][feature]
-#pragma unroll
-    for (int j = 0; j < J; j++) {
-      bf16x4 o;
-#pragma unroll
-      for (int r = 0; r < 4; r++) o[r] = (bf16)cur[j][r];
-      *reinterpret_cast<bf16x4*>(&xs[buf][c * XLD + n0 + j * 16 + q * 4]) = o;
+  // ---- program and parameter vectors -> LDS ----
+  {
+    const int* src = reinterpret_cast<const int*>(&kprog);
+    int* dst = reinterpret_cast<int*>(sp);
+    for (int i = tid; i < (int)(sizeof(DevProg) / 4); i += NTH) dst[i] = src[i];
+    const int npar4 = kprog.n_par * (D / 4);           // float4 slots
+    for (int i = tid; i < npar4; i += NTH) {
+      const int v = i >> 6, o = (i & 63) * 4;          // 64 float4 per vector
+      *reinterpret_cast<float4*>(par + v * D + o) = *reinterpret_cast<const float4*>(kprog.par_src[v] + o);
     }
+  }
+  __syncthreads();
+  const int n_ops = sp->n, n_lin = sp->n_lin;
+
+  float cur[4] = {0.f, 0.f, 0.f, 0.f}, sav0[4] = {0.f, 0.f, 0.f, 0.f}, sav1[4] = {0.f, 0.f, 0.f, 0.f};
+  auto publish = [&](int buf) {                        // cur -> bf16 image xs[buf][row][feature]
+    bf16x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; r++) o[r] = (bf16)cur[r];
+    *reinterpret_cast<bf16x4*>(&xs[(buf * 16 + c) * XLD + n0 + q * 4]) = o;
   };
 
-  for (int s = 0; s < prog.n; s++) {
-    const avlen_chain_op op = prog.op[s];
+  // ---- the weight-tile stream: tile t of the program = (Linear step, 64-wide k block); ring stage = t % NS ----
+  // Every thread issues 2 pieces per tile: slot = r*1024 + tid -> feature row slot>>3, 16-byte chunk slot&7.
+  int ld_idx = 0, ld_kt = 0;           // next tile to issue: Linear index / k block   (ld_idx == n_lin: stream exhausted)
+  DevLin ldl = sp->lin[0];
+  int issued = 0, consumed = 0;        // tiles issued / tiles whose data has been waited for
+  auto issue_one = [&]() {             // issue the next tile of the stream, if any
+    if (ld_idx >= n_lin) return;
+    char* stage = ring + (issued % NS) * TILE_BYTES;
+#if !defined(AVLEN_CHAIN_LAB) || AVLEN_CHAIN_LAB != 2
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const int slot = r * NTH + tid, frow = slot >> 3, ch = (slot & 7) ^ ((frow >> 1) & 7);
+      const char* src = ldl.w + ((long)frow * ldl.ld + ld_kt * 64 + ch * 8) * 2;
+      __builtin_amdgcn_global_load_lds((const void*)src,
+          (__attribute__((address_space(3))) void*)(stage + (r * NTH + wave * 64) * 16), 16, 0, 0);
+    }
+#endif
+    issued++;
+    if (++ld_kt == ldl.nkt) { ld_kt = 0; ld_idx++; ldl = sp->lin[ld_idx < n_lin ? ld_idx : 0]; }
+  };
+  issue_one(); issue_one();            // two tiles ahead from the start
+
+  for (int s = 0; s < n_ops; s++) {
+    const DevOp op = sp->op[s];
+#ifdef AVLEN_CHAIN_LAB
+    if (tid == 0 && blockIdx.x == 0) g_chain_stamps[s] = clock64();
+#endif
     switch (op.kind) {
       case AVLEN_CH_LOAD_X16: {                        // bf16 global rows [B][ld] -> xs[buf][.][0:K)
-        __syncthreads();
+        bar();
         const bf16* src = (const bf16*)op.p0;
-        for (int i = tid; i < 16 * (op.k / 8); i += NT) {
-          int rr = i / (op.k / 8), ch = i % (op.k / 8);
+        const int cpr = op.k >> 3;                     // 16-byte chunks per row
+        for (int i = tid; i < 16 * cpr; i += NTH) {
+          int rr = i / cpr, ch = i - rr * cpr;
           int gr = blockIdx.x * 16 + rr;
-          bf16x8 v;
-          if (gr < B) v = *reinterpret_cast<const bf16x8*>(src + (long)gr * op.ld + ch * 8);
-          else for (int e = 0; e < 8; e++) v[e] = (bf16)0.f;
-          *reinterpret_cast<bf16x8*>(&xs[op.buf][rr * XLD + ch * 8]) = v;
+          uint4 v = make_uint4(0, 0, 0, 0);
+          if (gr < B) v = *reinterpret_cast<const uint4*>(src + (long)gr * op.ld + ch * 8);
+          *reinterpret_cast<uint4*>(&xs[(op.buf * 16 + rr) * XLD + ch * 8]) = v;
         }
-        __syncthreads();
+        bar();
         break;
       }
       case AVLEN_CH_LOAD_CUR: {                        // fp32 global [B][ld] (256 features) -> cur (+ bf16 image)
         const float* src = (const float*)op.p0;
-#pragma unroll
-        for (int j = 0; j < J; j++) {
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (rok) v = *reinterpret_cast<const float4*>(src + (long)row * op.ld + n0 + j * 16 + q * 4);
-          cur[j][0] = v.x; cur[j][1] = v.y; cur[j][2] = v.z; cur[j][3] = v.w;
-        }
-        __syncthreads();
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rok) v = *reinterpret_cast<const float4*>(src + (long)row * op.ld + n0 + q * 4);
+        cur[0] = v.x; cur[1] = v.y; cur[2] = v.z; cur[3] = v.w;
+        bar();
         publish(op.buf);
-        __syncthreads();
+        bar();
         break;
       }
-      case AVLEN_CH_LINEAR: {                          // cur = act(W x + b) [+ sav[slot]]; x = xs[buf][.][0:K)
-        const bf16* W = (const bf16*)op.p0;            // [256][ld] bf16, row = output feature
-        const float* bias = (const float*)op.p1;
-        f32x4 acc[J];
+      case AVLEN_CH_LINEAR: {                          // cur = act(W x + b) [+ save slot]; x = xs[buf][.][0:K)
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int nkt = op.k >> 6;
+        const bf16* xrow = &xs[(op.buf * 16 + c) * XLD + q * 8];
+        const int wr = n0 + c;                         // this lane's feature row inside the tile
+        const int wsw = (wr >> 1) & 7;
+        for (int kt = 0; kt < nkt; kt++) {
+          // tile `consumed` has landed once only the pieces of the tiles issued after it are outstanding
+          const int ahead = issued - consumed - 1;
+          if (ahead >= 2) wait_vmcnt<4>(); else if (ahead == 1) wait_vmcnt<2>(); else wait_vmcnt<0>();
+          bar();                                       // everyone's pieces are in LDS; everyone has left the stage reused next
+          const char* stage = ring + (consumed % NS) * TILE_BYTES;
+          consumed++;
+          issue_one();
+#if !defined(AVLEN_CHAIN_LAB) || AVLEN_CHAIN_LAB != 3
 #pragma unroll
-        for (int j = 0; j < J; j++) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const int nks = op.k / 32;
-        const bf16* wrow[J];
-#pragma unroll
-        for (int j = 0; j < J; j++) wrow[j] = W + (long)(n0 + j * 16 + c) * op.ld + q * 8;
-        const bf16* xrow = &xs[op.buf][c * XLD + q * 8];
-        for (int k0 = 0; k0 < nks; k0 += 8) {          // 8 k-steps of weight fragments in flight, then the MFMAs
-          bf16x8 wf[8][J];
-#pragma unroll
-          for (int u = 0; u < 8; u++)
-            if (k0 + u < nks) {
-#pragma unroll
-              for (int j = 0; j < J; j++) wf[u][j] = *reinterpret_cast<const bf16x8*>(wrow[j] + (k0 + u) * 32);
-            }
-#pragma unroll
-          for (int u = 0; u < 8; u++)
-            if (k0 + u < nks) {
-              bf16x8 xf = *reinterpret_cast<const bf16x8*>(xrow + (k0 + u) * 32);
-#pragma unroll
-              for (int j = 0; j < J; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][j], xf, acc[j], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < J; j++) {
-          float4 bv = bias ? *reinterpret_cast<const float4*>(bias + n0 + j * 16 + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-          float b4[4] = {bv.x, bv.y, bv.z, bv.w};
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            float v = acc[j][r] + b4[r];
-            if (op.act == AVLEN_ACT_RELU) v = fmaxf(v, 0.f);
-            if (op.res) v += sav[j][r];
-            cur[j][r] = v;
+          for (int kh = 0; kh < 2; kh++) {
+            bf16x8 wf = *reinterpret_cast<const bf16x8*>(stage + wr * 128 + (((kh * 4 + q) ^ wsw) << 4));
+            bf16x8 xf = *reinterpret_cast<const bf16x8*>(xrow + kt * 64 + kh * 32);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc, 0, 0, 0);
           }
+#else
+          acc[0] += stage[0];
+#endif
         }
-        __syncthreads();                               // every wave has finished reading xs[buf]
-        publish(op.out_buf);
-        __syncthreads();
+        float4 bv = op.par >= 0 ? *reinterpret_cast<const float4*>(par + op.par * D + n0 + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float b4[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          float v = acc[r] + b4[r];
+          if (op.act == AVLEN_ACT_RELU) v = fmaxf(v, 0.f);
+          if (op.res == 1) v += sav0[r];
+          if (op.res == 2) v += sav1[r];
+          cur[r] = v;
+        }
+        if (op.out_buf == op.buf) bar();               // in place: every wave must have finished reading xs[buf]
+        publish(op.out_buf);                           // (the other image was last read before this step's barriers)
+        bar();
         break;
       }
       case AVLEN_CH_LAYERNORM: {                       // cur = LN(cur) * g + b over the 256 features of each row
-        const float* g = (const float*)op.p0; const float* bb = (const float*)op.p1;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < J; j++)
-#pragma unroll
-          for (int r = 0; r < 4; r++) { s1 += cur[j][r]; s2 += cur[j][r] * cur[j][r]; }
+        for (int r = 0; r < 4; r++) { s1 += cur[r]; s2 += cur[r] * cur[r]; }
         s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
         s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-        if (q == 0) { red[wave][c][0] = s1; red[wave][c][1] = s2; }
-        __syncthreads();
+        // partials as [8 float4 slots][16 rows][4 waves]: a row's 16 + 16 partial sums are 8 conflict-free ds_read_b128
+        if (q == 0) { red[(((wave >> 2) * 16 + c) << 2) + (wave & 3)] = s1; red[((((wave >> 2) + 4) * 16 + c) << 2) + (wave & 3)] = s2; }
+        const float4 gv = *reinterpret_cast<const float4*>(par + op.par * D + n0 + q * 4);
+        const float4 bv = *reinterpret_cast<const float4*>(par + (op.par + 1) * D + n0 + q * 4);
+        bar();
         float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-        for (int w = 0; w < NW; w++) { t1 += red[w][c][0]; t2 += red[w][c][1]; }
+        for (int w4 = 0; w4 < NW / 4; w4++) {
+          float4 a = *reinterpret_cast<const float4*>(&red[(w4 * 16 + c) << 2]);
+          float4 b = *reinterpret_cast<const float4*>(&red[((w4 + 4) * 16 + c) << 2]);
+          t1 += (a.x + a.y) + (a.z + a.w); t2 += (b.x + b.y) + (b.z + b.w);
+        }
         const float mean = t1 * (1.f / D);
         const float var = fmaxf(t2 * (1.f / D) - mean * mean, 0.f);
         const float rstd = rsqrtf(var + 1e-5f);
+        float g4[4] = {gv.x, gv.y, gv.z, gv.w}, b4[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
-        for (int j = 0; j < J; j++) {
-          float4 gv = *reinterpret_cast<const float4*>(g + n0 + j * 16 + q * 4);
-          float4 bv = *reinterpret_cast<const float4*>(bb + n0 + j * 16 + q * 4);
-          float g4[4] = {gv.x, gv.y, gv.z, gv.w}, b4[4] = {bv.x, bv.y, bv.z, bv.w};
-#pragma unroll
-          for (int r = 0; r < 4; r++) cur[j][r] = (cur[j][r] - mean) * rstd * g4[r] + b4[r];
-        }
+        for (int r = 0; r < 4; r++) cur[r] = (cur[r] - mean) * rstd * g4[r] + b4[r];
         publish(op.out_buf);                           // xs was last read before the barrier above
-        __syncthreads();
+        bar();                                         // also: everyone has read `red` before the next LayerNorm writes it
         break;
       }
-      case AVLEN_CH_SAVE: {
+      case AVLEN_CH_SAVE: {                            // registers -> save slot `res` (0 | 1)
 #pragma unroll
-        for (int j = 0; j < J; j++)
+        for (int r = 0; r < 4; r++) { if (op.res == 0) sav0[r] = cur[r]; else sav1[r] = cur[r]; }
+        break;
+      }
+      case AVLEN_CH_RECALL: {                          // save slot `res` -> registers and image `out_buf`
 #pragma unroll
-          for (int r = 0; r < 4; r++) sav[j][r] = cur[j][r];
+        for (int r = 0; r < 4; r++) cur[r] = op.res == 0 ? sav0[r] : sav1[r];
+        bar();
+        publish(op.out_buf);
+        bar();
         break;
       }
       case AVLEN_CH_STORE: {                           // cur -> fp32 global [B][ld] and/or bf16 global [B][ld2]
         float* dst = (float*)op.p0; bf16* dst16 = (bf16*)op.p1;
         if (rok) {
+          if (dst) *reinterpret_cast<float4*>(dst + (long)row * op.ld + n0 + q * 4) = make_float4(cur[0], cur[1], cur[2], cur[3]);
+          if (dst16) {
+            bf16x4 o;
 #pragma unroll
-          for (int j = 0; j < J; j++) {
-            if (dst) *reinterpret_cast<float4*>(dst + (long)row * op.ld + n0 + j * 16 + q * 4) =
-                make_float4(cur[j][0], cur[j][1], cur[j][2], cur[j][3]);
-            if (dst16) {
-              bf16x4 o;
-#pragma unroll
-              for (int r = 0; r < 4; r++) o[r] = (bf16)cur[j][r];
-              *reinterpret_cast<bf16x4*>(dst16 + (long)row * op.ld2 + n0 + j * 16 + q * 4) = o;
-            }
+            for (int r = 0; r < 4; r++) o[r] = (bf16)cur[r];
+            *reinterpret_cast<bf16x4*>(dst16 + (long)row * op.ld2 + n0 + q * 4) = o;
           }
         }
         break;
@@ -180,19 +252,43 @@ __global__ __launch_bounds__(1024 / J) void chain_kernel(avlen_chain prog, int B
       default: break;
     }
   }
+#ifdef AVLEN_CHAIN_LAB
+  if (tid == 0 && blockIdx.x == 0) g_chain_stamps[n_ops] = clock64();
+#endif
 }
 
 }  // namespace
 
 int avlen_chain_run(const avlen_chain* prog, int B, hipStream_t stream) {
   if (!prog || prog->n < 1 || prog->n > AVLEN_CHAIN_MAX_OPS || B <= 0) return AVLEN_ERR_ARG;
+  DevProg dp;
+  memset(&dp, 0, sizeof(dp));
+  dp.n = prog->n;
   for (int i = 0; i < prog->n; i++) {
     const avlen_chain_op& o = prog->op[i];
-    if ((o.kind == AVLEN_CH_LINEAR || o.kind == AVLEN_CH_LOAD_X16) && (o.k % 32 || o.k > KMAX || o.ld % 8)) return AVLEN_ERR_ARG;
-    if (o.buf < 0 || o.buf > 2 || o.out_buf < 0 || o.out_buf > 2) return AVLEN_ERR_ARG;
+    if (o.buf < 0 || o.buf >= NIMG || o.out_buf < 0 || o.out_buf >= NIMG) return AVLEN_ERR_ARG;
+    DevOp& d = dp.op[i];
+    d.kind = o.kind; d.k = o.k; d.ld = o.ld; d.ld2 = o.ld2; d.act = o.act; d.res = o.res; d.buf = o.buf; d.out_buf = o.out_buf;
+    d.par = -1; d.p0 = o.p0; d.p1 = o.p1;
+    if (o.kind == AVLEN_CH_LINEAR) {
+      if (o.k % 64 || o.k > KMAX || o.k < 64 || o.ld < o.k || o.ld % 8 || !o.p0 || dp.n_lin >= MAX_LIN) return AVLEN_ERR_ARG;
+      dp.lin[dp.n_lin++] = DevLin{(const char*)o.p0, o.ld, o.k >> 6};
+      if (o.p1) {
+        if (dp.n_par >= MAX_PAR || ((uintptr_t)o.p1 & 15)) return AVLEN_ERR_ARG;
+        d.par = dp.n_par; dp.par_src[dp.n_par++] = (const float*)o.p1;
+      }
+    } else if (o.kind == AVLEN_CH_LAYERNORM) {
+      if (!o.p0 || !o.p1 || dp.n_par + 2 > MAX_PAR || (((uintptr_t)o.p0 | (uintptr_t)o.p1) & 15)) return AVLEN_ERR_ARG;
+      d.par = dp.n_par; dp.par_src[dp.n_par++] = (const float*)o.p0; dp.par_src[dp.n_par++] = (const float*)o.p1;
+    } else if (o.kind == AVLEN_CH_LOAD_X16) {
+      if (o.k % 8 || o.k > KMAX || o.ld % 8) return AVLEN_ERR_ARG;
+    }
   }
-  const int blocks = ceil_div(B, 16);
-  if (blocks <= 64) hipLaunchKernelGGL(chain_kernel<1>, dim3(blocks), dim3(1024), 0, stream, *prog, B);
-  else hipLaunchKernelGGL(chain_kernel<4>, dim3(blocks), dim3(256), 0, stream, *prog, B);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(chain_kernel, dim3(ceil_div(B, 16)), dim3(NTH), LDS_BYTES, stream, dp, B);
   return avlen_launch_status();
 }

@@ -44,10 +44,11 @@ bool avlen_dconv_supported(int W, int Cin, int Cout, int KH, int KW, int stride,
 // ---- fused row-batch chain (chain.hip): a program of d=256 Linear / LayerNorm steps run by one kernel ----
 #define AVLEN_CH_LOAD_X16 1   /* p0: bf16 [B][ld] rows -> LDS image `buf`, k columns (multiple of 32) */
 #define AVLEN_CH_LOAD_CUR 2   /* p0: fp32 [B][ld] (256 features) -> registers, image -> `buf` */
-#define AVLEN_CH_LINEAR 3     /* p0: bf16 W[256][ld], p1: fp32 bias[256] or null; input image `buf` (k columns);
-                                 act; res != 0 adds the save slot; result -> registers and image `out_buf` */
+#define AVLEN_CH_LINEAR 3     /* p0: bf16 W[256][ld], p1: fp32 bias[256] or null; input image `buf` (k columns, k % 64 == 0);
+                                 act; res = 1 | 2 adds save slot 0 | 1; result -> registers and image `out_buf` */
 #define AVLEN_CH_LAYERNORM 4  /* p0: gamma, p1: beta (eps 1e-5); result -> registers and image `out_buf` */
-#define AVLEN_CH_SAVE 5       /* registers -> save slot */
+#define AVLEN_CH_SAVE 5       /* registers -> save slot `res` (0 | 1) */
+#define AVLEN_CH_RECALL 7     /* save slot `res` -> registers and image `out_buf` */
 #define AVLEN_CH_STORE 6      /* p0: fp32 [B][ld] or null, p1: bf16 [B][ld2] or null */
 #define AVLEN_CHAIN_MAX_OPS 40
 typedef struct { int kind, k, ld, ld2, act, res, buf, out_buf; const void* p0; const void* p1; } avlen_chain_op;

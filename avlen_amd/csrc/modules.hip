@@ -304,10 +304,11 @@ struct ChainB {
     auto& o = next(AVLEN_CH_LINEAR);
     o.p0 = (const char*)L.w16 + (size_t)r0 * L.ld16 * 2; o.p1 = L.b ? L.b + r0 : nullptr;
     o.k = L.ld16; o.ld = L.ld16; o.act = act; o.res = res; o.buf = buf; o.out_buf = out_buf;
-    if (!L.w16 || (L.ld16 % 32) || L.ld16 > 512 || L.out_f < r0 + 256) ok = false;
+    if (!L.w16 || (L.ld16 % 64) || L.ld16 > 320 || L.out_f < r0 + 256) ok = false;
   }
   void ln(const avlen_affine& a, int out_buf) { auto& o = next(AVLEN_CH_LAYERNORM); o.p0 = a.g; o.p1 = a.b; o.out_buf = out_buf; }
-  void save() { next(AVLEN_CH_SAVE); }
+  void save(int slot = 0) { auto& o = next(AVLEN_CH_SAVE); o.res = slot; }
+  void recall(int slot, int out_buf) { auto& o = next(AVLEN_CH_RECALL); o.res = slot; o.out_buf = out_buf; }
   void store(float* y, int ld, bf16* y16, int ld2) { auto& o = next(AVLEN_CH_STORE); o.p0 = y; o.ld = ld; o.p1 = y16; o.ld2 = ld2; }
 };
 
@@ -1004,12 +1005,13 @@ int smt_fwd_infer_bf16(const avlen_smt* p, const float* x, const float* memory, 
     ch.linear(e.lin1, 0, AVLEN_ACT_RELU, 0, 0, 1);
     ch.linear(e.lin2, 0, 0, 1, 1, 0);
     ch.ln(e.norm2, 0); ch.ln(tr.enc_norm, 0);                        // memory token
-    ch.linear(q.cross_attn.in_proj, 2 * d, 0, 0, 0, 2);              // cross attention output, parked in image 2
+    ch.linear(q.cross_attn.in_proj, 2 * d, 0, 0, 0, 1); ch.save(1);  // cross attention output, parked in save slot 1
     ch.load_cur(goal, d, 0); ch.save();
     ch.linear(q.self_attn.in_proj, 2 * d, 0, 0, 0, 1);
     ch.linear(q.self_attn.out_proj, 0, 0, 1, 1, 0);
     ch.ln(q.norm1, 0); ch.save();                                    // Y1
-    ch.linear(q.cross_attn.out_proj, 0, 0, 1, 2, 0);
+    ch.recall(1, 1);
+    ch.linear(q.cross_attn.out_proj, 0, 0, 1, 1, 0);
     ch.ln(q.norm2, 0); ch.save();                                    // Y2
     ch.linear(q.lin1, 0, AVLEN_ACT_RELU, 0, 0, 1);
     ch.linear(q.lin2, 0, 0, 1, 1, 0);
