@@ -84,8 +84,13 @@ class Dialog(C.Structure):
     _fields_ = [("fus0", Linear), ("fus2", Linear), ("tr", Transformer), ("pe", f32p), ("pe_len", C.c_int)]
 
 
+class LnFold(C.Structure):
+    _fields_ = [("w16f", vp), ("s", f32p), ("c", f32p)]
+
+
 class ClipBlock(C.Structure):
-    _fields_ = [("ln1", Affine), ("ln2", Affine), ("attn", Mha), ("fc", Linear), ("proj", Linear)]
+    _fields_ = [("ln1", Affine), ("ln2", Affine), ("attn", Mha), ("fc", Linear), ("proj", Linear), ("attn_fold", LnFold),
+                ("fc_fold", LnFold)]
 
 
 class ClipText(C.Structure):
@@ -158,6 +163,7 @@ SIGNATURES = {
     "avlen_minibatch_gather": (i32, [vp, vp, vp, i32, i32, i32, sz, i32, vp]),
     "avlen_copy_rows": (i32, [vp, i32, vp, i32, i32, i32, vp]),
     "avlen_multi_copy": (i32, [vp, vp, vp, i32, vp]),
+    "avlen_ln_fold_weights": (i32, [vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, vp]),
     "avlen_build_info": (C.c_char_p, []),
 }
 

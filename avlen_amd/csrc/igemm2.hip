@@ -42,6 +42,10 @@ struct G2 {
   int conv, H, W, Cin, cin_log2, OH, OW, KH, KW, kw_magic, stride, pad;
   int splitk, ksteps_per_split;
   int vec4;                   // N, ldc32, ldc16, ldr all multiples of 4: 16-byte / 8-byte epilogue accesses
+  // LayerNorm folded into the GEMM (A = raw bf16 rows x, W = bf16(W * gamma)): C = rstd_m * (acc - mean_m * ln_s[n]) + bias[n]
+  // with (sum, sum of squares) of row m in ln_stats[m][2] and mean/rstd over K columns; NULL -> plain epilogue
+  const float* ln_stats; const float* ln_s;
+  float* rowstats;            // optional output: rowstats[m][2] += (sum, sum of squares) of the final C row (N-tile partials)
   float* slab;
   const int* M_dev;           // optional: the live row count (<= M) is read from device memory (ragged batches)
   float* stats; int ohw;      // optional GroupNorm statistics: stats[sample][0|1][N] += sum / sum of squares of C
@@ -295,6 +299,27 @@ __global__ __launch_bounds__(NTH) void g2_kernel(G2 pp) {
     int col = n0 + wn * WTN + j * 16 + q * 4;
     bv[j] = p.bias ? ld4(p.bias, col, col, p.N, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  if (p.ln_stats) {            // folded LayerNorm: acc <- rstd * (acc - mean * s)
+    float4 sv[NI];
+#pragma unroll
+    for (int j = 0; j < NI; j++) {
+      int col = n0 + wn * WTN + j * 16 + q * 4;
+      sv[j] = ld4(p.ln_s, col, col, p.N, vec);
+    }
+    const float inv_k = 1.f / (float)p.K;
+#pragma unroll
+    for (int i = 0; i < MI; i++) {
+      int row = m0 + wm * WTM + i * 16 + r16;
+      float2 st = row < p.M ? *reinterpret_cast<const float2*>(p.ln_stats + (long)row * 2) : make_float2(0.f, 0.f);
+      const float mean = st.x * inv_k;
+      const float rstd = rsqrtf(fmaxf(st.y * inv_k - mean * mean, 0.f) + 1e-5f);
+#pragma unroll
+      for (int j = 0; j < NI; j++) {
+        acc[i][j][0] = rstd * (acc[i][j][0] - mean * sv[j].x); acc[i][j][1] = rstd * (acc[i][j][1] - mean * sv[j].y);
+        acc[i][j][2] = rstd * (acc[i][j][2] - mean * sv[j].z); acc[i][j][3] = rstd * (acc[i][j][3] - mean * sv[j].w);
+      }
+    }
+  }
   if (p.residual) {
     float4 rv[MI][NI];
 #pragma unroll
@@ -320,6 +345,22 @@ __global__ __launch_bounds__(NTH) void g2_kernel(G2 pp) {
         acc[i][j][0] = act2(acc[i][j][0] + bv[j].x, p.act); acc[i][j][1] = act2(acc[i][j][1] + bv[j].y, p.act);
         acc[i][j][2] = act2(acc[i][j][2] + bv[j].z, p.act); acc[i][j][3] = act2(acc[i][j][3] + bv[j].w, p.act);
       }
+  }
+  if (p.rowstats) {            // per-row (sum, sum of squares) of the final values: the next layer's LayerNorm statistics
+#pragma unroll
+    for (int i = 0; i < MI; i++) {
+      int row = m0 + wm * WTM + i * 16 + r16;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < NI; j++) {
+        int col = n0 + wn * WTN + j * 16 + q * 4;
+#pragma unroll
+        for (int r = 0; r < 4; r++) { float v = col + r < p.N ? acc[i][j][r] : 0.f; s1 += v; s2 += v * v; }
+      }
+      s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+      s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+      if (q == 0 && row < p.M) { atomicAdd(&p.rowstats[(long)row * 2], s1); atomicAdd(&p.rowstats[(long)row * 2 + 1], s2); }
+    }
   }
   if (LAB(4)) { if (acc[0][0][0] == 123.456f) p.C32[0] = 1.f; return; }
 #pragma unroll
@@ -418,6 +459,29 @@ __global__ void pack_fc_bf16_kernel(const float* __restrict__ w, bf16* __restric
   o[idx] = (bf16)w[((long)oc * C + c) * HW + pp];
 }
 
+// LayerNorm folding (derived data for avlen_gemm_bf16_ln): w16f[n][k] = bf16(W[n][k] * gamma[k]),
+// s[n] = sum_k float(w16f[n][k]), c[n] = bias[n] + sum_k beta[k] * W[n][k].  One block per output row.
+__global__ __launch_bounds__(256) void ln_fold_kernel(const float* __restrict__ W, const float* __restrict__ bias,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      bf16* __restrict__ w16f, int ld16, float* __restrict__ s,
+                                                      float* __restrict__ c, int K) {
+  __shared__ float sh[16];
+  const int n = blockIdx.x;
+  float sa = 0.f, ca = 0.f;
+  for (int k = threadIdx.x; k < ld16; k += 256) {
+    bf16 wf = (bf16)0.f;
+    if (k < K) {
+      const float w = W[(long)n * K + k];
+      wf = (bf16)(w * gamma[k]);
+      sa += (float)wf; ca += beta[k] * w;
+    }
+    w16f[(long)n * ld16 + k] = wf;
+  }
+  sa = block_sum(sa, sh);
+  ca = block_sum(ca, sh);
+  if (threadIdx.x == 0) { s[n] = sa; c[n] = ca + (bias ? bias[n] : 0.f); }
+}
+
 template <int BM, int BN, int WM, int WN, int NS, int NTH>
 int launch_ns(const G2& p, int m_tiles, int n_tiles, hipStream_t st) {
   size_t lds = (size_t)NS * (BM * 128 + (BN * 8 >= NTH ? BN * 128 : NTH * 16));
@@ -453,7 +517,7 @@ int run_g2(G2 p, void* ws, size_t ws_bytes, hipStream_t st) {
     p.g[0] = G2Grp{p.A, p.B, p.C32, p.C16, p.bias, p.residual, p.stats};
   }
   if (p.groups > MAXG) return AVLEN_ERR_ARG;
-  p.vec4 = !(p.N & 3) && !(p.ldc32 & 3) && !(p.ldc16 & 3) && !(p.ldr & 3) && aligned_to(ws, 16);
+  p.vec4 = !(p.N & 3) && !(p.ldc32 & 3) && !(p.ldc16 & 3) && !(p.ldr & 3) && aligned_to(ws, 16) && aligned_to(p.ln_s, 16);
   for (int g = 0; g < p.groups; g++)
     p.vec4 = p.vec4 && aligned_to(p.g[g].C32, 16) && aligned_to(p.g[g].C16, 8) && aligned_to(p.g[g].bias, 16) &&
              aligned_to(p.g[g].residual, 16);
@@ -488,7 +552,7 @@ int run_g2(G2 p, void* ws, size_t ws_bytes, hipStream_t st) {
   int nk = ceil_div(p.K, BK);
   long tiles = (long)m_tiles * n_tiles * p.groups;
   int split = 1;
-  if (tiles < 128 && nk >= 8 && !has_stats) {
+  if (tiles < 128 && nk >= 8 && !has_stats && !p.ln_stats && !p.rowstats) {
     long a = nk / 4, b = (256 + tiles - 1) / tiles;
     split = (int)(a < b ? a : b);
     if (split < 1) split = 1;
@@ -536,6 +600,13 @@ int run_g2(G2 p, void* ws, size_t ws_bytes, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" int avlen_ln_fold_weights(const float* W, const float* bias, const float* gamma, const float* beta, void* w16f,
+                                     int ld16, float* s, float* c, int N, int K, hipStream_t stream) {
+  if (!W || !gamma || !beta || !w16f || !s || !c || N <= 0 || K <= 0 || ld16 < K || (ld16 & 7)) return AVLEN_ERR_ARG;
+  hipLaunchKernelGGL(ln_fold_kernel, dim3(N), dim3(256), 0, stream, W, bias, gamma, beta, (bf16*)w16f, ld16, s, c, K);
+  return avlen_launch_status();
+}
 
 extern "C" size_t avlen_gemm_bf16_workspace_bytes(int M, int N) { return (size_t)32 * M * N * sizeof(float) + 256; }
 
@@ -601,6 +672,19 @@ int avlen_gemm_bf16_grouped(const void* const* A, int lda, const void* const* B,
   for (int g = 0; g < groups; g++)
     p.g[g] = G2Grp{(const bf16*)A[g], (const bf16*)B[g], C32[g], nullptr, bias ? bias[g] : nullptr, nullptr, nullptr};
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc32 = ldc32; p.act = act;
+  return run_g2(p, ws, ws_bytes, stream);
+}
+
+// avlen_gemm_bf16_dyn + LayerNorm folding / row statistics (see G2::ln_stats, G2::rowstats).
+int avlen_gemm_bf16_ln(const void* A, int lda, const void* B, int ldb, float* C32, int ldc32, void* C16, int ldc16,
+                       const float* bias, const float* residual, int ldr, int M, const int* M_dev, int N, int K, int act,
+                       const float* ln_stats, const float* ln_s, float* rowstats, void* ws, size_t ws_bytes,
+                       hipStream_t stream) {
+  if (ln_stats && !ln_s) return AVLEN_ERR_ARG;
+  G2 p = {};
+  p.A = (const bf16*)A; p.B = (const bf16*)B; p.C32 = C32; p.C16 = (bf16*)C16; p.bias = bias; p.residual = residual;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc32 = ldc32; p.ldc16 = ldc16; p.ldr = ldr; p.act = act;
+  p.M_dev = M_dev; p.ln_stats = ln_stats; p.ln_s = ln_s; p.rowstats = rowstats;
   return run_g2(p, ws, ws_bytes, stream);
 }
 

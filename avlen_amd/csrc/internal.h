@@ -32,6 +32,10 @@ int avlen_layernorm_fwd16_dyn(const float* x, const float* residual, const float
 int avlen_attention_fwd16_seg(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                               void* O16, int ldo16, const float* key_mask, float* lse, int B, int H, int Sq, int Sk, int D,
                               int causal, float scale, const int* seg_off, hipStream_t stream);
+int avlen_gemm_bf16_ln(const void* A, int lda, const void* B, int ldb, float* C32, int ldc32, void* C16, int ldc16,
+                       const float* bias, const float* residual, int ldr, int M, const int* M_dev, int N, int K, int act,
+                       const float* ln_stats, const float* ln_s, float* rowstats, void* ws, size_t ws_bytes,
+                       hipStream_t stream);
 int avlen_attention_qkv16(const void* QKV16, int ld, void* O16, int ldo16, int B, int H, int S, int causal, float scale,
                           const int* seg_off, hipStream_t stream);
 int avlen_gemm_bf16_dyn(const void* A, int lda, const void* B, int ldb, float* C32, int ldc32, void* C16, int ldc16,

@@ -207,7 +207,9 @@ __global__ void clip_segments_kernel(const int64_t* __restrict__ tokens, int* __
 }
 __global__ void clip_embed_ragged_kernel(const int64_t* __restrict__ tokens, const float* __restrict__ tok_emb,
                                          const float* __restrict__ pos_emb, float* __restrict__ x, const int* __restrict__ seg,
-                                         const int* __restrict__ rowmap, int B, int ctx, int width, int vocab) {
+                                         const int* __restrict__ rowmap, int B, int ctx, int width, int vocab,
+                                         __bf16* __restrict__ x16, float* __restrict__ stats) {
+  __shared__ float sh[16];
   const int row = blockIdx.x;
   if (row >= seg[B]) return;
   const int src = rowmap[row], t = src % ctx;
@@ -216,9 +218,20 @@ __global__ void clip_embed_ragged_kernel(const int64_t* __restrict__ tokens, con
   const float4* e = reinterpret_cast<const float4*>(tok_emb + id * width);
   const float4* p = reinterpret_cast<const float4*>(pos_emb + (long)t * width);
   float4* o = reinterpret_cast<float4*>(x + (long)row * width);
+  float s1 = 0.f, s2 = 0.f;
   for (int i = threadIdx.x; i < width / 4; i += blockDim.x) {
     float4 a = e[i], c = p[i];
-    o[i] = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
+    float4 v = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
+    o[i] = v;
+    if (x16) {           // bf16 copy + LayerNorm statistics of the row (LayerNorm folded into the first projection)
+      __bf16* d = x16 + (long)row * width + i * 4;
+      d[0] = (__bf16)v.x; d[1] = (__bf16)v.y; d[2] = (__bf16)v.z; d[3] = (__bf16)v.w;
+      s1 += (v.x + v.y) + (v.z + v.w); s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+  }
+  if (stats) {
+    s1 = block_sum(s1, sh); s2 = block_sum(s2, sh);
+    if (threadIdx.x == 0) { stats[(long)row * 2] = s1; stats[(long)row * 2 + 1] = s2; }
   }
 }
 __global__ void clip_gather_last_kernel(const float* __restrict__ x, float* __restrict__ out, const int* __restrict__ seg,
@@ -1224,14 +1237,41 @@ extern "C" int avlen_clip_text_fwd(const avlen_clip_text* p, const int64_t* toke
     int* rowmap = (int*)QKV;                          // [R]   (consumed by the embedding, before QKV is written)
     const int* live = seg + B;
     hipLaunchKernelGGL(clip_segments_kernel, dim3(1), dim3(1024), 0, st, tokens, seg, rowmap, B, ctx);
+    bool fold = D == 64 && ctx <= 96;                 // LayerNorms folded into the projections that follow them
+    for (int l = 0; l < p->layers && fold; l++)
+      fold = p->block[l].attn_fold.w16f && p->block[l].fc_fold.w16f && p->block[l].attn.in_proj.ld16 == wd;
+    // fold mode: Hn16 holds the raw residual stream in bf16, the rest of Hn the per-layer row statistics [2*layers][R][2]
+    float* stats = (float*)((char*)Hn + (size_t)R * wd * 2);
+    const size_t st_stride = (size_t)R * 2;
+    fold = fold && (size_t)wd * 2 >= (size_t)16 * p->layers;
+    { static int en = -1; if (en < 0) { const char* e = getenv("AVLEN_CLIP_FOLD"); en = e ? atoi(e) : 1; } fold = fold && en; }
+    if (fold) (void)hipMemsetAsync(stats + st_stride, 0, (2 * (size_t)p->layers - 1) * st_stride * sizeof(float), st);
     hipLaunchKernelGGL(clip_embed_ragged_kernel, dim3((unsigned)R), dim3(128), 0, st, tokens, p->tok_emb, p->pos_emb, X, seg,
-                       rowmap, B, ctx, wd, p->vocab);
+                       rowmap, B, ctx, wd, p->vocab, fold ? Hn16 : (bf16*)nullptr, fold ? stats : (float*)nullptr);
     TRY(avlen_launch_status());
     auto lin = [&](const avlen_linear& L, const bf16* X16, int ldx, float* Y32, int ld32, bf16* Y16, int ld16, int act,
                    const float* res) {
       return avlen_gemm_bf16_dyn(X16, ldx, L.w16, L.ld16, Y32, ld32, Y16, ld16, L.b, res, ld32, (int)R, live, L.out_f, L.ld16,
                                  act, c.gws, c.gws_bytes, c.st);
     };
+    if (fold) {
+      // per layer: 4 GEMMs + attention, no LayerNorm launch: the out_proj / c_proj epilogues emit the new residual
+      // stream in fp32 + bf16 and its row statistics; in_proj / c_fc apply the normalisation in their epilogue
+      for (int l = 0; l < p->layers; l++) {
+        const avlen_clip_block& b = p->block[l];
+        float* st1 = stats + (size_t)(2 * l) * st_stride; float* st2 = st1 + st_stride;
+        float* st_next = l + 1 < p->layers ? st2 + st_stride : nullptr;
+        TRY(avlen_gemm_bf16_ln(Hn16, wd, b.attn_fold.w16f, wd, nullptr, 0, QKV, 3 * wd, b.attn_fold.c, nullptr, 0, (int)R, live,
+                               3 * wd, wd, 0, st1, b.attn_fold.s, nullptr, c.gws, c.gws_bytes, st));
+        TRY(avlen_attention_qkv16(QKV, 3 * wd, AO16, wd, B, H, ctx, 1, scale, seg, st));
+        TRY(avlen_gemm_bf16_ln(AO16, wd, b.attn.out_proj.w16, b.attn.out_proj.ld16, X, wd, Hn16, wd, b.attn.out_proj.b, X, wd,
+                               (int)R, live, wd, b.attn.out_proj.ld16, 0, nullptr, nullptr, st2, c.gws, c.gws_bytes, st));
+        TRY(avlen_gemm_bf16_ln(Hn16, wd, b.fc_fold.w16f, wd, nullptr, 0, F16, b.fc.out_f, b.fc_fold.c, nullptr, 0, (int)R, live,
+                               b.fc.out_f, wd, AVLEN_ACT_QUICKGELU, st2, b.fc_fold.s, nullptr, c.gws, c.gws_bytes, st));
+        TRY(avlen_gemm_bf16_ln(F16, b.fc.out_f, b.proj.w16, b.proj.ld16, X, wd, Hn16, wd, b.proj.b, X, wd, (int)R, live, wd,
+                               b.proj.ld16, 0, nullptr, nullptr, st_next, c.gws, c.gws_bytes, st));
+      }
+    } else
     for (int l = 0; l < p->layers; l++) {
       const avlen_clip_block& b = p->block[l];
       TRY(avlen_layernorm_fwd16_dyn(X, nullptr, b.ln1.g, b.ln1.b, nullptr, Hn16, nullptr, nullptr, (int)R, live, wd, 1e-5f, st));

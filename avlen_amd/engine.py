@@ -133,10 +133,24 @@ class Packed:
         v.w16, v.ld16 = P(buf16), C_ * HW
         return v
 
+    def ln_fold(self, lin_w, lin_b, ln):
+        """LayerNorm `ln` folded into the Linear (lin_w, lin_b) that follows it (avlen_ln_fold_weights)."""
+        N_, K = lin_w.shape
+        w16f = torch.empty(N_, K, dtype=torch.bfloat16, device=self.device)
+        s = torch.empty(N_, dtype=torch.float32, device=self.device)
+        c = torch.empty(N_, dtype=torch.float32, device=self.device)
+        self.bufs += [w16f, s, c]
+        self.jobs.append(("fold", lin_w, (lin_b, ln.weight, ln.bias, s, c), w16f, (N_, K), 0))
+        return L.LnFold(P(w16f), P(s), P(c))
+
     def refresh(self):
         st = L.stream()
         for kind, w, buf, buf16, dims, c16 in self.jobs:
-            if kind == "conv":
+            if kind == "fold":
+                b, g, be, s, c = buf
+                L.call("avlen_ln_fold_weights", P(w), P(b) if b is not None else None, P(g), P(be), P(buf16), dims[1], P(s),
+                       P(c), dims[0], dims[1], st)
+            elif kind == "conv":
                 L.call("avlen_pack_conv_weight", P(w), P(buf), *dims, st)
                 L.call("avlen_pack_conv_weight_bf16", P(w), P(buf16), *dims, c16, st)
             else:
@@ -213,7 +227,7 @@ def dialog_view(enc, flat=None):
     return s
 
 
-def clip_view(clip, flat=None):
+def clip_view(clip, flat=None, packed=None):
     s = L.ClipText()
     s.tok_emb, s.pos_emb = P(clip.token_embedding.weight), P(clip.positional_embedding)
     for i, blk in enumerate(clip.transformer.resblocks):
@@ -222,6 +236,9 @@ def clip_view(clip, flat=None):
         b.attn = mha_view(blk.attn, flat)
         b.fc = linear_view(blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, flat)
         b.proj = linear_view(blk.mlp.c_proj.weight, blk.mlp.c_proj.bias, flat)
+        if packed is not None and blk.attn.in_proj_weight.shape[1] % 8 == 0:
+            b.attn_fold = packed.ln_fold(blk.attn.in_proj_weight, blk.attn.in_proj_bias, blk.ln_1)
+            b.fc_fold = packed.ln_fold(blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, blk.ln_2)
     s.ln_final = affine_view(clip.ln_final)
     s.text_proj = P(clip.text_projection)
     s.vocab, s.ctx = clip.vocab_size, clip.context_length

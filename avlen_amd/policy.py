@@ -674,7 +674,7 @@ class AudioNavDialogNet(_SMTBase):
 
     def build_views(self, eng, packed):
         super().build_views(eng, packed)
-        eng["clip"] = E.clip_view(self.clip, eng["flat"])
+        eng["clip"] = E.clip_view(self.clip, eng["flat"], packed)
         eng["dialog_layer"] = E.linear_view(self.dialog_layer.weight, self.dialog_layer.bias, eng["flat"])
         eng["dialog"] = E.dialog_view(self.dialog_state_encoder, eng["flat"])
 

@@ -55,7 +55,11 @@ typedef struct { avlen_enc_layer enc; avlen_affine enc_norm; avlen_dec_layer dec
 typedef struct { avlen_linear pose, fus0, fus2; avlen_transformer tr; } avlen_smt;
 /* DialogStateEncoder (dialog_state_encoder.py:42-99): fusion MLP(512->256->256), transformer, pe[100][256]. */
 typedef struct { avlen_linear fus0, fus2; avlen_transformer tr; float* pe; int pe_len; } avlen_dialog;
-typedef struct { avlen_affine ln1, ln2; avlen_mha attn; avlen_linear fc, proj; } avlen_clip_block;
+/* LayerNorm folded into the following Linear (derived data, bf16 fast path): LN(x) W^T + b == rstd * (x W'^T - mean * s) + c
+ * with W' = W * gamma (per input column), s[n] = sum_k W'[n][k], c[n] = b[n] + sum_k beta[k] W[n][k]; built by
+ * avlen_ln_fold_weights.  w16f NULL -> the LayerNorm runs as its own kernel. */
+typedef struct { void* w16f; float* s; float* c; } avlen_ln_fold;
+typedef struct { avlen_affine ln1, ln2; avlen_mha attn; avlen_linear fc, proj; avlen_ln_fold attn_fold, fc_fold; } avlen_clip_block;
 /* CLIP ViT-B/32 text tower (third party; call site policy.py:847-849). text_proj is [width][out]. */
 typedef struct { float* tok_emb; float* pos_emb; avlen_clip_block block[12]; avlen_affine ln_final;
                  float* text_proj; int vocab, ctx, width, heads, layers, out_dim; } avlen_clip_text;
@@ -95,6 +99,11 @@ size_t avlen_gemm_bf16_workspace_bytes(int M, int N);
 int avlen_conv2d_nhwc_bf16(const void* X, const void* Wp, const float* bias, const float* residual, float* Y32,
                            void* Y16, float* gn_stats, int B, int H, int W, int Cin, int Cout, int KH, int KW,
                            int stride, int pad, int act, void* ws, size_t ws_bytes, avlen_stream_t stream);
+/* Builds an avlen_ln_fold from a Linear (W fp32 [N][K], bias or NULL) and the LayerNorm (gamma, beta) in front of it;
+ * w16f rows are ld16 apart (>= K, multiple of 8, padding zero).  CLIP residual blocks: ln_1 -> attn.in_proj,
+ * ln_2 -> mlp.c_fc (third party CLIP, call site policy.py:847-849). */
+int avlen_ln_fold_weights(const float* W, const float* bias, const float* gamma, const float* beta, void* w16f, int ld16,
+                          float* s, float* c, int N, int K, avlen_stream_t stream);
 /* Direct stride-1 "same" convolution for the small-channel tower stages (LDS halo tile, register-resident weights):
  * (Cin,Cout,W,K) in {(16,16,64,3), (32,32,32,3), (8,16,64,7)}; X/Y NHWC bf16; optional fused GroupNorm statistics. */
 int avlen_conv_direct_bf16(const void* X, const void* Wp, void* Y16, float* gn_stats, int B, int W, int Cin, int Cout,
