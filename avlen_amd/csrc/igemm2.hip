@@ -84,7 +84,7 @@ __device__ __forceinline__ float4 ld4(const float* base, long off, int col, int 
 // then issue their share of the staging loads, waves 4-7 issue first and multiply after -- so that on every SIMD one wave's
 // MFMAs run under the other wave's global_load_lds issue (a 1 KiB piece holds its wave for ~60-100 cycles; measured on the
 // 4-wave kernel the two costs simply add: tools/gemm_lab.hip).
-template <int BM, int BN, int WM, int WN, int NS, int NTH>
+template <int BM, int BN, int WM, int WN, int NS, int NTH, bool CONV>
 __global__ __launch_bounds__(NTH) void g2_kernel(G2 pp) {
   G2 p = pp;
   {
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(NTH) void g2_kernel(G2 pp) {
     a_sw[r] = ((slot & 7) ^ ((row >> 1) & 7)) * 8;           // logical k offset (elements) of this lane's chunk
     int m = m0 + row;
     a_ok[r] = m < p.M;
-    if (p.conv) {
+    if (CONV) {
       int ohw = p.OH * p.OW;
       int mm = a_ok[r] ? m : 0;
       int b = mm / ohw, rr = mm - b * ohw;
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(NTH) void g2_kernel(G2 pp) {
     // and, for convolutions, the tap decode -- is computed once per K-step and shared by the A_ROUNDS gathers
     const int ka = k0 + a_sw[0];
     int ky = 0, kx = 0, ci = 0;
-    if (p.conv) {
+    if (CONV) {
       int tap = ka >> p.cin_log2;
       ci = ka & (p.Cin - 1);
       ky = (tap * p.kw_magic) >> 16; kx = tap - ky * p.KW;
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(NTH) void g2_kernel(G2 pp) {
 #pragma unroll
     for (int r = 0; r < A_ROUNDS; r++) {
       const char* src = zero;
-      if (p.conv) {
+      if (CONV) {
         int iy = a_iy0[r] + ky, ix = a_ix0[r] + kx;
         if (a_ok[r] && k_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
           src = a_src[r] + (((long)iy * p.W + ix) * p.Cin + ci) * 2;
@@ -482,17 +482,23 @@ __global__ __launch_bounds__(256) void ln_fold_kernel(const float* __restrict__ 
   if (threadIdx.x == 0) { s[n] = sa; c[n] = ca + (bias ? bias[n] : 0.f); }
 }
 
-template <int BM, int BN, int WM, int WN, int NS, int NTH>
-int launch_ns(const G2& p, int m_tiles, int n_tiles, hipStream_t st) {
+template <int BM, int BN, int WM, int WN, int NS, int NTH, bool CONV>
+int launch_cv(const G2& p, int m_tiles, int n_tiles, hipStream_t st) {
   size_t lds = (size_t)NS * (BM * 128 + (BN * 8 >= NTH ? BN * 128 : NTH * 16));
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&g2_kernel<BM, BN, WM, WN, NS, NTH>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&g2_kernel<BM, BN, WM, WN, NS, NTH, CONV>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((g2_kernel<BM, BN, WM, WN, NS, NTH>), dim3(m_tiles * n_tiles, p.groups, p.splitk), dim3(NTH), lds, st, p);
+  hipLaunchKernelGGL((g2_kernel<BM, BN, WM, WN, NS, NTH, CONV>), dim3(m_tiles * n_tiles, p.groups, p.splitk), dim3(NTH), lds, st, p);
   return avlen_launch_status();
+}
+// the implicit-GEMM gather (tap decode, bounds tests) is compiled out of the plain-GEMM instances
+template <int BM, int BN, int WM, int WN, int NS, int NTH>
+int launch_ns(const G2& p, int m_tiles, int n_tiles, hipStream_t st) {
+  return p.conv ? launch_cv<BM, BN, WM, WN, NS, NTH, true>(p, m_tiles, n_tiles, st)
+                : launch_cv<BM, BN, WM, WN, NS, NTH, false>(p, m_tiles, n_tiles, st);
 }
 
 // 4-wave tiles: NS = 4 (deep prefetch, one block per CU) when the grid cannot put 2+ blocks on every CU, else NS = 2.
