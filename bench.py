@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--envs", type=int, default=64)
     ap.add_argument("--rollout", type=int, default=150)
@@ -42,7 +42,7 @@ def parse():
 
 def kernel_roofline(prec_name):
     """Roofline of the DOMINANT kernel by GPU time in the rollout (profiles/r01_rocprof_summary.md):
-    g2_kernel<64,128,2,2,4>, the bf16 MFMA GEMM (global_load_lds staging, 4-stage LDS ring) on its heaviest call site, the
+    g2_kernel<64,128,2,4,NS,512>, the bf16 MFMA GEMM (8-wave ping-pong tile, global_load_lds staging) on its heaviest call site, the
     CLIP text MLP down-projection of one rollout step on the ragged batch (M = 2464 live rows, N = 512, K = 2048, fp32
     residual epilogue).  `achieved` = 2*M*N*K / duration measured live with HIP events on the launch stream; `peak` = dense
     bf16 MFMA; `traffic` = HBM bytes per launch from the rocprofv3 PMC passes (profiles/r01_pmc_traffic.json: 2 x FETCH_SIZE +
@@ -61,7 +61,7 @@ def kernel_roofline(prec_name):
     gw, cw = rp.gemm_work(), rp.conv_work()
     tf = gw["flops"] / sg / 1e12
     gb = cw["bytes"] / sc / 1e9
-    return {"bound": "mfma", "kernel": "g2_kernel<64,128,2,2,4> bf16 glds GEMM (CLIP c_proj, ragged M=2464 N=512 K=2048)",
+    return {"bound": "mfma", "kernel": "g2_kernel<64,128,2,4,4,512> bf16 glds GEMM (CLIP c_proj, ragged M=2464 N=512 K=2048)",
             "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
             "traffic": pmc.get("gemm", {}).get("traffic_bytes"), "algorithmic_flops": gw["flops"],
             "algorithmic_bytes": gw["bytes"], "us_per_launch": round(sg * 1e6, 2),

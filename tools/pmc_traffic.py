@@ -1,0 +1,39 @@
+"""Builds profiles/r01_pmc_traffic.json from the two rocprofv3 --pmc passes over tools/roofline_probe.py
+(FETCH_SIZE and WRITE_SIZE, separate runs, csv output): per-launch averages for the GEMM and direct-conv kernels with the
+gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE counts half of wide coalesced reads -> x2; WRITE_SIZE exact).
+Usage: python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>"""
+import csv, json, sys
+
+
+def per_kernel(path, counter):
+    acc = {}
+    for r in csv.DictReader(open(path)):
+        if r.get("Counter_Name") != counter:
+            continue
+        name = r["Kernel_Name"]
+        key = "gemm" if "g2_kernel" in name else ("dconv" if "dconv3x3_kernel" in name else None)
+        if key is None:
+            continue
+        a = acc.setdefault(key, [0.0, 0, name])
+        a[0] += float(r["Counter_Value"]); a[1] += 1
+    return {k: (v[0] / v[1], v[2]) for k, v in acc.items()}
+
+
+def main(fetch_csv, write_csv, out):
+    sys.path.insert(0, __file__.rsplit("/", 1)[0])
+    f, w = per_kernel(fetch_csv, "FETCH_SIZE"), per_kernel(write_csv, "WRITE_SIZE")
+    alg = {"gemm": 2464 * 2048 * 2 + 512 * 2048 * 2 + 2 * 2464 * 512 * 4, "dconv": 384 * 64 * 64 * 16 * 2 * 2}
+    res = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python tools/roofline_probe.py "
+                      "(two separate passes), summarised by tools/pmc_traffic.py",
+           "gfx950_note": "MI355X_MICROARCH.md HBM section: FETCH_SIZE (KB) reports half the bytes of wide (16 B/lane) coalesced "
+                          "reads incl. global_load...lds -> x2; WRITE_SIZE (KB) is exact for wide stores"}
+    for k in ("gemm", "dconv"):
+        fk, name = f[k]; wk, _ = w[k]
+        res[k] = {"kernel": name[:120], "FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "traffic_bytes": (2 * fk + wk) * 1024,
+                  "algorithmic_bytes": alg[k]}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])

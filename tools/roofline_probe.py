@@ -1,8 +1,9 @@
 """Runs the two kernels bench.py reports a roofline for, in isolation, so that rocprofv3 --pmc passes can attribute HBM
 traffic to them:
-  * `gemm`  : g2_kernel<64,128,2,2,4> -- the dominant kernel of the rollout by GPU time (profiles/r01_rocprof_summary.md): the
-              CLIP text MLP down-projection on the ragged batch (M = 2464 live rows = half of 64 x 77, N = 512, K = 2048),
-              bf16 operands via global_load_lds, fp32 residual epilogue.  MFMA-bound class.
+  * `gemm`  : g2_kernel<64,128,2,4,NS,512> (8-wave ping-pong tile) -- the dominant kernel of the rollout by GPU time
+              (profiles/r01_rocprof_summary.md), on its heaviest call site: the CLIP text MLP down-projection on the ragged
+              batch (M = 2464 live rows = half of 64 x 77, N = 512, K = 2048; NS = 4), bf16 operands via global_load_lds,
+              fp32 residual epilogue.  MFMA-bound class.
   * `dconv` : dconv3x3_kernel<16,16,64,3> -- the layer-1 3x3 convolution of the six ResNet towers (384 images of 64x64x16 per
               launch, bf16 in / bf16 out, fused GroupNorm statistics).  HBM-bound class.
 Prints event-timed durations and algorithmic FLOPs / bytes per launch as JSON."""
