@@ -225,6 +225,7 @@ class Policy(nn.Module):
         self._enc_group = None
         self._shared_mode = None
         self._stash = None
+        self._pinned = {}
         self._eng = None
         self._ws = E.Workspaces()
         self._dirty = True
@@ -314,7 +315,11 @@ class Policy(nn.Module):
             if deterministic:
                 action = probs.argmax(dim=-1, keepdim=True)
             elif self.sampling == "host":
-                pc = probs.cpu()                                        # sync; (B,A) floats
+                if out.get("probs_host") is not None:                   # launch-ahead: the copy is already in flight
+                    pc, ev = out["probs_host"]
+                    ev.synchronize()
+                else:
+                    pc = probs.cpu()                                    # sync; (B,A) floats
                 q = torch.empty_like(pc).exponential_(1)                # == torch.multinomial's race
                 action = (pc / q).argmax(-1, keepdim=True).to(dev)
             else:
@@ -344,6 +349,7 @@ class Policy(nn.Module):
         if st is not None:
             self._stash = None
             if st[0] == which and st[1] == self._arg_key(net_args):
+                torch.cuda.current_stream().wait_event(st[3])        # later kernels of the caller read this forward's outputs
                 return st[2]
         mode, grp = None, self._enc_group
         if grp is not None and self.precision == "bf16":
@@ -373,27 +379,47 @@ class Policy(nn.Module):
                 k.append(a)
         return tuple(k)
 
-    def _prefetch(self, which, *net_args):
+    def _prefetch(self, which, *net_args, stream=None):
         """Enqueue the forward of a later act*/get_value* call now (no host synchronisation).  The matching call, made
         with the same tensors, picks the result up instead of launching again; a trainer that evaluates pi_q, pi_g and
-        pi_l on one observation (ppo_trainer.py:375-636) can enqueue all three before the first host-side sampling, so
-        the GPU does not idle while the host draws actions."""
+        pi_l on one observation (ppo_trainer.py:375-636) can enqueue all three before the first host-side sampling.
+        `stream`: run this forward on its own HIP stream (ordered after everything enqueued so far on the current one), so
+        that independent policies overlap on the GPU and each one's probabilities reach the host as soon as IT is done."""
         self._stash = None
-        out = self._forward(which, *net_args)
-        self._stash = (which, self._arg_key(net_args), out)
+        cur = torch.cuda.current_stream()
+        run_on = stream if stream is not None else cur
+        if stream is not None:
+            stream.wait_stream(cur)
+        with torch.cuda.stream(run_on):
+            out = self._forward(which, *net_args)
+            if self.sampling == "host":
+                # the probabilities start their way to the host right behind this forward (pinned buffer + event)
+                probs = out[1]["probs"]
+                key = (which, tuple(probs.shape))
+                if key not in self._pinned:
+                    self._pinned[key] = torch.empty(probs.shape, dtype=probs.dtype, pin_memory=True)
+                pc = self._pinned[key]
+                pc.copy_(probs, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(run_on)
+                out[1]["probs_host"] = (pc, ev)
+            done = torch.cuda.Event()
+            done.record(run_on)
+        self._stash = (which, self._arg_key(net_args), out, done)
 
-    def prefetch_act(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks):
-        self._prefetch("goal", observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks)
+    def prefetch_act(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks, stream=None):
+        self._prefetch("goal", observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks,
+                       stream=stream)
 
     def prefetch_act_option(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks,
-                            query_state, last_query_info):
+                            query_state, last_query_info, stream=None):
         self._prefetch("option", observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks,
-                       query_state, last_query_info)
+                       query_state, last_query_info, stream=stream)
 
     def prefetch_act_dialog(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_dialog,
-                            ext_memory_masks, all_dialog, agent_step):
+                            ext_memory_masks, all_dialog, agent_step, stream=None):
         self._prefetch("vln", observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_dialog,
-                       ext_memory_masks, all_dialog, agent_step)
+                       ext_memory_masks, all_dialog, agent_step, stream=stream)
 
     # ------------------------------------------------------------------ reference API
     def act(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks,

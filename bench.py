@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-share", action="store_true", help="do not batch the three policies' visual towers")
-    ap.add_argument("--launch-ahead", action="store_true", help="enqueue pi_g / pi_l before pi_q's host sampling")
+    ap.add_argument("--no-launch-ahead", action="store_true", help="call the three policies strictly one after the other")
     return ap.parse_args()
 
 
@@ -96,7 +96,7 @@ def main():
     from avlen_amd.harness import Workload
     H, W = (int(x) for x in a.spectrogram.split("x"))
     wl = Workload(a.envs, a.rollout, spectrogram=(H, W, 2), precision=a.precision, pretraining=True, seed=rank,
-                  use_graphs=not a.no_graphs, share_encoders=not a.no_share, launch_ahead=a.launch_ahead)
+                  use_graphs=not a.no_graphs, share_encoders=not a.no_share, launch_ahead=not a.no_launch_ahead)
 
     def barrier():
         torch.cuda.synchronize()
