@@ -13,6 +13,7 @@ not alter any value the trainer can observe:
   the (300, T*N_mb, dim) tensor the reference materialises per minibatch (K21).
 """
 from collections import defaultdict
+import ctypes as C
 import torch
 
 from . import _lib as L
@@ -102,6 +103,7 @@ class RolloutStorage:
         if use_state_memory:
             self.em_vln_dialog = mk(self.em_vln_size, self.em_vln_capacity, self.em_dim_dialog)
         self.step = 0
+        self._plans = {}
 
     def to(self, device):
         dev = torch.device(device)
@@ -113,6 +115,7 @@ class RolloutStorage:
             if em is not None:
                 em.to(dev)
         self.device = dev
+        self._plans = {}
 
     # ---------------------------------------------------------------- insert (rollout_storage.py:214-297)
     def insert(self, observations, recurrent_hidden_states, actions, actions_option, action_log_probs, value_preds,
@@ -121,26 +124,50 @@ class RolloutStorage:
                last_query_info, agent_step):
         s = self.step
         dev = self.device
-        as_t = lambda x, dt=None: (x if torch.is_tensor(x) else torch.as_tensor(x)).to(dev, dtype=dt, non_blocking=True)
-        # all of the step's storage writes go out as one batched copy launch (L.multi_copy falls back to copy_ for
-        # host values / dtype conversions); shapes follow the reference's `tensor[step].copy_(value)` broadcasting
-        def fit(dst, v, dt=None):
-            v = as_t(v, dt if dt is not None else dst.dtype)
-            return (dst, v.reshape(dst.shape) if v.numel() == dst.numel() else v.expand_as(dst).contiguous())
-        pairs = [fit(self.observations[k][s + 1], observations[k]) for k in self.observations]
-        pairs += [fit(self.recurrent_hidden_states[s + 1], recurrent_hidden_states), fit(self.all_dialog[s], all_dialog),
-                  fit(self.query_state[s], query_state), fit(self.last_query_info[s], last_query_info),
-                  fit(self.agent_step[s], agent_step)]
-        if o_action is not None:
-            pairs += [fit(self.o_masks[s], o_mask), fit(self.ucnt_gt[s], ucnt_gt), fit(self.rl_masks[s], rl_masks),
-                      fit(self.o_actions[s], o_action), fit(self.action_probs[s], action_prob)]
-        pairs.append(fit(self.actions[s], actions))
-        if actions_option is not None:
-            pairs.append(fit(self.actions_option[s], actions_option))
-        pairs += [fit(self.prev_actions[s + 1], actions), fit(self.action_log_probs[s], action_log_probs),
-                  fit(self.value_preds[s], value_preds), fit(self.rewards[s], rewards),
-                  fit(self.masks[s + 1], not_done_masks), fit(self.masks_vln[s + 1], not_done_masks_vln)]
-        L.multi_copy(pairs)
+        # All of the step's storage writes go out as ONE batched copy launch.  The destination side (views, pointers,
+        # byte counts) depends only on the step index and is planned once per step slot; a source that is already a
+        # contiguous device tensor of the right dtype and size is passed by pointer, anything else (host values, dtype
+        # conversions, broadcasts -- the reference's `tensor[step].copy_(value)` semantics) is converted first.
+        have_o, have_opt = o_action is not None, actions_option is not None
+        plan = self._plans.get((s, have_o, have_opt))
+        if plan is None:
+            dsts = [self.observations[k][s + 1] for k in self.observations]
+            dsts += [self.recurrent_hidden_states[s + 1], self.all_dialog[s], self.query_state[s], self.last_query_info[s],
+                     self.agent_step[s]]
+            if have_o:
+                dsts += [self.o_masks[s], self.ucnt_gt[s], self.rl_masks[s], self.o_actions[s], self.action_probs[s]]
+            dsts.append(self.actions[s])
+            if have_opt:
+                dsts.append(self.actions_option[s])
+            dsts += [self.prev_actions[s + 1], self.action_log_probs[s], self.value_preds[s], self.rewards[s],
+                     self.masks[s + 1], self.masks_vln[s + 1]]
+            n = len(dsts)
+            plan = (dsts, (C.c_void_p * n)(*[d.data_ptr() for d in dsts]),
+                    (C.c_int64 * n)(*[d.numel() * d.element_size() for d in dsts]),
+                    [(d.dtype, d.numel()) for d in dsts])
+            self._plans[(s, have_o, have_opt)] = plan
+        dsts, dst_ptrs, sizes, meta = plan
+        srcs = [observations[k] for k in self.observations]
+        srcs += [recurrent_hidden_states, all_dialog, query_state, last_query_info, agent_step]
+        if have_o:
+            srcs += [o_mask, ucnt_gt, rl_masks, o_action, action_prob]
+        srcs.append(actions)
+        if have_opt:
+            srcs.append(actions_option)
+        srcs += [actions, action_log_probs, value_preds, rewards, not_done_masks, not_done_masks_vln]
+        keep, ptrs = [], []
+        for v, d, (dt, n) in zip(srcs, dsts, meta):
+            if not (torch.is_tensor(v) and v.is_cuda and v.dtype == dt and v.numel() == n and v.is_contiguous()):
+                v = (v if torch.is_tensor(v) else torch.as_tensor(v)).to(dev, dtype=dt, non_blocking=True)
+                v = v.reshape(d.shape) if v.numel() == n else v.expand_as(d)
+                v = v.contiguous()
+                keep.append(v)                       # alive until the launch below has been enqueued
+            ptrs.append(v.data_ptr())
+        if dev.type == "cuda":
+            L.call("avlen_multi_copy", (C.c_void_p * len(ptrs))(*ptrs), dst_ptrs, sizes, len(ptrs), L.stream())
+        else:
+            for v, d in zip(srcs, dsts):
+                d.copy_(v if torch.is_tensor(v) else torch.as_tensor(v))
         nd, ndv = self.masks[s + 1], self.masks_vln[s + 1]
         if self.use_external_memory:
             self.em.insert(em_features, nd, self.em_masks[s + 1])

@@ -45,6 +45,25 @@ def run(launch_ahead):
             e1.record(); torch.cuda.synchronize()
             print(f"   graph {name} {key[0]}/{key[1]}: {e0.elapsed_time(e1)/20*1e3:.0f} us GPU per replay")
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) == 1:
     run(False)
     run(True)
+
+
+def host_profile():
+    import cProfile, pstats
+    wl = Workload(64, 150, launch_ahead=True)
+    for _ in range(20):
+        wl.rollout_step()
+    torch.cuda.synchronize()
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(60):
+        wl.rollout_step()
+    pr.disable()
+    torch.cuda.synchronize()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "host":
+    host_profile()
