@@ -63,7 +63,8 @@ def kernel_roofline(prec_name):
     gb = cw["bytes"] / sc / 1e9
     return {"bound": "mfma", "kernel": "g2_kernel<64,128,2,4,4,512> bf16 glds GEMM (CLIP c_proj, ragged M=2464 N=512 K=2048)",
             "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
-            "traffic": pmc.get("gemm", {}).get("traffic_bytes"), "algorithmic_flops": gw["flops"],
+            "traffic": pmc.get("gemm", {}).get("traffic_bytes"), "mfma_util_pmc_percent": pmc.get("gemm", {}).get("MfmaUtil_percent"),
+            "algorithmic_flops": gw["flops"],
             "algorithmic_bytes": gw["bytes"], "us_per_launch": round(sg * 1e6, 2),
             "hbm_conv": {"bound": "hbm", "kernel": "dconv3x3_kernel<16,16,64,3> (tower layer-1 conv, 384 images/launch, bf16 "
                                                    "in/out, fused GN statistics)", "achieved": round(gb, 1), "peak": 8000.0,
