@@ -549,6 +549,11 @@ int run_g2(G2 p, void* ws, size_t ws_bytes, hipStream_t st) {
     // 64-row tiles when 128-row tiles would leave most of the 256 CUs idle (small rollout batches)
     if (bn >= 64 && (long)ceil_div(p.M, 128) * n_tiles * p.groups < 256 && p.M > 64) bm = 64;
     if (has_stats && bm == 64 && (p.ohw % 32)) bm = 128;
+    // 128x64 tiles also run 8 waves (4x2, 32-row wave tiles): -23 % on the towers' 64-channel convs (AVLEN_G2_N64=256 restores
+    // the 4-wave instance for A/B runs)
+    static int n64 = -1;
+    if (n64 < 0) { const char* e = getenv("AVLEN_G2_N64"); n64 = e ? atoi(e) : 512; }
+    if (n64 == 512 && bn == 64 && bm == 128 && (!has_stats || p.ohw % 32 == 0)) { nth = 512; ns = 2; }
   }
 #ifdef AVLEN_G2_LAB
   if (g_lab_cfg[0]) { bm = g_lab_cfg[0]; bn = g_lab_cfg[1]; nth = g_lab_cfg[2]; n_tiles = ceil_div(p.N, bn); }
