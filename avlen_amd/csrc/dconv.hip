@@ -22,9 +22,11 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero_page_dc[256];     //
 
 namespace {
 
-struct DcGroups { const bf16* x[8]; const bf16* w[8]; bf16* y[8]; float* stats[8]; };
+struct DcGroups { const bf16* x[8]; const bf16* w[8]; bf16* y[8]; float* stats[8];
+                  // NORM: the input is a RAW conv output; GroupNorm(16) + ReLU of it is applied while the halo is staged
+                  const float* nstats[8]; const float* ngamma[8]; const float* nbeta[8]; };
 
-template <int C, int CO, int W, int KSZ>      // C input channels (power of two >= 8), CO output channels, image W x W, KSZ x KSZ taps
+template <int C, int CO, int W, int KSZ, bool NORM>      // C input channels (power of two >= 8), CO output channels, image W x W, KSZ x KSZ taps
 __global__ __launch_bounds__(256) void dconv3x3_kernel(DcGroups gg, int B) {
   constexpr int TR = 8;                       // output rows per block
   constexpr int PAD = KSZ / 2;
@@ -60,14 +62,57 @@ __global__ __launch_bounds__(256) void dconv3x3_kernel(DcGroups gg, int B) {
   // ---- halo: rows y0-1 .. y0+TR, interior columns by global_load_lds (1 KiB pieces), border columns zeroed
   constexpr int PIECES_PER_ROW = (W * PB) / 1024;                                 // C=16,W=64: 2 ; C=32,W=32: 2 ; C=8,W=64: 1
   static_assert(PIECES_PER_ROW >= 1 && (W * PB) % 1024 == 0, "halo rows are staged in 1 KiB wave-instructions");
-  constexpr int NPIECES = HR * PIECES_PER_ROW;
-  for (int pc = wave; pc < NPIECES; pc += 4) {
-    int hr = pc / PIECES_PER_ROW, part = pc % PIECES_PER_ROW;
-    int iy = y0 - PAD + hr;
-    const char* src = (iy >= 0 && iy < W) ? (const char*)(x + (long)iy * W * C) + part * 1024 + lane * 16
-                                          : (const char*)g_zero_page_dc + lane * 16;
-    __builtin_amdgcn_global_load_lds((const void*)src,
-        (__attribute__((address_space(3))) void*)(halo + hr * ROWB + PAD * PB + part * 1024), 16, 0, 0);
+  if constexpr (!NORM) {
+    constexpr int NPIECES = HR * PIECES_PER_ROW;
+    for (int pc = wave; pc < NPIECES; pc += 4) {
+      int hr = pc / PIECES_PER_ROW, part = pc % PIECES_PER_ROW;
+      int iy = y0 - PAD + hr;
+      const char* src = (iy >= 0 && iy < W) ? (const char*)(x + (long)iy * W * C) + part * 1024 + lane * 16
+                                            : (const char*)g_zero_page_dc + lane * 16;
+      __builtin_amdgcn_global_load_lds((const void*)src,
+          (__attribute__((address_space(3))) void*)(halo + hr * ROWB + PAD * PB + part * 1024), 16, 0, 0);
+    }
+  } else {
+    // Fused GroupNorm(16) + ReLU of the producer: x is the producer's RAW output, its per-(sample, channel) sums are in
+    // nstats.  Scale / shift per channel once per block, then every 16-byte chunk (8 channels of one pixel) goes
+    // global -> registers -> a*x+b, max 0 -> bf16 -> LDS; rows outside the image stay exactly zero (the conv pads the
+    // NORMALISED activation).  Saves the separate apply pass: one read + one write of the activation.
+    __shared__ float s_scale[C], s_shift[C];
+    constexpr int CPG = C / 16;                                                   // channels per group
+    if (tid < 16) {
+      const float* st = gg.nstats[blockIdx.z] + (long)b * 2 * C;
+      double sum = 0.0, sq = 0.0;
+      for (int c = tid * CPG; c < (tid + 1) * CPG; c++) { sum += st[c]; sq += st[C + c]; }
+      double n = (double)(W * W) * CPG, mean = sum / n, var = sq / n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      float rstd = (float)(1.0 / sqrt(var + 1e-5));
+      for (int c = tid * CPG; c < (tid + 1) * CPG; c++) {
+        float sc = gg.ngamma[blockIdx.z][c] * rstd;
+        s_scale[c] = sc; s_shift[c] = gg.nbeta[blockIdx.z][c] - (float)mean * sc;
+      }
+    }
+    __syncthreads();
+    constexpr int CH_ROW = W * PB / 16;                                           // 16-byte chunks per image row
+    constexpr int CH_PIX = PB / 16;                                               // chunks per pixel
+    static_assert((256 % CH_PIX) == 0, "a thread keeps the same 8 channels on every chunk it stages");
+    const int c0 = (tid % CH_PIX) * 8;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { sc[i] = s_scale[c0 + i]; sh[i] = s_shift[c0 + i]; }
+    for (int i = tid; i < HR * CH_ROW; i += 256) {
+      const int hr = i / CH_ROW, ch = i - hr * CH_ROW;
+      const int iy = y0 - PAD + hr;
+      bf16x8 o;
+      if (iy >= 0 && iy < W) {
+        bf16x8 v = *reinterpret_cast<const bf16x8*>((const char*)(x + (long)iy * W * C) + ch * 16);
+#pragma unroll
+        for (int e = 0; e < 8; e++) o[e] = (bf16)fmaxf((float)v[e] * sc[e] + sh[e], 0.f);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; e++) o[e] = (bf16)0.f;
+      }
+      *reinterpret_cast<bf16x8*>(halo + hr * ROWB + PAD * PB + ch * 16) = o;
+    }
   }
   // left / right padding columns (PAD pixels each side)
   constexpr int PADCH = PAD * PB / 16;                                            // 16-byte chunks per side per row
@@ -142,20 +187,25 @@ __global__ __launch_bounds__(256) void dconv3x3_kernel(DcGroups gg, int B) {
 // X: NHWC bf16 (B, W, W, Cin); Y: (B, W, W, Cout) bf16; Wp: bf16 [Cout][K][K][Cin]; stats (optional, pre-zeroed):
 // [B][2][Cout] fp32.  Stride 1, "same" padding.
 int avlen_dconv_bf16_grouped(const void* const* X, const void* const* Wp, void* const* Y16, float* const* gn_stats,
-                             int groups, int B, int W, int Cin, int Cout, int K, hipStream_t stream) {
+                             int groups, int B, int W, int Cin, int Cout, int K, hipStream_t stream,
+                             const float* const* in_stats, const float* const* in_gamma, const float* const* in_beta) {
   if (groups < 1 || groups > 8 || B <= 0) return AVLEN_ERR_ARG;
   DcGroups gg = {};
+  const bool norm = in_stats != nullptr;
   for (int g = 0; g < groups; g++) {
     gg.x[g] = (const bf16*)X[g]; gg.w[g] = (const bf16*)Wp[g]; gg.y[g] = (bf16*)Y16[g];
     gg.stats[g] = gn_stats ? gn_stats[g] : nullptr;
+    if (norm) { gg.nstats[g] = in_stats[g]; gg.ngamma[g] = in_gamma[g]; gg.nbeta[g] = in_beta[g]; }
   }
   dim3 grid(W / 8, B, groups), block(256);
-  if (Cin == 16 && Cout == 16 && W == 64 && K == 3)
-    hipLaunchKernelGGL((dconv3x3_kernel<16, 16, 64, 3>), grid, block, 0, stream, gg, B);
-  else if (Cin == 32 && Cout == 32 && W == 32 && K == 3)
-    hipLaunchKernelGGL((dconv3x3_kernel<32, 32, 32, 3>), grid, block, 0, stream, gg, B);
-  else if (Cin == 8 && Cout == 16 && W == 64 && K == 7)
-    hipLaunchKernelGGL((dconv3x3_kernel<8, 16, 64, 7>), grid, block, 0, stream, gg, B);
+  if (Cin == 16 && Cout == 16 && W == 64 && K == 3) {
+    if (norm) hipLaunchKernelGGL((dconv3x3_kernel<16, 16, 64, 3, true>), grid, block, 0, stream, gg, B);
+    else hipLaunchKernelGGL((dconv3x3_kernel<16, 16, 64, 3, false>), grid, block, 0, stream, gg, B);
+  } else if (Cin == 32 && Cout == 32 && W == 32 && K == 3) {
+    if (norm) hipLaunchKernelGGL((dconv3x3_kernel<32, 32, 32, 3, true>), grid, block, 0, stream, gg, B);
+    else hipLaunchKernelGGL((dconv3x3_kernel<32, 32, 32, 3, false>), grid, block, 0, stream, gg, B);
+  } else if (Cin == 8 && Cout == 16 && W == 64 && K == 7 && !norm)
+    hipLaunchKernelGGL((dconv3x3_kernel<8, 16, 64, 7, false>), grid, block, 0, stream, gg, B);
   else
     return AVLEN_ERR_ARG;
   return avlen_launch_status();
@@ -170,5 +220,6 @@ bool avlen_dconv_supported(int W, int Cin, int Cout, int KH, int KW, int stride,
 extern "C" int avlen_conv_direct_bf16(const void* X, const void* Wp, void* Y16, float* gn_stats, int B, int W, int Cin,
                                       int Cout, int K, hipStream_t stream) {
   if (!avlen_dconv_supported(W, Cin, Cout, K, K, 1, K / 2)) return AVLEN_ERR_ARG;
-  return avlen_dconv_bf16_grouped(&X, &Wp, &Y16, gn_stats ? &gn_stats : nullptr, 1, B, W, Cin, Cout, K, stream);
+  return avlen_dconv_bf16_grouped(&X, &Wp, &Y16, gn_stats ? &gn_stats : nullptr, 1, B, W, Cin, Cout, K, stream, nullptr, nullptr,
+                                  nullptr);
 }

@@ -41,8 +41,12 @@ int avlen_attention_qkv16(const void* QKV16, int ld, void* O16, int ldo16, int B
 int avlen_gemm_bf16_dyn(const void* A, int lda, const void* B, int ldb, float* C32, int ldc32, void* C16, int ldc16,
                         const float* bias, const float* residual, int ldr, int M, const int* M_dev, int N, int K, int act,
                         void* ws, size_t ws_bytes, hipStream_t stream);
+// in_stats / in_gamma / in_beta (optional, 16/16@64 and 32/32@32 only): X is a RAW conv output whose GroupNorm(16) + ReLU is
+// applied while the halo is staged (saves the separate apply pass)
 int avlen_dconv_bf16_grouped(const void* const* X, const void* const* Wp, void* const* Y16, float* const* gn_stats,
-                             int groups, int B, int W, int Cin, int Cout, int K, hipStream_t stream);
+                             int groups, int B, int W, int Cin, int Cout, int K, hipStream_t stream,
+                             const float* const* in_stats = nullptr, const float* const* in_gamma = nullptr,
+                             const float* const* in_beta = nullptr);
 bool avlen_dconv_supported(int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
 
 // ---- fused row-batch chain (chain.hip): a program of d=256 Linear / LayerNorm steps run by one kernel ----

@@ -426,6 +426,8 @@ int resnet18_group_fwd_bf16(const avlen_resnet18* const* nets, const float* cons
     return avlen_groupnorm_apply_bf16_grouped(XR, 1, (const float* const*)stt, GA, BE, res ? RES : nullptr, OUT, G, B, HW, C, 16,
                                               relu, 1e-5f, st);
   };
+  static int fuse_gn = -1;                     // AVLEN_DCONV_FUSE_GN=0: run bn1 as its own pass (A/B knob)
+  if (fuse_gn < 0) { const char* e = getenv("AVLEN_DCONV_FUSE_GN"); fuse_gn = e ? atoi(e) : 1; }
   next_stats(ST);
   TRY(conv([](const avlen_resnet18* n) -> const avlen_conv& { return n->conv1; }, x0, raw[0], ST, 64));
   TRY(gn([](const avlen_resnet18* n) -> const avlen_affine& { return n->bn1; }, raw[0], ST, nullptr, act[0], 4096, 16, 1));
@@ -436,8 +438,18 @@ int resnet18_group_fwd_bf16(const avlen_resnet18* const* nets, const float* cons
     int s = k.conv1.stride, OH = (H + 2 - 3) / s + 1, Co = k.conv1.cout;
     next_stats(ST); next_stats(ST2);
     TRY(conv([i](const avlen_resnet18* n) -> const avlen_conv& { return n->block[i].conv1; }, cur, raw[0], ST, H));
-    TRY(gn([i](const avlen_resnet18* n) -> const avlen_affine& { return n->block[i].bn1; }, raw[0], ST, nullptr, a1, OH * OH, Co, 1));
-    TRY(conv([i](const avlen_resnet18* n) -> const avlen_conv& { return n->block[i].conv2; }, a1, raw[1], ST2, OH));
+    const avlen_conv& k2 = k.conv2;
+    if (fuse_gn && (Co == 16 || Co == 32) && avlen_dconv_supported(OH, k2.cin16, k2.cout, k2.kh, k2.kw, k2.stride, k2.pad)) {
+      // bn1 + ReLU feed conv2 only: applied inside the direct conv's halo staging (no separate pass over the activation)
+      for (int g = 0; g < G; g++) {
+        X[g] = raw[0][g]; Wt[g] = nets[g]->block[i].conv2.w16; Y[g] = raw[1][g];
+        GA[g] = nets[g]->block[i].bn1.g; BE[g] = nets[g]->block[i].bn1.b;
+      }
+      TRY(avlen_dconv_bf16_grouped(X, Wt, Y, ST2, G, B, OH, k2.cin16, k2.cout, k2.kh, st, (const float* const*)ST, GA, BE));
+    } else {
+      TRY(gn([i](const avlen_resnet18* n) -> const avlen_affine& { return n->block[i].bn1; }, raw[0], ST, nullptr, a1, OH * OH, Co, 1));
+      TRY(conv([i](const avlen_resnet18* n) -> const avlen_conv& { return n->block[i].conv2; }, a1, raw[1], ST2, OH));
+    }
     bf16** identity = cur;
     if (k.has_down) {
       next_stats(ST3);
