@@ -34,6 +34,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 __device__ long long g_chain_stamps[64];     // tools/chain_lab.hip: start time of every step (block 0)
 #endif
 
+__device__ __attribute__((aligned(16))) unsigned int g_zero_page_ch[4096];     // K tails of the weight tiles
+
 namespace {
 
 constexpr int D = 256;            // feature width of every step's output
@@ -45,11 +47,12 @@ constexpr int NS = 3;             // up to 2 tiles (64 KiB) in flight while one 
 constexpr int NIMG = 2;           // activation images (a third operand is parked in a register save slot)
 constexpr int XS_BYTES = NIMG * 16 * XLD * 2;
 constexpr int RED_BYTES = NW * 16 * 2 * 4;
-constexpr int MAX_LIN = 24, MAX_PAR = 36;      // Linear steps / 256-float parameter vectors per program
+constexpr int MAX_LIN = 24, MAX_PAR = 32;      // Linear steps / 256-float parameter vectors per program
+constexpr int ATT_BYTES = NW * 16 * 4 * 4;     // attention score partials [wave][row][key]
 
 // what the kernel reads: compiled from avlen_chain on the host
-struct DevOp { int kind, k, ld, ld2, act, res, buf, out_buf, par, pad; const void* p0; const void* p1; };
-struct DevLin { const char* w; int ld, nkt; };
+struct DevOp { int kind, k, ld, ld2, act, res, buf, out_buf, par, div, seq; float scale; const void* p0; const void* p1; };
+struct DevLin { const char* w; int ld, nkt, k, pad; };
 struct DevProg {
   int n, n_lin, n_par, pad;
   DevOp op[AVLEN_CHAIN_MAX_OPS];
@@ -58,7 +61,7 @@ struct DevProg {
 };
 constexpr int PROG_BYTES = (sizeof(DevProg) + 15) / 16 * 16;
 constexpr int PAR_BYTES = MAX_PAR * D * 4;
-constexpr int LDS_BYTES = NS * TILE_BYTES + XS_BYTES + RED_BYTES + PROG_BYTES + PAR_BYTES;
+constexpr int LDS_BYTES = NS * TILE_BYTES + XS_BYTES + RED_BYTES + ATT_BYTES + PROG_BYTES + PAR_BYTES;
 static_assert(LDS_BYTES <= 160 * 1024, "chain kernel LDS budget");
 static_assert(sizeof(DevProg) <= 4000, "kernel argument limit");
 
@@ -74,8 +77,9 @@ __global__ __launch_bounds__(NTH) void chain_kernel(DevProg kprog, int B) {
   char* ring = lds;                                                          // [NS][256][128 B]
   bf16* xs = reinterpret_cast<bf16*>(lds + NS * TILE_BYTES);                 // [NIMG][16][XLD]
   float* red = reinterpret_cast<float*>(lds + NS * TILE_BYTES + XS_BYTES);   // [8][16 rows][4]
-  DevProg* sp = reinterpret_cast<DevProg*>(lds + NS * TILE_BYTES + XS_BYTES + RED_BYTES);
-  float* par = reinterpret_cast<float*>(lds + NS * TILE_BYTES + XS_BYTES + RED_BYTES + PROG_BYTES);   // [MAX_PAR][256]
+  float* att = reinterpret_cast<float*>(lds + NS * TILE_BYTES + XS_BYTES + RED_BYTES);                  // [NW][16][4]
+  DevProg* sp = reinterpret_cast<DevProg*>(lds + NS * TILE_BYTES + XS_BYTES + RED_BYTES + ATT_BYTES);
+  float* par = reinterpret_cast<float*>(lds + NS * TILE_BYTES + XS_BYTES + RED_BYTES + ATT_BYTES + PROG_BYTES);   // [MAX_PAR][256]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, q = lane >> 4;
   const int row = blockIdx.x * 16 + c;                 // this lane's batch row
   const bool rok = row < B;
@@ -115,7 +119,8 @@ __global__ __launch_bounds__(NTH) void chain_kernel(DevProg kprog, int B) {
 #pragma unroll
     for (int r = 0; r < 2; r++) {
       const int slot = r * NTH + tid, frow = slot >> 3, ch = (slot & 7) ^ ((frow >> 1) & 7);
-      const char* src = ldl.w + ((long)frow * ldl.ld + ld_kt * 64 + ch * 8) * 2;
+      const int kcol = ld_kt * 64 + ch * 8;
+      const char* src = kcol < ldl.k ? ldl.w + ((long)frow * ldl.ld + kcol) * 2 : (const char*)g_zero_page_ch + tid * 16;
       __builtin_amdgcn_global_load_lds((const void*)src,
           (__attribute__((address_space(3))) void*)(stage + (r * NTH + wave * 64) * 16), 16, 0, 0);
     }
@@ -134,12 +139,12 @@ __global__ __launch_bounds__(NTH) void chain_kernel(DevProg kprog, int B) {
       case AVLEN_CH_LOAD_X16: {                        // bf16 global rows [B][ld] -> xs[buf][.][0:K)
         bar();
         const bf16* src = (const bf16*)op.p0;
-        const int cpr = op.k >> 3;                     // 16-byte chunks per row
+        const int cpr = ((op.k + 63) >> 6) << 3;       // 16-byte chunks per row, zero-filled up to a whole 64-wide k block
         for (int i = tid; i < 16 * cpr; i += NTH) {
           int rr = i / cpr, ch = i - rr * cpr;
           int gr = blockIdx.x * 16 + rr;
           uint4 v = make_uint4(0, 0, 0, 0);
-          if (gr < B) v = *reinterpret_cast<const uint4*>(src + (long)gr * op.ld + ch * 8);
+          if (gr < B && ch * 8 < op.k) v = *reinterpret_cast<const uint4*>(src + (long)gr * op.ld + ch * 8);
           *reinterpret_cast<uint4*>(&xs[(op.buf * 16 + rr) * XLD + ch * 8]) = v;
         }
         bar();
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(NTH) void chain_kernel(DevProg kprog, int B) {
       case AVLEN_CH_LOAD_CUR: {                        // fp32 global [B][ld] (256 features) -> cur (+ bf16 image)
         const float* src = (const float*)op.p0;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (rok) v = *reinterpret_cast<const float4*>(src + (long)row * op.ld + n0 + q * 4);
+        if (rok) v = *reinterpret_cast<const float4*>(src + (long)(row / op.div) * op.ld + n0 + q * 4);
         cur[0] = v.x; cur[1] = v.y; cur[2] = v.z; cur[3] = v.w;
         bar();
         publish(op.buf);
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(NTH) void chain_kernel(DevProg kprog, int B) {
       }
       case AVLEN_CH_LINEAR: {                          // cur = act(W x + b) [+ save slot]; x = xs[buf][.][0:K)
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const int nkt = op.k >> 6;
+        const int nkt = (op.k + 63) >> 6;
         const bf16* xrow = &xs[(op.buf * 16 + c) * XLD + q * 8];
         const int wr = n0 + c;                         // this lane's feature row inside the tile
         const int wsw = (wr >> 1) & 7;
@@ -236,17 +241,78 @@ __global__ __launch_bounds__(NTH) void chain_kernel(DevProg kprog, int B) {
         bar();
         break;
       }
-      case AVLEN_CH_STORE: {                           // cur -> fp32 global [B][ld] and/or bf16 global [B][ld2]
+      case AVLEN_CH_STORE: {                           // cur -> fp32 global and/or bf16 global (last row of every `div` rows)
         float* dst = (float*)op.p0; bf16* dst16 = (bf16*)op.p1;
-        if (rok) {
-          if (dst) *reinterpret_cast<float4*>(dst + (long)row * op.ld + n0 + q * 4) = make_float4(cur[0], cur[1], cur[2], cur[3]);
+        if (rok && (row % op.div) == op.div - 1) {
+          const long orow = row / op.div;
+          if (dst) *reinterpret_cast<float4*>(dst + orow * op.ld + n0 + q * 4) = make_float4(cur[0], cur[1], cur[2], cur[3]);
           if (dst16) {
             bf16x4 o;
 #pragma unroll
             for (int r = 0; r < 4; r++) o[r] = (bf16)cur[r];
-            *reinterpret_cast<bf16x4*>(dst16 + (long)row * op.ld2 + n0 + q * 4) = o;
+            *reinterpret_cast<bf16x4*>(dst16 + orow * op.ld2 + n0 + q * 4) = o;
           }
         }
+        break;
+      }
+      case AVLEN_CH_ATTN: {                            // 8 heads x D=32 inside groups of `seq` consecutive rows
+        const int S = op.seq, g0 = (c / S) * S;
+        float qv[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) qv[r] = op.res == 0 ? sav0[r] : sav1[r];
+        float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (j < S) {
+            bf16x4 kv = *reinterpret_cast<const bf16x4*>(&xs[(op.buf * 16 + g0 + j) * XLD + n0 + q * 4]);
+#pragma unroll
+            for (int r = 0; r < 4; r++) part[j] += qv[r] * (float)kv[r];
+          }
+#pragma unroll
+        for (int j = 0; j < 4; j++) { part[j] += __shfl_xor(part[j], 16, 64); part[j] += __shfl_xor(part[j], 32, 64); }
+        if (q == 0) *reinterpret_cast<float4*>(&att[(wave * 16 + c) * 4]) = make_float4(part[0], part[1], part[2], part[3]);
+        bar();
+        // a head is 32 features = this wave and its neighbour
+        const float4 pa = *reinterpret_cast<const float4*>(&att[((wave & ~1) * 16 + c) * 4]);
+        const float4 pb = *reinterpret_cast<const float4*>(&att[((wave | 1) * 16 + c) * 4]);
+        float sc[4] = {pa.x + pb.x, pa.y + pb.y, pa.z + pb.z, pa.w + pb.w};
+        const float* km = (const float*)op.p0;
+        const long grp = (long)(blockIdx.x * 16 + c) / S;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          bool ok = j < S && (!km || !rok || km[grp * S + j] != 0.f);
+          sc[j] = ok ? sc[j] * op.scale : -INFINITY;
+          mx = fmaxf(mx, sc[j]);
+        }
+        float den = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { sc[j] = sc[j] == -INFINITY ? 0.f : __expf(sc[j] - mx); den += sc[j]; }
+        const float inv = den > 0.f ? 1.f / den : 0.f;
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (j < S) {
+            bf16x4 vv = *reinterpret_cast<const bf16x4*>(&xs[(op.ld2 * 16 + g0 + j) * XLD + n0 + q * 4]);
+#pragma unroll
+            for (int r = 0; r < 4; r++) o[r] += sc[j] * inv * (float)vv[r];
+          }
+#pragma unroll
+        for (int r = 0; r < 4; r++) cur[r] = o[r];
+        bar();                                         // every wave has read the K / V images
+        publish(op.out_buf);
+        bar();
+        break;
+      }
+      case AVLEN_CH_ADD_PE: {                          // cur += table[step[row / div]]
+        const float* tab = (const float*)op.p0; const float* step = (const float*)op.p1;
+        int idx = rok ? (int)step[row / op.div] : 0;
+        idx = idx < 0 ? 0 : (idx >= op.k ? op.k - 1 : idx);
+        const float4 pv = *reinterpret_cast<const float4*>(tab + (long)idx * D + n0 + q * 4);
+        cur[0] += pv.x; cur[1] += pv.y; cur[2] += pv.z; cur[3] += pv.w;
+        bar();
+        publish(op.out_buf);
+        bar();
         break;
       }
       default: break;
@@ -269,10 +335,13 @@ int avlen_chain_run(const avlen_chain* prog, int B, hipStream_t stream) {
     if (o.buf < 0 || o.buf >= NIMG || o.out_buf < 0 || o.out_buf >= NIMG) return AVLEN_ERR_ARG;
     DevOp& d = dp.op[i];
     d.kind = o.kind; d.k = o.k; d.ld = o.ld; d.ld2 = o.ld2; d.act = o.act; d.res = o.res; d.buf = o.buf; d.out_buf = o.out_buf;
-    d.par = -1; d.p0 = o.p0; d.p1 = o.p1;
+    d.par = -1; d.p0 = o.p0; d.p1 = o.p1; d.div = o.div > 0 ? o.div : 1; d.seq = o.seq; d.scale = o.scale;
+    if (o.kind == AVLEN_CH_ATTN && ((o.seq != 1 && o.seq != 2 && o.seq != 4) || o.ld2 < 0 || o.ld2 >= NIMG || (o.res != 0 && o.res != 1)))
+      return AVLEN_ERR_ARG;
+    if (o.kind == AVLEN_CH_ADD_PE && (!o.p0 || !o.p1 || o.k < 1)) return AVLEN_ERR_ARG;
     if (o.kind == AVLEN_CH_LINEAR) {
-      if (o.k % 64 || o.k > KMAX || o.k < 64 || o.ld < o.k || o.ld % 8 || !o.p0 || dp.n_lin >= MAX_LIN) return AVLEN_ERR_ARG;
-      dp.lin[dp.n_lin++] = DevLin{(const char*)o.p0, o.ld, o.k >> 6};
+      if (o.k % 8 || o.k > KMAX || o.k < 8 || o.ld < o.k || o.ld % 8 || !o.p0 || dp.n_lin >= MAX_LIN) return AVLEN_ERR_ARG;
+      dp.lin[dp.n_lin++] = DevLin{(const char*)o.p0, o.ld, (o.k + 63) >> 6, o.k, 0};
       if (o.p1) {
         if (dp.n_par >= MAX_PAR || ((uintptr_t)o.p1 & 15)) return AVLEN_ERR_ARG;
         d.par = dp.n_par; dp.par_src[dp.n_par++] = (const float*)o.p1;

@@ -50,15 +50,21 @@ int avlen_dconv_bf16_grouped(const void* const* X, const void* const* Wp, void* 
 bool avlen_dconv_supported(int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
 
 // ---- fused row-batch chain (chain.hip): a program of d=256 Linear / LayerNorm steps run by one kernel ----
-#define AVLEN_CH_LOAD_X16 1   /* p0: bf16 [B][ld] rows -> LDS image `buf`, k columns (multiple of 32) */
-#define AVLEN_CH_LOAD_CUR 2   /* p0: fp32 [B][ld] (256 features) -> registers, image -> `buf` */
-#define AVLEN_CH_LINEAR 3     /* p0: bf16 W[256][ld], p1: fp32 bias[256] or null; input image `buf` (k columns, k % 64 == 0);
+#define AVLEN_CH_LOAD_X16 1   /* p0: bf16 [B][ld] rows -> LDS image `buf`, k columns (multiple of 8; zero-filled to a multiple of 64) */
+#define AVLEN_CH_LOAD_CUR 2   /* p0: fp32 [B/div][ld] (256 features), row r reads source row r/div -> registers, image -> `buf` */
+#define AVLEN_CH_LINEAR 3     /* p0: bf16 W[256][ld], p1: fp32 bias[256] or null; input image `buf` (k columns, k % 8 == 0);
                                  act; res = 1 | 2 adds save slot 0 | 1; result -> registers and image `out_buf` */
 #define AVLEN_CH_LAYERNORM 4  /* p0: gamma, p1: beta (eps 1e-5); result -> registers and image `out_buf` */
 #define AVLEN_CH_SAVE 5       /* registers -> save slot `res` (0 | 1) */
+#define AVLEN_CH_STORE 6      /* p0: fp32 [B/div][ld] or null, p1: bf16 [B/div][ld2] or null; div > 1: only the last row of
+                                 every group of `div` rows is stored (to row r/div) */
 #define AVLEN_CH_RECALL 7     /* save slot `res` -> registers and image `out_buf` */
-#define AVLEN_CH_STORE 6      /* p0: fp32 [B][ld] or null, p1: bf16 [B][ld2] or null */
+#define AVLEN_CH_ATTN 8       /* 8-head attention inside groups of `seq` (1|2|4) consecutive rows: Q = save slot `res`,
+                                 K = image `buf`, V = image `ld2`, p0: fp32 key mask [B/seq][seq] (1 = valid) or null,
+                                 `scale`; result -> registers and image `out_buf` */
+#define AVLEN_CH_ADD_PE 9     /* registers += p0[clamp(int(p1[r/div]), 0, k-1)][0..256): positional table p0 fp32 [k][256],
+                                 p1 fp32 [B/div]; result -> registers and image `out_buf` */
 #define AVLEN_CHAIN_MAX_OPS 40
-typedef struct { int kind, k, ld, ld2, act, res, buf, out_buf; const void* p0; const void* p1; } avlen_chain_op;
+typedef struct { int kind, k, ld, ld2, act, res, buf, out_buf, div, seq; float scale; int pad; const void* p0; const void* p1; } avlen_chain_op;
 typedef struct { int n; avlen_chain_op op[AVLEN_CHAIN_MAX_OPS]; } avlen_chain;
 int avlen_chain_run(const avlen_chain* prog, int B, hipStream_t stream);

@@ -308,21 +308,61 @@ struct ChainB {
     static avlen_chain_op dummy;
     if (p.n >= AVLEN_CHAIN_MAX_OPS) { ok = false; return dummy; }
     avlen_chain_op& o = p.op[p.n++];
-    o = avlen_chain_op{kind, 0, 0, 0, 0, 0, 0, 0, nullptr, nullptr};
+    o = avlen_chain_op{kind, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0.f, 0, nullptr, nullptr};
     return o;
   }
   void load_x16(const bf16* x, int ld, int k, int buf) { auto& o = next(AVLEN_CH_LOAD_X16); o.p0 = x; o.ld = ld; o.k = k; o.buf = buf; }
-  void load_cur(const float* x, int ld, int buf) { auto& o = next(AVLEN_CH_LOAD_CUR); o.p0 = x; o.ld = ld; o.buf = buf; }
+  void load_cur(const float* x, int ld, int buf, int div = 1) { auto& o = next(AVLEN_CH_LOAD_CUR); o.p0 = x; o.ld = ld; o.buf = buf; o.div = div; }
   void linear(const avlen_linear& L, int r0, int act, int res, int buf, int out_buf) {
     auto& o = next(AVLEN_CH_LINEAR);
     o.p0 = (const char*)L.w16 + (size_t)r0 * L.ld16 * 2; o.p1 = L.b ? L.b + r0 : nullptr;
     o.k = L.ld16; o.ld = L.ld16; o.act = act; o.res = res; o.buf = buf; o.out_buf = out_buf;
-    if (!L.w16 || (L.ld16 % 64) || L.ld16 > 320 || L.out_f < r0 + 256) ok = false;
+    if (!L.w16 || (L.ld16 % 8) || L.ld16 > 320 || L.out_f < r0 + 256) ok = false;
   }
   void ln(const avlen_affine& a, int out_buf) { auto& o = next(AVLEN_CH_LAYERNORM); o.p0 = a.g; o.p1 = a.b; o.out_buf = out_buf; }
   void save(int slot = 0) { auto& o = next(AVLEN_CH_SAVE); o.res = slot; }
   void recall(int slot, int out_buf) { auto& o = next(AVLEN_CH_RECALL); o.res = slot; o.out_buf = out_buf; }
-  void store(float* y, int ld, bf16* y16, int ld2) { auto& o = next(AVLEN_CH_STORE); o.p0 = y; o.ld = ld; o.p1 = y16; o.ld2 = ld2; }
+  void store(float* y, int ld, bf16* y16, int ld2, int div = 1) {
+    auto& o = next(AVLEN_CH_STORE); o.p0 = y; o.ld = ld; o.p1 = y16; o.ld2 = ld2; o.div = div;
+  }
+  void attn(int qslot, int kimg, int vimg, int out_buf, const float* key_mask, int seq, float scale) {
+    auto& o = next(AVLEN_CH_ATTN); o.res = qslot; o.buf = kimg; o.ld2 = vimg; o.out_buf = out_buf; o.p0 = key_mask; o.seq = seq;
+    o.scale = scale;
+  }
+  void add_pe(const float* table, int len, const float* step, int div, int out_buf) {
+    auto& o = next(AVLEN_CH_ADD_PE); o.p0 = table; o.k = len; o.p1 = step; o.div = div; o.out_buf = out_buf;
+  }
+  // nn.Transformer(1 encoder + 1 decoder layer, post-norm) on groups of S <= 4 rows (tokens of one sample), the single
+  // decoder target replicated on the group's rows; expects the fused sequence in registers, image 0 and save slot 0.
+  void small_transformer(const avlen_transformer& tr, const float* goal, const float* key_mask, int S, float* out) {
+    const int d = tr.d;
+    const float scale = 1.0f / sqrtf((float)(d / tr.nhead));
+    const avlen_enc_layer& e = tr.enc; const avlen_dec_layer& q = tr.dec;
+    linear(e.self_attn.in_proj, 0, 0, 0, 0, 1); save(1);                 // Q (registers)
+    linear(e.self_attn.in_proj, d, 0, 0, 0, 1);                          // K -> image 1
+    linear(e.self_attn.in_proj, 2 * d, 0, 0, 0, 0);                      // V -> image 0 (in place)
+    attn(1, 1, 0, 1, key_mask, S, scale);
+    linear(e.self_attn.out_proj, 0, 0, 1, 1, 0);                         // + Z
+    ln(e.norm1, 0); save();                                              // X1
+    linear(e.lin1, 0, AVLEN_ACT_RELU, 0, 0, 1);
+    linear(e.lin2, 0, 0, 1, 1, 0);
+    ln(e.norm2, 0); ln(tr.enc_norm, 0);                                  // memory tokens in image 0
+    load_cur(goal, d, 1, S); save();                                     // decoder target (one per sample), in place on image 1
+    linear(q.self_attn.in_proj, 2 * d, 0, 0, 1, 1);                      // one target token: self attention == V projection
+    linear(q.self_attn.out_proj, 0, 0, 1, 1, 1);
+    ln(q.norm1, 1); save();                                              // Y1
+    linear(q.cross_attn.in_proj, 0, 0, 0, 1, 1); save(1);                // cross-attention query
+    linear(q.cross_attn.in_proj, d, 0, 0, 0, 1);                         // K(memory) -> image 1
+    linear(q.cross_attn.in_proj, 2 * d, 0, 0, 0, 0);                     // V(memory) -> image 0 (in place)
+    attn(1, 1, 0, 1, key_mask, S, scale);
+    linear(q.cross_attn.out_proj, 0, 0, 1, 1, 0);                        // + Y1
+    ln(q.norm2, 0); save();
+    linear(q.lin1, 0, AVLEN_ACT_RELU, 0, 0, 1);
+    linear(q.lin2, 0, 0, 1, 1, 0);
+    ln(q.norm3, 0); ln(tr.dec_norm, 0);
+    store(out, d, nullptr, 0, S);
+    if (d != 256 || tr.nhead != 8 || e.lin1.out_f != 256 || q.lin1.out_f != 256) ok = false;
+  }
 };
 
 bool chain_enabled() {
@@ -1043,6 +1083,16 @@ int smt_fwd_infer_bf16(const avlen_smt* p, const float* x, const float* memory, 
     ch.ln(q.norm3, 0); ch.ln(tr.dec_norm, 0); ch.store(out, d, nullptr, 0);
     if (ch.ok && e.lin1.out_f == 256 && q.lin1.out_f == 256 && p->fus0.out_f == 256) return avlen_chain_run(&ch.p, B, st);
   }
+  if (!cto && (S == 2 || S == 4) && d == 256 && s.ldxf <= 320 && chain_enabled()) {
+    // a short memory (pi_l: M = 3): the whole state encoder -- fusion MLP, encoder layer, decoder layer -- is one chain
+    // launch; attention runs inside each sample's group of S rows
+    ChainB ch;
+    ch.load_x16(s.XF, s.ldxf, s.ldxf, 0);
+    ch.linear(p->fus0, 0, AVLEN_ACT_RELU, 0, 0, 1);
+    ch.linear(p->fus2, 0, 0, 0, 1, 0); ch.save();                     // Z
+    ch.small_transformer(tr, goal, s.maskx, S, out);
+    if (ch.ok && p->fus0.out_f == 256) return avlen_chain_run(&ch.p, (int)R, st);
+  }
   TRY(linear16(c, p->fus0, s.XF, s.ldxf, nullptr, 0, s.H1, d, (int)R, AVLEN_ACT_RELU, nullptr, 0));
   TRY(linear16(c, p->fus2, s.H1, d, s.tr.Z, d, s.tr.Z16, d, (int)R, 0, nullptr, 0));
   TRY(enc_fwd16(c, tr, s.tr, s.maskx, B, S, cto));
@@ -1091,14 +1141,30 @@ int dialog_fwd_bf16(const avlen_dialog* p, const float* x_att, const float* memo
   WsBump w(ws, ws_bytes); Dlg16Ws s; dlg16_layout(w, s, p, B, M);
   Ctx c{st, AVLEN_PREC_BF16, s.gws, s.gwsb};
   const int S = M + 1, d = p->tr.d; const long R = (long)B * S;
+  const bool small = (S == 2 || S == 4) && d == 256 && chain_enabled();
   if (d_emb) {
     hipLaunchKernelGGL(dialog_build16_kernel, dim3((unsigned)R), dim3(128), 0, st, x_att, memory_state, masks, d_emb, s.SEQ16,
                        (float*)nullptr, 2 * d, s.maskx, B, M, d);
     TRY(linear16(c, p->fus0, s.SEQ16, 2 * d, nullptr, 0, s.H1, d, (int)R, AVLEN_ACT_RELU, nullptr, 0));
+    if (small) {                    // fusion output -> + positional row -> encoder + decoder: one chain launch
+      ChainB ch;
+      ch.load_x16(s.H1, d, d, 0);
+      ch.linear(p->fus2, 0, 0, 0, 0, 1);
+      ch.add_pe(p->pe, p->pe_len, agent_step, S, 0); ch.save();
+      ch.small_transformer(p->tr, goal, s.maskx, S, out);
+      if (ch.ok) return avlen_chain_run(&ch.p, (int)R, st);
+    }
     TRY(linear16(c, p->fus2, s.H1, d, s.tr.Z, d, nullptr, 0, (int)R, 0, nullptr, 0));
   } else {
     hipLaunchKernelGGL(dialog_build16_kernel, dim3((unsigned)R), dim3(128), 0, st, x_att, memory_state, masks,
                        (const float*)nullptr, (bf16*)nullptr, s.tr.Z, d, s.maskx, B, M, d);
+    if (small) {
+      ChainB ch;
+      ch.load_cur(s.tr.Z, d, 0);
+      ch.add_pe(p->pe, p->pe_len, agent_step, S, 0); ch.save();
+      ch.small_transformer(p->tr, goal, s.maskx, S, out);
+      if (ch.ok) { TRY(avlen_launch_status()); return avlen_chain_run(&ch.p, (int)R, st); }
+    }
   }
   hipLaunchKernelGGL(add_pe16_kernel, dim3((unsigned)R), dim3(128), 0, st, s.tr.Z, s.tr.Z16, p->pe, agent_step, S, d, p->pe_len);
   TRY(avlen_launch_status());
