@@ -95,46 +95,54 @@ class Workload:
         self.o_action = torch.zeros(N, device=dev)
         self.o_mask = torch.ones(N, dtype=torch.long, device=dev)
         self.zero_dialog_feats = torch.zeros(N, 256, device=dev)
+        self.zero_probs = torch.zeros(N, 4, device=dev)
+        self._views = {}
         for k in self.rollouts.observations:
             self.rollouts.observations[k][0].copy_(self.sim[k][0])
 
     # -- one rollout step (ppo_trainer.py:375-391, 449, 608-636, 864-888) -----------------------------------
+    def _step_views(self, t):
+        """Every tensor the trainer would slice out of the storage / simulator output at step t (views of persistent
+        buffers, built once per step slot)."""
+        v = self._views.get(t)
+        if v is None:
+            ro = self.rollouts
+            v = dict(obs={k: x[t] for k, x in ro.observations.items()}, h=ro.recurrent_hidden_states[t],
+                     prev=ro.prev_actions[t], masks=ro.masks[t], masks_vln=ro.masks_vln[t],
+                     em_masks=ro.external_memory_masks[t], em_vln_masks=ro.external_memory_vln_masks[t],
+                     qs=self.query_state[t], lqi=self.last_query_info[t], dialog=self.dialog[t], astep=self.agent_step[t],
+                     nxt={k: self.sim[k][t + 1] for k in ro.observations}, rew=self.rewards[t], nd=self.not_done[t],
+                     rl=self.rl_masks[t], ucnt=self.ucnt_gt[t])
+            self._views[t] = v
+        return v
+
     def rollout_step(self):
         ro, t = self.rollouts, self.rollouts.step
-        obs = {k: v[t] for k, v in ro.observations.items()}
-        ro.query_state[t].copy_(self.query_state[t])
-        ro.last_query_info[t].copy_(self.last_query_info[t])
-        h = ro.recurrent_hidden_states[t]
-        em_masks = ro.external_memory_masks[t]
+        v = self._step_views(t)
+        obs, h, prev, em_masks = v["obs"], v["h"], v["prev"], v["em_masks"]
+        em_opt, em_goal = ro.external_memory_option[:, t], ro.external_memory_goal[:, t]
+        em_vln, em_dlg = ro.external_memory_vln[:, t], ro.external_memory_vln_dialog[:, t]
         if self.launch_ahead:
-            self.pi_q.prefetch_act_option(obs, h, ro.prev_actions[t], ro.masks[t], ro.external_memory_option[:, t], em_masks,
-                                          ro.query_state[t], ro.last_query_info[t])
+            self.pi_q.prefetch_act_option(obs, h, prev, v["masks"], em_opt, em_masks, v["qs"], v["lqi"])
             if self.pi_g is not None:
-                self.pi_g.prefetch_act(obs, h, ro.prev_actions[t], ro.masks[t], ro.external_memory_goal[:, t], em_masks,
-                                       stream=self._side[0])
+                self.pi_g.prefetch_act(obs, h, prev, v["masks"], em_goal, em_masks, stream=self._side[0])
             if self.pi_l is not None:
-                self.pi_l.prefetch_act_dialog(obs, h, ro.prev_actions[t], ro.masks_vln[t], ro.external_memory_vln[:, t],
-                                              ro.external_memory_vln_dialog[:, t], ro.external_memory_vln_masks[t],
-                                              self.dialog[t], self.agent_step[t], stream=self._side[1])
+                self.pi_l.prefetch_act_dialog(obs, h, prev, v["masks_vln"], em_vln, em_dlg, v["em_vln_masks"], v["dialog"],
+                                              v["astep"], stream=self._side[1])
         values, unct, a_opt, lp_opt, h, row_opt, probs_opt = self.pi_q.act_option(
-            obs, h, ro.prev_actions[t], ro.masks[t], ro.external_memory_option[:, t], em_masks, ro.query_state[t],
-            ro.last_query_info[t])
+            obs, h, prev, v["masks"], em_opt, em_masks, v["qs"], v["lqi"])
         actions, row_goal, row_vln, row_dlg, probs_vln = a_opt, row_opt[:, :276], row_opt[:, :276], self.zero_dialog_feats, None
         if self.pi_g is not None:
-            _, a_goal, _, _, row_goal, _ = self.pi_g.act(obs, h, ro.prev_actions[t], ro.masks[t],
-                                                           ro.external_memory_goal[:, t], em_masks)
+            _, a_goal, _, _, row_goal, _ = self.pi_g.act(obs, h, prev, v["masks"], em_goal, em_masks)
             actions = a_goal
         if self.pi_l is not None:
             _, a_vln, _, _, row_vln, row_dlg, probs_vln = self.pi_l.act_dialog(
-                obs, h, ro.prev_actions[t], ro.masks_vln[t], ro.external_memory_vln[:, t],
-                ro.external_memory_vln_dialog[:, t], ro.external_memory_vln_masks[t], self.dialog[t], self.agent_step[t])
+                obs, h, prev, v["masks_vln"], em_vln, em_dlg, v["em_vln_masks"], v["dialog"], v["astep"])
             actions = torch.where(a_opt == 1, a_vln, actions)           # queried envs follow pi_l
         if probs_vln is None:
-            probs_vln = torch.zeros(self.N, 4, device=self.dev)
-        nxt = {k: self.sim[k][t + 1] for k in ro.observations}
-        ro.insert(nxt, h, actions, a_opt, lp_opt, values, self.rewards[t], self.not_done[t], self.not_done[t],
-                  row_goal, row_opt, row_vln, row_dlg, self.dialog[t], self.o_action, self.o_mask, self.rl_masks[t],
-                  self.ucnt_gt[t], probs_vln, self.query_state[t], self.last_query_info[t], self.agent_step[t])
+            probs_vln = self.zero_probs
+        ro.insert(v["nxt"], h, actions, a_opt, lp_opt, values, v["rew"], v["nd"], v["nd"], row_goal, row_opt, row_vln, row_dlg,
+                  v["dialog"], self.o_action, self.o_mask, v["rl"], v["ucnt"], probs_vln, v["qs"], v["lqi"], v["astep"])
 
     # -- _update_agent (ppo_trainer.py:1045-1093) -------------------------------------------------------------
     def update(self):

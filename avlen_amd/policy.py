@@ -315,13 +315,17 @@ class Policy(nn.Module):
             if deterministic:
                 action = probs.argmax(dim=-1, keepdim=True)
             elif self.sampling == "host":
+                # == torch.multinomial's exponential race on the host generator; the noise does not depend on the
+                # probabilities, so it is drawn BEFORE waiting for them (same generator order as the reference)
+                q = torch.empty(probs.shape, dtype=probs.dtype).exponential_(1)
                 if out.get("probs_host") is not None:                   # launch-ahead: the copy is already in flight
                     pc, ev = out["probs_host"]
                     ev.synchronize()
                 else:
                     pc = probs.cpu()                                    # sync; (B,A) floats
-                q = torch.empty_like(pc).exponential_(1)                # == torch.multinomial's race
-                action = (pc / q).argmax(-1, keepdim=True).to(dev)
+                ah = self._host_action(B)
+                torch.argmax(pc / q, dim=-1, keepdim=True, out=ah)
+                action = ah.to(dev, non_blocking=True)
             else:
                 q = torch.empty_like(probs).exponential_(1)
                 action = (probs / q).argmax(-1, keepdim=True)
@@ -334,6 +338,14 @@ class Policy(nn.Module):
                    E.P(ent), B, L.stream())
             out.update(action=action, log_prob=logp, entropy_rows=ent)
         return out
+
+    def _host_action(self, B):
+        """Pinned staging buffer for the sampled actions (ring of 8: an upload is consumed long before its slot returns)."""
+        ring = self._pinned.get(("act", B))
+        if ring is None:
+            ring = self._pinned[("act", B)] = [[torch.empty(B, 1, dtype=torch.int64, pin_memory=True) for _ in range(8)], 0]
+        ring[1] = (ring[1] + 1) % 8
+        return ring[0][ring[1]]
 
     def _run_heads(self, which, feats, action=None, deterministic=False, need_sample=True):
         return self._finish(which, feats, self._heads_first(which, feats), action, deterministic, need_sample)
