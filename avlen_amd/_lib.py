@@ -38,7 +38,7 @@ class Linear(C.Structure):
 
 class Conv(C.Structure):
     _fields_ = [("w", f32p), ("b", f32p), ("cin", C.c_int), ("cout", C.c_int), ("kh", C.c_int), ("kw", C.c_int),
-                ("stride", C.c_int), ("pad", C.c_int), ("w16", vp), ("cin16", C.c_int)]
+                ("stride", C.c_int), ("pad", C.c_int), ("w16", vp), ("cin16", C.c_int), ("w16c", vp)]
 
 
 class Affine(C.Structure):

@@ -39,7 +39,7 @@ struct G2 {
   int M, N, K;
   int lda, ldb, ldc32, ldc16, ldr;
   int act;
-  int conv, H, W, Cin, cin_log2, OH, OW, KH, KW, kw_magic, stride, pad;
+  int conv, H, W, Cin, cin_log2, OH, OW, KH, KW, kw_magic, stride, pad, stride_w;   // stride_w: 0 = same as stride
   int splitk, ksteps_per_split;
   int vec4;                   // N, ldc32, ldc16, ldr all multiples of 4: 16-byte / 8-byte epilogue accesses
   // LayerNorm folded into the GEMM (A = raw bf16 rows x, W = bf16(W * gamma)): C = rstd_m * (acc - mean_m * ln_s[n]) + bias[n]
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(NTH) void g2_kernel(G2 pp) {
       int b = mm / ohw, rr = mm - b * ohw;
       int oy = rr / p.OW, ox = rr - oy * p.OW;
       a_src[r] = (const char*)(p.A + (long)b * p.H * p.W * p.Cin);
-      a_iy0[r] = oy * p.stride - p.pad; a_ix0[r] = ox * p.stride - p.pad;
+      a_iy0[r] = oy * p.stride - p.pad; a_ix0[r] = ox * (p.stride_w ? p.stride_w : p.stride) - p.pad;
     } else {
       a_src[r] = (const char*)(p.A + (long)(m < p.M ? m : m % p.M) * p.lda);     // surplus rows re-read distinct valid rows
       a_iy0[r] = 0; a_ix0[r] = 0;
@@ -655,9 +655,9 @@ extern "C" int avlen_conv2d_nhwc_bf16(const void* X, const void* Wp, const float
 // six ResNet towers of the three policies (and the two towers of one policy) as single launches.
 int avlen_conv2d_nhwc_bf16_grouped(const void* const* X, const void* const* Wp, float* const* Y32, void* const* Y16,
                                    float* const* gn_stats, int groups, int Bn, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
-                                   void* ws, size_t ws_bytes, hipStream_t stream, const float* const* bias, int act) {
+                                   void* ws, size_t ws_bytes, hipStream_t stream, const float* const* bias, int act, int stride_w) {
   if (Cin < 8 || (Cin & (Cin - 1)) || groups < 1 || groups > MAXG) return AVLEN_ERR_ARG;
-  int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+  int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / (stride_w ? stride_w : stride) + 1;
   if (OH <= 0 || OW <= 0 || (gn_stats && (OH * OW) % 64)) return AVLEN_ERR_ARG;
   G2 p = {};
   p.groups = groups;
@@ -668,6 +668,7 @@ int avlen_conv2d_nhwc_bf16_grouped(const void* const* X, const void* const* Wp, 
   if (gn_stats && bias) return AVLEN_ERR_ARG;
   p.M = Bn * OH * OW; p.N = Cout; p.K = KH * KW * Cin; p.lda = 8; p.ldb = p.K; p.ldc32 = Cout; p.ldc16 = Cout; p.ldr = Cout;
   p.conv = 1; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
+  p.stride_w = stride_w;
   p.ohw = OH * OW;
   int l2 = 0; while ((1 << l2) < Cin) l2++;
   p.cin_log2 = l2; p.kw_magic = (65536 + KW - 1) / KW;

@@ -22,7 +22,7 @@ int avlen_conv2d_nhwc_bf16_grouped(const void* const* X, const void* const* Wp, 
                                    float* const* gn_stats,
                                    int groups, int Bn, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                                    void* ws, size_t ws_bytes, hipStream_t stream, const float* const* bias = nullptr,
-                                   int act = 0);
+                                   int act = 0, int stride_w = 0);
 int avlen_gemm_bf16_grouped(const void* const* A, int lda, const void* const* B, int ldb, float* const* C32, int ldc32,
                             const float* const* bias, int groups, int M, int N, int K, int act, void* ws, size_t ws_bytes,
                             hipStream_t stream);

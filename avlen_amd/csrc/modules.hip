@@ -520,6 +520,11 @@ void cnn3_dims2(const avlen_cnn3* n, int H, int W, int oh[3], int ow[3]) {
     H = oh[i]; W = ow[i];
   }
 }
+// conv0 in "super-pixel" form (see avlen_conv::w16c): stride pixels x cin channels = one 8-channel pixel
+bool cnn3_superpixel(const avlen_cnn3* n, int W) {
+  const avlen_conv& k = n->conv[0];
+  return k.w16c && k.cin * k.stride == 8 && k.kw % k.stride == 0 && k.pad == 0 && W >= k.kw;
+}
 bool cnn3_has16(const avlen_cnn3* n) { return n->conv[0].w16 && n->conv[1].w16 && n->conv[2].w16 && n->fc.w16; }
 size_t cnn3_ws_bf16(const avlen_cnn3* n, int B, int H, int W) {
   int oh[3], ow[3]; cnn3_dims2(n, H, W, oh, ow);
@@ -544,12 +549,21 @@ int cnn3_fwd_bf16(const avlen_cnn3* n, const float* x, int B, int H, int W, floa
     mx = zmax(mx, avlen_gemm_bf16_workspace_bytes(B * oh[i] * ow[i], n->conv[i].cout));
   }
   void* gws = w.take<char>(mx);
-  TRY(avlen_cast_bf16(x, n->conv[0].cin, x16, 8, (long)B * H * W, n->conv[0].cin, st));     // channel-pad to 8
+  const bool sp = cnn3_superpixel(n, W);
+  const int wsp = sp ? ((ow[0] - 1) * n->conv[0].stride + n->conv[0].kw) / n->conv[0].stride : 0;   // super-pixels per row
+  if (sp) TRY(avlen_cast_bf16(x, W * n->conv[0].cin, x16, wsp * 8, (long)B * H, wsp * 8, st));     // drop the unused columns
+  else TRY(avlen_cast_bf16(x, n->conv[0].cin, x16, 8, (long)B * H * W, n->conv[0].cin, st));         // channel-pad to 8
   const bf16* cur = x16; int h = H, wd = W;
   for (int i = 0; i < 3; i++) {
     const avlen_conv& k = n->conv[i];
-    TRY(avlen_conv2d_nhwc_bf16(cur, k.w16, k.b, nullptr, nullptr, a[i], nullptr, B, h, wd, k.cin16, k.cout, k.kh, k.kw,
-                               k.stride, 0, i < 2 ? AVLEN_ACT_RELU : AVLEN_ACT_NONE, gws, mx, st));
+    if (i == 0 && sp) {
+      const void* X1 = cur; const void* W1 = k.w16c; void* Y1 = a[0]; const float* B1 = k.b;
+      TRY(avlen_conv2d_nhwc_bf16_grouped(&X1, &W1, nullptr, &Y1, nullptr, 1, B, h, wsp, 8, k.cout, k.kh, k.kw / k.stride, k.stride,
+                                         0, gws, mx, st, &B1, AVLEN_ACT_RELU, 1));
+    } else {
+      TRY(avlen_conv2d_nhwc_bf16(cur, k.w16, k.b, nullptr, nullptr, a[i], nullptr, B, h, wd, k.cin16, k.cout, k.kh, k.kw,
+                                 k.stride, 0, i < 2 ? AVLEN_ACT_RELU : AVLEN_ACT_NONE, gws, mx, st));
+    }
     cur = a[i]; h = oh[i]; wd = ow[i];
   }
   return avlen_gemm_bf16(cur, n->fc.ld16, n->fc.w16, n->fc.ld16, out, ld_out, nullptr, 0, n->fc.b, nullptr, 0, B,
@@ -574,17 +588,23 @@ int cnn3_group_fwd_bf16(const avlen_cnn3* const* nets, const float* x, int G, in
   mx *= G;
   void* gws = w.take<char>(mx);
   if (!w.ok()) return AVLEN_ERR_WS;
-  TRY(avlen_cast_bf16(x, n->conv[0].cin, x16, 8, (long)B * H * W, n->conv[0].cin, st));     // channel-pad to 8
+  bool sp = true;
+  for (int g = 0; g < G; g++) sp = sp && cnn3_superpixel(nets[g], W);
+  const int wsp = sp ? ((ow[0] - 1) * n->conv[0].stride + n->conv[0].kw) / n->conv[0].stride : 0;   // super-pixels per row
+  if (sp) TRY(avlen_cast_bf16(x, W * n->conv[0].cin, x16, wsp * 8, (long)B * H, wsp * 8, st));     // drop the unused columns
+  else TRY(avlen_cast_bf16(x, n->conv[0].cin, x16, 8, (long)B * H * W, n->conv[0].cin, st));         // channel-pad to 8
   const void* X[8]; const void* Wt[8]; void* Y[8]; const float* BI[8];
   int h = H, wd = W;
   for (int i = 0; i < 3; i++) {
     const avlen_conv& k = n->conv[i];
+    const bool spi = sp && i == 0;
     for (int g = 0; g < G; g++) {
       X[g] = i == 0 ? (const void*)x16 : (const void*)a[i - 1][g];
-      Wt[g] = nets[g]->conv[i].w16; Y[g] = a[i][g]; BI[g] = nets[g]->conv[i].b;
+      Wt[g] = spi ? nets[g]->conv[i].w16c : nets[g]->conv[i].w16; Y[g] = a[i][g]; BI[g] = nets[g]->conv[i].b;
     }
-    TRY(avlen_conv2d_nhwc_bf16_grouped(X, Wt, nullptr, Y, nullptr, G, B, h, wd, k.cin16, k.cout, k.kh, k.kw, k.stride, 0, gws, mx,
-                                       st, BI, i < 2 ? AVLEN_ACT_RELU : AVLEN_ACT_NONE));
+    TRY(avlen_conv2d_nhwc_bf16_grouped(X, Wt, nullptr, Y, nullptr, G, B, h, spi ? wsp : wd, spi ? 8 : k.cin16, k.cout, k.kh,
+                                       spi ? k.kw / k.stride : k.kw, k.stride, 0, gws, mx, st, BI,
+                                       i < 2 ? AVLEN_ACT_RELU : AVLEN_ACT_NONE, spi ? 1 : 0));
     h = oh[i]; wd = ow[i];
   }
   const void* FA[8]; const void* FB[8]; const float* FBI[8];

@@ -121,6 +121,11 @@ class Packed:
         self.jobs.append(("conv", conv.weight, buf, buf16, (O, I, KH, KW), c16))
         v = L.Conv(P(buf), P(conv.bias) if has_bias else None, I, O, KH, KW, conv.stride[0], conv.padding[0])
         v.w16, v.cin16 = P(buf16), c16
+        if I * conv.stride[0] == 8 and KW % conv.stride[0] == 0 and conv.padding[0] == 0 and I < 8:
+            bufc = torch.empty(O * KH * KW * I, dtype=torch.bfloat16, device=self.device)      # compact: super-pixel form
+            self.bufs.append(bufc)
+            self.jobs.append(("conv16c", conv.weight, None, bufc, (O, I, KH, KW), I))
+            v.w16c = P(bufc)
         return v
 
     def fc_after_flatten(self, lin, C_, HW):
@@ -150,6 +155,8 @@ class Packed:
                 b, g, be, s, c = buf
                 L.call("avlen_ln_fold_weights", P(w), P(b) if b is not None else None, P(g), P(be), P(buf16), dims[1], P(s),
                        P(c), dims[0], dims[1], st)
+            elif kind == "conv16c":
+                L.call("avlen_pack_conv_weight_bf16", P(w), P(buf16), *dims, c16, st)
             elif kind == "conv":
                 L.call("avlen_pack_conv_weight", P(w), P(buf), *dims, st)
                 L.call("avlen_pack_conv_weight_bf16", P(w), P(buf16), *dims, c16, st)

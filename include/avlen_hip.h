@@ -36,7 +36,11 @@ typedef struct ihipStream_t* avlen_stream_t;        /* == hipStream_t */
  * padding zero) used by the bf16 fast path; NULL -> that layer runs on the fp32-staged kernel. */
 typedef struct { float* w; float* b; int out_f; int in_f; void* w16; int ld16; } avlen_linear;
 /* w packed [cout][kh][kw][cin] fp32; w16: bf16 [cout][kh][kw][cin16] with cin16 = max(8, cin) zero-padded. */
-typedef struct { float* w; float* b; int cin, cout, kh, kw, stride, pad; void* w16; int cin16; } avlen_conv;
+/* w16c: optional compact bf16 copy [cout][kh][kw][cin] WITHOUT channel padding, for the "super-pixel" form of a conv whose
+ * cin * stride == 8 and kw % stride == 0 (AudioCNN conv0 on the 257x101 spectrogram, audio_cnn.py:62-83): `stride`
+ * horizontally adjacent pixels x cin channels form one 8-channel pixel, the conv becomes (kh, kw/stride), stride (stride, 1),
+ * K = kh*kw*cin instead of kh*kw*8. */
+typedef struct { float* w; float* b; int cin, cout, kh, kw, stride, pad; void* w16; int cin16; void* w16c; } avlen_conv;
 typedef struct { float* g; float* b; } avlen_affine;                               /* norm scale / shift */
 typedef struct { avlen_conv conv1, conv2, down; avlen_affine bn1, bn2, bnd; int has_down; } avlen_resblock;
 /* CustomResNet (smt_resnet.py:56-149): conv7x7 + GroupNorm(16) + 8 basic blocks + fc(8192->64).

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_sizes_match_header_layout():
     from avlen_amd import _lib
     # pointer,pointer,int,int
-    assert ctypes.sizeof(_lib.Linear) == 40 and ctypes.sizeof(_lib.Conv) == 56 and ctypes.sizeof(_lib.Affine) == 16
+    assert ctypes.sizeof(_lib.Linear) == 40 and ctypes.sizeof(_lib.Conv) == 64 and ctypes.sizeof(_lib.Affine) == 16
     assert ctypes.sizeof(_lib.Mha) == 80
 
 
@@ -47,7 +47,7 @@ def test_struct_sizes_against_c_compiler(tmp_path):
              "avlen_mha": _lib.Mha, "avlen_enc_layer": _lib.EncLayer, "avlen_dec_layer": _lib.DecLayer,
              "avlen_transformer": _lib.Transformer, "avlen_smt": _lib.Smt, "avlen_dialog": _lib.Dialog,
              "avlen_clip_block": _lib.ClipBlock, "avlen_clip_text": _lib.ClipText, "avlen_gru": _lib.Gru,
-             "avlen_heads": _lib.Heads}
+             "avlen_heads": _lib.Heads, "avlen_ln_fold": _lib.LnFold}
     src = tmp_path / "s.c"
     body = "\n".join(f'  printf("{n} %zu\\n", sizeof({n}));' for n in names)
     src.write_text(f'#include <stdio.h>\n#include "avlen_hip.h"\nint main(void) {{\n{body}\n  return 0; }}\n')

@@ -79,6 +79,20 @@ def test_encoders_match_reference(specs):
     close(f2[:, 144:272], golden("enc_audio_257")["out"])
 
 
+def test_audio_encoder_257_bf16_superpixel_conv(specs):
+    """bf16 fast path of the AudioCNN on the 257x101 spectrogram: conv0 (8x8, stride 4, 2 channels) runs in super-pixel
+    form (4 pixels x 2 channels = one 8-channel pixel, K = 128 instead of 512).  Tolerance: bf16 operands, 2e-2 of scale."""
+    pol = build("option", precision="bf16", spectrogram=(257, 101, 2))
+    load_fixture(pol, "option_257", specs)
+    pol.cuda()
+    obs = cu(fx.observations("enc", 2, (257, 101)))
+    f, _ = pol.net.features(pol, obs, torch.zeros(2, 1, dtype=torch.long, device="cuda"),
+                            extra=torch.zeros(2, 32, device="cuda"))
+    ref = golden("enc_audio_257")["out"]
+    err = float(np.abs(f[:, 144:272].cpu().numpy() - ref).max() / np.abs(ref).max())
+    assert err < 2e-2, err
+
+
 @pytest.mark.parametrize("pre", [True, False])
 @pytest.mark.parametrize("M", [4, 300])
 def test_option_policy_matches_reference(specs, pre, M):
