@@ -112,9 +112,11 @@ __global__ __launch_bounds__(NTH) void chain_kernel(DevProg kprog, int B) {
   int ld_idx = 0, ld_kt = 0;           // next tile to issue: Linear index / k block   (ld_idx == n_lin: stream exhausted)
   DevLin ldl = sp->lin[0];
   int issued = 0, consumed = 0;        // tiles issued / tiles whose data has been waited for
+  int st_issue = 0, st_cons = 0;       // their ring stages (issued % NS, consumed % NS)
   auto issue_one = [&]() {             // issue the next tile of the stream, if any
     if (ld_idx >= n_lin) return;
-    char* stage = ring + (issued % NS) * TILE_BYTES;
+    char* stage = ring + st_issue * TILE_BYTES;
+    if (++st_issue == NS) st_issue = 0;
 #if !defined(AVLEN_CHAIN_LAB) || AVLEN_CHAIN_LAB != 2
 #pragma unroll
     for (int r = 0; r < 2; r++) {
@@ -130,8 +132,9 @@ __global__ __launch_bounds__(NTH) void chain_kernel(DevProg kprog, int B) {
   };
   issue_one(); issue_one();            // two tiles ahead from the start
 
+  DevOp op = sp->op[0];
   for (int s = 0; s < n_ops; s++) {
-    const DevOp op = sp->op[s];
+    const DevOp nxt_op = sp->op[s + 1 < n_ops ? s + 1 : s];        // next step's descriptor: in flight during this step
 #ifdef AVLEN_CHAIN_LAB
     if (tid == 0 && blockIdx.x == 0) g_chain_stamps[s] = clock64();
 #endif
@@ -171,15 +174,18 @@ __global__ __launch_bounds__(NTH) void chain_kernel(DevProg kprog, int B) {
           const int ahead = issued - consumed - 1;
           if (ahead >= 2) wait_vmcnt<4>(); else if (ahead == 1) wait_vmcnt<2>(); else wait_vmcnt<0>();
           bar();                                       // everyone's pieces are in LDS; everyone has left the stage reused next
-          const char* stage = ring + (consumed % NS) * TILE_BYTES;
+          const char* stage = ring + st_cons * TILE_BYTES;
+          if (++st_cons == NS) st_cons = 0;
           consumed++;
           issue_one();
 #if !defined(AVLEN_CHAIN_LAB) || AVLEN_CHAIN_LAB != 3
-#pragma unroll
-          for (int kh = 0; kh < 2; kh++) {
-            bf16x8 wf = *reinterpret_cast<const bf16x8*>(stage + wr * 128 + (((kh * 4 + q) ^ wsw) << 4));
-            bf16x8 xf = *reinterpret_cast<const bf16x8*>(xrow + kt * 64 + kh * 32);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc, 0, 0, 0);
+          {                                            // all four fragment reads in flight before the first MFMA
+            bf16x8 wf0 = *reinterpret_cast<const bf16x8*>(stage + wr * 128 + ((q ^ wsw) << 4));
+            bf16x8 wf1 = *reinterpret_cast<const bf16x8*>(stage + wr * 128 + (((4 + q) ^ wsw) << 4));
+            bf16x8 xf0 = *reinterpret_cast<const bf16x8*>(xrow + kt * 64);
+            bf16x8 xf1 = *reinterpret_cast<const bf16x8*>(xrow + kt * 64 + 32);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0, xf0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1, xf1, acc, 0, 0, 0);
           }
 #else
           acc[0] += stage[0];
@@ -317,6 +323,7 @@ __global__ __launch_bounds__(NTH) void chain_kernel(DevProg kprog, int B) {
       }
       default: break;
     }
+    op = nxt_op;
   }
 #ifdef AVLEN_CHAIN_LAB
   if (tid == 0 && blockIdx.x == 0) g_chain_stamps[n_ops] = clock64();

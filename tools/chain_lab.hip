@@ -16,7 +16,7 @@ int main() {
   char* big; hipMalloc(&big, (size_t)512 << 20);
   avlen_chain p; p.n = 0;
   auto add = [&](int kind, int k, int ld, int act, int res, int buf, int ob, const void* p0, const void* p1) {
-    p.op[p.n++] = avlen_chain_op{kind, k, ld, 0, act, res, buf, ob, p0, p1};
+    p.op[p.n++] = avlen_chain_op{kind, k, ld, 0, act, res, buf, ob, 1, 0, 0.f, 0, p0, p1};
   };
   int wi = 0;
   auto lin = [&](int k, int act, int res, int buf, int ob) { add(AVLEN_CH_LINEAR, k, k, act, res, buf, ob, W + (size_t)(wi++) * d * 512 * 2, bias); };
