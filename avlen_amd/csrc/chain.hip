@@ -11,9 +11,9 @@
 //    dynamically indexed kernarg read is a ~300-cycle scalar round trip, and the chain would pay one or more per step;
 //  * every bias / gamma / beta vector is copied into an LDS table by one cooperative pass (a global round trip per step
 //    otherwise sits on the critical path: measured 2.6k of a LayerNorm step's 2.7k cycles).
-// Weights: each step's [256][K] bf16 matrix is streamed through a 3-stage LDS ring of [256][64] tiles by
-// global_load_lds_dwordx4 (1 KiB contiguous per wave-instruction, whole 128-byte lines, XOR swizzle on the source
-// address), and the A fragments are read back with ds_read_b128.  (Fragment-shaped global loads straight to VGPRs,
+// Weights: each step's [256][K] bf16 matrix is streamed through 3-stage LDS rings of [16][64] tiles, one ring per wave (a
+// wave multiplies only its own 16 output features), by global_load_lds_dwordx4 (whole 128-byte lines, XOR swizzle on the
+// source address), and the A fragments are read back with ds_read_b128; the stream itself needs no workgroup barrier.  (Fragment-shaped global loads straight to VGPRs,
 // 16 rows x 64 B per instruction, ran at 13 B/clk per CU: 4.4 us per 128 KiB step.)  The tile stream is continuous ACROSS
 // steps: while a step's epilogue / LayerNorm runs, the first tiles of the next Linear are already in flight (counted
 // s_waitcnt vmcnt, raw s_barrier -- a __syncthreads() would drain them).  LayerNorm reduces inside the lane, across q by
@@ -113,18 +113,21 @@ __global__ __launch_bounds__(NTH) void chain_kernel(DevProg kprog, int B) {
   DevLin ldl = sp->lin[0];
   int issued = 0, consumed = 0;        // tiles issued / tiles whose data has been waited for
   int st_issue = 0, st_cons = 0;       // their ring stages (issued % NS, consumed % NS)
+  // Each wave streams ONLY the 16 weight rows it multiplies (2 KiB per 64-wide k block = two 1 KiB pieces) into a private
+  // 3-stage ring, so the weight stream needs no workgroup barrier at all: the issuing wave's own counted vmcnt orders its
+  // ds_reads behind its LDS-DMA, and the waves drift freely inside a step.
+  char* wring = ring + wave * (NS * 2048);
   auto issue_one = [&]() {             // issue the next tile of the stream, if any
     if (ld_idx >= n_lin) return;
-    char* stage = ring + st_issue * TILE_BYTES;
+    char* stage = wring + st_issue * 2048;
     if (++st_issue == NS) st_issue = 0;
 #if !defined(AVLEN_CHAIN_LAB) || AVLEN_CHAIN_LAB != 2
 #pragma unroll
     for (int r = 0; r < 2; r++) {
-      const int slot = r * NTH + tid, frow = slot >> 3, ch = (slot & 7) ^ ((frow >> 1) & 7);
+      const int frow = n0 + r * 8 + (lane >> 3), ch = (lane & 7) ^ ((frow >> 1) & 7);
       const int kcol = ld_kt * 64 + ch * 8;
       const char* src = kcol < ldl.k ? ldl.w + ((long)frow * ldl.ld + kcol) * 2 : (const char*)g_zero_page_ch + tid * 16;
-      __builtin_amdgcn_global_load_lds((const void*)src,
-          (__attribute__((address_space(3))) void*)(stage + (r * NTH + wave * 64) * 16), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const void*)src, (__attribute__((address_space(3))) void*)(stage + r * 1024), 16, 0, 0);
     }
 #endif
     issued++;
@@ -173,15 +176,14 @@ __global__ __launch_bounds__(NTH) void chain_kernel(DevProg kprog, int B) {
           // tile `consumed` has landed once only the pieces of the tiles issued after it are outstanding
           const int ahead = issued - consumed - 1;
           if (ahead >= 2) wait_vmcnt<4>(); else if (ahead == 1) wait_vmcnt<2>(); else wait_vmcnt<0>();
-          bar();                                       // everyone's pieces are in LDS; everyone has left the stage reused next
-          const char* stage = ring + st_cons * TILE_BYTES;
+          const char* stage = wring + st_cons * 2048;   // private to this wave: no barrier
           if (++st_cons == NS) st_cons = 0;
           consumed++;
           issue_one();
 #if !defined(AVLEN_CHAIN_LAB) || AVLEN_CHAIN_LAB != 3
           {                                            // all four fragment reads in flight before the first MFMA
-            bf16x8 wf0 = *reinterpret_cast<const bf16x8*>(stage + wr * 128 + ((q ^ wsw) << 4));
-            bf16x8 wf1 = *reinterpret_cast<const bf16x8*>(stage + wr * 128 + (((4 + q) ^ wsw) << 4));
+            bf16x8 wf0 = *reinterpret_cast<const bf16x8*>(stage + c * 128 + ((q ^ wsw) << 4));
+            bf16x8 wf1 = *reinterpret_cast<const bf16x8*>(stage + c * 128 + (((4 + q) ^ wsw) << 4));
             bf16x8 xf0 = *reinterpret_cast<const bf16x8*>(xrow + kt * 64);
             bf16x8 xf1 = *reinterpret_cast<const bf16x8*>(xrow + kt * 64 + 32);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0, xf0, acc, 0, 0, 0);
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(NTH) void chain_kernel(DevProg kprog, int B) {
           cur[r] = v;
         }
         if (op.out_buf == op.buf) bar();               // in place: every wave must have finished reading xs[buf]
-        publish(op.out_buf);                           // (the other image was last read before this step's barriers)
+        publish(op.out_buf);                           // (the other image was last read before the previous step's barrier)
         bar();
         break;
       }
