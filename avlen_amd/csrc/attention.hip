@@ -444,6 +444,152 @@ __global__ __launch_bounds__(256) void attn_qkv16_kernel(const __bf16* __restric
   }
 }
 
+// Scene-memory self-attention straight from the packed bf16 projection [R][q | k | v] (D = 32, <= 160 tokens per sample,
+// key-padding mask): same scheme as attn_qkv16_kernel -- transposed scores so P stays in registers, V^T fragments by
+// ds_read_b64_tr_b16 from the row-major V tile -- with one MFMA k-step per score tile (K = D = 32) and up to 10 key tiles.
+__global__ __launch_bounds__(256) void attn_smt16_kernel(const __bf16* __restrict__ QKV, int ld, int koff, int voff,
+                                                         __bf16* __restrict__ O16, int ldo16, int S, float scale,
+                                                         const float* __restrict__ key_mask) {
+  constexpr int D = 32, SKP = 160, KR = 48, NKT = SKP / 16;    // 96-byte LDS rows: conflict-free for both read kinds
+  __shared__ __attribute__((aligned(16))) __bf16 qs[SKP * KR];
+  __shared__ __attribute__((aligned(16))) __bf16 ks[SKP * KR];
+  __shared__ __attribute__((aligned(16))) __bf16 vs[SKP * KR];
+  __shared__ float km[SKP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, q4 = lane >> 4;
+  const int h = blockIdx.x, b = blockIdx.y;
+  const long row0 = (long)b * S;
+  const int S32 = (S + 31) & ~31;
+  for (int i = tid; i < S32 * 4; i += 256) {                   // 4 x 16-byte chunks per 32-wide row
+    const int r = i >> 2, c = i & 3;
+    uint4 qv = make_uint4(0, 0, 0, 0), kv = qv, vv = qv;
+    if (r < S) {
+      const __bf16* base = QKV + (row0 + r) * ld + h * D + c * 8;
+      qv = *reinterpret_cast<const uint4*>(base);
+      kv = *reinterpret_cast<const uint4*>(base + koff);
+      vv = *reinterpret_cast<const uint4*>(base + voff);
+    }
+    *reinterpret_cast<uint4*>(&qs[r * KR + c * 8]) = qv;
+    *reinterpret_cast<uint4*>(&ks[r * KR + c * 8]) = kv;
+    *reinterpret_cast<uint4*>(&vs[r * KR + c * 8]) = vv;
+  }
+  for (int i = tid; i < SKP; i += 256) km[i] = (i < S && (!key_mask || key_mask[(long)b * S + i] != 0.f)) ? 1.f : 0.f;
+  __syncthreads();
+  const int n_kt = (S + 15) >> 4, n_kk = (S + 31) >> 5;
+  for (int mt = wave; mt * 16 < S; mt += 4) {
+    af32x4 sacc[NKT];
+#pragma unroll
+    for (int nt = 0; nt < NKT; nt++) sacc[nt] = (af32x4){0.f, 0.f, 0.f, 0.f};
+    abf16x8 qf = *reinterpret_cast<const abf16x8*>(&qs[(mt * 16 + r16) * KR + q4 * 8]);
+#pragma unroll
+    for (int nt = 0; nt < NKT; nt++)
+      if (nt < n_kt) {
+        abf16x8 kf = *reinterpret_cast<const abf16x8*>(&ks[(nt * 16 + r16) * KR + q4 * 8]);
+        sacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, sacc[nt], 0, 0, 0);      // S^T: rows = keys, cols = queries
+      }
+    const int qi = mt * 16 + r16;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int nt = 0; nt < NKT; nt++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int key = nt * 16 + q4 * 4 + r;
+        const bool ok = nt < n_kt && km[key] != 0.f;
+        const float v = ok ? sacc[nt][r] * scale : -INFINITY;
+        sacc[nt][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NKT; nt++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const float pv = (sacc[nt][r] == -INFINITY) ? 0.f : __expf(sacc[nt][r] - mx);
+        sum += pv; sacc[nt][r] = pv;
+      }
+    sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+    af32x4 oacc[2];
+    oacc[0] = (af32x4){0.f, 0.f, 0.f, 0.f}; oacc[1] = oacc[0];
+#pragma unroll
+    for (int kk = 0; kk < NKT / 2; kk++)
+      if (kk < n_kk) {
+        abf16x8 pf;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { pf[e] = (__bf16)sacc[2 * kk][e]; pf[4 + e] = (__bf16)sacc[2 * kk + 1][e]; }
+        const __bf16* vb = &vs[(kk * 32 + q4 * 4 + (r16 >> 2)) * KR + 4 * (r16 & 3)];
+#pragma unroll
+        for (int dt = 0; dt < 2; dt++) {
+          abf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) abf16x4*)(vb + dt * 16));
+          abf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) abf16x4*)(vb + 16 * KR + dt * 16));
+          abf16x8 vf;
+#pragma unroll
+          for (int e = 0; e < 4; e++) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
+          oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[dt], 0, 0, 0);
+        }
+      }
+    if (qi < S) {
+      const float inv = sum > 0.f ? 1.f / sum : 0.f;
+      __bf16* op = O16 + (row0 + qi) * ldo16 + h * D + q4 * 4;
+#pragma unroll
+      for (int dt = 0; dt < 2; dt++) {
+        abf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; r++) o[r] = (__bf16)(oacc[dt][r] * inv);
+        *reinterpret_cast<abf16x4*>(op + dt * 16) = o;
+      }
+    }
+  }
+}
+
+// One query per (sample, head) over <= 192 masked keys (the decoder's cross attention on the memory tokens), D = 32:
+// one wave per (sample, head); keys across lanes for the scores and the softmax, then output dims across lanes.
+__global__ __launch_bounds__(64) void attn_q1_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ K, int ldk,
+                                                     const float* __restrict__ V, int ldv, __bf16* __restrict__ O16, int ldo16,
+                                                     int Sk, float scale, const float* __restrict__ key_mask) {
+  constexpr int D = 32;
+  __shared__ float p[192];
+  const int lane = threadIdx.x, h = blockIdx.x, b = blockIdx.y;
+  const float* q = Q + (long)b * ldq + h * D;
+  float qv[D];
+#pragma unroll
+  for (int i = 0; i < D / 4; i++) {
+    float4 t = *reinterpret_cast<const float4*>(q + i * 4);
+    qv[4 * i] = t.x; qv[4 * i + 1] = t.y; qv[4 * i + 2] = t.z; qv[4 * i + 3] = t.w;
+  }
+  float sc[3]; float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < 3; t++) {
+    const int j = lane + 64 * t;
+    sc[t] = -INFINITY;
+    if (j < Sk && (!key_mask || key_mask[(long)b * Sk + j] != 0.f)) {
+      const float* kr = K + ((long)b * Sk + j) * ldk + h * D;
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < D / 4; i++) {
+        float4 kv = *reinterpret_cast<const float4*>(kr + i * 4);
+        a += qv[4 * i] * kv.x + qv[4 * i + 1] * kv.y + qv[4 * i + 2] * kv.z + qv[4 * i + 3] * kv.w;
+      }
+      sc[t] = a * scale;
+    }
+    mx = fmaxf(mx, sc[t]);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < 3; t++) { sc[t] = sc[t] == -INFINITY ? 0.f : __expf(sc[t] - mx); sum += sc[t]; }
+  sum = wave_sum(sum);
+  const float inv = sum > 0.f ? 1.f / sum : 0.f;
+#pragma unroll
+  for (int t = 0; t < 3; t++) p[lane + 64 * t] = sc[t] * inv;
+  __syncthreads();
+  // lanes 0-31: even keys, lanes 32-63: odd keys; lane & 31 = output dim
+  const int d = lane & 31, par = lane >> 5;
+  float o = 0.f;
+  for (int j = par; j < Sk; j += 2) o += p[j] * V[((long)b * Sk + j) * ldv + h * D + d];
+  o += __shfl_xor(o, 32, 64);
+  if (lane < 32) O16[(long)b * ldo16 + h * D + d] = (__bf16)o;
+}
+
 // dQ: lane per query (same streaming structure as forward).  Also writes delta = rowsum(dO * O).
 template <int D>
 __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ K,
@@ -573,6 +719,23 @@ int avlen_attention_fwd16(const float* Q, int ldq, const float* K, int ldk, cons
                           int causal, float scale, hipStream_t stream) {
   return avlen_attention_fwd16_seg(Q, ldq, K, ldk, V, ldv, O, ldo, O16, ldo16, key_mask, lse, B, H, Sq, Sk, D, causal, scale,
                                    nullptr, stream);
+}
+
+// SMT self-attention from the packed bf16 projection (D = 32): q | k | v at columns 0 | H*32 | 2*H*32; key_mask [B][S].
+int avlen_attention_smt16(const void* QKV16, int ld, void* O16, int ldo16, int B, int H, int S, float scale,
+                          const float* key_mask, hipStream_t stream) {
+  if (!QKV16 || !O16 || B <= 0 || H <= 0 || S <= 0 || S > 160 || (ld & 7) || (ldo16 & 3)) return AVLEN_ERR_ARG;
+  hipLaunchKernelGGL(attn_smt16_kernel, dim3(H, B), dim3(256), 0, stream, (const __bf16*)QKV16, ld, H * 32, 2 * H * 32,
+                     (__bf16*)O16, ldo16, S, scale, key_mask);
+  return avlen_launch_status();
+}
+// One query per sample (D = 32, fp32 q / k / v): the decoder's cross attention.
+int avlen_attention_q1(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, void* O16, int ldo16, int B,
+                       int H, int Sk, float scale, const float* key_mask, hipStream_t stream) {
+  if (!Q || !K || !V || !O16 || B <= 0 || H <= 0 || Sk <= 0 || Sk > 192 || ((ldq | ldk | ldv) & 3)) return AVLEN_ERR_ARG;
+  hipLaunchKernelGGL(attn_q1_kernel, dim3(H, B), dim3(64), 0, stream, Q, ldq, K, ldk, V, ldv, (__bf16*)O16, ldo16, Sk, scale,
+                     key_mask);
+  return avlen_launch_status();
 }
 
 // Packed bf16 projection [R][ld] with q | k | v at columns 0 | H*64 | 2*H*64 (head h at +64h) -> O16 [R][ldo16].

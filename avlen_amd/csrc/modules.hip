@@ -982,6 +982,9 @@ int enc_fwd16(const Ctx& c, const avlen_transformer& tr, Tr16Ws& t, const float*
   const avlen_enc_layer& e = tr.enc;
   if (cto) {                // one valid key: attention output == V(token)
     TRY(linear16_rows(c, e.self_attn.in_proj, 2 * d, d, t.Z16, d, nullptr, 0, t.AO16, d, (int)R, 0));
+  } else if (D == 32 && S <= 160) {    // packed bf16 q|k|v straight into the MFMA attention
+    TRY(linear16(c, e.self_attn.in_proj, t.Z16, d, nullptr, 0, (bf16*)t.QKV, 3 * d, (int)R, 0, nullptr, 0));
+    TRY(avlen_attention_smt16(t.QKV, 3 * d, t.AO16, d, B, H, S, scale, maskx, c.st));
   } else {
     TRY(linear16(c, e.self_attn.in_proj, t.Z16, d, t.QKV, 3 * d, nullptr, 0, (int)R, 0, nullptr, 0));
     TRY(avlen_attention_fwd16(t.QKV, 3 * d, t.QKV + d, 3 * d, t.QKV + 2 * d, 3 * d, nullptr, 0, t.AO16, d, maskx, nullptr, B,
@@ -1022,8 +1025,11 @@ int dec_fwd16(const Ctx& c, const avlen_transformer& tr, Tr16Ws& t, const float*
     b.ln(q.norm3, 0); b.ln(tr.dec_norm, 0); b.store(out, d, nullptr, 0);
     if (a.ok && b.ok && q.lin1.out_f == 256) {
       TRY(avlen_chain_run(&a.p, B, c.st));
-      TRY(avlen_attention_fwd16(t.Qc, d, t.KVc, 2 * d, t.KVc + d, 2 * d, nullptr, 0, t.AOc16, d, maskx, nullptr, B, H, 1, S, D, 0,
-                                scale, c.st));
+      if (D == 32 && S <= 192)
+        TRY(avlen_attention_q1(t.Qc, d, t.KVc, 2 * d, t.KVc + d, 2 * d, t.AOc16, d, B, H, S, scale, maskx, c.st));
+      else
+        TRY(avlen_attention_fwd16(t.Qc, d, t.KVc, 2 * d, t.KVc + d, 2 * d, nullptr, 0, t.AOc16, d, maskx, nullptr, B, H, 1, S, D,
+                                  0, scale, c.st));
       return avlen_chain_run(&b.p, B, c.st);
     }
   }
