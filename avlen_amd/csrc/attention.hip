@@ -447,17 +447,19 @@ __global__ __launch_bounds__(256) void attn_qkv16_kernel(const __bf16* __restric
 // Scene-memory self-attention straight from the packed bf16 projection [R][q | k | v] (D = 32, <= 160 tokens per sample,
 // key-padding mask): same scheme as attn_qkv16_kernel -- transposed scores so P stays in registers, V^T fragments by
 // ds_read_b64_tr_b16 from the row-major V tile -- with one MFMA k-step per score tile (K = D = 32) and up to 10 key tiles.
+template <int SKP>        // max tokens per sample (160 or 320)
 __global__ __launch_bounds__(256) void attn_smt16_kernel(const __bf16* __restrict__ QKV, int ld, int koff, int voff,
                                                          __bf16* __restrict__ O16, int ldo16, int S, float scale,
-                                                         const float* __restrict__ key_mask) {
-  constexpr int D = 32, SKP = 160, KR = 48, NKT = SKP / 16;    // 96-byte LDS rows: conflict-free for both read kinds
+                                                         const float* __restrict__ key_mask, const int* __restrict__ seg_off) {
+  constexpr int D = 32, KR = 48, NKT = SKP / 16;    // 96-byte LDS rows: conflict-free for both read kinds
   __shared__ __attribute__((aligned(16))) __bf16 qs[SKP * KR];
   __shared__ __attribute__((aligned(16))) __bf16 ks[SKP * KR];
   __shared__ __attribute__((aligned(16))) __bf16 vs[SKP * KR];
   __shared__ float km[SKP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, q4 = lane >> 4;
   const int h = blockIdx.x, b = blockIdx.y;
-  const long row0 = (long)b * S;
+  long row0 = (long)b * S;
+  if (seg_off) { row0 = seg_off[b]; S = min(seg_off[b + 1] - seg_off[b], SKP); key_mask = nullptr; }   // ragged: all tokens live
   const int S32 = (S + 31) & ~31;
   for (int i = tid; i < S32 * 4; i += 256) {                   // 4 x 16-byte chunks per 32-wide row
     const int r = i >> 2, c = i & 3;
@@ -543,12 +545,16 @@ __global__ __launch_bounds__(256) void attn_smt16_kernel(const __bf16* __restric
 
 // One query per (sample, head) over <= 192 masked keys (the decoder's cross attention on the memory tokens), D = 32:
 // one wave per (sample, head); keys across lanes for the scores and the softmax, then output dims across lanes.
+template <int T>          // keys per lane: up to 64*T keys
 __global__ __launch_bounds__(64) void attn_q1_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ K, int ldk,
                                                      const float* __restrict__ V, int ldv, __bf16* __restrict__ O16, int ldo16,
-                                                     int Sk, float scale, const float* __restrict__ key_mask) {
+                                                     int Sk, float scale, const float* __restrict__ key_mask,
+                                                     const int* __restrict__ seg_off) {
   constexpr int D = 32;
-  __shared__ float p[192];
+  __shared__ float p[64 * T];
   const int lane = threadIdx.x, h = blockIdx.x, b = blockIdx.y;
+  long krow0 = (long)b * Sk;
+  if (seg_off) { krow0 = seg_off[b]; Sk = min(seg_off[b + 1] - seg_off[b], 64 * T); key_mask = nullptr; }
   const float* q = Q + (long)b * ldq + h * D;
   float qv[D];
 #pragma unroll
@@ -556,13 +562,13 @@ __global__ __launch_bounds__(64) void attn_q1_kernel(const float* __restrict__ Q
     float4 t = *reinterpret_cast<const float4*>(q + i * 4);
     qv[4 * i] = t.x; qv[4 * i + 1] = t.y; qv[4 * i + 2] = t.z; qv[4 * i + 3] = t.w;
   }
-  float sc[3]; float mx = -INFINITY;
+  float sc[T]; float mx = -INFINITY;
 #pragma unroll
-  for (int t = 0; t < 3; t++) {
+  for (int t = 0; t < T; t++) {
     const int j = lane + 64 * t;
     sc[t] = -INFINITY;
     if (j < Sk && (!key_mask || key_mask[(long)b * Sk + j] != 0.f)) {
-      const float* kr = K + ((long)b * Sk + j) * ldk + h * D;
+      const float* kr = K + (krow0 + j) * ldk + h * D;
       float a = 0.f;
 #pragma unroll
       for (int i = 0; i < D / 4; i++) {
@@ -576,16 +582,16 @@ __global__ __launch_bounds__(64) void attn_q1_kernel(const float* __restrict__ Q
   mx = wave_max(mx);
   float sum = 0.f;
 #pragma unroll
-  for (int t = 0; t < 3; t++) { sc[t] = sc[t] == -INFINITY ? 0.f : __expf(sc[t] - mx); sum += sc[t]; }
+  for (int t = 0; t < T; t++) { sc[t] = sc[t] == -INFINITY ? 0.f : __expf(sc[t] - mx); sum += sc[t]; }
   sum = wave_sum(sum);
   const float inv = sum > 0.f ? 1.f / sum : 0.f;
 #pragma unroll
-  for (int t = 0; t < 3; t++) p[lane + 64 * t] = sc[t] * inv;
+  for (int t = 0; t < T; t++) p[lane + 64 * t] = sc[t] * inv;
   __syncthreads();
   // lanes 0-31: even keys, lanes 32-63: odd keys; lane & 31 = output dim
   const int d = lane & 31, par = lane >> 5;
   float o = 0.f;
-  for (int j = par; j < Sk; j += 2) o += p[j] * V[((long)b * Sk + j) * ldv + h * D + d];
+  for (int j = par; j < Sk; j += 2) o += p[j] * V[(krow0 + j) * ldv + h * D + d];
   o += __shfl_xor(o, 32, 64);
   if (lane < 32) O16[(long)b * ldo16 + h * D + d] = (__bf16)o;
 }
@@ -721,20 +727,35 @@ int avlen_attention_fwd16(const float* Q, int ldq, const float* K, int ldk, cons
                                    nullptr, stream);
 }
 
-// SMT self-attention from the packed bf16 projection (D = 32): q | k | v at columns 0 | H*32 | 2*H*32; key_mask [B][S].
+// SMT self-attention from the packed bf16 projection (D = 32): q | k | v at columns 0 | H*32 | 2*H*32; key_mask [B][S], or
+// seg_off [B+1] for a ragged batch of live tokens (S = upper bound of tokens per sample).
 int avlen_attention_smt16(const void* QKV16, int ld, void* O16, int ldo16, int B, int H, int S, float scale,
-                          const float* key_mask, hipStream_t stream) {
-  if (!QKV16 || !O16 || B <= 0 || H <= 0 || S <= 0 || S > 160 || (ld & 7) || (ldo16 & 3)) return AVLEN_ERR_ARG;
-  hipLaunchKernelGGL(attn_smt16_kernel, dim3(H, B), dim3(256), 0, stream, (const __bf16*)QKV16, ld, H * 32, 2 * H * 32,
-                     (__bf16*)O16, ldo16, S, scale, key_mask);
+                          const float* key_mask, const int* seg_off, hipStream_t stream) {
+  if (!QKV16 || !O16 || B <= 0 || H <= 0 || S <= 0 || S > 320 || (ld & 7) || (ldo16 & 3)) return AVLEN_ERR_ARG;
+  if (S <= 160)
+    hipLaunchKernelGGL(attn_smt16_kernel<160>, dim3(H, B), dim3(256), 0, stream, (const __bf16*)QKV16, ld, H * 32, 2 * H * 32,
+                       (__bf16*)O16, ldo16, S, scale, key_mask, seg_off);
+  else {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_smt16_kernel<320>), hipFuncAttributeMaxDynamicSharedMemorySize, 0);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(attn_smt16_kernel<320>, dim3(H, B), dim3(256), 0, stream, (const __bf16*)QKV16, ld, H * 32, 2 * H * 32,
+                       (__bf16*)O16, ldo16, S, scale, key_mask, seg_off);
+  }
   return avlen_launch_status();
 }
-// One query per sample (D = 32, fp32 q / k / v): the decoder's cross attention.
+// One query per sample (D = 32, fp32 q / k / v): the decoder's cross attention (<= 320 keys per sample).
 int avlen_attention_q1(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, void* O16, int ldo16, int B,
-                       int H, int Sk, float scale, const float* key_mask, hipStream_t stream) {
-  if (!Q || !K || !V || !O16 || B <= 0 || H <= 0 || Sk <= 0 || Sk > 192 || ((ldq | ldk | ldv) & 3)) return AVLEN_ERR_ARG;
-  hipLaunchKernelGGL(attn_q1_kernel, dim3(H, B), dim3(64), 0, stream, Q, ldq, K, ldk, V, ldv, (__bf16*)O16, ldo16, Sk, scale,
-                     key_mask);
+                       int H, int Sk, float scale, const float* key_mask, const int* seg_off, hipStream_t stream) {
+  if (!Q || !K || !V || !O16 || B <= 0 || H <= 0 || Sk <= 0 || Sk > 320 || ((ldq | ldk | ldv) & 3)) return AVLEN_ERR_ARG;
+  if (Sk <= 192)
+    hipLaunchKernelGGL(attn_q1_kernel<3>, dim3(H, B), dim3(64), 0, stream, Q, ldq, K, ldk, V, ldv, (__bf16*)O16, ldo16, Sk, scale,
+                       key_mask, seg_off);
+  else
+    hipLaunchKernelGGL(attn_q1_kernel<5>, dim3(H, B), dim3(64), 0, stream, Q, ldq, K, ldk, V, ldv, (__bf16*)O16, ldo16, Sk, scale,
+                       key_mask, seg_off);
   return avlen_launch_status();
 }
 

@@ -39,9 +39,9 @@ int avlen_gemm_bf16_ln(const void* A, int lda, const void* B, int ldb, float* C3
 int avlen_attention_qkv16(const void* QKV16, int ld, void* O16, int ldo16, int B, int H, int S, int causal, float scale,
                           const int* seg_off, hipStream_t stream);
 int avlen_attention_smt16(const void* QKV16, int ld, void* O16, int ldo16, int B, int H, int S, float scale,
-                          const float* key_mask, hipStream_t stream);
+                          const float* key_mask, const int* seg_off, hipStream_t stream);
 int avlen_attention_q1(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, void* O16, int ldo16, int B,
-                       int H, int Sk, float scale, const float* key_mask, hipStream_t stream);
+                       int H, int Sk, float scale, const float* key_mask, const int* seg_off, hipStream_t stream);
 int avlen_gemm_bf16_dyn(const void* A, int lda, const void* B, int ldb, float* C32, int ldc32, void* C16, int ldc16,
                         const float* bias, const float* residual, int ldr, int M, const int* M_dev, int N, int K, int act,
                         void* ws, size_t ws_bytes, hipStream_t stream);

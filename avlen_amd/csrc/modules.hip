@@ -21,7 +21,7 @@ namespace {
 
 constexpr size_t GEMM_SCRATCH = 96u << 20;       // split-K / accumulate slabs shared by one module call
 
-struct Ctx { hipStream_t st; int prec; void* gws; size_t gws_bytes; };
+struct Ctx { hipStream_t st; int prec; void* gws; size_t gws_bytes; const int* live = nullptr; const int* seg = nullptr; };
 
 // Y[M, out_f] (ldy) = act(X[M, in_f] (ldx) * W^T + b) + res
 int linear(const Ctx& c, const avlen_linear& L, const float* X, int ldx, float* Y, int ldy, int M, int act,
@@ -290,8 +290,15 @@ bool lin16_ok(const avlen_linear& L) { return L.w16 != nullptr && (L.ld16 % 8) =
 // Y = act(X16 * W16^T + b) + res  -> fp32 (Y32) and/or bf16 (Y16)
 int linear16(const Ctx& c, const avlen_linear& L, const bf16* X16, int ldx, float* Y32, int ld32, bf16* Y16, int ld16, int M,
              int act, const float* res, int ldr) {
+  if (c.live)          // ragged batch: only the first *live rows exist
+    return avlen_gemm_bf16_dyn(X16, ldx, L.w16, L.ld16, Y32, ld32, Y16, ld16, L.b, res, ldr, M, c.live, L.out_f, L.ld16, act, c.gws,
+                               c.gws_bytes, c.st);
   return avlen_gemm_bf16(X16, ldx, L.w16, L.ld16, Y32, ld32, Y16, ld16, L.b, res, ldr, M, L.out_f, L.ld16, act, c.gws,
                          c.gws_bytes, c.st);
+}
+int ln16(const Ctx& c, const float* x, const avlen_affine& a, float* y, bf16* y16, int rows, int d) {
+  if (c.live) return avlen_layernorm_fwd16_dyn(x, nullptr, a.g, a.b, y, y16, nullptr, nullptr, rows, c.live, d, 1e-5f, c.st);
+  return avlen_layernorm_fwd16(x, nullptr, a.g, a.b, y, y16, nullptr, nullptr, rows, d, 1e-5f, c.st);
 }
 int linear16_rows(const Ctx& c, const avlen_linear& L, int r0, int n, const bf16* X16, int ldx, float* Y32, int ld32,
                   bf16* Y16, int ld16, int M, int act) {
@@ -365,18 +372,65 @@ struct ChainB {
   }
 };
 
+bool ragged_enabled() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("AVLEN_SMT_RAGGED"); v = e ? atoi(e) : 1; }
+  return v != 0;
+}
+
 bool chain_enabled() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("AVLEN_CHAIN"); v = e ? atoi(e) : 1; }
   return v != 0;
 }
 
+// Live tokens of every sample: the valid memory slots (mask != 0, in slot order) followed by the current token.  Masked slots
+// are dead work for the whole encoder: no other token attends to them (src_key_padding_mask) and the decoder's cross
+// attention skips them (memory_key_padding_mask), smt_state_encoder.py:126-129,186.  seg[b] = first compact row of sample
+// b, seg[B] = number of live rows; rowmap[r] = b*(M+1) + s.  One wave per sample.
+__global__ void smt_segments_kernel(const float* __restrict__ masks, int* __restrict__ seg, int* __restrict__ rowmap, int B,
+                                    int M) {
+  __shared__ int cnt[1024];
+  __shared__ int off[1025];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = blockDim.x >> 6;
+  for (int b = wave; b < B; b += nw) {
+    int n = 0;
+    for (int s0 = 0; s0 < M; s0 += 64) {
+      const int s = s0 + lane;
+      const bool v = s < M && masks[(long)b * M + s] != 0.f;
+      n += __popcll(__ballot(v));
+    }
+    if (lane == 0) cnt[b] = n + 1;
+  }
+  __syncthreads();
+  if (t == 0) { int acc = 0; for (int b = 0; b < B; b++) { off[b] = acc; acc += cnt[b]; } off[B] = acc; }
+  __syncthreads();
+  for (int b = t; b <= B; b += blockDim.x) seg[b] = off[b];
+  for (int b = wave; b < B; b += nw) {
+    int o = off[b];
+    for (int s0 = 0; s0 < M; s0 += 64) {
+      const int s = s0 + lane;
+      const bool v = s < M && masks[(long)b * M + s] != 0.f;
+      const unsigned long long bal = __ballot(v);
+      if (v) rowmap[o + __popcll(bal & ((1ull << lane) - 1ull))] = b * (M + 1) + s;
+      o += __popcll(bal);
+    }
+    if (lane == 0) rowmap[o] = b * (M + 1) + M;
+  }
+}
+
 __global__ void smt_build16_kernel(const float* __restrict__ x, const float* __restrict__ memory,
                                    const int32_t* __restrict__ mem_index, int NC, const float* __restrict__ masks,
                                    const float* __restrict__ pw, const float* __restrict__ pb, bf16* __restrict__ XF, int ldxf,
-                                   float* __restrict__ maskx, int B, int M, int F, int pc, int cto) {
+                                   float* __restrict__ maskx, int B, int M, int F, int pc, int cto,
+                                   const int* __restrict__ seg, const int* __restrict__ rowmap) {
   const int S = cto ? 1 : M + 1;
-  const int row = blockIdx.x, b = row / S, s = cto ? M : row % S;
+  int row = blockIdx.x, b = row / S, s = cto ? M : row % S;
+  if (rowmap) {                       // ragged: compact row -> (sample, slot)
+    if (row >= seg[B]) return;
+    const int rs = rowmap[row];
+    b = rs / S; s = rs - b * S;
+  }
   const int col = mem_index ? mem_index[b] : b;
   const float* src = (s < M) ? memory + ((long)s * NC + col) * F : x + (long)b * F;
   const float* xp = x + (long)b * F + pc;
@@ -392,7 +446,7 @@ __global__ void smt_build16_kernel(const float* __restrict__ x, const float* __r
     float dh = heading_b - heading_a;
     dh = -atan2f(sinf(dh), cosf(dh));
     fmt[0] = r * cosf(phi); fmt[1] = r * sinf(phi); fmt[2] = cosf(dh); fmt[3] = sinf(dh); fmt[4] = expf(-bt);
-    maskx[(long)b * S + (cto ? 0 : s)] = (s < M) ? masks[(long)b * M + s] : 1.f;
+    if (!rowmap) maskx[(long)b * S + (cto ? 0 : s)] = (s < M) ? masks[(long)b * M + s] : 1.f;
   }
   __syncthreads();
   bf16* o = XF + (long)row * ldxf;
@@ -982,21 +1036,21 @@ int enc_fwd16(const Ctx& c, const avlen_transformer& tr, Tr16Ws& t, const float*
   const avlen_enc_layer& e = tr.enc;
   if (cto) {                // one valid key: attention output == V(token)
     TRY(linear16_rows(c, e.self_attn.in_proj, 2 * d, d, t.Z16, d, nullptr, 0, t.AO16, d, (int)R, 0));
-  } else if (D == 32 && S <= 160) {    // packed bf16 q|k|v straight into the MFMA attention
+  } else if (D == 32 && S <= 320) {    // packed bf16 q|k|v straight into the MFMA attention (ragged: live tokens only)
     TRY(linear16(c, e.self_attn.in_proj, t.Z16, d, nullptr, 0, (bf16*)t.QKV, 3 * d, (int)R, 0, nullptr, 0));
-    TRY(avlen_attention_smt16(t.QKV, 3 * d, t.AO16, d, B, H, S, scale, maskx, c.st));
+    TRY(avlen_attention_smt16(t.QKV, 3 * d, t.AO16, d, B, H, S, scale, c.seg ? nullptr : maskx, c.seg, c.st));
   } else {
+    if (c.live) return AVLEN_ERR_ARG;
     TRY(linear16(c, e.self_attn.in_proj, t.Z16, d, t.QKV, 3 * d, nullptr, 0, (int)R, 0, nullptr, 0));
     TRY(avlen_attention_fwd16(t.QKV, 3 * d, t.QKV + d, 3 * d, t.QKV + 2 * d, 3 * d, nullptr, 0, t.AO16, d, maskx, nullptr, B,
                               H, S, S, D, 0, scale, c.st));
   }
   TRY(linear16(c, e.self_attn.out_proj, t.AO16, d, t.T1, d, nullptr, 0, (int)R, 0, t.Z, d));
-  TRY(avlen_layernorm_fwd16(t.T1, nullptr, e.norm1.g, e.norm1.b, t.X1, t.X116, nullptr, nullptr, (int)R, d, 1e-5f, c.st));
+  TRY(ln16(c, t.T1, e.norm1, t.X1, t.X116, (int)R, d));
   TRY(linear16(c, e.lin1, t.X116, d, nullptr, 0, t.F116, d, (int)R, AVLEN_ACT_RELU, nullptr, 0));
   TRY(linear16(c, e.lin2, t.F116, d, t.T2, d, nullptr, 0, (int)R, 0, t.X1, d));
-  TRY(avlen_layernorm_fwd16(t.T2, nullptr, e.norm2.g, e.norm2.b, t.X2, nullptr, nullptr, nullptr, (int)R, d, 1e-5f, c.st));
-  TRY(avlen_layernorm_fwd16(t.X2, nullptr, tr.enc_norm.g, tr.enc_norm.b, nullptr, t.MEM16, nullptr, nullptr, (int)R, d, 1e-5f,
-                            c.st));
+  TRY(ln16(c, t.T2, e.norm2, t.X2, nullptr, (int)R, d));
+  TRY(ln16(c, t.X2, tr.enc_norm, nullptr, t.MEM16, (int)R, d));
   if (cto)                  // cross attention over one valid key == V projection of that token
     return linear16_rows(c, tr.dec.cross_attn.in_proj, 2 * d, d, t.MEM16, d, nullptr, 0, t.AOc16, d, (int)R, 0);
   return linear16_rows(c, tr.dec.cross_attn.in_proj, d, 2 * d, t.MEM16, d, t.KVc, 2 * d, nullptr, 0, (int)R, 0);
@@ -1025,8 +1079,9 @@ int dec_fwd16(const Ctx& c, const avlen_transformer& tr, Tr16Ws& t, const float*
     b.ln(q.norm3, 0); b.ln(tr.dec_norm, 0); b.store(out, d, nullptr, 0);
     if (a.ok && b.ok && q.lin1.out_f == 256) {
       TRY(avlen_chain_run(&a.p, B, c.st));
-      if (D == 32 && S <= 192)
-        TRY(avlen_attention_q1(t.Qc, d, t.KVc, 2 * d, t.KVc + d, 2 * d, t.AOc16, d, B, H, S, scale, maskx, c.st));
+      if (D == 32 && S <= 320)
+        TRY(avlen_attention_q1(t.Qc, d, t.KVc, 2 * d, t.KVc + d, 2 * d, t.AOc16, d, B, H, S, scale, c.seg ? nullptr : maskx, c.seg,
+                               c.st));
       else
         TRY(avlen_attention_fwd16(t.Qc, d, t.KVc, 2 * d, t.KVc + d, 2 * d, nullptr, 0, t.AOc16, d, maskx, nullptr, B, H, 1, S, D,
                                   0, scale, c.st));
@@ -1052,13 +1107,14 @@ int dec_fwd16(const Ctx& c, const avlen_transformer& tr, Tr16Ws& t, const float*
 
 bool smt_has16(const avlen_smt* p) { return lin16_ok(p->fus0) && lin16_ok(p->fus2) && tr_has16(p->tr); }
 
-struct Smt16Ws { bf16 *XF, *H1; float* maskx; Tr16Ws tr; void* gws; size_t gwsb; int ldxf; };
+struct Smt16Ws { bf16 *XF, *H1; float* maskx; Tr16Ws tr; void* gws; size_t gwsb; int ldxf; int *seg, *rowmap; };
 
 void smt16_layout(WsBump& w, Smt16Ws& s, const avlen_smt* p, long B, long M, int F, bool cto) {
   long S = cto ? 1 : M + 1, R = B * S; int d = p->tr.d;
   (void)F;
   s.ldxf = p->fus0.ld16;
   s.XF = w.take<bf16>(R * s.ldxf); s.H1 = w.take<bf16>(R * d); s.maskx = w.take<float>(B * S);
+  s.seg = w.take<int>(B + 1); s.rowmap = w.take<int>(R);
   tr16_layout(w, s.tr, B, S, d, cto);
   s.gwsb = zmax((size_t)(32u << 20), avlen_gemm_bf16_workspace_bytes(128, 768));
   s.gws = w.take<char>(s.gwsb);
@@ -1079,8 +1135,17 @@ int smt_fwd_infer_bf16(const avlen_smt* p, const float* x, const float* memory, 
   const int S = cto ? 1 : M + 1, d = tr.d;
   const long R = (long)B * S;
   if (!mem_index) NC = B;
+  // Ragged mode (memory history in use): only the live tokens -- valid memory slots + the current one -- go through the
+  // fusion MLP, the encoder layer and the decoder's K/V projection; with a 150-slot window of a 300-slot ring that is half
+  // of the rows.  Row counts live on the device (seg[B]); grids are sized for the maximum.
+  const bool ragged = !cto && masks && M > 4 && d / tr.nhead == 32 && S <= 320 && ragged_enabled();
+  if (ragged) {
+    hipLaunchKernelGGL(smt_segments_kernel, dim3(1), dim3(1024), 0, st, masks, s.seg, s.rowmap, B, M);
+    c.live = s.seg + B; c.seg = s.seg;
+  }
   hipLaunchKernelGGL(smt_build16_kernel, dim3((unsigned)R), dim3(128), 0, st, x, memory, mem_index, NC, masks, p->pose.w,
-                     p->pose.b, s.XF, s.ldxf, s.maskx, B, M, F, pose_col, cto ? 1 : 0);
+                     p->pose.b, s.XF, s.ldxf, s.maskx, B, M, F, pose_col, cto ? 1 : 0, ragged ? s.seg : (const int*)nullptr,
+                     ragged ? s.rowmap : (const int*)nullptr);
   TRY(avlen_launch_status());
   if (cto && d == 256 && chain_enabled()) {
     // `current_token_only`: every attention sees one valid key, so the whole encoder + decoder is a chain of row-wise
