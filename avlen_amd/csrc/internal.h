@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include "../../include/avlen_hip.h"
 
 int avlen_groupnorm_nhwc_ws(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
                             int B, int HW, int C, int G, int relu, float eps, float* part, hipStream_t stream);
@@ -72,3 +73,7 @@ bool avlen_dconv_supported(int W, int Cin, int Cout, int KH, int KW, int stride,
 typedef struct { int kind, k, ld, ld2, act, res, buf, out_buf, div, seq; float scale; int pad; const void* p0; const void* p1; } avlen_chain_op;
 typedef struct { int n; avlen_chain_op op[AVLEN_CHAIN_MAX_OPS]; } avlen_chain;
 int avlen_chain_run(const avlen_chain* prog, int B, hipStream_t stream);
+
+// ---- fused layers 3 + 4 of the ResNet towers (tower_tail.hip): one workgroup per image, activations in LDS ----
+int avlen_tower_tail_bf16(const avlen_resnet18* const* nets, const void* const* X, void* const* Y, int groups, int B,
+                          hipStream_t stream);

@@ -527,7 +527,16 @@ int resnet18_group_fwd_bf16(const avlen_resnet18* const* nets, const float* cons
   TRY(gn([](const avlen_resnet18* n) -> const avlen_affine& { return n->bn1; }, raw[0], ST, nullptr, act[0], 4096, 16, 1));
   bf16** cur = act[0]; bf16** a1 = act[1]; bf16** idt = act[2]; bf16** nxt = act[3];
   int H = 64;
+  static int tail = -1;                        // AVLEN_TOWER_TAIL=0: layers 3-4 as separate conv / GroupNorm launches (A/B knob)
+  if (tail < 0) { const char* e = getenv("AVLEN_TOWER_TAIL"); tail = e ? atoi(e) : 1; }
   for (int i = 0; i < 8; i++) {
+    if (i == 4 && tail && H == 32 && G <= 6) {
+      // layers 3 + 4 (four basic blocks): one launch, one workgroup per image, activations resident in LDS
+      for (int g = 0; g < G; g++) { X[g] = cur[g]; OUT[g] = nxt[g]; }
+      int rc = avlen_tower_tail_bf16(nets, X, OUT, G, B, st);
+      if (rc == AVLEN_OK) { cur = nxt; break; }
+      if (rc != AVLEN_ERR_ARG) return rc;      // unsupported channel plan: fall through to the layer-by-layer path
+    }
     const avlen_resblock& k = nets[0]->block[i];
     int s = k.conv1.stride, OH = (H + 2 - 3) / s + 1, Co = k.conv1.cout;
     next_stats(ST); next_stats(ST2);

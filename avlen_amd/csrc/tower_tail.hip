@@ -1,0 +1,327 @@
+// Layers 3 and 4 of the CustomResNet tower (smt_resnet.py:37-53, 100-131) as ONE launch: one workgroup per image keeps every
+// activation of the four basic blocks in LDS (16x16x64 and 8x8x128 bf16 tensors: 32 / 16 KiB each), streams the ten convs'
+// weights from L2 through a global_load_lds ring, takes the GroupNorm statistics from its own fp32 accumulators
+// (deterministic, no atomics: the whole image is in the block) and applies normalisation / residual / ReLU in place.
+// Replaces 10 implicit-GEMM launches + 10 GroupNorm-apply launches per tower group and all their HBM round trips: the
+// image's layer-2 output (64 KiB) is read once, the layer-4 output (16 KiB) written once.
+//
+// Layout of an activation in LDS: [pixel][C] bf16, 16-byte chunks XOR-swizzled by the pixel index so that the 16 pixels of
+// an MFMA row tile (consecutive, or every other one for the stride-2 convs) read conflict-free with ds_read_b128:
+// physical chunk = chunk ^ ((pixel / (16 / CP)) & (CP - 1)), CP = C / 8 chunks per pixel.  Zero padding is a bounds test on
+// the fragment read.  MFMA is issued transposed (W fragment first): a lane ends up with 4 consecutive channels of one
+// pixel -> 8-byte LDS stores.
+#include "common.h"
+#include "../../include/avlen_hip.h"
+#include "internal.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero_page_tt[4096];     // K tails / surplus pieces of the weight tiles
+
+namespace {
+
+constexpr int NTH = 512, NW = 8;
+constexpr int ACT = 32768;                    // one activation buffer (16x16x64 bf16)
+constexpr int RING3 = 4 * ACT;                // layer-3 weight ring: 3 stages of [64][64] (8 KiB) behind the four buffers
+constexpr int RING4 = 3 * ACT;                // layer-4 weight ring: 3 stages of [128][64] (16 KiB) over buffer D + the old ring
+constexpr int SCRATCH3 = RING3 + 3 * 8192;    // 1 KiB landing area of the layer-3 tiles' surplus pieces
+constexpr int STATS = SCRATCH3 + 1024;        // per-wave channel partials [8 waves][64 channels][2] fp32 = 4 KiB
+constexpr int COEF = STATS + 4096;            // scale / shift tables [4][128] fp32 = 2 KiB
+constexpr int LDS_BYTES = COEF + 2048;
+static_assert(RING4 + 3 * 16384 + 1024 <= STATS && LDS_BYTES <= 160 * 1024, "tower tail LDS budget");
+
+struct TailTower { const bf16* x; bf16* y; const bf16* w[10]; const float* g[10]; const float* b[10]; };
+struct TailArgs { TailTower t[6]; };
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void bar() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+template <int CP> __device__ __forceinline__ int swz(int pix) { return (pix / (16 / CP)) & (CP - 1); }
+
+// The weight stream of one layer: five convs back to back, tiles of [COUT][64 k], 3 stages, two 1 KiB pieces per wave and
+// tile (COUT = 64 fills only the first; the second then reads the zero page so that every tile counts the same in vmcnt).
+template <int COUT>
+struct WStream {
+  const bf16* w[5]; int K[5];
+  char* ring; int conv, kt, issued, consumed;
+  __device__ void init(char* r) { ring = r; conv = 0; kt = 0; issued = 0; consumed = 0; }
+  __device__ void issue(int tid, int wave, int lane) {
+    if (conv >= 5) return;
+    char* stage = ring + (issued % 3) * (COUT * 128);
+    // (select chains, not array indexing: a dynamically indexed member array would live in scratch memory)
+    const int Kc = conv == 0 ? K[0] : conv == 1 ? K[1] : conv == 2 ? K[2] : conv == 3 ? K[3] : K[4];
+    const bf16* wc = conv == 0 ? w[0] : conv == 1 ? w[1] : conv == 2 ? w[2] : conv == 3 ? w[3] : w[4];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const int piece = r * NW + wave;                       // 8 weight rows per piece
+      const int row = piece * 8 + (lane >> 3), ch = (lane & 7) ^ ((row >> 1) & 7);
+      const int kcol = kt * 64 + ch * 8;
+      const bool ok = piece * 8 < COUT && kcol < Kc;
+      const char* src = ok ? (const char*)(wc + (long)row * Kc + kcol) : (const char*)g_zero_page_tt + tid * 16;
+      char* dst = piece * 8 < COUT ? stage + piece * 1024 : ring + 3 * (COUT * 128);      // surplus piece: scratch past the ring
+      __builtin_amdgcn_global_load_lds((const void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+    issued++;
+    if (++kt == (Kc + 63) / 64) { kt = 0; conv++; }
+  }
+  __device__ const char* acquire() {                         // wait for the oldest tile in flight, make it visible to the block
+    const int ahead = issued - consumed - 1;
+    if (ahead >= 2) wait_vmcnt<4>(); else if (ahead == 1) wait_vmcnt<2>(); else wait_vmcnt<0>();
+    bar();
+    const char* stage = ring + (consumed % 3) * (COUT * 128);
+    consumed++;
+    return stage;
+  }
+};
+
+// One convolution out of LDS into LDS.  in: [HIN*HIN][CIN] swizzled; out: [HOUT*HOUT][COUT] swizzled (raw conv output, bf16);
+// part: per-wave channel sums of the fp32 accumulators [NW][64 channels of the wave][2].
+template <int CIN, int COUT, int HIN, int HOUT, int KS, int STRIDE>
+__device__ void conv_lds(const char* in, char* out, WStream<COUT>& ws, float* part, int tid) {
+  constexpr int PAD = KS / 2, M = HOUT * HOUT, MT = M / 16, K = KS * KS * CIN, NKT = (K + 63) / 64;
+  constexpr int CPI = CIN / 8, CPO = COUT / 8;
+  constexpr int MI = MT * (COUT / 16) / NW / 4;             // m-tiles per wave; 4 n-tiles per wave
+  static_assert(MI == 1 || MI == 2, "wave tiling");
+  const int lane = tid & 63, wave = tid >> 6, r16 = lane & 15, q4 = lane >> 4;
+  // layer 3 (M = 256, N = 64): wave -> m-tiles 2w, 2w+1, n-tiles 0..3;  layer 4 (M = 64, N = 128): m-tile w & 3, n-tiles 4(w>>2)..
+  const int mt0 = MI == 2 ? wave * 2 : (wave & 3), nt0 = MI == 2 ? 0 : (wave >> 2) * 4;
+  f32x4 acc[MI][4];
+#pragma unroll
+  for (int i = 0; i < MI; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int oy[MI], ox[MI];
+#pragma unroll
+  for (int i = 0; i < MI; i++) { const int p = (mt0 + i) * 16 + r16; oy[i] = p / HOUT; ox[i] = p % HOUT; }
+  for (int kt = 0; kt < NKT; kt++) {
+    const char* stage = ws.acquire();
+    ws.issue(tid, wave, lane);
+#pragma unroll
+    for (int kh = 0; kh < 2; kh++) {
+      const int k = kt * 64 + kh * 32 + q4 * 8;              // this lane's 8 reduction elements: one tap, 8 channels
+      const int tap = k / CIN, c0 = k % CIN;
+      const int ky = tap / KS, kx = tap % KS;
+      bf16x8 af[MI];
+#pragma unroll
+      for (int i = 0; i < MI; i++) {
+        const int iy = oy[i] * STRIDE + ky - PAD, ix = ox[i] * STRIDE + kx - PAD;
+        const bool ok = k < K && (unsigned)iy < (unsigned)HIN && (unsigned)ix < (unsigned)HIN;
+        const int pix = ok ? iy * HIN + ix : 0;
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(in + pix * (CIN * 2) + (((c0 >> 3) ^ swz<CPI>(pix)) << 4));
+        if (!ok) {
+#pragma unroll
+          for (int e = 0; e < 8; e++) v[e] = (bf16)0.f;
+        }
+        af[i] = v;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int wrow = (nt0 + j) * 16 + r16;
+        bf16x8 wf = *reinterpret_cast<const bf16x8*>(stage + wrow * 128 + (((kh * 4 + q4) ^ ((wrow >> 1) & 7)) << 4));
+#pragma unroll
+        for (int i = 0; i < MI; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[i], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+  // lane (r16, q4) holds pixel (mt0+i)*16 + r16, channels (nt0+j)*16 + 4*q4 + r.  Channel sums over the wave's pixels
+  // (reduce-scatter over the 16 pixel lanes), then the raw output as bf16.
+  const bool hi = r16 & 8, hi2 = r16 & 4;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    float v1[4], v2[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int i = 0; i < MI; i++) { const float v = acc[i][j][r]; a += v; b += v * v; }
+      v1[r] = a; v2[r] = b;
+    }
+    float a0 = hi ? v1[2] : v1[0], a1 = hi ? v1[3] : v1[1], b0 = hi ? v1[0] : v1[2], b1 = hi ? v1[1] : v1[3];
+    float c0 = hi ? v2[2] : v2[0], c1 = hi ? v2[3] : v2[1], d0 = hi ? v2[0] : v2[2], d1 = hi ? v2[1] : v2[3];
+    a0 += __shfl_xor(b0, 8, 64); a1 += __shfl_xor(b1, 8, 64); c0 += __shfl_xor(d0, 8, 64); c1 += __shfl_xor(d1, 8, 64);
+    float s1 = hi2 ? a1 : a0, t1 = hi2 ? a0 : a1, s2 = hi2 ? c1 : c0, t2 = hi2 ? c0 : c1;
+    s1 += __shfl_xor(t1, 4, 64); s2 += __shfl_xor(t2, 4, 64);
+    s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
+    s1 += __shfl_xor(s1, 1, 64); s2 += __shfl_xor(s2, 1, 64);
+    const int ch = (nt0 + j) * 16 + q4 * 4 + (hi ? 2 : 0) + (hi2 ? 1 : 0);
+    if ((r16 & 3) == 0) { part[(wave * 64 + ch - nt0 * 16) * 2] = s1; part[(wave * 64 + ch - nt0 * 16) * 2 + 1] = s2; }
+#pragma unroll
+    for (int i = 0; i < MI; i++) {
+      const int pix = (mt0 + i) * 16 + r16, chn = (nt0 + j) * 16 + q4 * 4;
+      bf16x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; r++) o[r] = (bf16)acc[i][j][r];
+      *reinterpret_cast<bf16x4*>(out + pix * (COUT * 2) + (((chn >> 3) ^ swz<CPO>(pix)) << 4) + (chn & 7) * 2) = o;
+    }
+  }
+}
+
+// GroupNorm(16) scale / shift of one raw tensor from the per-wave partial sums (deterministic order).
+template <int COUT, int M, int MI>
+__device__ void gn_coeffs(const float* part, const float* gamma, const float* beta, float* sc, float* sh, int tid) {
+  constexpr int CPG = COUT / 16;
+  if (tid < 16) {
+    double sum = 0.0, sq = 0.0;
+    for (int c = tid * CPG; c < (tid + 1) * CPG; c++)
+      for (int w = 0; w < NW; w++) {
+        // layer 3: every wave covers all channels; layer 4: waves 0-3 cover channels 0-63, waves 4-7 channels 64-127
+        if (MI == 1 && (w >> 2) != (c >> 6)) continue;
+        sum += part[(w * 64 + (c & 63)) * 2]; sq += part[(w * 64 + (c & 63)) * 2 + 1];
+      }
+    const double n = (double)M * CPG, mean = sum / n;
+    double var = sq / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+    for (int c = tid * CPG; c < (tid + 1) * CPG; c++) {
+      const float s = gamma[c] * rstd;
+      sc[c] = s; sh[c] = beta[c] - (float)mean * s;
+    }
+  }
+}
+
+// y = [relu]( x * sc + sh  [+ r * rsc + rsh | + r] ) in place on x, all tensors [M][C] with the same swizzle.
+template <int C, int M>
+__device__ void gn_apply_lds(char* x, const float* sc, const float* sh, const char* res, const float* rsc, const float* rsh,
+                             int relu, int tid) {
+  constexpr int CP = C / 8;
+  for (int i = tid; i < M * CP; i += NTH) {
+    const int pix = i / CP, pc = i % CP, c0 = (pc ^ swz<CP>(pix)) * 8;
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(x + i * 16);
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) f[e] = (float)v[e] * sc[c0 + e] + sh[c0 + e];
+    if (res) {
+      bf16x8 r = *reinterpret_cast<const bf16x8*>(res + i * 16);
+#pragma unroll
+      for (int e = 0; e < 8; e++) f[e] += rsc ? (float)r[e] * rsc[c0 + e] + rsh[c0 + e] : (float)r[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = (bf16)(relu ? fmaxf(f[e], 0.f) : f[e]);
+    *reinterpret_cast<bf16x8*>(x + i * 16) = v;
+  }
+}
+
+// One ResNet stage (two basic blocks, the first with stride 2 and a 1x1 downsample): input in `xin` ([HIN*HIN][CIN]),
+// result in `bufB`.  Buffers A, B, C are [HOUT*HOUT][COUT]; xin may overlap C/D (it is dead after the first two convs).
+template <int CIN, int COUT, int HIN, int HOUT>
+__device__ void stage(const char* xin, char* A, char* B, char* C, WStream<COUT>& ws, const TailTower& t, int base, float* part,
+                      float* sc, float* sh, float* sc2, float* sh2, int tid) {
+  constexpr int M = HOUT * HOUT, MI = (M / 16) * (COUT / 16) / NW / 4;
+  const int wave = tid >> 6, lane = tid & 63;
+  ws.issue(tid, wave, lane); ws.issue(tid, wave, lane);
+  // block 0
+  conv_lds<CIN, COUT, HIN, HOUT, 3, 2>(xin, A, ws, part, tid);                    // conv1 (stride 2)
+  bar();
+  gn_coeffs<COUT, M, MI>(part, t.g[base + 0], t.b[base + 0], sc, sh, tid);
+  bar();
+  conv_lds<CIN, COUT, HIN, HOUT, 1, 2>(xin, B, ws, part, tid);                    // downsample (1x1, stride 2): xin dead after this
+  bar();
+  gn_coeffs<COUT, M, MI>(part, t.g[base + 2], t.b[base + 2], sc2, sh2, tid);      // (the downsample's norm is conv index 2)
+  gn_apply_lds<COUT, M>(A, sc, sh, nullptr, nullptr, nullptr, 1, tid);            // a1 = relu(gn1(raw1))
+  bar();
+  conv_lds<COUT, COUT, HOUT, HOUT, 3, 1>(A, C, ws, part, tid);                    // conv2
+  bar();
+  gn_coeffs<COUT, M, MI>(part, t.g[base + 1], t.b[base + 1], sc, sh, tid);
+  bar();
+  gn_apply_lds<COUT, M>(C, sc, sh, B, sc2, sh2, 1, tid);                          // out0 = relu(gn2(raw2) + gn_d(rawd))  -> C
+  bar();
+  // block 1
+  conv_lds<COUT, COUT, HOUT, HOUT, 3, 1>(C, A, ws, part, tid);
+  bar();
+  gn_coeffs<COUT, M, MI>(part, t.g[base + 3], t.b[base + 3], sc, sh, tid);
+  bar();
+  gn_apply_lds<COUT, M>(A, sc, sh, nullptr, nullptr, nullptr, 1, tid);
+  bar();
+  conv_lds<COUT, COUT, HOUT, HOUT, 3, 1>(A, B, ws, part, tid);
+  bar();
+  gn_coeffs<COUT, M, MI>(part, t.g[base + 4], t.b[base + 4], sc, sh, tid);
+  bar();
+  gn_apply_lds<COUT, M>(B, sc, sh, C, nullptr, nullptr, 1, tid);                  // out1 = relu(gn2(raw) + out0)  -> B
+  bar();
+}
+
+__global__ __launch_bounds__(NTH) void tower_tail_kernel(TailArgs args, int Bn) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const TailTower& t = args.t[blockIdx.y];
+  const int img = blockIdx.x;
+  char* A = lds; char* B = lds + ACT; char* C = lds + 2 * ACT; char* D = lds + 3 * ACT;
+  float* part = reinterpret_cast<float*>(lds + STATS);
+  float* sc = reinterpret_cast<float*>(lds + COEF); float* sh = sc + 128; float* sc2 = sh + 128; float* sh2 = sc2 + 128;
+  // ---- layer-2 output [32*32][32] (64 KiB) -> C..D, swizzled (CP = 4), by LDS-DMA: 64 pieces of 16 pixels
+  {
+    const char* x = (const char*)(t.x + (long)img * 32 * 32 * 32);
+    for (int pc = wave; pc < 64; pc += NW) {
+      const int pix = pc * 16 + (lane >> 2), chunk = (lane & 3) ^ swz<4>(pix);
+      __builtin_amdgcn_global_load_lds((const void*)(x + pix * 64 + chunk * 16),
+          (__attribute__((address_space(3))) void*)(C + pc * 1024), 16, 0, 0);
+    }
+    wait_vmcnt<0>();
+  }
+  bar();
+  {
+    WStream<64> ws; ws.init(lds + RING3);
+    ws.K[0] = 288; ws.K[1] = 32; ws.K[2] = 576; ws.K[3] = 576; ws.K[4] = 576;
+    ws.w[0] = t.w[0]; ws.w[1] = t.w[2]; ws.w[2] = t.w[1]; ws.w[3] = t.w[3]; ws.w[4] = t.w[4];     // stream order: conv1, down, conv2, ...
+    stage<32, 64, 32, 16>(C, A, B, C, ws, t, 0, part, sc, sh, sc2, sh2, tid);
+  }
+  {
+    WStream<128> ws; ws.init(lds + RING4);
+    ws.K[0] = 576; ws.K[1] = 64; ws.K[2] = 1152; ws.K[3] = 1152; ws.K[4] = 1152;
+    ws.w[0] = t.w[5]; ws.w[1] = t.w[7]; ws.w[2] = t.w[6]; ws.w[3] = t.w[8]; ws.w[4] = t.w[9];
+    // layer-4 tensors are 16 KiB: A, A + 16 KiB and C are free (the stage input lives in B)
+    stage<64, 128, 16, 8>(B, A, A + 16384, C, ws, t, 5, part, sc, sh, sc2, sh2, tid);
+  }
+  // ---- layer-4 output (in A + 16 KiB): [64 pixels][128] -> global NHWC, un-swizzled
+  {
+    const char* o = A + 16384;
+    bf16* y = t.y + (long)img * 64 * 128;
+    for (int i = tid; i < 64 * 16; i += NTH) {
+      const int pix = i >> 4, pc = i & 15, c0 = (pc ^ swz<16>(pix)) * 8;
+      *reinterpret_cast<uint4*>(y + pix * 128 + c0) = *reinterpret_cast<const uint4*>(o + i * 16);
+    }
+  }
+  (void)Bn; (void)D;
+}
+
+}  // namespace
+
+// Layers 3 + 4 of `groups` (<= 6) towers: X[g] = layer-2 output NHWC bf16 (B, 32, 32, 32); Y[g] = layer-4 output NHWC bf16
+// (B, 8, 8, 128).  Conv weights bf16 [Cout][kh][kw][Cin] (K contiguous) in block order {conv1, conv2, down} x2 per layer
+// as in avlen_resblock; every tower must have the 32->64->128 channel plan.
+int avlen_tower_tail_bf16(const avlen_resnet18* const* nets, const void* const* X, void* const* Y, int groups, int B,
+                          hipStream_t stream) {
+  if (groups < 1 || groups > 6 || B <= 0) return AVLEN_ERR_ARG;
+  TailArgs a = {};
+  for (int g = 0; g < groups; g++) {
+    const avlen_resnet18* n = nets[g];
+    TailTower& t = a.t[g];
+    t.x = (const bf16*)X[g]; t.y = (bf16*)Y[g];
+    for (int l = 0; l < 2; l++) {                          // l = 0: layer 3 (blocks 4, 5); l = 1: layer 4 (blocks 6, 7)
+      const avlen_resblock& b0 = n->block[4 + 2 * l]; const avlen_resblock& b1 = n->block[5 + 2 * l];
+      const int cin = l == 0 ? 32 : 64, co = l == 0 ? 64 : 128;
+      if (!b0.has_down || b1.has_down || b0.conv1.cin16 != cin || b0.conv1.cout != co || b0.conv1.stride != 2 ||
+          b0.conv2.cin16 != co || b0.down.cin16 != cin || b0.down.kh != 1 || b1.conv1.cin16 != co || b1.conv2.cout != co ||
+          !b0.conv1.w16 || !b0.conv2.w16 || !b0.down.w16 || !b1.conv1.w16 || !b1.conv2.w16)
+        return AVLEN_ERR_ARG;
+      const int o = 5 * l;
+      t.w[o + 0] = (const bf16*)b0.conv1.w16; t.w[o + 1] = (const bf16*)b0.conv2.w16; t.w[o + 2] = (const bf16*)b0.down.w16;
+      t.w[o + 3] = (const bf16*)b1.conv1.w16; t.w[o + 4] = (const bf16*)b1.conv2.w16;
+      t.g[o + 0] = b0.bn1.g; t.b[o + 0] = b0.bn1.b; t.g[o + 1] = b0.bn2.g; t.b[o + 1] = b0.bn2.b;
+      t.g[o + 2] = b0.bnd.g; t.b[o + 2] = b0.bnd.b;
+      t.g[o + 3] = b1.bn1.g; t.b[o + 3] = b1.bn1.b; t.g[o + 4] = b1.bn2.g; t.b[o + 4] = b1.bn2.b;
+    }
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(tower_tail_kernel, dim3(B, groups), dim3(NTH), LDS_BYTES, stream, a, B);
+  return avlen_launch_status();
+}
