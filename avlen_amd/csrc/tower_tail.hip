@@ -21,17 +21,26 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page_tt[4096];     // K tails / surplus pieces of the weight tiles
 
+#ifdef AVLEN_TT_LAB
+__device__ long long g_tt_stamps[64];      // tools/tower_lab.hip: phase time stamps of block (0, 0)
+__device__ int g_tt_n;
+#define TT_STAMP() do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_tt_stamps[g_tt_n++] = clock64(); } while (0)
+#else
+#define TT_STAMP() do {} while (0)
+#endif
+
 namespace {
 
 constexpr int NTH = 512, NW = 8;
 constexpr int ACT = 32768;                    // one activation buffer (16x16x64 bf16)
 constexpr int RING3 = 4 * ACT;                // layer-3 weight ring: 3 stages of [64][64] (8 KiB) behind the four buffers
-constexpr int RING4 = 3 * ACT;                // layer-4 weight ring: 3 stages of [128][64] (16 KiB) over buffer D + the old ring
 constexpr int SCRATCH3 = RING3 + 3 * 8192;    // 1 KiB landing area of the layer-3 tiles' surplus pieces
 constexpr int STATS = SCRATCH3 + 1024;        // per-wave channel partials [8 waves][64 channels][2] fp32 = 4 KiB
 constexpr int COEF = STATS + 4096;            // scale / shift tables [4][128] fp32 = 2 KiB
-constexpr int LDS_BYTES = COEF + 2048;
-static_assert(RING4 + 3 * 16384 + 1024 <= STATS && LDS_BYTES <= 160 * 1024, "tower tail LDS budget");
+constexpr int WTAB = COEF + 2048;             // the ten weight pointers in stream order (an indexed private array would
+constexpr int LDS_BYTES = WTAB + 128;         // live in scratch: a VMEM load + vmcnt(0) per tile drains the whole ring)
+static_assert(2 * ACT + 16384 + 4 * 16384 <= SCRATCH3 && 3 * ACT + 7 * 8192 <= SCRATCH3 && LDS_BYTES <= 160 * 1024,
+              "tower tail LDS budget");
 
 struct TailTower { const bf16* x; bf16* y; const bf16* w[10]; const float* g[10]; const float* b[10]; };
 struct TailArgs { TailTower t[6]; };
@@ -45,17 +54,18 @@ template <int CP> __device__ __forceinline__ int swz(int pix) { return (pix / (1
 
 // The weight stream of one layer: five convs back to back, tiles of [COUT][64 k], 3 stages, two 1 KiB pieces per wave and
 // tile (COUT = 64 fills only the first; the second then reads the zero page so that every tile counts the same in vmcnt).
-template <int COUT>
-struct WStream {
-  const bf16* w[5]; int K[5];
-  char* ring; int conv, kt, issued, consumed;
-  __device__ void init(char* r) { ring = r; conv = 0; kt = 0; issued = 0; consumed = 0; }
-  __device__ void issue(int tid, int wave, int lane) {
-    if (conv >= 5) return;
-    char* stage = ring + (issued % 3) * (COUT * 128);
-    // (select chains, not array indexing: a dynamically indexed member array would live in scratch memory)
-    const int Kc = conv == 0 ? K[0] : conv == 1 ? K[1] : conv == 2 ? K[2] : conv == 3 ? K[3] : K[4];
-    const bf16* wc = conv == 0 ? w[0] : conv == 1 ? w[1] : conv == 2 ? w[2] : conv == 3 ? w[3] : w[4];
+template <int COUT, int NS, int K0, int K1, int K2>     // reduction lengths of the stream's convs: compile-time, or the
+struct WStream {                                          // select below turns into an indexed load from a spilled struct
+  const bf16* const* wt;                                   // weight pointers (LDS table)
+  char* ring; char* scratch; const char* zero; int nconv, conv, kt, issued, consumed;
+  __device__ __forceinline__ void init(char* r, char* scr, int n, const bf16* const* w, const char* z) {
+    ring = r; scratch = scr; zero = z; nconv = n; conv = 0; kt = 0; issued = 0; consumed = 0; wt = w;
+  }
+  __device__ __forceinline__ void issue(int tid, int wave, int lane) {
+    if (conv >= nconv) return;
+    char* stage = ring + (issued % NS) * (COUT * 128);
+    const int Kc = conv == 0 ? K0 : conv == 1 ? K1 : K2;
+    const bf16* wc = wt[conv];                               // LDS read (lgkmcnt): does not touch the VMEM counter
 #pragma unroll
     for (int r = 0; r < 2; r++) {
       const int piece = r * NW + wave;                       // 8 weight rows per piece
@@ -63,17 +73,22 @@ struct WStream {
       const int kcol = kt * 64 + ch * 8;
       const bool ok = piece * 8 < COUT && kcol < Kc;
       const char* src = ok ? (const char*)(wc + (long)row * Kc + kcol) : (const char*)g_zero_page_tt + tid * 16;
-      char* dst = piece * 8 < COUT ? stage + piece * 1024 : ring + 3 * (COUT * 128);      // surplus piece: scratch past the ring
+      char* dst = piece * 8 < COUT ? stage + piece * 1024 : scratch;      // surplus piece (COUT = 64): a scratch KiB
       __builtin_amdgcn_global_load_lds((const void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
     issued++;
     if (++kt == (Kc + 63) / 64) { kt = 0; conv++; }
   }
-  __device__ const char* acquire() {                         // wait for the oldest tile in flight, make it visible to the block
-    const int ahead = issued - consumed - 1;
-    if (ahead >= 2) wait_vmcnt<4>(); else if (ahead == 1) wait_vmcnt<2>(); else wait_vmcnt<0>();
+  __device__ __forceinline__ void prime(int tid, int wave, int lane) {
+    for (int i = 0; i < NS - 1; i++) issue(tid, wave, lane);
+  }
+  __device__ __forceinline__ const char* acquire() {                         // wait for the oldest tile in flight, make it visible to the block
+    const int ahead = issued - consumed - 1;                 // tiles issued after it: 2 pieces each may stay outstanding
+    if (ahead >= 6) wait_vmcnt<12>(); else if (ahead == 5) wait_vmcnt<10>(); else if (ahead == 4) wait_vmcnt<8>();
+    else if (ahead == 3) wait_vmcnt<6>(); else if (ahead == 2) wait_vmcnt<4>(); else if (ahead == 1) wait_vmcnt<2>();
+    else wait_vmcnt<0>();
     bar();
-    const char* stage = ring + (consumed % 3) * (COUT * 128);
+    const char* stage = ring + (consumed % NS) * (COUT * 128);
     consumed++;
     return stage;
   }
@@ -81,8 +96,8 @@ struct WStream {
 
 // One convolution out of LDS into LDS.  in: [HIN*HIN][CIN] swizzled; out: [HOUT*HOUT][COUT] swizzled (raw conv output, bf16);
 // part: per-wave channel sums of the fp32 accumulators [NW][64 channels of the wave][2].
-template <int CIN, int COUT, int HIN, int HOUT, int KS, int STRIDE>
-__device__ void conv_lds(const char* in, char* out, WStream<COUT>& ws, float* part, int tid) {
+template <int CIN, int COUT, int HIN, int HOUT, int KS, int STRIDE, class WS>
+__device__ __forceinline__ void conv_lds(const char* in, char* out, WS& ws, float* part, int tid) {
   constexpr int PAD = KS / 2, M = HOUT * HOUT, MT = M / 16, K = KS * KS * CIN, NKT = (K + 63) / 64;
   constexpr int CPI = CIN / 8, CPO = COUT / 8;
   constexpr int MI = MT * (COUT / 16) / NW / 4;             // m-tiles per wave; 4 n-tiles per wave
@@ -95,29 +110,41 @@ __device__ void conv_lds(const char* in, char* out, WStream<COUT>& ws, float* pa
   for (int i = 0; i < MI; i++)
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  int oy[MI], ox[MI];
+  // Per-lane gather plan, once per conv: for every tap the LDS byte offset of this lane's input pixel (or of a zeroed chunk
+  // when the tap falls into the padding) and the pixel's swizzle.  The K loop below is fully unrolled, so the tap of every
+  // K-step is a compile-time index into these registers and a fragment read costs three VALU ops -- computed per K-step
+  // (div / mod / bounds / swizzle per lane) the address math alone made the conv VALU-bound at ~2k cycles per tile.
+  constexpr int TAPS = KS * KS;
+  int aoff[TAPS][MI], asw[TAPS][MI];
 #pragma unroll
-  for (int i = 0; i < MI; i++) { const int p = (mt0 + i) * 16 + r16; oy[i] = p / HOUT; ox[i] = p % HOUT; }
+  for (int i = 0; i < MI; i++) {
+    const int p = (mt0 + i) * 16 + r16, oy = p / HOUT, ox = p % HOUT;
+#pragma unroll
+    for (int tp = 0; tp < TAPS; tp++) {
+      const int iy = oy * STRIDE + tp / KS - PAD, ix = ox * STRIDE + tp % KS - PAD;
+      const bool ok = (unsigned)iy < (unsigned)HIN && (unsigned)ix < (unsigned)HIN;
+      const int pix = iy * HIN + ix;
+      aoff[tp][i] = ok ? pix * (CIN * 2) : -1;
+      asw[tp][i] = swz<CPI>(pix);
+    }
+  }
+  const char* zero16 = ws.zero;                // a zeroed 16-byte chunk in LDS (padding taps, K tails)
+#pragma unroll
   for (int kt = 0; kt < NKT; kt++) {
     const char* stage = ws.acquire();
     ws.issue(tid, wave, lane);
 #pragma unroll
     for (int kh = 0; kh < 2; kh++) {
-      const int k = kt * 64 + kh * 32 + q4 * 8;              // this lane's 8 reduction elements: one tap, 8 channels
-      const int tap = k / CIN, c0 = k % CIN;
-      const int ky = tap / KS, kx = tap % KS;
+      const int kbase = kt * 64 + kh * 32;                   // compile-time: tap and first channel of this K-step
+      const int tp = kbase / CIN < TAPS ? kbase / CIN : TAPS - 1;
+      const bool live = kbase < K;                           // K tail (layer-3 conv1: 4.5 tiles; 1x1 convs: half a tile)
+      const int cbase = (kbase % CIN) / 8;                   // chunk of channel 0 of the step; this lane adds q4
       bf16x8 af[MI];
 #pragma unroll
       for (int i = 0; i < MI; i++) {
-        const int iy = oy[i] * STRIDE + ky - PAD, ix = ox[i] * STRIDE + kx - PAD;
-        const bool ok = k < K && (unsigned)iy < (unsigned)HIN && (unsigned)ix < (unsigned)HIN;
-        const int pix = ok ? iy * HIN + ix : 0;
-        bf16x8 v = *reinterpret_cast<const bf16x8*>(in + pix * (CIN * 2) + (((c0 >> 3) ^ swz<CPI>(pix)) << 4));
-        if (!ok) {
-#pragma unroll
-          for (int e = 0; e < 8; e++) v[e] = (bf16)0.f;
-        }
-        af[i] = v;
+        const int o = aoff[tp][i];
+        const char* ap = (live && o >= 0) ? in + o + (((cbase + q4) ^ asw[tp][i]) << 4) : zero16;
+        af[i] = *reinterpret_cast<const bf16x8*>(ap);
       }
 #pragma unroll
       for (int j = 0; j < 4; j++) {
@@ -163,7 +190,7 @@ __device__ void conv_lds(const char* in, char* out, WStream<COUT>& ws, float* pa
 
 // GroupNorm(16) scale / shift of one raw tensor from the per-wave partial sums (deterministic order).
 template <int COUT, int M, int MI>
-__device__ void gn_coeffs(const float* part, const float* gamma, const float* beta, float* sc, float* sh, int tid) {
+__device__ __forceinline__ void gn_coeffs(const float* part, const float* gamma, const float* beta, float* sc, float* sh, int tid) {
   constexpr int CPG = COUT / 16;
   if (tid < 16) {
     double sum = 0.0, sq = 0.0;
@@ -186,7 +213,7 @@ __device__ void gn_coeffs(const float* part, const float* gamma, const float* be
 
 // y = [relu]( x * sc + sh  [+ r * rsc + rsh | + r] ) in place on x, all tensors [M][C] with the same swizzle.
 template <int C, int M>
-__device__ void gn_apply_lds(char* x, const float* sc, const float* sh, const char* res, const float* rsc, const float* rsh,
+__device__ __forceinline__ void gn_apply_lds(char* x, const float* sc, const float* sh, const char* res, const float* rsc, const float* rsh,
                              int relu, int tid) {
   constexpr int CP = C / 8;
   for (int i = tid; i < M * CP; i += NTH) {
@@ -208,41 +235,49 @@ __device__ void gn_apply_lds(char* x, const float* sc, const float* sh, const ch
 
 // One ResNet stage (two basic blocks, the first with stride 2 and a 1x1 downsample): input in `xin` ([HIN*HIN][CIN]),
 // result in `bufB`.  Buffers A, B, C are [HOUT*HOUT][COUT]; xin may overlap C/D (it is dead after the first two convs).
-template <int CIN, int COUT, int HIN, int HOUT>
-__device__ void stage(const char* xin, char* A, char* B, char* C, WStream<COUT>& ws, const TailTower& t, int base, float* part,
+template <int CIN, int COUT, int HIN, int HOUT, class WS1, class WS2>
+__device__ __forceinline__ void stage(const char* xin, char* A, char* B, char* C, WS1& ws1, WS2& ws2, const TailTower& t, int base, float* part,
                       float* sc, float* sh, float* sc2, float* sh2, int tid) {
   constexpr int M = HOUT * HOUT, MI = (M / 16) * (COUT / 16) / NW / 4;
   const int wave = tid >> 6, lane = tid & 63;
-  ws.issue(tid, wave, lane); ws.issue(tid, wave, lane);
+  ws1.prime(tid, wave, lane);
+  TT_STAMP();
   // block 0
-  conv_lds<CIN, COUT, HIN, HOUT, 3, 2>(xin, A, ws, part, tid);                    // conv1 (stride 2)
+  conv_lds<CIN, COUT, HIN, HOUT, 3, 2>(xin, A, ws1, part, tid);                   // conv1 (stride 2)
   bar();
+  TT_STAMP();
   gn_coeffs<COUT, M, MI>(part, t.g[base + 0], t.b[base + 0], sc, sh, tid);
   bar();
-  conv_lds<CIN, COUT, HIN, HOUT, 1, 2>(xin, B, ws, part, tid);                    // downsample (1x1, stride 2): xin dead after this
+  conv_lds<CIN, COUT, HIN, HOUT, 1, 2>(xin, B, ws1, part, tid);                   // downsample (1x1, stride 2): xin dead after this
   bar();
-  gn_coeffs<COUT, M, MI>(part, t.g[base + 2], t.b[base + 2], sc2, sh2, tid);      // (the downsample's norm is conv index 2)
+  TT_STAMP();
+  ws2.prime(tid, wave, lane);                                                     // (its ring may overlap xin)
+  gn_coeffs<COUT, M, MI>(part, t.g[base + 2], t.b[base + 2], sc2, sh2, tid);
   gn_apply_lds<COUT, M>(A, sc, sh, nullptr, nullptr, nullptr, 1, tid);            // a1 = relu(gn1(raw1))
   bar();
-  conv_lds<COUT, COUT, HOUT, HOUT, 3, 1>(A, C, ws, part, tid);                    // conv2
+  TT_STAMP();
+  conv_lds<COUT, COUT, HOUT, HOUT, 3, 1>(A, C, ws2, part, tid);                   // conv2
   bar();
+  TT_STAMP();
   gn_coeffs<COUT, M, MI>(part, t.g[base + 1], t.b[base + 1], sc, sh, tid);
   bar();
   gn_apply_lds<COUT, M>(C, sc, sh, B, sc2, sh2, 1, tid);                          // out0 = relu(gn2(raw2) + gn_d(rawd))  -> C
   bar();
+  TT_STAMP();
   // block 1
-  conv_lds<COUT, COUT, HOUT, HOUT, 3, 1>(C, A, ws, part, tid);
+  conv_lds<COUT, COUT, HOUT, HOUT, 3, 1>(C, A, ws2, part, tid);
   bar();
   gn_coeffs<COUT, M, MI>(part, t.g[base + 3], t.b[base + 3], sc, sh, tid);
   bar();
   gn_apply_lds<COUT, M>(A, sc, sh, nullptr, nullptr, nullptr, 1, tid);
   bar();
-  conv_lds<COUT, COUT, HOUT, HOUT, 3, 1>(A, B, ws, part, tid);
+  conv_lds<COUT, COUT, HOUT, HOUT, 3, 1>(A, B, ws2, part, tid);
   bar();
   gn_coeffs<COUT, M, MI>(part, t.g[base + 4], t.b[base + 4], sc, sh, tid);
   bar();
   gn_apply_lds<COUT, M>(B, sc, sh, C, nullptr, nullptr, 1, tid);                  // out1 = relu(gn2(raw) + out0)  -> B
   bar();
+  TT_STAMP();
 }
 
 __global__ __launch_bounds__(NTH) void tower_tail_kernel(TailArgs args, int Bn) {
@@ -253,6 +288,15 @@ __global__ __launch_bounds__(NTH) void tower_tail_kernel(TailArgs args, int Bn) 
   char* A = lds; char* B = lds + ACT; char* C = lds + 2 * ACT; char* D = lds + 3 * ACT;
   float* part = reinterpret_cast<float*>(lds + STATS);
   float* sc = reinterpret_cast<float*>(lds + COEF); float* sh = sc + 128; float* sc2 = sh + 128; float* sh2 = sc2 + 128;
+  const bf16** wtab = reinterpret_cast<const bf16**>(lds + WTAB);
+  if (tid >= 64 && tid < 68) reinterpret_cast<unsigned*>(lds + WTAB + 96)[tid - 64] = 0u;      // the zero chunk
+  if (tid < 10) {                              // stream order: conv1, down, conv2, conv1', conv2' per layer
+    const int r = tid % 5, o = (tid / 5) * 5 + (r == 1 ? 2 : r == 2 ? 1 : r);      // 0,2,1,3,4 | 5,7,6,8,9
+    const bf16* wp = t.w[0];
+#pragma unroll
+    for (int i = 1; i < 10; i++) wp = o == i ? t.w[i] : wp;
+    wtab[tid] = wp;
+  }
   // ---- layer-2 output [32*32][32] (64 KiB) -> C..D, swizzled (CP = 4), by LDS-DMA: 64 pieces of 16 pixels
   {
     const char* x = (const char*)(t.x + (long)img * 32 * 32 * 32);
@@ -264,18 +308,20 @@ __global__ __launch_bounds__(NTH) void tower_tail_kernel(TailArgs args, int Bn) 
     wait_vmcnt<0>();
   }
   bar();
+  TT_STAMP();
   {
-    WStream<64> ws; ws.init(lds + RING3);
-    ws.K[0] = 288; ws.K[1] = 32; ws.K[2] = 576; ws.K[3] = 576; ws.K[4] = 576;
-    ws.w[0] = t.w[0]; ws.w[1] = t.w[2]; ws.w[2] = t.w[1]; ws.w[3] = t.w[3]; ws.w[4] = t.w[4];     // stream order: conv1, down, conv2, ...
-    stage<32, 64, 32, 16>(C, A, B, C, ws, t, 0, part, sc, sh, sc2, sh2, tid);
+    // layer 3: the first two convs read the staged input (C..D) and stream through the 3-stage ring behind the buffers; once
+    // the input is dead, buffer D joins the ring: 7 stages of 8 KiB -- 6 tiles (48 KiB) in flight, which is what it takes to
+    // keep one CU's L2 -> LDS path busy (2 small tiles in flight ran this kernel 2.5x slower: latency-bound)
+    WStream<64, 3, 288, 32, 32> w1; w1.init(lds + RING3, lds + SCRATCH3, 2, wtab, lds + WTAB + 96);
+    WStream<64, 7, 576, 576, 576> w2; w2.init(D, lds + SCRATCH3, 3, wtab + 2, lds + WTAB + 96);
+    stage<32, 64, 32, 16>(C, A, B, C, w1, w2, t, 0, part, sc, sh, sc2, sh2, tid);
   }
   {
-    WStream<128> ws; ws.init(lds + RING4);
-    ws.K[0] = 576; ws.K[1] = 64; ws.K[2] = 1152; ws.K[3] = 1152; ws.K[4] = 1152;
-    ws.w[0] = t.w[5]; ws.w[1] = t.w[7]; ws.w[2] = t.w[6]; ws.w[3] = t.w[8]; ws.w[4] = t.w[9];
-    // layer-4 tensors are 16 KiB: A, A + 16 KiB and C are free (the stage input lives in B)
-    stage<64, 128, 16, 8>(B, A, A + 16384, C, ws, t, 5, part, sc, sh, sc2, sh2, tid);
+    // layer 4 (16 KiB tensors: A, A + 16 KiB, lower half of C; input in B): ring of 4 x 16 KiB from the upper half of C on
+    WStream<128, 4, 576, 64, 64> w1; w1.init(C + 16384, lds + SCRATCH3, 2, wtab + 5, lds + WTAB + 96);
+    WStream<128, 4, 1152, 1152, 1152> w2; w2.init(C + 16384, lds + SCRATCH3, 3, wtab + 7, lds + WTAB + 96);
+    stage<64, 128, 16, 8>(B, A, A + 16384, C, w1, w2, t, 5, part, sc, sh, sc2, sh2, tid);
   }
   // ---- layer-4 output (in A + 16 KiB): [64 pixels][128] -> global NHWC, un-swizzled
   {
