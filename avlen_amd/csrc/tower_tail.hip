@@ -96,10 +96,36 @@ struct WStream {                                          // select below turns 
 
 // One convolution out of LDS into LDS.  in: [HIN*HIN][CIN] swizzled; out: [HOUT*HOUT][COUT] swizzled (raw conv output, bf16);
 // part: per-wave channel sums of the fp32 accumulators [NW][64 channels of the wave][2].
+// Per-lane gather plan of a conv geometry: for every tap the LDS byte offset of this lane's input pixel (-1 when the tap falls
+// into the padding) and the pixel's swizzle.  The K loop of conv_lds is fully unrolled, so the tap of every K-step is a
+// compile-time index into these registers and a fragment read costs three VALU ops -- computed per K-step (div / mod /
+// bounds / swizzle per lane) the address math alone made the conv VALU-bound at ~2k cycles per tile.  The three stride-1
+// 3x3 convs of a stage share one plan.
+template <int TAPS, int MI> struct Plan { int aoff[TAPS][MI], asw[TAPS][MI]; };
+template <int CIN, int COUT, int HIN, int HOUT, int KS, int STRIDE>
+__device__ __forceinline__ void make_plan(Plan<KS * KS, (HOUT * HOUT / 16) * (COUT / 16) / NW / 4>& pl, int tid) {
+  constexpr int PAD = KS / 2, MI = (HOUT * HOUT / 16) * (COUT / 16) / NW / 4, CPI = CIN / 8;
+  const int lane = tid & 63, wave = tid >> 6, r16 = lane & 15;
+  const int mt0 = MI == 2 ? wave * 2 : (wave & 3);
+#pragma unroll
+  for (int i = 0; i < MI; i++) {
+    const int p = (mt0 + i) * 16 + r16, oy = p / HOUT, ox = p % HOUT;
+#pragma unroll
+    for (int tp = 0; tp < KS * KS; tp++) {
+      const int iy = oy * STRIDE + tp / KS - PAD, ix = ox * STRIDE + tp % KS - PAD;
+      const bool ok = (unsigned)iy < (unsigned)HIN && (unsigned)ix < (unsigned)HIN;
+      const int pix = iy * HIN + ix;
+      pl.aoff[tp][i] = ok ? pix * (CIN * 2) : -1;
+      pl.asw[tp][i] = swz<CPI>(pix);
+    }
+  }
+}
+
 template <int CIN, int COUT, int HIN, int HOUT, int KS, int STRIDE, class WS>
-__device__ __forceinline__ void conv_lds(const char* in, char* out, WS& ws, float* part, int tid) {
-  constexpr int PAD = KS / 2, M = HOUT * HOUT, MT = M / 16, K = KS * KS * CIN, NKT = (K + 63) / 64;
-  constexpr int CPI = CIN / 8, CPO = COUT / 8;
+__device__ __forceinline__ void conv_lds(const char* in, char* out, WS& ws, float* part, int tid,
+                                         const Plan<KS * KS, (HOUT * HOUT / 16) * (COUT / 16) / NW / 4>& pl) {
+  constexpr int M = HOUT * HOUT, MT = M / 16, K = KS * KS * CIN, NKT = (K + 63) / 64, TAPS = KS * KS;
+  constexpr int CPO = COUT / 8;
   constexpr int MI = MT * (COUT / 16) / NW / 4;             // m-tiles per wave; 4 n-tiles per wave
   static_assert(MI == 1 || MI == 2, "wave tiling");
   const int lane = tid & 63, wave = tid >> 6, r16 = lane & 15, q4 = lane >> 4;
@@ -110,24 +136,7 @@ __device__ __forceinline__ void conv_lds(const char* in, char* out, WS& ws, floa
   for (int i = 0; i < MI; i++)
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  // Per-lane gather plan, once per conv: for every tap the LDS byte offset of this lane's input pixel (or of a zeroed chunk
-  // when the tap falls into the padding) and the pixel's swizzle.  The K loop below is fully unrolled, so the tap of every
-  // K-step is a compile-time index into these registers and a fragment read costs three VALU ops -- computed per K-step
-  // (div / mod / bounds / swizzle per lane) the address math alone made the conv VALU-bound at ~2k cycles per tile.
-  constexpr int TAPS = KS * KS;
-  int aoff[TAPS][MI], asw[TAPS][MI];
-#pragma unroll
-  for (int i = 0; i < MI; i++) {
-    const int p = (mt0 + i) * 16 + r16, oy = p / HOUT, ox = p % HOUT;
-#pragma unroll
-    for (int tp = 0; tp < TAPS; tp++) {
-      const int iy = oy * STRIDE + tp / KS - PAD, ix = ox * STRIDE + tp % KS - PAD;
-      const bool ok = (unsigned)iy < (unsigned)HIN && (unsigned)ix < (unsigned)HIN;
-      const int pix = iy * HIN + ix;
-      aoff[tp][i] = ok ? pix * (CIN * 2) : -1;
-      asw[tp][i] = swz<CPI>(pix);
-    }
-  }
+  // (gather plan `pl`: see make_plan)
   const char* zero16 = ws.zero;                // a zeroed 16-byte chunk in LDS (padding taps, K tails)
 #pragma unroll
   for (int kt = 0; kt < NKT; kt++) {
@@ -142,8 +151,8 @@ __device__ __forceinline__ void conv_lds(const char* in, char* out, WS& ws, floa
       bf16x8 af[MI];
 #pragma unroll
       for (int i = 0; i < MI; i++) {
-        const int o = aoff[tp][i];
-        const char* ap = (live && o >= 0) ? in + o + (((cbase + q4) ^ asw[tp][i]) << 4) : zero16;
+        const int o = pl.aoff[tp][i];
+        const char* ap = (live && o >= 0) ? in + o + (((cbase + q4) ^ pl.asw[tp][i]) << 4) : zero16;
         af[i] = *reinterpret_cast<const bf16x8*>(ap);
       }
 #pragma unroll
@@ -193,20 +202,19 @@ template <int COUT, int M, int MI>
 __device__ __forceinline__ void gn_coeffs(const float* part, const float* gamma, const float* beta, float* sc, float* sh, int tid) {
   constexpr int CPG = COUT / 16;
   if (tid < 16) {
-    double sum = 0.0, sq = 0.0;
+    float sum = 0.f, sq = 0.f;
     for (int c = tid * CPG; c < (tid + 1) * CPG; c++)
       for (int w = 0; w < NW; w++) {
         // layer 3: every wave covers all channels; layer 4: waves 0-3 cover channels 0-63, waves 4-7 channels 64-127
         if (MI == 1 && (w >> 2) != (c >> 6)) continue;
         sum += part[(w * 64 + (c & 63)) * 2]; sq += part[(w * 64 + (c & 63)) * 2 + 1];
       }
-    const double n = (double)M * CPG, mean = sum / n;
-    double var = sq / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+    const float inv_n = 1.f / (float)(M * CPG), mean = sum * inv_n;
+    const float var = fmaxf(sq * inv_n - mean * mean, 0.f);
+    const float rstd = rsqrtf(var + 1e-5f);
     for (int c = tid * CPG; c < (tid + 1) * CPG; c++) {
       const float s = gamma[c] * rstd;
-      sc[c] = s; sh[c] = beta[c] - (float)mean * s;
+      sc[c] = s; sh[c] = beta[c] - mean * s;
     }
   }
 }
@@ -243,12 +251,18 @@ __device__ __forceinline__ void stage(const char* xin, char* A, char* B, char* C
   ws1.prime(tid, wave, lane);
   TT_STAMP();
   // block 0
-  conv_lds<CIN, COUT, HIN, HOUT, 3, 2>(xin, A, ws1, part, tid);                   // conv1 (stride 2)
+  {
+    Plan<9, MI> p1; make_plan<CIN, COUT, HIN, HOUT, 3, 2>(p1, tid);
+    conv_lds<CIN, COUT, HIN, HOUT, 3, 2>(xin, A, ws1, part, tid, p1);             // conv1 (stride 2)
+  }
   bar();
   TT_STAMP();
   gn_coeffs<COUT, M, MI>(part, t.g[base + 0], t.b[base + 0], sc, sh, tid);
   bar();
-  conv_lds<CIN, COUT, HIN, HOUT, 1, 2>(xin, B, ws1, part, tid);                   // downsample (1x1, stride 2): xin dead after this
+  {
+    Plan<1, MI> pd; make_plan<CIN, COUT, HIN, HOUT, 1, 2>(pd, tid);
+    conv_lds<CIN, COUT, HIN, HOUT, 1, 2>(xin, B, ws1, part, tid, pd);             // downsample (1x1, stride 2): xin dead after this
+  }
   bar();
   TT_STAMP();
   ws2.prime(tid, wave, lane);                                                     // (its ring may overlap xin)
@@ -256,7 +270,8 @@ __device__ __forceinline__ void stage(const char* xin, char* A, char* B, char* C
   gn_apply_lds<COUT, M>(A, sc, sh, nullptr, nullptr, nullptr, 1, tid);            // a1 = relu(gn1(raw1))
   bar();
   TT_STAMP();
-  conv_lds<COUT, COUT, HOUT, HOUT, 3, 1>(A, C, ws2, part, tid);                   // conv2
+  Plan<9, MI> p3; make_plan<COUT, COUT, HOUT, HOUT, 3, 1>(p3, tid);                // shared by the three stride-1 convs
+  conv_lds<COUT, COUT, HOUT, HOUT, 3, 1>(A, C, ws2, part, tid, p3);               // conv2
   bar();
   TT_STAMP();
   gn_coeffs<COUT, M, MI>(part, t.g[base + 1], t.b[base + 1], sc, sh, tid);
@@ -265,13 +280,13 @@ __device__ __forceinline__ void stage(const char* xin, char* A, char* B, char* C
   bar();
   TT_STAMP();
   // block 1
-  conv_lds<COUT, COUT, HOUT, HOUT, 3, 1>(C, A, ws2, part, tid);
+  conv_lds<COUT, COUT, HOUT, HOUT, 3, 1>(C, A, ws2, part, tid, p3);
   bar();
   gn_coeffs<COUT, M, MI>(part, t.g[base + 3], t.b[base + 3], sc, sh, tid);
   bar();
   gn_apply_lds<COUT, M>(A, sc, sh, nullptr, nullptr, nullptr, 1, tid);
   bar();
-  conv_lds<COUT, COUT, HOUT, HOUT, 3, 1>(A, B, ws2, part, tid);
+  conv_lds<COUT, COUT, HOUT, HOUT, 3, 1>(A, B, ws2, part, tid, p3);
   bar();
   gn_coeffs<COUT, M, MI>(part, t.g[base + 4], t.b[base + 4], sc, sh, tid);
   bar();
