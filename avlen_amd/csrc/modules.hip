@@ -501,6 +501,10 @@ int resnet18_group_fwd_bf16(const avlen_resnet18* const* nets, const float* cons
   auto next_stats = [&](float** out) { for (int g = 0; g < G; g++) out[g] = stats_all + ((size_t)g * 21 + si) * stat_stride; si++; };
   for (int g = 0; g < G; g++) {
     if (!resnet18_has16(nets[g]) || channels[g] > 8) return AVLEN_ERR_ARG;
+    int same = -1;                      // towers of different policies read the same image: preprocess it once
+    for (int h = 0; h < g && same < 0; h++)
+      if (imgs[h] == imgs[g] && channels[h] == channels[g] && divisors[h] == divisors[g]) same = h;
+    if (same >= 0) { x0[g] = x0[same]; continue; }
     TRY(avlen_preprocess_image_bf16(imgs[g], x0[g], B, S, channels[g], divisors[g], st));
   }
   const void* X[8]; const void* Wt[8]; void* Y[8]; float* ST[8]; float* ST2[8]; float* ST3[8];
