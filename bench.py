@@ -90,10 +90,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
-    torch.cuda.set_device(local)
+    torch.cuda.set_device(local % torch.cuda.device_count())
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl")                    # RCCL over xGMI
+        # RCCL over xGMI ("nccl"); AVLEN_DIST_BACKEND=gloo rehearses the multi-rank flow on a single-GPU box
+        dist.init_process_group(os.environ.get("AVLEN_DIST_BACKEND", "nccl"))
     from avlen_amd.harness import Workload
     H, W = (int(x) for x in a.spectrogram.split("x"))
     wl = Workload(a.envs, a.rollout, spectrogram=(H, W, 2), precision=a.precision, pretraining=True, seed=rank,
