@@ -164,8 +164,11 @@ __global__ __launch_bounds__(256) void dconv3x3_kernel(DcGroups gg, int B) {
       }
     }
   }
-  // ---- GroupNorm statistics: reduce over the 16 pixel lanes, one atomic per channel per wave
+  // ---- GroupNorm statistics: reduce over the 16 pixel lanes, then over the block's 4 waves in LDS, then ONE atomic
+  // wave-instruction per block (2*CO consecutive floats of stats[b]).  Per-wave atomics (128 four-lane instructions per
+  // block) cost 7 of the kernel's 26 us.
   if (stats) {
+    __shared__ float bst[4][2][CO];
 #pragma unroll
     for (int j = 0; j < NT; j++)
 #pragma unroll
@@ -175,10 +178,15 @@ __global__ __launch_bounds__(256) void dconv3x3_kernel(DcGroups gg, int B) {
         for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
         if (r16 == 0) {
           int ch = j * 16 + q * 4 + r;
-          atomicAdd(&stats[((long)b * 2) * CO + ch], a);
-          atomicAdd(&stats[((long)b * 2 + 1) * CO + ch], c);
+          bst[wave][0][ch] = a; bst[wave][1][ch] = c;
         }
       }
+    __syncthreads();
+    if (tid < 2 * CO) {
+      const int which = tid / CO, ch = tid % CO;
+      const float v = (bst[0][which][ch] + bst[1][which][ch]) + (bst[2][which][ch] + bst[3][which][ch]);
+      atomicAdd(&stats[((long)b * 2 + which) * CO + ch], v);
+    }
   }
 }
 
