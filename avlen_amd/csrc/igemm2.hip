@@ -347,9 +347,12 @@ __global__ __launch_bounds__(NTH) void g2_kernel(G2 pp) {
       }
   }
   if (p.rowstats) {            // per-row (sum, sum of squares) of the final values: the next layer's LayerNorm statistics
+    // wave partials (4 columns x NI tiles per lane, 2 cross-lane moves) -> LDS -> one atomic per row and block: per-wave
+    // atomics were 16-lane instructions, 4 * MI * WN of them per block
+    float* rs = reinterpret_cast<float*>(lds);             // [BM][WN][2]; the staging ring is dead after the K loop
+    __syncthreads();                                       // every wave has left its last fragment reads
 #pragma unroll
     for (int i = 0; i < MI; i++) {
-      int row = m0 + wm * WTM + i * 16 + r16;
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int j = 0; j < NI; j++) {
@@ -359,7 +362,20 @@ __global__ __launch_bounds__(NTH) void g2_kernel(G2 pp) {
       }
       s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
       s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-      if (q == 0 && row < p.M) { atomicAdd(&p.rowstats[(long)row * 2], s1); atomicAdd(&p.rowstats[(long)row * 2 + 1], s2); }
+      if (q == 0) {
+        const int lr = wm * WTM + i * 16 + r16;
+        rs[(lr * WN + wn) * 2] = s1; rs[(lr * WN + wn) * 2 + 1] = s2;
+      }
+    }
+    __syncthreads();
+    for (int t = tid; t < BM * 2; t += NTH) {
+      const int lr = t >> 1, which = t & 1, row = m0 + lr;
+      if (row < p.M) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < WN; w++) v += rs[(lr * WN + w) * 2 + which];
+        atomicAdd(&p.rowstats[(long)row * 2 + which], v);
+      }
     }
   }
   if (LAB(4)) { if (acc[0][0][0] == 123.456f) p.C32[0] = 1.f; return; }
