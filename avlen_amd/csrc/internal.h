@@ -18,7 +18,8 @@ int avlen_preprocess_image_bf16(const float* x, void* y16, int B, int S, int C, 
 int avlen_groupnorm_apply_bf16_grouped(const void* const* x, int raw16, const float* const* stats,
                                        const float* const* gamma, const float* const* beta, const void* const* res16,
                                        void* const* y16, int groups, int B, int HW, int C, int G, int relu, float eps,
-                                       hipStream_t stream);
+                                       hipStream_t stream, const float* const* rstats = nullptr,
+                                       const float* const* rgamma = nullptr, const float* const* rbeta = nullptr, int rrelu = 0);
 int avlen_conv2d_nhwc_bf16_grouped(const void* const* X, const void* const* Wp, float* const* Y32, void* const* Y16,
                                    float* const* gn_stats,
                                    int groups, int Bn, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,

@@ -517,19 +517,34 @@ int resnet18_group_fwd_bf16(const avlen_resnet18* const* nets, const float* cons
     return avlen_conv2d_nhwc_bf16_grouped(X, Wt, nullptr, Y, stt, G, B, H, H, k0.cin16, k0.cout, k0.kh, k0.kw, k0.stride, k0.pad, gws,
                                           gwsb, st);
   };
-  auto gn = [&](auto getn, bf16** rawi, float** stt, bf16** res, bf16** yo, int HW, int C, int relu) -> int {
+  // rn != nullptr: the residual is a RAW conv output normalised on the fly with (rst, rn's affine, rrelu)
+  const float* RGA[8]; const float* RBE[8];
+  auto gn = [&](auto getn, bf16** rawi, float** stt, bf16** res, bf16** yo, int HW, int C, int relu,
+                const avlen_affine* (*rn)(const avlen_resnet18*, int) = nullptr, int rblk = 0, float** rst = nullptr, int rrelu = 0) -> int {
     for (int g = 0; g < G; g++) {
       XR[g] = rawi[g]; GA[g] = getn(nets[g]).g; BE[g] = getn(nets[g]).b; RES[g] = res ? res[g] : nullptr; OUT[g] = yo[g];
+      if (rn) { RGA[g] = rn(nets[g], rblk)->g; RBE[g] = rn(nets[g], rblk)->b; }
     }
     return avlen_groupnorm_apply_bf16_grouped(XR, 1, (const float* const*)stt, GA, BE, res ? RES : nullptr, OUT, G, B, HW, C, 16,
-                                              relu, 1e-5f, st);
+                                              relu, 1e-5f, st, rn ? (const float* const*)rst : nullptr, rn ? RGA : nullptr,
+                                              rn ? RBE : nullptr, rrelu);
   };
   static int fuse_gn = -1;                     // AVLEN_DCONV_FUSE_GN=0: run bn1 as its own pass (A/B knob)
   if (fuse_gn < 0) { const char* e = getenv("AVLEN_DCONV_FUSE_GN"); fuse_gn = e ? atoi(e) : 1; }
-  next_stats(ST);
-  TRY(conv([](const avlen_resnet18* n) -> const avlen_conv& { return n->conv1; }, x0, raw[0], ST, 64));
-  TRY(gn([](const avlen_resnet18* n) -> const avlen_affine& { return n->bn1; }, raw[0], ST, nullptr, act[0], 4096, 16, 1));
-  bf16** cur = act[0]; bf16** a1 = act[1]; bf16** idt = act[2]; bf16** nxt = act[3];
+  auto fuse_gn_on = [&]() { return fuse_gn != 0; };
+  static int resfuse = -1;                     // AVLEN_GN_RESFUSE=0: the stem's bn1 and the downsample norm as their own passes (A/B knob)
+  if (resfuse < 0) { const char* e = getenv("AVLEN_GN_RESFUSE"); resfuse = e ? atoi(e) : 1; }
+  float* STS[8];                               // the stem's statistics outlive block 0 when its norm is applied by the consumers
+  next_stats(STS);
+  const avlen_resblock& kb0 = nets[0]->block[0];
+  // The stem's bn1 + ReLU has two consumers: block 0's conv1 (a direct conv: applied in its halo staging) and block 0's
+  // residual add (applied inside that GroupNorm pass) -- the normalised stem output never exists in HBM.
+  const bool stem_fused = resfuse && fuse_gn_on() && !kb0.has_down && kb0.conv1.cout == 16 && nets[0]->conv1.cout == 16 &&
+                          avlen_dconv_supported(64, kb0.conv1.cin16, kb0.conv1.cout, kb0.conv1.kh, kb0.conv1.kw, kb0.conv1.stride, kb0.conv1.pad);
+  TRY(conv([](const avlen_resnet18* n) -> const avlen_conv& { return n->conv1; }, x0, stem_fused ? raw[2] : raw[0], STS, 64));
+  if (!stem_fused)
+    TRY(gn([](const avlen_resnet18* n) -> const avlen_affine& { return n->bn1; }, raw[0], STS, nullptr, act[0], 4096, 16, 1));
+  bf16** cur = stem_fused ? raw[2] : act[0]; bf16** a1 = act[1]; bf16** idt = act[2]; bf16** nxt = act[3];
   int H = 64;
   static int tail = -1;                        // AVLEN_TOWER_TAIL=0: layers 3-4 as separate conv / GroupNorm launches (A/B knob)
   if (tail < 0) { const char* e = getenv("AVLEN_TOWER_TAIL"); tail = e ? atoi(e) : 1; }
@@ -544,7 +559,15 @@ int resnet18_group_fwd_bf16(const avlen_resnet18* const* nets, const float* cons
     const avlen_resblock& k = nets[0]->block[i];
     int s = k.conv1.stride, OH = (H + 2 - 3) / s + 1, Co = k.conv1.cout;
     next_stats(ST); next_stats(ST2);
-    TRY(conv([i](const avlen_resnet18* n) -> const avlen_conv& { return n->block[i].conv1; }, cur, raw[0], ST, H));
+    const bool raw_in = i == 0 && stem_fused;     // cur is the stem's RAW output
+    if (raw_in) {
+      for (int g = 0; g < G; g++) {
+        X[g] = cur[g]; Wt[g] = nets[g]->block[0].conv1.w16; Y[g] = raw[0][g]; GA[g] = nets[g]->bn1.g; BE[g] = nets[g]->bn1.b;
+      }
+      TRY(avlen_dconv_bf16_grouped(X, Wt, Y, ST, G, B, H, k.conv1.cin16, k.conv1.cout, k.conv1.kh, st, (const float* const*)STS, GA, BE));
+    } else {
+      TRY(conv([i](const avlen_resnet18* n) -> const avlen_conv& { return n->block[i].conv1; }, cur, raw[0], ST, H));
+    }
     const avlen_conv& k2 = k.conv2;
     if (fuse_gn && (Co == 16 || Co == 32) && avlen_dconv_supported(OH, k2.cin16, k2.cout, k2.kh, k2.kw, k2.stride, k2.pad)) {
       // bn1 + ReLU feed conv2 only: applied inside the direct conv's halo staging (no separate pass over the activation)
@@ -558,14 +581,26 @@ int resnet18_group_fwd_bf16(const avlen_resnet18* const* nets, const float* cons
       TRY(conv([i](const avlen_resnet18* n) -> const avlen_conv& { return n->block[i].conv2; }, a1, raw[1], ST2, OH));
     }
     bf16** identity = cur;
+    bool down_fused = false;
     if (k.has_down) {
       next_stats(ST3);
       TRY(conv([i](const avlen_resnet18* n) -> const avlen_conv& { return n->block[i].down; }, cur, raw[2], ST3, H));
-      TRY(gn([i](const avlen_resnet18* n) -> const avlen_affine& { return n->block[i].bnd; }, raw[2], ST3, nullptr, idt, OH * OH, Co, 0));
-      identity = idt;
+      down_fused = resfuse != 0;
+      if (!down_fused)
+        TRY(gn([i](const avlen_resnet18* n) -> const avlen_affine& { return n->block[i].bnd; }, raw[2], ST3, nullptr, idt, OH * OH, Co, 0));
+      identity = down_fused ? raw[2] : idt;
     }
-    TRY(gn([i](const avlen_resnet18* n) -> const avlen_affine& { return n->block[i].bn2; }, raw[1], ST2, identity, nxt, OH * OH, Co, 1));
-    bf16** old = cur; cur = nxt; nxt = old;
+    auto bn2 = [i](const avlen_resnet18* n) -> const avlen_affine& { return n->block[i].bn2; };
+    if (raw_in)
+      TRY(gn(bn2, raw[1], ST2, identity, nxt, OH * OH, Co, 1,
+             [](const avlen_resnet18* n, int) -> const avlen_affine* { return &n->bn1; }, 0, STS, 1));
+    else if (down_fused)
+      TRY(gn(bn2, raw[1], ST2, identity, nxt, OH * OH, Co, 1,
+             [](const avlen_resnet18* n, int blk) -> const avlen_affine* { return &n->block[blk].bnd; }, i, ST3, 0));
+    else
+      TRY(gn(bn2, raw[1], ST2, identity, nxt, OH * OH, Co, 1));
+    if (raw_in) { cur = nxt; nxt = act[0]; }       // raw[2] goes back to being the downsample scratch
+    else { bf16** old = cur; cur = nxt; nxt = old; }
     H = OH;
   }
   const void* FA[8]; const void* FB[8]; const float* FBI[8];

@@ -11,19 +11,36 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8v;
 
 // GroupNorm apply for the bf16 fast path: x = raw fp32 conv output, statistics (per sample/channel sum, sumsq) come
 // from the conv epilogue; y (bf16) = [relu](xhat*g + b [+ res (bf16)]).  8 channels (16 B out) per thread-iteration.
+// RN: the residual is itself a RAW conv output whose own GroupNorm (statistics rstats, affine rgamma / rbeta, optional ReLU)
+// is applied on the fly and rounded to bf16 exactly as a separate apply pass would have stored it -- the stem's bn1 and the
+// downsample branch's norm never make their own trip through HBM.
 struct GnGroups { const void* x[8]; const float* stats[8]; const float* gamma[8]; const float* beta[8];
-                  const __bf16* res[8]; __bf16* y[8]; };
+                  const __bf16* res[8]; __bf16* y[8];
+                  const float* rstats[8]; const float* rgamma[8]; const float* rbeta[8]; };
 
-template <bool RAW16>      // RAW16: the raw conv output is stored in bf16 (statistics were taken from the fp32 accumulators)
+template <bool RAW16, bool RN>      // RAW16: the raw conv output is stored in bf16 (statistics were taken from the fp32 accumulators)
 __global__ __launch_bounds__(256) void gn_apply_bf16_kernel(GnGroups gg, int HW, int C, int G, int splits, int relu,
-                                                            float eps) {
+                                                            float eps, int rrelu) {
   const float* __restrict__ x = (const float*)gg.x[blockIdx.y]; const float* __restrict__ stats = gg.stats[blockIdx.y];
   const __bf16* __restrict__ x16 = (const __bf16*)gg.x[blockIdx.y];
   const float* __restrict__ gamma = gg.gamma[blockIdx.y]; const float* __restrict__ beta = gg.beta[blockIdx.y];
   const __bf16* __restrict__ res = gg.res[blockIdx.y]; __bf16* __restrict__ y = gg.y[blockIdx.y];
-  __shared__ float s_scale[128], s_shift[128];
+  __shared__ float s_scale[128], s_shift[128], s_rscale[RN ? 128 : 1], s_rshift[RN ? 128 : 1];
   const int b = blockIdx.x / splits, sp = blockIdx.x % splits, tid = threadIdx.x;
   const int cg = C / G;
+  if (RN && tid >= 64 && tid < 64 + G) {
+    const int t = tid - 64;
+    const float* st = gg.rstats[blockIdx.y] + (long)b * 2 * C;
+    double sum = 0.0, sq = 0.0;
+    for (int c = t * cg; c < (t + 1) * cg; c++) { sum += st[c]; sq += st[C + c]; }
+    double n = (double)HW * cg, mean = sum / n, var = sq / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    for (int c = t * cg; c < (t + 1) * cg; c++) {
+      float sc = gg.rgamma[blockIdx.y][c] * rstd;
+      s_rscale[c] = sc; s_rshift[c] = gg.rbeta[blockIdx.y][c] - (float)mean * sc;
+    }
+  }
   if (tid < G) {
     const float* st = stats + (long)b * 2 * C;
     double sum = 0.0, sq = 0.0;
@@ -45,6 +62,11 @@ __global__ __launch_bounds__(256) void gn_apply_bf16_kernel(GnGroups gg, int HW,
   float sc[8], sh[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) { sc[i] = s_scale[c0 + i]; sh[i] = s_shift[c0 + i]; }
+  float rsc[8], rsh[8];
+  if constexpr (RN) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) { rsc[i] = s_rscale[c0 + i]; rsh[i] = s_rshift[c0 + i]; }
+  }
   for (long f = beg + tid; f < end; f += 256) {
     float v[8];
     if constexpr (RAW16) {
@@ -58,6 +80,13 @@ __global__ __launch_bounds__(256) void gn_apply_bf16_kernel(GnGroups gg, int HW,
     }
     if (res) {
       bf16x8v r = *reinterpret_cast<const bf16x8v*>(res + base + f * 8);
+      if constexpr (RN) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          float t = (float)r[i] * rsc[i] + rsh[i];
+          r[i] = (__bf16)(rrelu ? fmaxf(t, 0.f) : t);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 8; i++) v[i] = v[i] * sc[i] + sh[i] + (float)r[i];
     } else {
@@ -355,7 +384,9 @@ extern "C" int avlen_layernorm_fwd(const float* x, const float* residual, const 
 int avlen_groupnorm_apply_bf16_grouped(const void* const* x, int raw16, const float* const* stats,
                                        const float* const* gamma, const float* const* beta, const void* const* res16,
                                        void* const* y16, int groups, int B, int HW, int C, int G, int relu, float eps,
-                                       hipStream_t stream) {
+                                       hipStream_t stream, const float* const* rstats, const float* const* rgamma,
+                                       const float* const* rbeta, int rrelu) {
+  if (rstats && (!res16 || !raw16 || G > 64)) return AVLEN_ERR_ARG;
   if (C > 128 || C % 8 || 2048 % C || C % G || groups < 1 || groups > 8) return AVLEN_ERR_ARG;
   long n8 = (long)HW * C / 8;
   int splits = 1;
@@ -364,11 +395,14 @@ int avlen_groupnorm_apply_bf16_grouped(const void* const* x, int raw16, const fl
   for (int g = 0; g < groups; g++) {
     gg.x[g] = x[g]; gg.stats[g] = stats[g]; gg.gamma[g] = gamma[g]; gg.beta[g] = beta[g];
     gg.res[g] = res16 ? (const __bf16*)res16[g] : nullptr; gg.y[g] = (__bf16*)y16[g];
+    if (rstats) { gg.rstats[g] = rstats[g]; gg.rgamma[g] = rgamma[g]; gg.rbeta[g] = rbeta[g]; }
   }
-  if (raw16)
-    hipLaunchKernelGGL((gn_apply_bf16_kernel<true>), dim3(B * splits, groups), dim3(256), 0, stream, gg, HW, C, G, splits, relu, eps);
+  if (rstats)
+    hipLaunchKernelGGL((gn_apply_bf16_kernel<true, true>), dim3(B * splits, groups), dim3(256), 0, stream, gg, HW, C, G, splits, relu, eps, rrelu);
+  else if (raw16)
+    hipLaunchKernelGGL((gn_apply_bf16_kernel<true, false>), dim3(B * splits, groups), dim3(256), 0, stream, gg, HW, C, G, splits, relu, eps, 0);
   else
-    hipLaunchKernelGGL((gn_apply_bf16_kernel<false>), dim3(B * splits, groups), dim3(256), 0, stream, gg, HW, C, G, splits, relu, eps);
+    hipLaunchKernelGGL((gn_apply_bf16_kernel<false, false>), dim3(B * splits, groups), dim3(256), 0, stream, gg, HW, C, G, splits, relu, eps, 0);
   return avlen_launch_status();
 }
 
@@ -376,7 +410,7 @@ int avlen_groupnorm_apply_bf16(const float* x, const float* stats, const float* 
                                void* y16, int B, int HW, int C, int G, int relu, float eps, hipStream_t stream) {
   const void* xv = x;
   return avlen_groupnorm_apply_bf16_grouped(&xv, 0, &stats, &gamma, &beta, res16 ? &res16 : nullptr, &y16, 1, B, HW, C, G, relu,
-                                            eps, stream);
+                                            eps, stream, nullptr, nullptr, nullptr, 0);
 }
 
 extern "C" int avlen_layernorm_bwd(const float* dy, const float* xsum, const float* gamma, const float* mean,
