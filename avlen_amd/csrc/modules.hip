@@ -241,6 +241,20 @@ __global__ void clip_gather_last_kernel(const float* __restrict__ x, float* __re
   for (int i = threadIdx.x; i < width; i += blockDim.x) out[(long)b * width + i] = src[i];
 }
 
+// Last-layer pruning: only the EOT row of every dialog leaves the tower, so after the last attention the residual stream
+// shrinks to one row per sample.  xe = last live row of x (fp32), aoe = the same row of the attention output (bf16);
+// the row-statistics slot of the compact stream is cleared for the out_proj epilogue's atomics.
+__global__ void clip_gather_last2_kernel(const float* __restrict__ x, const __bf16* __restrict__ ao, const int* __restrict__ seg,
+                                         float* __restrict__ xe, __bf16* __restrict__ aoe, float* __restrict__ stats, int width) {
+  const int b = blockIdx.x;
+  const long r = seg[b + 1] - 1;
+  for (int i = threadIdx.x; i < width; i += blockDim.x) {
+    xe[(long)b * width + i] = x[r * width + i];
+    aoe[(long)b * width + i] = ao[r * width + i];
+  }
+  if (threadIdx.x < 2) stats[b * 2 + threadIdx.x] = 0.f;
+}
+
 __global__ void clip_gather_eot_kernel(const int64_t* __restrict__ tokens, const float* __restrict__ x,
                                        float* __restrict__ out, int ctx, int width) {
   const int b = blockIdx.x;
@@ -1471,6 +1485,9 @@ extern "C" int avlen_clip_text_fwd(const avlen_clip_text* p, const int64_t* toke
       return avlen_gemm_bf16_dyn(X16, ldx, L.w16, L.ld16, Y32, ld32, Y16, ld16, L.b, res, ld32, (int)R, live, L.out_f, L.ld16,
                                  act, c.gws, c.gws_bytes, c.st);
     };
+    bool pruned = false;
+    static int prune = -1;                            // AVLEN_CLIP_PRUNE=0: last layer over every live token (A/B knob)
+    if (prune < 0) { const char* e = getenv("AVLEN_CLIP_PRUNE"); prune = e ? atoi(e) : 1; }
     if (fold) {
       // per layer: 4 GEMMs + attention, no LayerNorm launch: the out_proj / c_proj epilogues emit the new residual
       // stream in fp32 + bf16 and its row statistics; in_proj / c_fc apply the normalisation in their epilogue
@@ -1481,6 +1498,21 @@ extern "C" int avlen_clip_text_fwd(const avlen_clip_text* p, const int64_t* toke
         TRY(avlen_gemm_bf16_ln(Hn16, wd, b.attn_fold.w16f, wd, nullptr, 0, QKV, 3 * wd, b.attn_fold.c, nullptr, 0, (int)R, live,
                                3 * wd, wd, 0, st1, b.attn_fold.s, nullptr, c.gws, c.gws_bytes, st));
         TRY(avlen_attention_qkv16(QKV, 3 * wd, AO16, wd, B, H, ctx, 1, scale, seg, st));
+        if (prune && l + 1 == p->layers) {
+          // one row per sample from here on: out_proj, c_fc and c_proj shrink from the live token count to B rows
+          bf16* Fe16 = F16; bf16* AOe16 = Fe16 + (size_t)B * b.fc.out_f; bf16* He16 = AOe16 + (size_t)B * wd;
+          float* ste = (float*)(He16 + (size_t)B * wd);
+          hipLaunchKernelGGL(clip_gather_last2_kernel, dim3(B), dim3(128), 0, st, X, AO16, seg, E, AOe16, ste, wd);
+          TRY(avlen_launch_status());
+          TRY(avlen_gemm_bf16_ln(AOe16, wd, b.attn.out_proj.w16, b.attn.out_proj.ld16, E, wd, He16, wd, b.attn.out_proj.b, E, wd,
+                                 B, nullptr, wd, b.attn.out_proj.ld16, 0, nullptr, nullptr, ste, c.gws, c.gws_bytes, st));
+          TRY(avlen_gemm_bf16_ln(He16, wd, b.fc_fold.w16f, wd, nullptr, 0, Fe16, b.fc.out_f, b.fc_fold.c, nullptr, 0, B, nullptr,
+                                 b.fc.out_f, wd, AVLEN_ACT_QUICKGELU, ste, b.fc_fold.s, nullptr, c.gws, c.gws_bytes, st));
+          TRY(avlen_gemm_bf16_ln(Fe16, b.fc.out_f, b.proj.w16, b.proj.ld16, E, wd, nullptr, 0, b.proj.b, E, wd, B, nullptr, wd,
+                                 b.proj.ld16, 0, nullptr, nullptr, nullptr, c.gws, c.gws_bytes, st));
+          pruned = true;
+          break;
+        }
         TRY(avlen_gemm_bf16_ln(AO16, wd, b.attn.out_proj.w16, b.attn.out_proj.ld16, X, wd, Hn16, wd, b.attn.out_proj.b, X, wd,
                                (int)R, live, wd, b.attn.out_proj.ld16, 0, nullptr, nullptr, st2, c.gws, c.gws_bytes, st));
         TRY(avlen_gemm_bf16_ln(Hn16, wd, b.fc_fold.w16f, wd, nullptr, 0, F16, b.fc.out_f, b.fc_fold.c, nullptr, 0, (int)R, live,
@@ -1505,7 +1537,7 @@ extern "C" int avlen_clip_text_fwd(const avlen_clip_text* p, const int64_t* toke
       TRY(lin(b.fc, Hn16, wd, nullptr, 0, F16, b.fc.out_f, AVLEN_ACT_QUICKGELU, nullptr));
       TRY(lin(b.proj, F16, b.fc.out_f, X, wd, nullptr, 0, 0, X));
     }
-    hipLaunchKernelGGL(clip_gather_last_kernel, dim3(B), dim3(128), 0, st, X, E, seg, wd);
+    if (!pruned) hipLaunchKernelGGL(clip_gather_last_kernel, dim3(B), dim3(128), 0, st, X, E, seg, wd);
     TRY(avlen_launch_status());
     TRY(avlen_layernorm_fwd(E, nullptr, p->ln_final.g, p->ln_final.b, E2, nullptr, nullptr, B, wd, 1e-5f, st));
     return clip_project(p, E2, out, B, prec, gws, st);

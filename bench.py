@@ -79,9 +79,14 @@ def cpu_baseline(spec_hw):
     cores = os.cpu_count() or 1
     n, t = 16, 3
     eps, sec, thr = flow.cpu_baseline(specs, N=n, T=t, spectrogram=spec_hw, pretraining=True, threads=min(cores, 64))
+    # SURVEY 8(d) asks for both thread settings: the reference pins torch to ONE thread (run.py:113)
+    n1, t1 = 4, 2
+    eps1, sec1, _ = flow.cpu_baseline(specs, N=n1, T=t1, spectrogram=spec_hw, pretraining=True, threads=1)
     return {"value": round(eps, 3), "unit": "env-steps/s", "cores": thr, "kind": "port",
             "sample": f"oracle (plain PyTorch fp32 restatement), {n} envs x {t} steps of the 3-policy rollout incl. CLIP "
-                      f"text + one pi_q PPO update (2 epochs x 2 minibatches), {sec:.1f} s"}
+                      f"text + one pi_q PPO update (2 epochs x 2 minibatches), {sec:.1f} s",
+            "single_thread": {"value": round(eps1, 3), "cores": 1,
+                              "sample": f"same flow, torch.set_num_threads(1) as the reference runs it, {n1} envs x {t1} steps, {sec1:.1f} s"}}
 
 
 def main():

@@ -33,7 +33,7 @@ static float time_us(int M, int N, int K, const void* A, const void* B, void* C1
 
 int main(int argc, char** argv) {
   const bool ablate = argc > 1 && !strcmp(argv[1], "abl");
-  const int shapes[][3] = {{2464, 512, 512}, {2464, 512, 2048}, {2464, 2048, 512}, {2464, 1536, 512},
+  const int shapes[][3] = {{64, 512, 512}, {64, 2048, 512}, {64, 512, 2048}, {2464, 512, 512}, {2464, 512, 2048}, {2464, 2048, 512}, {2464, 1536, 512},
                            {9664, 256, 256}, {9664, 768, 256}, {4800, 64, 8192}, {8192, 8192, 1024}, {8192, 8192, 8192}};
   size_t maxA = (size_t)9664 * 8192, maxB = (size_t)8192 * 8192, maxC = (size_t)8192 * 8192;
   std::vector<unsigned short> h(maxB);
@@ -51,7 +51,7 @@ int main(int argc, char** argv) {
   // bm, bn, threads, stages, splitk
   const int cfgs_all[][5] = {{0, 0, 0, 0, 0}, {64, 128, 256, 4, 0}, {64, 128, 512, 2, 0}, {64, 128, 512, 3, 0}, {64, 128, 512, 4, 0},
                          {128, 128, 256, 2, 0}, {128, 128, 512, 2, 0}, {128, 128, 512, 3, 0}, {128, 128, 512, 4, 0},
-                         {256, 128, 512, 2, 0}, {256, 128, 512, 3, 0}, {128, 64, 512, 3, 0}, {64, 128, 512, 3, 2}, {128, 128, 512, 3, 2}};
+                         {256, 128, 512, 2, 0}, {256, 128, 512, 3, 0}, {128, 64, 512, 3, 0}, {64, 128, 512, 3, 2}, {64, 64, 256, 0, 0}};
   const int cfgs_abl[][5] = {{64, 128, 512, 2, 0}, {64, 128, 512, 4, 0}, {128, 128, 512, 2, 0}, {256, 128, 512, 3, 0}};
   const int (*cfgs)[5] = ablate ? cfgs_abl : cfgs_all;
   const int ncfg = ablate ? 4 : 14;
