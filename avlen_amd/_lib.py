@@ -139,6 +139,13 @@ SIGNATURES = {
     "avlen_resnet18_fwd": (i32, [C.POINTER(ResNet18), vp, i32, i32, i32, f32, vp, i32, i32, vp, sz, vp]),
     "avlen_resnet18_group_workspace_bytes": (sz, [i32, i32]),
     "avlen_resnet18_group_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp]),
+    "avlen_resnet18_any_workspace_bytes": (sz, [i32, i32, i32]),
+    "avlen_resnet18_any_fwd": (i32, [C.POINTER(ResNet18), vp, i32, i32, i32, i32, vp, i32, i32, vp, sz, vp]),
+    "avlen_resnet18_tv_workspace_bytes": (sz, [i32, i32, i32]),
+    "avlen_resnet18_tv_fwd": (i32, [C.POINTER(ResNet18), vp, i32, i32, i32, i32, vp, i32, i32, vp, sz, vp]),
+    "avlen_belief_input": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    "avlen_belief_update": (i32, [vp, i32, vp, i32, vp, i32, vp, C.c_long, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32,
+                                  i32, vp]),
     "avlen_cnn3_workspace_bytes": (sz, [C.POINTER(Cnn3), i32, i32, i32]),
     "avlen_cnn3_fwd": (i32, [C.POINTER(Cnn3), vp, i32, i32, i32, vp, i32, i32, vp, sz, vp]),
     "avlen_cnn3_group_workspace_bytes": (sz, [C.POINTER(Cnn3), i32, i32, i32, i32]),

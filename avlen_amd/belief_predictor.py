@@ -1,0 +1,199 @@
+"""Drop-in for ss_baselines/savi/models/belief_predictor.py (BeliefPredictor, :56-206): same constructor, attribute and
+state_dict names (`predictor.*`, `classifier.*`), same `update(observations, dones)` contract (writes
+`observations['location_belief']` / `['category_belief']` in place).
+
+What differs is where it runs: both spectrogram networks and the per-environment filter (exponential averaging of the
+predicted goal location in the odometry frame, label averaging, resets on `dones`, the "sound stopped" branches) execute
+on the MI355X through the C ABI (`avlen_resnet18_any_fwd`, `avlen_resnet18_tv_fwd`, `avlen_belief_update`); the reference
+copies the network outputs and every pose to the host and loops over environments in numpy.  No CPU fallback.
+"""
+import ctypes as C
+import logging
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import engine as E
+from . import nets as N
+from .policy import SPECTROGRAM, POSE, LOCATION_BELIEF, CATEGORY_BELIEF, CATEGORY, _f32
+
+LABEL_PREDICTOR_PATH = "data/pretrained_weights/semantic_audionav/savi/label_predictor.pth"    # belief_predictor.py:96
+
+
+class BeliefPredictor(nn.Module):
+    NUM_LABELS = 21
+
+    def __init__(self, belief_config, device, input_size, pose_indices, hidden_state_size, num_env=1,
+                 has_distractor_sound=False, precision="fp32", load_pretrained=True):
+        super().__init__()
+        self.config = belief_config
+        self.device = torch.device(device)
+        self.predict_label = belief_config.use_label_belief
+        self.predict_location = belief_config.use_location_belief
+        self.has_distractor_sound = has_distractor_sound
+        self.precision = precision
+        self.prec = {"fp32": L.PREC_FP32, "bf16": L.PREC_BF16}[precision]
+        if self.predict_location:
+            if not belief_config.online_training:
+                # belief_predictor.py:74-77 swaps in an ImageNet-pretrained torchvision resnet18 with a 23-way head
+                raise NotImplementedError("BeliefPredictor with online_training=False (pretrained torchvision location "
+                                          "predictor) is not part of the accelerated path")
+            self.predictor = N.ResNet18Params(23 if has_distractor_sound else 2)
+            self.predictor.fc = N._no_fwd(nn.Linear(4608, 2))
+        if self.predict_label:
+            self.classifier = N.TvResNet18Params(2, self.NUM_LABELS)
+        self.num_env = num_env
+        if belief_config.online_training:
+            self.regressor_criterion = nn.MSELoss()
+            self.optimizer = None
+        self._eng = None
+        self._ws = E.Workspaces()
+        self._state = None
+        if load_pretrained:
+            self.load_pretrained_weights()
+
+    # ---- reference API -------------------------------------------------------------------------
+    def load_pretrained_weights(self):
+        if self.predict_label:
+            state_dict = torch.load(LABEL_PREDICTOR_PATH, map_location="cpu")
+            cleaned = {k[len("predictor."):]: v for k, v in state_dict["audiogoal_predictor"].items() if "predictor." in k}
+            self.classifier.load_state_dict(cleaned)
+            self._eng = None
+            logging.info("Loaded pretrained label classifier")
+
+    def freeze_encoders(self):
+        if self.config.online_training:
+            if self.config.use_label_belief:
+                for p in self.classifier.parameters():
+                    p.requires_grad = False
+        elif self.config.use_label_belief or self.config.use_location_belief:
+            for p in self.parameters():
+                p.requires_grad = False
+        logging.info("Freezing belief predictor weights")
+
+    def set_eval_encoders(self):
+        if self.config.use_label_belief:
+            self.classifier.eval()
+        if self.config.use_location_belief:
+            self.predictor.eval()
+
+    @property
+    def last_pointgoal(self):
+        """Host view of the filter state, shaped like the reference's list (None = no estimate yet)."""
+        s = self._filter_state(self.num_env)
+        has, val = s["has_pg"].cpu(), s["last_pg"].cpu()
+        return [val[i].numpy() if has[i] else None for i in range(self.num_env)]
+
+    @property
+    def last_label(self):
+        s = self._filter_state(self.num_env)
+        has, val = s["has_label"].cpu(), s["last_label"].cpu()
+        return [val[i].numpy() if has[i] else None for i in range(self.num_env)]
+
+    # ---- engine --------------------------------------------------------------------------------
+    def _apply(self, fn, *a, **k):
+        self._eng, self._state = None, None
+        r = super()._apply(fn, *a, **k)
+        p = next(self.parameters(), None)
+        if p is not None:
+            self.device = p.device
+        return r
+
+    def load_state_dict(self, *a, **k):
+        self._eng = None
+        return super().load_state_dict(*a, **k)
+
+    def refresh_weights(self):
+        """Re-derive the packed / BatchNorm-folded weights after the parameters changed (optimizer step, checkpoint load)."""
+        if self._eng is not None:
+            self._eng["packed"].refresh()
+
+    def _engine(self, H, W):
+        key = (H, W)
+        if self._eng is None or self._eng["key"] != key:
+            dev = next(self.parameters()).device
+            assert dev.type == "cuda", "avlen_amd runs on the MI355X only (no CPU fallback)"
+            packed = E.Packed(dev)
+            eng = {"key": key, "packed": packed}
+            if self.predict_location:
+                h, w = H, W
+                for _ in range(3):                                   # three stride-2 stages (3x3, pad 1)
+                    h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+                assert 128 * h * w == self.predictor.fc.in_features, (
+                    "predictor.fc expects %d features, a %dx%d spectrogram yields %d" %
+                    (self.predictor.fc.in_features, H, W, 128 * h * w))
+                eng["predictor"] = E.resnet18_any_view(self.predictor, packed, 128, h * w)
+            if self.predict_label:
+                eng["classifier"] = E.resnet18_tv_view(self.classifier, packed)
+            packed.refresh()
+            self._eng = eng
+        return self._eng
+
+    def _filter_state(self, B):
+        if self._state is None or self._state["B"] != B:
+            dev = next(self.parameters()).device
+            z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)
+            self._state = {"B": B, "last_pg": z(B, 2), "has_pg": z(B, dt=torch.int32), "last_label": z(B, self.NUM_LABELS),
+                           "has_label": z(B, dt=torch.int32), "spec_sum": z(B), "pg": z(B, 2), "labels": z(B, self.NUM_LABELS)}
+        return self._state
+
+    def _predictor_input(self, observations):
+        spec = _f32(observations[SPECTROGRAM])
+        if not self.has_distractor_sound:
+            return spec
+        cat = _f32(observations[CATEGORY])
+        B, H, W, Cs = spec.shape
+        x = torch.empty(B, H, W, Cs + cat.shape[1], device=spec.device)
+        L.call("avlen_belief_input", E.P(spec), E.P(cat), E.P(x), B, H * W, Cs, cat.shape[1], L.stream())
+        return x
+
+    def _run(self, which, x, out):
+        B, H, W, Cin = x.shape
+        eng = self._engine(observations_hw(x)[0], observations_hw(x)[1])
+        fn = "avlen_resnet18_any" if which == "predictor" else "avlen_resnet18_tv"
+        nb = getattr(L.lib, fn + "_workspace_bytes")(B, H, W)
+        ws = self._ws.get(which, nb, x.device)
+        L.call(fn + "_fwd", C.byref(eng[which]), E.P(x), B, H, W, Cin, E.P(out), out.shape[1], self.prec, E.P(ws), nb, L.stream())
+        return out
+
+    def cnn_forward(self, observations):
+        """belief_predictor.py:126-137: (B, 2) point goals."""
+        x = self._predictor_input(observations)
+        return self._run("predictor", x, torch.empty(x.shape[0], 2, device=x.device))
+
+    def update(self, observations, dones):
+        """belief_predictor.py:139-206."""
+        if not (self.predict_label or self.predict_location):
+            return
+        spec = _f32(observations[SPECTROGRAM])
+        assert spec.is_cuda, "avlen_amd runs on the MI355X only (no CPU fallback)"
+        B = spec.shape[0]
+        s = self._filter_state(B)
+        pg = labels = pose = loc = catb = None
+        if self.predict_location:
+            pg = self._run("predictor", self._predictor_input(observations), s["pg"])
+            pose = _f32(observations[POSE])
+            loc = observations[LOCATION_BELIEF]
+            assert loc.dtype == torch.float32 and loc.is_contiguous()
+        if self.predict_label:
+            labels = self._run("classifier", spec, s["labels"])
+            catb = observations[CATEGORY_BELIEF]
+            assert catb.dtype == torch.float32 and catb.is_contiguous()
+        d = None
+        if dones is not None:
+            d = torch.as_tensor(dones, device=spec.device).to(torch.uint8).contiguous()
+        ptr = lambda t: E.P(t) if t is not None else None
+        L.call("avlen_belief_update", ptr(pg), 2, ptr(labels), self.NUM_LABELS, ptr(pose), pose.shape[1] if pose is not None else 0,
+               E.P(spec), spec[0].numel(), ptr(d), E.P(s["last_pg"]), E.P(s["has_pg"]), E.P(s["last_label"]), E.P(s["has_label"]),
+               ptr(loc), ptr(catb), E.P(s["spec_sum"]), B, self.NUM_LABELS, float(self.config.weighting_factor),
+               int(bool(self.config.current_pred_only)), L.stream())
+
+
+def observations_hw(x):
+    return x.shape[1], x.shape[2]
+
+
+class BeliefPredictorDDP(BeliefPredictor):
+    """belief_predictor.py:208-210.  Gradient synchronisation of the online-trained location predictor belongs to the
+    trainer's regressor step, which is outside this path; the class exists so `bp_class` selection keeps working."""

@@ -1,0 +1,262 @@
+// BeliefPredictor (ss_baselines/savi/models/belief_predictor.py:56-206) for gfx950: the two spectrogram networks and the
+// per-environment belief filter that runs between `RolloutStorage.insert` and the next `act` of every rollout step.
+//
+//   avlen_resnet18_any_fwd   <- predictor = custom_resnet18(2 | 23 ch), fc 4608 -> 2   (belief_predictor.py:66-72, 126-137;
+//                               smt_resnet.py:56-149 at the spectrogram's own size: no resize, GroupNorm(16))
+//   avlen_resnet18_tv_fwd    <- classifier = torchvision resnet18 (conv1 2 -> 64), eval-mode BatchNorm folded into the convs
+//                               by the host (belief_predictor.py:79-81, 179); third-party architecture, parity unpinned
+//   avlen_belief_input       <- cnn_forward's channel concat for the distractor variant (belief_predictor.py:129-134)
+//   avlen_belief_update      <- the python loop of update() (belief_predictor.py:139-206) + base_to_odom / odom_to_base
+//                               (:213-230), one thread per environment, filter state resident on the device (the reference
+//                               pulls the network outputs and every pose to the host and loops in numpy)
+//
+// The networks run on the fp32-staged implicit-GEMM conv (any H, W, Cin) and the generic GroupNorm: the spectrogram is
+// 65 x 26, so none of the towers' 64 x 64 specialisations apply; this path is correctness-first.
+#include "common.h"
+#include "../../include/avlen_hip.h"
+#include "internal.h"
+
+namespace {
+
+#define TRY(x) do { int _rc = (x); if (_rc != AVLEN_OK) return _rc; } while (0)
+
+inline int conv_out(int h, const avlen_conv& k) { return (h + 2 * k.pad - k.kh) / k.stride + 1; }
+
+__global__ void maxpool_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C, int OH,
+                                    int OW, int k, int s, int p) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long tot = (long)B * OH * OW * C;
+  if (i >= tot) return;
+  int c = (int)(i % C); long r = i / C;
+  int ox = (int)(r % OW); r /= OW;
+  int oy = (int)(r % OH); int b = (int)(r / OH);
+  float m = -INFINITY;
+  for (int dy = 0; dy < k; dy++) {
+    int iy = oy * s - p + dy;
+    if (iy < 0 || iy >= H) continue;
+    for (int dx = 0; dx < k; dx++) {
+      int ix = ox * s - p + dx;
+      if (ix < 0 || ix >= W) continue;
+      m = fmaxf(m, x[(((long)b * H + iy) * W + ix) * C + c]);
+    }
+  }
+  y[i] = m;
+}
+
+// adaptive average pool to 1x1: one block per sample, threads over channels
+__global__ void avgpool_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int HW, int C) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int i = 0; i < HW; i++) s += x[((long)b * HW + i) * C + c];
+    y[(long)b * C + c] = s / (float)HW;
+  }
+}
+
+__global__ void belief_input_kernel(const float* __restrict__ spec, const float* __restrict__ cat, float* __restrict__ out,
+                                    int B, int HW, int Cs, int Cc) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int C = Cs + Cc;
+  if (i >= (long)B * HW * C) return;
+  int c = (int)(i % C); long px = i / C; int b = (int)(px / HW);
+  out[i] = c < Cs ? spec[px * Cs + c] : cat[(long)b * Cc + (c - Cs)];
+}
+
+// per-environment sum of the spectrogram ("is the sound still playing", belief_predictor.py:157,187)
+__global__ void spec_sum_kernel(const float* __restrict__ spec, float* __restrict__ out, long n) {
+  __shared__ float sh[16];
+  const float* s = spec + (long)blockIdx.x * n;
+  float a = 0.f;
+  for (long i = threadIdx.x; i < n; i += blockDim.x) a += s[i];
+  a = block_sum(a, sh);
+  if (threadIdx.x == 0) out[blockIdx.x] = a;
+}
+
+// belief_predictor.py:213-230 in float32, as numpy evaluates them on float32 operands
+__device__ inline void base_to_odom(float bx, float by, const float* pose, float* ox, float* oy) {
+  const float angle = -pose[2];
+  const float d = sqrtf(bx * bx + by * by);
+  const float theta = atan2f(by, bx);
+  *ox = pose[0] + d * cosf(theta + angle);
+  *oy = pose[1] + d * sinf(theta + angle);
+}
+__device__ inline void odom_to_base(float ox, float oy, const float* pose, float* bx, float* by) {
+  const float angle = -pose[2];
+  const float dx = ox - pose[0], dy = oy - pose[1];
+  const float dth = atan2f(dy, dx) - angle;
+  const float d = sqrtf(dx * dx + dy * dy);
+  *bx = d * cosf(dth); *by = d * sinf(dth);
+}
+
+__global__ void belief_update_kernel(const float* __restrict__ pointgoals, int ld_pg, const float* __restrict__ labels, int ld_lab,
+                                     const float* __restrict__ pose, int ld_pose, const float* __restrict__ spec_sum,
+                                     const unsigned char* __restrict__ dones, float* __restrict__ last_pg,
+                                     int* __restrict__ has_pg, float* __restrict__ last_label, int* __restrict__ has_label,
+                                     float* __restrict__ location_belief, float* __restrict__ category_belief, int B, int n_label,
+                                     float w, int current_pred_only) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  const bool done = dones && dones[i];
+  const bool sounding = spec_sum[i] != 0.f;
+  if (pointgoals) {                                    // :146-172
+    const float* ps = pose + (long)i * ld_pose;
+    if (done) has_pg[i] = 0;
+    float ax, ay;
+    if (sounding) {
+      const float bx = -pointgoals[(long)i * ld_pg + 1], by = pointgoals[(long)i * ld_pg];
+      if (!has_pg[i] || current_pred_only) { ax = bx; ay = by; }
+      else {
+        float lx, ly;
+        odom_to_base(last_pg[i * 2], last_pg[i * 2 + 1], ps, &lx, &ly);
+        ax = (1.f - w) * bx + w * lx; ay = (1.f - w) * by + w * ly;
+      }
+      base_to_odom(ax, ay, ps, &last_pg[i * 2], &last_pg[i * 2 + 1]);
+      has_pg[i] = 1;
+    } else if (!has_pg[i]) { ax = 10.f; ay = 10.f; }
+    else odom_to_base(last_pg[i * 2], last_pg[i * 2 + 1], ps, &ax, &ay);
+    location_belief[i * 2] = ax; location_belief[i * 2 + 1] = ay;
+  }
+  if (labels) {                                        // :175-206
+    if (done) has_label[i] = 0;
+    float* ll = last_label + (long)i * n_label;
+    float* out = category_belief + (long)i * n_label;
+    const float* lab = labels + (long)i * ld_lab;
+    if (sounding) {
+      const bool fresh = !has_label[i] || current_pred_only;
+      for (int c = 0; c < n_label; c++) {
+        const float v = fresh ? lab[c] : (1.f - w) * lab[c] + w * ll[c];
+        ll[c] = v; out[c] = v;
+      }
+      has_label[i] = 1;
+    } else if (!has_label[i]) {
+      const float u = (float)(1.0 / (double)n_label);
+      for (int c = 0; c < n_label; c++) out[c] = u;
+    } else {
+      for (int c = 0; c < n_label; c++) out[c] = ll[c];
+    }
+  }
+}
+
+size_t any_ws(int B, int H, int W) { return 4 * ((size_t)B * H * W * 16 * sizeof(float) + 256) + 4096; }
+
+}  // namespace
+
+extern "C" size_t avlen_resnet18_any_workspace_bytes(int B, int H, int W) { return any_ws(B, H, W); }
+
+extern "C" int avlen_resnet18_any_fwd(const avlen_resnet18* net, const float* x, int B, int H, int W, int C, float* out,
+                                      int ld_out, int prec, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!net || !x || !out || B <= 0 || C != net->conv1.cin || ws_bytes < any_ws(B, H, W)) return AVLEN_ERR_WS;
+  // widest activation: conv1 / layer1 at (h1, w1, 16); every later stage halves the extent and doubles the channels
+  const int h1 = conv_out(H, net->conv1), w1 = conv_out(W, net->conv1);
+  if (h1 <= 0 || w1 <= 0 || h1 > H || w1 > W || net->conv1.cout > 16) return AVLEN_ERR_ARG;
+  WsBump w(ws, ws_bytes);
+  const size_t act = (size_t)B * H * W * 16;
+  float* buf[4];
+  for (int i = 0; i < 4; i++) buf[i] = w.take<float>(act);
+  const avlen_conv& c1 = net->conv1;
+  TRY(avlen_conv2d_nhwc(x, c1.w, nullptr, nullptr, buf[0], B, H, W, c1.cin, c1.cout, c1.kh, c1.kw, c1.stride, c1.pad, 0, prec, st));
+  TRY(avlen_groupnorm_nhwc(buf[0], net->bn1.g, net->bn1.b, nullptr, buf[1], B, h1 * w1, c1.cout, 16, 1, 1e-5f, st));
+  float* cur = buf[1]; float* t1 = buf[0]; float* t2 = buf[2]; float* t3 = buf[3];
+  int h = h1, wd = w1, ch = c1.cout;
+  for (int i = 0; i < 8; i++) {
+    const avlen_resblock& k = net->block[i];
+    if (k.conv1.cin != ch) return AVLEN_ERR_ARG;
+    const int oh = conv_out(h, k.conv1), ow = conv_out(wd, k.conv1), co = k.conv1.cout;
+    if (oh <= 0 || ow <= 0 || (size_t)B * oh * ow * co > act) return AVLEN_ERR_ARG;
+    TRY(avlen_conv2d_nhwc(cur, k.conv1.w, nullptr, nullptr, t1, B, h, wd, ch, co, k.conv1.kh, k.conv1.kw, k.conv1.stride,
+                          k.conv1.pad, 0, prec, st));
+    TRY(avlen_groupnorm_nhwc(t1, k.bn1.g, k.bn1.b, nullptr, t1, B, oh * ow, co, 16, 1, 1e-5f, st));
+    TRY(avlen_conv2d_nhwc(t1, k.conv2.w, nullptr, nullptr, t2, B, oh, ow, co, co, k.conv2.kh, k.conv2.kw, k.conv2.stride,
+                          k.conv2.pad, 0, prec, st));
+    const float* identity = cur;
+    if (k.has_down) {
+      TRY(avlen_conv2d_nhwc(cur, k.down.w, nullptr, nullptr, t3, B, h, wd, ch, co, k.down.kh, k.down.kw, k.down.stride,
+                            k.down.pad, 0, prec, st));
+      TRY(avlen_groupnorm_nhwc(t3, k.bnd.g, k.bnd.b, nullptr, t3, B, oh * ow, co, 16, 0, 1e-5f, st));
+      identity = t3;
+    }
+    TRY(avlen_groupnorm_nhwc(t2, k.bn2.g, k.bn2.b, identity, t2, B, oh * ow, co, 16, 1, 1e-5f, st));
+    float* o = cur; cur = t2; t2 = o;
+    h = oh; wd = ow; ch = co;
+  }
+  if (net->fc.in_f != h * wd * ch) return AVLEN_ERR_ARG;
+  return avlen_gemm(cur, net->fc.in_f, 0, net->fc.w, net->fc.in_f, 0, out, ld_out, net->fc.b, nullptr, 0, B, net->fc.out_f,
+                    net->fc.in_f, 0, prec, 1, 0.f, nullptr, 0, st);
+}
+
+// torchvision resnet18 after the host folded every eval-mode BatchNorm into its conv (conv.w scaled per output channel,
+// conv.b = beta - mean * scale): conv7x7 s2 + ReLU, maxpool 3x3 s2 p1, 8 BasicBlocks (ReLU after the residual add),
+// global average pool, fc.  Activation extents: conv1 output is the widest tensor (64 channels at ~H/2 x W/2).
+extern "C" size_t avlen_resnet18_tv_workspace_bytes(int B, int H, int W) {
+  return 4 * ((size_t)B * ((H + 1) / 2 + 1) * ((W + 1) / 2 + 1) * 64 * sizeof(float) + 256) + (size_t)B * 512 * sizeof(float) + 4096;
+}
+
+extern "C" int avlen_resnet18_tv_fwd(const avlen_resnet18* net, const float* x, int B, int H, int W, int C, float* out,
+                                     int ld_out, int prec, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!net || !x || !out || B <= 0 || C != net->conv1.cin || !net->conv1.b || ws_bytes < avlen_resnet18_tv_workspace_bytes(B, H, W))
+    return AVLEN_ERR_WS;
+  WsBump w(ws, ws_bytes);
+  const size_t act = (size_t)B * ((H + 1) / 2 + 1) * ((W + 1) / 2 + 1) * 64;
+  float* buf[4];
+  for (int i = 0; i < 4; i++) buf[i] = w.take<float>(act);
+  float* pooled = w.take<float>((size_t)B * 512);
+  const avlen_conv& c1 = net->conv1;
+  const int h1 = conv_out(H, c1), w1 = conv_out(W, c1);
+  if (h1 <= 0 || w1 <= 0 || (size_t)B * h1 * w1 * c1.cout > act) return AVLEN_ERR_ARG;
+  TRY(avlen_conv2d_nhwc(x, c1.w, c1.b, nullptr, buf[0], B, H, W, c1.cin, c1.cout, c1.kh, c1.kw, c1.stride, c1.pad, AVLEN_ACT_RELU,
+                        prec, st));
+  int h = (h1 + 2 - 3) / 2 + 1, wd = (w1 + 2 - 3) / 2 + 1, ch = c1.cout;
+  {
+    long tot = (long)B * h * wd * ch;
+    hipLaunchKernelGGL(maxpool_nhwc_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, buf[0], buf[1], B, h1, w1, ch, h,
+                       wd, 3, 2, 1);
+    TRY(avlen_launch_status());
+  }
+  float* cur = buf[1]; float* t1 = buf[0]; float* t2 = buf[2]; float* t3 = buf[3];
+  for (int i = 0; i < 8; i++) {
+    const avlen_resblock& k = net->block[i];
+    if (k.conv1.cin != ch || !k.conv1.b || !k.conv2.b) return AVLEN_ERR_ARG;
+    const int oh = conv_out(h, k.conv1), ow = conv_out(wd, k.conv1), co = k.conv1.cout;
+    if (oh <= 0 || ow <= 0 || (size_t)B * oh * ow * co > act || co > 512) return AVLEN_ERR_ARG;
+    TRY(avlen_conv2d_nhwc(cur, k.conv1.w, k.conv1.b, nullptr, t1, B, h, wd, ch, co, k.conv1.kh, k.conv1.kw, k.conv1.stride,
+                          k.conv1.pad, AVLEN_ACT_RELU, prec, st));
+    const float* identity = cur;
+    if (k.has_down) {
+      TRY(avlen_conv2d_nhwc(cur, k.down.w, k.down.b, nullptr, t3, B, h, wd, ch, co, k.down.kh, k.down.kw, k.down.stride,
+                            k.down.pad, 0, prec, st));
+      identity = t3;
+    }
+    TRY(avlen_conv2d_nhwc(t1, k.conv2.w, k.conv2.b, identity, t2, B, oh, ow, co, co, k.conv2.kh, k.conv2.kw, k.conv2.stride,
+                          k.conv2.pad, AVLEN_ACT_RELU_POST, prec, st));
+    float* o = cur; cur = t2; t2 = o;
+    h = oh; wd = ow; ch = co;
+  }
+  if (net->fc.in_f != ch) return AVLEN_ERR_ARG;
+  hipLaunchKernelGGL(avgpool_nhwc_kernel, dim3(B), dim3(256), 0, st, cur, pooled, h * wd, ch);
+  TRY(avlen_launch_status());
+  return avlen_gemm(pooled, ch, 0, net->fc.w, ch, 0, out, ld_out, net->fc.b, nullptr, 0, B, net->fc.out_f, ch, 0, prec, 1, 0.f,
+                    nullptr, 0, st);
+}
+
+extern "C" int avlen_belief_input(const float* spec, const float* category, float* out, int B, int HW, int Cs, int Cc,
+                                  hipStream_t st) {
+  if (!spec || !category || !out || B <= 0) return AVLEN_ERR_ARG;
+  long tot = (long)B * HW * (Cs + Cc);
+  hipLaunchKernelGGL(belief_input_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, spec, category, out, B, HW, Cs, Cc);
+  return avlen_launch_status();
+}
+
+extern "C" int avlen_belief_update(const float* pointgoals, int ld_pg, const float* labels, int ld_lab, const float* pose,
+                                   int ld_pose, const float* spectrogram, long spec_elems, const unsigned char* dones,
+                                   float* last_pointgoal, int* has_pointgoal, float* last_label, int* has_label,
+                                   float* location_belief, float* category_belief, float* spec_sum, int B, int n_label,
+                                   float weighting_factor, int current_pred_only, hipStream_t st) {
+  if (B <= 0 || !spectrogram || !spec_sum || (!pointgoals && !labels)) return AVLEN_ERR_ARG;
+  if (pointgoals && (!pose || !last_pointgoal || !has_pointgoal || !location_belief)) return AVLEN_ERR_ARG;
+  if (labels && (!last_label || !has_label || !category_belief)) return AVLEN_ERR_ARG;
+  hipLaunchKernelGGL(spec_sum_kernel, dim3(B), dim3(256), 0, st, spectrogram, spec_sum, spec_elems);
+  hipLaunchKernelGGL(belief_update_kernel, dim3((B + 63) / 64), dim3(64), 0, st, pointgoals, ld_pg, labels, ld_lab, pose, ld_pose,
+                     (const float*)spec_sum, dones, last_pointgoal, has_pointgoal, last_label, has_label, location_belief,
+                     category_belief, B, n_label, weighting_factor, current_pred_only);
+  return avlen_launch_status();
+}

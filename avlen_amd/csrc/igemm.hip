@@ -328,7 +328,10 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
 #pragma unroll
       for (int ni = 0; ni < NI; ni++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) acc[mi][ni][r] = act_apply(acc[mi][ni][r] + bv[ni], p.act) + rv[mi][ni][r];
+        for (int r = 0; r < 4; r++) {
+          float v = act_apply(acc[mi][ni][r] + bv[ni], p.act) + rv[mi][ni][r];
+          acc[mi][ni][r] = p.act == AVLEN_ACT_RELU_POST ? fmaxf(v, 0.f) : v;      // ReLU after the residual add
+        }
   } else {
 #pragma unroll
     for (int mi = 0; mi < 2; mi++)
@@ -362,6 +365,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __re
   if (bias) s += bias[col];
   s = act_apply(s, act);
   if (residual) s += residual[(long)row * ldr + col];
+  if (act == AVLEN_ACT_RELU_POST) s = fmaxf(s, 0.f);
   float* o = out + (long)row * ldc + col;
   *o = (beta != 0.f) ? beta * (*o) + s : s;
 }

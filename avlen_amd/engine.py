@@ -111,8 +111,13 @@ class Packed:
     def __init__(self, device, flat=None):
         self.device, self.bufs, self.jobs, self.flat = device, [], [], flat
 
-    def conv(self, conv, has_bias):
+    def conv(self, conv, has_bias, bf16=True):
         O, I, KH, KW = conv.weight.shape
+        if not bf16:                                  # fp32-staged kernels only (any channel count)
+            buf = torch.empty(O * KH * KW * I, dtype=torch.float32, device=self.device)
+            self.bufs.append(buf)
+            self.jobs.append(("conv32", conv.weight, buf, None, (O, I, KH, KW), 0))
+            return L.Conv(P(buf), P(conv.bias) if has_bias else None, I, O, KH, KW, conv.stride[0], conv.padding[0])
         buf = torch.empty(O * KH * KW * I, dtype=torch.float32, device=self.device)
         c16 = max(8, I)
         assert c16 & (c16 - 1) == 0, "bf16 conv path needs a power-of-two channel count"
@@ -127,6 +132,17 @@ class Packed:
             self.jobs.append(("conv16c", conv.weight, None, bufc, (O, I, KH, KW), I))
             v.w16c = P(bufc)
         return v
+
+    def conv_bn(self, conv, bn):
+        """conv followed by an eval-mode BatchNorm2d, folded: w' = w * gamma / sqrt(var + eps) per output channel,
+        b' = beta - mean * gamma / sqrt(var + eps)  (torchvision BasicBlock, belief_predictor.py:79-81)."""
+        O, I, KH, KW = conv.weight.shape
+        buf = torch.empty(O * KH * KW * I, dtype=torch.float32, device=self.device)
+        wf = torch.empty_like(conv.weight)
+        bias = torch.empty(O, dtype=torch.float32, device=self.device)
+        self.bufs += [buf, wf, bias]
+        self.jobs.append(("convbn", conv.weight, buf, (bn, wf, bias), (O, I, KH, KW), 0))
+        return L.Conv(P(buf), P(bias), I, O, KH, KW, conv.stride[0], conv.padding[0])
 
     def fc_after_flatten(self, lin, C_, HW):
         O = lin.weight.shape[0]
@@ -155,6 +171,15 @@ class Packed:
                 b, g, be, s, c = buf
                 L.call("avlen_ln_fold_weights", P(w), P(b) if b is not None else None, P(g), P(be), P(buf16), dims[1], P(s),
                        P(c), dims[0], dims[1], st)
+            elif kind == "conv32":
+                L.call("avlen_pack_conv_weight", P(w), P(buf), *dims, st)
+            elif kind == "convbn":
+                bn, wf, bias = buf16
+                with torch.no_grad():                 # weight preparation (derived data), not the compute path
+                    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+                    wf.copy_(w * scale[:, None, None, None])
+                    bias.copy_(bn.bias - bn.running_mean * scale)
+                L.call("avlen_pack_conv_weight", P(wf), P(buf), *dims, st)
             elif kind == "conv16c":
                 L.call("avlen_pack_conv_weight_bf16", P(w), P(buf16), *dims, c16, st)
             elif kind == "conv":
@@ -186,6 +211,47 @@ def resnet18_view(net, packed):
                 b.has_down = 0
             i += 1
     s.fc = packed.fc_after_flatten(net.fc, 128, 64)
+    return s
+
+
+def resnet18_any_view(net, packed, fc_c, fc_hw):
+    """CustomResNet at a non-64x64 input (BeliefPredictor.predictor): fp32-staged kernels, fc packed for (fc_c, fc_hw)."""
+    s = L.ResNet18()
+    s.conv1 = packed.conv(net.conv1, False, bf16=False)
+    s.bn1 = affine_view(net.bn1)
+    i = 0
+    for layer in (net.layer1, net.layer2, net.layer3, net.layer4):
+        for blk in layer:
+            b = s.block[i]
+            b.conv1 = packed.conv(blk.conv1, False, bf16=False)
+            b.conv2 = packed.conv(blk.conv2, False, bf16=False)
+            b.bn1, b.bn2 = affine_view(blk.bn1), affine_view(blk.bn2)
+            b.has_down = 0
+            if blk.downsample is not None:
+                b.down = packed.conv(blk.downsample[0], False, bf16=False)
+                b.bnd = affine_view(blk.downsample[1])
+                b.has_down = 1
+            i += 1
+    s.fc = packed.fc_after_flatten(net.fc, fc_c, fc_hw)
+    return s
+
+
+def resnet18_tv_view(net, packed):
+    """torchvision resnet18 with its BatchNorms folded into the convs (BeliefPredictor.classifier)."""
+    s = L.ResNet18()
+    s.conv1 = packed.conv_bn(net.conv1, net.bn1)
+    i = 0
+    for layer in (net.layer1, net.layer2, net.layer3, net.layer4):
+        for blk in layer:
+            b = s.block[i]
+            b.conv1 = packed.conv_bn(blk.conv1, blk.bn1)
+            b.conv2 = packed.conv_bn(blk.conv2, blk.bn2)
+            b.has_down = 0
+            if blk.downsample is not None:
+                b.down = packed.conv_bn(blk.downsample[0], blk.downsample[1])
+                b.has_down = 1
+            i += 1
+    s.fc = linear_view(net.fc.weight, net.fc.bias)
     return s
 
 

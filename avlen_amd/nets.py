@@ -110,6 +110,50 @@ class ResNet18Params(_Holder):
         return nn.Sequential(*blocks)
 
 
+class _TvBasicBlock(_Holder):
+    def __init__(self, inplanes, planes, stride, downsample):
+        super().__init__()
+        self.conv1 = _no_fwd(nn.Conv2d(inplanes, planes, 3, stride=stride, padding=1, bias=False))
+        self.bn1 = _no_fwd(nn.BatchNorm2d(planes))
+        self.relu = nn.Identity()
+        self.conv2 = _no_fwd(nn.Conv2d(planes, planes, 3, stride=1, padding=1, bias=False))
+        self.bn2 = _no_fwd(nn.BatchNorm2d(planes))
+        self.downsample = downsample
+        self.stride = stride
+
+
+class TvResNet18Params(_Holder):
+    """Parameter container with torchvision.models.resnet18's module tree and state_dict keys (third party; used by
+    belief_predictor.py:79-81 with conv1 replaced by Conv2d(2, 64, 7, 2, 3) and fc by Linear(512, n))."""
+
+    def __init__(self, num_input_channels, num_classes):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = _no_fwd(nn.Conv2d(num_input_channels, 64, kernel_size=7, stride=2, padding=3, bias=False))
+        self.bn1 = _no_fwd(nn.BatchNorm2d(64))
+        self.relu = nn.Identity()
+        self.maxpool = nn.Identity()
+        self.layer1 = self._make_layer(64, 1)
+        self.layer2 = self._make_layer(128, 2)
+        self.layer3 = self._make_layer(256, 2)
+        self.layer4 = self._make_layer(512, 2)
+        self.avgpool = nn.Identity()
+        self.fc = _no_fwd(nn.Linear(512, num_classes))
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def _make_layer(self, planes, stride):
+        down = None
+        if stride != 1 or self.inplanes != planes:
+            down = nn.Sequential(_no_fwd(nn.Conv2d(self.inplanes, planes, 1, stride=stride, bias=False)),
+                                 _no_fwd(nn.BatchNorm2d(planes)))
+        blocks = [_TvBasicBlock(self.inplanes, planes, stride, down)]
+        self.inplanes = planes
+        blocks.append(_TvBasicBlock(planes, planes, 1, None))
+        return nn.Sequential(*blocks)
+
+
 class SMTCNNParams(_Holder):
     """SMTCNN (smt_cnn.py:32-76): rgb_encoder + depth_encoder, each 64-d."""
 

@@ -30,6 +30,7 @@ typedef struct ihipStream_t* avlen_stream_t;        /* == hipStream_t */
 #define AVLEN_ACT_NONE 0
 #define AVLEN_ACT_RELU 1
 #define AVLEN_ACT_QUICKGELU 2
+#define AVLEN_ACT_RELU_POST 4   /* fp32-staged conv/GEMM only: ReLU AFTER the residual add (torchvision BasicBlock) */
 
 /* ------------------------------------------------------------------ parameter views ---------- */
 /* w[out_f][in_f] fp32 (canonical).  w16: optional bf16 shadow of the same matrix, row stride ld16 (multiple of 8,
@@ -178,6 +179,33 @@ size_t avlen_resnet18_group_workspace_bytes(int groups, int B);
 int avlen_resnet18_group_fwd(const avlen_resnet18* const* nets, const float* const* imgs, const int* channels,
                              const float* divisors, float* const* outs, int ld_out, int groups, int B, int S, void* ws,
                              size_t ws_bytes, avlen_stream_t stream);
+/* ---- BeliefPredictor (belief_predictor.py:56-206), SURVEY 8(f) rank 1 ---- */
+/* predictor = custom_resnet18 at the input's own extent (no resize; belief_predictor.py:66-72,126-137 over
+ * smt_resnet.py:132-146): x NHWC (B,H,W,C) fp32 -> out[b*ld_out + 0..fc.out_f).  conv weights in `w` (packed fp32),
+ * fc.w packed to the NHWC flatten order of the last stage. */
+size_t avlen_resnet18_any_workspace_bytes(int B, int H, int W);
+int avlen_resnet18_any_fwd(const avlen_resnet18* net, const float* x, int B, int H, int W, int C, float* out, int ld_out,
+                           int prec, void* ws, size_t ws_bytes, avlen_stream_t stream);
+/* classifier = torchvision resnet18 with conv1 (C -> 64) (belief_predictor.py:79-81,179; third-party architecture):
+ * eval-mode BatchNorms already folded into the convs by the host (conv.b = beta - mean*scale, bn* unused);
+ * conv7x7 s2 + ReLU, maxpool 3x3 s2 p1, 8 BasicBlocks, global average pool, fc. */
+size_t avlen_resnet18_tv_workspace_bytes(int B, int H, int W);
+int avlen_resnet18_tv_fwd(const avlen_resnet18* net, const float* x, int B, int H, int W, int C, float* out, int ld_out,
+                          int prec, void* ws, size_t ws_bytes, avlen_stream_t stream);
+/* cnn_forward's input for the distractor variant (belief_predictor.py:129-134): out (B,HW,Cs+Cc) = [spec | category]. */
+int avlen_belief_input(const float* spec, const float* category, float* out, int B, int HW, int Cs, int Cc,
+                       avlen_stream_t stream);
+/* The per-environment filter of BeliefPredictor.update (belief_predictor.py:146-206, 213-230), float32 like the numpy
+ * loop it replaces.  pointgoals (B,>=2) / labels (B,>=n_label): network outputs, either may be NULL (that half is
+ * skipped); pose (B,ld_pose) = x, y, heading, t; spectrogram (B,spec_elems) decides "sounding" (sum != 0); dones (B) bytes
+ * or NULL.  Filter state (last_pointgoal (B,2) in the odometry frame, last_label (B,n_label), has_* (B) flags) lives
+ * on the device and is updated in place; results are written into the observation tensors location_belief (B,2) and
+ * category_belief (B,n_label).  spec_sum: (B) scratch. */
+int avlen_belief_update(const float* pointgoals, int ld_pg, const float* labels, int ld_lab, const float* pose, int ld_pose,
+                        const float* spectrogram, long spec_elems, const unsigned char* dones, float* last_pointgoal,
+                        int* has_pointgoal, float* last_label, int* has_label, float* location_belief,
+                        float* category_belief, float* spec_sum, int B, int n_label, float weighting_factor,
+                        int current_pred_only, avlen_stream_t stream);
 size_t avlen_cnn3_workspace_bytes(const avlen_cnn3* net, int B, int H, int W);
 /* AudioCNN.forward (audio_cnn.py:136-151) / VisualCNN.cnn: x NHWC (B,H,W,conv[0].cin) -> out[b*ld_out + 0..fc.out_f). */
 int avlen_cnn3_fwd(const avlen_cnn3* net, const float* x, int B, int H, int W, float* out, int ld_out, int prec,

@@ -134,3 +134,22 @@ def stub_text_embedding(tokens, d=512):
     against the reference (the real CLIP package is absent)."""
     proj = sym("stub_clip.proj", (tokens.shape[1], d), 1.0)
     return torch.sin((tokens.float() / 1000.0) @ proj)
+
+
+def belief_scenario(tag, N=3, T=7, spectrogram=(65, 26)):
+    """Per-step inputs of BeliefPredictor.update (belief_predictor.py:139-206): T steps x N envs with every branch of the
+    filter exercised -- silent before any estimate, silent after one, episode resets while sounding and while silent,
+    dones=None (ddppo_trainer.py:729) and dones as a list (ppo_trainer.py:892)."""
+    silent = {(0, 1), (3, 1), (4, 1), (2, 2), (5, 0), (6, 2)}
+    done = {(3, 0), (4, 1), (5, 2), (6, 2)}
+    steps = []
+    for t in range(T):
+        o = observations(f"{tag}.t{t}", N, spectrogram, step=t)
+        for (tt, i) in silent:
+            if tt == t and i < N:
+                o["spectrogram"][i] = 0.0
+        o["location_belief"] = torch.zeros(N, 2)
+        o["category_belief"] = torch.zeros(N, 21)
+        dones = None if t == 0 else [(t, i) in done for i in range(N)]
+        steps.append((o, dones))
+    return steps

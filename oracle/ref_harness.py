@@ -163,6 +163,8 @@ def load():
     from ss_baselines.savi.models.visual_cnn import VisualCNN
     from ss_baselines.savi.models.smt_cnn import SMTCNN
     from ss_baselines.av_nav.models.rnn_state_encoder import RNNStateEncoder
+    from ss_baselines.savi.models.belief_predictor import BeliefPredictor
+    ns.BeliefPredictor = BeliefPredictor
     ns.policy = ref_policy
     ns.PPO = PPO
     ns.RolloutStorage = RolloutStorage

@@ -485,3 +485,105 @@ def adam_step(p, g, m, v, step, lr, eps, b1=0.9, b2=0.999):
     bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
     denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
     p.addcdiv_(m, denom, value=-lr / bc1)
+
+
+# --------------------------------------------------------------------------------------
+# a18 / f1: BeliefPredictor                           belief_predictor.py:56-206, 213-230
+# --------------------------------------------------------------------------------------
+
+
+def belief_cnn_forward(sd, obs, has_distractor_sound=False, p="predictor"):
+    """belief_predictor.py:126-137: custom_resnet18 on the spectrogram at its own size (no resize) -> (B,2)."""
+    spec = obs["spectrogram"].permute(0, 3, 1, 2)
+    if has_distractor_sound:
+        lab = obs["category"]
+        spec = torch.cat([spec, lab.reshape(lab.shape + (1, 1)).expand(lab.shape + spec.shape[-2:])], 1)
+    return custom_resnet18(sd, p, spec)
+
+
+def _batch_norm_eval(sd, p, x, eps=1e-5):
+    s = sd[p + ".weight"] / torch.sqrt(sd[p + ".running_var"] + eps)
+    return x * s.view(1, -1, 1, 1) + (sd[p + ".bias"] - sd[p + ".running_mean"] * s).view(1, -1, 1, 1)
+
+
+def tv_resnet18(sd, p, x):
+    """torchvision.models.resnet18 in eval mode (third party, un-vendored; PARITY UNPINNED: restated from the public
+    architecture -- conv7x7/2, BN, ReLU, maxpool3x3/2, 4 stages x 2 BasicBlocks (64,128,256,512), avgpool, fc --
+    anchored on the call sites belief_predictor.py:79-81,179)."""
+    x = torch.relu(_batch_norm_eval(sd, p + ".bn1", F.conv2d(x, sd[p + ".conv1.weight"], None, stride=2, padding=3)))
+    x = F.max_pool2d(x, 3, 2, 1)
+    for li, stride in ((1, 1), (2, 2), (3, 2), (4, 2)):
+        for bi in (0, 1):
+            q = f"{p}.layer{li}.{bi}"
+            s = stride if bi == 0 else 1
+            idt = x
+            out = torch.relu(_batch_norm_eval(sd, q + ".bn1", F.conv2d(x, sd[q + ".conv1.weight"], None, stride=s, padding=1)))
+            out = _batch_norm_eval(sd, q + ".bn2", F.conv2d(out, sd[q + ".conv2.weight"], None, stride=1, padding=1))
+            if q + ".downsample.0.weight" in sd:
+                idt = _batch_norm_eval(sd, q + ".downsample.1", F.conv2d(x, sd[q + ".downsample.0.weight"], None, stride=s))
+            x = torch.relu(out + idt)
+    return _lin(sd, p + ".fc", x.mean(dim=(2, 3)))
+
+
+def _base_to_odom(pg, pose):
+    import numpy as np                                      # belief_predictor.py:213-220
+    angle = -pose[2]
+    d = np.linalg.norm(pg)
+    theta = np.arctan2(pg[1], pg[0])
+    return np.array([pose[0] + d * np.cos(theta + angle), pose[1] + d * np.sin(theta + angle)])
+
+
+def _odom_to_base(pg, pose):
+    import numpy as np                                      # belief_predictor.py:223-230
+    angle = -pose[2]
+    delta = pg - pose[:2]
+    dth = np.arctan2(delta[1], delta[0]) - angle
+    d = np.linalg.norm(delta)
+    return np.array([d * np.cos(dth), d * np.sin(dth)])
+
+
+class BeliefFilter:
+    """The per-environment loop of BeliefPredictor.update (belief_predictor.py:146-206) over given network outputs."""
+
+    def __init__(self, num_env, weighting_factor=0.5, current_pred_only=False):
+        self.last_pointgoal = [None] * num_env
+        self.last_label = [None] * num_env
+        self.w, self.current_pred_only = weighting_factor, current_pred_only
+
+    def update(self, obs, dones, pointgoals=None, labels=None):
+        import numpy as np
+        B = obs["spectrogram"].shape[0]
+        if pointgoals is not None:
+            pgs = pointgoals.cpu().numpy()
+            for i in range(B):
+                pose = obs["pose"][i].cpu().numpy()
+                if dones is not None and dones[i]:
+                    self.last_pointgoal[i] = None
+                if obs["spectrogram"][i].sum().item() != 0:
+                    base = np.array([-pgs[i][1], pgs[i][0]])
+                    if self.last_pointgoal[i] is None or self.current_pred_only:
+                        avg = base
+                    else:
+                        avg = (1 - self.w) * base + self.w * _odom_to_base(self.last_pointgoal[i], pose)
+                    self.last_pointgoal[i] = _base_to_odom(avg, pose)
+                elif self.last_pointgoal[i] is None:
+                    avg = np.array([10, 10])
+                else:
+                    avg = _odom_to_base(self.last_pointgoal[i], pose)
+                obs["location_belief"][i].copy_(torch.from_numpy(np.asarray(avg)))
+        if labels is not None:
+            labs = labels[:, :21].cpu().numpy()
+            for i in range(B):
+                if dones is not None and dones[i]:
+                    self.last_label[i] = None
+                if obs["spectrogram"][i].sum().item() != 0:
+                    if self.last_label[i] is None or self.current_pred_only:
+                        avg = labs[i]
+                    else:
+                        avg = (1 - self.w) * labs[i] + self.w * self.last_label[i]
+                    self.last_label[i] = avg
+                elif self.last_label[i] is None:
+                    avg = np.ones(21) / 21
+                else:
+                    avg = self.last_label[i]
+                obs["category_belief"][i].copy_(torch.from_numpy(np.asarray(avg)))
