@@ -25,7 +25,7 @@ class BeliefPredictor(nn.Module):
     NUM_LABELS = 21
 
     def __init__(self, belief_config, device, input_size, pose_indices, hidden_state_size, num_env=1,
-                 has_distractor_sound=False, precision="fp32", load_pretrained=True):
+                 has_distractor_sound=False, precision="fp32", load_pretrained=True, use_graphs=False):
         super().__init__()
         self.config = belief_config
         self.device = torch.device(device)
@@ -50,6 +50,10 @@ class BeliefPredictor(nn.Module):
         self._eng = None
         self._ws = E.Workspaces()
         self._state = None
+        # use_graphs: the whole update (both networks + the filter, ~75 launches) is captured once per batch shape and
+        # replayed; inputs are staged into the graph's static buffers by one batched copy, beliefs copied out by another
+        self.use_graphs = use_graphs
+        self._graph = None
         if load_pretrained:
             self.load_pretrained_weights()
 
@@ -93,7 +97,7 @@ class BeliefPredictor(nn.Module):
 
     # ---- engine --------------------------------------------------------------------------------
     def _apply(self, fn, *a, **k):
-        self._eng, self._state = None, None
+        self._eng, self._state, self._graph = None, None, None
         r = super()._apply(fn, *a, **k)
         p = next(self.parameters(), None)
         if p is not None:
@@ -101,7 +105,7 @@ class BeliefPredictor(nn.Module):
         return r
 
     def load_state_dict(self, *a, **k):
-        self._eng = None
+        self._eng, self._graph = None, None
         return super().load_state_dict(*a, **k)
 
     def refresh_weights(self):
@@ -129,6 +133,11 @@ class BeliefPredictor(nn.Module):
             packed.refresh()
             self._eng = eng
         return self._eng
+
+    def _side_stream(self):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream()
+        return self._side
 
     def _filter_state(self, B):
         if self._state is None or self._state["B"] != B:
@@ -168,21 +177,74 @@ class BeliefPredictor(nn.Module):
             return
         spec = _f32(observations[SPECTROGRAM])
         assert spec.is_cuda, "avlen_amd runs on the MI355X only (no CPU fallback)"
-        B = spec.shape[0]
-        s = self._filter_state(B)
-        pg = labels = pose = loc = catb = None
-        if self.predict_location:
-            pg = self._run("predictor", self._predictor_input(observations), s["pg"])
-            pose = _f32(observations[POSE])
-            loc = observations[LOCATION_BELIEF]
-            assert loc.dtype == torch.float32 and loc.is_contiguous()
-        if self.predict_label:
-            labels = self._run("classifier", spec, s["labels"])
-            catb = observations[CATEGORY_BELIEF]
-            assert catb.dtype == torch.float32 and catb.is_contiguous()
         d = None
         if dones is not None:
-            d = torch.as_tensor(dones, device=spec.device).to(torch.uint8).contiguous()
+            d = dones if torch.is_tensor(dones) else torch.as_tensor(dones)
+            if d.device != spec.device or d.dtype != torch.uint8 or not d.is_contiguous():
+                d = d.to(device=spec.device, dtype=torch.uint8).contiguous()
+        obs = {SPECTROGRAM: spec}
+        if self.predict_location:
+            obs[POSE] = _f32(observations[POSE])
+            if self.has_distractor_sound:
+                obs[CATEGORY] = _f32(observations[CATEGORY])
+        outs = {}
+        if self.predict_location:
+            outs[LOCATION_BELIEF] = observations[LOCATION_BELIEF]
+        if self.predict_label:
+            outs[CATEGORY_BELIEF] = observations[CATEGORY_BELIEF]
+        for t in outs.values():
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
+        if not self.use_graphs:
+            return self._update_eager(obs, d, outs)
+        key = tuple((k, tuple(v.shape)) for k, v in sorted(obs.items()))
+        g = self._graph
+        if g is None or g["key"] != key:
+            self._engine(spec.shape[1], spec.shape[2])                    # packed weights exist before capture
+            self._filter_state(spec.shape[0])
+            st_in = {k: v.clone() for k, v in obs.items()}
+            st_d = torch.zeros(spec.shape[0], dtype=torch.uint8, device=spec.device)
+            st_out = {k: torch.zeros_like(v) for k, v in outs.items()}
+            saved = {k: v.clone() for k, v in self._state.items() if torch.is_tensor(v)}
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                                 # warm-up outside capture
+                self._update_eager(st_in, st_d, st_out)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._update_eager(st_in, st_d, st_out)
+            for k, v in saved.items():                                    # the warm-up must not advance the filter
+                self._state[k].copy_(v)
+            g = self._graph = {"key": key, "graph": graph, "in": st_in, "dones": st_d, "out": st_out,
+                               "zero": torch.zeros_like(st_d)}
+        pairs = [(g["in"][k], v) for k, v in obs.items()]
+        pairs.append((g["dones"], d if d is not None else g["zero"]))
+        L.multi_copy(pairs)
+        g["graph"].replay()
+        L.multi_copy([(outs[k], g["out"][k]) for k in outs])
+
+    def _update_eager(self, obs, d, outs):
+        spec = obs[SPECTROGRAM]
+        B = spec.shape[0]
+        s = self._filter_state(B)
+        pg = labels = pose = None
+        # the two networks are independent until the filter: they run on two streams (two branches of the captured graph);
+        # at these sizes (64 spectrograms of 65x26) every kernel fills a fraction of the chip
+        side = None
+        if self.predict_location and self.predict_label:
+            side = self._side_stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                labels = self._run("classifier", spec, s["labels"])
+        elif self.predict_label:
+            labels = self._run("classifier", spec, s["labels"])
+        if self.predict_location:
+            pg = self._run("predictor", self._predictor_input(obs), s["pg"])
+            pose = obs[POSE]
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+        loc, catb = outs.get(LOCATION_BELIEF), outs.get(CATEGORY_BELIEF)
         ptr = lambda t: E.P(t) if t is not None else None
         L.call("avlen_belief_update", ptr(pg), 2, ptr(labels), self.NUM_LABELS, ptr(pose), pose.shape[1] if pose is not None else 0,
                E.P(spec), spec[0].numel(), ptr(d), E.P(s["last_pg"]), E.P(s["has_pg"]), E.P(s["last_label"]), E.P(s["has_label"]),

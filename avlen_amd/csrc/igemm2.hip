@@ -336,14 +336,19 @@ __global__ __launch_bounds__(NTH) void g2_kernel(G2 pp) {
       for (int j = 0; j < NI; j++) {
         acc[i][j][0] = act2(acc[i][j][0] + bv[j].x, p.act) + rv[i][j].x; acc[i][j][1] = act2(acc[i][j][1] + bv[j].y, p.act) + rv[i][j].y;
         acc[i][j][2] = act2(acc[i][j][2] + bv[j].z, p.act) + rv[i][j].z; acc[i][j][3] = act2(acc[i][j][3] + bv[j].w, p.act) + rv[i][j].w;
+        if (p.act == AVLEN_ACT_RELU_POST) {        // ReLU after the residual add (torchvision BasicBlock)
+#pragma unroll
+          for (int r = 0; r < 4; r++) acc[i][j][r] = fmaxf(acc[i][j][r], 0.f);
+        }
       }
   } else {
 #pragma unroll
     for (int i = 0; i < MI; i++)
 #pragma unroll
       for (int j = 0; j < NI; j++) {
-        acc[i][j][0] = act2(acc[i][j][0] + bv[j].x, p.act); acc[i][j][1] = act2(acc[i][j][1] + bv[j].y, p.act);
-        acc[i][j][2] = act2(acc[i][j][2] + bv[j].z, p.act); acc[i][j][3] = act2(acc[i][j][3] + bv[j].w, p.act);
+        const int a1 = p.act == AVLEN_ACT_RELU_POST ? AVLEN_ACT_RELU : p.act;
+        acc[i][j][0] = act2(acc[i][j][0] + bv[j].x, a1); acc[i][j][1] = act2(acc[i][j][1] + bv[j].y, a1);
+        acc[i][j][2] = act2(acc[i][j][2] + bv[j].z, a1); acc[i][j][3] = act2(acc[i][j][3] + bv[j].w, a1);
       }
   }
   if (p.rowstats) {            // per-row (sum, sum of squares) of the final values: the next layer's LayerNorm statistics
@@ -429,6 +434,7 @@ __global__ void g2_reduce_kernel(G2Red rr, int M, int N, int ldc32, int ldc16, i
       if (g.bias) v += g.bias[col + r];
       v = act2(v, act);
       if (g.residual) v += g.residual[(long)row * ldr + col + r];
+      if (act == AVLEN_ACT_RELU_POST) v = fmaxf(v, 0.f);
       if (g.C32) g.C32[(long)row * ldc32 + col + r] = v;
       if (g.C16) g.C16[(long)row * ldc16 + col + r] = (bf16)v;
     }
@@ -443,6 +449,7 @@ __global__ void g2_reduce_kernel(G2Red rr, int M, int N, int ldc32, int ldc16, i
     if (g.bias) s += g.bias[col];
     s = act2(s, act);
     if (g.residual) s += g.residual[(long)row * ldr + col];
+    if (act == AVLEN_ACT_RELU_POST) s = fmaxf(s, 0.f);
     if (g.C32) g.C32[(long)row * ldc32 + col] = s;
     if (g.C16) g.C16[(long)row * ldc16 + col] = (bf16)s;
   }

@@ -119,8 +119,9 @@ class Packed:
             self.jobs.append(("conv32", conv.weight, buf, None, (O, I, KH, KW), 0))
             return L.Conv(P(buf), P(conv.bias) if has_bias else None, I, O, KH, KW, conv.stride[0], conv.padding[0])
         buf = torch.empty(O * KH * KW * I, dtype=torch.float32, device=self.device)
-        c16 = max(8, I)
-        assert c16 & (c16 - 1) == 0, "bf16 conv path needs a power-of-two channel count"
+        c16 = 8
+        while c16 < I:                                # bf16 conv path: power-of-two channel count >= 8 (zero padded)
+            c16 *= 2
         buf16 = torch.empty(O * KH * KW * c16, dtype=torch.bfloat16, device=self.device)
         self.bufs += [buf, buf16]
         self.jobs.append(("conv", conv.weight, buf, buf16, (O, I, KH, KW), c16))
@@ -140,9 +141,15 @@ class Packed:
         buf = torch.empty(O * KH * KW * I, dtype=torch.float32, device=self.device)
         wf = torch.empty_like(conv.weight)
         bias = torch.empty(O, dtype=torch.float32, device=self.device)
-        self.bufs += [buf, wf, bias]
-        self.jobs.append(("convbn", conv.weight, buf, (bn, wf, bias), (O, I, KH, KW), 0))
-        return L.Conv(P(buf), P(bias), I, O, KH, KW, conv.stride[0], conv.padding[0])
+        c16 = 8
+        while c16 < I:
+            c16 *= 2
+        buf16 = torch.empty(O * KH * KW * c16, dtype=torch.bfloat16, device=self.device)
+        self.bufs += [buf, wf, bias, buf16]
+        self.jobs.append(("convbn", conv.weight, buf, (bn, wf, bias, buf16), (O, I, KH, KW), c16))
+        v = L.Conv(P(buf), P(bias), I, O, KH, KW, conv.stride[0], conv.padding[0])
+        v.w16, v.cin16 = P(buf16), c16
+        return v
 
     def fc_after_flatten(self, lin, C_, HW):
         O = lin.weight.shape[0]
@@ -174,12 +181,13 @@ class Packed:
             elif kind == "conv32":
                 L.call("avlen_pack_conv_weight", P(w), P(buf), *dims, st)
             elif kind == "convbn":
-                bn, wf, bias = buf16
+                bn, wf, bias, w16 = buf16
                 with torch.no_grad():                 # weight preparation (derived data), not the compute path
                     scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
                     wf.copy_(w * scale[:, None, None, None])
                     bias.copy_(bn.bias - bn.running_mean * scale)
                 L.call("avlen_pack_conv_weight", P(wf), P(buf), *dims, st)
+                L.call("avlen_pack_conv_weight_bf16", P(wf), P(w16), *dims, c16, st)
             elif kind == "conv16c":
                 L.call("avlen_pack_conv_weight_bf16", P(w), P(buf16), *dims, c16, st)
             elif kind == "conv":
@@ -217,18 +225,18 @@ def resnet18_view(net, packed):
 def resnet18_any_view(net, packed, fc_c, fc_hw):
     """CustomResNet at a non-64x64 input (BeliefPredictor.predictor): fp32-staged kernels, fc packed for (fc_c, fc_hw)."""
     s = L.ResNet18()
-    s.conv1 = packed.conv(net.conv1, False, bf16=False)
+    s.conv1 = packed.conv(net.conv1, False)
     s.bn1 = affine_view(net.bn1)
     i = 0
     for layer in (net.layer1, net.layer2, net.layer3, net.layer4):
         for blk in layer:
             b = s.block[i]
-            b.conv1 = packed.conv(blk.conv1, False, bf16=False)
-            b.conv2 = packed.conv(blk.conv2, False, bf16=False)
+            b.conv1 = packed.conv(blk.conv1, False)
+            b.conv2 = packed.conv(blk.conv2, False)
             b.bn1, b.bn2 = affine_view(blk.bn1), affine_view(blk.bn2)
             b.has_down = 0
             if blk.downsample is not None:
-                b.down = packed.conv(blk.downsample[0], False, bf16=False)
+                b.down = packed.conv(blk.downsample[0], False)
                 b.bnd = affine_view(blk.downsample[1])
                 b.has_down = 1
             i += 1

@@ -29,7 +29,7 @@ class Workload:
     def __init__(self, num_envs, num_steps=150, spectrogram=(257, 101, 2), precision="bf16", pretraining=True,
                  em_capacity=150, ppo_epoch=2, num_mini_batch=2, device="cuda", seed=0, sampling="host",
                  with_dialog_policy=True, with_goal_policy=True, use_graphs=True, share_encoders=True, weight_seed=0,
-                 launch_ahead=True):
+                 launch_ahead=True, belief_predictor=False):
         self.N, self.T, self.dev = num_envs, num_steps, torch.device(device)
         self.spec = spectrogram
         # enqueue all three policies' forwards before the first host-side sampling; pi_g and pi_l run on their own streams,
@@ -56,6 +56,14 @@ class Workload:
         self.rollouts = RolloutStorage(T, N, osp, asp, 512, True, ems, em_capacity, ems, em_capacity, 3, 3, 276, 276,
                                        308, 256, num_recurrent_layers=-1, max_dialog_len=77, use_state_memory=True,
                                        device=self.dev)
+        self.belief = None
+        if belief_predictor:        # use_belief_predictor: True in the interactive yamls (ppo_trainer.py:892); 65x26 spectrogram only
+            import types
+            from .belief_predictor import BeliefPredictor
+            bcfg = types.SimpleNamespace(use_label_belief=True, use_location_belief=True, online_training=True,
+                                         current_pred_only=False, weighting_factor=0.5)
+            self.belief = BeliefPredictor(bcfg, self.dev, None, None, 512, num_env=num_envs, precision=precision,
+                                          load_pretrained=False, use_graphs=use_graphs).to(self.dev)
         self._make_simulator_output(seed)
 
     # -- what the CPU simulator + trainer bookkeeping would have produced, resident in HBM ------------------
@@ -77,6 +85,7 @@ class Workload:
         self.sim["pose"] = pose.to(dev)
         self.rewards = torch.randn(T, N, 1, generator=g).to(dev)
         self.not_done = (r(T, N, 1) >= 1.0 / 150).float().to(dev)
+        self.dones = (1.0 - self.not_done).view(T, N).to(torch.uint8)
         pe = sinusoid_table(1000, 32)
         self.query_state = pe[torch.randint(0, 4, (T, N), generator=g)].to(dev)
         self.last_query_info = pe[torch.randint(0, 150, (T, N), generator=g)].to(dev)
@@ -112,6 +121,7 @@ class Workload:
                      em_masks=ro.external_memory_masks[t], em_vln_masks=ro.external_memory_vln_masks[t],
                      qs=self.query_state[t], lqi=self.last_query_info[t], dialog=self.dialog[t], astep=self.agent_step[t],
                      nxt={k: self.sim[k][t + 1] for k in ro.observations}, rew=self.rewards[t], nd=self.not_done[t],
+                     dones=self.dones[t],
                      rl=self.rl_masks[t], ucnt=self.ucnt_gt[t])
             self._views[t] = v
         return v
@@ -141,6 +151,8 @@ class Workload:
             actions = torch.where(a_opt == 1, a_vln, actions)           # queried envs follow pi_l
         if probs_vln is None:
             probs_vln = self.zero_probs
+        if self.belief is not None:                 # beliefs of the NEW observation, written in place before it is stored
+            self.belief.update(v["nxt"], v["dones"])
         ro.insert(v["nxt"], h, actions, a_opt, lp_opt, values, v["rew"], v["nd"], v["nd"], row_goal, row_opt, row_vln, row_dlg,
                   v["dialog"], self.o_action, self.o_mask, v["rl"], v["ucnt"], probs_vln, v["qs"], v["lqi"], v["astep"])
 

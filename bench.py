@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-share", action="store_true", help="do not batch the three policies' visual towers")
     ap.add_argument("--no-launch-ahead", action="store_true", help="call the three policies strictly one after the other")
+    ap.add_argument("--belief", action="store_true",
+                    help="also run BeliefPredictor.update every step (SURVEY 8f rank 1; needs --spectrogram 65x26, the only size "
+                         "the reference's predictor.fc accepts)")
     return ap.parse_args()
 
 
@@ -103,7 +106,7 @@ def main():
     from avlen_amd.harness import Workload
     H, W = (int(x) for x in a.spectrogram.split("x"))
     wl = Workload(a.envs, a.rollout, spectrogram=(H, W, 2), precision=a.precision, pretraining=True, seed=rank,
-                  use_graphs=not a.no_graphs, share_encoders=not a.no_share, launch_ahead=not a.no_launch_ahead)
+                  use_graphs=not a.no_graphs, share_encoders=not a.no_share, launch_ahead=not a.no_launch_ahead, belief_predictor=a.belief)
 
     def barrier():
         torch.cuda.synchronize()
@@ -138,7 +141,7 @@ def main():
         "config": {"workload": "savi_interactive_1st_stage: pi_g+pi_l+pi_q rollout (CLIP ViT-B/32 text frozen) + pi_q "
                                "PPO update 2x2", "num_envs_per_gpu": a.envs, "rollout_steps": a.rollout,
                    "spectrogram": a.spectrogram, "parallelism": f"env-shard x{world}, RCCL grad all-reduce",
-                   "rollout_fraction_of_time": round(t_roll / dt, 3)},
+                   "rollout_fraction_of_time": round(t_roll / dt, 3), "belief_predictor": bool(a.belief)},
     }
     if rank == 0:
         if not a.no_roofline:

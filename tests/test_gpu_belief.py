@@ -136,3 +136,22 @@ def test_no_cpu_fallback():
     obs = fx.observations("cpu", 2)
     with pytest.raises(AssertionError, match="no CPU fallback"):
         bp.update(obs, None)
+
+
+def test_graph_replay_matches_eager():
+    """use_graphs=True: captured update == launch-by-launch update, over steps with dones=None / lists / silent envs."""
+    N = 3
+    bps = []
+    for ug in (False, True):
+        bp = BeliefPredictor(cfg(label=True), "cuda", None, None, 512, num_env=N, precision="bf16", load_pretrained=False,
+                             use_graphs=ug)
+        sd = predictor_sd("belief_loc")
+        sd.update(classifier_sd(bp))
+        bp.load_state_dict(sd, strict=False)
+        bps.append(bp.cuda())
+    for t, (obs, dones) in enumerate(fx.belief_scenario("belief_graph", N)):
+        o1, o2 = cu(obs), cu(obs)
+        bps[0].update(o1, dones)
+        bps[1].update(o2, dones)
+        for k in ("location_belief", "category_belief"):
+            assert torch.equal(o1[k], o2[k]), (t, k)
