@@ -152,6 +152,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline((H, W))
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()                      # rank 0 may still be timing the roofline kernel: leave together
         dist.destroy_process_group()
 
 
