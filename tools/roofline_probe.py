@@ -17,13 +17,18 @@ GEMM = dict(M=2464, N=512, K=2048)
 CONV = dict(B=384, W=64, C=16)
 
 
-def make_gemm():
-    M, N, K = GEMM["M"], GEMM["N"], GEMM["K"]
+def make_gemm(M=None, N=None, K=None, epilogue="residual32", act=0):
+    """epilogue: "residual32" = fp32 residual in/out (out_proj / c_proj), "bf16" = bias (+ activation), bf16 out only (in_proj / c_fc)."""
+    M, N, K = M or GEMM["M"], N or GEMM["N"], K or GEMM["K"]
     A = torch.randn(M, K, device="cuda").bfloat16(); Wt = (torch.randn(N, K, device="cuda") / math.sqrt(K)).bfloat16()
     b = torch.randn(N, device="cuda"); X = torch.randn(M, N, device="cuda")
+    Y16 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     nb = L.lib.avlen_gemm_bf16_workspace_bytes(M, N); ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
-    fn = lambda: L.call("avlen_gemm_bf16", P(A), K, P(Wt), K, P(X), N, None, 0, P(b), P(X), N, M, N, K, 0, None, 0, L.stream())
-    return fn, (A, Wt, b, X, ws)
+    if epilogue == "residual32":
+        fn = lambda: L.call("avlen_gemm_bf16", P(A), K, P(Wt), K, P(X), N, None, 0, P(b), P(X), N, M, N, K, 0, None, 0, L.stream())
+    else:
+        fn = lambda: L.call("avlen_gemm_bf16", P(A), K, P(Wt), K, None, 0, P(Y16), N, P(b), None, 0, M, N, K, act, None, 0, L.stream())
+    return fn, (A, Wt, b, X, Y16, ws)
 
 
 def make_conv():
@@ -45,6 +50,19 @@ def gemm_work():
 def conv_work():
     B, W, C = CONV["B"], CONV["W"], CONV["C"]
     return {"flops": 2.0 * B * W * W * C * C * 9, "bytes": B * W * W * C * 2 * 2}          # bf16 activation in + out, once each
+
+
+# the other GEMMs of one CLIP text block on the same ragged batch (same kernel family, NS = 2): qkv, out_proj, c_fc
+CLIP_SITES = {"in_proj": (2464, 1536, 512, "bf16", 0), "out_proj": (2464, 512, 512, "residual32", 0),
+              "c_fc": (2464, 2048, 512, "bf16", 2)}
+
+
+def clip_call_sites():
+    out = {}
+    for name, (M, N, K, ep, act) in CLIP_SITES.items():
+        s = measure(lambda: make_gemm(M, N, K, ep, act))
+        out[name] = {"M": M, "N": N, "K": K, "us_per_launch": round(s * 1e6, 2), "TFLOPs": round(2.0 * M * N * K / s / 1e12, 1)}
+    return out
 
 
 def measure(make, iters=40):
