@@ -230,6 +230,36 @@ extern "C" int avlen_multi_copy(const void* const* src, void* const* dst, const 
   return avlen_launch_status();
 }
 
+// Zero fill as an ordinary kernel node.  hipMemsetAsync inside a captured graph becomes a memset node; with several graphs
+// replaying concurrently on different streams those nodes were observed to clear their range at the wrong point of the
+// chain (CLIP row statistics wiped after the first accumulations), so captured paths never use them.
+__global__ void zero_kernel(float4* __restrict__ p, long n16, char* __restrict__ tail, int ntail) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+__global__ void zero_bytes_head_kernel(char* __restrict__ p, int n) {
+  if ((int)threadIdx.x < n) p[threadIdx.x] = 0;
+}
+int avlen_zero_bytes(void* p, size_t bytes, hipStream_t stream) {
+  if (!p) return AVLEN_ERR_ARG;
+  if (bytes == 0) return AVLEN_OK;
+  char* q = (char*)p;
+  const size_t head = (16 - ((size_t)q & 15)) & 15;             // bytes up to the first 16-byte boundary
+  if (head) {
+    const int n = (int)(head < bytes ? head : bytes);
+    hipLaunchKernelGGL(zero_bytes_head_kernel, dim3(1), dim3(64), 0, stream, q, n);
+    q += n; bytes -= n;
+    if (bytes == 0) return avlen_launch_status();
+  }
+  const long n16 = (long)(bytes >> 4);
+  long blocks = (n16 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(zero_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (float4*)q, n16, q + (n16 << 4), (int)(bytes & 15));
+  return avlen_launch_status();
+}
+
 extern "C" int avlen_copy_rows(const float* src, int lds, float* dst, int ldd, int rows, int cols, hipStream_t stream) {
   hipLaunchKernelGGL(copy_rows_kernel, grid1d((long)rows * cols), dim3(256), 0, stream, src, lds, dst, ldd, rows, cols);
   return avlen_launch_status();

@@ -14,6 +14,7 @@ int avlen_layernorm_fwd16(const float* x, const float* residual, const float* ga
 int avlen_attention_fwd16(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                           void* O16, int ldo16, const float* key_mask, float* lse, int B, int H, int Sq, int Sk, int D,
                           int causal, float scale, hipStream_t stream);
+int avlen_zero_bytes(void* p, size_t bytes, hipStream_t stream);      // zero fill as kernel node(s) under capture
 int avlen_preprocess_image_bf16(const float* x, void* y16, int B, int S, int C, float divisor, hipStream_t stream);
 int avlen_groupnorm_apply_bf16_grouped(const void* const* x, int raw16, const float* const* stats,
                                        const float* const* gamma, const float* const* beta, const void* const* res16,

@@ -510,7 +510,7 @@ int resnet18_group_fwd_bf16(const avlen_resnet18* const* nets, const float* cons
   float* stats_all = w.take<float>((size_t)G * 21 * stat_stride);
   size_t gwsb = (size_t)G * avlen_gemm_bf16_workspace_bytes(B, 64);
   void* gws = w.take<char>(gwsb);
-  if (hipMemsetAsync(stats_all, 0, (size_t)G * 21 * stat_stride * sizeof(float), st) != hipSuccess) return AVLEN_ERR_LAUNCH;
+  TRY(avlen_zero_bytes(stats_all, (size_t)G * 21 * stat_stride * sizeof(float), st));
   int si = 0;
   auto next_stats = [&](float** out) { for (int g = 0; g < G; g++) out[g] = stats_all + ((size_t)g * 21 + si) * stat_stride; si++; };
   for (int g = 0; g < G; g++) {
@@ -1476,7 +1476,7 @@ extern "C" int avlen_clip_text_fwd(const avlen_clip_text* p, const int64_t* toke
     const size_t st_stride = (size_t)R * 2;
     fold = fold && (size_t)wd * 2 >= (size_t)16 * p->layers;
     { static int en = -1; if (en < 0) { const char* e = getenv("AVLEN_CLIP_FOLD"); en = e ? atoi(e) : 1; } fold = fold && en; }
-    if (fold) (void)hipMemsetAsync(stats + st_stride, 0, (2 * (size_t)p->layers - 1) * st_stride * sizeof(float), st);
+    if (fold) TRY(avlen_zero_bytes(stats + st_stride, (2 * (size_t)p->layers - 1) * st_stride * sizeof(float), st));
     hipLaunchKernelGGL(clip_embed_ragged_kernel, dim3((unsigned)R), dim3(128), 0, st, tokens, p->tok_emb, p->pos_emb, X, seg,
                        rowmap, B, ctx, wd, p->vocab, fold ? Hn16 : (bf16*)nullptr, fold ? stats : (float*)nullptr);
     TRY(avlen_launch_status());

@@ -8,6 +8,7 @@ binaural spectrogram, pose, beliefs, 77-token dialog; everything is generated on
 HBM before timing starts ("simulator output").
 """
 import math
+import os
 import torch
 
 from . import policy as P
@@ -35,7 +36,9 @@ class Workload:
         # enqueue all three policies' forwards before the first host-side sampling; pi_g and pi_l run on their own streams,
         # overlap on the GPU and hand their probabilities to the host as each finishes (3.13 -> 2.73 ms per step)
         self.launch_ahead = launch_ahead
-        self._side = [torch.cuda.Stream(), torch.cuda.Stream()] if launch_ahead else None
+        self.text_ahead = os.environ.get("AVLEN_TEXT_AHEAD", "1") != "0"      # A/B knob
+        self._text_after = os.environ.get("AVLEN_TEXT_AHEAD", "1") == "2"     # 2: ordered after the current stream (debug)
+        self._side = [torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()] if launch_ahead else None
         osp, asp = savi_observation_space(spectrogram), ActionSpace(4)
         torch.manual_seed(weight_seed)          # identical initial weights on every rank (data-parallel replicas)
         kw = dict(SMT_KW, precision=precision, sampling=sampling, use_graphs=use_graphs)
@@ -134,6 +137,9 @@ class Workload:
         em_vln, em_dlg = ro.external_memory_vln[:, t], ro.external_memory_vln_dialog[:, t]
         if self.launch_ahead:
             self.pi_q.prefetch_act_option(obs, h, prev, v["masks"], em_opt, em_masks, v["qs"], v["lqi"])
+            if self.pi_l is not None and self.text_ahead:
+                # the text tower needs only the tokens: it runs beside pi_q's graph (the towers) instead of after it
+                self.pi_l.prefetch_text(v["dialog"], self._side[2], after_current=self._text_after)
             if self.pi_g is not None:
                 self.pi_g.prefetch_act(obs, h, prev, v["masks"], em_goal, em_masks, stream=self._side[0])
             if self.pi_l is not None:

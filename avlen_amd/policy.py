@@ -99,7 +99,7 @@ def _graphed(pol, which, fn, args, mode=None):
         # same observation as the leader's call: read the leader graph's static copy in place (no second staging copy)
         args[0] = grp.static_obs
         by_ptr = by_ptr + (0,)
-    key = (which, mode) + tuple(_sig(a) for a in args) + tuple(
+    key = (which, mode, getattr(pol.net, "_text_key", None)) + tuple(_sig(a) for a in args) + tuple(
         (args[i].data_ptr() if torch.is_tensor(args[i]) else id(args[i])) for i in by_ptr)
     g = pol._graphs.get(key)
     if g is None:
@@ -363,6 +363,13 @@ class Policy(nn.Module):
             if st[0] == which and st[1] == self._arg_key(net_args):
                 torch.cuda.current_stream().wait_event(st[3])        # later kernels of the caller read this forward's outputs
                 return st[2]
+        txt = getattr(self.net, "_text", None)
+        if which == "vln" and txt is not None:
+            tok = net_args[7]
+            if tok is not None and txt[0] == tok.data_ptr() and txt[1] == tuple(tok.shape):
+                torch.cuda.current_stream().wait_event(txt[3])
+            else:
+                self.net._text, self.net._text_key = None, None
         mode, grp = None, self._enc_group
         if grp is not None and self.precision == "bf16":
             if grp.leader is self:
@@ -374,7 +381,11 @@ class Policy(nn.Module):
         try:
             if not self.use_graphs:
                 return eager(*net_args)
-            return _graphed(self, which, eager, net_args, mode)
+            out = _graphed(self, which, eager, net_args, mode)
+            if which == "vln" and getattr(self.net, "_text", None) is not None:
+                self.net._text_read = torch.cuda.Event()
+                self.net._text_read.record(torch.cuda.current_stream())
+            return out
         finally:
             self._shared_mode = None
 
@@ -427,6 +438,13 @@ class Policy(nn.Module):
                             query_state, last_query_info, stream=None):
         self._prefetch("option", observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks,
                        query_state, last_query_info, stream=stream)
+
+    def prefetch_text(self, all_dialog, stream, after_current=True):
+        """pi_l only: start the frozen CLIP text tower for this step's dialog on `stream` right away (see net.prefetch_text).
+        after_current=False: do not order it after the work already enqueued on the current stream (the caller guarantees that
+        the previous forward that read the embedding has been waited for -- true once its act_dialog returned)."""
+        if self.use_graphs and hasattr(self.net, "prefetch_text"):
+            self.net.prefetch_text(self, all_dialog, stream, after_current)
 
     def prefetch_act_dialog(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_dialog,
                             ext_memory_masks, all_dialog, agent_step, stream=None):
@@ -768,6 +786,43 @@ class AudioNavDialogNet(_SMTBase):
         return out
 
     text_encoder_override = None      # tests: callable(tokens)->(B,512) replacing the CLIP tower (unpinned)
+    _text = None                      # (tokens ptr, shape, static embedding, event) of the last prefetch_text
+    _text_key = None                  # part of the graph key: a forward captured against the static embedding buffer
+    _text_read = None                 # event: the last forward that read the static embedding has been enqueued up to here
+
+    def prefetch_text(self, pol, tokens, stream, after_current=True):
+        """Enqueue CLIP.encode_text(tokens) NOW on `stream`: the text tower depends on nothing but the dialog tokens, so it
+        can run under the visual towers of the same step instead of after them.  The next run() with the same token tensor
+        reads the embedding from this call's static buffer."""
+        if self.text_encoder_override is not None or tokens is None:
+            return
+        tok = _i64(tokens)
+        cur = torch.cuda.current_stream()
+        if after_current:
+            stream.wait_stream(cur)                      # after every earlier reader of the embedding buffer
+        elif self._text_read is not None:
+            stream.wait_event(self._text_read)           # the last forward that read the embedding buffer
+        with torch.cuda.stream(stream):
+            key = ("text", tuple(tok.shape))
+            g = pol._graphs.get(key)
+            if g is None:
+                pol._engine()
+                g = pol._graphs[key] = _Graph(pol, lambda t: self.encode_text(pol, t), [tok])
+            emb = g([tok])
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        self._text = (tokens.data_ptr(), tuple(tokens.shape), emb, ev)
+        self._text_key = ("pretext", emb.data_ptr())
+
+    def _text_ready(self, all_dialog):
+        t = self._text
+        if t is None or all_dialog is None:
+            return None
+        if torch.cuda.is_current_stream_capturing():
+            return t[2]                                  # capture: the kernels read the static embedding buffer in place
+        if t[0] != all_dialog.data_ptr() or t[1] != tuple(all_dialog.shape):
+            return None                                  # other tokens (or a graph warm-up on clones): encode inside this forward
+        return t[2]
 
     def run(self, pol, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_dialog,
             ext_memory_masks, all_dialog, agent_step):
@@ -776,7 +831,10 @@ class AudioNavDialogNet(_SMTBase):
         cur = torch.cuda.current_stream()
         fork = torch.cuda.is_current_stream_capturing()
         s_txt = pol.side_streams()[2] if fork else cur
-        if all_dialog is not None:                       # frozen CLIP text tower: a parallel branch under capture
+        pre = self._text_ready(all_dialog)
+        if pre is not None:                              # embedding enqueued earlier by prefetch_text (static buffer)
+            e = pre
+        elif all_dialog is not None:                     # frozen CLIP text tower: a parallel branch under capture
             if fork:
                 s_txt.wait_stream(cur)
             with torch.cuda.stream(s_txt):
@@ -790,7 +848,7 @@ class AudioNavDialogNet(_SMTBase):
         st = L.stream()
         d_emb = None
         if all_dialog is not None:
-            if fork:
+            if fork and pre is None:
                 cur.wait_stream(s_txt)
             d_emb = torch.empty(B, d, device=dev)
             dl = eng["dialog_layer"]

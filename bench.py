@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-share", action="store_true", help="do not batch the three policies' visual towers")
     ap.add_argument("--no-launch-ahead", action="store_true", help="call the three policies strictly one after the other")
+    ap.add_argument("--stage", type=int, default=1, choices=[1, 2],
+                    help="1 = savi_interactive_1st_stage (pretraining=True, the metric's config); 2 = 2nd stage: pi_q attends over "
+                         "its 300-slot memory history in rollout and update (BASELINE configs[3] runs it at 32 envs per GPU)")
     ap.add_argument("--belief", action="store_true",
                     help="also run BeliefPredictor.update every step (SURVEY 8f rank 1; needs --spectrogram 65x26, the only size "
                          "the reference's predictor.fc accepts)")
@@ -106,7 +109,7 @@ def main():
         dist.init_process_group(os.environ.get("AVLEN_DIST_BACKEND", "nccl"))
     from avlen_amd.harness import Workload
     H, W = (int(x) for x in a.spectrogram.split("x"))
-    wl = Workload(a.envs, a.rollout, spectrogram=(H, W, 2), precision=a.precision, pretraining=True, seed=rank,
+    wl = Workload(a.envs, a.rollout, spectrogram=(H, W, 2), precision=a.precision, pretraining=(a.stage == 1), seed=rank,
                   use_graphs=not a.no_graphs, share_encoders=not a.no_share, launch_ahead=not a.no_launch_ahead, belief_predictor=a.belief)
 
     def barrier():
@@ -139,8 +142,8 @@ def main():
         "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.precision, "data": "synthetic",
-        "config": {"workload": "savi_interactive_1st_stage: pi_g+pi_l+pi_q rollout (CLIP ViT-B/32 text frozen) + pi_q "
-                               "PPO update 2x2", "num_envs_per_gpu": a.envs, "rollout_steps": a.rollout,
+        "config": {"workload": f"savi_interactive_{'1st' if a.stage == 1 else '2nd'}_stage: pi_g+pi_l+pi_q rollout (CLIP ViT-B/32 text "
+                               "frozen) + pi_q PPO update 2x2", "num_envs_per_gpu": a.envs, "rollout_steps": a.rollout,
                    "spectrogram": a.spectrogram, "parallelism": f"env-shard x{world}, RCCL grad all-reduce",
                    "rollout_fraction_of_time": round(t_roll / dt, 3), "belief_predictor": bool(a.belief)},
     }
