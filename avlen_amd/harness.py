@@ -37,6 +37,7 @@ class Workload:
         # overlap on the GPU and hand their probabilities to the host as each finishes (3.13 -> 2.73 ms per step)
         self.launch_ahead = launch_ahead
         self.text_ahead = os.environ.get("AVLEN_TEXT_AHEAD", "1") != "0"      # A/B knob
+        self._g_stream = int(os.environ.get("AVLEN_G_STREAM", "1"))
         self._text_after = os.environ.get("AVLEN_TEXT_AHEAD", "1") == "2"     # 2: ordered after the current stream (debug)
         # 1: launch it BEFORE pi_q's graph -- measured slower (22.8k vs 27.5k env-steps/s): the GEMM blocks that get the CUs first
         # squeeze the towers; launched second, the text tower fills the gaps the memory-bound tower kernels leave
@@ -146,7 +147,9 @@ class Workload:
             if self.pi_l is not None and self.text_ahead and not self._text_first:
                 self.pi_l.prefetch_text(v["dialog"], self._side[2], after_current=self._text_after)
             if self.pi_g is not None:
-                self.pi_g.prefetch_act(obs, h, prev, v["masks"], em_goal, em_masks, stream=self._side[0])
+                # pi_g shares pi_l's stream: both wait for pi_q's towers anyway, and a fourth busy stream ends up sharing a
+                # hardware queue with the text tower (pi_g then finished only after it)
+                self.pi_g.prefetch_act(obs, h, prev, v["masks"], em_goal, em_masks, stream=self._side[self._g_stream])
             if self.pi_l is not None:
                 self.pi_l.prefetch_act_dialog(obs, h, prev, v["masks_vln"], em_vln, em_dlg, v["em_vln_masks"], v["dialog"],
                                               v["astep"], stream=self._side[1])

@@ -12,6 +12,7 @@ action is drawn from that generator in the same order -> bit-exact actions for a
 sampling="device" keeps everything on the GPU (like the reference would on a CUDA device).
 """
 import ctypes as C
+import os
 import torch
 import torch.nn as nn
 
@@ -38,6 +39,21 @@ def _i64(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+_SPLIT = os.environ.get("AVLEN_SPLIT", "1") != "0"        # A/B knob: cut pi_l's forward in two around the text embedding
+
+
+_CAP = None
+
+
+def _capture_stream():
+    """ONE capture stream for every graph (as torch.cuda.graph does): each extra stream shifts the round-robin mapping of
+    streams to the 4 hardware queues, and with it which replaying graphs end up serialised behind each other."""
+    global _CAP
+    if _CAP is None:
+        _CAP = torch.cuda.Stream()
+    return _CAP
+
+
 class _Graph:
     """One captured forward: static input buffers + the HIP graph + its (static) outputs."""
 
@@ -50,18 +66,39 @@ class _Graph:
         ws_saved = pol._ws
         pol._ws = E.Workspaces()                         # this graph owns its scratch
         try:
-            side = torch.cuda.Stream()
+            side = _capture_stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                # warm-up outside capture (lazy HIP init, attributes)
                 fn(*self.static)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self.outs = fn(*self.static)
+            # Captured by hand (not `with torch.cuda.graph`) so that the forward may cut itself into TWO graphs at
+            # `split()`: the host can then wait for an outside event (pi_l's text tower) between the two replays.
+            self.graph, self.graph2, self.between = torch.cuda.CUDAGraph(), None, None
+            cap = _capture_stream()
+            cap.wait_stream(torch.cuda.current_stream())
+            pol._capture = self
+            try:
+                with torch.cuda.stream(cap):
+                    self.graph.capture_begin()
+                    try:
+                        self.outs = fn(*self.static)
+                    finally:
+                        (self.graph2 if self.graph2 is not None else self.graph).capture_end()
+            finally:
+                pol._capture = None
+            torch.cuda.current_stream().wait_stream(cap)
             self.ws = pol._ws
         finally:
             pol._ws = ws_saved
+
+    def split(self):
+        """Called by the forward under capture: everything enqueued so far becomes graph 1, the rest graph 2 (same pool)."""
+        if self.graph2 is not None:
+            return
+        self.graph.capture_end()
+        self.graph2 = torch.cuda.CUDAGraph()
+        self.graph2.capture_begin(self.graph.pool())
 
     def __call__(self, args):
         pairs = []
@@ -72,7 +109,15 @@ class _Graph:
             elif isinstance(s, dict) and s is not a:
                 pairs += [(s[k], a[k]) for k in s]
         L.multi_copy(pairs)                              # one launch for all static-input refreshes
-        self.graph.replay()
+        if self.graph2 is None:
+            if self.between is not None:
+                self.between()
+            self.graph.replay()
+        else:
+            self.graph.replay()
+            if self.between is not None:
+                self.between()                           # e.g. wait for the text tower's event on this stream
+            self.graph2.replay()
         return self.outs
 
 
@@ -109,6 +154,7 @@ def _graphed(pol, which, fn, args, mode=None):
         g = pol._graphs[key] = _Graph(pol, fn, args, by_ptr)
     if mode == "lead":
         grp.static_obs = g.static[0]
+    g.between = getattr(pol, "_between", None)
     outs, heads = g(args)
     outs = list(outs)
     outs[1] = rnn
@@ -225,6 +271,8 @@ class Policy(nn.Module):
         self._enc_group = None
         self._shared_mode = None
         self._stash = None
+        self._capture = None                  # the _Graph being captured (lets a forward cut itself in two, see _Graph.split)
+        self._between = None                  # host action between the two halves of a split graph
         self._pinned = {}
         self._eng = None
         self._ws = E.Workspaces()
@@ -367,7 +415,11 @@ class Policy(nn.Module):
         if which == "vln" and txt is not None:
             tok = net_args[7]
             if tok is not None and txt[0] == tok.data_ptr() and txt[1] == tuple(tok.shape):
-                torch.cuda.current_stream().wait_event(txt[3])
+                ev = txt[3]
+                if self.use_graphs:                      # the wait sits between the two halves of the captured forward
+                    self._between = lambda: torch.cuda.current_stream().wait_event(ev)
+                else:
+                    torch.cuda.current_stream().wait_event(ev)
             else:
                 self.net._text, self.net._text_key = None, None
         mode, grp = None, self._enc_group
@@ -381,7 +433,10 @@ class Policy(nn.Module):
         try:
             if not self.use_graphs:
                 return eager(*net_args)
-            out = _graphed(self, which, eager, net_args, mode)
+            try:
+                out = _graphed(self, which, eager, net_args, mode)
+            finally:
+                self._between = None
             if which == "vln" and getattr(self.net, "_text", None) is not None:
                 self.net._text_read = torch.cuda.Event()
                 self.net._text_read.record(torch.cuda.current_stream())
@@ -850,6 +905,8 @@ class AudioNavDialogNet(_SMTBase):
         if all_dialog is not None:
             if fork and pre is None:
                 cur.wait_stream(s_txt)
+            if fork and pre is not None and getattr(pol, "_capture", None) is not None and _SPLIT:
+                pol._capture.split()                     # everything above does not need the text embedding
             d_emb = torch.empty(B, d, device=dev)
             dl = eng["dialog_layer"]
             if pol.prec == L.PREC_BF16 and dl.w16:

@@ -31,8 +31,8 @@ for it in range(STEPS):
     mark("txt_start", wl._side[2]) if False else None
     wl.pi_l.prefetch_text(v["dialog"], wl._side[2], after_current=False)
     mark("txt_end", wl._side[2]); host_t = time.perf_counter()
-    wl.pi_g.prefetch_act(obs, h, prev, v["masks"], em_goal, em_masks, stream=wl._side[0])
-    mark("g_end", wl._side[0]); host_g = time.perf_counter()
+    wl.pi_g.prefetch_act(obs, h, prev, v["masks"], em_goal, em_masks, stream=wl._side[wl._g_stream])
+    mark("g_end", wl._side[wl._g_stream]); host_g = time.perf_counter()
     wl.pi_l.prefetch_act_dialog(obs, h, prev, v["masks_vln"], em_vln, em_dlg, v["em_vln_masks"], v["dialog"], v["astep"],
                                 stream=wl._side[1])
     mark("l_end", wl._side[1]); host_l = time.perf_counter()
