@@ -1,0 +1,27 @@
+#!/bin/bash
+# Collects the round's judged artifacts on the GPU box into gpurun_out/prof_final/ (copied into profiles/ afterwards):
+# default bench line, GPU parity-test log, rocprofv3 kernel statistics of a 30-step rollout + update, per-step / update
+# breakdowns, step timeline, and the three separate --pmc passes over tools/roofline_probe.py.
+set -o pipefail
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/prof_final
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+python3 $R/bench.py > $O/bench_default.log 2>&1 || exit 1
+tail -1 $O/bench_default.log | cut -c1-300
+python3 -m pytest $R/tests -m gpu -q > $O/gpu_parity_tests.log 2>&1 || exit 1
+tail -1 $O/gpu_parity_tests.log
+rocprofv3 --kernel-trace --stats -d /tmp/ps -o res -- python3 $R/bench.py --steps 1 --warmup 1 --rollout 30 --no-cpu-baseline --no-roofline > /tmp/ps.log 2>&1 || exit 1
+DB=$(find /tmp/ps -name "*.db" | head -1)
+python3 $R/tools/prof_summary.py $DB > $O/rocprof_summary_head.md || exit 1
+python3 $R/tools/step_breakdown.py $DB 30 > $O/step_breakdown.md || exit 1
+python3 $R/tools/update_breakdown.py $DB > $O/update_breakdown.md || exit 1
+python3 $R/tools/step_timeline.py 2>&1 | grep "times since" > $O/step_timeline.txt || exit 1
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o res -- python3 $R/tools/roofline_probe.py > /tmp/pmc_$c.log 2>&1 || exit 1
+  cp $(find /tmp/pmc_$c -name "*counter_collection.csv" | head -1) $O/pmc_${c}_counter_collection.csv || exit 1
+done
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmc_mfma -o res -- python3 $R/tools/roofline_probe.py > /tmp/pmc_mfma.log 2>&1 || exit 1
+cp $(find /tmp/pmc_mfma -name "*counter_collection.csv" | head -1) $O/pmc_MFMA_counter_collection.csv || exit 1
+python3 $R/tools/pmc_traffic.py $O/pmc_FETCH_SIZE_counter_collection.csv $O/pmc_WRITE_SIZE_counter_collection.csv $O/pmc_traffic.json $O/pmc_MFMA_counter_collection.csv > /dev/null || exit 1
+cat $O/pmc_traffic.json | head -30

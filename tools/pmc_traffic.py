@@ -19,7 +19,14 @@ def per_kernel(path, counter):
     return {k: (v[0] / v[1], v[2]) for k, v in acc.items()}
 
 
-def main(fetch_csv, write_csv, out):
+def mfma_util(path):
+    """MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (cycles x 1024 SIMDs) with cycles = GRBM_GUI_ACTIVE / 8 (rocprofv3 reports the
+    sum over the 8 XCDs, MI355X_MICROARCH.md), per kernel class, from the third pass."""
+    busy, act = per_kernel(path, "SQ_VALU_MFMA_BUSY_CYCLES"), per_kernel(path, "GRBM_GUI_ACTIVE")
+    return {k: 100.0 * busy[k][0] / (act[k][0] / 8.0 * 1024.0) for k in busy if k in act and act[k][0] > 0}
+
+
+def main(fetch_csv, write_csv, out, mfma_csv=None):
     sys.path.insert(0, __file__.rsplit("/", 1)[0])
     f, w = per_kernel(fetch_csv, "FETCH_SIZE"), per_kernel(write_csv, "WRITE_SIZE")
     alg = {"gemm": 2464 * 2048 * 2 + 512 * 2048 * 2 + 2 * 2464 * 512 * 4, "dconv": 384 * 64 * 64 * 16 * 2 * 2}
@@ -31,9 +38,15 @@ def main(fetch_csv, write_csv, out):
         fk, name = f[k]; wk, _ = w[k]
         res[k] = {"kernel": name[:120], "FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "traffic_bytes": (2 * fk + wk) * 1024,
                   "algorithmic_bytes": alg[k]}
+    if mfma_csv:
+        for k, v in mfma_util(mfma_csv).items():
+            if k in res:
+                res[k]["MfmaUtil_percent"] = round(v, 2)
+        res["mfma_note"] = ("MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), third rocprofv3 --pmc pass over "
+                            "tools/roofline_probe.py")
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:5])
