@@ -107,6 +107,12 @@ class Heads(C.Structure):
     _fields_ = [("action", Linear), ("critic", Linear), ("unct", Linear), ("has_unct", C.c_int)]
 
 
+class ExtMemOp(C.Structure):
+    _fields_ = [("memory", C.c_void_p), ("masks", C.c_void_p), ("feats", C.c_void_p), ("ld_feats", C.c_int),
+                ("not_done", C.c_void_p), ("masks_out", C.c_void_p), ("idx", C.c_int), ("total", C.c_int),
+                ("capacity", C.c_int), ("N", C.c_int), ("dim", C.c_int)]
+
+
 i32, f32, sz = C.c_int, C.c_float, C.c_size_t
 
 # name -> (restype, argtypes); every symbol declared in include/avlen_hip.h
@@ -167,6 +173,7 @@ SIGNATURES = {
     "avlen_grad_sumsq": (i32, [vp, sz, vp, vp]),
     "avlen_adam_step": (i32, [vp, vp, vp, vp, sz, f32, f32, f32, f32, i32, f32, vp, vp]),
     "avlen_extmem_insert": (i32, [vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "avlen_extmem_insert_multi": (i32, [vp, i32, vp]),
     "avlen_minibatch_gather": (i32, [vp, vp, vp, i32, i32, i32, sz, i32, vp]),
     "avlen_copy_rows": (i32, [vp, i32, vp, i32, i32, i32, vp]),
     "avlen_multi_copy": (i32, [vp, vp, vp, i32, vp]),

@@ -301,6 +301,32 @@ __global__ void extmem_insert_kernel(float* __restrict__ memory, float* __restri
   }
 }
 
+// All of a step's external-memory rings in one launch (blockIdx.y = ring)
+struct ExtMemOps { avlen_extmem_op op[4]; };
+__global__ void extmem_insert_multi_kernel(ExtMemOps ops) {
+  const avlen_extmem_op o = ops.op[blockIdx.y];
+  const int n = blockIdx.x;
+  if (n >= o.N) return;
+  __shared__ float sh[16];
+  __shared__ int s_over;
+  for (int i = threadIdx.x; i < o.dim; i += blockDim.x) o.memory[((long)o.idx * o.N + n) * o.dim + i] = o.feats[(long)n * o.ld_feats + i];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < o.total; i += blockDim.x) s += o.masks[(long)n * o.total + i];
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) s_over = (s == (float)o.capacity);
+  __syncthreads();
+  const int drop = (o.idx - o.capacity + o.total) % o.total;
+  const float nd = o.not_done[n];
+  for (int i = threadIdx.x; i < o.total; i += blockDim.x) {
+    float mv = o.masks[(long)n * o.total + i];
+    if (s_over && i == drop) mv = 0.f;
+    if (i == o.idx) mv = 1.f;
+    mv *= nd;
+    o.masks[(long)n * o.total + i] = mv;
+    if (o.masks_out) o.masks_out[(long)n * o.total + i] = mv;
+  }
+}
+
 template <typename T>
 __global__ void gather_kernel(const T* __restrict__ src, T* __restrict__ dst, const int64_t* __restrict__ env, int N, int n_mb,
                               size_t D, size_t tot) {
@@ -372,6 +398,19 @@ extern "C" int avlen_extmem_insert(float* memory, float* masks, const float* fea
   if (idx < 0 || idx >= total || N <= 0) return AVLEN_ERR_ARG;
   hipLaunchKernelGGL(extmem_insert_kernel, dim3(N), dim3(256), 0, stream, memory, masks, feats, ld_feats, not_done, masks_out,
                      idx, total, capacity, N, dim);
+  return avlen_launch_status();
+}
+
+extern "C" int avlen_extmem_insert_multi(const avlen_extmem_op* ops, int n, hipStream_t stream) {
+  if (!ops || n < 1 || n > 4) return AVLEN_ERR_ARG;
+  ExtMemOps o = {};
+  int maxn = 0;
+  for (int i = 0; i < n; i++) {
+    if (ops[i].idx < 0 || ops[i].idx >= ops[i].total || ops[i].N <= 0) return AVLEN_ERR_ARG;
+    o.op[i] = ops[i];
+    if (ops[i].N > maxn) maxn = ops[i].N;
+  }
+  hipLaunchKernelGGL(extmem_insert_multi_kernel, dim3(maxn, n), dim3(256), 0, stream, o);
   return avlen_launch_status();
 }
 

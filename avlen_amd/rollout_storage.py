@@ -52,6 +52,19 @@ class ExternalMemory:
                self.num_envs, self.dim, L.stream())
         self.idx = (self.idx + 1) % self.total_size
 
+    def fill_op(self, op, em_features, not_done_masks, masks_out=None):
+        """Describe this ring's insert in `op` (an _lib.ExtMemOp) for a batched `avlen_extmem_insert_multi` launch and advance
+        the ring index; returns the tensors that must stay alive until the launch is enqueued."""
+        f = em_features if em_features.is_contiguous() else em_features.contiguous()
+        nd = not_done_masks if (not_done_masks.dtype == torch.float32 and not_done_masks.is_contiguous()) \
+            else not_done_masks.float().contiguous()
+        op.memory, op.masks, op.feats, op.ld_feats = self.memory.data_ptr(), self.masks.data_ptr(), f.data_ptr(), f.shape[1]
+        op.not_done = nd.data_ptr()
+        op.masks_out = masks_out.data_ptr() if masks_out is not None else None
+        op.idx, op.total, op.capacity, op.N, op.dim = self.idx, self.total_size, self.capacity, self.num_envs, self.dim
+        self.idx = (self.idx + 1) % self.total_size
+        return f, nd
+
     def to(self, device):
         self.masks, self.memory = self.masks.to(device), self.memory.to(device)
 
@@ -104,6 +117,7 @@ class RolloutStorage:
             self.em_vln_dialog = mk(self.em_vln_size, self.em_vln_capacity, self.em_dim_dialog)
         self.step = 0
         self._plans = {}
+        self._em_ops = (L.ExtMemOp * 4)()
 
     def to(self, device):
         dev = torch.device(device)
@@ -169,14 +183,29 @@ class RolloutStorage:
             for v, d in zip(srcs, dsts):
                 d.copy_(v if torch.is_tensor(v) else torch.as_tensor(v))
         nd, ndv = self.masks[s + 1], self.masks_vln[s + 1]
-        if self.use_external_memory:
-            self.em.insert(em_features, nd, self.em_masks[s + 1])
-            self.em_option.insert(em_features_option, nd)
-            self.em_vln.insert(em_features_vln, ndv, self.em_vln_masks[s + 1])
-        if self.use_state_memory:
-            self.em_vln_dialog.insert(em_features_dialog, ndv)
-            if not self.use_external_memory:
+        if dev.type == "cuda":                         # the step's ring inserts as ONE launch
+            ops, n, alive = self._em_ops, 0, []
+            if self.use_external_memory:
+                alive.append(self.em.fill_op(ops[0], em_features, nd, self.em_masks[s + 1]))
+                alive.append(self.em_option.fill_op(ops[1], em_features_option, nd))
+                alive.append(self.em_vln.fill_op(ops[2], em_features_vln, ndv, self.em_vln_masks[s + 1]))
+                n = 3
+            if self.use_state_memory:
+                alive.append(self.em_vln_dialog.fill_op(ops[n], em_features_dialog, ndv))
+                n += 1
+            if n:
+                L.call("avlen_extmem_insert_multi", ops, n, L.stream())
+            if self.use_state_memory and not self.use_external_memory:
                 self.em_vln_masks[s + 1].copy_(self.em_vln_dialog.masks)
+        else:
+            if self.use_external_memory:
+                self.em.insert(em_features, nd, self.em_masks[s + 1])
+                self.em_option.insert(em_features_option, nd)
+                self.em_vln.insert(em_features_vln, ndv, self.em_vln_masks[s + 1])
+            if self.use_state_memory:
+                self.em_vln_dialog.insert(em_features_dialog, ndv)
+                if not self.use_external_memory:
+                    self.em_vln_masks[s + 1].copy_(self.em_vln_dialog.masks)
         self.step = s + 1
 
     def after_update(self):

@@ -48,9 +48,9 @@ def parse():
 
 def kernel_roofline(prec_name):
     """Roofline of the DOMINANT kernel by GPU time in the rollout (profiles/r01_rocprof_summary.md):
-    g2_kernel<64,128,2,4,NS,512>, the bf16 MFMA GEMM (8-wave ping-pong tile, global_load_lds staging) on its heaviest call site, the
-    CLIP text MLP down-projection of one rollout step on the ragged batch (M = 2464 live rows, N = 512, K = 2048, fp32
-    residual epilogue).  `achieved` = 2*M*N*K / duration measured live with HIP events on the launch stream; `peak` = dense
+    g2_kernel<64,128,2,4,2,512>, the bf16 MFMA GEMM (8-wave ping-pong tile, global_load_lds staging) on its heaviest call site, the
+    CLIP text MLP up-projection c_fc of one rollout step on the ragged batch (M = 2464 live rows, N = 2048, K = 512, bias +
+    QuickGELU, bf16 out); the block's other three GEMMs are listed under `other_call_sites`.  `achieved` = 2*M*N*K / duration measured live with HIP events on the launch stream; `peak` = dense
     bf16 MFMA; `traffic` = HBM bytes per launch from the rocprofv3 PMC passes (profiles/r01_pmc_traffic.json: 2 x FETCH_SIZE +
     WRITE_SIZE, gfx950 correction).  The HBM-bound kernel class (direct 3x3 conv of the towers' layer 1) is reported beside it
     as `hbm_conv`."""
@@ -67,7 +67,7 @@ def kernel_roofline(prec_name):
     gw, cw = rp.gemm_work(), rp.conv_work()
     tf = gw["flops"] / sg / 1e12
     gb = cw["bytes"] / sc / 1e9
-    return {"bound": "mfma", "kernel": "g2_kernel<64,128,2,4,4,512> bf16 glds GEMM (CLIP c_proj, ragged M=2464 N=512 K=2048)",
+    return {"bound": "mfma", "kernel": "g2_kernel<64,128,2,4,2,512> bf16 glds GEMM (CLIP c_fc, ragged M=2464 N=2048 K=512)",
             "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
             "traffic": pmc.get("gemm", {}).get("traffic_bytes"), "mfma_util_pmc_percent": pmc.get("gemm", {}).get("MfmaUtil_percent"),
             "algorithmic_flops": gw["flops"],

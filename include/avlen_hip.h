@@ -294,6 +294,10 @@ int avlen_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
  * masks (N,total).  Also snapshots the new masks to masks_out (N,total) when non-NULL. */
 int avlen_extmem_insert(float* memory, float* masks, const float* feats, int ld_feats, const float* not_done,
                         float* masks_out, int idx, int total, int capacity, int N, int dim, avlen_stream_t stream);
+/* The same for up to 4 rings in ONE launch (a rollout step writes the goal, option, vln and dialog rings). */
+typedef struct { float* memory; float* masks; const float* feats; int ld_feats; const float* not_done; float* masks_out;
+                 int idx, total, capacity, N, dim; } avlen_extmem_op;
+int avlen_extmem_insert_multi(const avlen_extmem_op* ops, int n, avlen_stream_t stream);
 /* recurrent_generator's gather (rollout_storage.py:649-782): dst[(t*n_mb + j), :] = src[t, env[j], :]
  * for t < T; src is (T_alloc, N, D) fp32 (elem_bytes=4) or int64 (elem_bytes=8). */
 int avlen_minibatch_gather(const void* src, void* dst, const int64_t* env, int T, int N, int n_mb, size_t D,

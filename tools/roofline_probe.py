@@ -1,9 +1,9 @@
 """Runs the two kernels bench.py reports a roofline for, in isolation, so that rocprofv3 --pmc passes can attribute HBM
 traffic to them:
-  * `gemm`  : g2_kernel<64,128,2,4,NS,512> (8-wave ping-pong tile) -- the dominant kernel of the rollout by GPU time
-              (profiles/r01_rocprof_summary.md), on its heaviest call site: the CLIP text MLP down-projection on the ragged
-              batch (M = 2464 live rows = half of 64 x 77, N = 512, K = 2048; NS = 4), bf16 operands via global_load_lds,
-              fp32 residual epilogue.  MFMA-bound class.
+  * `gemm`  : g2_kernel<64,128,2,4,2,512> (8-wave ping-pong tile, 2 LDS stages) -- the dominant kernel of the rollout by GPU
+              time (profiles/r01_rocprof_summary.md: 630 of 2400 us per step), on its heaviest call site: the CLIP text MLP
+              up-projection c_fc on the ragged batch (M = 2464 live rows = half of 64 x 77, N = 2048, K = 512), bf16 operands
+              via global_load_lds, bias + QuickGELU epilogue, bf16 output.  MFMA-bound class.
   * `dconv` : dconv3x3_kernel<16,16,64,3> -- the layer-1 3x3 convolution of the six ResNet towers (384 images of 64x64x16 per
               launch, bf16 in / bf16 out, fused GroupNorm statistics).  HBM-bound class.
 Prints event-timed durations and algorithmic FLOPs / bytes per launch as JSON."""
@@ -13,13 +13,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from avlen_amd import _lib as L
 from avlen_amd.engine import P
 
-GEMM = dict(M=2464, N=512, K=2048)
+GEMM = dict(M=2464, N=2048, K=512, epilogue="bf16", act=2)
 CONV = dict(B=384, W=64, C=16)
 
 
-def make_gemm(M=None, N=None, K=None, epilogue="residual32", act=0):
+def make_gemm(M=None, N=None, K=None, epilogue=None, act=None):
     """epilogue: "residual32" = fp32 residual in/out (out_proj / c_proj), "bf16" = bias (+ activation), bf16 out only (in_proj / c_fc)."""
     M, N, K = M or GEMM["M"], N or GEMM["N"], K or GEMM["K"]
+    epilogue = epilogue or GEMM["epilogue"]
+    act = GEMM["act"] if act is None else act
     A = torch.randn(M, K, device="cuda").bfloat16(); Wt = (torch.randn(N, K, device="cuda") / math.sqrt(K)).bfloat16()
     b = torch.randn(N, device="cuda"); X = torch.randn(M, N, device="cuda")
     Y16 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
@@ -44,7 +46,7 @@ def make_conv():
 
 def gemm_work():
     M, N, K = GEMM["M"], GEMM["N"], GEMM["K"]
-    return {"flops": 2.0 * M * N * K, "bytes": M * K * 2 + N * K * 2 + 2 * M * N * 4}     # A + W (bf16) + residual in/out (fp32)
+    return {"flops": 2.0 * M * N * K, "bytes": M * K * 2 + N * K * 2 + M * N * 2}         # A + W (bf16) in, bf16 out
 
 
 def conv_work():
@@ -52,9 +54,9 @@ def conv_work():
     return {"flops": 2.0 * B * W * W * C * C * 9, "bytes": B * W * W * C * 2 * 2}          # bf16 activation in + out, once each
 
 
-# the other GEMMs of one CLIP text block on the same ragged batch (same kernel family, NS = 2): qkv, out_proj, c_fc
+# the other GEMMs of one CLIP text block on the same ragged batch (same kernel family): qkv, out_proj (NS = 2), c_proj (NS = 4)
 CLIP_SITES = {"in_proj": (2464, 1536, 512, "bf16", 0), "out_proj": (2464, 512, 512, "residual32", 0),
-              "c_fc": (2464, 2048, 512, "bf16", 2)}
+              "c_proj": (2464, 512, 2048, "residual32", 0)}
 
 
 def clip_call_sites():
