@@ -64,6 +64,7 @@ class Workload:
                                        308, 256, num_recurrent_layers=-1, max_dialog_len=77, use_state_memory=True,
                                        device=self.dev)
         self.belief = None
+        self._act_buf = None
         if belief_predictor:        # use_belief_predictor: True in the interactive yamls (ppo_trainer.py:892); 65x26 spectrogram only
             import types
             from .belief_predictor import BeliefPredictor
@@ -162,7 +163,9 @@ class Workload:
         if self.pi_l is not None:
             _, a_vln, _, _, row_vln, row_dlg, probs_vln = self.pi_l.act_dialog(
                 obs, h, prev, v["masks_vln"], em_vln, em_dlg, v["em_vln_masks"], v["dialog"], v["astep"])
-            actions = torch.where(a_opt == 1, a_vln, actions)           # queried envs follow pi_l
+            if self._act_buf is None:
+                self._act_buf = torch.empty_like(a_vln)
+            actions = torch.where(a_opt == 1, a_vln, actions, out=self._act_buf)       # queried envs follow pi_l
         if probs_vln is None:
             probs_vln = self.zero_probs
         if self.belief is not None:                 # beliefs of the NEW observation, written in place before it is stored

@@ -117,6 +117,7 @@ class RolloutStorage:
             self.em_vln_dialog = mk(self.em_vln_size, self.em_vln_capacity, self.em_dim_dialog)
         self.step = 0
         self._plans = {}
+        self._src_plans = {}
         self._em_ops = (L.ExtMemOp * 4)()
 
     def to(self, device):
@@ -130,6 +131,7 @@ class RolloutStorage:
                 em.to(dev)
         self.device = dev
         self._plans = {}
+        self._src_plans = {}
 
     # ---------------------------------------------------------------- insert (rollout_storage.py:214-297)
     def insert(self, observations, recurrent_hidden_states, actions, actions_option, action_log_probs, value_preds,
@@ -169,17 +171,31 @@ class RolloutStorage:
         if have_opt:
             srcs.append(actions_option)
         srcs += [actions, action_log_probs, value_preds, rewards, not_done_masks, not_done_masks_vln]
-        keep, ptrs = [], []
-        for v, d, (dt, n) in zip(srcs, dsts, meta):
-            if not (torch.is_tensor(v) and v.is_cuda and v.dtype == dt and v.numel() == n and v.is_contiguous()):
-                v = (v if torch.is_tensor(v) else torch.as_tensor(v)).to(dev, dtype=dt, non_blocking=True)
-                v = v.reshape(d.shape) if v.numel() == n else v.expand_as(d)
-                v = v.contiguous()
-                keep.append(v)                       # alive until the launch below has been enqueued
-            ptrs.append(v.data_ptr())
-        if dev.type == "cuda":
-            L.call("avlen_multi_copy", (C.c_void_p * len(ptrs))(*ptrs), dst_ptrs, sizes, len(ptrs), L.stream())
+        # Fast path: the same source tensors (address, dtype, element count) as the last time this step slot was written -- a
+        # trainer that hands over views of persistent buffers, as the HIP-graph outputs are -- reuse the validated pointer array.
+        try:
+            sig = tuple((v.data_ptr(), v.dtype, v.numel(), v.is_contiguous()) for v in srcs)
+        except AttributeError:                           # a host scalar / list among the sources
+            sig = None
+        fast = self._src_plans.get((s, have_o, have_opt)) if sig is not None else None
+        if fast is not None and fast[0] == sig and dev.type == "cuda":
+            L.call("avlen_multi_copy", fast[1], dst_ptrs, sizes, len(sig), L.stream())
         else:
+            keep, ptrs, direct = [], [], True
+            for v, d, (dt, n) in zip(srcs, dsts, meta):
+                if not (torch.is_tensor(v) and v.is_cuda and v.dtype == dt and v.numel() == n and v.is_contiguous()):
+                    v = (v if torch.is_tensor(v) else torch.as_tensor(v)).to(dev, dtype=dt, non_blocking=True)
+                    v = v.reshape(d.shape) if v.numel() == n else v.expand_as(d)
+                    v = v.contiguous()
+                    keep.append(v)                       # alive until the launch below has been enqueued
+                    direct = False
+                ptrs.append(v.data_ptr())
+            if dev.type == "cuda":
+                arr = (C.c_void_p * len(ptrs))(*ptrs)
+                L.call("avlen_multi_copy", arr, dst_ptrs, sizes, len(ptrs), L.stream())
+                if direct and sig is not None:           # every source was usable in place: remember the pointer array
+                    self._src_plans[(s, have_o, have_opt)] = (sig, arr)
+        if dev.type != "cuda":
             for v, d in zip(srcs, dsts):
                 d.copy_(v if torch.is_tensor(v) else torch.as_tensor(v))
         nd, ndv = self.masks[s + 1], self.masks_vln[s + 1]
