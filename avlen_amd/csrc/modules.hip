@@ -19,13 +19,71 @@ static inline size_t zmax(size_t a, size_t b) { return a > b ? a : b; }
 
 namespace {
 
+typedef __bf16 bf16;
 constexpr size_t GEMM_SCRATCH = 96u << 20;       // split-K / accumulate slabs shared by one module call
 
-struct Ctx { hipStream_t st; int prec; void* gws; size_t gws_bytes; const int* live = nullptr; const int* seg = nullptr; };
+struct Ctx { hipStream_t st; int prec; void* gws; size_t gws_bytes; const int* live = nullptr; const int* seg = nullptr;
+             void* xs = nullptr; size_t xs_bytes = 0; };      // xs: operand scratch of the large-M bf16 products below
+
+// ---- large-M products of the TRAINING path (2nd stage: 722 k token rows per minibatch) ----
+// The training forward/backward keeps fp32 activations (LayerNorm / residual / softmax math and the saved tensors of the
+// backward).  The fp32-staged GEMM converts them on the fly and reaches ~95 TFLOP/s at M = 722 k, N = K = 256; casting the
+// operands to bf16 once (transposed for the weight gradient, whose contraction runs over the rows) and running the
+// glds / 8-wave MFMA kernel is 2x faster end to end even with the extra pass.  Same arithmetic (bf16 operands, fp32
+// accumulate), different summation order.  Used when bf16 mode is on, scratch was laid out and M >= big_m().
+long g_big_m = -1;
+long big_m() {
+  if (g_big_m < 0) { const char* e = getenv("AVLEN_BIGM"); g_big_m = e ? atol(e) : 16384; }
+  return g_big_m;
+}
+inline int pad8(long x) { return (int)((x + 7) & ~7L); }
+
+// fp32 [R][C] (row stride ld) -> bf16 [C][ldt] (transposed); columns R .. Rp-1 of every output row are zero
+__global__ void tcast_kernel(const float* __restrict__ src, int ld, bf16* __restrict__ dst, long ldt, long R, int C, long Rp) {
+  __shared__ float t[32][33];
+  const long r0 = (long)blockIdx.x * 32; const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x, ty = threadIdx.y;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const long r = r0 + ty + j * 8; const int c = c0 + tx;
+    t[ty + j * 8][tx] = (r < R && c < C) ? src[r * ld + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int c = c0 + ty + j * 8; const long r = r0 + tx;
+    if (c < C && r < Rp) dst[(long)c * ldt + r] = (bf16)t[tx][ty + j * 8];
+  }
+}
+int tcast(const Ctx& c, const float* src, int ld, bf16* dst, long ldt, long R, int C) {
+  const long Rp = ldt;
+  hipLaunchKernelGGL(tcast_kernel, dim3((unsigned)((Rp + 31) / 32), ceil_div(C, 32)), dim3(32, 8), 0, c.st, src, ld, dst, ldt, R, C, Rp);
+  return avlen_launch_status();
+}
+struct XsBump {        // carve 256-byte aligned pieces out of the operand scratch; ok() false -> caller falls back
+  char* base; size_t off, cap; bool good = true;
+  XsBump(const Ctx& c) : base((char*)c.xs), off(0), cap(c.xs_bytes) {}
+  bf16* take(size_t elems) {
+    size_t o = align_up(off, 256); off = o + elems * 2;
+    if (off > cap) good = false;
+    return (bf16*)(base + o);
+  }
+};
+bool big_path(const Ctx& c, long M) { return c.prec == AVLEN_PREC_BF16 && c.xs && M >= big_m(); }
 
 // Y[M, out_f] (ldy) = act(X[M, in_f] (ldx) * W^T + b) + res
 int linear(const Ctx& c, const avlen_linear& L, const float* X, int ldx, float* Y, int ldy, int M, int act,
            const float* res, int ldr) {
+  if (big_path(c, M)) {
+    const int Kp = pad8(L.in_f);
+    XsBump b(c);
+    bf16* X16 = b.take((size_t)M * Kp); bf16* W16 = b.take((size_t)L.out_f * Kp);
+    if (b.good) {
+      TRY(avlen_cast_bf16(X, ldx, X16, Kp, M, L.in_f, c.st));
+      TRY(avlen_cast_bf16(L.w, L.in_f, W16, Kp, L.out_f, L.in_f, c.st));
+      return avlen_gemm_bf16(X16, Kp, W16, Kp, Y, ldy, nullptr, 0, L.b, res, ldr, M, L.out_f, Kp, act, c.gws, c.gws_bytes, c.st);
+    }
+  }
   int sk = avlen_gemm_pick_splitk(M, L.out_f, L.in_f);
   if (avlen_gemm_workspace_bytes(M, L.out_f, L.in_f, sk) > c.gws_bytes) sk = 1;
   return avlen_gemm(X, ldx, 0, L.w, L.in_f, 0, Y, ldy, L.b, res, ldr, M, L.out_f, L.in_f, act, c.prec, sk, 0.f,
@@ -41,11 +99,33 @@ int linear_rows(const Ctx& c, const avlen_linear& L, int r0, int n, const float*
 // dX[M, in_f] = dY[M, out_f] * W (+ add)     add==dX allowed (in-place accumulate)
 int linear_dx(const Ctx& c, const avlen_linear& L, const float* dY, int ldy, float* dX, int ldx, int M, const float* add,
               int ldadd) {
+  if (big_path(c, M)) {
+    const int Np = pad8(L.out_f);
+    XsBump b(c);
+    bf16* dY16 = b.take((size_t)M * Np); bf16* WT16 = b.take((size_t)L.in_f * Np);
+    if (b.good) {
+      TRY(avlen_cast_bf16(dY, ldy, dY16, Np, M, L.out_f, c.st));
+      TRY(tcast(c, L.w, L.in_f, WT16, Np, L.out_f, L.in_f));           // W [out_f][in_f] -> W^T [in_f][Np]
+      return avlen_gemm_bf16(dY16, Np, WT16, Np, dX, ldx, nullptr, 0, nullptr, add, ldadd, M, L.in_f, Np, 0, c.gws, c.gws_bytes,
+                             c.st);
+    }
+  }
   return avlen_gemm(dY, ldy, 0, L.w, L.in_f, 1, dX, ldx, nullptr, add, ldadd, M, L.in_f, L.out_f, 0, c.prec, 1, 0.f,
                     c.gws, c.gws_bytes, c.st);
 }
 // dW[out_f, in_f] += dY^T X   (reduction over the M rows, split over the chip)
 int linear_dw(const Ctx& c, const avlen_linear& G, const float* dY, int ldy, const float* X, int ldx, int M) {
+  if (big_path(c, M)) {
+    const long Mp = pad8(M);
+    XsBump b(c);
+    bf16* dYT = b.take((size_t)G.out_f * Mp); bf16* XT = b.take((size_t)G.in_f * Mp);
+    if (b.good) {
+      TRY(tcast(c, dY, ldy, dYT, Mp, M, G.out_f));
+      TRY(tcast(c, X, ldx, XT, Mp, M, G.in_f));
+      return avlen_gemm_bf16(dYT, (int)Mp, XT, (int)Mp, G.w, G.in_f, nullptr, 0, nullptr, G.w, G.in_f, G.out_f, G.in_f, (int)Mp, 0,
+                             c.gws, c.gws_bytes, c.st);
+    }
+  }
   int sk = avlen_gemm_pick_splitk(G.out_f, G.in_f, M);
   while (sk > 1 && avlen_gemm_workspace_bytes(G.out_f, G.in_f, M, sk) > c.gws_bytes) sk /= 2;
   return avlen_gemm(dY, ldy, 1, X, ldx, 1, G.w, G.in_f, nullptr, nullptr, 0, G.out_f, G.in_f, M, 0, c.prec, sk, 1.f,
@@ -297,7 +377,6 @@ __global__ void gru_gate_kernel(const float* __restrict__ gi, const float* __res
 // =====================================================================================================
 namespace {
 
-typedef __bf16 bf16;
 
 bool lin16_ok(const avlen_linear& L) { return L.w16 != nullptr && (L.ld16 % 8) == 0; }
 
@@ -1043,7 +1122,8 @@ int transformer_bwd(const Ctx& c, const avlen_transformer& tr, const avlen_trans
   return AVLEN_OK;
 }
 
-struct SmtWs { float *XF, *FMT, *maskx, *H1, *Z; TrWs tr; TrBwdWs tb; float *dZ, *dH1, *dPE; void* gws; int ldxf; };
+struct SmtWs { float *XF, *FMT, *maskx, *H1, *Z; TrWs tr; TrBwdWs tb; float *dZ, *dH1, *dPE; void* gws; int ldxf;
+               void* xs; size_t xs_bytes; };
 
 void smt_layout(WsBump& w, SmtWs& s, const avlen_smt* p, long B, long M, int F, bool cto) {
   long S = cto ? 1 : M + 1, R = B * S;
@@ -1055,6 +1135,11 @@ void smt_layout(WsBump& w, SmtWs& s, const avlen_smt* p, long B, long M, int F, 
   trb_layout(w, s.tb, B, S, d, p->tr.nhead);
   s.dZ = w.take<float>(R * d); s.dH1 = w.take<float>(R * d); s.dPE = w.take<float>(R * 16);
   s.gws = w.take<char>(GEMM_SCRATCH);
+  s.xs = nullptr; s.xs_bytes = 0;
+  if (R >= big_m()) {            // operand scratch of the large-M bf16 products: two operands of up to 3d + ldxf columns
+    s.xs_bytes = (size_t)(R + 8) * (size_t)(4 * d + s.ldxf + 16) * 2 + ((size_t)4 << 20);
+    s.xs = w.take<char>(s.xs_bytes);
+  }
 }
 
 }  // namespace
@@ -1345,6 +1430,7 @@ extern "C" int avlen_smt_fwd(const avlen_smt* p, const float* x, const float* me
   WsBump w(ws, ws_bytes); SmtWs s;
   smt_layout(w, s, p, B, M, F, cto != 0);
   Ctx c{st, prec, s.gws, GEMM_SCRATCH};
+  c.xs = s.xs; c.xs_bytes = s.xs_bytes;
   const int S = cto ? 1 : M + 1, d = p->tr.d;
   const long R = (long)B * S;
   if (!mem_index) NC = B;
@@ -1362,6 +1448,7 @@ extern "C" int avlen_smt_bwd(const avlen_smt* p, const avlen_smt* g, const float
   WsBump w(ws, ws_bytes); SmtWs s;
   smt_layout(w, s, p, B, M, F, cto != 0);
   Ctx c{st, prec, s.gws, GEMM_SCRATCH};
+  c.xs = s.xs; c.xs_bytes = s.xs_bytes;
   const int S = cto ? 1 : M + 1, d = p->tr.d;
   const long R = (long)B * S;
   TRY(transformer_bwd(c, p->tr, g->tr, s.tr, s.tb, s.Z, s.maskx, goal, d_out, s.dZ, B, S, cto != 0));
@@ -1372,10 +1459,7 @@ extern "C" int avlen_smt_bwd(const avlen_smt* p, const avlen_smt* g, const float
   TRY(relu_bwd(c, s.dH1, s.H1, R * d));
   {
     avlen_linear g0 = g->fus0;            // dW0[d][F+12] += dH1^T XF  (XF rows are ldxf apart)
-    int sk = avlen_gemm_pick_splitk(g0.out_f, g0.in_f, (int)R);
-    while (sk > 1 && avlen_gemm_workspace_bytes(g0.out_f, g0.in_f, (int)R, sk) > GEMM_SCRATCH) sk /= 2;
-    TRY(avlen_gemm(s.dH1, d, 1, s.XF, s.ldxf, 1, g0.w, g0.in_f, nullptr, nullptr, 0, g0.out_f, g0.in_f, (int)R, 0, prec,
-                   sk, 1.f, s.gws, GEMM_SCRATCH, st));
+    TRY(linear_dw(c, g0, s.dH1, d, s.XF, s.ldxf, (int)R));
     TRY(colsum_acc(c, s.dH1, d, g0.b, (int)R, d));
   }
   // pose encoder: dPE[R,16] = dH1 * W0[:, pc:pc+16]
@@ -1593,3 +1677,7 @@ extern "C" int avlen_gru_fwd(const avlen_gru* p, const float* x, const float* h0
   TRY(avlen_launch_status());
   return avlen_copy_rows(hc, H, h_out, H, N, H, st);
 }
+
+// Row count from which the training path's Linear products take the cast-to-bf16 + glds GEMM route (default 16384,
+// env AVLEN_BIGM); <= 0 restores the default.  A tuning / test knob, not part of the reference's interface.
+extern "C" void avlen_set_big_m(long rows) { g_big_m = rows > 0 ? rows : 16384; }

@@ -241,6 +241,9 @@ int avlen_smt_fwd(const avlen_smt* p, const float* x, const float* memory, const
  * ACCUMULATED into `g` (same layout as p). */
 int avlen_smt_bwd(const avlen_smt* p, const avlen_smt* g, const float* goal, const float* d_out, int B, int M, int F,
                   int pose_col, int current_token_only, int prec, void* ws, size_t ws_bytes, avlen_stream_t stream);
+/* Tuning knob: row count from which the training path's Linear products (avlen_smt_fwd with save_for_backward,
+ * avlen_smt_bwd, bf16 mode) cast their fp32 operands to bf16 once and run the glds/MFMA GEMM (default 16384 rows). */
+void avlen_set_big_m(long rows);
 /* DialogStateEncoder.single_forward (dialog_state_encoder.py:114-155): x_att (B,d), memory_state (M,B,d),
  * masks (B,M), d_emb (B,d) or NULL, agent_step (B) float, goal (B,d) -> out (B,d). */
 size_t avlen_dialog_workspace_bytes(const avlen_dialog* p, int B, int M);

@@ -11,7 +11,7 @@ def _header_decls():
     src = open(os.path.join(ROOT, "include", "avlen_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     decls = {}
-    for m in re.finditer(r"\n(?:int|size_t|const char\*)\s+(avlen_\w+)\s*\(([^;]*?)\)\s*;", src):
+    for m in re.finditer(r"\n(?:int|size_t|void|const char\*)\s+(avlen_\w+)\s*\(([^;]*?)\)\s*;", src):
         args = m.group(2).strip()
         n = 0 if args in ("", "void") else len([a for a in args.split(",")])
         decls[m.group(1)] = n

@@ -382,10 +382,44 @@ def test_full_cycle_matches_reference(specs, pre):
 def test_gradients_match_oracle_autograd(specs):
     """Full-memory (pretraining=False) gradient of the PPO loss w.r.t. every trained parameter: HIP backward
     (heads + transformer incl. masked attention + fusion MLP + pose encoder) vs torch autograd on the oracle."""
+    _gradient_check(specs, "fp32", 2e-3)
+
+
+def test_gradients_bf16_training_products(specs):
+    """bf16 mode of the same backward on its two GEMM routes: the fp32-staged kernel and the large-M route (operands cast /
+    transposed to bf16 once, glds MFMA GEMM, split-K weight gradients; default from 16384 rows, forced here from 32).
+    The two BACKWARD routes run on the SAME saved forward and the same upstream gradient: identical bf16-rounded operands, only
+    the fp32 summation order differs -> 5e-3 of each tensor's norm (the pose-encoder bias gradient is a cancelling sum).  (Against fp32 autograd a 6-sample bf16 gradient is only
+    loosely comparable -- a bf16 ulp in the towers moves the action probabilities; that side is bounded by the bf16 policy
+    tests -- so the oracle comparison inside the helper is reported, not asserted, here.)"""
+    from avlen_amd import _lib as L
+    try:
+        L.lib.avlen_set_big_m(32)
+        rerun = {}
+        g_big = _gradient_check(specs, "bf16", float("inf"), loss_rtol=0.2, rerun_bwd=rerun)
+        f_big = rerun["forward"]()
+        L.lib.avlen_set_big_m(0)
+        g_v1 = rerun["again"]()                                                   # same workspace, other route
+        f_v1 = rerun["forward"]()
+        ferr = float((f_big - f_v1).norm() / f_v1.norm())
+        print("large-M forward vs fp32-staged forward on the same features, relative L2 difference:", ferr)
+        assert ferr < 2e-3, ferr            # same bf16 operands; LayerNorm / softmax downstream of a different summation order
+    finally:
+        L.lib.avlen_set_big_m(0)
+    worst = 0.0
+    for k in g_v1:
+        a, b = g_v1[k], g_big[k]
+        err = float((a - b).norm() / (a.norm() + 1e-12))
+        worst = max(worst, err)
+        assert err < 5e-3, (k, err)
+    print("large-M backward vs fp32-staged backward on the same saved forward, max relative L2 difference:", worst)
+
+
+def _gradient_check(specs, precision, tol, loss_rtol=1e-3, rerun_bwd=None):
     import flow
     B, M = 6, 9
     pre = False
-    pol = build("option", pretraining=pre)
+    pol = build("option", precision=precision, pretraining=pre)
     sd = load_fixture(pol, "option", specs)
     pol.cuda()
     tag = "grad"
@@ -427,16 +461,40 @@ def test_gradients_match_oracle_autograd(specs):
            E.P(ws), nb, L.stream())
     torch.cuda.synchronize()
     lossv = loss.cpu().numpy()
-    np.testing.assert_allclose(lossv[[0, 1, 2, 5]], [float(vl), float(al), float(h["entropy"]), float(ul)], rtol=1e-3,
-                               atol=1e-5)
-    worst = 0.0
+    np.testing.assert_allclose(lossv[[0, 1, 2, 5]], [float(vl), float(al), float(h["entropy"]), float(ul)], rtol=loss_rtol,
+                               atol=1e-5 if precision == "fp32" else 2e-3)
+    worst, out_grads = 0.0, {}
     for k in tr:
         ours = flat.grad_view(k, osd[k].shape).cpu().double()
         ref = osd[k].grad.double()
         err = float((ours - ref).abs().max() / (ref.abs().max() + 1e-8))
         worst = max(worst, err)
-        assert err < 2e-3, (k, err)
+        assert err < tol, (k, err)
+        out_grads[k] = ours
     print("max relative gradient error over trained params:", worst)
+    if rerun_bwd is not None:
+        smt_keys = [k for k in tr if k.startswith("net.smt_state_encoder.")]
+
+        def again():                         # the SMT backward once more from the same workspace and upstream gradient
+            first = {k: out_grads[k].clone() for k in smt_keys}
+            flat.grad.zero_()
+            L.call("avlen_smt_bwd", C.byref(eng["smt"]), C.byref(smt_g), E.P(goal), E.P(d_feats), Bq, Mq, F, 272, cto, pol.prec,
+                   E.P(ws), nb, L.stream())
+            torch.cuda.synchronize()
+            return {k: flat.grad_view(k, osd[k].shape).cpu().double() for k in smt_keys}
+        def forward_only():                  # the training forward (save_for_backward) on the SAME features, fresh workspace
+            feats = pol.net._last[0]
+            out = torch.empty(Bq, 256, device="cuda")
+            nb2 = L.lib.avlen_smt_workspace_bytes(C.byref(eng["smt"]), Bq, Mq, F, cto)
+            ws2 = torch.empty(nb2, dtype=torch.uint8, device="cuda")
+            memc, mkc = mem.cuda().contiguous(), mk.cuda().contiguous()
+            L.call("avlen_smt_fwd", C.byref(eng["smt"]), E.P(feats), E.P(memc), None, Bq, E.P(mkc), E.P(goal), E.P(out), Bq, Mq, F,
+                   272, cto, 1, pol.prec, E.P(ws2), nb2, L.stream())
+            torch.cuda.synchronize()
+            return out.cpu().double()
+        rerun_bwd["again"], rerun_bwd["forward"] = again, forward_only
+        return {k: out_grads[k] for k in smt_keys}
+    return out_grads
 
 
 def test_graph_replay_equals_eager(specs):
