@@ -463,6 +463,23 @@ __global__ void cast_rows_kernel(const float* __restrict__ src, int lds_, bf16* 
   dst[i] = c < cols ? (bf16)src[r * lds_ + c] : (bf16)0.f;
 }
 
+// Same cast, 8 elements (32 B in, 16 B out) per thread: both leading dimensions multiples of 8 and 16-byte aligned bases
+__global__ void cast_rows8_kernel(const float* __restrict__ src, int lds_, bf16* __restrict__ dst, int ldd, long rows, int cols) {
+  const int per_row = ldd >> 3;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * per_row) return;
+  const long r = i / per_row; const int c = (int)(i - r * per_row) << 3;
+  bf16x8 o;
+  if (c + 8 <= cols) {
+    const float4 a = *reinterpret_cast<const float4*>(src + r * lds_ + c), b = *reinterpret_cast<const float4*>(src + r * lds_ + c + 4);
+    o[0] = (bf16)a.x; o[1] = (bf16)a.y; o[2] = (bf16)a.z; o[3] = (bf16)a.w; o[4] = (bf16)b.x; o[5] = (bf16)b.y; o[6] = (bf16)b.z; o[7] = (bf16)b.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; e++) o[e] = c + e < cols ? (bf16)src[r * lds_ + c + e] : (bf16)0.f;
+  }
+  *reinterpret_cast<bf16x8*>(dst + r * ldd + c) = o;
+}
+
 // OIHW fp32 -> [O][KH][KW][Cp] bf16 (channels zero-padded to Cp)
 __global__ void pack_conv_bf16_kernel(const float* __restrict__ w, bf16* __restrict__ o, int O, int I, int KH, int KW, int Cp) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -737,6 +754,11 @@ int avlen_gemm_bf16_dyn(const void* A, int lda, const void* B, int ldb, float* C
 extern "C" int avlen_cast_bf16(const float* src, int ld_src, void* dst, int ld_dst, long rows, int cols, hipStream_t stream) {
   long tot = rows * ld_dst;
   if (tot <= 0) return AVLEN_ERR_ARG;
+  if (!(ld_src & 3) && !(ld_dst & 7) && !((uintptr_t)src & 15) && !((uintptr_t)dst & 15)) {
+    long t8 = tot >> 3;
+    hipLaunchKernelGGL(cast_rows8_kernel, dim3((unsigned)((t8 + 255) / 256)), dim3(256), 0, stream, src, ld_src, (bf16*)dst, ld_dst, rows, cols);
+    return avlen_launch_status();
+  }
   hipLaunchKernelGGL(cast_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, src, ld_src, (bf16*)dst, ld_dst, rows, cols);
   return avlen_launch_status();
 }
