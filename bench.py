@@ -132,9 +132,15 @@ def main():
             wl.rollout_step()
         torch.cuda.synchronize()
         t_roll += time.perf_counter() - s0
-        wl.update()
+        last = wl.update()
     barrier()
     dt = time.perf_counter() - t0
+    # outside the timed region: the run must have produced numbers (a kernel race shows up as NaN losses / memories, not a crash)
+    import math
+    ro = wl.rollouts
+    finite = all(math.isfinite(float(x)) for x in last) and bool(torch.isfinite(ro.value_preds).all()) and \
+        bool(torch.isfinite(ro.em_vln_dialog.memory).all()) and bool(torch.isfinite(ro.em.memory).all())
+    assert finite, f"non-finite results after the timed cycles: losses {last}"
     if world > 1:
         tt = torch.tensor([dt], device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
