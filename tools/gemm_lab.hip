@@ -31,8 +31,23 @@ static float time_us(int M, int N, int K, const void* A, const void* B, void* C1
   return ms * 1e3f / iters;
 }
 
+template <int BM, int BN, int WM, int WN, int NS, int NTH>
+static void occ(const char* name) {
+  size_t lds = (size_t)NS * (BM * 128 + (BN * 8 >= NTH ? BN * 128 : NTH * 16));
+  hipFuncSetAttribute(reinterpret_cast<const void*>(&g2_kernel<BM, BN, WM, WN, NS, NTH, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  int nb = -1;
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&g2_kernel<BM, BN, WM, WN, NS, NTH, false>), NTH, lds);
+  hipFuncAttributes fa; hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&g2_kernel<BM, BN, WM, WN, NS, NTH, false>));
+  printf("occupancy %s: %d blocks/CU (dyn LDS %zu B, %d VGPR+AGPR regs, static LDS %zu)\n", name, nb, lds, fa.numRegs, fa.sharedSizeBytes);
+}
+
 int main(int argc, char** argv) {
   const bool ablate = argc > 1 && !strcmp(argv[1], "abl");
+  if (argc > 1 && !strcmp(argv[1], "occ")) {
+    occ<64, 128, 2, 4, 2, 512>("64x128 ns2 t512"); occ<64, 128, 2, 4, 4, 512>("64x128 ns4 t512");
+    occ<128, 128, 2, 4, 2, 512>("128x128 ns2 t512"); occ<256, 128, 4, 2, 3, 512>("256x128 ns3 t512");
+    return 0;
+  }
   const int shapes[][3] = {{64, 512, 512}, {64, 2048, 512}, {64, 512, 2048}, {2464, 512, 512}, {2464, 512, 2048}, {2464, 2048, 512}, {2464, 1536, 512},
                            {9664, 256, 256}, {9664, 768, 256}, {4800, 64, 8192}, {8192, 8192, 1024}, {8192, 8192, 8192}};
   size_t maxA = (size_t)9664 * 8192, maxB = (size_t)8192 * 8192, maxC = (size_t)8192 * 8192;
