@@ -9,6 +9,7 @@ copies the network outputs and every pose to the host and loops over environment
 """
 import ctypes as C
 import logging
+import os
 
 import torch
 import torch.nn as nn
@@ -18,6 +19,8 @@ from . import engine as E
 from . import nets as N
 from .policy import SPECTROGRAM, POSE, LOCATION_BELIEF, CATEGORY_BELIEF, CATEGORY, _f32
 
+_TWO_STREAMS = os.environ.get("AVLEN_BELIEF_STREAMS", "2") != "1"     # A/B knob: the two networks on two streams
+_SHARED_CAPTURE = os.environ.get("AVLEN_BELIEF_SHARED_CAPTURE", "1") != "0"
 LABEL_PREDICTOR_PATH = "data/pretrained_weights/semantic_audionav/savi/label_predictor.pth"    # belief_predictor.py:96
 
 
@@ -212,8 +215,13 @@ class BeliefPredictor(nn.Module):
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                self._update_eager(st_in, st_d, st_out)
+            if _SHARED_CAPTURE:                                           # every extra stream shifts the stream -> hardware-queue map
+                from .policy import _capture_stream
+                with torch.cuda.graph(graph, stream=_capture_stream()):
+                    self._update_eager(st_in, st_d, st_out)
+            else:
+                with torch.cuda.graph(graph):
+                    self._update_eager(st_in, st_d, st_out)
             for k, v in saved.items():                                    # the warm-up must not advance the filter
                 self._state[k].copy_(v)
             g = self._graph = {"key": key, "graph": graph, "in": st_in, "dones": st_d, "out": st_out,
@@ -232,12 +240,14 @@ class BeliefPredictor(nn.Module):
         # the two networks are independent until the filter: they run on two streams (two branches of the captured graph);
         # at these sizes (64 spectrograms of 65x26) every kernel fills a fraction of the chip
         side = None
-        if self.predict_location and self.predict_label:
+        if self.predict_location and self.predict_label and _TWO_STREAMS:
             side = self._side_stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 labels = self._run("classifier", spec, s["labels"])
         elif self.predict_label:
+            labels = self._run("classifier", spec, s["labels"])
+        if self.predict_label and labels is None:
             labels = self._run("classifier", spec, s["labels"])
         if self.predict_location:
             pg = self._run("predictor", self._predictor_input(obs), s["pg"])
