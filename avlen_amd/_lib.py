@@ -152,6 +152,8 @@ SIGNATURES = {
     "avlen_belief_input": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "avlen_belief_update": (i32, [vp, i32, vp, i32, vp, i32, vp, C.c_long, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32,
                                   i32, vp]),
+    "avlen_resnet18_group_fwd_indexed": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, sz, vp]),
+    "avlen_cnn3_fwd_indexed": (i32, [C.POINTER(Cnn3), vp, vp, i32, i32, i32, vp, i32, vp, sz, vp]),
     "avlen_cnn3_workspace_bytes": (sz, [C.POINTER(Cnn3), i32, i32, i32]),
     "avlen_cnn3_fwd": (i32, [C.POINTER(Cnn3), vp, i32, i32, i32, vp, i32, i32, vp, sz, vp]),
     "avlen_cnn3_group_workspace_bytes": (sz, [C.POINTER(Cnn3), i32, i32, i32, i32]),

@@ -6,11 +6,14 @@
 namespace {
 
 // (B,S,S,C) fp32 -> (x/div, kxk mean) -> (B,64,64,8) bf16, channels >= C zero.  One thread per output pixel.
-__global__ void preprocess_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ y, int B, int S, int C, int k, float div) {
+// row_index (optional): image b of the batch is image row_index[b] of x (the PPO minibatch reads the rollout storage in place)
+__global__ void preprocess_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ y, int B, int S, int C, int k, float div,
+                                       const int* __restrict__ row_index) {
   long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (pix >= (long)B * 4096) return;
   int ox = (int)(pix % 64), oy = (int)((pix / 64) % 64), b = (int)(pix / 4096);
-  const float* src = x + (((long)b * S + oy * k) * S + ox * k) * C;
+  const long bs = row_index ? row_index[b] : b;
+  const float* src = x + ((bs * S + oy * k) * S + ox * k) * C;
   typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8v;
   bf16x8v o;
 #pragma unroll
@@ -149,10 +152,11 @@ extern "C" int avlen_preprocess_image(const float* x, float* y, int B, int S, in
   return avlen_launch_status();
 }
 
-int avlen_preprocess_image_bf16(const float* x, void* y16, int B, int S, int C, float divisor, hipStream_t stream) {
+int avlen_preprocess_image_bf16(const float* x, void* y16, int B, int S, int C, float divisor, hipStream_t stream,
+                                const int* row_index) {
   if (S % 64 || B <= 0 || C > 8) return AVLEN_ERR_ARG;
   long tot = (long)B * 4096;
-  hipLaunchKernelGGL(preprocess_bf16_kernel, grid1d(tot), dim3(256), 0, stream, x, (__bf16*)y16, B, S, C, S / 64, divisor);
+  hipLaunchKernelGGL(preprocess_bf16_kernel, grid1d(tot), dim3(256), 0, stream, x, (__bf16*)y16, B, S, C, S / 64, divisor, row_index);
   return avlen_launch_status();
 }
 

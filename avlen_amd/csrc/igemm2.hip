@@ -463,6 +463,15 @@ __global__ void cast_rows_kernel(const float* __restrict__ src, int lds_, bf16* 
   dst[i] = c < cols ? (bf16)src[r * lds_ + c] : (bf16)0.f;
 }
 
+__global__ void cast_rows_indexed_kernel(const float* __restrict__ src, int lds_, bf16* __restrict__ dst, int ldd, long rows, int cols,
+                                         const int* __restrict__ row_index, int rpi) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * ldd) return;
+  long r = i / ldd; int c = (int)(i - r * ldd);
+  const long item = r / rpi, rs = (long)row_index[item] * rpi + (r - item * rpi);
+  dst[i] = c < cols ? (bf16)src[rs * lds_ + c] : (bf16)0.f;
+}
+
 // Same cast, 8 elements (32 B in, 16 B out) per thread: both leading dimensions multiples of 8 and 16-byte aligned bases
 __global__ void cast_rows8_kernel(const float* __restrict__ src, int lds_, bf16* __restrict__ dst, int ldd, long rows, int cols) {
   const int per_row = ldd >> 3;
@@ -760,6 +769,16 @@ extern "C" int avlen_cast_bf16(const float* src, int ld_src, void* dst, int ld_d
     return avlen_launch_status();
   }
   hipLaunchKernelGGL(cast_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, src, ld_src, (bf16*)dst, ld_dst, rows, cols);
+  return avlen_launch_status();
+}
+
+int avlen_cast_bf16_indexed(const float* src, int ld_src, void* dst, int ld_dst, long rows, int cols, const int* row_index,
+                            int rows_per_item, hipStream_t stream) {
+  if (!row_index) return avlen_cast_bf16(src, ld_src, dst, ld_dst, rows, cols, stream);
+  long tot = rows * ld_dst;
+  if (tot <= 0 || rows_per_item <= 0) return AVLEN_ERR_ARG;
+  hipLaunchKernelGGL(cast_rows_indexed_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, src, ld_src, (bf16*)dst,
+                     ld_dst, rows, cols, row_index, rows_per_item);
   return avlen_launch_status();
 }
 

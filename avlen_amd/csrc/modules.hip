@@ -575,7 +575,7 @@ bool resnet18_has16(const avlen_resnet18* n) {
 // G towers of identical shape in lock-step: every conv / GroupNorm / fc is ONE grouped launch (blockIdx.y = tower).
 int resnet18_group_fwd_bf16(const avlen_resnet18* const* nets, const float* const* imgs, const int* channels,
                             const float* divisors, float* const* outs, int ld_out, int G, int B, int S, void* ws,
-                            size_t ws_bytes, hipStream_t st) {
+                            size_t ws_bytes, hipStream_t st, const int* row_index = nullptr) {
   if (G < 1 || G > 8 || ws_bytes < (size_t)G * resnet18_ws_bf16(B)) return AVLEN_ERR_WS;
   WsBump w(ws, ws_bytes);
   size_t px = (size_t)B * 4096;
@@ -598,7 +598,7 @@ int resnet18_group_fwd_bf16(const avlen_resnet18* const* nets, const float* cons
     for (int h = 0; h < g && same < 0; h++)
       if (imgs[h] == imgs[g] && channels[h] == channels[g] && divisors[h] == divisors[g]) same = h;
     if (same >= 0) { x0[g] = x0[same]; continue; }
-    TRY(avlen_preprocess_image_bf16(imgs[g], x0[g], B, S, channels[g], divisors[g], st));
+    TRY(avlen_preprocess_image_bf16(imgs[g], x0[g], B, S, channels[g], divisors[g], st, row_index));
   }
   const void* X[8]; const void* Wt[8]; void* Y[8]; float* ST[8]; float* ST2[8]; float* ST3[8];
   const float* GA[8]; const float* BE[8]; const void* RES[8]; void* OUT[8]; const void* XR[8];
@@ -732,7 +732,7 @@ size_t cnn3_ws_bf16(const avlen_cnn3* n, int B, int H, int W) {
   return tot + zmax(mx, avlen_gemm_bf16_workspace_bytes(B, n->fc.out_f)) + 4096;
 }
 int cnn3_fwd_bf16(const avlen_cnn3* n, const float* x, int B, int H, int W, float* out, int ld_out, void* ws,
-                  size_t ws_bytes, hipStream_t st) {
+                  size_t ws_bytes, hipStream_t st, const int* row_index = nullptr) {
   if (ws_bytes < cnn3_ws_bf16(n, B, H, W)) return AVLEN_ERR_WS;
   int oh[3], ow[3]; cnn3_dims2(n, H, W, oh, ow);
   WsBump w(ws, ws_bytes);
@@ -746,8 +746,8 @@ int cnn3_fwd_bf16(const avlen_cnn3* n, const float* x, int B, int H, int W, floa
   void* gws = w.take<char>(mx);
   const bool sp = cnn3_superpixel(n, W);
   const int wsp = sp ? ((ow[0] - 1) * n->conv[0].stride + n->conv[0].kw) / n->conv[0].stride : 0;   // super-pixels per row
-  if (sp) TRY(avlen_cast_bf16(x, W * n->conv[0].cin, x16, wsp * 8, (long)B * H, wsp * 8, st));     // drop the unused columns
-  else TRY(avlen_cast_bf16(x, n->conv[0].cin, x16, 8, (long)B * H * W, n->conv[0].cin, st));         // channel-pad to 8
+  if (sp) TRY(avlen_cast_bf16_indexed(x, W * n->conv[0].cin, x16, wsp * 8, (long)B * H, wsp * 8, row_index, H, st));     // drop the unused columns
+  else TRY(avlen_cast_bf16_indexed(x, n->conv[0].cin, x16, 8, (long)B * H * W, n->conv[0].cin, row_index, H * W, st));         // channel-pad to 8
   const bf16* cur = x16; int h = H, wd = W;
   for (int i = 0; i < 3; i++) {
     const avlen_conv& k = n->conv[i];
@@ -845,6 +845,13 @@ extern "C" int avlen_resnet18_group_fwd(const avlen_resnet18* const* nets, const
   return resnet18_group_fwd_bf16(nets, imgs, channels, divisors, outs, ld_out, groups, B, S, ws, ws_bytes, st);
 }
 
+extern "C" int avlen_resnet18_group_fwd_indexed(const avlen_resnet18* const* nets, const float* const* imgs, const int* channels,
+                                                const float* divisors, float* const* outs, int ld_out, int groups, int B, int S,
+                                                const int32_t* row_index, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!nets || groups < 1 || groups > 8 || B <= 0) return AVLEN_ERR_ARG;
+  return resnet18_group_fwd_bf16(nets, imgs, channels, divisors, outs, ld_out, groups, B, S, ws, ws_bytes, st, row_index);
+}
+
 extern "C" int avlen_resnet18_fwd(const avlen_resnet18* net, const float* img, int B, int S, int C, float divisor,
                                   float* out, int ld_out, int prec, void* ws, size_t ws_bytes, hipStream_t st) {
   if (!net || B <= 0 || ws_bytes < avlen_resnet18_workspace_bytes(B)) return AVLEN_ERR_WS;
@@ -902,6 +909,15 @@ extern "C" size_t avlen_cnn3_workspace_bytes(const avlen_cnn3* n, int B, int H, 
   for (int i = 0; i < 3; i++) tot += (size_t)B * oh[i] * ow[i] * n->conv[i].cout * sizeof(float) + 256;
   return zmax(tot + GEMM_SCRATCH + 1024, cnn3_ws_bf16(n, B, H, W));
 }
+extern "C" int avlen_cnn3_fwd_indexed(const avlen_cnn3* n, const float* x, const int32_t* row_index, int B, int H, int W, float* out,
+                                      int ld_out, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!n || B <= 0 || ws_bytes < avlen_cnn3_workspace_bytes(n, B, H, W)) return AVLEN_ERR_WS;
+  int oh[3], ow[3]; cnn3_dims(n, H, W, oh, ow);
+  if (oh[2] <= 0 || ow[2] <= 0 || n->fc.in_f != oh[2] * ow[2] * n->conv[2].cout) return AVLEN_ERR_ARG;
+  if (!(cnn3_has16(n) && n->conv[0].cin <= 8)) return AVLEN_ERR_ARG;          // bf16 fast path only
+  return cnn3_fwd_bf16(n, x, B, H, W, out, ld_out, ws, ws_bytes, st, row_index);
+}
+
 extern "C" int avlen_cnn3_fwd(const avlen_cnn3* n, const float* x, int B, int H, int W, float* out, int ld_out,
                               int prec, void* ws, size_t ws_bytes, hipStream_t st) {
   if (!n || B <= 0 || ws_bytes < avlen_cnn3_workspace_bytes(n, B, H, W)) return AVLEN_ERR_WS;

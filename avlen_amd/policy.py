@@ -27,7 +27,23 @@ POSE, SPECTROGRAM, LOCATION_BELIEF, CATEGORY_BELIEF, CATEGORY = "pose", "spectro
     "category_belief", "category"     # soundspaces/tasks/nav.py cls_uuid values
 
 
+class RowsOf:
+    """Rows `index` (int32, device) of the first axis of `base` -- a batch that is read in place from a larger tensor (the PPO
+    minibatch of the rollout storage) instead of being gathered first.  Only the bf16 encoders take it."""
+
+    def __init__(self, base, index):
+        assert base.dtype == torch.float32 and base.is_contiguous() and index.dtype == torch.int32 and index.is_contiguous()
+        self.base, self.index = base, index
+        self.shape = (index.numel(),) + tuple(base.shape[1:])
+        self.device = base.device
+
+    def materialise(self):
+        return self.base[self.index.long()]
+
+
 def _f32(t):
+    if isinstance(t, RowsOf):
+        return t
     if t.dtype != torch.float32:
         t = t.float()
     return t if t.is_contiguous() else t.contiguous()
@@ -649,6 +665,13 @@ class _SMTBase(Net):
         """-> feats (B, F) = [visual 128 | action 16 | audio 128 | (category 21) | pose 4 | (extra)], goal (B,d)."""
         eng = pol._engine()
         rgb, depth, spec = _f32(obs["rgb"]), _f32(obs["depth"]), _f32(obs[SPECTROGRAM])
+        idx = None
+        if isinstance(rgb, RowsOf):                      # minibatch rows of the storage, read in place (bf16 encoders only)
+            if pol.prec == L.PREC_BF16 and pol._shared_mode is None and isinstance(depth, RowsOf) and isinstance(spec, RowsOf) \
+                    and depth.index is rgb.index and spec.index is rgb.index:
+                idx = rgb.index
+            else:
+                rgb, depth, spec = (t.materialise() if isinstance(t, RowsOf) else t for t in (rgb, depth, spec))
         B = rgb.shape[0]
         dev = rgb.device
         F = self._feature_size
@@ -676,8 +699,12 @@ class _SMTBase(Net):
                     aud = grp.audio_buffers(B, dev)[grp.members.index(pol)]
                 else:
                     aud = None
-                    L.call("avlen_cnn3_fwd", C.byref(eng["audio"]), E.P(spec), B, H, W, E.P(feats, 144), F, prec, E.P(ws2), nb2,
-                           L.stream())
+                    if idx is not None:
+                        L.call("avlen_cnn3_fwd_indexed", C.byref(eng["audio"]), E.P(spec.base), E.P(idx), B, H, W, E.P(feats, 144), F,
+                               E.P(ws2), nb2, L.stream())
+                    else:
+                        L.call("avlen_cnn3_fwd", C.byref(eng["audio"]), E.P(spec), B, H, W, E.P(feats, 144), F, prec, E.P(ws2), nb2,
+                               L.stream())
                 if aud is not None:
                     L.call("avlen_copy_rows", E.P(aud), 128, E.P(feats, 144), F, B, 128, L.stream())
             if mode == "follow":
@@ -688,12 +715,16 @@ class _SMTBase(Net):
                 vis = None
                 G = 2
                 nets = (C.POINTER(L.ResNet18) * G)(C.pointer(eng["rgb"]), C.pointer(eng["depth"]))
-                imgs = (C.c_void_p * G)(rgb.data_ptr(), depth.data_ptr())
+                imgs = (C.c_void_p * G)(*((rgb.base.data_ptr(), depth.base.data_ptr()) if idx is not None else
+                                         (rgb.data_ptr(), depth.data_ptr())))
                 outs = (C.c_void_p * G)(feats.data_ptr(), feats.data_ptr() + 4 * 64)
                 chans, divs = (C.c_int * G)(rgb.shape[3], depth.shape[3]), (C.c_float * G)(255.0, 1.0)
                 nbg = L.lib.avlen_resnet18_group_workspace_bytes(G, B)
                 wsg = pol._ws.get("resnet_pair", nbg, dev)
-                L.call("avlen_resnet18_group_fwd", nets, imgs, chans, divs, outs, F, G, B, S, E.P(wsg), nbg, st)
+                if idx is not None:
+                    L.call("avlen_resnet18_group_fwd_indexed", nets, imgs, chans, divs, outs, F, G, B, S, E.P(idx), E.P(wsg), nbg, st)
+                else:
+                    L.call("avlen_resnet18_group_fwd", nets, imgs, chans, divs, outs, F, G, B, S, E.P(wsg), nbg, st)
             if vis is not None:
                 L.call("avlen_copy_rows", E.P(vis), 128, E.P(feats), F, B, 128, st)
             s_rgb = s_dep = s_aud

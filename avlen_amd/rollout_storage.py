@@ -278,7 +278,7 @@ class RolloutStorage:
                L.stream())
         return dst
 
-    def gather_minibatch(self, env, advantages=None):
+    def gather_minibatch(self, env, advantages=None, in_place=False):
         """The tensors PPO.update needs for the env subset `env` (int64, device), WITHOUT materialising the
         (em_size, T*n_mb, dim) memory: rows index the ring through `mem_index`."""
         T = self.step
@@ -286,8 +286,20 @@ class RolloutStorage:
         adv = self.advantages if advantages is None else advantages
         n_mb = env.numel()
         mem_index = env.to(torch.int32).repeat(T).contiguous()            # row t*n_mb+j reads ring column env[j]
+        obs = {}
+        if in_place:
+            # the three large sensors (470 KB per stored step at 257x101) are not gathered: the encoders read row
+            # t*N + env[j] of the (T+1, N, ...) storage directly (policy.RowsOf -> avlen_*_fwd_indexed)
+            from .policy import RowsOf
+            rows = (torch.arange(T, device=env.device, dtype=torch.int32).view(T, 1) * self.num_envs +
+                    env.to(torch.int32).view(1, n_mb)).reshape(-1).contiguous()
+            for k, v in self.observations.items():
+                big = k in ("rgb", "depth", "spectrogram") and v.dtype == torch.float32
+                obs[k] = RowsOf(v.view((-1,) + tuple(v.shape[2:])), rows) if big else g(v)
+        else:
+            obs = {k: g(v) for k, v in self.observations.items()}
         return {
-            "obs": {k: g(v) for k, v in self.observations.items()},
+            "obs": obs,
             "actions_option": g(self.actions_option), "prev_actions": g(self.prev_actions),
             "value_preds": g(self.value_preds), "returns": g(self.returns), "masks": g(self.masks),
             "old_log_probs": g(self.action_log_probs), "adv": g(adv), "rl_masks": g(self.rl_masks),

@@ -206,6 +206,14 @@ int avlen_belief_update(const float* pointgoals, int ld_pg, const float* labels,
                         int* has_pointgoal, float* last_label, int* has_label, float* location_belief,
                         float* category_belief, float* spec_sum, int B, int n_label, float weighting_factor,
                         int current_pred_only, avlen_stream_t stream);
+/* The same with a row index (bf16 fast path): image / spectrogram b of the batch is item row_index[b] of the tensor the
+ * pointer addresses -- the PPO minibatch (rollout_storage.py:591-810) reads the (T+1, N, ...) observation storage in place
+ * instead of gathering 470 KB per stored step first. */
+int avlen_resnet18_group_fwd_indexed(const avlen_resnet18* const* nets, const float* const* imgs, const int* channels,
+                                     const float* divisors, float* const* outs, int ld_out, int groups, int B, int S,
+                                     const int32_t* row_index, void* ws, size_t ws_bytes, avlen_stream_t stream);
+int avlen_cnn3_fwd_indexed(const avlen_cnn3* net, const float* x, const int32_t* row_index, int B, int H, int W, float* out,
+                           int ld_out, void* ws, size_t ws_bytes, avlen_stream_t stream);
 size_t avlen_cnn3_workspace_bytes(const avlen_cnn3* net, int B, int H, int W);
 /* AudioCNN.forward (audio_cnn.py:136-151) / VisualCNN.cnn: x NHWC (B,H,W,conv[0].cin) -> out[b*ld_out + 0..fc.out_f). */
 int avlen_cnn3_fwd(const avlen_cnn3* net, const float* x, int B, int H, int W, float* out, int ld_out, int prec,

@@ -537,3 +537,27 @@ def test_shared_grouped_towers_match_separate_calls(specs):
     for a, b in zip(outs[False], outs[True]):
         err = float((a - b).abs().max() / (b.abs().max() + 1e-9))
         assert err < 5e-2, err      # bf16 activations: one flipped bf16 ulp (0.4 %) propagates through the towers
+
+
+def test_minibatch_observations_read_in_place():
+    """PPO minibatch on the bf16 path: the encoders read rows t*N + env[j] of the (T+1, N, ...) observation storage through a
+    row index (avlen_resnet18_group_fwd_indexed / avlen_cnn3_fwd_indexed) instead of gathering 470 KB per stored step first.
+    Same rows in -> the audio features (no atomics on that path) are bit-identical, the visual ones equal up to the fp32
+    atomic order of the fused GroupNorm statistics."""
+    from avlen_amd.harness import Workload
+    wl = Workload(4, 3, spectrogram=(257, 101, 2), precision="bf16", pretraining=True, em_capacity=4, seed=7, use_graphs=False)
+    for _ in range(3):
+        wl.rollout_step()
+    ro, pol = wl.rollouts, wl.pi_q
+    env = torch.tensor([2, 0], device="cuda")
+    b0, b1 = ro.gather_minibatch(env, in_place=False), ro.gather_minibatch(env, in_place=True)
+    assert isinstance(b1["obs"]["rgb"], P.RowsOf) and not isinstance(b1["obs"]["pose"], P.RowsOf)
+    assert torch.equal(b1["obs"]["rgb"].materialise(), b0["obs"]["rgb"])           # the index addresses the gathered rows
+    f0, g0 = pol.net.features(pol, b0["obs"], b0["prev_actions"])
+    f0, g0 = f0.clone(), g0.clone()
+    f1, g1 = pol.net.features(pol, b1["obs"], b1["prev_actions"])
+    torch.cuda.synchronize()
+    assert torch.equal(f0[:, 144:272], f1[:, 144:272])                              # audio CNN
+    assert torch.equal(f0[:, 128:144], f1[:, 128:144]) and torch.equal(g0, g1)      # action embedding, goal vector
+    err = float((f0[:, :128] - f1[:, :128]).abs().max() / f0[:, :128].abs().max())
+    assert err < 3e-2, err
