@@ -136,6 +136,8 @@ SIGNATURES = {
     "avlen_attention_fwd": (i32, [vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp]),
     "avlen_attention_bwd": (i32, [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, i32, vp, i32,
                                   i32, i32, i32, i32, i32, i32, f32, vp]),
+    "avlen_attention_bwd_bf16": (i32, [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, i32, vp, i32,
+                                  i32, i32, i32, i32, i32, i32, f32, vp]),
     "avlen_preprocess_image": (i32, [vp, vp, i32, i32, i32, f32, vp]),
     "avlen_rgbd_concat": (i32, [vp, vp, vp, i32, i32, vp]),
     "avlen_feature_assemble": (i32, [vp, i32, C.POINTER(Linear), vp, i32, vp, i32, vp, i32, vp, i32, i32, vp, vp, vp,

@@ -797,10 +797,245 @@ int avlen_attention_fwd16_seg(const float* Q, int ldq, const float* K, int ldk, 
   return avlen_launch_status();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Self-attention BACKWARD on the matrix cores (bf16 operands, fp32 accumulate): one 256-thread block per (sample, head) holds
+// Q, K, V and dO of the head (S <= SKP tokens, D = 32) in LDS as bf16 and makes two passes over the S x S score matrix with the
+// forward kernel's idioms (transposed score tiles so that P / dS stay in registers as the B operand of the second MFMA,
+// hardware-transposing LDS reads for the other operand):
+//   pass 1, query-major : lane = (query r16, 8 keys)   ->  delta' = sum_k P dP, then dQ^T += K^T dS^T
+//   pass 2, key-major   : lane = (key r16, 8 queries)  ->  dV^T += dO^T P,  dK^T += Q^T dS
+// with P = exp(scale q.k - lse), dS = P (dO.v - delta') scale; dS enters its MFMAs as a bf16 hi + lo pair.  The fp32
+// rowsum(dO * O) is still written to `delta` for the caller.
+// Replaces the two fp32 VALU kernels above on the 2nd-stage training path (722 k token rows per minibatch: 5.2 ms -> per launch).
+template <int SKP, int NTH>      // NTH threads = NTH/64 waves share the head's tiles: one block per CU (LDS), so the waves of ONE block hide each other's latency
+__global__ __launch_bounds__(NTH) void attn_bwd16_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ K, int ldk,
+                                                         const float* __restrict__ V, int ldv, const float* __restrict__ O, int ldo,
+                                                         const float* __restrict__ dO, int lddo,
+                                                         const float* __restrict__ key_mask, const float* __restrict__ lse,
+                                                         float* __restrict__ delta, float* __restrict__ dQ, int lddq,
+                                                         float* __restrict__ dK, int lddk, float* __restrict__ dV, int lddv, int H,
+                                                         int S, float scale) {
+  constexpr int D = 32, KR = 48;                    // 96-byte LDS rows: conflict-free for both read kinds (as attn_smt16_kernel)
+  __shared__ __attribute__((aligned(16))) __bf16 qs[SKP * KR];
+  __shared__ __attribute__((aligned(16))) __bf16 ks[SKP * KR];
+  __shared__ __attribute__((aligned(16))) __bf16 vs[SKP * KR];
+  __shared__ __attribute__((aligned(16))) __bf16 gs[SKP * KR];
+  __shared__ float km[SKP], s_lse[SKP], s_del[SKP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, q4 = lane >> 4;
+  const int h = blockIdx.x, b = blockIdx.y;
+  const long row0 = (long)b * S;
+  const int S32 = (S + 31) & ~31;                   // rows S .. S32-1 are zero
+  // ---- stage: 4 x 32-byte chunks (8 floats) per row and tensor; delta from the fp32 dO and O of the same chunk
+  for (int i = tid; i < S32 * 4; i += NTH) {
+    const int r = i >> 2, c = i & 3;
+    abf16x8 q8, k8, v8, g8;
+#pragma unroll
+    for (int e = 0; e < 8; e++) { q8[e] = (__bf16)0.f; k8[e] = q8[e]; v8[e] = q8[e]; g8[e] = q8[e]; }
+    float dl = 0.f;
+    if (r < S) {
+      const float4* qp = reinterpret_cast<const float4*>(Q + (row0 + r) * ldq + h * D + c * 8);
+      const float4* kp = reinterpret_cast<const float4*>(K + (row0 + r) * ldk + h * D + c * 8);
+      const float4* vp = reinterpret_cast<const float4*>(V + (row0 + r) * ldv + h * D + c * 8);
+      const float4* gp = reinterpret_cast<const float4*>(dO + (row0 + r) * lddo + h * D + c * 8);
+      const float4* op = reinterpret_cast<const float4*>(O + (row0 + r) * ldo + h * D + c * 8);
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const float4 a = qp[u], bb = kp[u], cc = vp[u], g = gp[u], o = op[u];
+        q8[4 * u] = (__bf16)a.x; q8[4 * u + 1] = (__bf16)a.y; q8[4 * u + 2] = (__bf16)a.z; q8[4 * u + 3] = (__bf16)a.w;
+        k8[4 * u] = (__bf16)bb.x; k8[4 * u + 1] = (__bf16)bb.y; k8[4 * u + 2] = (__bf16)bb.z; k8[4 * u + 3] = (__bf16)bb.w;
+        v8[4 * u] = (__bf16)cc.x; v8[4 * u + 1] = (__bf16)cc.y; v8[4 * u + 2] = (__bf16)cc.z; v8[4 * u + 3] = (__bf16)cc.w;
+        g8[4 * u] = (__bf16)g.x; g8[4 * u + 1] = (__bf16)g.y; g8[4 * u + 2] = (__bf16)g.z; g8[4 * u + 3] = (__bf16)g.w;
+        dl += g.x * o.x + g.y * o.y + g.z * o.z + g.w * o.w;
+      }
+    }
+    *reinterpret_cast<abf16x8*>(&qs[r * KR + c * 8]) = q8;
+    *reinterpret_cast<abf16x8*>(&ks[r * KR + c * 8]) = k8;
+    *reinterpret_cast<abf16x8*>(&vs[r * KR + c * 8]) = v8;
+    *reinterpret_cast<abf16x8*>(&gs[r * KR + c * 8]) = g8;
+    dl += __shfl_xor(dl, 1, 64); dl += __shfl_xor(dl, 2, 64);      // the 4 chunk-threads of a row are adjacent lanes
+    if (c == 0) {
+      s_del[r] = dl;
+      if (r < S) delta[((long)b * H + h) * S + r] = dl;
+    }
+  }
+  for (int i = tid; i < SKP; i += NTH) {
+    km[i] = (i < S && (!key_mask || key_mask[(long)b * S + i] != 0.f)) ? 1.f : 0.f;
+    s_lse[i] = i < S ? lse[((long)b * H + h) * S + i] : 0.f;
+    if (i >= S32) s_del[i] = 0.f;
+  }
+  __syncthreads();
+  const int n_t = (S + 15) >> 4, n_kk = (S + 31) >> 5;
+  // ---- pass 1: per 16 queries and wave: delta', then dQ (two sweeps over the keys)
+  for (int mt = wave; mt < n_t; mt += NTH / 64) {
+    const int qi = mt * 16 + r16;
+    const abf16x8 qf = *reinterpret_cast<const abf16x8*>(&qs[qi * KR + q4 * 8]);
+    const abf16x8 gf = *reinterpret_cast<const abf16x8*>(&gs[qi * KR + q4 * 8]);
+    const float ls0 = s_lse[qi];
+    const bool qok = qi < S;
+    // sweep A: the softmax normaliser and delta' = sum_k P_k dP_k from the SAME bf16 products the gradients use.  (The forward's
+    // fp32 lse and rowsum(dO * O) are the same numbers mathematically, but P sums to 1 and dP - delta cancels -- exactly, when one
+    // key holds all the mass -- and bf16-rounded scores / dP against fp32 lse / delta leave 1e-1-sized ghosts in dK / dQ.)
+    float dl = 0.f, zs = 0.f;
+    for (int kk = 0; kk < n_kk; kk++) {
+      const af32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        const int krow = kk * 32 + t * 16 + r16;
+        const abf16x8 kf = *reinterpret_cast<const abf16x8*>(&ks[krow * KR + q4 * 8]);
+        const abf16x8 vf = *reinterpret_cast<const abf16x8*>(&vs[krow * KR + q4 * 8]);
+        const af32x4 sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, z, 0, 0, 0);
+        const af32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, gf, z, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int kj = kk * 32 + t * 16 + q4 * 4 + r;
+          if (qok && km[kj] != 0.f) { const float e = __expf(sc[r] * scale - ls0); zs += e; dl += e * dp[r]; }
+        }
+      }
+    }
+    zs += __shfl_xor(zs, 16, 64); zs += __shfl_xor(zs, 32, 64);
+    dl += __shfl_xor(dl, 16, 64); dl += __shfl_xor(dl, 32, 64);
+    // the row's softmax of the bf16-rounded scores: lse' = lse + log Z (Z = 1 +- 4e-3), delta' = sum_k P'_k dP_k
+    const float ls = (zs > 0.f) ? ls0 + __logf(zs) : ls0;
+    dl = (zs > 0.f) ? dl / zs : 0.f;
+    if (q4 == 0) { s_del[qi] = dl; s_lse[qi] = ls; }  // pass 2 (key-major) reads both after the barrier
+    af32x4 dqa[2];
+    dqa[0] = (af32x4){0.f, 0.f, 0.f, 0.f}; dqa[1] = dqa[0];
+    for (int kk = 0; kk < n_kk; kk++) {
+      const af32x4 z = {0.f, 0.f, 0.f, 0.f};
+      abf16x8 dsf, dsl;
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        const int krow = kk * 32 + t * 16 + r16;
+        const abf16x8 kf = *reinterpret_cast<const abf16x8*>(&ks[krow * KR + q4 * 8]);
+        const abf16x8 vf = *reinterpret_cast<const abf16x8*>(&vs[krow * KR + q4 * 8]);
+        const af32x4 sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, z, 0, 0, 0);   // [query r16][key kk*32 + t*16 + q4*4 + r]
+        const af32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, gf, z, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int kj = kk * 32 + t * 16 + q4 * 4 + r;
+          const float p = (qok && km[kj] != 0.f) ? __expf(sc[r] * scale - ls) : 0.f;
+          const float ds = p * (dp[r] - dl) * scale;
+          const __bf16 hi_ = (__bf16)ds;
+          dsf[t * 4 + r] = hi_;
+          dsl[t * 4 + r] = (__bf16)(ds - (float)hi_);
+        }
+      }
+      const __bf16* kb = &ks[(kk * 32 + q4 * 4 + (r16 >> 2)) * KR + 4 * (r16 & 3)];
+#pragma unroll
+      for (int dt = 0; dt < 2; dt++) {
+        abf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) abf16x4*)(kb + dt * 16));
+        abf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) abf16x4*)(kb + 16 * KR + dt * 16));
+        abf16x8 tf;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { tf[e] = lo[e]; tf[4 + e] = hi[e]; }
+        dqa[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf, dsf, dqa[dt], 0, 0, 0);
+        dqa[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf, dsl, dqa[dt], 0, 0, 0);
+      }
+    }
+    if (qok) {
+      float* oq = dQ + (row0 + qi) * lddq + h * D + q4 * 4;
+#pragma unroll
+      for (int dt = 0; dt < 2; dt++)
+        *reinterpret_cast<float4*>(oq + dt * 16) = make_float4(dqa[dt][0], dqa[dt][1], dqa[dt][2], dqa[dt][3]);
+    }
+  }
+  __syncthreads();
+  // ---- pass 2: dK, dV for 16 keys per wave iteration
+  for (int kt = wave; kt < n_t; kt += NTH / 64) {
+    const int key = kt * 16 + r16;
+    const abf16x8 kf = *reinterpret_cast<const abf16x8*>(&ks[key * KR + q4 * 8]);
+    const abf16x8 vf = *reinterpret_cast<const abf16x8*>(&vs[key * KR + q4 * 8]);
+    const bool kvalid = km[key] != 0.f;
+    af32x4 dva[2], dka[2];
+    dva[0] = (af32x4){0.f, 0.f, 0.f, 0.f}; dva[1] = dva[0]; dka[0] = dva[0]; dka[1] = dva[0];
+    for (int kk = 0; kk < n_kk; kk++) {
+      const af32x4 z = {0.f, 0.f, 0.f, 0.f};
+      af32x4 sc[2], dp[2];
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        const int qrow = kk * 32 + t * 16 + r16;
+        const abf16x8 qf = *reinterpret_cast<const abf16x8*>(&qs[qrow * KR + q4 * 8]);
+        const abf16x8 gf = *reinterpret_cast<const abf16x8*>(&gs[qrow * KR + q4 * 8]);
+        sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf, z, 0, 0, 0);       // [key r16][query kk*32 + t*16 + q4*4 + r]
+        dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, vf, z, 0, 0, 0);
+      }
+      // dS sums to zero over the keys of a row, so dK / dQ are cancelling sums: dS goes in as a bf16 hi + lo pair (two MFMAs)
+      abf16x8 pf, dsf, dsl;
+#pragma unroll
+      for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int qi = kk * 32 + t * 16 + q4 * 4 + r;
+          const float p = (kvalid && qi < S) ? __expf(sc[t][r] * scale - s_lse[qi]) : 0.f;
+          pf[t * 4 + r] = (__bf16)p;
+          const float ds = p * (dp[t][r] - s_del[qi]) * scale;
+          const __bf16 hi_ = (__bf16)ds;
+          dsf[t * 4 + r] = hi_;
+          dsl[t * 4 + r] = (__bf16)(ds - (float)hi_);
+        }
+      const __bf16* gb = &gs[(kk * 32 + q4 * 4 + (r16 >> 2)) * KR + 4 * (r16 & 3)];
+      const __bf16* qb = &qs[(kk * 32 + q4 * 4 + (r16 >> 2)) * KR + 4 * (r16 & 3)];
+#pragma unroll
+      for (int dt = 0; dt < 2; dt++) {
+        abf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) abf16x4*)(gb + dt * 16));
+        abf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) abf16x4*)(gb + 16 * KR + dt * 16));
+        abf16x8 tf;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { tf[e] = lo[e]; tf[4 + e] = hi[e]; }
+        dva[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf, pf, dva[dt], 0, 0, 0);
+        lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) abf16x4*)(qb + dt * 16));
+        hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) abf16x4*)(qb + 16 * KR + dt * 16));
+#pragma unroll
+        for (int e = 0; e < 4; e++) { tf[e] = lo[e]; tf[4 + e] = hi[e]; }
+        dka[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf, dsf, dka[dt], 0, 0, 0);
+        dka[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf, dsl, dka[dt], 0, 0, 0);
+      }
+    }
+    if (key < S) {
+      float* ov = dV + (row0 + key) * lddv + h * D + q4 * 4;
+      float* ok = dK + (row0 + key) * lddk + h * D + q4 * 4;
+#pragma unroll
+      for (int dt = 0; dt < 2; dt++) {
+        *reinterpret_cast<float4*>(ov + dt * 16) = make_float4(dva[dt][0], dva[dt][1], dva[dt][2], dva[dt][3]);
+        *reinterpret_cast<float4*>(ok + dt * 16) = make_float4(dka[dt][0], dka[dt][1], dka[dt][2], dka[dt][3]);
+      }
+    }
+  }
+}
+
+
 extern "C" int avlen_attention_fwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O,
                                    int ldo, const float* key_mask, float* lse, int B, int H, int Sq, int Sk, int D,
                                    int causal, float scale, hipStream_t stream) {
   return avlen_attention_fwd16(Q, ldq, K, ldk, V, ldv, O, ldo, nullptr, 0, key_mask, lse, B, H, Sq, Sk, D, causal, scale, stream);
+}
+
+// bf16-operand self-attention backward (Sq == Sk == S <= 320, D = 32, key mask, no causal mask); same arguments as
+// avlen_attention_bwd.  AVLEN_ERR_ARG when the shape is outside that envelope (the caller then takes the fp32 kernels).
+extern "C" int avlen_attention_bwd_bf16(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
+                                        const float* O, int ldo, const float* dO, int lddo, const float* key_mask,
+                                        const float* lse, float* delta, float* dQ, int lddq, float* dK, int lddk, float* dV,
+                                        int lddv, int B, int H, int Sq, int Sk, int D, int causal, float scale,
+                                        hipStream_t stream) {
+  if (B <= 0 || H <= 0 || Sq != Sk || Sq <= 0 || Sq > 320 || D != 32 || causal || ((ldq | ldk | ldv | ldo | lddo | lddq | lddk | lddv) & 3))
+    return AVLEN_ERR_ARG;
+  if (Sq <= 160)
+    hipLaunchKernelGGL((attn_bwd16_kernel<160, 256>), dim3(H, B), dim3(256), 0, stream, Q, ldq, K, ldk, V, ldv, O, ldo, dO, lddo, key_mask, lse,
+                       delta, dQ, lddq, dK, lddk, dV, lddv, H, Sq, scale);
+  else {
+    static int nth = -1;                           // AVLEN_ATTN_BWD16_THREADS=256|512|1024 (A/B knob)
+    if (nth < 0) { const char* e = getenv("AVLEN_ATTN_BWD16_THREADS"); nth = e ? atoi(e) : 1024; }
+    if (nth == 256)
+      hipLaunchKernelGGL((attn_bwd16_kernel<320, 256>), dim3(H, B), dim3(256), 0, stream, Q, ldq, K, ldk, V, ldv, O, ldo, dO, lddo, key_mask,
+                         lse, delta, dQ, lddq, dK, lddk, dV, lddv, H, Sq, scale);
+    else if (nth == 512)
+      hipLaunchKernelGGL((attn_bwd16_kernel<320, 512>), dim3(H, B), dim3(512), 0, stream, Q, ldq, K, ldk, V, ldv, O, ldo, dO, lddo, key_mask,
+                         lse, delta, dQ, lddq, dK, lddk, dV, lddv, H, Sq, scale);
+    else      // 16 waves: measured 9.2 / 5.6 / 4.0 ms for 256 / 512 / 1024 threads at 2400 x 8 heads x 301 tokens (fp32 kernels: 17 ms)
+      hipLaunchKernelGGL((attn_bwd16_kernel<320, 1024>), dim3(H, B), dim3(1024), 0, stream, Q, ldq, K, ldk, V, ldv, O, ldo, dO, lddo,
+                         key_mask, lse, delta, dQ, lddq, dK, lddk, dV, lddv, H, Sq, scale);
+  }
+  return avlen_launch_status();
 }
 
 extern "C" int avlen_attention_bwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,

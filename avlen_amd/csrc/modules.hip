@@ -31,6 +31,11 @@ struct Ctx { hipStream_t st; int prec; void* gws; size_t gws_bytes; const int* l
 // operands to bf16 once (transposed for the weight gradient, whose contraction runs over the rows) and running the
 // glds / 8-wave MFMA kernel is 2x faster end to end even with the extra pass.  Same arithmetic (bf16 operands, fp32
 // accumulate), different summation order.  Used when bf16 mode is on, scratch was laid out and M >= big_m().
+bool attn_bwd16_on() {          // AVLEN_ATTN_BWD16=0: fp32 attention backward in bf16 mode too (A/B knob)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("AVLEN_ATTN_BWD16"); v = e ? atoi(e) : 1; }
+  return v != 0;
+}
 long g_big_m = -1;
 long big_m() {
   if (g_big_m < 0) { const char* e = getenv("AVLEN_BIGM"); g_big_m = e ? atol(e) : 16384; }
@@ -1129,8 +1134,15 @@ int transformer_bwd(const Ctx& c, const avlen_transformer& tr, const avlen_trans
     TRY(linear_dx(c, wv, dAO, d, dZ, d, (int)R, dT1, d));                         // dZ = dT1 + dV Wv
   } else {
     float* dQKV = s.dA;
-    TRY(avlen_attention_bwd(t.QKV, 3 * d, t.QKV + d, 3 * d, t.QKV + 2 * d, 3 * d, t.AO, d, dAO, d, maskx, t.LSE, s.delta,
-                            dQKV, 3 * d, dQKV + d, 3 * d, dQKV + 2 * d, 3 * d, B, H, S, S, D, 0, scale, c.st));
+    // bf16 mode: the matrix-core backward (P / dS in registers); shapes outside its envelope take the fp32 kernels
+    int rc = AVLEN_ERR_ARG;
+    if (c.prec == AVLEN_PREC_BF16 && attn_bwd16_on())
+      rc = avlen_attention_bwd_bf16(t.QKV, 3 * d, t.QKV + d, 3 * d, t.QKV + 2 * d, 3 * d, t.AO, d, dAO, d, maskx, t.LSE, s.delta,
+                                    dQKV, 3 * d, dQKV + d, 3 * d, dQKV + 2 * d, 3 * d, B, H, S, S, D, 0, scale, c.st);
+    if (rc == AVLEN_ERR_ARG)
+      rc = avlen_attention_bwd(t.QKV, 3 * d, t.QKV + d, 3 * d, t.QKV + 2 * d, 3 * d, t.AO, d, dAO, d, maskx, t.LSE, s.delta,
+                               dQKV, 3 * d, dQKV + d, 3 * d, dQKV + 2 * d, 3 * d, B, H, S, S, D, 0, scale, c.st);
+    TRY(rc);
     TRY(linear_dw(c, ge.self_attn.in_proj, dQKV, 3 * d, Z, d, (int)R));
     TRY(colsum_acc(c, dQKV, 3 * d, ge.self_attn.in_proj.b, (int)R, 3 * d));
     TRY(linear_dx(c, e.self_attn.in_proj, dQKV, 3 * d, dZ, d, (int)R, dT1, d));   // dZ = dT1 + dQKV Win

@@ -145,6 +145,14 @@ int avlen_attention_bwd(const float* Q, int ldq, const float* K, int ldk, const 
                         const float* lse, float* delta, float* dQ, int lddq, float* dK, int lddk, float* dV,
                         int lddv, int B, int H, int Sq, int Sk, int D, int causal, float scale,
                         avlen_stream_t stream);
+/* The same gradients on the matrix cores (bf16 operands, fp32 accumulate; P and dS stay in registers) for the scene-memory
+ * encoder's self-attention: Sq == Sk <= 320, D == 32, no causal mask -- AVLEN_ERR_ARG outside that envelope.  Used by
+ * avlen_smt_bwd in bf16 mode. */
+int avlen_attention_bwd_bf16(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
+                             const float* O, int ldo, const float* dO, int lddo, const float* key_mask,
+                             const float* lse, float* delta, float* dQ, int lddq, float* dK, int lddk, float* dV,
+                             int lddv, int B, int H, int Sq, int Sk, int D, int causal, float scale,
+                             avlen_stream_t stream);
 
 /* ------------------------------------------------------------------ small fused kernels -------- */
 /* (B,S,S,C) NHWC fp32 -> (x / divisor) -> kxk block mean -> (B,64,64,C).  K1+K2: smt_cnn.py:83-93 +

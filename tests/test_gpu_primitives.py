@@ -206,6 +206,17 @@ def test_attention_fwd_bwd(L, B, H, Sq, Sk, D, causal, masked):
            L.ptr(lse), L.ptr(delta), L.ptr(dq), d, L.ptr(dk), d, L.ptr(dv), d, B, H, Sq, Sk, D, causal, scale, L.stream())
     torch.cuda.synchronize()
     assert rel_err(dq, q.grad) < 5e-5 and rel_err(dk, k.grad) < 5e-5 and rel_err(dv, v.grad) < 5e-5
+    if Sq == Sk and D == 32 and not causal:
+        # the matrix-core backward (bf16 operands, fp32 accumulate; the 2nd-stage training path): bf16 rounding of q, k, v, dO,
+        # P and dS -> 2e-2 of each gradient's largest element
+        dq2, dk2, dv2 = (torch.full((B, S, d), float("nan"), device="cuda") for S in (Sq, Sk, Sk))
+        delta2 = torch.empty(B, H, Sq, device="cuda")
+        L.call("avlen_attention_bwd_bf16", L.ptr(qd), d, L.ptr(kd), d, L.ptr(vd), d, L.ptr(o), d, L.ptr(dev(do)), d, L.ptr(md),
+               L.ptr(lse), L.ptr(delta2), L.ptr(dq2), d, L.ptr(dk2), d, L.ptr(dv2), d, B, H, Sq, Sk, D, causal, scale, L.stream())
+        torch.cuda.synchronize()
+        assert rel_err(delta2, delta) < 1e-5
+        e = (rel_err(dq2, q.grad), rel_err(dk2, k.grad), rel_err(dv2, v.grad))
+        assert max(e) < 2e-2, e
 
 
 def test_preprocess_and_pack(L):
