@@ -389,19 +389,32 @@ class Policy(nn.Module):
                     pc = probs.cpu()                                    # sync; (B,A) floats
                 ah = self._host_action(B)
                 torch.argmax(pc / q, dim=-1, keepdim=True, out=ah)
-                action = ah.to(dev, non_blocking=True)
+                action = self._result_bufs(which, B, dev)[0]
+                action.copy_(ah, non_blocking=True)
             else:
                 q = torch.empty_like(probs).exponential_(1)
                 action = (probs / q).argmax(-1, keepdim=True)
         if action is not None:
             action = _i64(action.view(B, 1))
-            logp = torch.empty(B, 1, device=dev)
-            ent = torch.empty(B, device=dev)
+            _, logp, ent = self._result_bufs(which, B, dev)
             h = self._heads(which)
             L.call("avlen_heads_fwd", C.byref(h), E.P(feats), d, A, None, None, None, None, E.P(action), E.P(logp),
                    E.P(ent), B, L.stream())
             out.update(action=action, log_prob=logp, entropy_rows=ent)
         return out
+
+    def _result_bufs(self, which, B, dev):
+        """Persistent (action, log_prob, entropy_rows) tensors of one head set and batch size: like the graph outputs they are
+        overwritten by the next call of the same kind (RolloutStorage.insert copies what it keeps), and their stable addresses let
+        the storage reuse its validated copy plan."""
+        if not self.use_graphs:                        # eager mode keeps the reference's fresh-tensor-per-call behaviour
+            return (torch.empty(B, 1, dtype=torch.int64, device=dev), torch.empty(B, 1, device=dev), torch.empty(B, device=dev))
+        key = ("res", which, B)
+        r = self._pinned.get(key)
+        if r is None or r[0].device != dev:
+            r = self._pinned[key] = (torch.empty(B, 1, dtype=torch.int64, device=dev), torch.empty(B, 1, device=dev),
+                                     torch.empty(B, device=dev))
+        return r
 
     def _host_action(self, B):
         """Pinned staging buffer for the sampled actions (ring of 8: an upload is consumed long before its slot returns)."""
