@@ -11,6 +11,7 @@ Sampling: `Categorical.sample()` of the reference CPU path consumes the torch CP
 action is drawn from that generator in the same order -> bit-exact actions for a fixed seed;
 sampling="device" keeps everything on the GPU (like the reference would on a CUDA device).
 """
+import contextlib
 import ctypes as C
 import os
 import torch
@@ -579,8 +580,10 @@ class Policy(nn.Module):
         run_on = stream if stream is not None else cur
         if stream is not None:
             stream.wait_stream(cur)
-        with torch.cuda.stream(run_on):
+        ctx = torch.cuda.stream(run_on) if stream is not None else contextlib.nullcontext()
+        with ctx:
             out = self._forward(which, *net_args)
+            done = torch.cuda.Event()
             if self.sampling == "host":
                 # the probabilities start their way to the host right behind this forward (pinned buffer + event)
                 probs = out[1]["probs"]
@@ -589,11 +592,10 @@ class Policy(nn.Module):
                     self._pinned[key] = torch.empty(probs.shape, dtype=probs.dtype, pin_memory=True)
                 pc = self._pinned[key]
                 pc.copy_(probs, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(run_on)
-                out[1]["probs_host"] = (pc, ev)
-            done = torch.cuda.Event()
-            done.record(run_on)
+                done.record(run_on)
+                out[1]["probs_host"] = (pc, done)          # one event: forward finished AND probabilities on the host
+            else:
+                done.record(run_on)
         self._stash = (which, self._arg_key(net_args), out, done)
 
     def prefetch_act(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks, stream=None):
