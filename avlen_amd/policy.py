@@ -973,6 +973,26 @@ class AudioNavDialogNet(_SMTBase):
     _text_key = None                  # part of the graph key: a forward captured against the static embedding buffer
     _text_read = None                 # event: the last forward that read the static embedding has been enqueued up to here
 
+    def _dialog_embed(self, pol, e):
+        """dialog_layer(CLIP embedding) (policy.py:849): (B, 512) -> (B, d)."""
+        eng = pol._engine()
+        B, d, dev, st = e.shape[0], self._hidden_size, e.device, L.stream()
+        d_emb = torch.empty(B, d, device=dev)
+        dl = eng["dialog_layer"]
+        if pol.prec == L.PREC_BF16 and dl.w16:
+            e16 = torch.empty(B, e.shape[1], device=dev, dtype=torch.bfloat16)
+            nbg = L.lib.avlen_gemm_bf16_workspace_bytes(B, d)
+            wsg = pol._ws.get("dlg_gemm", nbg, dev)
+            L.call("avlen_cast_bf16", E.P(e), e.shape[1], E.P(e16), e.shape[1], B, e.shape[1], st)
+            L.call("avlen_gemm_bf16", E.P(e16), e.shape[1], dl.w16, dl.ld16, E.P(d_emb), d, None, 0, dl.b, None, 0, B, d,
+                   e.shape[1], 0, E.P(wsg), nbg, st)
+        else:
+            nbg = L.lib.avlen_gemm_workspace_bytes(B, d, e.shape[1], 1)
+            wsg = pol._ws.get("dlg_gemm", nbg, dev)
+            L.call("avlen_gemm", E.P(e), e.shape[1], 0, dl.w, dl.in_f, 0, E.P(d_emb), d, dl.b, None, 0, B, d,
+                   e.shape[1], 0, pol.prec, 1, 0.0, E.P(wsg), nbg, st)
+        return d_emb
+
     def prefetch_text(self, pol, tokens, stream, after_current=True):
         """Enqueue CLIP.encode_text(tokens) NOW on `stream`: the text tower depends on nothing but the dialog tokens, so it
         can run under the visual towers of the same step instead of after them.  The next run() with the same token tensor
@@ -990,7 +1010,8 @@ class AudioNavDialogNet(_SMTBase):
             g = pol._graphs.get(key)
             if g is None:
                 pol._engine()
-                g = pol._graphs[key] = _Graph(pol, lambda t: self.encode_text(pol, t), [tok])
+                # the graph ends with dialog_layer: what the forward picks up is the (B, d) dialog embedding
+                g = pol._graphs[key] = _Graph(pol, lambda t: self._dialog_embed(pol, self.encode_text(pol, t)), [tok])
             emb = g([tok])
             ev = torch.cuda.Event()
             ev.record(stream)
@@ -1035,20 +1056,8 @@ class AudioNavDialogNet(_SMTBase):
                 cur.wait_stream(s_txt)
             if fork and pre is not None and getattr(pol, "_capture", None) is not None and _SPLIT:
                 pol._capture.split()                     # everything above does not need the text embedding
-            d_emb = torch.empty(B, d, device=dev)
-            dl = eng["dialog_layer"]
-            if pol.prec == L.PREC_BF16 and dl.w16:
-                e16 = torch.empty(B, e.shape[1], device=dev, dtype=torch.bfloat16)
-                nbg = L.lib.avlen_gemm_bf16_workspace_bytes(B, d)
-                wsg = pol._ws.get("dlg_gemm", nbg, dev)
-                L.call("avlen_cast_bf16", E.P(e), e.shape[1], E.P(e16), e.shape[1], B, e.shape[1], st)
-                L.call("avlen_gemm_bf16", E.P(e16), e.shape[1], dl.w16, dl.ld16, E.P(d_emb), d, None, 0, dl.b, None, 0, B, d,
-                       e.shape[1], 0, E.P(wsg), nbg, st)
-            else:
-                nbg = L.lib.avlen_gemm_workspace_bytes(B, d, e.shape[1], 1)
-                wsg = pol._ws.get("dlg_gemm", nbg, dev)
-                L.call("avlen_gemm", E.P(e), e.shape[1], 0, dl.w, dl.in_f, 0, E.P(d_emb), d, dl.b, None, 0, B, d,
-                       e.shape[1], 0, pol.prec, 1, 0.0, E.P(wsg), nbg, st)
+            # prefetch_text already applied dialog_layer inside the text graph; otherwise do it here
+            d_emb = e if pre is not None else self._dialog_embed(pol, e)
         memd = _f32(ext_memory_dialog)
         mk = _f32(ext_memory_masks)
         M = memd.shape[0]
