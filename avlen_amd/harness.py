@@ -30,12 +30,16 @@ class Workload:
     def __init__(self, num_envs, num_steps=150, spectrogram=(257, 101, 2), precision="bf16", pretraining=True,
                  em_capacity=150, ppo_epoch=2, num_mini_batch=2, device="cuda", seed=0, sampling="host",
                  with_dialog_policy=True, with_goal_policy=True, use_graphs=True, share_encoders=True, weight_seed=0,
-                 launch_ahead=True, belief_predictor=False):
+                 launch_ahead=True, belief_predictor=False, cached_views=False, distractor=False):
         self.N, self.T, self.dev = num_envs, num_steps, torch.device(device)
         self.spec = spectrogram
         # enqueue all three policies' forwards before the first host-side sampling; pi_g and pi_l run on their own streams,
         # overlap on the GPU and hand their probabilities to the host as each finishes (3.13 -> 2.73 ms per step)
         self.launch_ahead = launch_ahead
+        # The reference trainer slices fresh views of the storage every step (ppo_trainer.py:375-391): so does this driver, unless
+        # `cached_views` keeps the view objects per step slot (saves the host ~30 tensor-indexing calls per step).
+        self.cached_views = cached_views
+        self.distractor = distractor
         self.text_ahead = os.environ.get("AVLEN_TEXT_AHEAD", "1") != "0"      # A/B knob
         self._g_stream = int(os.environ.get("AVLEN_G_STREAM", "1"))
         self._text_after = os.environ.get("AVLEN_TEXT_AHEAD", "1") == "2"     # 2: ordered after the current stream (debug)
@@ -46,11 +50,13 @@ class Workload:
         osp, asp = savi_observation_space(spectrogram), ActionSpace(4)
         torch.manual_seed(weight_seed)          # identical initial weights on every rank (data-parallel replicas)
         kw = dict(SMT_KW, precision=precision, sampling=sampling, use_graphs=use_graphs)
-        self.pi_q = P.AudioNavOptionPolicy(osp, asp, pretraining=pretraining, use_category_input=False,
+        # distractor variant (BASELINE configs[4]): has_distractor_sound -> use_category_input for all three policies
+        # (ddppo_trainer.py:306,329,349,371); pi_l ignores it (policy.py:728-732)
+        self.pi_q = P.AudioNavOptionPolicy(osp, asp, pretraining=pretraining, use_category_input=distractor,
                                            query_count_emb_size=32, **kw).to(self.dev)
-        self.pi_g = (P.AudioNavSMTPolicy(osp, asp, pretraining=False, use_category_input=False, **kw).to(self.dev)
+        self.pi_g = (P.AudioNavSMTPolicy(osp, asp, pretraining=False, use_category_input=distractor, **kw).to(self.dev)
                      if with_goal_policy else None)
-        self.pi_l = (P.AudioNavDialogPolicy(osp, asp, pretraining=False, use_category_input=False, num_steps=3,
+        self.pi_l = (P.AudioNavDialogPolicy(osp, asp, pretraining=False, use_category_input=distractor, num_steps=3,
                                             **kw).to(self.dev) if with_dialog_policy else None)
         if share_encoders and precision == "bf16" and self.pi_g is not None and self.pi_l is not None:
             P.share_encoders(self.pi_q, self.pi_g, self.pi_l)
@@ -60,8 +66,9 @@ class Workload:
         self.agent.init_distributed(find_unused_params=True)
         T, N = self.T, self.N
         ems = em_capacity + T                       # ddppo_trainer.py:649-669: size = capacity + num_steps
-        self.rollouts = RolloutStorage(T, N, osp, asp, 512, True, ems, em_capacity, ems, em_capacity, 3, 3, 276, 276,
-                                       308, 256, num_recurrent_layers=-1, max_dialog_len=77, use_state_memory=True,
+        dg = self.pi_g.net.memory_dim if self.pi_g is not None else self.pi_q.net.memory_dim - 32
+        self.rollouts = RolloutStorage(T, N, osp, asp, 512, True, ems, em_capacity, ems, em_capacity, 3, 3, dg, 276,
+                                       self.pi_q.net.memory_dim, 256, num_recurrent_layers=-1, max_dialog_len=77, use_state_memory=True,
                                        device=self.dev)
         self.belief = None
         self._act_buf = None
@@ -121,7 +128,7 @@ class Workload:
     def _step_views(self, t):
         """Every tensor the trainer would slice out of the storage / simulator output at step t (views of persistent
         buffers, built once per step slot)."""
-        v = self._views.get(t)
+        v = self._views.get(t) if self.cached_views else None
         if v is None:
             ro = self.rollouts
             v = dict(obs={k: x[t] for k, x in ro.observations.items()}, h=ro.recurrent_hidden_states[t],
@@ -131,12 +138,12 @@ class Workload:
                      nxt={k: self.sim[k][t + 1] for k in ro.observations}, rew=self.rewards[t], nd=self.not_done[t],
                      dones=self.dones[t],
                      rl=self.rl_masks[t], ucnt=self.ucnt_gt[t])
-            self._views[t] = v
+            if self.cached_views:
+                self._views[t] = v
         return v
 
-    def rollout_step(self):
-        ro, t = self.rollouts, self.rollouts.step
-        v = self._step_views(t)
+    def _forward_all(self, ro, v, t):
+        """The three policies on the state `v` (step views) of storage `ro`, in the trainer's order (ppo_trainer.py:449, 608, 625)."""
         obs, h, prev, em_masks = v["obs"], v["h"], v["prev"], v["em_masks"]
         em_opt, em_goal = ro.external_memory_option[:, t], ro.external_memory_goal[:, t]
         em_vln, em_dlg = ro.external_memory_vln[:, t], ro.external_memory_vln_dialog[:, t]
@@ -156,22 +163,48 @@ class Workload:
                                               v["astep"], stream=self._side[1])
         values, unct, a_opt, lp_opt, h, row_opt, probs_opt = self.pi_q.act_option(
             obs, h, prev, v["masks"], em_opt, em_masks, v["qs"], v["lqi"])
-        actions, row_goal, row_vln, row_dlg, probs_vln = a_opt, row_opt[:, :276], row_opt[:, :276], self.zero_dialog_feats, None
+        dg = ro.em_dim_goal
+        o = dict(q_value=values, q_prob=probs_opt, a_q=a_opt, lp_q=lp_opt, h=h, row_q=row_opt, row_g=row_opt[:, :dg],
+                 row_l=row_opt[:, :276], row_d=self.zero_dialog_feats, l_prob=self.zero_probs, a_g=a_opt, a_l=a_opt,
+                 g_value=values, l_value=values, g_prob=self.zero_probs)
         if self.pi_g is not None:
-            _, a_goal, _, _, row_goal, _ = self.pi_g.act(obs, h, prev, v["masks"], em_goal, em_masks)
-            actions = a_goal
+            o["g_value"], o["a_g"], _, _, o["row_g"], o["g_prob"] = self.pi_g.act(obs, h, prev, v["masks"], em_goal, em_masks)
         if self.pi_l is not None:
-            _, a_vln, _, _, row_vln, row_dlg, probs_vln = self.pi_l.act_dialog(
+            o["l_value"], o["a_l"], _, _, o["row_l"], o["row_d"], o["l_prob"] = self.pi_l.act_dialog(
                 obs, h, prev, v["masks_vln"], em_vln, em_dlg, v["em_vln_masks"], v["dialog"], v["astep"])
+        return o
+
+    def policies_on(self, other, t=None):
+        """This workload's policies evaluated on ANOTHER workload's current state (its storage, memories, step inputs): the
+        bf16-vs-fp32 comparison of bench.py and the harness-vs-oracle tests.  Nothing is stored."""
+        t = other.rollouts.step if t is None else t
+        return self._forward_all(other.rollouts, other._step_views(t), t)
+
+    def rollout_step(self, return_outs=False):
+        ro, t = self.rollouts, self.rollouts.step
+        v = self._step_views(t)
+        o = self._forward_all(ro, v, t)
+        a_opt, actions = o["a_q"], o["a_q"]
+        if self.pi_g is not None:
+            actions = o["a_g"]
+        if self.pi_l is not None:
             if self._act_buf is None:
-                self._act_buf = torch.empty_like(a_vln)
-            actions = torch.where(a_opt == 1, a_vln, actions, out=self._act_buf)       # queried envs follow pi_l
-        if probs_vln is None:
-            probs_vln = self.zero_probs
+                self._act_buf = torch.empty_like(o["a_l"])
+            actions = torch.where(a_opt == 1, o["a_l"], actions, out=self._act_buf)       # queried envs follow pi_l
         if self.belief is not None:                 # beliefs of the NEW observation, written in place before it is stored
             self.belief.update(v["nxt"], v["dones"])
-        ro.insert(v["nxt"], h, actions, a_opt, lp_opt, values, v["rew"], v["nd"], v["nd"], row_goal, row_opt, row_vln, row_dlg,
-                  v["dialog"], self.o_action, self.o_mask, v["rl"], v["ucnt"], probs_vln, v["qs"], v["lqi"], v["astep"])
+        if return_outs:                             # graph outputs are overwritten by the next replay
+            o = {k: (x.clone() if torch.is_tensor(x) else x) for k, x in o.items()}
+            o["actions"] = actions.clone()
+        ro.insert(v["nxt"], o["h"], actions, a_opt, o["lp_q"], o["q_value"], v["rew"], v["nd"], v["nd"], o["row_g"], o["row_q"],
+                  o["row_l"], o["row_d"], v["dialog"], self.o_action, self.o_mask, v["rl"], v["ucnt"], o["l_prob"], v["qs"],
+                  v["lqi"], v["astep"])
+        return o if return_outs else None
+
+    def finite(self):
+        ro = self.rollouts
+        return bool(torch.isfinite(ro.value_preds).all()) and bool(torch.isfinite(ro.em_vln_dialog.memory).all()) and \
+            bool(torch.isfinite(ro.em.memory).all()) and bool(torch.isfinite(ro.em_option.memory).all())
 
     # -- _update_agent (ppo_trainer.py:1045-1093) -------------------------------------------------------------
     def update(self):

@@ -173,39 +173,52 @@ def _sig(a):
 
 
 class _Memo:
-    """A resolved launch of `_graphed` for one exact set of argument OBJECTS (a trainer that passes views of persistent
-    buffers, as the storage slices are): the graph, the staging copy as ready ctypes arrays, and the device addresses it was
-    built for.  Holding the tensors keeps their ids from being recycled."""
-    __slots__ = ("g", "tensors", "ptrs", "srcs", "dsts", "sizes", "n", "lead_static")
+    """A resolved launch of `_graphed` for one exact set of argument BUFFERS: the graph and the staging copy as ready ctypes
+    arrays.  Keyed on (address, dtype, shape, contiguity) of every tensor of the call -- not on Python object identity: a trainer
+    that slices fresh views of its storage every step (ppo_trainer.py:375-391) presents new objects over the same memory, and an
+    `id()` can be recycled by an unrelated object.  The memo holds no tensors: the copy reads whatever lives at the source
+    addresses at replay time, which is exactly what the caller passed."""
+    __slots__ = ("g", "srcs", "dsts", "sizes", "n", "lead_static")
+
+
+def _tsig(a):
+    return (a.data_ptr(), a.dtype, tuple(a.shape), a.is_contiguous())
 
 
 def _memo_key(pol, which, mode, args):
-    return (which, mode, getattr(pol.net, "_text_key", None), id(args[0])) + tuple(
-        id(a) if torch.is_tensor(a) else a for i, a in enumerate(args) if i not in (0, 1, 3))
+    obs = args[0]
+    return (which, mode, getattr(pol.net, "_text_key", None)) + tuple(_tsig(obs[k]) for k in pol.net.obs_keys) + tuple(
+        _tsig(a) if torch.is_tensor(a) else a for i, a in enumerate(args) if i not in (0, 1, 3))
 
 
 def _graphed(pol, which, fn, args, mode=None):
     # rnn_hidden_states (arg 1) and masks (arg 3) are not read by the SMT nets: keep them out of the graph
     raw = args
-    mk = _memo_key(pol, which, mode, raw) if (isinstance(raw[0], dict) and not getattr(pol, "_memo_off", False)) else None
+    # derived weights (packed convs, bf16 shadows) must be current BEFORE any replay: a load_state_dict / mark_params_changed
+    # since the last call only set the dirty flag.  The leader of an EncoderGroup replays the followers' towers too.
+    pol._engine()
+    if mode == "lead":
+        for m_ in pol._enc_group.members:
+            if m_ is not pol:
+                m_._engine()
+    mk = None
+    if isinstance(raw[0], dict) and not getattr(pol, "_memo_off", False):
+        try:
+            mk = _memo_key(pol, which, mode, raw)
+        except (KeyError, AttributeError):
+            mk = None
     m = pol._memos.get(mk) if mk is not None else None
-    if m is not None:
-        ok = True
-        for t, p_ in zip(m.tensors, m.ptrs):
-            if t.data_ptr() != p_:
-                ok = False
-                break
-        if ok and (mode != "follow" or pol._enc_group.static_obs is m.lead_static):
-            g = m.g
-            if mode == "lead":
-                pol._enc_group.static_obs = g.static[0]
-            if m.n:
-                L.call("avlen_multi_copy", m.srcs, m.dsts, m.sizes, m.n, L.stream())
-            g.between = getattr(pol, "_between", None)
-            outs, heads = g.replay_only()
-            outs = list(outs)
-            outs[1] = raw[1]
-            return tuple(outs), dict(heads)
+    if m is not None and (mode != "follow" or pol._enc_group.static_obs is m.lead_static):
+        g = m.g
+        if mode == "lead":
+            pol._enc_group.static_obs = g.static[0]
+        if m.n:
+            L.call("avlen_multi_copy", m.srcs, m.dsts, m.sizes, m.n, L.stream())
+        g.between = getattr(pol, "_between", None)
+        outs, heads = g.replay_only()
+        outs = list(outs)
+        outs[1] = raw[1]
+        return tuple(outs), dict(heads)
     args = list(args)
     rnn = args[1]
     args[1], args[3] = None, None
@@ -223,7 +236,6 @@ def _graphed(pol, which, fn, args, mode=None):
         (args[i].data_ptr() if torch.is_tensor(args[i]) else id(args[i])) for i in by_ptr)
     g = pol._graphs.get(key)
     if g is None:
-        pol._engine()                                    # flat/packed state must exist before capture
         if len(pol._graphs) >= 16:
             pol._graphs.clear()
             pol._memos.clear()
@@ -240,9 +252,6 @@ def _graphed(pol, which, fn, args, mode=None):
         if pairs is not None:
             mm = _Memo()
             mm.g = g
-            mm.tensors = [v for k, v in raw[0].items() if k in pol.net.obs_keys] + \
-                         [a for i, a in enumerate(raw) if i not in (0, 1, 3) and torch.is_tensor(a)]
-            mm.ptrs = [t.data_ptr() for t in mm.tensors]
             mm.n = len(pairs)
             mm.srcs = (C.c_void_p * max(mm.n, 1))(*[s_.data_ptr() for _, s_ in pairs])
             mm.dsts = (C.c_void_p * max(mm.n, 1))(*[d_.data_ptr() for d_, _ in pairs])
@@ -387,8 +396,10 @@ class Policy(nn.Module):
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
         self._eng = None
-        self._graphs = {}
-        self._memos = {}
+        # a leader's captured graph bakes in the engine / packed-weight addresses of every member of its EncoderGroup
+        for m in ([self] if self._enc_group is None else self._enc_group.members):
+            m._graphs = {}
+            m._memos = {}
         return r
 
     def side_streams(self):

@@ -165,8 +165,27 @@ class DecentralizedDistributedMixin:
         return (adv - mean) / (var.sqrt() + EPS_PPO)
 
     def init_distributed(self, find_unused_params=True):
-        self._distributed = distrib.is_available() and distrib.is_initialized() and distrib.get_world_size() > 1
+        """ddppo.py:61-84.  The reference wraps the policy in DistributedDataParallel here, whose constructor broadcasts rank 0's
+        parameters and buffers: replicas seeded per rank (ddppo_trainer.py:540-548) start from ONE model.  Same here, on the
+        flat buffer."""
+        # a 1-rank group still goes through the collective (as DDP's reducer does): the RCCL path is the same code at any size
+        self._distributed = distrib.is_available() and distrib.is_initialized()
         self.get_advantages = self._get_advantages_distributed
+        if self._distributed:
+            self.broadcast_parameters()
+
+    def broadcast_parameters(self, src=0):
+        pol = self.actor_critic
+        if next(pol.parameters()).is_cuda:
+            flat = pol._engine()["flat"]
+            distrib.broadcast(flat.flat, src=src)          # every parameter is a view into this buffer
+            for b in pol.buffers():
+                distrib.broadcast(b, src=src)
+            pol.mark_params_changed()                      # packed conv weights / bf16 shadows are derived data
+            pol._engine()
+        else:                                              # host-side rehearsal (gloo tests): no engine on a CPU
+            for t in list(pol.parameters()) + list(pol.buffers()):
+                distrib.broadcast(t.data, src=src)
 
     def reduce_gradients(self, flat):
         if getattr(self, "_distributed", False):

@@ -2,7 +2,8 @@
 """Headline benchmark: env-steps/s of the SAVi PPO rollout-and-update hot path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  (N>1 without a launcher: bench.py starts the N ranks itself, one process per GPU, before the parent touches the GPU;
+   under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it reads RANK/LOCAL_RANK/WORLD_SIZE.)
 
 Workload (BASELINE.json configs[2], the one the metric is quoted on): NUM_ENVS=64 per GPU, full
 pi_g / pi_l / pi_q three-policy stack with the CLIP ViT-B/32 text tower frozen, synthetic 128x128 RGB-D +
@@ -10,17 +11,28 @@ pi_g / pi_l / pi_q three-policy stack with the CLIP ViT-B/32 text tower frozen, 
 (2 epochs x 2 minibatches, interactive 1st-stage yaml).  One "step" = one full rollout+update cycle
 (N*T env-steps per GPU).  Environments shard across GPUs (weak scaling); the only collective is the RCCL
 all-reduce of pi_q's flat gradient, once per optimiser step.
+
+Besides the headline line, rank 0 of a 1-GPU run adds (each skippable, see the flags):
+  roofline          dominant kernel, isolated AND in situ (FLOPs routed through it per rollout step / its per-step time)
+  cpu_baseline      the oracle timed on the host cores at N=64 (bounded T), 1 thread and all threads
+  bf16_vs_fp32      the benched bf16 mode against the fp32 parity mode on identical weights/observations/seeds:
+                    max |value|, |prob| differences and the rate of sampled-action flips, per step on the SAME state
+  fp32_parity_mode  env-steps/s of the same cycle with precision="fp32" (the mode the 1e-3 / bit-exact tests run)
+  integration       env-steps/s with cached step views (round-1 harness) and of the imports-only integration
+                    (no encoder sharing, no launch-ahead)
+  gru_baseline      BASELINE configs[1]: N=16 GRU policy rollout + PPO 4x2 update
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 # The stream layout of the rollout (main + text + pi_g/pi_l streams) is tuned for the runtime's default of 4 hardware queues
 # per process (measured: 2/3/5/6/8 queues give 22k/22k/16k/25k/25k env-steps/s against 29k): pin it.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -35,11 +47,17 @@ def parse():
     ap.add_argument("--rollout", type=int, default=150)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--spectrogram", default="257x101")
+    ap.add_argument("--config", default="interactive", choices=["interactive", "gru"],
+                    help="interactive = BASELINE configs[2] (default); gru = configs[1] (N=16 GRU baseline, PPO 4x2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip bf16_vs_fp32 / fp32_parity_mode / integration / gru records")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-share", action="store_true", help="do not batch the three policies' visual towers")
     ap.add_argument("--no-launch-ahead", action="store_true", help="call the three policies strictly one after the other")
+    ap.add_argument("--cached-views", action="store_true",
+                    help="keep the per-step view objects of the storage (the reference trainer slices fresh ones every step)")
+    ap.add_argument("--distractor", action="store_true", help="BASELINE configs[4]: use_category_input (F = 297 / 329)")
     ap.add_argument("--stage", type=int, default=1, choices=[1, 2],
                     help="1 = savi_interactive_1st_stage (pretraining=True, the metric's config); 2 = 2nd stage: pi_q attends over "
                          "its 300-slot memory history in rollout and update (BASELINE configs[3] runs it at 32 envs per GPU)")
@@ -49,71 +67,260 @@ def parse():
     return ap.parse_args()
 
 
-def kernel_roofline(prec_name):
-    """Roofline of the DOMINANT kernel by GPU time in the rollout (profiles/r01_rocprof_summary.md):
-    g2_kernel<64,128,2,4,2,512>, the bf16 MFMA GEMM (8-wave ping-pong tile, global_load_lds staging) on its heaviest call site, the
+# --------------------------------------------------------------------------------------------------------------------
+# multi-rank entry: the parent never touches the GPU
+# --------------------------------------------------------------------------------------------------------------------
+def spawn_ranks(n):
+    """`bench.py --gpus N` without a launcher: start N ranks (one process per GPU), wait, propagate the worst exit code.
+    Rank 0 prints the JSON line on the inherited stdout."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# roofline of the dominant kernel
+# --------------------------------------------------------------------------------------------------------------------
+def kernel_roofline(prec_name, in_situ=None):
+    """Roofline of the DOMINANT kernel by GPU time in the rollout (profiles/): the bf16 MFMA GEMM on its heaviest call site, the
     CLIP text MLP up-projection c_fc of one rollout step on the ragged batch (M = 2464 live rows, N = 2048, K = 512, bias +
-    QuickGELU, bf16 out); the block's other three GEMMs are listed under `other_call_sites`.  `achieved` = 2*M*N*K / duration measured live with HIP events on the launch stream; `peak` = dense
-    bf16 MFMA; `traffic` = HBM bytes per launch from the rocprofv3 PMC passes (profiles/r01_pmc_traffic.json: 2 x FETCH_SIZE +
-    WRITE_SIZE, gfx950 correction).  The HBM-bound kernel class (direct 3x3 conv of the towers' layer 1) is reported beside it
-    as `hbm_conv`."""
+    QuickGELU, bf16 out); the block's other three GEMMs are listed under `other_call_sites`.  `achieved` = 2*M*N*K / duration
+    measured live with HIP events on the launch stream; `peak` = dense bf16 MFMA; `traffic` = HBM bytes per launch from the
+    rocprofv3 PMC passes (profiles/*_pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction).  The HBM-bound kernel
+    class (direct 3x3 conv of the towers' layer 1) is reported beside it as `hbm_conv`."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import roofline_probe as rp
     pmc = {}
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-    except Exception:
-        pass
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+            break
+        except Exception:
+            pass
     if prec_name != "bf16":
         return None
     sg, sc = rp.measure(rp.make_gemm), rp.measure(rp.make_conv)
     gw, cw = rp.gemm_work(), rp.conv_work()
     tf = gw["flops"] / sg / 1e12
     gb = cw["bytes"] / sc / 1e9
-    return {"bound": "mfma", "kernel": "g2_kernel<64,128,2,4,2,512> bf16 glds GEMM (CLIP c_fc, ragged M=2464 N=2048 K=512)",
-            "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
-            "traffic": pmc.get("gemm", {}).get("traffic_bytes"), "mfma_util_pmc_percent": pmc.get("gemm", {}).get("MfmaUtil_percent"),
-            "algorithmic_flops": gw["flops"],
-            "algorithmic_bytes": gw["bytes"], "us_per_launch": round(sg * 1e6, 2),
-            "other_call_sites": rp.clip_call_sites(),
-            "hbm_conv": {"bound": "hbm", "kernel": "dconv3x3_kernel<16,16,64,3> (tower layer-1 conv, 384 images/launch, bf16 "
-                                                   "in/out, fused GN statistics)", "achieved": round(gb, 1), "peak": 8000.0,
-                         "unit": "GB/s", "frac": round(gb / 8000.0, 4), "traffic": pmc.get("dconv", {}).get("traffic_bytes"),
-                         "algorithmic_bytes": cw["bytes"], "us_per_launch": round(sc * 1e6, 2)}}
+    out = {"bound": "mfma", "kernel": rp.GEMM_KERNEL_NAME + " bf16 glds GEMM (CLIP c_fc, ragged M=2464 N=2048 K=512)",
+           "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
+           "traffic": pmc.get("gemm", {}).get("traffic_bytes"), "mfma_util_pmc_percent": pmc.get("gemm", {}).get("MfmaUtil_percent"),
+           "algorithmic_flops": gw["flops"],
+           "algorithmic_bytes": gw["bytes"], "us_per_launch": round(sg * 1e6, 2),
+           "other_call_sites": rp.clip_call_sites(),
+           "hbm_conv": {"bound": "hbm", "kernel": "dconv3x3_kernel<16,16,64,3> (tower layer-1 conv, 384 images/launch, bf16 "
+                                                  "in/out, fused GN statistics)", "achieved": round(gb, 1), "peak": 8000.0,
+                        "unit": "GB/s", "frac": round(gb / 8000.0, 4), "traffic": pmc.get("dconv", {}).get("traffic_bytes"),
+                        "algorithmic_bytes": cw["bytes"], "us_per_launch": round(sc * 1e6, 2)}}
+    if in_situ:
+        out["in_situ"] = in_situ
+    try:
+        out["tower_convs"] = rp.tower_conv_table()
+    except Exception as e:                       # the table is an extra: never lose the headline line over it
+        out["tower_convs_error"] = repr(e)
+    return out
 
 
-def cpu_baseline(spec_hw):
+def text_tower_in_situ(wl):
+    """CLIP text tower of ONE rollout step at the benched batch, timed with HIP events on the stream it is launched on while
+    nothing else runs: FLOPs through the GEMM family per step / that time.  (The rocprof per-step table in profiles/ gives the
+    same quantity with the towers running beside it.)"""
+    import torch
+    pol = wl.pi_l
+    if pol is None:
+        return None
+    toks = wl.dialog[0]
+    st = torch.cuda.Stream()
+    live = int((toks.argmax(-1) + 1).sum())                      # rows that reach the GEMMs (EOT position + 1 per dialog)
+    N = toks.shape[0]
+    w = 512
+    # per live row and layer: in_proj 3w^2, out_proj w^2, c_fc 4w^2, c_proj 4w^2 MACs; the last layer's MLP and out_proj run on
+    # the N pooled rows only
+    flops = 2.0 * (11 * live * 12 * w * w + live * 3 * w * w + N * 9 * w * w)
+    for _ in range(3):
+        pol.prefetch_text(toks, st, after_current=True)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    it = 20
+    with torch.cuda.stream(st):
+        e0.record(st)
+    for _ in range(it):
+        pol.prefetch_text(toks, st, after_current=False)
+    with torch.cuda.stream(st):
+        e1.record(st)
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) / 1e3 / it
+    return {"what": "CLIP text tower graph of one rollout step, alone on its stream", "live_rows": live, "ms": round(sec * 1e3, 4),
+            "gemm_flops": flops, "TFLOPs": round(flops / sec / 1e12, 1), "frac_of_bf16_peak": round(flops / sec / 2.5e15, 4)}
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle, "port")
+# --------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(spec_hw, envs):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import flow                                            # the oracle: checker/baseline only, never the product
     specs = json.load(open(os.path.join(ROOT, "tests", "golden", "param_specs.json")))
     cores = os.cpu_count() or 1
-    n, t = 32, 6                      # ~20 s of host work on the GPU box's cores
+    # SURVEY 8(d): N = NUM_ENVS of the metric, >= 1 warm-up, same call order; T is shortened (150 steps of the oracle at N=64
+    # would take ~15 min) -- the rollout cost per step does not depend on T, the update's does (T*N samples), so the shortened
+    # cycle keeps the rollout:update proportion of samples
+    flow.cpu_baseline(specs, N=4, T=1, spectrogram=spec_hw, pretraining=True, threads=min(cores, 64))          # warm-up
+    n, t = envs, 2
     eps, sec, thr = flow.cpu_baseline(specs, N=n, T=t, spectrogram=spec_hw, pretraining=True, threads=min(cores, 64))
-    # SURVEY 8(d) asks for both thread settings: the reference pins torch to ONE thread (run.py:113)
-    n1, t1 = 8, 8
+    flow.cpu_baseline(specs, N=2, T=1, spectrogram=spec_hw, pretraining=True, threads=1)                        # warm-up
+    n1, t1 = envs, 1
     eps1, sec1, _ = flow.cpu_baseline(specs, N=n1, T=t1, spectrogram=spec_hw, pretraining=True, threads=1)
     return {"value": round(eps, 3), "unit": "env-steps/s", "cores": thr, "kind": "port",
             "sample": f"oracle (plain PyTorch fp32 restatement), {n} envs x {t} steps of the 3-policy rollout incl. CLIP "
-                      f"text + one pi_q PPO update (2 epochs x 2 minibatches), {sec:.1f} s",
+                      f"text + one pi_q PPO update (2 epochs x 2 minibatches), after a warm-up pass, {sec:.1f} s",
             "single_thread": {"value": round(eps1, 3), "cores": 1,
-                              "sample": f"same flow, torch.set_num_threads(1) as the reference runs it, {n1} envs x {t1} steps, {sec1:.1f} s"}}
+                              "sample": f"same flow, torch.set_num_threads(1) as the reference runs it (run.py:113), {n1} envs x "
+                                        f"{t1} step + update, {sec1:.1f} s"}}
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# bf16 (benched) vs fp32 (parity) mode
+# --------------------------------------------------------------------------------------------------------------------
+def bf16_vs_fp32(a, H, W, wl16):
+    """The benched mode against the fp32 parity mode: same weights (same weight seed), same synthetic observations, same host
+    RNG state.  Per step t the fp32 workload's state (storage views, memories written by fp32 forwards) is fed to BOTH sets of
+    policies with the host generator rewound in between, so `action_flip_rate` counts steps where bf16 arithmetic alone changed
+    the sampled action (no trajectory divergence mixed in)."""
+    import torch
+    from avlen_amd.harness import Workload
+    wl32 = Workload(a.envs, a.rollout, spectrogram=(H, W, 2), precision="fp32", pretraining=(a.stage == 1), seed=0,
+                    use_graphs=not a.no_graphs, share_encoders=False, launch_ahead=False, distractor=a.distractor)
+    T = a.rollout
+    mv = {"q_value": 0.0, "q_prob": 0.0, "g_prob": 0.0, "l_prob": 0.0, "g_value": 0.0, "l_value": 0.0}
+    flips = {"q": 0, "g": 0, "l": 0}
+    torch.manual_seed(4242)
+    t0 = time.perf_counter()
+    for t in range(T):
+        rng = torch.get_rng_state()
+        o16 = wl16.policies_on(wl32, t)
+        o16 = {k: v.clone() for k, v in o16.items()}
+        torch.set_rng_state(rng)
+        o32 = wl32.rollout_step(return_outs=True)
+        for k in mv:
+            mv[k] = max(mv[k], float((o16[k] - o32[k]).abs().max()))
+        for k in flips:
+            flips[k] += int((o16["a_" + k] != o32["a_" + k]).sum())
+    torch.cuda.synchronize()
+    t_roll = time.perf_counter() - t0
+    n = T * a.envs
+    # fp32 parity mode throughput: one more full cycle (the rollout above + this update warmed everything up)
+    wl32.update()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    wl32.cycle()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t1
+    rec = {"samples": n, "how": "per step on the fp32 workload's state, host RNG rewound between the two modes; N, T as benched",
+           "max_abs_value": round(max(mv["q_value"], mv["g_value"], mv["l_value"]), 6),
+           "max_abs_prob": round(max(mv["q_prob"], mv["g_prob"], mv["l_prob"]), 6),
+           "action_flip_rate": round((flips["q"] + flips["g"] + flips["l"]) / (3.0 * n), 6),
+           "per_policy": {"pi_q": {"max_abs_value": round(mv["q_value"], 6), "max_abs_prob": round(mv["q_prob"], 6),
+                                   "flips": flips["q"]},
+                          "pi_g": {"max_abs_value": round(mv["g_value"], 6), "max_abs_prob": round(mv["g_prob"], 6),
+                                   "flips": flips["g"]},
+                          "pi_l": {"max_abs_value": round(mv["l_value"], 6), "max_abs_prob": round(mv["l_prob"], 6),
+                                   "flips": flips["l"]}}}
+    fp32 = {"value": round(a.envs * T / dt, 2), "unit": "env-steps/s", "ms_per_step": round(dt * 1e3, 2),
+            "what": "same cycle, precision='fp32' (fp32 MFMA, deterministic reductions; the mode of the 1e-3 / bit-exact parity "
+                    "tests), graphs on, no encoder sharing / launch-ahead"}
+    del wl32
+    torch.cuda.empty_cache()
+    return rec, fp32
+
+
+def time_cycles(wl, warmup, steps):
+    import torch
+    for _ in range(warmup):
+        wl.cycle()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl.cycle()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def integration_records(a, H, W):
+    import torch
+    from avlen_amd.harness import Workload
+    out = {}
+    for name, kw in (("cached_views", dict(cached_views=True)),
+                     ("imports_only", dict(share_encoders=False, launch_ahead=False))):
+        kws = dict(spectrogram=(H, W, 2), precision=a.precision, pretraining=(a.stage == 1), seed=0, use_graphs=not a.no_graphs,
+                   share_encoders=not a.no_share, launch_ahead=not a.no_launch_ahead, distractor=a.distractor)
+        kws.update(kw)
+        wl = Workload(a.envs, a.rollout, **kws)
+        dt = time_cycles(wl, 1, 2)
+        out[name] = {"value": round(a.envs * a.rollout / dt, 2), "unit": "env-steps/s", "ms_per_step": round(dt * 1e3, 2)}
+        del wl
+        torch.cuda.empty_cache()
+    out["what"] = ("headline = fresh storage views every step (as ppo_trainer.py:375-391 slices them), encoder sharing + "
+                   "launch-ahead calls added to the trainer; cached_views = the round-1 harness (view objects kept per step "
+                   "slot); imports_only = the three-import-lines integration: no share_encoders, no prefetch_* calls")
+    return out
+
+
+def gru_record(a):
+    """BASELINE configs[1]: NUM_ENVS=16, AudioCNN + VisualCNN + single-layer GRU pi_g, PPO 4 epochs x 2 minibatches, bf16."""
+    import torch
+    from avlen_amd.harness import GruWorkload
+    H, W = (int(x) for x in a.spectrogram.split("x"))
+    wl = GruWorkload(16, a.rollout, spectrogram=(H, W, 2), precision=a.precision)
+    dt = time_cycles(wl, 1, 3)
+    rec = {"value": round(16 * a.rollout / dt, 2), "unit": "env-steps/s", "ms_per_step": round(dt * 1e3, 2),
+           "config": {"workload": "AudioNavBaselinePolicy (AudioCNN + VisualCNN + GRU-512) rollout + PPO 4 epochs x 2 minibatches",
+                      "num_envs": 16, "rollout_steps": a.rollout, "spectrogram": a.spectrogram, "dtype": a.precision}}
+    del wl
+    torch.cuda.empty_cache()
+    return rec
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a.gpus))
+    import torch
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    assert world == a.gpus or a.gpus == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
-    torch.cuda.set_device(local % torch.cuda.device_count())
+    backend = os.environ.get("AVLEN_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    assert backend != "nccl" or world <= ndev, f"{world} ranks need {world} GPUs, {ndev} visible"
+    torch.cuda.set_device(local % ndev)
     if world > 1:
         import torch.distributed as dist
         # RCCL over xGMI ("nccl"); AVLEN_DIST_BACKEND=gloo rehearses the multi-rank flow on a single-GPU box
-        dist.init_process_group(os.environ.get("AVLEN_DIST_BACKEND", "nccl"))
+        dist.init_process_group(backend)
+        assert dist.get_world_size() == world
     from avlen_amd.harness import Workload
     H, W = (int(x) for x in a.spectrogram.split("x"))
-    wl = Workload(a.envs, a.rollout, spectrogram=(H, W, 2), precision=a.precision, pretraining=(a.stage == 1), seed=rank,
-                  use_graphs=not a.no_graphs, share_encoders=not a.no_share, launch_ahead=not a.no_launch_ahead, belief_predictor=a.belief)
+    if a.config == "gru":
+        from avlen_amd.harness import GruWorkload
+        wl = GruWorkload(a.envs if a.envs != 64 else 16, a.rollout, spectrogram=(H, W, 2), precision=a.precision, seed=rank)
+        a.envs = wl.N
+    else:
+        wl = Workload(a.envs, a.rollout, spectrogram=(H, W, 2), precision=a.precision, pretraining=(a.stage == 1), seed=rank,
+                      use_graphs=not a.no_graphs, share_encoders=not a.no_share, launch_ahead=not a.no_launch_ahead,
+                      belief_predictor=a.belief, cached_views=a.cached_views, distractor=a.distractor)
 
     def barrier():
         torch.cuda.synchronize()
@@ -137,32 +344,45 @@ def main():
     dt = time.perf_counter() - t0
     # outside the timed region: the run must have produced numbers (a kernel race shows up as NaN losses / memories, not a crash)
     import math
-    ro = wl.rollouts
-    finite = all(math.isfinite(float(x)) for x in last) and bool(torch.isfinite(ro.value_preds).all()) and \
-        bool(torch.isfinite(ro.em_vln_dialog.memory).all()) and bool(torch.isfinite(ro.em.memory).all())
-    assert finite, f"non-finite results after the timed cycles: losses {last}"
+    assert all(math.isfinite(float(x)) for x in last) and wl.finite(), f"non-finite results after the timed cycles: losses {last}"
     if world > 1:
         tt = torch.tensor([dt], device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     env_steps = a.steps * a.envs * a.rollout * world
+    if a.config == "gru":
+        workload = "AudioNavBaselinePolicy (AudioCNN + VisualCNN + GRU-512) rollout + PPO update 4x2 (BASELINE configs[1])"
+    else:
+        workload = (f"savi_interactive_{'1st' if a.stage == 1 else '2nd'}_stage{' (distractor)' if a.distractor else ''}: "
+                    "pi_g+pi_l+pi_q rollout (CLIP ViT-B/32 text frozen) + pi_q PPO update 2x2")
     out = {
-        "metric": "env-steps/sec (encoder+GRU+PPO update) at NUM_ENVS=64", "value": round(env_steps / dt, 2),
+        "metric": f"env-steps/sec (encoder+GRU+PPO update) at NUM_ENVS={a.envs}", "value": round(env_steps / dt, 2),
         "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.precision, "data": "synthetic",
-        "config": {"workload": f"savi_interactive_{'1st' if a.stage == 1 else '2nd'}_stage: pi_g+pi_l+pi_q rollout (CLIP ViT-B/32 text "
-                               "frozen) + pi_q PPO update 2x2", "num_envs_per_gpu": a.envs, "rollout_steps": a.rollout,
+        "config": {"workload": workload, "num_envs_per_gpu": a.envs, "rollout_steps": a.rollout,
                    "spectrogram": a.spectrogram, "parallelism": f"env-shard x{world}, RCCL grad all-reduce",
-                   "rollout_fraction_of_time": round(t_roll / dt, 3), "belief_predictor": bool(a.belief)},
+                   "rollout_fraction_of_time": round(t_roll / dt, 3), "belief_predictor": bool(a.belief),
+                   "step_views": "cached" if a.cached_views else "fresh", "encoder_sharing": not a.no_share,
+                   "launch_ahead": not a.no_launch_ahead},
     }
     if rank == 0:
+        interactive = a.config == "interactive"
         if not a.no_roofline:
-            rl = kernel_roofline(a.precision)
+            situ = text_tower_in_situ(wl) if (interactive and a.precision == "bf16") else None
+            rl = kernel_roofline(a.precision, situ)
             if rl is not None:
                 out["roofline"] = rl
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline((H, W))
+        if world == 1 and interactive and not a.no_extras and a.precision == "bf16" and not a.belief:
+            out["bf16_vs_fp32"], out["fp32_parity_mode"] = bf16_vs_fp32(a, H, W, wl)
+            del wl
+            torch.cuda.empty_cache()
+            out["integration"] = integration_records(a, H, W)
+            import avlen_amd.harness as hz
+            if hasattr(hz, "GruWorkload"):
+                out["gru_baseline"] = gru_record(a)
+        if world == 1 and not a.no_cpu_baseline and interactive:
+            out["cpu_baseline"] = cpu_baseline((H, W), a.envs)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()                      # rank 0 may still be timing the roofline kernel: leave together

@@ -13,7 +13,7 @@ import restate as R
 class Storage:
     """RolloutStorage restated (rollout_storage.py:21-297) with ONE copy of each external memory."""
 
-    def __init__(self, T, N, obs0, em_size, em_cap, dim_goal=276, dim_option=308, vln_size=3, dim_dialog=256):
+    def __init__(self, T, N, obs0, em_size, em_cap, dim_goal=276, dim_option=308, vln_size=3, dim_dialog=256, dim_vln=276):
         self.T, self.N, self.step = T, N, 0
         self.obs = {k: torch.zeros(T + 1, N, *v.shape[1:]) for k, v in obs0.items()}
         for k, v in obs0.items():
@@ -34,7 +34,7 @@ class Storage:
         self.em_vln_masks = z(T + 1, N, vln_size)
         self.em = R.ExtMemoryRing(N, em_size, em_cap, dim_goal)
         self.em_option = R.ExtMemoryRing(N, em_size, em_cap, dim_option)
-        self.em_vln = R.ExtMemoryRing(N, vln_size, vln_size, dim_goal)
+        self.em_vln = R.ExtMemoryRing(N, vln_size, vln_size, dim_vln)
         self.em_vln_dialog = R.ExtMemoryRing(N, vln_size, vln_size, dim_dialog)
 
     def insert(self, obs, actions, actions_option, logp, values, rewards, not_done, not_done_vln,
@@ -104,8 +104,8 @@ class OptionAgent:
     """pi_q + its PPO optimiser state (ppo.py:31-303), restated."""
 
     def __init__(self, sd, pretraining, lr=2.5e-4, eps=1e-5, clip=0.2, epochs=2, mini_batches=2,
-                 value_coef=0.5, entropy_coef=0.05, max_grad_norm=0.2, unct_coef=0.5):
-        self.sd, self.pretraining = sd, pretraining
+                 value_coef=0.5, entropy_coef=0.05, max_grad_norm=0.2, unct_coef=0.5, use_category_input=False):
+        self.sd, self.pretraining, self.use_category_input = sd, pretraining, use_category_input
         self.lr, self.eps, self.clip, self.epochs, self.mb = lr, eps, clip, epochs, mini_batches
         self.vc, self.ec, self.gn, self.uc = value_coef, entropy_coef, max_grad_norm, unct_coef
         # only parameters that receive a gradient get Adam state (grad None -> skipped by torch.optim)
@@ -116,7 +116,7 @@ class OptionAgent:
 
     def forward(self, obs, prev_actions, em, em_masks, query_state, last_query_info):
         return R.option_net(self.sd, obs, prev_actions, em, em_masks, query_state, last_query_info,
-                            pretraining=self.pretraining)
+                            pretraining=self.pretraining, use_category_input=self.use_category_input)
 
     def act(self, obs, prev_actions, em, em_masks, qs, lqi, generator=None):
         with torch.no_grad():

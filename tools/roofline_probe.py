@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from avlen_amd import _lib as L
 from avlen_amd.engine import P
 
+GEMM_KERNEL_NAME = "g2_kernel<64,128,2,4,2,512>"
 GEMM = dict(M=2464, N=2048, K=512, epilogue="bf16", act=2)
 CONV = dict(B=384, W=64, C=16)
 
@@ -65,6 +66,57 @@ def clip_call_sites():
         s = measure(lambda: make_gemm(M, N, K, ep, act))
         out[name] = {"M": M, "N": N, "K": K, "us_per_launch": round(s * 1e6, 2), "TFLOPs": round(2.0 * M * N * K / s / 1e12, 1)}
     return out
+
+
+# per-conv table of one visual tower at the rollout batch (6 towers x 64 images = 384 images per launch):
+# (name, H_in, Cin, Cout, K, stride, launches per tower); M = B*OH*OW rows, N = Cout, K = k*k*Cin
+TOWER_CONVS = [("conv1 7x7 s2 (Cin 3->8 padded)", 64, 8, 16, 7, 1, 1), ("layer1 3x3", 64, 16, 16, 3, 1, 4),
+               ("layer2.0.conv1 3x3 s2", 64, 16, 32, 3, 2, 1), ("layer2 3x3", 32, 32, 32, 3, 1, 3),
+               ("layer2.0.down 1x1 s2", 64, 16, 32, 1, 2, 1),
+               ("layer3.0.conv1 3x3 s2", 32, 32, 64, 3, 2, 1), ("layer3 3x3", 16, 64, 64, 3, 1, 3),
+               ("layer4.0.conv1 3x3 s2", 16, 64, 128, 3, 2, 1), ("layer4 3x3", 8, 128, 128, 3, 1, 3)]
+
+
+def make_tower_conv(B, H, Cin, Cout, K, stride):
+    x16 = torch.randn(B, H, H, Cin, device="cuda").bfloat16()
+    w = torch.randn(Cout, Cin, K, K, device="cuda") / math.sqrt(Cin * K * K)
+    wp16 = torch.empty(Cout, K, K, Cin, device="cuda", dtype=torch.bfloat16)
+    L.call("avlen_pack_conv_weight_bf16", P(w), P(wp16), Cout, Cin, K, K, Cin, L.stream())
+    OH = (H + 2 * (K // 2) - K) // stride + 1
+    y = torch.empty(B, OH, OH, Cout, device="cuda", dtype=torch.bfloat16)
+    stats = torch.zeros(B, 2, Cout, device="cuda")
+    direct = stride == 1 and (Cin, Cout, H, K) in ((16, 16, 64, 3), (32, 32, 32, 3), (8, 16, 64, 7))
+    if direct:
+        fn = lambda: L.call("avlen_conv_direct_bf16", P(x16), P(wp16), P(y), P(stats), B, H, Cin, Cout, K, L.stream())
+        ws = None
+    else:
+        nb = L.lib.avlen_gemm_bf16_workspace_bytes(B * OH * OH, Cout)
+        ws = torch.empty(max(nb, 16), dtype=torch.uint8, device="cuda")
+        fn = lambda: L.call("avlen_conv2d_nhwc_bf16", P(x16), P(wp16), None, None, None, P(y), P(stats), B, H, H, Cin, Cout, K, K,
+                            stride, K // 2, 0, P(ws), nb, L.stream())
+    return fn, (x16, wp16, y, stats, ws), OH, ("dconv3x3_kernel" if direct else "g2_kernel<CONV>")
+
+
+def tower_conv_table(B=384):
+    """Every conv shape of a visual tower as a standalone launch at the rollout batch: M, N, K, us, TFLOP/s, fraction of the bf16
+    MFMA peak, and the HBM rate of its algorithmic bytes (bf16 activation in + out once).  Layers 3-4 run FUSED in
+    tower_tail_kernel in the product (one launch, activations in LDS); their standalone rows are the unfused comparison."""
+    rows = []
+    for name, H, Cin, Cout, K, stride, count in TOWER_CONVS:
+        holder = {}
+        def mk():
+            fn, keep, OH, kern = make_tower_conv(B, H, Cin, Cout, K, stride)
+            holder.update(OH=OH, kern=kern)
+            return fn, keep
+        s = measure(mk, iters=20)
+        OH = holder["OH"]
+        M, N, Kd = B * OH * OH, Cout, K * K * Cin
+        fl = 2.0 * M * N * Kd
+        by = B * H * H * Cin * 2 + M * N * 2
+        rows.append({"conv": name, "kernel": holder["kern"], "launches_per_tower": count, "M": M, "N": N, "K": Kd,
+                     "us": round(s * 1e6, 2), "TFLOPs": round(fl / s / 1e12, 1), "frac_mfma": round(fl / s / 2.5e15, 4),
+                     "GBps": round(by / s / 1e9, 1), "frac_hbm": round(by / s / 8e12, 4)})
+    return rows
 
 
 def measure(make, iters=40):
