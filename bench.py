@@ -202,6 +202,8 @@ def bf16_vs_fp32(a, H, W, wl16):
     from avlen_amd.harness import Workload
     wl32 = Workload(a.envs, a.rollout, spectrogram=(H, W, 2), precision="fp32", pretraining=(a.stage == 1), seed=0,
                     use_graphs=not a.no_graphs, share_encoders=False, launch_ahead=False, distractor=a.distractor)
+    # the timed cycles have trained pi_q: both modes must hold the SAME weights
+    wl32.pi_q.load_state_dict(wl16.pi_q.state_dict())
     T = a.rollout
     mv = {"q_value": 0.0, "q_prob": 0.0, "g_prob": 0.0, "l_prob": 0.0, "g_value": 0.0, "l_value": 0.0}
     flips = {"q": 0, "g": 0, "l": 0}
