@@ -174,6 +174,12 @@ SIGNATURES = {
                                        f32, f32, f32, f32, vp, vp, i32, vp]),
     "avlen_rl_mask_norm": (i32, [vp, i32, vp, vp]),
     "avlen_gae_scan": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, vp]),
+    "avlen_discounted_returns": (i32, [vp, vp, vp, vp, i32, i32, f32, vp]),
+    "avlen_baseline_train_workspace_bytes": (sz, [C.POINTER(Cnn3), C.POINTER(Cnn3), C.POINTER(Gru), i32, i32, i32, i32, i32, i32]),
+    "avlen_baseline_train_fwd": (i32, [C.POINTER(Cnn3), C.POINTER(Cnn3), C.POINTER(Gru), vp, vp, vp, vp, i32, vp, vp, vp, vp,
+                                       i32, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "avlen_baseline_train_bwd": (i32, [C.POINTER(Cnn3), C.POINTER(Cnn3), C.POINTER(Gru), C.POINTER(Cnn3), C.POINTER(Cnn3),
+                                       C.POINTER(Gru), vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     "avlen_grad_sumsq": (i32, [vp, sz, vp, vp]),
     "avlen_adam_step": (i32, [vp, vp, vp, vp, sz, f32, f32, f32, f32, i32, f32, vp, vp]),
     "avlen_extmem_insert": (i32, [vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),

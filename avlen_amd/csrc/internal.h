@@ -4,6 +4,18 @@
 #include <stddef.h>
 #include "../../include/avlen_hip.h"
 
+// per-call context of the module-level helpers (modules.hip): stream, arithmetic mode, split-K scratch, optional ragged-batch
+// descriptors, optional operand scratch of the large-M bf16 training products
+struct avlen_ctx { hipStream_t st; int prec; void* gws; size_t gws_bytes; const int* live = nullptr; const int* seg = nullptr;
+                   void* xs = nullptr; size_t xs_bytes = 0; };
+// Y = act(X W^T + b) + res;  dX = dY W (+ add);  G.w += dY^T X;  out[col] += sum_rows dY   (training products, modules.hip)
+int avlen_i_linear(const avlen_ctx& c, const avlen_linear& L, const float* X, int ldx, float* Y, int ldy, int M, int act,
+                   const float* res, int ldr);
+int avlen_i_linear_dx(const avlen_ctx& c, const avlen_linear& L, const float* dY, int ldy, float* dX, int ldx, int M,
+                      const float* add, int ldadd);
+int avlen_i_linear_dw(const avlen_ctx& c, const avlen_linear& G, const float* dY, int ldy, const float* X, int ldx, int M);
+int avlen_i_colsum_acc(const avlen_ctx& c, const float* dY, int ld, float* out, int rows, int N);
+
 int avlen_groupnorm_nhwc_ws(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
                             int B, int HW, int C, int G, int relu, float eps, float* part, hipStream_t stream);
 extern "C" size_t avlen_groupnorm_workspace_bytes(int B, int C);

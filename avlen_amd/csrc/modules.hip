@@ -22,8 +22,7 @@ namespace {
 typedef __bf16 bf16;
 constexpr size_t GEMM_SCRATCH = 96u << 20;       // split-K / accumulate slabs shared by one module call
 
-struct Ctx { hipStream_t st; int prec; void* gws; size_t gws_bytes; const int* live = nullptr; const int* seg = nullptr;
-             void* xs = nullptr; size_t xs_bytes = 0; };      // xs: operand scratch of the large-M bf16 products below
+typedef avlen_ctx Ctx;      // internal.h (xs: operand scratch of the large-M bf16 products below)
 
 // ---- large-M products of the TRAINING path (2nd stage: 722 k token rows per minibatch) ----
 // The training forward/backward keeps fp32 activations (LayerNorm / residual / softmax math and the saved tensors of the
@@ -166,6 +165,18 @@ int relu_bwd(const Ctx& c, float* dx, const float* y, long n) {
   hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.st, dx, y, n);
   return avlen_launch_status();
 }
+
+}  // namespace
+// shared with train_gru.hip (internal.h)
+int avlen_i_linear(const avlen_ctx& c, const avlen_linear& L, const float* X, int ldx, float* Y, int ldy, int M, int act,
+                   const float* res, int ldr) { return linear(c, L, X, ldx, Y, ldy, M, act, res, ldr); }
+int avlen_i_linear_dx(const avlen_ctx& c, const avlen_linear& L, const float* dY, int ldy, float* dX, int ldx, int M,
+                      const float* add, int ldadd) { return linear_dx(c, L, dY, ldy, dX, ldx, M, add, ldadd); }
+int avlen_i_linear_dw(const avlen_ctx& c, const avlen_linear& G, const float* dY, int ldy, const float* X, int ldx, int M) {
+  return linear_dw(c, G, dY, ldy, X, ldx, M);
+}
+int avlen_i_colsum_acc(const avlen_ctx& c, const float* dY, int ld, float* out, int rows, int N) { return colsum_acc(c, dY, ld, out, rows, N); }
+namespace {
 
 // SMT fusion input.  Row (b, s): src = s < M ? memory[s, b, :] : x[b, :]
 //   XF[row] = [ src[0:pc] | pose_encoder(format(relative_pose(x_pose[b] -> src_pose))) (16) | src[pc+4:F] ]

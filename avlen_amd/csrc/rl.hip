@@ -251,6 +251,19 @@ __global__ void gae_kernel(const float* __restrict__ rewards, float* __restrict_
   }
 }
 
+// use_gae=False branch (rollout_storage.py:406-412): returns[T] = next_value; returns[t] = returns[t+1] * gamma * masks[t+1] + r[t]
+__global__ void returns_kernel(const float* __restrict__ rewards, const float* __restrict__ masks, const float* __restrict__ next_value,
+                               float* __restrict__ returns, int T, int N, float gamma) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float r = next_value[n];
+  returns[(long)T * N + n] = r;
+  for (int t = T - 1; t >= 0; t--) {
+    r = r * gamma * masks[(long)(t + 1) * N + n] + rewards[(long)t * N + n];
+    returns[(long)t * N + n] = r;
+  }
+}
+
 __global__ void sumsq_kernel(const float* __restrict__ g, size_t n, double* __restrict__ out) {
   __shared__ float sh[16];
   float s = 0.f;
@@ -373,6 +386,13 @@ extern "C" int avlen_gae_scan(const float* rewards, float* values, const float* 
   if (T_used <= 0 || N <= 0) return AVLEN_ERR_ARG;
   hipLaunchKernelGGL(gae_kernel, dim3(ceil_div(N, 64)), dim3(64), 0, stream, rewards, values, masks, next_value, returns,
                      advantages, T_used, N, gamma, tau);
+  return avlen_launch_status();
+}
+
+extern "C" int avlen_discounted_returns(const float* rewards, const float* masks, const float* next_value, float* returns, int T_used,
+                                        int N, float gamma, hipStream_t stream) {
+  if (T_used <= 0 || N <= 0) return AVLEN_ERR_ARG;
+  hipLaunchKernelGGL(returns_kernel, dim3(ceil_div(N, 64)), dim3(64), 0, stream, rewards, masks, next_value, returns, T_used, N, gamma);
   return avlen_launch_status();
 }
 

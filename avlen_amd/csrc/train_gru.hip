@@ -1,0 +1,388 @@
+// Training path of the GRU baseline policy (BASELINE configs[1]): forward with saved activations and backward of
+//   AudioCNN / VisualCNN (audio_cnn.py:62-94,136-151; visual_cnn.py:82-107,165-190): conv+ReLU, conv+ReLU, conv, flatten, Linear+ReLU
+//   RNNStateEncoder.seq_forward (av_nav/models/rnn_state_encoder.py:92-143): hidden * mask before every step, 1-layer GRU
+//   AudioNavBaselineNet.forward (savi/ppo/policy.py:451-477): x = [audio | visual | category]
+// driven by avlen_amd/av_nav.py:PPO.update, which mirrors ss_baselines/av_nav/ppo/ppo.py:60-151 (evaluate_actions ->
+// clipped-surrogate / clipped-value / entropy loss -> backward -> clip-norm -> Adam).  The heads + loss backward is the same
+// kernel pi_q uses (avlen_ppo_loss_heads_bwd, rl.hip) and runs between the two entry points below.
+//
+// Convolution backward: the weight gradient is dY^T * im2col(X) and the data gradient col2im(dY * W) -- both products run on the
+// GEMM kernels of the training path (fp32-staged MFMA, or bf16 glds MFMA from 16384 rows on in bf16 mode); im2col writes the
+// [kh][kw][c] K-order of the packed weights (a (kw, c) run is contiguous in NHWC, so rows are copied in 16-byte pieces) and
+// col2im is a gather (no atomics, deterministic) that also applies the ReLU mask of the layer below.
+// Gradients are produced in the PACKED layouts the forward uses ([O][KH][KW][I]; fc columns in NHWC flatten order) and
+// re-laid into the canonical parameter layouts (OIHW; (O, C*H*W)) of the flat gradient buffer Adam steps over.
+#include "common.h"
+#include "../../include/avlen_hip.h"
+#include "internal.h"
+#include <math.h>
+
+#define TRY(x) do { int _rc = (x); if (_rc != AVLEN_OK) return _rc; } while (0)
+
+namespace {
+
+constexpr size_t GEMM_SCRATCH = 96u << 20;
+inline size_t zmax(size_t a, size_t b) { return a > b ? a : b; }
+
+struct Dims { int h[4], w[4], c[4]; };        // [0] = input, [i+1] = output of conv i
+Dims cnn_dims(const avlen_cnn3* n, int H, int W) {
+  Dims d; d.h[0] = H; d.w[0] = W; d.c[0] = n->conv[0].cin;
+  for (int i = 0; i < 3; i++) {
+    d.h[i + 1] = (d.h[i] - n->conv[i].kh) / n->conv[i].stride + 1;
+    d.w[i + 1] = (d.w[i] - n->conv[i].kw) / n->conv[i].stride + 1;
+    d.c[i + 1] = n->conv[i].cout;
+  }
+  return d;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// im2col / col2im (NHWC, no padding, square stride)
+// ---------------------------------------------------------------------------------------------------------------
+// cols[m][kh][kw][c] = X[b][oh*s + kh][ow*s + kw][c],  m = (b*OH + oh)*OW + ow.  One thread per V floats of a (kw, c) run.
+template <int V>
+__global__ void im2col_kernel(const float* __restrict__ X, float* __restrict__ cols, long total, int H, int W, int C, int OH, int OW,
+                              int KH, int KW, int s) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int run = KW * C / V;                    // V-float pieces per (m, kh)
+  const int j = (int)(i % run);
+  long r = i / run;
+  const int kh = (int)(r % KH); r /= KH;         // r = m
+  const int ow = (int)(r % OW); long q = r / OW;
+  const int oh = (int)(q % OH); const long b = q / OH;
+  const float* src = X + (((b * H + (long)oh * s + kh) * W + (long)ow * s) * C) + (long)j * V;
+  float* dst = cols + (r * KH + kh) * (long)(KW * C) + (long)j * V;
+  if (V == 4) *(float4*)dst = *(const float4*)src;
+  else dst[0] = src[0];
+}
+int im2col(hipStream_t st, const float* X, float* cols, long B, int H, int W, int C, int OH, int OW, int KH, int KW, int s) {
+  const bool v4 = (KW * C) % 4 == 0 && C % 4 == 0 && (((uintptr_t)X | (uintptr_t)cols) & 15) == 0;
+  const long total = B * OH * OW * KH * (long)(KW * C / (v4 ? 4 : 1));
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+  if (v4) hipLaunchKernelGGL(im2col_kernel<4>, dim3(blocks), dim3(256), 0, st, X, cols, total, H, W, C, OH, OW, KH, KW, s);
+  else hipLaunchKernelGGL(im2col_kernel<1>, dim3(blocks), dim3(256), 0, st, X, cols, total, H, W, C, OH, OW, KH, KW, s);
+  return avlen_launch_status();
+}
+
+// dX[b][h][w][c] = relu'(act) * sum over taps (kh, kw) with (h - kh) % s == 0, (w - kw) % s == 0, in range, of
+// dcols[(b, (h-kh)/s, (w-kw)/s)][kh][kw][c].  act = the (post-ReLU) activation that was this conv's input.
+template <int V>
+__global__ void col2im_relu_kernel(const float* __restrict__ dcols, const float* __restrict__ act, float* __restrict__ dX, long total,
+                                   int H, int W, int C, int OH, int OW, int KH, int KW, int s) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int cv = C / V;
+  const int c = (int)(i % cv) * V;
+  long r = i / cv;
+  const int w = (int)(r % W); r /= W;
+  const int h = (int)(r % H); const long b = r / H;
+  float acc[V];
+#pragma unroll
+  for (int v = 0; v < V; v++) acc[v] = 0.f;
+  const long K = (long)KH * KW * C;
+  for (int kh = h % s; kh < KH; kh += s) {
+    const int oh = (h - kh) / s;
+    if (h - kh < 0) break;
+    if (oh >= OH) continue;
+    for (int kw = w % s; kw < KW; kw += s) {
+      const int ow = (w - kw) / s;
+      if (w - kw < 0) break;
+      if (ow >= OW) continue;
+      const float* p = dcols + ((b * OH + oh) * OW + ow) * K + ((long)kh * KW + kw) * C + c;
+      if (V == 4) { const float4 t = *(const float4*)p; acc[0] += t.x; acc[1 % V] += t.y; acc[2 % V] += t.z; acc[3 % V] += t.w; }
+      else acc[0] += p[0];
+    }
+  }
+  const long o = ((b * H + h) * W + w) * C + c;
+#pragma unroll
+  for (int v = 0; v < V; v++) dX[o + v] = act[o + v] > 0.f ? acc[v] : 0.f;
+}
+int col2im_relu(hipStream_t st, const float* dcols, const float* act, float* dX, long B, int H, int W, int C, int OH, int OW, int KH,
+                int KW, int s) {
+  const bool v4 = C % 4 == 0;
+  const long total = B * H * W * (C / (v4 ? 4 : 1));
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+  if (v4) hipLaunchKernelGGL(col2im_relu_kernel<4>, dim3(blocks), dim3(256), 0, st, dcols, act, dX, total, H, W, C, OH, OW, KH, KW, s);
+  else hipLaunchKernelGGL(col2im_relu_kernel<1>, dim3(blocks), dim3(256), 0, st, dcols, act, dX, total, H, W, C, OH, OW, KH, KW, s);
+  return avlen_launch_status();
+}
+
+// dst[i] = (y[i] > 0) ? src[i] : 0 over rows of different strides (the Linear+ReLU output lives inside the GRU input rows)
+__global__ void relu_mask_rows_kernel(const float* __restrict__ src, int lds, const float* __restrict__ y, int ldy, float* __restrict__ dst,
+                                      int ldd, long rows, int cols) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  const long r = i / cols; const int c = (int)(i % cols);
+  dst[r * ldd + c] = y[r * ldy + c] > 0.f ? src[r * lds + c] : 0.f;
+}
+
+// packed gradient layouts -> canonical parameter layouts (accumulating)
+__global__ void unpack_conv_grad_kernel(const float* __restrict__ gp, float* __restrict__ g, int O, int I, int KH, int KW) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;          // canonical index ((o*I + c)*KH + kh)*KW + kw
+  if (i >= (long)O * I * KH * KW) return;
+  const int kw = (int)(i % KW); long r = i / KW;
+  const int kh = (int)(r % KH); r /= KH;
+  const int c = (int)(r % I); const int o = (int)(r / I);
+  g[i] += gp[(((long)o * KH + kh) * KW + kw) * I + c];
+}
+__global__ void unpack_fc_grad_kernel(const float* __restrict__ gp, float* __restrict__ g, int O, int C, int HW) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;          // canonical index (o*C + c)*HW + p
+  if (i >= (long)O * C * HW) return;
+  const int p = (int)(i % HW); long r = i / HW;
+  const int c = (int)(r % C); const long o = r / C;
+  g[i] += gp[(o * HW + p) * C + c];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// GRU (r | z | n gate order of nn.GRU): h' = (1 - z) n + z hm,  n = tanh(gi_n + r * gh_n),  hm = h_prev * mask
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void gru_mask_kernel(const float* __restrict__ h, const float* __restrict__ mask, float* __restrict__ hm, int N, int H) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (long)N * H) hm[i] = h[i] * mask[i / H];
+}
+__global__ void gru_gate_kernel(const float* __restrict__ gi, const float* __restrict__ gh, const float* __restrict__ hm,
+                                float* __restrict__ out, int N, int H) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)N * H) return;
+  const int n = (int)(i / H), j = (int)(i % H);
+  const float* a = gi + (long)n * 3 * H; const float* b = gh + (long)n * 3 * H;
+  const float r = 1.f / (1.f + expf(-(a[j] + b[j])));
+  const float z = 1.f / (1.f + expf(-(a[H + j] + b[H + j])));
+  const float nn = tanhf(a[2 * H + j] + r * b[2 * H + j]);
+  out[i] = (1.f - z) * nn + z * hm[i];
+}
+// dh = d_out[t] + carry * mask_next (carry = gradient w.r.t. hm of step t+1; null at the last step)
+// -> dGI[t], dGH[t], dhm_direct = dh * z
+__global__ void gru_gate_bwd_kernel(const float* __restrict__ gi, const float* __restrict__ gh, const float* __restrict__ hm,
+                                    const float* __restrict__ d_out, const float* __restrict__ carry, const float* __restrict__ mask_next,
+                                    float* __restrict__ dgi, float* __restrict__ dgh, float* __restrict__ dhm, int N, int H) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)N * H) return;
+  const int n = (int)(i / H), j = (int)(i % H);
+  const long o = (long)n * 3 * H;
+  const float* a = gi + o; const float* b = gh + o;
+  const float r = 1.f / (1.f + expf(-(a[j] + b[j])));
+  const float z = 1.f / (1.f + expf(-(a[H + j] + b[H + j])));
+  const float ghn = b[2 * H + j];
+  const float nn = tanhf(a[2 * H + j] + r * ghn);
+  float dh = d_out[i];
+  if (carry) dh += carry[i] * mask_next[n];
+  const float dn = dh * (1.f - z);
+  const float dz = dh * (hm[i] - nn);
+  const float dpn = dn * (1.f - nn * nn);
+  const float dpr = dpn * ghn * r * (1.f - r);
+  const float dpz = dz * z * (1.f - z);
+  dgi[o + j] = dpr; dgi[o + H + j] = dpz; dgi[o + 2 * H + j] = dpn;
+  dgh[o + j] = dpr; dgh[o + H + j] = dpz; dgh[o + 2 * H + j] = dpn * r;
+  dhm[i] = dh * z;
+}
+
+__global__ void rgbd_concat_kernel(const float* __restrict__ rgb, const float* __restrict__ depth, float* __restrict__ y, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;          // pixel index
+  if (i >= n) return;
+  float4 o; o.x = rgb[i * 3] * (1.f / 255.f); o.y = rgb[i * 3 + 1] * (1.f / 255.f); o.z = rgb[i * 3 + 2] * (1.f / 255.f); o.w = depth[i];
+  ((float4*)y)[i] = o;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// workspace layout (identical in forward and backward)
+// ---------------------------------------------------------------------------------------------------------------
+struct CnnWs { float* a[3]; };
+struct Ws {
+  float *rgbd, *X, *GI, *GH, *HM, *hc;
+  CnnWs aud, vis;
+  // backward scratch
+  float *dX, *dGI, *dGH, *dh[2], *dpre, *da, *db, *cols, *gpack;
+  void* gws; void* xs; size_t xs_bytes;
+};
+size_t cnn_cols_max(const avlen_cnn3* n, const Dims& d, long R) {
+  size_t mx = 0;
+  for (int i = 0; i < 3; i++)
+    mx = zmax(mx, (size_t)R * d.h[i + 1] * d.w[i + 1] * n->conv[i].kh * n->conv[i].kw * n->conv[i].cin);
+  return mx;
+}
+size_t cnn_act_max(const Dims& d, long R) {
+  size_t mx = 0;
+  for (int i = 1; i <= 3; i++) mx = zmax(mx, (size_t)R * d.h[i] * d.w[i] * d.c[i]);
+  return mx;
+}
+size_t cnn_gpack_max(const avlen_cnn3* n) {
+  size_t mx = (size_t)n->fc.out_f * n->fc.in_f;
+  for (int i = 0; i < 3; i++) mx = zmax(mx, (size_t)n->conv[i].cout * n->conv[i].kh * n->conv[i].kw * n->conv[i].cin);
+  return mx;
+}
+bool layout(WsBump& w, Ws& s, const avlen_cnn3* au, const avlen_cnn3* vi, const avlen_gru* g, int T, int N, int Ha, int Wa, int S,
+            int prec) {
+  const long R = (long)T * N;
+  const int H = g->hidden, F = g->in_f;
+  const Dims da = cnn_dims(au, Ha, Wa), dv = cnn_dims(vi, S, S);
+  s.rgbd = w.take<float>((size_t)R * S * S * 4);
+  s.X = w.take<float>((size_t)R * F);
+  s.GI = w.take<float>((size_t)R * 3 * H); s.GH = w.take<float>((size_t)R * 3 * H); s.HM = w.take<float>((size_t)R * H);
+  s.hc = w.take<float>((size_t)N * H);
+  for (int i = 0; i < 3; i++) {
+    s.aud.a[i] = w.take<float>((size_t)R * da.h[i + 1] * da.w[i + 1] * da.c[i + 1]);
+    s.vis.a[i] = w.take<float>((size_t)R * dv.h[i + 1] * dv.w[i + 1] * dv.c[i + 1]);
+  }
+  s.dX = w.take<float>((size_t)R * F);
+  s.dGI = w.take<float>((size_t)R * 3 * H); s.dGH = w.take<float>((size_t)R * 3 * H);
+  s.dh[0] = w.take<float>((size_t)N * H); s.dh[1] = w.take<float>((size_t)N * H);
+  s.dpre = w.take<float>((size_t)R * zmax(au->fc.out_f, vi->fc.out_f));
+  const size_t am = zmax(cnn_act_max(da, R), cnn_act_max(dv, R));
+  s.da = w.take<float>(am); s.db = w.take<float>(am);
+  const size_t cm = zmax(cnn_cols_max(au, da, R), cnn_cols_max(vi, dv, R));
+  s.cols = w.take<float>(cm);
+  s.gpack = w.take<float>(zmax(cnn_gpack_max(au), cnn_gpack_max(vi)));
+  s.gws = w.take<char>(GEMM_SCRATCH);
+  // operand scratch of the large-M bf16 products (modules.hip: cast / transposed-cast copies of both operands): the largest
+  // product is a conv's weight gradient, dY^T (cout x M) and cols^T (K x M)
+  s.xs = nullptr; s.xs_bytes = 0;
+  if (prec == AVLEN_PREC_BF16) {
+    s.xs_bytes = (cm + am + (size_t)64 * 1024 * 1024) * 2 + (1u << 20);
+    s.xs = w.take<char>(s.xs_bytes);
+  }
+  return w.ok();
+}
+
+int cnn_fwd(const avlen_ctx& c, const avlen_cnn3* n, const float* x, long R, int H, int W, CnnWs& a, float* out, int ld_out) {
+  const Dims d = cnn_dims(n, H, W);
+  if (d.h[3] <= 0 || d.w[3] <= 0 || n->fc.in_f != d.h[3] * d.w[3] * d.c[3]) return AVLEN_ERR_ARG;
+  const float* cur = x;
+  for (int i = 0; i < 3; i++) {
+    const avlen_conv& k = n->conv[i];
+    TRY(avlen_conv2d_nhwc(cur, k.w, k.b, nullptr, a.a[i], (int)R, d.h[i], d.w[i], k.cin, k.cout, k.kh, k.kw, k.stride, 0,
+                          i < 2 ? AVLEN_ACT_RELU : AVLEN_ACT_NONE, c.prec, c.st));
+    cur = a.a[i];
+  }
+  return avlen_i_linear(c, n->fc, cur, n->fc.in_f, out, ld_out, (int)R, AVLEN_ACT_RELU, nullptr, 0);
+}
+
+// d_out: gradient w.r.t. the CNN's (post-ReLU) output, rows `ld` apart inside dX; y: that output inside X
+int cnn_bwd(const avlen_ctx& c, Ws& s, const avlen_cnn3* n, const avlen_cnn3* g, const float* x, long R, int H, int W, CnnWs& a,
+            const float* d_out, const float* y, int ld) {
+  const Dims d = cnn_dims(n, H, W);
+  hipStream_t st = c.st;
+  const int O = n->fc.out_f, K = n->fc.in_f;
+  // fc + ReLU
+  {
+    const long tot = R * O;
+    hipLaunchKernelGGL(relu_mask_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_out, ld, y, ld, s.dpre, O, R, O);
+    TRY(avlen_zero_bytes(s.gpack, (size_t)O * K * 4, st));
+    avlen_linear G = n->fc; G.w = s.gpack; G.b = nullptr;
+    TRY(avlen_i_linear_dw(c, G, s.dpre, O, a.a[2], K, (int)R));
+    const long nw = (long)O * K;
+    hipLaunchKernelGGL(unpack_fc_grad_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, s.gpack, g->fc.w, O, d.c[3],
+                       d.h[3] * d.w[3]);
+    TRY(avlen_i_colsum_acc(c, s.dpre, O, g->fc.b, (int)R, O));
+    TRY(avlen_i_linear_dx(c, n->fc, s.dpre, O, s.da, K, (int)R, nullptr, 0));           // d a[2]  (conv 2 has no ReLU)
+  }
+  float* dy = s.da; float* other = s.db;
+  for (int i = 2; i >= 0; i--) {
+    const avlen_conv& k = n->conv[i];
+    const long M = R * d.h[i + 1] * d.w[i + 1];
+    const int Kc = k.kh * k.kw * k.cin;
+    const float* in = i == 0 ? x : a.a[i - 1];
+    if (M > 0x7fffffffL) return AVLEN_ERR_ARG;
+    // weight / bias gradient
+    TRY(im2col(st, in, s.cols, R, d.h[i], d.w[i], k.cin, d.h[i + 1], d.w[i + 1], k.kh, k.kw, k.stride));
+    TRY(avlen_zero_bytes(s.gpack, (size_t)k.cout * Kc * 4, st));
+    avlen_linear G{s.gpack, nullptr, k.cout, Kc, nullptr, 0};
+    TRY(avlen_i_linear_dw(c, G, dy, k.cout, s.cols, Kc, (int)M));
+    const long nw = (long)k.cout * Kc;
+    hipLaunchKernelGGL(unpack_conv_grad_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, s.gpack, g->conv[i].w, k.cout,
+                       k.cin, k.kh, k.kw);
+    TRY(avlen_i_colsum_acc(c, dy, k.cout, g->conv[i].b, (int)M, k.cout));
+    if (i == 0) break;
+    // data gradient: dcols = dY * Wp, gathered back onto the input pixels, masked by the ReLU of the layer below
+    avlen_linear Wl{k.w, nullptr, k.cout, Kc, nullptr, 0};
+    TRY(avlen_i_linear_dx(c, Wl, dy, k.cout, s.cols, Kc, (int)M, nullptr, 0));
+    TRY(col2im_relu(st, s.cols, a.a[i - 1], other, R, d.h[i], d.w[i], k.cin, d.h[i + 1], d.w[i + 1], k.kh, k.kw, k.stride));
+    float* t = dy; dy = other; other = t;
+  }
+  return avlen_launch_status();
+}
+
+}  // namespace
+
+extern "C" size_t avlen_baseline_train_workspace_bytes(const avlen_cnn3* audio, const avlen_cnn3* visual, const avlen_gru* gru,
+                                                       int T, int N, int Ha, int Wa, int S, int prec) {
+  WsBump w(nullptr, 0);
+  Ws s;
+  layout(w, s, audio, visual, gru, T, N, Ha, Wa, S, prec);
+  return w.off + 4096;
+}
+
+extern "C" int avlen_baseline_train_fwd(const avlen_cnn3* audio, const avlen_cnn3* visual, const avlen_gru* gru,
+                                        const float* spec, const float* rgb, const float* depth, const float* category, int ncat,
+                                        const float* h0, const float* masks, float* out, float* h_out, int T, int N, int Ha, int Wa,
+                                        int S, int prec, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!audio || !visual || !gru || T <= 0 || N <= 0) return AVLEN_ERR_ARG;
+  const int H = gru->hidden, F = gru->in_f;
+  if (audio->fc.out_f + visual->fc.out_f + ncat != F) return AVLEN_ERR_ARG;
+  WsBump w(ws, ws_bytes);
+  Ws s;
+  if (!ws || !layout(w, s, audio, visual, gru, T, N, Ha, Wa, S, prec)) return AVLEN_ERR_WS;
+  const long R = (long)T * N;
+  avlen_ctx c{st, prec, s.gws, GEMM_SCRATCH};
+  c.xs = s.xs; c.xs_bytes = s.xs_bytes;
+  const long px = R * S * S;
+  hipLaunchKernelGGL(rgbd_concat_kernel, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, st, rgb, depth, s.rgbd, px);
+  TRY(cnn_fwd(c, audio, spec, R, Ha, Wa, s.aud, s.X, F));
+  TRY(cnn_fwd(c, visual, s.rgbd, R, S, S, s.vis, s.X + audio->fc.out_f, F));
+  if (ncat) TRY(avlen_copy_rows(category, ncat, s.X + audio->fc.out_f + visual->fc.out_f, F, (int)R, ncat, st));
+  avlen_linear ih{gru->w_ih, gru->b_ih, 3 * H, F, nullptr, 0}, hh{gru->w_hh, gru->b_hh, 3 * H, H, nullptr, 0};
+  TRY(avlen_i_linear(c, ih, s.X, F, s.GI, 3 * H, (int)R, 0, nullptr, 0));
+  const float* hprev = h0;
+  const dim3 g((unsigned)(((long)N * H + 255) / 256));
+  avlen_ctx cs = c; cs.xs = nullptr;                     // N-row products of the recurrence: never the large-M route
+  for (int t = 0; t < T; t++) {
+    float* hm = s.HM + (size_t)t * N * H; float* gh = s.GH + (size_t)t * N * 3 * H;
+    hipLaunchKernelGGL(gru_mask_kernel, g, dim3(256), 0, st, hprev, masks + (size_t)t * N, hm, N, H);
+    TRY(avlen_i_linear(cs, hh, hm, H, gh, 3 * H, N, 0, nullptr, 0));
+    hipLaunchKernelGGL(gru_gate_kernel, g, dim3(256), 0, st, s.GI + (size_t)t * N * 3 * H, gh, hm, out + (size_t)t * N * H, N, H);
+    hprev = out + (size_t)t * N * H;
+  }
+  TRY(avlen_launch_status());
+  if (h_out) TRY(avlen_copy_rows(hprev, H, h_out, H, N, H, st));
+  return AVLEN_OK;
+}
+
+extern "C" int avlen_baseline_train_bwd(const avlen_cnn3* audio, const avlen_cnn3* visual, const avlen_gru* gru,
+                                        const avlen_cnn3* g_audio, const avlen_cnn3* g_visual, const avlen_gru* g_gru,
+                                        const float* spec, const float* masks, const float* d_out, int T, int N, int Ha, int Wa, int S,
+                                        int prec, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!audio || !visual || !gru || !g_audio || !g_visual || !g_gru || T <= 0 || N <= 0) return AVLEN_ERR_ARG;
+  const int H = gru->hidden, F = gru->in_f;
+  WsBump w(ws, ws_bytes);
+  Ws s;
+  if (!ws || !layout(w, s, audio, visual, gru, T, N, Ha, Wa, S, prec)) return AVLEN_ERR_WS;
+  const long R = (long)T * N;
+  avlen_ctx c{st, prec, s.gws, GEMM_SCRATCH};
+  c.xs = s.xs; c.xs_bytes = s.xs_bytes;
+  avlen_ctx cs = c; cs.xs = nullptr;
+  // ---- BPTT through the masked GRU
+  avlen_linear hh{gru->w_hh, gru->b_hh, 3 * H, H, nullptr, 0};
+  const dim3 g((unsigned)(((long)N * H + 255) / 256));
+  const float* carry = nullptr;
+  for (int t = T - 1; t >= 0; t--) {
+    float* dhm = s.dh[t & 1];
+    float* dgh = s.dGH + (size_t)t * N * 3 * H;
+    hipLaunchKernelGGL(gru_gate_bwd_kernel, g, dim3(256), 0, st, s.GI + (size_t)t * N * 3 * H, s.GH + (size_t)t * N * 3 * H,
+                       s.HM + (size_t)t * N * H, d_out + (size_t)t * N * H, carry, carry ? masks + (size_t)(t + 1) * N : nullptr,
+                       s.dGI + (size_t)t * N * 3 * H, dgh, dhm, N, H);
+    if (t > 0) TRY(avlen_i_linear_dx(cs, hh, dgh, 3 * H, dhm, H, N, dhm, H));       // dhm += dGH W_hh  (h0 is data: not needed at t = 0)
+    carry = dhm;
+  }
+  TRY(avlen_launch_status());
+  avlen_linear Gih{g_gru->w_ih, nullptr, 3 * H, F, nullptr, 0}, Ghh{g_gru->w_hh, nullptr, 3 * H, H, nullptr, 0};
+  TRY(avlen_i_linear_dw(c, Gih, s.dGI, 3 * H, s.X, F, (int)R));
+  TRY(avlen_i_linear_dw(c, Ghh, s.dGH, 3 * H, s.HM, H, (int)R));
+  TRY(avlen_i_colsum_acc(c, s.dGI, 3 * H, g_gru->b_ih, (int)R, 3 * H));
+  TRY(avlen_i_colsum_acc(c, s.dGH, 3 * H, g_gru->b_hh, (int)R, 3 * H));
+  avlen_linear ih{gru->w_ih, gru->b_ih, 3 * H, F, nullptr, 0};
+  TRY(avlen_i_linear_dx(c, ih, s.dGI, 3 * H, s.dX, F, (int)R, nullptr, 0));
+  // ---- the two CNNs (the category columns of x are data)
+  TRY(cnn_bwd(c, s, audio, g_audio, spec, R, Ha, Wa, s.aud, s.dX, s.X, F));
+  TRY(cnn_bwd(c, s, visual, g_visual, s.rgbd, R, S, S, s.vis, s.dX + audio->fc.out_f, s.X + audio->fc.out_f, F));
+  return avlen_launch_status();
+}

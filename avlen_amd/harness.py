@@ -222,3 +222,65 @@ class Workload:
         for _ in range(steps or self.T):
             self.rollout_step()
         return self.update()
+
+
+class GruWorkload:
+    """BASELINE configs[1]: NUM_ENVS=16, `AudioNavBaselinePolicy` (AudioCNN + VisualCNN + single-layer GRU), PPO 4 epochs x 2
+    minibatches, in the av_nav call pattern: act -> insert per step, then get_value -> compute_returns -> update ->
+    after_update.  Synthetic observations as in `Workload`, resident in HBM."""
+
+    def __init__(self, num_envs=16, num_steps=150, spectrogram=(257, 101, 2), precision="bf16", ppo_epoch=4, num_mini_batch=2,
+                 device="cuda", seed=0, weight_seed=0, sampling="host"):
+        from . import av_nav
+        self.N, self.T, self.dev = num_envs, num_steps, torch.device(device)
+        osp, asp = savi_observation_space(spectrogram), ActionSpace(4)
+        torch.manual_seed(weight_seed)
+        self.pol = P.AudioNavBaselinePolicy(osp, asp, "spectrogram", hidden_size=512, precision=precision,
+                                            sampling=sampling).to(self.dev)
+        self.agent = av_nav.DDPPO(self.pol, clip_param=0.2, ppo_epoch=ppo_epoch, num_mini_batch=num_mini_batch,
+                                  value_loss_coef=0.5, entropy_coef=0.01, lr=2.5e-4, eps=1e-5, max_grad_norm=0.5,
+                                  use_normalized_advantage=False)
+        self.agent.init_distributed(find_unused_params=True)
+        self.rollouts = av_nav.RolloutStorage(num_steps, num_envs, osp, asp, 512, num_recurrent_layers=1, device=self.dev)
+        T, N, dev = self.T, self.N, self.dev
+        g = torch.Generator(device="cpu").manual_seed(2000 + seed)
+        H, W, _ = spectrogram
+        r = lambda *s_: torch.rand(*s_, generator=g)
+        self.sim = {
+            "rgb": torch.randint(0, 256, (T + 1, N, 128, 128, 3), generator=g, dtype=torch.uint8).to(dev).float(),
+            "depth": r(T + 1, N, 128, 128, 1).to(dev),
+            "spectrogram": torch.log1p(3.0 * torch.randn(T + 1, N, H, W, 2, generator=g).abs()).to(dev),
+            "category": torch.nn.functional.one_hot(torch.randint(0, 21, (T + 1, N), generator=g), 21).float().to(dev),
+            "category_belief": torch.softmax(torch.randn(T + 1, N, 21, generator=g), -1).to(dev),
+            "location_belief": (3.0 * torch.randn(T + 1, N, 2, generator=g)).to(dev),
+            "pose": torch.stack([r(T + 1, N) * 20 - 10, r(T + 1, N) * 20 - 10, r(T + 1, N) * 2 * math.pi - math.pi,
+                                 torch.arange(T + 1).float().view(-1, 1).expand(-1, N)], -1).to(dev),
+        }
+        self.rewards = torch.randn(T, N, 1, generator=g).to(dev)
+        self.not_done = (r(T, N, 1) >= 1.0 / 150).float().to(dev)
+        for k in self.rollouts.observations:
+            self.rollouts.observations[k][0].copy_(self.sim[k][0])
+
+    def rollout_step(self):
+        ro, t = self.rollouts, self.rollouts.step
+        obs = {k: v[t] for k, v in ro.observations.items()}
+        v, a, lp, h, _, _ = self.pol.act(obs, ro.recurrent_hidden_states[t], ro.prev_actions[t], ro.masks[t], None, None)
+        ro.insert({k: self.sim[k][t + 1] for k in ro.observations}, h, a, lp, v, self.rewards[t], self.not_done[t])
+
+    def update(self):
+        ro = self.rollouts
+        nv = self.pol.get_value({k: v[-1] for k, v in ro.observations.items()}, ro.recurrent_hidden_states[-1], ro.prev_actions[-1],
+                                ro.masks[-1], None, None)
+        ro.compute_returns(nv, True, 0.99, 0.95)
+        out = self.agent.update(ro)
+        ro.after_update()
+        return out
+
+    def cycle(self, steps=None):
+        for _ in range(steps or self.T):
+            self.rollout_step()
+        return self.update()
+
+    def finite(self):
+        ro = self.rollouts
+        return bool(torch.isfinite(ro.value_preds).all()) and bool(torch.isfinite(ro.recurrent_hidden_states).all())

@@ -510,6 +510,13 @@ class Policy(nn.Module):
                                      torch.empty(B, device=dev))
         return r
 
+    def _ones(self, R):
+        """(R,) int64 ones on the device (rl_masks of a loss that masks nothing), cached."""
+        t = self._pinned.get(("ones", R))
+        if t is None:
+            t = self._pinned[("ones", R)] = torch.ones(R, dtype=torch.int64, device=next(self.parameters()).device)
+        return t
+
     def _host_action(self, B):
         """Pinned staging buffer for the sampled actions (ring of 8: an upload is consumed long before its slot returns)."""
         ring = self._pinned.get(("act", B))
@@ -1146,6 +1153,40 @@ class AudioNavBaselineNet(Net):
         return out, h_out, None
 
 
+    # ---- training path (avlen_amd/av_nav.py:PPO.update; csrc/train_gru.hip)
+    def _train_dims(self, obs, h0):
+        rgb, spec = obs["rgb"], obs[SPECTROGRAM]
+        R, Nn = rgb.shape[0], h0.shape[1]
+        assert R % Nn == 0, "rows must be T*N (T-major)"
+        return R // Nn, Nn, spec.shape[1], spec.shape[2], rgb.shape[1]
+
+    def train_forward(self, pol, observations, rnn_hidden_states, masks):
+        """evaluate_actions' forward over a (T*N)-row T-major minibatch with every activation kept for `train_backward`
+        (policy.py:451-477 + rnn_state_encoder.py:92-143).  -> out (R, hidden), workspace, dims."""
+        eng = pol._engine()
+        rgb, depth, spec = _f32(observations["rgb"]), _f32(observations["depth"]), _f32(observations[SPECTROGRAM])
+        h0 = _f32(rnn_hidden_states)
+        T, Nn, Ha, Wa, S = self._train_dims(observations, h0)
+        dev = rgb.device
+        cat = _f32(observations[CATEGORY]) if self._label else None
+        nb = L.lib.avlen_baseline_train_workspace_bytes(C.byref(eng["audio"]), C.byref(eng["visual"]), C.byref(eng["gru"]), T, Nn,
+                                                        Ha, Wa, S, pol.prec)
+        ws = pol._ws.get("train", nb, dev)
+        out = torch.empty(T * Nn, self._hidden_size, device=dev)
+        mk = _f32(masks.view(-1))
+        L.call("avlen_baseline_train_fwd", C.byref(eng["audio"]), C.byref(eng["visual"]), C.byref(eng["gru"]), E.P(spec), E.P(rgb),
+               E.P(depth), E.P(cat) if cat is not None else None, cat.shape[1] if cat is not None else 0, E.P(h0), E.P(mk), E.P(out),
+               None, T, Nn, Ha, Wa, S, pol.prec, E.P(ws), nb, L.stream())
+        return out, (ws, nb), (T, Nn, Ha, Wa, S, spec, mk)
+
+    def train_backward(self, pol, g, observations, masks, d_out, ws, dims):
+        eng = pol._engine()
+        T, Nn, Ha, Wa, S, spec, mk = dims
+        L.call("avlen_baseline_train_bwd", C.byref(eng["audio"]), C.byref(eng["visual"]), C.byref(eng["gru"]), C.byref(g["audio"]),
+               C.byref(g["visual"]), C.byref(g["gru"]), E.P(spec), E.P(mk), E.P(d_out), T, Nn, Ha, Wa, S, pol.prec, E.P(ws[0]),
+               ws[1], L.stream())
+
+
 # =========================================================================================================
 # policies (policy.py:299-356)
 # =========================================================================================================
@@ -1162,6 +1203,28 @@ class AudioNavBaselinePolicy(_NetPolicy):
         super().__init__(AudioNavBaselineNet(observation_space=observation_space, hidden_size=hidden_size,
                                              goal_sensor_uuid=goal_sensor_uuid, extra_rgb=extra_rgb,
                                              use_mlp_state_encoder=use_mlp_state_encoder), action_space.n, **eng_kw)
+
+    def grad_views(self, eng):
+        """Gradient structs for avlen_baseline_train_bwd / avlen_ppo_loss_heads_bwd: same struct types as the parameter views,
+        pointers into the flat gradient buffer at the CANONICAL tensors (conv OIHW, fc (out, C*H*W))."""
+        if "grads" not in eng:
+            flat = eng["flat"]
+            gp = lambda name: C.c_void_p(flat.grad_ptr(name))
+
+            def cnn(view, prefix):
+                g = L.Cnn3()
+                for i, idx in enumerate((0, 2, 4)):
+                    v = view.conv[i]
+                    g.conv[i] = L.Conv(gp(f"{prefix}.cnn.{idx}.weight"), gp(f"{prefix}.cnn.{idx}.bias"), v.cin, v.cout, v.kh,
+                                       v.kw, v.stride, v.pad)
+                g.fc = L.Linear(gp(f"{prefix}.cnn.6.weight"), gp(f"{prefix}.cnn.6.bias"), view.fc.out_f, view.fc.in_f)
+                return g
+            r = "net.state_encoder.rnn."
+            gru = L.Gru(gp(r + "weight_ih_l0"), gp(r + "weight_hh_l0"), gp(r + "bias_ih_l0"), gp(r + "bias_hh_l0"),
+                        eng["gru"].in_f, eng["gru"].hidden)
+            eng["grads"] = {"audio": cnn(eng["audio"], "net.audio_encoder"), "visual": cnn(eng["visual"], "net.visual_encoder"),
+                            "gru": gru, "heads": E.grad_struct_like(self._heads("goal"), eng["ptr2name"], flat)}
+        return eng["grads"]
 
 
 def _split_engine_kwargs(kwargs):

@@ -301,12 +301,32 @@ int avlen_rl_mask_norm(const int64_t* rl_masks, int R, float* norm, avlen_stream
  * values (T+1,N), masks (T+1,N), returns (T+1,N) out, advantages (T,N) out (= returns - values). */
 int avlen_gae_scan(const float* rewards, float* values, const float* masks, const float* next_value, float* returns,
                    float* advantages, int T_used, int N, float gamma, float tau, avlen_stream_t stream);
+/* use_gae=False branch of compute_returns (rollout_storage.py:406-412; common/rollout_storage.py:129-135). */
+int avlen_discounted_returns(const float* rewards, const float* masks, const float* next_value, float* returns, int T_used,
+                             int N, float gamma, avlen_stream_t stream);
 /* clip_grad_norm_ + Adam (ppo.py:297-300, torch.optim.Adam): norm_sq is a device double accumulated by
  * avlen_grad_sumsq over every trained segment, then each segment is stepped. */
 int avlen_grad_sumsq(const float* grad, size_t n, double* norm_sq, avlen_stream_t stream);
 int avlen_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr,
                     float beta1, float beta2, float eps, int step, float max_grad_norm, const double* norm_sq,
                     avlen_stream_t stream);
+
+/* ---- GRU baseline training (BASELINE configs[1]): AudioNavBaselineNet forward with saved activations and its backward
+ * (savi/ppo/policy.py:451-477; audio_cnn.py:62-94; visual_cnn.py:82-107; av_nav/models/rnn_state_encoder.py:92-143), driven by
+ * the av_nav PPO update (av_nav/ppo/ppo.py:60-151) between the two calls with avlen_ppo_loss_heads_bwd.  Rows are T-major
+ * (row = t*N + n).  rgb (R,S,S,3) 0..255, depth (R,S,S,1), spec (R,Ha,Wa,C); out (R,H).  g_*: gradient views with the SAME
+ * struct types whose w / b pointers address the CANONICAL gradient tensors (conv OIHW, fc (out, C*H*W), GRU as nn.GRU);
+ * gradients are accumulated into them.  The workspace carries the saved activations from _fwd to _bwd. */
+size_t avlen_baseline_train_workspace_bytes(const avlen_cnn3* audio, const avlen_cnn3* visual, const avlen_gru* gru, int T, int N,
+                                            int Ha, int Wa, int S, int prec);
+int avlen_baseline_train_fwd(const avlen_cnn3* audio, const avlen_cnn3* visual, const avlen_gru* gru, const float* spec,
+                             const float* rgb, const float* depth, const float* category, int ncat, const float* h0,
+                             const float* masks, float* out, float* h_out, int T, int N, int Ha, int Wa, int S, int prec, void* ws,
+                             size_t ws_bytes, avlen_stream_t stream);
+int avlen_baseline_train_bwd(const avlen_cnn3* audio, const avlen_cnn3* visual, const avlen_gru* gru, const avlen_cnn3* g_audio,
+                             const avlen_cnn3* g_visual, const avlen_gru* g_gru, const float* spec, const float* masks,
+                             const float* d_out, int T, int N, int Ha, int Wa, int S, int prec, void* ws, size_t ws_bytes,
+                             avlen_stream_t stream);
 
 /* ------------------------------------------------------------------ rollout storage ------------ */
 /* ExternalMemory.insert (rollout_storage.py:930-941) on ONE copy of the ring: memory (total,N,dim),

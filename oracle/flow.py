@@ -234,3 +234,121 @@ def cpu_baseline(specs, N=16, T=4, spectrogram=(257, 101), pretraining=True, em_
     agent.update(st)
     dt = time.perf_counter() - t0
     return N * T / dt, dt, torch.get_num_threads()
+
+
+# --------------------------------------------------------------------------------------------------
+# GRU baseline (BASELINE configs[1]): common/rollout_storage.py + av_nav/ppo/ppo.py restated
+# --------------------------------------------------------------------------------------------------
+class PlainStorage:
+    """ss_baselines/common/rollout_storage.py:16-235."""
+
+    def __init__(self, T, N, obs0, hidden=512):
+        self.T, self.N, self.step = T, N, 0
+        self.obs = {k: torch.zeros(T + 1, N, *v.shape[1:]) for k, v in obs0.items()}
+        for k, v in obs0.items():
+            self.obs[k][0].copy_(v)
+        z = torch.zeros
+        self.hidden = z(T + 1, 1, N, hidden)
+        self.rewards, self.value_preds, self.returns = z(T, N, 1), z(T + 1, N, 1), z(T + 1, N, 1)
+        self.action_log_probs = z(T, N, 1)
+        self.actions, self.prev_actions = z(T, N, 1, dtype=torch.long), z(T + 1, N, 1, dtype=torch.long)
+        self.masks = torch.ones(T + 1, N, 1)
+
+    def insert(self, obs, hidden, actions, logp, values, rewards, masks):
+        s = self.step
+        for k in obs:
+            self.obs[k][s + 1].copy_(obs[k])
+        self.hidden[s + 1].copy_(hidden)
+        self.actions[s].copy_(actions)
+        self.prev_actions[s + 1].copy_(actions)
+        self.action_log_probs[s].copy_(logp)
+        self.value_preds[s].copy_(values)
+        self.rewards[s].copy_(rewards)
+        self.masks[s + 1].copy_(masks)
+        self.step = (s + 1) % self.T
+
+    def after_update(self):
+        for k in self.obs:
+            self.obs[k][0].copy_(self.obs[k][-1])
+        self.hidden[0].copy_(self.hidden[-1])
+        self.masks[0].copy_(self.masks[-1])
+        self.prev_actions[0].copy_(self.prev_actions[-1])
+
+    def compute_returns(self, next_value, use_gae, gamma, tau):
+        if use_gae:
+            ret, vp = R.gae_returns(self.rewards, self.value_preds, self.masks, next_value, gamma, tau)
+            self.returns.copy_(ret)
+            self.value_preds.copy_(vp)
+        else:
+            self.returns[-1] = next_value
+            for t in reversed(range(self.T)):
+                self.returns[t] = self.returns[t + 1] * gamma * self.masks[t + 1] + self.rewards[t]
+
+    def minibatches(self, advantages, num_mini_batch):
+        N, T = self.N, self.T
+        per = N // num_mini_batch
+        perm = torch.randperm(N)
+        for start in range(0, N, per):
+            ind = perm[start:start + per]
+            fl = lambda x: x[:T, ind].reshape(T * len(ind), *x.shape[2:])
+            yield {"obs": {k: fl(v) for k, v in self.obs.items()}, "h0": self.hidden[0][:, ind], "actions": fl(self.actions),
+                   "value_preds": fl(self.value_preds), "returns": fl(self.returns), "masks": fl(self.masks),
+                   "old_log_probs": fl(self.action_log_probs), "adv": fl(advantages)}
+
+
+class BaselineAgent:
+    """AudioNavBaselinePolicy + av_nav PPO (ppo.py:16-165), restated: every policy parameter that receives a gradient
+    (net.* and the goal heads) is stepped by Adam after a global clip-norm."""
+
+    PREFIXES = ("net.", "action_distribution_goal.", "critic_goal.")
+
+    def __init__(self, sd, clip_param=0.2, ppo_epoch=4, num_mini_batch=2, value_loss_coef=0.5, entropy_coef=0.01, lr=7e-4,
+                 eps=1e-5, max_grad_norm=0.5, use_normalized_advantage=False):
+        self.sd = sd
+        self.clip, self.epochs, self.mb, self.vc, self.ec = clip_param, ppo_epoch, num_mini_batch, value_loss_coef, entropy_coef
+        self.lr, self.eps, self.gn, self.norm_adv = lr, eps, max_grad_norm, use_normalized_advantage
+        self.trained = [k for k in sd if k.startswith(self.PREFIXES)]
+        self.m = {k: torch.zeros_like(sd[k]) for k in self.trained}
+        self.v = {k: torch.zeros_like(sd[k]) for k in self.trained}
+        self.t = 0
+
+    def act(self, obs, hidden, masks, generator=None):
+        with torch.no_grad():
+            x, h = R.baseline_net(self.sd, obs, hidden, masks)
+            return R.heads(self.sd, "goal", x, generator=generator), h
+
+    def value(self, obs, hidden, masks):
+        with torch.no_grad():
+            x, _ = R.baseline_net(self.sd, obs, hidden, masks)
+            return R._lin(self.sd, "critic_goal.fc", x)
+
+    def update(self, st):
+        adv = st.returns[:-1] - st.value_preds[:-1]
+        if self.norm_adv:
+            adv = (adv - adv.mean()) / (adv.std() + 1e-5)
+        acc = [0.0, 0.0, 0.0]
+        for _ in range(self.epochs):
+            for b in st.minibatches(adv, self.mb):
+                for k in self.trained:
+                    self.sd[k].requires_grad_(True)
+                    self.sd[k].grad = None
+                x, _ = R.baseline_net(self.sd, b["obs"], b["h0"], b["masks"])
+                h = R.heads(self.sd, "goal", x, action=b["actions"])
+                ratio = torch.exp(h["log_prob"] - b["old_log_probs"])
+                surr1 = ratio * b["adv"]
+                surr2 = torch.clamp(ratio, 1.0 - self.clip, 1.0 + self.clip) * b["adv"]
+                action_loss = -torch.min(surr1, surr2).mean()
+                vpc = b["value_preds"] + (h["value"] - b["value_preds"]).clamp(-self.clip, self.clip)
+                value_loss = 0.5 * torch.max((h["value"] - b["returns"]).pow(2), (vpc - b["returns"]).pow(2)).mean()
+                (value_loss * self.vc + action_loss - h["entropy"] * self.ec).backward()
+                with torch.no_grad():
+                    grads, _ = R.clip_grad_norm([self.sd[k].grad for k in self.trained], self.gn)
+                    self.t += 1
+                    for k, g in zip(self.trained, grads):
+                        R.adam_step(self.sd[k], g, self.m[k], self.v[k], self.t, self.lr, self.eps)
+                for k in self.trained:
+                    self.sd[k].requires_grad_(False)
+                for i, x_ in enumerate((value_loss, action_loss, h["entropy"])):
+                    acc[i] += float(x_.detach())
+        n = self.epochs * self.mb
+        return acc[0] / n, acc[1] / n, acc[2] / n

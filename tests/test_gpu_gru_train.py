@@ -1,0 +1,130 @@
+"""BASELINE configs[1] on the HIP path: the GRU baseline policy (AudioCNN + VisualCNN + masked GRU) trained by the av_nav PPO
+mirror (avlen_amd/av_nav.py) -- rollout, returns, update and post-step parameters against goldens from the REFERENCE's own
+av_nav PPO / RolloutStorage / AudioNavBaselinePolicy (oracle/make_goldens_gru.py), and every parameter's gradient against torch
+autograd on the oracle."""
+import json
+import os
+import numpy as np
+import pytest
+import torch
+
+import fixtures as fx
+import cycle as cyc
+import flow
+import restate as R
+from conftest import golden, GOLDEN
+from avlen_amd import policy as P
+from avlen_amd import av_nav
+from avlen_amd.spaces import savi_observation_space, ActionSpace
+
+pytestmark = pytest.mark.gpu
+CFG = dict(clip_param=0.2, ppo_epoch=4, num_mini_batch=2, value_loss_coef=0.5, entropy_coef=0.01, lr=7e-4, eps=1e-5,
+           max_grad_norm=0.5, use_normalized_advantage=False)
+
+
+def cu(x):
+    if isinstance(x, dict):
+        return {k: v.cuda() for k, v in x.items()}
+    return x.cuda()
+
+
+def build(tag, spectro, precision="fp32"):
+    meta = json.load(open(os.path.join(GOLDEN, tag + "_keys.json")))
+    sd = fx.state_dict_for({k: tuple(v) for k, v in meta["spec"].items()})
+    pol = P.AudioNavBaselinePolicy(savi_observation_space(spectro + (2,)), ActionSpace(4), "spectrogram", hidden_size=512,
+                                   precision=precision)
+    missing = pol.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys and not missing.missing_keys
+    return pol.cuda(), sd, meta["keys"]
+
+
+@pytest.mark.parametrize("tag,spectro,use_gae", [("gru_cycle", (65, 26), True), ("gru_cycle_257_nogae", (257, 101), False)])
+def test_gru_cycle_matches_reference(tag, spectro, use_gae):
+    g = golden(tag)
+    T, N = 5, 4
+    pol, sd0, keys = build(tag, spectro)
+    agent = av_nav.PPO(pol, **CFG)
+    st = av_nav.RolloutStorage(T, N, savi_observation_space(spectro + (2,)), ActionSpace(4), 512, num_recurrent_layers=1)
+    o0 = cyc.first_obs(N, spectro, tag="gru")
+    for k in st.observations:
+        st.observations[k][0].copy_(o0[k])
+    st.recurrent_hidden_states[0].copy_(fx.sym("gru.h0", (1, N, 512), 0.5))
+    torch.manual_seed(777)
+    tol = dict(rtol=1e-3, atol=1e-3)
+    for t in range(T):
+        si = cyc.step_inputs(t, N, spectro, tag="gru")
+        so = {k: v[st.step] for k, v in st.observations.items()}
+        v, a, lp, h, _, probs = pol.act(so, st.recurrent_hidden_states[st.step], st.prev_actions[st.step], st.masks[st.step],
+                                        None, None)
+        np.testing.assert_allclose(v.cpu().numpy(), g["value"][t], **tol)
+        np.testing.assert_allclose(probs.cpu().numpy(), g["probs"][t], **tol)
+        np.testing.assert_allclose(h.cpu().numpy(), g["hidden"][t], **tol)
+        assert np.array_equal(a.cpu().numpy(), g["action"][t])                     # bit-exact sampling
+        st.insert(cu(si["next_obs"]), h, a, lp, v, si["rewards"].cuda(), si["not_done"].cuda())
+    nv = pol.get_value({k: v[-1] for k, v in st.observations.items()}, st.recurrent_hidden_states[-1], st.prev_actions[-1],
+                       st.masks[-1], None, None)
+    np.testing.assert_allclose(nv.cpu().numpy(), g["next_value"], **tol)
+    st.compute_returns(nv, use_gae, 0.99, 0.95)
+    np.testing.assert_allclose(st.returns.cpu().numpy()[:T], g["returns"][:T], **tol)
+    out = agent.update(st)
+    st.after_update()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(np.array(out), g["update"], rtol=3e-3, atol=1e-4)
+    sd = {k: v.detach().cpu() for k, v in pol.state_dict().items()}
+    pabs = np.array([float(sd[k].double().abs().sum()) for k in keys])
+    np.testing.assert_allclose(pabs, g["param_abs"], rtol=3e-4)
+    # the step itself (8 Adam steps at lr 7e-4): deltas of a few slices vs the reference's
+    for name, gold, sl in (("net.visual_encoder.cnn.0.weight", g["conv0_w"], np.s_[:2, :, :3, :3]),
+                           ("net.audio_encoder.cnn.6.weight", g["afc_w"], np.s_[:3, :16]),
+                           ("net.state_encoder.rnn.weight_hh_l0", g["whh"], np.s_[:4, :8]),
+                           ("critic_goal.fc.weight", g["critic_w"], np.s_[:, :16])):
+        d_ours = sd[name].numpy()[sl] - sd0[name].numpy()[sl]
+        d_ref = gold - sd0[name].numpy()[sl]
+        err = np.abs(d_ours - d_ref).max() / (np.abs(d_ref).max() + 1e-12)
+        assert err < 0.1, (name, err)
+    # unused heads untouched (grad None in the reference: skipped by clip-norm and Adam)
+    assert torch.equal(sd["critic_option.fc.weight"], sd0["critic_option.fc.weight"])
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_gru_gradients_match_oracle_autograd(precision):
+    """One (T=6) x (N=3) minibatch with mask resets: the HIP backward (loss + heads, BPTT, Linear, conv wgrad/dgrad via
+    im2col/col2im) vs torch autograd on the oracle, per parameter tensor."""
+    tag, spectro = "gru_cycle_257_nogae", (257, 101)
+    pol, sd, _ = build(tag, spectro, precision)
+    T, N = 6, 3
+    R_ = T * N
+    obs = fx.observations("grug", R_, spectro)
+    h0 = fx.sym("grug.h0", (1, N, 512), 0.5)
+    masks = torch.from_numpy((fx.unit("grug.m", R_) >= 0.25).astype("float32")).view(R_, 1)
+    act = fx.ints("grug.a", (R_, 1), 4)
+    old_lp, adv = -1.3 + fx.sym("grug.olp", (R_, 1), 0.2), fx.sym("grug.adv", (R_, 1), 1.0)
+    vp, ret = fx.sym("grug.vp", (R_, 1), 1.0), fx.sym("grug.ret", (R_, 1), 1.0)
+    osd = {k: v.clone() for k, v in sd.items()}
+    tr = [k for k in osd if k.startswith(flow.BaselineAgent.PREFIXES)]
+    for k in tr:
+        osd[k].requires_grad_(True)
+    x, _ = R.baseline_net(osd, obs, h0, masks)
+    h = R.heads(osd, "goal", x, action=act)
+    ratio = torch.exp(h["log_prob"] - old_lp)
+    al = -torch.min(ratio * adv, torch.clamp(ratio, 0.8, 1.2) * adv).mean()
+    vpc = vp + (h["value"] - vp).clamp(-0.2, 0.2)
+    vl = 0.5 * torch.max((h["value"] - ret).pow(2), (vpc - ret).pow(2)).mean()
+    (vl * 0.5 + al - h["entropy"] * 0.01).backward()
+    agent = av_nav.PPO(pol, **CFG)
+    loss = torch.zeros(6, device="cuda")
+    sample = (cu(obs), h0.cuda(), act.cuda(), None, vp.cuda(), ret.cuda(), masks.cuda(), old_lp.cuda(), adv.cuda())
+    flat = agent._forward_backward(sample, loss)
+    torch.cuda.synchronize()
+    lv = loss.cpu().numpy()
+    fp = precision == "fp32"
+    np.testing.assert_allclose(lv[[0, 1, 2]], [float(vl), float(al), float(h["entropy"])], rtol=1e-3 if fp else 5e-2,
+                               atol=1e-5 if fp else 5e-3)
+    worst = 0.0
+    for k in tr:
+        ours = flat.grad_view(k, osd[k].shape).cpu().double()
+        ref = osd[k].grad.double()
+        err = float((ours - ref).norm() / (ref.norm() + 1e-12))
+        worst = max(worst, err)
+        assert err < (2e-3 if fp else 0.12), (k, err)
+    print(f"{precision}: max relative L2 gradient error over {len(tr)} tensors: {worst:.3g}")
