@@ -16,6 +16,11 @@ int avlen_i_linear_dx(const avlen_ctx& c, const avlen_linear& L, const float* dY
 int avlen_i_linear_dw(const avlen_ctx& c, const avlen_linear& G, const float* dY, int ldy, const float* X, int ldx, int M);
 int avlen_i_colsum_acc(const avlen_ctx& c, const float* dY, int ld, float* out, int rows, int N);
 
+// fused masked GRU step (train_gru.hip): out = GRU(gi, hprev * mask), one wave per hidden unit
+bool avlen_i_gru_step_ok(int N, int H);
+int avlen_i_gru_step_fwd(const avlen_gru* p, const float* gi, const float* hprev, const float* mask, float* out, int N,
+                         hipStream_t st);
+
 int avlen_groupnorm_nhwc_ws(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
                             int B, int HW, int C, int G, int relu, float eps, float* part, hipStream_t stream);
 extern "C" size_t avlen_groupnorm_workspace_bytes(int B, int C);

@@ -1706,6 +1706,13 @@ extern "C" int avlen_gru_fwd(const avlen_gru* p, const float* x, const float* h0
   TRY(linear(c, ih, x, p->in_f, GI, 3 * H, T * N, 0, nullptr, 0));
   const float* hprev = h0;
   dim3 g((unsigned)(((long)N * H + 255) / 256));
+  if (avlen_i_gru_step_ok(N, H)) {          // few rows: one fused launch per step, one wave per hidden unit (train_gru.hip)
+    for (int t = 0; t < T; t++) {
+      TRY(avlen_i_gru_step_fwd(p, GI + (size_t)t * N * 3 * H, hprev, masks + (size_t)t * N, out + (size_t)t * N * H, N, st));
+      hprev = out + (size_t)t * N * H;
+    }
+    return avlen_copy_rows(hprev, H, h_out, H, N, H, st);
+  }
   for (int t = 0; t < T; t++) {
     hipLaunchKernelGGL(gru_mask_kernel, g, dim3(256), 0, st, hprev, masks + (size_t)t * N, hm, N, H);
     TRY(linear(c, hh, hm, H, GH, 3 * H, N, 0, nullptr, 0));

@@ -53,13 +53,18 @@ __global__ void im2col_kernel(const float* __restrict__ X, float* __restrict__ c
   const float* src = X + (((b * H + (long)oh * s + kh) * W + (long)ow * s) * C) + (long)j * V;
   float* dst = cols + (r * KH + kh) * (long)(KW * C) + (long)j * V;
   if (V == 4) *(float4*)dst = *(const float4*)src;
+  else if (V == 2) *(float2*)dst = *(const float2*)src;
   else dst[0] = src[0];
 }
 int im2col(hipStream_t st, const float* X, float* cols, long B, int H, int W, int C, int OH, int OW, int KH, int KW, int s) {
-  const bool v4 = (KW * C) % 4 == 0 && C % 4 == 0 && (((uintptr_t)X | (uintptr_t)cols) & 15) == 0;
-  const long total = B * OH * OW * KH * (long)(KW * C / (v4 ? 4 : 1));
+  // a (kw, c) run starts at float offset ((b*H + ih)*W + ow*s)*C: V-float pieces need W*C, s*C and KW*C to be multiples of V
+  auto ok = [&](int v) { return (KW * C) % v == 0 && (W * C) % v == 0 && (s * C) % v == 0 &&
+                                (((uintptr_t)X | (uintptr_t)cols) & (size_t)(4 * v - 1)) == 0; };
+  const int V = ok(4) ? 4 : ok(2) ? 2 : 1;
+  const long total = B * OH * OW * KH * (long)(KW * C / V);
   const unsigned blocks = (unsigned)((total + 255) / 256);
-  if (v4) hipLaunchKernelGGL(im2col_kernel<4>, dim3(blocks), dim3(256), 0, st, X, cols, total, H, W, C, OH, OW, KH, KW, s);
+  if (V == 4) hipLaunchKernelGGL(im2col_kernel<4>, dim3(blocks), dim3(256), 0, st, X, cols, total, H, W, C, OH, OW, KH, KW, s);
+  else if (V == 2) hipLaunchKernelGGL(im2col_kernel<2>, dim3(blocks), dim3(256), 0, st, X, cols, total, H, W, C, OH, OW, KH, KW, s);
   else hipLaunchKernelGGL(im2col_kernel<1>, dim3(blocks), dim3(256), 0, st, X, cols, total, H, W, C, OH, OW, KH, KW, s);
   return avlen_launch_status();
 }
@@ -135,46 +140,154 @@ __global__ void unpack_fc_grad_kernel(const float* __restrict__ gp, float* __res
 
 // ---------------------------------------------------------------------------------------------------------------
 // GRU (r | z | n gate order of nn.GRU): h' = (1 - z) n + z hm,  n = tanh(gi_n + r * gh_n),  hm = h_prev * mask
+// One launch per time step.  The recurrence is N (<= 16 here) rows against W_hh (3H x H): a tile GEMM gives it a dozen
+// workgroups and ~50 us; here ONE WAVE owns hidden unit j: it keeps rows j, H+j, 2H+j of W_hh in registers (3 x H/64 floats per
+// lane, read once, coalesced), forms the three dot products with every batch row by wave reductions and applies the gate
+// arithmetic in place -- H waves spread over the chip, W_hh streamed exactly once per step.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void gru_mask_kernel(const float* __restrict__ h, const float* __restrict__ mask, float* __restrict__ hm, int N, int H) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < (long)N * H) hm[i] = h[i] * mask[i / H];
+constexpr int GRU_HP = 8;                    // floats per lane of one weight row: H <= 64 * GRU_HP
+// Batch rows are processed MC at a time: all MC x 3 dot products are accumulated together (MC x GRU_HP independent loads in
+// flight per lane), reduced across the wave, and then lane m finishes row m -- its gi loads, the gate arithmetic and the stores
+// of the MC rows run in parallel lanes instead of as a serial tail in lane 0 (which made a step 29 us: ~8 dependent round trips).
+template <int MC>
+__global__ __launch_bounds__(256) void gru_step_fwd_kernel(const float* __restrict__ w_hh, const float* __restrict__ b_hh,
+                                                           const float* __restrict__ gi, const float* __restrict__ hprev,
+                                                           const float* __restrict__ mask, float* __restrict__ out,
+                                                           float* __restrict__ hm_save, float* __restrict__ gh_save, int N, int H) {
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= H) return;
+  float w[3][GRU_HP];
+#pragma unroll
+  for (int g = 0; g < 3; g++)
+#pragma unroll
+    for (int i = 0; i < GRU_HP; i++) { const int k = lane + 64 * i; w[g][i] = k < H ? w_hh[((long)g * H + j) * H + k] : 0.f; }
+  const float b0 = b_hh[j], b1 = b_hh[H + j], b2 = b_hh[2 * H + j];
+  for (int m0 = 0; m0 < N; m0 += MC) {
+    float a0[MC], a1[MC], a2[MC];
+#pragma unroll
+    for (int mm = 0; mm < MC; mm++) {
+      const int m = m0 + mm;
+      a0[mm] = a1[mm] = a2[mm] = 0.f;
+      if (m < N) {
+#pragma unroll
+        for (int i = 0; i < GRU_HP; i++) {
+          const int k = lane + 64 * i;
+          const float h = k < H ? hprev[(long)m * H + k] : 0.f;
+          a0[mm] += h * w[0][i]; a1[mm] += h * w[1][i]; a2[mm] += h * w[2][i];
+        }
+      }
+    }
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+#pragma unroll
+    for (int mm = 0; mm < MC; mm++) {
+      const float s0 = wave_sum(a0[mm]), s1 = wave_sum(a1[mm]), s2 = wave_sum(a2[mm]);
+      if (lane == mm) { r0 = s0; r1 = s1; r2 = s2; }
+    }
+    const int m = m0 + lane;
+    if (lane < MC && m < N) {
+      const float mk = mask[m];                       // the dot products are linear in the mask
+      const float hj = hprev[(long)m * H + j] * mk;
+      r0 = r0 * mk + b0; r1 = r1 * mk + b1; r2 = r2 * mk + b2;
+      const float* a = gi + (long)m * 3 * H;
+      const float r = 1.f / (1.f + expf(-(a[j] + r0)));
+      const float z = 1.f / (1.f + expf(-(a[H + j] + r1)));
+      const float nn = tanhf(a[2 * H + j] + r * r2);
+      out[(long)m * H + j] = (1.f - z) * nn + z * hj;
+      if (hm_save) {
+        hm_save[(long)m * H + j] = hj;
+        float* g = gh_save + (long)m * 3 * H;
+        g[j] = r0; g[H + j] = r1; g[2 * H + j] = r2;
+      }
+    }
+  }
 }
-__global__ void gru_gate_kernel(const float* __restrict__ gi, const float* __restrict__ gh, const float* __restrict__ hm,
-                                float* __restrict__ out, int N, int H) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long)N * H) return;
-  const int n = (int)(i / H), j = (int)(i % H);
-  const float* a = gi + (long)n * 3 * H; const float* b = gh + (long)n * 3 * H;
-  const float r = 1.f / (1.f + expf(-(a[j] + b[j])));
-  const float z = 1.f / (1.f + expf(-(a[H + j] + b[H + j])));
-  const float nn = tanhf(a[2 * H + j] + r * b[2 * H + j]);
-  out[i] = (1.f - z) * nn + z * hm[i];
+
+// Backward of step t for hidden unit j (one wave), fused with the carry from step t+1:
+//   dhm_{t+1}[m][j] = dz_{t+1}[m][j] + sum_n dGH_{t+1}[m][n] * W_hh[n][j]      (W_hh^T rows are contiguous in whhT: [H][3H])
+//   dh = d_out[t][m][j] + dhm_{t+1}[m][j] * mask_{t+1}[m]
+//   -> dGI[t], dGH[t] (rows m, columns j, H+j, 2H+j), dz_t = dh * z  (kept for the next launch)
+// `dgh_next` null: last step (no carry).  Same MC-rows-at-a-time structure as the forward.
+constexpr int GRU_KP = 24;                   // 3H <= 64 * GRU_KP
+template <int MC>
+__global__ __launch_bounds__(256) void gru_step_bwd_kernel(const float* __restrict__ whhT, const float* __restrict__ gi,
+                                                           const float* __restrict__ gh, const float* __restrict__ hm,
+                                                           const float* __restrict__ d_out, const float* __restrict__ dgh_next,
+                                                           const float* __restrict__ dz_next, const float* __restrict__ mask_next,
+                                                           float* __restrict__ dgi, float* __restrict__ dgh, float* __restrict__ dz,
+                                                           int N, int H) {
+  extern __shared__ float sd[];               // MC rows of dGH_{t+1}: shared by the block's four hidden units, staged once
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const bool valid = j < H;
+  const int jj = valid ? j : H - 1;
+  const int K = 3 * H;
+  float w[GRU_KP];
+  if (dgh_next) {
+#pragma unroll
+    for (int i = 0; i < GRU_KP; i++) { const int k = lane + 64 * i; w[i] = k < K ? whhT[(long)jj * K + min(k, K - 1)] : 0.f; }
+  }
+  for (int m0 = 0; m0 < N; m0 += MC) {
+    float carry = 0.f;
+    if (dgh_next) {
+      const int rows = min(MC, N - m0);
+      __syncthreads();
+      {
+        const float4* src = (const float4*)(dgh_next + (long)m0 * K);
+        const int n4 = rows * K / 4;            // K = 3H, H % 4 == 0 (checked by the launcher)
+        for (int i = threadIdx.x; i < n4; i += 256) ((float4*)sd)[i] = src[i];
+      }
+      __syncthreads();
+      float acc[MC];
+#pragma unroll
+      for (int mm = 0; mm < MC; mm++) {
+        acc[mm] = 0.f;
+        if (mm < rows) {
+#pragma unroll
+          for (int i = 0; i < GRU_KP; i++) { const int k = lane + 64 * i; if (k < K) acc[mm] += sd[mm * K + k] * w[i]; }
+        }
+      }
+#pragma unroll
+      for (int mm = 0; mm < MC; mm++) { const float sv = wave_sum(acc[mm]); if (lane == mm) carry = sv; }
+    }
+    const int m = m0 + lane;
+    if (valid && lane < MC && m < N) {
+      if (dgh_next) carry = (carry + dz_next[(long)m * H + j]) * mask_next[m];
+      const long o = (long)m * K;
+      const float* a = gi + o; const float* b = gh + o;
+      const float r = 1.f / (1.f + expf(-(a[j] + b[j])));
+      const float z = 1.f / (1.f + expf(-(a[H + j] + b[H + j])));
+      const float ghn = b[2 * H + j];
+      const float nn = tanhf(a[2 * H + j] + r * ghn);
+      const float dh = d_out[(long)m * H + j] + carry;
+      const float dn = dh * (1.f - z);
+      const float dzz = dh * (hm[(long)m * H + j] - nn);
+      const float dpn = dn * (1.f - nn * nn);
+      const float dpr = dpn * ghn * r * (1.f - r);
+      const float dpz = dzz * z * (1.f - z);
+      dgi[o + j] = dpr; dgi[o + H + j] = dpz; dgi[o + 2 * H + j] = dpn;
+      dgh[o + j] = dpr; dgh[o + H + j] = dpz; dgh[o + 2 * H + j] = dpn * r;
+      dz[(long)m * H + j] = dh * z;
+    }
+  }
 }
-// dh = d_out[t] + carry * mask_next (carry = gradient w.r.t. hm of step t+1; null at the last step)
-// -> dGI[t], dGH[t], dhm_direct = dh * z
-__global__ void gru_gate_bwd_kernel(const float* __restrict__ gi, const float* __restrict__ gh, const float* __restrict__ hm,
-                                    const float* __restrict__ d_out, const float* __restrict__ carry, const float* __restrict__ mask_next,
-                                    float* __restrict__ dgi, float* __restrict__ dgh, float* __restrict__ dhm, int N, int H) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long)N * H) return;
-  const int n = (int)(i / H), j = (int)(i % H);
-  const long o = (long)n * 3 * H;
-  const float* a = gi + o; const float* b = gh + o;
-  const float r = 1.f / (1.f + expf(-(a[j] + b[j])));
-  const float z = 1.f / (1.f + expf(-(a[H + j] + b[H + j])));
-  const float ghn = b[2 * H + j];
-  const float nn = tanhf(a[2 * H + j] + r * ghn);
-  float dh = d_out[i];
-  if (carry) dh += carry[i] * mask_next[n];
-  const float dn = dh * (1.f - z);
-  const float dz = dh * (hm[i] - nn);
-  const float dpn = dn * (1.f - nn * nn);
-  const float dpr = dpn * ghn * r * (1.f - r);
-  const float dpz = dz * z * (1.f - z);
-  dgi[o + j] = dpr; dgi[o + H + j] = dpz; dgi[o + 2 * H + j] = dpn;
-  dgh[o + j] = dpr; dgh[o + H + j] = dpz; dgh[o + 2 * H + j] = dpn * r;
-  dhm[i] = dh * z;
+
+// [R][C] -> [C][R]
+__global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int C) {
+  __shared__ float t[32][33];
+  const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x, ty = threadIdx.y;
+#pragma unroll
+  for (int jj = 0; jj < 4; jj++) {
+    const int r = r0 + ty + jj * 8, c = c0 + tx;
+    t[ty + jj * 8][tx] = (r < R && c < C) ? src[(long)r * C + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int jj = 0; jj < 4; jj++) {
+    const int c = c0 + ty + jj * 8, r = r0 + tx;
+    if (c < C && r < R) dst[(long)c * R + r] = t[tx][ty + jj * 8];
+  }
 }
 
 __global__ void rgbd_concat_kernel(const float* __restrict__ rgb, const float* __restrict__ depth, float* __restrict__ y, long n) {
@@ -192,7 +305,7 @@ struct Ws {
   float *rgbd, *X, *GI, *GH, *HM, *hc;
   CnnWs aud, vis;
   // backward scratch
-  float *dX, *dGI, *dGH, *dh[2], *dpre, *da, *db, *cols, *gpack;
+  float *dX, *dGI, *dGH, *dh[2], *dpre, *da, *db, *cols, *gpack, *whhT;
   void* gws; void* xs; size_t xs_bytes;
 };
 size_t cnn_cols_max(const avlen_cnn3* n, const Dims& d, long R) {
@@ -227,6 +340,7 @@ bool layout(WsBump& w, Ws& s, const avlen_cnn3* au, const avlen_cnn3* vi, const 
   s.dX = w.take<float>((size_t)R * F);
   s.dGI = w.take<float>((size_t)R * 3 * H); s.dGH = w.take<float>((size_t)R * 3 * H);
   s.dh[0] = w.take<float>((size_t)N * H); s.dh[1] = w.take<float>((size_t)N * H);
+  s.whhT = w.take<float>((size_t)3 * H * H);
   s.dpre = w.take<float>((size_t)R * zmax(au->fc.out_f, vi->fc.out_f));
   const size_t am = zmax(cnn_act_max(da, R), cnn_act_max(dv, R));
   s.da = w.take<float>(am); s.db = w.take<float>(am);
@@ -304,6 +418,17 @@ int cnn_bwd(const avlen_ctx& c, Ws& s, const avlen_cnn3* n, const avlen_cnn3* g,
 
 }  // namespace
 
+// one GRU step for up to a few dozen rows (rollout `act`, modules.hip:avlen_gru_fwd): see gru_step_fwd_kernel
+bool avlen_i_gru_step_ok(int N, int H) { return N <= 64 && H <= 64 * GRU_HP; }
+int avlen_i_gru_step_fwd(const avlen_gru* p, const float* gi, const float* hprev, const float* mask, float* out, int N,
+                         hipStream_t st) {
+  const int H = p->hidden;
+  auto kern = N <= 8 ? gru_step_fwd_kernel<8> : gru_step_fwd_kernel<16>;
+  hipLaunchKernelGGL(kern, dim3(ceil_div(H, 4)), dim3(256), 0, st, p->w_hh, p->b_hh, gi, hprev, mask, out,
+                     (float*)nullptr, (float*)nullptr, N, H);
+  return avlen_launch_status();
+}
+
 extern "C" size_t avlen_baseline_train_workspace_bytes(const avlen_cnn3* audio, const avlen_cnn3* visual, const avlen_gru* gru,
                                                        int T, int N, int Ha, int Wa, int S, int prec) {
   WsBump w(nullptr, 0);
@@ -330,16 +455,15 @@ extern "C" int avlen_baseline_train_fwd(const avlen_cnn3* audio, const avlen_cnn
   TRY(cnn_fwd(c, audio, spec, R, Ha, Wa, s.aud, s.X, F));
   TRY(cnn_fwd(c, visual, s.rgbd, R, S, S, s.vis, s.X + audio->fc.out_f, F));
   if (ncat) TRY(avlen_copy_rows(category, ncat, s.X + audio->fc.out_f + visual->fc.out_f, F, (int)R, ncat, st));
-  avlen_linear ih{gru->w_ih, gru->b_ih, 3 * H, F, nullptr, 0}, hh{gru->w_hh, gru->b_hh, 3 * H, H, nullptr, 0};
+  avlen_linear ih{gru->w_ih, gru->b_ih, 3 * H, F, nullptr, 0};
   TRY(avlen_i_linear(c, ih, s.X, F, s.GI, 3 * H, (int)R, 0, nullptr, 0));
+  if (H > 64 * GRU_HP) return AVLEN_ERR_ARG;
   const float* hprev = h0;
-  const dim3 g((unsigned)(((long)N * H + 255) / 256));
-  avlen_ctx cs = c; cs.xs = nullptr;                     // N-row products of the recurrence: never the large-M route
   for (int t = 0; t < T; t++) {
-    float* hm = s.HM + (size_t)t * N * H; float* gh = s.GH + (size_t)t * N * 3 * H;
-    hipLaunchKernelGGL(gru_mask_kernel, g, dim3(256), 0, st, hprev, masks + (size_t)t * N, hm, N, H);
-    TRY(avlen_i_linear(cs, hh, hm, H, gh, 3 * H, N, 0, nullptr, 0));
-    hipLaunchKernelGGL(gru_gate_kernel, g, dim3(256), 0, st, s.GI + (size_t)t * N * 3 * H, gh, hm, out + (size_t)t * N * H, N, H);
+    auto kern = N <= 8 ? gru_step_fwd_kernel<8> : gru_step_fwd_kernel<16>;
+    hipLaunchKernelGGL(kern, dim3(ceil_div(H, 4)), dim3(256), 0, st, gru->w_hh, gru->b_hh,
+                       s.GI + (size_t)t * N * 3 * H, hprev, masks + (size_t)t * N, out + (size_t)t * N * H,
+                       s.HM + (size_t)t * N * H, s.GH + (size_t)t * N * 3 * H, N, H);
     hprev = out + (size_t)t * N * H;
   }
   TRY(avlen_launch_status());
@@ -359,19 +483,17 @@ extern "C" int avlen_baseline_train_bwd(const avlen_cnn3* audio, const avlen_cnn
   const long R = (long)T * N;
   avlen_ctx c{st, prec, s.gws, GEMM_SCRATCH};
   c.xs = s.xs; c.xs_bytes = s.xs_bytes;
-  avlen_ctx cs = c; cs.xs = nullptr;
-  // ---- BPTT through the masked GRU
-  avlen_linear hh{gru->w_hh, gru->b_hh, 3 * H, H, nullptr, 0};
-  const dim3 g((unsigned)(((long)N * H + 255) / 256));
-  const float* carry = nullptr;
+  // ---- BPTT through the masked GRU: one launch per step (see gru_step_bwd_kernel)
+  if (3 * H > 64 * GRU_KP || H % 4) return AVLEN_ERR_ARG;
+  hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(3 * H, 32), ceil_div(H, 32)), dim3(32, 8), 0, st, gru->w_hh, s.whhT, 3 * H, H);
   for (int t = T - 1; t >= 0; t--) {
-    float* dhm = s.dh[t & 1];
-    float* dgh = s.dGH + (size_t)t * N * 3 * H;
-    hipLaunchKernelGGL(gru_gate_bwd_kernel, g, dim3(256), 0, st, s.GI + (size_t)t * N * 3 * H, s.GH + (size_t)t * N * 3 * H,
-                       s.HM + (size_t)t * N * H, d_out + (size_t)t * N * H, carry, carry ? masks + (size_t)(t + 1) * N : nullptr,
-                       s.dGI + (size_t)t * N * 3 * H, dgh, dhm, N, H);
-    if (t > 0) TRY(avlen_i_linear_dx(cs, hh, dgh, 3 * H, dhm, H, N, dhm, H));       // dhm += dGH W_hh  (h0 is data: not needed at t = 0)
-    carry = dhm;
+    const bool last = t == T - 1;
+    // 8 rows per pass: 8 x 3H floats of LDS (48 KB at H = 512)
+    hipLaunchKernelGGL(gru_step_bwd_kernel<8>, dim3(ceil_div(H, 4)), dim3(256), (size_t)8 * 3 * H * sizeof(float), st, s.whhT, s.GI + (size_t)t * N * 3 * H,
+                       s.GH + (size_t)t * N * 3 * H, s.HM + (size_t)t * N * H, d_out + (size_t)t * N * H,
+                       last ? nullptr : s.dGH + (size_t)(t + 1) * N * 3 * H, last ? nullptr : s.dh[(t + 1) & 1],
+                       last ? nullptr : masks + (size_t)(t + 1) * N, s.dGI + (size_t)t * N * 3 * H, s.dGH + (size_t)t * N * 3 * H,
+                       s.dh[t & 1], N, H);
   }
   TRY(avlen_launch_status());
   avlen_linear Gih{g_gru->w_ih, nullptr, 3 * H, F, nullptr, 0}, Ghh{g_gru->w_hh, nullptr, 3 * H, H, nullptr, 0};
