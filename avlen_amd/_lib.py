@@ -138,15 +138,15 @@ SIGNATURES = {
                                   i32, i32, i32, i32, i32, i32, f32, vp]),
     "avlen_attention_bwd_bf16": (i32, [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, i32, vp, i32,
                                   i32, i32, i32, i32, i32, i32, f32, vp]),
-    "avlen_preprocess_image": (i32, [vp, vp, i32, i32, i32, f32, vp]),
-    "avlen_rgbd_concat": (i32, [vp, vp, vp, i32, i32, vp]),
+    "avlen_preprocess_image": (i32, [vp, i32, vp, i32, i32, i32, f32, vp]),
+    "avlen_rgbd_concat": (i32, [vp, i32, vp, vp, i32, i32, vp]),
     "avlen_feature_assemble": (i32, [vp, i32, C.POINTER(Linear), vp, i32, vp, i32, vp, i32, vp, i32, i32, vp, vp, vp,
                                      i32, i32, vp]),
     "avlen_concat_rows": (i32, [vp, i32, i32, vp, i32, i32, vp, i32, i32, vp]),
     "avlen_resnet18_workspace_bytes": (sz, [i32]),
-    "avlen_resnet18_fwd": (i32, [C.POINTER(ResNet18), vp, i32, i32, i32, f32, vp, i32, i32, vp, sz, vp]),
+    "avlen_resnet18_fwd": (i32, [C.POINTER(ResNet18), vp, i32, i32, i32, i32, f32, vp, i32, i32, vp, sz, vp]),
     "avlen_resnet18_group_workspace_bytes": (sz, [i32, i32]),
-    "avlen_resnet18_group_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp]),
+    "avlen_resnet18_group_fwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp]),
     "avlen_resnet18_any_workspace_bytes": (sz, [i32, i32, i32]),
     "avlen_resnet18_any_fwd": (i32, [C.POINTER(ResNet18), vp, i32, i32, i32, i32, vp, i32, i32, vp, sz, vp]),
     "avlen_resnet18_tv_workspace_bytes": (sz, [i32, i32, i32]),
@@ -154,7 +154,7 @@ SIGNATURES = {
     "avlen_belief_input": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "avlen_belief_update": (i32, [vp, i32, vp, i32, vp, i32, vp, C.c_long, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32,
                                   i32, vp]),
-    "avlen_resnet18_group_fwd_indexed": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, sz, vp]),
+    "avlen_resnet18_group_fwd_indexed": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, sz, vp]),
     "avlen_cnn3_fwd_indexed": (i32, [C.POINTER(Cnn3), vp, vp, i32, i32, i32, vp, i32, vp, sz, vp]),
     "avlen_cnn3_workspace_bytes": (sz, [C.POINTER(Cnn3), i32, i32, i32]),
     "avlen_cnn3_fwd": (i32, [C.POINTER(Cnn3), vp, i32, i32, i32, vp, i32, i32, vp, sz, vp]),
@@ -176,7 +176,7 @@ SIGNATURES = {
     "avlen_gae_scan": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, vp]),
     "avlen_discounted_returns": (i32, [vp, vp, vp, vp, i32, i32, f32, vp]),
     "avlen_baseline_train_workspace_bytes": (sz, [C.POINTER(Cnn3), C.POINTER(Cnn3), C.POINTER(Gru), i32, i32, i32, i32, i32, i32]),
-    "avlen_baseline_train_fwd": (i32, [C.POINTER(Cnn3), C.POINTER(Cnn3), C.POINTER(Gru), vp, vp, vp, vp, i32, vp, vp, vp, vp,
+    "avlen_baseline_train_fwd": (i32, [C.POINTER(Cnn3), C.POINTER(Cnn3), C.POINTER(Gru), vp, vp, i32, vp, vp, i32, vp, vp, vp, vp,
                                        i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     "avlen_baseline_train_bwd": (i32, [C.POINTER(Cnn3), C.POINTER(Cnn3), C.POINTER(Gru), C.POINTER(Cnn3), C.POINTER(Cnn3),
                                        C.POINTER(Gru), vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, sz, vp]),

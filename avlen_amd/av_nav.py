@@ -24,10 +24,12 @@ EPS_PPO = 1e-5
 
 class RolloutStorage:
     def __init__(self, num_steps, num_envs, observation_space, action_space, recurrent_hidden_state_size,
-                 num_recurrent_layers=1, device="cuda"):
+                 num_recurrent_layers=1, device="cuda", uint8_sensors=("rgb",)):
         T, N, dev = num_steps, num_envs, torch.device(device)
         z = lambda *s, **k: torch.zeros(*s, device=dev, **k)
-        self.observations = {k: z(T + 1, N, *sp.shape) for k, sp in observation_space.spaces.items()}
+        # RGB stays uint8 (see avlen_amd/rollout_storage.py): a quarter of the bytes to store and to read back
+        self.observations = {k: z(T + 1, N, *sp.shape, dtype=torch.uint8 if k in uint8_sensors else torch.float32)
+                             for k, sp in observation_space.spaces.items()}
         self.recurrent_hidden_states = z(T + 1, num_recurrent_layers, N, recurrent_hidden_state_size)
         self.rewards, self.value_preds, self.returns = z(T, N, 1), z(T + 1, N, 1), z(T + 1, N, 1)
         self.action_log_probs = z(T, N, 1)
@@ -77,7 +79,11 @@ class RolloutStorage:
         for d in src.shape[2:]:
             D *= d
         dst = torch.empty((T * n_mb,) + tuple(src.shape[2:]), dtype=src.dtype, device=src.device)
-        L.call("avlen_minibatch_gather", P(src), P(dst), P(env), T, self.num_envs, n_mb, D, src.element_size(), L.stream())
+        es = src.element_size()
+        if es == 1:                                        # uint8 frames move as 4-byte words
+            assert D % 4 == 0
+            D, es = D // 4, 4
+        L.call("avlen_minibatch_gather", P(src), P(dst), P(env), T, self.num_envs, n_mb, D, es, L.stream())
         return dst
 
     def recurrent_generator(self, advantages, num_mini_batch):

@@ -5,15 +5,17 @@
 
 namespace {
 
-// (B,S,S,C) fp32 -> (x/div, kxk mean) -> (B,64,64,8) bf16, channels >= C zero.  One thread per output pixel.
+// (B,S,S,C) fp32 or uint8 (RGB stays uint8 from the simulator to here) -> (x/div, kxk mean) -> (B,64,64,8) bf16,
+// channels >= C zero.  One thread per output pixel.  uint8 pixels are converted to float first: bit-identical to fp32 storage.
 // row_index (optional): image b of the batch is image row_index[b] of x (the PPO minibatch reads the rollout storage in place)
-__global__ void preprocess_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ y, int B, int S, int C, int k, float div,
+template <typename T>
+__global__ void preprocess_bf16_kernel(const T* __restrict__ x, __bf16* __restrict__ y, int B, int S, int C, int k, float div,
                                        const int* __restrict__ row_index) {
   long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (pix >= (long)B * 4096) return;
   int ox = (int)(pix % 64), oy = (int)((pix / 64) % 64), b = (int)(pix / 4096);
   const long bs = row_index ? row_index[b] : b;
-  const float* src = x + ((bs * S + oy * k) * S + ox * k) * C;
+  const T* src = x + ((bs * S + oy * k) * S + ox * k) * C;
   typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8v;
   bf16x8v o;
 #pragma unroll
@@ -21,7 +23,7 @@ __global__ void preprocess_bf16_kernel(const float* __restrict__ x, __bf16* __re
     float s = 0.f;
     if (c < C) {
       for (int dy = 0; dy < k; dy++)
-        for (int dx = 0; dx < k; dx++) s += src[((long)dy * S + dx) * C + c] / div;
+        for (int dx = 0; dx < k; dx++) s += (float)src[((long)dy * S + dx) * C + c] / div;
       s /= (float)(k * k);
     }
     o[c] = (__bf16)s;
@@ -47,7 +49,8 @@ __global__ void preprocess_kernel(const float* __restrict__ x, float* __restrict
   y[idx] = s * scale / (float)(k * k);
 }
 
-__global__ void preprocess_exact_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int S, int C, int k,
+template <typename T>
+__global__ void preprocess_exact_kernel(const T* __restrict__ x, float* __restrict__ y, int B, int S, int C, int k,
                                         float div) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long tot = (long)B * 64 * 64 * C;
@@ -55,19 +58,20 @@ __global__ void preprocess_exact_kernel(const float* __restrict__ x, float* __re
   int c = (int)(idx % C);
   long p = idx / C;
   int ox = (int)(p % 64), oy = (int)((p / 64) % 64), b = (int)(p / 4096);
-  const float* src = x + (((long)b * S + oy * k) * S + ox * k) * C + c;
+  const T* src = x + (((long)b * S + oy * k) * S + ox * k) * C + c;
   float s = 0.f;
   for (int dy = 0; dy < k; dy++)
-    for (int dx = 0; dx < k; dx++) s += src[((long)dy * S + dx) * C] / div;   // same rounding as x/255 then mean
+    for (int dx = 0; dx < k; dx++) s += (float)src[((long)dy * S + dx) * C] / div;   // same rounding as x/255 then mean
   y[idx] = s / (float)(k * k);
 }
 
-__global__ void rgbd_concat_kernel(const float* __restrict__ rgb, const float* __restrict__ depth,
+template <typename T>
+__global__ void rgbd_concat_kernel(const T* __restrict__ rgb, const float* __restrict__ depth,
                                    float* __restrict__ y, long npix) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npix) return;
   float4 o;
-  o.x = rgb[i * 3] / 255.0f; o.y = rgb[i * 3 + 1] / 255.0f; o.z = rgb[i * 3 + 2] / 255.0f; o.w = depth[i];
+  o.x = (float)rgb[i * 3] / 255.0f; o.y = (float)rgb[i * 3 + 1] / 255.0f; o.z = (float)rgb[i * 3 + 2] / 255.0f; o.w = depth[i];
   reinterpret_cast<float4*>(y)[i] = o;
 }
 
@@ -142,27 +146,35 @@ __global__ void copy_rows_kernel(const float* __restrict__ src, int lds, float* 
 
 static inline dim3 grid1d(long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
 
-extern "C" int avlen_preprocess_image(const float* x, float* y, int B, int S, int C, float divisor, hipStream_t stream) {
+extern "C" int avlen_preprocess_image(const void* x, int x_u8, float* y, int B, int S, int C, float divisor, hipStream_t stream) {
   if (S % 64 || B <= 0) return AVLEN_ERR_ARG;
   long tot = (long)B * 4096 * C;
-  if (divisor == 1.0f)
-    hipLaunchKernelGGL(preprocess_kernel, grid1d(tot), dim3(256), 0, stream, x, y, B, S, C, S / 64, 1.0f);
+  if (x_u8)
+    hipLaunchKernelGGL(preprocess_exact_kernel<uint8_t>, grid1d(tot), dim3(256), 0, stream, (const uint8_t*)x, y, B, S, C, S / 64, divisor);
+  else if (divisor == 1.0f)
+    hipLaunchKernelGGL(preprocess_kernel, grid1d(tot), dim3(256), 0, stream, (const float*)x, y, B, S, C, S / 64, 1.0f);
   else
-    hipLaunchKernelGGL(preprocess_exact_kernel, grid1d(tot), dim3(256), 0, stream, x, y, B, S, C, S / 64, divisor);
+    hipLaunchKernelGGL(preprocess_exact_kernel<float>, grid1d(tot), dim3(256), 0, stream, (const float*)x, y, B, S, C, S / 64, divisor);
   return avlen_launch_status();
 }
 
-int avlen_preprocess_image_bf16(const float* x, void* y16, int B, int S, int C, float divisor, hipStream_t stream,
+int avlen_preprocess_image_bf16(const void* x, int x_u8, void* y16, int B, int S, int C, float divisor, hipStream_t stream,
                                 const int* row_index) {
   if (S % 64 || B <= 0 || C > 8) return AVLEN_ERR_ARG;
   long tot = (long)B * 4096;
-  hipLaunchKernelGGL(preprocess_bf16_kernel, grid1d(tot), dim3(256), 0, stream, x, (__bf16*)y16, B, S, C, S / 64, divisor, row_index);
+  if (x_u8)
+    hipLaunchKernelGGL(preprocess_bf16_kernel<uint8_t>, grid1d(tot), dim3(256), 0, stream, (const uint8_t*)x, (__bf16*)y16, B, S, C,
+                       S / 64, divisor, row_index);
+  else
+    hipLaunchKernelGGL(preprocess_bf16_kernel<float>, grid1d(tot), dim3(256), 0, stream, (const float*)x, (__bf16*)y16, B, S, C, S / 64,
+                       divisor, row_index);
   return avlen_launch_status();
 }
 
-extern "C" int avlen_rgbd_concat(const float* rgb, const float* depth, float* y, int B, int HW, hipStream_t stream) {
+extern "C" int avlen_rgbd_concat(const void* rgb, int rgb_u8, const float* depth, float* y, int B, int HW, hipStream_t stream) {
   long npix = (long)B * HW;
-  hipLaunchKernelGGL(rgbd_concat_kernel, grid1d(npix), dim3(256), 0, stream, rgb, depth, y, npix);
+  if (rgb_u8) hipLaunchKernelGGL(rgbd_concat_kernel<uint8_t>, grid1d(npix), dim3(256), 0, stream, (const uint8_t*)rgb, depth, y, npix);
+  else hipLaunchKernelGGL(rgbd_concat_kernel<float>, grid1d(npix), dim3(256), 0, stream, (const float*)rgb, depth, y, npix);
   return avlen_launch_status();
 }
 

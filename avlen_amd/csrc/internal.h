@@ -32,7 +32,7 @@ int avlen_attention_fwd16(const float* Q, int ldq, const float* K, int ldk, cons
                           void* O16, int ldo16, const float* key_mask, float* lse, int B, int H, int Sq, int Sk, int D,
                           int causal, float scale, hipStream_t stream);
 int avlen_zero_bytes(void* p, size_t bytes, hipStream_t stream);      // zero fill as kernel node(s) under capture
-int avlen_preprocess_image_bf16(const float* x, void* y16, int B, int S, int C, float divisor, hipStream_t stream,
+int avlen_preprocess_image_bf16(const void* x, int x_u8, void* y16, int B, int S, int C, float divisor, hipStream_t stream,
                                 const int* row_index = nullptr);
 // rows are grouped in items of `rows_per_item`; item i of the batch is item row_index[i] of src
 int avlen_cast_bf16_indexed(const float* src, int ld_src, void* dst, int ld_dst, long rows, int cols, const int* row_index,

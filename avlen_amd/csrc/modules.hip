@@ -589,7 +589,7 @@ bool resnet18_has16(const avlen_resnet18* n) {
 }
 
 // G towers of identical shape in lock-step: every conv / GroupNorm / fc is ONE grouped launch (blockIdx.y = tower).
-int resnet18_group_fwd_bf16(const avlen_resnet18* const* nets, const float* const* imgs, const int* channels,
+int resnet18_group_fwd_bf16(const avlen_resnet18* const* nets, const void* const* imgs, const int* img_u8, const int* channels,
                             const float* divisors, float* const* outs, int ld_out, int G, int B, int S, void* ws,
                             size_t ws_bytes, hipStream_t st, const int* row_index = nullptr) {
   if (G < 1 || G > 8 || ws_bytes < (size_t)G * resnet18_ws_bf16(B)) return AVLEN_ERR_WS;
@@ -614,7 +614,7 @@ int resnet18_group_fwd_bf16(const avlen_resnet18* const* nets, const float* cons
     for (int h = 0; h < g && same < 0; h++)
       if (imgs[h] == imgs[g] && channels[h] == channels[g] && divisors[h] == divisors[g]) same = h;
     if (same >= 0) { x0[g] = x0[same]; continue; }
-    TRY(avlen_preprocess_image_bf16(imgs[g], x0[g], B, S, channels[g], divisors[g], st, row_index));
+    TRY(avlen_preprocess_image_bf16(imgs[g], img_u8 ? img_u8[g] : 0, x0[g], B, S, channels[g], divisors[g], st, row_index));
   }
   const void* X[8]; const void* Wt[8]; void* Y[8]; float* ST[8]; float* ST2[8]; float* ST3[8];
   const float* GA[8]; const float* BE[8]; const void* RES[8]; void* OUT[8]; const void* XR[8];
@@ -718,9 +718,9 @@ int resnet18_group_fwd_bf16(const avlen_resnet18* const* nets, const float* cons
   return avlen_gemm_bf16_grouped(FA, fc.ld16, FB, fc.ld16, outs, ld_out, FBI, G, B, fc.out_f, fc.ld16, 0, gws, gwsb, st);
 }
 
-int resnet18_fwd_bf16(const avlen_resnet18* net, const float* img, int B, int S, int C, float divisor, float* out,
+int resnet18_fwd_bf16(const avlen_resnet18* net, const void* img, int img_u8, int B, int S, int C, float divisor, float* out,
                       int ld_out, void* ws, size_t ws_bytes, hipStream_t st) {
-  return resnet18_group_fwd_bf16(&net, &img, &C, &divisor, &out, ld_out, 1, B, S, ws, ws_bytes, st);
+  return resnet18_group_fwd_bf16(&net, &img, &img_u8, &C, &divisor, &out, ld_out, 1, B, S, ws, ws_bytes, st);
 }
 
 // ---- 3-conv CNNs ----
@@ -854,25 +854,25 @@ extern "C" size_t avlen_resnet18_workspace_bytes(int B) {
 
 extern "C" size_t avlen_resnet18_group_workspace_bytes(int groups, int B) { return (size_t)groups * resnet18_ws_bf16(B) + 4096; }
 
-extern "C" int avlen_resnet18_group_fwd(const avlen_resnet18* const* nets, const float* const* imgs, const int* channels,
+extern "C" int avlen_resnet18_group_fwd(const avlen_resnet18* const* nets, const void* const* imgs, const int* img_u8, const int* channels,
                                         const float* divisors, float* const* outs, int ld_out, int groups, int B, int S,
                                         void* ws, size_t ws_bytes, hipStream_t st) {
   if (!nets || groups < 1 || groups > 8 || B <= 0) return AVLEN_ERR_ARG;
-  return resnet18_group_fwd_bf16(nets, imgs, channels, divisors, outs, ld_out, groups, B, S, ws, ws_bytes, st);
+  return resnet18_group_fwd_bf16(nets, imgs, img_u8, channels, divisors, outs, ld_out, groups, B, S, ws, ws_bytes, st);
 }
 
-extern "C" int avlen_resnet18_group_fwd_indexed(const avlen_resnet18* const* nets, const float* const* imgs, const int* channels,
+extern "C" int avlen_resnet18_group_fwd_indexed(const avlen_resnet18* const* nets, const void* const* imgs, const int* img_u8, const int* channels,
                                                 const float* divisors, float* const* outs, int ld_out, int groups, int B, int S,
                                                 const int32_t* row_index, void* ws, size_t ws_bytes, hipStream_t st) {
   if (!nets || groups < 1 || groups > 8 || B <= 0) return AVLEN_ERR_ARG;
-  return resnet18_group_fwd_bf16(nets, imgs, channels, divisors, outs, ld_out, groups, B, S, ws, ws_bytes, st, row_index);
+  return resnet18_group_fwd_bf16(nets, imgs, img_u8, channels, divisors, outs, ld_out, groups, B, S, ws, ws_bytes, st, row_index);
 }
 
-extern "C" int avlen_resnet18_fwd(const avlen_resnet18* net, const float* img, int B, int S, int C, float divisor,
+extern "C" int avlen_resnet18_fwd(const avlen_resnet18* net, const void* img, int img_u8, int B, int S, int C, float divisor,
                                   float* out, int ld_out, int prec, void* ws, size_t ws_bytes, hipStream_t st) {
   if (!net || B <= 0 || ws_bytes < avlen_resnet18_workspace_bytes(B)) return AVLEN_ERR_WS;
   if (prec == AVLEN_PREC_BF16 && resnet18_has16(net) && C <= 8)
-    return resnet18_fwd_bf16(net, img, B, S, C, divisor, out, ld_out, ws, ws_bytes, st);
+    return resnet18_fwd_bf16(net, img, img_u8, B, S, C, divisor, out, ld_out, ws, ws_bytes, st);
   WsBump w(ws, ws_bytes);
   size_t act = (size_t)B * 64 * 64 * 16;
   float* x0 = w.take<float>(act);
@@ -882,7 +882,7 @@ extern "C" int avlen_resnet18_fwd(const avlen_resnet18* net, const float* img, i
   void* gws = w.take<char>(GEMM_SCRATCH);
   Ctx c{st, prec, gws, GEMM_SCRATCH};
 
-  TRY(avlen_preprocess_image(img, x0, B, S, C, divisor, st));
+  TRY(avlen_preprocess_image(img, img_u8, x0, B, S, C, divisor, st));
   const avlen_conv& c1 = net->conv1;
   TRY(avlen_conv2d_nhwc(x0, c1.w, nullptr, nullptr, buf[0], B, 64, 64, c1.cin, c1.cout, c1.kh, c1.kw, c1.stride, c1.pad,
                         0, prec, st));

@@ -290,12 +290,6 @@ __global__ void transpose_kernel(const float* __restrict__ src, float* __restric
   }
 }
 
-__global__ void rgbd_concat_kernel(const float* __restrict__ rgb, const float* __restrict__ depth, float* __restrict__ y, long n) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;          // pixel index
-  if (i >= n) return;
-  float4 o; o.x = rgb[i * 3] * (1.f / 255.f); o.y = rgb[i * 3 + 1] * (1.f / 255.f); o.z = rgb[i * 3 + 2] * (1.f / 255.f); o.w = depth[i];
-  ((float4*)y)[i] = o;
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // workspace layout (identical in forward and backward)
@@ -438,7 +432,7 @@ extern "C" size_t avlen_baseline_train_workspace_bytes(const avlen_cnn3* audio, 
 }
 
 extern "C" int avlen_baseline_train_fwd(const avlen_cnn3* audio, const avlen_cnn3* visual, const avlen_gru* gru,
-                                        const float* spec, const float* rgb, const float* depth, const float* category, int ncat,
+                                        const float* spec, const void* rgb, int rgb_u8, const float* depth, const float* category, int ncat,
                                         const float* h0, const float* masks, float* out, float* h_out, int T, int N, int Ha, int Wa,
                                         int S, int prec, void* ws, size_t ws_bytes, hipStream_t st) {
   if (!audio || !visual || !gru || T <= 0 || N <= 0) return AVLEN_ERR_ARG;
@@ -450,8 +444,7 @@ extern "C" int avlen_baseline_train_fwd(const avlen_cnn3* audio, const avlen_cnn
   const long R = (long)T * N;
   avlen_ctx c{st, prec, s.gws, GEMM_SCRATCH};
   c.xs = s.xs; c.xs_bytes = s.xs_bytes;
-  const long px = R * S * S;
-  hipLaunchKernelGGL(rgbd_concat_kernel, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, st, rgb, depth, s.rgbd, px);
+  TRY(avlen_rgbd_concat(rgb, rgb_u8, depth, s.rgbd, (int)R, S * S, st));
   TRY(cnn_fwd(c, audio, spec, R, Ha, Wa, s.aud, s.X, F));
   TRY(cnn_fwd(c, visual, s.rgbd, R, S, S, s.vis, s.X + audio->fc.out_f, F));
   if (ncat) TRY(avlen_copy_rows(category, ncat, s.X + audio->fc.out_f + visual->fc.out_f, F, (int)R, ncat, st));

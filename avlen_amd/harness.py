@@ -88,7 +88,8 @@ class Workload:
         H, W, _ = self.spec
         r = lambda *s: torch.rand(*s, generator=g)
         self.sim = {
-            "rgb": torch.randint(0, 256, (T + 1, N, 128, 128, 3), generator=g, dtype=torch.uint8).to(dev).float(),
+            # uint8 as the simulator's RGB sensor produces it: stays uint8 through the storage into the tower prologue (f2)
+            "rgb": torch.randint(0, 256, (T + 1, N, 128, 128, 3), generator=g, dtype=torch.uint8).to(dev),
             "depth": r(T + 1, N, 128, 128, 1).to(dev),
             "spectrogram": torch.log1p(3.0 * torch.randn(T + 1, N, H, W, 2, generator=g).abs()).to(dev),
             "category": torch.nn.functional.one_hot(torch.randint(0, 21, (T + 1, N), generator=g), 21).float().to(dev),
@@ -247,7 +248,7 @@ class GruWorkload:
         H, W, _ = spectrogram
         r = lambda *s_: torch.rand(*s_, generator=g)
         self.sim = {
-            "rgb": torch.randint(0, 256, (T + 1, N, 128, 128, 3), generator=g, dtype=torch.uint8).to(dev).float(),
+            "rgb": torch.randint(0, 256, (T + 1, N, 128, 128, 3), generator=g, dtype=torch.uint8).to(dev),
             "depth": r(T + 1, N, 128, 128, 1).to(dev),
             "spectrogram": torch.log1p(3.0 * torch.randn(T + 1, N, H, W, 2, generator=g).abs()).to(dev),
             "category": torch.nn.functional.one_hot(torch.randint(0, 21, (T + 1, N), generator=g), 21).float().to(dev),

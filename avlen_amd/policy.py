@@ -33,7 +33,8 @@ class RowsOf:
     minibatch of the rollout storage) instead of being gathered first.  Only the bf16 encoders take it."""
 
     def __init__(self, base, index):
-        assert base.dtype == torch.float32 and base.is_contiguous() and index.dtype == torch.int32 and index.is_contiguous()
+        assert base.dtype in (torch.float32, torch.uint8) and base.is_contiguous() and index.dtype == torch.int32 \
+            and index.is_contiguous()
         self.base, self.index = base, index
         self.shape = (index.numel(),) + tuple(base.shape[1:])
         self.device = base.device
@@ -48,6 +49,20 @@ def _f32(t):
     if t.dtype != torch.float32:
         t = t.float()
     return t if t.is_contiguous() else t.contiguous()
+
+
+def _img(t):
+    """An image sensor as the kernels take it: uint8 pixels stay uint8 (RGB is kept uint8 from the simulator through the
+    rollout storage into the tower prologue, which converts and divides exactly as the fp32 path does); anything else fp32."""
+    if isinstance(t, RowsOf):
+        return t
+    if t.dtype == torch.uint8:
+        return t if t.is_contiguous() else t.contiguous()
+    return _f32(t)
+
+
+def _u8(t):
+    return 1 if (t.base if isinstance(t, RowsOf) else t).dtype == torch.uint8 else 0
 
 
 def _i64(t):
@@ -168,7 +183,7 @@ def _sig(a):
     if torch.is_tensor(a):
         return (tuple(a.shape), a.dtype)
     if isinstance(a, dict):
-        return tuple((k, tuple(v.shape)) for k, v in sorted(a.items()))
+        return tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(a.items()))
     return a
 
 
@@ -222,7 +237,7 @@ def _graphed(pol, which, fn, args, mode=None):
     args = list(args)
     rnn = args[1]
     args[1], args[3] = None, None
-    args[0] = {k: _f32(v) for k, v in args[0].items() if k in pol.net.obs_keys}
+    args[0] = {k: (_img(v) if k == "rgb" else _f32(v)) for k, v in args[0].items() if k in pol.net.obs_keys}
     by_ptr = (4, 5) if which == "vln" else (4,)          # ext_memory (+ dialog memory): persistent ring buffers
     for i in by_ptr:
         if torch.is_tensor(args[i]):
@@ -327,7 +342,7 @@ class EncoderGroup:
         G = 2 * len(self.members)
         nets = (C.POINTER(L.ResNet18) * G)()
         imgs, outs = (C.c_void_p * G)(), (C.c_void_p * G)()
-        chans, divs = (C.c_int * G)(), (C.c_float * G)()
+        chans, divs, u8 = (C.c_int * G)(), (C.c_float * G)(), (C.c_int * G)()
         for i, m in enumerate(self.members):
             eng = m._engine()
             for j, (key, img, div) in enumerate((("rgb", rgb, 255.0), ("depth", depth, 1.0))):
@@ -335,10 +350,10 @@ class EncoderGroup:
                 nets[g] = C.pointer(eng[key])
                 imgs[g] = img.data_ptr()
                 outs[g] = bufs[i].data_ptr() + 4 * 64 * j
-                chans[g], divs[g] = img.shape[3], div
+                chans[g], divs[g], u8[g] = img.shape[3], div, _u8(img)
         nb = L.lib.avlen_resnet18_group_workspace_bytes(G, B)
         ws = pol._ws.get("resnet_group", nb, dev)
-        L.call("avlen_resnet18_group_fwd", nets, imgs, chans, divs, outs, 128, G, B, rgb.shape[1], E.P(ws), nb, L.stream())
+        L.call("avlen_resnet18_group_fwd", nets, imgs, u8, chans, divs, outs, 128, G, B, rgb.shape[1], E.P(ws), nb, L.stream())
         return bufs[0]
 
 
@@ -779,7 +794,7 @@ class _SMTBase(Net):
     def features(self, pol, obs, prev_actions, extra=None):
         """-> feats (B, F) = [visual 128 | action 16 | audio 128 | (category 21) | pose 4 | (extra)], goal (B,d)."""
         eng = pol._engine()
-        rgb, depth, spec = _f32(obs["rgb"]), _f32(obs["depth"]), _f32(obs[SPECTROGRAM])
+        rgb, depth, spec = _img(obs["rgb"]), _f32(obs["depth"]), _f32(obs[SPECTROGRAM])
         idx = None
         if isinstance(rgb, RowsOf):                      # minibatch rows of the storage, read in place (bf16 encoders only)
             if pol.prec == L.PREC_BF16 and pol._shared_mode is None and isinstance(depth, RowsOf) and isinstance(spec, RowsOf) \
@@ -834,12 +849,14 @@ class _SMTBase(Net):
                                          (rgb.data_ptr(), depth.data_ptr())))
                 outs = (C.c_void_p * G)(feats.data_ptr(), feats.data_ptr() + 4 * 64)
                 chans, divs = (C.c_int * G)(rgb.shape[3], depth.shape[3]), (C.c_float * G)(255.0, 1.0)
+                u8 = (C.c_int * G)(_u8(rgb), 0)
                 nbg = L.lib.avlen_resnet18_group_workspace_bytes(G, B)
                 wsg = pol._ws.get("resnet_pair", nbg, dev)
                 if idx is not None:
-                    L.call("avlen_resnet18_group_fwd_indexed", nets, imgs, chans, divs, outs, F, G, B, S, E.P(idx), E.P(wsg), nbg, st)
+                    L.call("avlen_resnet18_group_fwd_indexed", nets, imgs, u8, chans, divs, outs, F, G, B, S, E.P(idx), E.P(wsg), nbg,
+                           st)
                 else:
-                    L.call("avlen_resnet18_group_fwd", nets, imgs, chans, divs, outs, F, G, B, S, E.P(wsg), nbg, st)
+                    L.call("avlen_resnet18_group_fwd", nets, imgs, u8, chans, divs, outs, F, G, B, S, E.P(wsg), nbg, st)
             if vis is not None:
                 L.call("avlen_copy_rows", E.P(vis), 128, E.P(feats), F, B, 128, st)
             s_rgb = s_dep = s_aud
@@ -852,10 +869,10 @@ class _SMTBase(Net):
                 s_rgb.wait_stream(cur)
                 s_dep.wait_stream(cur)
             with torch.cuda.stream(s_rgb):
-                L.call("avlen_resnet18_fwd", C.byref(eng["rgb"]), E.P(rgb), B, S, rgb.shape[3], 255.0, E.P(feats, 0), F, prec,
+                L.call("avlen_resnet18_fwd", C.byref(eng["rgb"]), E.P(rgb), _u8(rgb), B, S, rgb.shape[3], 255.0, E.P(feats, 0), F, prec,
                        E.P(ws_rgb), nb, L.stream())
             with torch.cuda.stream(s_dep):
-                L.call("avlen_resnet18_fwd", C.byref(eng["depth"]), E.P(depth), B, S, depth.shape[3], 1.0, E.P(feats, 64), F,
+                L.call("avlen_resnet18_fwd", C.byref(eng["depth"]), E.P(depth), 0, B, S, depth.shape[3], 1.0, E.P(feats, 64), F,
                        prec, E.P(ws_dep), nb, L.stream())
             L.call("avlen_cnn3_fwd", C.byref(eng["audio"]), E.P(spec), B, H, W, E.P(feats, 144), F, prec, E.P(ws2), nb2, st)
         pa = _i64(prev_actions.view(B, -1)[:, :1])
@@ -1120,7 +1137,7 @@ class AudioNavBaselineNet(Net):
 
     def run(self, pol, observations, rnn_hidden_states, prev_actions, masks, ext_memory=None, ext_memory_masks=None):
         eng = pol._engine()
-        rgb, depth, spec = _f32(observations["rgb"]), _f32(observations["depth"]), _f32(observations[SPECTROGRAM])
+        rgb, depth, spec = _img(observations["rgb"]), _f32(observations["depth"]), _f32(observations[SPECTROGRAM])
         R = rgb.shape[0]
         dev = rgb.device
         st = L.stream()
@@ -1132,7 +1149,7 @@ class AudioNavBaselineNet(Net):
         L.call("avlen_cnn3_fwd", C.byref(eng["audio"]), E.P(spec), R, H, W, E.P(x, 0), F, pol.prec, E.P(ws), nb, st)
         S = rgb.shape[1]
         rgbd = torch.empty(R, S, S, 4, device=dev)
-        L.call("avlen_rgbd_concat", E.P(rgb), E.P(depth), E.P(rgbd), R, S * S, st)
+        L.call("avlen_rgbd_concat", E.P(rgb), _u8(rgb), E.P(depth), E.P(rgbd), R, S * S, st)
         nb2 = L.lib.avlen_cnn3_workspace_bytes(C.byref(eng["visual"]), R, S, S)
         ws2 = pol._ws.get("visual", nb2, dev)
         L.call("avlen_cnn3_fwd", C.byref(eng["visual"]), E.P(rgbd), R, S, S, E.P(x, self._hidden_size), F, pol.prec,
@@ -1164,7 +1181,7 @@ class AudioNavBaselineNet(Net):
         """evaluate_actions' forward over a (T*N)-row T-major minibatch with every activation kept for `train_backward`
         (policy.py:451-477 + rnn_state_encoder.py:92-143).  -> out (R, hidden), workspace, dims."""
         eng = pol._engine()
-        rgb, depth, spec = _f32(observations["rgb"]), _f32(observations["depth"]), _f32(observations[SPECTROGRAM])
+        rgb, depth, spec = _img(observations["rgb"]), _f32(observations["depth"]), _f32(observations[SPECTROGRAM])
         h0 = _f32(rnn_hidden_states)
         T, Nn, Ha, Wa, S = self._train_dims(observations, h0)
         dev = rgb.device
@@ -1175,7 +1192,7 @@ class AudioNavBaselineNet(Net):
         out = torch.empty(T * Nn, self._hidden_size, device=dev)
         mk = _f32(masks.view(-1))
         L.call("avlen_baseline_train_fwd", C.byref(eng["audio"]), C.byref(eng["visual"]), C.byref(eng["gru"]), E.P(spec), E.P(rgb),
-               E.P(depth), E.P(cat) if cat is not None else None, cat.shape[1] if cat is not None else 0, E.P(h0), E.P(mk), E.P(out),
+               _u8(rgb), E.P(depth), E.P(cat) if cat is not None else None, cat.shape[1] if cat is not None else 0, E.P(h0), E.P(mk), E.P(out),
                None, T, Nn, Ha, Wa, S, pol.prec, E.P(ws), nb, L.stream())
         return out, (ws, nb), (T, Nn, Ha, Wa, S, spec, mk)
 

@@ -75,13 +75,19 @@ class RolloutStorage:
                  external_memory_option_capacity, external_memory_vln_size, external_memory_vln_capacity,
                  external_memory_dim_goal, external_memory_dim_vln, external_memory_dim_option,
                  external_memory_dim_dialog, num_recurrent_layers=1, max_dialog_len=20, query_count_emb_size=32,
-                 use_state_memory=False, device="cuda", skip_sensors=()):
+                 use_state_memory=False, device="cuda", skip_sensors=("audiogoal",), uint8_sensors=("rgb",)):
         T, N, dev = num_steps, num_envs, torch.device(device)
         z = lambda *s, **k: torch.zeros(*s, device=dev, **k)
         self.num_steps, self.num_envs, self.device = T, N, dev
-        # `skip_sensors`: sensors no network reads (e.g. raw `audiogoal`) need not live in HBM
-        self.observations = {k: z(T + 1, N, *sp.shape) for k, sp in observation_space.spaces.items()
-                             if k not in skip_sensors}
+        # Observation staging (reference: rollout_storage.py:58-63 keeps every sensor as fp32, 404 KB per env-step):
+        # * `skip_sensors`: the raw `audiogoal` waveform (2 x 16000 fp32 = 128 KB per env-step) is copied into the reference's
+        #   buffers but no network reads it (the goal sensor is `spectrogram`): it is not kept in HBM;
+        # * `uint8_sensors`: RGB is uint8 0..255 at the sensor; it stays uint8 here (49 KB instead of 196 KB per stored frame,
+        #   and 4x less to read back in the PPO update) and the tower prologue converts / divides exactly as on fp32 pixels.
+        #   `insert` accepts uint8 (device, or pinned host: copied asynchronously) or integer-valued fp32 frames.
+        self.uint8_sensors = tuple(k for k in uint8_sensors if k in observation_space.spaces)
+        self.observations = {k: z(T + 1, N, *sp.shape, dtype=torch.uint8 if k in self.uint8_sensors else torch.float32)
+                             for k, sp in observation_space.spaces.items() if k not in skip_sensors}
         if num_recurrent_layers < 1:
             num_recurrent_layers = 1
         self.recurrent_hidden_states = z(T + 1, num_recurrent_layers, N, recurrent_hidden_state_size)
@@ -274,8 +280,11 @@ class RolloutStorage:
         for d in src.shape[2:]:
             D *= d
         dst = torch.empty((T * n_mb,) + tuple(src.shape[2:]), dtype=src.dtype, device=src.device)
-        L.call("avlen_minibatch_gather", P(src), P(dst), P(env), T, self.num_envs, n_mb, D, src.element_size(),
-               L.stream())
+        es = src.element_size()
+        if es == 1:                                        # uint8 frames move as 4-byte words
+            assert D % 4 == 0
+            D, es = D // 4, 4
+        L.call("avlen_minibatch_gather", P(src), P(dst), P(env), T, self.num_envs, n_mb, D, es, L.stream())
         return dst
 
     def gather_minibatch(self, env, advantages=None, in_place=False):
@@ -294,7 +303,7 @@ class RolloutStorage:
             rows = (torch.arange(T, device=env.device, dtype=torch.int32).view(T, 1) * self.num_envs +
                     env.to(torch.int32).view(1, n_mb)).reshape(-1).contiguous()
             for k, v in self.observations.items():
-                big = k in ("rgb", "depth", "spectrogram") and v.dtype == torch.float32
+                big = k in ("rgb", "depth", "spectrogram") and (v.dtype == torch.float32 or (k == "rgb" and v.dtype == torch.uint8))
                 obs[k] = RowsOf(v.view((-1,) + tuple(v.shape[2:])), rows) if big else g(v)
         else:
             obs = {k: g(v) for k, v in self.observations.items()}

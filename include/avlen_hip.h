@@ -155,11 +155,14 @@ int avlen_attention_bwd_bf16(const float* Q, int ldq, const float* K, int ldk, c
                              avlen_stream_t stream);
 
 /* ------------------------------------------------------------------ small fused kernels -------- */
-/* (B,S,S,C) NHWC fp32 -> (x / divisor) -> kxk block mean -> (B,64,64,C).  K1+K2: smt_cnn.py:83-93 +
- * common/utils.py:467-557 (area resize to 64, identity crop).  divisor = 255 for rgb, 1 for depth. */
-int avlen_preprocess_image(const float* x, float* y, int B, int S, int C, float divisor, avlen_stream_t stream);
+/* (B,S,S,C) NHWC -> (x / divisor) -> kxk block mean -> (B,64,64,C).  K1+K2: smt_cnn.py:83-93 +
+ * common/utils.py:467-557 (area resize to 64, identity crop).  divisor = 255 for rgb, 1 for depth.
+ * Image arguments of this section and of the tower entry points below come with a `*_u8` flag: 0 = fp32 pixels (what
+ * common/utils.py:129-156 `batch_obs` hands over), 1 = uint8 pixels as the simulator produces them (RGB stays
+ * uint8 from the sensor through the rollout storage to this prologue; converted to float first, so bit-identical). */
+int avlen_preprocess_image(const void* x, int x_u8, float* y, int B, int S, int C, float divisor, avlen_stream_t stream);
 /* VisualCNN input (visual_cnn.py:165-183): y[b,h,w,:] = [rgb/255 (3), depth (1)]. */
-int avlen_rgbd_concat(const float* rgb, const float* depth, float* y, int B, int HW, avlen_stream_t stream);
+int avlen_rgbd_concat(const void* rgb, int rgb_u8, const float* depth, float* y, int B, int HW, avlen_stream_t stream);
 /* Non-CNN feature columns (policy.py:662-674, 1035-1036, 1062-1063): for each row b
  *   feats[b, col_action .. +16)   = action_encoder.w[:, prev_action[b]] + b      (one-hot x Linear)
  *   feats[b, col_cat .. +21)      = category[b]              (only if category != NULL)
@@ -178,13 +181,13 @@ int avlen_concat_rows(const float* a, int lda, int na, const float* b, int ldb, 
 size_t avlen_resnet18_workspace_bytes(int B);
 /* SMTCNN tower (smt_cnn.py:78-115 + smt_resnet.py:132-146) on one modality: img (B,S,S,C) raw sensor,
  * divisor = 255 for rgb, 1 for depth; writes 64 features to out[b*ld_out + 0..63]. */
-int avlen_resnet18_fwd(const avlen_resnet18* net, const float* img, int B, int S, int C, float divisor, float* out,
+int avlen_resnet18_fwd(const avlen_resnet18* net, const void* img, int img_u8, int B, int S, int C, float divisor, float* out,
                        int ld_out, int prec, void* ws, size_t ws_bytes, avlen_stream_t stream);
 /* `groups` (<= 8) towers of identical shape in lock-step on the bf16 fast path: every conv / GroupNorm / fc is ONE
  * grouped launch (blockIdx.y = tower).  Used to run rgb+depth of a policy -- or all six towers of pi_q/pi_g/pi_l,
  * which see the same observation -- as single launches.  Arrays are host arrays of length `groups`. */
 size_t avlen_resnet18_group_workspace_bytes(int groups, int B);
-int avlen_resnet18_group_fwd(const avlen_resnet18* const* nets, const float* const* imgs, const int* channels,
+int avlen_resnet18_group_fwd(const avlen_resnet18* const* nets, const void* const* imgs, const int* img_u8, const int* channels,
                              const float* divisors, float* const* outs, int ld_out, int groups, int B, int S, void* ws,
                              size_t ws_bytes, avlen_stream_t stream);
 /* ---- BeliefPredictor (belief_predictor.py:56-206), SURVEY 8(f) rank 1 ---- */
@@ -217,7 +220,7 @@ int avlen_belief_update(const float* pointgoals, int ld_pg, const float* labels,
 /* The same with a row index (bf16 fast path): image / spectrogram b of the batch is item row_index[b] of the tensor the
  * pointer addresses -- the PPO minibatch (rollout_storage.py:591-810) reads the (T+1, N, ...) observation storage in place
  * instead of gathering 470 KB per stored step first. */
-int avlen_resnet18_group_fwd_indexed(const avlen_resnet18* const* nets, const float* const* imgs, const int* channels,
+int avlen_resnet18_group_fwd_indexed(const avlen_resnet18* const* nets, const void* const* imgs, const int* img_u8, const int* channels,
                                      const float* divisors, float* const* outs, int ld_out, int groups, int B, int S,
                                      const int32_t* row_index, void* ws, size_t ws_bytes, avlen_stream_t stream);
 int avlen_cnn3_fwd_indexed(const avlen_cnn3* net, const float* x, const int32_t* row_index, int B, int H, int W, float* out,
@@ -320,7 +323,7 @@ int avlen_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
 size_t avlen_baseline_train_workspace_bytes(const avlen_cnn3* audio, const avlen_cnn3* visual, const avlen_gru* gru, int T, int N,
                                             int Ha, int Wa, int S, int prec);
 int avlen_baseline_train_fwd(const avlen_cnn3* audio, const avlen_cnn3* visual, const avlen_gru* gru, const float* spec,
-                             const float* rgb, const float* depth, const float* category, int ncat, const float* h0,
+                             const void* rgb, int rgb_u8, const float* depth, const float* category, int ncat, const float* h0,
                              const float* masks, float* out, float* h_out, int T, int N, int Ha, int Wa, int S, int prec, void* ws,
                              size_t ws_bytes, avlen_stream_t stream);
 int avlen_baseline_train_bwd(const avlen_cnn3* audio, const avlen_cnn3* visual, const avlen_gru* gru, const avlen_cnn3* g_audio,

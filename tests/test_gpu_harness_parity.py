@@ -99,7 +99,7 @@ def test_benched_harness_matches_oracle(precision, pre, distractor):
                           (ro.prev_actions, st.prev_actions), (ro.actions_option, st.actions_option), (ro.masks, st.masks),
                           (ro.action_log_probs, st.action_log_probs), (ro.rl_masks, st.rl_masks),
                           (ro.observations["spectrogram"], st.obs["spectrogram"]), (ro.observations["rgb"], st.obs["rgb"])):
-            assert torch.equal(mine.cpu(), ref), (t, tuple(ref.shape))
+            assert torch.equal(mine.cpu().to(ref.dtype), ref), (t, tuple(ref.shape))
     print(f"{precision} pre={pre} distractor={distractor}: worst |value| {worst['v']:.3g} |prob| {worst['p']:.3g} "
           f"row (rel) {worst['row']:.3g}")
     # update: same host RNG draw order for the minibatch permutations
@@ -194,3 +194,59 @@ def test_ddppo_update_through_rccl_one_rank():
     # identity reduction; the loss log itself is accumulated with float atomics (1e-7 run-to-run)
     np.testing.assert_allclose(np.array(outs[0][0]), np.array(outs[1][0]), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(outs[0][1].cpu().numpy(), outs[1][1].cpu().numpy(), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_uint8_rgb_end_to_end_is_bit_identical(precision):
+    """RGB kept uint8 from the sensor through the rollout storage into the tower prologue.  The features computed from
+    uint8 pixels equal the ones computed from the same pixels stored as fp32 BIT FOR BIT (fp32 mode; bf16 mode up to the atomic
+    order of the fused GroupNorm statistics), `insert` takes pinned-host uint8 frames, and the PPO minibatch reads the uint8 rows of
+    the storage in place."""
+    from avlen_amd import policy as P
+    wl = Workload(4, 3, spectrogram=(65, 26, 2), precision=precision, pretraining=True, em_capacity=3, seed=9, use_graphs=False,
+                  share_encoders=False, launch_ahead=False, with_goal_policy=False, with_dialog_policy=False)
+    ro, pol = wl.rollouts, wl.pi_q
+    assert ro.observations["rgb"].dtype == torch.uint8 and "audiogoal" not in ro.observations
+    obs8 = {k: v[0] for k, v in ro.observations.items()}
+    obs32 = dict(obs8, rgb=obs8["rgb"].float())
+    pa = ro.prev_actions[0]
+    f8, _ = pol.net.features(pol, obs8, pa)
+    f8 = f8.clone()
+    f32, _ = pol.net.features(pol, obs32, pa)
+    torch.cuda.synchronize()
+    if precision == "fp32":
+        assert torch.equal(f8, f32)
+    else:
+        assert float((f8 - f32).abs().max()) < 3e-2 * float(f32.abs().max())
+    assert float(f8[:, :64].abs().max()) > 0
+    # insert from a pinned host uint8 frame (asynchronous H2D) and from an integer-valued fp32 device frame
+    for _ in range(3):
+        wl.rollout_step()
+    host = torch.randint(0, 256, (4, 128, 128, 3), dtype=torch.uint8).pin_memory()
+    nxt = {k: wl.sim[k][1] for k in ro.observations}
+    nxt["rgb"] = host
+    z = torch.zeros
+    ro.step = 0
+    args = (z(1, 4, 512, device="cuda"), z(4, 1, dtype=torch.long, device="cuda"), z(4, 1, dtype=torch.long, device="cuda"),
+            z(4, 1, device="cuda"), z(4, 1, device="cuda"), z(4, 1, device="cuda"), torch.ones(4, 1, device="cuda"),
+            torch.ones(4, 1, device="cuda"), z(4, 276, device="cuda"), z(4, 308, device="cuda"), z(4, 276, device="cuda"),
+            z(4, 256, device="cuda"), z(4, 77, dtype=torch.long, device="cuda"), z(4, device="cuda"),
+            torch.ones(4, dtype=torch.long, device="cuda"), torch.ones(4, dtype=torch.long, device="cuda"),
+            z(4, dtype=torch.long, device="cuda"), z(4, 4, device="cuda"), z(4, 32, device="cuda"), z(4, 32, device="cuda"),
+            z(4, device="cuda"))
+    ro.insert(nxt, *args)
+    torch.cuda.synchronize()
+    assert torch.equal(ro.observations["rgb"][1].cpu(), host)
+    ro.step = 0
+    nxt["rgb"] = host.cuda().float()
+    ro.insert(nxt, *args)
+    torch.cuda.synchronize()
+    assert torch.equal(ro.observations["rgb"][1].cpu(), host)
+    # minibatch rows read in place from the uint8 storage
+    ro.step = 3
+    b = ro.gather_minibatch(torch.tensor([1, 3], device="cuda"), in_place=True)
+    if precision == "bf16":
+        assert isinstance(b["obs"]["rgb"], P.RowsOf) and b["obs"]["rgb"].base.dtype == torch.uint8
+    b0 = ro.gather_minibatch(torch.tensor([1, 3], device="cuda"), in_place=False)
+    assert b0["obs"]["rgb"].dtype == torch.uint8
+    assert torch.equal(b0["obs"]["rgb"], ro.observations["rgb"][:3][:, [1, 3]].reshape(6, 128, 128, 3))

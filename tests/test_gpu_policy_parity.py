@@ -566,3 +566,55 @@ def test_minibatch_observations_read_in_place():
     assert torch.equal(f0[:, 128:144], f1[:, 128:144]) and torch.equal(g0, g1)      # action embedding, goal vector
     err = float((f0[:, :128] - f1[:, :128]).abs().max() / f0[:, :128].abs().max())
     assert err < 3e-2, err
+
+
+def test_full_cycle_distractor_matches_reference(specs):
+    """BASELINE configs[4] (semantic_audionav_distractor: use_category_input=True, feature dims 297 / 329) through the whole cycle:
+    rollout with sampled actions, insert, GAE, PPO.update -- vs the reference's own PPO / RolloutStorage (oracle/make_goldens_dis.py)."""
+    g = golden("cycle_dis")
+    keys = json.load(open(os.path.join(GOLDEN, "cycle_dis_keys.json")))
+    T, N, EMS, EMC = 6, 4, 12, 6
+    pol = build("option", pretraining=True, distractor=True)
+    load_fixture(pol, "option_distractor", specs)
+    pol.cuda()
+    assert pol.net.memory_dim == 329
+    agent = DDPPO(pol, 0.2, 2, 2, 0.5, 0.05, lr=2.5e-4, eps=1e-5, max_grad_norm=0.2, use_normalized_advantage=False)
+    st = RolloutStorage(T, N, savi_observation_space(), ActionSpace(4), 512, True, EMS, EMC, EMS, EMC, 3, 3, 297, 276,
+                        329, 256, num_recurrent_layers=-1, max_dialog_len=77, use_state_memory=True, device="cuda")
+    o0 = cyc.first_obs(N, tag="dis")
+    for k in st.observations:
+        st.observations[k][0].copy_(o0[k])
+    torch.manual_seed(2025)
+    for t in range(T):
+        si = cyc.step_inputs(t, N, tag="dis")
+        st.query_state[st.step].copy_(si["query_state"])
+        st.last_query_info[st.step].copy_(si["last_query_info"])
+        so = {k: v[st.step] for k, v in st.observations.items()}
+        v, u, ao, lp, h, row, probs = pol.act_option(
+            so, st.recurrent_hidden_states[st.step], st.prev_actions[st.step], st.masks[st.step],
+            st.external_memory_option[:, st.step].contiguous(), st.external_memory_masks[st.step],
+            st.query_state[st.step], st.last_query_info[st.step])
+        close(v, g["value"][t]); close(probs, g["probs"][t])
+        assert np.array_equal(ao.cpu().numpy(), g["action_option"][t])
+        z = torch.zeros
+        st.insert(cu(si["next_obs"]), h, si["actions"].cuda(), ao, lp, v, si["rewards"].cuda(), si["not_done"].cuda(),
+                  si["not_done"].cuda(), row[:, :297].contiguous(), row, row[:, :276].contiguous(),
+                  z(N, 256, device="cuda"), z(N, 77, dtype=torch.long, device="cuda"), z(N), torch.ones(N, dtype=torch.long),
+                  si["rl_masks"], si["ucnt_gt"], z(N, 4, device="cuda"), si["query_state"].cuda(),
+                  si["last_query_info"].cuda(), si["agent_step"])
+    lo = {k: v[-1] for k, v in st.observations.items()}
+    nv = pol.get_value_option(lo, st.recurrent_hidden_states[st.step], st.prev_actions[st.step], st.masks[st.step],
+                              st.external_memory_option[:, st.step].contiguous(), st.external_memory_masks[st.step],
+                              st.query_state[st.step - 1], st.last_query_info[st.step - 1])
+    close(nv, g["next_value"])
+    st.compute_returns(nv, True, 0.99, 0.95)
+    close(st.returns[:T], g["returns"][:T])
+    out = agent.update(st)
+    st.after_update()
+    torch.cuda.synchronize()
+    assert np.array_equal(st.em_masks.cpu().numpy(), g["em_masks"])
+    np.testing.assert_allclose(np.array(out), g["update"], rtol=2e-3, atol=2e-4)
+    sd = {k: v.detach().cpu() for k, v in pol.state_dict().items()}
+    pabs = np.array([float(sd[k].double().abs().sum()) for k in keys])
+    np.testing.assert_allclose(pabs, g["param_abs"], rtol=2e-5)
+    close(sd["net.smt_state_encoder.fusion_encoder.0.weight"][:4, 270:300], g["fusion0_w"], rtol=2e-3, atol=2e-5)

@@ -225,13 +225,13 @@ def test_preprocess_and_pack(L):
     rgb = torch.randint(0, 256, (B, 128, 128, 3)).float()
     ref = F.interpolate((rgb.permute(0, 3, 1, 2) / 255.0), size=(64, 64), mode="area").permute(0, 2, 3, 1)
     y = torch.empty(B, 64, 64, 3, device="cuda")
-    L.call("avlen_preprocess_image", L.ptr(dev(rgb)), L.ptr(y), B, 128, 3, 255.0, L.stream())
+    L.call("avlen_preprocess_image", L.ptr(dev(rgb)), 0, L.ptr(y), B, 128, 3, 255.0, L.stream())
     torch.cuda.synchronize()
     assert float((y.cpu() - ref).abs().max()) < 1e-6
     dep = torch.rand(B, 128, 128, 1)
     ref = F.interpolate(dep.permute(0, 3, 1, 2), size=(64, 64), mode="area").permute(0, 2, 3, 1)
     y = torch.empty(B, 64, 64, 1, device="cuda")
-    L.call("avlen_preprocess_image", L.ptr(dev(dep)), L.ptr(y), B, 128, 1, 1.0, L.stream())
+    L.call("avlen_preprocess_image", L.ptr(dev(dep)), 0, L.ptr(y), B, 128, 1, 1.0, L.stream())
     torch.cuda.synchronize()
     assert float((y.cpu() - ref).abs().max()) < 1e-6
     w = torch.randn(64, 128 * 64)
