@@ -636,6 +636,10 @@ int run_g2(G2 p, void* ws, size_t ws_bytes, hipStream_t st) {
     if (bm == 64 && bn == 128) rc = ns == 2 ? launch_ns<64, 128, 2, 4, 2, 512>(p, m_tiles, n_tiles, st) : ns == 3 ? launch_ns<64, 128, 2, 4, 3, 512>(p, m_tiles, n_tiles, st) : launch_ns<64, 128, 2, 4, 4, 512>(p, m_tiles, n_tiles, st);
     else if (bm == 128 && bn == 128) rc = ns == 2 ? launch_ns<128, 128, 2, 4, 2, 512>(p, m_tiles, n_tiles, st) : ns == 3 ? launch_ns<128, 128, 2, 4, 3, 512>(p, m_tiles, n_tiles, st) : launch_ns<128, 128, 2, 4, 4, 512>(p, m_tiles, n_tiles, st);
     else if (bm == 256 && bn == 128) rc = ns == 2 ? launch_ns<256, 128, 4, 2, 2, 512>(p, m_tiles, n_tiles, st) : launch_ns<256, 128, 4, 2, 3, 512>(p, m_tiles, n_tiles, st);
+#ifdef AVLEN_G2_LAB
+    else if (bm == 64 && bn == 256) rc = ns == 2 ? launch_ns<64, 256, 2, 4, 2, 512>(p, m_tiles, n_tiles, st) : launch_ns<64, 256, 2, 4, 3, 512>(p, m_tiles, n_tiles, st);
+    else if (bm == 128 && bn == 256) rc = ns == 2 ? launch_ns<128, 256, 2, 4, 2, 512>(p, m_tiles, n_tiles, st) : launch_ns<128, 256, 2, 4, 3, 512>(p, m_tiles, n_tiles, st);
+#endif
     else if (bm == 128 && bn == 64) rc = ns == 2 ? launch_ns<128, 64, 4, 2, 2, 512>(p, m_tiles, n_tiles, st) : ns == 3 ? launch_ns<128, 64, 4, 2, 3, 512>(p, m_tiles, n_tiles, st) : launch_ns<128, 64, 4, 2, 4, 512>(p, m_tiles, n_tiles, st);
   } else if (bm == 64) {
     rc = (bn == 64) ? launch4<64, 64, 2, 2>(p, m_tiles, n_tiles, st) : launch4<64, 128, 2, 2>(p, m_tiles, n_tiles, st);

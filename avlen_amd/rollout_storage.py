@@ -43,6 +43,32 @@ class ExternalMemory:
         self.masks = torch.zeros(num_envs, total_size, device=device)
         self.memory = torch.zeros(total_size, num_envs, dim, device=device)
         self.idx = 0
+        self.env_id = 0
+        self._masks_replay = None                      # (num_steps, N, total): allocated by the first insert_replay
+
+    @property
+    def masks_replay(self):
+        if self._masks_replay is None:
+            self._masks_replay = torch.zeros(self.num_steps, self.num_envs, self.total_size, device=self.memory.device)
+        return self._masks_replay
+
+    def insert_replay(self, em_features):
+        """rollout_storage.py:943-952: a whole stored sequence (k, dim) of ONE environment becomes slots 0..k-1 of ring column
+        `env_id`; step i of the replayed sequence sees slots 0..i-1."""
+        mr = self.masks_replay
+        mr[:, self.env_id, :] = 0.0
+        k = em_features.size(0)
+        self.memory[:k, self.env_id, :].copy_(em_features)
+        for i in range(1, self.num_steps):
+            mr[i, self.env_id, :i] = 1.0
+        self.env_id = (self.env_id + 1) % self.num_envs
+
+    def pop_at(self, idx):
+        """rollout_storage.py:954-956 (eval: an environment is paused, base_trainer.py:186-289): drop column `idx`."""
+        keep = [i for i in range(self.masks.shape[0]) if i != idx]
+        self.masks = self.masks[keep].contiguous()
+        self.memory = self.memory[:, keep].contiguous()
+        self.num_envs = len(keep)                      # the insert kernel sizes its grid by it
 
     def insert(self, em_features, not_done_masks, masks_out=None):
         f = em_features if em_features.is_contiguous() else em_features.contiguous()
@@ -67,6 +93,8 @@ class ExternalMemory:
 
     def to(self, device):
         self.masks, self.memory = self.masks.to(device), self.memory.to(device)
+        if self._masks_replay is not None:
+            self._masks_replay = self._masks_replay.to(device)
 
 
 class RolloutStorage:
@@ -122,6 +150,7 @@ class RolloutStorage:
         if use_state_memory:
             self.em_vln_dialog = mk(self.em_vln_size, self.em_vln_capacity, self.em_dim_dialog)
         self.step = 0
+        self.env_id = 0                                  # insert_replay cursor (rollout_storage.py:174-176)
         self._plans = {}
         self._src_plans = {}
         self._em_ops = (L.ExtMemOp * 4)()
@@ -230,6 +259,66 @@ class RolloutStorage:
                     self.em_vln_masks[s + 1].copy_(self.em_vln_dialog.masks)
         self.step = s + 1
 
+    # ---------------------------------------------------------------- replay / dialog pre-training side
+    def insert_replay(self, observations, recurrent_hidden_states, actions, actions_option, action_log_probs, value_preds,
+                      rewards, not_done_masks, not_done_masks_vln, em_features, em_features_dialog, all_dialog, o_action, o_mask,
+                      action_prob, query_state, agent_step):
+        """rollout_storage.py:300-371: one environment's whole stored dialog episode (num_steps rows) becomes column `env_id` of
+        every buffer (REPLAY_STORE path, ppo_trainer.py:913-951).  Mirrors the reference statement by statement, including that
+        `em_features` feeds both the goal and the vln ring."""
+        T, e, dev = self.num_steps, self.env_id, self.device
+        c = lambda dst, src: dst.copy_(src if torch.is_tensor(src) else torch.as_tensor(src))
+        for k in observations:
+            if k in self.observations:
+                c(self.observations[k][:T, e], observations[k])
+        c(self.recurrent_hidden_states[:T, :, e, :], recurrent_hidden_states)
+        c(self.all_dialog[:T, e], all_dialog)
+        c(self.query_state[:T, e], query_state)
+        c(self.agent_step[:T, e], agent_step)
+        if o_action is not None:
+            c(self.o_masks[:T, e], o_mask)
+            c(self.o_actions[:T, e], o_action)
+            c(self.action_probs[:T, e], action_prob)
+        c(self.actions[:T, e], actions)
+        if actions_option is not None:
+            c(self.actions_option[:T, e], actions_option)
+        c(self.prev_actions[:T, e], actions)
+        c(self.action_log_probs[:T, e], action_log_probs)
+        c(self.value_preds[:T, e], value_preds)
+        c(self.rewards[:T, e], rewards)
+        c(self.masks[:T, e], not_done_masks)
+        c(self.masks_vln[:T, e], not_done_masks_vln)
+        f = (em_features if torch.is_tensor(em_features) else torch.as_tensor(em_features)).to(dev)
+        if self.use_external_memory:
+            self.em.insert_replay(f)
+            self.em_masks[:T, e, :].copy_(self.em.masks_replay[:, e, :])
+            self.em_vln.insert_replay(f)
+            self.em_vln_masks[:T, e, :].copy_(self.em_vln.masks_replay[:, e, :])
+        if self.use_state_memory:
+            fd = (em_features_dialog if torch.is_tensor(em_features_dialog) else torch.as_tensor(em_features_dialog)).to(dev)
+            self.em_vln_dialog.insert_replay(fd)
+            self.em_vln_masks[:T, e, :].copy_(self.em_vln.masks_replay[:, e, :] if self.use_external_memory
+                                              else self.em_vln_dialog.masks_replay[:, e, :])
+        self.env_id = e + 1
+        self.step = T
+
+    def dialog_batching(self):
+        """rollout_storage.py:414-588: every environment, steps [0, step), flattened T-major -- the 17-tuple `PPO.update_dialog`
+        consumes.  The memories come out as the reference's (em_size, T*N, dim) tensors (every copy of a ring is identical)."""
+        T, N = self.step, self.num_envs
+        fl = lambda x: x[:T].reshape((T * N,) + tuple(x.shape[2:]))
+        mem = lambda em: (em.memory.unsqueeze(1).expand(-1, T, -1, -1).reshape(em.total_size, T * N, em.dim)
+                          if em is not None else None)
+        obs = defaultdict(list)
+        for k, v in self.observations.items():
+            obs[k] = fl(v)
+        use_em, use_sm = self.use_external_memory, self.use_state_memory
+        return (obs, self.recurrent_hidden_states[0], fl(self.actions), fl(self.prev_actions), fl(self.value_preds),
+                fl(self.returns), fl(self.masks), fl(self.action_log_probs), mem(self.em) if use_em else None,
+                mem(self.em_vln) if use_em else None, mem(self.em_vln_dialog) if use_sm else None,
+                fl(self.em_masks) if use_em else None, fl(self.em_vln_masks) if (use_em or use_sm) else None, fl(self.all_dialog),
+                fl(self.agent_step), self.num_steps, self.num_envs)
+
     def after_update(self):
         s = self.step
         pairs = [(v[0], v[s]) for v in self.observations.values()]
@@ -241,9 +330,11 @@ class RolloutStorage:
 
     # ---------------------------------------------------------------- GAE (rollout_storage.py:394-412)
     def compute_returns(self, next_value, use_gae, gamma, tau):
-        if not use_gae:
-            raise NotImplementedError("avlen_amd implements the GAE branch (use_gae: True in every AVLEN yaml)")
         nv = next_value.detach().float().contiguous()
+        if not use_gae:                                  # rollout_storage.py:406-412
+            L.call("avlen_discounted_returns", P(self.rewards), P(self.masks), P(nv), P(self.returns), self.step, self.num_envs,
+                   float(gamma), L.stream())
+            return
         L.call("avlen_gae_scan", P(self.rewards), P(self.value_preds), P(self.masks), P(nv), P(self.returns),
                P(self.advantages), self.step, self.num_envs, float(gamma), float(tau), L.stream())
 
@@ -267,6 +358,22 @@ class RolloutStorage:
     @property
     def external_memory_masks(self):
         return self.em_masks
+
+    @property
+    def external_memory_goal_idx(self):
+        return self.em.idx
+
+    @property
+    def external_memory_option_idx(self):
+        return self.em_option.idx
+
+    @property
+    def external_memory_vln_idx(self):
+        return self.em_vln.idx
+
+    @property
+    def external_memory_vln_dialog_idx(self):
+        return self.em_vln_dialog.idx
 
     @property
     def external_memory_vln_masks(self):

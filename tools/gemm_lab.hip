@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <vector>
+#include <array>
 
 __global__ void naive_kernel(const bf16* A, const bf16* B, const float* bias, float* C, int M, int N, int K) {
   int n = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
@@ -48,8 +49,13 @@ int main(int argc, char** argv) {
     occ<128, 128, 2, 4, 2, 512>("128x128 ns2 t512"); occ<256, 128, 4, 2, 3, 512>("256x128 ns3 t512");
     return 0;
   }
-  const int shapes[][3] = {{64, 512, 512}, {64, 2048, 512}, {64, 512, 2048}, {2464, 512, 512}, {2464, 512, 2048}, {2464, 2048, 512}, {2464, 1536, 512},
+  const bool clip = argc > 1 && !strcmp(argv[1], "clip");
+  const int shapes_all[][3] = {{64, 512, 512}, {64, 2048, 512}, {64, 512, 2048}, {2464, 512, 512}, {2464, 512, 2048}, {2464, 2048, 512}, {2464, 1536, 512},
                            {9664, 256, 256}, {9664, 768, 256}, {4800, 64, 8192}, {8192, 8192, 1024}, {8192, 8192, 8192}};
+  const int shapes_clip[][3] = {{2464, 512, 512}, {2464, 512, 2048}, {2464, 2048, 512}, {2464, 1536, 512}};
+  std::vector<std::array<int, 3>> shapes;
+  if (clip) for (auto& s_ : shapes_clip) shapes.push_back({s_[0], s_[1], s_[2]});
+  else for (auto& s_ : shapes_all) shapes.push_back({s_[0], s_[1], s_[2]});
   size_t maxA = (size_t)9664 * 8192, maxB = (size_t)8192 * 8192, maxC = (size_t)8192 * 8192;
   std::vector<unsigned short> h(maxB);
   unsigned s = 12345;
@@ -68,8 +74,10 @@ int main(int argc, char** argv) {
                          {128, 128, 256, 2, 0}, {128, 128, 512, 2, 0}, {128, 128, 512, 3, 0}, {128, 128, 512, 4, 0},
                          {256, 128, 512, 2, 0}, {256, 128, 512, 3, 0}, {128, 64, 512, 3, 0}, {64, 128, 512, 3, 2}, {64, 64, 256, 0, 0}};
   const int cfgs_abl[][5] = {{64, 128, 512, 2, 0}, {64, 128, 512, 4, 0}, {128, 128, 512, 2, 0}, {256, 128, 512, 3, 0}};
-  const int (*cfgs)[5] = ablate ? cfgs_abl : cfgs_all;
-  const int ncfg = ablate ? 4 : 14;
+  const int cfgs_clip[][5] = {{0, 0, 0, 0, 0}, {64, 128, 512, 2, 0}, {64, 256, 512, 2, 0}, {64, 256, 512, 3, 0}, {128, 256, 512, 2, 0},
+                              {128, 256, 512, 3, 0}, {128, 128, 256, 2, 0}, {64, 64, 256, 0, 0}};
+  const int (*cfgs)[5] = ablate ? cfgs_abl : clip ? cfgs_clip : cfgs_all;
+  const int ncfg = ablate ? 4 : clip ? 8 : 14;
   for (auto& sh : shapes) {
     int M = sh[0], N = sh[1], K = sh[2];
     bool big = (double)M * N * K > 1e11;
