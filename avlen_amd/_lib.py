@@ -174,6 +174,8 @@ SIGNATURES = {
                                        f32, f32, f32, f32, vp, vp, i32, vp]),
     "avlen_rl_mask_norm": (i32, [vp, i32, vp, vp]),
     "avlen_gae_scan": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, vp]),
+    "avlen_spectrogram_workspace_bytes": (sz, [i32, i32, i32, i32]),
+    "avlen_spectrogram": (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, vp, vp, sz, vp]),
     "avlen_discounted_returns": (i32, [vp, vp, vp, vp, i32, i32, f32, vp]),
     "avlen_baseline_train_workspace_bytes": (sz, [C.POINTER(Cnn3), C.POINTER(Cnn3), C.POINTER(Gru), i32, i32, i32, i32, i32, i32]),
     "avlen_baseline_train_fwd": (i32, [C.POINTER(Cnn3), C.POINTER(Cnn3), C.POINTER(Gru), vp, vp, i32, vp, vp, i32, vp, vp, vp, vp,

@@ -331,6 +331,15 @@ int avlen_baseline_train_bwd(const avlen_cnn3* audio, const avlen_cnn3* visual, 
                              const float* d_out, int T, int N, int Ha, int Wa, int S, int prec, void* ws, size_t ws_bytes,
                              avlen_stream_t stream);
 
+/* ---- binaural spectrogram on the device (soundspaces/tasks/nav.py:88-101 SpectrogramSensor.compute_spectrogram):
+ * audio (B, 2, L) fp32 -> log1p(pool x pool block mean of |STFT|) -> out (B, ceil(NB/pool), ceil(F/pool), 2), NB = nfft/2 + 1,
+ * F = 1 + L/hop centred frames.  window (nfft) = the analysis window already zero-padded to nfft; basis (2*NB, nfft) = rows
+ * cos(2 pi k n / nfft) for k < NB, then -sin(...).  reflect: 1 = reflect padding of the signal (librosa < 0.10), 0 = zeros.
+ * Third-party definitions (librosa.stft, skimage block_reduce) restated: parity unpinned. */
+size_t avlen_spectrogram_workspace_bytes(int B, int L, int nfft, int hop);
+int avlen_spectrogram(const float* audio, int B, int L, const float* window, const float* basis, int nfft, int hop, int pool,
+                      int reflect, float* out, void* ws, size_t ws_bytes, avlen_stream_t stream);
+
 /* ------------------------------------------------------------------ rollout storage ------------ */
 /* ExternalMemory.insert (rollout_storage.py:930-941) on ONE copy of the ring: memory (total,N,dim),
  * masks (N,total).  Also snapshots the new masks to masks_out (N,total) when non-NULL. */
