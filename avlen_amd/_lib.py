@@ -174,6 +174,10 @@ SIGNATURES = {
                                        f32, f32, f32, f32, vp, vp, i32, vp]),
     "avlen_rl_mask_norm": (i32, [vp, i32, vp, vp]),
     "avlen_gae_scan": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, vp]),
+    "avlen_resnet18_train_workspace_bytes": (sz, [C.POINTER(ResNet18), i32, i32, i32, i32]),
+    "avlen_resnet18_train_fwd": (i32, [C.POINTER(ResNet18), vp, i32, i32, i32, vp, i32, i32, vp, sz, vp]),
+    "avlen_resnet18_train_bwd": (i32, [C.POINTER(ResNet18), C.POINTER(ResNet18), vp, vp, i32, i32, i32, i32, vp, i32, vp, sz, vp]),
+    "avlen_belief_regression_loss": (i32, [vp, vp, C.c_long, vp, i32, vp, vp, i32, vp]),
     "avlen_spectrogram_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "avlen_spectrogram": (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, vp, vp, sz, vp]),
     "avlen_discounted_returns": (i32, [vp, vp, vp, vp, i32, i32, f32, vp]),

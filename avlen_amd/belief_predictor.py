@@ -137,6 +137,56 @@ class BeliefPredictor(nn.Module):
             self._eng = eng
         return self._eng
 
+    # ---- online regression of the location predictor (ppo_trainer.py:996-1015) ---------------------
+    def _train_state(self):
+        if getattr(self, "_flat", None) is None or not self._flat.intact(self.predictor):
+            self._flat = E.FlatParams(self.predictor, ("",))          # every predictor parameter is trained
+            self._eng = None                                           # views hold parameter addresses: rebuild
+            dev = self._flat.flat.device
+            n = self._flat.n_trained
+            self._adam = {"m": torch.zeros(n, device=dev), "v": torch.zeros(n, device=dev), "step": 0,
+                          "norm_sq": torch.zeros(1, dtype=torch.float64, device=dev)}
+            self._grad_view = None
+        return self._flat
+
+    def regression_step(self, obs_batch, acc, apply=True):
+        """One optimiser step on a batch of stored observations: predictor forward (activations kept), masked MSE against the
+        transformed point goal, backward through the GroupNorm ResNet-18, Adam (lr / eps / betas of `self.optimizer` when the
+        trainer set one, torch defaults otherwise).  acc (3,) device floats += (loss, correct rows, masked rows)."""
+        flat = self._train_state()
+        x = self._predictor_input(obs_batch)
+        spec = _f32(obs_batch[SPECTROGRAM])
+        gts = _f32(obs_batch[POINTGOAL])
+        B, H, W, _ = x.shape
+        eng = self._engine(H, W)
+        if self._grad_view is None:
+            self._grad_view = resnet18_grad_view(eng["predictor"], flat)
+        net, dev, st = eng["predictor"], x.device, L.stream()
+        nb = L.lib.avlen_resnet18_train_workspace_bytes(C.byref(net), B, H, W, self.prec)
+        ws = self._ws.get("train", nb, dev)
+        preds, d_preds = torch.empty(B, 2, device=dev), torch.empty(B, 2, device=dev)
+        flat.grad.zero_()
+        L.call("avlen_resnet18_train_fwd", C.byref(net), E.P(x), B, H, W, E.P(preds), 2, self.prec, E.P(ws), nb, st)
+        L.call("avlen_belief_regression_loss", E.P(preds), E.P(spec), spec[0].numel(), E.P(gts), gts.shape[1], E.P(d_preds),
+               E.P(acc), B, st)
+        L.call("avlen_resnet18_train_bwd", C.byref(net), C.byref(self._grad_view), E.P(x), E.P(d_preds), 2, B, H, W, None,
+               self.prec, E.P(ws), nb, st)
+        self.reduce_gradients(flat)
+        if not apply:                                      # gradient only (tests): flat.grad holds it
+            return preds
+        ad = self._adam
+        ad["step"] += 1
+        pg = self.optimizer.param_groups[0] if self.optimizer is not None else {"lr": 1e-3, "eps": 1e-8, "betas": (0.9, 0.999)}
+        b1, b2 = pg.get("betas", (0.9, 0.999))
+        # plain Adam: the trainer does not clip this gradient (no norm accumulator -> no scaling)
+        L.call("avlen_adam_step", E.P(flat.flat), E.P(flat.grad), E.P(ad["m"]), E.P(ad["v"]), flat.n_trained, float(pg["lr"]),
+               float(b1), float(b2), float(pg["eps"]), ad["step"], 0.0, None, st)
+        self._eng["packed"].refresh()                      # packed conv / fc copies follow the stepped weights
+        return preds
+
+    def reduce_gradients(self, flat):
+        pass
+
     def _side_stream(self):
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream()
@@ -266,6 +316,59 @@ def observations_hw(x):
     return x.shape[1], x.shape[2]
 
 
+def resnet18_grad_view(net_view, flat, prefix=""):
+    """avlen_resnet18 gradient struct for avlen_resnet18_train_bwd: same dims as `net_view`, pointers at the CANONICAL gradient
+    tensors inside `flat.grad` (names as in CustomResNet.state_dict(), smt_resnet.py:56-149)."""
+    gp = lambda n: C.c_void_p(flat.grad_ptr(prefix + n))
+    g = L.ResNet18()
+
+    def conv(v, name):
+        return L.Conv(gp(name), None, v.cin, v.cout, v.kh, v.kw, v.stride, v.pad)
+    g.conv1 = conv(net_view.conv1, "conv1.weight")
+    g.bn1 = L.Affine(gp("bn1.weight"), gp("bn1.bias"))
+    for i in range(8):
+        b, name = net_view.block[i], f"layer{i // 2 + 1}.{i % 2}."
+        gb = g.block[i]
+        gb.conv1, gb.conv2 = conv(b.conv1, name + "conv1.weight"), conv(b.conv2, name + "conv2.weight")
+        gb.bn1 = L.Affine(gp(name + "bn1.weight"), gp(name + "bn1.bias"))
+        gb.bn2 = L.Affine(gp(name + "bn2.weight"), gp(name + "bn2.bias"))
+        gb.has_down = b.has_down
+        if b.has_down:
+            gb.down = conv(b.down, name + "downsample.0.weight")
+            gb.bnd = L.Affine(gp(name + "downsample.1.weight"), gp(name + "downsample.1.bias"))
+    g.fc = L.Linear(gp("fc.weight"), gp("fc.bias"), net_view.fc.out_f, net_view.fc.in_f)
+    return g
+
+
+POINTGOAL = "pointgoal_with_gps_compass"        # IntegratedPointGoalGPSAndCompassSensor.cls_uuid
+
+
+def train_belief_predictor(bp, rollouts, num_epoch=5, num_mini_batch=1):
+    """Mirror of the trainer method (ppo_trainer.py:959-1030; called after every PPO update when `online_training` is on,
+    ddppo_trainer.py:977-978): `num_epoch` passes over the stored steps, one optimiser step per minibatch of the location
+    predictor on (spectrogram -> transformed point goal) with silent rows masked out.  -> (mean loss, prediction accuracy)."""
+    adv = torch.zeros_like(rollouts.returns)
+    acc = torch.zeros(3, device=rollouts.returns.device)
+    for _ in range(num_epoch):
+        for sample in rollouts.recurrent_generator(adv, num_mini_batch):
+            bp.regression_step(sample[0], acc)
+    loss, correct, n = (float(x) for x in acc.cpu())
+    return loss / (num_epoch * num_mini_batch), (correct / n if n else 0)
+
+
 class BeliefPredictorDDP(BeliefPredictor):
-    """belief_predictor.py:208-210.  Gradient synchronisation of the online-trained location predictor belongs to the
-    trainer's regressor step, which is outside this path; the class exists so `bp_class` selection keeps working."""
+    """belief_predictor.py:208-210: the data-parallel variant -- one all-reduce (RCCL) of the flat predictor gradient per
+    regression step, parameters broadcast from rank 0 at `init_distributed`."""
+
+    def init_distributed(self, find_unused_params=True):
+        import torch.distributed as distrib
+        self._dist = distrib.is_available() and distrib.is_initialized()
+        if self._dist:
+            distrib.broadcast(self._train_state().flat, src=0)
+            self._eng = None
+
+    def reduce_gradients(self, flat):
+        if getattr(self, "_dist", False):
+            import torch.distributed as distrib
+            distrib.all_reduce(flat.grad)
+            flat.grad.mul_(1.0 / distrib.get_world_size())

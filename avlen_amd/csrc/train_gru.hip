@@ -18,6 +18,7 @@
 #include <math.h>
 
 #define TRY(x) do { int _rc = (x); if (_rc != AVLEN_OK) return _rc; } while (0)
+#include "train_kernels.h"
 
 namespace {
 
@@ -33,109 +34,6 @@ Dims cnn_dims(const avlen_cnn3* n, int H, int W) {
     d.c[i + 1] = n->conv[i].cout;
   }
   return d;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// im2col / col2im (NHWC, no padding, square stride)
-// ---------------------------------------------------------------------------------------------------------------
-// cols[m][kh][kw][c] = X[b][oh*s + kh][ow*s + kw][c],  m = (b*OH + oh)*OW + ow.  One thread per V floats of a (kw, c) run.
-template <int V>
-__global__ void im2col_kernel(const float* __restrict__ X, float* __restrict__ cols, long total, int H, int W, int C, int OH, int OW,
-                              int KH, int KW, int s) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int run = KW * C / V;                    // V-float pieces per (m, kh)
-  const int j = (int)(i % run);
-  long r = i / run;
-  const int kh = (int)(r % KH); r /= KH;         // r = m
-  const int ow = (int)(r % OW); long q = r / OW;
-  const int oh = (int)(q % OH); const long b = q / OH;
-  const float* src = X + (((b * H + (long)oh * s + kh) * W + (long)ow * s) * C) + (long)j * V;
-  float* dst = cols + (r * KH + kh) * (long)(KW * C) + (long)j * V;
-  if (V == 4) *(float4*)dst = *(const float4*)src;
-  else if (V == 2) *(float2*)dst = *(const float2*)src;
-  else dst[0] = src[0];
-}
-int im2col(hipStream_t st, const float* X, float* cols, long B, int H, int W, int C, int OH, int OW, int KH, int KW, int s) {
-  // a (kw, c) run starts at float offset ((b*H + ih)*W + ow*s)*C: V-float pieces need W*C, s*C and KW*C to be multiples of V
-  auto ok = [&](int v) { return (KW * C) % v == 0 && (W * C) % v == 0 && (s * C) % v == 0 &&
-                                (((uintptr_t)X | (uintptr_t)cols) & (size_t)(4 * v - 1)) == 0; };
-  const int V = ok(4) ? 4 : ok(2) ? 2 : 1;
-  const long total = B * OH * OW * KH * (long)(KW * C / V);
-  const unsigned blocks = (unsigned)((total + 255) / 256);
-  if (V == 4) hipLaunchKernelGGL(im2col_kernel<4>, dim3(blocks), dim3(256), 0, st, X, cols, total, H, W, C, OH, OW, KH, KW, s);
-  else if (V == 2) hipLaunchKernelGGL(im2col_kernel<2>, dim3(blocks), dim3(256), 0, st, X, cols, total, H, W, C, OH, OW, KH, KW, s);
-  else hipLaunchKernelGGL(im2col_kernel<1>, dim3(blocks), dim3(256), 0, st, X, cols, total, H, W, C, OH, OW, KH, KW, s);
-  return avlen_launch_status();
-}
-
-// dX[b][h][w][c] = relu'(act) * sum over taps (kh, kw) with (h - kh) % s == 0, (w - kw) % s == 0, in range, of
-// dcols[(b, (h-kh)/s, (w-kw)/s)][kh][kw][c].  act = the (post-ReLU) activation that was this conv's input.
-template <int V>
-__global__ void col2im_relu_kernel(const float* __restrict__ dcols, const float* __restrict__ act, float* __restrict__ dX, long total,
-                                   int H, int W, int C, int OH, int OW, int KH, int KW, int s) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int cv = C / V;
-  const int c = (int)(i % cv) * V;
-  long r = i / cv;
-  const int w = (int)(r % W); r /= W;
-  const int h = (int)(r % H); const long b = r / H;
-  float acc[V];
-#pragma unroll
-  for (int v = 0; v < V; v++) acc[v] = 0.f;
-  const long K = (long)KH * KW * C;
-  for (int kh = h % s; kh < KH; kh += s) {
-    const int oh = (h - kh) / s;
-    if (h - kh < 0) break;
-    if (oh >= OH) continue;
-    for (int kw = w % s; kw < KW; kw += s) {
-      const int ow = (w - kw) / s;
-      if (w - kw < 0) break;
-      if (ow >= OW) continue;
-      const float* p = dcols + ((b * OH + oh) * OW + ow) * K + ((long)kh * KW + kw) * C + c;
-      if (V == 4) { const float4 t = *(const float4*)p; acc[0] += t.x; acc[1 % V] += t.y; acc[2 % V] += t.z; acc[3 % V] += t.w; }
-      else acc[0] += p[0];
-    }
-  }
-  const long o = ((b * H + h) * W + w) * C + c;
-#pragma unroll
-  for (int v = 0; v < V; v++) dX[o + v] = act[o + v] > 0.f ? acc[v] : 0.f;
-}
-int col2im_relu(hipStream_t st, const float* dcols, const float* act, float* dX, long B, int H, int W, int C, int OH, int OW, int KH,
-                int KW, int s) {
-  const bool v4 = C % 4 == 0;
-  const long total = B * H * W * (C / (v4 ? 4 : 1));
-  const unsigned blocks = (unsigned)((total + 255) / 256);
-  if (v4) hipLaunchKernelGGL(col2im_relu_kernel<4>, dim3(blocks), dim3(256), 0, st, dcols, act, dX, total, H, W, C, OH, OW, KH, KW, s);
-  else hipLaunchKernelGGL(col2im_relu_kernel<1>, dim3(blocks), dim3(256), 0, st, dcols, act, dX, total, H, W, C, OH, OW, KH, KW, s);
-  return avlen_launch_status();
-}
-
-// dst[i] = (y[i] > 0) ? src[i] : 0 over rows of different strides (the Linear+ReLU output lives inside the GRU input rows)
-__global__ void relu_mask_rows_kernel(const float* __restrict__ src, int lds, const float* __restrict__ y, int ldy, float* __restrict__ dst,
-                                      int ldd, long rows, int cols) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows * cols) return;
-  const long r = i / cols; const int c = (int)(i % cols);
-  dst[r * ldd + c] = y[r * ldy + c] > 0.f ? src[r * lds + c] : 0.f;
-}
-
-// packed gradient layouts -> canonical parameter layouts (accumulating)
-__global__ void unpack_conv_grad_kernel(const float* __restrict__ gp, float* __restrict__ g, int O, int I, int KH, int KW) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;          // canonical index ((o*I + c)*KH + kh)*KW + kw
-  if (i >= (long)O * I * KH * KW) return;
-  const int kw = (int)(i % KW); long r = i / KW;
-  const int kh = (int)(r % KH); r /= KH;
-  const int c = (int)(r % I); const int o = (int)(r / I);
-  g[i] += gp[(((long)o * KH + kh) * KW + kw) * I + c];
-}
-__global__ void unpack_fc_grad_kernel(const float* __restrict__ gp, float* __restrict__ g, int O, int C, int HW) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;          // canonical index (o*C + c)*HW + p
-  if (i >= (long)O * C * HW) return;
-  const int p = (int)(i % HW); long r = i / HW;
-  const int c = (int)(r % C); const long o = r / C;
-  g[i] += gp[(o * HW + p) * C + c];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -392,7 +290,7 @@ int cnn_bwd(const avlen_ctx& c, Ws& s, const avlen_cnn3* n, const avlen_cnn3* g,
     const float* in = i == 0 ? x : a.a[i - 1];
     if (M > 0x7fffffffL) return AVLEN_ERR_ARG;
     // weight / bias gradient
-    TRY(im2col(st, in, s.cols, R, d.h[i], d.w[i], k.cin, d.h[i + 1], d.w[i + 1], k.kh, k.kw, k.stride));
+    TRY(im2col(st, in, s.cols, R, d.h[i], d.w[i], k.cin, d.h[i + 1], d.w[i + 1], k.kh, k.kw, k.stride, 0));
     TRY(avlen_zero_bytes(s.gpack, (size_t)k.cout * Kc * 4, st));
     avlen_linear G{s.gpack, nullptr, k.cout, Kc, nullptr, 0};
     TRY(avlen_i_linear_dw(c, G, dy, k.cout, s.cols, Kc, (int)M));
@@ -404,7 +302,7 @@ int cnn_bwd(const avlen_ctx& c, Ws& s, const avlen_cnn3* n, const avlen_cnn3* g,
     // data gradient: dcols = dY * Wp, gathered back onto the input pixels, masked by the ReLU of the layer below
     avlen_linear Wl{k.w, nullptr, k.cout, Kc, nullptr, 0};
     TRY(avlen_i_linear_dx(c, Wl, dy, k.cout, s.cols, Kc, (int)M, nullptr, 0));
-    TRY(col2im_relu(st, s.cols, a.a[i - 1], other, R, d.h[i], d.w[i], k.cin, d.h[i + 1], d.w[i + 1], k.kh, k.kw, k.stride));
+    TRY(col2im_relu(st, s.cols, a.a[i - 1], other, R, d.h[i], d.w[i], k.cin, d.h[i + 1], d.w[i + 1], k.kh, k.kw, k.stride, 0));
     float* t = dy; dy = other; other = t;
   }
   return avlen_launch_status();

@@ -331,6 +331,23 @@ int avlen_baseline_train_bwd(const avlen_cnn3* audio, const avlen_cnn3* visual, 
                              const float* d_out, int T, int N, int Ha, int Wa, int S, int prec, void* ws, size_t ws_bytes,
                              avlen_stream_t stream);
 
+/* ---- GroupNorm ResNet-18 training (CustomResNet, smt_resnet.py:37-149): forward with saved activations + backward.
+ * Users: BeliefPredictor's online regression (ppo_trainer.py:959-1030) and pi_l's towers under PPO.update_dialog (ppo.py:99-154).
+ * x (B,H,W,C) NHWC fp32 is the network input proper (towers: the preprocessed 64x64 image); out (B, fc.out_f).  `grads`: the same
+ * struct type whose conv .w / GroupNorm .g,.b / fc .w,.b pointers address CANONICAL gradient tensors (conv OIHW, fc
+ * (out, C*H*W)); accumulated into.  d_x: optional input gradient.  The workspace carries the activations from _fwd to _bwd. */
+size_t avlen_resnet18_train_workspace_bytes(const avlen_resnet18* net, int B, int H, int W, int prec);
+int avlen_resnet18_train_fwd(const avlen_resnet18* net, const float* x, int B, int H, int W, float* out, int ld_out, int prec,
+                             void* ws, size_t ws_bytes, avlen_stream_t stream);
+int avlen_resnet18_train_bwd(const avlen_resnet18* net, const avlen_resnet18* grads, const float* x, const float* d_out,
+                             int ld_dout, int B, int H, int W, float* d_x, int prec, void* ws, size_t ws_bytes,
+                             avlen_stream_t stream);
+/* Loss of train_belief_predictor (ppo_trainer.py:1000-1008, 1017-1022): masked MSE between preds (R,2) and the transformed
+ * goal (gt[1], -gt[0]); mask = the row's spectrogram (spec_elems values) is not all-zero.  d_preds (R,2) out;
+ * acc[0] += loss, acc[1] += correct rows (rounded prediction equals the goal), acc[2] += masked rows. */
+int avlen_belief_regression_loss(const float* preds, const float* spec, long spec_elems, const float* gts, int ld_gt,
+                                 float* d_preds, float* acc, int R, avlen_stream_t stream);
+
 /* ---- binaural spectrogram on the device (soundspaces/tasks/nav.py:88-101 SpectrogramSensor.compute_spectrogram):
  * audio (B, 2, L) fp32 -> log1p(pool x pool block mean of |STFT|) -> out (B, ceil(NB/pool), ceil(F/pool), 2), NB = nfft/2 + 1,
  * F = 1 + L/hop centred frames.  window (nfft) = the analysis window already zero-padded to nfft; basis (2*NB, nfft) = rows

@@ -155,3 +155,132 @@ def test_graph_replay_matches_eager():
         bps[1].update(o2, dones)
         for k in ("location_belief", "category_belief"):
             assert torch.equal(o1[k], o2[k]), (t, k)
+
+
+def _train_batch(tag, R, distractor):
+    spec = torch.log1p(3.0 * fx.uni(tag + ".spec", (R, 65, 26, 2), 0.0, 2.0))
+    spec[1] = 0.0
+    spec[R - 2] = 0.0
+    obs = {"spectrogram": spec, "pointgoal_with_gps_compass": fx.ints(tag + ".pg", (R, 2), 9).float() - 4.0}
+    if distractor:
+        cat = torch.zeros(R, 21)
+        cat[torch.arange(R), fx.ints(tag + ".cat", (R,), 21)] = 1.0
+        obs["category"] = cat
+    return obs
+
+
+@pytest.mark.parametrize("name,distractor", [("belief_train", False), ("belief_train_distractor", True)])
+def test_online_regression_matches_reference(name, distractor):
+    """`train_belief_predictor`'s minibatch body (ppo_trainer.py:996-1022): GroupNorm ResNet-18 forward + backward on the HIP
+    path, masked MSE, Adam -- three optimiser steps vs the reference's BeliefPredictor + torch Adam (oracle/make_goldens_belief_train.py):
+    per-step loss and predictions, accuracy counters, every parameter tensor after the steps."""
+    g = golden(name)
+    sd = predictor_sd("belief_loc_distractor" if distractor else "belief_loc")
+    bp = BeliefPredictor(cfg(), "cuda", None, None, 512, num_env=2, has_distractor_sound=distractor, load_pretrained=False)
+    bp.load_state_dict(sd, strict=False)
+    bp = bp.cuda()
+    bp.optimizer = torch.optim.Adam(bp.predictor.parameters(), lr=1e-3)
+    acc = torch.zeros(3, device="cuda")
+    R = 6
+    prev = 0.0
+    for step in range(3):
+        preds = bp.regression_step(cu(_train_batch(f"{name}.{step % 2}", R, distractor)), acc)
+        torch.cuda.synchronize()
+        live = [0, 2, 3, 5]
+        # step 0 is the plain forward (2e-3); later steps run on weights that took Adam steps of +-lr wherever the gradient is
+        # near zero (sign-sensitive): 1 % of the prediction scale
+        err = np.abs(preds.cpu().numpy()[live] - g["preds"][step][live]).max() / np.abs(g["preds"][step][live]).max()
+        a = float(acc[0])
+        lerr = abs((a - prev) - g["losses"][step]) / g["losses"][step]
+        print(f"step {step}: prediction err {err:.3g} of scale, loss err {lerr:.3g}")
+        assert err < (2e-3 if step == 0 else 1e-2) and lerr < (2e-3 if step == 0 else 2e-2)
+        prev = a
+    assert float(acc[1]) == float(g["correct"]) and float(acc[2]) == float(g["nsample"])
+    new = {k[len("predictor."):]: v.detach().cpu() for k, v in bp.state_dict().items() if k.startswith("predictor.")}
+    keys = sorted(new)
+    pabs = np.array([float(new[k].double().abs().sum()) for k in keys])
+    np.testing.assert_allclose(pabs, g["param_abs"], rtol=1e-2)          # small bias tensors: three sign-sensitive steps of lr each
+    old = {k[len("predictor."):]: v for k, v in sd.items() if k.startswith("predictor.")}
+    # the parameter step itself: direction of the three-step delta vs the reference's (element-wise an Adam step is +-lr where the
+    # gradient is near zero, so single elements may flip; the tensors as a whole must agree)
+    for key, gold, sl in (("conv1.weight", g["conv1_w"], np.s_[:2, :2]), ("fc.weight", g["fc_w"], np.s_[:, :16]),
+                          ("layer4.1.conv2.weight", g["l4_w"], np.s_[:2, :4, 1, 1]),
+                          ("layer2.0.downsample.1.weight", g["bn_g"], np.s_[:])):
+        d_ours = (new[key].numpy()[sl] - old[key].numpy()[sl]).ravel().astype(np.float64)
+        d_ref = (gold - old[key].numpy()[sl]).ravel().astype(np.float64)
+        cos = float(d_ours @ d_ref / (np.linalg.norm(d_ours) * np.linalg.norm(d_ref) + 1e-30))
+        assert cos > 0.9, (key, cos)
+    # inference after training uses the stepped weights (packed copies refreshed)
+    o = cu(_train_batch(f"{name}.0", R, distractor))
+    again = bp.cnn_forward(o).cpu().numpy()
+    assert np.abs(again - g["preds"][0]).max() > 1e-3
+
+
+def test_train_belief_predictor_over_the_rollout_storage():
+    """The trainer-side loop (ppo_trainer.py:959-1030): 5 epochs x 1 minibatch over every stored step of the RolloutStorage."""
+    from avlen_amd.belief_predictor import train_belief_predictor
+    from avlen_amd.rollout_storage import RolloutStorage
+    from avlen_amd.spaces import ActionSpace
+
+    class Box:
+        def __init__(self, shape):
+            self.shape = shape
+
+    class Space:
+        spaces = {"spectrogram": Box((65, 26, 2)), "pointgoal_with_gps_compass": Box((2,)), "pose": Box((4,))}
+    T, N = 4, 3
+    st = RolloutStorage(T, N, Space(), ActionSpace(4), 8, True, 6, 3, 6, 3, 3, 3, 5, 5, 5, 5, num_recurrent_layers=1,
+                        max_dialog_len=7, use_state_memory=True, device="cuda")
+    st.observations["spectrogram"].copy_(torch.log1p(3.0 * fx.uni("tb.spec", (T + 1, N, 65, 26, 2), 0.0, 2.0)))
+    st.observations["pointgoal_with_gps_compass"].copy_(fx.ints("tb.pg", (T + 1, N, 2), 7).float() - 3.0)
+    st.step = T
+    bp = BeliefPredictor(cfg(), "cuda", None, None, 512, num_env=N, load_pretrained=False)
+    bp.load_state_dict(predictor_sd("belief_loc"), strict=False)
+    bp = bp.cuda()
+    torch.manual_seed(0)
+    l1, a1 = train_belief_predictor(bp, st)
+    l2, a2 = train_belief_predictor(bp, st)
+    assert np.isfinite(l1) and np.isfinite(l2) and l2 < l1 and 0.0 <= a1 <= 1.0       # the regression makes progress
+
+
+@pytest.mark.parametrize("precision,distractor", [("fp32", False), ("fp32", True), ("bf16", False)])
+def test_predictor_gradients_match_oracle_autograd(precision, distractor):
+    """Every parameter gradient of the masked-MSE regression loss through the GroupNorm ResNet-18 (7x7 stem, 16 3x3 convs, three
+    strided 1x1 downsamples, 20 GroupNorms, residual adds, fc): HIP backward (im2col / col2im GEMMs, GroupNorm backward with the
+    ReLU masks folded in) vs torch autograd on the oracle restatement."""
+    name = "belief_loc_distractor" if distractor else "belief_loc"
+    sd = predictor_sd(name)
+    bp = BeliefPredictor(cfg(), "cuda", None, None, 512, num_env=2, has_distractor_sound=distractor, load_pretrained=False,
+                         precision=precision)
+    bp.load_state_dict(sd, strict=False)
+    bp = bp.cuda()
+    R_ = 5
+    obs = _train_batch("bgrad", R_, distractor)
+    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith("predictor.")}
+    preds = R.belief_cnn_forward(osd, obs, has_distractor_sound=distractor)
+    masks = (obs["spectrogram"].reshape(R_, -1).sum(1, keepdim=True) != 0).float()
+    gts = obs["pointgoal_with_gps_compass"]
+    tg = torch.stack([gts[:, 1], -gts[:, 0]], 1)
+    loss = torch.nn.functional.mse_loss(masks * preds, masks * tg)
+    loss.backward()
+    acc = torch.zeros(3, device="cuda")
+    ours = bp.regression_step(cu(obs), acc, apply=False)
+    torch.cuda.synchronize()
+    fp = precision == "fp32"
+    np.testing.assert_allclose(float(acc[0]), float(loss), rtol=1e-3 if fp else 5e-2)
+    flat, worst, dot, n1, n2 = bp._flat, 0.0, 0.0, 0.0, 0.0
+    for k, v in osd.items():
+        n = k[len("predictor."):]
+        mine = flat.grad_view(n, v.shape).cpu().double()
+        ref = v.grad.double()
+        err = float((mine - ref).norm() / (ref.norm() + 1e-30))
+        worst = max(worst, err)
+        dot, n1, n2 = dot + float((mine * ref).sum()), n1 + float((mine * mine).sum()), n2 + float((ref * ref).sum())
+        if fp:
+            assert err < 2e-3, (k, err)
+    cos = dot / ((n1 * n2) ** 0.5 + 1e-30)
+    print(f"{precision} distractor={distractor}: max relative L2 gradient error over {len(osd)} tensors: {worst:.3g}; cosine of the "
+          f"whole gradient {cos:.4f}")
+    # bf16 operands through 20 convolutions and 20 GroupNorms of a random-weight network: single small tensors (cancelling sums
+    # such as a GroupNorm bias) deviate by tens of percent; the gradient as a whole must still point the same way
+    assert cos > (0.999999 if fp else 0.97), cos
