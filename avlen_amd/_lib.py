@@ -162,7 +162,17 @@ SIGNATURES = {
     "avlen_cnn3_group_fwd": (i32, [vp, vp, i32, i32, i32, i32, vp, i32, vp, sz, vp]),
     "avlen_smt_workspace_bytes": (sz, [C.POINTER(Smt), i32, i32, i32, i32]),
     "avlen_smt_fwd": (i32, [C.POINTER(Smt), vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
-    "avlen_smt_bwd": (i32, [C.POINTER(Smt), C.POINTER(Smt), vp, vp, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "avlen_smt_bwd": (i32, [C.POINTER(Smt), C.POINTER(Smt), vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, sz, vp]),
+    "avlen_dialog_train_workspace_bytes": (sz, [C.POINTER(Dialog), i32, i32]),
+    "avlen_dialog_train_fwd": (i32, [C.POINTER(Dialog), vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, sz, vp]),
+    "avlen_dialog_bwd": (i32, [C.POINTER(Dialog), C.POINTER(Dialog), vp, vp, i32, vp, vp, i32, i32, i32, vp, sz, vp]),
+    "avlen_linear_bwd_workspace_bytes": (sz, []),
+    "avlen_linear_bwd": (i32, [C.POINTER(Linear), C.POINTER(Linear), vp, i32, vp, i32, vp, i32, i32, i32, vp, sz, vp]),
+    "avlen_action_encoder_bwd": (i32, [vp, i32, vp, C.POINTER(Linear), i32, vp]),
+    "avlen_dialog_loss_heads_bwd": (i32, [C.POINTER(Heads), C.POINTER(Heads), vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "avlen_cnn3_train_workspace_bytes": (sz, [C.POINTER(Cnn3), i32, i32, i32, i32]),
+    "avlen_cnn3_train_fwd": (i32, [C.POINTER(Cnn3), vp, i32, i32, i32, vp, i32, i32, vp, sz, vp]),
+    "avlen_cnn3_train_bwd": (i32, [C.POINTER(Cnn3), C.POINTER(Cnn3), vp, vp, vp, i32, i32, i32, i32, i32, vp, sz, vp]),
     "avlen_dialog_workspace_bytes": (sz, [C.POINTER(Dialog), i32, i32]),
     "avlen_dialog_fwd": (i32, [C.POINTER(Dialog), vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, sz, vp]),
     "avlen_clip_text_workspace_bytes": (sz, [C.POINTER(ClipText), i32]),

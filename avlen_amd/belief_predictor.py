@@ -316,28 +316,7 @@ def observations_hw(x):
     return x.shape[1], x.shape[2]
 
 
-def resnet18_grad_view(net_view, flat, prefix=""):
-    """avlen_resnet18 gradient struct for avlen_resnet18_train_bwd: same dims as `net_view`, pointers at the CANONICAL gradient
-    tensors inside `flat.grad` (names as in CustomResNet.state_dict(), smt_resnet.py:56-149)."""
-    gp = lambda n: C.c_void_p(flat.grad_ptr(prefix + n))
-    g = L.ResNet18()
-
-    def conv(v, name):
-        return L.Conv(gp(name), None, v.cin, v.cout, v.kh, v.kw, v.stride, v.pad)
-    g.conv1 = conv(net_view.conv1, "conv1.weight")
-    g.bn1 = L.Affine(gp("bn1.weight"), gp("bn1.bias"))
-    for i in range(8):
-        b, name = net_view.block[i], f"layer{i // 2 + 1}.{i % 2}."
-        gb = g.block[i]
-        gb.conv1, gb.conv2 = conv(b.conv1, name + "conv1.weight"), conv(b.conv2, name + "conv2.weight")
-        gb.bn1 = L.Affine(gp(name + "bn1.weight"), gp(name + "bn1.bias"))
-        gb.bn2 = L.Affine(gp(name + "bn2.weight"), gp(name + "bn2.bias"))
-        gb.has_down = b.has_down
-        if b.has_down:
-            gb.down = conv(b.down, name + "downsample.0.weight")
-            gb.bnd = L.Affine(gp(name + "downsample.1.weight"), gp(name + "downsample.1.bias"))
-    g.fc = L.Linear(gp("fc.weight"), gp("fc.bias"), net_view.fc.out_f, net_view.fc.in_f)
-    return g
+resnet18_grad_view = E.resnet18_grad_view
 
 
 POINTGOAL = "pointgoal_with_gps_compass"        # IntegratedPointGoalGPSAndCompassSensor.cls_uuid

@@ -1161,7 +1161,7 @@ int transformer_bwd(const Ctx& c, const avlen_transformer& tr, const avlen_trans
   return AVLEN_OK;
 }
 
-struct SmtWs { float *XF, *FMT, *maskx, *H1, *Z; TrWs tr; TrBwdWs tb; float *dZ, *dH1, *dPE; void* gws; int ldxf;
+struct SmtWs { float *XF, *FMT, *maskx, *H1, *Z; TrWs tr; TrBwdWs tb; float *dZ, *dH1, *dPE, *dXc; void* gws; int ldxf;
                void* xs; size_t xs_bytes; };
 
 void smt_layout(WsBump& w, SmtWs& s, const avlen_smt* p, long B, long M, int F, bool cto) {
@@ -1173,6 +1173,7 @@ void smt_layout(WsBump& w, SmtWs& s, const avlen_smt* p, long B, long M, int F, 
   tr_layout(w, s.tr, B, S, d, p->tr.nhead, cto);
   trb_layout(w, s.tb, B, S, d, p->tr.nhead);
   s.dZ = w.take<float>(R * d); s.dH1 = w.take<float>(R * d); s.dPE = w.take<float>(R * 16);
+  s.dXc = w.take<float>(B * s.ldxf);             // gradient w.r.t. the current token's fusion input (update_dialog)
   s.gws = w.take<char>(GEMM_SCRATCH);
   s.xs = nullptr; s.xs_bytes = 0;
   if (R >= big_m()) {            // operand scratch of the large-M bf16 products: two operands of up to 3d + ldxf columns
@@ -1481,8 +1482,20 @@ extern "C" int avlen_smt_fwd(const avlen_smt* p, const float* x, const float* me
   return transformer_fwd(c, p->tr, s.tr, s.Z, s.maskx, goal, out, B, S, cto != 0);
 }
 
+// d_x[b][0:pc] = dXF_cur[0:pc], d_x[b][pc:pc+4] = 0 (the pose is data), d_x[b][pc+4:F] = dXF_cur[pc+16:F+12]
+__global__ void smt_dx_scatter_kernel(const float* __restrict__ dXc, int ldxf, float* __restrict__ d_x, int ld_dx, int B, int F, int pc) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * F) return;
+  const int b = (int)(i / F), col = (int)(i % F);
+  float v = 0.f;
+  if (col < pc) v = dXc[(long)b * ldxf + col];
+  else if (col >= pc + 4) v = dXc[(long)b * ldxf + col + 12];
+  d_x[(long)b * ld_dx + col] = v;
+}
+
 extern "C" int avlen_smt_bwd(const avlen_smt* p, const avlen_smt* g, const float* goal, const float* d_out, int B, int M,
-                             int F, int pose_col, int cto, int prec, void* ws, size_t ws_bytes, hipStream_t st) {
+                             int F, int pose_col, int cto, int prec, float* d_x, int ld_dx, void* ws, size_t ws_bytes,
+                             hipStream_t st) {
   if (!p || !g || ws_bytes < avlen_smt_workspace_bytes(p, B, M, F, cto)) return AVLEN_ERR_WS;
   WsBump w(ws, ws_bytes); SmtWs s;
   smt_layout(w, s, p, B, M, F, cto != 0);
@@ -1507,6 +1520,16 @@ extern "C" int avlen_smt_bwd(const avlen_smt* p, const avlen_smt* g, const float
   int rpb = R >= 65536 ? 2048 : 256;
   hipLaunchKernelGGL(pose_grad_kernel, dim3((unsigned)((R + rpb - 1) / rpb)), dim3(96), 0, st, s.dPE, s.FMT, g->pose.w,
                      g->pose.b, R, rpb);
+  if (d_x) {
+    // gradient w.r.t. the CURRENT observation's features (pi_l under update_dialog: the encoders are trained through it; the
+    // memory rows are stored data).  Current token = row b*S + (S-1): dXF_cur [B, F+12] = dH1_cur * W0
+    const float* cur = s.dH1 + (long)(S - 1) * d;
+    TRY(avlen_gemm(cur, S * d, 0, p->fus0.w, p->fus0.in_f, 1, s.dXc, s.ldxf, nullptr, nullptr, 0, B, p->fus0.in_f, d, 0, prec, 1,
+                   0.f, s.gws, GEMM_SCRATCH, st));
+    const long n = (long)B * F;
+    hipLaunchKernelGGL(smt_dx_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s.dXc, s.ldxf, d_x, ld_dx, B, F,
+                       pose_col);
+  }
   return avlen_launch_status();
 }
 
@@ -1514,13 +1537,30 @@ extern "C" int avlen_smt_bwd(const avlen_smt* p, const avlen_smt* g, const float
 // Dialog state encoder
 // =====================================================================================================
 namespace {
-struct DlgWs { float *SEQ, *maskx, *H1, *Z; TrWs tr; void* gws; };
-void dlg_layout(WsBump& w, DlgWs& s, const avlen_dialog* p, long B, long M) {
+struct DlgWs { float *SEQ, *maskx, *H1, *Z; TrWs tr; void* gws; TrBwdWs tb; float *dZ, *dH1, *dSEQ; };
+void dlg_layout(WsBump& w, DlgWs& s, const avlen_dialog* p, long B, long M, bool train = false) {
   long S = M + 1, R = B * S; int d = p->tr.d;
   s.SEQ = w.take<float>(R * 2 * d); s.maskx = w.take<float>(B * S);
   s.H1 = w.take<float>(R * d); s.Z = w.take<float>(R * d);
   tr_layout(w, s.tr, B, S, d, p->tr.nhead, false);
   s.gws = w.take<char>(GEMM_SCRATCH);
+  if (train) {                                    // the inference layout is a prefix of the training layout
+    trb_layout(w, s.tb, B, S, d, p->tr.nhead);
+    s.dZ = w.take<float>(R * d); s.dH1 = w.take<float>(R * d); s.dSEQ = w.take<float>(R * 2 * d);
+  }
+}
+// d_x_att[b] = dSEQ[(b, M)][0:d];   d_demb[b] = sum_s dSEQ[(b, s)][d:2d]   (the dialog embedding is repeated on every token)
+__global__ void dialog_split_grad_kernel(const float* __restrict__ dseq, int ldseq, float* __restrict__ d_x_att,
+                                         float* __restrict__ d_demb, int S, int d) {
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < d; i += blockDim.x) {
+    d_x_att[(long)b * d + i] = dseq[((long)b * S + (S - 1)) * ldseq + i];
+    if (d_demb) {
+      float a = 0.f;
+      for (int s2 = 0; s2 < S; s2++) a += dseq[((long)b * S + s2) * ldseq + d + i];
+      d_demb[(long)b * d + i] = a;
+    }
+  }
 }
 }  // namespace
 
@@ -1550,6 +1590,94 @@ extern "C" int avlen_dialog_fwd(const avlen_dialog* p, const float* x_att, const
   hipLaunchKernelGGL(add_pe_kernel, dim3((unsigned)R), dim3(128), 0, st, s.Z, p->pe, agent_step, S, d, p->pe_len);
   TRY(avlen_launch_status());
   return transformer_fwd(c, p->tr, s.tr, s.Z, s.maskx, goal, out, B, S, false);
+}
+
+// ---- training form (PPO.update_dialog, ppo.py:99-154): fp32-staged kernels, every activation kept in the workspace ----
+extern "C" size_t avlen_dialog_train_workspace_bytes(const avlen_dialog* p, int B, int M) {
+  WsBump w(nullptr, 0); DlgWs s; dlg_layout(w, s, p, B, M, true);
+  return w.off + 4096;
+}
+
+extern "C" int avlen_dialog_train_fwd(const avlen_dialog* p, const float* x_att, const float* memory_state, const float* masks,
+                                      const float* d_emb, const float* agent_step, const float* goal, float* out, int B, int M,
+                                      int prec, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!p || B <= 0 || ws_bytes < avlen_dialog_train_workspace_bytes(p, B, M)) return AVLEN_ERR_WS;
+  WsBump w(ws, ws_bytes); DlgWs s; dlg_layout(w, s, p, B, M, true);
+  Ctx c{st, prec, s.gws, GEMM_SCRATCH};
+  const int S = M + 1, d = p->tr.d; const long R = (long)B * S;
+  const int ldseq = d_emb ? 2 * d : d;
+  float* seq = d_emb ? s.SEQ : s.Z;
+  hipLaunchKernelGGL(dialog_build_kernel, dim3((unsigned)R), dim3(128), 0, st, x_att, memory_state, masks, d_emb, seq, ldseq, s.maskx,
+                     B, M, d);
+  TRY(avlen_launch_status());
+  if (d_emb) {
+    TRY(linear(c, p->fus0, s.SEQ, 2 * d, s.H1, d, (int)R, AVLEN_ACT_RELU, nullptr, 0));
+    TRY(linear(c, p->fus2, s.H1, d, s.Z, d, (int)R, 0, nullptr, 0));
+  }
+  hipLaunchKernelGGL(add_pe_kernel, dim3((unsigned)R), dim3(128), 0, st, s.Z, p->pe, agent_step, S, d, p->pe_len);
+  TRY(avlen_launch_status());
+  return transformer_fwd(c, p->tr, s.tr, s.Z, s.maskx, goal, out, B, S, false);
+}
+
+// g: gradient views (accumulated).  d_x_att (B,d) out; d_demb (B,d) out when the forward had a dialog embedding (else NULL).
+extern "C" int avlen_dialog_bwd(const avlen_dialog* p, const avlen_dialog* g, const float* goal, const float* d_out, int has_dialog,
+                                float* d_x_att, float* d_demb, int B, int M, int prec, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!p || !g || !d_out || !d_x_att || B <= 0 || ws_bytes < avlen_dialog_train_workspace_bytes(p, B, M)) return AVLEN_ERR_WS;
+  if (has_dialog && !d_demb) return AVLEN_ERR_ARG;
+  WsBump w(ws, ws_bytes); DlgWs s; dlg_layout(w, s, p, B, M, true);
+  Ctx c{st, prec, s.gws, GEMM_SCRATCH};
+  const int S = M + 1, d = p->tr.d; const long R = (long)B * S;
+  // the positional encoding is an additive constant: dZ is the gradient of the fusion output as well
+  TRY(transformer_bwd(c, p->tr, g->tr, s.tr, s.tb, s.Z, s.maskx, goal, d_out, s.dZ, B, S, false));
+  if (has_dialog) {
+    TRY(linear_dw(c, g->fus2, s.dZ, d, s.H1, d, (int)R));
+    TRY(colsum_acc(c, s.dZ, d, g->fus2.b, (int)R, d));
+    TRY(linear_dx(c, p->fus2, s.dZ, d, s.dH1, d, (int)R, nullptr, 0));
+    TRY(relu_bwd(c, s.dH1, s.H1, R * d));
+    TRY(linear_dw(c, g->fus0, s.dH1, d, s.SEQ, 2 * d, (int)R));
+    TRY(colsum_acc(c, s.dH1, d, g->fus0.b, (int)R, d));
+    TRY(linear_dx(c, p->fus0, s.dH1, d, s.dSEQ, 2 * d, (int)R, nullptr, 0));
+    hipLaunchKernelGGL(dialog_split_grad_kernel, dim3((unsigned)B), dim3(128), 0, st, s.dSEQ, 2 * d, d_x_att, d_demb, S, d);
+  } else {
+    hipLaunchKernelGGL(dialog_split_grad_kernel, dim3((unsigned)B), dim3(128), 0, st, s.dZ, d, d_x_att, (float*)nullptr, S, d);
+  }
+  return avlen_launch_status();
+}
+
+// Generic Linear backward for single layers that sit between modules (pi_l's dialog_layer, policy.py:849):
+// G.w += dY^T X, G.b += colsum(dY), dX = dY W (optional)
+extern "C" int avlen_linear_bwd(const avlen_linear* L, const avlen_linear* G, const float* X, int ldx, const float* dY, int ldy,
+                                float* dX, int lddx, int M, int prec, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!L || !G || !X || !dY || M <= 0 || ws_bytes < GEMM_SCRATCH) return AVLEN_ERR_WS;
+  Ctx c{st, prec, ws, GEMM_SCRATCH};
+  TRY(linear_dw(c, *G, dY, ldy, X, ldx, M));
+  TRY(colsum_acc(c, dY, ldy, G->b, M, L->out_f));
+  if (dX) TRY(linear_dx(c, *L, dY, ldy, dX, lddx, M, nullptr, 0));
+  return AVLEN_OK;
+}
+extern "C" size_t avlen_linear_bwd_workspace_bytes(void) { return GEMM_SCRATCH; }
+
+// action_encoder = Linear(one_hot(prev_action)) (policy.py:662-667): gw[j][a] += sum_{b: a_b = a} d[b][j], gb[j] += sum_b d[b][j]
+namespace {
+__global__ void action_encoder_bwd_kernel(const float* __restrict__ d, int ld, const int64_t* __restrict__ prev_actions,
+                                          float* __restrict__ gw, float* __restrict__ gb, int B, int n_out, int n_act) {
+  const int j = threadIdx.x;                      // one block, n_out threads: deterministic
+  if (j >= n_out) return;
+  float sb = 0.f;
+  for (int b = 0; b < B; b++) {
+    const float v = d[(long)b * ld + j];
+    const long a = prev_actions[b];
+    sb += v;
+    if (a >= 0 && a < n_act) gw[(long)j * n_act + a] += v;
+  }
+  gb[j] += sb;
+}
+}  // namespace
+extern "C" int avlen_action_encoder_bwd(const float* d_feats, int ld, const int64_t* prev_actions, const avlen_linear* G, int B,
+                                        hipStream_t st) {
+  if (!d_feats || !prev_actions || !G || B <= 0 || G->out_f > 256) return AVLEN_ERR_ARG;
+  hipLaunchKernelGGL(action_encoder_bwd_kernel, dim3(1), dim3(256), 0, st, d_feats, ld, prev_actions, G->w, G->b, B, G->out_f, G->in_f);
+  return avlen_launch_status();
 }
 
 // =====================================================================================================

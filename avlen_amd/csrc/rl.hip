@@ -375,6 +375,78 @@ extern "C" int avlen_ppo_loss_heads_bwd(const avlen_heads* h, const avlen_heads*
   return avlen_launch_status();
 }
 
+// ---- PPO.update_dialog's loss (ppo.py:139-145): CrossEntropyLoss(weight=w) between the vln action logits of the rows with
+// o_masks != 0 and their oracle actions:  loss = sum_i w[y_i] * (-log p_i[y_i]) / sum_i w[y_i].
+// Pass 1: norm[0] = sum_i m_i w[y_i].  Pass 2: logits = feats * W^T + b, loss, d logits = m_i w[y_i] (p - onehot) / norm,
+// head gradients (accumulated with atomics), d_feats = d logits * W.
+namespace {
+__global__ void dialog_norm_kernel(const float* __restrict__ o_actions, const int64_t* __restrict__ o_masks, const float* __restrict__ wcls,
+                                   int A, float* __restrict__ norm, int R) {
+  __shared__ float sh[16];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < R; i += blockDim.x)
+    if (o_masks[i] != 0) { const int y = (int)o_actions[i]; if (y >= 0 && y < A) s += wcls[y]; }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) norm[0] = s;
+}
+__global__ __launch_bounds__(256) void dialog_loss_kernel(avlen_heads h, avlen_heads g, const float* __restrict__ feats, int d, int A,
+                                                          const float* __restrict__ o_actions, const int64_t* __restrict__ o_masks,
+                                                          const float* __restrict__ wcls, const float* __restrict__ norm,
+                                                          float* __restrict__ loss, float* __restrict__ d_feats, int R) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= R) return;
+  const float* f = feats + (long)row * d;
+  float z[MAXA], mx = -INFINITY;
+#pragma unroll
+  for (int a = 0; a < MAXA; a++) {
+    z[a] = -INFINITY;
+    if (a < A) { z[a] = row_dot(f, h.action.w + (long)a * d, d, lane) + h.action.b[a]; mx = fmaxf(mx, z[a]); }
+  }
+  float se = 0.f;
+#pragma unroll
+  for (int a = 0; a < MAXA; a++) if (a < A) se += expf(z[a] - mx);
+  const float lse = mx + logf(se);
+  const bool on = o_masks[row] != 0;
+  const int y = (int)o_actions[row];
+  const float wy = (on && y >= 0 && y < A) ? wcls[y] : 0.f;
+  const float inv = norm[0] > 0.f ? 1.f / norm[0] : 0.f;
+  float dz[MAXA];
+#pragma unroll
+  for (int a = 0; a < MAXA; a++) dz[a] = a < A ? wy * inv * (expf(z[a] - lse) - (a == y ? 1.f : 0.f)) : 0.f;
+  float zy = 0.f;
+#pragma unroll
+  for (int a = 0; a < MAXA; a++) if (a == y) zy = z[a];
+  if (lane == 0 && wy != 0.f) atomicAdd(loss, -wy * inv * (zy - lse));
+  // head gradients and d_feats: lanes stride the feature columns
+  for (int k = lane; k < d; k += 64) {
+    const float fk = f[k];
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < MAXA; a++)
+      if (a < A) {
+        acc += dz[a] * h.action.w[(long)a * d + k];
+        if (wy != 0.f) atomicAdd(&g.action.w[(long)a * d + k], dz[a] * fk);
+      }
+    d_feats[(long)row * d + k] = acc;
+  }
+  if (wy != 0.f) {
+#pragma unroll
+    for (int a = 0; a < MAXA; a++) if (a < A && lane == a) atomicAdd(&g.action.b[a], dz[a]);
+  }
+}
+}  // namespace
+
+extern "C" int avlen_dialog_loss_heads_bwd(const avlen_heads* h, const avlen_heads* g, const float* feats, int d, int A,
+                                           const float* o_actions, const int64_t* o_masks, const float* class_weights, float* norm,
+                                           float* loss, float* d_feats, int R, hipStream_t stream) {
+  if (!h || !g || !feats || !o_actions || !o_masks || !class_weights || !norm || !loss || !d_feats || R <= 0 || A > MAXA) return AVLEN_ERR_ARG;
+  hipLaunchKernelGGL(dialog_norm_kernel, dim3(1), dim3(1024), 0, stream, o_actions, o_masks, class_weights, A, norm, R);
+  hipLaunchKernelGGL(dialog_loss_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, stream, *h, *g, feats, d, A, o_actions, o_masks,
+                     class_weights, norm, loss, d_feats, R);
+  return avlen_launch_status();
+}
+
 extern "C" int avlen_rl_mask_norm(const int64_t* rl_masks, int R, float* norm, hipStream_t stream) {
   hipLaunchKernelGGL(rl_mask_norm_kernel, dim3(1), dim3(1024), 0, stream, rl_masks, R, norm);
   return avlen_launch_status();

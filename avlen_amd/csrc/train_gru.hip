@@ -399,3 +399,51 @@ extern "C" int avlen_baseline_train_bwd(const avlen_cnn3* audio, const avlen_cnn
   TRY(cnn_bwd(c, s, visual, g_visual, s.rgbd, R, S, S, s.vis, s.dX + audio->fc.out_f, s.X + audio->fc.out_f, F));
   return avlen_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// AudioCNN alone (pi_l's goal encoder under PPO.update_dialog, ppo.py:99-154): the same forward / backward as above with its
+// own workspace.  out rows are ld_out apart (the CNN's 128 columns inside the policy's feature rows).
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+bool cnn_layout(WsBump& w, Ws& s, const avlen_cnn3* n, long R, int H, int W, int prec) {
+  const Dims d = cnn_dims(n, H, W);
+  for (int i = 0; i < 3; i++) s.aud.a[i] = w.take<float>((size_t)R * d.h[i + 1] * d.w[i + 1] * d.c[i + 1]);
+  s.dpre = w.take<float>((size_t)R * n->fc.out_f);
+  const size_t am = cnn_act_max(d, R), cm = cnn_cols_max(n, d, R);
+  s.da = w.take<float>(am); s.db = w.take<float>(am);
+  s.cols = w.take<float>(cm);
+  s.gpack = w.take<float>(cnn_gpack_max(n));
+  s.gws = w.take<char>(GEMM_SCRATCH);
+  s.xs = nullptr; s.xs_bytes = 0;
+  if (prec == AVLEN_PREC_BF16) {
+    s.xs_bytes = (cm + am + (size_t)64 * 1024 * 1024) * 2 + (1u << 20);
+    s.xs = w.take<char>(s.xs_bytes);
+  }
+  return w.ok();
+}
+}  // namespace
+
+extern "C" size_t avlen_cnn3_train_workspace_bytes(const avlen_cnn3* net, int B, int H, int W, int prec) {
+  WsBump w(nullptr, 0); Ws s;
+  cnn_layout(w, s, net, B, H, W, prec);
+  return w.off + 4096;
+}
+extern "C" int avlen_cnn3_train_fwd(const avlen_cnn3* net, const float* x, int B, int H, int W, float* out, int ld_out, int prec,
+                                    void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!net || !x || !out || B <= 0) return AVLEN_ERR_ARG;
+  WsBump w(ws, ws_bytes); Ws s;
+  if (!ws || !cnn_layout(w, s, net, B, H, W, prec)) return AVLEN_ERR_WS;
+  avlen_ctx c{st, prec, s.gws, GEMM_SCRATCH};
+  c.xs = s.xs; c.xs_bytes = s.xs_bytes;
+  return cnn_fwd(c, net, x, B, H, W, s.aud, out, ld_out);
+}
+// y = the forward's output rows (post-ReLU), d_out = their gradient; both ld apart
+extern "C" int avlen_cnn3_train_bwd(const avlen_cnn3* net, const avlen_cnn3* grads, const float* x, const float* y, const float* d_out,
+                                    int ld, int B, int H, int W, int prec, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!net || !grads || !x || !y || !d_out || B <= 0) return AVLEN_ERR_ARG;
+  WsBump w(ws, ws_bytes); Ws s;
+  if (!ws || !cnn_layout(w, s, net, B, H, W, prec)) return AVLEN_ERR_WS;
+  avlen_ctx c{st, prec, s.gws, GEMM_SCRATCH};
+  c.xs = s.xs; c.xs_bytes = s.xs_bytes;
+  return cnn_bwd(c, s, net, grads, x, B, H, W, s.aud, d_out, y, ld);
+}

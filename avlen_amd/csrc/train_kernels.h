@@ -156,29 +156,40 @@ __global__ __launch_bounds__(256) void gn_train_fwd_kernel(const float* __restri
                                                            const float* __restrict__ beta, const float* __restrict__ residual,
                                                            float* __restrict__ y, float* __restrict__ stats, int HW, int C, int G,
                                                            int relu, float eps) {
-  __shared__ float s1[256], s2[256], mu[128], rs[128];
+  __shared__ float s1[256], mu[128], rs[128];
   const int b = blockIdx.x, t = threadIdx.x;
   const long n = (long)HW * C;
   const float* xb = x + (long)b * n;
-  float a = 0.f, q = 0.f;
-  for (long i = t; i < n; i += 256) { const float v = xb[i]; a += v; q += v * v; }
-  s1[t] = a; s2[t] = q;
+  const int cg = C / G, c = t % C, g = c / cg;
+  const float cnt = (float)HW * cg;
+  // two passes (mean, then centred sum of squares): E[x^2] - mean^2 in fp32 loses the variance of groups whose mean dwarfs
+  // their spread, and the backward divides by that variance (1 % gradient errors through the towers with the fixture weights)
+  float a = 0.f;
+  for (long i = t; i < n; i += 256) a += xb[i];
+  s1[t] = a;
   __syncthreads();
-  const int cg = C / G;
-  if (t < G) {                                     // channels g*cg .. +cg; thread slots with the same channel: t' % C == c
-    float sa = 0.f, sq = 0.f;
-    for (int c = t * cg; c < (t + 1) * cg; c++)
-      for (int k = c; k < 256; k += C) { sa += s1[k]; sq += s2[k]; }
-    const float cnt = (float)HW * cg;
-    const float m = sa / cnt;
-    const float var = fmaxf(sq / cnt - m * m, 0.f);
-    const float r = rsqrtf(var + eps);
-    mu[t] = m; rs[t] = r;
-    stats[((long)b * G + t) * 2] = m; stats[((long)b * G + t) * 2 + 1] = r;
+  if (t < G) {                                     // channels t*cg .. +cg; thread slots with the same channel: k % C == c
+    float sa = 0.f;
+    for (int cc = t * cg; cc < (t + 1) * cg; cc++)
+      for (int k = cc; k < 256; k += C) sa += s1[k];
+    mu[t] = sa / cnt;
   }
   __syncthreads();
-  const int c = t % C, g = c / cg;
-  const float sc = rs[g] * gamma[c], sh = beta[c] - mu[g] * sc;
+  const float m = mu[g];
+  float q = 0.f;
+  for (long i = t; i < n; i += 256) { const float v = xb[i] - m; q += v * v; }
+  s1[t] = q;
+  __syncthreads();
+  if (t < G) {
+    float sq = 0.f;
+    for (int cc = t * cg; cc < (t + 1) * cg; cc++)
+      for (int k = cc; k < 256; k += C) sq += s1[k];
+    const float r = rsqrtf(sq / cnt + eps);
+    rs[t] = r;
+    stats[((long)b * G + t) * 2] = mu[t]; stats[((long)b * G + t) * 2 + 1] = r;
+  }
+  __syncthreads();
+  const float sc = rs[g] * gamma[c], sh = beta[c] - m * sc;
   float* yb = y + (long)b * n;
   const float* rb = residual ? residual + (long)b * n : nullptr;
   for (long i = t; i < n; i += 256) {

@@ -345,6 +345,41 @@ def heads_view(action_lin, critic_lin, unct_lin=None):
     return h
 
 
+def resnet18_grad_view(net_view, flat, prefix=""):
+    """avlen_resnet18 gradient struct for avlen_resnet18_train_bwd: same dims as `net_view`, pointers at the CANONICAL gradient
+    tensors inside `flat.grad` (names as in CustomResNet.state_dict(), smt_resnet.py:56-149)."""
+    gp = lambda n: C.c_void_p(flat.grad_ptr(prefix + n))
+    g = L.ResNet18()
+
+    def conv(v, name):
+        return L.Conv(gp(name), None, v.cin, v.cout, v.kh, v.kw, v.stride, v.pad)
+    g.conv1 = conv(net_view.conv1, "conv1.weight")
+    g.bn1 = L.Affine(gp("bn1.weight"), gp("bn1.bias"))
+    for i in range(8):
+        b, name = net_view.block[i], f"layer{i // 2 + 1}.{i % 2}."
+        gb = g.block[i]
+        gb.conv1, gb.conv2 = conv(b.conv1, name + "conv1.weight"), conv(b.conv2, name + "conv2.weight")
+        gb.bn1 = L.Affine(gp(name + "bn1.weight"), gp(name + "bn1.bias"))
+        gb.bn2 = L.Affine(gp(name + "bn2.weight"), gp(name + "bn2.bias"))
+        gb.has_down = b.has_down
+        if b.has_down:
+            gb.down = conv(b.down, name + "downsample.0.weight")
+            gb.bnd = L.Affine(gp(name + "downsample.1.weight"), gp(name + "downsample.1.bias"))
+    g.fc = L.Linear(gp("fc.weight"), gp("fc.bias"), net_view.fc.out_f, net_view.fc.in_f)
+    return g
+
+
+def cnn3_grad_view(net_view, flat, prefix):
+    """avlen_cnn3 gradient struct (canonical conv OIHW / fc (out, C*H*W) tensors inside flat.grad)."""
+    gp = lambda n: C.c_void_p(flat.grad_ptr(prefix + n))
+    g = L.Cnn3()
+    for i, idx in enumerate((0, 2, 4)):
+        v = net_view.conv[i]
+        g.conv[i] = L.Conv(gp(f"cnn.{idx}.weight"), gp(f"cnn.{idx}.bias"), v.cin, v.cout, v.kh, v.kw, v.stride, v.pad)
+    g.fc = L.Linear(gp("cnn.6.weight"), gp("cnn.6.bias"), net_view.fc.out_f, net_view.fc.in_f)
+    return g
+
+
 def grad_struct_like(view, name_of_ptr, flat):
     """Build a struct of the same ctypes type whose pointers address the matching ranges of flat.grad.
     `name_of_ptr`: {param data_ptr -> name}.  Pointers into a packed projection (row slices) are not

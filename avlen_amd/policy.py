@@ -1105,6 +1105,82 @@ class AudioNavDialogNet(_SMTBase):
         return out, rnn_hidden_states, feats, out
 
 
+    # ---- training path of PPO.update_dialog (ppo.py:99-154; csrc: train_resnet.hip, train_gru.hip, modules.hip) -----------
+    def train_forward(self, pol, obs, prev_actions, ext_memory, mem_index, ext_memory_dialog, ext_memory_masks, all_dialog,
+                      agent_step):
+        """evaluate_actions_dialog's forward (policy.py:807-865) with every activation kept: towers, AudioCNN, feature row, SMT
+        encoder, frozen CLIP -> dialog_layer, dialog encoder.  -> (x_att_dialog (R, d), saved)."""
+        eng = pol._engine()
+        rgb, depth, spec = _img(obs["rgb"]), _f32(obs["depth"]), _f32(obs[SPECTROGRAM])
+        R, S, dev, st, prec = rgb.shape[0], rgb.shape[1], rgb.device, L.stream(), pol.prec
+        F = self._feature_size
+        feats = torch.empty(R, F, device=dev)
+        goal = torch.empty(R, self._hidden_size, device=dev)
+        sv = {"R": R}
+        # visual towers: the preprocessed (x/255, 2x2 mean) 64x64 images are the networks' inputs
+        for key, img, div, col in (("rgb", rgb, 255.0, 0), ("depth", depth, 1.0, 64)):
+            x0 = torch.empty(R, 64, 64, img.shape[3], device=dev)
+            L.call("avlen_preprocess_image", E.P(img), _u8(img), E.P(x0), R, S, img.shape[3], div, st)
+            nb = L.lib.avlen_resnet18_train_workspace_bytes(C.byref(eng[key]), R, 64, 64, prec)
+            ws = pol._ws.get("train_" + key, nb, dev)
+            L.call("avlen_resnet18_train_fwd", C.byref(eng[key]), E.P(x0), R, 64, 64, E.P(feats, col), F, prec, E.P(ws), nb, st)
+            sv[key] = (x0, ws, nb)
+        H, W = spec.shape[1], spec.shape[2]
+        nb = L.lib.avlen_cnn3_train_workspace_bytes(C.byref(eng["audio"]), R, H, W, prec)
+        ws = pol._ws.get("train_audio", nb, dev)
+        L.call("avlen_cnn3_train_fwd", C.byref(eng["audio"]), E.P(spec), R, H, W, E.P(feats, 144), F, prec, E.P(ws), nb, st)
+        sv["audio"] = (spec, ws, nb, H, W)
+        pa = _i64(prev_actions.view(R, -1)[:, :1])
+        pose, cb, lb = _f32(obs[POSE]), _f32(obs[CATEGORY_BELIEF]), _f32(obs[LOCATION_BELIEF])
+        L.call("avlen_feature_assemble", E.P(feats), F, C.byref(eng["action"]), E.P(pa), 128, None, self._col_cat, E.P(pose),
+               self._x_dims - 4, None, 0, self._x_dims, E.P(cb), E.P(lb), E.P(goal), self._hidden_size, R, st)
+        x_att, smt_saved = self.smt(pol, feats, goal, ext_memory, ext_memory_masks, "smt_train", mem_index, save=True)
+        d_emb = e = None
+        if all_dialog is not None:
+            e = _f32(self.text_encoder_override(all_dialog) if self.text_encoder_override is not None
+                     else self.encode_text(pol, all_dialog))                 # frozen CLIP tower: no gradient
+            d_emb = self._dialog_embed(pol, e)
+        memd, mk, step = _f32(ext_memory_dialog), _f32(ext_memory_masks), _f32(agent_step.reshape(-1))
+        M = memd.shape[0]
+        nb = L.lib.avlen_dialog_train_workspace_bytes(C.byref(eng["dialog"]), R, M)
+        ws = pol._ws.get("train_dialog", nb, dev)
+        out = torch.empty(R, self._hidden_size, device=dev)
+        L.call("avlen_dialog_train_fwd", C.byref(eng["dialog"]), E.P(x_att), E.P(memd), E.P(mk), E.P(d_emb) if d_emb is not None
+               else None, E.P(step), E.P(goal), E.P(out), R, M, prec, E.P(ws), nb, st)
+        sv.update(feats=feats, goal=goal, pa=pa, smt=smt_saved, e=e, dialog=(ws, nb, M), keep=(memd, mk, step, x_att, d_emb))
+        return out, sv
+
+    def train_backward(self, pol, g, sv, d_out):
+        """Gradient of every trained parameter of pi_l given d_out = dL/d(x_att_dialog)."""
+        eng = pol._engine()
+        R, dev, st, prec, d = sv["R"], d_out.device, L.stream(), pol.prec, self._hidden_size
+        F = self._feature_size
+        ws, nb, M = sv["dialog"]
+        has_dialog = sv["e"] is not None
+        d_x_att = torch.empty(R, d, device=dev)
+        d_demb = torch.empty(R, d, device=dev) if has_dialog else None
+        L.call("avlen_dialog_bwd", C.byref(eng["dialog"]), C.byref(g["dialog"]), E.P(sv["goal"]), E.P(d_out), int(has_dialog),
+               E.P(d_x_att), E.P(d_demb) if has_dialog else None, R, M, prec, E.P(ws), nb, st)
+        if has_dialog:
+            e = sv["e"]
+            nbl = L.lib.avlen_linear_bwd_workspace_bytes()
+            wsl = pol._ws.get("linear_bwd", nbl, dev)
+            L.call("avlen_linear_bwd", C.byref(eng["dialog_layer"]), C.byref(g["dialog_layer"]), E.P(e), e.shape[1], E.P(d_demb), d,
+                   None, 0, R, prec, E.P(wsl), nbl, st)
+        ws, nb, B, Ms, Fs, cto = sv["smt"]
+        d_x = torch.empty(R, F, device=dev)
+        L.call("avlen_smt_bwd", C.byref(eng["smt"]), C.byref(g["smt"]), E.P(sv["goal"]), E.P(d_x_att), B, Ms, Fs, self._x_dims - 4,
+               cto, prec, E.P(d_x), F, E.P(ws), nb, st)
+        for key, col in (("rgb", 0), ("depth", 64)):
+            x0, wst, nbt = sv[key]
+            L.call("avlen_resnet18_train_bwd", C.byref(eng[key]), C.byref(g[key]), E.P(x0), E.P(d_x, col), F, R, 64, 64, None, prec,
+                   E.P(wst), nbt, st)
+        L.call("avlen_action_encoder_bwd", E.P(d_x, 128), F, E.P(sv["pa"]), C.byref(g["action"]), R, st)
+        spec, wsa, nba, H, W = sv["audio"]
+        L.call("avlen_cnn3_train_bwd", C.byref(eng["audio"]), C.byref(g["audio"]), E.P(spec), E.P(sv["feats"], 144), E.P(d_x, 144),
+               F, R, H, W, prec, E.P(wsa), nba, st)
+
+
 class AudioNavBaselineNet(Net):
     """policy.py:379-498: [AudioCNN 512 | VisualCNN 512 | category 21] -> masked GRU (config 2)."""
 
@@ -1258,7 +1334,26 @@ class AudioNavSMTPolicy(_NetPolicy):
 
 
 class AudioNavDialogPolicy(_NetPolicy):
-    TRAINED_PREFIXES = ()
+    # frozen on the interactive rollout path; the parameters `PPO.update_dialog` reaches (ppo.py:99-154: everything under the
+    # vln action logits except the frozen CLIP tower, ddppo_trainer.py:401-403) come first in the flat buffer
+    TRAINED_PREFIXES = ("net.visual_encoder.", "net.goal_encoder.", "net.action_encoder.", "net.smt_state_encoder.",
+                        "net.dialog_layer.", "net.dialog_state_encoder.", "action_distribution_vln.")
+
+    def grad_views(self, eng):
+        if "grads" not in eng:
+            flat, p2n = eng["flat"], eng["ptr2name"]
+            gp = lambda n: C.c_void_p(flat.grad_ptr(n))
+            lin = lambda v, n: L.Linear(gp(n + ".weight"), gp(n + ".bias"), v.out_f, v.in_f)
+            eng["grads"] = {
+                "rgb": E.resnet18_grad_view(eng["rgb"], flat, "net.visual_encoder.rgb_encoder."),
+                "depth": E.resnet18_grad_view(eng["depth"], flat, "net.visual_encoder.depth_encoder."),
+                "audio": E.cnn3_grad_view(eng["audio"], flat, "net.goal_encoder."),
+                "action": lin(eng["action"], "net.action_encoder"),
+                "smt": E.grad_struct_like(eng["smt"], p2n, flat),
+                "dialog_layer": lin(eng["dialog_layer"], "net.dialog_layer"),
+                "dialog": E.grad_struct_like(eng["dialog"], p2n, flat),
+                "heads": E.grad_struct_like(self._heads("vln"), p2n, flat)}
+        return eng["grads"]
 
     def __init__(self, observation_space, action_space, hidden_size=128, **kwargs):
         ek = _split_engine_kwargs(kwargs)

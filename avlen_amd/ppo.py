@@ -96,7 +96,7 @@ class PPO(nn.Module):
                float(self.value_loss_coef), float(self.entropy_coef), float(self.unct_coef), E.P(loss_row),
                E.P(d_feats), R, st)
         L.call("avlen_smt_bwd", C.byref(eng["smt"]), C.byref(smt_g), E.P(goal), E.P(d_feats), B, M, F, net._x_dims - 4,
-               cto, pol.prec, E.P(ws), nb, st)
+               cto, pol.prec, None, 0, E.P(ws), nb, st)
         self.reduce_gradients(flat)
         ad = self._adam_state(flat)
         ad["step"] += 1
@@ -129,8 +129,59 @@ class PPO(nn.Module):
         return (float(s[0]) / num_updates, float(s[1]) / num_updates, float(s[2]) / num_updates, float(s[3]),
                 float(s[4]), float(s[5]) / num_updates)
 
+    DIALOG_CLASS_WEIGHTS = (0.0, 0.33, 0.33, 0.33)       # weight_type = 'balanced' (ppo.py:69-76)
+
     def update_dialog(self, rollouts):
-        raise NotImplementedError("dialog pre-training (ppo.py:99-154) is outside the accelerated path (SURVEY §8)")
+        """ppo.py:99-154 (dialog pre-training of pi_l): ONE optimiser step of `dialog_optimizer` on the class-weighted cross
+        entropy between the vln action logits of the rows with o_masks != 0 and the oracle actions, over every stored step of
+        every environment.  The gradient reaches the dialog encoder, dialog_layer, the SMT state encoder and -- unlike pi_q's
+        update -- the visual towers, the AudioCNN and the action encoder (policy.py:807-808 takes the features with grad); the
+        CLIP tower is frozen.  No gradient clipping (the reference calls optimizer.step() directly).  Returns the loss as a
+        0-dim device tensor."""
+        flat, loss = self._dialog_forward_backward(rollouts)
+        pol = self.actor_critic
+        dev, st = flat.flat.device, L.stream()
+        self.reduce_gradients(flat)
+        if getattr(self, "_adam_dialog", None) is None or self._adam_dialog["m"].numel() != flat.n_trained:
+            self._adam_dialog = {"m": torch.zeros(flat.n_trained, device=dev), "v": torch.zeros(flat.n_trained, device=dev), "step": 0}
+        ad = self._adam_dialog
+        ad["step"] += 1
+        pg = self.dialog_optimizer.param_groups[0]
+        L.call("avlen_adam_step", E.P(flat.flat), E.P(flat.grad), E.P(ad["m"]), E.P(ad["v"]), flat.n_trained, float(pg["lr"]), 0.9,
+               0.999, float(pg["eps"]), ad["step"], 0.0, None, st)
+        pol.mark_params_changed()                 # conv / fc weights moved: packed copies and bf16 shadows follow
+        pol._engine()
+        return loss
+
+    def _dialog_forward_backward(self, rollouts):
+        """Loss and gradient of update_dialog's batch: fills the flat gradient buffer; -> (FlatParams, loss tensor)."""
+        pol, net = self.actor_critic, self.actor_critic.net
+        T, N = rollouts.step, rollouts.num_envs
+        R = T * N
+        (obs, _h, _actions, prev_actions, _, _, _masks, _, _, _em_vln, _em_dlg, _em_masks, em_vln_masks, all_dialog, agent_step,
+         _, _) = rollouts.dialog_batching()
+        eng = pol._engine()
+        flat = eng["flat"]
+        g = pol.grad_views(eng)
+        dev, st = flat.flat.device, L.stream()
+        flat.grad.zero_()
+        # the ring is stored once: row t*N + n reads column n (no (em_size, T*N, dim) copy for the SMT encoder)
+        mem_index = torch.arange(N, device=dev, dtype=torch.int32).repeat(T).contiguous()
+        emd = rollouts.em_vln_dialog
+        memd = emd.memory.unsqueeze(1).expand(-1, T, -1, -1).reshape(emd.total_size, R, emd.dim).contiguous()
+        out, sv = net.train_forward(pol, obs, prev_actions, rollouts.em_vln.memory, mem_index, memd, em_vln_masks, all_dialog,
+                                    agent_step)
+        d = out.shape[1]
+        o_actions = rollouts.o_actions[:T].reshape(-1).contiguous()
+        o_masks = rollouts.o_masks[:T].reshape(-1).contiguous()
+        wcls = torch.tensor(self.DIALOG_CLASS_WEIGHTS, device=dev)
+        scratch = torch.zeros(2, device=dev)                      # [norm, loss]
+        d_out = torch.empty(R, d, device=dev)
+        heads = pol._heads("vln")
+        L.call("avlen_dialog_loss_heads_bwd", C.byref(heads), C.byref(g["heads"]), E.P(out), d, pol.dim_actions, E.P(o_actions),
+               E.P(o_masks), E.P(wcls), E.P(scratch), E.P(scratch, 1), E.P(d_out), R, st)
+        net.train_backward(pol, g, sv, d_out)
+        return flat, scratch[1]
 
     def before_step(self):
         pass

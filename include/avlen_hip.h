@@ -259,7 +259,8 @@ int avlen_smt_fwd(const avlen_smt* p, const float* x, const float* memory, const
  * path: policy.py:1035-1036).  `ws` must be the forward's workspace, untouched.  Gradients are
  * ACCUMULATED into `g` (same layout as p). */
 int avlen_smt_bwd(const avlen_smt* p, const avlen_smt* g, const float* goal, const float* d_out, int B, int M, int F,
-                  int pose_col, int current_token_only, int prec, void* ws, size_t ws_bytes, avlen_stream_t stream);
+                  int pose_col, int current_token_only, int prec, float* d_x, int ld_dx, void* ws, size_t ws_bytes,
+                  avlen_stream_t stream);
 /* Tuning knob: row count from which the training path's Linear products (avlen_smt_fwd with save_for_backward,
  * avlen_smt_bwd, bf16 mode) cast their fp32 operands to bf16 once and run the glds/MFMA GEMM (default 16384 rows). */
 void avlen_set_big_m(long rows);
@@ -330,6 +331,35 @@ int avlen_baseline_train_bwd(const avlen_cnn3* audio, const avlen_cnn3* visual, 
                              const avlen_cnn3* g_visual, const avlen_gru* g_gru, const float* spec, const float* masks,
                              const float* d_out, int T, int N, int Ha, int Wa, int S, int prec, void* ws, size_t ws_bytes,
                              avlen_stream_t stream);
+
+/* ---- PPO.update_dialog (ppo.py:99-154): the pieces of pi_l's backward that are not shared with pi_q's update.
+ * avlen_smt_bwd's d_x (B, F; optional) = gradient w.r.t. the current observation's feature row (pose columns zero).
+ * Dialog state encoder (dialog_state_encoder.py:114-155) in training form: _train_fwd keeps every activation in the workspace,
+ * _bwd accumulates parameter gradients into `g` and returns d_x_att (B,d) and, when the forward had a dialog embedding, d_demb. */
+size_t avlen_dialog_train_workspace_bytes(const avlen_dialog* p, int B, int M);
+int avlen_dialog_train_fwd(const avlen_dialog* p, const float* x_att, const float* memory_state, const float* masks,
+                           const float* d_emb, const float* agent_step, const float* goal, float* out, int B, int M, int prec,
+                           void* ws, size_t ws_bytes, avlen_stream_t stream);
+int avlen_dialog_bwd(const avlen_dialog* p, const avlen_dialog* g, const float* goal, const float* d_out, int has_dialog,
+                     float* d_x_att, float* d_demb, int B, int M, int prec, void* ws, size_t ws_bytes, avlen_stream_t stream);
+/* One Linear between modules (dialog_layer, policy.py:849): G.w += dY^T X, G.b += colsum dY, dX = dY W (dX optional). */
+size_t avlen_linear_bwd_workspace_bytes(void);
+int avlen_linear_bwd(const avlen_linear* L, const avlen_linear* G, const float* X, int ldx, const float* dY, int ldy, float* dX,
+                     int lddx, int M, int prec, void* ws, size_t ws_bytes, avlen_stream_t stream);
+/* action_encoder = Linear(one_hot(prev_action)) (policy.py:662-667): G.w[j][a] += sum_{b: a_b = a} d[b][j], G.b[j] += sum_b d[b][j]. */
+int avlen_action_encoder_bwd(const float* d_feats, int ld, const int64_t* prev_actions, const avlen_linear* G, int B,
+                             avlen_stream_t stream);
+/* CrossEntropyLoss(weight) of the vln action logits over rows with o_masks != 0 against o_actions (ppo.py:139-145), its head
+ * gradients (accumulated) and d_feats (R,d).  norm: 1 float scratch; loss: 1 float, accumulated. */
+int avlen_dialog_loss_heads_bwd(const avlen_heads* h, const avlen_heads* g, const float* feats, int d, int A,
+                                const float* o_actions, const int64_t* o_masks, const float* class_weights, float* norm,
+                                float* loss, float* d_feats, int R, avlen_stream_t stream);
+/* AudioCNN alone in training form (pi_l's goal encoder under update_dialog): see avlen_baseline_train_*. */
+size_t avlen_cnn3_train_workspace_bytes(const avlen_cnn3* net, int B, int H, int W, int prec);
+int avlen_cnn3_train_fwd(const avlen_cnn3* net, const float* x, int B, int H, int W, float* out, int ld_out, int prec, void* ws,
+                         size_t ws_bytes, avlen_stream_t stream);
+int avlen_cnn3_train_bwd(const avlen_cnn3* net, const avlen_cnn3* grads, const float* x, const float* y, const float* d_out,
+                         int ld, int B, int H, int W, int prec, void* ws, size_t ws_bytes, avlen_stream_t stream);
 
 /* ---- GroupNorm ResNet-18 training (CustomResNet, smt_resnet.py:37-149): forward with saved activations + backward.
  * Users: BeliefPredictor's online regression (ppo_trainer.py:959-1030) and pi_l's towers under PPO.update_dialog (ppo.py:99-154).

@@ -463,7 +463,7 @@ def _gradient_check(specs, precision, tol, loss_rtol=1e-3, rerun_bwd=None):
            E.P(tens[2]), E.P(tens[3]), E.P(tens[4]), E.P(tens[5]), E.P(tens[6]), E.P(norm), 0.2, 0.5, 0.05, 0.5,
            E.P(loss), E.P(d_feats), B, L.stream())
     L.call("avlen_smt_bwd", C.byref(eng["smt"]), C.byref(smt_g), E.P(goal), E.P(d_feats), Bq, Mq, F, 272, cto, pol.prec,
-           E.P(ws), nb, L.stream())
+           None, 0, E.P(ws), nb, L.stream())
     torch.cuda.synchronize()
     lossv = loss.cpu().numpy()
     np.testing.assert_allclose(lossv[[0, 1, 2, 5]], [float(vl), float(al), float(h["entropy"]), float(ul)], rtol=loss_rtol,
@@ -484,7 +484,7 @@ def _gradient_check(specs, precision, tol, loss_rtol=1e-3, rerun_bwd=None):
             first = {k: out_grads[k].clone() for k in smt_keys}
             flat.grad.zero_()
             L.call("avlen_smt_bwd", C.byref(eng["smt"]), C.byref(smt_g), E.P(goal), E.P(d_feats), Bq, Mq, F, 272, cto, pol.prec,
-                   E.P(ws), nb, L.stream())
+                   None, 0, E.P(ws), nb, L.stream())
             torch.cuda.synchronize()
             return {k: flat.grad_view(k, osd[k].shape).cpu().double() for k in smt_keys}
         def forward_only():                  # the training forward (save_for_backward) on the SAME features, fresh workspace

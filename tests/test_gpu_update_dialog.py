@@ -1,0 +1,135 @@
+"""`PPO.update_dialog` (dialog pre-training of pi_l; ss_baselines/savi/ppo/ppo.py:99-154) on the HIP path:
+ (1) against a golden from the reference's own PPO / RolloutStorage / AudioNavDialogPolicy (oracle/make_goldens_dialog.py):
+     the loss, which parameter tensors the step moves, and by how much;
+ (2) every parameter gradient against torch autograd on the oracle restatement -- the backward runs through the dialog state
+     encoder, dialog_layer, the SMT state encoder, both GroupNorm ResNet-18 towers, the AudioCNN and the action encoder.
+CLIP is replaced by the same stub embedding on every side (third-party, absent: SURVEY 8c)."""
+import json
+import os
+import numpy as np
+import pytest
+import torch
+
+import fixtures as fx
+import restate as R
+from conftest import golden, GOLDEN, param_specs
+from avlen_amd import policy as P
+from avlen_amd.ppo import DDPPO
+from avlen_amd.rollout_storage import RolloutStorage
+from avlen_amd.spaces import savi_observation_space, ActionSpace, SMT_KW
+
+pytestmark = pytest.mark.gpu
+T, N = 3, 2
+
+
+def fill(st):
+    for t in range(T):
+        o = fx.observations(f"dlgupd.obs{t}", N)
+        for k in st.observations:
+            st.observations[k][t].copy_(o[k])
+        st.prev_actions[t].copy_(fx.ints(f"dlgupd.pa{t}", (N, 1), 4))
+        st.all_dialog[t].copy_(fx.dialog_tokens(f"dlgupd.tok{t}", N))
+        st.agent_step[t].copy_(fx.ints(f"dlgupd.as{t}", (N,), 3).float())
+        st.o_actions[t].copy_(fx.ints(f"dlgupd.oa{t}", (N,), 3).float() + 1.0)
+        st.o_masks[t].copy_(torch.tensor([1, 0] if t == 1 else [1, 1]))
+    st.o_actions[0, 1] = 0.0
+    st.em_vln_masks[:T].copy_(torch.from_numpy((fx.unit("dlgupd.mk", T * N * 3) < 0.7).astype("float32")).view(T, N, 3))
+    st.em_vln.memory.copy_(fx.memory("dlgupd.mem", 3, N, 276, 272))
+    st.em_vln_dialog.memory.copy_(fx.sym("dlgupd.memd", (3, N, 256)))
+    st.step = T
+
+
+def setup(precision="fp32"):
+    pol = P.AudioNavDialogPolicy(savi_observation_space(), ActionSpace(4), pretraining=False, use_category_input=False,
+                                 num_steps=3, precision=precision, **SMT_KW)
+    sd = fx.state_dict_for({k: tuple(v) for k, v in param_specs()["dialog"].items()})
+    assert not pol.load_state_dict(sd, strict=False).unexpected_keys
+    pol.cuda()
+    pol.net.text_encoder_override = lambda t: fx.stub_text_embedding(t.cpu()).cuda()
+    agent = DDPPO(pol, 0.2, 2, 2, 0.5, 0.05, lr=2.5e-4, eps=1e-5, max_grad_norm=0.2, use_normalized_advantage=False)
+    st = RolloutStorage(T, N, savi_observation_space(), ActionSpace(4), 512, True, 3, 3, 3, 3, 3, 3, 276, 276, 308, 256,
+                        num_recurrent_layers=-1, max_dialog_len=77, use_state_memory=True, device="cuda")
+    fill(st)
+    return pol, agent, st, sd
+
+
+def test_update_dialog_matches_reference():
+    g = golden("dialog_update")
+    meta = json.load(open(os.path.join(GOLDEN, "dialog_update_keys.json")))
+    pol, agent, st, _ = setup()
+    sd0 = {k: v.detach().cpu().clone() for k, v in pol.state_dict().items()}
+    loss = agent.update_dialog(st)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(float(loss), float(g["loss"]), rtol=1e-3)
+    sd = {k: v.detach().cpu() for k, v in pol.state_dict().items()}
+    moved = [k for k in meta["keys"] if not torch.equal(sd[k], sd0[k])]
+    assert moved == meta["moved"]                 # exactly the tensors the reference's dialog_optimizer steps
+    assert not any(k.startswith("net.clip.") and not torch.equal(sd[k], sd0[k]) for k in sd0)      # CLIP stays frozen
+    # one Adam step at lr 1e-5 moves every element with a non-zero gradient by ~lr: the summed |delta| per tensor counts them
+    dabs = np.array([float((sd[k] - sd0[k]).double().abs().sum()) for k in meta["keys"]])
+    np.testing.assert_allclose(dabs, g["delta_abs"], rtol=3e-2, atol=2e-5)
+    pabs = np.array([float(sd[k].double().abs().sum()) for k in meta["keys"]])
+    np.testing.assert_allclose(pabs, g["param_abs"], rtol=1e-4)
+
+
+@pytest.mark.parametrize("with_dialog", [True, False])
+def test_update_dialog_gradients_match_oracle_autograd(with_dialog):
+    pol, agent, st, sd0 = setup()
+    if not with_dialog:
+        st.all_dialog.zero_()
+    osd = {k: v.clone() for k, v in sd0.items()}
+    tr = [k for k in osd if k.startswith(P.AudioNavDialogPolicy.TRAINED_PREFIXES)]
+    for k in tr:
+        osd[k].requires_grad_(True)
+    fl = lambda x: x[:T].reshape((T * N,) + tuple(x.shape[2:])).cpu()
+    obs = {k: fl(v).float() for k, v in st.observations.items()}
+    mem = st.em_vln.memory.cpu().unsqueeze(1).expand(-1, T, -1, -1).reshape(3, T * N, 276)
+    memd = st.em_vln_dialog.memory.cpu().unsqueeze(1).expand(-1, T, -1, -1).reshape(3, T * N, 256)
+    toks = fl(st.all_dialog)
+    if with_dialog:
+        xd, _ = R.dialog_net(osd, obs, fl(st.prev_actions), mem, memd, fl(st.em_vln_masks), toks, fl(st.agent_step),
+                             clip_fn=fx.stub_text_embedding)
+    else:
+        xd, _ = R.dialog_net(osd, obs, fl(st.prev_actions), mem, memd, fl(st.em_vln_masks), None, fl(st.agent_step))
+    logits = R._lin(osd, "action_distribution_vln.linear", xd)
+    m = fl(st.o_masks) != 0
+    loss = torch.nn.functional.cross_entropy(logits[m], fl(st.o_actions)[m].long(), weight=torch.tensor([0.0, 0.33, 0.33, 0.33]))
+    loss.backward()
+    if not with_dialog:
+        pol.net.text_encoder_override = None
+        orig = agent._dialog_forward_backward
+
+        class _NoDialog:            # the reference's without_dialog=True: all_dialog = None (policy.py:144-145)
+            pass
+        import avlen_amd.rollout_storage as rs
+        db = st.dialog_batching
+        st.dialog_batching = lambda: tuple(None if i == 13 else x for i, x in enumerate(db()))
+    flat, ours = agent._dialog_forward_backward(st)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(float(ours), float(loss), rtol=1e-3)
+    worst, n_checked, errs = 0.0, 0, []
+    for k in tr:
+        ref = osd[k].grad
+        mine = flat.grad_view(k, osd[k].shape).cpu().double()
+        if ref is None:
+            assert float(mine.abs().max()) == 0.0, k
+            continue
+        err = float((mine - ref.double()).norm() / (ref.double().norm() + 1e-30))
+        worst = max(worst, err)
+        n_checked += 1
+        errs.append((err, k, float(ref.double().norm())))
+    errs.sort(reverse=True)
+    print(f"with_dialog={with_dialog}: max relative L2 gradient error over {n_checked} tensors: {worst:.3g}")
+    groups = {}
+    for e_, k_, n_ in errs:
+        gk = ".".join(k_.split(".")[:3])
+        groups[gk] = max(groups.get(gk, 0.0), e_)
+    for gk, e_ in sorted(groups.items(), key=lambda kv: -kv[1]):
+        print(f"   {e_:.3g}  {gk}")
+    # Everything above the towers agrees to 1e-4.  Inside the towers a handful of ReLU inputs of this fixture lie within 1e-5 of
+    # zero (2 of the 98,304 outputs of rgb layer3.0, counted on the oracle): whichever side of zero an implementation's rounding
+    # puts them on switches one element of the upstream gradient on or off -- 1/sqrt(#active) ~ 0.5 % of the gradient norm of
+    # every layer below.  tools/tower_grad_probe.py (no ties) shows the same kernels at 3e-6.
+    for gk, e_ in groups.items():
+        assert e_ < (2e-2 if "visual_encoder" in gk else 1e-3), (gk, e_)
+
