@@ -11,7 +11,7 @@ python3 $R/bench.py > $O/bench_default.log 2>&1 || exit 1
 tail -1 $O/bench_default.log | cut -c1-300
 python3 -m pytest $R/tests -m gpu -q > $O/gpu_parity_tests.log 2>&1 || exit 1
 tail -1 $O/gpu_parity_tests.log
-rocprofv3 --kernel-trace --stats -d /tmp/ps -o res -- python3 $R/bench.py --steps 1 --warmup 1 --rollout 30 --no-cpu-baseline --no-roofline > /tmp/ps.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats -d /tmp/ps -o res -- python3 $R/bench.py --steps 1 --warmup 1 --rollout 30 --no-cpu-baseline --no-roofline --no-extras > /tmp/ps.log 2>&1 || exit 1
 DB=$(find /tmp/ps -name "*.db" | head -1)
 python3 $R/tools/prof_summary.py $DB > $O/rocprof_summary_head.md || exit 1
 python3 $R/tools/step_breakdown.py $DB 30 > $O/step_breakdown.md || exit 1
@@ -25,3 +25,10 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output
 cp $(find /tmp/pmc_mfma -name "*counter_collection.csv" | head -1) $O/pmc_MFMA_counter_collection.csv || exit 1
 python3 $R/tools/pmc_traffic.py $O/pmc_FETCH_SIZE_counter_collection.csv $O/pmc_WRITE_SIZE_counter_collection.csv $O/pmc_traffic.json $O/pmc_MFMA_counter_collection.csv > /dev/null || exit 1
 cat $O/pmc_traffic.json | head -30
+# the other configurations (one line each)
+python3 $R/bench.py --config gru --steps 3 --no-roofline --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_gru.log
+python3 $R/bench.py --distractor --steps 3 --no-roofline --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/bench_distractor.log
+python3 $R/bench.py --stage 2 --envs 32 --steps 2 --no-roofline --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/bench_stage2_envs32.log
+rocprofv3 --kernel-trace --stats -d /tmp/pg -o res -- python3 $R/bench.py --config gru --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > /tmp/pg.log 2>&1 || exit 1
+python3 $R/tools/prof_summary.py $(find /tmp/pg -name "*.db" | head -1) "rocprofv3 --kernel-trace --stats -- python bench.py --config gru --steps 1 --warmup 1" > $O/rocprof_gru.md
+cut -c1-200 $O/bench_gru.log $O/bench_distractor.log $O/bench_stage2_envs32.log
