@@ -93,10 +93,14 @@ def P(t, off_floats=0):
     return C.c_void_p(t.data_ptr() + 4 * off_floats)
 
 
-def linear_view(w, b, flat=None):
+def linear_view(w, b, flat=None, packed=None):
     v = L.Linear(P(w), P(b) if b is not None else None, w.shape[0], w.shape[1])
     if flat is not None and w.shape[1] % 8 == 0:
         v.w16, v.ld16 = flat.shadow_ptr(w), w.shape[1]
+    elif packed is not None:
+        # in_f not a multiple of 8 (the distractor variant's fusion input: 297 / 329 + 12 columns): the bf16 GEMMs need
+        # 16-byte rows, so the shadow is a zero-padded derived copy [out_f][ld16]
+        v.w16, v.ld16 = packed.linear_pad(w)
     return v
 
 
@@ -161,6 +165,22 @@ class Packed:
         v.w16, v.ld16 = P(buf16), C_ * HW
         return v
 
+    def linear_pad(self, w):
+        """bf16 copy of a Linear weight with rows padded to a multiple of 8 columns (pad columns stay zero)."""
+        out_f, in_f = w.shape
+        ld = (in_f + 7) // 8 * 8
+        buf16 = torch.zeros(out_f, ld, dtype=torch.bfloat16, device=self.device)
+        self.bufs.append(buf16)
+        self.jobs.append(("pad16", w, None, buf16, (out_f, in_f), ld))
+        return P(buf16), ld
+
+    def refresh_pads(self):
+        """Only the padded Linear shadows (the ones among them that are TRAINED move with every optimiser step)."""
+        st = L.stream()
+        for kind, w, buf, buf16, dims, c16 in self.jobs:
+            if kind == "pad16":
+                L.call("avlen_cast_bf16", P(w), dims[1], P(buf16), c16, dims[0], dims[1], st)
+
     def ln_fold(self, lin_w, lin_b, ln):
         """LayerNorm `ln` folded into the Linear (lin_w, lin_b) that follows it (avlen_ln_fold_weights)."""
         N_, K = lin_w.shape
@@ -178,6 +198,8 @@ class Packed:
                 b, g, be, s, c = buf
                 L.call("avlen_ln_fold_weights", P(w), P(b) if b is not None else None, P(g), P(be), P(buf16), dims[1], P(s),
                        P(c), dims[0], dims[1], st)
+            elif kind == "pad16":
+                L.call("avlen_cast_bf16", P(w), dims[1], P(buf16), c16, dims[0], dims[1], st)
             elif kind == "conv32":
                 L.call("avlen_pack_conv_weight", P(w), P(buf), *dims, st)
             elif kind == "convbn":
@@ -289,10 +311,10 @@ def transformer_view(t, d, nhead, flat=None):
     return s
 
 
-def smt_view(enc, flat=None):
+def smt_view(enc, flat=None, packed=None):
     s = L.Smt()
     s.pose = linear_view(enc.pose_encoder.weight, enc.pose_encoder.bias)
-    s.fus0 = linear_view(enc.fusion_encoder[0].weight, enc.fusion_encoder[0].bias, flat)
+    s.fus0 = linear_view(enc.fusion_encoder[0].weight, enc.fusion_encoder[0].bias, flat, packed)
     s.fus2 = linear_view(enc.fusion_encoder[2].weight, enc.fusion_encoder[2].bias, flat)
     s.tr = transformer_view(enc.transformer, enc._dim_feedforward, enc._nhead, flat)
     return s

@@ -789,7 +789,7 @@ class _SMTBase(Net):
         eng["depth"] = E.resnet18_view(self.visual_encoder.depth_encoder, packed)
         eng["audio"] = E.cnn3_view(self.goal_encoder, packed)
         eng["action"] = E.linear_view(self.action_encoder.weight, self.action_encoder.bias)
-        eng["smt"] = E.smt_view(self.smt_state_encoder, eng["flat"])
+        eng["smt"] = E.smt_view(self.smt_state_encoder, eng["flat"], packed)
 
     def features(self, pol, obs, prev_actions, extra=None):
         """-> feats (B, F) = [visual 128 | action 16 | audio 128 | (category 21) | pose 4 | (extra)], goal (B,d)."""

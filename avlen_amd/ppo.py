@@ -107,6 +107,7 @@ class PPO(nn.Module):
         L.call("avlen_adam_step", E.P(flat.flat), E.P(flat.grad), E.P(ad["m"]), E.P(ad["v"]), flat.n_trained, float(lr),
                0.9, 0.999, float(eps), ad["step"], float(self.max_grad_norm), E.P(ad["norm_sq"]), st)
         flat.refresh16(trained_only=True)                 # bf16 shadows of the updated weights (rollout fast path)
+        eng["packed"].refresh_pads()                      # ... and the padded shadow of a fusion input that is not 8-aligned
 
     def update(self, rollouts):
         advantages = self.get_advantages(rollouts).contiguous()
