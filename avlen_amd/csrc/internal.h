@@ -15,7 +15,16 @@ int avlen_i_linear_dx(const avlen_ctx& c, const avlen_linear& L, const float* dY
                       const float* add, int ldadd);
 int avlen_i_linear_dw(const avlen_ctx& c, const avlen_linear& G, const float* dY, int ldy, const float* X, int ldx, int M);
 int avlen_i_colsum_acc(const avlen_ctx& c, const float* dY, int ld, float* out, int rows, int N);
+// conv weight gradient G.w[cout][KH*KW*C] += dY^T im2col(X) on the large-M bf16 route with the gather fused into the operand
+// cast; AVLEN_NOT_BIG = route not applicable (caller: im2col + avlen_i_linear_dw)
+#define AVLEN_NOT_BIG 100
+int avlen_i_conv_dw16(const avlen_ctx& c, const avlen_linear& G, const float* dY, int ldy, const float* X, long B, int H, int W,
+                      int C, int OH, int OW, int KH, int KW, int s, int pad);
 
+// few-row Linear against a tall weight matrix (train_gru.hip): out = x W^T + b, one wave per output column
+bool avlen_i_skinny_linear_ok(int M, int K);
+int avlen_i_skinny_linear(const float* x, int ldx, const float* W, const float* b, float* out, int ldo, int M, int N, int K,
+                          hipStream_t st);
 // fused masked GRU step (train_gru.hip): out = GRU(gi, hprev * mask), one wave per hidden unit
 bool avlen_i_gru_step_ok(int N, int H);
 int avlen_i_gru_step_fwd(const avlen_gru* p, const float* gi, const float* hprev, const float* mask, float* out, int N,

@@ -136,6 +136,57 @@ int linear_dw(const Ctx& c, const avlen_linear& G, const float* dY, int ldy, con
                     c.gws, c.gws_bytes, c.st);
 }
 
+// Convolution weight gradient on the large-M bf16 route WITHOUT materialising im2col(X) in fp32: the gather is fused into the
+// transposed cast (cols^T [K][Mp] bf16 is written straight from X), so the fp32 im2col buffer (1.2 GB for the GRU baseline's
+// first visual conv) is neither written nor read back.  G.w [cout][K] (packed layout) += dY^T * im2col(X).
+// Returns AVLEN_NOT_BIG when the route does not apply (fp32 mode / few rows): the caller takes im2col + linear_dw.
+__global__ void tcast_im2col_kernel(const float* __restrict__ X, bf16* __restrict__ dst, long ldt, long M, int K, long Mp, int H, int W,
+                                    int C, int OH, int OW, int KH, int KW, int s, int pad) {
+  __shared__ float t[32][33];
+  const long r0 = (long)blockIdx.x * 32; const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int k = c0 + tx;
+  int kh = 0, kw = 0, cc = 0;
+  const bool kok = k < K;
+  if (kok) { cc = k % C; const int tap = k / C; kw = tap % KW; kh = tap / KW; }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const unsigned m = (unsigned)r0 + ty + j * 8;          // M < 2^31 (checked by the launcher): 32-bit decode
+    float v = 0.f;
+    if (kok && m < (unsigned)M) {
+      const unsigned q = m / (unsigned)OW; const int ow = (int)(m - q * OW);
+      const unsigned b = q / (unsigned)OH; const int oh = (int)(q - b * OH);
+      const int ih = oh * s + kh - pad, iw = ow * s + kw - pad;
+      if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) v = X[(((long)b * H + ih) * W + iw) * C + cc];
+    }
+    t[ty + j * 8][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int kk = c0 + ty + j * 8; const long m = r0 + tx;
+    if (kk < K && m < Mp) dst[(long)kk * ldt + m] = (bf16)t[tx][ty + j * 8];
+  }
+}
+}  // namespace
+int avlen_i_conv_dw16(const avlen_ctx& c, const avlen_linear& G, const float* dY, int ldy, const float* X, long B, int H, int W,
+                      int C, int OH, int OW, int KH, int KW, int s, int pad) {
+  const long M = B * OH * OW;
+  const int K = KH * KW * C;
+  if (!big_path(c, M) || M > 0x7ffffff0L) return AVLEN_NOT_BIG;
+  const long Mp = pad8(M);
+  XsBump b(c);
+  bf16* dYT = b.take((size_t)G.out_f * Mp); bf16* XT = b.take((size_t)K * Mp);
+  if (!b.good) return AVLEN_NOT_BIG;
+  TRY(tcast(c, dY, ldy, dYT, Mp, M, G.out_f));
+  hipLaunchKernelGGL(tcast_im2col_kernel, dim3((unsigned)((Mp + 31) / 32), ceil_div(K, 32)), dim3(32, 8), 0, c.st, X, XT, Mp, M, K, Mp,
+                     H, W, C, OH, OW, KH, KW, s, pad);
+  TRY(avlen_launch_status());
+  return avlen_gemm_bf16(dYT, (int)Mp, XT, (int)Mp, G.w, K, nullptr, 0, nullptr, G.w, K, G.out_f, K, (int)Mp, 0, c.gws, c.gws_bytes,
+                         c.st);
+}
+namespace {
+
 // ---------------------------------------------------------------- small kernels used by the modules
 __global__ void colsum_acc_kernel(const float* __restrict__ dY, int ld, float* __restrict__ out, int rows, int N,
                                   int rows_per_block) {
@@ -1831,7 +1882,10 @@ extern "C" int avlen_gru_fwd(const avlen_gru* p, const float* x, const float* h0
   void* gws = w.take<char>(GEMM_SCRATCH);
   Ctx c{st, prec, gws, GEMM_SCRATCH};
   avlen_linear ih{p->w_ih, p->b_ih, 3 * H, p->in_f}, hh{p->w_hh, p->b_hh, 3 * H, H};
-  TRY(linear(c, ih, x, p->in_f, GI, 3 * H, T * N, 0, nullptr, 0));
+  if (avlen_i_skinny_linear_ok(T * N, p->in_f) && (p->in_f & 7))      // a rollout step: 16 rows, K = 1045 (not 8-aligned)
+    TRY(avlen_i_skinny_linear(x, p->in_f, p->w_ih, p->b_ih, GI, 3 * H, T * N, 3 * H, p->in_f, st));
+  else
+    TRY(linear(c, ih, x, p->in_f, GI, 3 * H, T * N, 0, nullptr, 0));
   const float* hprev = h0;
   dim3 g((unsigned)(((long)N * H + 255) / 256));
   if (avlen_i_gru_step_ok(N, H)) {          // few rows: one fused launch per step, one wave per hidden unit (train_gru.hip)

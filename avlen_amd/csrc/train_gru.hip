@@ -290,10 +290,13 @@ int cnn_bwd(const avlen_ctx& c, Ws& s, const avlen_cnn3* n, const avlen_cnn3* g,
     const float* in = i == 0 ? x : a.a[i - 1];
     if (M > 0x7fffffffL) return AVLEN_ERR_ARG;
     // weight / bias gradient
-    TRY(im2col(st, in, s.cols, R, d.h[i], d.w[i], k.cin, d.h[i + 1], d.w[i + 1], k.kh, k.kw, k.stride, 0));
     TRY(avlen_zero_bytes(s.gpack, (size_t)k.cout * Kc * 4, st));
     avlen_linear G{s.gpack, nullptr, k.cout, Kc, nullptr, 0};
-    TRY(avlen_i_linear_dw(c, G, dy, k.cout, s.cols, Kc, (int)M));
+    int rc = avlen_i_conv_dw16(c, G, dy, k.cout, in, R, d.h[i], d.w[i], k.cin, d.h[i + 1], d.w[i + 1], k.kh, k.kw, k.stride, 0);
+    if (rc == AVLEN_NOT_BIG) {
+      TRY(im2col(st, in, s.cols, R, d.h[i], d.w[i], k.cin, d.h[i + 1], d.w[i + 1], k.kh, k.kw, k.stride, 0));
+      TRY(avlen_i_linear_dw(c, G, dy, k.cout, s.cols, Kc, (int)M));
+    } else TRY(rc);
     const long nw = (long)k.cout * Kc;
     hipLaunchKernelGGL(unpack_conv_grad_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, s.gpack, g->conv[i].w, k.cout,
                        k.cin, k.kh, k.kw);
@@ -309,6 +312,45 @@ int cnn_bwd(const avlen_ctx& c, Ws& s, const avlen_cnn3* n, const avlen_cnn3* g,
 }
 
 }  // namespace
+
+// out[m][n] = sum_k x[m][k] W[n][k] + b[n] for a handful of rows (M <= 64) against a tall weight matrix whose K is not
+// 8-aligned (the GRU's input projection: 16 x 1045 x 1536 per rollout step): one wave per output column, W row in registers,
+// 16 rows at a time.  The tile GEMM needs 56 us for it (a dozen workgroups, fp32 staging); this is latency only.
+namespace {
+constexpr int SK_KP = 20;                    // K <= 64 * SK_KP
+__global__ __launch_bounds__(256) void skinny_linear_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ W,
+                                                            const float* __restrict__ b, float* __restrict__ out, int ldo, int M,
+                                                            int N, int K) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float w[SK_KP];
+#pragma unroll
+  for (int i = 0; i < SK_KP; i++) { const int k = lane + 64 * i; w[i] = k < K ? W[(long)n * K + k] : 0.f; }
+  const float bn = b ? b[n] : 0.f;
+  for (int m0 = 0; m0 < M; m0 += 16) {
+    float acc[16];
+#pragma unroll
+    for (int mm = 0; mm < 16; mm++) {
+      acc[mm] = 0.f;
+      if (m0 + mm < M) {
+#pragma unroll
+        for (int i = 0; i < SK_KP; i++) { const int k = lane + 64 * i; acc[mm] += (k < K ? x[(long)(m0 + mm) * ldx + k] : 0.f) * w[i]; }
+      }
+    }
+    float r = 0.f;
+#pragma unroll
+    for (int mm = 0; mm < 16; mm++) { const float sv = wave_sum(acc[mm]); if (lane == mm) r = sv; }
+    if (lane < 16 && m0 + lane < M) out[(long)(m0 + lane) * ldo + n] = r + bn;
+  }
+}
+}  // namespace
+bool avlen_i_skinny_linear_ok(int M, int K) { return M <= 64 && K <= 64 * SK_KP; }
+int avlen_i_skinny_linear(const float* x, int ldx, const float* W, const float* b, float* out, int ldo, int M, int N, int K,
+                          hipStream_t st) {
+  hipLaunchKernelGGL(skinny_linear_kernel, dim3(ceil_div(N, 4)), dim3(256), 0, st, x, ldx, W, b, out, ldo, M, N, K);
+  return avlen_launch_status();
+}
 
 // one GRU step for up to a few dozen rows (rollout `act`, modules.hip:avlen_gru_fwd): see gru_step_fwd_kernel
 bool avlen_i_gru_step_ok(int N, int H) { return N <= 64 && H <= 64 * GRU_HP; }

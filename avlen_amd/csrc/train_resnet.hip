@@ -105,9 +105,12 @@ int conv_bwd(const avlen_ctx& c, Ws& s, const avlen_conv& k, float* gw, const fl
     if (M > 0x7fffffffL) return AVLEN_ERR_ARG;
     const float* xc = x + b0 * H * W * k.cin;
     const float* dyc = dy + b0 * OH * OW * k.cout;
-    const float* cols = xc;
-    if (!pointwise) { TRY(im2col(c.st, xc, s.cols, nb, H, W, k.cin, OH, OW, k.kh, k.kw, k.stride, k.pad)); cols = s.cols; }
-    TRY(avlen_i_linear_dw(c, G, dyc, k.cout, cols, Kc, (int)M));
+    int rc = pointwise ? AVLEN_NOT_BIG : avlen_i_conv_dw16(c, G, dyc, k.cout, xc, nb, H, W, k.cin, OH, OW, k.kh, k.kw, k.stride, k.pad);
+    if (rc == AVLEN_NOT_BIG) {
+      const float* cols = xc;
+      if (!pointwise) { TRY(im2col(c.st, xc, s.cols, nb, H, W, k.cin, OH, OW, k.kh, k.kw, k.stride, k.pad)); cols = s.cols; }
+      TRY(avlen_i_linear_dw(c, G, dyc, k.cout, cols, Kc, (int)M));
+    } else TRY(rc);
     if (dx) {
       float* dxc = dx + b0 * H * W * k.cin;
       TRY(avlen_i_linear_dx(c, Wl, dyc, k.cout, s.cols, Kc, (int)M, nullptr, 0));
