@@ -1024,7 +1024,7 @@ extern "C" int avlen_attention_bwd_bf16(const float* Q, int ldq, const float* K,
                        delta, dQ, lddq, dK, lddk, dV, lddv, H, Sq, scale);
   else {
     static int nth = -1;                           // AVLEN_ATTN_BWD16_THREADS=256|512|1024 (A/B knob)
-    if (nth < 0) { const char* e = getenv("AVLEN_ATTN_BWD16_THREADS"); nth = e ? atoi(e) : 1024; }
+    if (nth < 0) nth = (int)avlen_knob("AVLEN_ATTN_BWD16_THREADS", 1024);
     if (nth == 256)
       hipLaunchKernelGGL((attn_bwd16_kernel<320, 256>), dim3(H, B), dim3(256), 0, stream, Q, ldq, K, ldk, V, ldv, O, ldo, dO, lddo, key_mask,
                          lse, delta, dQ, lddq, dK, lddk, dV, lddv, H, Sq, scale);

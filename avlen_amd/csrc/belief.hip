@@ -252,7 +252,7 @@ int any_fwd_bf16(const avlen_resnet18* net, const float* x, int B, int H, int W,
   if (!w.ok() || c1.cin16 > 32) return AVLEN_ERR_WS;
   auto conv = [&](const avlen_conv& k, const __bf16* in, float* o32, int h, int wd) {
     static int split = -1;                             // AVLEN_BELIEF_SPLITK=0: no split-K on the predictor's convs (A/B knob)
-    if (split < 0) { const char* e = getenv("AVLEN_BELIEF_SPLITK"); split = e ? atoi(e) : 1; }
+    if (split < 0) split = (int)avlen_knob("AVLEN_BELIEF_SPLITK", 1);
     return avlen_conv2d_nhwc_bf16(in, k.w16, nullptr, nullptr, o32, nullptr, nullptr, B, h, wd, k.cin16, k.cout, k.kh, k.kw, k.stride,
                                   k.pad, 0, split ? gws : nullptr, split ? CONV_SCRATCH : 0, st);
   };

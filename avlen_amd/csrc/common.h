@@ -16,6 +16,15 @@ static inline int avlen_launch_status() {
   return e == hipSuccess ? AVLEN_OK : AVLEN_ERR_LAUNCH;
 }
 
+// Tuning decisions that were measured with environment-variable A/B switches are CONSTANTS in the shipped library;
+// a lab build (-DAVLEN_LAB_KNOBS) restores the overrides for re-measuring.
+#ifdef AVLEN_LAB_KNOBS
+#include <stdlib.h>
+static inline long avlen_knob(const char* name, long dflt) { const char* e = getenv(name); return e ? atol(e) : dflt; }
+#else
+#define avlen_knob(name, dflt) (dflt)
+#endif
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

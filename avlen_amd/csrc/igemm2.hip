@@ -555,9 +555,9 @@ template <int BM, int BN, int WM, int WN>
 int launch4(const G2& p, int m_tiles, int n_tiles, hipStream_t st) {
   long blocks = (long)m_tiles * n_tiles * p.splitk * p.groups;
   static int forced = -1;                       // AVLEN_G2_NS=2|4 pins the stage count (A/B measurements)
-  if (forced < 0) { const char* e = getenv("AVLEN_G2_NS"); forced = e ? atoi(e) : 0; }
+  if (forced < 0) forced = (int)avlen_knob("AVLEN_G2_NS", 0);
   static long thresh = -1;
-  if (thresh < 0) { const char* e = getenv("AVLEN_G2_NS_BLOCKS"); thresh = e ? atol(e) : 480; }
+  if (thresh < 0) thresh = (long)avlen_knob("AVLEN_G2_NS_BLOCKS", 480);
   bool deep = forced ? forced == 4 : blocks < thresh;
   if (!deep) return launch_ns<BM, BN, WM, WN, 2, 256>(p, m_tiles, n_tiles, st);
   return launch_ns<BM, BN, WM, WN, 4, 256>(p, m_tiles, n_tiles, st);
@@ -601,7 +601,7 @@ int run_g2(G2 p, void* ws, size_t ws_bytes, hipStream_t st) {
     // 128x64 tiles also run 8 waves (4x2, 32-row wave tiles): -23 % on the towers' 64-channel convs (AVLEN_G2_N64=256 restores
     // the 4-wave instance for A/B runs)
     static int n64 = -1;
-    if (n64 < 0) { const char* e = getenv("AVLEN_G2_N64"); n64 = e ? atoi(e) : 512; }
+    if (n64 < 0) n64 = (int)avlen_knob("AVLEN_G2_N64", 512);
     if (n64 == 512 && bn == 64 && bm == 128 && (!has_stats || p.ohw % 32 == 0)) { nth = 512; ns = 2; }
   }
 #ifdef AVLEN_G2_LAB

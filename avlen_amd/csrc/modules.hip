@@ -32,12 +32,12 @@ typedef avlen_ctx Ctx;      // internal.h (xs: operand scratch of the large-M bf
 // accumulate), different summation order.  Used when bf16 mode is on, scratch was laid out and M >= big_m().
 bool attn_bwd16_on() {          // AVLEN_ATTN_BWD16=0: fp32 attention backward in bf16 mode too (A/B knob)
   static int v = -1;
-  if (v < 0) { const char* e = getenv("AVLEN_ATTN_BWD16"); v = e ? atoi(e) : 1; }
+  if (v < 0) v = (int)avlen_knob("AVLEN_ATTN_BWD16", 1);
   return v != 0;
 }
 long g_big_m = -1;
 long big_m() {
-  if (g_big_m < 0) { const char* e = getenv("AVLEN_BIGM"); g_big_m = e ? atol(e) : 16384; }
+  if (g_big_m < 0) g_big_m = (long)avlen_knob("AVLEN_BIGM", 16384);
   return g_big_m;
 }
 inline int pad8(long x) { return (int)((x + 7) & ~7L); }
@@ -534,13 +534,13 @@ struct ChainB {
 
 bool ragged_enabled() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("AVLEN_SMT_RAGGED"); v = e ? atoi(e) : 1; }
+  if (v < 0) v = (int)avlen_knob("AVLEN_SMT_RAGGED", 1);
   return v != 0;
 }
 
 bool chain_enabled() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("AVLEN_CHAIN"); v = e ? atoi(e) : 1; }
+  if (v < 0) v = (int)avlen_knob("AVLEN_CHAIN", 1);
   return v != 0;
 }
 
@@ -690,10 +690,10 @@ int resnet18_group_fwd_bf16(const avlen_resnet18* const* nets, const void* const
                                               rn ? RBE : nullptr, rrelu);
   };
   static int fuse_gn = -1;                     // AVLEN_DCONV_FUSE_GN=0: run bn1 as its own pass (A/B knob)
-  if (fuse_gn < 0) { const char* e = getenv("AVLEN_DCONV_FUSE_GN"); fuse_gn = e ? atoi(e) : 1; }
+  if (fuse_gn < 0) fuse_gn = (int)avlen_knob("AVLEN_DCONV_FUSE_GN", 1);
   auto fuse_gn_on = [&]() { return fuse_gn != 0; };
   static int resfuse = -1;                     // AVLEN_GN_RESFUSE=0: the stem's bn1 and the downsample norm as their own passes (A/B knob)
-  if (resfuse < 0) { const char* e = getenv("AVLEN_GN_RESFUSE"); resfuse = e ? atoi(e) : 1; }
+  if (resfuse < 0) resfuse = (int)avlen_knob("AVLEN_GN_RESFUSE", 1);
   float* STS[8];                               // the stem's statistics outlive block 0 when its norm is applied by the consumers
   next_stats(STS);
   const avlen_resblock& kb0 = nets[0]->block[0];
@@ -707,7 +707,7 @@ int resnet18_group_fwd_bf16(const avlen_resnet18* const* nets, const void* const
   bf16** cur = stem_fused ? raw[2] : act[0]; bf16** a1 = act[1]; bf16** idt = act[2]; bf16** nxt = act[3];
   int H = 64;
   static int tail = -1;                        // AVLEN_TOWER_TAIL=0: layers 3-4 as separate conv / GroupNorm launches (A/B knob)
-  if (tail < 0) { const char* e = getenv("AVLEN_TOWER_TAIL"); tail = e ? atoi(e) : 1; }
+  if (tail < 0) tail = (int)avlen_knob("AVLEN_TOWER_TAIL", 1);
   for (int i = 0; i < 8; i++) {
     if (i == 4 && tail && H == 32 && G <= 6) {
       // layers 3 + 4 (four basic blocks): one launch, one workgroup per image, activations resident in LDS
@@ -1777,7 +1777,7 @@ extern "C" int avlen_clip_text_fwd(const avlen_clip_text* p, const int64_t* toke
     float* stats = (float*)((char*)Hn + (size_t)R * wd * 2);
     const size_t st_stride = (size_t)R * 2;
     fold = fold && (size_t)wd * 2 >= (size_t)16 * p->layers;
-    { static int en = -1; if (en < 0) { const char* e = getenv("AVLEN_CLIP_FOLD"); en = e ? atoi(e) : 1; } fold = fold && en; }
+    { static int en = -1; if (en < 0) en = (int)avlen_knob("AVLEN_CLIP_FOLD", 1); fold = fold && en; }
     if (fold) TRY(avlen_zero_bytes(stats + st_stride, (2 * (size_t)p->layers - 1) * st_stride * sizeof(float), st));
     hipLaunchKernelGGL(clip_embed_ragged_kernel, dim3((unsigned)R), dim3(128), 0, st, tokens, p->tok_emb, p->pos_emb, X, seg,
                        rowmap, B, ctx, wd, p->vocab, fold ? Hn16 : (bf16*)nullptr, fold ? stats : (float*)nullptr);
@@ -1789,7 +1789,7 @@ extern "C" int avlen_clip_text_fwd(const avlen_clip_text* p, const int64_t* toke
     };
     bool pruned = false;
     static int prune = -1;                            // AVLEN_CLIP_PRUNE=0: last layer over every live token (A/B knob)
-    if (prune < 0) { const char* e = getenv("AVLEN_CLIP_PRUNE"); prune = e ? atoi(e) : 1; }
+    if (prune < 0) prune = (int)avlen_knob("AVLEN_CLIP_PRUNE", 1);
     if (fold) {
       // per layer: 4 GEMMs + attention, no LayerNorm launch: the out_proj / c_proj epilogues emit the new residual
       // stream in fp32 + bf16 and its row statistics; in_proj / c_fc apply the normalisation in their epilogue
