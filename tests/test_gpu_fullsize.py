@@ -74,3 +74,49 @@ def test_gae_identity_and_update_touches_only_trained_parameters(cycle):
             frozen += 1
     assert changed >= 30 and frozen >= 100        # q/k projections get exactly-zero gradients when pretraining=True
     ro.after_update()
+
+
+def test_gru_baseline_full_size_sequence_equals_stepwise():
+    """BASELINE configs[1] at full size (N=16, T=150, 257x101, bf16): the masked-GRU SEQUENCE forward of the update (T-major rows,
+    avlen_baseline_train_fwd: fused step kernels, saved activations) reproduces the hidden states the 150 single-step rollout
+    calls produced -- the reference's own RNN test pattern (habitat-lab-dialog/test/test_rnn_state_encoder.py:16-75, 1e-3) at
+    the benched size -- and one PPO update moves exactly the parameters that receive a gradient."""
+    from avlen_amd.harness import GruWorkload
+    torch.manual_seed(7)
+    wl = GruWorkload(16, 150)
+    for _ in range(wl.T):
+        wl.rollout_step()
+    ro, pol = wl.rollouts, wl.pol
+    assert torch.isfinite(ro.value_preds).all() and torch.isfinite(ro.action_log_probs).all()
+    assert int(ro.actions.min()) >= 0 and int(ro.actions.max()) <= 3 and (ro.action_log_probs <= 1e-6).all()
+    env = torch.arange(16, device="cuda")
+    obs = {k: ro._gather(v, env, 150) for k, v in ro.observations.items()}
+    out, _, _ = pol.net.train_forward(pol, obs, ro.recurrent_hidden_states[0], ro._gather(ro.masks, env, 150))
+    torch.cuda.synchronize()
+    stepwise = ro.recurrent_hidden_states[1:, 0].reshape(150 * 16, -1)           # hidden after step t, T-major
+    err = float((out - stepwise).abs().max())
+    assert err < 2e-2, err            # bf16 operands on both sides, different GEMM tilings (step: 16 rows, sequence: 2400 rows)
+    before = {n: p.detach().clone() for n, p in pol.named_parameters()}
+    vals = wl.update()
+    assert all(v == v and abs(v) < 1e4 for v in vals)
+    moved = [n for n, p in pol.named_parameters() if not torch.equal(p.detach(), before[n])]
+    assert all(n.startswith(pol.TRAINED_PREFIXES) for n in moved) and len(moved) == 24
+    assert wl.finite()
+
+
+@pytest.mark.parametrize("stage,distractor,envs", [(2, False, 32), (1, True, 32)])
+def test_per_gpu_share_of_the_sharded_configs(stage, distractor, envs):
+    """BASELINE configs[3] / configs[4] shard 256 environments as 8 x 32: one rank's share at full rollout length through the
+    benched harness (2nd stage: pi_q attends over its memory history in rollout and update; distractor: F = 297 / 329)."""
+    from avlen_amd.harness import Workload
+    torch.manual_seed(11)
+    wl = Workload(envs, 150, pretraining=(stage == 1), distractor=distractor)
+    out = wl.cycle()
+    torch.cuda.synchronize()
+    ro = wl.rollouts
+    assert all(v == v and abs(v) < 1e4 for v in out) and wl.finite()
+    probs = ro.action_probs[:150]
+    assert float((probs.sum(-1) - 1).abs().max()) < 1e-5 and (probs >= 0).all()
+    # after_update carried the last step over; the rings hold the rollout's 150 inserted rows per environment
+    assert int(ro.step) == 0 and ro.em_option.memory.shape == (300, envs, 329 if distractor else 308)
+    assert float(ro.em_option.memory.abs().sum()) > 0
