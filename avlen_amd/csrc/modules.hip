@@ -659,8 +659,15 @@ int resnet18_group_fwd_bf16(const avlen_resnet18* const* nets, const void* const
   TRY(avlen_zero_bytes(stats_all, (size_t)G * 21 * stat_stride * sizeof(float), st));
   int si = 0;
   auto next_stats = [&](float** out) { for (int g = 0; g < G; g++) out[g] = stats_all + ((size_t)g * 21 + si) * stat_stride; si++; };
+  // Preprocessing + stem + layer 1 as one launch per tower group (tower_head.hip: the 64x64x16 activation never leaves the CU)
+  static int head = -1;                        // AVLEN_TOWER_HEAD=0 (lab build): the launch-per-layer path below
+  if (head < 0) head = (int)avlen_knob("AVLEN_TOWER_HEAD", 1);
+  bool use_head = head != 0;
   for (int g = 0; g < G; g++) {
     if (!resnet18_has16(nets[g]) || channels[g] > 8) return AVLEN_ERR_ARG;
+    use_head = use_head && avlen_tower_head_supported(nets[g], S, channels[g]);
+  }
+  for (int g = 0; g < G && !use_head; g++) {
     int same = -1;                      // towers of different policies read the same image: preprocess it once
     for (int h = 0; h < g && same < 0; h++)
       if (imgs[h] == imgs[g] && channels[h] == channels[g] && divisors[h] == divisors[g]) same = h;
@@ -701,14 +708,20 @@ int resnet18_group_fwd_bf16(const avlen_resnet18* const* nets, const void* const
   // residual add (applied inside that GroupNorm pass) -- the normalised stem output never exists in HBM.
   const bool stem_fused = resfuse && fuse_gn_on() && !kb0.has_down && kb0.conv1.cout == 16 && nets[0]->conv1.cout == 16 &&
                           avlen_dconv_supported(64, kb0.conv1.cin16, kb0.conv1.cout, kb0.conv1.kh, kb0.conv1.kw, kb0.conv1.stride, kb0.conv1.pad);
-  TRY(conv([](const avlen_resnet18* n) -> const avlen_conv& { return n->conv1; }, x0, stem_fused ? raw[2] : raw[0], STS, 64));
-  if (!stem_fused)
-    TRY(gn([](const avlen_resnet18* n) -> const avlen_affine& { return n->bn1; }, raw[0], STS, nullptr, act[0], 4096, 16, 1));
-  bf16** cur = stem_fused ? raw[2] : act[0]; bf16** a1 = act[1]; bf16** idt = act[2]; bf16** nxt = act[3];
+  if (use_head) {
+    void* HY[8];
+    for (int g = 0; g < G; g++) HY[g] = act[0][g];
+    TRY(avlen_tower_head_bf16(nets, imgs, img_u8, channels, divisors, row_index, HY, G, B, S, st));
+  } else {
+    TRY(conv([](const avlen_resnet18* n) -> const avlen_conv& { return n->conv1; }, x0, stem_fused ? raw[2] : raw[0], STS, 64));
+    if (!stem_fused)
+      TRY(gn([](const avlen_resnet18* n) -> const avlen_affine& { return n->bn1; }, raw[0], STS, nullptr, act[0], 4096, 16, 1));
+  }
+  bf16** cur = (stem_fused && !use_head) ? raw[2] : act[0]; bf16** a1 = act[1]; bf16** idt = act[2]; bf16** nxt = act[3];
   int H = 64;
   static int tail = -1;                        // AVLEN_TOWER_TAIL=0: layers 3-4 as separate conv / GroupNorm launches (A/B knob)
   if (tail < 0) tail = (int)avlen_knob("AVLEN_TOWER_TAIL", 1);
-  for (int i = 0; i < 8; i++) {
+  for (int i = use_head ? 2 : 0; i < 8; i++) {
     if (i == 4 && tail && H == 32 && G <= 6) {
       // layers 3 + 4 (four basic blocks): one launch, one workgroup per image, activations resident in LDS
       for (int g = 0; g < G; g++) { X[g] = cur[g]; OUT[g] = nxt[g]; }

@@ -1,0 +1,337 @@
+// Stem + layer 1 of the CustomResNet tower (smt_resnet.py:132-141: conv 7x7 -> GroupNorm -> ReLU -> two basic blocks of
+// 16 channels at 64x64) -- with the sensor preprocessing (x / divisor, k x k block mean: smt_cnn.py:83-93) in front -- as ONE
+// launch: one workgroup per image keeps the whole 64x64x16 activation in LDS (136 KiB with a one-pixel zero frame,
+// so that the 3x3 taps need no bounds test), the basic blocks' residual and every raw conv output in REGISTERS (a wave
+// owns 8 image rows: 32 MFMA row tiles, 64 + 64 packed-bf16 registers), the conv weights as MFMA fragments in registers, and
+// takes the GroupNorm statistics from its own fp32 accumulators, reduced in a fixed order (deterministic: no atomics).
+// Replaces, per tower group: preprocess + 7x7 direct conv + four 3x3 direct convs + two GroupNorm-apply passes = 8 launches
+// that move the 128 KiB activation through HBM 13 times; here the image is read once and the layer-1 output written once.
+//
+// Same arithmetic as the launch-per-layer path (dconv.hip / norm.hip): bf16 operands, fp32 MFMA accumulation in the same K
+// order ([ky][kx][c] taps, 32 per step), raw conv outputs rounded to bf16 before GroupNorm, statistics from the fp32
+// accumulators, var = E[x^2] - mean^2 in double, y = relu(x * (gamma * rstd) + (beta - mean * gamma * rstd) [+ residual]).
+//
+// LDS layout of the 16-channel image: [66 rows][66 pixels][32 B]; the two 16-byte chunks of a pixel are swapped when
+// (pixel >> 3) & 1 so that the 16 pixels of an MFMA row tile read conflict-free (tower_tail.hip uses the same rule).
+#include "common.h"
+#include "../../include/avlen_hip.h"
+#include "internal.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+namespace {
+
+constexpr int HTH = 512, HNW = 8;
+constexpr int ROWP = 66;                          // pixels per LDS row at 16 channels (1 + 64 + 1); 66 rows (1 + 64 + 1)
+constexpr int IMG_BYTES = 66 * ROWP * 32;         // 139392
+constexpr int ROWP0 = 70;                         // stem input: 70 rows x 70 pixels (3 + 64 + 3), 16 B per pixel (8 channels)
+constexpr int PART_OFF = IMG_BYTES;               // [8 waves][16 channels][2] fp32
+constexpr int COEF_OFF = PART_OFF + HNW * 16 * 2 * 4;
+constexpr int HEAD_LDS = COEF_OFF + 2 * 16 * 4;
+static_assert(70 * ROWP0 * 16 <= IMG_BYTES && HEAD_LDS <= 160 * 1024, "tower head LDS budget");
+
+struct HeadTower { const void* img; int u8; int C; float div; const bf16* w[5]; const float* g[5]; const float* b[5]; bf16* y; };
+struct HeadArgs { HeadTower t[8]; const int* row_index; int S; long long* prof; };
+#ifdef AVLEN_HEAD_PROF          // tools/head_lab.hip: phase timestamps of every workgroup's wave 0
+#define HEAD_STAMP(k) do { if (args.prof && tid == 0) args.prof[(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define HEAD_STAMP(k) do { } while (0)
+#endif
+
+// four bf16 values packed in two 32-bit registers (a bf16x4 vector may be kept one element per register: 2x the pressure)
+struct P4 { unsigned lo, hi; };
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+__device__ __forceinline__ unsigned pack2(f32x2 v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)); }   // one v_cvt_pk_bf16_f32
+__device__ __forceinline__ P4 pack4(float a, float b, float c, float d) { return P4{pack2((f32x2){a, b}), pack2((f32x2){c, d})}; }
+__device__ __forceinline__ f32x2 unlo(const P4& p) { return (f32x2){__uint_as_float(p.lo << 16), __uint_as_float(p.lo & 0xffff0000u)}; }
+__device__ __forceinline__ f32x2 unhi(const P4& p) { return (f32x2){__uint_as_float(p.hi << 16), __uint_as_float(p.hi & 0xffff0000u)}; }
+__device__ __forceinline__ f32x2 relu2(f32x2 v) { return (f32x2){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)}; }
+// sum over the 16 lanes of a DPP row (the 16 pixels of an MFMA tile column group): 4 v_add_f32 with DPP operands, no LDS
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));   // row_mirror
+  return v;
+}
+
+__device__ __forceinline__ int a16(int y, int p, int chunk) { return (y * ROWP + p) * 32 + ((chunk ^ ((p >> 3) & 1)) << 4); }
+
+// The common sensor shapes (128 x 128 -> 64 x 64, rgb or depth): a lane's K * C inputs of one source row are contiguous and
+// even in number -> 8-byte (fp32) / 2-byte (uint8) vector loads, all of a pixel's loads in flight together.  Same arithmetic
+// as the generic loop: each element divided by `div`, summed in (dy, dx) order, scaled by 1 / K^2.
+template <int K, int C, typename T>
+__device__ __forceinline__ void preprocess_tile(const T* __restrict__ img, float div, float inv, char* lds, int tid) {
+  constexpr int S = 64 * K, E = K * C;            // elements per source row and output pixel
+  static_assert(E % 2 == 0, "vector loads need an even span");
+  typedef __attribute__((ext_vector_type(2))) T T2;
+  bf16x8 zero8;
+#pragma unroll
+  for (int e = 0; e < 8; e++) zero8[e] = (bf16)0.f;
+#pragma unroll 2
+  for (int i = tid; i < 4096; i += HTH) {
+    const int oy = i >> 6, ox = i & 63;
+    const T* p = img + ((long)oy * K * S + ox * K) * C;
+    T2 v[K][E / 2];
+#pragma unroll
+    for (int dy = 0; dy < K; dy++)
+#pragma unroll
+      for (int j = 0; j < E / 2; j++) v[dy][j] = *reinterpret_cast<const T2*>(p + (long)dy * S * C + 2 * j);
+    bf16x8 o = zero8;
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+      float s = 0.f;
+#pragma unroll
+      for (int dy = 0; dy < K; dy++)
+#pragma unroll
+        for (int dx = 0; dx < K; dx++) { const int e = dx * C + c; s += (float)v[dy][e >> 1][e & 1] / div; }
+      o[c] = (bf16)(s * inv);
+    }
+    *reinterpret_cast<bf16x8*>(lds + ((oy + 3) * ROWP0 + ox + 3) * 16) = o;
+  }
+}
+
+// per-wave statistics -> block statistics -> scale / shift of the 16 channels (GroupNorm(16) on 16 channels = per channel).
+// Fixed summation order (lanes by DPP butterflies, waves 0..7 in sequence): deterministic.  The moments are combined in double
+// (E[x^2] - mean^2 cancels), the reciprocal square root is taken in fp32 (correctly rounded sqrt and division).
+__device__ __forceinline__ void finish_stats(float (&s1)[4], float (&s2)[4], char* lds, const float* __restrict__ gamma,
+                                             const float* __restrict__ beta, int tid, int wave, int r16, int q) {
+  float* part = reinterpret_cast<float*>(lds + PART_OFF);
+  float* coef = reinterpret_cast<float*>(lds + COEF_OFF);
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const float a = row16_sum(s1[r]), c = row16_sum(s2[r]);
+    if (r16 == 0) *reinterpret_cast<float2*>(&part[(wave * 16 + q * 4 + r) * 2]) = make_float2(a, c);
+  }
+  __syncthreads();                                // every wave has also finished reading the image of this conv
+  if (tid < 16) {
+    double sum = 0.0, sq = 0.0;
+#pragma unroll
+    for (int w = 0; w < HNW; w++) { const float2 v = *reinterpret_cast<const float2*>(&part[(w * 16 + tid) * 2]); sum += v.x; sq += v.y; }
+    const double mean = sum * (1.0 / 4096.0);
+    double var = sq * (1.0 / 4096.0) - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = 1.0f / sqrtf((float)var + 1e-5f);
+    const float sc = gamma[tid] * rstd;
+    coef[tid] = sc; coef[16 + tid] = beta[tid] - (float)mean * sc;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(HTH) void tower_head_kernel(HeadArgs args, int B) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, q = lane >> 4;
+  const HeadTower& t = args.t[blockIdx.y];
+  const int b = blockIdx.x;
+  const float* coef = reinterpret_cast<const float*>(lds + COEF_OFF);
+  bf16x8 zero8;
+#pragma unroll
+  for (int e = 0; e < 8; e++) zero8[e] = (bf16)0.f;
+
+  HEAD_STAMP(0);
+  // ---- sensor preprocessing straight into the stem's LDS image: (x / div, k x k mean) -> 8 channels (>= C: zero), 3-pixel zero frame
+  {
+    const int S = args.S, k = S / 64, C = t.C;
+    const long bs = args.row_index ? args.row_index[b] : b;
+    const float div = t.div, inv = 1.f / (float)(k * k);
+    if (k == 2 && C == 3 && !t.u8) preprocess_tile<2, 3, float>((const float*)t.img + bs * S * S * 3, div, inv, lds, tid);
+    else if (k == 2 && C == 3) preprocess_tile<2, 3, unsigned char>((const unsigned char*)t.img + bs * S * S * 3, div, inv, lds, tid);
+    else if (k == 2 && C == 1 && !t.u8) preprocess_tile<2, 1, float>((const float*)t.img + bs * S * S, div, inv, lds, tid);
+    else
+      for (int i = tid; i < 4096; i += HTH) {
+        const int oy = i >> 6, ox = i & 63;
+        bf16x8 o = zero8;
+        const long base = ((bs * S + (long)oy * k) * S + (long)ox * k) * C;
+        for (int c = 0; c < C; c++) {
+          float s = 0.f;
+          for (int dy = 0; dy < k; dy++)
+            for (int dx = 0; dx < k; dx++) {
+              const long idx = base + ((long)dy * S + dx) * C + c;
+              s += (t.u8 ? (float)((const unsigned char*)t.img)[idx] : ((const float*)t.img)[idx]) / div;
+            }
+          o[c] = (bf16)(s * inv);
+        }
+        *reinterpret_cast<bf16x8*>(lds + ((oy + 3) * ROWP0 + ox + 3) * 16) = o;
+      }
+    for (int i = tid; i < 70 * 70; i += HTH) {
+      const int row = i / 70, col = i - row * 70;
+      if (row < 3 || row >= 67 || col < 3 || col >= 67) *reinterpret_cast<bf16x8*>(lds + i * 16) = zero8;
+    }
+  }
+  __syncthreads();
+  HEAD_STAMP(1);
+
+  P4 rawp[32], res[32];
+  float s1[4], s2[4];
+
+  // ---- stem: 7x7, 8 (padded) -> 16 channels.  K = 49 taps x 8 channels: k-step s, lane quarter q = tap 4 s + q.
+  // Every LDS address is (per-lane base of the k-step) + (compile-time offset of the tile): nothing per tile stays in registers.
+  {
+    const bf16* __restrict__ wt = t.w[0];
+    bf16x8 wf[13];
+    int tap_base[13];
+#pragma unroll
+    for (int s = 0; s < 13; s++) {
+      const int tap = 4 * s + q;
+      const bool ok = tap < 49;
+      wf[s] = ok ? *reinterpret_cast<const bf16x8*>(wt + (long)r16 * 392 + tap * 8) : zero8;
+      const int tp = ok ? tap : 48, ky = tp / 7, kx = tp - ky * 7;
+      tap_base[s] = ((wave * 8 + ky) * ROWP0 + r16 + kx) * 16;          // frame row = y + ky, frame pixel = x + kx
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) { s1[r] = 0.f; s2[r] = 0.f; }
+#pragma unroll
+    for (int rr = 0; rr < 8; rr++) {
+#pragma unroll
+      for (int mt = 0; mt < 4; mt++) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 13; s++) {
+          const bf16x8 xf = *reinterpret_cast<const bf16x8*>(lds + tap_base[s] + (rr * ROWP0 + mt * 16) * 16);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], xf, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) { const float v = acc[r]; s1[r] += v; s2[r] += v * v; }
+        rawp[rr * 4 + mt] = pack4(acc[0], acc[1], acc[2], acc[3]);
+      }
+    }
+  }
+  HEAD_STAMP(2);
+  finish_stats(s1, s2, lds, t.g[0], t.b[0], tid, wave, r16, q);
+  HEAD_STAMP(3);
+  // pixel (y, x) of the 16-channel image lives at frame (y + 1, x + 1); this lane's store slot for tile (rr, mt) = wr_base + const
+  const int wr_base = a16(wave * 8 + 1, r16 + 1, q >> 1) + (q & 1) * 8;
+  {
+    // a0 = relu(GN(raw)) -> LDS (16-channel layout) and the residual registers; the one-pixel frame zeroed
+    const f32x2 sc0 = {coef[q * 4], coef[q * 4 + 1]}, sc1 = {coef[q * 4 + 2], coef[q * 4 + 3]};
+    const f32x2 sh0 = {coef[16 + q * 4], coef[16 + q * 4 + 1]}, sh1 = {coef[16 + q * 4 + 2], coef[16 + q * 4 + 3]};
+#pragma unroll
+    for (int rr = 0; rr < 8; rr++) {
+#pragma unroll
+      for (int mt = 0; mt < 4; mt++) {
+        const P4 o = {pack2(relu2(unlo(rawp[rr * 4 + mt]) * sc0 + sh0)), pack2(relu2(unhi(rawp[rr * 4 + mt]) * sc1 + sh1))};
+        res[rr * 4 + mt] = o;
+        *reinterpret_cast<uint2*>(lds + wr_base + (rr * ROWP + mt * 16) * 32) = make_uint2(o.lo, o.hi);
+      }
+    }
+    for (int i = tid; i < 2 * 132 + 64 * 4; i += HTH) {
+      int off;
+      if (i < 264) off = ((i / 132) * 65 * ROWP) * 32 + (i % 132) * 16;                    // frame rows 0 and 65
+      else { const int j = i - 264, row = 1 + (j >> 2); off = (row * ROWP + ((j >> 1) & 1) * 65) * 32 + (j & 1) * 16; }
+      *reinterpret_cast<bf16x8*>(lds + off) = zero8;
+    }
+  }
+  __syncthreads();
+  HEAD_STAMP(4);
+
+  // ---- layer 1: four 3x3 convs, 16 -> 16.  K = 9 taps x 16 channels: k-step s, quarter q = tap 2 s + (q >> 1), chunk q & 1
+  for (int ci = 0; ci < 4; ci++) {
+    const bool second = ci & 1;                   // conv2 of a basic block: + residual, result becomes the next residual
+    const bf16* __restrict__ wt = t.w[1 + ci];
+    bf16x8 wf[5];
+    int rd_base[5];
+#pragma unroll
+    for (int s = 0; s < 5; s++) {
+      const int k = 32 * s + 8 * q;
+      wf[s] = k < 144 ? *reinterpret_cast<const bf16x8*>(wt + (long)r16 * 144 + k) : zero8;
+      int tap = 2 * s + (q >> 1);
+      if (tap > 8) tap = 8;
+      const int ky = tap / 3, kx = tap - ky * 3;
+      rd_base[s] = a16(wave * 8 + ky, r16 + kx, q & 1);       // frame row y + ky, frame pixel x + kx; + 16 px keeps the swizzle bit
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) { s1[r] = 0.f; s2[r] = 0.f; }
+#pragma unroll
+    for (int rr = 0; rr < 8; rr++) {
+#pragma unroll
+      for (int mt = 0; mt < 4; mt++) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 5; s++) {
+          const bf16x8 xf = *reinterpret_cast<const bf16x8*>(lds + rd_base[s] + (rr * ROWP + mt * 16) * 32);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], xf, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) { const float v = acc[r]; s1[r] += v; s2[r] += v * v; }
+        rawp[rr * 4 + mt] = pack4(acc[0], acc[1], acc[2], acc[3]);
+      }
+    }
+    HEAD_STAMP(5 + 2 * ci);
+    finish_stats(s1, s2, lds, t.g[1 + ci], t.b[1 + ci], tid, wave, r16, q);
+    HEAD_STAMP(6 + 2 * ci);
+    const f32x2 sc0 = {coef[q * 4], coef[q * 4 + 1]}, sc1 = {coef[q * 4 + 2], coef[q * 4 + 3]};
+    const f32x2 sh0 = {coef[16 + q * 4], coef[16 + q * 4 + 1]}, sh1 = {coef[16 + q * 4 + 2], coef[16 + q * 4 + 3]};
+#pragma unroll
+    for (int rr = 0; rr < 8; rr++) {
+#pragma unroll
+      for (int mt = 0; mt < 4; mt++) {
+        f32x2 v0 = unlo(rawp[rr * 4 + mt]) * sc0 + sh0, v1 = unhi(rawp[rr * 4 + mt]) * sc1 + sh1;
+        if (second) { v0 += unlo(res[rr * 4 + mt]); v1 += unhi(res[rr * 4 + mt]); }
+        const P4 o = {pack2(relu2(v0)), pack2(relu2(v1))};
+        if (second) res[rr * 4 + mt] = o;
+        *reinterpret_cast<uint2*>(lds + wr_base + (rr * ROWP + mt * 16) * 32) = make_uint2(o.lo, o.hi);
+      }
+    }
+    __syncthreads();
+  }
+  HEAD_STAMP(13);
+  // ---- layer-1 output, NHWC bf16: the frame's interior, 16 B per lane, consecutive lanes consecutive addresses
+  {
+    uint4* __restrict__ yo = reinterpret_cast<uint4*>(t.y + (long)b * 4096 * 16);
+#pragma unroll 4
+    for (int i = tid; i < 8192; i += HTH) {
+      const int px = i >> 1, y = px >> 6, x = px & 63;
+      yo[i] = *reinterpret_cast<const uint4*>(lds + a16(y + 1, x + 1, i & 1));
+    }
+  }
+  HEAD_STAMP(14);
+  (void)B;
+}
+
+}  // namespace
+
+bool avlen_tower_head_supported(const avlen_resnet18* n, int S, int C) {
+  if (!n || S % 64 || S < 64 || C < 1 || C > 8) return false;
+  const avlen_conv& k = n->conv1;
+  if (!k.w16 || k.cin16 != 8 || k.cout != 16 || k.kh != 7 || k.kw != 7 || k.stride != 1 || k.pad != 3) return false;
+  for (int i = 0; i < 2; i++) {
+    const avlen_resblock& bl = n->block[i];
+    if (bl.has_down) return false;
+    const avlen_conv* cs[2] = {&bl.conv1, &bl.conv2};
+    for (const avlen_conv* c : cs)
+      if (!c->w16 || c->cin16 != 16 || c->cout != 16 || c->kh != 3 || c->kw != 3 || c->stride != 1 || c->pad != 1) return false;
+  }
+  return true;
+}
+
+// Y[g] = layer-1 output (post-ReLU) NHWC bf16 (B, 64, 64, 16) of tower g; imgs[g] (B or more images of S x S x C, fp32 or uint8)
+int avlen_tower_head_bf16(const avlen_resnet18* const* nets, const void* const* imgs, const int* img_u8, const int* channels,
+                          const float* divisors, const int* row_index, void* const* Y, int groups, int B, int S,
+                          hipStream_t stream) {
+  if (groups < 1 || groups > 8 || B <= 0) return AVLEN_ERR_ARG;
+  HeadArgs a = {};
+  a.row_index = row_index; a.S = S;
+  for (int g = 0; g < groups; g++) {
+    const avlen_resnet18* n = nets[g];
+    if (!avlen_tower_head_supported(n, S, channels[g])) return AVLEN_ERR_ARG;
+    HeadTower& t = a.t[g];
+    t.img = imgs[g]; t.u8 = img_u8 ? img_u8[g] : 0; t.C = channels[g]; t.div = divisors[g]; t.y = (bf16*)Y[g];
+    t.w[0] = (const bf16*)n->conv1.w16; t.g[0] = n->bn1.g; t.b[0] = n->bn1.b;
+    for (int i = 0; i < 2; i++) {
+      t.w[1 + 2 * i] = (const bf16*)n->block[i].conv1.w16; t.g[1 + 2 * i] = n->block[i].bn1.g; t.b[1 + 2 * i] = n->block[i].bn1.b;
+      t.w[2 + 2 * i] = (const bf16*)n->block[i].conv2.w16; t.g[2 + 2 * i] = n->block[i].bn2.g; t.b[2 + 2 * i] = n->block[i].bn2.b;
+    }
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, HEAD_LDS);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(tower_head_kernel, dim3(B, groups), dim3(HTH), HEAD_LDS, stream, a, B);
+  return avlen_launch_status();
+}
