@@ -27,16 +27,17 @@ namespace {
 constexpr int HTH = 512, HNW = 8;
 constexpr int ROWP = 66;                          // pixels per LDS row at 16 channels (1 + 64 + 1); 66 rows (1 + 64 + 1)
 constexpr int IMG_BYTES = 66 * ROWP * 32;         // 139392
-constexpr int ROWP0 = 70;                         // stem input: 70 rows x 70 pixels (3 + 64 + 3), 16 B per pixel (8 channels)
+constexpr int ROWP0 = 70;                         // stem input: 70 rows x 70 pixels (3 + 64 + 3), 8 B per pixel (4 channels)
 constexpr int PART_OFF = IMG_BYTES;               // [8 waves][16 channels][2] fp32
 constexpr int COEF_OFF = PART_OFF + HNW * 16 * 2 * 4;
-constexpr int HEAD_LDS = COEF_OFF + 2 * 16 * 4;
-static_assert(70 * ROWP0 * 16 <= IMG_BYTES && HEAD_LDS <= 160 * 1024, "tower head LDS budget");
+constexpr int GB_OFF = COEF_OFF + 2 * 16 * 4;        // gamma, beta of the five GroupNorms: [5][2][16] fp32
+constexpr int HEAD_LDS = GB_OFF + 5 * 32 * 4;
+static_assert((70 * ROWP0 + 2) * 8 <= IMG_BYTES && HEAD_LDS <= 160 * 1024, "tower head LDS budget");
 
 struct HeadTower { const void* img; int u8; int C; float div; const bf16* w[5]; const float* g[5]; const float* b[5]; bf16* y; };
 struct HeadArgs { HeadTower t[8]; const int* row_index; int S; long long* prof; };
 #ifdef AVLEN_HEAD_PROF          // tools/head_lab.hip: phase timestamps of every workgroup's wave 0
-#define HEAD_STAMP(k) do { if (args.prof && tid == 0) args.prof[(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define HEAD_STAMP(k) do { if (args.prof && tid == AVLEN_HEAD_PROF) args.prof[(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define HEAD_STAMP(k) do { } while (0)
 #endif
@@ -49,7 +50,11 @@ __device__ __forceinline__ unsigned pack2(f32x2 v) { return __builtin_bit_cast(u
 __device__ __forceinline__ P4 pack4(float a, float b, float c, float d) { return P4{pack2((f32x2){a, b}), pack2((f32x2){c, d})}; }
 __device__ __forceinline__ f32x2 unlo(const P4& p) { return (f32x2){__uint_as_float(p.lo << 16), __uint_as_float(p.lo & 0xffff0000u)}; }
 __device__ __forceinline__ f32x2 unhi(const P4& p) { return (f32x2){__uint_as_float(p.hi << 16), __uint_as_float(p.hi & 0xffff0000u)}; }
-__device__ __forceinline__ f32x2 relu2(f32x2 v) { return (f32x2){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)}; }
+typedef __attribute__((ext_vector_type(2))) short i16x2;
+// bf16 pair -> relu of both halves: as int16 a negative float is a negative integer (v_pk_max_i16 against 0; -0.0 -> +0.0)
+__device__ __forceinline__ unsigned relu_pk(unsigned v) {
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, v), (i16x2){0, 0}));
+}
 // sum over the 16 lanes of a DPP row (the 16 pixels of an MFMA tile column group): 4 v_add_f32 with DPP operands, no LDS
 __device__ __forceinline__ float row16_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
@@ -67,11 +72,8 @@ __device__ __forceinline__ int a16(int y, int p, int chunk) { return (y * ROWP +
 template <int K, int C, typename T>
 __device__ __forceinline__ void preprocess_tile(const T* __restrict__ img, float div, float inv, char* lds, int tid) {
   constexpr int S = 64 * K, E = K * C;            // elements per source row and output pixel
-  static_assert(E % 2 == 0, "vector loads need an even span");
+  static_assert(E % 2 == 0 && C <= 4, "vector loads need an even span");
   typedef __attribute__((ext_vector_type(2))) T T2;
-  bf16x8 zero8;
-#pragma unroll
-  for (int e = 0; e < 8; e++) zero8[e] = (bf16)0.f;
 #pragma unroll 2
   for (int i = tid; i < 4096; i += HTH) {
     const int oy = i >> 6, ox = i & 63;
@@ -81,7 +83,7 @@ __device__ __forceinline__ void preprocess_tile(const T* __restrict__ img, float
     for (int dy = 0; dy < K; dy++)
 #pragma unroll
       for (int j = 0; j < E / 2; j++) v[dy][j] = *reinterpret_cast<const T2*>(p + (long)dy * S * C + 2 * j);
-    bf16x8 o = zero8;
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < C; c++) {
       float s = 0.f;
@@ -89,17 +91,19 @@ __device__ __forceinline__ void preprocess_tile(const T* __restrict__ img, float
       for (int dy = 0; dy < K; dy++)
 #pragma unroll
         for (int dx = 0; dx < K; dx++) { const int e = dx * C + c; s += (float)v[dy][e >> 1][e & 1] / div; }
-      o[c] = (bf16)(s * inv);
+      o[c] = s * inv;
     }
-    *reinterpret_cast<bf16x8*>(lds + ((oy + 3) * ROWP0 + ox + 3) * 16) = o;
+    const P4 pk = pack4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<uint2*>(lds + ((oy + 3) * ROWP0 + ox + 3) * 8) = make_uint2(pk.lo, pk.hi);
   }
 }
 
 // per-wave statistics -> block statistics -> scale / shift of the 16 channels (GroupNorm(16) on 16 channels = per channel).
 // Fixed summation order (lanes by DPP butterflies, waves 0..7 in sequence): deterministic.  The moments are combined in double
 // (E[x^2] - mean^2 cancels), the reciprocal square root is taken in fp32 (correctly rounded sqrt and division).
-__device__ __forceinline__ void finish_stats(float (&s1)[4], float (&s2)[4], char* lds, const float* __restrict__ gamma,
-                                             const float* __restrict__ beta, int tid, int wave, int r16, int q) {
+__device__ __forceinline__ void finish_stats(float (&s1)[4], float (&s2)[4], char* lds, int norm, int tid, int wave, int r16, int q) {
+  const float* gamma = reinterpret_cast<const float*>(lds + GB_OFF) + norm * 32;
+  const float* beta = gamma + 16;
   float* part = reinterpret_cast<float*>(lds + PART_OFF);
   float* coef = reinterpret_cast<float*>(lds + COEF_OFF);
 #pragma unroll
@@ -134,6 +138,10 @@ __global__ __launch_bounds__(HTH) void tower_head_kernel(HeadArgs args, int B) {
   for (int e = 0; e < 8; e++) zero8[e] = (bf16)0.f;
 
   HEAD_STAMP(0);
+  if (tid < 160) {                                // GroupNorm affine parameters -> LDS (read inside the statistics' critical section)
+    const int n = tid >> 5, j = tid & 31;
+    reinterpret_cast<float*>(lds + GB_OFF)[tid] = j < 16 ? t.g[n][j] : t.b[n][j - 16];
+  }
   // ---- sensor preprocessing straight into the stem's LDS image: (x / div, k x k mean) -> 8 channels (>= C: zero), 3-pixel zero frame
   {
     const int S = args.S, k = S / 64, C = t.C;
@@ -145,22 +153,25 @@ __global__ __launch_bounds__(HTH) void tower_head_kernel(HeadArgs args, int B) {
     else
       for (int i = tid; i < 4096; i += HTH) {
         const int oy = i >> 6, ox = i & 63;
-        bf16x8 o = zero8;
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
         const long base = ((bs * S + (long)oy * k) * S + (long)ox * k) * C;
-        for (int c = 0; c < C; c++) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          if (c >= C) break;
           float s = 0.f;
           for (int dy = 0; dy < k; dy++)
             for (int dx = 0; dx < k; dx++) {
               const long idx = base + ((long)dy * S + dx) * C + c;
               s += (t.u8 ? (float)((const unsigned char*)t.img)[idx] : ((const float*)t.img)[idx]) / div;
             }
-          o[c] = (bf16)(s * inv);
+          o[c] = s * inv;
         }
-        *reinterpret_cast<bf16x8*>(lds + ((oy + 3) * ROWP0 + ox + 3) * 16) = o;
+        const P4 pk = pack4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<uint2*>(lds + ((oy + 3) * ROWP0 + ox + 3) * 8) = make_uint2(pk.lo, pk.hi);
       }
-    for (int i = tid; i < 70 * 70; i += HTH) {
+    for (int i = tid; i < 70 * 70 + 2; i += HTH) {                       // + 2: the zero tap of the last row's last tile reads past the frame
       const int row = i / 70, col = i - row * 70;
-      if (row < 3 || row >= 67 || col < 3 || col >= 67) *reinterpret_cast<bf16x8*>(lds + i * 16) = zero8;
+      if (row < 3 || row >= 67 || col < 3 || col >= 67) *reinterpret_cast<uint2*>(lds + i * 8) = make_uint2(0u, 0u);
     }
   }
   __syncthreads();
@@ -169,40 +180,49 @@ __global__ __launch_bounds__(HTH) void tower_head_kernel(HeadArgs args, int B) {
   P4 rawp[32], res[32];
   float s1[4], s2[4];
 
-  // ---- stem: 7x7, 8 (padded) -> 16 channels.  K = 49 taps x 8 channels: k-step s, lane quarter q = tap 4 s + q.
-  // Every LDS address is (per-lane base of the k-step) + (compile-time offset of the tile): nothing per tile stays in registers.
+  // ---- stem: 7x7, 4 (padded) -> 16 channels, INPUT-ROW STATIONARY.  A k-step of 32 = one kernel row (7 taps + a zero tap) x 4
+  // channels, so the B fragment of frame row f -- lane (x, q): pixels x + 2 q, x + 2 q + 1, 16 contiguous bytes -- serves the 7
+  // output rows f - ky with the weights of kernel row ky: each fragment is read from LDS once and used by up to 7 MFMAs (LDS
+  // bandwidth, not MFMA, bounded the output-stationary form).  Addresses = per-lane base + compile-time offset.
   {
-    const bf16* __restrict__ wt = t.w[0];
-    bf16x8 wf[13];
-    int tap_base[13];
+    const bf16* __restrict__ wt = t.w[0];         // [16][49][8] (the packing of the launch-per-layer path); channels 4..7 are zero
+    bf16x8 wf[7];
 #pragma unroll
-    for (int s = 0; s < 13; s++) {
-      const int tap = 4 * s + q;
-      const bool ok = tap < 49;
-      wf[s] = ok ? *reinterpret_cast<const bf16x8*>(wt + (long)r16 * 392 + tap * 8) : zero8;
-      const int tp = ok ? tap : 48, ky = tp / 7, kx = tp - ky * 7;
-      tap_base[s] = ((wave * 8 + ky) * ROWP0 + r16 + kx) * 16;          // frame row = y + ky, frame pixel = x + kx
+    for (int ky = 0; ky < 7; ky++) {
+      const int kx = 2 * q;
+      const uint2 w0 = *reinterpret_cast<const uint2*>(wt + (long)r16 * 392 + (ky * 7 + kx) * 8);
+      const uint2 w1 = kx + 1 < 7 ? *reinterpret_cast<const uint2*>(wt + (long)r16 * 392 + (ky * 7 + kx + 1) * 8) : make_uint2(0u, 0u);
+      wf[ky] = __builtin_bit_cast(bf16x8, make_uint4(w0.x, w0.y, w1.x, w1.y));
     }
+    const int st_base = ((wave * 8) * ROWP0 + r16 + 2 * q) * 8;
 #pragma unroll
     for (int r = 0; r < 4; r++) { s1[r] = 0.f; s2[r] = 0.f; }
 #pragma unroll
-    for (int rr = 0; rr < 8; rr++) {
+    for (int mt = 0; mt < 4; mt++) {
+      f32x4 acc[8];
 #pragma unroll
-      for (int mt = 0; mt < 4; mt++) {
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int rr = 0; rr < 8; rr++) acc[rr] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < 13; s++) {
-          const bf16x8 xf = *reinterpret_cast<const bf16x8*>(lds + tap_base[s] + (rr * ROWP0 + mt * 16) * 16);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], xf, acc, 0, 0, 0);
+      for (int fr = 0; fr < 14; fr++) {
+        const uint2 x0 = *reinterpret_cast<const uint2*>(lds + st_base + (fr * ROWP0 + mt * 16) * 8);
+        const uint2 x1 = *reinterpret_cast<const uint2*>(lds + st_base + (fr * ROWP0 + mt * 16) * 8 + 8);
+        const bf16x8 xf = __builtin_bit_cast(bf16x8, make_uint4(x0.x, x0.y, x1.x, x1.y));
+#pragma unroll
+        for (int ky = 0; ky < 7; ky++) {
+          const int rr = fr - ky;
+          if (rr >= 0 && rr < 8) acc[rr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ky], xf, acc[rr], 0, 0, 0);
         }
+      }
 #pragma unroll
-        for (int r = 0; r < 4; r++) { const float v = acc[r]; s1[r] += v; s2[r] += v * v; }
-        rawp[rr * 4 + mt] = pack4(acc[0], acc[1], acc[2], acc[3]);
+      for (int rr = 0; rr < 8; rr++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) { const float v = acc[rr][r]; s1[r] += v; s2[r] += v * v; }
+        rawp[rr * 4 + mt] = pack4(acc[rr][0], acc[rr][1], acc[rr][2], acc[rr][3]);
       }
     }
   }
   HEAD_STAMP(2);
-  finish_stats(s1, s2, lds, t.g[0], t.b[0], tid, wave, r16, q);
+  finish_stats(s1, s2, lds, 0, tid, wave, r16, q);
   HEAD_STAMP(3);
   // pixel (y, x) of the 16-channel image lives at frame (y + 1, x + 1); this lane's store slot for tile (rr, mt) = wr_base + const
   const int wr_base = a16(wave * 8 + 1, r16 + 1, q >> 1) + (q & 1) * 8;
@@ -214,7 +234,7 @@ __global__ __launch_bounds__(HTH) void tower_head_kernel(HeadArgs args, int B) {
     for (int rr = 0; rr < 8; rr++) {
 #pragma unroll
       for (int mt = 0; mt < 4; mt++) {
-        const P4 o = {pack2(relu2(unlo(rawp[rr * 4 + mt]) * sc0 + sh0)), pack2(relu2(unhi(rawp[rr * 4 + mt]) * sc1 + sh1))};
+        const P4 o = {relu_pk(pack2(unlo(rawp[rr * 4 + mt]) * sc0 + sh0)), relu_pk(pack2(unhi(rawp[rr * 4 + mt]) * sc1 + sh1))};
         res[rr * 4 + mt] = o;
         *reinterpret_cast<uint2*>(lds + wr_base + (rr * ROWP + mt * 16) * 32) = make_uint2(o.lo, o.hi);
       }
@@ -229,40 +249,52 @@ __global__ __launch_bounds__(HTH) void tower_head_kernel(HeadArgs args, int B) {
   __syncthreads();
   HEAD_STAMP(4);
 
-  // ---- layer 1: four 3x3 convs, 16 -> 16.  K = 9 taps x 16 channels: k-step s, quarter q = tap 2 s + (q >> 1), chunk q & 1
-  for (int ci = 0; ci < 4; ci++) {
-    const bool second = ci & 1;                   // conv2 of a basic block: + residual, result becomes the next residual
-    const bf16* __restrict__ wt = t.w[1 + ci];
-    bf16x8 wf[5];
-    int rd_base[5];
+  // ---- layer 1: four 3x3 convs, 16 -> 16, input-row stationary as well.  k-steps of 32 = 2 taps x 16 channels:
+  //   F(f) = frame row f, taps kx 0 / 1 (lane quarter q: tap q >> 1, channel half q & 1): used by output rows f - ky, ky = 0..2
+  //   G(f) = frame rows f / f + 1, tap kx 2: (ky 0, ky 1) of output row f and (ky 2, zero) of output row f - 2
+  // -> 5 MFMAs per output tile as before, but 2 fragment reads per (frame row, column tile) instead of 5 per output tile.
+  const int f_base = a16(wave * 8, r16 + (q >> 1), q & 1);
+  const int g_base = a16(wave * 8 + (q >> 1), r16 + 2, q & 1);
+  const int g_last = a16(wave * 8, r16 + 2, q & 1);          // frame row 9 of the wave: its second half would leave the frame (weights zero)
+  for (int blk = 0; blk < 2; blk++)
 #pragma unroll
-    for (int s = 0; s < 5; s++) {
-      const int k = 32 * s + 8 * q;
-      wf[s] = k < 144 ? *reinterpret_cast<const bf16x8*>(wt + (long)r16 * 144 + k) : zero8;
-      int tap = 2 * s + (q >> 1);
-      if (tap > 8) tap = 8;
-      const int ky = tap / 3, kx = tap - ky * 3;
-      rd_base[s] = a16(wave * 8 + ky, r16 + kx, q & 1);       // frame row y + ky, frame pixel x + kx; + 16 px keeps the swizzle bit
-    }
+  for (int cj = 0; cj < 2; cj++) {
+    const int ci = blk * 2 + cj;
+    const bool second = cj == 1;                  // conv2 of a basic block: + residual, result becomes the next residual
+    const bf16* __restrict__ wt = t.w[1 + ci] + (long)r16 * 144 + (q & 1) * 8;      // [16][9][16]
+    bf16x8 wF[3], wG01, wG2;
+#pragma unroll
+    for (int ky = 0; ky < 3; ky++) wF[ky] = *reinterpret_cast<const bf16x8*>(wt + (ky * 3 + (q >> 1)) * 16);
+    wG01 = *reinterpret_cast<const bf16x8*>(wt + ((q >> 1) * 3 + 2) * 16);
+    wG2 = (q >> 1) == 0 ? *reinterpret_cast<const bf16x8*>(wt + 8 * 16) : zero8;
 #pragma unroll
     for (int r = 0; r < 4; r++) { s1[r] = 0.f; s2[r] = 0.f; }
 #pragma unroll
-    for (int rr = 0; rr < 8; rr++) {
+    for (int mt = 0; mt < 4; mt++) {
+      f32x4 acc[8];
 #pragma unroll
-      for (int mt = 0; mt < 4; mt++) {
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int rr = 0; rr < 8; rr++) acc[rr] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < 5; s++) {
-          const bf16x8 xf = *reinterpret_cast<const bf16x8*>(lds + rd_base[s] + (rr * ROWP + mt * 16) * 32);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], xf, acc, 0, 0, 0);
+      for (int fr = 0; fr < 10; fr++) {
+        const bf16x8 F = *reinterpret_cast<const bf16x8*>(lds + f_base + (fr * ROWP + mt * 16) * 32);
+        const bf16x8 G = *reinterpret_cast<const bf16x8*>(lds + (fr == 9 ? g_last : g_base) + (fr * ROWP + mt * 16) * 32);
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++) {
+          const int rr = fr - ky;
+          if (rr >= 0 && rr < 8) acc[rr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wF[ky], F, acc[rr], 0, 0, 0);
         }
+        if (fr < 8) acc[fr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wG01, G, acc[fr], 0, 0, 0);
+        if (fr >= 2) acc[fr - 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wG2, G, acc[fr - 2], 0, 0, 0);
+      }
 #pragma unroll
-        for (int r = 0; r < 4; r++) { const float v = acc[r]; s1[r] += v; s2[r] += v * v; }
-        rawp[rr * 4 + mt] = pack4(acc[0], acc[1], acc[2], acc[3]);
+      for (int rr = 0; rr < 8; rr++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) { const float v = acc[rr][r]; s1[r] += v; s2[r] += v * v; }
+        rawp[rr * 4 + mt] = pack4(acc[rr][0], acc[rr][1], acc[rr][2], acc[rr][3]);
       }
     }
     HEAD_STAMP(5 + 2 * ci);
-    finish_stats(s1, s2, lds, t.g[1 + ci], t.b[1 + ci], tid, wave, r16, q);
+    finish_stats(s1, s2, lds, 1 + ci, tid, wave, r16, q);
     HEAD_STAMP(6 + 2 * ci);
     const f32x2 sc0 = {coef[q * 4], coef[q * 4 + 1]}, sc1 = {coef[q * 4 + 2], coef[q * 4 + 3]};
     const f32x2 sh0 = {coef[16 + q * 4], coef[16 + q * 4 + 1]}, sh1 = {coef[16 + q * 4 + 2], coef[16 + q * 4 + 3]};
@@ -272,7 +304,7 @@ __global__ __launch_bounds__(HTH) void tower_head_kernel(HeadArgs args, int B) {
       for (int mt = 0; mt < 4; mt++) {
         f32x2 v0 = unlo(rawp[rr * 4 + mt]) * sc0 + sh0, v1 = unhi(rawp[rr * 4 + mt]) * sc1 + sh1;
         if (second) { v0 += unlo(res[rr * 4 + mt]); v1 += unhi(res[rr * 4 + mt]); }
-        const P4 o = {pack2(relu2(v0)), pack2(relu2(v1))};
+        const P4 o = {relu_pk(pack2(v0)), relu_pk(pack2(v1))};
         if (second) res[rr * 4 + mt] = o;
         *reinterpret_cast<uint2*>(lds + wr_base + (rr * ROWP + mt * 16) * 32) = make_uint2(o.lo, o.hi);
       }
@@ -296,7 +328,7 @@ __global__ __launch_bounds__(HTH) void tower_head_kernel(HeadArgs args, int B) {
 }  // namespace
 
 bool avlen_tower_head_supported(const avlen_resnet18* n, int S, int C) {
-  if (!n || S % 64 || S < 64 || C < 1 || C > 8) return false;
+  if (!n || S % 64 || S < 64 || C < 1 || C > 4) return false;
   const avlen_conv& k = n->conv1;
   if (!k.w16 || k.cin16 != 8 || k.cout != 16 || k.kh != 7 || k.kw != 7 || k.stride != 1 || k.pad != 3) return false;
   for (int i = 0; i < 2; i++) {

@@ -211,8 +211,9 @@ def test_uint8_rgb_end_to_end_is_bit_identical(precision):
     obs32 = dict(obs8, rgb=obs8["rgb"].float())
     pa = ro.prev_actions[0]
     f8, _ = pol.net.features(pol, obs8, pa)
-    f8 = f8.clone()
+    f8 = f8[:, :276].clone()             # [visual 128 | action 16 | audio 128 | pose 4]; the caller fills the columns behind (extra=None here)
     f32, _ = pol.net.features(pol, obs32, pa)
+    f32 = f32[:, :276]
     torch.cuda.synchronize()
     if precision == "fp32":
         assert torch.equal(f8, f32)

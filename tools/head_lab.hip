@@ -1,6 +1,6 @@
 // Stand-alone lab for csrc/tower_head.hip: launches the kernel on random data (B images x G towers), prints the launch time and
 // the mean duration of each phase from wave-0 timestamps (s_memtime).  Not part of the library.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -ffp-contract=off -DAVLEN_HEAD_PROF tools/head_lab.hip -o tools/bin/head_lab
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -ffp-contract=off [-DAVLEN_HEAD_PROF=<stamping thread: 0, 448>] tools/head_lab.hip -o tools/bin/head_lab
 //   tools/bin/head_lab [B=64] [G=6] [S=128] [u8=0]
 #include "../avlen_amd/csrc/tower_head.hip"
 #include <cstdio>
@@ -113,6 +113,7 @@ int main(int argc, char** argv) {
   CK(hipDeviceSynchronize());
   float ms; hipEventElapsedTime(&ms, e0, e1);
   printf("B=%d G=%d S=%d u8=%d: %.1f us per launch (%d workgroups)\n", B, G, S, u8, ms * 1000 / IT, B * G);
+#ifdef AVLEN_HEAD_PROF
   std::vector<long long> h((size_t)B * G * 16);
   hipMemcpy(h.data(), prof, h.size() * 8, hipMemcpyDeviceToHost);
   const char* names[14] = {"preprocess", "stem conv", "stem stats", "a0 write", "conv1", "stats1", "apply1+conv2", "stats2", "apply2+conv3",
@@ -123,6 +124,7 @@ int main(int argc, char** argv) {
   for (int k = 0; k < 14; k++) tot += ph[k];
   for (int k = 0; k < 14; k++) printf("  %-14s %6.1f %%  (%.0f ticks)\n", names[k], 100 * ph[k] / tot, ph[k] / (B * G));
   printf("  workgroup total %.0f ticks\n", tot / (B * G));
+#endif
   // tower 0, image 0 against the CPU restatement
   if (!a.t[0].u8) {
     const HeadTower& t = a.t[0];
