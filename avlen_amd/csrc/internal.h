@@ -106,7 +106,7 @@ typedef struct { int kind, k, ld, ld2, act, res, buf, out_buf, div, seq; float s
 typedef struct { int n; avlen_chain_op op[AVLEN_CHAIN_MAX_OPS]; } avlen_chain;
 int avlen_chain_run(const avlen_chain* prog, int B, hipStream_t stream);
 
-// ---- preprocessing + stem + layer 1 of the ResNet towers (tower_head.hip): one workgroup per image, activations in LDS / registers ----
+// ---- preprocessing + stem + layers 1-2 of the ResNet towers (tower_head.hip): one workgroup per image, activations in LDS / registers ----
 bool avlen_tower_head_supported(const avlen_resnet18* net, int S, int C);
 int avlen_tower_head_bf16(const avlen_resnet18* const* nets, const void* const* imgs, const int* img_u8, const int* channels,
                           const float* divisors, const int* row_index, void* const* Y, int groups, int B, int S,

@@ -659,7 +659,7 @@ int resnet18_group_fwd_bf16(const avlen_resnet18* const* nets, const void* const
   TRY(avlen_zero_bytes(stats_all, (size_t)G * 21 * stat_stride * sizeof(float), st));
   int si = 0;
   auto next_stats = [&](float** out) { for (int g = 0; g < G; g++) out[g] = stats_all + ((size_t)g * 21 + si) * stat_stride; si++; };
-  // Preprocessing + stem + layer 1 as one launch per tower group (tower_head.hip: the 64x64x16 activation never leaves the CU)
+  // Preprocessing + stem + layers 1-2 as one launch per tower group (tower_head.hip: the 64x64x16 / 32x32x32 activations never leave the CU)
   static int head = -1;                        // AVLEN_TOWER_HEAD=0 (lab build): the launch-per-layer path below
   if (head < 0) head = (int)avlen_knob("AVLEN_TOWER_HEAD", 1);
   bool use_head = head != 0;
@@ -718,10 +718,10 @@ int resnet18_group_fwd_bf16(const avlen_resnet18* const* nets, const void* const
       TRY(gn([](const avlen_resnet18* n) -> const avlen_affine& { return n->bn1; }, raw[0], STS, nullptr, act[0], 4096, 16, 1));
   }
   bf16** cur = (stem_fused && !use_head) ? raw[2] : act[0]; bf16** a1 = act[1]; bf16** idt = act[2]; bf16** nxt = act[3];
-  int H = 64;
+  int H = use_head ? 32 : 64;
   static int tail = -1;                        // AVLEN_TOWER_TAIL=0: layers 3-4 as separate conv / GroupNorm launches (A/B knob)
   if (tail < 0) tail = (int)avlen_knob("AVLEN_TOWER_TAIL", 1);
-  for (int i = use_head ? 2 : 0; i < 8; i++) {
+  for (int i = use_head ? 4 : 0; i < 8; i++) {
     if (i == 4 && tail && H == 32 && G <= 6) {
       // layers 3 + 4 (four basic blocks): one launch, one workgroup per image, activations resident in LDS
       for (int g = 0; g < G; g++) { X[g] = cur[g]; OUT[g] = nxt[g]; }

@@ -1,5 +1,6 @@
-// Stem + layer 1 of the CustomResNet tower (smt_resnet.py:132-141: conv 7x7 -> GroupNorm -> ReLU -> two basic blocks of
-// 16 channels at 64x64) -- with the sensor preprocessing (x / divisor, k x k block mean: smt_cnn.py:83-93) in front -- as ONE
+// Stem + layers 1 and 2 of the CustomResNet tower (smt_resnet.py:132-141: conv 7x7 -> GroupNorm -> ReLU -> two basic blocks
+// of 16 channels at 64x64 -> two basic blocks of 32 channels at 32x32, the first with stride 2 and a 1x1 stride-2 downsample
+// + GroupNorm on the skip) -- with the sensor preprocessing (x / divisor, k x k block mean: smt_cnn.py:83-93) in front -- as ONE
 // launch: one workgroup per image keeps the whole 64x64x16 activation in LDS (136 KiB with a one-pixel zero frame,
 // so that the 3x3 taps need no bounds test), the basic blocks' residual and every raw conv output in REGISTERS (a wave
 // owns 8 image rows: 32 MFMA row tiles, 64 + 64 packed-bf16 registers), the conv weights as MFMA fragments in registers, and
@@ -29,15 +30,19 @@ constexpr int ROWP = 66;                          // pixels per LDS row at 16 ch
 constexpr int IMG_BYTES = 66 * ROWP * 32;         // 139392
 constexpr int ROWP0 = 70;                         // stem input: 70 rows x 70 pixels (3 + 64 + 3), 8 B per pixel (4 channels)
 constexpr int PART_OFF = IMG_BYTES;               // [8 waves][16 channels][2] fp32
-constexpr int COEF_OFF = PART_OFF + HNW * 16 * 2 * 4;
-constexpr int GB_OFF = COEF_OFF + 2 * 16 * 4;        // gamma, beta of the five GroupNorms: [5][2][16] fp32
-constexpr int HEAD_LDS = GB_OFF + 5 * 32 * 4;
+constexpr int COEF_OFF = PART_OFF + HNW * 16 * 2 * 4; // scale[32], shift[32]
+constexpr int GB_OFF = COEF_OFF + 2 * 32 * 4;        // gamma, beta of the ten GroupNorms: [5][2][16] then [5][2][32] fp32
+constexpr int HEAD_LDS = GB_OFF + (5 * 32 + 5 * 64) * 4;
+constexpr int ROWQ = 34;                          // layer 2: 34 rows x 34 pixels (1 + 32 + 1) x 64 B (32 channels)
+static_assert(ROWQ * ROWQ * 64 <= IMG_BYTES, "the 32-channel frame reuses the 16-channel frame's space");
 static_assert((70 * ROWP0 + 2) * 8 <= IMG_BYTES && HEAD_LDS <= 160 * 1024, "tower head LDS budget");
 
-struct HeadTower { const void* img; int u8; int C; float div; const bf16* w[5]; const float* g[5]; const float* b[5]; bf16* y; };
+// w / g / b: 0 stem, 1..4 layer 1 (block 0 conv1, conv2, block 1 conv1, conv2), 5 block 2 downsample, 6 / 7 block 2 conv1 / conv2,
+// 8 / 9 block 3 conv1 / conv2
+struct HeadTower { const void* img; int u8; int C; float div; const bf16* w[10]; const float* g[10]; const float* b[10]; bf16* y; };
 struct HeadArgs { HeadTower t[8]; const int* row_index; int S; long long* prof; };
 #ifdef AVLEN_HEAD_PROF          // tools/head_lab.hip: phase timestamps of every workgroup's wave 0
-#define HEAD_STAMP(k) do { if (args.prof && tid == AVLEN_HEAD_PROF) args.prof[(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define HEAD_STAMP(k) do { if (args.prof && tid == AVLEN_HEAD_PROF) args.prof[(blockIdx.y * gridDim.x + blockIdx.x) * 32 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define HEAD_STAMP(k) do { } while (0)
 #endif
@@ -65,6 +70,10 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 
 __device__ __forceinline__ int a16(int y, int p, int chunk) { return (y * ROWP + p) * 32 + ((chunk ^ ((p >> 3) & 1)) << 4); }
+
+// 32-channel frame: 64 B per pixel = four 16-byte chunks, rotated by (pixel >> 1) & 3 so that 8 neighbouring pixels' reads of
+// the same chunk fall on 8 different 16-byte bank groups
+__device__ __forceinline__ int a32(int y, int p, int chunk) { return (y * ROWQ + p) * 64 + ((chunk ^ ((p >> 1) & 3)) << 4); }
 
 // The common sensor shapes (128 x 128 -> 64 x 64, rgb or depth): a lane's K * C inputs of one source row are contiguous and
 // even in number -> 8-byte (fp32) / 2-byte (uint8) vector loads, all of a pixel's loads in flight together.  Same arithmetic
@@ -98,30 +107,117 @@ __device__ __forceinline__ void preprocess_tile(const T* __restrict__ img, float
   }
 }
 
-// per-wave statistics -> block statistics -> scale / shift of the 16 channels (GroupNorm(16) on 16 channels = per channel).
+// per-wave statistics -> block statistics -> scale / shift per channel.  GroupNorm(16): NCH = 16 -> one channel per group
+// (4096 values), NCH = 32 -> two channels per group (2048 values).  s1 / s2 hold this lane's four partial sums: NCH = 16 the
+// channels q * 4 + r; NCH = 32 the groups (r >> 1) * 8 + q * 2 + (r & 1) (r >> 1 = cout tile, r & 1 = channel pair).
 // Fixed summation order (lanes by DPP butterflies, waves 0..7 in sequence): deterministic.  The moments are combined in double
 // (E[x^2] - mean^2 cancels), the reciprocal square root is taken in fp32 (correctly rounded sqrt and division).
-__device__ __forceinline__ void finish_stats(float (&s1)[4], float (&s2)[4], char* lds, int norm, int tid, int wave, int r16, int q) {
-  const float* gamma = reinterpret_cast<const float*>(lds + GB_OFF) + norm * 32;
-  const float* beta = gamma + 16;
+#ifdef AVLEN_HEAD_PROF
+#define FS_STAMP(k) do { if (prof && gb == 32 && tid == AVLEN_HEAD_PROF) prof[k] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FS_STAMP(k) do { } while (0)
+#endif
+template <int NCH>
+__device__ __forceinline__ void finish_stats(float (&s1)[4], float (&s2)[4], char* lds, int gb, int tid, int wave, int r16, int q,
+                                             long long* prof = nullptr) {
+  FS_STAMP(24);
+  const float* gamma = reinterpret_cast<const float*>(lds + GB_OFF) + gb;
+  const float* beta = gamma + NCH;
   float* part = reinterpret_cast<float*>(lds + PART_OFF);
   float* coef = reinterpret_cast<float*>(lds + COEF_OFF);
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const float a = row16_sum(s1[r]), c = row16_sum(s2[r]);
-    if (r16 == 0) *reinterpret_cast<float2*>(&part[(wave * 16 + q * 4 + r) * 2]) = make_float2(a, c);
+    const int slot = NCH == 16 ? q * 4 + r : (r >> 1) * 8 + q * 2 + (r & 1);
+    if (r16 == 0) *reinterpret_cast<float2*>(&part[(wave * 16 + slot) * 2]) = make_float2(a, c);
   }
+  FS_STAMP(25);
   __syncthreads();                                // every wave has also finished reading the image of this conv
-  if (tid < 16) {
+  FS_STAMP(26);
+  if (tid < NCH) {
+    const int g = NCH == 16 ? tid : tid >> 1;
     double sum = 0.0, sq = 0.0;
 #pragma unroll
-    for (int w = 0; w < HNW; w++) { const float2 v = *reinterpret_cast<const float2*>(&part[(w * 16 + tid) * 2]); sum += v.x; sq += v.y; }
-    const double mean = sum * (1.0 / 4096.0);
-    double var = sq * (1.0 / 4096.0) - mean * mean;
+    for (int w = 0; w < HNW; w++) { const float2 v = *reinterpret_cast<const float2*>(&part[(w * 16 + g) * 2]); sum += v.x; sq += v.y; }
+    constexpr double inv_n = NCH == 16 ? 1.0 / 4096.0 : 1.0 / 2048.0;
+    const double mean = sum * inv_n;
+    double var = sq * inv_n - mean * mean;
     if (var < 0.0) var = 0.0;
     const float rstd = 1.0f / sqrtf((float)var + 1e-5f);
     const float sc = gamma[tid] * rstd;
-    coef[tid] = sc; coef[16 + tid] = beta[tid] - (float)mean * sc;
+    coef[tid] = sc; coef[32 + tid] = beta[tid] - (float)mean * sc;
+  }
+  FS_STAMP(27);
+  __syncthreads();
+  FS_STAMP(28);
+}
+
+// One 3x3 stride-1 conv 32 -> 32 over the 32 x 32 frame + GroupNorm (+ residual) + ReLU, input-row stationary: a wave owns 4
+// output rows x 2 column tiles x 2 cout tiles.  Per column tile: the three kx-shifted fragments of frame row f (lane (x, q):
+// channels 8 q .. 8 q + 7 of pixel x + kx) are read once and feed the output rows f - ky through the 18 weight fragments.
+template <bool SECOND>
+__device__ __forceinline__ void conv32_gn(const bf16* __restrict__ wt, int gb, char* lds, P4 (&rawp)[32], P4 (&res)[32], int tid, int wave,
+                                          int r16, int q) {
+  const float* coef = reinterpret_cast<const float*>(lds + COEF_OFF);
+  bf16x8 W[9][2];
+#pragma unroll
+  for (int tap = 0; tap < 9; tap++)
+#pragma unroll
+    for (int ct = 0; ct < 2; ct++) W[tap][ct] = *reinterpret_cast<const bf16x8*>(wt + (long)(ct * 16 + r16) * 288 + tap * 32 + 8 * q);
+  int rd[3];
+#pragma unroll
+  for (int kx = 0; kx < 3; kx++) rd[kx] = a32(wave * 4, r16 + kx, q);
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int pt = 0; pt < 2; pt++) {
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) { acc[rr][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[rr][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int f = 0; f < 6; f++) {
+      bf16x8 F[3];
+#pragma unroll
+      for (int kx = 0; kx < 3; kx++) F[kx] = *reinterpret_cast<const bf16x8*>(lds + rd[kx] + (f * ROWQ + pt * 16) * 64);
+#pragma unroll
+      for (int ky = 0; ky < 3; ky++) {
+        const int rr = f - ky;
+        if (rr >= 0 && rr < 4) {
+#pragma unroll
+          for (int kx = 0; kx < 3; kx++) {
+            acc[rr][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[ky * 3 + kx][0], F[kx], acc[rr][0], 0, 0, 0);
+            acc[rr][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[ky * 3 + kx][1], F[kx], acc[rr][1], 0, 0, 0);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+      for (int ct = 0; ct < 2; ct++) {
+        const f32x4 v = acc[rr][ct];
+        s1[ct * 2] += v[0] + v[1]; s2[ct * 2] += v[0] * v[0] + v[1] * v[1];
+        s1[ct * 2 + 1] += v[2] + v[3]; s2[ct * 2 + 1] += v[2] * v[2] + v[3] * v[3];
+        rawp[(rr * 2 + pt) * 2 + ct] = pack4(v[0], v[1], v[2], v[3]);
+      }
+  }
+  finish_stats<32>(s1, s2, lds, gb, tid, wave, r16, q);
+#pragma unroll
+  for (int ct = 0; ct < 2; ct++) {
+    const int c0 = ct * 16 + q * 4;
+    const f32x2 sc0 = {coef[c0], coef[c0 + 1]}, sc1 = {coef[c0 + 2], coef[c0 + 3]};
+    const f32x2 sh0 = {coef[32 + c0], coef[32 + c0 + 1]}, sh1 = {coef[32 + c0 + 2], coef[32 + c0 + 3]};
+    const int wr = a32(wave * 4 + 1, r16 + 1, ct * 2 + (q >> 1)) + (q & 1) * 8;
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+      for (int pt = 0; pt < 2; pt++) {
+        const int ti = (rr * 2 + pt) * 2 + ct;
+        f32x2 v0 = unlo(rawp[ti]) * sc0 + sh0, v1 = unhi(rawp[ti]) * sc1 + sh1;
+        if (SECOND) { v0 += unlo(res[ti]); v1 += unhi(res[ti]); }
+        const P4 o = {relu_pk(pack2(v0)), relu_pk(pack2(v1))};
+        if (SECOND) res[ti] = o;
+        *reinterpret_cast<uint2*>(lds + wr + (rr * ROWQ + pt * 16) * 64) = make_uint2(o.lo, o.hi);
+      }
   }
   __syncthreads();
 }
@@ -138,9 +234,10 @@ __global__ __launch_bounds__(HTH) void tower_head_kernel(HeadArgs args, int B) {
   for (int e = 0; e < 8; e++) zero8[e] = (bf16)0.f;
 
   HEAD_STAMP(0);
-  if (tid < 160) {                                // GroupNorm affine parameters -> LDS (read inside the statistics' critical section)
-    const int n = tid >> 5, j = tid & 31;
-    reinterpret_cast<float*>(lds + GB_OFF)[tid] = j < 16 ? t.g[n][j] : t.b[n][j - 16];
+  if (tid < 480) {                                // GroupNorm affine parameters -> LDS (read inside the statistics' critical section)
+    const bool l1 = tid < 160;
+    const int n = l1 ? tid >> 5 : 5 + ((tid - 160) >> 6), j = l1 ? tid & 31 : (tid - 160) & 63, nch = l1 ? 16 : 32;
+    reinterpret_cast<float*>(lds + GB_OFF)[tid] = j < nch ? t.g[n][j] : t.b[n][j - nch];
   }
   // ---- sensor preprocessing straight into the stem's LDS image: (x / div, k x k mean) -> 8 channels (>= C: zero), 3-pixel zero frame
   {
@@ -222,14 +319,14 @@ __global__ __launch_bounds__(HTH) void tower_head_kernel(HeadArgs args, int B) {
     }
   }
   HEAD_STAMP(2);
-  finish_stats(s1, s2, lds, 0, tid, wave, r16, q);
+  finish_stats<16>(s1, s2, lds, 0, tid, wave, r16, q);
   HEAD_STAMP(3);
   // pixel (y, x) of the 16-channel image lives at frame (y + 1, x + 1); this lane's store slot for tile (rr, mt) = wr_base + const
   const int wr_base = a16(wave * 8 + 1, r16 + 1, q >> 1) + (q & 1) * 8;
   {
     // a0 = relu(GN(raw)) -> LDS (16-channel layout) and the residual registers; the one-pixel frame zeroed
     const f32x2 sc0 = {coef[q * 4], coef[q * 4 + 1]}, sc1 = {coef[q * 4 + 2], coef[q * 4 + 3]};
-    const f32x2 sh0 = {coef[16 + q * 4], coef[16 + q * 4 + 1]}, sh1 = {coef[16 + q * 4 + 2], coef[16 + q * 4 + 3]};
+    const f32x2 sh0 = {coef[32 + q * 4], coef[32 + q * 4 + 1]}, sh1 = {coef[32 + q * 4 + 2], coef[32 + q * 4 + 3]};
 #pragma unroll
     for (int rr = 0; rr < 8; rr++) {
 #pragma unroll
@@ -294,10 +391,10 @@ __global__ __launch_bounds__(HTH) void tower_head_kernel(HeadArgs args, int B) {
       }
     }
     HEAD_STAMP(5 + 2 * ci);
-    finish_stats(s1, s2, lds, 1 + ci, tid, wave, r16, q);
+    finish_stats<16>(s1, s2, lds, (1 + ci) * 32, tid, wave, r16, q, args.prof ? args.prof + (blockIdx.y * gridDim.x + blockIdx.x) * 32 : nullptr);
     HEAD_STAMP(6 + 2 * ci);
     const f32x2 sc0 = {coef[q * 4], coef[q * 4 + 1]}, sc1 = {coef[q * 4 + 2], coef[q * 4 + 3]};
-    const f32x2 sh0 = {coef[16 + q * 4], coef[16 + q * 4 + 1]}, sh1 = {coef[16 + q * 4 + 2], coef[16 + q * 4 + 3]};
+    const f32x2 sh0 = {coef[32 + q * 4], coef[32 + q * 4 + 1]}, sh1 = {coef[32 + q * 4 + 2], coef[32 + q * 4 + 3]};
 #pragma unroll
     for (int rr = 0; rr < 8; rr++) {
 #pragma unroll
@@ -312,16 +409,122 @@ __global__ __launch_bounds__(HTH) void tower_head_kernel(HeadArgs args, int B) {
     __syncthreads();
   }
   HEAD_STAMP(13);
-  // ---- layer-1 output, NHWC bf16: the frame's interior, 16 B per lane, consecutive lanes consecutive addresses
+  // ---- layer 2, block 0: 1x1 stride-2 downsample + GroupNorm of the skip -> residual registers (no ReLU).  Output pixel (oy, ox)
+  // reads the layer-1 frame at (2 oy + 1, 2 ox + 1); K = 16 channels: the upper half of the k-step carries zero weights.
   {
-    uint4* __restrict__ yo = reinterpret_cast<uint4*>(t.y + (long)b * 4096 * 16);
-#pragma unroll 4
-    for (int i = tid; i < 8192; i += HTH) {
-      const int px = i >> 1, y = px >> 6, x = px & 63;
-      yo[i] = *reinterpret_cast<const uint4*>(lds + a16(y + 1, x + 1, i & 1));
+    const bf16* __restrict__ wt = t.w[5];         // [32][16]
+    bf16x8 wD[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ct++) wD[ct] = (q >> 1) == 0 ? *reinterpret_cast<const bf16x8*>(wt + (long)(ct * 16 + r16) * 16 + 8 * (q & 1)) : zero8;
+    const int rdD = a16(2 * (wave * 4) + 1, 2 * r16 + 1, q & 1);
+#pragma unroll
+    for (int r = 0; r < 4; r++) { s1[r] = 0.f; s2[r] = 0.f; }
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+      for (int pt = 0; pt < 2; pt++) {
+        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(lds + rdD + (2 * rr * ROWP + 32 * pt) * 32);
+#pragma unroll
+        for (int ct = 0; ct < 2; ct++) {
+          const f32x4 v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wD[ct], xf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          s1[ct * 2] += v[0] + v[1]; s2[ct * 2] += v[0] * v[0] + v[1] * v[1];
+          s1[ct * 2 + 1] += v[2] + v[3]; s2[ct * 2 + 1] += v[2] * v[2] + v[3] * v[3];
+          res[(rr * 2 + pt) * 2 + ct] = pack4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    finish_stats<32>(s1, s2, lds, 160, tid, wave, r16, q);
+#pragma unroll
+    for (int ct = 0; ct < 2; ct++) {
+      const int c0 = ct * 16 + q * 4;
+      const f32x2 sc0 = {coef[c0], coef[c0 + 1]}, sc1 = {coef[c0 + 2], coef[c0 + 3]};
+      const f32x2 sh0 = {coef[32 + c0], coef[32 + c0 + 1]}, sh1 = {coef[32 + c0 + 2], coef[32 + c0 + 3]};
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const int ti = i * 2 + ct;
+        res[ti] = P4{pack2(unlo(res[ti]) * sc0 + sh0), pack2(unhi(res[ti]) * sc1 + sh1)};
+      }
     }
   }
   HEAD_STAMP(14);
+  // ---- block 0 conv1: 3x3 stride 2, 16 -> 32 (k-steps of 2 taps x 16 channels as in layer 1; the fragment of a column tile serves
+  // both cout tiles), GroupNorm + ReLU -> the 32-channel frame, which takes the 16-channel frame's place once every wave is done
+  {
+    const bf16* __restrict__ wt = t.w[6];         // [32][9][16]
+    bf16x8 wA[5][2];
+    int rdA[5];
+#pragma unroll
+    for (int s = 0; s < 5; s++) {
+      const int k = 32 * s + 8 * q;
+#pragma unroll
+      for (int ct = 0; ct < 2; ct++) wA[s][ct] = k < 144 ? *reinterpret_cast<const bf16x8*>(wt + (long)(ct * 16 + r16) * 144 + k) : zero8;
+      int tap = 2 * s + (q >> 1);
+      if (tap > 8) tap = 8;
+      const int ky = tap / 3, kx = tap - ky * 3;
+      rdA[s] = a16(2 * (wave * 4) + ky, 2 * r16 + kx, q & 1);            // frame (2 oy + ky, 2 ox + kx)
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) { s1[r] = 0.f; s2[r] = 0.f; }
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+      for (int pt = 0; pt < 2; pt++) {
+        f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int s = 0; s < 5; s++) {
+          const bf16x8 xf = *reinterpret_cast<const bf16x8*>(lds + rdA[s] + (2 * rr * ROWP + 32 * pt) * 32);
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wA[s][0], xf, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wA[s][1], xf, acc[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int ct = 0; ct < 2; ct++) {
+          const f32x4 v = acc[ct];
+          s1[ct * 2] += v[0] + v[1]; s2[ct * 2] += v[0] * v[0] + v[1] * v[1];
+          s1[ct * 2 + 1] += v[2] + v[3]; s2[ct * 2 + 1] += v[2] * v[2] + v[3] * v[3];
+          rawp[(rr * 2 + pt) * 2 + ct] = pack4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    finish_stats<32>(s1, s2, lds, 160 + 64, tid, wave, r16, q);
+#pragma unroll
+    for (int ct = 0; ct < 2; ct++) {
+      const int c0 = ct * 16 + q * 4;
+      const f32x2 sc0 = {coef[c0], coef[c0 + 1]}, sc1 = {coef[c0 + 2], coef[c0 + 3]};
+      const f32x2 sh0 = {coef[32 + c0], coef[32 + c0 + 1]}, sh1 = {coef[32 + c0 + 2], coef[32 + c0 + 3]};
+      const int wr = a32(wave * 4 + 1, r16 + 1, ct * 2 + (q >> 1)) + (q & 1) * 8;
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+        for (int pt = 0; pt < 2; pt++) {
+          const int ti = (rr * 2 + pt) * 2 + ct;
+          const P4 o = {relu_pk(pack2(unlo(rawp[ti]) * sc0 + sh0)), relu_pk(pack2(unhi(rawp[ti]) * sc1 + sh1))};
+          *reinterpret_cast<uint2*>(lds + wr + (rr * ROWQ + pt * 16) * 64) = make_uint2(o.lo, o.hi);
+        }
+    }
+    // the one-pixel zero frame of the 32-channel image: rows 0 and 33 (34 px x 4 chunks each), columns 0 and 33 of rows 1..32
+    for (int i = tid; i < 2 * 136 + 32 * 8; i += HTH) {
+      int off;
+      if (i < 272) off = ((i / 136) * 33 * ROWQ) * 64 + (i % 136) * 16;
+      else { const int j = i - 272, row = 1 + (j >> 3); off = (row * ROWQ + ((j >> 2) & 1) * 33) * 64 + (j & 3) * 16; }
+      *reinterpret_cast<bf16x8*>(lds + off) = zero8;
+    }
+  }
+  __syncthreads();
+  HEAD_STAMP(15);
+  conv32_gn<true>(t.w[7], 160 + 128, lds, rawp, res, tid, wave, r16, q);          // block 0 conv2 + skip
+  HEAD_STAMP(16);
+  conv32_gn<false>(t.w[8], 160 + 192, lds, rawp, res, tid, wave, r16, q);         // block 1 conv1
+  HEAD_STAMP(17);
+  conv32_gn<true>(t.w[9], 160 + 256, lds, rawp, res, tid, wave, r16, q);          // block 1 conv2 + identity
+  HEAD_STAMP(18);
+  // ---- layer-2 output, NHWC bf16 (32 x 32 x 32): the frame's interior, 16 B per lane, consecutive lanes consecutive addresses
+  {
+    uint4* __restrict__ yo = reinterpret_cast<uint4*>(t.y + (long)b * 1024 * 32);
+#pragma unroll 4
+    for (int i = tid; i < 4096; i += HTH) {
+      const int px = i >> 2, y = px >> 5, x = px & 31;
+      yo[i] = *reinterpret_cast<const uint4*>(lds + a32(y + 1, x + 1, i & 3));
+    }
+  }
+  HEAD_STAMP(19);
   (void)B;
 }
 
@@ -331,17 +534,22 @@ bool avlen_tower_head_supported(const avlen_resnet18* n, int S, int C) {
   if (!n || S % 64 || S < 64 || C < 1 || C > 4) return false;
   const avlen_conv& k = n->conv1;
   if (!k.w16 || k.cin16 != 8 || k.cout != 16 || k.kh != 7 || k.kw != 7 || k.stride != 1 || k.pad != 3) return false;
+  auto conv3 = [](const avlen_conv& c, int cin, int cout, int stride) {
+    return c.w16 && c.cin16 == cin && c.cout == cout && c.kh == 3 && c.kw == 3 && c.stride == stride && c.pad == 1;
+  };
   for (int i = 0; i < 2; i++) {
     const avlen_resblock& bl = n->block[i];
-    if (bl.has_down) return false;
-    const avlen_conv* cs[2] = {&bl.conv1, &bl.conv2};
-    for (const avlen_conv* c : cs)
-      if (!c->w16 || c->cin16 != 16 || c->cout != 16 || c->kh != 3 || c->kw != 3 || c->stride != 1 || c->pad != 1) return false;
+    if (bl.has_down || !conv3(bl.conv1, 16, 16, 1) || !conv3(bl.conv2, 16, 16, 1)) return false;
   }
-  return true;
+  const avlen_resblock& b2 = n->block[2];
+  const avlen_resblock& b3 = n->block[3];
+  if (!b2.has_down || !conv3(b2.conv1, 16, 32, 2) || !conv3(b2.conv2, 32, 32, 1)) return false;
+  const avlen_conv& d = b2.down;
+  if (!d.w16 || d.cin16 != 16 || d.cout != 32 || d.kh != 1 || d.kw != 1 || d.stride != 2 || d.pad != 0) return false;
+  return !b3.has_down && conv3(b3.conv1, 32, 32, 1) && conv3(b3.conv2, 32, 32, 1);
 }
 
-// Y[g] = layer-1 output (post-ReLU) NHWC bf16 (B, 64, 64, 16) of tower g; imgs[g] (B or more images of S x S x C, fp32 or uint8)
+// Y[g] = layer-2 output (post-ReLU) NHWC bf16 (B, 32, 32, 32) of tower g; imgs[g] (B or more images of S x S x C, fp32 or uint8)
 int avlen_tower_head_bf16(const avlen_resnet18* const* nets, const void* const* imgs, const int* img_u8, const int* channels,
                           const float* divisors, const int* row_index, void* const* Y, int groups, int B, int S,
                           hipStream_t stream) {
@@ -358,6 +566,13 @@ int avlen_tower_head_bf16(const avlen_resnet18* const* nets, const void* const* 
       t.w[1 + 2 * i] = (const bf16*)n->block[i].conv1.w16; t.g[1 + 2 * i] = n->block[i].bn1.g; t.b[1 + 2 * i] = n->block[i].bn1.b;
       t.w[2 + 2 * i] = (const bf16*)n->block[i].conv2.w16; t.g[2 + 2 * i] = n->block[i].bn2.g; t.b[2 + 2 * i] = n->block[i].bn2.b;
     }
+    const avlen_resblock& b2 = n->block[2];
+    const avlen_resblock& b3 = n->block[3];
+    t.w[5] = (const bf16*)b2.down.w16; t.g[5] = b2.bnd.g; t.b[5] = b2.bnd.b;
+    t.w[6] = (const bf16*)b2.conv1.w16; t.g[6] = b2.bn1.g; t.b[6] = b2.bn1.b;
+    t.w[7] = (const bf16*)b2.conv2.w16; t.g[7] = b2.bn2.g; t.b[7] = b2.bn2.b;
+    t.w[8] = (const bf16*)b3.conv1.w16; t.g[8] = b3.bn1.g; t.b[8] = b3.bn1.b;
+    t.w[9] = (const bf16*)b3.conv2.w16; t.g[9] = b3.bn2.g; t.b[9] = b3.bn2.b;
   }
   static bool attr_set = false;
   if (!attr_set) {

@@ -15,6 +15,37 @@ static float bf_round(float f) { unsigned u; memcpy(&u, &f, 4); u = (u + 0x7fffu
 static float bf_to_f(unsigned short v) { unsigned u = (unsigned)v << 16; float f; memcpy(&f, &u, 4); return f; }
 
 // CPU restatement of the kernel's arithmetic for one image (double accumulation; the comparison allows for bf16 roundings that flip)
+static void conv_gn_cpu(const std::vector<float>& in, int H, int cin, int cout, int ks, int stride, const std::vector<unsigned short>& wt,
+                        const std::vector<float>& g, const std::vector<float>& b, const std::vector<float>* resid, bool relu,
+                        std::vector<float>& o) {
+  const int pad = ks / 2, K = ks * ks * cin, OH = (H + 2 * pad - ks) / stride + 1, npx = OH * OH, cpg = cout / 16;
+  std::vector<double> raw((size_t)npx * cout);
+  for (int y = 0; y < OH; y++) for (int xx = 0; xx < OH; xx++) for (int co = 0; co < cout; co++) {
+    double a = 0;
+    for (int ky = 0; ky < ks; ky++) for (int kx = 0; kx < ks; kx++) {
+      const int iy = y * stride + ky - pad, ix = xx * stride + kx - pad;
+      if (iy < 0 || iy >= H || ix < 0 || ix >= H) continue;
+      for (int c = 0; c < cin; c++) a += (double)bf_to_f(wt[(size_t)co * K + (ky * ks + kx) * cin + c]) * in[((size_t)iy * H + ix) * cin + c];
+    }
+    raw[((size_t)y * OH + xx) * cout + co] = a;
+  }
+  o.assign((size_t)npx * cout, 0.f);
+  for (int grp = 0; grp < 16; grp++) {
+    double s1 = 0, s2 = 0;
+    for (int p = 0; p < npx; p++) for (int j = 0; j < cpg; j++) { const double v = raw[(size_t)p * cout + grp * cpg + j]; s1 += v; s2 += v * v; }
+    const double n = (double)npx * cpg, mean = s1 / n, var = s2 / n - mean * mean;
+    for (int j = 0; j < cpg; j++) {
+      const int co = grp * cpg + j;
+      const float sc = g[co] * (float)(1.0 / sqrt(var + 1e-5)), sh = b[co] - (float)mean * sc;
+      for (int p = 0; p < npx; p++) {
+        float v = bf_round((float)raw[(size_t)p * cout + co]) * sc + sh;
+        if (resid) v += (*resid)[(size_t)p * cout + co];
+        o[(size_t)p * cout + co] = bf_round(relu ? (v > 0.f ? v : 0.f) : v);
+      }
+    }
+  }
+}
+
 static void cpu_head(const std::vector<float>& img, int S, int C, float div, const std::vector<unsigned short>* w, const std::vector<float>* gm,
                      const std::vector<float>* bt, std::vector<float>& out) {
   const int k = S / 64;
@@ -24,42 +55,23 @@ static void cpu_head(const std::vector<float>& img, int S, int C, float div, con
     for (int dy = 0; dy < k; dy++) for (int dx = 0; dx < k; dx++) s += img[((size_t)(oy * k + dy) * S + ox * k + dx) * C + c] / div;
     x[((size_t)oy * 64 + ox) * 8 + c] = bf_round(s * (1.f / (k * k)));
   }
-  auto conv_gn = [&](const std::vector<float>& in, int cin, int ks, const std::vector<unsigned short>& wt, const std::vector<float>& g,
-                     const std::vector<float>& b, const std::vector<float>* resid, std::vector<float>& o) {
-    const int pad = ks / 2, K = ks * ks * cin;
-    std::vector<double> raw((size_t)4096 * 16);
-    for (int y = 0; y < 64; y++) for (int xx = 0; xx < 64; xx++) for (int co = 0; co < 16; co++) {
-      double a = 0;
-      for (int ky = 0; ky < ks; ky++) for (int kx = 0; kx < ks; kx++) {
-        const int iy = y + ky - pad, ix = xx + kx - pad;
-        if (iy < 0 || iy >= 64 || ix < 0 || ix >= 64) continue;
-        for (int c = 0; c < cin; c++) a += (double)bf_to_f(wt[(size_t)co * K + (ky * ks + kx) * cin + c]) * in[((size_t)iy * 64 + ix) * cin + c];
-      }
-      raw[((size_t)y * 64 + xx) * 16 + co] = a;
-    }
-    o.assign((size_t)4096 * 16, 0.f);
-    for (int co = 0; co < 16; co++) {
-      double s1 = 0, s2 = 0;
-      for (int p = 0; p < 4096; p++) { s1 += raw[(size_t)p * 16 + co]; s2 += raw[(size_t)p * 16 + co] * raw[(size_t)p * 16 + co]; }
-      const double mean = s1 / 4096, var = s2 / 4096 - mean * mean;
-      const float sc = g[co] * (float)(1.0 / sqrt(var + 1e-5)), sh = b[co] - (float)mean * sc;
-      for (int p = 0; p < 4096; p++) {
-        float v = bf_round((float)raw[(size_t)p * 16 + co]) * sc + sh;
-        if (resid) v += (*resid)[(size_t)p * 16 + co];
-        o[(size_t)p * 16 + co] = bf_round(v > 0.f ? v : 0.f);
-      }
-    }
-  };
-  std::vector<float> a0, a1, a2, a3, a4;
-  conv_gn(x, 8, 7, w[0], gm[0], bt[0], nullptr, a0);
-  conv_gn(a0, 16, 3, w[1], gm[1], bt[1], nullptr, a1);
-  conv_gn(a1, 16, 3, w[2], gm[2], bt[2], &a0, a2);
-  conv_gn(a2, 16, 3, w[3], gm[3], bt[3], nullptr, a3);
-  conv_gn(a3, 16, 3, w[4], gm[4], bt[4], &a2, a4);
-  out = a4;
+  std::vector<float> a0, a1, a2, a3, a4, d, e1, e2, e3, e4;
+  conv_gn_cpu(x, 64, 8, 16, 7, 1, w[0], gm[0], bt[0], nullptr, true, a0);
+  conv_gn_cpu(a0, 64, 16, 16, 3, 1, w[1], gm[1], bt[1], nullptr, true, a1);
+  conv_gn_cpu(a1, 64, 16, 16, 3, 1, w[2], gm[2], bt[2], &a0, true, a2);
+  conv_gn_cpu(a2, 64, 16, 16, 3, 1, w[3], gm[3], bt[3], nullptr, true, a3);
+  conv_gn_cpu(a3, 64, 16, 16, 3, 1, w[4], gm[4], bt[4], &a2, true, a4);
+  conv_gn_cpu(a4, 64, 16, 32, 1, 2, w[5], gm[5], bt[5], nullptr, false, d);          // downsample + norm (no ReLU)
+  conv_gn_cpu(a4, 64, 16, 32, 3, 2, w[6], gm[6], bt[6], nullptr, true, e1);
+  conv_gn_cpu(e1, 32, 32, 32, 3, 1, w[7], gm[7], bt[7], &d, true, e2);
+  conv_gn_cpu(e2, 32, 32, 32, 3, 1, w[8], gm[8], bt[8], nullptr, true, e3);
+  conv_gn_cpu(e3, 32, 32, 32, 3, 1, w[9], gm[9], bt[9], &e2, true, e4);
+  out = e4;
 }
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+static const size_t WSIZE[10] = {16 * 392, 16 * 144, 16 * 144, 16 * 144, 16 * 144, 32 * 16, 32 * 144, 32 * 288, 32 * 288, 32 * 288};
 
 int main(int argc, char** argv) {
   const int B = argc > 1 ? atoi(argv[1]) : 64, G = argc > 2 ? atoi(argv[2]) : 6, S = argc > 3 ? atoi(argv[3]) : 128;
@@ -87,10 +99,12 @@ int main(int argc, char** argv) {
     const size_t n = (size_t)B * S * S * t.C;
     if (t.u8) { void* p; hipMalloc(&p, n); hipMemset(p, 77, n); t.img = p; }
     else t.img = devf(n, t.C == 3 ? 128.f : 0.5f, t.C == 3 ? 100.f : 0.4f);
-    t.w[0] = (const bf16*)dev(16 * 392 * 2, true, 0.1f);
-    for (int i = 1; i < 5; i++) t.w[i] = (const bf16*)dev(16 * 144 * 2, true, 0.12f);
-    for (int i = 0; i < 5; i++) { t.g[i] = devf(16, 1.f, 0.2f); t.b[i] = devf(16, 0.f, 0.2f); }
-    void* y; hipMalloc(&y, (size_t)B * 4096 * 16 * 2); t.y = (bf16*)y;
+    for (int i = 0; i < 10; i++) {
+      t.w[i] = (const bf16*)dev(WSIZE[i] * 2, true, i == 0 ? 0.1f : i == 5 ? 0.3f : i < 7 ? 0.12f : 0.08f);
+      const int nch = i < 5 ? 16 : 32;
+      t.g[i] = devf(nch, 1.f, 0.2f); t.b[i] = devf(nch, 0.f, 0.2f);
+    }
+    void* y; hipMalloc(&y, (size_t)B * 1024 * 32 * 2); t.y = (bf16*)y;
   }
   {
     float* d; hipMalloc(&d, 64 * 4); float h[64];
@@ -100,7 +114,7 @@ int main(int argc, char** argv) {
     for (int l = 0; l < 64; l++) { const int r = l / 16; ok = ok && h[l] == (float)(16 * (16 * r) + 120); }
     printf("row16_sum self-test: %s (%g %g %g %g)\n", ok ? "ok" : "WRONG", h[0], h[16], h[37], h[63]);
   }
-  long long* prof; CK(hipMalloc(&prof, (size_t)B * G * 16 * 8));
+  long long* prof; CK(hipMalloc(&prof, (size_t)B * G * 32 * 8));
   a.prof = prof;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, HEAD_LDS));
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -114,35 +128,42 @@ int main(int argc, char** argv) {
   float ms; hipEventElapsedTime(&ms, e0, e1);
   printf("B=%d G=%d S=%d u8=%d: %.1f us per launch (%d workgroups)\n", B, G, S, u8, ms * 1000 / IT, B * G);
 #ifdef AVLEN_HEAD_PROF
-  std::vector<long long> h((size_t)B * G * 16);
+  std::vector<long long> h((size_t)B * G * 32);
   hipMemcpy(h.data(), prof, h.size() * 8, hipMemcpyDeviceToHost);
-  const char* names[14] = {"preprocess", "stem conv", "stem stats", "a0 write", "conv1", "stats1", "apply1+conv2", "stats2", "apply2+conv3",
-                           "stats3", "apply3+conv4", "stats4", "apply4", "store"};
-  double tot = 0; std::vector<double> ph(14, 0.0);
+  const int NP = 19;
+  const char* names[NP] = {"preprocess", "stem conv", "stem stats", "a0 write", "conv1", "stats1", "apply1+conv2", "stats2", "apply2+conv3",
+                           "stats3", "apply3+conv4", "stats4", "apply4", "l2 downsample", "l2 conv s2", "l2 conv2", "l2 conv3", "l2 conv4", "store"};
+  double tot = 0; std::vector<double> ph(NP, 0.0);
   for (int w = 0; w < B * G; w++)
-    for (int k = 0; k < 14; k++) ph[k] += (double)(h[w * 16 + k + 1] - h[w * 16 + k]);
-  for (int k = 0; k < 14; k++) tot += ph[k];
-  for (int k = 0; k < 14; k++) printf("  %-14s %6.1f %%  (%.0f ticks)\n", names[k], 100 * ph[k] / tot, ph[k] / (B * G));
+    for (int k = 0; k < NP; k++) ph[k] += (double)(h[w * 32 + k + 1] - h[w * 32 + k]);
+  for (int k = 0; k < NP; k++) tot += ph[k];
+  for (int k = 0; k < NP; k++) printf("  %-14s %6.1f %%  (%.0f ticks)\n", names[k], 100 * ph[k] / tot, ph[k] / (B * G));
   printf("  workgroup total %.0f ticks\n", tot / (B * G));
+  {
+    double d[4] = {0, 0, 0, 0};
+    for (int w = 0; w < B * G; w++) for (int k = 0; k < 4; k++) d[k] += (double)(h[w * 32 + 25 + k] - h[w * 32 + 24 + k]);
+    printf("  inside stats1: reduce+write %.0f, barrier %.0f, serial section %.0f, barrier %.0f ticks\n", d[0] / (B * G), d[1] / (B * G), d[2] / (B * G), d[3] / (B * G));
+  }
 #endif
   // tower 0, image 0 against the CPU restatement
   if (!a.t[0].u8) {
     const HeadTower& t = a.t[0];
     std::vector<float> img((size_t)S * S * t.C); hipMemcpy(img.data(), t.img, img.size() * 4, hipMemcpyDeviceToHost);
-    std::vector<unsigned short> w[5]; std::vector<float> gm[5], bt[5];
-    for (int i = 0; i < 5; i++) {
-      w[i].resize(i ? 16 * 144 : 16 * 392); hipMemcpy(w[i].data(), t.w[i], w[i].size() * 2, hipMemcpyDeviceToHost);
-      gm[i].resize(16); bt[i].resize(16);
-      hipMemcpy(gm[i].data(), t.g[i], 64, hipMemcpyDeviceToHost); hipMemcpy(bt[i].data(), t.b[i], 64, hipMemcpyDeviceToHost);
+    std::vector<unsigned short> w[10]; std::vector<float> gm[10], bt[10];
+    for (int i = 0; i < 10; i++) {
+      w[i].resize(WSIZE[i]); hipMemcpy(w[i].data(), t.w[i], w[i].size() * 2, hipMemcpyDeviceToHost);
+      const int nch = i < 5 ? 16 : 32;
+      gm[i].resize(nch); bt[i].resize(nch);
+      hipMemcpy(gm[i].data(), t.g[i], nch * 4, hipMemcpyDeviceToHost); hipMemcpy(bt[i].data(), t.b[i], nch * 4, hipMemcpyDeviceToHost);
     }
     std::vector<float> ref; cpu_head(img, S, t.C, t.div, w, gm, bt, ref);
-    std::vector<unsigned short> yy((size_t)4096 * 16); hipMemcpy(yy.data(), t.y, yy.size() * 2, hipMemcpyDeviceToHost);
+    std::vector<unsigned short> yy((size_t)1024 * 32); hipMemcpy(yy.data(), t.y, yy.size() * 2, hipMemcpyDeviceToHost);
     double mx = 0, sm = 0, rf = 0; int bad = 0;
     for (size_t i = 0; i < ref.size(); i++) { const double d = fabs((double)bf_to_f(yy[i]) - ref[i]); mx = d > mx ? d : mx; sm += d; rf += fabs(ref[i]); bad += d > 0.05; }
     printf("  vs CPU restatement: max |d| %.4f, mean |d| %.5f (mean |ref| %.4f), %d of %zu beyond 0.05\n", mx, sm / ref.size(), rf / ref.size(), bad, ref.size());
   }
   // sanity: output finite and non-trivial
-  std::vector<unsigned short> y((size_t)4096 * 16);
+  std::vector<unsigned short> y((size_t)1024 * 32);
   hipMemcpy(y.data(), a.t[0].y, y.size() * 2, hipMemcpyDeviceToHost);
   double sum = 0; for (auto v : y) { unsigned u = (unsigned)v << 16; float f; memcpy(&f, &u, 4); sum += f; }
   printf("  mean of tower 0 image 0 output: %.5f\n", sum / y.size());
