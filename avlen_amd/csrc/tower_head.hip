@@ -60,6 +60,24 @@ typedef __attribute__((ext_vector_type(2))) short i16x2;
 __device__ __forceinline__ unsigned relu_pk(unsigned v) {
   return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, v), (i16x2){0, 0}));
 }
+// workgroup barrier that orders LDS traffic only: weight prefetches (global loads) stay in flight across it -- __syncthreads()
+// would drain them (vmcnt(0)); the kernel's only global stores are its last statements
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+// per-lane statistics of one accumulator tile, two channels per instruction (v_pk_add_f32 / v_pk_fma_f32)
+__device__ __forceinline__ void stat16(const f32x4& v, f32x2& sA, f32x2& sB, f32x2& qA, f32x2& qB) {
+  const f32x2 a = {v[0], v[1]}, b = {v[2], v[3]};
+  sA += a; sB += b;
+  qA = __builtin_elementwise_fma(a, a, qA); qB = __builtin_elementwise_fma(b, b, qB);
+}
+// 32-channel stages: channels (0, 1) and (2, 3) of a tile are the two GroupNorm groups of the lane -> horizontal pairs
+__device__ __forceinline__ void stat32(const f32x4& v, float& g0, float& g1, float& h0, float& h1) {
+  g0 += v[0] + v[1]; g1 += v[2] + v[3];
+  h0 = __builtin_fmaf(v[1], v[1], __builtin_fmaf(v[0], v[0], h0)); h1 = __builtin_fmaf(v[3], v[3], __builtin_fmaf(v[2], v[2], h1));
+}
 // sum over the 16 lanes of a DPP row (the 16 pixels of an MFMA tile column group): 4 v_add_f32 with DPP operands, no LDS
 __device__ __forceinline__ float row16_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
@@ -132,7 +150,7 @@ __device__ __forceinline__ void finish_stats(float (&s1)[4], float (&s2)[4], cha
     if (r16 == 0) *reinterpret_cast<float2*>(&part[(wave * 16 + slot) * 2]) = make_float2(a, c);
   }
   FS_STAMP(25);
-  __syncthreads();                                // every wave has also finished reading the image of this conv
+  lds_barrier();                                // every wave has also finished reading the image of this conv
   FS_STAMP(26);
   if (tid < NCH) {
     const int g = NCH == 16 ? tid : tid >> 1;
@@ -148,22 +166,25 @@ __device__ __forceinline__ void finish_stats(float (&s1)[4], float (&s2)[4], cha
     coef[tid] = sc; coef[32 + tid] = beta[tid] - (float)mean * sc;
   }
   FS_STAMP(27);
-  __syncthreads();
+  lds_barrier();
   FS_STAMP(28);
 }
 
 // One 3x3 stride-1 conv 32 -> 32 over the 32 x 32 frame + GroupNorm (+ residual) + ReLU, input-row stationary: a wave owns 4
 // output rows x 2 column tiles x 2 cout tiles.  Per column tile: the three kx-shifted fragments of frame row f (lane (x, q):
 // channels 8 q .. 8 q + 7 of pixel x + kx) are read once and feed the output rows f - ky through the 18 weight fragments.
-template <bool SECOND>
-__device__ __forceinline__ void conv32_gn(const bf16* __restrict__ wt, int gb, char* lds, P4 (&rawp)[32], P4 (&res)[32], int tid, int wave,
-                                          int r16, int q) {
-  const float* coef = reinterpret_cast<const float*>(lds + COEF_OFF);
-  bf16x8 W[9][2];
+__device__ __forceinline__ void load_w32(bf16x8 (&W)[9][2], const bf16* __restrict__ wt, int r16, int q) {
 #pragma unroll
   for (int tap = 0; tap < 9; tap++)
 #pragma unroll
     for (int ct = 0; ct < 2; ct++) W[tap][ct] = *reinterpret_cast<const bf16x8*>(wt + (long)(ct * 16 + r16) * 288 + tap * 32 + 8 * q);
+}
+// W: this conv's weight fragments (already loaded or in flight); next_wt: the following 32-channel conv's weights, fetched into
+// W as soon as the MFMAs are done, so that the L2 round trip runs under the statistics / apply phases (nullptr: none)
+template <bool SECOND>
+__device__ __forceinline__ void conv32_gn(bf16x8 (&W)[9][2], const bf16* __restrict__ next_wt, int gb, char* lds, P4 (&rawp)[32],
+                                          P4 (&res)[32], int tid, int wave, int r16, int q) {
+  const float* coef = reinterpret_cast<const float*>(lds + COEF_OFF);
   int rd[3];
 #pragma unroll
   for (int kx = 0; kx < 3; kx++) rd[kx] = a32(wave * 4, r16 + kx, q);
@@ -195,10 +216,10 @@ __device__ __forceinline__ void conv32_gn(const bf16* __restrict__ wt, int gb, c
 #pragma unroll
       for (int ct = 0; ct < 2; ct++) {
         const f32x4 v = acc[rr][ct];
-        s1[ct * 2] += v[0] + v[1]; s2[ct * 2] += v[0] * v[0] + v[1] * v[1];
-        s1[ct * 2 + 1] += v[2] + v[3]; s2[ct * 2 + 1] += v[2] * v[2] + v[3] * v[3];
+        stat32(v, s1[ct * 2], s1[ct * 2 + 1], s2[ct * 2], s2[ct * 2 + 1]);
         rawp[(rr * 2 + pt) * 2 + ct] = pack4(v[0], v[1], v[2], v[3]);
       }
+    if (pt == 1 && next_wt) load_w32(W, next_wt, r16, q);
   }
   finish_stats<32>(s1, s2, lds, gb, tid, wave, r16, q);
 #pragma unroll
@@ -219,7 +240,7 @@ __device__ __forceinline__ void conv32_gn(const bf16* __restrict__ wt, int gb, c
         *reinterpret_cast<uint2*>(lds + wr + (rr * ROWQ + pt * 16) * 64) = make_uint2(o.lo, o.hi);
       }
   }
-  __syncthreads();
+  lds_barrier();
 }
 
 __global__ __launch_bounds__(HTH) void tower_head_kernel(HeadArgs args, int B) {
@@ -234,6 +255,18 @@ __global__ __launch_bounds__(HTH) void tower_head_kernel(HeadArgs args, int B) {
   for (int e = 0; e < 8; e++) zero8[e] = (bf16)0.f;
 
   HEAD_STAMP(0);
+  // the stem's weight fragments: fetched first, the L2 round trip runs under the preprocessing
+  bf16x8 wf[7];
+  {
+    const bf16* __restrict__ wt = t.w[0];         // [16][49][8] (the packing of the launch-per-layer path); channels 4..7 are zero
+#pragma unroll
+    for (int ky = 0; ky < 7; ky++) {
+      const int kx = 2 * q;
+      const uint2 w0 = *reinterpret_cast<const uint2*>(wt + (long)r16 * 392 + (ky * 7 + kx) * 8);
+      const uint2 w1 = kx + 1 < 7 ? *reinterpret_cast<const uint2*>(wt + (long)r16 * 392 + (ky * 7 + kx + 1) * 8) : make_uint2(0u, 0u);
+      wf[ky] = __builtin_bit_cast(bf16x8, make_uint4(w0.x, w0.y, w1.x, w1.y));
+    }
+  }
   if (tid < 480) {                                // GroupNorm affine parameters -> LDS (read inside the statistics' critical section)
     const bool l1 = tid < 160;
     const int n = l1 ? tid >> 5 : 5 + ((tid - 160) >> 6), j = l1 ? tid & 31 : (tid - 160) & 63, nch = l1 ? 16 : 32;
@@ -271,7 +304,7 @@ __global__ __launch_bounds__(HTH) void tower_head_kernel(HeadArgs args, int B) {
       if (row < 3 || row >= 67 || col < 3 || col >= 67) *reinterpret_cast<uint2*>(lds + i * 8) = make_uint2(0u, 0u);
     }
   }
-  __syncthreads();
+  lds_barrier();
   HEAD_STAMP(1);
 
   P4 rawp[32], res[32];
@@ -282,18 +315,8 @@ __global__ __launch_bounds__(HTH) void tower_head_kernel(HeadArgs args, int B) {
   // output rows f - ky with the weights of kernel row ky: each fragment is read from LDS once and used by up to 7 MFMAs (LDS
   // bandwidth, not MFMA, bounded the output-stationary form).  Addresses = per-lane base + compile-time offset.
   {
-    const bf16* __restrict__ wt = t.w[0];         // [16][49][8] (the packing of the launch-per-layer path); channels 4..7 are zero
-    bf16x8 wf[7];
-#pragma unroll
-    for (int ky = 0; ky < 7; ky++) {
-      const int kx = 2 * q;
-      const uint2 w0 = *reinterpret_cast<const uint2*>(wt + (long)r16 * 392 + (ky * 7 + kx) * 8);
-      const uint2 w1 = kx + 1 < 7 ? *reinterpret_cast<const uint2*>(wt + (long)r16 * 392 + (ky * 7 + kx + 1) * 8) : make_uint2(0u, 0u);
-      wf[ky] = __builtin_bit_cast(bf16x8, make_uint4(w0.x, w0.y, w1.x, w1.y));
-    }
     const int st_base = ((wave * 8) * ROWP0 + r16 + 2 * q) * 8;
-#pragma unroll
-    for (int r = 0; r < 4; r++) { s1[r] = 0.f; s2[r] = 0.f; }
+    f32x2 sA = {0.f, 0.f}, sB = {0.f, 0.f}, qA = {0.f, 0.f}, qB = {0.f, 0.f};       // sums / sums of squares of channels (0, 1), (2, 3)
 #pragma unroll
     for (int mt = 0; mt < 4; mt++) {
       f32x4 acc[8];
@@ -312,11 +335,11 @@ __global__ __launch_bounds__(HTH) void tower_head_kernel(HeadArgs args, int B) {
       }
 #pragma unroll
       for (int rr = 0; rr < 8; rr++) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) { const float v = acc[rr][r]; s1[r] += v; s2[r] += v * v; }
+        stat16(acc[rr], sA, sB, qA, qB);
         rawp[rr * 4 + mt] = pack4(acc[rr][0], acc[rr][1], acc[rr][2], acc[rr][3]);
       }
     }
+    s1[0] = sA[0]; s1[1] = sA[1]; s1[2] = sB[0]; s1[3] = sB[1]; s2[0] = qA[0]; s2[1] = qA[1]; s2[2] = qB[0]; s2[3] = qB[1];
   }
   HEAD_STAMP(2);
   finish_stats<16>(s1, s2, lds, 0, tid, wave, r16, q);
@@ -343,7 +366,7 @@ __global__ __launch_bounds__(HTH) void tower_head_kernel(HeadArgs args, int B) {
       *reinterpret_cast<bf16x8*>(lds + off) = zero8;
     }
   }
-  __syncthreads();
+  lds_barrier();
   HEAD_STAMP(4);
 
   // ---- layer 1: four 3x3 convs, 16 -> 16, input-row stationary as well.  k-steps of 32 = 2 taps x 16 channels:
@@ -353,19 +376,21 @@ __global__ __launch_bounds__(HTH) void tower_head_kernel(HeadArgs args, int B) {
   const int f_base = a16(wave * 8, r16 + (q >> 1), q & 1);
   const int g_base = a16(wave * 8 + (q >> 1), r16 + 2, q & 1);
   const int g_last = a16(wave * 8, r16 + 2, q & 1);          // frame row 9 of the wave: its second half would leave the frame (weights zero)
+  bf16x8 wF[3], wG01, wG2;                        // [16][9][16] weights as fragments, fetched one conv ahead
+  auto load_w16 = [&](const bf16* __restrict__ w) {
+    const bf16* wt = w + (long)r16 * 144 + (q & 1) * 8;
+#pragma unroll
+    for (int ky = 0; ky < 3; ky++) wF[ky] = *reinterpret_cast<const bf16x8*>(wt + (ky * 3 + (q >> 1)) * 16);
+    wG01 = *reinterpret_cast<const bf16x8*>(wt + ((q >> 1) * 3 + 2) * 16);
+    wG2 = (q >> 1) == 0 ? *reinterpret_cast<const bf16x8*>(wt + 8 * 16) : zero8;
+  };
+  load_w16(t.w[1]);
   for (int blk = 0; blk < 2; blk++)
 #pragma unroll
   for (int cj = 0; cj < 2; cj++) {
     const int ci = blk * 2 + cj;
     const bool second = cj == 1;                  // conv2 of a basic block: + residual, result becomes the next residual
-    const bf16* __restrict__ wt = t.w[1 + ci] + (long)r16 * 144 + (q & 1) * 8;      // [16][9][16]
-    bf16x8 wF[3], wG01, wG2;
-#pragma unroll
-    for (int ky = 0; ky < 3; ky++) wF[ky] = *reinterpret_cast<const bf16x8*>(wt + (ky * 3 + (q >> 1)) * 16);
-    wG01 = *reinterpret_cast<const bf16x8*>(wt + ((q >> 1) * 3 + 2) * 16);
-    wG2 = (q >> 1) == 0 ? *reinterpret_cast<const bf16x8*>(wt + 8 * 16) : zero8;
-#pragma unroll
-    for (int r = 0; r < 4; r++) { s1[r] = 0.f; s2[r] = 0.f; }
+    f32x2 sA = {0.f, 0.f}, sB = {0.f, 0.f}, qA = {0.f, 0.f}, qB = {0.f, 0.f};       // sums / sums of squares of channels (0, 1), (2, 3)
 #pragma unroll
     for (int mt = 0; mt < 4; mt++) {
       f32x4 acc[8];
@@ -385,11 +410,12 @@ __global__ __launch_bounds__(HTH) void tower_head_kernel(HeadArgs args, int B) {
       }
 #pragma unroll
       for (int rr = 0; rr < 8; rr++) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) { const float v = acc[rr][r]; s1[r] += v; s2[r] += v * v; }
+        stat16(acc[rr], sA, sB, qA, qB);
         rawp[rr * 4 + mt] = pack4(acc[rr][0], acc[rr][1], acc[rr][2], acc[rr][3]);
       }
     }
+    s1[0] = sA[0]; s1[1] = sA[1]; s1[2] = sB[0]; s1[3] = sB[1]; s2[0] = qA[0]; s2[1] = qA[1]; s2[2] = qB[0]; s2[3] = qB[1];
+    if (ci < 3) load_w16(t.w[2 + ci]);
     HEAD_STAMP(5 + 2 * ci);
     finish_stats<16>(s1, s2, lds, (1 + ci) * 32, tid, wave, r16, q, args.prof ? args.prof + (blockIdx.y * gridDim.x + blockIdx.x) * 32 : nullptr);
     HEAD_STAMP(6 + 2 * ci);
@@ -406,7 +432,7 @@ __global__ __launch_bounds__(HTH) void tower_head_kernel(HeadArgs args, int B) {
         *reinterpret_cast<uint2*>(lds + wr_base + (rr * ROWP + mt * 16) * 32) = make_uint2(o.lo, o.hi);
       }
     }
-    __syncthreads();
+    lds_barrier();
   }
   HEAD_STAMP(13);
   // ---- layer 2, block 0: 1x1 stride-2 downsample + GroupNorm of the skip -> residual registers (no ReLU).  Output pixel (oy, ox)
@@ -427,8 +453,7 @@ __global__ __launch_bounds__(HTH) void tower_head_kernel(HeadArgs args, int B) {
 #pragma unroll
         for (int ct = 0; ct < 2; ct++) {
           const f32x4 v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wD[ct], xf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-          s1[ct * 2] += v[0] + v[1]; s2[ct * 2] += v[0] * v[0] + v[1] * v[1];
-          s1[ct * 2 + 1] += v[2] + v[3]; s2[ct * 2 + 1] += v[2] * v[2] + v[3] * v[3];
+          stat32(v, s1[ct * 2], s1[ct * 2 + 1], s2[ct * 2], s2[ct * 2 + 1]);
           res[(rr * 2 + pt) * 2 + ct] = pack4(v[0], v[1], v[2], v[3]);
         }
       }
@@ -446,6 +471,7 @@ __global__ __launch_bounds__(HTH) void tower_head_kernel(HeadArgs args, int B) {
     }
   }
   HEAD_STAMP(14);
+  bf16x8 W32[9][2];                               // weight fragments of the 32 -> 32 convs: fetched one conv ahead
   // ---- block 0 conv1: 3x3 stride 2, 16 -> 32 (k-steps of 2 taps x 16 channels as in layer 1; the fragment of a column tile serves
   // both cout tiles), GroupNorm + ReLU -> the 32-channel frame, which takes the 16-channel frame's place once every wave is done
   {
@@ -478,11 +504,11 @@ __global__ __launch_bounds__(HTH) void tower_head_kernel(HeadArgs args, int B) {
 #pragma unroll
         for (int ct = 0; ct < 2; ct++) {
           const f32x4 v = acc[ct];
-          s1[ct * 2] += v[0] + v[1]; s2[ct * 2] += v[0] * v[0] + v[1] * v[1];
-          s1[ct * 2 + 1] += v[2] + v[3]; s2[ct * 2 + 1] += v[2] * v[2] + v[3] * v[3];
+          stat32(v, s1[ct * 2], s1[ct * 2 + 1], s2[ct * 2], s2[ct * 2 + 1]);
           rawp[(rr * 2 + pt) * 2 + ct] = pack4(v[0], v[1], v[2], v[3]);
         }
       }
+    load_w32(W32, t.w[7], r16, q);
     finish_stats<32>(s1, s2, lds, 160 + 64, tid, wave, r16, q);
 #pragma unroll
     for (int ct = 0; ct < 2; ct++) {
@@ -507,13 +533,13 @@ __global__ __launch_bounds__(HTH) void tower_head_kernel(HeadArgs args, int B) {
       *reinterpret_cast<bf16x8*>(lds + off) = zero8;
     }
   }
-  __syncthreads();
+  lds_barrier();
   HEAD_STAMP(15);
-  conv32_gn<true>(t.w[7], 160 + 128, lds, rawp, res, tid, wave, r16, q);          // block 0 conv2 + skip
+  conv32_gn<true>(W32, t.w[8], 160 + 128, lds, rawp, res, tid, wave, r16, q);          // block 0 conv2 + skip
   HEAD_STAMP(16);
-  conv32_gn<false>(t.w[8], 160 + 192, lds, rawp, res, tid, wave, r16, q);         // block 1 conv1
+  conv32_gn<false>(W32, t.w[9], 160 + 192, lds, rawp, res, tid, wave, r16, q);         // block 1 conv1
   HEAD_STAMP(17);
-  conv32_gn<true>(t.w[9], 160 + 256, lds, rawp, res, tid, wave, r16, q);          // block 1 conv2 + identity
+  conv32_gn<true>(W32, nullptr, 160 + 256, lds, rawp, res, tid, wave, r16, q);         // block 1 conv2 + identity
   HEAD_STAMP(18);
   // ---- layer-2 output, NHWC bf16 (32 x 32 x 32): the frame's interior, 16 B per lane, consecutive lanes consecutive addresses
   {
