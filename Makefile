@@ -10,7 +10,7 @@ OBJS  := $(patsubst $(SRC)/%.hip,$(OBJ)/%.o,$(SRCS))
 
 all: $(LIB)
 
-$(OBJ)/%.o: $(SRC)/%.hip $(SRC)/common.h $(SRC)/internal.h include/avlen_hip.h
+$(OBJ)/%.o: $(SRC)/%.hip $(SRC)/common.h $(SRC)/internal.h $(SRC)/tower_util.h include/avlen_hip.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

@@ -38,7 +38,7 @@ class Linear(C.Structure):
 
 class Conv(C.Structure):
     _fields_ = [("w", f32p), ("b", f32p), ("cin", C.c_int), ("cout", C.c_int), ("kh", C.c_int), ("kw", C.c_int),
-                ("stride", C.c_int), ("pad", C.c_int), ("w16", vp), ("cin16", C.c_int), ("w16c", vp)]
+                ("stride", C.c_int), ("pad", C.c_int), ("w16", vp), ("cin16", C.c_int), ("w16c", vp), ("w16f", vp)]
 
 
 class Affine(C.Structure):
@@ -127,6 +127,7 @@ SIGNATURES = {
     "avlen_conv_direct_bf16": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "avlen_cast_bf16": (i32, [vp, i32, vp, i32, C.c_long, i32, vp]),
     "avlen_pack_conv_weight_bf16": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "avlen_pack_conv_weight_frag": (i32, [vp, vp, i32, i32, vp]),
     "avlen_pack_fc_after_flatten_bf16": (i32, [vp, vp, i32, i32, i32, vp]),
     "avlen_pack_conv_weight": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "avlen_pack_fc_after_flatten": (i32, [vp, vp, i32, i32, i32, vp]),

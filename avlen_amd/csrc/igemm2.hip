@@ -819,6 +819,21 @@ extern "C" int avlen_pack_conv_weight_bf16(const float* w_oihw, void* w_packed, 
   return avlen_launch_status();
 }
 
+// w16 [cout][K] -> fragment order [cout/16][K/32][lane = 16 q + r][8]: lane's chunk = w16[16 t + r][32 i + 8 q ..]
+__global__ void pack_conv_frag_kernel(const uint4* __restrict__ w16, uint4* __restrict__ w16f, int cout, int K) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;              // one 16-byte chunk
+  const int ksteps = K / 32;
+  if (idx >= (long)cout * ksteps * 4) return;
+  const int lane = idx & 63, i = (idx >> 6) % ksteps, t = (int)((idx >> 6) / ksteps), r = lane & 15, q = lane >> 4;
+  w16f[idx] = w16[((long)(t * 16 + r) * K + i * 32 + 8 * q) >> 3];
+}
+extern "C" int avlen_pack_conv_weight_frag(const void* w16, void* w16f, int cout, int K, hipStream_t stream) {
+  if (!w16 || !w16f || cout % 16 || K % 32 || cout <= 0 || K <= 0) return AVLEN_ERR_ARG;
+  const long tot = (long)cout * (K / 32) * 4;
+  hipLaunchKernelGGL(pack_conv_frag_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, (const uint4*)w16, (uint4*)w16f, cout, K);
+  return avlen_launch_status();
+}
+
 extern "C" int avlen_pack_fc_after_flatten_bf16(const float* w, void* w_packed, int O, int C, int HW, hipStream_t stream) {
   long tot = (long)O * C * HW;
   hipLaunchKernelGGL(pack_fc_bf16_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, w, (bf16*)w_packed, O, C, HW);

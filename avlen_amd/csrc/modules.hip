@@ -722,7 +722,7 @@ int resnet18_group_fwd_bf16(const avlen_resnet18* const* nets, const void* const
   static int tail = -1;                        // AVLEN_TOWER_TAIL=0: layers 3-4 as separate conv / GroupNorm launches (A/B knob)
   if (tail < 0) tail = (int)avlen_knob("AVLEN_TOWER_TAIL", 1);
   for (int i = use_head ? 4 : 0; i < 8; i++) {
-    if (i == 4 && tail && H == 32 && G <= 6) {
+    if (i == 4 && tail && H == 32) {
       // layers 3 + 4 (four basic blocks): one launch, one workgroup per image, activations resident in LDS
       for (int g = 0; g < G; g++) { X[g] = cur[g]; OUT[g] = nxt[g]; }
       int rc = avlen_tower_tail_bf16(nets, X, OUT, G, B, st);

@@ -1,363 +1,387 @@
-// Layers 3 and 4 of the CustomResNet tower (smt_resnet.py:37-53, 100-131) as ONE launch: one workgroup per image keeps every
-// activation of the four basic blocks in LDS (16x16x64 and 8x8x128 bf16 tensors: 32 / 16 KiB each), streams the ten convs'
-// weights from L2 through a global_load_lds ring, takes the GroupNorm statistics from its own fp32 accumulators
-// (deterministic, no atomics: the whole image is in the block) and applies normalisation / residual / ReLU in place.
-// Replaces 10 implicit-GEMM launches + 10 GroupNorm-apply launches per tower group and all their HBM round trips: the
-// image's layer-2 output (64 KiB) is read once, the layer-4 output (16 KiB) written once.
+// Layers 3 and 4 of the CustomResNet tower (smt_resnet.py:37-53, 100-131: per layer a stride-2 basic block with a 1x1 stride-2
+// downsample + GroupNorm on the skip, then a stride-1 basic block; 32 -> 64 channels at 16x16, 64 -> 128 at 8x8) as ONE launch:
+// one workgroup per image, the activation of the current stage as a zero-framed bf16 image in LDS (34x34x32 input, 18x18x64,
+// 10x10x128), every raw conv output and the residual in registers, the conv weights as MFMA fragments in REGISTERS -- a wave
+// multiplies only its own 16 output channels, so a weight is fetched from L2 exactly once per workgroup and never passes
+// through LDS -- read from the fragment-order copy avlen_conv::w16f (1 KiB contiguous per wave and k-step; from the [cout][K]
+// layout a load touched 16 half-used lines and the 288 KiB of a layer-4 conv took 7 us per workgroup) one conv ahead, and the
+// GroupNorm statistics from the fp32 accumulators (fixed order, no atomics).
 //
-// Layout of an activation in LDS: [pixel][C] bf16, 16-byte chunks XOR-swizzled by the pixel index so that the 16 pixels of
-// an MFMA row tile (consecutive, or every other one for the stride-2 convs) read conflict-free with ds_read_b128:
-// physical chunk = chunk ^ ((pixel / (16 / CP)) & (CP - 1)), CP = C / 8 chunks per pixel.  Zero padding is a bounds test on
-// the fragment read.  MFMA is issued transposed (W fragment first): a lane ends up with 4 consecutive channels of one
-// pixel -> 8-byte LDS stores.
+// Work split (8 waves): layer 3 -- wave w owns cout tile w & 3 and output rows 8 (w >> 2) .. + 7 (an MFMA column tile = one
+// 16-pixel row); layer 4 -- wave w owns cout tile w and all four column tiles (two 8-pixel rows each).  The stride-1 convs
+// run input-row stationary: the kx-shifted fragments of a frame row are read once and feed the output rows row - ky.
+// GroupNorm(16): 64 channels -> a lane's four accumulator channels are exactly one group; 128 channels -> half a group.
+//
+// Same arithmetic as the launch-per-layer path: bf16 operands, fp32 MFMA accumulation over [ky][kx][c], raw conv outputs
+// rounded to bf16 before the normalisation, statistics from the fp32 accumulators, var = E[x^2] - mean^2 in double.
 #include "common.h"
 #include "../../include/avlen_hip.h"
 #include "internal.h"
-
-typedef __bf16 bf16;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-
-__device__ __attribute__((aligned(16))) unsigned int g_zero_page_tt[4096];     // K tails / surplus pieces of the weight tiles
-
-#ifdef AVLEN_TT_LAB
-__device__ long long g_tt_stamps[64];      // tools/tower_lab.hip: phase time stamps of block (0, 0)
-__device__ int g_tt_n;
-#define TT_STAMP() do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_tt_stamps[g_tt_n++] = clock64(); } while (0)
-#else
-#define TT_STAMP() do {} while (0)
-#endif
+#include "tower_util.h"
 
 namespace {
 
-constexpr int NTH = 512, NW = 8;
-constexpr int ACT = 32768;                    // one activation buffer (16x16x64 bf16)
-constexpr int RING3 = 4 * ACT;                // layer-3 weight ring: 3 stages of [64][64] (8 KiB) behind the four buffers
-constexpr int SCRATCH3 = RING3 + 3 * 8192;    // 1 KiB landing area of the layer-3 tiles' surplus pieces
-constexpr int STATS = SCRATCH3 + 1024;        // per-wave channel partials [8 waves][64 channels][2] fp32 = 4 KiB
-constexpr int COEF = STATS + 4096;            // scale / shift tables [4][128] fp32 = 2 KiB
-constexpr int WTAB = COEF + 2048;             // the ten weight pointers in stream order (an indexed private array would
-constexpr int LDS_BYTES = WTAB + 128;         // live in scratch: a VMEM load + vmcnt(0) per tile drains the whole ring)
-static_assert(2 * ACT + 16384 + 4 * 16384 <= SCRATCH3 && 3 * ACT + 7 * 8192 <= SCRATCH3 && LDS_BYTES <= 160 * 1024,
-              "tower tail LDS budget");
+constexpr int TTH = 512;
+constexpr int R32 = 34, R64 = 18, R128 = 10;      // frame edge (pixels) of the 32- / 64- / 128-channel images
+constexpr int FRAME_BYTES = R32 * R32 * 64;       // 73984: the largest frame; the later ones reuse its space
+constexpr int TPART_OFF = FRAME_BYTES;            // [8 waves][4 lane quarters][2] fp32 (+ pad)
+constexpr int TCOEF_OFF = TPART_OFF + 1024;       // scale[128], shift[128]
+constexpr int TGB_OFF = TCOEF_OFF + 1024;         // gamma | beta of the ten GroupNorms: 5 x (64 + 64), 5 x (128 + 128) fp32
+constexpr int TAIL_LDS = TGB_OFF + (5 * 128 + 5 * 256) * 4;
+static_assert(R64 * R64 * 128 <= FRAME_BYTES && R128 * R128 * 256 <= FRAME_BYTES && TAIL_LDS <= 160 * 1024, "tower tail LDS budget");
 
+// w / g / b per layer (l = 0: layer 3, l = 1: layer 4), index 5 l + {0 downsample, 1 block 0 conv1 (stride 2), 2 block 0 conv2,
+// 3 block 1 conv1, 4 block 1 conv2}
 struct TailTower { const bf16* x; bf16* y; const bf16* w[10]; const float* g[10]; const float* b[10]; };
-struct TailArgs { TailTower t[6]; };
+struct TailArgs { TailTower t[8]; long long* prof; };
+#ifdef AVLEN_TAIL_PROF          // tools/tail_lab.hip: phase timestamps of one wave of every workgroup
+#define TAIL_STAMP(k) do { if (args.prof && tid == AVLEN_TAIL_PROF) args.prof[(blockIdx.y * gridDim.x + blockIdx.x) * 32 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TAIL_STAMP(k) do { } while (0)
+#endif
 
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-__device__ __forceinline__ void bar() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+// frames: [row][pixel][C * 2 bytes], 16-byte chunks rotated by the pixel index so that neighbouring pixels' reads of one chunk
+// fall on different bank groups; + 16 pixels (a column tile) leaves the rotation unchanged
+__device__ __forceinline__ int a32(int y, int p, int chunk) { return (y * R32 + p) * 64 + ((chunk ^ ((p >> 1) & 3)) << 4); }
+__device__ __forceinline__ int a64(int y, int p, int chunk) { return (y * R64 + p) * 128 + ((chunk ^ (p & 7)) << 4); }
+__device__ __forceinline__ int a128(int y, int p, int chunk) { return (y * R128 + p) * 256 + ((chunk ^ (p & 7)) << 4); }
+
+// per-lane sums -> scale / shift of NCH channels.  NCH = 64: the lane's sums are those of group (cout tile) * 4 + q over the
+// wave's 8 rows (the group's other half: wave + 4); NCH = 128: of half a group, (cout tile = wave) * 2 + (q >> 1).
+template <int NCH>
+__device__ __forceinline__ void finish_stats_t(float s1, float s2, char* lds, int gb, int tid, int wave, int r16, int q) {
+  const float* gamma = reinterpret_cast<const float*>(lds + TGB_OFF) + gb;
+  const float* beta = gamma + NCH;
+  float2* part = reinterpret_cast<float2*>(lds + TPART_OFF);
+  float* coef = reinterpret_cast<float*>(lds + TCOEF_OFF);
+  const float a = row16_sum(s1), c = row16_sum(s2);
+  if (r16 == 0) part[wave * 4 + q] = make_float2(a, c);
+  lds_barrier();                                  // every wave has also finished reading the image of this conv
+  if (tid < NCH) {
+    float2 u, v;
+    if (NCH == 64) { const int g = tid >> 2, ct = g >> 2, qq = g & 3; u = part[ct * 4 + qq]; v = part[(ct + 4) * 4 + qq]; }
+    else { const int w = tid >> 4, qq = (tid >> 2) & 2; u = part[w * 4 + qq]; v = part[w * 4 + qq + 1]; }
+    constexpr double inv_n = NCH == 64 ? 1.0 / 1024.0 : 1.0 / 512.0;
+    const double mean = ((double)u.x + (double)v.x) * inv_n;
+    double var = ((double)u.y + (double)v.y) * inv_n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = 1.0f / sqrtf((float)var + 1e-5f);
+    const float sc = gamma[tid] * rstd;
+    coef[tid] = sc; coef[128 + tid] = beta[tid] - (float)mean * sc;
+  }
+  lds_barrier();
 }
-template <int CP> __device__ __forceinline__ int swz(int pix) { return (pix / (16 / CP)) & (CP - 1); }
 
-// The weight stream of one layer: five convs back to back, tiles of [COUT][64 k], 3 stages, two 1 KiB pieces per wave and
-// tile (COUT = 64 fills only the first; the second then reads the zero page so that every tile counts the same in vmcnt).
-template <int COUT, int NS, int K0, int K1, int K2>     // reduction lengths of the stream's convs: compile-time, or the
-struct WStream {                                          // select below turns into an indexed load from a spilled struct
-  const bf16* const* wt;                                   // weight pointers (LDS table)
-  char* ring; char* scratch; const char* zero; int nconv, conv, kt, issued, consumed;
-  __device__ __forceinline__ void init(char* r, char* scr, int n, const bf16* const* w, const char* z) {
-    ring = r; scratch = scr; zero = z; nconv = n; conv = 0; kt = 0; issued = 0; consumed = 0; wt = w;
-  }
-  __device__ __forceinline__ void issue(int tid, int wave, int lane) {
-    if (conv >= nconv) return;
-    char* stage = ring + (issued % NS) * (COUT * 128);
-    const int Kc = conv == 0 ? K0 : conv == 1 ? K1 : K2;
-    const bf16* wc = wt[conv];                               // LDS read (lgkmcnt): does not touch the VMEM counter
-#pragma unroll
-    for (int r = 0; r < 2; r++) {
-      const int piece = r * NW + wave;                       // 8 weight rows per piece
-      const int row = piece * 8 + (lane >> 3), ch = (lane & 7) ^ ((row >> 1) & 7);
-      const int kcol = kt * 64 + ch * 8;
-      const bool ok = piece * 8 < COUT && kcol < Kc;
-      const char* src = ok ? (const char*)(wc + (long)row * Kc + kcol) : (const char*)g_zero_page_tt + tid * 16;
-      char* dst = piece * 8 < COUT ? stage + piece * 1024 : scratch;      // surplus piece (COUT = 64): a scratch KiB
-      __builtin_amdgcn_global_load_lds((const void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-    }
-    issued++;
-    if (++kt == (Kc + 63) / 64) { kt = 0; conv++; }
-  }
-  __device__ __forceinline__ void prime(int tid, int wave, int lane) {
-    for (int i = 0; i < NS - 1; i++) issue(tid, wave, lane);
-  }
-  __device__ __forceinline__ const char* acquire() {                         // wait for the oldest tile in flight, make it visible to the block
-    const int ahead = issued - consumed - 1;                 // tiles issued after it: 2 pieces each may stay outstanding
-    if (ahead >= 6) wait_vmcnt<12>(); else if (ahead == 5) wait_vmcnt<10>(); else if (ahead == 4) wait_vmcnt<8>();
-    else if (ahead == 3) wait_vmcnt<6>(); else if (ahead == 2) wait_vmcnt<4>(); else if (ahead == 1) wait_vmcnt<2>();
-    else wait_vmcnt<0>();
-    bar();
-    const char* stage = ring + (consumed % NS) * (COUT * 128);
-    consumed++;
-    return stage;
-  }
-};
+__device__ __forceinline__ void stat1(const f32x4& v, float& s1, float& s2) {
+  s1 += (v[0] + v[1]) + (v[2] + v[3]);
+  s2 = __builtin_fmaf(v[3], v[3], __builtin_fmaf(v[2], v[2], __builtin_fmaf(v[1], v[1], __builtin_fmaf(v[0], v[0], s2))));
+}
 
-// One convolution out of LDS into LDS.  in: [HIN*HIN][CIN] swizzled; out: [HOUT*HOUT][COUT] swizzled (raw conv output, bf16);
-// part: per-wave channel sums of the fp32 accumulators [NW][64 channels of the wave][2].
-// Per-lane gather plan of a conv geometry: for every tap the LDS byte offset of this lane's input pixel (-1 when the tap falls
-// into the padding) and the pixel's swizzle.  The K loop of conv_lds is fully unrolled, so the tap of every K-step is a
-// compile-time index into these registers and a fragment read costs three VALU ops -- computed per K-step (div / mod /
-// bounds / swizzle per lane) the address math alone made the conv VALU-bound at ~2k cycles per tile.  The three stride-1
-// 3x3 convs of a stage share one plan.
-template <int TAPS, int MI> struct Plan { int aoff[TAPS][MI], asw[TAPS][MI]; };
-template <int CIN, int COUT, int HIN, int HOUT, int KS, int STRIDE>
-__device__ __forceinline__ void make_plan(Plan<KS * KS, (HOUT * HOUT / 16) * (COUT / 16) / NW / 4>& pl, int tid) {
-  constexpr int PAD = KS / 2, MI = (HOUT * HOUT / 16) * (COUT / 16) / NW / 4, CPI = CIN / 8;
-  const int lane = tid & 63, wave = tid >> 6, r16 = lane & 15;
-  const int mt0 = MI == 2 ? wave * 2 : (wave & 3);
+// y = [relu](raw * scale + shift [+ res]) for NT packed tiles of the lane's four channels c0 .. c0 + 3 -> LDS (8 bytes at
+// wr + tile * tile_stride) and, with SECOND, the residual registers
+template <int NT, bool SECOND>
+__device__ __forceinline__ void apply_tiles(const P4 (&rawp)[NT], P4 (&res)[NT], const float* coef, int c0, char* lds, int wr, int tile_stride) {
+  const f32x2 sc0 = {coef[c0], coef[c0 + 1]}, sc1 = {coef[c0 + 2], coef[c0 + 3]};
+  const f32x2 sh0 = {coef[128 + c0], coef[128 + c0 + 1]}, sh1 = {coef[128 + c0 + 2], coef[128 + c0 + 3]};
 #pragma unroll
-  for (int i = 0; i < MI; i++) {
-    const int p = (mt0 + i) * 16 + r16, oy = p / HOUT, ox = p % HOUT;
-#pragma unroll
-    for (int tp = 0; tp < KS * KS; tp++) {
-      const int iy = oy * STRIDE + tp / KS - PAD, ix = ox * STRIDE + tp % KS - PAD;
-      const bool ok = (unsigned)iy < (unsigned)HIN && (unsigned)ix < (unsigned)HIN;
-      const int pix = iy * HIN + ix;
-      pl.aoff[tp][i] = ok ? pix * (CIN * 2) : -1;
-      pl.asw[tp][i] = swz<CPI>(pix);
-    }
+  for (int i = 0; i < NT; i++) {
+    f32x2 v0 = unlo(rawp[i]) * sc0 + sh0, v1 = unhi(rawp[i]) * sc1 + sh1;
+    if (SECOND) { v0 += unlo(res[i]); v1 += unhi(res[i]); }
+    const P4 o = {relu_pk(pack2(v0)), relu_pk(pack2(v1))};
+    if (SECOND) res[i] = o;
+    *reinterpret_cast<uint2*>(lds + wr + i * tile_stride) = make_uint2(o.lo, o.hi);
   }
 }
 
-template <int CIN, int COUT, int HIN, int HOUT, int KS, int STRIDE, class WS>
-__device__ __forceinline__ void conv_lds(const char* in, char* out, WS& ws, float* part, int tid,
-                                         const Plan<KS * KS, (HOUT * HOUT / 16) * (COUT / 16) / NW / 4>& pl) {
-  constexpr int M = HOUT * HOUT, MT = M / 16, K = KS * KS * CIN, NKT = (K + 63) / 64, TAPS = KS * KS;
-  constexpr int CPO = COUT / 8;
-  constexpr int MI = MT * (COUT / 16) / NW / 4;             // m-tiles per wave; 4 n-tiles per wave
-  static_assert(MI == 1 || MI == 2, "wave tiling");
-  const int lane = tid & 63, wave = tid >> 6, r16 = lane & 15, q4 = lane >> 4;
-  // layer 3 (M = 256, N = 64): wave -> m-tiles 2w, 2w+1, n-tiles 0..3;  layer 4 (M = 64, N = 128): m-tile w & 3, n-tiles 4(w>>2)..
-  const int mt0 = MI == 2 ? wave * 2 : (wave & 3), nt0 = MI == 2 ? 0 : (wave >> 2) * 4;
-  f32x4 acc[MI][4];
+// ---- layer 3: 3x3 stride-1 conv 64 -> 64 over the 16x16 frame.  W[(tap) * 2 + half]: the lane's fragment of its cout tile.
+__device__ __forceinline__ void load_w64(bf16x8 (&W)[18], const bf16* __restrict__ wt, int ct, int r16, int q) {
 #pragma unroll
-  for (int i = 0; i < MI; i++)
+  for (int i = 0; i < 18; i++) W[i] = *reinterpret_cast<const bf16x8*>(wt + ((long)(ct * 18 + i) * 64 + q * 16 + r16) * 8);
+}
+template <bool SECOND>
+__device__ __forceinline__ void conv64_gn(bf16x8 (&W)[18], const bf16* __restrict__ next_wt, int gb, char* lds, P4 (&rawp)[8], P4 (&res)[8],
+                                          int tid, int wave, int r16, int q) {
+  const int ct = wave & 3, half = wave >> 2;
+  int rd[3][2];
 #pragma unroll
-    for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  // (gather plan `pl`: see make_plan)
-  const char* zero16 = ws.zero;                // a zeroed 16-byte chunk in LDS (padding taps, K tails)
+  for (int kx = 0; kx < 3; kx++)
 #pragma unroll
-  for (int kt = 0; kt < NKT; kt++) {
-    const char* stage = ws.acquire();
-    ws.issue(tid, wave, lane);
+    for (int hf = 0; hf < 2; hf++) rd[kx][hf] = a64(half * 8, r16 + kx, 4 * hf + q);
+  f32x4 acc[8];
 #pragma unroll
-    for (int kh = 0; kh < 2; kh++) {
-      const int kbase = kt * 64 + kh * 32;                   // compile-time: tap and first channel of this K-step
-      const int tp = kbase / CIN < TAPS ? kbase / CIN : TAPS - 1;
-      const bool live = kbase < K;                           // K tail (layer-3 conv1: 4.5 tiles; 1x1 convs: half a tile)
-      const int cbase = (kbase % CIN) / 8;                   // chunk of channel 0 of the step; this lane adds q4
-      bf16x8 af[MI];
+  for (int rr = 0; rr < 8; rr++) acc[rr] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < MI; i++) {
-        const int o = pl.aoff[tp][i];
-        const char* ap = (live && o >= 0) ? in + o + (((cbase + q4) ^ pl.asw[tp][i]) << 4) : zero16;
-        af[i] = *reinterpret_cast<const bf16x8*>(ap);
-      }
+  for (int f = 0; f < 10; f++) {
+    bf16x8 F[3][2];
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int wrow = (nt0 + j) * 16 + r16;
-        bf16x8 wf = *reinterpret_cast<const bf16x8*>(stage + wrow * 128 + (((kh * 4 + q4) ^ ((wrow >> 1) & 7)) << 4));
+    for (int kx = 0; kx < 3; kx++)
 #pragma unroll
-        for (int i = 0; i < MI; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[i], acc[i][j], 0, 0, 0);
+      for (int hf = 0; hf < 2; hf++) F[kx][hf] = *reinterpret_cast<const bf16x8*>(lds + rd[kx][hf] + f * (R64 * 128));
+#pragma unroll
+    for (int ky = 0; ky < 3; ky++) {
+      const int rr = f - ky;
+      if (rr >= 0 && rr < 8) {
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++)
+#pragma unroll
+          for (int hf = 0; hf < 2; hf++)
+            acc[rr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[(ky * 3 + kx) * 2 + hf], F[kx][hf], acc[rr], 0, 0, 0);
       }
     }
   }
-  // lane (r16, q4) holds pixel (mt0+i)*16 + r16, channels (nt0+j)*16 + 4*q4 + r.  Channel sums over the wave's pixels
-  // (reduce-scatter over the 16 pixel lanes), then the raw output as bf16.
-  const bool hi = r16 & 8, hi2 = r16 & 4;
+  if (next_wt) load_w64(W, next_wt, ct, r16, q);
+  float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    float v1[4], v2[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      float a = 0.f, b = 0.f;
-#pragma unroll
-      for (int i = 0; i < MI; i++) { const float v = acc[i][j][r]; a += v; b += v * v; }
-      v1[r] = a; v2[r] = b;
-    }
-    float a0 = hi ? v1[2] : v1[0], a1 = hi ? v1[3] : v1[1], b0 = hi ? v1[0] : v1[2], b1 = hi ? v1[1] : v1[3];
-    float c0 = hi ? v2[2] : v2[0], c1 = hi ? v2[3] : v2[1], d0 = hi ? v2[0] : v2[2], d1 = hi ? v2[1] : v2[3];
-    a0 += __shfl_xor(b0, 8, 64); a1 += __shfl_xor(b1, 8, 64); c0 += __shfl_xor(d0, 8, 64); c1 += __shfl_xor(d1, 8, 64);
-    float s1 = hi2 ? a1 : a0, t1 = hi2 ? a0 : a1, s2 = hi2 ? c1 : c0, t2 = hi2 ? c0 : c1;
-    s1 += __shfl_xor(t1, 4, 64); s2 += __shfl_xor(t2, 4, 64);
-    s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
-    s1 += __shfl_xor(s1, 1, 64); s2 += __shfl_xor(s2, 1, 64);
-    const int ch = (nt0 + j) * 16 + q4 * 4 + (hi ? 2 : 0) + (hi2 ? 1 : 0);
-    if ((r16 & 3) == 0) { part[(wave * 64 + ch - nt0 * 16) * 2] = s1; part[(wave * 64 + ch - nt0 * 16) * 2 + 1] = s2; }
-#pragma unroll
-    for (int i = 0; i < MI; i++) {
-      const int pix = (mt0 + i) * 16 + r16, chn = (nt0 + j) * 16 + q4 * 4;
-      bf16x4 o;
-#pragma unroll
-      for (int r = 0; r < 4; r++) o[r] = (bf16)acc[i][j][r];
-      *reinterpret_cast<bf16x4*>(out + pix * (COUT * 2) + (((chn >> 3) ^ swz<CPO>(pix)) << 4) + (chn & 7) * 2) = o;
-    }
-  }
+  for (int rr = 0; rr < 8; rr++) { stat1(acc[rr], s1, s2); rawp[rr] = pack4(acc[rr][0], acc[rr][1], acc[rr][2], acc[rr][3]); }
+  finish_stats_t<64>(s1, s2, lds, gb, tid, wave, r16, q);
+  apply_tiles<8, SECOND>(rawp, res, reinterpret_cast<const float*>(lds + TCOEF_OFF), ct * 16 + q * 4, lds,
+                         a64(half * 8 + 1, r16 + 1, ct * 2 + (q >> 1)) + (q & 1) * 8, R64 * 128);
+  lds_barrier();
 }
 
-// GroupNorm(16) scale / shift of one raw tensor from the per-wave partial sums (deterministic order).
-template <int COUT, int M, int MI>
-__device__ __forceinline__ void gn_coeffs(const float* part, const float* gamma, const float* beta, float* sc, float* sh, int tid) {
-  constexpr int CPG = COUT / 16;
-  if (tid < 16) {
-    float sum = 0.f, sq = 0.f;
-    for (int c = tid * CPG; c < (tid + 1) * CPG; c++)
-      for (int w = 0; w < NW; w++) {
-        // layer 3: every wave covers all channels; layer 4: waves 0-3 cover channels 0-63, waves 4-7 channels 64-127
-        if (MI == 1 && (w >> 2) != (c >> 6)) continue;
-        sum += part[(w * 64 + (c & 63)) * 2]; sq += part[(w * 64 + (c & 63)) * 2 + 1];
+// ---- layer 4: 3x3 stride-1 conv 128 -> 128 over the 8x8 frame.  Column tile pt = output rows 2 pt, 2 pt + 1 (lane: row
+// r16 >> 3, pixel r16 & 7).  The fragment of frame rows (f, f + 1) serves every (pt, ky) with 2 pt + ky = f.
+__device__ __forceinline__ void load_w128(bf16x8 (&W)[36], const bf16* __restrict__ wt, int ct, int r16, int q) {
+#pragma unroll
+  for (int i = 0; i < 36; i++) W[i] = *reinterpret_cast<const bf16x8*>(wt + ((long)(ct * 36 + i) * 64 + q * 16 + r16) * 8);
+}
+template <bool SECOND>
+__device__ __forceinline__ void conv128_gn(bf16x8 (&W)[36], const bf16* __restrict__ next_wt, int gb, char* lds, P4 (&rawp)[4], P4 (&res)[4],
+                                           int tid, int wave, int r16, int q) {
+  const int ct = wave, ly = r16 >> 3, lx = r16 & 7;
+  int rd[3][2];                                   // chunk 4 j + q: j even / odd (j >> 1 adds 8 chunks = 128 B)
+#pragma unroll
+  for (int kx = 0; kx < 3; kx++)
+#pragma unroll
+    for (int jo = 0; jo < 2; jo++) rd[kx][jo] = a128(ly, lx + kx, 4 * jo + q);
+  f32x4 acc[4];
+#pragma unroll
+  for (int pt = 0; pt < 4; pt++) acc[pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int f = 0; f < 9; f++) {
+#pragma unroll
+    for (int kx = 0; kx < 3; kx++) {
+      bf16x8 F[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) F[j] = *reinterpret_cast<const bf16x8*>(lds + rd[kx][j & 1] + (j >> 1) * 128 + f * (R128 * 256));
+#pragma unroll
+      for (int ky = 0; ky < 3; ky++) {
+        const int pt2 = f - ky;                   // = 2 pt
+        if (pt2 >= 0 && pt2 < 8 && (pt2 & 1) == 0) {
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            acc[pt2 >> 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[(ky * 3 + kx) * 4 + j], F[j], acc[pt2 >> 1], 0, 0, 0);
+        }
       }
-    const float inv_n = 1.f / (float)(M * CPG), mean = sum * inv_n;
-    const float var = fmaxf(sq * inv_n - mean * mean, 0.f);
-    const float rstd = rsqrtf(var + 1e-5f);
-    for (int c = tid * CPG; c < (tid + 1) * CPG; c++) {
-      const float s = gamma[c] * rstd;
-      sc[c] = s; sh[c] = beta[c] - mean * s;
     }
   }
+  if (next_wt) load_w128(W, next_wt, ct, r16, q);
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int pt = 0; pt < 4; pt++) { stat1(acc[pt], s1, s2); rawp[pt] = pack4(acc[pt][0], acc[pt][1], acc[pt][2], acc[pt][3]); }
+  finish_stats_t<128>(s1, s2, lds, gb, tid, wave, r16, q);
+  apply_tiles<4, SECOND>(rawp, res, reinterpret_cast<const float*>(lds + TCOEF_OFF), ct * 16 + q * 4, lds,
+                         a128(ly + 1, lx + 1, ct * 2 + (q >> 1)) + (q & 1) * 8, 2 * R128 * 256);
+  lds_barrier();
 }
 
-// y = [relu]( x * sc + sh  [+ r * rsc + rsh | + r] ) in place on x, all tensors [M][C] with the same swizzle.
-template <int C, int M>
-__device__ __forceinline__ void gn_apply_lds(char* x, const float* sc, const float* sh, const char* res, const float* rsc, const float* rsh,
-                             int relu, int tid) {
-  constexpr int CP = C / 8;
-  for (int i = tid; i < M * CP; i += NTH) {
-    const int pix = i / CP, pc = i % CP, c0 = (pc ^ swz<CP>(pix)) * 8;
-    bf16x8 v = *reinterpret_cast<const bf16x8*>(x + i * 16);
-    float f[8];
-#pragma unroll
-    for (int e = 0; e < 8; e++) f[e] = (float)v[e] * sc[c0 + e] + sh[c0 + e];
-    if (res) {
-      bf16x8 r = *reinterpret_cast<const bf16x8*>(res + i * 16);
-#pragma unroll
-      for (int e = 0; e < 8; e++) f[e] += rsc ? (float)r[e] * rsc[c0 + e] + rsh[c0 + e] : (float)r[e];
-    }
-#pragma unroll
-    for (int e = 0; e < 8; e++) v[e] = (bf16)(relu ? fmaxf(f[e], 0.f) : f[e]);
-    *reinterpret_cast<bf16x8*>(x + i * 16) = v;
-  }
-}
-
-// One ResNet stage (two basic blocks, the first with stride 2 and a 1x1 downsample): input in `xin` ([HIN*HIN][CIN]),
-// result in `bufB`.  Buffers A, B, C are [HOUT*HOUT][COUT]; xin may overlap C/D (it is dead after the first two convs).
-template <int CIN, int COUT, int HIN, int HOUT, class WS1, class WS2>
-__device__ __forceinline__ void stage(const char* xin, char* A, char* B, char* C, WS1& ws1, WS2& ws2, const TailTower& t, int base, float* part,
-                      float* sc, float* sh, float* sc2, float* sh2, int tid) {
-  constexpr int M = HOUT * HOUT, MI = (M / 16) * (COUT / 16) / NW / 4;
-  const int wave = tid >> 6, lane = tid & 63;
-  ws1.prime(tid, wave, lane);
-  TT_STAMP();
-  // block 0
-  {
-    Plan<9, MI> p1; make_plan<CIN, COUT, HIN, HOUT, 3, 2>(p1, tid);
-    conv_lds<CIN, COUT, HIN, HOUT, 3, 2>(xin, A, ws1, part, tid, p1);             // conv1 (stride 2)
-  }
-  bar();
-  TT_STAMP();
-  gn_coeffs<COUT, M, MI>(part, t.g[base + 0], t.b[base + 0], sc, sh, tid);
-  bar();
-  {
-    Plan<1, MI> pd; make_plan<CIN, COUT, HIN, HOUT, 1, 2>(pd, tid);
-    conv_lds<CIN, COUT, HIN, HOUT, 1, 2>(xin, B, ws1, part, tid, pd);             // downsample (1x1, stride 2): xin dead after this
-  }
-  bar();
-  TT_STAMP();
-  ws2.prime(tid, wave, lane);                                                     // (its ring may overlap xin)
-  gn_coeffs<COUT, M, MI>(part, t.g[base + 2], t.b[base + 2], sc2, sh2, tid);
-  gn_apply_lds<COUT, M>(A, sc, sh, nullptr, nullptr, nullptr, 1, tid);            // a1 = relu(gn1(raw1))
-  bar();
-  TT_STAMP();
-  Plan<9, MI> p3; make_plan<COUT, COUT, HOUT, HOUT, 3, 1>(p3, tid);                // shared by the three stride-1 convs
-  conv_lds<COUT, COUT, HOUT, HOUT, 3, 1>(A, C, ws2, part, tid, p3);               // conv2
-  bar();
-  TT_STAMP();
-  gn_coeffs<COUT, M, MI>(part, t.g[base + 1], t.b[base + 1], sc, sh, tid);
-  bar();
-  gn_apply_lds<COUT, M>(C, sc, sh, B, sc2, sh2, 1, tid);                          // out0 = relu(gn2(raw2) + gn_d(rawd))  -> C
-  bar();
-  TT_STAMP();
-  // block 1
-  conv_lds<COUT, COUT, HOUT, HOUT, 3, 1>(C, A, ws2, part, tid, p3);
-  bar();
-  gn_coeffs<COUT, M, MI>(part, t.g[base + 3], t.b[base + 3], sc, sh, tid);
-  bar();
-  gn_apply_lds<COUT, M>(A, sc, sh, nullptr, nullptr, nullptr, 1, tid);
-  bar();
-  conv_lds<COUT, COUT, HOUT, HOUT, 3, 1>(A, B, ws2, part, tid, p3);
-  bar();
-  gn_coeffs<COUT, M, MI>(part, t.g[base + 4], t.b[base + 4], sc, sh, tid);
-  bar();
-  gn_apply_lds<COUT, M>(B, sc, sh, C, nullptr, nullptr, 1, tid);                  // out1 = relu(gn2(raw) + out0)  -> B
-  bar();
-  TT_STAMP();
-}
-
-__global__ __launch_bounds__(NTH) void tower_tail_kernel(TailArgs args, int Bn) {
+__global__ __launch_bounds__(TTH) void tower_tail_kernel(TailArgs args, int Bn) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, q = lane >> 4;
   const TailTower& t = args.t[blockIdx.y];
   const int img = blockIdx.x;
-  char* A = lds; char* B = lds + ACT; char* C = lds + 2 * ACT; char* D = lds + 3 * ACT;
-  float* part = reinterpret_cast<float*>(lds + STATS);
-  float* sc = reinterpret_cast<float*>(lds + COEF); float* sh = sc + 128; float* sc2 = sh + 128; float* sh2 = sc2 + 128;
-  const bf16** wtab = reinterpret_cast<const bf16**>(lds + WTAB);
-  if (tid >= 64 && tid < 68) reinterpret_cast<unsigned*>(lds + WTAB + 96)[tid - 64] = 0u;      // the zero chunk
-  if (tid < 10) {                              // stream order: conv1, down, conv2, conv1', conv2' per layer
-    const int r = tid % 5, o = (tid / 5) * 5 + (r == 1 ? 2 : r == 2 ? 1 : r);      // 0,2,1,3,4 | 5,7,6,8,9
-    const bf16* wp = t.w[0];
+  const float* coef = reinterpret_cast<const float*>(lds + TCOEF_OFF);
+  bf16x8 zero8;
 #pragma unroll
-    for (int i = 1; i < 10; i++) wp = o == i ? t.w[i] : wp;
-    wtab[tid] = wp;
+  for (int e = 0; e < 8; e++) zero8[e] = (bf16)0.f;
+  TAIL_STAMP(0);
+
+  // =========================================================== layer 3 ===========================================================
+  const int ct3 = wave & 3, half = wave >> 2;
+  // weights of the downsample (K = 32: one k-step) and of the stride-2 conv (K = 288: one tap per k-step): first, under the image load
+  bf16x8 wD3 = *reinterpret_cast<const bf16x8*>(t.w[0] + ((long)ct3 * 64 + lane) * 8);
+  bf16x8 wA3[9];
+#pragma unroll
+  for (int tap = 0; tap < 9; tap++) wA3[tap] = *reinterpret_cast<const bf16x8*>(t.w[1] + ((long)(ct3 * 9 + tap) * 64 + lane) * 8);
+  // GroupNorm affine parameters -> LDS; the layer-2 output (32 x 32 x 32, NHWC) -> the zero-framed 34 x 34 image
+  for (int i = tid; i < 5 * 128 + 5 * 256; i += TTH) {
+    const bool l3 = i < 640;
+    const int n = l3 ? i >> 7 : 5 + ((i - 640) >> 8), j = l3 ? i & 127 : (i - 640) & 255, nch = l3 ? 64 : 128;
+    reinterpret_cast<float*>(lds + TGB_OFF)[i] = j < nch ? t.g[n][j] : t.b[n][j - nch];
   }
-  // ---- layer-2 output [32*32][32] (64 KiB) -> C..D, swizzled (CP = 4), by LDS-DMA: 64 pieces of 16 pixels
   {
-    const char* x = (const char*)(t.x + (long)img * 32 * 32 * 32);
-    for (int pc = wave; pc < 64; pc += NW) {
-      const int pix = pc * 16 + (lane >> 2), chunk = (lane & 3) ^ swz<4>(pix);
-      __builtin_amdgcn_global_load_lds((const void*)(x + pix * 64 + chunk * 16),
-          (__attribute__((address_space(3))) void*)(C + pc * 1024), 16, 0, 0);
+    const uint4* __restrict__ x = reinterpret_cast<const uint4*>(t.x + (long)img * 1024 * 32);
+#pragma unroll 4
+    for (int i = tid; i < 4096; i += TTH) {
+      const int px = i >> 2, y = px >> 5, xx = px & 31;
+      *reinterpret_cast<uint4*>(lds + a32(y + 1, xx + 1, i & 3)) = x[i];
     }
-    wait_vmcnt<0>();
-  }
-  bar();
-  TT_STAMP();
-  {
-    // layer 3: the first two convs read the staged input (C..D) and stream through the 3-stage ring behind the buffers; once
-    // the input is dead, buffer D joins the ring: 7 stages of 8 KiB -- 6 tiles (48 KiB) in flight, which is what it takes to
-    // keep one CU's L2 -> LDS path busy (2 small tiles in flight ran this kernel 2.5x slower: latency-bound)
-    WStream<64, 3, 288, 32, 32> w1; w1.init(lds + RING3, lds + SCRATCH3, 2, wtab, lds + WTAB + 96);
-    WStream<64, 7, 576, 576, 576> w2; w2.init(D, lds + SCRATCH3, 3, wtab + 2, lds + WTAB + 96);
-    stage<32, 64, 32, 16>(C, A, B, C, w1, w2, t, 0, part, sc, sh, sc2, sh2, tid);
-  }
-  {
-    // layer 4 (16 KiB tensors: A, A + 16 KiB, lower half of C; input in B): ring of 4 x 16 KiB from the upper half of C on
-    WStream<128, 4, 576, 64, 64> w1; w1.init(C + 16384, lds + SCRATCH3, 2, wtab + 5, lds + WTAB + 96);
-    WStream<128, 4, 1152, 1152, 1152> w2; w2.init(C + 16384, lds + SCRATCH3, 3, wtab + 7, lds + WTAB + 96);
-    stage<64, 128, 16, 8>(B, A, A + 16384, C, w1, w2, t, 5, part, sc, sh, sc2, sh2, tid);
-  }
-  // ---- layer-4 output (in A + 16 KiB): [64 pixels][128] -> global NHWC, un-swizzled
-  {
-    const char* o = A + 16384;
-    bf16* y = t.y + (long)img * 64 * 128;
-    for (int i = tid; i < 64 * 16; i += NTH) {
-      const int pix = i >> 4, pc = i & 15, c0 = (pc ^ swz<16>(pix)) * 8;
-      *reinterpret_cast<uint4*>(y + pix * 128 + c0) = *reinterpret_cast<const uint4*>(o + i * 16);
+    for (int i = tid; i < 2 * 136 + 32 * 8; i += TTH) {
+      int off;
+      if (i < 272) off = ((i / 136) * 33 * R32) * 64 + (i % 136) * 16;
+      else { const int j = i - 272, row = 1 + (j >> 3); off = (row * R32 + ((j >> 2) & 1) * 33) * 64 + (j & 3) * 16; }
+      *reinterpret_cast<bf16x8*>(lds + off) = zero8;
     }
   }
-  (void)Bn; (void)D;
+  lds_barrier();
+  TAIL_STAMP(1);
+
+  P4 rawp3[8], res3[8];
+  // ---- downsample 1x1 stride 2 + GroupNorm (no ReLU) -> residual registers.  Output (oy, ox) reads frame (2 oy + 1, 2 ox + 1).
+  {
+    const int rdD = a32(2 * (half * 8) + 1, 2 * r16 + 1, q);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 8; rr++) {
+      const bf16x8 xf = *reinterpret_cast<const bf16x8*>(lds + rdD + rr * (2 * R32 * 64));
+      const f32x4 v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wD3, xf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      stat1(v, s1, s2);
+      res3[rr] = pack4(v[0], v[1], v[2], v[3]);
+    }
+    finish_stats_t<64>(s1, s2, lds, 0, tid, wave, r16, q);
+    const int c0 = ct3 * 16 + q * 4;
+    const f32x2 sc0 = {coef[c0], coef[c0 + 1]}, sc1 = {coef[c0 + 2], coef[c0 + 3]};
+    const f32x2 sh0 = {coef[128 + c0], coef[128 + c0 + 1]}, sh1 = {coef[128 + c0 + 2], coef[128 + c0 + 3]};
+#pragma unroll
+    for (int rr = 0; rr < 8; rr++) res3[rr] = P4{pack2(unlo(res3[rr]) * sc0 + sh0), pack2(unhi(res3[rr]) * sc1 + sh1)};
+  }
+  TAIL_STAMP(2);
+  bf16x8 W64[18];
+  // ---- block 0 conv1: 3x3 stride 2, 32 -> 64: frame (2 oy + ky, 2 ox + kx), chunk q; GroupNorm + ReLU -> the 64-channel frame
+  {
+    int rdA[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; kx++) rdA[kx] = a32(2 * (half * 8), 2 * r16 + kx, q);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 8; rr++) {
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) {
+          const bf16x8 xf = *reinterpret_cast<const bf16x8*>(lds + rdA[kx] + (2 * rr + ky) * (R32 * 64));
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wA3[ky * 3 + kx], xf, acc, 0, 0, 0);
+        }
+      stat1(acc, s1, s2);
+      rawp3[rr] = pack4(acc[0], acc[1], acc[2], acc[3]);
+    }
+    load_w64(W64, t.w[2], ct3, r16, q);
+    finish_stats_t<64>(s1, s2, lds, 128, tid, wave, r16, q);
+    apply_tiles<8, false>(rawp3, res3, coef, ct3 * 16 + q * 4, lds, a64(half * 8 + 1, r16 + 1, ct3 * 2 + (q >> 1)) + (q & 1) * 8, R64 * 128);
+    // zero frame of the 64-channel image: rows 0 and 17 (18 px x 8 chunks each), columns 0 and 17 of rows 1..16
+    for (int i = tid; i < 2 * 144 + 16 * 16; i += TTH) {
+      int off;
+      if (i < 288) off = ((i / 144) * 17 * R64) * 128 + (i % 144) * 16;
+      else { const int j = i - 288, row = 1 + (j >> 4); off = (row * R64 + ((j >> 3) & 1) * 17) * 128 + (j & 7) * 16; }
+      *reinterpret_cast<bf16x8*>(lds + off) = zero8;
+    }
+  }
+  lds_barrier();
+  TAIL_STAMP(3);
+  conv64_gn<true>(W64, t.w[3], 256, lds, rawp3, res3, tid, wave, r16, q);           // block 0 conv2 + skip
+  TAIL_STAMP(4);
+  conv64_gn<false>(W64, t.w[4], 384, lds, rawp3, res3, tid, wave, r16, q);          // block 1 conv1
+  TAIL_STAMP(5);
+  conv64_gn<true>(W64, nullptr, 512, lds, rawp3, res3, tid, wave, r16, q);          // block 1 conv2 + identity
+  TAIL_STAMP(6);
+
+  // =========================================================== layer 4 ===========================================================
+  const int ct4 = wave, ly = r16 >> 3, lx = r16 & 7;
+  P4 rawp4[4], res4[4];
+  bf16x8 W128[36];
+  // ---- downsample 1x1 stride 2, 64 -> 128 (K = 64: two k-steps) + GroupNorm -> residual registers
+  {
+    bf16x8 wD[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; hf++) wD[hf] = *reinterpret_cast<const bf16x8*>(t.w[5] + ((long)(ct4 * 2 + hf) * 64 + lane) * 8);
+    int rdD[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; hf++) rdD[hf] = a64(2 * ly + 1, 2 * lx + 1, 4 * hf + q);
+    // the stride-2 conv's weights (K = 576: 18 k-steps) into the first half of W128, under the downsample
+#pragma unroll
+    for (int i = 0; i < 18; i++) W128[i] = *reinterpret_cast<const bf16x8*>(t.w[6] + ((long)(ct4 * 18 + i) * 64 + lane) * 8);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int pt = 0; pt < 4; pt++) {
+      f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int hf = 0; hf < 2; hf++)
+        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wD[hf], *reinterpret_cast<const bf16x8*>(lds + rdD[hf] + pt * (4 * R64 * 128)), v, 0, 0, 0);
+      stat1(v, s1, s2);
+      res4[pt] = pack4(v[0], v[1], v[2], v[3]);
+    }
+    finish_stats_t<128>(s1, s2, lds, 640, tid, wave, r16, q);
+    const int c0 = ct4 * 16 + q * 4;
+    const f32x2 sc0 = {coef[c0], coef[c0 + 1]}, sc1 = {coef[c0 + 2], coef[c0 + 3]};
+    const f32x2 sh0 = {coef[128 + c0], coef[128 + c0 + 1]}, sh1 = {coef[128 + c0 + 2], coef[128 + c0 + 3]};
+#pragma unroll
+    for (int pt = 0; pt < 4; pt++) res4[pt] = P4{pack2(unlo(res4[pt]) * sc0 + sh0), pack2(unhi(res4[pt]) * sc1 + sh1)};
+  }
+  TAIL_STAMP(7);
+  // ---- block 0 conv1: 3x3 stride 2, 64 -> 128: frame (2 oy + ky, 2 ox + kx), chunks 4 hf + q
+  {
+    int rdA[3][2];
+#pragma unroll
+    for (int kx = 0; kx < 3; kx++)
+#pragma unroll
+      for (int hf = 0; hf < 2; hf++) rdA[kx][hf] = a64(2 * ly, 2 * lx + kx, 4 * hf + q);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int pt = 0; pt < 4; pt++) {
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++)
+#pragma unroll
+          for (int hf = 0; hf < 2; hf++) {
+            const bf16x8 xf = *reinterpret_cast<const bf16x8*>(lds + rdA[kx][hf] + (4 * pt + ky) * (R64 * 128));
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W128[(ky * 3 + kx) * 2 + hf], xf, acc, 0, 0, 0);
+          }
+      stat1(acc, s1, s2);
+      rawp4[pt] = pack4(acc[0], acc[1], acc[2], acc[3]);
+    }
+    load_w128(W128, t.w[7], ct4, r16, q);
+    finish_stats_t<128>(s1, s2, lds, 640 + 256, tid, wave, r16, q);
+    apply_tiles<4, false>(rawp4, res4, coef, ct4 * 16 + q * 4, lds, a128(ly + 1, lx + 1, ct4 * 2 + (q >> 1)) + (q & 1) * 8, 2 * R128 * 256);
+    // zero frame of the 128-channel image: rows 0 and 9 (10 px x 16 chunks each), columns 0 and 9 of rows 1..8
+    for (int i = tid; i < 2 * 160 + 8 * 32; i += TTH) {
+      int off;
+      if (i < 320) off = ((i / 160) * 9 * R128) * 256 + (i % 160) * 16;
+      else { const int j = i - 320, row = 1 + (j >> 5); off = (row * R128 + ((j >> 4) & 1) * 9) * 256 + (j & 15) * 16; }
+      *reinterpret_cast<bf16x8*>(lds + off) = zero8;
+    }
+  }
+  lds_barrier();
+  TAIL_STAMP(8);
+  conv128_gn<true>(W128, t.w[8], 640 + 512, lds, rawp4, res4, tid, wave, r16, q);    // block 0 conv2 + skip
+  TAIL_STAMP(9);
+  conv128_gn<false>(W128, t.w[9], 640 + 768, lds, rawp4, res4, tid, wave, r16, q);   // block 1 conv1
+  TAIL_STAMP(10);
+  conv128_gn<true>(W128, nullptr, 640 + 1024, lds, rawp4, res4, tid, wave, r16, q);  // block 1 conv2 + identity
+  TAIL_STAMP(11);
+  // ---- layer-4 output, NHWC bf16 (8 x 8 x 128): the frame's interior
+  {
+    uint4* __restrict__ yo = reinterpret_cast<uint4*>(t.y + (long)img * 64 * 128);
+    for (int i = tid; i < 1024; i += TTH) {
+      const int px = i >> 4, y = px >> 3, x = px & 7;
+      yo[i] = *reinterpret_cast<const uint4*>(lds + a128(y + 1, x + 1, i & 15));
+    }
+  }
+  TAIL_STAMP(12);
+  (void)Bn;
 }
 
 }  // namespace
 
-// Layers 3 + 4 of `groups` (<= 6) towers: X[g] = layer-2 output NHWC bf16 (B, 32, 32, 32); Y[g] = layer-4 output NHWC bf16
-// (B, 8, 8, 128).  Conv weights bf16 [Cout][kh][kw][Cin] (K contiguous) in block order {conv1, conv2, down} x2 per layer
-// as in avlen_resblock; every tower must have the 32->64->128 channel plan.
+// Layers 3 + 4 of `groups` (<= 8) towers: X[g] = layer-2 output NHWC bf16 (B, 32, 32, 32); Y[g] = layer-4 output NHWC bf16
+// (B, 8, 8, 128).  Conv weights: the fragment-order copies avlen_conv::w16f; every tower must have the 32 -> 64 -> 128
+// channel plan.
 int avlen_tower_tail_bf16(const avlen_resnet18* const* nets, const void* const* X, void* const* Y, int groups, int B,
                           hipStream_t stream) {
-  if (groups < 1 || groups > 6 || B <= 0) return AVLEN_ERR_ARG;
+  if (groups < 1 || groups > 8 || B <= 0) return AVLEN_ERR_ARG;
   TailArgs a = {};
   for (int g = 0; g < groups; g++) {
     const avlen_resnet18* n = nets[g];
@@ -366,23 +390,26 @@ int avlen_tower_tail_bf16(const avlen_resnet18* const* nets, const void* const* 
     for (int l = 0; l < 2; l++) {                          // l = 0: layer 3 (blocks 4, 5); l = 1: layer 4 (blocks 6, 7)
       const avlen_resblock& b0 = n->block[4 + 2 * l]; const avlen_resblock& b1 = n->block[5 + 2 * l];
       const int cin = l == 0 ? 32 : 64, co = l == 0 ? 64 : 128;
-      if (!b0.has_down || b1.has_down || b0.conv1.cin16 != cin || b0.conv1.cout != co || b0.conv1.stride != 2 ||
-          b0.conv2.cin16 != co || b0.down.cin16 != cin || b0.down.kh != 1 || b1.conv1.cin16 != co || b1.conv2.cout != co ||
-          !b0.conv1.w16 || !b0.conv2.w16 || !b0.down.w16 || !b1.conv1.w16 || !b1.conv2.w16)
+      auto conv3 = [](const avlen_conv& c, int ci, int cout, int stride) {
+        return c.w16 && c.w16f && c.cin16 == ci && c.cout == cout && c.kh == 3 && c.kw == 3 && c.stride == stride && c.pad == 1;
+      };
+      const avlen_conv& d = b0.down;
+      if (!b0.has_down || b1.has_down || !conv3(b0.conv1, cin, co, 2) || !conv3(b0.conv2, co, co, 1) || !conv3(b1.conv1, co, co, 1) ||
+          !conv3(b1.conv2, co, co, 1) || !d.w16 || !d.w16f || d.cin16 != cin || d.cout != co || d.kh != 1 || d.kw != 1 || d.stride != 2 || d.pad != 0)
         return AVLEN_ERR_ARG;
       const int o = 5 * l;
-      t.w[o + 0] = (const bf16*)b0.conv1.w16; t.w[o + 1] = (const bf16*)b0.conv2.w16; t.w[o + 2] = (const bf16*)b0.down.w16;
-      t.w[o + 3] = (const bf16*)b1.conv1.w16; t.w[o + 4] = (const bf16*)b1.conv2.w16;
-      t.g[o + 0] = b0.bn1.g; t.b[o + 0] = b0.bn1.b; t.g[o + 1] = b0.bn2.g; t.b[o + 1] = b0.bn2.b;
-      t.g[o + 2] = b0.bnd.g; t.b[o + 2] = b0.bnd.b;
-      t.g[o + 3] = b1.bn1.g; t.b[o + 3] = b1.bn1.b; t.g[o + 4] = b1.bn2.g; t.b[o + 4] = b1.bn2.b;
+      t.w[o + 0] = (const bf16*)d.w16f; t.g[o + 0] = b0.bnd.g; t.b[o + 0] = b0.bnd.b;
+      t.w[o + 1] = (const bf16*)b0.conv1.w16f; t.g[o + 1] = b0.bn1.g; t.b[o + 1] = b0.bn1.b;
+      t.w[o + 2] = (const bf16*)b0.conv2.w16f; t.g[o + 2] = b0.bn2.g; t.b[o + 2] = b0.bn2.b;
+      t.w[o + 3] = (const bf16*)b1.conv1.w16f; t.g[o + 3] = b1.bn1.g; t.b[o + 3] = b1.bn1.b;
+      t.w[o + 4] = (const bf16*)b1.conv2.w16f; t.g[o + 4] = b1.bn2.g; t.b[o + 4] = b1.bn2.b;
     }
   }
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS);
     attr_set = true;
   }
-  hipLaunchKernelGGL(tower_tail_kernel, dim3(B, groups), dim3(NTH), LDS_BYTES, stream, a, B);
+  hipLaunchKernelGGL(tower_tail_kernel, dim3(B, groups), dim3(TTH), TAIL_LDS, stream, a, B);
   return avlen_launch_status();
 }

@@ -131,6 +131,11 @@ class Packed:
         self.jobs.append(("conv", conv.weight, buf, buf16, (O, I, KH, KW), c16))
         v = L.Conv(P(buf), P(conv.bias) if has_bias else None, I, O, KH, KW, conv.stride[0], conv.padding[0])
         v.w16, v.cin16 = P(buf16), c16
+        if O % 16 == 0 and (KH * KW * c16) % 32 == 0 and c16 >= 32:       # fragment-order copy (register-resident weights: tower_tail)
+            buff = torch.empty_like(buf16)
+            self.bufs.append(buff)
+            self.jobs.append(("frag", buf16, None, buff, (O, KH * KW * c16), 0))
+            v.w16f = P(buff)
         if I * conv.stride[0] == 8 and KW % conv.stride[0] == 0 and conv.padding[0] == 0 and I < 8:
             bufc = torch.empty(O * KH * KW * I, dtype=torch.bfloat16, device=self.device)      # compact: super-pixel form
             self.bufs.append(bufc)
@@ -210,6 +215,8 @@ class Packed:
                     bias.copy_(bn.bias - bn.running_mean * scale)
                 L.call("avlen_pack_conv_weight", P(wf), P(buf), *dims, st)
                 L.call("avlen_pack_conv_weight_bf16", P(wf), P(w16), *dims, c16, st)
+            elif kind == "frag":                      # queued after the conv's own job: w16 is up to date
+                L.call("avlen_pack_conv_weight_frag", P(w), P(buf16), dims[0], dims[1], st)
             elif kind == "conv16c":
                 L.call("avlen_pack_conv_weight_bf16", P(w), P(buf16), *dims, c16, st)
             elif kind == "conv":

@@ -41,7 +41,10 @@ typedef struct { float* w; float* b; int out_f; int in_f; void* w16; int ld16; }
  * cin * stride == 8 and kw % stride == 0 (AudioCNN conv0 on the 257x101 spectrogram, audio_cnn.py:62-83): `stride`
  * horizontally adjacent pixels x cin channels form one 8-channel pixel, the conv becomes (kh, kw/stride), stride (stride, 1),
  * K = kh*kw*cin instead of kh*kw*8. */
-typedef struct { float* w; float* b; int cin, cout, kh, kw, stride, pad; void* w16; int cin16; void* w16c; } avlen_conv;
+/* w16f: optional copy of w16 in MFMA-fragment order for kernels that keep their weights in registers (tower_tail.hip): with
+ * K = kh*kw*cin16 (a multiple of 32) and cout a multiple of 16, [cout/16][K/32][lane 0..63][8] bf16 where lane = 16 q + r holds
+ * w16[16 t + r][32 i + 8 q .. + 7] -- one 16-byte load per lane, 1 KiB contiguous per wave and k-step. */
+typedef struct { float* w; float* b; int cin, cout, kh, kw, stride, pad; void* w16; int cin16; void* w16c; void* w16f; } avlen_conv;
 typedef struct { float* g; float* b; } avlen_affine;                               /* norm scale / shift */
 typedef struct { avlen_conv conv1, conv2, down; avlen_affine bn1, bn2, bnd; int has_down; } avlen_resblock;
 /* CustomResNet (smt_resnet.py:56-149): conv7x7 + GroupNorm(16) + 8 basic blocks + fc(8192->64).
@@ -117,6 +120,8 @@ int avlen_cast_bf16(const float* src, int ld_src, void* dst, int ld_dst, long ro
 int avlen_pack_conv_weight_bf16(const float* w_oihw, void* w_packed, int O, int I, int KH, int KW, int Cpad,
                                 avlen_stream_t stream);
 int avlen_pack_fc_after_flatten_bf16(const float* w, void* w_packed, int O, int C, int HW, avlen_stream_t stream);
+/* w16 [cout][K] -> w16f (avlen_conv::w16f), cout % 16 == 0, K % 32 == 0 */
+int avlen_pack_conv_weight_frag(const void* w16, void* w16f, int cout, int K, avlen_stream_t stream);
 
 /* ------------------------------------------------------------------ normalisation ------------- */
 /* y = [relu]( GroupNorm_G(x)*g + b [+ residual] ), x NHWC (B,HW,C).  smt_resnet.py:30-33,40-51,79. */

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_sizes_match_header_layout():
     from avlen_amd import _lib
     # pointer,pointer,int,int
-    assert ctypes.sizeof(_lib.Linear) == 40 and ctypes.sizeof(_lib.Conv) == 64 and ctypes.sizeof(_lib.Affine) == 16
+    assert ctypes.sizeof(_lib.Linear) == 40 and ctypes.sizeof(_lib.Conv) == 72 and ctypes.sizeof(_lib.Affine) == 16
     assert ctypes.sizeof(_lib.Mha) == 80
 
 
