@@ -34,7 +34,7 @@ constexpr int ROWQ = 34;                          // layer 2: 34 rows x 34 pixel
 static_assert(ROWQ * ROWQ * 64 <= IMG_BYTES, "the 32-channel frame reuses the 16-channel frame's space");
 static_assert((70 * ROWP0 + 2) * 8 <= IMG_BYTES && HEAD_LDS <= 160 * 1024, "tower head LDS budget");
 
-// w / g / b: 0 stem, 1..4 layer 1 (block 0 conv1, conv2, block 1 conv1, conv2), 5 block 2 downsample, 6 / 7 block 2 conv1 / conv2,
+// w (7..9: the fragment-order copies avlen_conv::w16f) / g / b: 0 stem, 1..4 layer 1 (block 0 conv1, conv2, block 1 conv1, conv2), 5 block 2 downsample, 6 / 7 block 2 conv1 / conv2,
 // 8 / 9 block 3 conv1 / conv2
 struct HeadTower { const void* img; int u8; int C; float div; const bf16* w[10]; const float* g[10]; const float* b[10]; bf16* y; };
 struct HeadArgs { HeadTower t[8]; const int* row_index; int S; long long* prof; };
@@ -134,7 +134,7 @@ __device__ __forceinline__ void load_w32(bf16x8 (&W)[9][2], const bf16* __restri
 #pragma unroll
   for (int tap = 0; tap < 9; tap++)
 #pragma unroll
-    for (int ct = 0; ct < 2; ct++) W[tap][ct] = *reinterpret_cast<const bf16x8*>(wt + (long)(ct * 16 + r16) * 288 + tap * 32 + 8 * q);
+    for (int ct = 0; ct < 2; ct++) W[tap][ct] = *reinterpret_cast<const bf16x8*>(wt + ((long)(ct * 9 + tap) * 64 + q * 16 + r16) * 8);   // w16f
 }
 // W: this conv's weight fragments (already loaded or in flight); next_wt: the following 32-channel conv's weights, fetched into
 // W as soon as the MFMAs are done, so that the L2 round trip runs under the statistics / apply phases (nullptr: none)
@@ -526,10 +526,10 @@ bool avlen_tower_head_supported(const avlen_resnet18* n, int S, int C) {
   }
   const avlen_resblock& b2 = n->block[2];
   const avlen_resblock& b3 = n->block[3];
-  if (!b2.has_down || !conv3(b2.conv1, 16, 32, 2) || !conv3(b2.conv2, 32, 32, 1)) return false;
+  if (!b2.has_down || !conv3(b2.conv1, 16, 32, 2) || !conv3(b2.conv2, 32, 32, 1) || !b2.conv2.w16f) return false;
   const avlen_conv& d = b2.down;
   if (!d.w16 || d.cin16 != 16 || d.cout != 32 || d.kh != 1 || d.kw != 1 || d.stride != 2 || d.pad != 0) return false;
-  return !b3.has_down && conv3(b3.conv1, 32, 32, 1) && conv3(b3.conv2, 32, 32, 1);
+  return !b3.has_down && conv3(b3.conv1, 32, 32, 1) && conv3(b3.conv2, 32, 32, 1) && b3.conv1.w16f && b3.conv2.w16f;
 }
 
 // Y[g] = layer-2 output (post-ReLU) NHWC bf16 (B, 32, 32, 32) of tower g; imgs[g] (B or more images of S x S x C, fp32 or uint8)
@@ -553,9 +553,9 @@ int avlen_tower_head_bf16(const avlen_resnet18* const* nets, const void* const* 
     const avlen_resblock& b3 = n->block[3];
     t.w[5] = (const bf16*)b2.down.w16; t.g[5] = b2.bnd.g; t.b[5] = b2.bnd.b;
     t.w[6] = (const bf16*)b2.conv1.w16; t.g[6] = b2.bn1.g; t.b[6] = b2.bn1.b;
-    t.w[7] = (const bf16*)b2.conv2.w16; t.g[7] = b2.bn2.g; t.b[7] = b2.bn2.b;
-    t.w[8] = (const bf16*)b3.conv1.w16; t.g[8] = b3.bn1.g; t.b[8] = b3.bn1.b;
-    t.w[9] = (const bf16*)b3.conv2.w16; t.g[9] = b3.bn2.g; t.b[9] = b3.bn2.b;
+    t.w[7] = (const bf16*)b2.conv2.w16f; t.g[7] = b2.bn2.g; t.b[7] = b2.bn2.b;
+    t.w[8] = (const bf16*)b3.conv1.w16f; t.g[8] = b3.bn1.g; t.b[8] = b3.bn1.b;
+    t.w[9] = (const bf16*)b3.conv2.w16f; t.g[9] = b3.bn2.g; t.b[9] = b3.bn2.b;
   }
   static bool attr_set = false;
   if (!attr_set) {

@@ -91,7 +91,7 @@ def spawn_ranks(n):
 # --------------------------------------------------------------------------------------------------------------------
 # roofline of the dominant kernel
 # --------------------------------------------------------------------------------------------------------------------
-def kernel_roofline(prec_name, in_situ=None):
+def kernel_roofline(prec_name, in_situ=None, towers=None):
     """Roofline of the DOMINANT kernel by GPU time in the rollout (profiles/): the bf16 MFMA GEMM on its heaviest call site, the
     CLIP text MLP up-projection c_fc of one rollout step on the ragged batch (M = 2464 live rows, N = 2048, K = 512, bias +
     QuickGELU, bf16 out); the block's other three GEMMs are listed under `other_call_sites`.  `achieved` = 2*M*N*K / duration
@@ -119,17 +119,51 @@ def kernel_roofline(prec_name, in_situ=None):
            "algorithmic_flops": gw["flops"],
            "algorithmic_bytes": gw["bytes"], "us_per_launch": round(sg * 1e6, 2),
            "other_call_sites": rp.clip_call_sites(),
-           "hbm_conv": {"bound": "hbm", "kernel": "dconv3x3_kernel<16,16,64,3> (tower layer-1 conv, 384 images/launch, bf16 "
-                                                  "in/out, fused GN statistics)", "achieved": round(gb, 1), "peak": 8000.0,
+           "hbm_conv": {"bound": "hbm", "kernel": "dconv3x3_kernel<16,16,64,3> (tower layer-1 conv as a standalone launch, 384 "
+                                                  "images, bf16 in/out, fused GN statistics; the product runs it inside tower_head)", "achieved": round(gb, 1), "peak": 8000.0,
                         "unit": "GB/s", "frac": round(gb / 8000.0, 4), "traffic": pmc.get("dconv", {}).get("traffic_bytes"),
                         "algorithmic_bytes": cw["bytes"], "us_per_launch": round(sc * 1e6, 2)}}
     if in_situ:
         out["in_situ"] = in_situ
-    try:
+    if towers:
+        out["towers_fused"] = towers
+    try:                                         # the convs as STANDALONE launches (the fallback path; the product runs them fused)
         out["tower_convs"] = rp.tower_conv_table()
     except Exception as e:                       # the table is an extra: never lose the headline line over it
         out["tower_convs_error"] = repr(e)
     return out
+
+
+def towers_fused(wl):
+    """The visual towers of ONE rollout step at the benched batch as the product runs them -- one grouped call for the six towers
+    (rgb + depth of pi_q, pi_g, pi_l) x N images: tower_head (preprocessing + stem + layers 1-2), tower_tail (layers 3-4), fc
+    GEMM -- timed with HIP events on the launch stream while nothing else runs.  FLOPs: SURVEY 8(d), 581.4 MF per tower pair
+    and sample; algorithmic HBM bytes: the images read once (uint8 rgb, fp32 depth) + the (N, 64) features written."""
+    import torch
+    grp = getattr(wl.pi_q, "_enc_group", None)
+    if grp is None:
+        return None
+    obs = {k: v[0] for k, v in wl.rollouts.observations.items()}
+    rgb, depth = obs["rgb"], obs["depth"]
+    fn = lambda: grp.run_all(wl.pi_q, rgb, depth)
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    it = 20
+    e0.record()
+    for _ in range(it):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) / 1e3 / it
+    N, pairs = rgb.shape[0], len(grp.members)
+    flops = 581.4e6 * N * pairs
+    by = pairs * N * (rgb[0].numel() * rgb.element_size() + depth[0].numel() * depth.element_size() + 2 * 64 * 4)
+    return {"what": "%d towers x %d images, one grouped call (tower_head + tower_tail + fc), alone on its stream" % (2 * pairs, N),
+            "us": round(sec * 1e6, 1), "flops": flops, "TFLOPs": round(flops / sec / 1e12, 1),
+            "frac_of_bf16_peak": round(flops / sec / 2.5e15, 4), "us_per_tower_image": round(sec * 1e6 / (2 * pairs * N), 3),
+            "algorithmic_hbm_bytes": by, "GBps": round(by / sec / 1e9, 1)}
 
 
 def text_tower_in_situ(wl):
@@ -372,7 +406,8 @@ def main():
         interactive = a.config == "interactive"
         if not a.no_roofline:
             situ = text_tower_in_situ(wl) if (interactive and a.precision == "bf16") else None
-            rl = kernel_roofline(a.precision, situ)
+            tw = towers_fused(wl) if (interactive and a.precision == "bf16") else None
+            rl = kernel_roofline(a.precision, situ, tw)
             if rl is not None:
                 out["roofline"] = rl
         if world == 1 and interactive and not a.no_extras and a.precision == "bf16" and not a.belief:

@@ -73,6 +73,8 @@ static void cpu_head(const std::vector<float>& img, int S, int C, float div, con
 
 static const size_t WSIZE[10] = {16 * 392, 16 * 144, 16 * 144, 16 * 144, 16 * 144, 32 * 16, 32 * 144, 32 * 288, 32 * 288, 32 * 288};
 
+static const bf16* wrow[8][3];      // [cout][K] copies of the fragment-order weights (CPU check)
+
 int main(int argc, char** argv) {
   const int B = argc > 1 ? atoi(argv[1]) : 64, G = argc > 2 ? atoi(argv[2]) : 6, S = argc > 3 ? atoi(argv[3]) : 128;
   const int u8 = argc > 4 ? atoi(argv[4]) : 0;
@@ -101,6 +103,14 @@ int main(int argc, char** argv) {
     else t.img = devf(n, t.C == 3 ? 128.f : 0.5f, t.C == 3 ? 100.f : 0.4f);
     for (int i = 0; i < 10; i++) {
       t.w[i] = (const bf16*)dev(WSIZE[i] * 2, true, i == 0 ? 0.1f : i == 5 ? 0.3f : i < 7 ? 0.12f : 0.08f);
+      if (i >= 7) {                                       // the 32 -> 32 convs are read in fragment order (avlen_conv::w16f)
+        std::vector<unsigned short> w(WSIZE[i]), wf(WSIZE[i]);
+        hipMemcpy(w.data(), t.w[i], w.size() * 2, hipMemcpyDeviceToHost);
+        for (int tt = 0; tt < 2; tt++) for (int ii = 0; ii < 9; ii++) for (int ln = 0; ln < 64; ln++) for (int e = 0; e < 8; e++)
+          wf[(((size_t)tt * 9 + ii) * 64 + ln) * 8 + e] = w[(size_t)(tt * 16 + (ln & 15)) * 288 + ii * 32 + 8 * (ln >> 4) + e];
+        void* d; hipMalloc(&d, wf.size() * 2); hipMemcpy(d, wf.data(), wf.size() * 2, hipMemcpyHostToDevice);
+        wrow[g][i - 7] = t.w[i]; t.w[i] = (const bf16*)d;
+      }
       const int nch = i < 5 ? 16 : 32;
       t.g[i] = devf(nch, 1.f, 0.2f); t.b[i] = devf(nch, 0.f, 0.2f);
     }
@@ -151,7 +161,7 @@ int main(int argc, char** argv) {
     std::vector<float> img((size_t)S * S * t.C); hipMemcpy(img.data(), t.img, img.size() * 4, hipMemcpyDeviceToHost);
     std::vector<unsigned short> w[10]; std::vector<float> gm[10], bt[10];
     for (int i = 0; i < 10; i++) {
-      w[i].resize(WSIZE[i]); hipMemcpy(w[i].data(), t.w[i], w[i].size() * 2, hipMemcpyDeviceToHost);
+      w[i].resize(WSIZE[i]); hipMemcpy(w[i].data(), i >= 7 ? wrow[0][i - 7] : t.w[i], w[i].size() * 2, hipMemcpyDeviceToHost);
       const int nch = i < 5 ? 16 : 32;
       gm[i].resize(nch); bt[i].resize(nch);
       hipMemcpy(gm[i].data(), t.g[i], nch * 4, hipMemcpyDeviceToHost); hipMemcpy(bt[i].data(), t.b[i], nch * 4, hipMemcpyDeviceToHost);

@@ -78,6 +78,14 @@ def run3():
         cur.wait_stream(s)
 
 print("full batch, one graph: %.0f us" % timed(run_full))
+for nb in (32, 16, 8):
+    r_, o_, w_ = make(tok[:nb].contiguous())
+    g_ = capture(r_, s1)
+    def run_part(g_=g_):
+        with torch.cuda.stream(s1):
+            g_.replay()
+        torch.cuda.current_stream().wait_stream(s1)
+    print("first %d dialogs alone, one graph: %.0f us" % (nb, timed(run_part)))
 for frac in splits:
     print("two graphs (%.0f%% / %.0f%%) on two streams: %.0f us" % (100 * frac, 100 - 100 * frac, timed(run_split(frac))))
 print("three graphs on three streams: %.0f us" % timed(run3))
