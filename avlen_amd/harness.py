@@ -46,7 +46,8 @@ class Workload:
         # 1: launch it BEFORE pi_q's graph -- measured slower (22.8k vs 27.5k env-steps/s): the GEMM blocks that get the CUs first
         # squeeze the towers; launched second, the text tower fills the gaps the memory-bound tower kernels leave
         self._text_first = os.environ.get("AVLEN_TEXT_FIRST", "0") != "0"
-        self._side = [torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()] if launch_ahead else None
+        tp = int(os.environ.get("AVLEN_TEXT_PRIORITY", "0"))            # lab knob: stream priority of the text tower's stream
+        self._side = [torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream(priority=tp)] if launch_ahead else None
         osp, asp = savi_observation_space(spectrogram), ActionSpace(4)
         torch.manual_seed(weight_seed)          # identical initial weights on every rank (data-parallel replicas)
         kw = dict(SMT_KW, precision=precision, sampling=sampling, use_graphs=use_graphs)

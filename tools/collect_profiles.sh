@@ -11,12 +11,18 @@ python3 $R/bench.py > $O/bench_default.log 2>&1 || exit 1
 tail -1 $O/bench_default.log | cut -c1-300
 python3 -m pytest $R/tests -m gpu -q > $O/gpu_parity_tests.log 2>&1 || exit 1
 tail -1 $O/gpu_parity_tests.log
-rocprofv3 --kernel-trace --stats -d /tmp/ps -o res -- python3 $R/bench.py --steps 1 --warmup 1 --rollout 30 --no-cpu-baseline --no-roofline --no-extras > /tmp/ps.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats -d /tmp/ps -o res -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-extras > /tmp/ps.log 2>&1 || exit 1
 DB=$(find /tmp/ps -name "*.db" | head -1)
 python3 $R/tools/prof_summary.py $DB > $O/rocprof_summary_head.md || exit 1
-python3 $R/tools/step_breakdown.py $DB 30 > $O/step_breakdown.md || exit 1
+python3 $R/tools/step_breakdown.py $DB 150 > $O/step_breakdown.md || exit 1
 python3 $R/tools/update_breakdown.py $DB > $O/update_breakdown.md || exit 1
 python3 $R/tools/step_timeline.py 2>&1 | grep "times since" > $O/step_timeline.txt || exit 1
+python3 $R/tools/step_trace.py $DB 150 40 > $O/step_trace.txt || exit 1
+# phase tables of the fused tower kernels (lab binaries built here: tools/bin is not tracked)
+if [ -x $R/tools/bin/head_lab0 ]; then $R/tools/bin/head_lab0 64 6 128 1 > $O/tower_head_phases.txt || exit 1; fi
+if [ -x $R/tools/bin/tail_lab ]; then $R/tools/bin/tail_lab 64 6 > $O/tower_tail_phases.txt || exit 1; fi
+if [ -x $R/tools/bin/gridbar_lab ]; then $R/tools/bin/gridbar_lab 256 200 1 > $O/grid_barrier_probe.txt || exit 1; fi
+python3 $R/tools/text_split_probe.py 2>&1 | grep -E "us$|tokens" > $O/text_tower_scaling.txt || exit 1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o res -- python3 $R/tools/roofline_probe.py > /tmp/pmc_$c.log 2>&1 || exit 1
   cp $(find /tmp/pmc_$c -name "*counter_collection.csv" | head -1) $O/pmc_${c}_counter_collection.csv || exit 1
