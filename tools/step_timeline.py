@@ -28,7 +28,7 @@ for it in range(STEPS):
     mark("t0", cur)
     wl.pi_q.prefetch_act_option(obs, h, prev, v["masks"], em_opt, em_masks, v["qs"], v["lqi"])
     mark("q_end", cur); host_q = time.perf_counter()
-    mark("txt_start", wl._side[2]) if False else None
+    mark("txt_start", wl._side[2])
     wl.pi_l.prefetch_text(v["dialog"], wl._side[2], after_current=False)
     mark("txt_end", wl._side[2]); host_t = time.perf_counter()
     wl.pi_g.prefetch_act(obs, h, prev, v["masks"], em_goal, em_masks, stream=wl._side[wl._g_stream])
@@ -48,7 +48,7 @@ for it in range(STEPS):
               v["dialog"], wl.o_action, wl.o_mask, v["rl"], v["ucnt"], probs_vln, v["qs"], v["lqi"], v["astep"])
     mark("insert_end", cur); host_ins = time.perf_counter()
     torch.cuda.synchronize()
-    for k in ("q_end", "txt_end", "g_end", "l_end", "insert_end"):
+    for k in ("q_end", "txt_start", "txt_end", "g_end", "l_end", "insert_end"):
         acc[k] = acc.get(k, 0.0) + ev["t0"].elapsed_time(ev[k])
     for k, x in (("launch_q", host_q), ("launch_txt", host_t), ("launch_g", host_g), ("launch_l", host_l), ("act_q_done", host_aq),
                  ("act_g_done", host_ag), ("act_l_done", host_al), ("insert_done", host_ins)):
