@@ -282,7 +282,9 @@ def dialog_state_encoder(sd, p, x_att, memory_state, memory_masks, d_emb, agent_
 
 def clip_encode_text(sd, p, tokens, nhead=8):
     """tokens (B,77) int64 -> (B,512).  x = tok_emb + pos_emb; 12 pre-norm residual blocks with a
-    causal mask and QuickGELU MLP; ln_final; take the row of the EOT token (= argmax id); project."""
+    causal mask and QuickGELU MLP; ln_final; take the row of the EOT token (= argmax id); project.
+    openai/CLIP is absent (parity unpinned against it); cross-checked against Hugging Face transformers' CLIPTextModelWithProjection
+    with the same weights in tests/test_clip_independent.py."""
     x = sd[p + ".token_embedding.weight"][tokens] + sd[p + ".positional_embedding"]
     x = x.permute(1, 0, 2)                                          # (S,B,d)
     i = 0
@@ -509,7 +511,8 @@ def _batch_norm_eval(sd, p, x, eps=1e-5):
 def tv_resnet18(sd, p, x):
     """torchvision.models.resnet18 in eval mode (third party, un-vendored; PARITY UNPINNED: restated from the public
     architecture -- conv7x7/2, BN, ReLU, maxpool3x3/2, 4 stages x 2 BasicBlocks (64,128,256,512), avgpool, fc --
-    anchored on the call sites belief_predictor.py:79-81,179)."""
+    anchored on the call sites belief_predictor.py:79-81,179; cross-checked against Hugging Face transformers'
+    ResNetForImageClassification with the same weights in tests/test_tv_resnet18_independent.py)."""
     x = torch.relu(_batch_norm_eval(sd, p + ".bn1", F.conv2d(x, sd[p + ".conv1.weight"], None, stride=2, padding=3)))
     x = F.max_pool2d(x, 3, 2, 1)
     for li, stride in ((1, 1), (2, 2), (3, 2), (4, 2)):
