@@ -10,7 +10,8 @@ Pinned: every function below is compared with the reference's own modules execut
 build container (see tests/test_oracle_vs_golden.py).  NOT pinned ("parity unpinned"):
 ``clip_encode_text`` -- OpenAI CLIP is an un-vendored, un-pinned third-party dependency
 (README.md:61) that is absent from /root/reference; the function restates CLIP's public
-text-transformer definition and is anchored only on the call site policy.py:847-849.
+text-transformer definition and is anchored on the call site policy.py:847-849; it is cross-checked
+against Hugging Face transformers' independent CLIP text model (tests/test_clip_independent.py).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this file.
 The product package ``avlen_amd`` never does.
