@@ -1,19 +1,25 @@
 // Stem + layers 1 and 2 of the CustomResNet tower (smt_resnet.py:132-141: conv 7x7 -> GroupNorm -> ReLU -> two basic blocks
 // of 16 channels at 64x64 -> two basic blocks of 32 channels at 32x32, the first with stride 2 and a 1x1 stride-2 downsample
 // + GroupNorm on the skip) -- with the sensor preprocessing (x / divisor, k x k block mean: smt_cnn.py:83-93) in front -- as ONE
-// launch: one workgroup per image keeps the whole 64x64x16 activation in LDS (136 KiB with a one-pixel zero frame,
-// so that the 3x3 taps need no bounds test), the basic blocks' residual and every raw conv output in REGISTERS (a wave
-// owns 8 image rows: 32 MFMA row tiles, 64 + 64 packed-bf16 registers), the conv weights as MFMA fragments in registers, and
-// takes the GroupNorm statistics from its own fp32 accumulators, reduced in a fixed order (deterministic: no atomics).
-// Replaces, per tower group: preprocess + 7x7 direct conv + four 3x3 direct convs + two GroupNorm-apply passes = 8 launches
-// that move the 128 KiB activation through HBM 13 times; here the image is read once and the layer-1 output written once.
+// launch, one 512-thread workgroup per image:
+//  * the activation of the current stage is ONE zero-framed bf16 image in LDS (64x64x16: 66 x 66 x 32 B = 136 KiB; 32x32x32:
+//    34 x 34 x 64 B in the same space), so that the taps need no bounds tests;
+//  * the basic blocks' residual and every raw conv output live in REGISTERS as packed bf16 pairs (layer 1: a wave owns 8 image
+//    rows = 32 MFMA tiles, 64 + 64 registers) -- the second and third live tensor of a block never need LDS;
+//  * the convs run INPUT-ROW STATIONARY: the kx-shifted B fragments of a frame row are read from LDS once and feed the output
+//    rows row - ky (with 16 output channels a fragment read otherwise feeds a single MFMA and LDS bandwidth is the bound);
+//  * the conv weights are MFMA fragments in registers, fetched one conv ahead (barriers order LDS traffic only);
+//  * GroupNorm statistics come from the kernel's own fp32 accumulators: packed per-lane sums, 16-lane DPP row sums, a fixed-order
+//    combine of the 8 waves in double (deterministic: no atomics); normalise / residual / ReLU on packed pairs.
+// Replaces preprocess + 10 conv + 4 GroupNorm-apply launches that moved the activation through HBM ~20 times: the image is read
+// once and the 32x32x32 layer-2 output (64 KiB) written once.
 //
-// Same arithmetic as the launch-per-layer path (dconv.hip / norm.hip): bf16 operands, fp32 MFMA accumulation in the same K
-// order ([ky][kx][c] taps, 32 per step), raw conv outputs rounded to bf16 before GroupNorm, statistics from the fp32
-// accumulators, var = E[x^2] - mean^2 in double, y = relu(x * (gamma * rstd) + (beta - mean * gamma * rstd) [+ residual]).
+// Arithmetic: bf16 operands, fp32 MFMA accumulation (K order: frame row, then kx, then channel), raw conv outputs rounded to
+// bf16 before the normalisation, statistics from the fp32 accumulators, var = E[x^2] - mean^2 in double, rstd = 1 / sqrt(var + eps)
+// in fp32, y = relu(x * (gamma * rstd) + (beta - mean * gamma * rstd) [+ residual]), rounded to bf16.
 //
 // LDS layout of the 16-channel image: [66 rows][66 pixels][32 B]; the two 16-byte chunks of a pixel are swapped when
-// (pixel >> 3) & 1 so that the 16 pixels of an MFMA row tile read conflict-free (tower_tail.hip uses the same rule).
+// (pixel >> 3) & 1 so that the 16 pixels of an MFMA row tile read conflict-free.
 #include "common.h"
 #include "../../include/avlen_hip.h"
 #include "internal.h"
@@ -34,8 +40,8 @@ constexpr int ROWQ = 34;                          // layer 2: 34 rows x 34 pixel
 static_assert(ROWQ * ROWQ * 64 <= IMG_BYTES, "the 32-channel frame reuses the 16-channel frame's space");
 static_assert((70 * ROWP0 + 2) * 8 <= IMG_BYTES && HEAD_LDS <= 160 * 1024, "tower head LDS budget");
 
-// w (7..9: the fragment-order copies avlen_conv::w16f) / g / b: 0 stem, 1..4 layer 1 (block 0 conv1, conv2, block 1 conv1, conv2), 5 block 2 downsample, 6 / 7 block 2 conv1 / conv2,
-// 8 / 9 block 3 conv1 / conv2
+// w / g / b: 0 stem, 1..4 layer 1 (block 0 conv1, conv2, block 1 conv1, conv2), 5 block 2 downsample, 6 / 7 block 2 conv1 /
+// conv2, 8 / 9 block 3 conv1 / conv2; w[7..9] are the fragment-order copies avlen_conv::w16f, the others [cout][kh][kw][cin16]
 struct HeadTower { const void* img; int u8; int C; float div; const bf16* w[10]; const float* g[10]; const float* b[10]; bf16* y; };
 struct HeadArgs { HeadTower t[8]; const int* row_index; int S; long long* prof; };
 #ifdef AVLEN_HEAD_PROF          // tools/head_lab.hip: phase timestamps of every workgroup's wave 0
@@ -87,15 +93,8 @@ __device__ __forceinline__ void preprocess_tile(const T* __restrict__ img, float
 // channels q * 4 + r; NCH = 32 the groups (r >> 1) * 8 + q * 2 + (r & 1) (r >> 1 = cout tile, r & 1 = channel pair).
 // Fixed summation order (lanes by DPP butterflies, waves 0..7 in sequence): deterministic.  The moments are combined in double
 // (E[x^2] - mean^2 cancels), the reciprocal square root is taken in fp32 (correctly rounded sqrt and division).
-#ifdef AVLEN_HEAD_PROF
-#define FS_STAMP(k) do { if (prof && gb == 32 && tid == AVLEN_HEAD_PROF) prof[k] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define FS_STAMP(k) do { } while (0)
-#endif
 template <int NCH>
-__device__ __forceinline__ void finish_stats(float (&s1)[4], float (&s2)[4], char* lds, int gb, int tid, int wave, int r16, int q,
-                                             long long* prof = nullptr) {
-  FS_STAMP(24);
+__device__ __forceinline__ void finish_stats(float (&s1)[4], float (&s2)[4], char* lds, int gb, int tid, int wave, int r16, int q) {
   const float* gamma = reinterpret_cast<const float*>(lds + GB_OFF) + gb;
   const float* beta = gamma + NCH;
   float* part = reinterpret_cast<float*>(lds + PART_OFF);
@@ -106,9 +105,7 @@ __device__ __forceinline__ void finish_stats(float (&s1)[4], float (&s2)[4], cha
     const int slot = NCH == 16 ? q * 4 + r : (r >> 1) * 8 + q * 2 + (r & 1);
     if (r16 == 0) *reinterpret_cast<float2*>(&part[(wave * 16 + slot) * 2]) = make_float2(a, c);
   }
-  FS_STAMP(25);
   lds_barrier();                                // every wave has also finished reading the image of this conv
-  FS_STAMP(26);
   if (tid < NCH) {
     const int g = NCH == 16 ? tid : tid >> 1;
     double sum = 0.0, sq = 0.0;
@@ -122,9 +119,7 @@ __device__ __forceinline__ void finish_stats(float (&s1)[4], float (&s2)[4], cha
     const float sc = gamma[tid] * rstd;
     coef[tid] = sc; coef[32 + tid] = beta[tid] - (float)mean * sc;
   }
-  FS_STAMP(27);
   lds_barrier();
-  FS_STAMP(28);
 }
 
 // One 3x3 stride-1 conv 32 -> 32 over the 32 x 32 frame + GroupNorm (+ residual) + ReLU, input-row stationary: a wave owns 4
@@ -374,7 +369,7 @@ __global__ __launch_bounds__(HTH) void tower_head_kernel(HeadArgs args, int B) {
     s1[0] = sA[0]; s1[1] = sA[1]; s1[2] = sB[0]; s1[3] = sB[1]; s2[0] = qA[0]; s2[1] = qA[1]; s2[2] = qB[0]; s2[3] = qB[1];
     if (ci < 3) load_w16(t.w[2 + ci]);
     HEAD_STAMP(5 + 2 * ci);
-    finish_stats<16>(s1, s2, lds, (1 + ci) * 32, tid, wave, r16, q, args.prof ? args.prof + (blockIdx.y * gridDim.x + blockIdx.x) * 32 : nullptr);
+    finish_stats<16>(s1, s2, lds, (1 + ci) * 32, tid, wave, r16, q);
     HEAD_STAMP(6 + 2 * ci);
     const f32x2 sc0 = {coef[q * 4], coef[q * 4 + 1]}, sc1 = {coef[q * 4 + 2], coef[q * 4 + 3]};
     const f32x2 sh0 = {coef[32 + q * 4], coef[32 + q * 4 + 1]}, sh1 = {coef[32 + q * 4 + 2], coef[32 + q * 4 + 3]};

@@ -149,11 +149,6 @@ int main(int argc, char** argv) {
   for (int k = 0; k < NP; k++) tot += ph[k];
   for (int k = 0; k < NP; k++) printf("  %-14s %6.1f %%  (%.0f ticks)\n", names[k], 100 * ph[k] / tot, ph[k] / (B * G));
   printf("  workgroup total %.0f ticks\n", tot / (B * G));
-  {
-    double d[4] = {0, 0, 0, 0};
-    for (int w = 0; w < B * G; w++) for (int k = 0; k < 4; k++) d[k] += (double)(h[w * 32 + 25 + k] - h[w * 32 + 24 + k]);
-    printf("  inside stats1: reduce+write %.0f, barrier %.0f, serial section %.0f, barrier %.0f ticks\n", d[0] / (B * G), d[1] / (B * G), d[2] / (B * G), d[3] / (B * G));
-  }
 #endif
   // tower 0, image 0 against the CPU restatement
   if (!a.t[0].u8) {
