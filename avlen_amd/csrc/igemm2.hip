@@ -201,6 +201,25 @@ __global__ __launch_bounds__(NTH) void g2_kernel(G2 pp) {
   const int r16 = lane & 15, q = lane >> 4;
   const bool loads_first = NTH == 512 && wave >= 4;
 
+  // The deep-prefetch 64x128 instance runs the problems that cannot fill the chip (one block per CU: registers are free): its
+  // epilogue operands -- bias and the fp32 residual tile -- are fetched NOW, under the K loop, instead of as a dependent round trip
+  // behind it (the loads are older than every staging load, so the loop's counted vmcnt waits cover them).
+  constexpr bool EARLY = NS == 4 && BM == 64 && BN == 128 && NTH == 512 && !CONV;
+  float4 bv_e[EARLY ? NI : 1], rv_e[EARLY ? MI : 1][EARLY ? NI : 1];
+  const bool early = EARLY && p.splitk == 1 && p.vec4 != 0 && !p.ln_stats;
+  if (EARLY && early) {
+#pragma unroll
+    for (int j = 0; j < NI; j++) {
+      const int col = n0 + wn * WTN + j * 16 + q * 4;
+      bv_e[j] = p.bias ? ld4(p.bias, col, col, p.N, true) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < MI; i++) {
+        const int row = m0 + wm * WTM + i * 16 + r16;
+        rv_e[i][j] = (p.residual && row < p.M) ? ld4(p.residual, (long)row * p.ldr + col, col, p.N, true) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  }
+
   // ---- software pipeline: tiles kt .. kt+NS-2 in flight while tile kt is multiplied ----
   const int nkt = kt_end - kt_beg;
 #pragma unroll
@@ -297,7 +316,8 @@ __global__ __launch_bounds__(NTH) void g2_kernel(G2 pp) {
 #pragma unroll
   for (int j = 0; j < NI; j++) {
     int col = n0 + wn * WTN + j * 16 + q * 4;
-    bv[j] = p.bias ? ld4(p.bias, col, col, p.N, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (EARLY && early) bv[j] = bv_e[EARLY ? j : 0];
+    else bv[j] = p.bias ? ld4(p.bias, col, col, p.N, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   if (p.ln_stats) {            // folded LayerNorm: acc <- rstd * (acc - mean * s)
     float4 sv[NI];
@@ -328,7 +348,8 @@ __global__ __launch_bounds__(NTH) void g2_kernel(G2 pp) {
       for (int j = 0; j < NI; j++) {
         int col = n0 + wn * WTN + j * 16 + q * 4;
         int row = m0 + wm * WTM + i * 16 + r16;
-        rv[i][j] = row < p.M ? ld4(p.residual, (long)row * p.ldr + col, col, p.N, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (EARLY && early) rv[i][j] = rv_e[EARLY ? i : 0][EARLY ? j : 0];
+        else rv[i][j] = row < p.M ? ld4(p.residual, (long)row * p.ldr + col, col, p.N, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
     for (int i = 0; i < MI; i++)
@@ -351,6 +372,32 @@ __global__ __launch_bounds__(NTH) void g2_kernel(G2 pp) {
         acc[i][j][2] = act2(acc[i][j][2] + bv[j].z, a1); acc[i][j][3] = act2(acc[i][j][3] + bv[j].w, a1);
       }
   }
+  // C stores first: they are in flight while the row statistics are reduced (two barriers + one atomic per row)
+  if (LAB(4)) { if (acc[0][0][0] == 123.456f) p.C32[0] = 1.f; return; }
+#pragma unroll
+  for (int i = 0; i < MI; i++)
+#pragma unroll
+    for (int j = 0; j < NI; j++) {
+      int col = n0 + wn * WTN + j * 16 + q * 4;
+      int row = m0 + wm * WTM + i * 16 + r16;
+      if (row >= p.M || col >= p.N) continue;
+      if (vec) {
+        if (p.C32) *reinterpret_cast<float4*>(p.C32 + (long)row * p.ldc32 + col) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        if (p.C16) {
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; r++) o[r] = (bf16)acc[i][j][r];
+          *reinterpret_cast<bf16x4*>(p.C16 + (long)row * p.ldc16 + col) = o;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          if (col + r < p.N) {
+            if (p.C32) p.C32[(long)row * p.ldc32 + col + r] = acc[i][j][r];
+            if (p.C16) p.C16[(long)row * p.ldc16 + col + r] = (bf16)acc[i][j][r];
+          }
+      }
+    }
   if (p.rowstats) {            // per-row (sum, sum of squares) of the final values: the next layer's LayerNorm statistics
     // wave partials (4 columns x NI tiles per lane, 2 cross-lane moves) -> LDS -> one atomic per row and block: per-wave
     // atomics were 16-lane instructions, 4 * MI * WN of them per block
@@ -383,31 +430,6 @@ __global__ __launch_bounds__(NTH) void g2_kernel(G2 pp) {
       }
     }
   }
-  if (LAB(4)) { if (acc[0][0][0] == 123.456f) p.C32[0] = 1.f; return; }
-#pragma unroll
-  for (int i = 0; i < MI; i++)
-#pragma unroll
-    for (int j = 0; j < NI; j++) {
-      int col = n0 + wn * WTN + j * 16 + q * 4;
-      int row = m0 + wm * WTM + i * 16 + r16;
-      if (row >= p.M || col >= p.N) continue;
-      if (vec) {
-        if (p.C32) *reinterpret_cast<float4*>(p.C32 + (long)row * p.ldc32 + col) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-        if (p.C16) {
-          bf16x4 o;
-#pragma unroll
-          for (int r = 0; r < 4; r++) o[r] = (bf16)acc[i][j][r];
-          *reinterpret_cast<bf16x4*>(p.C16 + (long)row * p.ldc16 + col) = o;
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-          if (col + r < p.N) {
-            if (p.C32) p.C32[(long)row * p.ldc32 + col + r] = acc[i][j][r];
-            if (p.C16) p.C16[(long)row * p.ldc16 + col + r] = (bf16)acc[i][j][r];
-          }
-      }
-    }
 }
 
 // Deterministic split-K reduction + epilogue; blockIdx.y = group (all groups of a grouped launch in one pass).
@@ -591,7 +613,7 @@ int run_g2(G2 p, void* ws, size_t ws_bytes, hipStream_t st) {
     const long t64 = (long)ceil_div(m_est, 64) * n_tiles * p.groups;
     if (t128 >= 4096) { bm = 256; ns = 3; }
     else if (t128 >= 400) { bm = 128; ns = 2; }
-    else { bm = 64; ns = (t64 < 256 && p.K >= 1024) ? 4 : 2; }
+    else { bm = 64; ns = t64 < 256 ? 4 : 2; }          // < 256 tiles: one block per CU anyway -> deep prefetch, early epilogue operands
     if (has_stats && bm == 64 && (p.ohw % 32)) { bm = 128; ns = 2; }
     if (has_stats && (p.ohw % 64)) nth = 256;        // (not reached: the conv entry point requires ohw % 64 == 0)
   } else {
