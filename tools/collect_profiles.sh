@@ -35,6 +35,7 @@ cat $O/pmc_traffic.json | head -30
 python3 $R/bench.py --config gru --steps 3 --no-roofline --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_gru.log
 python3 $R/bench.py --distractor --steps 3 --no-roofline --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/bench_distractor.log
 python3 $R/bench.py --stage 2 --envs 32 --steps 2 --no-roofline --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/bench_stage2_envs32.log
+python3 $R/bench.py --belief --spectrogram 65x26 --steps 3 --no-roofline --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/bench_belief_65x26.log
 rocprofv3 --kernel-trace --stats -d /tmp/pg -o res -- python3 $R/bench.py --config gru --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > /tmp/pg.log 2>&1 || exit 1
 python3 $R/tools/prof_summary.py $(find /tmp/pg -name "*.db" | head -1) "rocprofv3 --kernel-trace --stats -- python bench.py --config gru --steps 1 --warmup 1" > $O/rocprof_gru.md
-cut -c1-200 $O/bench_gru.log $O/bench_distractor.log $O/bench_stage2_envs32.log
+cut -c1-200 $O/bench_gru.log $O/bench_distractor.log $O/bench_stage2_envs32.log $O/bench_belief_65x26.log
