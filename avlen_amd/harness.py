@@ -232,13 +232,13 @@ class GruWorkload:
     after_update.  Synthetic observations as in `Workload`, resident in HBM."""
 
     def __init__(self, num_envs=16, num_steps=150, spectrogram=(257, 101, 2), precision="bf16", ppo_epoch=4, num_mini_batch=2,
-                 device="cuda", seed=0, weight_seed=0, sampling="host"):
+                 device="cuda", seed=0, weight_seed=0, sampling="host", use_graphs=True):
         from . import av_nav
         self.N, self.T, self.dev = num_envs, num_steps, torch.device(device)
         osp, asp = savi_observation_space(spectrogram), ActionSpace(4)
         torch.manual_seed(weight_seed)
         self.pol = P.AudioNavBaselinePolicy(osp, asp, "spectrogram", hidden_size=512, precision=precision,
-                                            sampling=sampling).to(self.dev)
+                                            sampling=sampling, use_graphs=use_graphs).to(self.dev)
         self.agent = av_nav.DDPPO(self.pol, clip_param=0.2, ppo_epoch=ppo_epoch, num_mini_batch=num_mini_batch,
                                   value_loss_coef=0.5, entropy_coef=0.01, lr=2.5e-4, eps=1e-5, max_grad_norm=0.5,
                                   use_normalized_advantage=False)

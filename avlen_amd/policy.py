@@ -202,13 +202,16 @@ def _tsig(a):
 
 def _memo_key(pol, which, mode, args):
     obs = args[0]
+    skip = (0,) if getattr(pol.net, "reads_rnn_state", False) else (0, 1, 3)
     return (which, mode, getattr(pol.net, "_text_key", None)) + tuple(_tsig(obs[k]) for k in pol.net.obs_keys) + tuple(
-        _tsig(a) if torch.is_tensor(a) else a for i, a in enumerate(args) if i not in (0, 1, 3))
+        _tsig(a) if torch.is_tensor(a) else a for i, a in enumerate(args) if i not in skip)
 
 
 def _graphed(pol, which, fn, args, mode=None):
-    # rnn_hidden_states (arg 1) and masks (arg 3) are not read by the SMT nets: keep them out of the graph
+    # rnn_hidden_states (arg 1) and masks (arg 3) are not read by the SMT nets: keep them out of the graph.  The GRU baseline
+    # (net.reads_rnn_state) reads both: they become staged inputs and the graph's new hidden state is returned.
     raw = args
+    keep_rnn = getattr(pol.net, "reads_rnn_state", False)
     # derived weights (packed convs, bf16 shadows) must be current BEFORE any replay: a load_state_dict / mark_params_changed
     # since the last call only set the dirty flag.  The leader of an EncoderGroup replays the followers' towers too.
     pol._engine()
@@ -232,11 +235,15 @@ def _graphed(pol, which, fn, args, mode=None):
         g.between = getattr(pol, "_between", None)
         outs, heads = g.replay_only()
         outs = list(outs)
-        outs[1] = raw[1]
+        if not keep_rnn:
+            outs[1] = raw[1]
         return tuple(outs), dict(heads)
     args = list(args)
     rnn = args[1]
-    args[1], args[3] = None, None
+    if keep_rnn:
+        args[1], args[3] = _f32(args[1]), _f32(args[3])
+    else:
+        args[1], args[3] = None, None
     args[0] = {k: (_img(v) if k == "rgb" else _f32(v)) for k, v in args[0].items() if k in pol.net.obs_keys}
     by_ptr = (4, 5) if which == "vln" else (4,)          # ext_memory (+ dialog memory): persistent ring buffers
     for i in by_ptr:
@@ -262,7 +269,7 @@ def _graphed(pol, which, fn, args, mode=None):
         # memoise when every tensor was used exactly as passed (no dtype / layout conversion made a temporary)
         followed = mode == "follow" and args[0] is grp.static_obs
         same = followed or all(args[0][k] is raw[0][k] for k in args[0])
-        same = same and all(args[i] is raw[i] for i in range(len(raw)) if i not in (0, 1, 3))
+        same = same and all(args[i] is raw[i] for i in range(len(raw)) if i != 0 and (keep_rnn or i not in (1, 3)))
         pairs = g.staging_pairs(args) if same else None
         if pairs is not None:
             mm = _Memo()
@@ -277,7 +284,8 @@ def _graphed(pol, which, fn, args, mode=None):
             pol._memos[mk] = mm
     outs, heads = g(args)
     outs = list(outs)
-    outs[1] = rnn
+    if not keep_rnn:
+        outs[1] = rnn
     return tuple(outs), dict(heads)
 
 
@@ -1183,6 +1191,7 @@ class AudioNavDialogNet(_SMTBase):
 
 class AudioNavBaselineNet(Net):
     """policy.py:379-498: [AudioCNN 512 | VisualCNN 512 | category 21] -> masked GRU (config 2)."""
+    reads_rnn_state = True            # a captured forward stages rnn_hidden_states / masks and returns the new hidden state
 
     def __init__(self, observation_space, hidden_size, goal_sensor_uuid, extra_rgb=False, use_mlp_state_encoder=False):
         super().__init__()
@@ -1190,6 +1199,7 @@ class AudioNavBaselineNet(Net):
             "avlen_amd implements the spectrogram-goal GRU baseline"
         self.goal_sensor_uuid, self._hidden_size = goal_sensor_uuid, hidden_size
         self._label = CATEGORY in observation_space.spaces
+        self.obs_keys = ("rgb", "depth", SPECTROGRAM) + ((CATEGORY,) if self._label else ())
         H, W, _ = observation_space.spaces["rgb"].shape
         self.visual_encoder = N.Cnn3Params(4, (H, W), N.VISUAL_GEOMETRY, hidden_size)
         sh, sw, sc = observation_space.spaces[SPECTROGRAM].shape
