@@ -19,8 +19,8 @@ from . import engine as E
 from . import nets as N
 from .policy import SPECTROGRAM, POSE, LOCATION_BELIEF, CATEGORY_BELIEF, CATEGORY, _f32
 
-_TWO_STREAMS = os.environ.get("AVLEN_BELIEF_STREAMS", "2") != "1"     # A/B knob: the two networks on two streams
-_SHARED_CAPTURE = os.environ.get("AVLEN_BELIEF_SHARED_CAPTURE", "1") != "0"
+_TWO_STREAMS = True          # the two networks run on two streams (decided by measurement)
+_SHARED_CAPTURE = True
 LABEL_PREDICTOR_PATH = "data/pretrained_weights/semantic_audionav/savi/label_predictor.pth"    # belief_predictor.py:96
 
 

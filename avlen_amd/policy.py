@@ -71,7 +71,7 @@ def _i64(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-_SPLIT = os.environ.get("AVLEN_SPLIT", "1") != "0"        # A/B knob: cut pi_l's forward in two around the text embedding
+_SPLIT = True        # pi_l's captured forward is cut in two around the text embedding (decided by measurement: DESIGN section 3)
 
 
 _CAP = None
