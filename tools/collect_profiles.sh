@@ -21,6 +21,7 @@ python3 $R/tools/step_trace.py $DB 150 40 > $O/step_trace.txt || exit 1
 # phase tables of the fused tower kernels (lab binaries built here: tools/bin is not tracked)
 if [ -x $R/tools/bin/head_lab0 ]; then $R/tools/bin/head_lab0 64 6 128 1 > $O/tower_head_phases.txt || exit 1; fi
 if [ -x $R/tools/bin/tail_lab ]; then $R/tools/bin/tail_lab 64 6 > $O/tower_tail_phases.txt || exit 1; fi
+if [ -f $O/tower_head_phases.txt ] && [ -f $O/tower_tail_phases.txt ]; then python3 $R/tools/tower_phase_table.py $O/tower_head_phases.txt $O/tower_tail_phases.txt > $O/tower_phase_table.md || exit 1; fi
 if [ -x $R/tools/bin/gridbar_lab ]; then $R/tools/bin/gridbar_lab 256 200 1 > $O/grid_barrier_probe.txt || exit 1; fi
 python3 $R/tools/text_split_probe.py 2>&1 | grep -E "us$|tokens" > $O/text_tower_scaling.txt || exit 1
 for c in FETCH_SIZE WRITE_SIZE; do
