@@ -26,3 +26,18 @@ def param_specs():
 @pytest.fixture(scope="session")
 def specs():
     return param_specs()
+
+
+@pytest.fixture(autouse=True)
+def _quiesce_gpu_between_tests(request):
+    """GPU tests build policies whose HIP graphs are destroyed when the garbage collector gets to them: do that here, with the
+    device idle, rather than at an arbitrary allocation inside the next test while its graphs replay."""
+    yield
+    if request.node.get_closest_marker("gpu") is None:
+        return
+    import gc
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+        gc.collect()
+        torch.cuda.synchronize()
