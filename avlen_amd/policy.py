@@ -259,6 +259,7 @@ def _graphed(pol, which, fn, args, mode=None):
     g = pol._graphs.get(key)
     if g is None:
         if len(pol._graphs) >= 16:
+            torch.cuda.synchronize()                     # a graph that is still executing must not be destroyed under the GPU
             pol._graphs.clear()
             pol._memos.clear()
         g = pol._graphs[key] = _Graph(pol, fn, args, by_ptr)
