@@ -78,3 +78,16 @@ def test_indexed_rows_equal_gathered_rows(towers):
     a = run_group(pol, rgb, depth, index=idx, rows=6)
     b = run_group(pol, rgb[idx.long()].contiguous(), depth[idx.long()].contiguous())
     assert torch.equal(a, b)
+
+
+def test_fragment_order_weight_copy():
+    """avlen_pack_conv_weight_frag: w16 [cout][K] -> [cout/16][K/32][lane = 16 q + r][8] with lane's chunk = w16[16 t + r][32 i + 8 q ..]."""
+    cout, K = 64, 576
+    w = torch.randn(cout, K, device="cuda").bfloat16()
+    f = torch.empty_like(w)
+    L.call("avlen_pack_conv_weight_frag", E.P(w), E.P(f), cout, K, L.stream())
+    torch.cuda.synchronize()
+    ref = w.view(cout // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()       # [t][i][q][r][8]
+    assert torch.equal(f.view(-1), ref.view(-1))
+    with pytest.raises(L.AvlenHipError):
+        L.call("avlen_pack_conv_weight_frag", E.P(w), E.P(f), 60, K, L.stream())            # cout % 16 != 0
