@@ -267,7 +267,7 @@ int avlen_smt_bwd(const avlen_smt* p, const avlen_smt* g, const float* goal, con
                   int pose_col, int current_token_only, int prec, float* d_x, int ld_dx, void* ws, size_t ws_bytes,
                   avlen_stream_t stream);
 /* Tuning knob: row count from which the training path's Linear products (avlen_smt_fwd with save_for_backward,
- * avlen_smt_bwd, bf16 mode) cast their fp32 operands to bf16 once and run the glds/MFMA GEMM (default 16384 rows). */
+ * avlen_smt_bwd, bf16 mode) cast their fp32 operands to bf16 once and run the glds/MFMA GEMM (default 4096 rows). */
 void avlen_set_big_m(long rows);
 /* DialogStateEncoder.single_forward (dialog_state_encoder.py:114-155): x_att (B,d), memory_state (M,B,d),
  * masks (B,M), d_emb (B,d) or NULL, agent_step (B) float, goal (B,d) -> out (B,d). */

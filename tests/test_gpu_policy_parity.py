@@ -392,7 +392,7 @@ def test_gradients_match_oracle_autograd(specs):
 
 def test_gradients_bf16_training_products(specs):
     """bf16 mode of the same backward on its two GEMM routes: the fp32-staged kernel and the large-M route (operands cast /
-    transposed to bf16 once, glds MFMA GEMM, split-K weight gradients; default from 16384 rows, forced here from 32).
+    transposed to bf16 once, glds MFMA GEMM, split-K weight gradients; default from 4096 rows, forced here from 32).
     The two BACKWARD routes run on the SAME saved forward and the same upstream gradient: identical bf16-rounded operands, only
     the fp32 summation order differs -> 5e-3 of each tensor's norm (the pose-encoder bias gradient is a cancelling sum).  (Against fp32 autograd a 6-sample bf16 gradient is only
     loosely comparable -- a bf16 ulp in the towers moves the action probabilities; that side is bounded by the bf16 policy
