@@ -133,3 +133,27 @@ def test_update_dialog_gradients_match_oracle_autograd(with_dialog):
     for gk, e_ in groups.items():
         assert e_ < (2e-2 if "visual_encoder" in gk else 1e-3), (gk, e_)
 
+
+
+def test_derived_weights_follow_a_dialog_update():
+    """update_dialog trains pi_l's visual towers: after the step the bf16 fast path (fused tower kernels: packed bf16 conv weights
+    and their fragment-order copies, bf16 shadows of the Linear layers) must compute with the UPDATED weights -- same features as a
+    fresh policy that loaded the updated state_dict."""
+    pol, agent, st, _ = setup(precision="bf16")
+    obs = {k: v[0] for k, v in st.observations.items()}
+    pa = st.prev_actions[0]
+    before, _ = pol.net.features(pol, obs, pa)
+    before = before[:, :276].clone()
+    for g in agent.dialog_optimizer.param_groups:
+        g["lr"] = 1e-2                                   # a step large enough to move the towers' output visibly
+    agent.update_dialog(st)
+    after, _ = pol.net.features(pol, obs, pa)
+    after = after[:, :276].clone()
+    fresh = P.AudioNavDialogPolicy(savi_observation_space(), ActionSpace(4), pretraining=False, use_category_input=False,
+                                   num_steps=3, precision="bf16", **SMT_KW)
+    fresh.load_state_dict(pol.state_dict())
+    fresh.cuda()
+    ref, _ = fresh.net.features(fresh, obs, pa)
+    torch.cuda.synchronize()
+    assert float((after - before).abs().max()) > 1e-3            # the step reached the towers
+    assert torch.equal(after, ref[:, :276])                       # and every derived copy followed it
