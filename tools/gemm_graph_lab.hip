@@ -11,6 +11,8 @@ int main(int argc, char** argv) {
   const int max_abl = argc > 1 ? atoi(argv[1]) : 0;
   const int ns_override = argc > 2 ? atoi(argv[2]) : 0;      // stage count for every shape (0: the dispatcher's choice)
   const int nth_override = argc > 3 ? atoi(argv[3]) : 512;   // 256: the 4-wave instance (32x64 wave tiles)
+  const int split_override = argc > 4 ? atoi(argv[4]) : 0;   // split-K factor (GEMM + reduce kernel per node pair)
+  g_lab_cfg[4] = split_override;
   if (ns_override) { g_lab_cfg[0] = 64; g_lab_cfg[1] = 128; g_lab_cfg[2] = nth_override; g_lab_cfg[3] = ns_override; }
   const int shapes[][3] = {{2464, 1536, 512}, {2464, 512, 512}, {2464, 2048, 512}, {2464, 512, 2048},
                            {320, 1536, 512}, {320, 512, 512}, {320, 2048, 512}, {320, 512, 2048}};
