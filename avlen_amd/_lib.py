@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libavlen_hip.so")
 
-PREC_FP32, PREC_BF16 = 0, 1
+PREC_FP32, PREC_BF16, PREC_BF16X3, PREC_FP16 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_QUICKGELU = 0, 1, 2
 
 _ERR = {1: "bad argument", 2: "kernel launch failed", 3: "workspace too small / missing"}
@@ -33,12 +33,13 @@ vp = C.c_void_p
 
 
 class Linear(C.Structure):
-    _fields_ = [("w", f32p), ("b", f32p), ("out_f", C.c_int), ("in_f", C.c_int), ("w16", vp), ("ld16", C.c_int)]
+    _fields_ = [("w", f32p), ("b", f32p), ("out_f", C.c_int), ("in_f", C.c_int), ("w16", vp), ("ld16", C.c_int), ("w16lo", vp)]
 
 
 class Conv(C.Structure):
     _fields_ = [("w", f32p), ("b", f32p), ("cin", C.c_int), ("cout", C.c_int), ("kh", C.c_int), ("kw", C.c_int),
-                ("stride", C.c_int), ("pad", C.c_int), ("w16", vp), ("cin16", C.c_int), ("w16c", vp), ("w16f", vp)]
+                ("stride", C.c_int), ("pad", C.c_int), ("w16", vp), ("cin16", C.c_int), ("w16c", vp), ("w16f", vp), ("w16lo", vp),
+                ("w16flo", vp)]
 
 
 class Affine(C.Structure):
@@ -96,7 +97,7 @@ class ClipBlock(C.Structure):
 class ClipText(C.Structure):
     _fields_ = [("tok_emb", f32p), ("pos_emb", f32p), ("block", ClipBlock * 12), ("ln_final", Affine),
                 ("text_proj", f32p), ("vocab", C.c_int), ("ctx", C.c_int), ("width", C.c_int), ("heads", C.c_int),
-                ("layers", C.c_int), ("out_dim", C.c_int)]
+                ("layers", C.c_int), ("out_dim", C.c_int), ("half_fmt", C.c_int)]
 
 
 class Gru(C.Structure):
@@ -126,6 +127,8 @@ SIGNATURES = {
     "avlen_conv2d_nhwc_bf16": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     "avlen_conv_direct_bf16": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "avlen_cast_bf16": (i32, [vp, i32, vp, i32, C.c_long, i32, vp]),
+    "avlen_cast_h16": (i32, [vp, i32, vp, i32, C.c_long, i32, i32, vp]),
+    "avlen_gemm_h16": (i32, [vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     "avlen_pack_conv_weight_bf16": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "avlen_pack_conv_weight_frag": (i32, [vp, vp, i32, i32, vp]),
     "avlen_pack_fc_after_flatten_bf16": (i32, [vp, vp, i32, i32, i32, vp]),
@@ -206,6 +209,7 @@ SIGNATURES = {
     "avlen_copy_rows": (i32, [vp, i32, vp, i32, i32, i32, vp]),
     "avlen_multi_copy": (i32, [vp, vp, vp, i32, vp]),
     "avlen_ln_fold_weights": (i32, [vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, vp]),
+    "avlen_ln_fold_weights_h16": (i32, [vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, vp]),
     "avlen_build_info": (C.c_char_p, []),
 }
 

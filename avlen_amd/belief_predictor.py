@@ -36,7 +36,7 @@ class BeliefPredictor(nn.Module):
         self.predict_location = belief_config.use_location_belief
         self.has_distractor_sound = has_distractor_sound
         self.precision = precision
-        self.prec = {"fp32": L.PREC_FP32, "bf16": L.PREC_BF16}[precision]
+        self.prec = {"fp32": L.PREC_FP32, "bf16": L.PREC_BF16, "bf16x3": L.PREC_BF16X3}[precision]
         if self.predict_location:
             if not belief_config.online_training:
                 # belief_predictor.py:74-77 swaps in an ImageNet-pretrained torchvision resnet18 with a 23-way head

@@ -345,6 +345,19 @@ __global__ __launch_bounds__(256) void attn_mfma64_kernel(const float* __restric
 // consecutive output dims per lane -> 8-byte stores.  The softmax reductions are in-lane + 2 cross-lane moves.
 typedef __attribute__((ext_vector_type(4))) __bf16 abf16x4;
 
+typedef __attribute__((ext_vector_type(8))) _Float16 af16x8;
+typedef __attribute__((ext_vector_type(4))) short ai16x4;
+template <bool F16> __device__ __forceinline__ af32x4 amfma16(const abf16x8& a, const abf16x8& b, const af32x4& c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(af16x8, a), __builtin_bit_cast(af16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+template <bool F16> __device__ __forceinline__ __bf16 ato16(float v) {
+  if constexpr (F16) return __builtin_bit_cast(__bf16, (_Float16)v);
+  else return (__bf16)v;
+}
+
+// F16: the packed projection and the output hold IEEE half values (same byte layout; the transposing LDS read moves 16-bit words)
+template <bool F16>
 __global__ __launch_bounds__(256) void attn_qkv16_kernel(const __bf16* __restrict__ QKV, int ld, int koff, int voff,
                                                          __bf16* __restrict__ O16, int ldo16, int S, int causal, float scale,
                                                          const int* __restrict__ seg_off) {
@@ -384,7 +397,7 @@ __global__ __launch_bounds__(256) void attn_qkv16_kernel(const __bf16* __restric
       for (int nt = 0; nt < 6; nt++)
         if (nt < n_kt) {
           abf16x8 kf = *reinterpret_cast<const abf16x8*>(&ks[(nt * 16 + r16) * KR + kk * 32 + q4 * 8]);
-          sacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, sacc[nt], 0, 0, 0);
+          sacc[nt] = amfma16<F16>(kf, qf, sacc[nt]);
         }
     }
     const int qi = mt * 16 + r16;
@@ -418,7 +431,7 @@ __global__ __launch_bounds__(256) void attn_qkv16_kernel(const __bf16* __restric
       if (kk < n_kk) {
         abf16x8 pf;
 #pragma unroll
-        for (int e = 0; e < 4; e++) { pf[e] = (__bf16)sacc[2 * kk][e]; pf[4 + e] = (__bf16)sacc[2 * kk + 1][e]; }
+        for (int e = 0; e < 4; e++) { pf[e] = ato16<F16>(sacc[2 * kk][e]); pf[4 + e] = ato16<F16>(sacc[2 * kk + 1][e]); }
         const __bf16* vb = &vs[(kk * 32 + q4 * 4 + (r16 >> 2)) * KR + 4 * (r16 & 3)];
 #pragma unroll
         for (int dt = 0; dt < 4; dt++) {
@@ -427,7 +440,7 @@ __global__ __launch_bounds__(256) void attn_qkv16_kernel(const __bf16* __restric
           abf16x8 vf;
 #pragma unroll
           for (int e = 0; e < 4; e++) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
-          oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[dt], 0, 0, 0);
+          oacc[dt] = amfma16<F16>(vf, pf, oacc[dt]);
         }
       }
     if (qi < S) {
@@ -437,7 +450,7 @@ __global__ __launch_bounds__(256) void attn_qkv16_kernel(const __bf16* __restric
       for (int dt = 0; dt < 4; dt++) {
         abf16x4 o;
 #pragma unroll
-        for (int r = 0; r < 4; r++) o[r] = (__bf16)(oacc[dt][r] * inv);
+        for (int r = 0; r < 4; r++) o[r] = ato16<F16>(oacc[dt][r] * inv);
         *reinterpret_cast<abf16x4*>(op + dt * 16) = o;
       }
     }
@@ -761,10 +774,14 @@ int avlen_attention_q1(const float* Q, int ldq, const float* K, int ldk, const f
 
 // Packed bf16 projection [R][ld] with q | k | v at columns 0 | H*64 | 2*H*64 (head h at +64h) -> O16 [R][ldo16].
 int avlen_attention_qkv16(const void* QKV16, int ld, void* O16, int ldo16, int B, int H, int S, int causal, float scale,
-                          const int* seg_off, hipStream_t stream) {
+                          const int* seg_off, hipStream_t stream, int f16) {
   if (!QKV16 || !O16 || B <= 0 || H <= 0 || S <= 0 || S > 96 || (ld & 7) || (ldo16 & 3)) return AVLEN_ERR_ARG;
-  hipLaunchKernelGGL(attn_qkv16_kernel, dim3(H, B), dim3(256), 0, stream, (const __bf16*)QKV16, ld, H * 64, 2 * H * 64,
-                     (__bf16*)O16, ldo16, S, causal, scale, seg_off);
+  if (f16)
+    hipLaunchKernelGGL(attn_qkv16_kernel<true>, dim3(H, B), dim3(256), 0, stream, (const __bf16*)QKV16, ld, H * 64, 2 * H * 64,
+                       (__bf16*)O16, ldo16, S, causal, scale, seg_off);
+  else
+    hipLaunchKernelGGL(attn_qkv16_kernel<false>, dim3(H, B), dim3(256), 0, stream, (const __bf16*)QKV16, ld, H * 64, 2 * H * 64,
+                       (__bf16*)O16, ldo16, S, causal, scale, seg_off);
   return avlen_launch_status();
 }
 

@@ -14,6 +14,9 @@
 // arithmetic modes share the structure:
 //   BF16: operands rounded to bf16 while staging, v_mfma_f32_16x16x32_bf16, fp32 accumulate
 //   FP32: v_mfma_f32_16x16x4_f32 (exact fp32 fma chain) -- the parity mode
+//   X3  : compensated bf16 ("bf16x3"): every fp32 operand is split while staging into hi = bf16(x) and lo = bf16(x - hi), and
+//         a product is three bf16 MFMAs (lo*hi + hi*lo + hi*hi) into the same fp32 accumulator: ~2^-17 relative error per
+//         product instead of 2^-9, at 3/16 of the fp32 MFMA's cycles
 // Epilogue: + bias, ReLU / QuickGELU, + residual, fp32 store; or split-K slabs reduced by
 // avlen_splitk_reduce (deterministic, no atomics).
 #include "common.h"
@@ -40,8 +43,9 @@ struct IgemmParams {
   int a_vec, b_vec;        // 16-byte vector loads allowed along the contiguous dim
 };
 
-template <bool BF16> struct Elem { using T = float; static constexpr int LDS = 36; };
-template <> struct Elem<true> { using T = __bf16; static constexpr int LDS = 40; };
+constexpr int MODE_FP32 = 0, MODE_BF16 = 1, MODE_X3 = 2;
+template <int MODE> struct Elem { using T = __bf16; static constexpr int LDS = 40; };
+template <> struct Elem<MODE_FP32> { using T = float; static constexpr int LDS = 36; };
 
 __device__ __forceinline__ float act_apply(float v, int act) {
   if (act == 1) return fmaxf(v, 0.f);
@@ -49,16 +53,19 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   return v;
 }
 
-template <int BN, bool BF16>
+template <int BN, int MODE>
 __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
-  using T = typename Elem<BF16>::T;
-  constexpr int LDS = Elem<BF16>::LDS;
+  using T = typename Elem<MODE>::T;
+  constexpr int LDS = Elem<MODE>::LDS;
+  constexpr bool BF16 = MODE == MODE_BF16, X3 = MODE == MODE_X3;
   constexpr int NI = BN / 16;
   constexpr int A_IT = BM * 8 / NTHREADS;                      // float4 per thread for the A tile (=4)
   constexpr int B_IT = (BN * 8 + NTHREADS - 1) / NTHREADS;     // >= 1
 
   __shared__ __attribute__((aligned(16))) T As[BM * LDS];
   __shared__ __attribute__((aligned(16))) T Bs[BN * LDS];
+  __shared__ __attribute__((aligned(16))) T Al[X3 ? BM * LDS : 8];       // X3: the low halves of the split operands
+  __shared__ __attribute__((aligned(16))) T Bl[X3 ? BN * LDS : 8];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n_tiles = (p.N + BN - 1) / BN;
@@ -201,14 +208,24 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
     }
   };
 
-  auto put4 = [&](T* dst, float4 v) {          // 4 consecutive k of one LDS row
-    if constexpr (BF16) {
+  auto put4 = [&](T* dst, T* dst_lo, float4 v) {          // 4 consecutive k of one LDS row
+    if constexpr (BF16 || X3) {
       typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
       bf16x4 o; o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
       *reinterpret_cast<bf16x4*>(dst) = o;
+      if constexpr (X3) {
+        bf16x4 l; l[0] = (__bf16)(v.x - (float)o[0]); l[1] = (__bf16)(v.y - (float)o[1]);
+        l[2] = (__bf16)(v.z - (float)o[2]); l[3] = (__bf16)(v.w - (float)o[3]);
+        *reinterpret_cast<bf16x4*>(dst_lo) = l;
+      }
     } else {
       *reinterpret_cast<float4*>(dst) = v;
     }
+  };
+  auto put1 = [&](T* dst, T* dst_lo, float v) {
+    const T h = (T)v;
+    *dst = h;
+    if constexpr (X3) *dst_lo = (T)(v - (float)h);
   };
 
   auto store_a = [&]() {
@@ -219,11 +236,14 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
         int kk = f / (BM / 4), mq = f % (BM / 4);
         float t[4] = {a_reg[i].x, a_reg[i].y, a_reg[i].z, a_reg[i].w};
 #pragma unroll
-        for (int j = 0; j < 4; j++) As[(mq * 4 + j) * LDS + kk] = (T)t[j];
+        for (int j = 0; j < 4; j++) put1(&As[(mq * 4 + j) * LDS + kk], &Al[X3 ? (mq * 4 + j) * LDS + kk : 0], t[j]);
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < A_IT; i++) put4(&As[((tid >> 3) + i * 32) * LDS + (tid & 7) * 4], a_reg[i]);
+      for (int i = 0; i < A_IT; i++) {
+        const int o = ((tid >> 3) + i * 32) * LDS + (tid & 7) * 4;
+        put4(&As[o], &Al[X3 ? o : 0], a_reg[i]);
+      }
     }
   };
   auto store_b = [&]() {
@@ -235,9 +255,10 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
           int kk = f / (BN / 4), nq = f % (BN / 4);
           float t[4] = {b_reg[i].x, b_reg[i].y, b_reg[i].z, b_reg[i].w};
 #pragma unroll
-          for (int j = 0; j < 4; j++) Bs[(nq * 4 + j) * LDS + kk] = (T)t[j];
+          for (int j = 0; j < 4; j++) put1(&Bs[(nq * 4 + j) * LDS + kk], &Bl[X3 ? (nq * 4 + j) * LDS + kk : 0], t[j]);
         } else {
-          put4(&Bs[(f >> 3) * LDS + (f & 7) * 4], b_reg[i]);
+          const int o = (f >> 3) * LDS + (f & 7) * 4;
+          put4(&Bs[o], &Bl[X3 ? o : 0], b_reg[i]);
         }
       }
     }
@@ -270,6 +291,26 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
 #pragma unroll
         for (int ni = 0; ni < NI; ni++)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+    } else if constexpr (X3) {
+      bf16x8 ah[2], al[2], bh[NI], bl[NI];
+#pragma unroll
+      for (int mi = 0; mi < 2; mi++) {
+        ah[mi] = *reinterpret_cast<const bf16x8*>(&As[(wave * 32 + mi * 16 + r16) * LDS + q * 8]);
+        al[mi] = *reinterpret_cast<const bf16x8*>(&Al[(wave * 32 + mi * 16 + r16) * LDS + q * 8]);
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ni++) {
+        bh[ni] = *reinterpret_cast<const bf16x8*>(&Bs[(ni * 16 + r16) * LDS + q * 8]);
+        bl[ni] = *reinterpret_cast<const bf16x8*>(&Bl[(ni * 16 + r16) * LDS + q * 8]);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++) {                      // small terms first, then the leading product
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+        }
     } else {
 #pragma unroll
       for (int kk = 0; kk < BK / 4; kk++) {
@@ -370,7 +411,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __re
   *o = (beta != 0.f) ? beta * (*o) + s : s;
 }
 
-template <bool BF16>
+template <int BF16>
 int launch_igemm(const IgemmParams& p, hipStream_t st) {
   int bn = p.N <= 16 ? 16 : p.N <= 32 ? 32 : p.N <= 64 ? 64 : 128;
   int n_tiles = ceil_div(p.N, bn), m_tiles = ceil_div(p.M, BM);
@@ -423,7 +464,8 @@ static int run_igemm(IgemmParams p, int prec, float beta, void* ws, size_t ws_by
     if (!ws || ws_bytes < avlen_gemm_workspace_bytes(p.M, p.N, p.K, splits)) return AVLEN_ERR_WS;
     p.C = (float*)ws;
   }
-  int rc = (prec == AVLEN_PREC_BF16) ? launch_igemm<true>(p, st) : launch_igemm<false>(p, st);
+  int rc = prec == AVLEN_PREC_BF16 ? launch_igemm<MODE_BF16>(p, st)
+         : prec == AVLEN_PREC_BF16X3 ? launch_igemm<MODE_X3>(p, st) : launch_igemm<MODE_FP32>(p, st);
   if (rc != AVLEN_OK) return rc;
   if (p.to_slab) {
     long tot = (long)p.M * p.N;

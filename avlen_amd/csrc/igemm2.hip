@@ -15,6 +15,7 @@
 //  * small grids split K across blockIdx.z into fp32 slabs (deterministic reduce, no atomics).
 #include "common.h"
 #include "../../include/avlen_hip.h"
+#include "internal.h"
 #include <stdlib.h>
 #include <stdint.h>
 
@@ -49,6 +50,13 @@ struct G2 {
   float* slab;
   const int* M_dev;           // optional: the live row count (<= M) is read from device memory (ragged batches)
   float* stats; int ohw;      // optional GroupNorm statistics: stats[sample][0|1][N] += sum / sum of squares of C
+  // 16-bit operand format: 0 = bf16, 1 = fp16 (IEEE half; v_mfma_f32_16x16x32_f16, C16 written as fp16)
+  int f16;
+  // Compensated bf16 ("bf16x3"): every operand is a PAIR of bf16 planes, hi = bf16(x) and lo = bf16(x - hi), the lo plane
+  // `a_lo` / `b_lo` BYTES behind the hi plane (same layout).  The K loop runs three passes over K -- (A_lo, W_hi),
+  // (A_hi, W_lo), (A_hi, W_hi) -- into the same fp32 accumulators: the product is exact to ~2^-17 per term instead of 2^-9.
+  // c16_lo (elements): the bf16 output is written as a pair too, lo plane at C16 + c16_lo.  x3 == 0: plain bf16.
+  int x3; long a_lo, b_lo, c16_lo;
 #ifdef AVLEN_G2_LAB
   int ablate;                 // tools/gemm_lab.hip only: 1 = no fragment reads / MFMA, 2 = no staging loads, 4 = no C stores
 #endif
@@ -84,7 +92,19 @@ __device__ __forceinline__ float4 ld4(const float* base, long off, int col, int 
 // then issue their share of the staging loads, waves 4-7 issue first and multiply after -- so that on every SIMD one wave's
 // MFMAs run under the other wave's global_load_lds issue (a 1 KiB piece holds its wave for ~60-100 cycles; measured on the
 // 4-wave kernel the two costs simply add: tools/gemm_lab.hip).
-template <int BM, int BN, int WM, int WN, int NS, int NTH, bool CONV>
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+template <bool F16> __device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// fp32 -> the 16-bit storage format (bit pattern in a bf16-typed slot)
+template <bool F16> __device__ __forceinline__ bf16 to16(float v) {
+  if constexpr (F16) return __builtin_bit_cast(bf16, (_Float16)v);
+  else return (bf16)v;
+}
+
+template <int BM, int BN, int WM, int WN, int NS, int NTH, bool CONV, bool F16 = false>
 __global__ __launch_bounds__(NTH) void g2_kernel(G2 pp) {
   G2 p = pp;
   {
@@ -122,7 +142,8 @@ __global__ __launch_bounds__(NTH) void g2_kernel(G2 pp) {
     const int t = (label < rr ? label * (qq + 1) : rr * (qq + 1) + (label - rr) * qq) + idx;
     m0 = (t / n_tiles) * BM; n0 = (t % n_tiles) * BN;
   }
-  const int nk_total = (p.K + BK - 1) / BK;
+  const int nk_pass = (p.K + BK - 1) / BK;                    // K-steps of one pass over K
+  const int nk_total = p.x3 ? 3 * nk_pass : nk_pass;
   const int kt_beg = blockIdx.z * p.ksteps_per_split;
   const int kt_end = min(nk_total, kt_beg + p.ksteps_per_split);
 
@@ -158,7 +179,10 @@ __global__ __launch_bounds__(NTH) void g2_kernel(G2 pp) {
   auto issue = [&](int kt, int stage) {
     char* abase = lds + stage * STAGE;
     char* bbase = abase + A_BYTES;
-    const int k0 = kt * BK;
+    // bf16x3: pass 0 = (A_lo, W_hi), pass 1 = (A_hi, W_lo), pass 2 = (A_hi, W_hi)
+    const int pass = (kt >= nk_pass) + (kt >= 2 * nk_pass);
+    const long a_off = (p.x3 && pass == 0) ? p.a_lo : 0, b_off = (p.x3 && pass == 1) ? p.b_lo : 0;
+    const int k0 = (kt - pass * nk_pass) * BK;
     // the swizzle term ((row>>1)&7) is the same for all of a thread's rows (they are >= 32 rows apart), so the k offset --
     // and, for convolutions, the tap decode -- is computed once per K-step and shared by the A_ROUNDS gathers
     const int ka = k0 + a_sw[0];
@@ -175,9 +199,9 @@ __global__ __launch_bounds__(NTH) void g2_kernel(G2 pp) {
       if (CONV) {
         int iy = a_iy0[r] + ky, ix = a_ix0[r] + kx;
         if (a_ok[r] && k_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-          src = a_src[r] + (((long)iy * p.W + ix) * p.Cin + ci) * 2;
+          src = a_src[r] + (((long)iy * p.W + ix) * p.Cin + ci) * 2 + a_off;
       } else if (k_ok) {
-        src = a_src[r] + (long)ka * 2;
+        src = a_src[r] + (long)ka * 2 + a_off;
       }
       __builtin_amdgcn_global_load_lds((const void*)src,
           (__attribute__((address_space(3))) void*)(abase + (r * NTH + wave * 64) * 16), 16, 0, 0);
@@ -185,7 +209,7 @@ __global__ __launch_bounds__(NTH) void g2_kernel(G2 pp) {
 #pragma unroll
     for (int r = 0; r < B_ROUNDS; r++) {
       int k = k0 + b_sw[r];
-      const char* src = (k < p.K) ? b_src[r] + (long)k * 2 : zero;
+      const char* src = (k < p.K) ? b_src[r] + (long)k * 2 + b_off : zero;
       __builtin_amdgcn_global_load_lds((const void*)src,
           (__attribute__((address_space(3))) void*)(bbase + (r * NTH + wave * 64) * 16), 16, 0, 0);
     }
@@ -254,7 +278,7 @@ __global__ __launch_bounds__(NTH) void g2_kernel(G2 pp) {
         for (int i = 0; i < MI; i++)
 #pragma unroll
           for (int j = 0; j < NI; j++)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = mfma16<F16>(bfr[j], af[i], acc[i][j]);
       }
     }
     if (more && !loads_first) issue(kt_beg + it + NS - 1, (it + NS - 1) % NS);
@@ -386,15 +410,25 @@ __global__ __launch_bounds__(NTH) void g2_kernel(G2 pp) {
         if (p.C16) {
           bf16x4 o;
 #pragma unroll
-          for (int r = 0; r < 4; r++) o[r] = (bf16)acc[i][j][r];
+          for (int r = 0; r < 4; r++) o[r] = to16<F16>(acc[i][j][r]);
           *reinterpret_cast<bf16x4*>(p.C16 + (long)row * p.ldc16 + col) = o;
+          if (!F16 && p.c16_lo) {
+            bf16x4 l;
+#pragma unroll
+            for (int r = 0; r < 4; r++) l[r] = (bf16)(acc[i][j][r] - (float)o[r]);
+            *reinterpret_cast<bf16x4*>(p.C16 + p.c16_lo + (long)row * p.ldc16 + col) = l;
+          }
         }
       } else {
 #pragma unroll
         for (int r = 0; r < 4; r++)
           if (col + r < p.N) {
             if (p.C32) p.C32[(long)row * p.ldc32 + col + r] = acc[i][j][r];
-            if (p.C16) p.C16[(long)row * p.ldc16 + col + r] = (bf16)acc[i][j][r];
+            if (p.C16) {
+              const bf16 hv = to16<F16>(acc[i][j][r]);
+              p.C16[(long)row * p.ldc16 + col + r] = hv;
+              if (!F16 && p.c16_lo) p.C16[p.c16_lo + (long)row * p.ldc16 + col + r] = (bf16)(acc[i][j][r] - (float)hv);
+            }
           }
       }
     }
@@ -434,8 +468,14 @@ __global__ __launch_bounds__(NTH) void g2_kernel(G2 pp) {
 
 // Deterministic split-K reduction + epilogue; blockIdx.y = group (all groups of a grouped launch in one pass).
 struct G2Red { G2Grp g[MAXG]; const float* slab; };
+__device__ __forceinline__ void put16(bf16* C16, long idx, float v, int f16, long c16_lo) {
+  if (f16) { C16[idx] = to16<true>(v); return; }
+  const bf16 h = (bf16)v;
+  C16[idx] = h;
+  if (c16_lo) C16[c16_lo + idx] = (bf16)(v - (float)h);
+}
 __global__ void g2_reduce_kernel(G2Red rr, int M, int N, int ldc32, int ldc16, int ldr, int splits, int act,
-                                 const int* __restrict__ M_dev) {
+                                 const int* __restrict__ M_dev, int f16, long c16_lo) {
   const G2Grp g = rr.g[blockIdx.y];
   const long tot = (long)M * N;
   const float* __restrict__ slab = rr.slab + (size_t)blockIdx.y * splits * tot;
@@ -458,7 +498,7 @@ __global__ void g2_reduce_kernel(G2Red rr, int M, int N, int ldc32, int ldc16, i
       if (g.residual) v += g.residual[(long)row * ldr + col + r];
       if (act == AVLEN_ACT_RELU_POST) v = fmaxf(v, 0.f);
       if (g.C32) g.C32[(long)row * ldc32 + col + r] = v;
-      if (g.C16) g.C16[(long)row * ldc16 + col + r] = (bf16)v;
+      if (g.C16) put16(g.C16, (long)row * ldc16 + col + r, v, f16, c16_lo);
     }
     return;
   }
@@ -473,16 +513,22 @@ __global__ void g2_reduce_kernel(G2Red rr, int M, int N, int ldc32, int ldc16, i
     if (g.residual) s += g.residual[(long)row * ldr + col];
     if (act == AVLEN_ACT_RELU_POST) s = fmaxf(s, 0.f);
     if (g.C32) g.C32[(long)row * ldc32 + col] = s;
-    if (g.C16) g.C16[(long)row * ldc16 + col] = (bf16)s;
+    if (g.C16) put16(g.C16, (long)row * ldc16 + col, s, f16, c16_lo);
   }
 }
 
+// fp32 -> 16-bit storage: fmt 0 = bf16, 1 = fp16, 2 = the bf16 LOW plane of the compensated pair (bf16(x - bf16(x)))
+__device__ __forceinline__ bf16 cvt16(float v, int fmt) {
+  if (fmt == 1) return to16<true>(v);
+  const bf16 h = (bf16)v;
+  return fmt == 2 ? (bf16)(v - (float)h) : h;
+}
 // fp32 -> bf16 with row padding (pad columns zero-filled)
-__global__ void cast_rows_kernel(const float* __restrict__ src, int lds_, bf16* __restrict__ dst, int ldd, long rows, int cols) {
+__global__ void cast_rows_kernel(const float* __restrict__ src, int lds_, bf16* __restrict__ dst, int ldd, long rows, int cols, int fmt) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * ldd) return;
   long r = i / ldd; int c = (int)(i - r * ldd);
-  dst[i] = c < cols ? (bf16)src[r * lds_ + c] : (bf16)0.f;
+  dst[i] = c < cols ? cvt16(src[r * lds_ + c], fmt) : (bf16)0.f;
 }
 
 __global__ void cast_rows_indexed_kernel(const float* __restrict__ src, int lds_, bf16* __restrict__ dst, int ldd, long rows, int cols,
@@ -495,7 +541,7 @@ __global__ void cast_rows_indexed_kernel(const float* __restrict__ src, int lds_
 }
 
 // Same cast, 8 elements (32 B in, 16 B out) per thread: both leading dimensions multiples of 8 and 16-byte aligned bases
-__global__ void cast_rows8_kernel(const float* __restrict__ src, int lds_, bf16* __restrict__ dst, int ldd, long rows, int cols) {
+__global__ void cast_rows8_kernel(const float* __restrict__ src, int lds_, bf16* __restrict__ dst, int ldd, long rows, int cols, int fmt) {
   const int per_row = ldd >> 3;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * per_row) return;
@@ -503,10 +549,17 @@ __global__ void cast_rows8_kernel(const float* __restrict__ src, int lds_, bf16*
   bf16x8 o;
   if (c + 8 <= cols) {
     const float4 a = *reinterpret_cast<const float4*>(src + r * lds_ + c), b = *reinterpret_cast<const float4*>(src + r * lds_ + c + 4);
-    o[0] = (bf16)a.x; o[1] = (bf16)a.y; o[2] = (bf16)a.z; o[3] = (bf16)a.w; o[4] = (bf16)b.x; o[5] = (bf16)b.y; o[6] = (bf16)b.z; o[7] = (bf16)b.w;
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    if (fmt == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) o[e] = (bf16)v[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; e++) o[e] = cvt16(v[e], fmt);
+    }
   } else {
 #pragma unroll
-    for (int e = 0; e < 8; e++) o[e] = c + e < cols ? (bf16)src[r * lds_ + c + e] : (bf16)0.f;
+    for (int e = 0; e < 8; e++) o[e] = c + e < cols ? cvt16(src[r * lds_ + c + e], fmt) : (bf16)0.f;
   }
   *reinterpret_cast<bf16x8*>(dst + r * ldd + c) = o;
 }
@@ -535,7 +588,7 @@ __global__ void pack_fc_bf16_kernel(const float* __restrict__ w, bf16* __restric
 __global__ __launch_bounds__(256) void ln_fold_kernel(const float* __restrict__ W, const float* __restrict__ bias,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       bf16* __restrict__ w16f, int ld16, float* __restrict__ s,
-                                                      float* __restrict__ c, int K) {
+                                                      float* __restrict__ c, int K, int fmt) {
   __shared__ float sh[16];
   const int n = blockIdx.x;
   float sa = 0.f, ca = 0.f;
@@ -543,8 +596,9 @@ __global__ __launch_bounds__(256) void ln_fold_kernel(const float* __restrict__ 
     bf16 wf = (bf16)0.f;
     if (k < K) {
       const float w = W[(long)n * K + k];
-      wf = (bf16)(w * gamma[k]);
-      sa += (float)wf; ca += beta[k] * w;
+      if (fmt == 1) { const _Float16 hv = (_Float16)(w * gamma[k]); wf = __builtin_bit_cast(bf16, hv); sa += (float)hv; }
+      else { wf = (bf16)(w * gamma[k]); sa += (float)wf; }
+      ca += beta[k] * w;
     }
     w16f[(long)n * ld16 + k] = wf;
   }
@@ -553,21 +607,30 @@ __global__ __launch_bounds__(256) void ln_fold_kernel(const float* __restrict__ 
   if (threadIdx.x == 0) { s[n] = sa; c[n] = ca + (bias ? bias[n] : 0.f); }
 }
 
-template <int BM, int BN, int WM, int WN, int NS, int NTH, bool CONV>
+template <int BM, int BN, int WM, int WN, int NS, int NTH, bool CONV, bool F16 = false>
 int launch_cv(const G2& p, int m_tiles, int n_tiles, hipStream_t st) {
   size_t lds = (size_t)NS * (BM * 128 + (BN * 8 >= NTH ? BN * 128 : NTH * 16));
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&g2_kernel<BM, BN, WM, WN, NS, NTH, CONV>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&g2_kernel<BM, BN, WM, WN, NS, NTH, CONV, F16>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((g2_kernel<BM, BN, WM, WN, NS, NTH, CONV>), dim3(m_tiles * n_tiles, p.groups, p.splitk), dim3(NTH), lds, st, p);
+  hipLaunchKernelGGL((g2_kernel<BM, BN, WM, WN, NS, NTH, CONV, F16>), dim3(m_tiles * n_tiles, p.groups, p.splitk), dim3(NTH), lds, st, p);
   return avlen_launch_status();
 }
-// the implicit-GEMM gather (tap decode, bounds tests) is compiled out of the plain-GEMM instances
+// the implicit-GEMM gather (tap decode, bounds tests) is compiled out of the plain-GEMM instances; fp16 operands are
+// instantiated for the tiles their users reach: plain GEMMs on the 8-wave 128-column tiles (CLIP text tower, dialog_layer) and
+// convolutions on the 4-wave small-N tiles and the 8-wave 64-column tile (AudioCNN)
 template <int BM, int BN, int WM, int WN, int NS, int NTH>
 int launch_ns(const G2& p, int m_tiles, int n_tiles, hipStream_t st) {
+  if (p.f16) {
+    if constexpr (NTH == 512 && BN == 128)
+      if (!p.conv) return launch_cv<BM, BN, WM, WN, NS, NTH, false, true>(p, m_tiles, n_tiles, st);
+    if constexpr (BN <= 64)
+      if (p.conv) return launch_cv<BM, BN, WM, WN, NS, NTH, true, true>(p, m_tiles, n_tiles, st);
+    return AVLEN_ERR_ARG;
+  }
   return p.conv ? launch_cv<BM, BN, WM, WN, NS, NTH, true>(p, m_tiles, n_tiles, st)
                 : launch_cv<BM, BN, WM, WN, NS, NTH, false>(p, m_tiles, n_tiles, st);
 }
@@ -586,6 +649,11 @@ int launch4(const G2& p, int m_tiles, int n_tiles, hipStream_t st) {
 }
 
 bool aligned_to(const void* q, size_t a) { return ((uintptr_t)q & (a - 1)) == 0; }
+
+void apply_opts(G2& p, const avlen_g2_opts* o) {
+  if (!o) return;
+  p.f16 = o->f16; p.x3 = o->x3; p.a_lo = o->a_lo; p.b_lo = o->b_lo; p.c16_lo = o->c16_lo;
+}
 
 int run_g2(G2 p, void* ws, size_t ws_bytes, hipStream_t st) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K & 7) || (p.lda & 7) || (p.ldb & 7)) return AVLEN_ERR_ARG;
@@ -631,7 +699,8 @@ int run_g2(G2 p, void* ws, size_t ws_bytes, hipStream_t st) {
 #endif
   if (nth == 256 && bn == 128 && bm == 256) bm = 128;
   int m_tiles = ceil_div(p.M, bm);
-  int nk = ceil_div(p.K, BK);
+  if (p.f16 && p.x3) return AVLEN_ERR_ARG;
+  int nk = ceil_div(p.K, BK) * (p.x3 ? 3 : 1);
   long tiles = (long)m_tiles * n_tiles * p.groups;
   int split = 1;
   if (tiles < 128 && nk >= 8 && !has_stats && !p.ln_stats && !p.rowstats) {
@@ -679,7 +748,7 @@ int run_g2(G2 p, void* ws, size_t ws_bytes, hipStream_t st) {
     G2Red rr; rr.slab = p.slab;
     for (int g = 0; g < MAXG; g++) rr.g[g] = p.g[g < p.groups ? g : 0];
     hipLaunchKernelGGL(g2_reduce_kernel, dim3((unsigned)((tot / 4 + 256) / 256), p.groups), dim3(256), 0, st, rr, p.M, p.N,
-                       p.ldc32, p.ldc16, p.ldr, p.splitk, p.act, p.M_dev);
+                       p.ldc32, p.ldc16, p.ldr, p.splitk, p.act, p.M_dev, p.f16, p.x3 ? p.c16_lo : 0L);
     return avlen_launch_status();
   }
   return AVLEN_OK;
@@ -687,11 +756,15 @@ int run_g2(G2 p, void* ws, size_t ws_bytes, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int avlen_ln_fold_weights_h16(const float* W, const float* bias, const float* gamma, const float* beta, void* w16f,
+                                         int ld16, float* s, float* c, int N, int K, int fmt, hipStream_t stream) {
+  if (!W || !gamma || !beta || !w16f || !s || !c || N <= 0 || K <= 0 || ld16 < K || (ld16 & 7) || fmt < 0 || fmt > 1) return AVLEN_ERR_ARG;
+  hipLaunchKernelGGL(ln_fold_kernel, dim3(N), dim3(256), 0, stream, W, bias, gamma, beta, (bf16*)w16f, ld16, s, c, K, fmt);
+  return avlen_launch_status();
+}
 extern "C" int avlen_ln_fold_weights(const float* W, const float* bias, const float* gamma, const float* beta, void* w16f,
                                      int ld16, float* s, float* c, int N, int K, hipStream_t stream) {
-  if (!W || !gamma || !beta || !w16f || !s || !c || N <= 0 || K <= 0 || ld16 < K || (ld16 & 7)) return AVLEN_ERR_ARG;
-  hipLaunchKernelGGL(ln_fold_kernel, dim3(N), dim3(256), 0, stream, W, bias, gamma, beta, (bf16*)w16f, ld16, s, c, K);
-  return avlen_launch_status();
+  return avlen_ln_fold_weights_h16(W, bias, gamma, beta, w16f, ld16, s, c, N, K, 0, stream);
 }
 
 extern "C" size_t avlen_gemm_bf16_workspace_bytes(int M, int N) { return (size_t)32 * M * N * sizeof(float) + 256; }
@@ -730,7 +803,8 @@ extern "C" int avlen_conv2d_nhwc_bf16(const void* X, const void* Wp, const float
 // six ResNet towers of the three policies (and the two towers of one policy) as single launches.
 int avlen_conv2d_nhwc_bf16_grouped(const void* const* X, const void* const* Wp, float* const* Y32, void* const* Y16,
                                    float* const* gn_stats, int groups, int Bn, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
-                                   void* ws, size_t ws_bytes, hipStream_t stream, const float* const* bias, int act, int stride_w) {
+                                   void* ws, size_t ws_bytes, hipStream_t stream, const float* const* bias, int act, int stride_w,
+                                   const avlen_g2_opts* o) {
   if (Cin < 8 || (Cin & (Cin - 1)) || groups < 1 || groups > MAXG) return AVLEN_ERR_ARG;
   int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / (stride_w ? stride_w : stride) + 1;
   if (OH <= 0 || OW <= 0 || (gn_stats && (OH * OW) % 64)) return AVLEN_ERR_ARG;
@@ -747,18 +821,20 @@ int avlen_conv2d_nhwc_bf16_grouped(const void* const* X, const void* const* Wp, 
   p.ohw = OH * OW;
   int l2 = 0; while ((1 << l2) < Cin) l2++;
   p.cin_log2 = l2; p.kw_magic = (65536 + KW - 1) / KW;
+  apply_opts(p, o);
   return run_g2(p, ws, ws_bytes, stream);
 }
 
 int avlen_gemm_bf16_grouped(const void* const* A, int lda, const void* const* B, int ldb, float* const* C32, int ldc32,
                             const float* const* bias, int groups, int M, int N, int K, int act, void* ws, size_t ws_bytes,
-                            hipStream_t stream) {
+                            hipStream_t stream, const avlen_g2_opts* o) {
   if (groups < 1 || groups > MAXG) return AVLEN_ERR_ARG;
   G2 p = {};
   p.groups = groups;
   for (int g = 0; g < groups; g++)
     p.g[g] = G2Grp{(const bf16*)A[g], (const bf16*)B[g], C32[g], nullptr, bias ? bias[g] : nullptr, nullptr, nullptr};
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc32 = ldc32; p.act = act;
+  apply_opts(p, o);
   return run_g2(p, ws, ws_bytes, stream);
 }
 
@@ -766,36 +842,49 @@ int avlen_gemm_bf16_grouped(const void* const* A, int lda, const void* const* B,
 int avlen_gemm_bf16_ln(const void* A, int lda, const void* B, int ldb, float* C32, int ldc32, void* C16, int ldc16,
                        const float* bias, const float* residual, int ldr, int M, const int* M_dev, int N, int K, int act,
                        const float* ln_stats, const float* ln_s, float* rowstats, void* ws, size_t ws_bytes,
-                       hipStream_t stream) {
+                       hipStream_t stream, const avlen_g2_opts* o) {
   if (ln_stats && !ln_s) return AVLEN_ERR_ARG;
   G2 p = {};
   p.A = (const bf16*)A; p.B = (const bf16*)B; p.C32 = C32; p.C16 = (bf16*)C16; p.bias = bias; p.residual = residual;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc32 = ldc32; p.ldc16 = ldc16; p.ldr = ldr; p.act = act;
   p.M_dev = M_dev; p.ln_stats = ln_stats; p.ln_s = ln_s; p.rowstats = rowstats;
+  apply_opts(p, o);
   return run_g2(p, ws, ws_bytes, stream);
 }
 
 // Same as avlen_gemm_bf16 with the live row count taken from device memory (*M_dev <= M): tiles beyond it exit at once.
 int avlen_gemm_bf16_dyn(const void* A, int lda, const void* B, int ldb, float* C32, int ldc32, void* C16, int ldc16,
                         const float* bias, const float* residual, int ldr, int M, const int* M_dev, int N, int K, int act,
-                        void* ws, size_t ws_bytes, hipStream_t stream) {
+                        void* ws, size_t ws_bytes, hipStream_t stream, const avlen_g2_opts* o) {
   G2 p = {};
   p.A = (const bf16*)A; p.B = (const bf16*)B; p.C32 = C32; p.C16 = (bf16*)C16; p.bias = bias; p.residual = residual;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc32 = ldc32; p.ldc16 = ldc16; p.ldr = ldr; p.act = act;
   p.M_dev = M_dev;
+  apply_opts(p, o);
   return run_g2(p, ws, ws_bytes, stream);
 }
 
-extern "C" int avlen_cast_bf16(const float* src, int ld_src, void* dst, int ld_dst, long rows, int cols, hipStream_t stream) {
+// avlen_gemm_bf16 with fp16 operands (fmt = 1): A, B and the 16-bit output hold IEEE half values
+extern "C" int avlen_gemm_h16(const void* A, int lda, const void* B, int ldb, float* C32, int ldc32, void* C16,
+                              int ldc16, const float* bias, const float* residual, int ldr, int M, int N, int K,
+                              int act, int fmt, void* ws, size_t ws_bytes, hipStream_t stream) {
+  avlen_g2_opts o; o.f16 = fmt == 1;
+  return avlen_gemm_bf16_dyn(A, lda, B, ldb, C32, ldc32, C16, ldc16, bias, residual, ldr, M, nullptr, N, K, act, ws, ws_bytes, stream, &o);
+}
+
+extern "C" int avlen_cast_h16(const float* src, int ld_src, void* dst, int ld_dst, long rows, int cols, int fmt, hipStream_t stream) {
   long tot = rows * ld_dst;
-  if (tot <= 0) return AVLEN_ERR_ARG;
+  if (tot <= 0 || fmt < 0 || fmt > 2) return AVLEN_ERR_ARG;
   if (!(ld_src & 3) && !(ld_dst & 7) && !((uintptr_t)src & 15) && !((uintptr_t)dst & 15)) {
     long t8 = tot >> 3;
-    hipLaunchKernelGGL(cast_rows8_kernel, dim3((unsigned)((t8 + 255) / 256)), dim3(256), 0, stream, src, ld_src, (bf16*)dst, ld_dst, rows, cols);
+    hipLaunchKernelGGL(cast_rows8_kernel, dim3((unsigned)((t8 + 255) / 256)), dim3(256), 0, stream, src, ld_src, (bf16*)dst, ld_dst, rows, cols, fmt);
     return avlen_launch_status();
   }
-  hipLaunchKernelGGL(cast_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, src, ld_src, (bf16*)dst, ld_dst, rows, cols);
+  hipLaunchKernelGGL(cast_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, src, ld_src, (bf16*)dst, ld_dst, rows, cols, fmt);
   return avlen_launch_status();
+}
+extern "C" int avlen_cast_bf16(const float* src, int ld_src, void* dst, int ld_dst, long rows, int cols, hipStream_t stream) {
+  return avlen_cast_h16(src, ld_src, dst, ld_dst, rows, cols, 0, stream);
 }
 
 // 8 output elements per thread, 8-byte loads (source rows only need an even leading dimension: 202 floats for the spectrogram)

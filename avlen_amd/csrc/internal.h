@@ -8,6 +8,10 @@
 // descriptors, optional operand scratch of the large-M bf16 training products
 struct avlen_ctx { hipStream_t st; int prec; void* gws; size_t gws_bytes; const int* live = nullptr; const int* seg = nullptr;
                    void* xs = nullptr; size_t xs_bytes = 0; };
+// Operand options of the 16-bit MFMA GEMM family (igemm2.hip).  f16: the 16-bit operands / outputs are IEEE half instead of bf16.
+// x3 ("bf16x3", compensated bf16): every operand is a pair of bf16 planes, hi = bf16(x) and lo = bf16(x - hi); the lo plane of A / W
+// lies a_lo / b_lo BYTES behind the hi plane, the lo plane of the bf16 output c16_lo ELEMENTS behind C16 (0: hi only).
+struct avlen_g2_opts { int f16 = 0; int x3 = 0; long a_lo = 0, b_lo = 0, c16_lo = 0; };
 // Y = act(X W^T + b) + res;  dX = dY W (+ add);  G.w += dY^T X;  out[col] += sum_rows dY   (training products, modules.hip)
 int avlen_i_linear(const avlen_ctx& c, const avlen_linear& L, const float* X, int ldx, float* Y, int ldy, int M, int act,
                    const float* res, int ldr);
@@ -55,10 +59,10 @@ int avlen_conv2d_nhwc_bf16_grouped(const void* const* X, const void* const* Wp, 
                                    float* const* gn_stats,
                                    int groups, int Bn, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                                    void* ws, size_t ws_bytes, hipStream_t stream, const float* const* bias = nullptr,
-                                   int act = 0, int stride_w = 0);
+                                   int act = 0, int stride_w = 0, const avlen_g2_opts* o = nullptr);
 int avlen_gemm_bf16_grouped(const void* const* A, int lda, const void* const* B, int ldb, float* const* C32, int ldc32,
                             const float* const* bias, int groups, int M, int N, int K, int act, void* ws, size_t ws_bytes,
-                            hipStream_t stream);
+                            hipStream_t stream, const avlen_g2_opts* o = nullptr);
 int avlen_layernorm_fwd16_dyn(const float* x, const float* residual, const float* gamma, const float* beta, float* y,
                               void* y16, float* mean, float* rstd, int rows, const int* rows_dev, int d, float eps,
                               hipStream_t stream);
@@ -68,16 +72,16 @@ int avlen_attention_fwd16_seg(const float* Q, int ldq, const float* K, int ldk, 
 int avlen_gemm_bf16_ln(const void* A, int lda, const void* B, int ldb, float* C32, int ldc32, void* C16, int ldc16,
                        const float* bias, const float* residual, int ldr, int M, const int* M_dev, int N, int K, int act,
                        const float* ln_stats, const float* ln_s, float* rowstats, void* ws, size_t ws_bytes,
-                       hipStream_t stream);
+                       hipStream_t stream, const avlen_g2_opts* o = nullptr);
 int avlen_attention_qkv16(const void* QKV16, int ld, void* O16, int ldo16, int B, int H, int S, int causal, float scale,
-                          const int* seg_off, hipStream_t stream);
+                          const int* seg_off, hipStream_t stream, int f16 = 0);
 int avlen_attention_smt16(const void* QKV16, int ld, void* O16, int ldo16, int B, int H, int S, float scale,
                           const float* key_mask, const int* seg_off, hipStream_t stream);
 int avlen_attention_q1(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, void* O16, int ldo16, int B,
                        int H, int Sk, float scale, const float* key_mask, const int* seg_off, hipStream_t stream);
 int avlen_gemm_bf16_dyn(const void* A, int lda, const void* B, int ldb, float* C32, int ldc32, void* C16, int ldc16,
                         const float* bias, const float* residual, int ldr, int M, const int* M_dev, int N, int K, int act,
-                        void* ws, size_t ws_bytes, hipStream_t stream);
+                        void* ws, size_t ws_bytes, hipStream_t stream, const avlen_g2_opts* o = nullptr);
 // in_stats / in_gamma / in_beta (optional, 16/16@64 and 32/32@32 only): X is a RAW conv output whose GroupNorm(16) + ReLU is
 // applied while the halo is staged (saves the separate apply pass)
 int avlen_dconv_bf16_grouped(const void* const* X, const void* const* Wp, void* const* Y16, float* const* gn_stats,

@@ -355,7 +355,7 @@ __global__ void clip_segments_kernel(const int64_t* __restrict__ tokens, int* __
 __global__ void clip_embed_ragged_kernel(const int64_t* __restrict__ tokens, const float* __restrict__ tok_emb,
                                          const float* __restrict__ pos_emb, float* __restrict__ x, const int* __restrict__ seg,
                                          const int* __restrict__ rowmap, int B, int ctx, int width, int vocab,
-                                         __bf16* __restrict__ x16, float* __restrict__ stats) {
+                                         __bf16* __restrict__ x16, float* __restrict__ stats, int f16) {
   __shared__ float sh[16];
   const int row = blockIdx.x;
   if (row >= seg[B]) return;
@@ -370,9 +370,14 @@ __global__ void clip_embed_ragged_kernel(const int64_t* __restrict__ tokens, con
     float4 a = e[i], c = p[i];
     float4 v = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
     o[i] = v;
-    if (x16) {           // bf16 copy + LayerNorm statistics of the row (LayerNorm folded into the first projection)
+    if (x16) {           // 16-bit copy + LayerNorm statistics of the row (LayerNorm folded into the first projection)
       __bf16* d = x16 + (long)row * width + i * 4;
-      d[0] = (__bf16)v.x; d[1] = (__bf16)v.y; d[2] = (__bf16)v.z; d[3] = (__bf16)v.w;
+      if (f16) {
+        d[0] = __builtin_bit_cast(__bf16, (_Float16)v.x); d[1] = __builtin_bit_cast(__bf16, (_Float16)v.y);
+        d[2] = __builtin_bit_cast(__bf16, (_Float16)v.z); d[3] = __builtin_bit_cast(__bf16, (_Float16)v.w);
+      } else {
+        d[0] = (__bf16)v.x; d[1] = (__bf16)v.y; d[2] = (__bf16)v.z; d[3] = (__bf16)v.w;
+      }
       s1 += (v.x + v.y) + (v.z + v.w); s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
     }
   }
@@ -1772,7 +1777,12 @@ extern "C" int avlen_clip_text_fwd(const avlen_clip_text* p, const int64_t* toke
   void* gws = w.take<char>(GEMM_SCRATCH);
   Ctx c{st, prec, gws, GEMM_SCRATCH};
   const float scale = 1.0f / sqrtf((float)D);
-  bool fast = prec == AVLEN_PREC_BF16 && B <= 1024;
+  // the 16-bit shadows of this module's weights are in ONE format (p->half_fmt: 0 = bf16, 1 = fp16); the fast path runs when
+  // the requested arithmetic matches it
+  const bool f16 = prec == AVLEN_PREC_FP16;
+  bool fast = ((prec == AVLEN_PREC_BF16 && p->half_fmt == 0) || (f16 && p->half_fmt == 1)) && B <= 1024;
+  if (f16 && !fast) return AVLEN_ERR_ARG;             // no fp16 fallback: the caller asked for shadows it did not build
+  avlen_g2_opts go; go.f16 = f16;
   for (int l = 0; l < p->layers && fast; l++) {
     const avlen_clip_block& b = p->block[l];
     fast = lin16_ok(b.attn.in_proj) && lin16_ok(b.attn.out_proj) && lin16_ok(b.fc) && lin16_ok(b.proj);
@@ -1791,14 +1801,15 @@ extern "C" int avlen_clip_text_fwd(const avlen_clip_text* p, const int64_t* toke
     const size_t st_stride = (size_t)R * 2;
     fold = fold && (size_t)wd * 2 >= (size_t)16 * p->layers;
     { static int en = -1; if (en < 0) en = (int)avlen_knob("AVLEN_CLIP_FOLD", 1); fold = fold && en; }
+    if (f16 && !fold) return AVLEN_ERR_ARG;           // the fp16 tower exists in the folded-LayerNorm form only
     if (fold) TRY(avlen_zero_bytes(stats + st_stride, (2 * (size_t)p->layers - 1) * st_stride * sizeof(float), st));
     hipLaunchKernelGGL(clip_embed_ragged_kernel, dim3((unsigned)R), dim3(128), 0, st, tokens, p->tok_emb, p->pos_emb, X, seg,
-                       rowmap, B, ctx, wd, p->vocab, fold ? Hn16 : (bf16*)nullptr, fold ? stats : (float*)nullptr);
+                       rowmap, B, ctx, wd, p->vocab, fold ? Hn16 : (bf16*)nullptr, fold ? stats : (float*)nullptr, f16 ? 1 : 0);
     TRY(avlen_launch_status());
     auto lin = [&](const avlen_linear& L, const bf16* X16, int ldx, float* Y32, int ld32, bf16* Y16, int ld16, int act,
                    const float* res) {
       return avlen_gemm_bf16_dyn(X16, ldx, L.w16, L.ld16, Y32, ld32, Y16, ld16, L.b, res, ld32, (int)R, live, L.out_f, L.ld16,
-                                 act, c.gws, c.gws_bytes, c.st);
+                                 act, c.gws, c.gws_bytes, c.st, &go);
     };
     bool pruned = false;
     static int prune = -1;                            // AVLEN_CLIP_PRUNE=0: last layer over every live token (A/B knob)
@@ -1811,8 +1822,8 @@ extern "C" int avlen_clip_text_fwd(const avlen_clip_text* p, const int64_t* toke
         float* st1 = stats + (size_t)(2 * l) * st_stride; float* st2 = st1 + st_stride;
         float* st_next = l + 1 < p->layers ? st2 + st_stride : nullptr;
         TRY(avlen_gemm_bf16_ln(Hn16, wd, b.attn_fold.w16f, wd, nullptr, 0, QKV, 3 * wd, b.attn_fold.c, nullptr, 0, (int)R, live,
-                               3 * wd, wd, 0, st1, b.attn_fold.s, nullptr, c.gws, c.gws_bytes, st));
-        TRY(avlen_attention_qkv16(QKV, 3 * wd, AO16, wd, B, H, ctx, 1, scale, seg, st));
+                               3 * wd, wd, 0, st1, b.attn_fold.s, nullptr, c.gws, c.gws_bytes, st, &go));
+        TRY(avlen_attention_qkv16(QKV, 3 * wd, AO16, wd, B, H, ctx, 1, scale, seg, st, f16 ? 1 : 0));
         if (prune && l + 1 == p->layers) {
           // one row per sample from here on: out_proj, c_fc and c_proj shrink from the live token count to B rows
           bf16* Fe16 = F16; bf16* AOe16 = Fe16 + (size_t)B * b.fc.out_f; bf16* He16 = AOe16 + (size_t)B * wd;
@@ -1820,20 +1831,20 @@ extern "C" int avlen_clip_text_fwd(const avlen_clip_text* p, const int64_t* toke
           hipLaunchKernelGGL(clip_gather_last2_kernel, dim3(B), dim3(128), 0, st, X, AO16, seg, E, AOe16, ste, wd);
           TRY(avlen_launch_status());
           TRY(avlen_gemm_bf16_ln(AOe16, wd, b.attn.out_proj.w16, b.attn.out_proj.ld16, E, wd, He16, wd, b.attn.out_proj.b, E, wd,
-                                 B, nullptr, wd, b.attn.out_proj.ld16, 0, nullptr, nullptr, ste, c.gws, c.gws_bytes, st));
+                                 B, nullptr, wd, b.attn.out_proj.ld16, 0, nullptr, nullptr, ste, c.gws, c.gws_bytes, st, &go));
           TRY(avlen_gemm_bf16_ln(He16, wd, b.fc_fold.w16f, wd, nullptr, 0, Fe16, b.fc.out_f, b.fc_fold.c, nullptr, 0, B, nullptr,
-                                 b.fc.out_f, wd, AVLEN_ACT_QUICKGELU, ste, b.fc_fold.s, nullptr, c.gws, c.gws_bytes, st));
+                                 b.fc.out_f, wd, AVLEN_ACT_QUICKGELU, ste, b.fc_fold.s, nullptr, c.gws, c.gws_bytes, st, &go));
           TRY(avlen_gemm_bf16_ln(Fe16, b.fc.out_f, b.proj.w16, b.proj.ld16, E, wd, nullptr, 0, b.proj.b, E, wd, B, nullptr, wd,
-                                 b.proj.ld16, 0, nullptr, nullptr, nullptr, c.gws, c.gws_bytes, st));
+                                 b.proj.ld16, 0, nullptr, nullptr, nullptr, c.gws, c.gws_bytes, st, &go));
           pruned = true;
           break;
         }
         TRY(avlen_gemm_bf16_ln(AO16, wd, b.attn.out_proj.w16, b.attn.out_proj.ld16, X, wd, Hn16, wd, b.attn.out_proj.b, X, wd,
-                               (int)R, live, wd, b.attn.out_proj.ld16, 0, nullptr, nullptr, st2, c.gws, c.gws_bytes, st));
+                               (int)R, live, wd, b.attn.out_proj.ld16, 0, nullptr, nullptr, st2, c.gws, c.gws_bytes, st, &go));
         TRY(avlen_gemm_bf16_ln(Hn16, wd, b.fc_fold.w16f, wd, nullptr, 0, F16, b.fc.out_f, b.fc_fold.c, nullptr, 0, (int)R, live,
-                               b.fc.out_f, wd, AVLEN_ACT_QUICKGELU, st2, b.fc_fold.s, nullptr, c.gws, c.gws_bytes, st));
+                               b.fc.out_f, wd, AVLEN_ACT_QUICKGELU, st2, b.fc_fold.s, nullptr, c.gws, c.gws_bytes, st, &go));
         TRY(avlen_gemm_bf16_ln(F16, b.fc.out_f, b.proj.w16, b.proj.ld16, X, wd, Hn16, wd, b.proj.b, X, wd, (int)R, live, wd,
-                               b.proj.ld16, 0, nullptr, nullptr, st_next, c.gws, c.gws_bytes, st));
+                               b.proj.ld16, 0, nullptr, nullptr, st_next, c.gws, c.gws_bytes, st, &go));
       }
     } else
     for (int l = 0; l < p->layers; l++) {
@@ -1841,7 +1852,7 @@ extern "C" int avlen_clip_text_fwd(const avlen_clip_text* p, const int64_t* toke
       TRY(avlen_layernorm_fwd16_dyn(X, nullptr, b.ln1.g, b.ln1.b, nullptr, Hn16, nullptr, nullptr, (int)R, live, wd, 1e-5f, st));
       if (D == 64 && ctx <= 96) {                      // packed bf16 q|k|v straight into the MFMA attention
         TRY(lin(b.attn.in_proj, Hn16, wd, nullptr, 0, (bf16*)QKV, 3 * wd, 0, nullptr));
-        TRY(avlen_attention_qkv16(QKV, 3 * wd, AO16, wd, B, H, ctx, 1, scale, seg, st));
+        TRY(avlen_attention_qkv16(QKV, 3 * wd, AO16, wd, B, H, ctx, 1, scale, seg, st, f16 ? 1 : 0));
       } else {
         TRY(lin(b.attn.in_proj, Hn16, wd, QKV, 3 * wd, nullptr, 0, 0, nullptr));
         TRY(avlen_attention_fwd16_seg(QKV, 3 * wd, QKV + wd, 3 * wd, QKV + 2 * wd, 3 * wd, nullptr, 0, AO16, wd, nullptr,
@@ -1855,7 +1866,7 @@ extern "C" int avlen_clip_text_fwd(const avlen_clip_text* p, const int64_t* toke
     if (!pruned) hipLaunchKernelGGL(clip_gather_last_kernel, dim3(B), dim3(128), 0, st, X, E, seg, wd);
     TRY(avlen_launch_status());
     TRY(avlen_layernorm_fwd(E, nullptr, p->ln_final.g, p->ln_final.b, E2, nullptr, nullptr, B, wd, 1e-5f, st));
-    return clip_project(p, E2, out, B, prec, gws, st);
+    return clip_project(p, E2, out, B, f16 ? AVLEN_PREC_BF16X3 : prec, gws, st);
   }
   hipLaunchKernelGGL(clip_embed_kernel, dim3((unsigned)R), dim3(128), 0, st, tokens, p->tok_emb, p->pos_emb, X, ctx, wd,
                      p->vocab);

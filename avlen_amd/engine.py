@@ -45,18 +45,27 @@ class FlatParams:
         self._ptrs = {n: p.data_ptr() for n, p in named}
         # bf16 shadow of the whole buffer (same offsets): the w16 operands of the bf16 fast path
         self.flat16 = torch.zeros(off, dtype=torch.bfloat16, device=dev)
+        # further 16-bit shadows, built on first use: fmt 1 = fp16 (AVLEN_PREC_FP16 modules), fmt 2 = the LOW plane of the
+        # compensated bf16 pair, bf16(w - bf16(w)) (AVLEN_PREC_BF16X3 modules)
+        self.extra16 = {}
 
     def refresh16(self, trained_only=False):
         n = self.n_trained if trained_only else self.flat.numel()
         if n:
             L.call("avlen_cast_bf16", P(self.flat), n, P(self.flat16), n, 1, n, L.stream())
+            for fmt, buf in self.extra16.items():
+                L.call("avlen_cast_h16", P(self.flat), n, P(buf), n, 1, n, fmt, L.stream())
 
-    def shadow_ptr(self, t):
-        """bf16 shadow address of parameter tensor t (a view into flat), or None."""
+    def shadow_ptr(self, t, fmt=0):
+        """16-bit shadow address of parameter tensor t (a view into flat) in format fmt (0 bf16, 1 fp16, 2 bf16 low plane), or None."""
         off = (t.data_ptr() - self.flat.data_ptr()) // 4
         if off < 0 or off >= self.flat.numel():
             return None
-        return C.c_void_p(self.flat16.data_ptr() + 2 * off)
+        if fmt == 0:
+            return C.c_void_p(self.flat16.data_ptr() + 2 * off)
+        if fmt not in self.extra16:
+            self.extra16[fmt] = torch.zeros(self.flat.numel(), dtype=torch.int16, device=self.device)
+        return C.c_void_p(self.extra16[fmt].data_ptr() + 2 * off)
 
     def intact(self, module):
         for n, p in module.named_parameters():
@@ -93,10 +102,13 @@ def P(t, off_floats=0):
     return C.c_void_p(t.data_ptr() + 4 * off_floats)
 
 
-def linear_view(w, b, flat=None, packed=None):
+def linear_view(w, b, flat=None, packed=None, fmt=0, lo=False):
+    """fmt: format of the 16-bit shadow w16 (0 bf16, 1 fp16); lo: also the low plane of the compensated bf16 pair (w16lo)."""
     v = L.Linear(P(w), P(b) if b is not None else None, w.shape[0], w.shape[1])
     if flat is not None and w.shape[1] % 8 == 0:
-        v.w16, v.ld16 = flat.shadow_ptr(w), w.shape[1]
+        v.w16, v.ld16 = flat.shadow_ptr(w, fmt), w.shape[1]
+        if lo:
+            v.w16lo = flat.shadow_ptr(w, 2)
     elif packed is not None:
         # in_f not a multiple of 8 (the distractor variant's fusion input: 297 / 329 + 12 columns): the bf16 GEMMs need
         # 16-byte rows, so the shadow is a zero-padded derived copy [out_f][ld16]
@@ -186,14 +198,14 @@ class Packed:
             if kind == "pad16":
                 L.call("avlen_cast_bf16", P(w), dims[1], P(buf16), c16, dims[0], dims[1], st)
 
-    def ln_fold(self, lin_w, lin_b, ln):
-        """LayerNorm `ln` folded into the Linear (lin_w, lin_b) that follows it (avlen_ln_fold_weights)."""
+    def ln_fold(self, lin_w, lin_b, ln, fmt=0):
+        """LayerNorm `ln` folded into the Linear (lin_w, lin_b) that follows it (avlen_ln_fold_weights); fmt 1: fp16 weights."""
         N_, K = lin_w.shape
         w16f = torch.empty(N_, K, dtype=torch.bfloat16, device=self.device)
         s = torch.empty(N_, dtype=torch.float32, device=self.device)
         c = torch.empty(N_, dtype=torch.float32, device=self.device)
         self.bufs += [w16f, s, c]
-        self.jobs.append(("fold", lin_w, (lin_b, ln.weight, ln.bias, s, c), w16f, (N_, K), 0))
+        self.jobs.append(("fold", lin_w, (lin_b, ln.weight, ln.bias, s, c), w16f, (N_, K), fmt))
         return L.LnFold(P(w16f), P(s), P(c))
 
     def refresh(self):
@@ -201,8 +213,8 @@ class Packed:
         for kind, w, buf, buf16, dims, c16 in self.jobs:
             if kind == "fold":
                 b, g, be, s, c = buf
-                L.call("avlen_ln_fold_weights", P(w), P(b) if b is not None else None, P(g), P(be), P(buf16), dims[1], P(s),
-                       P(c), dims[0], dims[1], st)
+                L.call("avlen_ln_fold_weights_h16", P(w), P(b) if b is not None else None, P(g), P(be), P(buf16), dims[1], P(s),
+                       P(c), dims[0], dims[1], c16, st)
             elif kind == "pad16":
                 L.call("avlen_cast_bf16", P(w), dims[1], P(buf16), c16, dims[0], dims[1], st)
             elif kind == "conv32":
@@ -301,8 +313,9 @@ def cnn3_view(net, packed):
     return s
 
 
-def mha_view(m, flat=None):
-    return L.Mha(linear_view(m.in_proj_weight, m.in_proj_bias, flat), linear_view(m.out_proj.weight, m.out_proj.bias, flat))
+def mha_view(m, flat=None, fmt=0, lo=False):
+    return L.Mha(linear_view(m.in_proj_weight, m.in_proj_bias, flat, fmt=fmt, lo=lo),
+                 linear_view(m.out_proj.weight, m.out_proj.bias, flat, fmt=fmt, lo=lo))
 
 
 def transformer_view(t, d, nhead, flat=None):
@@ -337,18 +350,20 @@ def dialog_view(enc, flat=None):
     return s
 
 
-def clip_view(clip, flat=None, packed=None):
+def clip_view(clip, flat=None, packed=None, fmt=0):
+    """fmt: format of the tower's 16-bit weight shadows (0 bf16, 1 fp16: AVLEN_PREC_FP16 calls)."""
     s = L.ClipText()
+    s.half_fmt = fmt
     s.tok_emb, s.pos_emb = P(clip.token_embedding.weight), P(clip.positional_embedding)
     for i, blk in enumerate(clip.transformer.resblocks):
         b = s.block[i]
         b.ln1, b.ln2 = affine_view(blk.ln_1), affine_view(blk.ln_2)
-        b.attn = mha_view(blk.attn, flat)
-        b.fc = linear_view(blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, flat)
-        b.proj = linear_view(blk.mlp.c_proj.weight, blk.mlp.c_proj.bias, flat)
+        b.attn = mha_view(blk.attn, flat, fmt)
+        b.fc = linear_view(blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, flat, fmt=fmt)
+        b.proj = linear_view(blk.mlp.c_proj.weight, blk.mlp.c_proj.bias, flat, fmt=fmt)
         if packed is not None and blk.attn.in_proj_weight.shape[1] % 8 == 0:
-            b.attn_fold = packed.ln_fold(blk.attn.in_proj_weight, blk.attn.in_proj_bias, blk.ln_1)
-            b.fc_fold = packed.ln_fold(blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, blk.ln_2)
+            b.attn_fold = packed.ln_fold(blk.attn.in_proj_weight, blk.attn.in_proj_bias, blk.ln_1, fmt)
+            b.fc_fold = packed.ln_fold(blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, blk.ln_2, fmt)
     s.ln_final = affine_view(clip.ln_final)
     s.text_proj = P(clip.text_projection)
     s.vocab, s.ctx = clip.vocab_size, clip.context_length

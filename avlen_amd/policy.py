@@ -22,7 +22,10 @@ from . import engine as E
 from . import nets as N
 
 DUAL_GOAL_DELIMITER = ","
-_PREC = {"fp32": L.PREC_FP32, "bf16": L.PREC_BF16}
+_PREC = {"fp32": L.PREC_FP32, "bf16": L.PREC_BF16, "bf16x3": L.PREC_BF16X3, "fp16": L.PREC_FP16}
+# precision="bf16x3" (the accurate fast mode): compensated bf16 everywhere except the frozen CLIP text tower, which runs in
+# fp16 -- the precision the reference itself runs it in on a CUDA device (clip.load converts the weights to half)
+_MODE_MODULES = {"bf16x3": {"clip": "fp16"}}
 
 POSE, SPECTROGRAM, LOCATION_BELIEF, CATEGORY_BELIEF, CATEGORY = "pose", "spectrogram", "location_belief", \
     "category_belief", "category"     # soundspaces/tasks/nav.py cls_uuid values
@@ -394,6 +397,7 @@ class Policy(nn.Module):
         self.uncertainty_option = N.CriticHeadParams(d, 2)
         self.critic_vln = N.CriticHeadParams(d)
         self.precision, self.sampling = precision, sampling
+        self.module_precision = dict(_MODE_MODULES.get(precision, {}))
         self.use_graphs = use_graphs          # capture each act*/get_value* forward in a HIP graph (static shapes)
         self._graphs = {}
         self._memos = {}
@@ -438,6 +442,12 @@ class Policy(nn.Module):
     @property
     def prec(self):
         return _PREC[self.precision]
+
+    # Per-module arithmetic (keys: "towers", "audio", "smt", "clip", "dialog"): modules exchange fp32 tensors, so each one may run
+    # in its own mode; unnamed modules use `precision`.
+    def prec_of(self, module):
+        mp = self.module_precision
+        return _PREC[mp[module]] if mp and module in mp else _PREC[self.precision]
 
     def _engine(self):
         p0 = next(self.parameters())
@@ -817,7 +827,7 @@ class _SMTBase(Net):
         feats = torch.empty(B, F, device=dev)
         goal = torch.empty(B, self._hidden_size, device=dev)
         st = L.stream()
-        prec = pol.prec
+        prec, prec_a = pol.prec_of("towers"), pol.prec_of("audio")
         S = rgb.shape[1]
         H, W = spec.shape[1], spec.shape[2]
         nb2 = L.lib.avlen_cnn3_workspace_bytes(C.byref(eng["audio"]), B, H, W)
@@ -842,7 +852,7 @@ class _SMTBase(Net):
                         L.call("avlen_cnn3_fwd_indexed", C.byref(eng["audio"]), E.P(spec.base), E.P(idx), B, H, W, E.P(feats, 144), F,
                                E.P(ws2), nb2, L.stream())
                     else:
-                        L.call("avlen_cnn3_fwd", C.byref(eng["audio"]), E.P(spec), B, H, W, E.P(feats, 144), F, prec, E.P(ws2), nb2,
+                        L.call("avlen_cnn3_fwd", C.byref(eng["audio"]), E.P(spec), B, H, W, E.P(feats, 144), F, prec_a, E.P(ws2), nb2,
                                L.stream())
                 if aud is not None:
                     L.call("avlen_copy_rows", E.P(aud), 128, E.P(feats, 144), F, B, 128, L.stream())
@@ -883,7 +893,7 @@ class _SMTBase(Net):
             with torch.cuda.stream(s_dep):
                 L.call("avlen_resnet18_fwd", C.byref(eng["depth"]), E.P(depth), 0, B, S, depth.shape[3], 1.0, E.P(feats, 64), F,
                        prec, E.P(ws_dep), nb, L.stream())
-            L.call("avlen_cnn3_fwd", C.byref(eng["audio"]), E.P(spec), B, H, W, E.P(feats, 144), F, prec, E.P(ws2), nb2, st)
+            L.call("avlen_cnn3_fwd", C.byref(eng["audio"]), E.P(spec), B, H, W, E.P(feats, 144), F, prec_a, E.P(ws2), nb2, st)
         pa = _i64(prev_actions.view(B, -1)[:, :1])
         cat = _f32(obs[CATEGORY]) if self._use_category_input else None
         pose = _f32(obs[POSE])
@@ -916,7 +926,7 @@ class _SMTBase(Net):
         ws = pol._ws.get(save_key, nb, dev)
         L.call("avlen_smt_fwd", C.byref(eng["smt"]), E.P(feats), E.P(mem) if mem is not None else None,
                E.P(mem_index) if mem_index is not None else None, NC, E.P(masks) if masks is not None else None,
-               E.P(goal), E.P(out), B, M, F, self._x_dims - 4, cto, 1 if save else 0, pol.prec, E.P(ws), nb, L.stream())
+               E.P(goal), E.P(out), B, M, F, self._x_dims - 4, cto, 1 if save else 0, pol.prec_of("smt"), E.P(ws), nb, L.stream())
         return out, (ws, nb, B, M, F, cto)
 
 
@@ -998,8 +1008,8 @@ class AudioNavDialogNet(_SMTBase):
 
     def build_views(self, eng, packed):
         super().build_views(eng, packed)
-        eng["clip"] = E.clip_view(self.clip, eng["flat"], packed)
-        eng["dialog_layer"] = E.linear_view(self.dialog_layer.weight, self.dialog_layer.bias, eng["flat"])
+        eng["clip"] = E.clip_view(self.clip, eng["flat"], packed, fmt=eng.get("clip_fmt", 0))
+        eng["dialog_layer"] = E.linear_view(self.dialog_layer.weight, self.dialog_layer.bias, eng["flat"], fmt=eng.get("clip_fmt", 0))
         eng["dialog"] = E.dialog_view(self.dialog_state_encoder, eng["flat"])
 
     def encode_text(self, pol, tokens):
@@ -1009,7 +1019,7 @@ class AudioNavDialogNet(_SMTBase):
         out = torch.empty(B, self.clip.text_projection.shape[1], device=tok.device)
         nb = L.lib.avlen_clip_text_workspace_bytes(C.byref(eng["clip"]), B)
         ws = pol._ws.get("clip", nb, tok.device)
-        L.call("avlen_clip_text_fwd", C.byref(eng["clip"]), E.P(tok), E.P(out), B, pol.prec, E.P(ws), nb, L.stream())
+        L.call("avlen_clip_text_fwd", C.byref(eng["clip"]), E.P(tok), E.P(out), B, pol.prec_of("clip"), E.P(ws), nb, L.stream())
         return out
 
     text_encoder_override = None      # tests: callable(tokens)->(B,512) replacing the CLIP tower (unpinned)
@@ -1023,18 +1033,20 @@ class AudioNavDialogNet(_SMTBase):
         B, d, dev, st = e.shape[0], self._hidden_size, e.device, L.stream()
         d_emb = torch.empty(B, d, device=dev)
         dl = eng["dialog_layer"]
-        if pol.prec == L.PREC_BF16 and dl.w16:
+        pc = pol.prec_of("clip")
+        if pc in (L.PREC_BF16, L.PREC_FP16) and dl.w16:
+            fmt = 1 if pc == L.PREC_FP16 else 0
             e16 = torch.empty(B, e.shape[1], device=dev, dtype=torch.bfloat16)
             nbg = L.lib.avlen_gemm_bf16_workspace_bytes(B, d)
             wsg = pol._ws.get("dlg_gemm", nbg, dev)
-            L.call("avlen_cast_bf16", E.P(e), e.shape[1], E.P(e16), e.shape[1], B, e.shape[1], st)
-            L.call("avlen_gemm_bf16", E.P(e16), e.shape[1], dl.w16, dl.ld16, E.P(d_emb), d, None, 0, dl.b, None, 0, B, d,
-                   e.shape[1], 0, E.P(wsg), nbg, st)
+            L.call("avlen_cast_h16", E.P(e), e.shape[1], E.P(e16), e.shape[1], B, e.shape[1], fmt, st)
+            L.call("avlen_gemm_h16", E.P(e16), e.shape[1], dl.w16, dl.ld16, E.P(d_emb), d, None, 0, dl.b, None, 0, B, d,
+                   e.shape[1], 0, fmt, E.P(wsg), nbg, st)
         else:
             nbg = L.lib.avlen_gemm_workspace_bytes(B, d, e.shape[1], 1)
             wsg = pol._ws.get("dlg_gemm", nbg, dev)
             L.call("avlen_gemm", E.P(e), e.shape[1], 0, dl.w, dl.in_f, 0, E.P(d_emb), d, dl.b, None, 0, B, d,
-                   e.shape[1], 0, pol.prec, 1, 0.0, E.P(wsg), nbg, st)
+                   e.shape[1], 0, pol.prec_of("clip"), 1, 0.0, E.P(wsg), nbg, st)
         return d_emb
 
     def prefetch_text(self, pol, tokens, stream, after_current=True):
@@ -1110,7 +1122,7 @@ class AudioNavDialogNet(_SMTBase):
         nb = L.lib.avlen_dialog_workspace_bytes(C.byref(eng["dialog"]), B, M)
         ws = pol._ws.get("dialog", nb, dev)
         L.call("avlen_dialog_fwd", C.byref(eng["dialog"]), E.P(x_att), E.P(memd), E.P(mk),
-               E.P(d_emb) if d_emb is not None else None, E.P(step), E.P(goal), E.P(out), B, M, pol.prec, E.P(ws), nb, st)
+               E.P(d_emb) if d_emb is not None else None, E.P(step), E.P(goal), E.P(out), B, M, pol.prec_of("dialog"), E.P(ws), nb, st)
         return out, rnn_hidden_states, feats, out
 
 
@@ -1296,6 +1308,7 @@ class AudioNavBaselineNet(Net):
 # =========================================================================================================
 class _NetPolicy(Policy):
     def _build_views(self, eng, packed):
+        eng["clip_fmt"] = 1 if self.prec_of("clip") == L.PREC_FP16 else 0
         self.net.build_views(eng, packed)
 
 

@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--envs", type=int, default=64)
     ap.add_argument("--rollout", type=int, default=150)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3"])
     ap.add_argument("--spectrogram", default="257x101")
     ap.add_argument("--config", default="interactive", choices=["interactive", "gru"],
                     help="interactive = BASELINE configs[2] (default); gru = configs[1] (N=16 GRU baseline, PPO 4x2)")

@@ -11,7 +11,8 @@
  * sequences are batch-major [B][S][d]; functions enqueue work on `stream` and return immediately
  * (never allocate, never synchronise; graph-capturable); return AVLEN_OK (0) or an AVLEN_ERR_* code.
  * `prec` selects the MFMA operand type of the dense products: AVLEN_PREC_FP32 (exact fp32 MFMA,
- * the parity mode) or AVLEN_PREC_BF16 (bf16 operands, fp32 accumulate).  Scratch comes from the
+ * the parity mode), AVLEN_PREC_BF16 (bf16 operands, fp32 accumulate) or AVLEN_PREC_BF16X3 (every operand split into
+ * bf16 hi + lo, three bf16 MFMAs per product: fp32-grade results at matrix-core speed).  Scratch comes from the
  * caller: ask the matching *_workspace_bytes() first.
  */
 #ifndef AVLEN_HIP_H
@@ -27,6 +28,9 @@ typedef struct ihipStream_t* avlen_stream_t;        /* == hipStream_t */
 
 #define AVLEN_PREC_FP32 0
 #define AVLEN_PREC_BF16 1
+#define AVLEN_PREC_BF16X3 2   /* compensated bf16: operands split hi + lo, three bf16 MFMAs per product, fp32 accumulate */
+#define AVLEN_PREC_FP16 3     /* IEEE half operands, fp32 accumulate: the frozen CLIP text tower (what the reference's CUDA path runs
+                                 it in, clip.load -> fp16) and the AudioCNN of the bf16x3 mode; needs fp16 weight shadows */
 #define AVLEN_ACT_NONE 0
 #define AVLEN_ACT_RELU 1
 #define AVLEN_ACT_QUICKGELU 2
@@ -35,7 +39,8 @@ typedef struct ihipStream_t* avlen_stream_t;        /* == hipStream_t */
 /* ------------------------------------------------------------------ parameter views ---------- */
 /* w[out_f][in_f] fp32 (canonical).  w16: optional bf16 shadow of the same matrix, row stride ld16 (multiple of 8,
  * padding zero) used by the bf16 fast path; NULL -> that layer runs on the fp32-staged kernel. */
-typedef struct { float* w; float* b; int out_f; int in_f; void* w16; int ld16; } avlen_linear;
+/* w16lo: optional LOW plane of the compensated bf16 pair, bf16(w - bf16(w)), same layout as w16 (AVLEN_PREC_BF16X3 fast paths). */
+typedef struct { float* w; float* b; int out_f; int in_f; void* w16; int ld16; void* w16lo; } avlen_linear;
 /* w packed [cout][kh][kw][cin] fp32; w16: bf16 [cout][kh][kw][cin16] with cin16 = max(8, cin) zero-padded. */
 /* w16c: optional compact bf16 copy [cout][kh][kw][cin] WITHOUT channel padding, for the "super-pixel" form of a conv whose
  * cin * stride == 8 and kw % stride == 0 (AudioCNN conv0 on the 257x101 spectrogram, audio_cnn.py:62-83): `stride`
@@ -44,7 +49,9 @@ typedef struct { float* w; float* b; int out_f; int in_f; void* w16; int ld16; }
 /* w16f: optional copy of w16 in MFMA-fragment order for kernels that keep their weights in registers (tower_tail.hip): with
  * K = kh*kw*cin16 (a multiple of 32) and cout a multiple of 16, [cout/16][K/32][lane 0..63][8] bf16 where lane = 16 q + r holds
  * w16[16 t + r][32 i + 8 q .. + 7] -- one 16-byte load per lane, 1 KiB contiguous per wave and k-step. */
-typedef struct { float* w; float* b; int cin, cout, kh, kw, stride, pad; void* w16; int cin16; void* w16c; void* w16f; } avlen_conv;
+/* w16lo / w16flo: optional LOW planes of the compensated bf16 pair (bf16(w - bf16(w))) in the layouts of w16 / w16f. */
+typedef struct { float* w; float* b; int cin, cout, kh, kw, stride, pad; void* w16; int cin16; void* w16c; void* w16f;
+                 void* w16lo; void* w16flo; } avlen_conv;
 typedef struct { float* g; float* b; } avlen_affine;                               /* norm scale / shift */
 typedef struct { avlen_conv conv1, conv2, down; avlen_affine bn1, bn2, bnd; int has_down; } avlen_resblock;
 /* CustomResNet (smt_resnet.py:56-149): conv7x7 + GroupNorm(16) + 8 basic blocks + fc(8192->64).
@@ -69,8 +76,9 @@ typedef struct { avlen_linear fus0, fus2; avlen_transformer tr; float* pe; int p
 typedef struct { void* w16f; float* s; float* c; } avlen_ln_fold;
 typedef struct { avlen_affine ln1, ln2; avlen_mha attn; avlen_linear fc, proj; avlen_ln_fold attn_fold, fc_fold; } avlen_clip_block;
 /* CLIP ViT-B/32 text tower (third party; call site policy.py:847-849). text_proj is [width][out]. */
+/* half_fmt: format of every 16-bit weight shadow of the tower (w16, w16f): 0 = bf16, 1 = fp16 (AVLEN_PREC_FP16 calls). */
 typedef struct { float* tok_emb; float* pos_emb; avlen_clip_block block[12]; avlen_affine ln_final;
-                 float* text_proj; int vocab, ctx, width, heads, layers, out_dim; } avlen_clip_text;
+                 float* text_proj; int vocab, ctx, width, heads, layers, out_dim, half_fmt; } avlen_clip_text;
 /* nn.GRU(in, H, 1 layer) (av_nav/models/rnn_state_encoder.py:36-40): w_ih[3H][in], w_hh[3H][H], r|z|n. */
 typedef struct { float* w_ih; float* w_hh; float* b_ih; float* b_hh; int in_f, hidden; } avlen_gru;
 /* CategoricalNet + CriticHead (+ CriticHead2) of one policy (policy.py:46-61, 279-297). */
@@ -117,6 +125,16 @@ int avlen_ln_fold_weights(const float* W, const float* bias, const float* gamma,
 int avlen_conv_direct_bf16(const void* X, const void* Wp, void* Y16, float* gn_stats, int B, int W, int Cin, int Cout,
                            int K, avlen_stream_t stream);
 int avlen_cast_bf16(const float* src, int ld_src, void* dst, int ld_dst, long rows, int cols, avlen_stream_t stream);
+/* The same cast into another 16-bit format: fmt 0 = bf16, 1 = fp16 (IEEE half), 2 = the LOW plane of the compensated bf16 pair,
+ * bf16(x - bf16(x)) (AVLEN_PREC_BF16X3 operands are hi + lo planes of identical layout). */
+int avlen_cast_h16(const float* src, int ld_src, void* dst, int ld_dst, long rows, int cols, int fmt, avlen_stream_t stream);
+/* avlen_gemm_bf16 on 16-bit operands of format fmt (0 = bf16, 1 = fp16; C16 is written in the same format). */
+int avlen_gemm_h16(const void* A, int lda, const void* B, int ldb, float* C32, int ldc32, void* C16, int ldc16,
+                   const float* bias, const float* residual, int ldr, int M, int N, int K, int act, int fmt, void* ws,
+                   size_t ws_bytes, avlen_stream_t stream);
+/* avlen_ln_fold_weights with the folded weights stored in format fmt (0 = bf16, 1 = fp16). */
+int avlen_ln_fold_weights_h16(const float* W, const float* bias, const float* gamma, const float* beta, void* w16f, int ld16,
+                              float* s, float* c, int N, int K, int fmt, avlen_stream_t stream);
 int avlen_pack_conv_weight_bf16(const float* w_oihw, void* w_packed, int O, int I, int KH, int KW, int Cpad,
                                 avlen_stream_t stream);
 int avlen_pack_fc_after_flatten_bf16(const float* w, void* w_packed, int O, int C, int HW, avlen_stream_t stream);
