@@ -128,6 +128,10 @@ SIGNATURES = {
     "avlen_conv_direct_bf16": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "avlen_cast_bf16": (i32, [vp, i32, vp, i32, C.c_long, i32, vp]),
     "avlen_cast_h16": (i32, [vp, i32, vp, i32, C.c_long, i32, i32, vp]),
+    "avlen_pack_conv_weight_h16": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "avlen_pack_fc_after_flatten_h16": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "avlen_resnet18_group_x3_workspace_bytes": (sz, [i32, i32]),
+    "avlen_resnet18_group_fwd_x3": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, sz, vp]),
     "avlen_gemm_h16": (i32, [vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     "avlen_pack_conv_weight_bf16": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "avlen_pack_conv_weight_frag": (i32, [vp, vp, i32, i32, vp]),

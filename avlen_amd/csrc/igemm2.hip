@@ -565,22 +565,22 @@ __global__ void cast_rows8_kernel(const float* __restrict__ src, int lds_, bf16*
 }
 
 // OIHW fp32 -> [O][KH][KW][Cp] bf16 (channels zero-padded to Cp)
-__global__ void pack_conv_bf16_kernel(const float* __restrict__ w, bf16* __restrict__ o, int O, int I, int KH, int KW, int Cp) {
+__global__ void pack_conv_bf16_kernel(const float* __restrict__ w, bf16* __restrict__ o, int O, int I, int KH, int KW, int Cp, int fmt) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long tot = (long)O * KH * KW * Cp;
   if (idx >= tot) return;
   int ci = (int)(idx % Cp); long r = idx / Cp;
   int kx = (int)(r % KW); r /= KW;
   int ky = (int)(r % KH); int oc = (int)(r / KH);
-  o[idx] = ci < I ? (bf16)w[(((long)oc * I + ci) * KH + ky) * KW + kx] : (bf16)0.f;
+  o[idx] = ci < I ? cvt16(w[(((long)oc * I + ci) * KH + ky) * KW + kx], fmt) : (bf16)0.f;
 }
 // (O, C*HW) fp32 (NCHW flatten) -> (O, HW*C) bf16 (NHWC flatten)
-__global__ void pack_fc_bf16_kernel(const float* __restrict__ w, bf16* __restrict__ o, int O, int C, int HW) {
+__global__ void pack_fc_bf16_kernel(const float* __restrict__ w, bf16* __restrict__ o, int O, int C, int HW, int fmt) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long tot = (long)O * C * HW;
   if (idx >= tot) return;
   int c = (int)(idx % C); long r = idx / C; int pp = (int)(r % HW); int oc = (int)(r / HW);
-  o[idx] = (bf16)w[((long)oc * C + c) * HW + pp];
+  o[idx] = cvt16(w[((long)oc * C + c) * HW + pp], fmt);
 }
 
 // LayerNorm folding (derived data for avlen_gemm_bf16_ln): w16f[n][k] = bf16(W[n][k] * gamma[k]),
@@ -923,11 +923,16 @@ int avlen_cast_bf16_indexed(const float* src, int ld_src, void* dst, int ld_dst,
   return avlen_launch_status();
 }
 
+extern "C" int avlen_pack_conv_weight_h16(const float* w_oihw, void* w_packed, int O, int I, int KH, int KW, int Cpad, int fmt,
+                                          hipStream_t stream) {
+  if (fmt < 0 || fmt > 2) return AVLEN_ERR_ARG;
+  long tot = (long)O * KH * KW * Cpad;
+  hipLaunchKernelGGL(pack_conv_bf16_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, w_oihw, (bf16*)w_packed, O, I, KH, KW, Cpad, fmt);
+  return avlen_launch_status();
+}
 extern "C" int avlen_pack_conv_weight_bf16(const float* w_oihw, void* w_packed, int O, int I, int KH, int KW, int Cpad,
                                            hipStream_t stream) {
-  long tot = (long)O * KH * KW * Cpad;
-  hipLaunchKernelGGL(pack_conv_bf16_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, w_oihw, (bf16*)w_packed, O, I, KH, KW, Cpad);
-  return avlen_launch_status();
+  return avlen_pack_conv_weight_h16(w_oihw, w_packed, O, I, KH, KW, Cpad, 0, stream);
 }
 
 // w16 [cout][K] -> fragment order [cout/16][K/32][lane = 16 q + r][8]: lane's chunk = w16[16 t + r][32 i + 8 q ..]
@@ -945,8 +950,12 @@ extern "C" int avlen_pack_conv_weight_frag(const void* w16, void* w16f, int cout
   return avlen_launch_status();
 }
 
-extern "C" int avlen_pack_fc_after_flatten_bf16(const float* w, void* w_packed, int O, int C, int HW, hipStream_t stream) {
+extern "C" int avlen_pack_fc_after_flatten_h16(const float* w, void* w_packed, int O, int C, int HW, int fmt, hipStream_t stream) {
+  if (fmt < 0 || fmt > 2) return AVLEN_ERR_ARG;
   long tot = (long)O * C * HW;
-  hipLaunchKernelGGL(pack_fc_bf16_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, w, (bf16*)w_packed, O, C, HW);
+  hipLaunchKernelGGL(pack_fc_bf16_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, w, (bf16*)w_packed, O, C, HW, fmt);
   return avlen_launch_status();
+}
+extern "C" int avlen_pack_fc_after_flatten_bf16(const float* w, void* w_packed, int O, int C, int HW, hipStream_t stream) {
+  return avlen_pack_fc_after_flatten_h16(w, w_packed, O, C, HW, 0, stream);
 }

@@ -119,3 +119,10 @@ int avlen_tower_head_bf16(const avlen_resnet18* const* nets, const void* const* 
 // ---- fused layers 3 + 4 of the ResNet towers (tower_tail.hip): one workgroup per image, activations in LDS ----
 int avlen_tower_tail_bf16(const avlen_resnet18* const* nets, const void* const* X, void* const* Y, int groups, int B,
                           hipStream_t stream);
+
+// ---- the ResNet tower in compensated bf16 (tower_x3.hip): stem + four band convs + layers 2-4 fused; fp32 layer-4 output ----
+bool avlen_tower_x3_supported(const avlen_resnet18* net, int S, int C);
+size_t avlen_tower_x3_workspace_bytes(int groups, int B);
+int avlen_tower_x3_fwd(const avlen_resnet18* const* nets, const void* const* imgs, const int* img_u8, const int* channels,
+                       const float* divisors, const int* row_index, float* const* Y, int groups, int B, int S, void* ws,
+                       size_t ws_bytes, hipStream_t stream);

@@ -937,6 +937,30 @@ extern "C" int avlen_resnet18_group_fwd_indexed(const avlen_resnet18* const* net
   return resnet18_group_fwd_bf16(nets, imgs, img_u8, channels, divisors, outs, ld_out, groups, B, S, ws, ws_bytes, st, row_index);
 }
 
+// ---- compensated bf16 (AVLEN_PREC_BF16X3): `groups` towers in lock-step on tower_x3.hip, then fc (8192 -> 64) on the
+// compensated staged GEMM.  row_index (optional): image b of the batch is image row_index[b] of imgs[g].
+extern "C" size_t avlen_resnet18_group_x3_workspace_bytes(int groups, int B) {
+  return avlen_tower_x3_workspace_bytes(groups, B) + (size_t)groups * ((size_t)B * 8192 * sizeof(float) + 256) + GEMM_SCRATCH + 4096;
+}
+extern "C" int avlen_resnet18_group_fwd_x3(const avlen_resnet18* const* nets, const void* const* imgs, const int* img_u8,
+                                           const int* channels, const float* divisors, float* const* outs, int ld_out, int groups,
+                                           int B, int S, const int32_t* row_index, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!nets || groups < 1 || groups > 8 || B <= 0) return AVLEN_ERR_ARG;
+  if (ws_bytes < avlen_resnet18_group_x3_workspace_bytes(groups, B)) return AVLEN_ERR_WS;
+  for (int g = 0; g < groups; g++)
+    if (!avlen_tower_x3_supported(nets[g], S, channels[g])) return AVLEN_ERR_ARG;
+  WsBump w(ws, ws_bytes);
+  float* Y[8];
+  for (int g = 0; g < groups; g++) Y[g] = w.take<float>((size_t)B * 8192);
+  void* gws = w.take<char>(GEMM_SCRATCH);
+  const size_t tb = avlen_tower_x3_workspace_bytes(groups, B);
+  void* tws = w.take<char>(tb);
+  TRY(avlen_tower_x3_fwd(nets, imgs, img_u8, channels, divisors, row_index, Y, groups, B, S, tws, tb, st));
+  Ctx c{st, AVLEN_PREC_BF16X3, gws, GEMM_SCRATCH};
+  for (int g = 0; g < groups; g++) TRY(linear(c, nets[g]->fc, Y[g], 8192, outs[g], ld_out, B, 0, nullptr, 0));
+  return AVLEN_OK;
+}
+
 extern "C" int avlen_resnet18_fwd(const avlen_resnet18* net, const void* img, int img_u8, int B, int S, int C, float divisor,
                                   float* out, int ld_out, int prec, void* ws, size_t ws_bytes, hipStream_t st) {
   if (!net || B <= 0 || ws_bytes < avlen_resnet18_workspace_bytes(B)) return AVLEN_ERR_WS;

@@ -124,8 +124,9 @@ class Packed:
     """Conv / post-flatten fc weights re-laid out for the NHWC implicit-GEMM kernels.  The packed copies
     are derived data: rebuilt (by HIP kernels) whenever the canonical parameters may have changed."""
 
-    def __init__(self, device, flat=None):
-        self.device, self.bufs, self.jobs, self.flat = device, [], [], flat
+    def __init__(self, device, flat=None, lo=False):
+        # lo: also build the LOW planes of the compensated bf16 pairs (w16lo / w16flo: AVLEN_PREC_BF16X3 fast paths)
+        self.device, self.bufs, self.jobs, self.flat, self.lo = device, [], [], flat, lo
 
     def conv(self, conv, has_bias, bf16=True):
         O, I, KH, KW = conv.weight.shape
@@ -143,11 +144,21 @@ class Packed:
         self.jobs.append(("conv", conv.weight, buf, buf16, (O, I, KH, KW), c16))
         v = L.Conv(P(buf), P(conv.bias) if has_bias else None, I, O, KH, KW, conv.stride[0], conv.padding[0])
         v.w16, v.cin16 = P(buf16), c16
+        if self.lo:
+            buf16lo = torch.empty_like(buf16)
+            self.bufs.append(buf16lo)
+            self.jobs.append(("conv_lo", conv.weight, None, buf16lo, (O, I, KH, KW), c16))
+            v.w16lo = P(buf16lo)
         if O % 16 == 0 and (KH * KW * c16) % 32 == 0 and c16 >= 32:       # fragment-order copy (register-resident weights: tower_tail)
             buff = torch.empty_like(buf16)
             self.bufs.append(buff)
             self.jobs.append(("frag", buf16, None, buff, (O, KH * KW * c16), 0))
             v.w16f = P(buff)
+            if self.lo:
+                bufflo = torch.empty_like(buf16)
+                self.bufs.append(bufflo)
+                self.jobs.append(("frag", buf16lo, None, bufflo, (O, KH * KW * c16), 0))
+                v.w16flo = P(bufflo)
         if I * conv.stride[0] == 8 and KW % conv.stride[0] == 0 and conv.padding[0] == 0 and I < 8:
             bufc = torch.empty(O * KH * KW * I, dtype=torch.bfloat16, device=self.device)      # compact: super-pixel form
             self.bufs.append(bufc)
@@ -229,6 +240,8 @@ class Packed:
                 L.call("avlen_pack_conv_weight_bf16", P(wf), P(w16), *dims, c16, st)
             elif kind == "frag":                      # queued after the conv's own job: w16 is up to date
                 L.call("avlen_pack_conv_weight_frag", P(w), P(buf16), dims[0], dims[1], st)
+            elif kind == "conv_lo":
+                L.call("avlen_pack_conv_weight_h16", P(w), P(buf16), *dims, c16, 2, st)
             elif kind == "conv16c":
                 L.call("avlen_pack_conv_weight_bf16", P(w), P(buf16), *dims, c16, st)
             elif kind == "conv":

@@ -445,6 +445,9 @@ class Policy(nn.Module):
 
     # Per-module arithmetic (keys: "towers", "audio", "smt", "clip", "dialog"): modules exchange fp32 tensors, so each one may run
     # in its own mode; unnamed modules use `precision`.
+    def uses_x3(self):
+        return self.precision == "bf16x3" or "bf16x3" in (self.module_precision or {}).values()
+
     def prec_of(self, module):
         mp = self.module_precision
         return _PREC[mp[module]] if mp and module in mp else _PREC[self.precision]
@@ -456,7 +459,7 @@ class Policy(nn.Module):
                                "(there is no CPU fallback)")
         if self._eng is None:
             flat = E.FlatParams(self, self.TRAINED_PREFIXES)
-            packed = E.Packed(flat.device, flat)
+            packed = E.Packed(flat.device, flat, lo=self.uses_x3())
             eng = {"flat": flat, "packed": packed}
             self._build_views(eng, packed)
             ptr2name = {p.data_ptr(): n for n, p in self.named_parameters()}
@@ -879,6 +882,19 @@ class _SMTBase(Net):
             if vis is not None:
                 L.call("avlen_copy_rows", E.P(vis), 128, E.P(feats), F, B, 128, st)
             s_rgb = s_dep = s_aud
+        elif prec == L.PREC_BF16X3 and eng["rgb"].conv1.w16lo:
+            # compensated bf16: both towers in lock-step on tower_x3.hip (row index: minibatch rows read in place)
+            G = 2
+            nets = (C.POINTER(L.ResNet18) * G)(C.pointer(eng["rgb"]), C.pointer(eng["depth"]))
+            imgs = (C.c_void_p * G)(rgb.data_ptr(), depth.data_ptr())
+            outs = (C.c_void_p * G)(feats.data_ptr(), feats.data_ptr() + 4 * 64)
+            chans, divs = (C.c_int * G)(rgb.shape[3], depth.shape[3]), (C.c_float * G)(255.0, 1.0)
+            u8 = (C.c_int * G)(_u8(rgb), 0)
+            nbg = L.lib.avlen_resnet18_group_x3_workspace_bytes(G, B)
+            wsg = pol._ws.get("resnet_pair_x3", nbg, dev)
+            L.call("avlen_resnet18_group_fwd_x3", nets, imgs, u8, chans, divs, outs, F, G, B, S, None, E.P(wsg), nbg, st)
+            L.call("avlen_cnn3_fwd", C.byref(eng["audio"]), E.P(spec), B, H, W, E.P(feats, 144), F, prec_a, E.P(ws2), nb2, st)
+            s_rgb = s_dep = cur
         else:
             nb = L.lib.avlen_resnet18_workspace_bytes(B)
             ws_rgb, ws_dep = pol._ws.get("resnet_rgb", nb, dev), pol._ws.get("resnet_depth", nb, dev)

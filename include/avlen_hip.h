@@ -204,6 +204,16 @@ int avlen_concat_rows(const float* a, int lda, int na, const float* b, int ldb, 
 size_t avlen_resnet18_workspace_bytes(int B);
 /* SMTCNN tower (smt_cnn.py:78-115 + smt_resnet.py:132-146) on one modality: img (B,S,S,C) raw sensor,
  * divisor = 255 for rgb, 1 for depth; writes 64 features to out[b*ld_out + 0..63]. */
+/* The same towers in compensated bf16 (AVLEN_PREC_BF16X3; needs the w16lo / w16flo planes): `groups` towers of identical
+ * shape, image b of the batch = image row_index[b] of imgs[g] when row_index is given; outs[g] (B, 64) fp32 with row stride ld_out. */
+size_t avlen_resnet18_group_x3_workspace_bytes(int groups, int B);
+int avlen_resnet18_group_fwd_x3(const avlen_resnet18* const* nets, const void* const* imgs, const int* img_u8, const int* channels,
+                                const float* divisors, float* const* outs, int ld_out, int groups, int B, int S,
+                                const int32_t* row_index, void* ws, size_t ws_bytes, avlen_stream_t stream);
+/* avlen_pack_conv_weight_bf16 into 16-bit format fmt (0 = bf16, 1 = fp16, 2 = low plane of the compensated bf16 pair) */
+int avlen_pack_conv_weight_h16(const float* w_oihw, void* w_packed, int O, int I, int KH, int KW, int Cpad, int fmt,
+                               avlen_stream_t stream);
+int avlen_pack_fc_after_flatten_h16(const float* w, void* w_packed, int O, int C, int HW, int fmt, avlen_stream_t stream);
 int avlen_resnet18_fwd(const avlen_resnet18* net, const void* img, int img_u8, int B, int S, int C, float divisor, float* out,
                        int ld_out, int prec, void* ws, size_t ws_bytes, avlen_stream_t stream);
 /* `groups` (<= 8) towers of identical shape in lock-step on the bf16 fast path: every conv / GroupNorm / fc is ONE

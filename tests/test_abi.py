@@ -33,9 +33,9 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_sizes_match_header_layout():
     from avlen_amd import _lib
-    # pointer,pointer,int,int
-    assert ctypes.sizeof(_lib.Linear) == 40 and ctypes.sizeof(_lib.Conv) == 72 and ctypes.sizeof(_lib.Affine) == 16
-    assert ctypes.sizeof(_lib.Mha) == 80
+    # avlen_linear: 2 pointers, 2 ints, pointer, int (+pad), pointer; avlen_conv: 2 pointers, 6 ints, pointer, int (+pad), 4 pointers
+    assert ctypes.sizeof(_lib.Linear) == 48 and ctypes.sizeof(_lib.Conv) == 88 and ctypes.sizeof(_lib.Affine) == 16
+    assert ctypes.sizeof(_lib.Mha) == 96
 
 
 def test_struct_sizes_against_c_compiler(tmp_path):
