@@ -45,6 +45,9 @@ constexpr int NTH = 1024, NW = 16;
 constexpr int TILE_BYTES = D * 128;            // one ring stage: [256 features][64 k] bf16
 constexpr int NS = 3;             // up to 2 tiles (64 KiB) in flight while one is multiplied
 constexpr int NIMG = 2;           // activation images (a third operand is parked in a register save slot)
+// Compensated bf16 (X3): the activation image is a PAIR of bf16 planes (hi, lo) and a block takes 8 batch rows instead of 16, so
+// the pair fits the space of the plain image (the chain is bound by the weight stream, not by the half-used MFMA columns); the
+// weight stream carries [16][32] hi + [16][32] lo per ring stage (the same 2 KiB) and a k-step is three MFMAs.
 constexpr int XS_BYTES = NIMG * 16 * XLD * 2;
 constexpr int RED_BYTES = NW * 16 * 2 * 4;
 constexpr int MAX_LIN = 24, MAX_PAR = 32;      // Linear steps / 256-float parameter vectors per program
@@ -52,7 +55,7 @@ constexpr int ATT_BYTES = NW * 16 * 4 * 4;     // attention score partials [wave
 
 // what the kernel reads: compiled from avlen_chain on the host
 struct DevOp { int kind, k, ld, ld2, act, res, buf, out_buf, par, div, seq; float scale; const void* p0; const void* p1; };
-struct DevLin { const char* w; int ld, nkt, k, pad; };
+struct DevLin { const char* w; const char* wl; int ld, nkt, k, pad; };
 struct DevProg {
   int n, n_lin, n_par, pad;
   DevOp op[AVLEN_CHAIN_MAX_OPS];
@@ -66,23 +69,28 @@ static_assert(LDS_BYTES <= 160 * 1024, "chain kernel LDS budget");
 static_assert(sizeof(DevProg) <= 4000, "kernel argument limit");
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ float lo_of(float v, bf16 h) { return v - (float)h; }
 // LDS-only barrier: does not drain the weight tiles in flight
 __device__ __forceinline__ void bar() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 }
 
+template <bool X3>
 __global__ __launch_bounds__(NTH) void chain_kernel(DevProg kprog, int B) {
+  constexpr int RB = X3 ? 8 : 16;                                            // batch rows per block
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* ring = lds;                                                          // [NS][256][128 B]
-  bf16* xs = reinterpret_cast<bf16*>(lds + NS * TILE_BYTES);                 // [NIMG][16][XLD]
+  bf16* xs = reinterpret_cast<bf16*>(lds + NS * TILE_BYTES);                 // [NIMG][RB][XLD] (X3: hi planes, then the lo planes)
+  bf16* xl = xs + NIMG * RB * XLD;                                           // X3 only
   float* red = reinterpret_cast<float*>(lds + NS * TILE_BYTES + XS_BYTES);   // [8][16 rows][4]
   float* att = reinterpret_cast<float*>(lds + NS * TILE_BYTES + XS_BYTES + RED_BYTES);                  // [NW][16][4]
   DevProg* sp = reinterpret_cast<DevProg*>(lds + NS * TILE_BYTES + XS_BYTES + RED_BYTES + ATT_BYTES);
   float* par = reinterpret_cast<float*>(lds + NS * TILE_BYTES + XS_BYTES + RED_BYTES + ATT_BYTES + PROG_BYTES);   // [MAX_PAR][256]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, q = lane >> 4;
-  const int row = blockIdx.x * 16 + c;                 // this lane's batch row
-  const bool rok = row < B;
+  const int cr = c & (RB - 1);                         // X3: lanes 8..15 mirror rows 0..7 (their results are never stored)
+  const int row = blockIdx.x * RB + cr;                // this lane's batch row
+  const bool rok = c < RB && row < B;
   const int n0 = wave * 16;
 
   // ---- program and parameter vectors -> LDS ----
@@ -100,11 +108,19 @@ __global__ __launch_bounds__(NTH) void chain_kernel(DevProg kprog, int B) {
   const int n_ops = sp->n, n_lin = sp->n_lin;
 
   float cur[4] = {0.f, 0.f, 0.f, 0.f}, sav0[4] = {0.f, 0.f, 0.f, 0.f}, sav1[4] = {0.f, 0.f, 0.f, 0.f};
-  auto publish = [&](int buf) {                        // cur -> bf16 image xs[buf][row][feature]
+  auto publish = [&](int buf) {                        // cur -> bf16 image xs[buf][row][feature] (X3: + the low plane)
     bf16x4 o;
 #pragma unroll
     for (int r = 0; r < 4; r++) o[r] = (bf16)cur[r];
-    *reinterpret_cast<bf16x4*>(&xs[(buf * 16 + c) * XLD + n0 + q * 4]) = o;
+    if (c < RB) {
+      *reinterpret_cast<bf16x4*>(&xs[(buf * RB + c) * XLD + n0 + q * 4]) = o;
+      if (X3) {
+        bf16x4 l;
+#pragma unroll
+        for (int r = 0; r < 4; r++) l[r] = (bf16)lo_of(cur[r], o[r]);
+        *reinterpret_cast<bf16x4*>(&xl[(buf * RB + c) * XLD + n0 + q * 4]) = l;
+      }
+    }
   };
 
   // ---- the weight-tile stream: tile t of the program = (Linear step, 64-wide k block); ring stage = t % NS ----
@@ -122,12 +138,22 @@ __global__ __launch_bounds__(NTH) void chain_kernel(DevProg kprog, int B) {
     char* stage = wring + st_issue * 2048;
     if (++st_issue == NS) st_issue = 0;
 #if !defined(AVLEN_CHAIN_LAB) || AVLEN_CHAIN_LAB != 2
+    if (X3) {                          // piece 0: [16 rows][32 k] of W_hi, piece 1: of W_lo (64-byte rows, chunk ^ ((row >> 1) & 3))
+      const int frow = n0 + (lane >> 2), ch = (lane & 3) ^ ((frow >> 1) & 3);
+      const int kcol = ld_kt * 32 + ch * 8;
+      const long off = ((long)frow * ldl.ld + kcol) * 2;
+      const bool ok = kcol < ldl.k;
+      const char* zp = (const char*)g_zero_page_ch + tid * 16;
+      __builtin_amdgcn_global_load_lds((const void*)(ok ? ldl.w + off : zp), (__attribute__((address_space(3))) void*)(stage), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const void*)(ok ? ldl.wl + off : zp), (__attribute__((address_space(3))) void*)(stage + 1024), 16, 0, 0);
+    } else {
 #pragma unroll
     for (int r = 0; r < 2; r++) {
       const int frow = n0 + r * 8 + (lane >> 3), ch = (lane & 7) ^ ((frow >> 1) & 7);
       const int kcol = ld_kt * 64 + ch * 8;
       const char* src = kcol < ldl.k ? ldl.w + ((long)frow * ldl.ld + kcol) * 2 : (const char*)g_zero_page_ch + tid * 16;
       __builtin_amdgcn_global_load_lds((const void*)src, (__attribute__((address_space(3))) void*)(stage + r * 1024), 16, 0, 0);
+    }
     }
 #endif
     issued++;
@@ -145,13 +171,18 @@ __global__ __launch_bounds__(NTH) void chain_kernel(DevProg kprog, int B) {
       case AVLEN_CH_LOAD_X16: {                        // bf16 global rows [B][ld] -> xs[buf][.][0:K)
         bar();
         const bf16* src = (const bf16*)op.p0;
+        const bf16* srcl = (const bf16*)op.p1;         // X3: the low plane (same layout)
         const int cpr = ((op.k + 63) >> 6) << 3;       // 16-byte chunks per row, zero-filled up to a whole 64-wide k block
-        for (int i = tid; i < 16 * cpr; i += NTH) {
+        for (int i = tid; i < RB * cpr; i += NTH) {
           int rr = i / cpr, ch = i - rr * cpr;
-          int gr = blockIdx.x * 16 + rr;
-          uint4 v = make_uint4(0, 0, 0, 0);
-          if (gr < B && ch * 8 < op.k) v = *reinterpret_cast<const uint4*>(src + (long)gr * op.ld + ch * 8);
-          *reinterpret_cast<uint4*>(&xs[(op.buf * 16 + rr) * XLD + ch * 8]) = v;
+          int gr = blockIdx.x * RB + rr;
+          uint4 v = make_uint4(0, 0, 0, 0), vl = v;
+          if (gr < B && ch * 8 < op.k) {
+            v = *reinterpret_cast<const uint4*>(src + (long)gr * op.ld + ch * 8);
+            if (X3) vl = *reinterpret_cast<const uint4*>(srcl + (long)gr * op.ld + ch * 8);
+          }
+          *reinterpret_cast<uint4*>(&xs[(op.buf * RB + rr) * XLD + ch * 8]) = v;
+          if (X3) *reinterpret_cast<uint4*>(&xl[(op.buf * RB + rr) * XLD + ch * 8]) = vl;
         }
         bar();
         break;
@@ -168,8 +199,9 @@ __global__ __launch_bounds__(NTH) void chain_kernel(DevProg kprog, int B) {
       }
       case AVLEN_CH_LINEAR: {                          // cur = act(W x + b) [+ save slot]; x = xs[buf][.][0:K)
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const int nkt = (op.k + 63) >> 6;
-        const bf16* xrow = &xs[(op.buf * 16 + c) * XLD + q * 8];
+        const int nkt = X3 ? (op.k + 31) >> 5 : (op.k + 63) >> 6;
+        const bf16* xrow = &xs[(op.buf * RB + cr) * XLD + q * 8];
+        const bf16* xrowl = &xl[(op.buf * RB + cr) * XLD + q * 8];
         const int wr = n0 + c;                         // this lane's feature row inside the tile
         const int wsw = (wr >> 1) & 7;
         for (int kt = 0; kt < nkt; kt++) {
@@ -181,7 +213,16 @@ __global__ __launch_bounds__(NTH) void chain_kernel(DevProg kprog, int B) {
           consumed++;
           issue_one();
 #if !defined(AVLEN_CHAIN_LAB) || AVLEN_CHAIN_LAB != 3
-          {                                            // all four fragment reads in flight before the first MFMA
+          if (X3) {
+            const int sw3 = (wr >> 1) & 3;
+            bf16x8 wh = *reinterpret_cast<const bf16x8*>(stage + c * 64 + ((q ^ sw3) << 4));
+            bf16x8 wl = *reinterpret_cast<const bf16x8*>(stage + 1024 + c * 64 + ((q ^ sw3) << 4));
+            bf16x8 xh = *reinterpret_cast<const bf16x8*>(xrow + kt * 32);
+            bf16x8 xlo = *reinterpret_cast<const bf16x8*>(xrowl + kt * 32);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xlo, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc, 0, 0, 0);
+          } else {                                     // all four fragment reads in flight before the first MFMA
             bf16x8 wf0 = *reinterpret_cast<const bf16x8*>(stage + c * 128 + ((q ^ wsw) << 4));
             bf16x8 wf1 = *reinterpret_cast<const bf16x8*>(stage + c * 128 + (((4 + q) ^ wsw) << 4));
             bf16x8 xf0 = *reinterpret_cast<const bf16x8*>(xrow + kt * 64);
@@ -264,7 +305,7 @@ __global__ __launch_bounds__(NTH) void chain_kernel(DevProg kprog, int B) {
         break;
       }
       case AVLEN_CH_ATTN: {                            // 8 heads x D=32 inside groups of `seq` consecutive rows
-        const int S = op.seq, g0 = (c / S) * S;
+        const int S = op.seq, g0 = (cr / S) * S;
         float qv[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) qv[r] = op.res == 0 ? sav0[r] : sav1[r];
@@ -272,20 +313,26 @@ __global__ __launch_bounds__(NTH) void chain_kernel(DevProg kprog, int B) {
 #pragma unroll
         for (int j = 0; j < 4; j++)
           if (j < S) {
-            bf16x4 kv = *reinterpret_cast<const bf16x4*>(&xs[(op.buf * 16 + g0 + j) * XLD + n0 + q * 4]);
+            bf16x4 kv = *reinterpret_cast<const bf16x4*>(&xs[(op.buf * RB + g0 + j) * XLD + n0 + q * 4]);
+            float kf[4] = {(float)kv[0], (float)kv[1], (float)kv[2], (float)kv[3]};
+            if (X3) {
+              bf16x4 kl = *reinterpret_cast<const bf16x4*>(&xl[(op.buf * RB + g0 + j) * XLD + n0 + q * 4]);
 #pragma unroll
-            for (int r = 0; r < 4; r++) part[j] += qv[r] * (float)kv[r];
+              for (int r = 0; r < 4; r++) kf[r] += (float)kl[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) part[j] += qv[r] * kf[r];
           }
 #pragma unroll
         for (int j = 0; j < 4; j++) { part[j] += __shfl_xor(part[j], 16, 64); part[j] += __shfl_xor(part[j], 32, 64); }
-        if (q == 0) *reinterpret_cast<float4*>(&att[(wave * 16 + c) * 4]) = make_float4(part[0], part[1], part[2], part[3]);
+        if (q == 0 && c < RB) *reinterpret_cast<float4*>(&att[(wave * 16 + c) * 4]) = make_float4(part[0], part[1], part[2], part[3]);
         bar();
         // a head is 32 features = this wave and its neighbour
-        const float4 pa = *reinterpret_cast<const float4*>(&att[((wave & ~1) * 16 + c) * 4]);
-        const float4 pb = *reinterpret_cast<const float4*>(&att[((wave | 1) * 16 + c) * 4]);
+        const float4 pa = *reinterpret_cast<const float4*>(&att[((wave & ~1) * 16 + cr) * 4]);
+        const float4 pb = *reinterpret_cast<const float4*>(&att[((wave | 1) * 16 + cr) * 4]);
         float sc[4] = {pa.x + pb.x, pa.y + pb.y, pa.z + pb.z, pa.w + pb.w};
         const float* km = (const float*)op.p0;
-        const long grp = (long)(blockIdx.x * 16 + c) / S;
+        const long grp = (long)(blockIdx.x * RB + cr) / S;
         float mx = -INFINITY;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -301,9 +348,15 @@ __global__ __launch_bounds__(NTH) void chain_kernel(DevProg kprog, int B) {
 #pragma unroll
         for (int j = 0; j < 4; j++)
           if (j < S) {
-            bf16x4 vv = *reinterpret_cast<const bf16x4*>(&xs[(op.ld2 * 16 + g0 + j) * XLD + n0 + q * 4]);
+            bf16x4 vv = *reinterpret_cast<const bf16x4*>(&xs[(op.ld2 * RB + g0 + j) * XLD + n0 + q * 4]);
+            float vf[4] = {(float)vv[0], (float)vv[1], (float)vv[2], (float)vv[3]};
+            if (X3) {
+              bf16x4 vl = *reinterpret_cast<const bf16x4*>(&xl[(op.ld2 * RB + g0 + j) * XLD + n0 + q * 4]);
 #pragma unroll
-            for (int r = 0; r < 4; r++) o[r] += sc[j] * inv * (float)vv[r];
+              for (int r = 0; r < 4; r++) vf[r] += (float)vl[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) o[r] += sc[j] * inv * vf[r];
           }
 #pragma unroll
         for (int r = 0; r < 4; r++) cur[r] = o[r];
@@ -334,7 +387,7 @@ __global__ __launch_bounds__(NTH) void chain_kernel(DevProg kprog, int B) {
 
 }  // namespace
 
-int avlen_chain_run(const avlen_chain* prog, int B, hipStream_t stream) {
+int avlen_chain_run(const avlen_chain* prog, int B, hipStream_t stream, int x3) {
   if (!prog || prog->n < 1 || prog->n > AVLEN_CHAIN_MAX_OPS || B <= 0) return AVLEN_ERR_ARG;
   DevProg dp;
   memset(&dp, 0, sizeof(dp));
@@ -350,7 +403,8 @@ int avlen_chain_run(const avlen_chain* prog, int B, hipStream_t stream) {
     if (o.kind == AVLEN_CH_ADD_PE && (!o.p0 || !o.p1 || o.k < 1)) return AVLEN_ERR_ARG;
     if (o.kind == AVLEN_CH_LINEAR) {
       if (o.k % 8 || o.k > KMAX || o.k < 8 || o.ld < o.k || o.ld % 8 || !o.p0 || dp.n_lin >= MAX_LIN) return AVLEN_ERR_ARG;
-      dp.lin[dp.n_lin++] = DevLin{(const char*)o.p0, o.ld, (o.k + 63) >> 6, o.k, 0};
+      if (x3 && !o.p2) return AVLEN_ERR_ARG;
+      dp.lin[dp.n_lin++] = DevLin{(const char*)o.p0, (const char*)o.p2, o.ld, x3 ? (o.k + 31) >> 5 : (o.k + 63) >> 6, o.k, 0};
       if (o.p1) {
         if (dp.n_par >= MAX_PAR || ((uintptr_t)o.p1 & 15)) return AVLEN_ERR_ARG;
         d.par = dp.n_par; dp.par_src[dp.n_par++] = (const float*)o.p1;
@@ -359,14 +413,16 @@ int avlen_chain_run(const avlen_chain* prog, int B, hipStream_t stream) {
       if (!o.p0 || !o.p1 || dp.n_par + 2 > MAX_PAR || (((uintptr_t)o.p0 | (uintptr_t)o.p1) & 15)) return AVLEN_ERR_ARG;
       d.par = dp.n_par; dp.par_src[dp.n_par++] = (const float*)o.p0; dp.par_src[dp.n_par++] = (const float*)o.p1;
     } else if (o.kind == AVLEN_CH_LOAD_X16) {
-      if (o.k % 8 || o.k > KMAX || o.ld % 8) return AVLEN_ERR_ARG;
+      if (o.k % 8 || o.k > KMAX || o.ld % 8 || (x3 && !o.p1)) return AVLEN_ERR_ARG;
     }
   }
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL(chain_kernel, dim3(ceil_div(B, 16)), dim3(NTH), LDS_BYTES, stream, dp, B);
+  if (x3) hipLaunchKernelGGL(chain_kernel<true>, dim3(ceil_div(B, 8)), dim3(NTH), LDS_BYTES, stream, dp, B);
+  else hipLaunchKernelGGL(chain_kernel<false>, dim3(ceil_div(B, 16)), dim3(NTH), LDS_BYTES, stream, dp, B);
   return avlen_launch_status();
 }

@@ -7,7 +7,8 @@
 // per-call context of the module-level helpers (modules.hip): stream, arithmetic mode, split-K scratch, optional ragged-batch
 // descriptors, optional operand scratch of the large-M bf16 training products
 struct avlen_ctx { hipStream_t st; int prec; void* gws; size_t gws_bytes; const int* live = nullptr; const int* seg = nullptr;
-                   void* xs = nullptr; size_t xs_bytes = 0; };
+                   void* xs = nullptr; size_t xs_bytes = 0;
+                   int x3 = 0; };      // fast paths: the 16-bit operands are compensated bf16 pairs (hi plane + lo plane)
 // Operand options of the 16-bit MFMA GEMM family (igemm2.hip).  f16: the 16-bit operands / outputs are IEEE half instead of bf16.
 // x3 ("bf16x3", compensated bf16): every operand is a pair of bf16 planes, hi = bf16(x) and lo = bf16(x - hi); the lo plane of A / W
 // lies a_lo / b_lo BYTES behind the hi plane, the lo plane of the bf16 output c16_lo ELEMENTS behind C16 (0: hi only).
@@ -91,7 +92,8 @@ int avlen_dconv_bf16_grouped(const void* const* X, const void* const* Wp, void* 
 bool avlen_dconv_supported(int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
 
 // ---- fused row-batch chain (chain.hip): a program of d=256 Linear / LayerNorm steps run by one kernel ----
-#define AVLEN_CH_LOAD_X16 1   /* p0: bf16 [B][ld] rows -> LDS image `buf`, k columns (multiple of 8; zero-filled to a multiple of 64) */
+#define AVLEN_CH_LOAD_X16 1   /* p0: bf16 [B][ld] rows -> LDS image `buf`, k columns (multiple of 8; zero-filled to a multiple of 64);
+                                 compensated programs: p1 = the low plane of the same rows */
 #define AVLEN_CH_LOAD_CUR 2   /* p0: fp32 [B/div][ld] (256 features), row r reads source row r/div -> registers, image -> `buf` */
 #define AVLEN_CH_LINEAR 3     /* p0: bf16 W[256][ld], p1: fp32 bias[256] or null; input image `buf` (k columns, k % 8 == 0);
                                  act; res = 1 | 2 adds save slot 0 | 1; result -> registers and image `out_buf` */
@@ -106,9 +108,11 @@ bool avlen_dconv_supported(int W, int Cin, int Cout, int KH, int KW, int stride,
 #define AVLEN_CH_ADD_PE 9     /* registers += p0[clamp(int(p1[r/div]), 0, k-1)][0..256): positional table p0 fp32 [k][256],
                                  p1 fp32 [B/div]; result -> registers and image `out_buf` */
 #define AVLEN_CHAIN_MAX_OPS 40
-typedef struct { int kind, k, ld, ld2, act, res, buf, out_buf, div, seq; float scale; int pad; const void* p0; const void* p1; } avlen_chain_op;
+typedef struct { int kind, k, ld, ld2, act, res, buf, out_buf, div, seq; float scale; int pad; const void* p0; const void* p1;
+                 const void* p2; } avlen_chain_op;      /* p2: LINEAR: the low plane of the weights (compensated bf16 programs) */
 typedef struct { int n; avlen_chain_op op[AVLEN_CHAIN_MAX_OPS]; } avlen_chain;
-int avlen_chain_run(const avlen_chain* prog, int B, hipStream_t stream);
+// x3: compensated bf16 (LINEAR needs p2; LOAD_X16 takes the low plane of its rows in p1); a block then takes 8 batch rows
+int avlen_chain_run(const avlen_chain* prog, int B, hipStream_t stream, int x3 = 0);
 
 // ---- preprocessing + stem + layers 1-2 of the ResNet towers (tower_head.hip): one workgroup per image, activations in LDS / registers ----
 bool avlen_tower_head_supported(const avlen_resnet18* net, int S, int C);

@@ -453,8 +453,15 @@ namespace {
 bool lin16_ok(const avlen_linear& L) { return L.w16 != nullptr && (L.ld16 % 8) == 0; }
 
 // Y = act(X16 * W16^T + b) + res  -> fp32 (Y32) and/or bf16 (Y16)
+// c.x3: X16 / Y16 are compensated pairs, their low planes xlo / ylo ELEMENTS behind the high planes; the weights' low plane is L.w16lo
 int linear16(const Ctx& c, const avlen_linear& L, const bf16* X16, int ldx, float* Y32, int ld32, bf16* Y16, int ld16, int M,
-             int act, const float* res, int ldr) {
+             int act, const float* res, int ldr, long xlo = 0, long ylo = 0) {
+  if (c.x3) {
+    if (!L.w16lo || !xlo || (Y16 && !ylo)) return AVLEN_ERR_ARG;
+    avlen_g2_opts o; o.x3 = 1; o.a_lo = xlo * 2; o.b_lo = (const char*)L.w16lo - (const char*)L.w16; o.c16_lo = ylo;
+    return avlen_gemm_bf16_dyn(X16, ldx, L.w16, L.ld16, Y32, ld32, Y16, ld16, L.b, res, ldr, M, c.live, L.out_f, L.ld16, act, c.gws,
+                               c.gws_bytes, c.st, &o);
+  }
   if (c.live)          // ragged batch: only the first *live rows exist
     return avlen_gemm_bf16_dyn(X16, ldx, L.w16, L.ld16, Y32, ld32, Y16, ld16, L.b, res, ldr, M, c.live, L.out_f, L.ld16, act, c.gws,
                                c.gws_bytes, c.st);
@@ -466,30 +473,36 @@ int ln16(const Ctx& c, const float* x, const avlen_affine& a, float* y, bf16* y1
   return avlen_layernorm_fwd16(x, nullptr, a.g, a.b, y, y16, nullptr, nullptr, rows, d, 1e-5f, c.st);
 }
 int linear16_rows(const Ctx& c, const avlen_linear& L, int r0, int n, const bf16* X16, int ldx, float* Y32, int ld32,
-                  bf16* Y16, int ld16, int M, int act) {
+                  bf16* Y16, int ld16, int M, int act, long xlo = 0, long ylo = 0) {
   avlen_linear S = L;
   S.w16 = (char*)L.w16 + (size_t)r0 * L.ld16 * 2; S.b = L.b ? L.b + r0 : nullptr; S.out_f = n;
-  return linear16(c, S, X16, ldx, Y32, ld32, Y16, ld16, M, act, nullptr, 0);
+  if (L.w16lo) S.w16lo = (char*)L.w16lo + (size_t)r0 * L.ld16 * 2;
+  return linear16(c, S, X16, ldx, Y32, ld32, Y16, ld16, M, act, nullptr, 0, xlo, ylo);
 }
 
 // ---- program builder for the fused row-batch chain (chain.hip) ----
 struct ChainB {
-  avlen_chain p; bool ok;
-  ChainB() : ok(true) { p.n = 0; }
+  avlen_chain p; bool ok; bool x3;                  // x3: a compensated-bf16 program (run with avlen_chain_run(..., 1))
+  explicit ChainB(bool x3_ = false) : ok(true), x3(x3_) { p.n = 0; }
   avlen_chain_op& next(int kind) {
     static avlen_chain_op dummy;
     if (p.n >= AVLEN_CHAIN_MAX_OPS) { ok = false; return dummy; }
     avlen_chain_op& o = p.op[p.n++];
-    o = avlen_chain_op{kind, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0.f, 0, nullptr, nullptr};
+    o = avlen_chain_op{kind, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0.f, 0, nullptr, nullptr, nullptr};
     return o;
   }
-  void load_x16(const bf16* x, int ld, int k, int buf) { auto& o = next(AVLEN_CH_LOAD_X16); o.p0 = x; o.ld = ld; o.k = k; o.buf = buf; }
+  int run(int B, hipStream_t st) const { return avlen_chain_run(&p, B, st, x3 ? 1 : 0); }
+  void load_x16(const bf16* x, int ld, int k, int buf, const bf16* xlo = nullptr) {
+    auto& o = next(AVLEN_CH_LOAD_X16); o.p0 = x; o.p1 = xlo; o.ld = ld; o.k = k; o.buf = buf;
+    if (x3 && !xlo) ok = false;
+  }
   void load_cur(const float* x, int ld, int buf, int div = 1) { auto& o = next(AVLEN_CH_LOAD_CUR); o.p0 = x; o.ld = ld; o.buf = buf; o.div = div; }
   void linear(const avlen_linear& L, int r0, int act, int res, int buf, int out_buf) {
     auto& o = next(AVLEN_CH_LINEAR);
     o.p0 = (const char*)L.w16 + (size_t)r0 * L.ld16 * 2; o.p1 = L.b ? L.b + r0 : nullptr;
+    o.p2 = L.w16lo ? (const char*)L.w16lo + (size_t)r0 * L.ld16 * 2 : nullptr;
     o.k = L.ld16; o.ld = L.ld16; o.act = act; o.res = res; o.buf = buf; o.out_buf = out_buf;
-    if (!L.w16 || (L.ld16 % 8) || L.ld16 > 320 || L.out_f < r0 + 256) ok = false;
+    if (!L.w16 || (L.ld16 % 8) || L.ld16 > 320 || L.out_f < r0 + 256 || (x3 && !L.w16lo)) ok = false;
   }
   void ln(const avlen_affine& a, int out_buf) { auto& o = next(AVLEN_CH_LAYERNORM); o.p0 = a.g; o.p1 = a.b; o.out_buf = out_buf; }
   void save(int slot = 0) { auto& o = next(AVLEN_CH_SAVE); o.res = slot; }
@@ -588,7 +601,7 @@ __global__ void smt_build16_kernel(const float* __restrict__ x, const float* __r
                                    const int32_t* __restrict__ mem_index, int NC, const float* __restrict__ masks,
                                    const float* __restrict__ pw, const float* __restrict__ pb, bf16* __restrict__ XF, int ldxf,
                                    float* __restrict__ maskx, int B, int M, int F, int pc, int cto,
-                                   const int* __restrict__ seg, const int* __restrict__ rowmap) {
+                                   const int* __restrict__ seg, const int* __restrict__ rowmap, bf16* __restrict__ XFlo) {
   const int S = cto ? 1 : M + 1;
   int row = blockIdx.x, b = row / S, s = cto ? M : row % S;
   if (rowmap) {                       // ragged: compact row -> (sample, slot)
@@ -624,7 +637,9 @@ __global__ void smt_build16_kernel(const float* __restrict__ x, const float* __r
 #pragma unroll
       for (int k = 0; k < 5; k++) v += pw[j * 5 + k] * fmt[k];
     } else if (i < F + 12) v = src[i - 12];
-    o[i] = (bf16)v;
+    const bf16 hv = (bf16)v;
+    o[i] = hv;
+    if (XFlo) XFlo[(long)row * ldxf + i] = (bf16)(v - (float)hv);
   }
 }
 
@@ -1297,13 +1312,14 @@ struct Tr16Ws {
 
 void tr16_layout(WsBump& w, Tr16Ws& t, long B, long S, int d, bool cto) {
   long R = B * S;
-  t.Z16 = w.take<bf16>(R * d); t.AO16 = w.take<bf16>(R * d); t.X116 = w.take<bf16>(R * d); t.F116 = w.take<bf16>(R * d);
-  t.MEM16 = w.take<bf16>(R * d);
+  // every bf16 buffer has room for the low plane of a compensated pair right behind it (lo = hi + R*d / B*d elements)
+  t.Z16 = w.take<bf16>(2 * R * d); t.AO16 = w.take<bf16>(2 * R * d); t.X116 = w.take<bf16>(2 * R * d); t.F116 = w.take<bf16>(2 * R * d);
+  t.MEM16 = w.take<bf16>(2 * R * d);
   t.Z = w.take<float>(R * d); t.QKV = cto ? nullptr : w.take<float>(R * 3 * d); t.T1 = w.take<float>(R * d);
   t.X1 = w.take<float>(R * d); t.T2 = w.take<float>(R * d); t.X2 = w.take<float>(R * d);
   t.KVc = cto ? nullptr : w.take<float>(R * 2 * d);
-  t.tgt16 = w.take<bf16>(B * d); t.V016 = w.take<bf16>(B * d); t.Y116 = w.take<bf16>(B * d); t.AOc16 = w.take<bf16>(B * d);
-  t.Y216 = w.take<bf16>(B * d); t.G116 = w.take<bf16>(B * d);
+  t.tgt16 = w.take<bf16>(2 * B * d); t.V016 = w.take<bf16>(2 * B * d); t.Y116 = w.take<bf16>(2 * B * d); t.AOc16 = w.take<bf16>(2 * B * d);
+  t.Y216 = w.take<bf16>(2 * B * d); t.G116 = w.take<bf16>(2 * B * d);
   t.U1 = w.take<float>(B * d); t.Y1 = w.take<float>(B * d); t.Qc = w.take<float>(B * d); t.U2 = w.take<float>(B * d);
   t.Y2 = w.take<float>(B * d); t.U3 = w.take<float>(B * d); t.Y3 = w.take<float>(B * d);
 }
@@ -1386,6 +1402,12 @@ int dec_fwd16(const Ctx& c, const avlen_transformer& tr, Tr16Ws& t, const float*
 }
 
 bool smt_has16(const avlen_smt* p) { return lin16_ok(p->fus0) && lin16_ok(p->fus2) && tr_has16(p->tr); }
+bool tr_has16lo(const avlen_transformer& t) {
+  return t.enc.self_attn.in_proj.w16lo && t.enc.self_attn.out_proj.w16lo && t.enc.lin1.w16lo && t.enc.lin2.w16lo &&
+         t.dec.cross_attn.in_proj.w16lo && t.dec.cross_attn.out_proj.w16lo && t.dec.self_attn.in_proj.w16lo &&
+         t.dec.self_attn.out_proj.w16lo && t.dec.lin1.w16lo && t.dec.lin2.w16lo;
+}
+bool smt_has16lo(const avlen_smt* p) { return smt_has16(p) && p->fus0.w16lo && p->fus2.w16lo && tr_has16lo(p->tr); }
 
 struct Smt16Ws { bf16 *XF, *H1; float* maskx; Tr16Ws tr; void* gws; size_t gwsb; int ldxf; int *seg, *rowmap; };
 
@@ -1393,7 +1415,7 @@ void smt16_layout(WsBump& w, Smt16Ws& s, const avlen_smt* p, long B, long M, int
   long S = cto ? 1 : M + 1, R = B * S; int d = p->tr.d;
   (void)F;
   s.ldxf = p->fus0.ld16;
-  s.XF = w.take<bf16>(R * s.ldxf); s.H1 = w.take<bf16>(R * d); s.maskx = w.take<float>(B * S);
+  s.XF = w.take<bf16>(2 * R * s.ldxf); s.H1 = w.take<bf16>(2 * R * d); s.maskx = w.take<float>(B * S);
   s.seg = w.take<int>(B + 1); s.rowmap = w.take<int>(R);
   tr16_layout(w, s.tr, B, S, d, cto);
   s.gwsb = zmax((size_t)(32u << 20), avlen_gemm_bf16_workspace_bytes(128, 768));
@@ -1405,12 +1427,15 @@ size_t smt16_ws_bytes(const avlen_smt* p, int B, int M, int F, bool cto) {
 }
 
 // SMTStateEncoder forward, inference only, bf16 operands (all rollout calls of pi_g / pi_l / pi_q)
+// x3: compensated bf16 -- every 16-bit operand is a (hi, lo) pair, the weights' low planes are avlen_linear::w16lo.  Returns
+// AVLEN_NOT_BIG when the shape has no compensated fast path yet (caller: fp32-staged path with compensated products).
 int smt_fwd_infer_bf16(const avlen_smt* p, const float* x, const float* memory, const int32_t* mem_index, int NC,
                        const float* masks, const float* goal, float* out, int B, int M, int F, int pose_col, bool cto,
-                       void* ws, size_t ws_bytes, hipStream_t st) {
+                       void* ws, size_t ws_bytes, hipStream_t st, bool x3 = false) {
   if (ws_bytes < smt16_ws_bytes(p, B, M, F, cto)) return AVLEN_ERR_WS;
   WsBump w(ws, ws_bytes); Smt16Ws s; smt16_layout(w, s, p, B, M, F, cto);
   Ctx c{st, AVLEN_PREC_BF16, s.gws, s.gwsb};
+  c.x3 = x3 ? 1 : 0;
   const avlen_transformer& tr = p->tr;
   const int S = cto ? 1 : M + 1, d = tr.d;
   const long R = (long)B * S;
@@ -1419,20 +1444,24 @@ int smt_fwd_infer_bf16(const avlen_smt* p, const float* x, const float* memory, 
   // fusion MLP, the encoder layer and the decoder's K/V projection; with a 150-slot window of a 300-slot ring that is half
   // of the rows.  Row counts live on the device (seg[B]); grids are sized for the maximum.
   const bool ragged = !cto && masks && M > 4 && d / tr.nhead == 32 && S <= 320 && ragged_enabled();
+  const bool chain_cto = cto && d == 256 && chain_enabled();
+  const bool chain_small = !cto && (S == 2 || S == 4) && d == 256 && s.ldxf <= 320 && chain_enabled();
+  if (x3 && !chain_cto && !chain_small) return AVLEN_NOT_BIG;
+  bf16* XFlo = x3 ? s.XF + R * s.ldxf : nullptr;
   if (ragged) {
     hipLaunchKernelGGL(smt_segments_kernel, dim3(1), dim3(1024), 0, st, masks, s.seg, s.rowmap, B, M);
     c.live = s.seg + B; c.seg = s.seg;
   }
   hipLaunchKernelGGL(smt_build16_kernel, dim3((unsigned)R), dim3(128), 0, st, x, memory, mem_index, NC, masks, p->pose.w,
                      p->pose.b, s.XF, s.ldxf, s.maskx, B, M, F, pose_col, cto ? 1 : 0, ragged ? s.seg : (const int*)nullptr,
-                     ragged ? s.rowmap : (const int*)nullptr);
+                     ragged ? s.rowmap : (const int*)nullptr, XFlo);
   TRY(avlen_launch_status());
-  if (cto && d == 256 && chain_enabled()) {
+  if (chain_cto) {
     // `current_token_only`: every attention sees one valid key, so the whole encoder + decoder is a chain of row-wise
     // steps (attention output == V projection); one launch.
     const avlen_enc_layer& e = tr.enc; const avlen_dec_layer& q = tr.dec;
-    ChainB ch;
-    ch.load_x16(s.XF, s.ldxf, s.ldxf, 0);
+    ChainB ch(x3);
+    ch.load_x16(s.XF, s.ldxf, s.ldxf, 0, XFlo);
     ch.linear(p->fus0, 0, AVLEN_ACT_RELU, 0, 0, 1);
     ch.linear(p->fus2, 0, 0, 0, 1, 0); ch.save();                     // Z
     ch.linear(e.self_attn.in_proj, 2 * d, 0, 0, 0, 1);               // V(Z)
@@ -1452,18 +1481,20 @@ int smt_fwd_infer_bf16(const avlen_smt* p, const float* x, const float* memory, 
     ch.linear(q.lin1, 0, AVLEN_ACT_RELU, 0, 0, 1);
     ch.linear(q.lin2, 0, 0, 1, 1, 0);
     ch.ln(q.norm3, 0); ch.ln(tr.dec_norm, 0); ch.store(out, d, nullptr, 0);
-    if (ch.ok && e.lin1.out_f == 256 && q.lin1.out_f == 256 && p->fus0.out_f == 256) return avlen_chain_run(&ch.p, B, st);
+    if (ch.ok && e.lin1.out_f == 256 && q.lin1.out_f == 256 && p->fus0.out_f == 256) return ch.run(B, st);
+    if (x3) return AVLEN_NOT_BIG;
   }
-  if (!cto && (S == 2 || S == 4) && d == 256 && s.ldxf <= 320 && chain_enabled()) {
+  if (chain_small) {
     // a short memory (pi_l: M = 3): the whole state encoder -- fusion MLP, encoder layer, decoder layer -- is one chain
     // launch; attention runs inside each sample's group of S rows
-    ChainB ch;
-    ch.load_x16(s.XF, s.ldxf, s.ldxf, 0);
+    ChainB ch(x3);
+    ch.load_x16(s.XF, s.ldxf, s.ldxf, 0, XFlo);
     ch.linear(p->fus0, 0, AVLEN_ACT_RELU, 0, 0, 1);
     ch.linear(p->fus2, 0, 0, 0, 1, 0); ch.save();                     // Z
     ch.small_transformer(tr, goal, s.maskx, S, out);
-    if (ch.ok && p->fus0.out_f == 256) return avlen_chain_run(&ch.p, (int)R, st);
+    if (ch.ok && p->fus0.out_f == 256) return ch.run((int)R, st);
   }
+  if (x3) return AVLEN_NOT_BIG;
   TRY(linear16(c, p->fus0, s.XF, s.ldxf, nullptr, 0, s.H1, d, (int)R, AVLEN_ACT_RELU, nullptr, 0));
   TRY(linear16(c, p->fus2, s.H1, d, s.tr.Z, d, s.tr.Z16, d, (int)R, 0, nullptr, 0));
   TRY(enc_fwd16(c, tr, s.tr, s.maskx, B, S, cto));
@@ -1474,11 +1505,20 @@ int smt_fwd_infer_bf16(const avlen_smt* p, const float* x, const float* memory, 
 __global__ void dialog_build16_kernel(const float* __restrict__ x_att, const float* __restrict__ mem,
                                       const float* __restrict__ masks, const float* __restrict__ d_emb,
                                       bf16* __restrict__ seq16, float* __restrict__ seq32, int ldseq, float* __restrict__ maskx,
-                                      int B, int M, int d) {
+                                      int B, int M, int d, bf16* __restrict__ seq16lo) {
   const int S = M + 1, row = blockIdx.x, b = row / S, s = row % S;
   const float* src = s < M ? mem + ((long)s * B + b) * d : x_att + (long)b * d;
   for (int i = threadIdx.x; i < d; i += blockDim.x) {
-    if (seq16) { seq16[(long)row * ldseq + i] = (bf16)src[i]; if (d_emb) seq16[(long)row * ldseq + d + i] = (bf16)d_emb[(long)b * d + i]; }
+    if (seq16) {
+      const float v = src[i]; const bf16 hv = (bf16)v;
+      seq16[(long)row * ldseq + i] = hv;
+      if (seq16lo) seq16lo[(long)row * ldseq + i] = (bf16)(v - (float)hv);
+      if (d_emb) {
+        const float e = d_emb[(long)b * d + i]; const bf16 he = (bf16)e;
+        seq16[(long)row * ldseq + d + i] = he;
+        if (seq16lo) seq16lo[(long)row * ldseq + d + i] = (bf16)(e - (float)he);
+      }
+    }
     if (seq32) seq32[(long)row * d + i] = src[i];
   }
   if (threadIdx.x == 0) maskx[(long)b * S + s] = s < M ? masks[(long)b * M + s] : 1.f;
@@ -1498,43 +1538,49 @@ __global__ void add_pe16_kernel(float* __restrict__ z, bf16* __restrict__ z16, c
 struct Dlg16Ws { bf16 *SEQ16, *H1; float* maskx; Tr16Ws tr; void* gws; size_t gwsb; };
 void dlg16_layout(WsBump& w, Dlg16Ws& s, const avlen_dialog* p, long B, long M) {
   long S = M + 1, R = B * S; int d = p->tr.d;
-  s.SEQ16 = w.take<bf16>(R * 2 * d); s.H1 = w.take<bf16>(R * d); s.maskx = w.take<float>(B * S);
+  s.SEQ16 = w.take<bf16>(2 * R * 2 * d); s.H1 = w.take<bf16>(2 * R * d); s.maskx = w.take<float>(B * S);
   tr16_layout(w, s.tr, B, S, d, false);
   s.gwsb = 32u << 20; s.gws = w.take<char>(s.gwsb);
 }
 size_t dlg16_ws_bytes(const avlen_dialog* p, int B, int M) { WsBump w(nullptr, 0); Dlg16Ws s; dlg16_layout(w, s, p, B, M); return w.off + 4096; }
 bool dlg_has16(const avlen_dialog* p) { return lin16_ok(p->fus0) && lin16_ok(p->fus2) && tr_has16(p->tr); }
+bool dlg_has16lo(const avlen_dialog* p) { return dlg_has16(p) && p->fus0.w16lo && p->fus2.w16lo && tr_has16lo(p->tr); }
 
 int dialog_fwd_bf16(const avlen_dialog* p, const float* x_att, const float* memory_state, const float* masks,
                     const float* d_emb, const float* agent_step, const float* goal, float* out, int B, int M, void* ws,
-                    size_t ws_bytes, hipStream_t st) {
+                    size_t ws_bytes, hipStream_t st, bool x3 = false) {
   if (ws_bytes < dlg16_ws_bytes(p, B, M)) return AVLEN_ERR_WS;
   WsBump w(ws, ws_bytes); Dlg16Ws s; dlg16_layout(w, s, p, B, M);
   Ctx c{st, AVLEN_PREC_BF16, s.gws, s.gwsb};
+  c.x3 = x3 ? 1 : 0;
   const int S = M + 1, d = p->tr.d; const long R = (long)B * S;
   const bool small = (S == 2 || S == 4) && d == 256 && chain_enabled();
+  if (x3 && !small) return AVLEN_NOT_BIG;
   if (d_emb) {
+    const long seqlo = R * 2 * d, h1lo = R * d;
     hipLaunchKernelGGL(dialog_build16_kernel, dim3((unsigned)R), dim3(128), 0, st, x_att, memory_state, masks, d_emb, s.SEQ16,
-                       (float*)nullptr, 2 * d, s.maskx, B, M, d);
-    TRY(linear16(c, p->fus0, s.SEQ16, 2 * d, nullptr, 0, s.H1, d, (int)R, AVLEN_ACT_RELU, nullptr, 0));
+                       (float*)nullptr, 2 * d, s.maskx, B, M, d, x3 ? s.SEQ16 + seqlo : (bf16*)nullptr);
+    TRY(linear16(c, p->fus0, s.SEQ16, 2 * d, nullptr, 0, s.H1, d, (int)R, AVLEN_ACT_RELU, nullptr, 0, seqlo, h1lo));
     if (small) {                    // fusion output -> + positional row -> encoder + decoder: one chain launch
-      ChainB ch;
-      ch.load_x16(s.H1, d, d, 0);
+      ChainB ch(x3);
+      ch.load_x16(s.H1, d, d, 0, x3 ? s.H1 + h1lo : nullptr);
       ch.linear(p->fus2, 0, 0, 0, 0, 1);
       ch.add_pe(p->pe, p->pe_len, agent_step, S, 0); ch.save();
       ch.small_transformer(p->tr, goal, s.maskx, S, out);
-      if (ch.ok) return avlen_chain_run(&ch.p, (int)R, st);
+      if (ch.ok) return ch.run((int)R, st);
+      if (x3) return AVLEN_ERR_ARG;
     }
     TRY(linear16(c, p->fus2, s.H1, d, s.tr.Z, d, nullptr, 0, (int)R, 0, nullptr, 0));
   } else {
     hipLaunchKernelGGL(dialog_build16_kernel, dim3((unsigned)R), dim3(128), 0, st, x_att, memory_state, masks,
-                       (const float*)nullptr, (bf16*)nullptr, s.tr.Z, d, s.maskx, B, M, d);
+                       (const float*)nullptr, (bf16*)nullptr, s.tr.Z, d, s.maskx, B, M, d, (bf16*)nullptr);
     if (small) {
-      ChainB ch;
+      ChainB ch(x3);
       ch.load_cur(s.tr.Z, d, 0);
       ch.add_pe(p->pe, p->pe_len, agent_step, S, 0); ch.save();
       ch.small_transformer(p->tr, goal, s.maskx, S, out);
-      if (ch.ok) { TRY(avlen_launch_status()); return avlen_chain_run(&ch.p, (int)R, st); }
+      if (ch.ok) { TRY(avlen_launch_status()); return ch.run((int)R, st); }
+      if (x3) return AVLEN_ERR_ARG;
     }
   }
   hipLaunchKernelGGL(add_pe16_kernel, dim3((unsigned)R), dim3(128), 0, st, s.tr.Z, s.tr.Z16, p->pe, agent_step, S, d, p->pe_len);
@@ -1560,6 +1606,10 @@ extern "C" int avlen_smt_fwd(const avlen_smt* p, const float* x, const float* me
   if (ws_bytes < avlen_smt_workspace_bytes(p, B, M, F, cto)) return AVLEN_ERR_WS;
   if (prec == AVLEN_PREC_BF16 && !save_for_backward && (cto || M > 0) && smt_has16(p))
     return smt_fwd_infer_bf16(p, x, memory, mem_index, NC, masks, goal, out, B, M, F, pose_col, cto != 0, ws, ws_bytes, st);
+  if (prec == AVLEN_PREC_BF16X3 && !save_for_backward && (cto || M > 0) && smt_has16lo(p)) {
+    const int rc = smt_fwd_infer_bf16(p, x, memory, mem_index, NC, masks, goal, out, B, M, F, pose_col, cto != 0, ws, ws_bytes, st, true);
+    if (rc != AVLEN_NOT_BIG) return rc;
+  }
   WsBump w(ws, ws_bytes); SmtWs s;
   smt_layout(w, s, p, B, M, F, cto != 0);
   Ctx c{st, prec, s.gws, GEMM_SCRATCH};
@@ -1668,6 +1718,10 @@ extern "C" int avlen_dialog_fwd(const avlen_dialog* p, const float* x_att, const
   if (!p || B <= 0 || ws_bytes < avlen_dialog_workspace_bytes(p, B, M)) return AVLEN_ERR_WS;
   if (prec == AVLEN_PREC_BF16 && dlg_has16(p))
     return dialog_fwd_bf16(p, x_att, memory_state, masks, d_emb, agent_step, goal, out, B, M, ws, ws_bytes, st);
+  if (prec == AVLEN_PREC_BF16X3 && dlg_has16lo(p)) {
+    const int rc = dialog_fwd_bf16(p, x_att, memory_state, masks, d_emb, agent_step, goal, out, B, M, ws, ws_bytes, st, true);
+    if (rc != AVLEN_NOT_BIG) return rc;
+  }
   WsBump w(ws, ws_bytes); DlgWs s; dlg_layout(w, s, p, B, M);
   Ctx c{st, prec, s.gws, GEMM_SCRATCH};
   const int S = M + 1, d = p->tr.d; const long R = (long)B * S;

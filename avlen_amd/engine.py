@@ -113,6 +113,8 @@ def linear_view(w, b, flat=None, packed=None, fmt=0, lo=False):
         # in_f not a multiple of 8 (the distractor variant's fusion input: 297 / 329 + 12 columns): the bf16 GEMMs need
         # 16-byte rows, so the shadow is a zero-padded derived copy [out_f][ld16]
         v.w16, v.ld16 = packed.linear_pad(w)
+        if lo:
+            v.w16lo, _ = packed.linear_pad(w, 2)
     return v
 
 
@@ -193,13 +195,13 @@ class Packed:
         v.w16, v.ld16 = P(buf16), C_ * HW
         return v
 
-    def linear_pad(self, w):
-        """bf16 copy of a Linear weight with rows padded to a multiple of 8 columns (pad columns stay zero)."""
+    def linear_pad(self, w, fmt=0):
+        """16-bit copy (fmt 0 bf16, 2 low plane) of a Linear weight with rows padded to a multiple of 8 columns (pad columns zero)."""
         out_f, in_f = w.shape
         ld = (in_f + 7) // 8 * 8
         buf16 = torch.zeros(out_f, ld, dtype=torch.bfloat16, device=self.device)
         self.bufs.append(buf16)
-        self.jobs.append(("pad16", w, None, buf16, (out_f, in_f), ld))
+        self.jobs.append(("pad16", w, fmt, buf16, (out_f, in_f), ld))
         return P(buf16), ld
 
     def refresh_pads(self):
@@ -207,7 +209,7 @@ class Packed:
         st = L.stream()
         for kind, w, buf, buf16, dims, c16 in self.jobs:
             if kind == "pad16":
-                L.call("avlen_cast_bf16", P(w), dims[1], P(buf16), c16, dims[0], dims[1], st)
+                L.call("avlen_cast_h16", P(w), dims[1], P(buf16), c16, dims[0], dims[1], buf or 0, st)
 
     def ln_fold(self, lin_w, lin_b, ln, fmt=0):
         """LayerNorm `ln` folded into the Linear (lin_w, lin_b) that follows it (avlen_ln_fold_weights); fmt 1: fp16 weights."""
@@ -227,7 +229,7 @@ class Packed:
                 L.call("avlen_ln_fold_weights_h16", P(w), P(b) if b is not None else None, P(g), P(be), P(buf16), dims[1], P(s),
                        P(c), dims[0], dims[1], c16, st)
             elif kind == "pad16":
-                L.call("avlen_cast_bf16", P(w), dims[1], P(buf16), c16, dims[0], dims[1], st)
+                L.call("avlen_cast_h16", P(w), dims[1], P(buf16), c16, dims[0], dims[1], buf or 0, st)
             elif kind == "conv32":
                 L.call("avlen_pack_conv_weight", P(w), P(buf), *dims, st)
             elif kind == "convbn":
@@ -331,33 +333,33 @@ def mha_view(m, flat=None, fmt=0, lo=False):
                  linear_view(m.out_proj.weight, m.out_proj.bias, flat, fmt=fmt, lo=lo))
 
 
-def transformer_view(t, d, nhead, flat=None):
+def transformer_view(t, d, nhead, flat=None, lo=False):
     s = L.Transformer()
     e, q = t.encoder.layers[0], t.decoder.layers[0]
-    lv = lambda m: linear_view(m.weight, m.bias, flat)
-    s.enc = L.EncLayer(mha_view(e.self_attn, flat), lv(e.linear1), lv(e.linear2), affine_view(e.norm1), affine_view(e.norm2))
+    lv = lambda m: linear_view(m.weight, m.bias, flat, lo=lo)
+    s.enc = L.EncLayer(mha_view(e.self_attn, flat, lo=lo), lv(e.linear1), lv(e.linear2), affine_view(e.norm1), affine_view(e.norm2))
     s.enc_norm = affine_view(t.encoder.norm)
-    s.dec = L.DecLayer(mha_view(q.self_attn, flat), mha_view(q.multihead_attn, flat), lv(q.linear1), lv(q.linear2),
+    s.dec = L.DecLayer(mha_view(q.self_attn, flat, lo=lo), mha_view(q.multihead_attn, flat, lo=lo), lv(q.linear1), lv(q.linear2),
                        affine_view(q.norm1), affine_view(q.norm2), affine_view(q.norm3))
     s.dec_norm = affine_view(t.decoder.norm)
     s.d, s.nhead = d, nhead
     return s
 
 
-def smt_view(enc, flat=None, packed=None):
+def smt_view(enc, flat=None, packed=None, lo=False):
     s = L.Smt()
     s.pose = linear_view(enc.pose_encoder.weight, enc.pose_encoder.bias)
-    s.fus0 = linear_view(enc.fusion_encoder[0].weight, enc.fusion_encoder[0].bias, flat, packed)
-    s.fus2 = linear_view(enc.fusion_encoder[2].weight, enc.fusion_encoder[2].bias, flat)
-    s.tr = transformer_view(enc.transformer, enc._dim_feedforward, enc._nhead, flat)
+    s.fus0 = linear_view(enc.fusion_encoder[0].weight, enc.fusion_encoder[0].bias, flat, packed, lo=lo)
+    s.fus2 = linear_view(enc.fusion_encoder[2].weight, enc.fusion_encoder[2].bias, flat, lo=lo)
+    s.tr = transformer_view(enc.transformer, enc._dim_feedforward, enc._nhead, flat, lo=lo)
     return s
 
 
-def dialog_view(enc, flat=None):
+def dialog_view(enc, flat=None, lo=False):
     s = L.Dialog()
-    s.fus0 = linear_view(enc.fusion_encoder[0].weight, enc.fusion_encoder[0].bias, flat)
-    s.fus2 = linear_view(enc.fusion_encoder[2].weight, enc.fusion_encoder[2].bias, flat)
-    s.tr = transformer_view(enc.dialog_transformer, enc._dim_feedforward, enc._nhead, flat)
+    s.fus0 = linear_view(enc.fusion_encoder[0].weight, enc.fusion_encoder[0].bias, flat, lo=lo)
+    s.fus2 = linear_view(enc.fusion_encoder[2].weight, enc.fusion_encoder[2].bias, flat, lo=lo)
+    s.tr = transformer_view(enc.dialog_transformer, enc._dim_feedforward, enc._nhead, flat, lo=lo)
     s.pe = P(enc.pos_encode.pe)
     s.pe_len = enc.pos_encode.pe.shape[0]
     return s

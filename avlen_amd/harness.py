@@ -59,7 +59,7 @@ class Workload:
                      if with_goal_policy else None)
         self.pi_l = (P.AudioNavDialogPolicy(osp, asp, pretraining=False, use_category_input=distractor, num_steps=3,
                                             **kw).to(self.dev) if with_dialog_policy else None)
-        if share_encoders and precision == "bf16" and self.pi_g is not None and self.pi_l is not None:
+        if share_encoders and precision in ("bf16", "bf16x3") and self.pi_g is not None and self.pi_l is not None:
             P.share_encoders(self.pi_q, self.pi_g, self.pi_l)
         self.agent = DDPPO(self.pi_q, clip_param=0.2, ppo_epoch=ppo_epoch, num_mini_batch=num_mini_batch,
                            value_loss_coef=0.5, entropy_coef=0.05, lr=2.5e-4, eps=1e-5, max_grad_norm=0.2,

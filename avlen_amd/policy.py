@@ -341,6 +341,14 @@ class EncoderGroup:
         B, H, W = spec.shape[0], spec.shape[1], spec.shape[2]
         bufs = self.audio_buffers(B, spec.device)
         G = len(self.members)
+        pa = pol.prec_of("audio")
+        if pa != L.PREC_BF16:                            # no grouped form in this precision: one call per member
+            for m, buf in zip(self.members, bufs):
+                eng = m._engine()
+                nb = L.lib.avlen_cnn3_workspace_bytes(C.byref(eng["audio"]), B, H, W)
+                ws = pol._ws.get("audio_m%d" % self.members.index(m), nb, spec.device)
+                L.call("avlen_cnn3_fwd", C.byref(eng["audio"]), E.P(spec), B, H, W, E.P(buf), 128, pa, E.P(ws), nb, L.stream())
+            return bufs[0]
         nets = (C.POINTER(L.Cnn3) * G)(*[C.pointer(m._engine()["audio"]) for m in self.members])
         outs = (C.c_void_p * G)(*[b.data_ptr() for b in bufs])
         nb = L.lib.avlen_cnn3_group_workspace_bytes(nets[0], G, B, H, W)
@@ -363,6 +371,12 @@ class EncoderGroup:
                 imgs[g] = img.data_ptr()
                 outs[g] = bufs[i].data_ptr() + 4 * 64 * j
                 chans[g], divs[g], u8[g] = img.shape[3], div, _u8(img)
+        if pol.prec_of("towers") == L.PREC_BF16X3:
+            nb = L.lib.avlen_resnet18_group_x3_workspace_bytes(G, B)
+            ws = pol._ws.get("resnet_group_x3", nb, dev)
+            L.call("avlen_resnet18_group_fwd_x3", nets, imgs, u8, chans, divs, outs, 128, G, B, rgb.shape[1], None, E.P(ws), nb,
+                   L.stream())
+            return bufs[0]
         nb = L.lib.avlen_resnet18_group_workspace_bytes(G, B)
         ws = pol._ws.get("resnet_group", nb, dev)
         L.call("avlen_resnet18_group_fwd", nets, imgs, u8, chans, divs, outs, 128, G, B, rgb.shape[1], E.P(ws), nb, L.stream())
@@ -370,8 +384,9 @@ class EncoderGroup:
 
 
 def share_encoders(leader, *followers):
-    """Opt-in cross-policy tower batching (see EncoderGroup).  All members must use precision="bf16"."""
-    assert all(m.precision == "bf16" for m in (leader,) + followers), "encoder sharing runs on the bf16 fast path"
+    """Opt-in cross-policy tower batching (see EncoderGroup).  All members must use the same fast precision ("bf16" / "bf16x3")."""
+    assert leader.precision in ("bf16", "bf16x3") and all(m.precision == leader.precision for m in followers), \
+        "encoder sharing runs on the grouped fast paths (bf16 / bf16x3), one precision for all members"
     return EncoderGroup(leader, followers)
 
 
@@ -590,7 +605,7 @@ class Policy(nn.Module):
             else:
                 self.net._text, self.net._text_key = None, None
         mode, grp = None, self._enc_group
-        if grp is not None and self.precision == "bf16":
+        if grp is not None and self.precision in ("bf16", "bf16x3"):
             if grp.leader is self:
                 grp.mark(net_args[0])
                 mode = "lead"
@@ -811,17 +826,19 @@ class _SMTBase(Net):
         eng["depth"] = E.resnet18_view(self.visual_encoder.depth_encoder, packed)
         eng["audio"] = E.cnn3_view(self.goal_encoder, packed)
         eng["action"] = E.linear_view(self.action_encoder.weight, self.action_encoder.bias)
-        eng["smt"] = E.smt_view(self.smt_state_encoder, eng["flat"], packed)
+        eng["smt"] = E.smt_view(self.smt_state_encoder, eng["flat"], packed, lo=packed.lo)
 
     def features(self, pol, obs, prev_actions, extra=None):
         """-> feats (B, F) = [visual 128 | action 16 | audio 128 | (category 21) | pose 4 | (extra)], goal (B,d)."""
         eng = pol._engine()
         rgb, depth, spec = _img(obs["rgb"]), _f32(obs["depth"]), _f32(obs[SPECTROGRAM])
         idx = None
-        if isinstance(rgb, RowsOf):                      # minibatch rows of the storage, read in place (bf16 encoders only)
-            if pol.prec == L.PREC_BF16 and pol._shared_mode is None and isinstance(depth, RowsOf) and isinstance(spec, RowsOf) \
-                    and depth.index is rgb.index and spec.index is rgb.index:
+        if isinstance(rgb, RowsOf):                      # minibatch rows of the storage, read in place (grouped fast encoders only)
+            if pol.prec_of("towers") in (L.PREC_BF16, L.PREC_BF16X3) and pol._shared_mode is None and isinstance(depth, RowsOf) \
+                    and isinstance(spec, RowsOf) and depth.index is rgb.index and spec.index is rgb.index:
                 idx = rgb.index
+                if pol.prec_of("audio") != L.PREC_BF16:  # the indexed AudioCNN exists on the bf16 path only
+                    spec = spec.materialise()
             else:
                 rgb, depth, spec = (t.materialise() if isinstance(t, RowsOf) else t for t in (rgb, depth, spec))
         B = rgb.shape[0]
@@ -838,7 +855,8 @@ class _SMTBase(Net):
         cur = torch.cuda.current_stream()
         fork = torch.cuda.is_current_stream_capturing()
         mode, grp = pol._shared_mode, pol._enc_group
-        if prec == L.PREC_BF16:
+        x3 = prec == L.PREC_BF16X3 and bool(eng["rgb"].conv1.w16lo)
+        if prec == L.PREC_BF16 or x3:
             # bf16 fast path: the towers run as grouped launches (rgb+depth of this policy, or -- leader of an
             # EncoderGroup -- all towers of all member policies); the audio CNN is a parallel branch under capture
             s_aud = pol.side_streams()[0] if fork else cur
@@ -851,7 +869,7 @@ class _SMTBase(Net):
                     aud = grp.audio_buffers(B, dev)[grp.members.index(pol)]
                 else:
                     aud = None
-                    if idx is not None:
+                    if idx is not None and isinstance(spec, RowsOf):
                         L.call("avlen_cnn3_fwd_indexed", C.byref(eng["audio"]), E.P(spec.base), E.P(idx), B, H, W, E.P(feats, 144), F,
                                E.P(ws2), nb2, L.stream())
                     else:
@@ -872,29 +890,22 @@ class _SMTBase(Net):
                 outs = (C.c_void_p * G)(feats.data_ptr(), feats.data_ptr() + 4 * 64)
                 chans, divs = (C.c_int * G)(rgb.shape[3], depth.shape[3]), (C.c_float * G)(255.0, 1.0)
                 u8 = (C.c_int * G)(_u8(rgb), 0)
-                nbg = L.lib.avlen_resnet18_group_workspace_bytes(G, B)
-                wsg = pol._ws.get("resnet_pair", nbg, dev)
-                if idx is not None:
-                    L.call("avlen_resnet18_group_fwd_indexed", nets, imgs, u8, chans, divs, outs, F, G, B, S, E.P(idx), E.P(wsg), nbg,
-                           st)
+                if x3:
+                    nbg = L.lib.avlen_resnet18_group_x3_workspace_bytes(G, B)
+                    wsg = pol._ws.get("resnet_pair_x3", nbg, dev)
+                    L.call("avlen_resnet18_group_fwd_x3", nets, imgs, u8, chans, divs, outs, F, G, B, S,
+                           E.P(idx) if idx is not None else None, E.P(wsg), nbg, st)
                 else:
-                    L.call("avlen_resnet18_group_fwd", nets, imgs, u8, chans, divs, outs, F, G, B, S, E.P(wsg), nbg, st)
+                    nbg = L.lib.avlen_resnet18_group_workspace_bytes(G, B)
+                    wsg = pol._ws.get("resnet_pair", nbg, dev)
+                    if idx is not None:
+                        L.call("avlen_resnet18_group_fwd_indexed", nets, imgs, u8, chans, divs, outs, F, G, B, S, E.P(idx), E.P(wsg),
+                               nbg, st)
+                    else:
+                        L.call("avlen_resnet18_group_fwd", nets, imgs, u8, chans, divs, outs, F, G, B, S, E.P(wsg), nbg, st)
             if vis is not None:
                 L.call("avlen_copy_rows", E.P(vis), 128, E.P(feats), F, B, 128, st)
             s_rgb = s_dep = s_aud
-        elif prec == L.PREC_BF16X3 and eng["rgb"].conv1.w16lo:
-            # compensated bf16: both towers in lock-step on tower_x3.hip (row index: minibatch rows read in place)
-            G = 2
-            nets = (C.POINTER(L.ResNet18) * G)(C.pointer(eng["rgb"]), C.pointer(eng["depth"]))
-            imgs = (C.c_void_p * G)(rgb.data_ptr(), depth.data_ptr())
-            outs = (C.c_void_p * G)(feats.data_ptr(), feats.data_ptr() + 4 * 64)
-            chans, divs = (C.c_int * G)(rgb.shape[3], depth.shape[3]), (C.c_float * G)(255.0, 1.0)
-            u8 = (C.c_int * G)(_u8(rgb), 0)
-            nbg = L.lib.avlen_resnet18_group_x3_workspace_bytes(G, B)
-            wsg = pol._ws.get("resnet_pair_x3", nbg, dev)
-            L.call("avlen_resnet18_group_fwd_x3", nets, imgs, u8, chans, divs, outs, F, G, B, S, None, E.P(wsg), nbg, st)
-            L.call("avlen_cnn3_fwd", C.byref(eng["audio"]), E.P(spec), B, H, W, E.P(feats, 144), F, prec_a, E.P(ws2), nb2, st)
-            s_rgb = s_dep = cur
         else:
             nb = L.lib.avlen_resnet18_workspace_bytes(B)
             ws_rgb, ws_dep = pol._ws.get("resnet_rgb", nb, dev), pol._ws.get("resnet_depth", nb, dev)
@@ -1026,7 +1037,7 @@ class AudioNavDialogNet(_SMTBase):
         super().build_views(eng, packed)
         eng["clip"] = E.clip_view(self.clip, eng["flat"], packed, fmt=eng.get("clip_fmt", 0))
         eng["dialog_layer"] = E.linear_view(self.dialog_layer.weight, self.dialog_layer.bias, eng["flat"], fmt=eng.get("clip_fmt", 0))
-        eng["dialog"] = E.dialog_view(self.dialog_state_encoder, eng["flat"])
+        eng["dialog"] = E.dialog_view(self.dialog_state_encoder, eng["flat"], lo=packed.lo)
 
     def encode_text(self, pol, tokens):
         eng = pol._engine()

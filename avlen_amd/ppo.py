@@ -122,7 +122,7 @@ class PPO(nn.Module):
             perm = torch.randperm(N)                                   # host RNG, same draw as the reference
             for start in range(0, N, per):
                 env = perm[start:start + per].to(log.device)
-                b = rollouts.gather_minibatch(env, advantages, in_place=self.actor_critic.precision == "bf16")
+                b = rollouts.gather_minibatch(env, advantages, in_place=self.actor_critic.precision in ("bf16", "bf16x3"))
                 self._minibatch_step(rollouts, b, log[n_updates])
                 n_updates += 1
         s = log[:n_updates].double().sum(0).cpu()                      # one sync per update()
