@@ -460,14 +460,16 @@ __global__ __launch_bounds__(256) void attn_qkv16_kernel(const __bf16* __restric
 // Scene-memory self-attention straight from the packed bf16 projection [R][q | k | v] (D = 32, <= 160 tokens per sample,
 // key-padding mask): same scheme as attn_qkv16_kernel -- transposed scores so P stays in registers, V^T fragments by
 // ds_read_b64_tr_b16 from the row-major V tile -- with one MFMA k-step per score tile (K = D = 32) and up to 10 key tiles.
-template <int SKP>        // max tokens per sample (160 or 320)
+template <int SKP, bool X3>        // max tokens per sample (160 or 320); X3: compensated bf16 pairs (low planes qkv_lo / o_lo elements behind)
 __global__ __launch_bounds__(256) void attn_smt16_kernel(const __bf16* __restrict__ QKV, int ld, int koff, int voff,
                                                          __bf16* __restrict__ O16, int ldo16, int S, float scale,
-                                                         const float* __restrict__ key_mask, const int* __restrict__ seg_off) {
+                                                         const float* __restrict__ key_mask, const int* __restrict__ seg_off,
+                                                         long qkv_lo, long o_lo) {
   constexpr int D = 32, KR = 48, NKT = SKP / 16;    // 96-byte LDS rows: conflict-free for both read kinds
-  __shared__ __attribute__((aligned(16))) __bf16 qs[SKP * KR];
-  __shared__ __attribute__((aligned(16))) __bf16 ks[SKP * KR];
-  __shared__ __attribute__((aligned(16))) __bf16 vs[SKP * KR];
+  constexpr int NP = X3 ? 2 : 1;                    // planes: hi (, lo)
+  __shared__ __attribute__((aligned(16))) __bf16 qs[X3 ? 1 : SKP * KR];     // X3: the Q fragments come straight from global memory
+  __shared__ __attribute__((aligned(16))) __bf16 ks[NP][SKP * KR];
+  __shared__ __attribute__((aligned(16))) __bf16 vs[NP][SKP * KR];
   __shared__ float km[SKP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, q4 = lane >> 4;
   const int h = blockIdx.x, b = blockIdx.y;
@@ -476,16 +478,19 @@ __global__ __launch_bounds__(256) void attn_smt16_kernel(const __bf16* __restric
   const int S32 = (S + 31) & ~31;
   for (int i = tid; i < S32 * 4; i += 256) {                   // 4 x 16-byte chunks per 32-wide row
     const int r = i >> 2, c = i & 3;
-    uint4 qv = make_uint4(0, 0, 0, 0), kv = qv, vv = qv;
-    if (r < S) {
-      const __bf16* base = QKV + (row0 + r) * ld + h * D + c * 8;
-      qv = *reinterpret_cast<const uint4*>(base);
-      kv = *reinterpret_cast<const uint4*>(base + koff);
-      vv = *reinterpret_cast<const uint4*>(base + voff);
+#pragma unroll
+    for (int pl = 0; pl < NP; pl++) {
+      uint4 qv = make_uint4(0, 0, 0, 0), kv = qv, vv = qv;
+      if (r < S) {
+        const __bf16* base = QKV + (pl ? qkv_lo : 0) + (row0 + r) * ld + h * D + c * 8;
+        qv = *reinterpret_cast<const uint4*>(base);
+        kv = *reinterpret_cast<const uint4*>(base + koff);
+        vv = *reinterpret_cast<const uint4*>(base + voff);
+      }
+      if (!X3) *reinterpret_cast<uint4*>(&qs[r * KR + c * 8]) = qv;
+      *reinterpret_cast<uint4*>(&ks[pl][r * KR + c * 8]) = kv;
+      *reinterpret_cast<uint4*>(&vs[pl][r * KR + c * 8]) = vv;
     }
-    *reinterpret_cast<uint4*>(&qs[r * KR + c * 8]) = qv;
-    *reinterpret_cast<uint4*>(&ks[r * KR + c * 8]) = kv;
-    *reinterpret_cast<uint4*>(&vs[r * KR + c * 8]) = vv;
   }
   for (int i = tid; i < SKP; i += 256) km[i] = (i < S && (!key_mask || key_mask[(long)b * S + i] != 0.f)) ? 1.f : 0.f;
   __syncthreads();
@@ -494,11 +499,27 @@ __global__ __launch_bounds__(256) void attn_smt16_kernel(const __bf16* __restric
     af32x4 sacc[NKT];
 #pragma unroll
     for (int nt = 0; nt < NKT; nt++) sacc[nt] = (af32x4){0.f, 0.f, 0.f, 0.f};
-    abf16x8 qf = *reinterpret_cast<const abf16x8*>(&qs[(mt * 16 + r16) * KR + q4 * 8]);
+    abf16x8 qf, ql;
+    if (X3) {
+      uint4 a = make_uint4(0, 0, 0, 0), l = a;
+      if (mt * 16 + r16 < S) {
+        const __bf16* qp = QKV + (row0 + mt * 16 + r16) * ld + h * D + q4 * 8;
+        a = *reinterpret_cast<const uint4*>(qp); l = *reinterpret_cast<const uint4*>(qp + qkv_lo);
+      }
+      qf = __builtin_bit_cast(abf16x8, a); ql = __builtin_bit_cast(abf16x8, l);
+    } else {
+      qf = *reinterpret_cast<const abf16x8*>(&qs[(mt * 16 + r16) * KR + q4 * 8]);
+      ql = qf;
+    }
 #pragma unroll
     for (int nt = 0; nt < NKT; nt++)
       if (nt < n_kt) {
-        abf16x8 kf = *reinterpret_cast<const abf16x8*>(&ks[(nt * 16 + r16) * KR + q4 * 8]);
+        abf16x8 kf = *reinterpret_cast<const abf16x8*>(&ks[0][(nt * 16 + r16) * KR + q4 * 8]);
+        if (X3) {
+          abf16x8 kl = *reinterpret_cast<const abf16x8*>(&ks[NP - 1][(nt * 16 + r16) * KR + q4 * 8]);
+          sacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qf, sacc[nt], 0, 0, 0);
+          sacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, ql, sacc[nt], 0, 0, 0);
+        }
         sacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, sacc[nt], 0, 0, 0);      // S^T: rows = keys, cols = queries
       }
     const int qi = mt * 16 + r16;
@@ -528,18 +549,29 @@ __global__ __launch_bounds__(256) void attn_smt16_kernel(const __bf16* __restric
 #pragma unroll
     for (int kk = 0; kk < NKT / 2; kk++)
       if (kk < n_kk) {
-        abf16x8 pf;
+        abf16x8 pf, pl;
 #pragma unroll
-        for (int e = 0; e < 4; e++) { pf[e] = (__bf16)sacc[2 * kk][e]; pf[4 + e] = (__bf16)sacc[2 * kk + 1][e]; }
-        const __bf16* vb = &vs[(kk * 32 + q4 * 4 + (r16 >> 2)) * KR + 4 * (r16 & 3)];
+        for (int e = 0; e < 4; e++) {
+          pf[e] = (__bf16)sacc[2 * kk][e]; pf[4 + e] = (__bf16)sacc[2 * kk + 1][e];
+          if (X3) { pl[e] = (__bf16)(sacc[2 * kk][e] - (float)pf[e]); pl[4 + e] = (__bf16)(sacc[2 * kk + 1][e] - (float)pf[4 + e]); }
+        }
+        const int vo = (kk * 32 + q4 * 4 + (r16 >> 2)) * KR + 4 * (r16 & 3);
 #pragma unroll
         for (int dt = 0; dt < 2; dt++) {
-          abf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) abf16x4*)(vb + dt * 16));
-          abf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) abf16x4*)(vb + 16 * KR + dt * 16));
-          abf16x8 vf;
+          abf16x8 vf[NP];
 #pragma unroll
-          for (int e = 0; e < 4; e++) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
-          oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[dt], 0, 0, 0);
+          for (int p2 = 0; p2 < NP; p2++) {
+            const __bf16* vb = &vs[p2][vo];
+            abf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) abf16x4*)(vb + dt * 16));
+            abf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) abf16x4*)(vb + 16 * KR + dt * 16));
+#pragma unroll
+            for (int e = 0; e < 4; e++) { vf[p2][e] = lo[e]; vf[p2][4 + e] = hi[e]; }
+          }
+          if (X3) {
+            oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[0], pl, oacc[dt], 0, 0, 0);
+            oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[NP - 1], pf, oacc[dt], 0, 0, 0);
+          }
+          oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[0], pf, oacc[dt], 0, 0, 0);
         }
       }
     if (qi < S) {
@@ -547,10 +579,11 @@ __global__ __launch_bounds__(256) void attn_smt16_kernel(const __bf16* __restric
       __bf16* op = O16 + (row0 + qi) * ldo16 + h * D + q4 * 4;
 #pragma unroll
       for (int dt = 0; dt < 2; dt++) {
-        abf16x4 o;
+        abf16x4 o, ol;
 #pragma unroll
-        for (int r = 0; r < 4; r++) o[r] = (__bf16)(oacc[dt][r] * inv);
+        for (int r = 0; r < 4; r++) { const float v = oacc[dt][r] * inv; o[r] = (__bf16)v; ol[r] = (__bf16)(v - (float)o[r]); }
         *reinterpret_cast<abf16x4*>(op + dt * 16) = o;
+        if (X3) *reinterpret_cast<abf16x4*>(op + o_lo + dt * 16) = ol;
       }
     }
   }
@@ -562,7 +595,7 @@ template <int T>          // keys per lane: up to 64*T keys
 __global__ __launch_bounds__(64) void attn_q1_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ K, int ldk,
                                                      const float* __restrict__ V, int ldv, __bf16* __restrict__ O16, int ldo16,
                                                      int Sk, float scale, const float* __restrict__ key_mask,
-                                                     const int* __restrict__ seg_off) {
+                                                     const int* __restrict__ seg_off, long o_lo) {
   constexpr int D = 32;
   __shared__ float p[64 * T];
   const int lane = threadIdx.x, h = blockIdx.x, b = blockIdx.y;
@@ -606,7 +639,11 @@ __global__ __launch_bounds__(64) void attn_q1_kernel(const float* __restrict__ Q
   float o = 0.f;
   for (int j = par; j < Sk; j += 2) o += p[j] * V[(krow0 + j) * ldv + h * D + d];
   o += __shfl_xor(o, 32, 64);
-  if (lane < 32) O16[(long)b * ldo16 + h * D + d] = (__bf16)o;
+  if (lane < 32) {
+    const __bf16 hv = (__bf16)o;
+    O16[(long)b * ldo16 + h * D + d] = hv;
+    if (o_lo) O16[o_lo + (long)b * ldo16 + h * D + d] = (__bf16)(o - (float)hv);
+  }
 }
 
 // dQ: lane per query (same streaming structure as forward).  Also writes delta = rowsum(dO * O).
@@ -743,32 +780,42 @@ int avlen_attention_fwd16(const float* Q, int ldq, const float* K, int ldk, cons
 // SMT self-attention from the packed bf16 projection (D = 32): q | k | v at columns 0 | H*32 | 2*H*32; key_mask [B][S], or
 // seg_off [B+1] for a ragged batch of live tokens (S = upper bound of tokens per sample).
 int avlen_attention_smt16(const void* QKV16, int ld, void* O16, int ldo16, int B, int H, int S, float scale,
-                          const float* key_mask, const int* seg_off, hipStream_t stream) {
+                          const float* key_mask, const int* seg_off, hipStream_t stream, long qkv_lo, long o_lo) {
   if (!QKV16 || !O16 || B <= 0 || H <= 0 || S <= 0 || S > 320 || (ld & 7) || (ldo16 & 3)) return AVLEN_ERR_ARG;
+  if (qkv_lo || o_lo) {                 // compensated pairs: both planes of k and v in LDS, q fragments from global memory
+    if (!qkv_lo || !o_lo) return AVLEN_ERR_ARG;
+    if (S <= 160)
+      hipLaunchKernelGGL((attn_smt16_kernel<160, true>), dim3(H, B), dim3(256), 0, stream, (const __bf16*)QKV16, ld, H * 32, 2 * H * 32,
+                         (__bf16*)O16, ldo16, S, scale, key_mask, seg_off, qkv_lo, o_lo);
+    else
+      hipLaunchKernelGGL((attn_smt16_kernel<320, true>), dim3(H, B), dim3(256), 0, stream, (const __bf16*)QKV16, ld, H * 32, 2 * H * 32,
+                         (__bf16*)O16, ldo16, S, scale, key_mask, seg_off, qkv_lo, o_lo);
+    return avlen_launch_status();
+  }
   if (S <= 160)
-    hipLaunchKernelGGL(attn_smt16_kernel<160>, dim3(H, B), dim3(256), 0, stream, (const __bf16*)QKV16, ld, H * 32, 2 * H * 32,
-                       (__bf16*)O16, ldo16, S, scale, key_mask, seg_off);
+    hipLaunchKernelGGL((attn_smt16_kernel<160, false>), dim3(H, B), dim3(256), 0, stream, (const __bf16*)QKV16, ld, H * 32, 2 * H * 32,
+                       (__bf16*)O16, ldo16, S, scale, key_mask, seg_off, 0L, 0L);
   else {
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_smt16_kernel<320>), hipFuncAttributeMaxDynamicSharedMemorySize, 0);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_smt16_kernel<320, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 0);
       attr_set = true;
     }
-    hipLaunchKernelGGL(attn_smt16_kernel<320>, dim3(H, B), dim3(256), 0, stream, (const __bf16*)QKV16, ld, H * 32, 2 * H * 32,
-                       (__bf16*)O16, ldo16, S, scale, key_mask, seg_off);
+    hipLaunchKernelGGL((attn_smt16_kernel<320, false>), dim3(H, B), dim3(256), 0, stream, (const __bf16*)QKV16, ld, H * 32, 2 * H * 32,
+                       (__bf16*)O16, ldo16, S, scale, key_mask, seg_off, 0L, 0L);
   }
   return avlen_launch_status();
 }
 // One query per sample (D = 32, fp32 q / k / v): the decoder's cross attention (<= 320 keys per sample).
 int avlen_attention_q1(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, void* O16, int ldo16, int B,
-                       int H, int Sk, float scale, const float* key_mask, const int* seg_off, hipStream_t stream) {
+                       int H, int Sk, float scale, const float* key_mask, const int* seg_off, hipStream_t stream, long o_lo) {
   if (!Q || !K || !V || !O16 || B <= 0 || H <= 0 || Sk <= 0 || Sk > 320 || ((ldq | ldk | ldv) & 3)) return AVLEN_ERR_ARG;
   if (Sk <= 192)
     hipLaunchKernelGGL(attn_q1_kernel<3>, dim3(H, B), dim3(64), 0, stream, Q, ldq, K, ldk, V, ldv, (__bf16*)O16, ldo16, Sk, scale,
-                       key_mask, seg_off);
+                       key_mask, seg_off, o_lo);
   else
     hipLaunchKernelGGL(attn_q1_kernel<5>, dim3(H, B), dim3(64), 0, stream, Q, ldq, K, ldk, V, ldv, (__bf16*)O16, ldo16, Sk, scale,
-                       key_mask, seg_off);
+                       key_mask, seg_off, o_lo);
   return avlen_launch_status();
 }
 

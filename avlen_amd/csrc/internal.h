@@ -64,9 +64,10 @@ int avlen_conv2d_nhwc_bf16_grouped(const void* const* X, const void* const* Wp, 
 int avlen_gemm_bf16_grouped(const void* const* A, int lda, const void* const* B, int ldb, float* const* C32, int ldc32,
                             const float* const* bias, int groups, int M, int N, int K, int act, void* ws, size_t ws_bytes,
                             hipStream_t stream, const avlen_g2_opts* o = nullptr);
+// y16_lo (elements): also write the low plane of the compensated bf16 pair at y16 + y16_lo
 int avlen_layernorm_fwd16_dyn(const float* x, const float* residual, const float* gamma, const float* beta, float* y,
                               void* y16, float* mean, float* rstd, int rows, const int* rows_dev, int d, float eps,
-                              hipStream_t stream);
+                              hipStream_t stream, long y16_lo = 0);
 int avlen_attention_fwd16_seg(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                               void* O16, int ldo16, const float* key_mask, float* lse, int B, int H, int Sq, int Sk, int D,
                               int causal, float scale, const int* seg_off, hipStream_t stream);
@@ -76,10 +77,12 @@ int avlen_gemm_bf16_ln(const void* A, int lda, const void* B, int ldb, float* C3
                        hipStream_t stream, const avlen_g2_opts* o = nullptr);
 int avlen_attention_qkv16(const void* QKV16, int ld, void* O16, int ldo16, int B, int H, int S, int causal, float scale,
                           const int* seg_off, hipStream_t stream, int f16 = 0);
+// lo planes (elements; 0 = plain bf16): qkv_lo behind QKV16, o_lo behind O16 -- compensated bf16 (three MFMAs per product, P split
+// into hi + lo); only the <= 160-token instance exists in that mode
 int avlen_attention_smt16(const void* QKV16, int ld, void* O16, int ldo16, int B, int H, int S, float scale,
-                          const float* key_mask, const int* seg_off, hipStream_t stream);
+                          const float* key_mask, const int* seg_off, hipStream_t stream, long qkv_lo = 0, long o_lo = 0);
 int avlen_attention_q1(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, void* O16, int ldo16, int B,
-                       int H, int Sk, float scale, const float* key_mask, const int* seg_off, hipStream_t stream);
+                       int H, int Sk, float scale, const float* key_mask, const int* seg_off, hipStream_t stream, long o_lo = 0);
 int avlen_gemm_bf16_dyn(const void* A, int lda, const void* B, int ldb, float* C32, int ldc32, void* C16, int ldc16,
                         const float* bias, const float* residual, int ldr, int M, const int* M_dev, int N, int K, int act,
                         void* ws, size_t ws_bytes, hipStream_t stream, const avlen_g2_opts* o = nullptr);

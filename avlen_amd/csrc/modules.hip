@@ -468,9 +468,9 @@ int linear16(const Ctx& c, const avlen_linear& L, const bf16* X16, int ldx, floa
   return avlen_gemm_bf16(X16, ldx, L.w16, L.ld16, Y32, ld32, Y16, ld16, L.b, res, ldr, M, L.out_f, L.ld16, act, c.gws,
                          c.gws_bytes, c.st);
 }
-int ln16(const Ctx& c, const float* x, const avlen_affine& a, float* y, bf16* y16, int rows, int d) {
-  if (c.live) return avlen_layernorm_fwd16_dyn(x, nullptr, a.g, a.b, y, y16, nullptr, nullptr, rows, c.live, d, 1e-5f, c.st);
-  return avlen_layernorm_fwd16(x, nullptr, a.g, a.b, y, y16, nullptr, nullptr, rows, d, 1e-5f, c.st);
+int ln16(const Ctx& c, const float* x, const avlen_affine& a, float* y, bf16* y16, int rows, int d, long ylo = 0) {
+  if (c.x3 && y16 && !ylo) return AVLEN_ERR_ARG;
+  return avlen_layernorm_fwd16_dyn(x, nullptr, a.g, a.b, y, y16, nullptr, nullptr, rows, c.live, d, 1e-5f, c.st, c.x3 ? ylo : 0);
 }
 int linear16_rows(const Ctx& c, const avlen_linear& L, int r0, int n, const bf16* X16, int ldx, float* Y32, int ld32,
                   bf16* Y16, int ld16, int M, int act, long xlo = 0, long ylo = 0) {
@@ -1328,28 +1328,32 @@ void tr16_layout(WsBump& w, Tr16Ws& t, long B, long S, int d, bool cto) {
 int enc_fwd16(const Ctx& c, const avlen_transformer& tr, Tr16Ws& t, const float* maskx, int B, int S, bool cto) {
   const int d = tr.d, H = tr.nhead, D = d / H;
   const long R = (long)B * S;
+  const long lo = R * d;          // compensated mode: the low plane of every [R][d] bf16 buffer lies R*d elements behind it
   const float scale = 1.0f / sqrtf((float)D);
   const avlen_enc_layer& e = tr.enc;
+  if (c.x3 && (cto || !(D == 32 && S <= 320))) return AVLEN_ERR_ARG;
   if (cto) {                // one valid key: attention output == V(token)
     TRY(linear16_rows(c, e.self_attn.in_proj, 2 * d, d, t.Z16, d, nullptr, 0, t.AO16, d, (int)R, 0));
   } else if (D == 32 && S <= 320) {    // packed bf16 q|k|v straight into the MFMA attention (ragged: live tokens only)
-    TRY(linear16(c, e.self_attn.in_proj, t.Z16, d, nullptr, 0, (bf16*)t.QKV, 3 * d, (int)R, 0, nullptr, 0));
-    TRY(avlen_attention_smt16(t.QKV, 3 * d, t.AO16, d, B, H, S, scale, c.seg ? nullptr : maskx, c.seg, c.st));
+    // (compensated: the fp32-sized QKV buffer holds the hi plane [R][3d] followed by the lo plane)
+    TRY(linear16(c, e.self_attn.in_proj, t.Z16, d, nullptr, 0, (bf16*)t.QKV, 3 * d, (int)R, 0, nullptr, 0, lo, 3 * lo));
+    TRY(avlen_attention_smt16(t.QKV, 3 * d, t.AO16, d, B, H, S, scale, c.seg ? nullptr : maskx, c.seg, c.st, c.x3 ? 3 * lo : 0,
+                              c.x3 ? lo : 0));
   } else {
     if (c.live) return AVLEN_ERR_ARG;
     TRY(linear16(c, e.self_attn.in_proj, t.Z16, d, t.QKV, 3 * d, nullptr, 0, (int)R, 0, nullptr, 0));
     TRY(avlen_attention_fwd16(t.QKV, 3 * d, t.QKV + d, 3 * d, t.QKV + 2 * d, 3 * d, nullptr, 0, t.AO16, d, maskx, nullptr, B,
                               H, S, S, D, 0, scale, c.st));
   }
-  TRY(linear16(c, e.self_attn.out_proj, t.AO16, d, t.T1, d, nullptr, 0, (int)R, 0, t.Z, d));
-  TRY(ln16(c, t.T1, e.norm1, t.X1, t.X116, (int)R, d));
-  TRY(linear16(c, e.lin1, t.X116, d, nullptr, 0, t.F116, d, (int)R, AVLEN_ACT_RELU, nullptr, 0));
-  TRY(linear16(c, e.lin2, t.F116, d, t.T2, d, nullptr, 0, (int)R, 0, t.X1, d));
+  TRY(linear16(c, e.self_attn.out_proj, t.AO16, d, t.T1, d, nullptr, 0, (int)R, 0, t.Z, d, lo, 0));
+  TRY(ln16(c, t.T1, e.norm1, t.X1, t.X116, (int)R, d, lo));
+  TRY(linear16(c, e.lin1, t.X116, d, nullptr, 0, t.F116, d, (int)R, AVLEN_ACT_RELU, nullptr, 0, lo, lo));
+  TRY(linear16(c, e.lin2, t.F116, d, t.T2, d, nullptr, 0, (int)R, 0, t.X1, d, lo, 0));
   TRY(ln16(c, t.T2, e.norm2, t.X2, nullptr, (int)R, d));
-  TRY(ln16(c, t.X2, tr.enc_norm, nullptr, t.MEM16, (int)R, d));
+  TRY(ln16(c, t.X2, tr.enc_norm, nullptr, t.MEM16, (int)R, d, lo));
   if (cto)                  // cross attention over one valid key == V projection of that token
     return linear16_rows(c, tr.dec.cross_attn.in_proj, 2 * d, d, t.MEM16, d, nullptr, 0, t.AOc16, d, (int)R, 0);
-  return linear16_rows(c, tr.dec.cross_attn.in_proj, d, 2 * d, t.MEM16, d, t.KVc, 2 * d, nullptr, 0, (int)R, 0);
+  return linear16_rows(c, tr.dec.cross_attn.in_proj, d, 2 * d, t.MEM16, d, t.KVc, 2 * d, nullptr, 0, (int)R, 0, lo, 0);
 }
 
 // Decoder layer for one target token per sample on the bf16 path.
@@ -1358,31 +1362,34 @@ int dec_fwd16(const Ctx& c, const avlen_transformer& tr, Tr16Ws& t, const float*
   const int d = tr.d, H = tr.nhead, D = d / H;
   const float scale = 1.0f / sqrtf((float)D);
   const avlen_dec_layer& q = tr.dec;
-  if (!cto && d == 256 && chain_enabled()) {          // two fused chains around the cross attention
-    ChainB a;
+  if (c.x3 && (cto || d != 256 || !(D == 32 && S <= 320))) return AVLEN_ERR_ARG;
+  if (!cto && d == 256 && (chain_enabled() || c.x3)) {          // two fused chains around the cross attention
+    const long blo = (long)B * d;                     // low plane of the [B][d] bf16 buffers
+    ChainB a(c.x3 != 0);
     a.load_cur(tgt, d, 0); a.save();
     a.linear(q.self_attn.in_proj, 2 * d, 0, 0, 0, 1);                // one target token: self attention == V projection
     a.linear(q.self_attn.out_proj, 0, 0, 1, 1, 0);
     a.ln(q.norm1, 0); a.store(t.Y1, d, nullptr, 0);
     a.linear(q.cross_attn.in_proj, 0, 0, 0, 0, 1); a.store(t.Qc, d, nullptr, 0);
-    ChainB b;
+    ChainB b(c.x3 != 0);
     b.load_cur(t.Y1, d, 0); b.save();
-    b.load_x16(t.AOc16, d, d, 1);
+    b.load_x16(t.AOc16, d, d, 1, c.x3 ? t.AOc16 + blo : nullptr);
     b.linear(q.cross_attn.out_proj, 0, 0, 1, 1, 0);
     b.ln(q.norm2, 0); b.save();
     b.linear(q.lin1, 0, AVLEN_ACT_RELU, 0, 0, 1);
     b.linear(q.lin2, 0, 0, 1, 1, 0);
     b.ln(q.norm3, 0); b.ln(tr.dec_norm, 0); b.store(out, d, nullptr, 0);
     if (a.ok && b.ok && q.lin1.out_f == 256) {
-      TRY(avlen_chain_run(&a.p, B, c.st));
+      TRY(a.run(B, c.st));
       if (D == 32 && S <= 320)
         TRY(avlen_attention_q1(t.Qc, d, t.KVc, 2 * d, t.KVc + d, 2 * d, t.AOc16, d, B, H, S, scale, c.seg ? nullptr : maskx, c.seg,
-                               c.st));
+                               c.st, c.x3 ? blo : 0));
       else
         TRY(avlen_attention_fwd16(t.Qc, d, t.KVc, 2 * d, t.KVc + d, 2 * d, nullptr, 0, t.AOc16, d, maskx, nullptr, B, H, 1, S, D,
                                   0, scale, c.st));
-      return avlen_chain_run(&b.p, B, c.st);
+      return b.run(B, c.st);
     }
+    if (c.x3) return AVLEN_ERR_ARG;
   }
   TRY(avlen_cast_bf16(tgt, d, t.tgt16, d, B, d, c.st));
   TRY(linear16_rows(c, q.self_attn.in_proj, 2 * d, d, t.tgt16, d, nullptr, 0, t.V016, d, B, 0));
@@ -1446,7 +1453,8 @@ int smt_fwd_infer_bf16(const avlen_smt* p, const float* x, const float* memory, 
   const bool ragged = !cto && masks && M > 4 && d / tr.nhead == 32 && S <= 320 && ragged_enabled();
   const bool chain_cto = cto && d == 256 && chain_enabled();
   const bool chain_small = !cto && (S == 2 || S == 4) && d == 256 && s.ldxf <= 320 && chain_enabled();
-  if (x3 && !chain_cto && !chain_small) return AVLEN_NOT_BIG;
+  const bool general_x3 = !cto && d == 256 && d / tr.nhead == 32 && S <= 320 && p->fus0.out_f == 256;
+  if (x3 && !chain_cto && !chain_small && !general_x3) return AVLEN_NOT_BIG;
   bf16* XFlo = x3 ? s.XF + R * s.ldxf : nullptr;
   if (ragged) {
     hipLaunchKernelGGL(smt_segments_kernel, dim3(1), dim3(1024), 0, st, masks, s.seg, s.rowmap, B, M);
@@ -1494,9 +1502,9 @@ int smt_fwd_infer_bf16(const avlen_smt* p, const float* x, const float* memory, 
     ch.small_transformer(tr, goal, s.maskx, S, out);
     if (ch.ok && p->fus0.out_f == 256) return ch.run((int)R, st);
   }
-  if (x3) return AVLEN_NOT_BIG;
-  TRY(linear16(c, p->fus0, s.XF, s.ldxf, nullptr, 0, s.H1, d, (int)R, AVLEN_ACT_RELU, nullptr, 0));
-  TRY(linear16(c, p->fus2, s.H1, d, s.tr.Z, d, s.tr.Z16, d, (int)R, 0, nullptr, 0));
+  if (x3 && !general_x3) return AVLEN_NOT_BIG;
+  TRY(linear16(c, p->fus0, s.XF, s.ldxf, nullptr, 0, s.H1, d, (int)R, AVLEN_ACT_RELU, nullptr, 0, R * s.ldxf, R * d));
+  TRY(linear16(c, p->fus2, s.H1, d, s.tr.Z, d, s.tr.Z16, d, (int)R, 0, nullptr, 0, R * d, R * d));
   TRY(enc_fwd16(c, tr, s.tr, s.maskx, B, S, cto));
   return dec_fwd16(c, tr, s.tr, s.maskx, goal, out, B, S, cto);
 }

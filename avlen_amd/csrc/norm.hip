@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float* __restrict__ y, __bf16* __restrict__ y16,
                                                      float* __restrict__ mean_o, float* __restrict__ rstd_o, int rows,
-                                                     float eps, const int* __restrict__ rows_dev) {
+                                                     float eps, const int* __restrict__ rows_dev, long y16_lo) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows || (rows_dev && row >= *rows_dev)) return;
@@ -224,7 +224,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     int c = lane + i * 64;
     float o = (v[i] - mean) * rstd * gamma[c] + beta[c];
     if (y) y[(long)row * d + c] = o;
-    if (y16) y16[(long)row * d + c] = (__bf16)o;
+    if (y16) {
+      const __bf16 hv = (__bf16)o;
+      y16[(long)row * d + c] = hv;
+      if (y16_lo) y16[y16_lo + (long)row * d + c] = (__bf16)(o - (float)hv);      // low plane of the compensated pair
+    }
   }
   if (mean_o && lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
 }
@@ -361,15 +365,15 @@ int avlen_layernorm_fwd16(const float* x, const float* residual, const float* ga
 
 int avlen_layernorm_fwd16_dyn(const float* x, const float* residual, const float* gamma, const float* beta, float* y,
                               void* y16, float* mean, float* rstd, int rows, const int* rows_dev, int d, float eps,
-                              hipStream_t stream) {
+                              hipStream_t stream, long y16_lo) {
   if (rows <= 0) return AVLEN_ERR_ARG;
   dim3 grid(ceil_div(rows, 4)), block(256);
   __bf16* h = (__bf16*)y16;
   switch (d) {
-    case 256: hipLaunchKernelGGL((ln_fwd_kernel<4>), grid, block, 0, stream, x, residual, gamma, beta, y, h, mean, rstd, rows, eps, rows_dev); break;
-    case 512: hipLaunchKernelGGL((ln_fwd_kernel<8>), grid, block, 0, stream, x, residual, gamma, beta, y, h, mean, rstd, rows, eps, rows_dev); break;
-    case 128: hipLaunchKernelGGL((ln_fwd_kernel<2>), grid, block, 0, stream, x, residual, gamma, beta, y, h, mean, rstd, rows, eps, rows_dev); break;
-    case 64: hipLaunchKernelGGL((ln_fwd_kernel<1>), grid, block, 0, stream, x, residual, gamma, beta, y, h, mean, rstd, rows, eps, rows_dev); break;
+    case 256: hipLaunchKernelGGL((ln_fwd_kernel<4>), grid, block, 0, stream, x, residual, gamma, beta, y, h, mean, rstd, rows, eps, rows_dev, y16_lo); break;
+    case 512: hipLaunchKernelGGL((ln_fwd_kernel<8>), grid, block, 0, stream, x, residual, gamma, beta, y, h, mean, rstd, rows, eps, rows_dev, y16_lo); break;
+    case 128: hipLaunchKernelGGL((ln_fwd_kernel<2>), grid, block, 0, stream, x, residual, gamma, beta, y, h, mean, rstd, rows, eps, rows_dev, y16_lo); break;
+    case 64: hipLaunchKernelGGL((ln_fwd_kernel<1>), grid, block, 0, stream, x, residual, gamma, beta, y, h, mean, rstd, rows, eps, rows_dev, y16_lo); break;
     default: return AVLEN_ERR_ARG;
   }
   return avlen_launch_status();
