@@ -56,7 +56,7 @@ class ResNet18(C.Structure):
 
 
 class Cnn3(C.Structure):
-    _fields_ = [("conv", Conv * 3), ("fc", Linear)]
+    _fields_ = [("conv", Conv * 3), ("fc", Linear), ("half_fmt", C.c_int)]
 
 
 class Mha(C.Structure):

@@ -131,5 +131,5 @@ int avlen_tower_tail_bf16(const avlen_resnet18* const* nets, const void* const* 
 bool avlen_tower_x3_supported(const avlen_resnet18* net, int S, int C);
 size_t avlen_tower_x3_workspace_bytes(int groups, int B);
 int avlen_tower_x3_fwd(const avlen_resnet18* const* nets, const void* const* imgs, const int* img_u8, const int* channels,
-                       const float* divisors, const int* row_index, float* const* Y, int groups, int B, int S, void* ws,
+                       const float* divisors, const int* row_index, void* const* Y, int groups, int B, int S, void* ws,
                        size_t ws_bytes, hipStream_t stream);

@@ -831,9 +831,13 @@ size_t cnn3_ws_bf16(const avlen_cnn3* n, int B, int H, int W) {
   }
   return tot + zmax(mx, avlen_gemm_bf16_workspace_bytes(B, n->fc.out_f)) + 4096;
 }
+// f16: the 16-bit shadows of this CNN (n->half_fmt == 1) and every 16-bit activation are IEEE half
 int cnn3_fwd_bf16(const avlen_cnn3* n, const float* x, int B, int H, int W, float* out, int ld_out, void* ws,
-                  size_t ws_bytes, hipStream_t st, const int* row_index = nullptr) {
+                  size_t ws_bytes, hipStream_t st, const int* row_index = nullptr, bool f16 = false) {
   if (ws_bytes < cnn3_ws_bf16(n, B, H, W)) return AVLEN_ERR_WS;
+  if (f16 != (n->half_fmt == 1) || (f16 && row_index)) return AVLEN_ERR_ARG;
+  avlen_g2_opts go; go.f16 = f16;
+  const int fmt = f16 ? 1 : 0;
   int oh[3], ow[3]; cnn3_dims2(n, H, W, oh, ow);
   WsBump w(ws, ws_bytes);
   bf16* x16 = w.take<bf16>((size_t)B * H * W * 8);
@@ -846,31 +850,39 @@ int cnn3_fwd_bf16(const avlen_cnn3* n, const float* x, int B, int H, int W, floa
   void* gws = w.take<char>(mx);
   const bool sp = cnn3_superpixel(n, W);
   const int wsp = sp ? ((ow[0] - 1) * n->conv[0].stride + n->conv[0].kw) / n->conv[0].stride : 0;   // super-pixels per row
-  if (sp) TRY(avlen_cast_bf16_indexed(x, W * n->conv[0].cin, x16, wsp * 8, (long)B * H, wsp * 8, row_index, H, st));     // drop the unused columns
+  if (f16) {
+    if (sp) TRY(avlen_cast_h16(x, W * n->conv[0].cin, x16, wsp * 8, (long)B * H, wsp * 8, fmt, st));
+    else TRY(avlen_cast_h16(x, n->conv[0].cin, x16, 8, (long)B * H * W, n->conv[0].cin, fmt, st));
+  } else if (sp) TRY(avlen_cast_bf16_indexed(x, W * n->conv[0].cin, x16, wsp * 8, (long)B * H, wsp * 8, row_index, H, st));     // drop the unused columns
   else TRY(avlen_cast_bf16_indexed(x, n->conv[0].cin, x16, 8, (long)B * H * W, n->conv[0].cin, row_index, H * W, st));         // channel-pad to 8
   const bf16* cur = x16; int h = H, wd = W;
   for (int i = 0; i < 3; i++) {
     const avlen_conv& k = n->conv[i];
+    const void* X1 = cur; void* Y1 = a[i]; const float* B1 = k.b;
     if (i == 0 && sp) {
-      const void* X1 = cur; const void* W1 = k.w16c; void* Y1 = a[0]; const float* B1 = k.b;
+      const void* W1 = k.w16c;
       TRY(avlen_conv2d_nhwc_bf16_grouped(&X1, &W1, nullptr, &Y1, nullptr, 1, B, h, wsp, 8, k.cout, k.kh, k.kw / k.stride, k.stride,
-                                         0, gws, mx, st, &B1, AVLEN_ACT_RELU, 1));
+                                         0, gws, mx, st, &B1, AVLEN_ACT_RELU, 1, &go));
     } else {
-      TRY(avlen_conv2d_nhwc_bf16(cur, k.w16, k.b, nullptr, nullptr, a[i], nullptr, B, h, wd, k.cin16, k.cout, k.kh, k.kw,
-                                 k.stride, 0, i < 2 ? AVLEN_ACT_RELU : AVLEN_ACT_NONE, gws, mx, st));
+      const void* W1 = k.w16;
+      TRY(avlen_conv2d_nhwc_bf16_grouped(&X1, &W1, nullptr, &Y1, nullptr, 1, B, h, wd, k.cin16, k.cout, k.kh, k.kw, k.stride, 0, gws,
+                                         mx, st, &B1, i < 2 ? AVLEN_ACT_RELU : AVLEN_ACT_NONE, 0, &go));
     }
     cur = a[i]; h = oh[i]; wd = ow[i];
   }
-  return avlen_gemm_bf16(cur, n->fc.ld16, n->fc.w16, n->fc.ld16, out, ld_out, nullptr, 0, n->fc.b, nullptr, 0, B,
-                         n->fc.out_f, n->fc.ld16, AVLEN_ACT_RELU, gws, mx, st);
+  return avlen_gemm_bf16_dyn(cur, n->fc.ld16, n->fc.w16, n->fc.ld16, out, ld_out, nullptr, 0, n->fc.b, nullptr, 0, B, nullptr,
+                             n->fc.out_f, n->fc.ld16, AVLEN_ACT_RELU, gws, mx, st, &go);
 }
 
 // `G` CNNs of identical architecture (the audio encoders of pi_q / pi_g / pi_l) on the SAME input: one cast, one grouped
 // launch per layer.
 int cnn3_group_fwd_bf16(const avlen_cnn3* const* nets, const float* x, int G, int B, int H, int W, float* const* outs,
-                        int ld_out, void* ws, size_t ws_bytes, hipStream_t st) {
+                        int ld_out, void* ws, size_t ws_bytes, hipStream_t st, bool f16 = false) {
   const avlen_cnn3* n = nets[0];
   if (ws_bytes < (size_t)G * cnn3_ws_bf16(n, B, H, W)) return AVLEN_ERR_WS;
+  for (int g = 0; g < G; g++) if (f16 != (nets[g]->half_fmt == 1)) return AVLEN_ERR_ARG;
+  avlen_g2_opts go; go.f16 = f16;
+  const int fmt = f16 ? 1 : 0;
   int oh[3], ow[3]; cnn3_dims2(n, H, W, oh, ow);
   WsBump w(ws, ws_bytes);
   bf16* x16 = w.take<bf16>((size_t)B * H * W * 8);
@@ -886,8 +898,8 @@ int cnn3_group_fwd_bf16(const avlen_cnn3* const* nets, const float* x, int G, in
   bool sp = true;
   for (int g = 0; g < G; g++) sp = sp && cnn3_superpixel(nets[g], W);
   const int wsp = sp ? ((ow[0] - 1) * n->conv[0].stride + n->conv[0].kw) / n->conv[0].stride : 0;   // super-pixels per row
-  if (sp) TRY(avlen_cast_bf16(x, W * n->conv[0].cin, x16, wsp * 8, (long)B * H, wsp * 8, st));     // drop the unused columns
-  else TRY(avlen_cast_bf16(x, n->conv[0].cin, x16, 8, (long)B * H * W, n->conv[0].cin, st));         // channel-pad to 8
+  if (sp) TRY(avlen_cast_h16(x, W * n->conv[0].cin, x16, wsp * 8, (long)B * H, wsp * 8, fmt, st));     // drop the unused columns
+  else TRY(avlen_cast_h16(x, n->conv[0].cin, x16, 8, (long)B * H * W, n->conv[0].cin, fmt, st));         // channel-pad to 8
   const void* X[8]; const void* Wt[8]; void* Y[8]; const float* BI[8];
   int h = H, wd = W;
   for (int i = 0; i < 3; i++) {
@@ -899,13 +911,13 @@ int cnn3_group_fwd_bf16(const avlen_cnn3* const* nets, const float* x, int G, in
     }
     TRY(avlen_conv2d_nhwc_bf16_grouped(X, Wt, nullptr, Y, nullptr, G, B, h, spi ? wsp : wd, spi ? 8 : k.cin16, k.cout, k.kh,
                                        spi ? k.kw / k.stride : k.kw, k.stride, 0, gws, mx, st, BI,
-                                       i < 2 ? AVLEN_ACT_RELU : AVLEN_ACT_NONE, spi ? 1 : 0));
+                                       i < 2 ? AVLEN_ACT_RELU : AVLEN_ACT_NONE, spi ? 1 : 0, &go));
     h = oh[i]; wd = ow[i];
   }
   const void* FA[8]; const void* FB[8]; const float* FBI[8];
   for (int g = 0; g < G; g++) { FA[g] = a[2][g]; FB[g] = nets[g]->fc.w16; FBI[g] = nets[g]->fc.b; }
   return avlen_gemm_bf16_grouped(FA, n->fc.ld16, FB, n->fc.ld16, outs, ld_out, FBI, G, B, n->fc.out_f, n->fc.ld16, AVLEN_ACT_RELU,
-                                 gws, mx, st);
+                                 gws, mx, st, &go);
 }
 
 }  // namespace
@@ -917,6 +929,7 @@ extern "C" size_t avlen_cnn3_group_workspace_bytes(const avlen_cnn3* n, int grou
 extern "C" int avlen_cnn3_group_fwd(const avlen_cnn3* const* nets, const float* x, int groups, int B, int H, int W,
                                     float* const* outs, int ld_out, void* ws, size_t ws_bytes, hipStream_t st) {
   if (!nets || groups < 1 || groups > 8 || B <= 0) return AVLEN_ERR_ARG;
+  const bool f16 = nets[0]->half_fmt == 1;              // the format of the nets' 16-bit shadows selects bf16 / fp16 arithmetic
   for (int g = 0; g < groups; g++) {
     if (!cnn3_has16(nets[g])) return AVLEN_ERR_ARG;
     for (int i = 0; i < 3; i++) {
@@ -924,7 +937,7 @@ extern "C" int avlen_cnn3_group_fwd(const avlen_cnn3* const* nets, const float* 
       if (a.cin != b.cin || a.cout != b.cout || a.kh != b.kh || a.kw != b.kw || a.stride != b.stride) return AVLEN_ERR_ARG;
     }
   }
-  return cnn3_group_fwd_bf16(nets, x, groups, B, H, W, outs, ld_out, ws, ws_bytes, st);
+  return cnn3_group_fwd_bf16(nets, x, groups, B, H, W, outs, ld_out, ws, ws_bytes, st, f16);
 }
 
 // =====================================================================================================
@@ -965,15 +978,22 @@ extern "C" int avlen_resnet18_group_fwd_x3(const avlen_resnet18* const* nets, co
   for (int g = 0; g < groups; g++)
     if (!avlen_tower_x3_supported(nets[g], S, channels[g])) return AVLEN_ERR_ARG;
   WsBump w(ws, ws_bytes);
-  float* Y[8];
-  for (int g = 0; g < groups; g++) Y[g] = w.take<float>((size_t)B * 8192);
+  void* Y[8];
+  for (int g = 0; g < groups; g++) Y[g] = w.take<bf16>((size_t)2 * B * 8192);           // hi plane, lo plane
   void* gws = w.take<char>(GEMM_SCRATCH);
   const size_t tb = avlen_tower_x3_workspace_bytes(groups, B);
   void* tws = w.take<char>(tb);
   TRY(avlen_tower_x3_fwd(nets, imgs, img_u8, channels, divisors, row_index, Y, groups, B, S, tws, tb, st));
-  Ctx c{st, AVLEN_PREC_BF16X3, gws, GEMM_SCRATCH};
-  for (int g = 0; g < groups; g++) TRY(linear(c, nets[g]->fc, Y[g], 8192, outs[g], ld_out, B, 0, nullptr, 0));
-  return AVLEN_OK;
+  // fc (8192 -> 64) of all towers: one grouped compensated GEMM (the weights' low planes lie at one common distance)
+  const void* FA[8]; const void* FB[8]; const float* FBI[8];
+  const avlen_linear& fc = nets[0]->fc;
+  avlen_g2_opts o; o.x3 = 1; o.a_lo = (long)B * 8192 * 2; o.b_lo = (const char*)fc.w16lo - (const char*)fc.w16;
+  for (int g = 0; g < groups; g++) {
+    const avlen_linear& f = nets[g]->fc;
+    if (!f.w16 || !f.w16lo || f.ld16 != 8192 || (const char*)f.w16lo - (const char*)f.w16 != o.b_lo) return AVLEN_ERR_ARG;
+    FA[g] = Y[g]; FB[g] = f.w16; FBI[g] = f.b;
+  }
+  return avlen_gemm_bf16_grouped(FA, 8192, FB, 8192, outs, ld_out, FBI, groups, B, fc.out_f, 8192, 0, gws, GEMM_SCRATCH, st, &o);
 }
 
 extern "C" int avlen_resnet18_fwd(const avlen_resnet18* net, const void* img, int img_u8, int B, int S, int C, float divisor,
@@ -1047,8 +1067,12 @@ extern "C" int avlen_cnn3_fwd(const avlen_cnn3* n, const float* x, int B, int H,
   if (!n || B <= 0 || ws_bytes < avlen_cnn3_workspace_bytes(n, B, H, W)) return AVLEN_ERR_WS;
   int oh[3], ow[3]; cnn3_dims(n, H, W, oh, ow);
   if (oh[2] <= 0 || ow[2] <= 0 || n->fc.in_f != oh[2] * ow[2] * n->conv[2].cout) return AVLEN_ERR_ARG;
-  if (prec == AVLEN_PREC_BF16 && cnn3_has16(n) && n->conv[0].cin <= 8)
+  if (prec == AVLEN_PREC_BF16 && n->half_fmt == 0 && cnn3_has16(n) && n->conv[0].cin <= 8)
     return cnn3_fwd_bf16(n, x, B, H, W, out, ld_out, ws, ws_bytes, st);
+  if (prec == AVLEN_PREC_FP16) {
+    if (n->half_fmt != 1 || !cnn3_has16(n) || n->conv[0].cin > 8) return AVLEN_ERR_ARG;     // no fp16 fallback
+    return cnn3_fwd_bf16(n, x, B, H, W, out, ld_out, ws, ws_bytes, st, nullptr, true);
+  }
   WsBump w(ws, ws_bytes);
   float* a[3];
   for (int i = 0; i < 3; i++) a[i] = w.take<float>((size_t)B * oh[i] * ow[i] * n->conv[i].cout);

@@ -306,9 +306,9 @@ struct RestTower {
   const float* r;                                                             // block input of that block (materialised fp32): the residual
   const bf16* wh[15]; const bf16* wl[15];                                     // [stage * 5 + conv]
   const float* g[15]; const float* b[15];
-  float* y;                                                                   // layer-4 output NHWC fp32 (B, 8, 8, 128)
+  bf16* y;                                                                    // layer-4 output NHWC (B, 8, 8, 128) as a bf16 pair
 };
-struct RestArgs { RestTower t[8]; };
+struct RestArgs { RestTower t[8]; long y_lo; };                               // y_lo: elements from the hi plane to the lo plane
 
 __device__ __forceinline__ void stat_pair(const f32x4& v, float& g0, float& g1, float& h0, float& h1) {     // 32 channels: 2 per group
   g0 += v[0] + v[1]; g1 += v[2] + v[3];
@@ -780,11 +780,16 @@ __global__ __launch_bounds__(RTH) void rest_x3_kernel(RestArgs args) {
   // ---- layer-4 output (post ReLU) = the residual registers of the last block: NHWC fp32 (8, 8, 128)
   {
     const int ly = r16 >> 3, lx = r16 & 7;
-    float* __restrict__ y = t.y + (long)img * 64 * 128;
+    bf16* __restrict__ y = t.y + (long)img * 64 * 128;
 #pragma unroll
-    for (int pt = 0; pt < 4; pt++)
-      *reinterpret_cast<float4*>(y + ((long)(2 * pt + ly) * 8 + lx) * 128 + wave * 16 + q * 4) =
-          make_float4(res4[pt][0], res4[pt][1], res4[pt][2], res4[pt][3]);
+    for (int pt = 0; pt < 4; pt++) {
+      const float v[4] = {res4[pt][0], res4[pt][1], res4[pt][2], res4[pt][3]};
+      uint2 hh, ll;
+      split4(v, hh, ll);
+      const long o = ((long)(2 * pt + ly) * 8 + lx) * 128 + wave * 16 + q * 4;
+      *reinterpret_cast<uint2*>(y + o) = hh;
+      *reinterpret_cast<uint2*>(y + args.y_lo + o) = ll;
+    }
   }
 }
 
@@ -821,9 +826,10 @@ size_t avlen_tower_x3_workspace_bytes(int groups, int B) {
   return (size_t)groups * (4 * (act + 256) + 5 * ((size_t)B * 32 * sizeof(float) + 256) + (size_t)B * 8192 * sizeof(float) + 256) + 4096;
 }
 
-// Y[g] = layer-4 output NHWC fp32 (B, 8, 8, 128) of tower g (the caller applies fc); imgs[g]: B (or, with row_index, more) images
+// Y[g] = layer-4 output NHWC (B, 8, 8, 128) of tower g as a compensated bf16 pair (hi plane, lo plane B * 8192 elements behind;
+// the caller applies fc); imgs[g]: B (or, with row_index, more) images
 int avlen_tower_x3_fwd(const avlen_resnet18* const* nets, const void* const* imgs, const int* img_u8, const int* channels,
-                       const float* divisors, const int* row_index, float* const* Y, int groups, int B, int S, void* ws,
+                       const float* divisors, const int* row_index, void* const* Y, int groups, int B, int S, void* ws,
                        size_t ws_bytes, hipStream_t stream) {
   if (groups < 1 || groups > 8 || B <= 0 || ws_bytes < avlen_tower_x3_workspace_bytes(groups, B)) return AVLEN_ERR_WS;
   WsBump w(ws, ws_bytes);
@@ -873,10 +879,11 @@ int avlen_tower_x3_fwd(const avlen_resnet18* const* nets, const void* const* img
   }
   {
     RestArgs a = {};
+    a.y_lo = (long)B * 8192;
     for (int g = 0; g < groups; g++) {
       const avlen_resnet18* n = nets[g];
       RestTower& t = a.t[g];
-      t.x = raw[g][2]; t.xst = st[g] + 4 * sb; t.xg = n->block[1].bn2.g; t.xb = n->block[1].bn2.b; t.r = a2[g]; t.y = Y[g];
+      t.x = raw[g][2]; t.xst = st[g] + 4 * sb; t.xg = n->block[1].bn2.g; t.xb = n->block[1].bn2.b; t.r = a2[g]; t.y = (bf16*)Y[g];
       for (int l = 0; l < 3; l++) {
         const avlen_resblock& b0 = n->block[2 + 2 * l]; const avlen_resblock& b1 = n->block[3 + 2 * l];
         const int o = 5 * l;

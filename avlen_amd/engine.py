@@ -130,7 +130,8 @@ class Packed:
         # lo: also build the LOW planes of the compensated bf16 pairs (w16lo / w16flo: AVLEN_PREC_BF16X3 fast paths)
         self.device, self.bufs, self.jobs, self.flat, self.lo = device, [], [], flat, lo
 
-    def conv(self, conv, has_bias, bf16=True):
+    def conv(self, conv, has_bias, bf16=True, fmt=0):
+        """fmt: format of the 16-bit copies (0 bf16, 1 fp16)."""
         O, I, KH, KW = conv.weight.shape
         if not bf16:                                  # fp32-staged kernels only (any channel count)
             buf = torch.empty(O * KH * KW * I, dtype=torch.float32, device=self.device)
@@ -143,10 +144,10 @@ class Packed:
             c16 *= 2
         buf16 = torch.empty(O * KH * KW * c16, dtype=torch.bfloat16, device=self.device)
         self.bufs += [buf, buf16]
-        self.jobs.append(("conv", conv.weight, buf, buf16, (O, I, KH, KW), c16))
+        self.jobs.append(("conv", conv.weight, buf, buf16, (O, I, KH, KW), (c16, fmt)))
         v = L.Conv(P(buf), P(conv.bias) if has_bias else None, I, O, KH, KW, conv.stride[0], conv.padding[0])
         v.w16, v.cin16 = P(buf16), c16
-        if self.lo:
+        if self.lo and fmt == 0:
             buf16lo = torch.empty_like(buf16)
             self.bufs.append(buf16lo)
             self.jobs.append(("conv_lo", conv.weight, None, buf16lo, (O, I, KH, KW), c16))
@@ -156,7 +157,7 @@ class Packed:
             self.bufs.append(buff)
             self.jobs.append(("frag", buf16, None, buff, (O, KH * KW * c16), 0))
             v.w16f = P(buff)
-            if self.lo:
+            if self.lo and fmt == 0:
                 bufflo = torch.empty_like(buf16)
                 self.bufs.append(bufflo)
                 self.jobs.append(("frag", buf16lo, None, bufflo, (O, KH * KW * c16), 0))
@@ -164,7 +165,7 @@ class Packed:
         if I * conv.stride[0] == 8 and KW % conv.stride[0] == 0 and conv.padding[0] == 0 and I < 8:
             bufc = torch.empty(O * KH * KW * I, dtype=torch.bfloat16, device=self.device)      # compact: super-pixel form
             self.bufs.append(bufc)
-            self.jobs.append(("conv16c", conv.weight, None, bufc, (O, I, KH, KW), I))
+            self.jobs.append(("conv16c", conv.weight, None, bufc, (O, I, KH, KW), (I, fmt)))
             v.w16c = P(bufc)
         return v
 
@@ -185,14 +186,21 @@ class Packed:
         v.w16, v.cin16 = P(buf16), c16
         return v
 
-    def fc_after_flatten(self, lin, C_, HW):
+    def fc_after_flatten(self, lin, C_, HW, fmt=0):
         O = lin.weight.shape[0]
         buf = torch.empty(O * C_ * HW, dtype=torch.float32, device=self.device)
-        buf16 = torch.empty(O * C_ * HW, dtype=torch.bfloat16, device=self.device)
-        self.bufs += [buf, buf16]
-        self.jobs.append(("fc", lin.weight, buf, buf16, (O, C_, HW), 0))
+        want_lo = self.lo and fmt == 0
+        # the low plane lies right behind the high plane: one common distance for every tower's fc (grouped compensated GEMM)
+        both = torch.empty((2 if want_lo else 1) * O * C_ * HW, dtype=torch.bfloat16, device=self.device)
+        buf16 = both[:O * C_ * HW]
+        self.bufs += [buf, both]
+        self.jobs.append(("fc", lin.weight, buf, buf16, (O, C_, HW), fmt))
         v = L.Linear(P(buf), P(lin.bias), O, C_ * HW)
         v.w16, v.ld16 = P(buf16), C_ * HW
+        if want_lo:
+            buf16lo = both[O * C_ * HW:]
+            self.jobs.append(("fc_lo", lin.weight, None, buf16lo, (O, C_, HW), 2))
+            v.w16lo = P(buf16lo)
         return v
 
     def linear_pad(self, w, fmt=0):
@@ -245,13 +253,15 @@ class Packed:
             elif kind == "conv_lo":
                 L.call("avlen_pack_conv_weight_h16", P(w), P(buf16), *dims, c16, 2, st)
             elif kind == "conv16c":
-                L.call("avlen_pack_conv_weight_bf16", P(w), P(buf16), *dims, c16, st)
+                L.call("avlen_pack_conv_weight_h16", P(w), P(buf16), *dims, c16[0], c16[1], st)
             elif kind == "conv":
                 L.call("avlen_pack_conv_weight", P(w), P(buf), *dims, st)
-                L.call("avlen_pack_conv_weight_bf16", P(w), P(buf16), *dims, c16, st)
+                L.call("avlen_pack_conv_weight_h16", P(w), P(buf16), *dims, c16[0], c16[1], st)
+            elif kind == "fc_lo":
+                L.call("avlen_pack_fc_after_flatten_h16", P(w), P(buf16), *dims, 2, st)
             else:
                 L.call("avlen_pack_fc_after_flatten", P(w), P(buf), *dims, st)
-                L.call("avlen_pack_fc_after_flatten_bf16", P(w), P(buf16), *dims, st)
+                L.call("avlen_pack_fc_after_flatten_h16", P(w), P(buf16), *dims, c16, st)
         if self.flat is not None:
             self.flat.refresh16()
 
@@ -319,12 +329,14 @@ def resnet18_tv_view(net, packed):
     return s
 
 
-def cnn3_view(net, packed):
+def cnn3_view(net, packed, fmt=0):
+    """fmt: format of the 16-bit weight shadows (0 bf16, 1 fp16: AVLEN_PREC_FP16 calls)."""
     s = L.Cnn3()
+    s.half_fmt = fmt
     for i, idx in enumerate((0, 2, 4)):
-        s.conv[i] = packed.conv(net.cnn[idx], True)
+        s.conv[i] = packed.conv(net.cnn[idx], True, fmt=fmt)
     h, w = net.out_hw
-    s.fc = packed.fc_after_flatten(net.cnn[6], 64, h * w)
+    s.fc = packed.fc_after_flatten(net.cnn[6], 64, h * w, fmt=fmt)
     return s
 
 

@@ -59,7 +59,8 @@ typedef struct { avlen_conv conv1, conv2, down; avlen_affine bn1, bn2, bnd; int 
 typedef struct { avlen_conv conv1; avlen_affine bn1; avlen_resblock block[8]; avlen_linear fc; } avlen_resnet18;
 /* AudioCNN / VisualCNN (audio_cnn.py:62-94, visual_cnn.py:82-107): 3 convs (+bias, ReLU after the
  * first two) + fc + ReLU.  fc.w packed to the NHWC flatten order. */
-typedef struct { avlen_conv conv[3]; avlen_linear fc; } avlen_cnn3;
+/* half_fmt: format of the 16-bit weight shadows (w16, w16c, fc.w16): 0 = bf16, 1 = fp16 (AVLEN_PREC_FP16 calls). */
+typedef struct { avlen_conv conv[3]; avlen_linear fc; int half_fmt; } avlen_cnn3;
 typedef struct { avlen_linear in_proj, out_proj; } avlen_mha;                      /* packed q|k|v rows */
 typedef struct { avlen_mha self_attn; avlen_linear lin1, lin2; avlen_affine norm1, norm2; } avlen_enc_layer;
 typedef struct { avlen_mha self_attn, cross_attn; avlen_linear lin1, lin2; avlen_affine norm1, norm2, norm3; } avlen_dec_layer;
