@@ -18,19 +18,23 @@ GEMM = dict(M=2464, N=2048, K=512, epilogue="bf16", act=2)
 CONV = dict(B=384, W=64, C=16)
 
 
+FMT = 0          # 16-bit operand format of the probed GEMM: 0 = bf16, 1 = fp16 (the CLIP text tower of the bf16x3 mode)
+
+
 def make_gemm(M=None, N=None, K=None, epilogue=None, act=None):
-    """epilogue: "residual32" = fp32 residual in/out (out_proj / c_proj), "bf16" = bias (+ activation), bf16 out only (in_proj / c_fc)."""
+    """epilogue: "residual32" = fp32 residual in/out (out_proj / c_proj), "bf16" = bias (+ activation), 16-bit out only (in_proj / c_fc)."""
     M, N, K = M or GEMM["M"], N or GEMM["N"], K or GEMM["K"]
     epilogue = epilogue or GEMM["epilogue"]
     act = GEMM["act"] if act is None else act
-    A = torch.randn(M, K, device="cuda").bfloat16(); Wt = (torch.randn(N, K, device="cuda") / math.sqrt(K)).bfloat16()
+    dt = torch.float16 if FMT == 1 else torch.bfloat16
+    A = torch.randn(M, K, device="cuda").to(dt); Wt = (torch.randn(N, K, device="cuda") / math.sqrt(K)).to(dt)
     b = torch.randn(N, device="cuda"); X = torch.randn(M, N, device="cuda")
-    Y16 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    Y16 = torch.empty(M, N, device="cuda", dtype=dt)
     nb = L.lib.avlen_gemm_bf16_workspace_bytes(M, N); ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
     if epilogue == "residual32":
-        fn = lambda: L.call("avlen_gemm_bf16", P(A), K, P(Wt), K, P(X), N, None, 0, P(b), P(X), N, M, N, K, 0, None, 0, L.stream())
+        fn = lambda: L.call("avlen_gemm_h16", P(A), K, P(Wt), K, P(X), N, None, 0, P(b), P(X), N, M, N, K, 0, FMT, None, 0, L.stream())
     else:
-        fn = lambda: L.call("avlen_gemm_bf16", P(A), K, P(Wt), K, None, 0, P(Y16), N, P(b), None, 0, M, N, K, act, None, 0, L.stream())
+        fn = lambda: L.call("avlen_gemm_h16", P(A), K, P(Wt), K, None, 0, P(Y16), N, P(b), None, 0, M, N, K, act, FMT, None, 0, L.stream())
     return fn, (A, Wt, b, X, Y16, ws)
 
 
