@@ -113,7 +113,8 @@ __global__ __launch_bounds__(256) void c16_x3_kernel(C16Args args) {
     const float* __restrict__ x = t.x + (long)b * 4096 * 16;
     const float* __restrict__ r = has_r ? t.r + (long)b * 4096 * 16 : nullptr;
     float* __restrict__ ao = t.a_out ? t.a_out + (long)b * 4096 * 16 : nullptr;
-    for (int i = tid; i < HROWS * 128; i += 256) {
+#pragma unroll
+    for (int i = tid; i < HROWS * 128; i += 256) {          // 5 rounds: every load of the halo in flight together
       const int hr = i >> 7, px = (i >> 1) & 63, ch = i & 1;
       const int iy = y0 - 1 + hr;
       uint2 h0 = make_uint2(0u, 0u), h1 = h0, l0 = h0, l1 = h0;
@@ -201,7 +202,44 @@ constexpr int SPLANE = (SROWS * SCOLS + 2) * 8;            // 4 channels x bf16 
 struct StemTower { const void* img; int u8; int C; float div; const bf16* wh; const bf16* wl; float* y; float* yst; };
 struct StemArgs { StemTower t[8]; const int* row_index; int S; };
 
-__global__ __launch_bounds__(256) void stem_x3_kernel(StemArgs args) {
+// The common sensor shapes (128 x 128 -> 64 x 64, rgb or depth): the K * C inputs of one source row of an output pixel are contiguous
+// and even in number -> vector loads, all of a pixel's loads in flight together.  Same arithmetic as the generic loop: each element
+// divided by `div`, summed in (dy, dx) order, scaled by 1 / K^2.
+template <int K, int C, typename T>
+__device__ __forceinline__ void stem_fill(const T* __restrict__ img, float div, float inv, char* halo, int y0, int tid) {
+  constexpr int S = 64 * K, E = K * C;
+  static_assert(E % 2 == 0 && C <= 4, "vector loads need an even span");
+  typedef __attribute__((ext_vector_type(2))) T T2;
+#pragma unroll 2
+  for (int i = tid; i < SROWS * SCOLS + 2; i += 256) {
+    const int hr = i / SCOLS, col = i - hr * SCOLS;
+    const int oy = y0 - 3 + hr, ox = col - 3;
+    uint2 h = make_uint2(0u, 0u), l = h;
+    if (hr < SROWS && oy >= 0 && oy < 64 && ox >= 0 && ox < 64) {
+      const T* p = img + ((long)oy * K * S + ox * K) * C;
+      T2 v[K][E / 2];
+#pragma unroll
+      for (int dy = 0; dy < K; dy++)
+#pragma unroll
+        for (int j = 0; j < E / 2; j++) v[dy][j] = *reinterpret_cast<const T2*>(p + (long)dy * S * C + 2 * j);
+      float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        float sm = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < K; dy++)
+#pragma unroll
+          for (int dx = 0; dx < K; dx++) { const int e = dx * C + c; sm += (float)v[dy][e >> 1][e & 1] / div; }
+        o[c] = sm * inv;
+      }
+      split4(o, h, l);
+    }
+    *reinterpret_cast<uint2*>(halo + i * 8) = h;
+    *reinterpret_cast<uint2*>(halo + SPLANE + i * 8) = l;
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void stem_x3_kernel(StemArgs args) {
   __shared__ __attribute__((aligned(16))) char halo[2 * SPLANE];
   __shared__ float bst[4][2][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, q = lane >> 4;
@@ -223,6 +261,10 @@ __global__ __launch_bounds__(256) void stem_x3_kernel(StemArgs args) {
     const int S = args.S, k = S / 64, C = t.C;
     const long bs = args.row_index ? args.row_index[b] : b;
     const float div = t.div, inv = 1.f / (float)(k * k);
+    if (k == 2 && C == 3 && t.u8) stem_fill<2, 3, unsigned char>((const unsigned char*)t.img + bs * S * S * 3, div, inv, halo, y0, tid);
+    else if (k == 2 && C == 3) stem_fill<2, 3, float>((const float*)t.img + bs * S * S * 3, div, inv, halo, y0, tid);
+    else if (k == 2 && C == 1 && !t.u8) stem_fill<2, 1, float>((const float*)t.img + bs * S * S, div, inv, halo, y0, tid);
+    else
     for (int i = tid; i < SROWS * SCOLS + 2; i += 256) {
       const int hr = i / SCOLS, col = i - hr * SCOLS;
       const int oy = y0 - 3 + hr, ox = col - 3;
@@ -251,10 +293,9 @@ __global__ __launch_bounds__(256) void stem_x3_kernel(StemArgs args) {
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   float* __restrict__ y = t.y + (long)b * 4096 * 16;
   const int base = ((2 * wave) * SCOLS + r16 + 2 * q) * 8;
-#pragma unroll
-  for (int rr = 0; rr < 2; rr++)
-#pragma unroll
-    for (int mt = 0; mt < 4; mt++) {
+#pragma unroll 1
+  for (int tile = 0; tile < 8; tile++) {                  // not unrolled: 8 x 28 hoisted LDS reads would spill
+      const int rr = tile >> 2, mt = tile & 3;
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ky = 0; ky < 7; ky++) {
@@ -286,6 +327,9 @@ __global__ __launch_bounds__(256) void stem_x3_kernel(StemArgs args) {
 // layers 2-4: one workgroup (512 threads) per image
 // ========================================================================================================================
 constexpr int RTH = 512;
+#ifndef AVLEN_X3_STAGGER
+#define AVLEN_X3_STAGGER 8       // s_sleep units (64 cycles) by which waves 4-7 enter a conv's tap loop late: their LDS read bursts then
+#endif                           // fall under the MFMA segments of their SIMD partners (waves 0-3) instead of colliding with them
 constexpr int R32 = 34, R64 = 18, R128 = 10;
 constexpr int PLANE = R32 * R32 * 64;                       // 73984 B: one plane of the largest frame; the later frames reuse the space
 constexpr int HALF16 = 34 * HCOLS * 32;                     // 71808 B: one plane of a half image of the 16-channel stage
@@ -298,7 +342,9 @@ static_assert(REST_LDS <= 160 * 1024, "tower x3 LDS budget");
 
 __device__ __forceinline__ int a32(int y, int p, int chunk) { return (y * R32 + p) * 64 + ((chunk ^ ((p >> 1) & 3)) << 4); }
 __device__ __forceinline__ int a64(int y, int p, int chunk) { return (y * R64 + p) * 128 + ((chunk ^ (p & 7)) << 4); }
-__device__ __forceinline__ int a128(int y, int p, int chunk) { return (y * R128 + p) * 256 + ((chunk ^ (p & 7)) << 4); }
+// 128 channels: a pixel is one 256-byte bank row; a ds_read_b128 lane group holds 8 lanes of each of two lane quarters (chunks
+// c, c + 1) on image rows y, y + 1 -- the row parity moves the slot into the other half, so the 16 lanes hit 16 different slots
+__device__ __forceinline__ int a128(int y, int p, int chunk) { return (y * R128 + p) * 256 + ((chunk ^ (p & 7) ^ ((y & 1) << 3)) << 4); }
 
 // GroupNorm index per stage: 0 downsample, 1 block 0 conv1 (stride 2), 2 block 0 conv2, 3 block 1 conv1, 4 block 1 conv2
 struct RestTower {
@@ -308,7 +354,12 @@ struct RestTower {
   const float* g[15]; const float* b[15];
   bf16* y;                                                                    // layer-4 output NHWC (B, 8, 8, 128) as a bf16 pair
 };
-struct RestArgs { RestTower t[8]; long y_lo; };                               // y_lo: elements from the hi plane to the lo plane
+struct RestArgs { RestTower t[8]; long y_lo; long long* prof; };              // y_lo: elements from the hi plane to the lo plane
+#ifdef AVLEN_X3_PROF            // tools/x3_lab.hip: phase timestamps of one thread of every workgroup
+#define X3_STAMP(k) do { if (args.prof && tid == AVLEN_X3_PROF) args.prof[(blockIdx.y * gridDim.x + blockIdx.x) * 32 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define X3_STAMP(k) do { } while (0)
+#endif
 
 __device__ __forceinline__ void stat_pair(const f32x4& v, float& g0, float& g1, float& h0, float& h1) {     // 32 channels: 2 per group
   g0 += v[0] + v[1]; g1 += v[2] + v[3];
@@ -386,6 +437,13 @@ __device__ __forceinline__ bf16x8 wfrag(const bf16* __restrict__ w, int ct, int 
   return *reinterpret_cast<const bf16x8*>(w + ((long)(ct * ksteps + i) * 64 + lane) * 8);
 }
 
+// The stride-1 convs below share one schedule.  Per tap: the weight fragments of the NEXT tap are requested first (two register
+// sets, the tap loop unrolled by two: no copies, no wait at the loop end), then the tap's tiles are processed in groups with the
+// LDS reads of group g + 1 in flight under the MFMAs of group g (sched_barrier pins "reads issued, then MFMAs": left alone the
+// scheduler issued two reads, waited, one MFMA).  Waves 4-7 enter the tap loop half a tap late (AVLEN_X3_STAGGER): their read
+// bursts fall under the MFMA segments of their SIMD partners instead of colliding with them.
+#define X3_PIN() __builtin_amdgcn_sched_barrier(0)
+
 // ---- 32 channels @ 32 x 32: wave owns rows oy(rr) = 16 (rr >> 1) + 2 wave + (rr & 1), both column tiles, both cout tiles
 __device__ __forceinline__ int row32(int wave, int rr) { return 16 * (rr >> 1) + 2 * wave + (rr & 1); }
 template <int MODE>
@@ -394,31 +452,43 @@ __device__ __forceinline__ void conv32(const bf16* __restrict__ wh, const bf16* 
   f32x4 acc[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  // [hi ct0, hi ct1, lo ct0, lo ct1] of the current tap; the next tap's fragments are in flight while this one is multiplied
-  // (the tap loop is NOT unrolled: unrolled, the scheduler hoists every tap's loads to the top and spills)
-  bf16x8 W[4], Wn[4];
-  auto loadw = [&](bf16x8 (&D)[4], int tap) {
+  auto loadw = [&](bf16x8 (&D)[4], int tap) {             // [hi ct0, hi ct1, lo ct0, lo ct1]
     D[0] = wfrag(wh, 0, 9, tap, lane); D[1] = wfrag(wh, 1, 9, tap, lane);
     D[2] = wfrag(wl, 0, 9, tap, lane); D[3] = wfrag(wl, 1, 9, tap, lane);
   };
-  loadw(W, 0);
-#pragma unroll 1
-  for (int tap = 0; tap < 9; tap++) {
-    loadw(Wn, tap + 1 < 9 ? tap + 1 : tap);
+  // group g = tile (rr = g >> 1, pt = g & 1): 2 reads, 6 MFMAs (64 + 64 accumulator / residual registers leave room for no more)
+  auto body = [&](const bf16x8 (&W)[4], int tap) {
     const int ky = tap / 3, kx = tap - ky * 3;
+    int ad[8];
 #pragma unroll
-    for (int rr = 0; rr < 4; rr++)
+    for (int g = 0; g < 8; g++) ad[g] = a32(row32(wave, g >> 1) + ky, (g & 1) * 16 + r16 + kx, q);
+    bf16x8 F[2][2];                                       // [set][hi, lo]
+    auto rd = [&](int g, bf16x8 (&D)[2]) {
+      D[0] = *reinterpret_cast<const bf16x8*>(lds + ad[g]); D[1] = *reinterpret_cast<const bf16x8*>(lds + PLANE + ad[g]);
+    };
+    auto mm = [&](int g, const bf16x8 (&D)[2]) {
+      acc[2 * g] = mma3(W[0], W[2], D[0], D[1], acc[2 * g]);
+      acc[2 * g + 1] = mma3(W[1], W[3], D[0], D[1], acc[2 * g + 1]);
+    };
+    rd(0, F[0]);
 #pragma unroll
-      for (int pt = 0; pt < 2; pt++) {
-        const int ad = a32(row32(wave, rr) + ky, pt * 16 + r16 + kx, q);
-        const bf16x8 xh = *reinterpret_cast<const bf16x8*>(lds + ad), xl = *reinterpret_cast<const bf16x8*>(lds + PLANE + ad);
-        const int ti = (rr * 2 + pt) * 2;
-        acc[ti] = mma3(W[0], W[2], xh, xl, acc[ti]);
-        acc[ti + 1] = mma3(W[1], W[3], xh, xl, acc[ti + 1]);
-      }
-#pragma unroll
-    for (int i = 0; i < 4; i++) W[i] = Wn[i];
+    for (int g = 0; g < 8; g++) {
+      if (g + 1 < 8) rd(g + 1, F[(g + 1) & 1]);
+      X3_PIN();
+      mm(g, F[g & 1]);
+    }
+  };
+  bf16x8 W0[4], W1[4];
+  loadw(W0, 0);
+  if (AVLEN_X3_STAGGER && wave >= 4) __builtin_amdgcn_s_sleep(AVLEN_X3_STAGGER);
+#pragma unroll 1
+  for (int t2 = 0; t2 < 8; t2 += 2) {
+    loadw(W1, t2 + 1); X3_PIN();
+    body(W0, t2);
+    loadw(W0, t2 + 2); X3_PIN();
+    body(W1, t2 + 1);
   }
+  body(W0, 8);
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < 16; i++) { const int ct = i & 1; stat_pair(acc[i], s1[ct * 2], s1[ct * 2 + 1], s2[ct * 2], s2[ct * 2 + 1]); }
@@ -444,27 +514,49 @@ __device__ __forceinline__ void conv64(const bf16* __restrict__ wh, const bf16* 
   f32x4 acc[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  bf16x8 W[4], Wn[4];                                     // [hi hf0, hi hf1, lo hf0, lo hf1]
-  auto loadw = [&](bf16x8 (&D)[4], int tap) {
+  auto loadw = [&](bf16x8 (&D)[4], int tap) {             // [hi hf0, hi hf1, lo hf0, lo hf1]
     D[0] = wfrag(wh, ct, 18, tap * 2, lane); D[1] = wfrag(wh, ct, 18, tap * 2 + 1, lane);
     D[2] = wfrag(wl, ct, 18, tap * 2, lane); D[3] = wfrag(wl, ct, 18, tap * 2 + 1, lane);
   };
-  loadw(W, 0);
-#pragma unroll 1
-  for (int tap = 0; tap < 9; tap++) {
-    loadw(Wn, tap + 1 < 9 ? tap + 1 : tap);
+  // group g = rows 2 g, 2 g + 1 (8 reads, 12 MFMAs)
+  auto body = [&](const bf16x8 (&W)[4], int tap) {
     const int ky = tap / 3, kx = tap - ky * 3;
+    const int ad0 = a64(half * 8 + ky, r16 + kx, q), ad1 = a64(half * 8 + ky, r16 + kx, 4 + q);      // + rr rows: the swizzle does not depend on the row
+    bf16x8 F[2][8];                                       // [set][row j: hf0 hi, hf0 lo, hf1 hi, hf1 lo]
+    auto rd = [&](int g, bf16x8 (&D)[8]) {
 #pragma unroll
-    for (int rr = 0; rr < 8; rr++)
-#pragma unroll
-      for (int hf = 0; hf < 2; hf++) {
-        const int ad = a64(half * 8 + rr + ky, r16 + kx, 4 * hf + q);
-        const bf16x8 xh = *reinterpret_cast<const bf16x8*>(lds + ad), xl = *reinterpret_cast<const bf16x8*>(lds + PLANE + ad);
-        acc[rr] = mma3(W[hf], W[2 + hf], xh, xl, acc[rr]);
+      for (int j = 0; j < 2; j++) {
+        const int o = (2 * g + j) * (R64 * 128);
+        D[4 * j] = *reinterpret_cast<const bf16x8*>(lds + ad0 + o); D[4 * j + 1] = *reinterpret_cast<const bf16x8*>(lds + PLANE + ad0 + o);
+        D[4 * j + 2] = *reinterpret_cast<const bf16x8*>(lds + ad1 + o); D[4 * j + 3] = *reinterpret_cast<const bf16x8*>(lds + PLANE + ad1 + o);
       }
+    };
+    auto mm = [&](int g, const bf16x8 (&D)[8]) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) W[i] = Wn[i];
+      for (int j = 0; j < 2; j++) {
+        acc[2 * g + j] = mma3(W[0], W[2], D[4 * j], D[4 * j + 1], acc[2 * g + j]);
+        acc[2 * g + j] = mma3(W[1], W[3], D[4 * j + 2], D[4 * j + 3], acc[2 * g + j]);
+      }
+    };
+    rd(0, F[0]);
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      if (g + 1 < 4) rd(g + 1, F[(g + 1) & 1]);
+      X3_PIN();
+      mm(g, F[g & 1]);
+    }
+  };
+  bf16x8 W0[4], W1[4];
+  loadw(W0, 0);
+  if (AVLEN_X3_STAGGER && wave >= 4) __builtin_amdgcn_s_sleep(AVLEN_X3_STAGGER);
+#pragma unroll 1
+  for (int t2 = 0; t2 < 8; t2 += 2) {
+    loadw(W1, t2 + 1); X3_PIN();
+    body(W0, t2);
+    loadw(W0, t2 + 2); X3_PIN();
+    body(W1, t2 + 1);
   }
+  body(W0, 8);
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int rr = 0; rr < 8; rr++) stat_quad(acc[rr], s1, s2);
@@ -484,27 +576,47 @@ __device__ __forceinline__ void conv128(const bf16* __restrict__ wh, const bf16*
   f32x4 acc[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  bf16x8 W[8], Wn[8];                                     // [hi j0..3, lo j0..3]
-  auto loadw = [&](bf16x8 (&D)[8], int tap) {
+  auto loadw = [&](bf16x8 (&D)[8], int tap) {             // [hi j0..3, lo j0..3]
 #pragma unroll
     for (int j = 0; j < 4; j++) { D[j] = wfrag(wh, ct, 36, tap * 4 + j, lane); D[4 + j] = wfrag(wl, ct, 36, tap * 4 + j, lane); }
   };
-  loadw(W, 0);
-#pragma unroll 1
-  for (int tap = 0; tap < 9; tap++) {
-    loadw(Wn, tap + 1 < 9 ? tap + 1 : tap);
+  // group g = column tile pt = g (8 reads, 12 MFMAs); + 2 rows per tile: the row parity (the swizzle's top bit) does not change
+  auto body = [&](const bf16x8 (&W)[8], int tap) {
     const int ky = tap / 3, kx = tap - ky * 3;
+    int ad[4];
 #pragma unroll
-    for (int pt = 0; pt < 4; pt++)
+    for (int j = 0; j < 4; j++) ad[j] = a128(ly + ky, lx + kx, 4 * j + q);
+    bf16x8 F[2][8];                                       // [set][j hi x4, j lo x4]
+    auto rd = [&](int g, bf16x8 (&D)[8]) {
+      const int o = 2 * g * (R128 * 256);
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const int ad = a128(2 * pt + ly + ky, lx + kx, 4 * j + q);
-        const bf16x8 xh = *reinterpret_cast<const bf16x8*>(lds + ad), xl = *reinterpret_cast<const bf16x8*>(lds + PLANE + ad);
-        acc[pt] = mma3(W[j], W[4 + j], xh, xl, acc[pt]);
+        D[j] = *reinterpret_cast<const bf16x8*>(lds + ad[j] + o); D[4 + j] = *reinterpret_cast<const bf16x8*>(lds + PLANE + ad[j] + o);
       }
+    };
+    auto mm = [&](int g, const bf16x8 (&D)[8]) {
 #pragma unroll
-    for (int i = 0; i < 8; i++) W[i] = Wn[i];
+      for (int j = 0; j < 4; j++) acc[g] = mma3(W[j], W[4 + j], D[j], D[4 + j], acc[g]);
+    };
+    rd(0, F[0]);
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      if (g + 1 < 4) rd(g + 1, F[(g + 1) & 1]);
+      X3_PIN();
+      mm(g, F[g & 1]);
+    }
+  };
+  bf16x8 W0[8], W1[8];
+  loadw(W0, 0);
+  if (AVLEN_X3_STAGGER && wave >= 4) __builtin_amdgcn_s_sleep(AVLEN_X3_STAGGER);
+#pragma unroll 1
+  for (int t2 = 0; t2 < 8; t2 += 2) {
+    loadw(W1, t2 + 1); X3_PIN();
+    body(W0, t2);
+    loadw(W0, t2 + 2); X3_PIN();
+    body(W1, t2 + 1);
   }
+  body(W0, 8);
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int pt = 0; pt < 4; pt++) stat_quad(acc[pt], s1, s2);
@@ -550,6 +662,7 @@ __global__ __launch_bounds__(RTH) void rest_x3_kernel(RestArgs args) {
     reinterpret_cast<float*>(lds + XCOEF_OFF)[tid] = sc; reinterpret_cast<float*>(lds + XCOEF_OFF)[128 + tid] = sh;
   }
   lds_barrier();
+  X3_STAMP(0);
 
   // =========================================================== layer 2 entry ===========================================================
   // in = relu(GN(x) + r) (64 x 64 x 16) read in two half-image passes; 3x3 stride-2 conv 16 -> 32 and the 1x1 stride-2 downsample.
@@ -582,6 +695,7 @@ __global__ __launch_bounds__(RTH) void rest_x3_kernel(RestArgs args) {
 #pragma unroll
     for (int h = 0; h < 2; h++) {
       // frame row fr <-> image row 32 h - 1 + fr, fr = 0 .. 32; frame column = image column + 1
+#pragma unroll 3
       for (int i = tid; i < 33 * 128; i += RTH) {
         const int fr = i >> 7, px = (i >> 1) & 63, ch = i & 1;
         const int iy = 32 * h - 1 + fr;
@@ -607,6 +721,7 @@ __global__ __launch_bounds__(RTH) void rest_x3_kernel(RestArgs args) {
         *reinterpret_cast<uint4*>(lds + PLANE + ad) = make_uint4(0u, 0u, 0u, 0u);
       }
       lds_barrier();
+      X3_STAMP(1 + 2 * h);
       const int rdD = h16(4 * wave + 1, 2 * r16 + 1, q & 1);
 #pragma unroll
       for (int j = 0; j < 2; j++)
@@ -638,6 +753,7 @@ __global__ __launch_bounds__(RTH) void rest_x3_kernel(RestArgs args) {
           }
       }
       lds_barrier();                                      // every wave is done with this half before it is overwritten
+      X3_STAMP(2 + 2 * h);
     }
   }
   {
@@ -665,9 +781,13 @@ __global__ __launch_bounds__(RTH) void rest_x3_kernel(RestArgs args) {
     zero_frame<32>(lds, tid);
   }
   lds_barrier();
+  X3_STAMP(5);
   conv32<1>(t.wh[2], t.wl[2], 128, lds, res2, tid, wave, lane, r16, q);                // block 0 conv2 + skip
+  X3_STAMP(6);
   conv32<0>(t.wh[3], t.wl[3], 192, lds, res2, tid, wave, lane, r16, q);                // block 1 conv1
+  X3_STAMP(7);
   conv32<1>(t.wh[4], t.wl[4], 256, lds, res2, tid, wave, lane, r16, q);                // block 1 conv2 + identity
+  X3_STAMP(8);
 
   // =========================================================== layer 3 ===========================================================
   f32x4 res3[8];
@@ -682,19 +802,28 @@ __global__ __launch_bounds__(RTH) void rest_x3_kernel(RestArgs args) {
                       (f32x4){0.f, 0.f, 0.f, 0.f});
       raw3[rr] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    bf16x8 Wh = wfrag(t.wh[6], ct, 9, 0, lane), Wl = wfrag(t.wl[6], ct, 9, 0, lane);
-#pragma unroll 1
-    for (int tap = 0; tap < 9; tap++) {
-      const int nt = tap + 1 < 9 ? tap + 1 : tap;
-      const bf16x8 Nh = wfrag(t.wh[6], ct, 9, nt, lane), Nl = wfrag(t.wl[6], ct, 9, nt, lane);
+    auto body3 = [&](const bf16x8& Wh, const bf16x8& Wl, int tap) {
       const int ky = tap / 3, kx = tap - ky * 3;
+      const int ad = a32(2 * (half * 8) + ky, 2 * r16 + kx, q);               // + 2 rr rows: the swizzle does not depend on the row
+      bf16x8 F[8][2];
 #pragma unroll
       for (int rr = 0; rr < 8; rr++) {
-        const int ad = a32(2 * (half * 8 + rr) + ky, 2 * r16 + kx, q);
-        raw3[rr] = mma3(Wh, Wl, *reinterpret_cast<const bf16x8*>(lds + ad), *reinterpret_cast<const bf16x8*>(lds + PLANE + ad), raw3[rr]);
+        F[rr][0] = *reinterpret_cast<const bf16x8*>(lds + ad + 2 * rr * (R32 * 64));
+        F[rr][1] = *reinterpret_cast<const bf16x8*>(lds + PLANE + ad + 2 * rr * (R32 * 64));
       }
-      Wh = Nh; Wl = Nl;
+      X3_PIN();
+#pragma unroll
+      for (int rr = 0; rr < 8; rr++) raw3[rr] = mma3(Wh, Wl, F[rr][0], F[rr][1], raw3[rr]);
+    };
+    bf16x8 W0h = wfrag(t.wh[6], ct, 9, 0, lane), W0l = wfrag(t.wl[6], ct, 9, 0, lane), W1h, W1l;
+#pragma unroll 1
+    for (int t2 = 0; t2 < 8; t2 += 2) {
+      W1h = wfrag(t.wh[6], ct, 9, t2 + 1, lane); W1l = wfrag(t.wl[6], ct, 9, t2 + 1, lane); X3_PIN();
+      body3(W0h, W0l, t2);
+      W0h = wfrag(t.wh[6], ct, 9, t2 + 2, lane); W0l = wfrag(t.wl[6], ct, 9, t2 + 2, lane); X3_PIN();
+      body3(W1h, W1l, t2 + 1);
     }
+    body3(W0h, W0l, 8);
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int rr = 0; rr < 8; rr++) stat_quad(res3[rr], s1, s2);
@@ -713,9 +842,13 @@ __global__ __launch_bounds__(RTH) void rest_x3_kernel(RestArgs args) {
     zero_frame<64>(lds, tid);
   }
   lds_barrier();
+  X3_STAMP(9);
   conv64<1>(t.wh[7], t.wl[7], 320 + 256, lds, res3, tid, wave, lane, r16, q);
+  X3_STAMP(10);
   conv64<0>(t.wh[8], t.wl[8], 320 + 384, lds, res3, tid, wave, lane, r16, q);
+  X3_STAMP(11);
   conv64<1>(t.wh[9], t.wl[9], 320 + 512, lds, res3, tid, wave, lane, r16, q);
+  X3_STAMP(12);
 
   // =========================================================== layer 4 ===========================================================
   f32x4 res4[4];
@@ -736,26 +869,37 @@ __global__ __launch_bounds__(RTH) void rest_x3_kernel(RestArgs args) {
       res4[pt] = v;
       raw4[pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    bf16x8 W[4], Wn[4];
     auto loadw = [&](bf16x8 (&D)[4], int tap) {
 #pragma unroll
       for (int hf = 0; hf < 2; hf++) { D[hf] = wfrag(t.wh[11], ct, 18, tap * 2 + hf, lane); D[2 + hf] = wfrag(t.wl[11], ct, 18, tap * 2 + hf, lane); }
     };
-    loadw(W, 0);
-#pragma unroll 1
-    for (int tap = 0; tap < 9; tap++) {
-      loadw(Wn, tap + 1 < 9 ? tap + 1 : tap);
+    auto body4 = [&](const bf16x8 (&W)[4], int tap) {
       const int ky = tap / 3, kx = tap - ky * 3;
+      const int ad0 = a64(2 * ly + ky, 2 * lx + kx, q), ad1 = a64(2 * ly + ky, 2 * lx + kx, 4 + q);
+      bf16x8 F[4][4];
 #pragma unroll
-      for (int pt = 0; pt < 4; pt++)
+      for (int pt = 0; pt < 4; pt++) {
+        const int o = 4 * pt * (R64 * 128);
+        F[pt][0] = *reinterpret_cast<const bf16x8*>(lds + ad0 + o); F[pt][1] = *reinterpret_cast<const bf16x8*>(lds + PLANE + ad0 + o);
+        F[pt][2] = *reinterpret_cast<const bf16x8*>(lds + ad1 + o); F[pt][3] = *reinterpret_cast<const bf16x8*>(lds + PLANE + ad1 + o);
+      }
+      X3_PIN();
 #pragma unroll
-        for (int hf = 0; hf < 2; hf++) {
-          const int ad = a64(2 * (2 * pt + ly) + ky, 2 * lx + kx, 4 * hf + q);
-          raw4[pt] = mma3(W[hf], W[2 + hf], *reinterpret_cast<const bf16x8*>(lds + ad), *reinterpret_cast<const bf16x8*>(lds + PLANE + ad), raw4[pt]);
-        }
-#pragma unroll
-      for (int i = 0; i < 4; i++) W[i] = Wn[i];
+      for (int pt = 0; pt < 4; pt++) {
+        raw4[pt] = mma3(W[0], W[2], F[pt][0], F[pt][1], raw4[pt]);
+        raw4[pt] = mma3(W[1], W[3], F[pt][2], F[pt][3], raw4[pt]);
+      }
+    };
+    bf16x8 W0[4], W1[4];
+    loadw(W0, 0);
+#pragma unroll 1
+    for (int t2 = 0; t2 < 8; t2 += 2) {
+      loadw(W1, t2 + 1); X3_PIN();
+      body4(W0, t2);
+      loadw(W0, t2 + 2); X3_PIN();
+      body4(W1, t2 + 1);
     }
+    body4(W0, 8);
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int pt = 0; pt < 4; pt++) stat_quad(res4[pt], s1, s2);
@@ -774,9 +918,13 @@ __global__ __launch_bounds__(RTH) void rest_x3_kernel(RestArgs args) {
     zero_frame<128>(lds, tid);
   }
   lds_barrier();
+  X3_STAMP(13);
   conv128<1>(t.wh[12], t.wl[12], 960 + 512, lds, res4, tid, wave, lane, r16, q);
+  X3_STAMP(14);
   conv128<0>(t.wh[13], t.wl[13], 960 + 768, lds, res4, tid, wave, lane, r16, q);
+  X3_STAMP(15);
   conv128<1>(t.wh[14], t.wl[14], 960 + 1024, lds, res4, tid, wave, lane, r16, q);
+  X3_STAMP(16);
   // ---- layer-4 output (post ReLU) = the residual registers of the last block: NHWC fp32 (8, 8, 128)
   {
     const int ly = r16 >> 3, lx = r16 & 7;

@@ -6,7 +6,7 @@ import torch
 from avlen_amd.harness import Workload
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-wl = Workload(N, 150, spectrogram=(257, 101, 2), precision="bf16", pretraining=True)
+wl = Workload(N, 150, spectrogram=(257, 101, 2), precision=os.environ.get("AVLEN_PREC", "bf16x3"), pretraining=True)
 for _ in range(20):
     wl.rollout_step()
 torch.cuda.synchronize()
