@@ -36,15 +36,36 @@ class _CopyAxis:
         return (m.shape[0], self._em.num_copies, m.shape[1], m.shape[2])
 
 
+class _RingTensor(torch.Tensor):
+    """The (total, N, dim) ring of an eval-time `ExternalMemory(num_copies=1)`.  The reference keeps (total, copies, N, dim) and
+    its eval loop reads `test_em.memory[:, 0]` (ppo_trainer.py:1912-1959): that exact index pattern -- (all slots, an int copy) --
+    returns the whole ring here (every copy is identical by construction, rollout_storage.py:924-933); anything else is ordinary
+    tensor indexing."""
+
+    @staticmethod
+    def __new__(cls, t):
+        return torch.Tensor._make_subclass(cls, t)
+
+    def __getitem__(self, idx):
+        if isinstance(idx, tuple) and len(idx) == 2 and isinstance(idx[0], slice) and idx[0] == slice(None) and isinstance(idx[1], int):
+            return self.as_subclass(torch.Tensor)
+        return super().__getitem__(idx)
+
+
 class ExternalMemory:
     def __init__(self, num_envs, total_size, capacity, dim, num_copies=1, num_steps=150, device="cpu"):
         self.num_envs, self.total_size, self.capacity, self.dim = num_envs, total_size, capacity, dim
         self.num_copies, self.num_steps = num_copies, num_steps
         self.masks = torch.zeros(num_envs, total_size, device=device)
-        self.memory = torch.zeros(total_size, num_envs, dim, device=device)
+        self.memory = self._wrap(torch.zeros(total_size, num_envs, dim, device=device))
         self.idx = 0
         self.env_id = 0
         self._masks_replay = None                      # (num_steps, N, total): allocated by the first insert_replay
+
+    def _wrap(self, t):
+        # the trainer's own eval-time objects (num_copies=1) answer `memory[:, 0]` like the reference's 4-D tensor; the rollout
+        # storage's rings (num_copies = T + 1, reached through RolloutStorage.external_memory_*[:, step]) stay plain tensors
+        return _RingTensor(t) if self.num_copies == 1 else t
 
     @property
     def masks_replay(self):
@@ -59,16 +80,18 @@ class ExternalMemory:
         mr[:, self.env_id, :] = 0.0
         k = em_features.size(0)
         self.memory[:k, self.env_id, :].copy_(em_features)
-        for i in range(1, self.num_steps):
-            mr[i, self.env_id, :i] = 1.0
+        # step i sees slots 0..i-1: a strictly lower-triangular (num_steps, total) pattern, written in one op
+        tri = torch.ones(self.num_steps, self.total_size, device=mr.device).tril(-1)
+        mr[:, self.env_id, :] = tri
         self.env_id = (self.env_id + 1) % self.num_envs
 
     def pop_at(self, idx):
         """rollout_storage.py:954-956 (eval: an environment is paused, base_trainer.py:186-289): drop column `idx`."""
         keep = [i for i in range(self.masks.shape[0]) if i != idx]
         self.masks = self.masks[keep].contiguous()
-        self.memory = self.memory[:, keep].contiguous()
+        self.memory = self._wrap(self.memory.as_subclass(torch.Tensor)[:, keep].contiguous())
         self.num_envs = len(keep)                      # the insert kernel sizes its grid by it
+        self._masks_replay = None                      # sized for the old environment count (ADVICE r2)
 
     def insert(self, em_features, not_done_masks, masks_out=None):
         f = em_features if em_features.is_contiguous() else em_features.contiguous()
@@ -92,7 +115,7 @@ class ExternalMemory:
         return f, nd
 
     def to(self, device):
-        self.masks, self.memory = self.masks.to(device), self.memory.to(device)
+        self.masks, self.memory = self.masks.to(device), self._wrap(self.memory.as_subclass(torch.Tensor).to(device))
         if self._masks_replay is not None:
             self._masks_replay = self._masks_replay.to(device)
 
