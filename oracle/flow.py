@@ -187,7 +187,7 @@ def clip_text_spec(width=512, layers=12, ctx=77, vocab=49408, out=512, prefix="n
     return s
 
 
-def cpu_baseline(specs, N=16, T=4, spectrogram=(257, 101), pretraining=True, em_size=300, threads=None):
+def cpu_baseline(specs, N=16, T=4, spectrogram=(257, 101), pretraining=True, em_size=300, threads=None, mini_batches=2):
     """Time ONE bounded rollout(T steps, 3 policies incl. CLIP text) + pi_q update (2 epochs x 2 minibatches)
     of the oracle on the host cores.  Returns (env_steps_per_second, seconds, threads)."""
     import time
@@ -209,7 +209,7 @@ def cpu_baseline(specs, N=16, T=4, spectrogram=(257, 101), pretraining=True, em_
     sl = with_audio(specs["dialog"])
     sl.update(clip_text_spec())
     sd_l = mk(sl)
-    agent = OptionAgent(sd_q, pretraining=pretraining)
+    agent = OptionAgent(sd_q, pretraining=pretraining, mini_batches=mini_batches)
     obs0 = fx.observations("cpu.obs0", N, spectrogram)
     st = Storage(T, N, obs0, em_size, em_size // 2)
     pe = sinus_pe(1000)
