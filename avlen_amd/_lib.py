@@ -255,7 +255,12 @@ def multi_copy(pairs):
             if src.data_ptr() != dst.data_ptr() and src.numel():
                 batch.append((dst, src))
         else:
-            dst.copy_(src if torch.is_tensor(src) else torch.as_tensor(src), non_blocking=True)
+            src = src if torch.is_tensor(src) else torch.as_tensor(src)
+            if dst.dtype == torch.uint8 and src.is_floating_point():
+                # a float frame going into uint8 storage (RolloutStorage(uint8_sensors=...)): round to nearest and saturate -- a plain
+                # cast truncates fractions and wraps values outside 0..255 (e.g. an augmented or 0..1-normalised image)
+                src = src.round().clamp_(0, 255)
+            dst.copy_(src, non_blocking=True)
     if not batch:
         return
     n = len(batch)

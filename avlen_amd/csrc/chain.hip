@@ -416,12 +416,9 @@ int avlen_chain_run(const avlen_chain* prog, int B, hipStream_t stream, int x3) 
       if (o.k % 8 || o.k > KMAX || o.ld % 8 || (x3 && !o.p1)) return AVLEN_ERR_ARG;
     }
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    attr_set = true;
-  }
+  static unsigned long long done0 = 0, done1 = 0;
+  if (avlen_set_dyn_lds(reinterpret_cast<const void*>(&chain_kernel<false>), LDS_BYTES, &done0) != AVLEN_OK ||
+      avlen_set_dyn_lds(reinterpret_cast<const void*>(&chain_kernel<true>), LDS_BYTES, &done1) != AVLEN_OK) return AVLEN_ERR_LAUNCH;
   if (x3) hipLaunchKernelGGL(chain_kernel<true>, dim3(ceil_div(B, 8)), dim3(NTH), LDS_BYTES, stream, dp, B);
   else hipLaunchKernelGGL(chain_kernel<false>, dim3(ceil_div(B, 16)), dim3(NTH), LDS_BYTES, stream, dp, B);
   return avlen_launch_status();

@@ -26,6 +26,17 @@ static inline long avlen_knob(const char* name, long dflt) { const char* e = get
 #endif
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): `done` is the call site's own static bit mask.
+// Returns AVLEN_OK or AVLEN_ERR_LAUNCH (a process may drive several devices; the attribute is per device).
+static inline int avlen_set_dyn_lds(const void* fn, int bytes, unsigned long long* done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return AVLEN_ERR_LAUNCH;
+  if (*done & (1ull << dev)) return AVLEN_OK;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return AVLEN_ERR_LAUNCH;
+  *done |= 1ull << dev;
+  return AVLEN_OK;
+}
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // bump allocator over a caller-provided workspace (never allocates device memory itself)

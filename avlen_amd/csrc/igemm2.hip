@@ -610,12 +610,9 @@ __global__ __launch_bounds__(256) void ln_fold_kernel(const float* __restrict__ 
 template <int BM, int BN, int WM, int WN, int NS, int NTH, bool CONV, bool F16 = false>
 int launch_cv(const G2& p, int m_tiles, int n_tiles, hipStream_t st) {
   size_t lds = (size_t)NS * (BM * 128 + (BN * 8 >= NTH ? BN * 128 : NTH * 16));
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&g2_kernel<BM, BN, WM, WN, NS, NTH, CONV, F16>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static unsigned long long attr_done = 0;
+  if (avlen_set_dyn_lds(reinterpret_cast<const void*>(&g2_kernel<BM, BN, WM, WN, NS, NTH, CONV, F16>), (int)lds, &attr_done) != AVLEN_OK)
+    return AVLEN_ERR_LAUNCH;
   hipLaunchKernelGGL((g2_kernel<BM, BN, WM, WN, NS, NTH, CONV, F16>), dim3(m_tiles * n_tiles, p.groups, p.splitk), dim3(NTH), lds, st, p);
   return avlen_launch_status();
 }

@@ -1838,24 +1838,37 @@ extern "C" size_t avlen_linear_bwd_workspace_bytes(void) { return GEMM_SCRATCH; 
 
 // action_encoder = Linear(one_hot(prev_action)) (policy.py:662-667): gw[j][a] += sum_{b: a_b = a} d[b][j], gb[j] += sum_b d[b][j]
 namespace {
-__global__ void action_encoder_bwd_kernel(const float* __restrict__ d, int ld, const int64_t* __restrict__ prev_actions,
-                                          float* __restrict__ gw, float* __restrict__ gb, int B, int n_out, int n_act) {
-  const int j = threadIdx.x;                      // one block, n_out threads: deterministic
-  if (j >= n_out) return;
-  float sb = 0.f;
-  for (int b = 0; b < B; b++) {
+// One block per output feature j: the rows are split over the block's 256 threads, each keeps per-action partial sums in
+// registers (n_act <= 8), a fixed-order LDS reduction combines them (deterministic), one write per (j, action).
+__global__ __launch_bounds__(256) void action_encoder_bwd_kernel(const float* __restrict__ d, int ld, const int64_t* __restrict__ prev_actions,
+                                                                 float* __restrict__ gw, float* __restrict__ gb, int B, int n_out, int n_act) {
+  __shared__ float red[256][9];
+  const int j = blockIdx.x, t = threadIdx.x;
+  float acc[9];
+#pragma unroll
+  for (int a = 0; a < 9; a++) acc[a] = 0.f;
+  for (int b = t; b < B; b += 256) {
     const float v = d[(long)b * ld + j];
     const long a = prev_actions[b];
-    sb += v;
-    if (a >= 0 && a < n_act) gw[(long)j * n_act + a] += v;
+    acc[8] += v;
+#pragma unroll
+    for (int k = 0; k < 8; k++) if (a == k) acc[k] += v;
   }
-  gb[j] += sb;
+#pragma unroll
+  for (int a = 0; a < 9; a++) red[t][a] = acc[a];
+  __syncthreads();
+  if (t < 9) {
+    float s = 0.f;
+    for (int i = 0; i < 256; i++) s += red[i][t];
+    if (t == 8) gb[j] += s;
+    else if (t < n_act) gw[(long)j * n_act + t] += s;
+  }
 }
 }  // namespace
 extern "C" int avlen_action_encoder_bwd(const float* d_feats, int ld, const int64_t* prev_actions, const avlen_linear* G, int B,
                                         hipStream_t st) {
-  if (!d_feats || !prev_actions || !G || B <= 0 || G->out_f > 256) return AVLEN_ERR_ARG;
-  hipLaunchKernelGGL(action_encoder_bwd_kernel, dim3(1), dim3(256), 0, st, d_feats, ld, prev_actions, G->w, G->b, B, G->out_f, G->in_f);
+  if (!d_feats || !prev_actions || !G || B <= 0 || G->out_f > 256 || G->in_f > 8) return AVLEN_ERR_ARG;
+  hipLaunchKernelGGL(action_encoder_bwd_kernel, dim3(G->out_f), dim3(256), 0, st, d_feats, ld, prev_actions, G->w, G->b, B, G->out_f, G->in_f);
   return avlen_launch_status();
 }
 

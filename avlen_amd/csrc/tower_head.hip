@@ -552,11 +552,8 @@ int avlen_tower_head_bf16(const avlen_resnet18* const* nets, const void* const* 
     t.w[8] = (const bf16*)b3.conv1.w16f; t.g[8] = b3.bn1.g; t.b[8] = b3.bn1.b;
     t.w[9] = (const bf16*)b3.conv2.w16f; t.g[9] = b3.bn2.g; t.b[9] = b3.bn2.b;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, HEAD_LDS);
-    attr_set = true;
-  }
+  static unsigned long long attr_done = 0;
+  if (avlen_set_dyn_lds(reinterpret_cast<const void*>(&tower_head_kernel), HEAD_LDS, &attr_done) != AVLEN_OK) return AVLEN_ERR_LAUNCH;
   hipLaunchKernelGGL(tower_head_kernel, dim3(B, groups), dim3(HTH), HEAD_LDS, stream, a, B);
   return avlen_launch_status();
 }

@@ -405,11 +405,8 @@ int avlen_tower_tail_bf16(const avlen_resnet18* const* nets, const void* const* 
       t.w[o + 4] = (const bf16*)b1.conv2.w16f; t.g[o + 4] = b1.bn2.g; t.b[o + 4] = b1.bn2.b;
     }
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS);
-    attr_set = true;
-  }
+  static unsigned long long attr_done = 0;
+  if (avlen_set_dyn_lds(reinterpret_cast<const void*>(&tower_tail_kernel), TAIL_LDS, &attr_done) != AVLEN_OK) return AVLEN_ERR_LAUNCH;
   hipLaunchKernelGGL(tower_tail_kernel, dim3(B, groups), dim3(TTH), TAIL_LDS, stream, a, B);
   return avlen_launch_status();
 }

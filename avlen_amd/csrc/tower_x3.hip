@@ -1045,11 +1045,8 @@ int avlen_tower_x3_fwd(const avlen_resnet18* const* nets, const void* const* img
         t.g[o + 3] = b1.bn1.g; t.b[o + 3] = b1.bn1.b; t.g[o + 4] = b1.bn2.g; t.b[o + 4] = b1.bn2.b;
       }
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rest_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, REST_LDS);
-      attr_set = true;
-    }
+    static unsigned long long attr_done = 0;
+    if (avlen_set_dyn_lds(reinterpret_cast<const void*>(&rest_x3_kernel), REST_LDS, &attr_done) != AVLEN_OK) return AVLEN_ERR_LAUNCH;
     hipLaunchKernelGGL(rest_x3_kernel, dim3(B, groups), dim3(RTH), REST_LDS, stream, a);
   }
   return avlen_launch_status();

@@ -284,8 +284,10 @@ def _graphed(pol, which, fn, args, mode=None):
             mm.dsts = (C.c_void_p * max(mm.n, 1))(*[d_.data_ptr() for d_, _ in pairs])
             mm.sizes = (C.c_int64 * max(mm.n, 1))(*[d_.numel() * d_.element_size() for d_, _ in pairs])
             mm.lead_static = grp.static_obs if mode == "follow" else None
-            if len(pol._memos) >= 1024:
-                pol._memos.clear()
+            # bounded: a caller that presents freshly allocated observation tensors every step (eval: batch_obs) would otherwise
+            # add one memo per distinct address tuple for ever; the oldest entries go first (dicts keep insertion order)
+            while len(pol._memos) >= 512:
+                pol._memos.pop(next(iter(pol._memos)))
             pol._memos[mk] = mm
     outs, heads = g(args)
     outs = list(outs)

@@ -160,7 +160,7 @@ class PPO(nn.Module):
         T, N = rollouts.step, rollouts.num_envs
         R = T * N
         (obs, _h, _actions, prev_actions, _, _, _masks, _, _, _em_vln, _em_dlg, _em_masks, em_vln_masks, all_dialog, agent_step,
-         _, _) = rollouts.dialog_batching()
+         _, _) = rollouts.dialog_batching(memories=False)
         eng = pol._engine()
         flat = eng["flat"]
         g = pol.grad_views(eng)

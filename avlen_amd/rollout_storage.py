@@ -325,13 +325,15 @@ class RolloutStorage:
         self.env_id = e + 1
         self.step = T
 
-    def dialog_batching(self):
+    def dialog_batching(self, memories=True):
         """rollout_storage.py:414-588: every environment, steps [0, step), flattened T-major -- the 17-tuple `PPO.update_dialog`
-        consumes.  The memories come out as the reference's (em_size, T*N, dim) tensors (every copy of a ring is identical)."""
+        consumes.  The memories come out as the reference's (em_size, T*N, dim) tensors (every copy of a ring is identical);
+        memories=False leaves their three slots None (avlen_amd's own update_dialog reads the rings in place through a row index:
+        at N = 64, T = 150 the expanded copies are ~12 GB of transient traffic nobody reads)."""
         T, N = self.step, self.num_envs
         fl = lambda x: x[:T].reshape((T * N,) + tuple(x.shape[2:]))
         mem = lambda em: (em.memory.unsqueeze(1).expand(-1, T, -1, -1).reshape(em.total_size, T * N, em.dim)
-                          if em is not None else None)
+                          if (em is not None and memories) else None)
         obs = defaultdict(list)
         for k, v in self.observations.items():
             obs[k] = fl(v)
