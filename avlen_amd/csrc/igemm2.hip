@@ -47,6 +47,10 @@ struct G2 {
   // with (sum, sum of squares) of row m in ln_stats[m][2] and mean/rstd over K columns; NULL -> plain epilogue
   const float* ln_stats; const float* ln_s;
   float* rowstats;            // optional output: rowstats[m][2] += (sum, sum of squares) of the final C row (N-tile partials)
+  // Deterministic form of the two fields above: rs_slabs != 0 -> every N tile STORES its partial at
+  // rowstats[(n_tile * M_alloc + m) * 2] (no atomics, nothing to zero); ln_slabs = s > 1 -> ln_stats holds s such slabs, added
+  // in slab order by the consumer
+  int rs_slabs, ln_slabs;
   float* slab;
   const int* M_dev;           // optional: the live row count (<= M) is read from device memory (ragged batches)
   float* stats; int ohw;      // optional GroupNorm statistics: stats[sample][0|1][N] += sum / sum of squares of C
@@ -355,6 +359,8 @@ __global__ __launch_bounds__(NTH) void g2_kernel(G2 pp) {
     for (int i = 0; i < MI; i++) {
       int row = m0 + wm * WTM + i * 16 + r16;
       float2 st = row < p.M ? *reinterpret_cast<const float2*>(p.ln_stats + (long)row * 2) : make_float2(0.f, 0.f);
+      for (int sl = 1; sl < p.ln_slabs; sl++)
+        if (row < p.M) { const float2 t2 = *reinterpret_cast<const float2*>(p.ln_stats + ((long)sl * M_alloc + row) * 2); st.x += t2.x; st.y += t2.y; }
       const float mean = st.x * inv_k;
       const float rstd = rsqrtf(fmaxf(st.y * inv_k - mean * mean, 0.f) + 1e-5f);
 #pragma unroll
@@ -460,7 +466,8 @@ __global__ __launch_bounds__(NTH) void g2_kernel(G2 pp) {
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < WN; w++) v += rs[(lr * WN + w) * 2 + which];
-        atomicAdd(&p.rowstats[(long)row * 2 + which], v);
+        if (p.rs_slabs) p.rowstats[((long)(n0 / BN) * M_alloc + row) * 2 + which] = v;
+        else atomicAdd(&p.rowstats[(long)row * 2 + which], v);
       }
     }
   }
@@ -650,6 +657,7 @@ bool aligned_to(const void* q, size_t a) { return ((uintptr_t)q & (a - 1)) == 0;
 void apply_opts(G2& p, const avlen_g2_opts* o) {
   if (!o) return;
   p.f16 = o->f16; p.x3 = o->x3; p.a_lo = o->a_lo; p.b_lo = o->b_lo; p.c16_lo = o->c16_lo;
+  p.rs_slabs = o->rs_slabs; p.ln_slabs = o->ln_slabs;
 }
 
 int run_g2(G2 p, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -697,6 +705,7 @@ int run_g2(G2 p, void* ws, size_t ws_bytes, hipStream_t st) {
   if (nth == 256 && bn == 128 && bm == 256) bm = 128;
   int m_tiles = ceil_div(p.M, bm);
   if (p.f16 && p.x3) return AVLEN_ERR_ARG;
+  if (p.rs_slabs && (bn != 128 || p.rs_slabs != n_tiles)) return AVLEN_ERR_ARG;      // the caller sized rowstats for ceil(N / 128) slabs
   int nk = ceil_div(p.K, BK) * (p.x3 ? 3 : 1);
   long tiles = (long)m_tiles * n_tiles * p.groups;
   int split = 1;

@@ -12,7 +12,9 @@ struct avlen_ctx { hipStream_t st; int prec; void* gws; size_t gws_bytes; const 
 // Operand options of the 16-bit MFMA GEMM family (igemm2.hip).  f16: the 16-bit operands / outputs are IEEE half instead of bf16.
 // x3 ("bf16x3", compensated bf16): every operand is a pair of bf16 planes, hi = bf16(x) and lo = bf16(x - hi); the lo plane of A / W
 // lies a_lo / b_lo BYTES behind the hi plane, the lo plane of the bf16 output c16_lo ELEMENTS behind C16 (0: hi only).
-struct avlen_g2_opts { int f16 = 0; int x3 = 0; long a_lo = 0, b_lo = 0, c16_lo = 0; };
+// rs_slabs / ln_slabs: deterministic row statistics (avlen_gemm_bf16_ln): the producer stores one partial slab [M][2] per 128-column
+// tile (rs_slabs = ceil(N / 128), rowstats sized rs_slabs * M * 2, no zeroing), the consumer adds ln_slabs slabs in order.
+struct avlen_g2_opts { int f16 = 0; int x3 = 0; long a_lo = 0, b_lo = 0, c16_lo = 0; int rs_slabs = 0, ln_slabs = 0; };
 // Y = act(X W^T + b) + res;  dX = dY W (+ add);  G.w += dY^T X;  out[col] += sum_rows dY   (training products, modules.hip)
 int avlen_i_linear(const avlen_ctx& c, const avlen_linear& L, const float* X, int ldx, float* Y, int ldy, int M, int act,
                    const float* res, int ldr);

@@ -404,7 +404,7 @@ __global__ void clip_gather_last2_kernel(const float* __restrict__ x, const __bf
     xe[(long)b * width + i] = x[r * width + i];
     aoe[(long)b * width + i] = ao[r * width + i];
   }
-  if (threadIdx.x < 2) stats[b * 2 + threadIdx.x] = 0.f;
+  if (stats && threadIdx.x < 2) stats[b * 2 + threadIdx.x] = 0.f;
 }
 
 __global__ void clip_gather_eot_kernel(const int64_t* __restrict__ tokens, const float* __restrict__ x,
@@ -1919,13 +1919,17 @@ extern "C" int avlen_clip_text_fwd(const avlen_clip_text* p, const int64_t* toke
     bool fold = D == 64 && ctx <= 96;                 // LayerNorms folded into the projections that follow them
     for (int l = 0; l < p->layers && fold; l++)
       fold = p->block[l].attn_fold.w16f && p->block[l].fc_fold.w16f && p->block[l].attn.in_proj.ld16 == wd;
-    // fold mode: Hn16 holds the raw residual stream in bf16, the rest of Hn the per-layer row statistics [2*layers][R][2]
+    // fold mode: Hn16 holds the raw residual stream in bf16, the rest of Hn the per-layer row statistics: 2 * layers arrays of
+    // SL slabs [R][2] -- a producing GEMM STORES one partial per 128-column tile (SL = width / 128), the consumer adds them in
+    // slab order: no atomics, bit-reproducible, nothing to zero
     float* stats = (float*)((char*)Hn + (size_t)R * wd * 2);
-    const size_t st_stride = (size_t)R * 2;
-    fold = fold && (size_t)wd * 2 >= (size_t)16 * p->layers;
+    const int SL = (wd + 127) / 128;
+    const size_t st_stride = (size_t)R * 2 * SL;
+    fold = fold && (size_t)wd * 2 >= (size_t)16 * p->layers * SL;
     { static int en = -1; if (en < 0) en = (int)avlen_knob("AVLEN_CLIP_FOLD", 1); fold = fold && en; }
     if (f16 && !fold) return AVLEN_ERR_ARG;           // the fp16 tower exists in the folded-LayerNorm form only
-    if (fold) TRY(avlen_zero_bytes(stats + st_stride, (2 * (size_t)p->layers - 1) * st_stride * sizeof(float), st));
+    avlen_g2_opts g_in1 = go, g_inS = go, g_out = go;   // consumer of the embedding's statistics (1 slab) / of a GEMM's (SL); producer
+    g_in1.ln_slabs = 1; g_inS.ln_slabs = SL; g_out.rs_slabs = SL;
     hipLaunchKernelGGL(clip_embed_ragged_kernel, dim3((unsigned)R), dim3(128), 0, st, tokens, p->tok_emb, p->pos_emb, X, seg,
                        rowmap, B, ctx, wd, p->vocab, fold ? Hn16 : (bf16*)nullptr, fold ? stats : (float*)nullptr, f16 ? 1 : 0);
     TRY(avlen_launch_status());
@@ -1945,29 +1949,29 @@ extern "C" int avlen_clip_text_fwd(const avlen_clip_text* p, const int64_t* toke
         float* st1 = stats + (size_t)(2 * l) * st_stride; float* st2 = st1 + st_stride;
         float* st_next = l + 1 < p->layers ? st2 + st_stride : nullptr;
         TRY(avlen_gemm_bf16_ln(Hn16, wd, b.attn_fold.w16f, wd, nullptr, 0, QKV, 3 * wd, b.attn_fold.c, nullptr, 0, (int)R, live,
-                               3 * wd, wd, 0, st1, b.attn_fold.s, nullptr, c.gws, c.gws_bytes, st, &go));
+                               3 * wd, wd, 0, st1, b.attn_fold.s, nullptr, c.gws, c.gws_bytes, st, l == 0 ? &g_in1 : &g_inS));
         TRY(avlen_attention_qkv16(QKV, 3 * wd, AO16, wd, B, H, ctx, 1, scale, seg, st, f16 ? 1 : 0));
         if (prune && l + 1 == p->layers) {
           // one row per sample from here on: out_proj, c_fc and c_proj shrink from the live token count to B rows
           bf16* Fe16 = F16; bf16* AOe16 = Fe16 + (size_t)B * b.fc.out_f; bf16* He16 = AOe16 + (size_t)B * wd;
-          float* ste = (float*)(He16 + (size_t)B * wd);
-          hipLaunchKernelGGL(clip_gather_last2_kernel, dim3(B), dim3(128), 0, st, X, AO16, seg, E, AOe16, ste, wd);
+          float* ste = (float*)(He16 + (size_t)B * wd);                     // SL slabs [B][2]
+          hipLaunchKernelGGL(clip_gather_last2_kernel, dim3(B), dim3(128), 0, st, X, AO16, seg, E, AOe16, (float*)nullptr, wd);
           TRY(avlen_launch_status());
           TRY(avlen_gemm_bf16_ln(AOe16, wd, b.attn.out_proj.w16, b.attn.out_proj.ld16, E, wd, He16, wd, b.attn.out_proj.b, E, wd,
-                                 B, nullptr, wd, b.attn.out_proj.ld16, 0, nullptr, nullptr, ste, c.gws, c.gws_bytes, st, &go));
+                                 B, nullptr, wd, b.attn.out_proj.ld16, 0, nullptr, nullptr, ste, c.gws, c.gws_bytes, st, &g_out));
           TRY(avlen_gemm_bf16_ln(He16, wd, b.fc_fold.w16f, wd, nullptr, 0, Fe16, b.fc.out_f, b.fc_fold.c, nullptr, 0, B, nullptr,
-                                 b.fc.out_f, wd, AVLEN_ACT_QUICKGELU, ste, b.fc_fold.s, nullptr, c.gws, c.gws_bytes, st, &go));
+                                 b.fc.out_f, wd, AVLEN_ACT_QUICKGELU, ste, b.fc_fold.s, nullptr, c.gws, c.gws_bytes, st, &g_inS));
           TRY(avlen_gemm_bf16_ln(Fe16, b.fc.out_f, b.proj.w16, b.proj.ld16, E, wd, nullptr, 0, b.proj.b, E, wd, B, nullptr, wd,
                                  b.proj.ld16, 0, nullptr, nullptr, nullptr, c.gws, c.gws_bytes, st, &go));
           pruned = true;
           break;
         }
         TRY(avlen_gemm_bf16_ln(AO16, wd, b.attn.out_proj.w16, b.attn.out_proj.ld16, X, wd, Hn16, wd, b.attn.out_proj.b, X, wd,
-                               (int)R, live, wd, b.attn.out_proj.ld16, 0, nullptr, nullptr, st2, c.gws, c.gws_bytes, st, &go));
+                               (int)R, live, wd, b.attn.out_proj.ld16, 0, nullptr, nullptr, st2, c.gws, c.gws_bytes, st, &g_out));
         TRY(avlen_gemm_bf16_ln(Hn16, wd, b.fc_fold.w16f, wd, nullptr, 0, F16, b.fc.out_f, b.fc_fold.c, nullptr, 0, (int)R, live,
-                               b.fc.out_f, wd, AVLEN_ACT_QUICKGELU, st2, b.fc_fold.s, nullptr, c.gws, c.gws_bytes, st, &go));
+                               b.fc.out_f, wd, AVLEN_ACT_QUICKGELU, st2, b.fc_fold.s, nullptr, c.gws, c.gws_bytes, st, &g_inS));
         TRY(avlen_gemm_bf16_ln(F16, b.fc.out_f, b.proj.w16, b.proj.ld16, X, wd, Hn16, wd, b.proj.b, X, wd, (int)R, live, wd,
-                               b.proj.ld16, 0, nullptr, nullptr, st_next, c.gws, c.gws_bytes, st, &go));
+                               b.proj.ld16, 0, nullptr, nullptr, st_next, c.gws, c.gws_bytes, st, st_next ? &g_out : &go));
       }
     } else
     for (int l = 0; l < p->layers; l++) {

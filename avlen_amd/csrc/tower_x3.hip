@@ -62,7 +62,14 @@ __device__ __forceinline__ void gn_coef(double sum, double sq, double inv_n, flo
 // ========================================================================================================================
 // 64 x 64 x 16 stage: band kernels (256 threads, 8 output rows per workgroup)
 // ========================================================================================================================
-constexpr int BAND = 8;
+constexpr int BAND = 8, NBAND = 64 / BAND;
+// GroupNorm statistics of a 64 x 64 x 16 tensor: every band workgroup WRITES its (sum, sum of squares) per channel -- layout
+// [image][band][2][16] -- and the consumer adds the 8 partials in band order: no atomics, bit-reproducible
+__device__ __forceinline__ void band_sums(const float* __restrict__ st, int c, double& sum, double& sq) {
+  sum = 0.0; sq = 0.0;
+#pragma unroll
+  for (int k = 0; k < NBAND; k++) { sum += (double)st[k * 32 + c]; sq += (double)st[k * 32 + 16 + c]; }
+}
 constexpr int HROWS = BAND + 2, HCOLS = 66;                 // 3x3 halo of a band
 constexpr int HPLANE = HROWS * HCOLS * 32;                  // bytes of one plane (hi or lo) of the 16-channel halo
 __device__ __forceinline__ int h16(int y, int p, int chunk) { return (y * HCOLS + p) * 32 + ((chunk ^ ((p >> 3) & 1)) << 4); }
@@ -95,12 +102,14 @@ __global__ __launch_bounds__(256) void c16_x3_kernel(C16Args args) {
     } else { wh[s] = zero_frag(); wl[s] = zero_frag(); }
   }
   if (tid < 16) {
-    const float* st = t.xst + (long)b * 32;
-    gn_coef((double)st[tid], (double)st[16 + tid], 1.0 / 4096.0, t.xg[tid], t.xb[tid], s_coef[0][tid], s_coef[1][tid]);
+    double sum, sq;
+    band_sums(t.xst + (long)b * NBAND * 32, tid, sum, sq);
+    gn_coef(sum, sq, 1.0 / 4096.0, t.xg[tid], t.xb[tid], s_coef[0][tid], s_coef[1][tid]);
   } else if (tid < 32 && t.r && t.rst) {
     const int c = tid - 16;
-    const float* st = t.rst + (long)b * 32;
-    gn_coef((double)st[c], (double)st[16 + c], 1.0 / 4096.0, t.rg[c], t.rb[c], s_coef[2][c], s_coef[3][c]);
+    double sum, sq;
+    band_sums(t.rst + (long)b * NBAND * 32, c, sum, sq);
+    gn_coef(sum, sq, 1.0 / 4096.0, t.rg[c], t.rb[c], s_coef[2][c], s_coef[3][c]);
   }
   __syncthreads();
   // ---- halo staging: 10 rows x 64 pixels x 2 chunks of 8 channels; a thread keeps the same 8 channels on every item
@@ -192,7 +201,7 @@ __global__ __launch_bounds__(256) void c16_x3_kernel(C16Args args) {
   if (tid < 32) {
     const int which = tid >> 4, ch = tid & 15;
     const float v = (bst[0][which][ch] + bst[1][which][ch]) + (bst[2][which][ch] + bst[3][which][ch]);
-    atomicAdd(&t.yst[((long)b * 2 + which) * 16 + ch], v);
+    t.yst[(((long)b * NBAND + blockIdx.x) * 2 + which) * 16 + ch] = v;
   }
 }
 
@@ -319,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void stem_x3_kernel(StemArgs args) {
   if (tid < 32) {
     const int which = tid >> 4, ch = tid & 15;
     const float v = (bst[0][which][ch] + bst[1][which][ch]) + (bst[2][which][ch] + bst[3][which][ch]);
-    atomicAdd(&t.yst[((long)b * 2 + which) * 16 + ch], v);
+    t.yst[(((long)b * NBAND + blockIdx.x) * 2 + which) * 16 + ch] = v;
   }
 }
 
@@ -656,9 +665,10 @@ __global__ __launch_bounds__(RTH) void rest_x3_kernel(RestArgs args) {
     reinterpret_cast<float*>(lds + XGB_OFF)[i] = j < nch ? t.g[n][j] : t.b[n][j - nch];
   }
   if (tid < 16) {
-    const float* st = t.xst + (long)img * 32;
     float sc, sh;
-    gn_coef((double)st[tid], (double)st[16 + tid], 1.0 / 4096.0, t.xg[tid], t.xb[tid], sc, sh);
+    double sum, sq;
+    band_sums(t.xst + (long)img * NBAND * 32, tid, sum, sq);
+    gn_coef(sum, sq, 1.0 / 4096.0, t.xg[tid], t.xb[tid], sc, sh);
     reinterpret_cast<float*>(lds + XCOEF_OFF)[tid] = sc; reinterpret_cast<float*>(lds + XCOEF_OFF)[128 + tid] = sh;
   }
   lds_barrier();
@@ -971,7 +981,7 @@ bool avlen_tower_x3_supported(const avlen_resnet18* n, int S, int C) {
 // scratch per tower: 4 fp32 tensors of the 64 x 64 x 16 stage, 5 statistics blocks, the layer-4 output
 size_t avlen_tower_x3_workspace_bytes(int groups, int B) {
   const size_t act = (size_t)B * 4096 * 16 * sizeof(float);
-  return (size_t)groups * (4 * (act + 256) + 5 * ((size_t)B * 32 * sizeof(float) + 256) + (size_t)B * 8192 * sizeof(float) + 256) + 4096;
+  return (size_t)groups * (4 * (act + 256) + 5 * ((size_t)B * NBAND * 32 * sizeof(float) + 256) + (size_t)B * 8192 * sizeof(float) + 256) + 4096;
 }
 
 // Y[g] = layer-4 output NHWC (B, 8, 8, 128) of tower g as a compensated bf16 pair (hi plane, lo plane B * 8192 elements behind;
@@ -983,16 +993,14 @@ int avlen_tower_x3_fwd(const avlen_resnet18* const* nets, const void* const* img
   WsBump w(ws, ws_bytes);
   const size_t act = (size_t)B * 4096 * 16;
   float* raw[8][3]; float* a2[8]; float* st[8];
-  float* st_all = w.take<float>((size_t)groups * 5 * B * 32);
+  float* st_all = w.take<float>((size_t)groups * 5 * B * NBAND * 32);
   for (int g = 0; g < groups; g++) {
     for (int i = 0; i < 3; i++) raw[g][i] = w.take<float>(act);
     a2[g] = w.take<float>(act);
-    st[g] = st_all + (size_t)g * 5 * B * 32;
+    st[g] = st_all + (size_t)g * 5 * B * NBAND * 32;
     if (!avlen_tower_x3_supported(nets[g], S, channels[g])) return AVLEN_ERR_ARG;
   }
-  int rc = avlen_zero_bytes(st_all, (size_t)groups * 5 * B * 32 * sizeof(float), stream);
-  if (rc != AVLEN_OK) return rc;
-  const size_t sb = (size_t)B * 32;                       // one statistics block
+  const size_t sb = (size_t)B * NBAND * 32;               // one statistics block (written whole by its producer: no zeroing)
   dim3 grid(64 / BAND, B, groups);
   {
     StemArgs a = {};

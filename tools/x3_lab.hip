@@ -31,8 +31,8 @@ int main(int argc, char** argv) {
   for (int g = 0; g < G; g++) {
     RestTower& t = a.t[g];
     t.x = dev_f((size_t)B * 4096 * 16, -1.f, 1.f); t.r = dev_f((size_t)B * 4096 * 16, 0.f, 1.f);
-    std::vector<float> st((size_t)B * 32);
-    for (int b = 0; b < B; b++) for (int c = 0; c < 16; c++) { st[b * 32 + c] = 0.f; st[b * 32 + 16 + c] = 4096.f / 3; }
+    std::vector<float> st((size_t)B * NBAND * 32);
+    for (int b = 0; b < B * NBAND; b++) for (int c = 0; c < 16; c++) { st[b * 32 + c] = 0.f; st[b * 32 + 16 + c] = 4096.f / 3 / NBAND; }
     float* dst; hipMalloc((void**)&dst, st.size() * 4); hipMemcpy(dst, st.data(), st.size() * 4, hipMemcpyHostToDevice);
     t.xst = dst; t.xg = dev_f(16, 1.f, 1.f); t.xb = dev_f(16, 0.f, 0.f);
     for (int i = 0; i < 15; i++) {
