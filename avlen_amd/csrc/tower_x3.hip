@@ -59,172 +59,171 @@ __device__ __forceinline__ void gn_coef(double sum, double sq, double inv_n, flo
   sh = beta - (float)mean * sc;
 }
 
-// ========================================================================================================================
-// 64 x 64 x 16 stage: band kernels (256 threads, 8 output rows per workgroup)
-// ========================================================================================================================
-constexpr int BAND = 8, NBAND = 64 / BAND;
-// GroupNorm statistics of a 64 x 64 x 16 tensor: every band workgroup WRITES its (sum, sum of squares) per channel -- layout
-// [image][band][2][16] -- and the consumer adds the 8 partials in band order: no atomics, bit-reproducible
-__device__ __forceinline__ void band_sums(const float* __restrict__ st, int c, double& sum, double& sq) {
-  sum = 0.0; sq = 0.0;
-#pragma unroll
-  for (int k = 0; k < NBAND; k++) { sum += (double)st[k * 32 + c]; sq += (double)st[k * 32 + 16 + c]; }
-}
-constexpr int HROWS = BAND + 2, HCOLS = 66;                 // 3x3 halo of a band
-constexpr int HPLANE = HROWS * HCOLS * 32;                  // bytes of one plane (hi or lo) of the 16-channel halo
+constexpr int HCOLS = 66;                                   // 64 pixels + the 3x3 zero frame
 __device__ __forceinline__ int h16(int y, int p, int chunk) { return (y * HCOLS + p) * 32 + ((chunk ^ ((p >> 3) & 1)) << 4); }
+template <int K, int C, typename T>
+__device__ __forceinline__ void l1_fill(const T* __restrict__ img, float scale, char* lds, int tid);
 
-struct C16Tower {
-  const float* x; const float* xst; const float* xg; const float* xb;         // producer's raw output + its GroupNorm
-  const float* r; const float* rst; const float* rg; const float* rb;         // optional residual: raw (rst != null -> relu(GN(r))) or materialised
-  float* a_out;                                                                 // optional: the staged activation, fp32 (interior rows)
-  const bf16* wh; const bf16* wl;                                               // [16][9][16] hi / lo
-  float* y; float* yst;                                                         // raw output (B, 64, 64, 16) fp32, statistics [B][2][16]
+// ========================================================================================================================
+// stem + layer 1 fused: one workgroup (512 threads) per image
+// ========================================================================================================================
+// The 64 x 64 x 16 activation as a compensated pair is 256 KiB: twice a CU's LDS.  The workgroup therefore walks every conv in
+// two half-image passes over ONE LDS frame (34 rows x 66 pixels x 32 B per plane, hi + lo): the top half of a conv's input is
+// written into the frame by the previous conv's normalise-and-split pass (registers -> LDS, never leaves the CU), the bottom
+// half comes back from a per-image scratch image (the only global round trip: ~135 KB out + ~135 KB in per conv, L2 / Infinity
+// Cache resident) by LDS-DMA.  Raw outputs of both halves stay in registers (128 fp32 per lane) until the GroupNorm statistics
+// of the whole image are known.  The residual (block input) is an fp32 scratch image read and written in place by its owner lane.
+constexpr int RTH = 512;
+__device__ __attribute__((aligned(16))) unsigned int g_zero_page_x3[4096];
+constexpr int L1_PLANE = 71 * 1024;                         // 34 x 66 x 32 B = 71,808 B, rounded up to whole 1 KiB DMA pieces
+constexpr int L1_PART_OFF = 2 * L1_PLANE;                   // [8 waves][16 ch][2] fp32
+constexpr int L1_COEF_OFF = L1_PART_OFF + 8 * 16 * 2 * 4;   // scale[16] shift[16]
+constexpr int L1_GB_OFF = L1_COEF_OFF + 32 * 4;             // gamma | beta of the 5 GroupNorms
+constexpr int L1_LDS = L1_GB_OFF + 5 * 32 * 4;
+constexpr int S70 = 70;
+static_assert((S70 * S70 + 2) * 8 <= L1_PLANE && L1_LDS <= 160 * 1024, "layer-1 LDS budget");
+constexpr long APLANE = 64L * 64 * 16;                      // elements of one plane of the scratch activation image
+
+struct L1Tower {
+  const void* img; int u8; int C; float div;
+  const bf16* wh[5]; const bf16* wl[5];                     // stem [16][49][8], then the four [16][9][16] convs: hi / lo
+  const float* g[5]; const float* b[5];
+  bf16* a0; bf16* a1;                                       // scratch activation images (B x 2 planes x 64 x 64 x 16): ping / pong
 };
-struct C16Args { C16Tower t[8]; };
+struct L1Args { L1Tower t[8]; const int* row_index; int S; };
+#ifdef AVLEN_X3_PROF            // tools/x3_lab.hip: phase timestamps of one thread of every workgroup
+#define X3_STAMP(k) do { if (prof && tid == AVLEN_X3_PROF) prof[(long)item * 32 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define X3_WALL(k) do { if (args.prof && tid == AVLEN_X3_PROF) args.prof[(long)item * 32 + (k)] = (long long)wall_clock64(); } while (0)
+#else
+#define X3_STAMP(k) do { } while (0)
+#define X3_WALL(k) do { } while (0)
+#endif
 
-// in = relu(GN(x) [+ res]) staged as hi / lo halo planes; 3x3 conv 16 -> 16; raw fp32 out + per-(sample, channel) sums
-__global__ __launch_bounds__(256) void c16_x3_kernel(C16Args args) {
-  __shared__ __attribute__((aligned(16))) char halo[2 * HPLANE];
-  __shared__ float s_coef[4][16];                       // scale, shift of x; scale, shift of r
-  __shared__ float bst[4][2][16];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, q = lane >> 4;
-  const int y0 = blockIdx.x * BAND, b = blockIdx.y;
-  const C16Tower& t = args.t[blockIdx.z];
-  // weight fragments: k-step s = taps 2s, 2s+1 x 16 channels; lane (r16, q): tap 2s + (q >> 1), channels 8 (q & 1) ..
-  bf16x8 wh[5], wl[5];
-#pragma unroll
-  for (int s = 0; s < 5; s++) {
-    const int k = 32 * s + 8 * q;
-    if (k < 144) {
-      wh[s] = *reinterpret_cast<const bf16x8*>(t.wh + (long)r16 * 144 + k);
-      wl[s] = *reinterpret_cast<const bf16x8*>(t.wl + (long)r16 * 144 + k);
-    } else { wh[s] = zero_frag(); wl[s] = zero_frag(); }
+
+// one half of a scratch activation image -> the LDS frame (both planes): frame row fr <-> image row 32 h - 1 + fr, frame pixel
+// p <-> image pixel p - 1; rows / pixels outside the image read the zero page.  The chunk swizzle of h16() is applied on the
+// SOURCE address (the LDS side of an LDS-DMA is lane-linear).
+template <int LPLANE>
+__device__ __forceinline__ void l1_load_half(const bf16* __restrict__ act, int h, char* lds, int wave, int lane) {
+#pragma unroll 1
+  for (int pc = wave; pc < 2 * 71; pc += 8) {
+    const int pl = pc >= 71, piece = pc - pl * 71;
+    const int L = piece * 64 + lane;                        // 16-byte slot inside the plane
+    const int row = L / 132, c16 = L - row * 132, px = c16 >> 1, chunk = (c16 & 1) ^ ((px >> 3) & 1);
+    const int iy = 32 * h - 1 + row;
+    const bool ok = row < 34 && px >= 1 && px <= 64 && iy >= 0 && iy < 64;
+    const char* src = ok ? (const char*)(act + pl * APLANE + ((long)iy * 64 + (px - 1)) * 16 + chunk * 8)
+                         : (const char*)g_zero_page_x3 + lane * 16;
+    __builtin_amdgcn_global_load_lds((const void*)src, (__attribute__((address_space(3))) void*)(lds + pl * LPLANE + piece * 1024), 16, 0, 0);
   }
-  if (tid < 16) {
-    double sum, sq;
-    band_sums(t.xst + (long)b * NBAND * 32, tid, sum, sq);
-    gn_coef(sum, sq, 1.0 / 4096.0, t.xg[tid], t.xb[tid], s_coef[0][tid], s_coef[1][tid]);
-  } else if (tid < 32 && t.r && t.rst) {
-    const int c = tid - 16;
-    double sum, sq;
-    band_sums(t.rst + (long)b * NBAND * 32, c, sum, sq);
-    gn_coef(sum, sq, 1.0 / 4096.0, t.rg[c], t.rb[c], s_coef[2][c], s_coef[3][c]);
-  }
-  __syncthreads();
-  // ---- halo staging: 10 rows x 64 pixels x 2 chunks of 8 channels; a thread keeps the same 8 channels on every item
-  {
-    const int c0 = (tid & 1) * 8;
-    float sc[8], sh[8], rsc[8], rsh[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) { sc[i] = s_coef[0][c0 + i]; sh[i] = s_coef[1][c0 + i]; rsc[i] = s_coef[2][c0 + i]; rsh[i] = s_coef[3][c0 + i]; }
-    const bool has_r = t.r != nullptr, r_raw = t.rst != nullptr;
-    const float* __restrict__ x = t.x + (long)b * 4096 * 16;
-    const float* __restrict__ r = has_r ? t.r + (long)b * 4096 * 16 : nullptr;
-    float* __restrict__ ao = t.a_out ? t.a_out + (long)b * 4096 * 16 : nullptr;
-#pragma unroll
-    for (int i = tid; i < HROWS * 128; i += 256) {          // 5 rounds: every load of the halo in flight together
-      const int hr = i >> 7, px = (i >> 1) & 63, ch = i & 1;
-      const int iy = y0 - 1 + hr;
-      uint2 h0 = make_uint2(0u, 0u), h1 = h0, l0 = h0, l1 = h0;
-      if (iy >= 0 && iy < 64) {
-        const long off = ((long)iy * 64 + px) * 16 + c0;
-        const float4 a = *reinterpret_cast<const float4*>(x + off), c = *reinterpret_cast<const float4*>(x + off + 4);
-        float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
-#pragma unroll
-        for (int e = 0; e < 8; e++) v[e] = v[e] * sc[e] + sh[e];
-        if (has_r) {
-          const float4 ra = *reinterpret_cast<const float4*>(r + off), rc = *reinterpret_cast<const float4*>(r + off + 4);
-          float rv[8] = {ra.x, ra.y, ra.z, ra.w, rc.x, rc.y, rc.z, rc.w};
-          if (r_raw) {
-#pragma unroll
-            for (int e = 0; e < 8; e++) rv[e] = fmaxf(rv[e] * rsc[e] + rsh[e], 0.f);
-          }
-#pragma unroll
-          for (int e = 0; e < 8; e++) v[e] += rv[e];
-        }
-#pragma unroll
-        for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
-        if (ao && hr >= 1 && hr <= BAND) {
-          *reinterpret_cast<float4*>(ao + off) = make_float4(v[0], v[1], v[2], v[3]);
-          *reinterpret_cast<float4*>(ao + off + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        }
-        const float va[4] = {v[0], v[1], v[2], v[3]}, vb[4] = {v[4], v[5], v[6], v[7]};
-        split4(va, h0, l0); split4(vb, h1, l1);
-      }
-      const int ad = h16(hr, px + 1, ch);
-      *reinterpret_cast<uint4*>(halo + ad) = make_uint4(h0.x, h0.y, h1.x, h1.y);
-      *reinterpret_cast<uint4*>(halo + HPLANE + ad) = make_uint4(l0.x, l0.y, l1.x, l1.y);
-    }
-    for (int i = tid; i < HROWS * 4; i += 256) {          // zero columns 0 and 65 (2 chunks each), both planes
-      const int hr = i >> 2, side = (i >> 1) & 1, ch = i & 1;
-      const int ad = h16(hr, side ? 65 : 0, ch);
-      *reinterpret_cast<uint4*>(halo + ad) = make_uint4(0u, 0u, 0u, 0u);
-      *reinterpret_cast<uint4*>(halo + HPLANE + ad) = make_uint4(0u, 0u, 0u, 0u);
-    }
-  }
-  __syncthreads();
-  // ---- conv: wave owns rows 2 wave, 2 wave + 1 of the band x 4 column tiles
-  int rd[5];
-#pragma unroll
-  for (int s = 0; s < 5; s++) {
-    int tap = 2 * s + (q >> 1);
-    if (tap > 8) tap = 8;                                // zero weights there
-    const int ky = tap / 3, kx = tap - ky * 3;
-    rd[s] = h16(2 * wave + ky, r16 + kx, q & 1);
-  }
-  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-  float* __restrict__ y = t.y + (long)b * 4096 * 16;
-#pragma unroll
-  for (int rr = 0; rr < 2; rr++)
-#pragma unroll
-    for (int mt = 0; mt < 4; mt++) {
-      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < 5; s++) {
-        const int off = rd[s] + (rr * HCOLS + mt * 16) * 32;
-        const bf16x8 xh = *reinterpret_cast<const bf16x8*>(halo + off), xl = *reinterpret_cast<const bf16x8*>(halo + HPLANE + off);
-        acc = mma3(wh[s], wl[s], xh, xl, acc);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; r++) { s1[r] += acc[r]; s2[r] = __builtin_fmaf(acc[r], acc[r], s2[r]); }
-      const int oy = y0 + 2 * wave + rr, ox = mt * 16 + r16;
-      *reinterpret_cast<float4*>(y + ((long)oy * 64 + ox) * 16 + q * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    }
-  // ---- statistics: 16-lane row sums, the block's 4 waves in LDS, one atomic per (statistic, channel) and block
+}
+
+__device__ __forceinline__ void l1_finish16(float (&s1)[4], float (&s2)[4], char* lds, int gi, int tid, int wave, int r16, int q) {
+  const float* gamma = reinterpret_cast<const float*>(lds + L1_GB_OFF) + gi * 32;
+  float* part = reinterpret_cast<float*>(lds + L1_PART_OFF);
+  float* coef = reinterpret_cast<float*>(lds + L1_COEF_OFF);
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const float a = row16_sum(s1[r]), c = row16_sum(s2[r]);
-    if (r16 == 0) { bst[wave][0][q * 4 + r] = a; bst[wave][1][q * 4 + r] = c; }
+    if (r16 == 0) *reinterpret_cast<float2*>(&part[(wave * 16 + q * 4 + r) * 2]) = make_float2(a, c);
   }
-  __syncthreads();
-  if (tid < 32) {
-    const int which = tid >> 4, ch = tid & 15;
-    const float v = (bst[0][which][ch] + bst[1][which][ch]) + (bst[2][which][ch] + bst[3][which][ch]);
-    t.yst[(((long)b * NBAND + blockIdx.x) * 2 + which) * 16 + ch] = v;
+  lds_barrier();                                            // every wave has also finished reading the frame
+  if (tid < 16) {
+    double sum = 0.0, sq = 0.0;
+#pragma unroll
+    for (int w = 0; w < 8; w++) { const float2 v = *reinterpret_cast<const float2*>(&part[(w * 16 + tid) * 2]); sum += v.x; sq += v.y; }
+    gn_coef(sum, sq, 1.0 / 4096.0, gamma[tid], gamma[16 + tid], coef[tid], coef[16 + tid]);
+  }
+  lds_barrier();
+}
+
+// normalise (+ residual) + ReLU of the 32 raw tiles; split into hi / lo; -> the scratch image `dst` (both planes, all rows),
+// the residual image (END: this is a block output) and -- rows -1 .. 32 -- straight into the LDS frame as the next conv's top half
+// RES: `dst` still holds the block's input (this block's residual) as a compensated pair; each lane reads the elements it is
+// about to overwrite.  The loads run three rows of tiles ahead of their use through a ring of four; the first three rows are
+// requested before the GroupNorm statistics are combined (l1_res_prefetch), so their latency hides behind that phase's barriers.
+struct L1Ring { uint2 h[4][4], l[4][4]; };
+__device__ __forceinline__ void l1_res_fetch(L1Ring& ring, const bf16* __restrict__ dst, unsigned le, int g) {
+#pragma unroll
+  for (int mt = 0; mt < 4; mt++) {
+    const int te = ((32 * (g >> 2) + (g & 3)) * 64 + mt * 16) * 16;
+    ring.h[g & 3][mt] = *reinterpret_cast<const uint2*>((dst + te) + le);
+    ring.l[g & 3][mt] = *reinterpret_cast<const uint2*>((dst + APLANE + te) + le);
+  }
+}
+__device__ __forceinline__ unsigned l1_lane_elem(int wave, int r16, int q) {
+  // one 32-bit element offset per lane; a tile's offset is a compile-time constant folded into the (uniform) base pointer, so
+  // no per-tile 64-bit addresses are kept alive across the kernel
+  unsigned le = (unsigned)((4 * wave * 64 + r16) * 16 + q * 4);
+  asm volatile("" : "+v"(le));
+  return le;
+}
+__device__ __forceinline__ void l1_res_prefetch(L1Ring& ring, const bf16* __restrict__ dst, int wave, int r16, int q) {
+  const unsigned le = l1_lane_elem(wave, r16, q);
+#pragma unroll
+  for (int g = 0; g < 3; g++) l1_res_fetch(ring, dst, le, g);
+}
+
+template <bool RES, bool ALLROWS, bool TOLDS>
+__device__ __forceinline__ void l1_apply(const f32x4 (&acc)[32], L1Ring& ring, char* lds, bf16* __restrict__ dst, int wave, int r16, int q) {
+  const float* coef = reinterpret_cast<const float*>(lds + L1_COEF_OFF);
+  float sc[4], sh[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) { sc[r] = coef[q * 4 + r]; sh[r] = coef[16 + q * 4 + r]; }
+  const unsigned le = l1_lane_elem(wave, r16, q);
+  unsigned ll0 = (unsigned)(h16(4 * wave + 1, r16 + 1, q >> 1) + (q & 1) * 8);
+  asm volatile("" : "+v"(ll0));
+#pragma unroll
+  for (int g = 0; g < 8; g++) {                             // g = (h, rr): image row 32 h + 4 wave + rr
+    const int h = g >> 2, rr = g & 3;
+    if (RES && g + 3 < 8) l1_res_fetch(ring, dst, le, g + 3);
+    // rows 0 .. 30 of an intermediate activation never leave the CU (the next conv's top half is written to LDS below)
+    const bool to_global = ALLROWS || h == 1 || (rr == 3 && wave == 7);
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) {
+      const int te = ((32 * h + rr) * 64 + mt * 16) * 16;
+      const f32x4& a = acc[(h * 4 + rr) * 4 + mt];
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) v[r] = a[r] * sc[r] + sh[r];
+      if (RES) {
+        const uint2 uh = ring.h[g & 3][mt], ul = ring.l[g & 3][mt];
+        v[0] += __uint_as_float(uh.x << 16) + __uint_as_float(ul.x << 16);
+        v[1] += __uint_as_float(uh.x & 0xffff0000u) + __uint_as_float(ul.x & 0xffff0000u);
+        v[2] += __uint_as_float(uh.y << 16) + __uint_as_float(ul.y << 16);
+        v[3] += __uint_as_float(uh.y & 0xffff0000u) + __uint_as_float(ul.y & 0xffff0000u);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
+      uint2 hh, ll;
+      split4(v, hh, ll);
+      if (to_global) {
+        *reinterpret_cast<uint2*>((dst + te) + le) = hh;
+        *reinterpret_cast<uint2*>((dst + APLANE + te) + le) = ll;
+      }
+      // rows -1 .. 32 of the image are the next conv's top half: frame row = image row + 1 (h = 1 reaches it with wave 0, rr 0)
+      if (TOLDS && (h == 0 || (rr == 0 && wave == 0))) {
+        const int tl = ((32 * h + rr) * HCOLS + mt * 16) * 32;
+        *reinterpret_cast<uint2*>(lds + ll0 + tl) = hh;
+        *reinterpret_cast<uint2*>(lds + ll0 + tl + L1_PLANE) = ll;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-// ---- stem: preprocessing (x / div, k x k mean) + 7x7 conv, C (<= 4) -> 16 channels
-constexpr int SROWS = BAND + 6, SCOLS = 70;
-constexpr int SPLANE = (SROWS * SCOLS + 2) * 8;            // 4 channels x bf16 per pixel (+ 2: the zero tap of the last tile reads past the row)
-struct StemTower { const void* img; int u8; int C; float div; const bf16* wh; const bf16* wl; float* y; float* yst; };
-struct StemArgs { StemTower t[8]; const int* row_index; int S; };
-
-// The common sensor shapes (128 x 128 -> 64 x 64, rgb or depth): the K * C inputs of one source row of an output pixel are contiguous
-// and even in number -> vector loads, all of a pixel's loads in flight together.  Same arithmetic as the generic loop: each element
-// divided by `div`, summed in (dy, dx) order, scaled by 1 / K^2.
+// preprocessing of the whole image (x / div, K x K mean) into the stem's LDS image: 70 x 70 pixels x 4 channels, hi / lo planes
 template <int K, int C, typename T>
-__device__ __forceinline__ void stem_fill(const T* __restrict__ img, float div, float inv, char* halo, int y0, int tid) {
+__device__ __forceinline__ void l1_fill(const T* __restrict__ img, float scale, char* lds, int tid) {
   constexpr int S = 64 * K, E = K * C;
   static_assert(E % 2 == 0 && C <= 4, "vector loads need an even span");
   typedef __attribute__((ext_vector_type(2))) T T2;
-#pragma unroll 2
-  for (int i = tid; i < SROWS * SCOLS + 2; i += 256) {
-    const int hr = i / SCOLS, col = i - hr * SCOLS;
-    const int oy = y0 - 3 + hr, ox = col - 3;
+#pragma unroll 5
+  for (int i = tid; i < S70 * S70 + 2; i += 512) {
+    const int hr = i / S70, col = i - hr * S70;
+    const int oy = hr - 3, ox = col - 3;
     uint2 h = make_uint2(0u, 0u), l = h;
-    if (hr < SROWS && oy >= 0 && oy < 64 && ox >= 0 && ox < 64) {
+    if (hr < S70 && oy >= 0 && oy < 64 && ox >= 0 && ox < 64) {
       const T* p = img + ((long)oy * K * S + ox * K) * C;
       T2 v[K][E / 2];
 #pragma unroll
@@ -238,104 +237,195 @@ __device__ __forceinline__ void stem_fill(const T* __restrict__ img, float div, 
 #pragma unroll
         for (int dy = 0; dy < K; dy++)
 #pragma unroll
-          for (int dx = 0; dx < K; dx++) { const int e = dx * C + c; sm += (float)v[dy][e >> 1][e & 1] / div; }
-        o[c] = sm * inv;
+          for (int dx = 0; dx < K; dx++) { const int e = dx * C + c; sm += (float)v[dy][e >> 1][e & 1]; }
+        o[c] = sm * scale;
       }
       split4(o, h, l);
     }
-    *reinterpret_cast<uint2*>(halo + i * 8) = h;
-    *reinterpret_cast<uint2*>(halo + SPLANE + i * 8) = l;
+    *reinterpret_cast<uint2*>(lds + i * 8) = h;
+    *reinterpret_cast<uint2*>(lds + L1_PLANE + i * 8) = l;
   }
 }
 
-__global__ __launch_bounds__(256, 2) void stem_x3_kernel(StemArgs args) {
-  __shared__ __attribute__((aligned(16))) char halo[2 * SPLANE];
-  __shared__ float bst[4][2][16];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, q = lane >> 4;
-  const int y0 = blockIdx.x * BAND, b = blockIdx.y;
-  const StemTower& t = args.t[blockIdx.z];
-  // weights [16][49][8] (channels 4..7 zero): k-step = kernel row ky, lane (r16, q) takes taps kx = 2 q, 2 q + 1 (4 channels each)
-  bf16x8 wh[7], wl[7];
+__device__ __forceinline__ void l1_body(const L1Args& args, int g, int img, char* lds, long long* prof, int item) {
+  // the thread index is made opaque per work item: everything derived from it is recomputed inside the item instead of being
+  // hoisted out of the queue loop and kept alive (spilled) across both bodies
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, wave = tid >> 6, r16 = lane & 15, q = lane >> 4;
+  const L1Tower& t = args.t[g];
+  bf16* __restrict__ A0 = t.a0 + (long)img * 2 * APLANE;
+  bf16* __restrict__ A1 = t.a1 + (long)img * 2 * APLANE;
+  if (tid < 160) reinterpret_cast<float*>(lds + L1_GB_OFF)[tid] = (tid & 31) < 16 ? t.g[tid >> 5][tid & 15] : t.b[tid >> 5][tid & 15];
+  X3_STAMP(0);
+  f32x4 acc[32];
+  L1Ring ring;
+  float s1[4], s2[4];
+  auto zero_stats = [&]() {
 #pragma unroll
-  for (int ky = 0; ky < 7; ky++) {
-    const int kx = 2 * q;
-    const long o0 = (long)r16 * 392 + (ky * 7 + kx) * 8;
-    const uint2 a0 = *reinterpret_cast<const uint2*>(t.wh + o0), b0 = *reinterpret_cast<const uint2*>(t.wl + o0);
-    uint2 a1 = make_uint2(0u, 0u), b1 = a1;
-    if (kx + 1 < 7) { a1 = *reinterpret_cast<const uint2*>(t.wh + o0 + 8); b1 = *reinterpret_cast<const uint2*>(t.wl + o0 + 8); }
-    wh[ky] = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, a1.x, a1.y));
-    wl[ky] = __builtin_bit_cast(bf16x8, make_uint4(b0.x, b0.y, b1.x, b1.y));
-  }
+    for (int r = 0; r < 4; r++) { s1[r] = 0.f; s2[r] = 0.f; }
+  };
+  auto add_stats = [&]() {
+#pragma unroll
+    for (int i = 0; i < 32; i++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) { s1[r] += acc[i][r]; s2[r] = __builtin_fmaf(acc[i][r], acc[i][r], s2[r]); }
+  };
+  // ---- stem: the preprocessed 4-channel image (hi / lo, 3-pixel zero frame) in LDS, whole image at once
   {
+    bf16x8 wh[7], wl[7];
+#pragma unroll
+    for (int ky = 0; ky < 7; ky++) {
+      const int kx = 2 * q;
+      const long o0 = (long)r16 * 392 + (ky * 7 + kx) * 8;
+      const uint2 a0 = *reinterpret_cast<const uint2*>(t.wh[0] + o0), b0 = *reinterpret_cast<const uint2*>(t.wl[0] + o0);
+      uint2 a1 = make_uint2(0u, 0u), b1 = a1;
+      if (kx + 1 < 7) { a1 = *reinterpret_cast<const uint2*>(t.wh[0] + o0 + 8); b1 = *reinterpret_cast<const uint2*>(t.wl[0] + o0 + 8); }
+      wh[ky] = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, a1.x, a1.y));
+      wl[ky] = __builtin_bit_cast(bf16x8, make_uint4(b0.x, b0.y, b1.x, b1.y));
+    }
     const int S = args.S, k = S / 64, C = t.C;
-    const long bs = args.row_index ? args.row_index[b] : b;
-    const float div = t.div, inv = 1.f / (float)(k * k);
-    if (k == 2 && C == 3 && t.u8) stem_fill<2, 3, unsigned char>((const unsigned char*)t.img + bs * S * S * 3, div, inv, halo, y0, tid);
-    else if (k == 2 && C == 3) stem_fill<2, 3, float>((const float*)t.img + bs * S * S * 3, div, inv, halo, y0, tid);
-    else if (k == 2 && C == 1 && !t.u8) stem_fill<2, 1, float>((const float*)t.img + bs * S * S, div, inv, halo, y0, tid);
+    const long bs = args.row_index ? args.row_index[img] : img;
+    // mean over the k x k window of x / div as (sum x) * (1 / (div k^2)): one rounding instead of k^2 + 1 (a few 1e-8 relative, far
+    // inside the 2^-17 of the compensated products) and one multiply per channel instead of k^2 divisions
+    const float scale = 1.f / (t.div * (float)(k * k));
+    if (k == 2 && C == 3 && t.u8) l1_fill<2, 3, unsigned char>((const unsigned char*)t.img + bs * S * S * 3, scale, lds, tid);
+    else if (k == 2 && C == 3) l1_fill<2, 3, float>((const float*)t.img + bs * S * S * 3, scale, lds, tid);
+    else if (k == 2 && C == 1 && !t.u8) l1_fill<2, 1, float>((const float*)t.img + bs * S * S, scale, lds, tid);
     else
-    for (int i = tid; i < SROWS * SCOLS + 2; i += 256) {
-      const int hr = i / SCOLS, col = i - hr * SCOLS;
-      const int oy = y0 - 3 + hr, ox = col - 3;
-      uint2 h = make_uint2(0u, 0u), l = h;
-      if (hr < SROWS && oy >= 0 && oy < 64 && ox >= 0 && ox < 64) {
-        float o[4] = {0.f, 0.f, 0.f, 0.f};
-        const long base = ((bs * S + (long)oy * k) * S + (long)ox * k) * C;
+      for (int i = tid; i < S70 * S70 + 2; i += RTH) {
+        const int hr = i / S70, col = i - hr * S70;
+        const int oy = hr - 3, ox = col - 3;
+        uint2 h = make_uint2(0u, 0u), l = h;
+        if (hr < S70 && oy >= 0 && oy < 64 && ox >= 0 && ox < 64) {
+          float o[4] = {0.f, 0.f, 0.f, 0.f};
+          const long base = ((bs * S + (long)oy * k) * S + (long)ox * k) * C;
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-          if (c >= C) break;
-          float s = 0.f;
-          for (int dy = 0; dy < k; dy++)
-            for (int dx = 0; dx < k; dx++) {
-              const long idx = base + ((long)dy * S + dx) * C + c;
-              s += (t.u8 ? (float)((const unsigned char*)t.img)[idx] : ((const float*)t.img)[idx]) / div;
-            }
-          o[c] = s * inv;
+          for (int c = 0; c < 4; c++) {
+            if (c >= C) break;
+            float sm = 0.f;
+            for (int dy = 0; dy < k; dy++)
+              for (int dx = 0; dx < k; dx++) {
+                const long idx = base + ((long)dy * S + dx) * C + c;
+                sm += t.u8 ? (float)((const unsigned char*)t.img)[idx] : ((const float*)t.img)[idx];
+              }
+            o[c] = sm * scale;
+          }
+          split4(o, h, l);
         }
-        split4(o, h, l);
+        *reinterpret_cast<uint2*>(lds + i * 8) = h;
+        *reinterpret_cast<uint2*>(lds + L1_PLANE + i * 8) = l;
       }
-      *reinterpret_cast<uint2*>(halo + i * 8) = h;
-      *reinterpret_cast<uint2*>(halo + SPLANE + i * 8) = l;
+    lds_barrier();
+    X3_STAMP(1);
+    // a wave's four output rows of one column tile share their input rows: each of the 10 input rows is read once and feeds the
+    // (up to 4) accumulators whose kernel row it is
+#pragma unroll
+    for (int hm = 0; hm < 8; hm++) {
+      const int h = hm >> 2, mt = hm & 3;
+      const int base = ((32 * h + 4 * wave) * S70 + mt * 16 + r16 + 2 * q) * 8;
+      f32x4 a[4];
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) a[rr] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ir = 0; ir < 10; ir++) {
+        const int off = base + ir * S70 * 8;
+        const uint2 x0 = *reinterpret_cast<const uint2*>(lds + off), x1 = *reinterpret_cast<const uint2*>(lds + off + 8);
+        const uint2 l0 = *reinterpret_cast<const uint2*>(lds + L1_PLANE + off), l1 = *reinterpret_cast<const uint2*>(lds + L1_PLANE + off + 8);
+        const bf16x8 X = __builtin_bit_cast(bf16x8, make_uint4(x0.x, x0.y, x1.x, x1.y)), L = __builtin_bit_cast(bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++)
+          if (ir - rr >= 0 && ir - rr < 7) a[rr] = mma3(wh[ir - rr], wl[ir - rr], X, L, a[rr]);
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) acc[(h * 4 + rr) * 4 + mt] = a[rr];
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
-  __syncthreads();
-  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-  float* __restrict__ y = t.y + (long)b * 4096 * 16;
-  const int base = ((2 * wave) * SCOLS + r16 + 2 * q) * 8;
+  X3_STAMP(2);
+  zero_stats(); add_stats();
+  l1_finish16(s1, s2, lds, 0, tid, wave, r16, q);
+  X3_STAMP(3);
+  // zero the frame's border: rows 0 and the left / right pixel columns are rewritten by every DMA, the direct writes leave them alone
+  l1_apply<false, true, true>(acc, ring, lds, A0, wave, r16, q);
+  auto zero_top_border = [&]() {                             // frame row 0 (image row -1) and pixels 0 / 65 of rows 1 .. 33, both planes
+    for (int i = tid; i < 132 + 33 * 4; i += RTH) {
+      int ad;
+      if (i < 132) ad = h16(0, i >> 1, i & 1);
+      else { const int j = i - 132; ad = h16(1 + (j >> 2), (j & 2) ? 65 : 0, j & 1); }
+      *reinterpret_cast<uint4*>(lds + ad) = make_uint4(0u, 0u, 0u, 0u);
+      *reinterpret_cast<uint4*>(lds + L1_PLANE + ad) = make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  zero_top_border();
+  X3_STAMP(4);
+  // ---- the four 3x3 convs of layer 1
+  bf16* src = A0; bf16* dst = A1;
 #pragma unroll 1
-  for (int tile = 0; tile < 8; tile++) {                  // not unrolled: 8 x 28 hoisted LDS reads would spill
-      const int rr = tile >> 2, mt = tile & 3;
-      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int blk = 0; blk < 2; blk++)
 #pragma unroll
-      for (int ky = 0; ky < 7; ky++) {
-        const int off = base + ((rr + ky) * SCOLS + mt * 16) * 8;
-        const uint2 x0 = *reinterpret_cast<const uint2*>(halo + off), x1 = *reinterpret_cast<const uint2*>(halo + off + 8);
-        const uint2 l0 = *reinterpret_cast<const uint2*>(halo + SPLANE + off), l1 = *reinterpret_cast<const uint2*>(halo + SPLANE + off + 8);
-        acc = mma3(wh[ky], wl[ky], __builtin_bit_cast(bf16x8, make_uint4(x0.x, x0.y, x1.x, x1.y)),
-                   __builtin_bit_cast(bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y)), acc);
-      }
+  for (int cj = 0; cj < 2; cj++) {                          // cj is static: the residual ring lives only inside a block's conv2
+    const int ci = 2 * blk + cj;
+    bf16x8 wh[5], wl[5];
 #pragma unroll
-      for (int r = 0; r < 4; r++) { s1[r] += acc[r]; s2[r] = __builtin_fmaf(acc[r], acc[r], s2[r]); }
-      const int oy = y0 + 2 * wave + rr, ox = mt * 16 + r16;
-      *reinterpret_cast<float4*>(y + ((long)oy * 64 + ox) * 16 + q * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    for (int s = 0; s < 5; s++) {
+      const int k = 32 * s + 8 * q;
+      if (k < 144) {
+        wh[s] = *reinterpret_cast<const bf16x8*>(t.wh[1 + ci] + (long)r16 * 144 + k);
+        wl[s] = *reinterpret_cast<const bf16x8*>(t.wl[1 + ci] + (long)r16 * 144 + k);
+      } else { wh[s] = zero_frag(); wl[s] = zero_frag(); }
+    }
+    int rd[5];
+#pragma unroll
+    for (int s = 0; s < 5; s++) {
+      int tap = 2 * s + (q >> 1);
+      if (tap > 8) tap = 8;
+      const int ky = tap / 3, kx = tap - ky * 3;
+      rd[s] = h16(4 * wave + ky, r16 + kx, q & 1);
     }
 #pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const float a = row16_sum(s1[r]), c = row16_sum(s2[r]);
-    if (r16 == 0) { bst[wave][0][q * 4 + r] = a; bst[wave][1][q * 4 + r] = c; }
-  }
-  __syncthreads();
-  if (tid < 32) {
-    const int which = tid >> 4, ch = tid & 15;
-    const float v = (bst[0][which][ch] + bst[1][which][ch]) + (bst[2][which][ch] + bst[3][which][ch]);
-    t.yst[(((long)b * NBAND + blockIdx.x) * 2 + which) * 16 + ch] = v;
+    for (int h = 0; h < 2; h++) {
+      if (h == 1) {
+        // the scratch image was written by this workgroup's previous normalise pass: stores retired, then everyone has left the
+        // top half before the DMA overwrites the frame
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        l1_load_half<L1_PLANE>(src, 1, lds, wave, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();
+      if (h == 1) X3_STAMP(6 + 5 * ci);
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) {
+          f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < 5; s++) {
+            const int off = rd[s] + (rr * HCOLS + mt * 16) * 32;
+            a = mma3(wh[s], wl[s], *reinterpret_cast<const bf16x8*>(lds + off), *reinterpret_cast<const bf16x8*>(lds + L1_PLANE + off), a);
+          }
+          acc[(h * 4 + rr) * 4 + mt] = a;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      X3_STAMP(5 + 5 * ci + 2 * h);
+    }
+    if (cj == 1) l1_res_prefetch(ring, dst, wave, r16, q);
+    zero_stats(); add_stats();
+    l1_finish16(s1, s2, lds, 1 + ci, tid, wave, r16, q);
+    X3_STAMP(8 + 5 * ci);
+    if (cj == 0) l1_apply<false, false, true>(acc, ring, lds, dst, wave, r16, q);
+    else if (blk == 0) l1_apply<true, true, true>(acc, ring, lds, dst, wave, r16, q);
+    else l1_apply<true, true, false>(acc, ring, lds, dst, wave, r16, q);
+    if (ci < 3) zero_top_border();
+    X3_STAMP(9 + 5 * ci);
+    bf16* tmp = src; src = dst; dst = tmp;
   }
 }
 
 // ========================================================================================================================
 // layers 2-4: one workgroup (512 threads) per image
 // ========================================================================================================================
-constexpr int RTH = 512;
 #ifndef AVLEN_X3_STAGGER
 #define AVLEN_X3_STAGGER 8       // s_sleep units (64 cycles) by which waves 4-7 enter a conv's tap loop late: their LDS read bursts then
 #endif                           // fall under the MFMA segments of their SIMD partners (waves 0-3) instead of colliding with them
@@ -357,18 +447,12 @@ __device__ __forceinline__ int a128(int y, int p, int chunk) { return (y * R128 
 
 // GroupNorm index per stage: 0 downsample, 1 block 0 conv1 (stride 2), 2 block 0 conv2, 3 block 1 conv1, 4 block 1 conv2
 struct RestTower {
-  const float* x; const float* xst; const float* xg; const float* xb;        // layer-1 block 1 conv2: raw output + its GroupNorm
-  const float* r;                                                             // block input of that block (materialised fp32): the residual
+  const bf16* a;                                                              // layer-1 output (B x 2 planes x 64 x 64 x 16): hi / lo
   const bf16* wh[15]; const bf16* wl[15];                                     // [stage * 5 + conv]
   const float* g[15]; const float* b[15];
   bf16* y;                                                                    // layer-4 output NHWC (B, 8, 8, 128) as a bf16 pair
 };
-struct RestArgs { RestTower t[8]; long y_lo; long long* prof; };              // y_lo: elements from the hi plane to the lo plane
-#ifdef AVLEN_X3_PROF            // tools/x3_lab.hip: phase timestamps of one thread of every workgroup
-#define X3_STAMP(k) do { if (args.prof && tid == AVLEN_X3_PROF) args.prof[(blockIdx.y * gridDim.x + blockIdx.x) * 32 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define X3_STAMP(k) do { } while (0)
-#endif
+struct RestArgs { RestTower t[8]; long y_lo; };              // y_lo: elements from the hi plane to the lo plane
 
 __device__ __forceinline__ void stat_pair(const f32x4& v, float& g0, float& g1, float& h0, float& h1) {     // 32 channels: 2 per group
   g0 += v[0] + v[1]; g1 += v[2] + v[3];
@@ -650,26 +734,19 @@ __device__ __forceinline__ void zero_frame(char* lds, int tid) {
   }
 }
 
-__global__ __launch_bounds__(RTH) void rest_x3_kernel(RestArgs args) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, q = lane >> 4;
-  const RestTower& t = args.t[blockIdx.y];
-  const int img = blockIdx.x;
+__device__ __forceinline__ void rest_body(const RestArgs& args, int g, int img, char* lds, long long* prof, int item) {
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));                             // as in l1_body
+  const int lane = tid & 63, wave = tid >> 6, r16 = lane & 15, q = lane >> 4;
+  const RestTower& t = args.t[g];
   const float* coef = reinterpret_cast<const float*>(lds + XCOEF_OFF);
-  // ---- GroupNorm affine parameters -> LDS; the scale / shift of the layer-1 output's GroupNorm -> coef (input transform)
+  // ---- GroupNorm affine parameters -> LDS
   for (int i = tid; i < 5 * 64 + 5 * 128 + 5 * 256; i += RTH) {
     int n, j, nch;
     if (i < 320) { n = i >> 6; j = i & 63; nch = 32; }
     else if (i < 960) { n = 5 + ((i - 320) >> 7); j = (i - 320) & 127; nch = 64; }
     else { n = 10 + ((i - 960) >> 8); j = (i - 960) & 255; nch = 128; }
     reinterpret_cast<float*>(lds + XGB_OFF)[i] = j < nch ? t.g[n][j] : t.b[n][j - nch];
-  }
-  if (tid < 16) {
-    float sc, sh;
-    double sum, sq;
-    band_sums(t.xst + (long)img * NBAND * 32, tid, sum, sq);
-    gn_coef(sum, sq, 1.0 / 4096.0, t.xg[tid], t.xb[tid], sc, sh);
-    reinterpret_cast<float*>(lds + XCOEF_OFF)[tid] = sc; reinterpret_cast<float*>(lds + XCOEF_OFF)[128 + tid] = sh;
   }
   lds_barrier();
   X3_STAMP(0);
@@ -696,40 +773,12 @@ __global__ __launch_bounds__(RTH) void rest_x3_kernel(RestArgs args) {
       WD[ct] = (q >> 1) == 0 ? *reinterpret_cast<const bf16x8*>(wDh + (long)(ct * 16 + r16) * 16 + 8 * (q & 1)) : zero_frag();
       WD[2 + ct] = (q >> 1) == 0 ? *reinterpret_cast<const bf16x8*>(wDl + (long)(ct * 16 + r16) * 16 + 8 * (q & 1)) : zero_frag();
     }
-    const int c0 = (tid & 1) * 8;
-    float sc[8], sh[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) { sc[i] = coef[c0 + i]; sh[i] = coef[128 + c0 + i]; }
-    const float* __restrict__ x = t.x + (long)img * 4096 * 16;
-    const float* __restrict__ r = t.r + (long)img * 4096 * 16;
+    const bf16* __restrict__ act = t.a + (long)img * 2 * APLANE;
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-      // frame row fr <-> image row 32 h - 1 + fr, fr = 0 .. 32; frame column = image column + 1
-#pragma unroll 3
-      for (int i = tid; i < 33 * 128; i += RTH) {
-        const int fr = i >> 7, px = (i >> 1) & 63, ch = i & 1;
-        const int iy = 32 * h - 1 + fr;
-        uint2 h0 = make_uint2(0u, 0u), h1 = h0, l0 = h0, l1 = h0;
-        if (iy >= 0) {
-          const long off = ((long)iy * 64 + px) * 16 + c0;
-          const float4 a = *reinterpret_cast<const float4*>(x + off), c = *reinterpret_cast<const float4*>(x + off + 4);
-          const float4 ra = *reinterpret_cast<const float4*>(r + off), rc = *reinterpret_cast<const float4*>(r + off + 4);
-          float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
-          const float rv[8] = {ra.x, ra.y, ra.z, ra.w, rc.x, rc.y, rc.z, rc.w};
-#pragma unroll
-          for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e] * sc[e] + sh[e] + rv[e], 0.f);
-          const float va[4] = {v[0], v[1], v[2], v[3]}, vb[4] = {v[4], v[5], v[6], v[7]};
-          split4(va, h0, l0); split4(vb, h1, l1);
-        }
-        const int ad = h16(fr, px + 1, ch);
-        *reinterpret_cast<uint4*>(lds + ad) = make_uint4(h0.x, h0.y, h1.x, h1.y);
-        *reinterpret_cast<uint4*>(lds + PLANE + ad) = make_uint4(l0.x, l0.y, l1.x, l1.y);
-      }
-      for (int i = tid; i < 33 * 2; i += RTH) {           // frame column 0 (image column -1); column 65 is never read by a stride-2 tap
-        const int ad = h16(i >> 1, 0, i & 1);
-        *reinterpret_cast<uint4*>(lds + ad) = make_uint4(0u, 0u, 0u, 0u);
-        *reinterpret_cast<uint4*>(lds + PLANE + ad) = make_uint4(0u, 0u, 0u, 0u);
-      }
+      // frame row fr <-> image row 32 h - 1 + fr, fr = 0 .. 33; frame column = image column + 1; borders come from the zero page
+      l1_load_half<PLANE>(act, h, lds, wave, lane);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       lds_barrier();
       X3_STAMP(1 + 2 * h);
       const int rdD = h16(4 * wave + 1, 2 * r16 + 1, q & 1);
@@ -951,6 +1000,85 @@ __global__ __launch_bounds__(RTH) void rest_x3_kernel(RestArgs args) {
   }
 }
 
+// ========================================================================================================================
+// One PERSISTENT launch for the whole tower group: a work queue of 2 n items (n = images x towers)
+// ========================================================================================================================
+// Both bodies need (almost) a whole CU's LDS, so a launch of n one-image workgroups runs in ceil(n / 256) rounds: the step's
+// 6 towers x 64 images = 384 workgroups cost two rounds per kernel, the second half empty.  Here ~256 resident workgroups pull
+// items from ONE queue: items [0, n) are the stem + layer-1 bodies, items [n, 2 n) the layer 2-4 bodies of the same images in the
+// same order -- 768 half-sized items fill 256 CUs in three rounds instead of four.  A layer 2-4 item waits for its image's flag:
+// that image's layer-1 item has a smaller ticket, so it is held by a workgroup that is already running and never waits itself --
+// the queue cannot deadlock whatever part of the grid is resident.  Hand-off (cdna_hip_programming.md, Guideline 16): every storing
+// wave drains its stores, the workgroup's barrier, ONE lane's agent-scope release, a relaxed agent-scope flag store; the consumer
+// polls the flag relaxed, ONE lane's agent-scope acquire, barrier, then plain (LDS-DMA) loads.  The queue head and the flags are
+// zeroed by a memset node in front of every launch.
+struct TowerArgs { L1Args l1; RestArgs rest; unsigned* q; int B; int n; long long* prof; };   // q[0]: head, q[1]: give-up word, q[4 + i]: flags
+constexpr int QSLOT_OFF = REST_LDS > L1_LDS ? REST_LDS : L1_LDS;
+constexpr int TOWER_LDS = QSLOT_OFF + 16;
+static_assert(TOWER_LDS <= 160 * 1024, "tower x3 LDS budget");
+typedef __attribute__((address_space(1))) unsigned gu32;
+
+__global__ __launch_bounds__(RTH) void tower_x3_kernel(TowerArgs args) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x;
+  volatile int* slot = reinterpret_cast<volatile int*>(lds + QSLOT_OFF);
+  gu32* qw = (gu32*)args.q;
+  const int n = args.n;
+  for (;;) {
+    if (tid == 0) *slot = (int)__hip_atomic_fetch_add(qw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    int item = __builtin_amdgcn_readfirstlane(*slot);
+    __syncthreads();                                        // the slot is rewritten only after every wave has read it
+    if (item >= 2 * n) break;
+    X3_WALL(29);
+    if (item < n) {
+      l1_body(args.l1, item / args.B, item % args.B, lds, args.prof, item);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_store(qw + 4 + item, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+      const int j = item - n;
+      if (tid == 0) {
+        unsigned spins = 0;
+        bool ok = true;
+        while (__hip_atomic_load(qw + 4 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+          __builtin_amdgcn_s_sleep(32);
+          // ~2^22 polls (seconds) without the producer: give up rather than hang the GPU -- the outputs are then garbage and
+          // the give-up word is left set for the host
+          if (++spins > (1u << 22) || __hip_atomic_load(qw + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = false; break; }
+        }
+        if (!ok) { __hip_atomic_store(qw + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *slot = -1; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (__builtin_amdgcn_readfirstlane(*slot) == -1) break;
+      X3_WALL(30);
+      rest_body(args.rest, j / args.B, j % args.B, lds, args.prof, item);
+    }
+    X3_WALL(31);
+    __syncthreads();                                        // LDS (and the slot) are free for the next item
+  }
+}
+
+static int launch_tower_x3(TowerArgs& a, size_t q_bytes, hipStream_t stream) {
+  static unsigned long long attr_done = 0;
+  static int n_cu = 0;
+  if (avlen_set_dyn_lds(reinterpret_cast<const void*>(&tower_x3_kernel), TOWER_LDS, &attr_done) != AVLEN_OK) return AVLEN_ERR_LAUNCH;
+  if (!n_cu) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+  }
+  if (avlen_zero_bytes(a.q, q_bytes, stream) != AVLEN_OK) return AVLEN_ERR_LAUNCH;
+  const int grid = 2 * a.n < n_cu ? 2 * a.n : n_cu;         // one workgroup per CU (LDS): more would only queue behind them
+  hipLaunchKernelGGL(tower_x3_kernel, dim3(grid), dim3(RTH), TOWER_LDS, stream, a);
+  return avlen_launch_status();
+}
+static inline size_t tower_x3_queue_bytes(int n) { return align_up(sizeof(unsigned) * (4 + (size_t)n), 256); }
+
 }  // namespace
 
 bool avlen_tower_x3_supported(const avlen_resnet18* n, int S, int C) {
@@ -978,10 +1106,10 @@ bool avlen_tower_x3_supported(const avlen_resnet18* n, int S, int C) {
   return true;
 }
 
-// scratch per tower: 4 fp32 tensors of the 64 x 64 x 16 stage, 5 statistics blocks, the layer-4 output
+// scratch per tower and image: two activation images (hi + lo planes of 64 x 64 x 16 bf16)
 size_t avlen_tower_x3_workspace_bytes(int groups, int B) {
-  const size_t act = (size_t)B * 4096 * 16 * sizeof(float);
-  return (size_t)groups * (4 * (act + 256) + 5 * ((size_t)B * NBAND * 32 * sizeof(float) + 256) + (size_t)B * 8192 * sizeof(float) + 256) + 4096;
+  const size_t img = (size_t)APLANE * 2 * 2 * sizeof(bf16);
+  return tower_x3_queue_bytes(B * groups) + (size_t)groups * (2 * 256 + (size_t)B * img) + 4096;
 }
 
 // Y[g] = layer-4 output NHWC (B, 8, 8, 128) of tower g as a compensated bf16 pair (hi plane, lo plane B * 8192 elements behind;
@@ -991,71 +1119,39 @@ int avlen_tower_x3_fwd(const avlen_resnet18* const* nets, const void* const* img
                        size_t ws_bytes, hipStream_t stream) {
   if (groups < 1 || groups > 8 || B <= 0 || ws_bytes < avlen_tower_x3_workspace_bytes(groups, B)) return AVLEN_ERR_WS;
   WsBump w(ws, ws_bytes);
-  const size_t act = (size_t)B * 4096 * 16;
-  float* raw[8][3]; float* a2[8]; float* st[8];
-  float* st_all = w.take<float>((size_t)groups * 5 * B * NBAND * 32);
+  const int n = B * groups;
+  TowerArgs a = {};
+  a.q = w.take<unsigned>(tower_x3_queue_bytes(n) / sizeof(unsigned));      // first: the memset block starts at the workspace's start
+  a.B = B; a.n = n;
+  a.l1.row_index = row_index; a.l1.S = S;
+  a.rest.y_lo = (long)B * 8192;
   for (int g = 0; g < groups; g++) {
-    for (int i = 0; i < 3; i++) raw[g][i] = w.take<float>(act);
-    a2[g] = w.take<float>(act);
-    st[g] = st_all + (size_t)g * 5 * B * NBAND * 32;
-    if (!avlen_tower_x3_supported(nets[g], S, channels[g])) return AVLEN_ERR_ARG;
-  }
-  const size_t sb = (size_t)B * NBAND * 32;               // one statistics block (written whole by its producer: no zeroing)
-  dim3 grid(64 / BAND, B, groups);
-  {
-    StemArgs a = {};
-    a.row_index = row_index; a.S = S;
-    for (int g = 0; g < groups; g++) {
-      const avlen_resnet18* n = nets[g];
-      a.t[g] = StemTower{imgs[g], img_u8 ? img_u8[g] : 0, channels[g], divisors[g], (const bf16*)n->conv1.w16, (const bf16*)n->conv1.w16lo,
-                         raw[g][0], st[g]};
+    const avlen_resnet18* nn = nets[g];
+    if (!avlen_tower_x3_supported(nn, S, channels[g])) return AVLEN_ERR_ARG;
+    // a0 = relu(GN0(stem)); block 0: a1 = relu(GN1(conv1(a0))), a0 = relu(GN2(conv2(a1)) + a0) [in place: the residual is what
+    // a0 held]; block 1: a1 = relu(GN3(conv1(a0))), a0 = relu(GN4(conv2(a1)) + a0) = the layer-1 output
+    L1Tower& t = a.l1.t[g];
+    t.img = imgs[g]; t.u8 = img_u8 ? img_u8[g] : 0; t.C = channels[g]; t.div = divisors[g];
+    const avlen_conv* cv[5] = {&nn->conv1, &nn->block[0].conv1, &nn->block[0].conv2, &nn->block[1].conv1, &nn->block[1].conv2};
+    const avlen_affine* gn[5] = {&nn->bn1, &nn->block[0].bn1, &nn->block[0].bn2, &nn->block[1].bn1, &nn->block[1].bn2};
+    for (int i = 0; i < 5; i++) { t.wh[i] = (const bf16*)cv[i]->w16; t.wl[i] = (const bf16*)cv[i]->w16lo; t.g[i] = gn[i]->g; t.b[i] = gn[i]->b; }
+    t.a0 = w.take<bf16>((size_t)B * 2 * APLANE);
+    t.a1 = w.take<bf16>((size_t)B * 2 * APLANE);
+    RestTower& r = a.rest.t[g];
+    r.a = t.a0; r.y = (bf16*)Y[g];
+    for (int l = 0; l < 3; l++) {
+      const avlen_resblock& b0 = nn->block[2 + 2 * l]; const avlen_resblock& b1 = nn->block[3 + 2 * l];
+      const int o = 5 * l;
+      const bool frag = l > 0;
+      r.wh[o] = (const bf16*)(frag ? b0.down.w16f : b0.down.w16); r.wl[o] = (const bf16*)(frag ? b0.down.w16flo : b0.down.w16lo);
+      r.wh[o + 1] = (const bf16*)(frag ? b0.conv1.w16f : b0.conv1.w16); r.wl[o + 1] = (const bf16*)(frag ? b0.conv1.w16flo : b0.conv1.w16lo);
+      r.wh[o + 2] = (const bf16*)b0.conv2.w16f; r.wl[o + 2] = (const bf16*)b0.conv2.w16flo;
+      r.wh[o + 3] = (const bf16*)b1.conv1.w16f; r.wl[o + 3] = (const bf16*)b1.conv1.w16flo;
+      r.wh[o + 4] = (const bf16*)b1.conv2.w16f; r.wl[o + 4] = (const bf16*)b1.conv2.w16flo;
+      r.g[o] = b0.bnd.g; r.b[o] = b0.bnd.b; r.g[o + 1] = b0.bn1.g; r.b[o + 1] = b0.bn1.b; r.g[o + 2] = b0.bn2.g; r.b[o + 2] = b0.bn2.b;
+      r.g[o + 3] = b1.bn1.g; r.b[o + 3] = b1.bn1.b; r.g[o + 4] = b1.bn2.g; r.b[o + 4] = b1.bn2.b;
     }
-    hipLaunchKernelGGL(stem_x3_kernel, grid, dim3(256), 0, stream, a);
   }
-  // raw0 = stem; a0 = relu(GN0(raw0)).  block 0: raw1 = conv1(a0), raw2 = conv2(relu(GN1(raw1))), a2 = relu(GN2(raw2) + a0);
-  // block 1: raw3 = conv1(a2) [a2 materialised], raw4 = conv2(relu(GN3(raw3))), layer-1 output = relu(GN4(raw4) + a2)
-  for (int i = 0; i < 4; i++) {
-    C16Args a = {};
-    for (int g = 0; g < groups; g++) {
-      const avlen_resnet18* n = nets[g];
-      C16Tower& t = a.t[g];
-      // buffers: raw[0] = raw0 (kept until a2 exists), raw[1] / raw[2] ping-pong
-      if (i == 0) { t.x = raw[g][0]; t.xst = st[g]; t.xg = n->bn1.g; t.xb = n->bn1.b; t.y = raw[g][1]; t.yst = st[g] + sb;
-                    t.wh = (const bf16*)n->block[0].conv1.w16; t.wl = (const bf16*)n->block[0].conv1.w16lo; }
-      if (i == 1) { t.x = raw[g][1]; t.xst = st[g] + sb; t.xg = n->block[0].bn1.g; t.xb = n->block[0].bn1.b; t.y = raw[g][2]; t.yst = st[g] + 2 * sb;
-                    t.wh = (const bf16*)n->block[0].conv2.w16; t.wl = (const bf16*)n->block[0].conv2.w16lo; }
-      if (i == 2) { t.x = raw[g][2]; t.xst = st[g] + 2 * sb; t.xg = n->block[0].bn2.g; t.xb = n->block[0].bn2.b;
-                    t.r = raw[g][0]; t.rst = st[g]; t.rg = n->bn1.g; t.rb = n->bn1.b; t.a_out = a2[g];
-                    t.y = raw[g][1]; t.yst = st[g] + 3 * sb;
-                    t.wh = (const bf16*)n->block[1].conv1.w16; t.wl = (const bf16*)n->block[1].conv1.w16lo; }
-      if (i == 3) { t.x = raw[g][1]; t.xst = st[g] + 3 * sb; t.xg = n->block[1].bn1.g; t.xb = n->block[1].bn1.b; t.y = raw[g][2]; t.yst = st[g] + 4 * sb;
-                    t.wh = (const bf16*)n->block[1].conv2.w16; t.wl = (const bf16*)n->block[1].conv2.w16lo; }
-    }
-    hipLaunchKernelGGL(c16_x3_kernel, grid, dim3(256), 0, stream, a);
-  }
-  {
-    RestArgs a = {};
-    a.y_lo = (long)B * 8192;
-    for (int g = 0; g < groups; g++) {
-      const avlen_resnet18* n = nets[g];
-      RestTower& t = a.t[g];
-      t.x = raw[g][2]; t.xst = st[g] + 4 * sb; t.xg = n->block[1].bn2.g; t.xb = n->block[1].bn2.b; t.r = a2[g]; t.y = (bf16*)Y[g];
-      for (int l = 0; l < 3; l++) {
-        const avlen_resblock& b0 = n->block[2 + 2 * l]; const avlen_resblock& b1 = n->block[3 + 2 * l];
-        const int o = 5 * l;
-        const bool frag = l > 0;
-        t.wh[o] = (const bf16*)(frag ? b0.down.w16f : b0.down.w16); t.wl[o] = (const bf16*)(frag ? b0.down.w16flo : b0.down.w16lo);
-        t.wh[o + 1] = (const bf16*)(frag ? b0.conv1.w16f : b0.conv1.w16); t.wl[o + 1] = (const bf16*)(frag ? b0.conv1.w16flo : b0.conv1.w16lo);
-        t.wh[o + 2] = (const bf16*)b0.conv2.w16f; t.wl[o + 2] = (const bf16*)b0.conv2.w16flo;
-        t.wh[o + 3] = (const bf16*)b1.conv1.w16f; t.wl[o + 3] = (const bf16*)b1.conv1.w16flo;
-        t.wh[o + 4] = (const bf16*)b1.conv2.w16f; t.wl[o + 4] = (const bf16*)b1.conv2.w16flo;
-        t.g[o] = b0.bnd.g; t.b[o] = b0.bnd.b; t.g[o + 1] = b0.bn1.g; t.b[o + 1] = b0.bn1.b; t.g[o + 2] = b0.bn2.g; t.b[o + 2] = b0.bn2.b;
-        t.g[o + 3] = b1.bn1.g; t.b[o + 3] = b1.bn1.b; t.g[o + 4] = b1.bn2.g; t.b[o + 4] = b1.bn2.b;
-      }
-    }
-    static unsigned long long attr_done = 0;
-    if (avlen_set_dyn_lds(reinterpret_cast<const void*>(&rest_x3_kernel), REST_LDS, &attr_done) != AVLEN_OK) return AVLEN_ERR_LAUNCH;
-    hipLaunchKernelGGL(rest_x3_kernel, dim3(B, groups), dim3(RTH), REST_LDS, stream, a);
-  }
-  return avlen_launch_status();
+  if (!w.ok()) return AVLEN_ERR_WS;
+  return launch_tower_x3(a, tower_x3_queue_bytes(n), stream);
 }
