@@ -97,7 +97,7 @@ class ClipBlock(C.Structure):
 class ClipText(C.Structure):
     _fields_ = [("tok_emb", f32p), ("pos_emb", f32p), ("block", ClipBlock * 12), ("ln_final", Affine),
                 ("text_proj", f32p), ("vocab", C.c_int), ("ctx", C.c_int), ("width", C.c_int), ("heads", C.c_int),
-                ("layers", C.c_int), ("out_dim", C.c_int), ("half_fmt", C.c_int)]
+                ("layers", C.c_int), ("out_dim", C.c_int), ("half_fmt", C.c_int), ("wstream", vp)]
 
 
 class Gru(C.Structure):
@@ -185,6 +185,8 @@ SIGNATURES = {
     "avlen_dialog_fwd": (i32, [C.POINTER(Dialog), vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, sz, vp]),
     "avlen_clip_text_workspace_bytes": (sz, [C.POINTER(ClipText), i32]),
     "avlen_clip_text_fwd": (i32, [C.POINTER(ClipText), vp, vp, i32, i32, vp, sz, vp]),
+    "avlen_clip_stream_bytes": (sz, [C.POINTER(ClipText)]),
+    "avlen_clip_pack_stream": (i32, [C.POINTER(ClipText), vp, i32, vp]),
     "avlen_gru_workspace_bytes": (sz, [C.POINTER(Gru), i32, i32]),
     "avlen_gru_fwd": (i32, [C.POINTER(Gru), vp, vp, vp, vp, vp, i32, i32, i32, vp, sz, vp]),
     "avlen_heads_fwd": (i32, [C.POINTER(Heads), vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]),

@@ -1,0 +1,542 @@
+// CLIP text tower (third party: open_clip / clip.model.Transformer, 12 x ResidualAttentionBlock, width 512, 8 heads, QuickGELU;
+// call site ss_baselines/savi/ppo/policy.py:847-849) as ONE launch, SEQUENCE-STATIONARY: one workgroup (512 threads) per dialog
+// carries its <= 80 tokens through all 12 layers.
+//
+// Why: as a chain of launches (71 kernels) the tower is latency-bound -- 12-20 us per GEMM whatever the row count, 0.9 ms per step,
+// on ALL 256 CUs (a 2.5 k-row GEMM cannot hide its prologue / epilogue) -- and it serialises with the visual towers, which also
+// want every CU.  Here a dialog's residual stream never leaves the CU:
+//   * residual x (80 x 512 fp32) lives in REGISTERS in MFMA accumulator layout (wave w owns columns [64 w, 64 w + 64): 80 VGPRs);
+//     the out_proj / c_proj products accumulate straight into it,
+//   * LayerNorm output, per-head-pair Q / K / V, the attention output and the MLP hidden chunk are fp16 (bf16) images in LDS,
+//   * the weights (6.3 MB per layer) are STREAMED: every wave owns a private, fragment-ordered stream (packed once by
+//     avlen_clip_pack_stream: [wave][layer][768 fragments][64 lanes][16 B] in exactly the order the wave consumes them) and keeps
+//     CT_RING fragments (1 KiB each) in flight through a register ring -- no LDS staging, no descriptor set-up, no barrier on the weight path.
+// A CU's ingest (~64 B/clk) bounds a layer at ~47 us, its matrix pipe at ~55 us for 80 tokens: ~0.7-0.8 ms for the tower on 64 CUs,
+// leaving 192 CUs to the visual towers of the same step (tower_x3 / tower_head run beside it instead of before it).
+// Arithmetic: 16-bit operands (fp16 for AVLEN_PREC_FP16, bf16 for AVLEN_PREC_BF16), fp32 accumulation, LayerNorm / softmax /
+// QuickGELU in fp32 -- the same formats as the launch-per-GEMM path, with the LayerNorm applied explicitly (not folded).
+#include "common.h"
+#include "../../include/avlen_hip.h"
+#include "internal.h"
+#include "tower_util.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 h16x4;
+
+constexpr int CT_TH = 512, CT_ROWS = 80;
+constexpr int CT_PAD = 16;                                  // padding fragments at the end of a wave's stream (>= the deepest ring)
+constexpr int CT_FRAGS = 768;                               // weight fragments (1 KiB) per wave per layer: 4 x (48 + 16) + 8 x (32 + 32)
+// LDS map (bytes).  Every image has 16 bytes of padding per row: the 16 rows of an MFMA operand fragment then start in 16 distinct
+// 16-byte bank slots (conflict-free ds_read_b128) with NO address arithmetic -- a k-step is an immediate offset.
+constexpr int XN_ROW = 1024 + 16, QK_ROW = 128 + 16, HC_ROW = 512 + 16;
+constexpr int XN_OFF = 0;                                   // LayerNorm output [80][512] 16-bit
+constexpr int QO_OFF = XN_OFF + 80 * XN_ROW;                // Q, then (in place) the attention output: [2 heads][80][64]
+constexpr int KS_OFF = QO_OFF + 2 * 80 * QK_ROW;            // K [2][80][64]
+constexpr int VS_OFF = KS_OFF + 2 * 80 * QK_ROW;            // V [2][96][64]: rows 80 .. 95 stay zero (finite operands for masked keys)
+constexpr int HC_OFF = QO_OFF;                              // MLP hidden chunk [80][256] 16-bit: aliases Q | K
+constexpr int PART_OFF = VS_OFF + 2 * 96 * QK_ROW;          // LayerNorm partials [80][8 waves] float2
+constexpr int CT_LDS = PART_OFF + 80 * 8 * 8;
+static_assert(HC_OFF + 80 * HC_ROW <= VS_OFF && CT_LDS <= 160 * 1024, "CLIP tower LDS budget");
+
+struct ClipLayerP { const float *ln1g, *ln1b, *ln2g, *ln2b, *b_in, *b_out, *b_fc, *b_proj; };
+struct ClipArgs {
+  const int64_t* tokens; const float* tok_emb; const float* pos_emb; const uint4* wstream; float* E;
+  int ctx, vocab, layers; long frags_per_wave;              // stream stride of a wave (fragments)
+  ClipLayerP L[12];
+  long long* prof;                                          // lab builds (AVLEN_CT_PROF): per-workgroup phase cycle totals [B][8]
+};
+#ifdef AVLEN_CT_PROF
+#define CT_T0() long long ct_t = __builtin_amdgcn_s_memtime(); long long ct_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define CT_PH(k) do { const long long n_ = __builtin_amdgcn_s_memtime(); ct_acc[k] += n_ - ct_t; ct_t = n_; } while (0)
+#define CT_DUMP() do { if (a.prof && tid == 0) for (int k_ = 0; k_ < 8; k_++) a.prof[(long)b * 8 + k_] = ct_acc[k_]; } while (0)
+#else
+#define CT_T0() do { } while (0)
+#define CT_PH(k) do { } while (0)
+#define CT_DUMP() do { } while (0)
+#endif
+
+template <bool F16> __device__ __forceinline__ f32x4 cmma(const uint4& w, const uint4& x, const f32x4& c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, w), __builtin_bit_cast(h16x8, x), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c, 0, 0, 0);
+}
+// four fp32 -> four 16-bit values (8 bytes)
+template <bool F16> __device__ __forceinline__ uint2 cvt4(float a, float b, float c, float d) {
+  if constexpr (F16) { const h16x4 v = {(_Float16)a, (_Float16)b, (_Float16)c, (_Float16)d}; return __builtin_bit_cast(uint2, v); }
+  else return make_uint2(pack2((f32x2){a, b}), pack2((f32x2){c, d}));
+}
+__device__ __forceinline__ uint4 lds16(const char* p) { return *reinterpret_cast<const uint4*>(p); }
+
+// One attention unit: head `ah` of the pair, query tile `mt`; scores transposed (lane (r16, q) holds query 16 mt + r16, keys
+// 16 nt + 4 q + r) so P stays in registers; every key tile is computed and the causal mask does the rest (no branches: a masked
+// tile costs two MFMAs, a branch would cut the block).  The output overwrites the unit's own Q rows.
+template <bool F16, int CT_MT>
+__device__ __forceinline__ void clip_attn_unit(char* lds, int ah, int mt, int r16, int q) {
+  const char* Qb = lds + QO_OFF + ah * 80 * QK_ROW;
+  const char* Kb = lds + KS_OFF + ah * 80 * QK_ROW;
+  const char* Vb = lds + VS_OFF + ah * 96 * QK_ROW;
+  const int qi = 16 * mt + r16;
+  uint4 qf[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; kk++) qf[kk] = lds16(Qb + qi * QK_ROW + (4 * kk + q) * 16);
+  f32x4 sacc[CT_MT];
+#pragma unroll
+  for (int nt = 0; nt < CT_MT; nt++) {
+    sacc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++)
+      sacc[nt] = cmma<F16>(lds16(Kb + (16 * nt + r16) * QK_ROW + (4 * kk + q) * 16), qf[kk], sacc[nt]);
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int nt = 0; nt < CT_MT; nt++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const float v = (16 * nt + 4 * q + r <= qi) ? sacc[nt][r] : -INFINITY;
+      sacc[nt][r] = v;
+      mx = fmaxf(mx, v);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < CT_MT; nt++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {                           // exp(-inf) = 0: the diagonal keeps mx finite
+      const float pv = __expf(sacc[nt][r] - mx);
+      sum += pv; sacc[nt][r] = pv;
+    }
+  sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+  // O^T = V^T P^T over 32-key steps; V^T fragments by the transposing LDS read from the row-major V image
+  f32x4 oacc[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; dt++) oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kk = 0; kk < (CT_MT + 1) / 2; kk++) {
+    const uint2 p0 = cvt4<F16>(sacc[2 * kk][0], sacc[2 * kk][1], sacc[2 * kk][2], sacc[2 * kk][3]);
+    uint2 p1 = make_uint2(0u, 0u);
+    if (2 * kk + 1 < CT_MT) p1 = cvt4<F16>(sacc[(2 * kk + 1) % CT_MT][0], sacc[(2 * kk + 1) % CT_MT][1], sacc[(2 * kk + 1) % CT_MT][2], sacc[(2 * kk + 1) % CT_MT][3]);
+    const uint4 pf = make_uint4(p0.x, p0.y, p1.x, p1.y);
+    const int vr = 32 * kk + 4 * q + (r16 >> 2);            // and vr + 16
+#pragma unroll
+    for (int dt = 0; dt < 4; dt++) {
+      const int cb = (16 * dt + 4 * (r16 & 3)) * 2;
+      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(Vb + vr * QK_ROW + cb));
+      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(Vb + (vr + 16) * QK_ROW + cb));
+      const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+      oacc[dt] = cmma<F16>(make_uint4(l2.x, l2.y, h2.x, h2.y), pf, oacc[dt]);
+    }
+  }
+  const float inv = __builtin_amdgcn_rcpf(sum);             // sum >= 1 (the diagonal term is exp(0))
+  char* Ob = lds + QO_OFF + ah * 80 * QK_ROW;
+#pragma unroll
+  for (int dt = 0; dt < 4; dt++) {
+    const uint2 o = cvt4<F16>(oacc[dt][0] * inv, oacc[dt][1] * inv, oacc[dt][2] * inv, oacc[dt][3] * inv);
+    *reinterpret_cast<uint2*>(Ob + qi * QK_ROW + (16 * dt + 4 * q) * 2) = o;
+  }
+}
+
+// the whole tower for one dialog of CT_MT live 16-row tiles (CT_MT = ceil(L / 16): a shorter dialog skips the dead tiles' work --
+// one straight-line instance per tile count)
+template <bool F16, int CT_MT>
+__device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, const int64_t* __restrict__ tk, int L, int b) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, q = lane >> 4;
+  const int eot = L - 1;
+  // weight fragments in flight per wave (every phase's length is a multiple of it): the short-dialog instances have the registers
+  // for a deeper ring
+  constexpr int CT_RING = CT_MT <= 3 ? 16 : 8;
+  // the V images start zeroed: rows past the live tiles are read (with zero probabilities) by the 32-key steps of P V
+  for (int i = tid; i < 2 * 96 * QK_ROW / 16; i += CT_TH) *reinterpret_cast<uint4*>(lds + VS_OFF + i * 16) = make_uint4(0u, 0u, 0u, 0u);
+  // ---- residual stream: token + positional embedding; lane (r16, q) of wave w holds rows 16 i + r16, columns 64 w + 16 j + 4 q ..
+  f32x4 xr[CT_MT][4];
+#pragma unroll
+  for (int i = 0; i < CT_MT; i++) {
+    const int m = 16 * i + r16;
+    long id = m < L ? tk[m] : 0;
+    id = id < 0 ? 0 : (id >= a.vocab ? a.vocab - 1 : id);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int col = 64 * wave + 16 * j + 4 * q;
+      float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < L) {
+        const float4 t = *reinterpret_cast<const float4*>(a.tok_emb + id * 512 + col);
+        const float4 p = *reinterpret_cast<const float4*>(a.pos_emb + (long)m * 512 + col);
+        e = make_float4(t.x + p.x, t.y + p.y, t.z + p.z, t.w + p.w);
+      }
+      xr[i][j] = (f32x4){e.x, e.y, e.z, e.w};
+    }
+  }
+  // ---- weight ring: CT_RING fragments in flight; fragment f of this wave's stream is wp[f * 64] (64 lanes x 16 B, coalesced)
+  // (uniform base in SGPRs + one 32-bit lane offset: the per-fragment offsets are scalar adds, not per-lane 64-bit addresses)
+  const uint4* __restrict__ wp = a.wstream + (long)__builtin_amdgcn_readfirstlane(wave) * a.frags_per_wave * 64;
+  const unsigned wl = (unsigned)lane;
+  uint4 wq[CT_RING];
+#pragma unroll
+  for (int s = 0; s < CT_RING; s++) wq[s] = wp[s * 64 + wl];
+  // TAKE(s): the fragment in ring slot s, and the slot's refill CT_RING fragments ahead (the stream ends with CT_RING fragments of padding)
+#define CT_TAKE(dst, s) do { dst = wq[s]; wq[s] = wp[(CT_RING + (s)) * 64 + wl]; } while (0)
+#define CT_STEP(f) do { if ((f) % CT_RING == CT_RING - 1) wp += CT_RING * 64; } while (0)
+
+  float* part = reinterpret_cast<float*>(lds + PART_OFF);
+  // LayerNorm of the residual stream -> XN (16-bit image)
+  auto layer_norm = [&](const float* __restrict__ g, const float* __restrict__ be) {
+    float4 gv[4], bv[4];                                    // requested first: their latency hides behind the statistics
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      gv[j] = *reinterpret_cast<const float4*>(g + 64 * wave + 16 * j + 4 * q);
+      bv[j] = *reinterpret_cast<const float4*>(be + 64 * wave + 16 * j + 4 * q);
+    }
+#pragma unroll
+    for (int i = 0; i < CT_MT; i++) {
+      f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};                // two columns per instruction (v_pk_add_f32 / v_pk_fma_f32)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const f32x2 lo = {xr[i][j][0], xr[i][j][1]}, hi = {xr[i][j][2], xr[i][j][3]};
+        s1 += lo; s1 += hi;
+        s2 = __builtin_elementwise_fma(lo, lo, s2); s2 = __builtin_elementwise_fma(hi, hi, s2);
+      }
+      float a1 = s1[0] + s1[1], a2 = s2[0] + s2[1];
+      a1 += __shfl_xor(a1, 16, 64); a2 += __shfl_xor(a2, 16, 64);
+      a1 += __shfl_xor(a1, 32, 64); a2 += __shfl_xor(a2, 32, 64);
+      if (q == 0) *reinterpret_cast<float2*>(&part[((16 * i + r16) * 8 + wave) * 2]) = make_float2(a1, a2);
+    }
+    lds_barrier();
+#pragma unroll
+    for (int i = 0; i < CT_MT; i++) {
+      const int m = 16 * i + r16;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {                         // fixed order over the 8 waves: bit-reproducible
+        const float4 pp = *reinterpret_cast<const float4*>(&part[(m * 8 + 2 * k) * 2]);
+        s1 += pp.x; s2 += pp.y; s1 += pp.z; s2 += pp.w;
+      }
+      const float mean = s1 * (1.f / 512.f);
+      const float rstd = rsqrtf(fmaxf(s2 * (1.f / 512.f) - mean * mean, 0.f) + 1e-5f);
+      const float nm = -mean * rstd;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {                         // y = x (rstd g) + (b - mean rstd g)
+        const f32x2 glo = {gv[j].x, gv[j].y}, ghi = {gv[j].z, gv[j].w}, blo = {bv[j].x, bv[j].y}, bhi = {bv[j].z, bv[j].w};
+        const f32x2 alo = glo * rstd, ahi = ghi * rstd;
+        const f32x2 clo = __builtin_elementwise_fma(glo, (f32x2){nm, nm}, blo), chi = __builtin_elementwise_fma(ghi, (f32x2){nm, nm}, bhi);
+        const f32x2 ylo = __builtin_elementwise_fma((f32x2){xr[i][j][0], xr[i][j][1]}, alo, clo);
+        const f32x2 yhi = __builtin_elementwise_fma((f32x2){xr[i][j][2], xr[i][j][3]}, ahi, chi);
+        *reinterpret_cast<uint2*>(lds + XN_OFF + m * XN_ROW + (64 * wave + 16 * j + 4 * q) * 2) = cvt4<F16>(ylo[0], ylo[1], yhi[0], yhi[1]);
+      }
+    }
+    lds_barrier();
+  };
+
+  CT_T0();
+  for (int layer = 0; layer < a.layers; layer++) {
+    const ClipLayerP& P = a.L[layer];
+    CT_PH(7);
+    layer_norm(P.ln1g, P.ln1b);
+    CT_PH(0);
+    // ================================================= attention, two heads at a time =================================================
+#pragma unroll 1
+    for (int hp = 0; hp < 4; hp++) {
+      // ---- in_proj of the pair: 24 column tiles (head a: q 4 | k 4 | v 4), wave w takes tiles 3 w .. 3 w + 2; K = 512
+      {
+        f32x4 acc[CT_MT][3];
+#pragma unroll
+        for (int i = 0; i < CT_MT; i++)
+#pragma unroll
+          for (int t = 0; t < 3; t++) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // the activation fragments of k-step ks + 1 are requested before the MFMAs of k-step ks (LDS latency off the critical path)
+        uint4 xf[2][CT_MT];
+#pragma unroll
+        for (int i = 0; i < CT_MT; i++) xf[0][i] = lds16(lds + XN_OFF + (16 * i + r16) * XN_ROW + q * 16);
+#pragma unroll
+        for (int ks = 0; ks < 16; ks++) {
+          if (ks + 1 < 16) {
+#pragma unroll
+            for (int i = 0; i < CT_MT; i++) xf[(ks + 1) & 1][i] = lds16(lds + XN_OFF + (16 * i + r16) * XN_ROW + (4 * (ks + 1) + q) * 16);
+          }
+#pragma unroll
+          for (int t = 0; t < 3; t++) {
+            const int f = 3 * ks + t;                       // 0 .. 47: turns of the ring
+            uint4 w;
+            CT_TAKE(w, f % CT_RING);
+            CT_STEP(f);
+#pragma unroll
+            for (int i = 0; i < CT_MT; i++) acc[i][t] = cmma<F16>(w, xf[ks & 1][i], acc[i][t]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // bias, Q pre-scaled by 1 / sqrt(64) (exact), -> the pair's Q / K / V images
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+          const int gt = 3 * wave + t, ah = gt / 12, ty = (gt % 12) >> 2, sub = gt & 3;
+          const int n = ty * 512 + (2 * hp + ah) * 64 + sub * 16 + 4 * q;
+          const float4 bi = *reinterpret_cast<const float4*>(P.b_in + n);
+          const float sc = ty == 0 ? 0.125f : 1.f;
+          char* base = lds + (ty == 0 ? QO_OFF + ah * 80 * QK_ROW : ty == 1 ? KS_OFF + ah * 80 * QK_ROW : VS_OFF + ah * 96 * QK_ROW);
+#pragma unroll
+          for (int i = 0; i < CT_MT; i++) {
+            const int m = 16 * i + r16;
+            const uint2 o = cvt4<F16>((acc[i][t][0] + bi.x) * sc, (acc[i][t][1] + bi.y) * sc, (acc[i][t][2] + bi.z) * sc, (acc[i][t][3] + bi.w) * sc);
+            *reinterpret_cast<uint2*>(base + m * QK_ROW + (16 * sub + 4 * q) * 2) = o;
+          }
+        }
+      }
+      lds_barrier();
+      CT_PH(1);
+      // ---- causal attention: units (head of the pair, 16-query tile), branch-free bodies; a wave with two units runs them in one
+      // basic block (two independent dependency chains for the scheduler to interleave: a unit alone is latency-bound)
+      if (wave + 8 < 2 * CT_MT) {
+        clip_attn_unit<F16, CT_MT>(lds, wave / CT_MT, wave % CT_MT, r16, q);
+        clip_attn_unit<F16, CT_MT>(lds, (wave + 8) / CT_MT, (wave + 8) % CT_MT, r16, q);
+      } else if (wave < 2 * CT_MT) {
+        clip_attn_unit<F16, CT_MT>(lds, wave / CT_MT, wave % CT_MT, r16, q);
+      }
+      lds_barrier();
+      CT_PH(2);
+      // ---- out_proj, the pair's 128 input columns: x += O_pair W_out[:, 128 hp ..]^T (wave w: its 64 output columns, 4 tiles)
+      uint4 of[2][CT_MT];
+#pragma unroll
+      for (int i = 0; i < CT_MT; i++) of[0][i] = lds16(lds + QO_OFF + (16 * i + r16) * QK_ROW + q * 16);
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+        if (ks + 1 < 4) {
+#pragma unroll
+          for (int i = 0; i < CT_MT; i++)
+            of[(ks + 1) & 1][i] = lds16(lds + QO_OFF + ((ks + 1) >> 1) * 80 * QK_ROW + (16 * i + r16) * QK_ROW + (4 * ((ks + 1) & 1) + q) * 16);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          const int f = 4 * ks + t;
+          uint4 w;
+          CT_TAKE(w, f % CT_RING);
+          CT_STEP(f);
+#pragma unroll
+          for (int i = 0; i < CT_MT; i++) xr[i][t] = cmma<F16>(w, of[ks & 1][i], xr[i][t]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      lds_barrier();                                          // the next pair's in_proj overwrites Q / K / V
+      CT_PH(3);
+    }
+    {
+      float4 bo[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) bo[j] = *reinterpret_cast<const float4*>(P.b_out + 64 * wave + 16 * j + 4 * q);
+#pragma unroll
+      for (int i = 0; i < CT_MT; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) { xr[i][j][0] += bo[j].x; xr[i][j][1] += bo[j].y; xr[i][j][2] += bo[j].z; xr[i][j][3] += bo[j].w; }
+    }
+    // ======================================================= MLP, 256 hidden units at a time =======================================================
+    layer_norm(P.ln2g, P.ln2b);
+    CT_PH(4);
+#pragma unroll 1
+    for (int c = 0; c < 8; c++) {
+      {
+        f32x4 acc[CT_MT][2];
+#pragma unroll
+        for (int i = 0; i < CT_MT; i++) { acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
+        uint4 xf[2][CT_MT];
+#pragma unroll
+        for (int i = 0; i < CT_MT; i++) xf[0][i] = lds16(lds + XN_OFF + (16 * i + r16) * XN_ROW + q * 16);
+#pragma unroll
+        for (int ks = 0; ks < 16; ks++) {
+          if (ks + 1 < 16) {
+#pragma unroll
+            for (int i = 0; i < CT_MT; i++) xf[(ks + 1) & 1][i] = lds16(lds + XN_OFF + (16 * i + r16) * XN_ROW + (4 * (ks + 1) + q) * 16);
+          }
+#pragma unroll
+          for (int t = 0; t < 2; t++) {
+            const int f = 2 * ks + t;
+            uint4 w;
+            CT_TAKE(w, f % CT_RING);
+            CT_STEP(f);
+#pragma unroll
+            for (int i = 0; i < CT_MT; i++) acc[i][t] = cmma<F16>(w, xf[ks & 1][i], acc[i][t]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+          const float4 bf = *reinterpret_cast<const float4*>(P.b_fc + 256 * c + 32 * wave + 16 * t + 4 * q);
+#pragma unroll
+          for (int i = 0; i < CT_MT; i++) {
+            const int m = 16 * i + r16;
+            float v[4] = {acc[i][t][0] + bf.x, acc[i][t][1] + bf.y, acc[i][t][2] + bf.z, acc[i][t][3] + bf.w};
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[r] = v[r] * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v[r]));      // QuickGELU (1-ulp reciprocal)
+            *reinterpret_cast<uint2*>(lds + HC_OFF + m * HC_ROW + (32 * wave + 16 * t + 4 * q) * 2) = cvt4<F16>(v[0], v[1], v[2], v[3]);
+          }
+        }
+      }
+      lds_barrier();
+      CT_PH(5);
+      uint4 hf[2][CT_MT];
+#pragma unroll
+      for (int i = 0; i < CT_MT; i++) hf[0][i] = lds16(lds + HC_OFF + (16 * i + r16) * HC_ROW + q * 16);
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++) {
+        if (ks + 1 < 8) {
+#pragma unroll
+          for (int i = 0; i < CT_MT; i++) hf[(ks + 1) & 1][i] = lds16(lds + HC_OFF + (16 * i + r16) * HC_ROW + (4 * (ks + 1) + q) * 16);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          const int f = 4 * ks + t;
+          uint4 w;
+          CT_TAKE(w, f % CT_RING);
+          CT_STEP(f);
+#pragma unroll
+          for (int i = 0; i < CT_MT; i++) xr[i][t] = cmma<F16>(w, hf[ks & 1][i], xr[i][t]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      lds_barrier();                                          // the next chunk's hidden image overwrites this one
+      CT_PH(6);
+    }
+    {
+      float4 bp[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) bp[j] = *reinterpret_cast<const float4*>(P.b_proj + 64 * wave + 16 * j + 4 * q);
+#pragma unroll
+      for (int i = 0; i < CT_MT; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) { xr[i][j][0] += bp[j].x; xr[i][j][1] += bp[j].y; xr[i][j][2] += bp[j].z; xr[i][j][3] += bp[j].w; }
+    }
+  }
+  // ---- the EOT row of the residual stream (ln_final and the projection follow as their own small launches)
+#pragma unroll
+  for (int i = 0; i < CT_MT; i++)
+    if (16 * i + r16 == eot) {
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        *reinterpret_cast<float4*>(a.E + (long)b * 512 + 64 * wave + 16 * j + 4 * q) = make_float4(xr[i][j][0], xr[i][j][1], xr[i][j][2], xr[i][j][3]);
+    }
+  CT_DUMP();
+#undef CT_TAKE
+#undef CT_STEP
+}
+
+// Measured and rejected (tools/clip_lab.hip, 64 dialogs): eight extra "L2 warmer" workgroups (one per XCD) streaming the same bytes
+// 0.75 MB ahead of the dialogs, paced by per-dialog progress words -- 925 -> 1236 us: a dialog's stream already runs at the CU's
+// ingest ceiling (~43 of ~51 B/clk), not at the Infinity-Cache latency, and the progress stores cost more than the warm lines save.
+template <bool F16>
+__global__ __launch_bounds__(CT_TH) void clip_tower_kernel(ClipArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x, ctx = a.ctx;
+  const int64_t* __restrict__ tk = a.tokens + (long)b * ctx;
+  // ---- live length: tokens up to the EOT (= first position of the largest id, as torch.argmax) -- nothing after it can reach
+  // the output through the causal mask
+  int L;
+  {
+    long best = -1; int bi = 0x7fffffff;
+    for (int k = lane; k < ctx; k += 64) { const long v = tk[k]; if (v > best) { best = v; bi = k; } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const long ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    L = __builtin_amdgcn_readfirstlane(bi) + 1;
+  }
+  switch ((L + 15) >> 4) {
+    case 1: clip_tower_body<F16, 1>(a, lds, tk, L, b); break;
+    case 2: clip_tower_body<F16, 2>(a, lds, tk, L, b); break;
+    case 3: clip_tower_body<F16, 3>(a, lds, tk, L, b); break;
+    case 4: clip_tower_body<F16, 4>(a, lds, tk, L, b); break;
+    default: clip_tower_body<F16, 5>(a, lds, tk, L, b); break;
+  }
+}
+
+struct ClipLayerWeights { const float* w_in[12]; const float* w_out[12]; const float* w_fc[12]; const float* w_proj[12]; };
+// ---- weight stream packer: fragment f of wave w of layer l, lane (r16, q), element e = W[n][k] of the matrix / tile / k-step the
+// kernel consumes at that point (see the kernel's loops)
+__global__ void clip_pack_stream_kernel(ClipLayerWeights wts, uint4* __restrict__ dst, int layers, long frags_per_wave, int fmt) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;           // one thread per (layer, wave, fragment, lane)
+  const long total = (long)layers * 8 * CT_FRAGS * 64;
+  if (gid >= total) return;
+  const int lane = (int)(gid & 63);
+  long rest = gid >> 6;
+  const int f = (int)(rest % CT_FRAGS); rest /= CT_FRAGS;
+  const int wave = (int)(rest & 7), layer = (int)(rest >> 3);
+  const int r16 = lane & 15, q = lane >> 4;
+  const float* W; int ld, n, k;
+  if (f < 256) {                                            // attention: 4 pairs x (48 in_proj + 16 out_proj)
+    const int hp = f >> 6, g = f & 63;
+    if (g < 48) {
+      const int ks = g / 3, t = g % 3, gt = 3 * wave + t, ah = gt / 12, ty = (gt % 12) >> 2, sub = gt & 3;
+      W = wts.w_in[layer]; ld = 512; n = ty * 512 + (2 * hp + ah) * 64 + sub * 16 + r16; k = 32 * ks + 8 * q;
+    } else {
+      const int ks = (g - 48) >> 2, t = (g - 48) & 3;
+      W = wts.w_out[layer]; ld = 512; n = 64 * wave + 16 * t + r16; k = 128 * hp + 32 * ks + 8 * q;
+    }
+  } else {                                                  // MLP: 8 chunks x (32 c_fc + 32 c_proj)
+    const int c = (f - 256) >> 6, g = (f - 256) & 63;
+    if (g < 32) {
+      const int ks = g >> 1, t = g & 1;
+      W = wts.w_fc[layer]; ld = 512; n = 256 * c + 32 * wave + 16 * t + r16; k = 32 * ks + 8 * q;
+    } else {
+      const int ks = (g - 32) >> 2, t = (g - 32) & 3;
+      W = wts.w_proj[layer]; ld = 2048; n = 64 * wave + 16 * t + r16; k = 256 * c + 32 * ks + 8 * q;
+    }
+  }
+  const float4 v0 = *reinterpret_cast<const float4*>(W + (long)n * ld + k), v1 = *reinterpret_cast<const float4*>(W + (long)n * ld + k + 4);
+  uint2 lo, hi;
+  if (fmt == 1) { lo = cvt4<true>(v0.x, v0.y, v0.z, v0.w); hi = cvt4<true>(v1.x, v1.y, v1.z, v1.w); }
+  else { lo = cvt4<false>(v0.x, v0.y, v0.z, v0.w); hi = cvt4<false>(v1.x, v1.y, v1.z, v1.w); }
+  dst[((long)wave * frags_per_wave + (long)layer * CT_FRAGS + f) * 64 + lane] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+
+bool clip_stream_shape_ok(const avlen_clip_text* p) {
+  if (!p || p->width != 512 || p->heads != 8 || p->layers < 1 || p->layers > 12 || p->ctx > CT_ROWS) return false;
+  for (int l = 0; l < p->layers; l++) {
+    const avlen_clip_block& b = p->block[l];
+    if (b.attn.in_proj.out_f != 1536 || b.attn.in_proj.in_f != 512 || b.attn.out_proj.out_f != 512 || b.attn.out_proj.in_f != 512 ||
+        b.fc.out_f != 2048 || b.fc.in_f != 512 || b.proj.out_f != 512 || b.proj.in_f != 2048) return false;
+    if (!b.attn.in_proj.b || !b.attn.out_proj.b || !b.fc.b || !b.proj.b) return false;
+  }
+  return true;
+}
+inline long clip_frags_per_wave(int layers) { return (long)layers * CT_FRAGS + CT_PAD; }
+
+}  // namespace
+
+extern "C" size_t avlen_clip_stream_bytes(const avlen_clip_text* p) {
+  return clip_stream_shape_ok(p) ? (size_t)8 * clip_frags_per_wave(p->layers) * 1024 : 0;
+}
+
+// Builds the per-wave weight stream of the one-launch tower from the fp32 weights (fmt 0: bf16, 1: fp16).  Derived data: call
+// again whenever the weights change (CLIP is frozen in the reference: once).
+extern "C" int avlen_clip_pack_stream(const avlen_clip_text* p, void* dst, int fmt, hipStream_t st) {
+  if (!clip_stream_shape_ok(p) || !dst) return AVLEN_ERR_ARG;
+  ClipLayerWeights w = {};
+  for (int l = 0; l < p->layers; l++) {
+    w.w_in[l] = p->block[l].attn.in_proj.w; w.w_out[l] = p->block[l].attn.out_proj.w;
+    w.w_fc[l] = p->block[l].fc.w; w.w_proj[l] = p->block[l].proj.w;
+  }
+  const long fpw = clip_frags_per_wave(p->layers);
+  if (avlen_zero_bytes(dst, (size_t)8 * fpw * 1024, st) != AVLEN_OK) return AVLEN_ERR_LAUNCH;      // the 16 padding fragments per wave
+  const long total = (long)p->layers * 8 * CT_FRAGS * 64;
+  hipLaunchKernelGGL(clip_pack_stream_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, (uint4*)dst, p->layers, fpw, fmt);
+  return avlen_launch_status();
+}
+
+// X rows of the residual stream at each dialog's EOT token (B x 512 fp32) through the 12 blocks in one launch
+int avlen_clip_tower_stream_fwd(const avlen_clip_text* p, const int64_t* tokens, float* E, int B, int f16, hipStream_t st) {
+  if (!clip_stream_shape_ok(p) || !p->wstream || B <= 0) return AVLEN_ERR_ARG;
+  ClipArgs a = {};
+  a.tokens = tokens; a.tok_emb = p->tok_emb; a.pos_emb = p->pos_emb; a.wstream = (const uint4*)p->wstream; a.E = E;
+  a.ctx = p->ctx; a.vocab = p->vocab; a.layers = p->layers; a.frags_per_wave = clip_frags_per_wave(p->layers);
+  const int grid = B;
+  for (int l = 0; l < p->layers; l++) {
+    const avlen_clip_block& b = p->block[l];
+    a.L[l] = ClipLayerP{b.ln1.g, b.ln1.b, b.ln2.g, b.ln2.b, b.attn.in_proj.b, b.attn.out_proj.b, b.fc.b, b.proj.b};
+  }
+  static unsigned long long done0 = 0, done1 = 0;
+  if (f16) {
+    if (avlen_set_dyn_lds(reinterpret_cast<const void*>(&clip_tower_kernel<true>), CT_LDS, &done1) != AVLEN_OK) return AVLEN_ERR_LAUNCH;
+    hipLaunchKernelGGL(clip_tower_kernel<true>, dim3(grid), dim3(CT_TH), CT_LDS, st, a);
+  } else {
+    if (avlen_set_dyn_lds(reinterpret_cast<const void*>(&clip_tower_kernel<false>), CT_LDS, &done0) != AVLEN_OK) return AVLEN_ERR_LAUNCH;
+    hipLaunchKernelGGL(clip_tower_kernel<false>, dim3(grid), dim3(CT_TH), CT_LDS, st, a);
+  }
+  return avlen_launch_status();
+}

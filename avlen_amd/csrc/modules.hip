@@ -1910,6 +1910,12 @@ extern "C" int avlen_clip_text_fwd(const avlen_clip_text* p, const int64_t* toke
     const avlen_clip_block& b = p->block[l];
     fast = lin16_ok(b.attn.in_proj) && lin16_ok(b.attn.out_proj) && lin16_ok(b.fc) && lin16_ok(b.proj);
   }
+  if (fast && p->wstream && avlen_clip_stream_bytes(p)) {
+    // the 12 blocks as ONE sequence-stationary launch (clip_tower.hip) -> the EOT rows; ln_final + projection as before
+    TRY(avlen_clip_tower_stream_fwd(p, tokens, E, B, f16 ? 1 : 0, st));
+    TRY(avlen_layernorm_fwd(E, nullptr, p->ln_final.g, p->ln_final.b, E2, nullptr, nullptr, B, wd, 1e-5f, st));
+    return clip_project(p, E2, out, B, f16 ? AVLEN_PREC_BF16X3 : prec, gws, st);
+  }
   if (fast) {      // bf16 operands from HBM; ragged batch: only the tokens up to each EOT are computed
     bf16* Hn16 = (bf16*)Hn; bf16* AO16 = (bf16*)AO; bf16* F16 = (bf16*)Fh;
     int* seg = (int*)E2;                              // [B+1] (E2 is used again only after the layers)

@@ -1,6 +1,7 @@
 """Host-side engine shared by the policies: flat parameter storage, packed weights, C-struct views of
 the parameters, workspaces.  PyTorch is used for device memory only."""
 import ctypes as C
+import os
 import torch
 
 from . import _lib as L
@@ -250,6 +251,8 @@ class Packed:
                 L.call("avlen_pack_conv_weight_bf16", P(wf), P(w16), *dims, c16, st)
             elif kind == "frag":                      # queued after the conv's own job: w16 is up to date
                 L.call("avlen_pack_conv_weight_frag", P(w), P(buf16), dims[0], dims[1], st)
+            elif kind == "clipstream":
+                L.call("avlen_clip_pack_stream", C.byref(w), P(buf16), c16, st)
             elif kind == "conv_lo":
                 L.call("avlen_pack_conv_weight_h16", P(w), P(buf16), *dims, c16, 2, st)
             elif kind == "conv16c":
@@ -396,6 +399,14 @@ def clip_view(clip, flat=None, packed=None, fmt=0):
     s.vocab, s.ctx = clip.vocab_size, clip.context_length
     s.width, s.heads, s.layers = clip.transformer.width, clip.heads, clip.transformer.layers
     s.out_dim = clip.text_projection.shape[1]
+    if packed is not None and os.environ.get("AVLEN_CLIP_STREAM", "1") != "0":
+        # per-wave weight stream of the one-launch tower (csrc/clip_tower.hip); 0 bytes: shape not supported -> launch-per-GEMM path
+        nb = L.lib.avlen_clip_stream_bytes(C.byref(s))
+        if nb:
+            buf = torch.empty(nb, dtype=torch.uint8, device=packed.device)
+            packed.bufs.append(buf)
+            packed.jobs.append(("clipstream", s, None, buf, None, fmt))
+            s.wstream = P(buf)
     return s
 
 

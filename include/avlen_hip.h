@@ -78,8 +78,10 @@ typedef struct { void* w16f; float* s; float* c; } avlen_ln_fold;
 typedef struct { avlen_affine ln1, ln2; avlen_mha attn; avlen_linear fc, proj; avlen_ln_fold attn_fold, fc_fold; } avlen_clip_block;
 /* CLIP ViT-B/32 text tower (third party; call site policy.py:847-849). text_proj is [width][out]. */
 /* half_fmt: format of every 16-bit weight shadow of the tower (w16, w16f): 0 = bf16, 1 = fp16 (AVLEN_PREC_FP16 calls). */
+/* wstream: per-wave fragment-ordered copy of the 12 blocks' Linear weights in half_fmt (avlen_clip_pack_stream; NULL = absent):
+ * with it the 16-bit forward runs the blocks as ONE sequence-stationary launch (csrc/clip_tower.hip). */
 typedef struct { float* tok_emb; float* pos_emb; avlen_clip_block block[12]; avlen_affine ln_final;
-                 float* text_proj; int vocab, ctx, width, heads, layers, out_dim, half_fmt; } avlen_clip_text;
+                 float* text_proj; int vocab, ctx, width, heads, layers, out_dim, half_fmt; void* wstream; } avlen_clip_text;
 /* nn.GRU(in, H, 1 layer) (av_nav/models/rnn_state_encoder.py:36-40): w_ih[3H][in], w_hh[3H][H], r|z|n. */
 typedef struct { float* w_ih; float* w_hh; float* b_ih; float* b_hh; int in_f, hidden; } avlen_gru;
 /* CategoricalNet + CriticHead (+ CriticHead2) of one policy (policy.py:46-61, 279-297). */
@@ -308,6 +310,10 @@ int avlen_dialog_fwd(const avlen_dialog* p, const float* x_att, const float* mem
 size_t avlen_clip_text_workspace_bytes(const avlen_clip_text* p, int B);
 int avlen_clip_text_fwd(const avlen_clip_text* p, const int64_t* tokens, float* out, int B, int prec, void* ws,
                         size_t ws_bytes, avlen_stream_t stream);
+/* The one-launch tower's weight stream (csrc/clip_tower.hip): bytes for `p` (0: shape not supported -- width 512, 8 heads,
+ * ctx <= 80, 4x MLP, biases present) and the packer (fmt 0 bf16, 1 fp16; from the fp32 weights; derived data). */
+size_t avlen_clip_stream_bytes(const avlen_clip_text* p);
+int avlen_clip_pack_stream(const avlen_clip_text* p, void* dst, int fmt, avlen_stream_t stream);
 
 /* ------------------------------------------------------------------ GRU ------------------------ */
 /* RNNStateEncoder (rnn_state_encoder.py:80-143).  T==1: single_forward; T>1: seq_forward with x (T*N,in)

@@ -1,0 +1,62 @@
+// Stand-alone lab for csrc/clip_tower.hip: the one-launch CLIP text tower on random weights / tokens (B dialogs with EOT positions
+// spread over 2 .. 72), launch time and the per-phase cycle totals of the slowest and the mean workgroup.  Not part of the library.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -ffp-contract=off -DAVLEN_CT_PROF tools/clip_lab.hip -o tools/bin/clip_lab
+//   tools/bin/clip_lab [B=64] [fixed_len=0]
+#include "../avlen_amd/csrc/clip_tower.hip"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+int avlen_zero_bytes(void* p, size_t bytes, hipStream_t s) { return hipMemsetAsync(p, 0, bytes, s) == hipSuccess ? 0 : 2; }
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+int main(int argc, char** argv) {
+  const int B = argc > 1 ? atoi(argv[1]) : 64, fixed = argc > 2 ? atoi(argv[2]) : 0, layers = 12, ctx = 77, vocab = 49408;
+  srand(5);
+  auto dev_f = [&](size_t n, float lo, float hi) {
+    std::vector<float> h(n);
+    for (auto& v : h) v = lo + (hi - lo) * (rand() % 10001) / 10000.f;
+    void* d; hipMalloc(&d, n * 4); hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice); return (float*)d;
+  };
+  ClipArgs a = {};
+  std::vector<long long> tok((size_t)B * ctx, 0);
+  for (int b = 0; b < B; b++) {
+    const int ln = fixed ? fixed : 2 + (b * 71) / (B > 1 ? B - 1 : 1);
+    for (int k = 0; k < ln; k++) tok[(size_t)b * ctx + k] = 1 + rand() % 40000;
+    tok[(size_t)b * ctx] = 49406; tok[(size_t)b * ctx + ln] = 49407;
+  }
+  void* dt; CK(hipMalloc(&dt, tok.size() * 8)); CK(hipMemcpy(dt, tok.data(), tok.size() * 8, hipMemcpyHostToDevice));
+  a.tokens = (const int64_t*)dt; a.tok_emb = dev_f((size_t)vocab * 512, -0.05f, 0.05f); a.pos_emb = dev_f((size_t)ctx * 512, -0.02f, 0.02f);
+  a.ctx = ctx; a.vocab = vocab; a.layers = layers; a.frags_per_wave = clip_frags_per_wave(layers);
+  const size_t wb = (size_t)8 * a.frags_per_wave * 1024;
+  void* ws; CK(hipMalloc(&ws, wb));
+  { std::vector<unsigned short> h(wb / 2); for (auto& v : h) { _Float16 f = (_Float16)(((rand() % 2001) / 1000.f - 1.f) * 0.03f); v = __builtin_bit_cast(unsigned short, f); }
+    CK(hipMemcpy(ws, h.data(), wb, hipMemcpyHostToDevice)); }
+  a.wstream = (const uint4*)ws;
+  for (int l = 0; l < layers; l++)
+    a.L[l] = ClipLayerP{dev_f(512, 1.f, 1.f), dev_f(512, 0.f, 0.f), dev_f(512, 1.f, 1.f), dev_f(512, 0.f, 0.f), dev_f(1536, -0.01f, 0.01f),
+                        dev_f(512, -0.01f, 0.01f), dev_f(2048, -0.01f, 0.01f), dev_f(512, -0.01f, 0.01f)};
+  void* E; CK(hipMalloc(&E, (size_t)B * 512 * 4)); a.E = (float*)E;
+  long long* prof; CK(hipMalloc((void**)&prof, (size_t)B * 8 * 8)); CK(hipMemset(prof, 0, (size_t)B * 64)); a.prof = prof;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&clip_tower_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, CT_LDS));
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipStream_t s1; hipStreamCreateWithFlags(&s1, hipStreamNonBlocking);
+  auto run = [&]() { hipLaunchKernelGGL(clip_tower_kernel<true>, dim3(B), dim3(CT_TH), CT_LDS, s1, a); };
+  for (int it = 0; it < 2; it++) run();
+  CK(hipDeviceSynchronize());
+  hipEventRecord(e0, s1);
+  for (int it = 0; it < 5; it++) run();
+  hipEventRecord(e1, s1); CK(hipDeviceSynchronize());
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  printf("clip_tower_kernel: %d dialogs: %.1f us per launch\n", B, ms * 200.f);
+  std::vector<long long> hp((size_t)B * 8); CK(hipMemcpy(hp.data(), prof, hp.size() * 8, hipMemcpyDeviceToHost));
+  std::vector<float> he((size_t)B * 512); CK(hipMemcpy(he.data(), E, he.size() * 4, hipMemcpyDeviceToHost));
+  double cs = 0; for (float v : he) cs += v; printf("  output checksum %.6f\n", cs);
+  static const char* NAME[8] = {"ln1", "in_proj", "attention", "out_proj", "ln2", "c_fc + gelu", "c_proj", "bias / loop"};
+  double tot_mean = 0, tot_max = 0;
+  for (int k = 0; k < 8; k++) {
+    double s = 0, mx = 0; for (int b = 0; b < B; b++) { s += (double)hp[b * 8 + k]; if ((double)hp[b * 8 + k] > mx) mx = (double)hp[b * 8 + k]; }
+    printf("  %-12s mean %9.0f  max %9.0f cycles per layer\n", NAME[k], s / B / layers, mx / layers);
+    tot_mean += s / B / layers; tot_max += mx / layers;
+  }
+  printf("  per layer: mean %.0f, sum of maxima %.0f cycles\n", tot_mean, tot_max);
+  return 0;
+}
