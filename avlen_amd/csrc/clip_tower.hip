@@ -45,12 +45,13 @@ struct ClipArgs {
   const int64_t* tokens; const float* tok_emb; const float* pos_emb; const uint4* wstream; float* E;
   int ctx, vocab, layers; long frags_per_wave;              // stream stride of a wave (fragments)
   ClipLayerP L[12];
-  long long* prof;                                          // lab builds (AVLEN_CT_PROF): per-workgroup phase cycle totals [B][8]
+  long long* prof;                                          // lab builds (AVLEN_CT_PROF): per-workgroup phase cycle totals [2 B][8]
+  unsigned* flags; char* xchg; int B;                       // K / V hand-off of the 5-tile dialogs: flag word per dialog, slots
 };
 #ifdef AVLEN_CT_PROF
 #define CT_T0() long long ct_t = __builtin_amdgcn_s_memtime(); long long ct_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define CT_PH(k) do { const long long n_ = __builtin_amdgcn_s_memtime(); ct_acc[k] += n_ - ct_t; ct_t = n_; } while (0)
-#define CT_DUMP() do { if (a.prof && tid == 0) for (int k_ = 0; k_ < 8; k_++) a.prof[(long)b * 8 + k_] = ct_acc[k_]; } while (0)
+#define CT_DUMP() do { if (a.prof && tid == 0) for (int k_ = 0; k_ < 8; k_++) a.prof[(long)blockIdx.x * 8 + k_] = ct_acc[k_]; } while (0)
 #else
 #define CT_T0() do { } while (0)
 #define CT_PH(k) do { } while (0)
@@ -136,22 +137,75 @@ __device__ __forceinline__ void clip_attn_unit(char* lds, int ah, int mt, int r1
   }
 }
 
-// the whole tower for one dialog of CT_MT live 16-row tiles (CT_MT = ceil(L / 16): a shorter dialog skips the dead tiles' work --
-// one straight-line instance per tile count)
-template <bool F16, int CT_MT>
+// ---- K / V hand-off between the two workgroups of a 5-tile dialog (cdna_hip_programming.md, Guideline 16, form R1) ----
+// slot (dialog, layer, head pair): [k | v][head of the pair][row 0 .. 47][64] 16-bit = 24,576 B.  Producer: write-through (agent-scope
+// relaxed atomic) 8-byte stores, every storing wave drains, workgroup barrier, ONE lane stores the sequence number to the dialog's
+// flag word.  Consumer: one lane polls the flag, ONE agent-scope acquire, barrier, then plain loads.  The flags are zeroed by a
+// memset node in front of every launch; a slot is written once per launch, so the producer never has to wait for the consumer.
+constexpr int CT_XROWS = 48, CT_SLOT = 2 * 2 * CT_XROWS * 128, CT_SLOTS = 48;
+typedef __attribute__((address_space(1))) unsigned gu32;
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+__device__ __forceinline__ int clip_kv_lds(int idx16) {      // 16-byte chunk index of a slot -> byte offset of the chunk in LDS
+  const int col = idx16 & 7, row = (idx16 >> 3) % CT_XROWS, head = (idx16 / (8 * CT_XROWS)) & 1, kv = idx16 / (16 * CT_XROWS);
+  return (kv ? VS_OFF + head * 96 * QK_ROW : KS_OFF + head * 80 * QK_ROW) + row * QK_ROW + col * 16;
+}
+__device__ __forceinline__ void clip_publish_kv(const ClipArgs& a, const char* lds, int b, int seq0, int tid) {
+  gu64* slot = (gu64*)(a.xchg + ((long)b * CT_SLOTS + seq0) * CT_SLOT);
+#pragma unroll
+  for (int k = 0; k < CT_SLOT / 16 / CT_TH; k++) {
+    const int c = tid + k * CT_TH;
+    const uint4 v = *reinterpret_cast<const uint4*>(lds + clip_kv_lds(c));
+    __hip_atomic_store(slot + 2 * c, ((unsigned long long)v.y << 32) | v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(slot + 2 * c + 1, ((unsigned long long)v.w << 32) | v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave: its stores have left
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store((gu32*)(a.flags + b), (unsigned)(seq0 + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool clip_fetch_kv(const ClipArgs& a, char* lds, int b, int seq0, int tid) {
+  volatile int* ok = reinterpret_cast<volatile int*>(lds + PART_OFF);      // the LayerNorm partials are idle here
+  if (tid == 0) {
+    unsigned spins = 0;
+    int good = 1;
+    while (__hip_atomic_load((gu32*)(a.flags + b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(seq0 + 1)) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1u << 24)) { good = 0; break; }        // seconds without the producer: give up (garbage output) rather than hang
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    *ok = good;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (*ok == 0) return false;
+  const uint4* slot = reinterpret_cast<const uint4*>(a.xchg + ((long)b * CT_SLOTS + seq0) * CT_SLOT);
+#pragma unroll
+  for (int k = 0; k < CT_SLOT / 16 / CT_TH; k++) {
+    const int c = tid + k * CT_TH;
+    *reinterpret_cast<uint4*>(lds + clip_kv_lds(c)) = slot[c];
+  }
+  lds_barrier();
+  return true;
+}
+
+// the whole tower for the 16-row tiles [I0, CT_MT) of one dialog (CT_MT = ceil(L / 16) live tiles: a shorter dialog skips the dead
+// tiles' work -- one straight-line instance per tile range).  A dialog of 5 tiles is carried by TWO workgroups: rows 0 .. 47 (I0 = 0,
+// CT_MT = 3, PUB: after every head pair's in_proj it publishes its K / V rows) and rows 48 .. 79 (I0 = 3, CT_MT = 5: it fetches those
+// rows before its attention) -- the mask is causal, so the hand-off is one-directional and the first workgroup never waits.
+template <bool F16, int I0, int CT_MT, bool PUB>
 __device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, const int64_t* __restrict__ tk, int L, int b) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, q = lane >> 4;
   const int eot = L - 1;
+  constexpr int NT = CT_MT - I0;                            // this workgroup's tiles: rows 16 (I0 + i) + r16
   // weight fragments in flight per wave (every phase's length is a multiple of it): the short-dialog instances have the registers
   // for a deeper ring
-  constexpr int CT_RING = CT_MT <= 3 ? 16 : 8;
+  constexpr int CT_RING = NT <= 3 ? 16 : 8;
   // the V images start zeroed: rows past the live tiles are read (with zero probabilities) by the 32-key steps of P V
   for (int i = tid; i < 2 * 96 * QK_ROW / 16; i += CT_TH) *reinterpret_cast<uint4*>(lds + VS_OFF + i * 16) = make_uint4(0u, 0u, 0u, 0u);
   // ---- residual stream: token + positional embedding; lane (r16, q) of wave w holds rows 16 i + r16, columns 64 w + 16 j + 4 q ..
-  f32x4 xr[CT_MT][4];
+  f32x4 xr[NT][4];
 #pragma unroll
-  for (int i = 0; i < CT_MT; i++) {
-    const int m = 16 * i + r16;
+  for (int i = 0; i < NT; i++) {
+    const int m = 16 * (I0 + i) + r16;
     long id = m < L ? tk[m] : 0;
     id = id < 0 ? 0 : (id >= a.vocab ? a.vocab - 1 : id);
 #pragma unroll
@@ -187,7 +241,7 @@ __device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, co
       bv[j] = *reinterpret_cast<const float4*>(be + 64 * wave + 16 * j + 4 * q);
     }
 #pragma unroll
-    for (int i = 0; i < CT_MT; i++) {
+    for (int i = 0; i < NT; i++) {
       f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};                // two columns per instruction (v_pk_add_f32 / v_pk_fma_f32)
 #pragma unroll
       for (int j = 0; j < 4; j++) {
@@ -198,12 +252,12 @@ __device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, co
       float a1 = s1[0] + s1[1], a2 = s2[0] + s2[1];
       a1 += __shfl_xor(a1, 16, 64); a2 += __shfl_xor(a2, 16, 64);
       a1 += __shfl_xor(a1, 32, 64); a2 += __shfl_xor(a2, 32, 64);
-      if (q == 0) *reinterpret_cast<float2*>(&part[((16 * i + r16) * 8 + wave) * 2]) = make_float2(a1, a2);
+      if (q == 0) *reinterpret_cast<float2*>(&part[((16 * (I0 + i) + r16) * 8 + wave) * 2]) = make_float2(a1, a2);
     }
     lds_barrier();
 #pragma unroll
-    for (int i = 0; i < CT_MT; i++) {
-      const int m = 16 * i + r16;
+    for (int i = 0; i < NT; i++) {
+      const int m = 16 * (I0 + i) + r16;
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int k = 0; k < 4; k++) {                         // fixed order over the 8 waves: bit-reproducible
@@ -237,20 +291,20 @@ __device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, co
     for (int hp = 0; hp < 4; hp++) {
       // ---- in_proj of the pair: 24 column tiles (head a: q 4 | k 4 | v 4), wave w takes tiles 3 w .. 3 w + 2; K = 512
       {
-        f32x4 acc[CT_MT][3];
+        f32x4 acc[NT][3];
 #pragma unroll
-        for (int i = 0; i < CT_MT; i++)
+        for (int i = 0; i < NT; i++)
 #pragma unroll
           for (int t = 0; t < 3; t++) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         // the activation fragments of k-step ks + 1 are requested before the MFMAs of k-step ks (LDS latency off the critical path)
-        uint4 xf[2][CT_MT];
+        uint4 xf[2][NT];
 #pragma unroll
-        for (int i = 0; i < CT_MT; i++) xf[0][i] = lds16(lds + XN_OFF + (16 * i + r16) * XN_ROW + q * 16);
+        for (int i = 0; i < NT; i++) xf[0][i] = lds16(lds + XN_OFF + (16 * (I0 + i) + r16) * XN_ROW + q * 16);
 #pragma unroll
         for (int ks = 0; ks < 16; ks++) {
           if (ks + 1 < 16) {
 #pragma unroll
-            for (int i = 0; i < CT_MT; i++) xf[(ks + 1) & 1][i] = lds16(lds + XN_OFF + (16 * i + r16) * XN_ROW + (4 * (ks + 1) + q) * 16);
+            for (int i = 0; i < NT; i++) xf[(ks + 1) & 1][i] = lds16(lds + XN_OFF + (16 * (I0 + i) + r16) * XN_ROW + (4 * (ks + 1) + q) * 16);
           }
 #pragma unroll
           for (int t = 0; t < 3; t++) {
@@ -259,7 +313,7 @@ __device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, co
             CT_TAKE(w, f % CT_RING);
             CT_STEP(f);
 #pragma unroll
-            for (int i = 0; i < CT_MT; i++) acc[i][t] = cmma<F16>(w, xf[ks & 1][i], acc[i][t]);
+            for (int i = 0; i < NT; i++) acc[i][t] = cmma<F16>(w, xf[ks & 1][i], acc[i][t]);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -272,35 +326,32 @@ __device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, co
           const float sc = ty == 0 ? 0.125f : 1.f;
           char* base = lds + (ty == 0 ? QO_OFF + ah * 80 * QK_ROW : ty == 1 ? KS_OFF + ah * 80 * QK_ROW : VS_OFF + ah * 96 * QK_ROW);
 #pragma unroll
-          for (int i = 0; i < CT_MT; i++) {
-            const int m = 16 * i + r16;
+          for (int i = 0; i < NT; i++) {
+            const int m = 16 * (I0 + i) + r16;
             const uint2 o = cvt4<F16>((acc[i][t][0] + bi.x) * sc, (acc[i][t][1] + bi.y) * sc, (acc[i][t][2] + bi.z) * sc, (acc[i][t][3] + bi.w) * sc);
             *reinterpret_cast<uint2*>(base + m * QK_ROW + (16 * sub + 4 * q) * 2) = o;
           }
         }
       }
       lds_barrier();
+      if (PUB) clip_publish_kv(a, lds, b, layer * 4 + hp, tid);
+      if (I0 > 0) { if (!clip_fetch_kv(a, lds, b, layer * 4 + hp, tid)) return; }
       CT_PH(1);
-      // ---- causal attention: units (head of the pair, 16-query tile), branch-free bodies; a wave with two units runs them in one
-      // basic block (two independent dependency chains for the scheduler to interleave: a unit alone is latency-bound)
-      if (wave + 8 < 2 * CT_MT) {
-        clip_attn_unit<F16, CT_MT>(lds, wave / CT_MT, wave % CT_MT, r16, q);
-        clip_attn_unit<F16, CT_MT>(lds, (wave + 8) / CT_MT, (wave + 8) % CT_MT, r16, q);
-      } else if (wave < 2 * CT_MT) {
-        clip_attn_unit<F16, CT_MT>(lds, wave / CT_MT, wave % CT_MT, r16, q);
-      }
+      // ---- causal attention: units (head of the pair, 16-query tile), one per wave and round (two units of a wave in one basic block
+      // -- for the scheduler to interleave -- spilled at 5 tiles and ran slower)
+      for (int u = wave; u < 2 * NT; u += 8) clip_attn_unit<F16, CT_MT>(lds, u / NT, I0 + u % NT, r16, q);
       lds_barrier();
       CT_PH(2);
       // ---- out_proj, the pair's 128 input columns: x += O_pair W_out[:, 128 hp ..]^T (wave w: its 64 output columns, 4 tiles)
-      uint4 of[2][CT_MT];
+      uint4 of[2][NT];
 #pragma unroll
-      for (int i = 0; i < CT_MT; i++) of[0][i] = lds16(lds + QO_OFF + (16 * i + r16) * QK_ROW + q * 16);
+      for (int i = 0; i < NT; i++) of[0][i] = lds16(lds + QO_OFF + (16 * (I0 + i) + r16) * QK_ROW + q * 16);
 #pragma unroll
       for (int ks = 0; ks < 4; ks++) {
         if (ks + 1 < 4) {
 #pragma unroll
-          for (int i = 0; i < CT_MT; i++)
-            of[(ks + 1) & 1][i] = lds16(lds + QO_OFF + ((ks + 1) >> 1) * 80 * QK_ROW + (16 * i + r16) * QK_ROW + (4 * ((ks + 1) & 1) + q) * 16);
+          for (int i = 0; i < NT; i++)
+            of[(ks + 1) & 1][i] = lds16(lds + QO_OFF + ((ks + 1) >> 1) * 80 * QK_ROW + (16 * (I0 + i) + r16) * QK_ROW + (4 * ((ks + 1) & 1) + q) * 16);
         }
 #pragma unroll
         for (int t = 0; t < 4; t++) {
@@ -309,7 +360,7 @@ __device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, co
           CT_TAKE(w, f % CT_RING);
           CT_STEP(f);
 #pragma unroll
-          for (int i = 0; i < CT_MT; i++) xr[i][t] = cmma<F16>(w, of[ks & 1][i], xr[i][t]);
+          for (int i = 0; i < NT; i++) xr[i][t] = cmma<F16>(w, of[ks & 1][i], xr[i][t]);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -321,7 +372,7 @@ __device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, co
 #pragma unroll
       for (int j = 0; j < 4; j++) bo[j] = *reinterpret_cast<const float4*>(P.b_out + 64 * wave + 16 * j + 4 * q);
 #pragma unroll
-      for (int i = 0; i < CT_MT; i++)
+      for (int i = 0; i < NT; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) { xr[i][j][0] += bo[j].x; xr[i][j][1] += bo[j].y; xr[i][j][2] += bo[j].z; xr[i][j][3] += bo[j].w; }
     }
@@ -331,17 +382,17 @@ __device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, co
 #pragma unroll 1
     for (int c = 0; c < 8; c++) {
       {
-        f32x4 acc[CT_MT][2];
+        f32x4 acc[NT][2];
 #pragma unroll
-        for (int i = 0; i < CT_MT; i++) { acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
-        uint4 xf[2][CT_MT];
+        for (int i = 0; i < NT; i++) { acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
+        uint4 xf[2][NT];
 #pragma unroll
-        for (int i = 0; i < CT_MT; i++) xf[0][i] = lds16(lds + XN_OFF + (16 * i + r16) * XN_ROW + q * 16);
+        for (int i = 0; i < NT; i++) xf[0][i] = lds16(lds + XN_OFF + (16 * (I0 + i) + r16) * XN_ROW + q * 16);
 #pragma unroll
         for (int ks = 0; ks < 16; ks++) {
           if (ks + 1 < 16) {
 #pragma unroll
-            for (int i = 0; i < CT_MT; i++) xf[(ks + 1) & 1][i] = lds16(lds + XN_OFF + (16 * i + r16) * XN_ROW + (4 * (ks + 1) + q) * 16);
+            for (int i = 0; i < NT; i++) xf[(ks + 1) & 1][i] = lds16(lds + XN_OFF + (16 * (I0 + i) + r16) * XN_ROW + (4 * (ks + 1) + q) * 16);
           }
 #pragma unroll
           for (int t = 0; t < 2; t++) {
@@ -350,7 +401,7 @@ __device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, co
             CT_TAKE(w, f % CT_RING);
             CT_STEP(f);
 #pragma unroll
-            for (int i = 0; i < CT_MT; i++) acc[i][t] = cmma<F16>(w, xf[ks & 1][i], acc[i][t]);
+            for (int i = 0; i < NT; i++) acc[i][t] = cmma<F16>(w, xf[ks & 1][i], acc[i][t]);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -358,8 +409,8 @@ __device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, co
         for (int t = 0; t < 2; t++) {
           const float4 bf = *reinterpret_cast<const float4*>(P.b_fc + 256 * c + 32 * wave + 16 * t + 4 * q);
 #pragma unroll
-          for (int i = 0; i < CT_MT; i++) {
-            const int m = 16 * i + r16;
+          for (int i = 0; i < NT; i++) {
+            const int m = 16 * (I0 + i) + r16;
             float v[4] = {acc[i][t][0] + bf.x, acc[i][t][1] + bf.y, acc[i][t][2] + bf.z, acc[i][t][3] + bf.w};
 #pragma unroll
             for (int r = 0; r < 4; r++) v[r] = v[r] * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v[r]));      // QuickGELU (1-ulp reciprocal)
@@ -369,14 +420,14 @@ __device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, co
       }
       lds_barrier();
       CT_PH(5);
-      uint4 hf[2][CT_MT];
+      uint4 hf[2][NT];
 #pragma unroll
-      for (int i = 0; i < CT_MT; i++) hf[0][i] = lds16(lds + HC_OFF + (16 * i + r16) * HC_ROW + q * 16);
+      for (int i = 0; i < NT; i++) hf[0][i] = lds16(lds + HC_OFF + (16 * (I0 + i) + r16) * HC_ROW + q * 16);
 #pragma unroll
       for (int ks = 0; ks < 8; ks++) {
         if (ks + 1 < 8) {
 #pragma unroll
-          for (int i = 0; i < CT_MT; i++) hf[(ks + 1) & 1][i] = lds16(lds + HC_OFF + (16 * i + r16) * HC_ROW + (4 * (ks + 1) + q) * 16);
+          for (int i = 0; i < NT; i++) hf[(ks + 1) & 1][i] = lds16(lds + HC_OFF + (16 * (I0 + i) + r16) * HC_ROW + (4 * (ks + 1) + q) * 16);
         }
 #pragma unroll
         for (int t = 0; t < 4; t++) {
@@ -385,7 +436,7 @@ __device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, co
           CT_TAKE(w, f % CT_RING);
           CT_STEP(f);
 #pragma unroll
-          for (int i = 0; i < CT_MT; i++) xr[i][t] = cmma<F16>(w, hf[ks & 1][i], xr[i][t]);
+          for (int i = 0; i < NT; i++) xr[i][t] = cmma<F16>(w, hf[ks & 1][i], xr[i][t]);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -397,15 +448,15 @@ __device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, co
 #pragma unroll
       for (int j = 0; j < 4; j++) bp[j] = *reinterpret_cast<const float4*>(P.b_proj + 64 * wave + 16 * j + 4 * q);
 #pragma unroll
-      for (int i = 0; i < CT_MT; i++)
+      for (int i = 0; i < NT; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) { xr[i][j][0] += bp[j].x; xr[i][j][1] += bp[j].y; xr[i][j][2] += bp[j].z; xr[i][j][3] += bp[j].w; }
     }
   }
   // ---- the EOT row of the residual stream (ln_final and the projection follow as their own small launches)
 #pragma unroll
-  for (int i = 0; i < CT_MT; i++)
-    if (16 * i + r16 == eot) {
+  for (int i = 0; i < NT; i++)
+    if (16 * (I0 + i) + r16 == eot) {
 #pragma unroll
       for (int j = 0; j < 4; j++)
         *reinterpret_cast<float4*>(a.E + (long)b * 512 + 64 * wave + 16 * j + 4 * q) = make_float4(xr[i][j][0], xr[i][j][1], xr[i][j][2], xr[i][j][3]);
@@ -415,6 +466,9 @@ __device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, co
 #undef CT_STEP
 }
 
+// Measured and rejected: the same body on FOUR waves (one per SIMD, 512 registers each: residual stream + projection accumulators in
+// the accumulator file, a 16-32 fragment ring, no spills at <= 3 tiles) -- 1060 / 1583 us at 40 / 72 tokens against 880 / 1200 on eight
+// waves: a lone wave per SIMD cannot hide its own LDS / waitcnt / MFMA-issue latencies.
 // Measured and rejected (tools/clip_lab.hip, 64 dialogs): eight extra "L2 warmer" workgroups (one per XCD) streaming the same bytes
 // 0.75 MB ahead of the dialogs, paced by per-dialog progress words -- 925 -> 1236 us: a dialog's stream already runs at the CU's
 // ingest ceiling (~43 of ~51 B/clk), not at the Infinity-Cache latency, and the progress stores cost more than the warm lines save.
@@ -422,7 +476,10 @@ template <bool F16>
 __global__ __launch_bounds__(CT_TH) void clip_tower_kernel(ClipArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int lane = threadIdx.x & 63;
-  const int b = blockIdx.x, ctx = a.ctx;
+  // workgroups [0, B): the second halves of the 5-tile dialogs (dispatched FIRST: the idle ones exit at once, the real ones must not
+  // queue for a CU behind the first halves they depend on); [B, 2 B): the dialogs (id % 8 == dialog % 8 when 8 | B: same XCD)
+  const int role = (int)blockIdx.x < a.B ? 1 : 0;
+  const int b = (int)blockIdx.x - (1 - role) * a.B, ctx = a.ctx;
   const int64_t* __restrict__ tk = a.tokens + (long)b * ctx;
   // ---- live length: tokens up to the EOT (= first position of the largest id, as torch.argmax) -- nothing after it can reach
   // the output through the causal mask
@@ -437,12 +494,17 @@ __global__ __launch_bounds__(CT_TH) void clip_tower_kernel(ClipArgs a) {
     }
     L = __builtin_amdgcn_readfirstlane(bi) + 1;
   }
-  switch ((L + 15) >> 4) {
-    case 1: clip_tower_body<F16, 1>(a, lds, tk, L, b); break;
-    case 2: clip_tower_body<F16, 2>(a, lds, tk, L, b); break;
-    case 3: clip_tower_body<F16, 3>(a, lds, tk, L, b); break;
-    case 4: clip_tower_body<F16, 4>(a, lds, tk, L, b); break;
-    default: clip_tower_body<F16, 5>(a, lds, tk, L, b); break;
+  const int mt = (L + 15) >> 4;
+  if (role) {
+    if (mt >= 5) clip_tower_body<F16, 3, 5, false>(a, lds, tk, L, b);
+    return;
+  }
+  switch (mt) {
+    case 1: clip_tower_body<F16, 0, 1, false>(a, lds, tk, L, b); break;
+    case 2: clip_tower_body<F16, 0, 2, false>(a, lds, tk, L, b); break;
+    case 3: clip_tower_body<F16, 0, 3, false>(a, lds, tk, L, b); break;
+    case 4: clip_tower_body<F16, 0, 4, false>(a, lds, tk, L, b); break;
+    default: clip_tower_body<F16, 0, 3, true>(a, lds, tk, L, b); break;
   }
 }
 
@@ -520,12 +582,17 @@ extern "C" int avlen_clip_pack_stream(const avlen_clip_text* p, void* dst, int f
 }
 
 // X rows of the residual stream at each dialog's EOT token (B x 512 fp32) through the 12 blocks in one launch
-int avlen_clip_tower_stream_fwd(const avlen_clip_text* p, const int64_t* tokens, float* E, int B, int f16, hipStream_t st) {
-  if (!clip_stream_shape_ok(p) || !p->wstream || B <= 0) return AVLEN_ERR_ARG;
+size_t avlen_clip_tower_stream_ws_bytes(int B) { return 4096 + (size_t)B * CT_SLOTS * CT_SLOT; }
+
+int avlen_clip_tower_stream_fwd(const avlen_clip_text* p, const int64_t* tokens, float* E, int B, int f16, void* ws, size_t ws_bytes,
+                                hipStream_t st) {
+  if (!clip_stream_shape_ok(p) || !p->wstream || B <= 0 || B > 1024 || !ws || ws_bytes < avlen_clip_tower_stream_ws_bytes(B)) return AVLEN_ERR_ARG;
+  if (avlen_zero_bytes(ws, 4096, st) != AVLEN_OK) return AVLEN_ERR_LAUNCH;       // the flag words (own block at the workspace's start)
   ClipArgs a = {};
   a.tokens = tokens; a.tok_emb = p->tok_emb; a.pos_emb = p->pos_emb; a.wstream = (const uint4*)p->wstream; a.E = E;
   a.ctx = p->ctx; a.vocab = p->vocab; a.layers = p->layers; a.frags_per_wave = clip_frags_per_wave(p->layers);
-  const int grid = B;
+  a.flags = (unsigned*)ws; a.xchg = (char*)ws + 4096; a.B = B;
+  const int grid = 2 * B;
   for (int l = 0; l < p->layers; l++) {
     const avlen_clip_block& b = p->block[l];
     a.L[l] = ClipLayerP{b.ln1.g, b.ln1.b, b.ln2.g, b.ln2.b, b.attn.in_proj.b, b.attn.out_proj.b, b.fc.b, b.proj.b};

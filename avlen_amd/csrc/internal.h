@@ -136,4 +136,6 @@ int avlen_tower_x3_fwd(const avlen_resnet18* const* nets, const void* const* img
                        const float* divisors, const int* row_index, void* const* Y, int groups, int B, int S, void* ws,
                        size_t ws_bytes, hipStream_t stream);
 // clip_tower.hip: the 12 blocks of the CLIP text tower in one sequence-stationary launch -> E[b] = residual row at the EOT token
-int avlen_clip_tower_stream_fwd(const avlen_clip_text* p, const int64_t* tokens, float* E, int B, int f16, hipStream_t st);
+size_t avlen_clip_tower_stream_ws_bytes(int B);
+int avlen_clip_tower_stream_fwd(const avlen_clip_text* p, const int64_t* tokens, float* E, int B, int f16, void* ws, size_t ws_bytes,
+                                hipStream_t st);

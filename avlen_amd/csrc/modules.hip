@@ -1910,9 +1910,10 @@ extern "C" int avlen_clip_text_fwd(const avlen_clip_text* p, const int64_t* toke
     const avlen_clip_block& b = p->block[l];
     fast = lin16_ok(b.attn.in_proj) && lin16_ok(b.attn.out_proj) && lin16_ok(b.fc) && lin16_ok(b.proj);
   }
-  if (fast && p->wstream && avlen_clip_stream_bytes(p)) {
+  if (fast && p->wstream && avlen_clip_stream_bytes(p) && (size_t)((char*)E - (char*)X) >= avlen_clip_tower_stream_ws_bytes(B)) {
     // the 12 blocks as ONE sequence-stationary launch (clip_tower.hip) -> the EOT rows; ln_final + projection as before
-    TRY(avlen_clip_tower_stream_fwd(p, tokens, E, B, f16 ? 1 : 0, st));
+    // (its hand-off slots live in the activation buffers of the launch-per-GEMM path: X .. Fh, unused here)
+    TRY(avlen_clip_tower_stream_fwd(p, tokens, E, B, f16 ? 1 : 0, X, (size_t)((char*)E - (char*)X), st));
     TRY(avlen_layernorm_fwd(E, nullptr, p->ln_final.g, p->ln_final.b, E2, nullptr, nullptr, B, wd, 1e-5f, st));
     return clip_project(p, E2, out, B, f16 ? AVLEN_PREC_BF16X3 : prec, gws, st);
   }

@@ -15,7 +15,6 @@
 // activation fragments are re-read from LDS per tap -- with three MFMAs per fragment pair the matrix pipe, not LDS, is the bound
 // (the bf16 kernels are input-row stationary with register-resident weights: 2 x 144 registers would not fit here).
 #include "common.h"
-#include <stdlib.h>
 #include "../../include/avlen_hip.h"
 #include "internal.h"
 #include "tower_util.h"
@@ -1075,7 +1074,7 @@ static int launch_tower_x3(TowerArgs& a, size_t q_bytes, hipStream_t stream) {
   }
   if (avlen_zero_bytes(a.q, q_bytes, stream) != AVLEN_OK) return AVLEN_ERR_LAUNCH;
   int cap = n_cu;
-  { static int env_cap = -1; if (env_cap < 0) { const char* e = getenv("AVLEN_TOWER_WGS"); env_cap = e ? atoi(e) : 0; } if (env_cap > 0 && env_cap < cap) cap = env_cap; }
+  { static long lab_cap = -1; if (lab_cap < 0) lab_cap = avlen_knob("AVLEN_TOWER_WGS", 0); if (lab_cap > 0 && lab_cap < cap) cap = (int)lab_cap; }   // lab builds only
   const int grid = 2 * a.n < cap ? 2 * a.n : cap;           // one workgroup per CU (LDS): more would only queue behind them
   hipLaunchKernelGGL(tower_x3_kernel, dim3(grid), dim3(RTH), TOWER_LDS, stream, a);
   return avlen_launch_status();

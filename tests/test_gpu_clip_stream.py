@@ -1,0 +1,59 @@
+"""The opt-in one-launch CLIP text tower (csrc/clip_tower.hip, AVLEN_CLIP_STREAM=1: sequence-stationary workgroups, per-wave weight
+streams, two workgroups with a K / V hand-off for dialogs of 5 row tiles) against the default launch-per-GEMM tower and the fp32
+path: same 16-bit formats, so both fast towers must sit at the same distance from fp32; dialog lengths cover every tile count
+(1 .. 5 tiles, i.e. every kernel instance incl. the split one) and the extremes (EOT at position 1 and at 76)."""
+import os
+
+import pytest
+import torch
+
+from avlen_amd import policy as P
+from avlen_amd.spaces import savi_observation_space, ActionSpace, SMT_KW
+
+pytestmark = pytest.mark.gpu
+
+
+def _tokens(n, gen):
+    toks = torch.zeros(n, 77, dtype=torch.long)
+    lens = [1, 76, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 72] + [int(x) for x in torch.randint(2, 76, (n - 15,), generator=gen)]
+    for b, ln in enumerate(lens[:n]):
+        toks[b, :ln] = torch.randint(1, 49406, (ln,), generator=gen)
+        toks[b, 0] = 49406
+        toks[b, ln] = 49407
+    return toks.cuda()
+
+
+def _policy(mode, stream, sd=None):
+    os.environ["AVLEN_CLIP_STREAM"] = "1" if stream else "0"
+    try:
+        torch.manual_seed(3)
+        pol = P.AudioNavDialogPolicy(savi_observation_space((65, 26, 2)), ActionSpace(4), pretraining=False, num_steps=3,
+                                     precision=mode, **SMT_KW).to("cuda")
+        if sd is not None:
+            pol.load_state_dict(sd)
+        pol._engine()
+    finally:
+        os.environ.pop("AVLEN_CLIP_STREAM", None)
+    return pol
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
+def test_stream_tower_matches_the_gemm_chain_tower(mode):
+    gen = torch.Generator().manual_seed(11)
+    tok = _tokens(24, gen)
+    ref_pol = _policy("fp32", False)
+    sd = ref_pol.state_dict()
+    ref = ref_pol.net.encode_text(ref_pol, tok).clone()
+    chain_pol, stream_pol = _policy(mode, False, sd), _policy(mode, True, sd)
+    assert not chain_pol._engine()["clip"].wstream and stream_pol._engine()["clip"].wstream
+    chain = chain_pol.net.encode_text(chain_pol, tok).clone()
+    out = stream_pol.net.encode_text(stream_pol, tok).clone()
+    again = stream_pol.net.encode_text(stream_pol, tok).clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    assert torch.equal(out, again)                                  # fixed-order reductions: bit-reproducible
+    e_chain, e_stream = float((chain - ref).abs().max()), float((out - ref).abs().max())
+    scale = float(ref.abs().max())
+    print(f"{mode}: |chain - fp32| {e_chain:.3e}  |stream - fp32| {e_stream:.3e}  |stream - chain| {float((out - chain).abs().max()):.3e}  (max |ref| {scale:.3f})")
+    tol = (1e-2 if mode == "bf16x3" else 6e-2) * max(1.0, scale)     # fp16 / bf16 operands through 12 blocks
+    assert e_stream < tol and e_stream < 2.0 * e_chain + 1e-3

@@ -1,13 +1,30 @@
 // Stand-alone lab for csrc/clip_tower.hip: the one-launch CLIP text tower on random weights / tokens (B dialogs with EOT positions
 // spread over 2 .. 72), launch time and the per-phase cycle totals of the slowest and the mean workgroup.  Not part of the library.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -ffp-contract=off -DAVLEN_CT_PROF tools/clip_lab.hip -o tools/bin/clip_lab
-//   tools/bin/clip_lab [B=64] [fixed_len=0]
+//   tools/bin/clip_lab [B=64] [fixed_len=0] [co-runner workgroups=0] [co-runner mode: 1 spin, 2 stream memory]
 #include "../avlen_amd/csrc/clip_tower.hip"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 int avlen_zero_bytes(void* p, size_t bytes, hipStream_t s) { return hipMemsetAsync(p, 0, bytes, s) == hipSuccess ? 0 : 2; }
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+// a co-runner on another stream: `n` workgroups that hold a whole CU each (158 KB of LDS) for ~`us` microseconds, either spinning
+// (mode 1) or streaming a private 4 MB window of memory (mode 2: L2 / Infinity Cache traffic like the visual towers' scratch)
+__global__ __launch_bounds__(512) void corunner_kernel(float4* buf, long per_wg, long long ticks, int mode) {
+  extern __shared__ char sm[];
+  float4* p = buf + (long)blockIdx.x * per_wg;
+  const long long t0 = wall_clock64();
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  long i = threadIdx.x;
+  while (wall_clock64() - t0 < ticks) {
+    if (mode == 2) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) { const float4 v = p[i]; acc.x += v.x; p[i] = make_float4(v.x + 1.f, v.y, v.z, v.w); i += 512; if (i >= per_wg) i = threadIdx.x; }
+    } else __builtin_amdgcn_s_sleep(64);
+  }
+  if (acc.x == 12345.678f) sm[0] = 1;
+}
+
 int main(int argc, char** argv) {
   const int B = argc > 1 ? atoi(argv[1]) : 64, fixed = argc > 2 ? atoi(argv[2]) : 0, layers = 12, ctx = 77, vocab = 49408;
   srand(5);
@@ -35,11 +52,25 @@ int main(int argc, char** argv) {
     a.L[l] = ClipLayerP{dev_f(512, 1.f, 1.f), dev_f(512, 0.f, 0.f), dev_f(512, 1.f, 1.f), dev_f(512, 0.f, 0.f), dev_f(1536, -0.01f, 0.01f),
                         dev_f(512, -0.01f, 0.01f), dev_f(2048, -0.01f, 0.01f), dev_f(512, -0.01f, 0.01f)};
   void* E; CK(hipMalloc(&E, (size_t)B * 512 * 4)); a.E = (float*)E;
-  long long* prof; CK(hipMalloc((void**)&prof, (size_t)B * 8 * 8)); CK(hipMemset(prof, 0, (size_t)B * 64)); a.prof = prof;
+  long long* prof; CK(hipMalloc((void**)&prof, (size_t)2 * B * 8 * 8)); CK(hipMemset(prof, 0, (size_t)2 * B * 64)); a.prof = prof;
+  void* xw; CK(hipMalloc(&xw, avlen_clip_tower_stream_ws_bytes(B))); a.flags = (unsigned*)xw; a.xchg = (char*)xw + 4096; a.B = B;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&clip_tower_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, CT_LDS));
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipStream_t s1; hipStreamCreateWithFlags(&s1, hipStreamNonBlocking);
-  auto run = [&]() { hipLaunchKernelGGL(clip_tower_kernel<true>, dim3(B), dim3(CT_TH), CT_LDS, s1, a); };
+  const int co_n = argc > 3 ? atoi(argv[3]) : 0, co_mode = argc > 4 ? atoi(argv[4]) : 1;
+  hipStream_t s2; hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+  const long per_wg = (4l << 20) / 16;
+  float4* cobuf = nullptr;
+  if (co_n) { CK(hipMalloc((void**)&cobuf, (size_t)co_n * per_wg * 16)); CK(hipMemset(cobuf, 0, (size_t)co_n * per_wg * 16));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&corunner_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024)); }
+  // each timed iteration: co-runner first (it takes its CUs), then the tower; the next iteration waits for both
+  hipEvent_t ec; hipEventCreateWithFlags(&ec, hipEventDisableTiming);
+  auto run = [&]() {
+    if (co_n) hipLaunchKernelGGL(corunner_kernel, dim3(co_n), dim3(512), 158 * 1024, s2, cobuf, per_wg, 70000ll, co_mode);   // ~700 us at 100 MHz
+    hipMemsetAsync(xw, 0, 4096, s1);
+    hipLaunchKernelGGL(clip_tower_kernel<true>, dim3(2 * B), dim3(CT_TH), CT_LDS, s1, a);
+    if (co_n) { hipEventRecord(ec, s2); hipStreamWaitEvent(s1, ec, 0); hipEventRecord(ec, s1); hipStreamWaitEvent(s2, ec, 0); }
+  };
   for (int it = 0; it < 2; it++) run();
   CK(hipDeviceSynchronize());
   hipEventRecord(e0, s1);
@@ -47,14 +78,16 @@ int main(int argc, char** argv) {
   hipEventRecord(e1, s1); CK(hipDeviceSynchronize());
   float ms; hipEventElapsedTime(&ms, e0, e1);
   printf("clip_tower_kernel: %d dialogs: %.1f us per launch\n", B, ms * 200.f);
-  std::vector<long long> hp((size_t)B * 8); CK(hipMemcpy(hp.data(), prof, hp.size() * 8, hipMemcpyDeviceToHost));
+  std::vector<long long> hp((size_t)2 * B * 8); CK(hipMemcpy(hp.data(), prof, hp.size() * 8, hipMemcpyDeviceToHost));
   std::vector<float> he((size_t)B * 512); CK(hipMemcpy(he.data(), E, he.size() * 4, hipMemcpyDeviceToHost));
   double cs = 0; for (float v : he) cs += v; printf("  output checksum %.6f\n", cs);
   static const char* NAME[8] = {"ln1", "in_proj", "attention", "out_proj", "ln2", "c_fc + gelu", "c_proj", "bias / loop"};
   double tot_mean = 0, tot_max = 0;
   for (int k = 0; k < 8; k++) {
-    double s = 0, mx = 0; for (int b = 0; b < B; b++) { s += (double)hp[b * 8 + k]; if ((double)hp[b * 8 + k] > mx) mx = (double)hp[b * 8 + k]; }
-    printf("  %-12s mean %9.0f  max %9.0f cycles per layer\n", NAME[k], s / B / layers, mx / layers);
+    double s = 0, mx = 0, s2 = 0; int n2 = 0;
+    for (int b = B; b < 2 * B; b++) { s += (double)hp[b * 8 + k]; if ((double)hp[b * 8 + k] > mx) mx = (double)hp[b * 8 + k]; }
+    for (int b = 0; b < B; b++) if (hp[b * 8 + 1]) { s2 += (double)hp[b * 8 + k]; n2++; }
+    printf("  %-12s mean %9.0f  max %9.0f cycles per layer | second halves (%d): mean %9.0f\n", NAME[k], s / B / layers, mx / layers, n2, n2 ? s2 / n2 / layers : 0.0);
     tot_mean += s / B / layers; tot_max += mx / layers;
   }
   printf("  per layer: mean %.0f, sum of maxima %.0f cycles\n", tot_mean, tot_max);
