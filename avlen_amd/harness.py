@@ -61,6 +61,14 @@ class Workload:
                                             **kw).to(self.dev) if with_dialog_policy else None)
         if share_encoders and precision in ("bf16", "bf16x3") and self.pi_g is not None and self.pi_l is not None:
             P.share_encoders(self.pi_q, self.pi_g, self.pi_l)
+        # bf16x3: the tower group is ONE persistent launch holding a CU per workgroup, so the text tower launched ahead on its own
+        # stream starts when the towers end.  Reserving CUs (avlen_set_tower_x3_reserved_cus) was measured: 64 reserved CUs bring the
+        # synchronised step from 1.97 to 1.87 ms but the free-running cycle only from 354 to ~348 ms (towers 0.50 -> 0.62 ms, and
+        # the update's tower calls slow down with it) -- inside the noise, so the default stays 0; AVLEN_TOWER_RESERVE=n re-measures.
+        reserve = int(os.environ.get("AVLEN_TOWER_RESERVE", "0"))
+        if reserve:
+            from . import _lib as L
+            L.lib.avlen_set_tower_x3_reserved_cus(reserve)
         self.agent = DDPPO(self.pi_q, clip_param=0.2, ppo_epoch=ppo_epoch, num_mini_batch=num_mini_batch,
                            value_loss_coef=0.5, entropy_coef=0.05, lr=2.5e-4, eps=1e-5, max_grad_norm=0.2,
                            use_normalized_advantage=False)

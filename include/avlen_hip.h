@@ -300,6 +300,9 @@ int avlen_smt_bwd(const avlen_smt* p, const avlen_smt* g, const float* goal, con
 /* Tuning knob: row count from which the training path's Linear products (avlen_smt_fwd with save_for_backward,
  * avlen_smt_bwd, bf16 mode) cast their fp32 operands to bf16 once and run the glds/MFMA GEMM (default 4096 rows). */
 void avlen_set_big_m(long rows);
+/* Scheduling knob of the bf16x3 tower group (one persistent work-queue launch, one workgroup per CU): CUs it leaves free for the
+ * other streams of the step (default 0 = every CU). */
+void avlen_set_tower_x3_reserved_cus(int n);
 /* DialogStateEncoder.single_forward (dialog_state_encoder.py:114-155): x_att (B,d), memory_state (M,B,d),
  * masks (B,M), d_emb (B,d) or NULL, agent_step (B) float, goal (B,d) -> out (B,d). */
 size_t avlen_dialog_workspace_bytes(const avlen_dialog* p, int B, int M);

@@ -6,7 +6,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from avlen_amd.harness import Workload
 
-wl = Workload(64, 150, spectrogram=(257, 101, 2), precision="bf16", pretraining=True)
+wl = Workload(64, 150, spectrogram=(257, 101, 2), precision=os.environ.get("AVLEN_PREC", "bf16x3"), pretraining=True)
 wl.cycle(); wl.cycle()
 S = lambda: (torch.cuda.synchronize(), time.perf_counter())[1]
 for rep in range(2):
