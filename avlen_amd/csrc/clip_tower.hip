@@ -27,7 +27,7 @@ typedef __attribute__((ext_vector_type(4))) _Float16 h16x4;
 
 constexpr int CT_TH = 512, CT_ROWS = 80;
 constexpr int CT_PAD = 16;                                  // padding fragments at the end of a wave's stream (>= the deepest ring)
-constexpr int CT_FRAGS = 768;                               // weight fragments (1 KiB) per wave per layer: 4 x (48 + 16) + 8 x (32 + 32)
+constexpr int CT_FRAGS = 384;                               // weight fragments (1 KiB) per wave, layer and column half: 2 x (48 + 16) + 4 x (32 + 32)
 // LDS map (bytes).  Every image has 16 bytes of padding per row: the 16 rows of an MFMA operand fragment then start in 16 distinct
 // 16-byte bank slots (conflict-free ds_read_b128) with NO address arithmetic -- a k-step is an immediate offset.
 constexpr int XN_ROW = 1024 + 16, QK_ROW = 128 + 16, HC_ROW = 512 + 16;
@@ -46,7 +46,8 @@ struct ClipArgs {
   int ctx, vocab, layers; long frags_per_wave;              // stream stride of a wave (fragments)
   ClipLayerP L[12];
   long long* prof;                                          // lab builds (AVLEN_CT_PROF): per-workgroup phase cycle totals [2 B][8]
-  unsigned* flags; char* xchg; int B;                       // K / V hand-off of the 5-tile dialogs: flag word per dialog, slots
+  unsigned* flags; char* xchg; int B;                       // K / V hand-off of the 5-tile dialogs: flag word per (dialog, column half), slots
+  unsigned* xflags; char* xslots;                           // partial-sum exchange between the two column halves: flag per workgroup, 2 slots each
 };
 #ifdef AVLEN_CT_PROF
 #define CT_T0() long long ct_t = __builtin_amdgcn_s_memtime(); long long ct_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
@@ -142,7 +143,7 @@ __device__ __forceinline__ void clip_attn_unit(char* lds, int ah, int mt, int r1
 // relaxed atomic) 8-byte stores, every storing wave drains, workgroup barrier, ONE lane stores the sequence number to the dialog's
 // flag word.  Consumer: one lane polls the flag, ONE agent-scope acquire, barrier, then plain loads.  The flags are zeroed by a
 // memset node in front of every launch; a slot is written once per launch, so the producer never has to wait for the consumer.
-constexpr int CT_XROWS = 48, CT_SLOT = 2 * 2 * CT_XROWS * 128, CT_SLOTS = 48;
+constexpr int CT_XROWS = 48, CT_SLOT = 2 * 2 * CT_XROWS * 128, CT_SLOTS = 24;      // slots per (dialog, column half): layer x its 2 head pairs
 typedef __attribute__((address_space(1))) unsigned gu32;
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 __device__ __forceinline__ int clip_kv_lds(int idx16) {      // 16-byte chunk index of a slot -> byte offset of the chunk in LDS
@@ -187,12 +188,69 @@ __device__ __forceinline__ bool clip_fetch_kv(const ClipArgs& a, char* lds, int 
   return true;
 }
 
+// ---- partial-sum exchange between the two COLUMN halves of a dialog (same Guideline-16 form, symmetric) ----
+// Every dialog (every row half of a 5-tile dialog) is carried by two workgroups that split the heads and the MLP's hidden units, i.e.
+// the WEIGHT STREAM: a CU's ingest bounds one workgroup at ~47 us per 6.3 MB layer, so each streams half.  Twice per layer both hold
+// a partial of the new residual stream over all 512 columns (half 0: x + its partial, half 1: its partial alone); each writes its
+// registers to its own slot (two slots, ping-pong: the partner publishes exchange k + 1 only after it has read slot k), raises its
+// flag, waits for the partner's and adds the partner's slot: both end with the same x (one commutative addition).
+constexpr int CT_XSLOT = 4 * 4 * CT_TH * 16;                // up to 4 row tiles x 4 column tiles x 512 lanes x 16 B = 128 KB
+template <int NT>
+__device__ __forceinline__ bool clip_exchange(const ClipArgs& a, char* lds, f32x4 (&xr)[NT][4], int unit, unsigned seq, int tid) {
+  static_assert(NT <= 4, "exchange slot size");
+  // uniform slot bases (SGPRs) + ONE laundered 32-bit lane offset: the per-access addresses are invariant across the layer loop
+  // and would otherwise be hoisted out of it and kept alive (96 address pairs: 600 spilled registers)
+  char* mine = a.xslots + ((long)unit * 2 + (seq & 1)) * CT_XSLOT;
+  const char* theirs = a.xslots + ((long)(unit ^ 1) * 2 + (seq & 1)) * CT_XSLOT;
+  unsigned lo8 = (unsigned)tid * 2u, lo16 = (unsigned)tid;
+  asm volatile("" : "+v"(lo8), "+v"(lo16));
+#pragma unroll
+  for (int i = 0; i < NT; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {                           // write-through (agent-scope, sc1) 16-byte stores: no release fence; one
+      // fabric write per lane -- as 8-byte atomic stores (twice the writes) an exchange took 8 us
+      const float4* dstp = reinterpret_cast<const float4*>(mine + (long)(i * 4 + j) * CT_TH * 16) + lo16;
+      asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dstp), "v"(xr[i][j]) : "memory");
+    }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave: its stores have left
+  __syncthreads();
+  volatile int* ok = reinterpret_cast<volatile int*>(lds + PART_OFF);
+  if (tid == 0) {
+    __hip_atomic_store((gu32*)(a.xflags + unit), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    int good = 1;
+    while (__hip_atomic_load((gu32*)(a.xflags + (unit ^ 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seq) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > (1u << 24)) { good = 0; break; }        // seconds without the partner: give up (garbage output) rather than hang
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    *ok = good;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (*ok == 0) return false;
+  {                                                         // ALL loads in flight at once: one round trip, not one per row tile
+    float4 v[NT][4];
+#pragma unroll
+    for (int i = 0; i < NT; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) v[i][j] = reinterpret_cast<const float4*>(theirs + (long)(i * 4 + j) * CT_TH * 16)[lo16];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NT; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) { xr[i][j][0] += v[i][j].x; xr[i][j][1] += v[i][j].y; xr[i][j][2] += v[i][j].z; xr[i][j][3] += v[i][j].w; }
+  }
+  __syncthreads();                                          // the flag word in LDS is free again
+  return true;
+}
+
 // the whole tower for the 16-row tiles [I0, CT_MT) of one dialog (CT_MT = ceil(L / 16) live tiles: a shorter dialog skips the dead
 // tiles' work -- one straight-line instance per tile range).  A dialog of 5 tiles is carried by TWO workgroups: rows 0 .. 47 (I0 = 0,
 // CT_MT = 3, PUB: after every head pair's in_proj it publishes its K / V rows) and rows 48 .. 79 (I0 = 3, CT_MT = 5: it fetches those
 // rows before its attention) -- the mask is causal, so the hand-off is one-directional and the first workgroup never waits.
 template <bool F16, int I0, int CT_MT, bool PUB>
-__device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, const int64_t* __restrict__ tk, int L, int b) {
+__device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, const int64_t* __restrict__ tk, int L, int b, int h, int unit) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, q = lane >> 4;
   const int eot = L - 1;
   constexpr int NT = CT_MT - I0;                            // this workgroup's tiles: rows 16 (I0 + i) + r16
@@ -222,7 +280,7 @@ __device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, co
   }
   // ---- weight ring: CT_RING fragments in flight; fragment f of this wave's stream is wp[f * 64] (64 lanes x 16 B, coalesced)
   // (uniform base in SGPRs + one 32-bit lane offset: the per-fragment offsets are scalar adds, not per-lane 64-bit addresses)
-  const uint4* __restrict__ wp = a.wstream + (long)__builtin_amdgcn_readfirstlane(wave) * a.frags_per_wave * 64;
+  const uint4* __restrict__ wp = a.wstream + (long)(h * 8 + __builtin_amdgcn_readfirstlane(wave)) * a.frags_per_wave * 64;
   const unsigned wl = (unsigned)lane;
   uint4 wq[CT_RING];
 #pragma unroll
@@ -287,8 +345,15 @@ __device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, co
     layer_norm(P.ln1g, P.ln1b);
     CT_PH(0);
     // ================================================= attention, two heads at a time =================================================
+    if (h) {                                                // half 1 carries its partial alone (the exchange adds half 0's x + partial)
+#pragma unroll
+      for (int i = 0; i < NT; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) xr[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll 1
-    for (int hp = 0; hp < 4; hp++) {
+    for (int jp = 0; jp < 2; jp++) {
+      const int hp = 2 * h + jp;                              // this column half's head pairs
       // ---- in_proj of the pair: 24 column tiles (head a: q 4 | k 4 | v 4), wave w takes tiles 3 w .. 3 w + 2; K = 512
       {
         f32x4 acc[NT][3];
@@ -334,8 +399,8 @@ __device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, co
         }
       }
       lds_barrier();
-      if (PUB) clip_publish_kv(a, lds, b, layer * 4 + hp, tid);
-      if (I0 > 0) { if (!clip_fetch_kv(a, lds, b, layer * 4 + hp, tid)) return; }
+      if (PUB) clip_publish_kv(a, lds, 2 * b + h, layer * 2 + jp, tid);
+      if (I0 > 0) { if (!clip_fetch_kv(a, lds, 2 * b + h, layer * 2 + jp, tid)) return; }
       CT_PH(1);
       // ---- causal attention: units (head of the pair, 16-query tile), one per wave and round (two units of a wave in one basic block
       // -- for the scheduler to interleave -- spilled at 5 tiles and ran slower)
@@ -367,7 +432,7 @@ __device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, co
       lds_barrier();                                          // the next pair's in_proj overwrites Q / K / V
       CT_PH(3);
     }
-    {
+    if (h == 0) {
       float4 bo[4];
 #pragma unroll
       for (int j = 0; j < 4; j++) bo[j] = *reinterpret_cast<const float4*>(P.b_out + 64 * wave + 16 * j + 4 * q);
@@ -376,11 +441,19 @@ __device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, co
 #pragma unroll
         for (int j = 0; j < 4; j++) { xr[i][j][0] += bo[j].x; xr[i][j][1] += bo[j].y; xr[i][j][2] += bo[j].z; xr[i][j][3] += bo[j].w; }
     }
+    if (!clip_exchange<NT>(a, lds, xr, unit, 2u * layer + 1u, tid)) return;
     // ======================================================= MLP, 256 hidden units at a time =======================================================
     layer_norm(P.ln2g, P.ln2b);
     CT_PH(4);
+    if (h) {
+#pragma unroll
+      for (int i = 0; i < NT; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) xr[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll 1
-    for (int c = 0; c < 8; c++) {
+    for (int jc = 0; jc < 4; jc++) {
+      const int c = 4 * h + jc;                               // this column half's hidden-unit chunks
       {
         f32x4 acc[NT][2];
 #pragma unroll
@@ -443,7 +516,7 @@ __device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, co
       lds_barrier();                                          // the next chunk's hidden image overwrites this one
       CT_PH(6);
     }
-    {
+    if (h == 0) {
       float4 bp[4];
 #pragma unroll
       for (int j = 0; j < 4; j++) bp[j] = *reinterpret_cast<const float4*>(P.b_proj + 64 * wave + 16 * j + 4 * q);
@@ -452,11 +525,12 @@ __device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, co
 #pragma unroll
         for (int j = 0; j < 4; j++) { xr[i][j][0] += bp[j].x; xr[i][j][1] += bp[j].y; xr[i][j][2] += bp[j].z; xr[i][j][3] += bp[j].w; }
     }
+    if (!clip_exchange<NT>(a, lds, xr, unit, 2u * layer + 2u, tid)) return;
   }
   // ---- the EOT row of the residual stream (ln_final and the projection follow as their own small launches)
 #pragma unroll
   for (int i = 0; i < NT; i++)
-    if (16 * (I0 + i) + r16 == eot) {
+    if (h == 0 && 16 * (I0 + i) + r16 == eot) {
 #pragma unroll
       for (int j = 0; j < 4; j++)
         *reinterpret_cast<float4*>(a.E + (long)b * 512 + 64 * wave + 16 * j + 4 * q) = make_float4(xr[i][j][0], xr[i][j][1], xr[i][j][2], xr[i][j][3]);
@@ -476,10 +550,14 @@ template <bool F16>
 __global__ __launch_bounds__(CT_TH) void clip_tower_kernel(ClipArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int lane = threadIdx.x & 63;
-  // workgroups [0, B): the second halves of the 5-tile dialogs (dispatched FIRST: the idle ones exit at once, the real ones must not
-  // queue for a CU behind the first halves they depend on); [B, 2 B): the dialogs (id % 8 == dialog % 8 when 8 | B: same XCD)
-  const int role = (int)blockIdx.x < a.B ? 1 : 0;
-  const int b = (int)blockIdx.x - (1 - role) * a.B, ctx = a.ctx;
+  // workgroup id -> (pair p, column half h): blocks of 16 ids hold 8 pairs, half 0 in ids 0 .. 7 and half 1 in ids 8 .. 15 of the block --
+  // the two halves of a pair are dispatched within 16 ids of each other and share id % 8, i.e. (round-robin placement) an XCD.
+  // Pairs [0, B) are the dialogs / the FIRST row halves of the 5-tile dialogs, pairs [B, 2 B) the second row halves: whatever a
+  // workgroup waits for (its column partner, the first row half's K / V) has a smaller or neighbouring id and never waits for it.
+  const int id = (int)blockIdx.x, h = (id >> 3) & 1, p = (id >> 4) * 8 + (id & 7);
+  if (p >= 2 * a.B) return;
+  const int row_half = p >= a.B ? 1 : 0, b = p - row_half * a.B, ctx = a.ctx;
+  const int unit = (b * 2 + row_half) * 2 + h;                // exchange partner: unit ^ 1
   const int64_t* __restrict__ tk = a.tokens + (long)b * ctx;
   // ---- live length: tokens up to the EOT (= first position of the largest id, as torch.argmax) -- nothing after it can reach
   // the output through the causal mask
@@ -495,16 +573,16 @@ __global__ __launch_bounds__(CT_TH) void clip_tower_kernel(ClipArgs a) {
     L = __builtin_amdgcn_readfirstlane(bi) + 1;
   }
   const int mt = (L + 15) >> 4;
-  if (role) {
-    if (mt >= 5) clip_tower_body<F16, 3, 5, false>(a, lds, tk, L, b);
+  if (row_half) {
+    if (mt >= 5) clip_tower_body<F16, 3, 5, false>(a, lds, tk, L, b, h, unit);
     return;
   }
   switch (mt) {
-    case 1: clip_tower_body<F16, 0, 1, false>(a, lds, tk, L, b); break;
-    case 2: clip_tower_body<F16, 0, 2, false>(a, lds, tk, L, b); break;
-    case 3: clip_tower_body<F16, 0, 3, false>(a, lds, tk, L, b); break;
-    case 4: clip_tower_body<F16, 0, 4, false>(a, lds, tk, L, b); break;
-    default: clip_tower_body<F16, 0, 3, true>(a, lds, tk, L, b); break;
+    case 1: clip_tower_body<F16, 0, 1, false>(a, lds, tk, L, b, h, unit); break;
+    case 2: clip_tower_body<F16, 0, 2, false>(a, lds, tk, L, b, h, unit); break;
+    case 3: clip_tower_body<F16, 0, 3, false>(a, lds, tk, L, b, h, unit); break;
+    case 4: clip_tower_body<F16, 0, 4, false>(a, lds, tk, L, b, h, unit); break;
+    default: clip_tower_body<F16, 0, 3, true>(a, lds, tk, L, b, h, unit); break;
   }
 }
 
@@ -512,17 +590,17 @@ struct ClipLayerWeights { const float* w_in[12]; const float* w_out[12]; const f
 // ---- weight stream packer: fragment f of wave w of layer l, lane (r16, q), element e = W[n][k] of the matrix / tile / k-step the
 // kernel consumes at that point (see the kernel's loops)
 __global__ void clip_pack_stream_kernel(ClipLayerWeights wts, uint4* __restrict__ dst, int layers, long frags_per_wave, int fmt) {
-  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;           // one thread per (layer, wave, fragment, lane)
-  const long total = (long)layers * 8 * CT_FRAGS * 64;
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;           // one thread per (layer, half, wave, fragment, lane)
+  const long total = (long)layers * 16 * CT_FRAGS * 64;
   if (gid >= total) return;
   const int lane = (int)(gid & 63);
   long rest = gid >> 6;
-  const int f = (int)(rest % CT_FRAGS); rest /= CT_FRAGS;
-  const int wave = (int)(rest & 7), layer = (int)(rest >> 3);
+  const int fp = (int)(rest % CT_FRAGS); rest /= CT_FRAGS;
+  const int wave = (int)(rest & 7), h = (int)((rest >> 3) & 1), layer = (int)(rest >> 4);
   const int r16 = lane & 15, q = lane >> 4;
   const float* W; int ld, n, k;
-  if (f < 256) {                                            // attention: 4 pairs x (48 in_proj + 16 out_proj)
-    const int hp = f >> 6, g = f & 63;
+  if (fp < 128) {                                           // attention: this half's 2 pairs x (48 in_proj + 16 out_proj)
+    const int hp = 2 * h + (fp >> 6), g = fp & 63;
     if (g < 48) {
       const int ks = g / 3, t = g % 3, gt = 3 * wave + t, ah = gt / 12, ty = (gt % 12) >> 2, sub = gt & 3;
       W = wts.w_in[layer]; ld = 512; n = ty * 512 + (2 * hp + ah) * 64 + sub * 16 + r16; k = 32 * ks + 8 * q;
@@ -530,8 +608,8 @@ __global__ void clip_pack_stream_kernel(ClipLayerWeights wts, uint4* __restrict_
       const int ks = (g - 48) >> 2, t = (g - 48) & 3;
       W = wts.w_out[layer]; ld = 512; n = 64 * wave + 16 * t + r16; k = 128 * hp + 32 * ks + 8 * q;
     }
-  } else {                                                  // MLP: 8 chunks x (32 c_fc + 32 c_proj)
-    const int c = (f - 256) >> 6, g = (f - 256) & 63;
+  } else {                                                  // MLP: this half's 4 chunks x (32 c_fc + 32 c_proj)
+    const int c = 4 * h + ((fp - 128) >> 6), g = (fp - 128) & 63;
     if (g < 32) {
       const int ks = g >> 1, t = g & 1;
       W = wts.w_fc[layer]; ld = 512; n = 256 * c + 32 * wave + 16 * t + r16; k = 32 * ks + 8 * q;
@@ -544,7 +622,7 @@ __global__ void clip_pack_stream_kernel(ClipLayerWeights wts, uint4* __restrict_
   uint2 lo, hi;
   if (fmt == 1) { lo = cvt4<true>(v0.x, v0.y, v0.z, v0.w); hi = cvt4<true>(v1.x, v1.y, v1.z, v1.w); }
   else { lo = cvt4<false>(v0.x, v0.y, v0.z, v0.w); hi = cvt4<false>(v1.x, v1.y, v1.z, v1.w); }
-  dst[((long)wave * frags_per_wave + (long)layer * CT_FRAGS + f) * 64 + lane] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+  dst[((long)(h * 8 + wave) * frags_per_wave + (long)layer * CT_FRAGS + fp) * 64 + lane] = make_uint4(lo.x, lo.y, hi.x, hi.y);
 }
 
 bool clip_stream_shape_ok(const avlen_clip_text* p) {
@@ -562,7 +640,7 @@ inline long clip_frags_per_wave(int layers) { return (long)layers * CT_FRAGS + C
 }  // namespace
 
 extern "C" size_t avlen_clip_stream_bytes(const avlen_clip_text* p) {
-  return clip_stream_shape_ok(p) ? (size_t)8 * clip_frags_per_wave(p->layers) * 1024 : 0;
+  return clip_stream_shape_ok(p) ? (size_t)16 * clip_frags_per_wave(p->layers) * 1024 : 0;
 }
 
 // Builds the per-wave weight stream of the one-launch tower from the fp32 weights (fmt 0: bf16, 1: fp16).  Derived data: call
@@ -575,24 +653,27 @@ extern "C" int avlen_clip_pack_stream(const avlen_clip_text* p, void* dst, int f
     w.w_fc[l] = p->block[l].fc.w; w.w_proj[l] = p->block[l].proj.w;
   }
   const long fpw = clip_frags_per_wave(p->layers);
-  if (avlen_zero_bytes(dst, (size_t)8 * fpw * 1024, st) != AVLEN_OK) return AVLEN_ERR_LAUNCH;      // the 16 padding fragments per wave
-  const long total = (long)p->layers * 8 * CT_FRAGS * 64;
+  if (avlen_zero_bytes(dst, (size_t)16 * fpw * 1024, st) != AVLEN_OK) return AVLEN_ERR_LAUNCH;      // the 16 padding fragments per wave
+  const long total = (long)p->layers * 16 * CT_FRAGS * 64;
   hipLaunchKernelGGL(clip_pack_stream_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, (uint4*)dst, p->layers, fpw, fmt);
   return avlen_launch_status();
 }
 
 // X rows of the residual stream at each dialog's EOT token (B x 512 fp32) through the 12 blocks in one launch
-size_t avlen_clip_tower_stream_ws_bytes(int B) { return 4096 + (size_t)B * CT_SLOTS * CT_SLOT; }
+// flag block (16 KB: zeroed before every launch) | K / V slots (dialog, column half) | exchange slots (4 workgroups per dialog x 2)
+size_t avlen_clip_tower_stream_ws_bytes(int B) { return 16384 + (size_t)B * 2 * CT_SLOTS * CT_SLOT + (size_t)B * 4 * 2 * CT_XSLOT; }
 
 int avlen_clip_tower_stream_fwd(const avlen_clip_text* p, const int64_t* tokens, float* E, int B, int f16, void* ws, size_t ws_bytes,
                                 hipStream_t st) {
   if (!clip_stream_shape_ok(p) || !p->wstream || B <= 0 || B > 1024 || !ws || ws_bytes < avlen_clip_tower_stream_ws_bytes(B)) return AVLEN_ERR_ARG;
-  if (avlen_zero_bytes(ws, 4096, st) != AVLEN_OK) return AVLEN_ERR_LAUNCH;       // the flag words (own block at the workspace's start)
+  if (B > 512) return AVLEN_ERR_ARG;
+  if (avlen_zero_bytes(ws, 16384, st) != AVLEN_OK) return AVLEN_ERR_LAUNCH;      // the flag words (own block at the workspace's start)
   ClipArgs a = {};
   a.tokens = tokens; a.tok_emb = p->tok_emb; a.pos_emb = p->pos_emb; a.wstream = (const uint4*)p->wstream; a.E = E;
   a.ctx = p->ctx; a.vocab = p->vocab; a.layers = p->layers; a.frags_per_wave = clip_frags_per_wave(p->layers);
-  a.flags = (unsigned*)ws; a.xchg = (char*)ws + 4096; a.B = B;
-  const int grid = 2 * B;
+  a.flags = (unsigned*)ws; a.xflags = a.flags + 2 * B; a.xchg = (char*)ws + 16384; a.B = B;
+  a.xslots = a.xchg + (size_t)B * 2 * CT_SLOTS * CT_SLOT;
+  const int grid = ((2 * B + 7) / 8) * 16;
   for (int l = 0; l < p->layers; l++) {
     const avlen_clip_block& b = p->block[l];
     a.L[l] = ClipLayerP{b.ln1.g, b.ln1.b, b.ln2.g, b.ln2.b, b.attn.in_proj.b, b.attn.out_proj.b, b.fc.b, b.proj.b};

@@ -1877,7 +1877,8 @@ extern "C" int avlen_action_encoder_bwd(const float* d_feats, int ld, const int6
 // =====================================================================================================
 extern "C" size_t avlen_clip_text_workspace_bytes(const avlen_clip_text* p, int B) {
   size_t R = (size_t)B * p->ctx, wd = p->width;
-  return (R * (wd * 3 + 3 * wd + 4 * wd) + (size_t)B * wd * 2) * sizeof(float) + GEMM_SCRATCH + 8192;
+  return (R * (wd * 3 + 3 * wd + 4 * wd) + (size_t)B * wd * 2) * sizeof(float) + GEMM_SCRATCH + 8192 +
+         (p->wstream ? avlen_clip_tower_stream_ws_bytes(B) + 256 : 0);
 }
 
 // out = E2 @ text_proj   (text_proj stored [width][out_dim]); a handful of row tiles -> split K over the chip
@@ -1910,10 +1911,12 @@ extern "C" int avlen_clip_text_fwd(const avlen_clip_text* p, const int64_t* toke
     const avlen_clip_block& b = p->block[l];
     fast = lin16_ok(b.attn.in_proj) && lin16_ok(b.attn.out_proj) && lin16_ok(b.fc) && lin16_ok(b.proj);
   }
-  if (fast && p->wstream && avlen_clip_stream_bytes(p) && (size_t)((char*)E - (char*)X) >= avlen_clip_tower_stream_ws_bytes(B)) {
+  if (fast && p->wstream && avlen_clip_stream_bytes(p)) {
     // the 12 blocks as ONE sequence-stationary launch (clip_tower.hip) -> the EOT rows; ln_final + projection as before
-    // (its hand-off slots live in the activation buffers of the launch-per-GEMM path: X .. Fh, unused here)
-    TRY(avlen_clip_tower_stream_fwd(p, tokens, E, B, f16 ? 1 : 0, X, (size_t)((char*)E - (char*)X), st));
+    const size_t sb = avlen_clip_tower_stream_ws_bytes(B);
+    void* sws = w.take<char>(sb);
+    if (!w.ok()) return AVLEN_ERR_WS;
+    TRY(avlen_clip_tower_stream_fwd(p, tokens, E, B, f16 ? 1 : 0, sws, sb, st));
     TRY(avlen_layernorm_fwd(E, nullptr, p->ln_final.g, p->ln_final.b, E2, nullptr, nullptr, B, wd, 1e-5f, st));
     return clip_project(p, E2, out, B, f16 ? AVLEN_PREC_BF16X3 : prec, gws, st);
   }

@@ -399,10 +399,9 @@ def clip_view(clip, flat=None, packed=None, fmt=0):
     s.vocab, s.ctx = clip.vocab_size, clip.context_length
     s.width, s.heads, s.layers = clip.transformer.width, clip.heads, clip.transformer.layers
     s.out_dim = clip.text_projection.shape[1]
-    if packed is not None and os.environ.get("AVLEN_CLIP_STREAM", "0") == "1":
-        # OPT-IN (AVLEN_CLIP_STREAM=1): per-wave weight stream of the one-launch sequence-stationary tower (csrc/clip_tower.hip).
-        # Measured: 0.97 ms alone against 0.93 ms for the launch-per-GEMM tower, and no faster beside the visual towers
-        # (both are bound by the memory system), so the default stays the launch-per-GEMM path.  0 bytes: shape not supported.
+    if packed is not None and os.environ.get("AVLEN_CLIP_STREAM", "1") != "0":
+        # per-wave weight streams of the one-launch sequence-stationary tower (csrc/clip_tower.hip): 0.76 ms for 64 dialogs against
+        # 0.93 ms for the launch-per-GEMM tower (AVLEN_CLIP_STREAM=0 keeps that one).  0 bytes: shape not supported.
         nb = L.lib.avlen_clip_stream_bytes(C.byref(s))
         if nb:
             buf = torch.empty(nb, dtype=torch.uint8, device=packed.device)

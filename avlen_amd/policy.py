@@ -110,7 +110,7 @@ class _Graph:
             torch.cuda.synchronize()
             # Captured by hand (not `with torch.cuda.graph`) so that the forward may cut itself into TWO graphs at
             # `split()`: the host can then wait for an outside event (pi_l's text tower) between the two replays.
-            self.graph, self.graph2, self.between = torch.cuda.CUDAGraph(), None, None
+            self.graph, self.graph2, self.between, self.mid = torch.cuda.CUDAGraph(), None, None, None
             cap = _capture_stream()
             cap.wait_stream(torch.cuda.current_stream())
             pol._capture = self
@@ -159,6 +159,8 @@ class _Graph:
             self.graph.replay()
             if self.between is not None:
                 self.between()
+            if self.mid is not None:
+                self.mid()                               # only ever between the halves of a cut graph (never in front of a whole one)
             self.graph2.replay()
         return self.outs
 
@@ -179,6 +181,8 @@ class _Graph:
             self.graph.replay()
             if self.between is not None:
                 self.between()                           # e.g. wait for the text tower's event on this stream
+            if self.mid is not None:
+                self.mid()
             self.graph2.replay()
         return self.outs
 
@@ -237,6 +241,7 @@ def _graphed(pol, which, fn, args, mode=None):
         if m.n:
             L.call("avlen_multi_copy", m.srcs, m.dsts, m.sizes, m.n, L.stream())
         g.between = getattr(pol, "_between", None)
+        g.mid = getattr(pol, "_mid", None)
         outs, heads = g.replay_only()
         outs = list(outs)
         if not keep_rnn:
@@ -270,6 +275,7 @@ def _graphed(pol, which, fn, args, mode=None):
     if mode == "lead":
         grp.static_obs = g.static[0]
     g.between = getattr(pol, "_between", None)
+    g.mid = getattr(pol, "_mid", None)
     if mk is not None:
         # memoise when every tensor was used exactly as passed (no dtype / layout conversion made a temporary)
         followed = mode == "follow" and args[0] is grp.static_obs
@@ -310,6 +316,10 @@ class EncoderGroup:
         self.static_obs = None         # the leader graph's static observation buffers (followers read them in place)
         self.key = None
         self.pending = set()
+        # recorded on the leader's stream as soon as the shared encoders (all towers, all AudioCNNs) of a leader call are enqueued:
+        # a follower launched ahead on its own stream waits for THIS, not for the rest of the leader's forward
+        self.ready = None
+        self.ready_key = None
         for m in self.members:
             m._enc_group = self
 
@@ -320,6 +330,14 @@ class EncoderGroup:
     def mark(self, obs):
         self.key = self._key(obs)
         self.pending = set(id(m) for m in self.members[1:])
+        self.ready_key = None
+
+    def signal(self):
+        """The shared encoders of the marked observation are enqueued on the current stream."""
+        if self.ready is None:
+            self.ready = torch.cuda.Event()
+        self.ready.record(torch.cuda.current_stream())
+        self.ready_key = self.key
 
     def claim(self, pol, obs):
         """True once per leader call for a follower that presents the leader's observation tensors."""
@@ -426,6 +444,7 @@ class Policy(nn.Module):
         self._memos = {}                      # resolved launches per exact argument objects (see _Memo)
         self._capture = None                  # the _Graph being captured (lets a forward cut itself in two, see _Graph.split)
         self._between = None                  # host action between the two halves of a split graph
+        self._mid = None                      # leader of an EncoderGroup: EncoderGroup.signal between the halves of its cut graph
         self._pinned = {}
         self._eng = None
         self._ws = E.Workspaces()
@@ -612,6 +631,7 @@ class Policy(nn.Module):
             if grp.leader is self:
                 grp.mark(net_args[0])
                 mode = "lead"
+                self._mid = grp.signal if self.use_graphs else None      # between the halves of the leader's graph (cut in net.features)
             elif grp.claim(self, net_args[0]):
                 mode = "follow"
         self._shared_mode = mode
@@ -622,6 +642,9 @@ class Policy(nn.Module):
                 out = _graphed(self, which, eager, net_args, mode)
             finally:
                 self._between = None
+                self._mid = None
+            if mode == "lead" and grp.ready_key != grp.key:
+                grp.signal()                             # the forward was not cut (no capture fork): the whole graph is the wait
             if which == "vln" and getattr(self.net, "_text", None) is not None:
                 self.net._text_read = torch.cuda.Event()
                 self.net._text_read.record(torch.cuda.current_stream())
@@ -652,7 +675,15 @@ class Policy(nn.Module):
         cur = torch.cuda.current_stream()
         run_on = stream if stream is not None else cur
         if stream is not None:
-            stream.wait_stream(cur)
+            grp = self._enc_group
+            obs = net_args[0] if net_args and isinstance(net_args[0], dict) else None
+            if (grp is not None and grp.leader is not self and obs is not None and grp.ready_key is not None
+                    and grp.ready_key == grp._key(obs) and os.environ.get("AVLEN_FOLLOW_EARLY", "1") != "0"):
+                # a follower of the marked observation: the shared encoders' event covers everything it reads (it was recorded on
+                # the current stream, behind every earlier write to the storage it reads)
+                stream.wait_event(grp.ready)
+            else:
+                stream.wait_stream(cur)
         ctx = torch.cuda.stream(run_on) if stream is not None else contextlib.nullcontext()
         with ctx:
             out = self._forward(which, *net_args)
@@ -884,6 +915,14 @@ class _SMTBase(Net):
                 vis = grp.buffers(B, dev)[grp.members.index(pol)]
             elif mode == "lead":
                 vis = grp.run_all(pol, rgb, depth)
+                # the followers need nothing else of this forward: cut the captured graph here (the replay records grp.ready
+                # between the two halves, see Policy._forward); eager: record it now
+                if fork:
+                    if pol._capture is not None and pol._capture.graph2 is None:
+                        cur.wait_stream(s_aud)
+                        pol._capture.split()
+                else:
+                    grp.signal()
             else:
                 vis = None
                 G = 2

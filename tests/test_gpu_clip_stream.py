@@ -1,5 +1,5 @@
-"""The opt-in one-launch CLIP text tower (csrc/clip_tower.hip, AVLEN_CLIP_STREAM=1: sequence-stationary workgroups, per-wave weight
-streams, two workgroups with a K / V hand-off for dialogs of 5 row tiles) against the default launch-per-GEMM tower and the fp32
+"""The one-launch CLIP text tower (csrc/clip_tower.hip; AVLEN_CLIP_STREAM=0 selects the launch-per-GEMM tower: sequence-stationary
+workgroups, per-wave weight streams, two column halves per dialog, two row halves with a K / V hand-off for dialogs of 5 row tiles) against the launch-per-GEMM tower and the fp32
 path: same 16-bit formats, so both fast towers must sit at the same distance from fp32; dialog lengths cover every tile count
 (1 .. 5 tiles, i.e. every kernel instance incl. the split one) and the extremes (EOT at position 1 and at 76)."""
 import os

@@ -43,7 +43,7 @@ int main(int argc, char** argv) {
   void* dt; CK(hipMalloc(&dt, tok.size() * 8)); CK(hipMemcpy(dt, tok.data(), tok.size() * 8, hipMemcpyHostToDevice));
   a.tokens = (const int64_t*)dt; a.tok_emb = dev_f((size_t)vocab * 512, -0.05f, 0.05f); a.pos_emb = dev_f((size_t)ctx * 512, -0.02f, 0.02f);
   a.ctx = ctx; a.vocab = vocab; a.layers = layers; a.frags_per_wave = clip_frags_per_wave(layers);
-  const size_t wb = (size_t)8 * a.frags_per_wave * 1024;
+  const size_t wb = (size_t)16 * a.frags_per_wave * 1024;
   void* ws; CK(hipMalloc(&ws, wb));
   { std::vector<unsigned short> h(wb / 2); for (auto& v : h) { _Float16 f = (_Float16)(((rand() % 2001) / 1000.f - 1.f) * 0.03f); v = __builtin_bit_cast(unsigned short, f); }
     CK(hipMemcpy(ws, h.data(), wb, hipMemcpyHostToDevice)); }
@@ -52,8 +52,9 @@ int main(int argc, char** argv) {
     a.L[l] = ClipLayerP{dev_f(512, 1.f, 1.f), dev_f(512, 0.f, 0.f), dev_f(512, 1.f, 1.f), dev_f(512, 0.f, 0.f), dev_f(1536, -0.01f, 0.01f),
                         dev_f(512, -0.01f, 0.01f), dev_f(2048, -0.01f, 0.01f), dev_f(512, -0.01f, 0.01f)};
   void* E; CK(hipMalloc(&E, (size_t)B * 512 * 4)); a.E = (float*)E;
-  long long* prof; CK(hipMalloc((void**)&prof, (size_t)2 * B * 8 * 8)); CK(hipMemset(prof, 0, (size_t)2 * B * 64)); a.prof = prof;
-  void* xw; CK(hipMalloc(&xw, avlen_clip_tower_stream_ws_bytes(B))); a.flags = (unsigned*)xw; a.xchg = (char*)xw + 4096; a.B = B;
+  long long* prof; CK(hipMalloc((void**)&prof, (size_t)4 * B * 8 * 8)); CK(hipMemset(prof, 0, (size_t)4 * B * 64)); a.prof = prof;
+  void* xw; CK(hipMalloc(&xw, avlen_clip_tower_stream_ws_bytes(B))); a.flags = (unsigned*)xw; a.xflags = a.flags + 2 * B; a.xchg = (char*)xw + 16384; a.B = B;
+  a.xslots = a.xchg + (size_t)B * 2 * CT_SLOTS * CT_SLOT;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&clip_tower_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, CT_LDS));
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipStream_t s1; hipStreamCreateWithFlags(&s1, hipStreamNonBlocking);
@@ -67,8 +68,8 @@ int main(int argc, char** argv) {
   hipEvent_t ec; hipEventCreateWithFlags(&ec, hipEventDisableTiming);
   auto run = [&]() {
     if (co_n) hipLaunchKernelGGL(corunner_kernel, dim3(co_n), dim3(512), 158 * 1024, s2, cobuf, per_wg, 70000ll, co_mode);   // ~700 us at 100 MHz
-    hipMemsetAsync(xw, 0, 4096, s1);
-    hipLaunchKernelGGL(clip_tower_kernel<true>, dim3(2 * B), dim3(CT_TH), CT_LDS, s1, a);
+    hipMemsetAsync(xw, 0, 16384, s1);
+    hipLaunchKernelGGL(clip_tower_kernel<true>, dim3(((2 * B + 7) / 8) * 16), dim3(CT_TH), CT_LDS, s1, a);
     if (co_n) { hipEventRecord(ec, s2); hipStreamWaitEvent(s1, ec, 0); hipEventRecord(ec, s1); hipStreamWaitEvent(s2, ec, 0); }
   };
   for (int it = 0; it < 2; it++) run();
@@ -78,15 +79,18 @@ int main(int argc, char** argv) {
   hipEventRecord(e1, s1); CK(hipDeviceSynchronize());
   float ms; hipEventElapsedTime(&ms, e0, e1);
   printf("clip_tower_kernel: %d dialogs: %.1f us per launch\n", B, ms * 200.f);
-  std::vector<long long> hp((size_t)2 * B * 8); CK(hipMemcpy(hp.data(), prof, hp.size() * 8, hipMemcpyDeviceToHost));
+  std::vector<long long> hp((size_t)4 * B * 8); CK(hipMemcpy(hp.data(), prof, hp.size() * 8, hipMemcpyDeviceToHost));
   std::vector<float> he((size_t)B * 512); CK(hipMemcpy(he.data(), E, he.size() * 4, hipMemcpyDeviceToHost));
   double cs = 0; for (float v : he) cs += v; printf("  output checksum %.6f\n", cs);
   static const char* NAME[8] = {"ln1", "in_proj", "attention", "out_proj", "ln2", "c_fc + gelu", "c_proj", "bias / loop"};
   double tot_mean = 0, tot_max = 0;
   for (int k = 0; k < 8; k++) {
     double s = 0, mx = 0, s2 = 0; int n2 = 0;
-    for (int b = B; b < 2 * B; b++) { s += (double)hp[b * 8 + k]; if ((double)hp[b * 8 + k] > mx) mx = (double)hp[b * 8 + k]; }
-    for (int b = 0; b < B; b++) if (hp[b * 8 + 1]) { s2 += (double)hp[b * 8 + k]; n2++; }
+    for (int id = 0; id < 4 * B; id++) {
+      const int p = (id >> 4) * 8 + (id & 7);
+      if (p < B) { s += (double)hp[id * 8 + k] / 2; if ((double)hp[id * 8 + k] > mx) mx = (double)hp[id * 8 + k]; }
+      else if (p < 2 * B && hp[id * 8 + 1]) { s2 += (double)hp[id * 8 + k]; n2++; }
+    }
     printf("  %-12s mean %9.0f  max %9.0f cycles per layer | second halves (%d): mean %9.0f\n", NAME[k], s / B / layers, mx / layers, n2, n2 ? s2 / n2 / layers : 0.0);
     tot_mean += s / B / layers; tot_max += mx / layers;
   }
