@@ -18,12 +18,20 @@ python3 $R/tools/step_breakdown.py $DB 150 > $O/step_breakdown.md || exit 1
 python3 $R/tools/update_breakdown.py $DB > $O/update_breakdown.md || exit 1
 python3 $R/tools/step_timeline.py 2>&1 | grep "times since" > $O/step_timeline.txt || exit 1
 python3 $R/tools/step_trace.py $DB 150 40 > $O/step_trace.txt || exit 1
-# phase tables of the fused tower kernels (lab binaries built here: tools/bin is not tracked)
+# phase tables of the persistent tower launch and of the one-launch text tower (lab binaries built here: tools/bin is not tracked)
+if [ -x $R/tools/bin/x3_lab ]; then $R/tools/bin/x3_lab 64 6 > $O/tower_x3_phases.txt || exit 1; fi
+if [ -x $R/tools/bin/clip_lab ]; then
+  $R/tools/bin/clip_lab 64 > $O/clip_tower_phases.txt || exit 1
+  $R/tools/bin/clip_lab 64 72 >> $O/clip_tower_phases.txt || exit 1
+  $R/tools/bin/clip_lab 64 40 >> $O/clip_tower_phases.txt || exit 1
+  for m in "160 1" "160 2"; do set -- $m; $R/tools/bin/clip_lab 64 0 $1 $2 | grep "per launch" | sed "s/^/co-runner $1 workgroups, mode $2 (1 spin, 2 stream memory): /" >> $O/clip_tower_phases.txt; done
+fi
+python3 $R/tools/clip_stream_probe.py 2>&1 | grep "stream=" > $O/clip_tower_parity_and_time.txt || exit 1
 if [ -x $R/tools/bin/head_lab0 ]; then $R/tools/bin/head_lab0 64 6 128 1 > $O/tower_head_phases.txt || exit 1; fi
 if [ -x $R/tools/bin/tail_lab ]; then $R/tools/bin/tail_lab 64 6 > $O/tower_tail_phases.txt || exit 1; fi
 if [ -f $O/tower_head_phases.txt ] && [ -f $O/tower_tail_phases.txt ]; then python3 $R/tools/tower_phase_table.py $O/tower_head_phases.txt $O/tower_tail_phases.txt > $O/tower_phase_table.md || exit 1; fi
 if [ -x $R/tools/bin/gridbar_lab ]; then $R/tools/bin/gridbar_lab 256 200 1 > $O/grid_barrier_probe.txt || exit 1; fi
-python3 $R/tools/text_split_probe.py 2>&1 | grep -E "us$|tokens" > $O/text_tower_scaling.txt || exit 1
+AVLEN_CLIP_STREAM=0 python3 $R/tools/text_split_probe.py 2>&1 | grep -E "us$|tokens" > $O/text_tower_scaling.txt || exit 1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o res -- python3 $R/tools/roofline_probe.py > /tmp/pmc_$c.log 2>&1 || exit 1
   cp $(find /tmp/pmc_$c -name "*counter_collection.csv" | head -1) $O/pmc_${c}_counter_collection.csv || exit 1
@@ -36,7 +44,9 @@ cat $O/pmc_traffic.json | head -30
 python3 $R/bench.py --config gru --steps 3 --no-roofline --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_gru.log
 python3 $R/bench.py --distractor --steps 3 --no-roofline --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/bench_distractor.log
 python3 $R/bench.py --stage 2 --envs 32 --steps 2 --no-roofline --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/bench_stage2_envs32.log
+python3 $R/bench.py --stage 2 --envs 32 --steps 2 --no-roofline --no-cpu-baseline --no-extras --precision bf16 2>/dev/null | tail -1 > $O/bench_stage2_envs32_bf16.log
+python3 $R/bench.py --precision bf16 --steps 3 --no-roofline --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/bench_bf16.log
 python3 $R/bench.py --belief --spectrogram 65x26 --steps 3 --no-roofline --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/bench_belief_65x26.log
 rocprofv3 --kernel-trace --stats -d /tmp/pg -o res -- python3 $R/bench.py --config gru --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > /tmp/pg.log 2>&1 || exit 1
 python3 $R/tools/prof_summary.py $(find /tmp/pg -name "*.db" | head -1) "rocprofv3 --kernel-trace --stats -- python bench.py --config gru --steps 1 --warmup 1" > $O/rocprof_gru.md
-cut -c1-200 $O/bench_gru.log $O/bench_distractor.log $O/bench_stage2_envs32.log $O/bench_belief_65x26.log
+cut -c1-200 $O/bench_gru.log $O/bench_distractor.log $O/bench_stage2_envs32.log $O/bench_stage2_envs32_bf16.log $O/bench_bf16.log $O/bench_belief_65x26.log

@@ -11,7 +11,9 @@ def per_kernel(path, counter):
         if r.get("Counter_Name") != counter:
             continue
         name = r["Kernel_Name"]
-        key = "gemm" if "g2_kernel" in name else ("dconv" if "dconv3x3_kernel" in name else None)
+        probe_gemm = "g2_kernel" in name and ("ILi64ELi128ELi2ELi4ELi2ELi512ELb0E" in name or "<64, 128, 2, 4, 2, 512, false" in name)
+        key = ("gemm" if probe_gemm else "dconv" if "dconv3x3_kernel" in name else
+               "tower_x3" if "tower_x3_kernel" in name else "clip_tower" if "clip_tower_kernel" in name else None)
         if key is None:
             continue
         a = acc.setdefault(key, [0.0, 0, name])
@@ -29,12 +31,17 @@ def mfma_util(path):
 def main(fetch_csv, write_csv, out, mfma_csv=None):
     sys.path.insert(0, __file__.rsplit("/", 1)[0])
     f, w = per_kernel(fetch_csv, "FETCH_SIZE"), per_kernel(write_csv, "WRITE_SIZE")
-    alg = {"gemm": 2464 * 512 * 2 + 2048 * 512 * 2 + 2464 * 2048 * 2, "dconv": 384 * 64 * 64 * 16 * 2 * 2}
+    # tower_x3: the images read once (uint8 rgb, fp32 depth: 3 pairs x 64 samples) + the layer-4 planes written; clip_tower: the
+    # 16-bit weights of 12 blocks read once (what a perfect cache hierarchy would fetch) + tokens / embedding rows / outputs
+    alg = {"gemm": 2464 * 512 * 2 + 2048 * 512 * 2 + 2464 * 2048 * 2, "dconv": 384 * 64 * 64 * 16 * 2 * 2,
+           "tower_x3": 3 * 64 * (128 * 128 * 3 + 128 * 128 * 4) + 384 * 8192 * 4, "clip_tower": 12 * 3145728 * 2 + 2501 * 512 * 4 * 2}
     res = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python tools/roofline_probe.py "
                       "(two separate passes), summarised by tools/pmc_traffic.py",
            "gfx950_note": "MI355X_MICROARCH.md HBM section: FETCH_SIZE (KB) reports half the bytes of wide (16 B/lane) coalesced "
                           "reads incl. global_load...lds -> x2; WRITE_SIZE (KB) is exact for wide stores"}
-    for k in ("gemm", "dconv"):
+    for k in ("gemm", "dconv", "tower_x3", "clip_tower"):
+        if k not in f or k not in w:
+            continue
         fk, name = f[k]; wk, _ = w[k]
         res[k] = {"kernel": name[:120], "FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "traffic_bytes": (2 * fk + wk) * 1024,
                   "algorithmic_bytes": alg[k]}

@@ -136,7 +136,35 @@ def measure(make, iters=40):
     return e0.elapsed_time(e1) / 1e3 / iters
 
 
+def product_kernels():
+    """The two big kernels of a bf16x3 rollout step AS THE PRODUCT LAUNCHES THEM (so that the --pmc passes see them under their
+    own names): the tower group (tower_x3_kernel: 6 towers x 64 images, persistent work queue) and the CLIP text tower
+    (clip_tower_kernel: 64 dialogs).  Returns their event-timed durations."""
+    from avlen_amd.harness import Workload
+    wl = Workload(64, 2, precision="bf16x3", use_graphs=True)
+    grp = wl.pi_q._enc_group
+    obs = {k: v[0] for k, v in wl.rollouts.observations.items()}
+    pol, toks = wl.pi_l, wl.dialog[0]
+    st = torch.cuda.current_stream()
+    tw = lambda: grp.run_all(wl.pi_q, obs["rgb"], obs["depth"])
+    tx = lambda: pol.net.encode_text(pol, toks)
+    out = {}
+    for name, fn in (("tower_x3_us", tw), ("clip_tower_us", tx)):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        out[name] = e0.elapsed_time(e1) / 10 * 1e3
+    return out
+
+
 if __name__ == "__main__":
     sg, sc = measure(make_gemm), measure(make_conv)
-    print(json.dumps({"gemm_us": sg * 1e6, "gemm_TFLOPs": gemm_work()["flops"] / sg / 1e12, "conv_us": sc * 1e6,
-                      "conv_GBps": conv_work()["bytes"] / sc / 1e9}))
+    res = {"gemm_us": sg * 1e6, "gemm_TFLOPs": gemm_work()["flops"] / sg / 1e12, "conv_us": sc * 1e6,
+           "conv_GBps": conv_work()["bytes"] / sc / 1e9}
+    res.update(product_kernels())
+    print(json.dumps(res))

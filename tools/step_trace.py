@@ -11,7 +11,7 @@ marks = [r[0] for r in rows if "ppo_loss" in r[2]]
 lo, hi = marks[3] + 1e6, marks[4] - 1e5
 sel = [r for r in rows if r[0] >= lo and r[1] <= hi]
 # a step starts with the tower head launch of the lead policy (one per step; the update is outside the window)
-heads = [i for i, r in enumerate(sel) if "tower_head" in r[2] or "stem_x3" in r[2]]
+heads = [i for i, r in enumerate(sel) if "tower_head" in r[2] or "tower_x3_kernel" in r[2]]
 a, b = heads[k], heads[k + 1]
 # the text graph of this step started before the head: include kernels back to the previous insert
 t0 = sel[a][0]
