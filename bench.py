@@ -153,6 +153,18 @@ def kernel_roofline(prec_name, in_situ=None, towers=None):
                "us_per_launch": towers["us"], "measured": "in situ: the product's grouped call, HIP events on the launch stream"}
         if x3:
             top["mfma_issue_frac"] = round(3 * towers["frac_of_bf16_peak"], 4)
+            try:                                     # per conv INSIDE the fused bodies: from the committed phase-stamp profile (a lab
+                import tower_x3_phase_table as tpt   # build of the same kernel, tools/x3_lab.hip), not re-measured by this run
+                t = tpt.table(os.path.join(ROOT, "profiles", "r03_tower_x3_phases.txt"))
+                top["tower_convs_in_situ"] = {"source": "profiles/r03_tower_x3_phases.txt (tools/x3_lab: phase stamps of the product kernel, "
+                                                        "384 images; algorithmic FLOPs of a conv over its whole phase incl. GroupNorm "
+                                                        "statistics and the normalise / split pass, per CU)",
+                                              "whole_tower_frac_mfma_algorithmic": t["whole_tower_frac_mfma_algorithmic"],
+                                              "whole_tower_frac_mfma_issue": t["whole_tower_frac_mfma_issue"],
+                                              "rows": [{"conv": r["conv"], "us": r["us"], "frac_mfma": r["frac_mfma_algorithmic"],
+                                                        "frac_mfma_issue": r["frac_mfma_issue"]} for r in t["rows"]]}
+            except Exception as e:
+                top["tower_convs_in_situ_error"] = repr(e)
         top.update(out)
         top["gemm_probe"] = probe
         out = top
@@ -405,6 +417,8 @@ def main():
     H, W = (int(x) for x in a.spectrogram.split("x"))
     if a.config == "gru":
         from avlen_amd.harness import GruWorkload
+        if a.precision == "bf16x3":
+            a.precision = "bf16"                         # BASELINE configs[1] names bf16; the GRU baseline has no bf16x3 fast path
         wl = GruWorkload(a.envs if a.envs != 64 else 16, a.rollout, spectrogram=(H, W, 2), precision=a.precision, seed=rank)
         a.envs = wl.N
     else:
