@@ -43,7 +43,8 @@ long big_m() {
 inline int pad8(long x) { return (int)((x + 7) & ~7L); }
 
 // fp32 [R][C] (row stride ld) -> bf16 [C][ldt] (transposed); columns R .. Rp-1 of every output row are zero
-__global__ void tcast_kernel(const float* __restrict__ src, int ld, bf16* __restrict__ dst, long ldt, long R, int C, long Rp) {
+// lo: also write the LOW plane of the compensated pair (bf16(v - bf16(v))) `lo` elements behind the high one
+__global__ void tcast_kernel(const float* __restrict__ src, int ld, bf16* __restrict__ dst, long ldt, long R, int C, long Rp, long lo) {
   __shared__ float t[32][33];
   const long r0 = (long)blockIdx.x * 32; const int c0 = blockIdx.y * 32;
   const int tx = threadIdx.x, ty = threadIdx.y;
@@ -56,13 +57,33 @@ __global__ void tcast_kernel(const float* __restrict__ src, int ld, bf16* __rest
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int c = c0 + ty + j * 8; const long r = r0 + tx;
-    if (c < C && r < Rp) dst[(long)c * ldt + r] = (bf16)t[tx][ty + j * 8];
+    if (c < C && r < Rp) {
+      const float v = t[tx][ty + j * 8];
+      const bf16 h = (bf16)v;
+      dst[(long)c * ldt + r] = h;
+      if (lo) dst[lo + (long)c * ldt + r] = (bf16)(v - (float)h);
+    }
   }
 }
-int tcast(const Ctx& c, const float* src, int ld, bf16* dst, long ldt, long R, int C) {
+int tcast(const Ctx& c, const float* src, int ld, bf16* dst, long ldt, long R, int C, long lo = 0) {
   const long Rp = ldt;
-  hipLaunchKernelGGL(tcast_kernel, dim3((unsigned)((Rp + 31) / 32), ceil_div(C, 32)), dim3(32, 8), 0, c.st, src, ld, dst, ldt, R, C, Rp);
+  hipLaunchKernelGGL(tcast_kernel, dim3((unsigned)((Rp + 31) / 32), ceil_div(C, 32)), dim3(32, 8), 0, c.st, src, ld, dst, ldt, R, C, Rp, lo);
   return avlen_launch_status();
+}
+// fp32 rows -> 16-bit operand (compensated: high plane + low plane `lo` elements behind it)
+int cast_pair(const Ctx& c, const float* src, int ld, bf16* dst, int ldd, long rows, int cols, long lo) {
+  TRY(avlen_cast_h16(src, ld, dst, ldd, rows, cols, 0, c.st));
+  if (lo) TRY(avlen_cast_h16(src, ld, dst + lo, ldd, rows, cols, 2, c.st));
+  return AVLEN_OK;
+}
+// the large-M product on the glds / MFMA kernel: plain bf16, or -- compensated mode -- three K-concatenated passes over hi / lo planes
+int big_gemm(const Ctx& c, const bf16* A, int lda, long a_lo, const bf16* B, int ldb, long b_lo, float* Y, int ldy, const float* bias,
+             const float* res, int ldr, int M, int N, int K, int act) {
+  if (c.prec == AVLEN_PREC_BF16X3) {
+    avlen_g2_opts o; o.x3 = 1; o.a_lo = a_lo * 2; o.b_lo = b_lo * 2;
+    return avlen_gemm_bf16_dyn(A, lda, B, ldb, Y, ldy, nullptr, 0, bias, res, ldr, M, nullptr, N, K, act, c.gws, c.gws_bytes, c.st, &o);
+  }
+  return avlen_gemm_bf16(A, lda, B, ldb, Y, ldy, nullptr, 0, bias, res, ldr, M, N, K, act, c.gws, c.gws_bytes, c.st);
 }
 struct XsBump {        // carve 256-byte aligned pieces out of the operand scratch; ok() false -> caller falls back
   char* base; size_t off, cap; bool good = true;
@@ -73,19 +94,21 @@ struct XsBump {        // carve 256-byte aligned pieces out of the operand scrat
     return (bf16*)(base + o);
   }
 };
-bool big_path(const Ctx& c, long M) { return c.prec == AVLEN_PREC_BF16 && c.xs && M >= big_m(); }
+bool big_path(const Ctx& c, long M) { return (c.prec == AVLEN_PREC_BF16 || c.prec == AVLEN_PREC_BF16X3) && c.xs && M >= big_m(); }
 
 // Y[M, out_f] (ldy) = act(X[M, in_f] (ldx) * W^T + b) + res
 int linear(const Ctx& c, const avlen_linear& L, const float* X, int ldx, float* Y, int ldy, int M, int act,
            const float* res, int ldr) {
   if (big_path(c, M)) {
     const int Kp = pad8(L.in_f);
+    const int np = c.prec == AVLEN_PREC_BF16X3 ? 2 : 1;              // planes per operand
     XsBump b(c);
-    bf16* X16 = b.take((size_t)M * Kp); bf16* W16 = b.take((size_t)L.out_f * Kp);
+    bf16* X16 = b.take((size_t)np * M * Kp); bf16* W16 = b.take((size_t)np * L.out_f * Kp);
     if (b.good) {
-      TRY(avlen_cast_bf16(X, ldx, X16, Kp, M, L.in_f, c.st));
-      TRY(avlen_cast_bf16(L.w, L.in_f, W16, Kp, L.out_f, L.in_f, c.st));
-      return avlen_gemm_bf16(X16, Kp, W16, Kp, Y, ldy, nullptr, 0, L.b, res, ldr, M, L.out_f, Kp, act, c.gws, c.gws_bytes, c.st);
+      const long xl = np > 1 ? (long)M * Kp : 0, wl = np > 1 ? (long)L.out_f * Kp : 0;
+      TRY(cast_pair(c, X, ldx, X16, Kp, M, L.in_f, xl));
+      TRY(cast_pair(c, L.w, L.in_f, W16, Kp, L.out_f, L.in_f, wl));
+      return big_gemm(c, X16, Kp, xl, W16, Kp, wl, Y, ldy, L.b, res, ldr, M, L.out_f, Kp, act);
     }
   }
   int sk = avlen_gemm_pick_splitk(M, L.out_f, L.in_f);
@@ -105,13 +128,14 @@ int linear_dx(const Ctx& c, const avlen_linear& L, const float* dY, int ldy, flo
               int ldadd) {
   if (big_path(c, M)) {
     const int Np = pad8(L.out_f);
+    const int np = c.prec == AVLEN_PREC_BF16X3 ? 2 : 1;
     XsBump b(c);
-    bf16* dY16 = b.take((size_t)M * Np); bf16* WT16 = b.take((size_t)L.in_f * Np);
+    bf16* dY16 = b.take((size_t)np * M * Np); bf16* WT16 = b.take((size_t)np * L.in_f * Np);
     if (b.good) {
-      TRY(avlen_cast_bf16(dY, ldy, dY16, Np, M, L.out_f, c.st));
-      TRY(tcast(c, L.w, L.in_f, WT16, Np, L.out_f, L.in_f));           // W [out_f][in_f] -> W^T [in_f][Np]
-      return avlen_gemm_bf16(dY16, Np, WT16, Np, dX, ldx, nullptr, 0, nullptr, add, ldadd, M, L.in_f, Np, 0, c.gws, c.gws_bytes,
-                             c.st);
+      const long yl = np > 1 ? (long)M * Np : 0, wl = np > 1 ? (long)L.in_f * Np : 0;
+      TRY(cast_pair(c, dY, ldy, dY16, Np, M, L.out_f, yl));
+      TRY(tcast(c, L.w, L.in_f, WT16, Np, L.out_f, L.in_f, wl));       // W [out_f][in_f] -> W^T [in_f][Np]
+      return big_gemm(c, dY16, Np, yl, WT16, Np, wl, dX, ldx, nullptr, add, ldadd, M, L.in_f, Np, 0);
     }
   }
   return avlen_gemm(dY, ldy, 0, L.w, L.in_f, 1, dX, ldx, nullptr, add, ldadd, M, L.in_f, L.out_f, 0, c.prec, 1, 0.f,
@@ -121,13 +145,14 @@ int linear_dx(const Ctx& c, const avlen_linear& L, const float* dY, int ldy, flo
 int linear_dw(const Ctx& c, const avlen_linear& G, const float* dY, int ldy, const float* X, int ldx, int M) {
   if (big_path(c, M)) {
     const long Mp = pad8(M);
+    const int np = c.prec == AVLEN_PREC_BF16X3 ? 2 : 1;
     XsBump b(c);
-    bf16* dYT = b.take((size_t)G.out_f * Mp); bf16* XT = b.take((size_t)G.in_f * Mp);
+    bf16* dYT = b.take((size_t)np * G.out_f * Mp); bf16* XT = b.take((size_t)np * G.in_f * Mp);
     if (b.good) {
-      TRY(tcast(c, dY, ldy, dYT, Mp, M, G.out_f));
-      TRY(tcast(c, X, ldx, XT, Mp, M, G.in_f));
-      return avlen_gemm_bf16(dYT, (int)Mp, XT, (int)Mp, G.w, G.in_f, nullptr, 0, nullptr, G.w, G.in_f, G.out_f, G.in_f, (int)Mp, 0,
-                             c.gws, c.gws_bytes, c.st);
+      const long yl = np > 1 ? (long)G.out_f * Mp : 0, xl = np > 1 ? (long)G.in_f * Mp : 0;
+      TRY(tcast(c, dY, ldy, dYT, Mp, M, G.out_f, yl));
+      TRY(tcast(c, X, ldx, XT, Mp, M, G.in_f, xl));
+      return big_gemm(c, dYT, (int)Mp, yl, XT, (int)Mp, xl, G.w, G.in_f, nullptr, G.w, G.in_f, G.out_f, G.in_f, (int)Mp, 0);
     }
   }
   int sk = avlen_gemm_pick_splitk(G.out_f, G.in_f, M);
@@ -173,7 +198,7 @@ int avlen_i_conv_dw16(const avlen_ctx& c, const avlen_linear& G, const float* dY
                       int C, int OH, int OW, int KH, int KW, int s, int pad) {
   const long M = B * OH * OW;
   const int K = KH * KW * C;
-  if (!big_path(c, M) || M > 0x7ffffff0L) return AVLEN_NOT_BIG;
+  if (!big_path(c, M) || c.prec != AVLEN_PREC_BF16 || M > 0x7ffffff0L) return AVLEN_NOT_BIG;     // plain bf16 only (no compensated form)
   const long Mp = pad8(M);
   XsBump b(c);
   bf16* dYT = b.take((size_t)G.out_f * Mp); bf16* XT = b.take((size_t)K * Mp);
@@ -1309,7 +1334,7 @@ void smt_layout(WsBump& w, SmtWs& s, const avlen_smt* p, long B, long M, int F, 
   s.gws = w.take<char>(GEMM_SCRATCH);
   s.xs = nullptr; s.xs_bytes = 0;
   if (R >= big_m()) {            // operand scratch of the large-M bf16 products: two operands of up to 3d + ldxf columns
-    s.xs_bytes = (size_t)(R + 8) * (size_t)(4 * d + s.ldxf + 16) * 2 + ((size_t)4 << 20);
+    s.xs_bytes = 2 * ((size_t)(R + 8) * (size_t)(4 * d + s.ldxf + 16) * 2 + ((size_t)4 << 20));     // x 2: hi + lo planes (bf16x3)
     s.xs = w.take<char>(s.xs_bytes);
   }
 }
