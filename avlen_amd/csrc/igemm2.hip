@@ -889,6 +889,38 @@ extern "C" int avlen_cast_h16(const float* src, int ld_src, void* dst, int ld_ds
   hipLaunchKernelGGL(cast_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, src, ld_src, (bf16*)dst, ld_dst, rows, cols, fmt);
   return avlen_launch_status();
 }
+// fp32 rows -> the compensated pair in ONE pass over the source: hi plane at dst, lo plane `lo` elements behind it
+__global__ void cast_pair8_kernel(const float* __restrict__ src, int lds_, bf16* __restrict__ dst, int ldd, long rows, int cols, long lo,
+                                  int vec) {
+  const int per_row = ldd >> 3;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * per_row) return;
+  const long r = i / per_row; const int c = (int)(i - r * per_row) << 3;
+  float v[8];
+  if (vec && c + 8 <= cols) {
+    const float4 a = *reinterpret_cast<const float4*>(src + r * lds_ + c), b = *reinterpret_cast<const float4*>(src + r * lds_ + c + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = c + e < cols ? src[r * lds_ + c + e] : 0.f;
+  }
+  bf16x8 h, l;
+#pragma unroll
+  for (int e = 0; e < 8; e++) { h[e] = (bf16)v[e]; l[e] = (bf16)(v[e] - (float)h[e]); }
+  *reinterpret_cast<bf16x8*>(dst + r * ldd + c) = h;
+  *reinterpret_cast<bf16x8*>(dst + lo + r * ldd + c) = l;
+}
+int avlen_cast_pair(const float* src, int ld_src, void* dst, int ld_dst, long rows, int cols, long lo, hipStream_t stream) {
+  if (rows * ld_dst <= 0 || lo <= 0) return AVLEN_ERR_ARG;
+  if (!(ld_dst & 7) && !((uintptr_t)dst & 15) && !(lo & 7)) {
+    const long t8 = (rows * ld_dst) >> 3;
+    const int vec = !(ld_src & 3) && !((uintptr_t)src & 15);
+    hipLaunchKernelGGL(cast_pair8_kernel, dim3((unsigned)((t8 + 255) / 256)), dim3(256), 0, stream, src, ld_src, (bf16*)dst, ld_dst, rows, cols, lo, vec);
+    return avlen_launch_status();
+  }
+  int rc = avlen_cast_h16(src, ld_src, dst, ld_dst, rows, cols, 0, stream);
+  return rc ? rc : avlen_cast_h16(src, ld_src, (bf16*)dst + lo, ld_dst, rows, cols, 2, stream);
+}
 extern "C" int avlen_cast_bf16(const float* src, int ld_src, void* dst, int ld_dst, long rows, int cols, hipStream_t stream) {
   return avlen_cast_h16(src, ld_src, dst, ld_dst, rows, cols, 0, stream);
 }

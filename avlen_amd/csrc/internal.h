@@ -139,3 +139,5 @@ int avlen_tower_x3_fwd(const avlen_resnet18* const* nets, const void* const* img
 size_t avlen_clip_tower_stream_ws_bytes(int B);
 int avlen_clip_tower_stream_fwd(const avlen_clip_text* p, const int64_t* tokens, float* E, int B, int f16, void* ws, size_t ws_bytes,
                                 hipStream_t st);
+// fp32 rows -> compensated bf16 pair in one pass (hi plane at dst, lo plane `lo` elements behind it)
+int avlen_cast_pair(const float* src, int ld_src, void* dst, int ld_dst, long rows, int cols, long lo, hipStream_t stream);

@@ -72,9 +72,8 @@ int tcast(const Ctx& c, const float* src, int ld, bf16* dst, long ldt, long R, i
 }
 // fp32 rows -> 16-bit operand (compensated: high plane + low plane `lo` elements behind it)
 int cast_pair(const Ctx& c, const float* src, int ld, bf16* dst, int ldd, long rows, int cols, long lo) {
-  TRY(avlen_cast_h16(src, ld, dst, ldd, rows, cols, 0, c.st));
-  if (lo) TRY(avlen_cast_h16(src, ld, dst + lo, ldd, rows, cols, 2, c.st));
-  return AVLEN_OK;
+  if (lo) return avlen_cast_pair(src, ld, dst, ldd, rows, cols, lo, c.st);
+  return avlen_cast_h16(src, ld, dst, ldd, rows, cols, 0, c.st);
 }
 // the large-M product on the glds / MFMA kernel: plain bf16, or -- compensated mode -- three K-concatenated passes over hi / lo planes
 int big_gemm(const Ctx& c, const bf16* A, int lda, long a_lo, const bf16* B, int ldb, long b_lo, float* Y, int ldy, const float* bias,
