@@ -37,6 +37,11 @@ class BeliefPredictor(nn.Module):
         self.has_distractor_sound = has_distractor_sound
         self.precision = precision
         self.prec = {"fp32": L.PREC_FP32, "bf16": L.PREC_BF16, "bf16x3": L.PREC_BF16X3}[precision]
+        # inference of the two auxiliary ResNets under the bf16x3 policies: fp16 operands (as their AudioCNN; 8x closer to fp32 than
+        # bf16, on the launch-per-layer 16-bit kernels) -- the staged compensated kernels cost 4 ms per step here.  The online
+        # regression keeps self.prec.
+        self.prec_inf = L.PREC_FP16 if precision == "bf16x3" else self.prec
+        self._fmt = 1 if precision == "bf16x3" else 0
         if self.predict_location:
             if not belief_config.online_training:
                 # belief_predictor.py:74-77 swaps in an ImageNet-pretrained torchvision resnet18 with a 23-way head
@@ -130,9 +135,9 @@ class BeliefPredictor(nn.Module):
                 assert 128 * h * w == self.predictor.fc.in_features, (
                     "predictor.fc expects %d features, a %dx%d spectrogram yields %d" %
                     (self.predictor.fc.in_features, H, W, 128 * h * w))
-                eng["predictor"] = E.resnet18_any_view(self.predictor, packed, 128, h * w)
+                eng["predictor"] = E.resnet18_any_view(self.predictor, packed, 128, h * w, fmt=self._fmt)
             if self.predict_label:
-                eng["classifier"] = E.resnet18_tv_view(self.classifier, packed)
+                eng["classifier"] = E.resnet18_tv_view(self.classifier, packed, fmt=self._fmt)
             packed.refresh()
             self._eng = eng
         return self._eng
@@ -216,7 +221,7 @@ class BeliefPredictor(nn.Module):
         fn = "avlen_resnet18_any" if which == "predictor" else "avlen_resnet18_tv"
         nb = getattr(L.lib, fn + "_workspace_bytes")(B, H, W)
         ws = self._ws.get(which, nb, x.device)
-        L.call(fn + "_fwd", C.byref(eng[which]), E.P(x), B, H, W, Cin, E.P(out), out.shape[1], self.prec, E.P(ws), nb, L.stream())
+        L.call(fn + "_fwd", C.byref(eng[which]), E.P(x), B, H, W, Cin, E.P(out), out.shape[1], self.prec_inf, E.P(ws), nb, L.stream())
         return out
 
     def cnn_forward(self, observations):

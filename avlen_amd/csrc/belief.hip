@@ -142,11 +142,16 @@ __global__ void belief_update_kernel(const float* __restrict__ pointgoals, int l
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8b;
 
+// 16-bit storage of the fast flows: bf16, or -- f16 -- IEEE half in the same slots (AVLEN_PREC_FP16: the bf16x3 policies' mode for
+// these auxiliary networks; weights packed with fmt 1)
+__device__ __forceinline__ __bf16 h16_from(float v, int f16) { return f16 ? __builtin_bit_cast(__bf16, (_Float16)v) : (__bf16)v; }
+__device__ __forceinline__ float h16_to(__bf16 v, int f16) { return f16 ? (float)__builtin_bit_cast(_Float16, v) : (float)v; }
+
 // GroupNorm(G) for the bf16 flow: x = raw conv output in fp32 (B,HW,C), one block per sample (the activations of these
 // networks are a few tens of KB per sample and stay in L2 between the two passes); y (bf16) = [relu](xhat*g + b [+ res]).
 __global__ __launch_bounds__(1024) void gn_any16_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const __bf16* __restrict__ res,
-                                                       __bf16* __restrict__ y, int HW, int C, int G, int relu, float eps) {
+                                                       __bf16* __restrict__ y, int HW, int C, int G, int relu, float eps, int f16) {
   __shared__ float s_sum[128], s_sq[128], s_scale[128], s_shift[128];
   __shared__ float part[2][1024][4];                   // per-thread partials, reduced in a FIXED order (bit-reproducible)
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -191,22 +196,23 @@ __global__ __launch_bounds__(1024) void gn_any16_kernel(const float* __restrict_
     float o[4] = {v.x * sc[0] + sh[0], v.y * sc[1] + sh[1], v.z * sc[2] + sh[2], v.w * sc[3] + sh[3]};
     if (rb) {
 #pragma unroll
-      for (int i = 0; i < 4; i++) o[i] += (float)rb[f * 4 + i];
+      for (int i = 0; i < 4; i++) o[i] += h16_to(rb[f * 4 + i], f16);
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++) yb[f * 4 + i] = (__bf16)(relu ? fmaxf(o[i], 0.f) : o[i]);
+    for (int i = 0; i < 4; i++) yb[f * 4 + i] = h16_from(relu ? fmaxf(o[i], 0.f) : o[i], f16);
   }
 }
 
-int gn_any16(const float* x, const avlen_affine& n, const __bf16* res, __bf16* y, int B, int HW, int C, int relu, hipStream_t st) {
+int gn_any16(const float* x, const avlen_affine& n, const __bf16* res, __bf16* y, int B, int HW, int C, int relu, hipStream_t st,
+             int f16 = 0) {
   if (C > 128 || (1024 % C) || (C % 16)) return AVLEN_ERR_ARG;
-  hipLaunchKernelGGL(gn_any16_kernel, dim3(B), dim3(1024), 0, st, x, n.g, n.b, res, y, HW, C, 16, relu, 1e-5f);
+  hipLaunchKernelGGL(gn_any16_kernel, dim3(B), dim3(1024), 0, st, x, n.g, n.b, res, y, HW, C, 16, relu, 1e-5f, f16);
   return avlen_launch_status();
 }
 
 // maxpool for the bf16 flow: fp32 in, fp32 (the next block's residual) and bf16 (the next conv's operand) out
 __global__ void maxpool_nhwc2_kernel(const float* __restrict__ x, float* __restrict__ y32, __bf16* __restrict__ y16, int B, int H,
-                                     int W, int C, int OH, int OW, int k, int s, int p) {
+                                     int W, int C, int OH, int OW, int k, int s, int p, int f16) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long tot = (long)B * OH * OW * C;
   if (i >= tot) return;
@@ -223,7 +229,7 @@ __global__ void maxpool_nhwc2_kernel(const float* __restrict__ x, float* __restr
       m = fmaxf(m, x[(((long)b * H + iy) * W + ix) * C + c]);
     }
   }
-  y32[i] = m; y16[i] = (__bf16)m;
+  y32[i] = m; y16[i] = h16_from(m, f16);
 }
 
 constexpr size_t CONV_SCRATCH = (size_t)32 << 20;       // split-K slabs of the bf16 convs (run_g2 falls back to fewer splits)
@@ -240,7 +246,7 @@ bool conv16_ok(const avlen_conv& k) { return k.w16 && k.cin16 >= 8 && !(k.cin16 
 // bf16 flow of the GroupNorm ResNet: every conv on the glds/MFMA implicit GEMM (fp32 raw output), GroupNorm reads the fp32
 // raw tensor and writes the bf16 activation the next conv consumes.
 int any_fwd_bf16(const avlen_resnet18* net, const float* x, int B, int H, int W, int C, float* out, int ld_out, void* ws,
-                 size_t ws_bytes, hipStream_t st) {
+                 size_t ws_bytes, hipStream_t st, int f16 = 0) {
   WsBump w(ws, ws_bytes);
   const size_t px = (size_t)B * H * W;
   const avlen_conv& c1 = net->conv1;
@@ -253,13 +259,14 @@ int any_fwd_bf16(const avlen_resnet18* net, const float* x, int B, int H, int W,
   auto conv = [&](const avlen_conv& k, const __bf16* in, float* o32, int h, int wd) {
     static int split = -1;                             // AVLEN_BELIEF_SPLITK=0: no split-K on the predictor's convs (A/B knob)
     if (split < 0) split = (int)avlen_knob("AVLEN_BELIEF_SPLITK", 1);
-    return avlen_conv2d_nhwc_bf16(in, k.w16, nullptr, nullptr, o32, nullptr, nullptr, B, h, wd, k.cin16, k.cout, k.kh, k.kw, k.stride,
-                                  k.pad, 0, split ? gws : nullptr, split ? CONV_SCRATCH : 0, st);
+    avlen_g2_opts go; go.f16 = f16;
+    return avlen_conv2d_nhwc_h16(in, k.w16, nullptr, nullptr, o32, nullptr, nullptr, B, h, wd, k.cin16, k.cout, k.kh, k.kw, k.stride,
+                                 k.pad, 0, split ? gws : nullptr, split ? CONV_SCRATCH : 0, st, &go);
   };
-  TRY(avlen_cast_bf16(x, C, x16, c1.cin16, (long)px, C, st));
+  TRY(avlen_cast_h16(x, C, x16, c1.cin16, (long)px, C, f16 ? 1 : 0, st));
   const int h1 = conv_out(H, c1), w1 = conv_out(W, c1);
   TRY(conv(c1, x16, raw[0], H, W));
-  TRY(gn_any16(raw[0], net->bn1, nullptr, act[0], B, h1 * w1, c1.cout, 1, st));
+  TRY(gn_any16(raw[0], net->bn1, nullptr, act[0], B, h1 * w1, c1.cout, 1, st, f16));
   __bf16* cur = act[0]; __bf16* a1 = act[1]; __bf16* idt = act[2]; __bf16* nxt = act[3];
   int h = h1, wd = w1, ch = c1.cout;
   for (int i = 0; i < 8; i++) {
@@ -268,21 +275,21 @@ int any_fwd_bf16(const avlen_resnet18* net, const float* x, int B, int H, int W,
     const int oh = conv_out(h, k.conv1), ow = conv_out(wd, k.conv1), co = k.conv1.cout;
     if (oh <= 0 || ow <= 0 || (size_t)B * oh * ow * co > px * 16) return AVLEN_ERR_ARG;
     TRY(conv(k.conv1, cur, raw[0], h, wd));
-    TRY(gn_any16(raw[0], k.bn1, nullptr, a1, B, oh * ow, co, 1, st));
+    TRY(gn_any16(raw[0], k.bn1, nullptr, a1, B, oh * ow, co, 1, st, f16));
     TRY(conv(k.conv2, a1, raw[1], oh, ow));
     const __bf16* identity = cur;
     if (k.has_down) {
       TRY(conv(k.down, cur, raw[2], h, wd));
-      TRY(gn_any16(raw[2], k.bnd, nullptr, idt, B, oh * ow, co, 0, st));
+      TRY(gn_any16(raw[2], k.bnd, nullptr, idt, B, oh * ow, co, 0, st, f16));
       identity = idt;
     }
-    TRY(gn_any16(raw[1], k.bn2, identity, nxt, B, oh * ow, co, 1, st));
+    TRY(gn_any16(raw[1], k.bn2, identity, nxt, B, oh * ow, co, 1, st, f16));
     __bf16* o = cur; cur = nxt; nxt = o;
     h = oh; wd = ow; ch = co;
   }
   if (net->fc.in_f != h * wd * ch || !net->fc.w16) return AVLEN_ERR_ARG;
-  return avlen_gemm_bf16(cur, net->fc.in_f, net->fc.w16, net->fc.ld16, out, ld_out, nullptr, 0, net->fc.b, nullptr, 0, B,
-                         net->fc.out_f, net->fc.in_f, 0, gws, CONV_SCRATCH, st);
+  return avlen_gemm_h16(cur, net->fc.in_f, net->fc.w16, net->fc.ld16, out, ld_out, nullptr, 0, net->fc.b, nullptr, 0, B,
+                        net->fc.out_f, net->fc.in_f, 0, f16 ? 1 : 0, gws, CONV_SCRATCH, st);
 }
 
 }  // namespace
@@ -295,11 +302,12 @@ extern "C" int avlen_resnet18_any_fwd(const avlen_resnet18* net, const float* x,
   // widest activation: conv1 / layer1 at (h1, w1, 16); every later stage halves the extent and doubles the channels
   const int h1 = conv_out(H, net->conv1), w1 = conv_out(W, net->conv1);
   if (h1 <= 0 || w1 <= 0 || h1 > H || w1 > W || net->conv1.cout > 16) return AVLEN_ERR_ARG;
-  if (prec == AVLEN_PREC_BF16) {
+  if (prec == AVLEN_PREC_BF16 || prec == AVLEN_PREC_FP16) {        // the caller packed the 16-bit weights in the matching format
     bool ok = conv16_ok(net->conv1) && net->fc.w16;
     for (int i = 0; i < 8 && ok; i++)
       ok = conv16_ok(net->block[i].conv1) && conv16_ok(net->block[i].conv2) && (!net->block[i].has_down || conv16_ok(net->block[i].down));
-    if (ok) return any_fwd_bf16(net, x, B, H, W, C, out, ld_out, ws, ws_bytes, st);
+    if (ok) return any_fwd_bf16(net, x, B, H, W, C, out, ld_out, ws, ws_bytes, st, prec == AVLEN_PREC_FP16);
+    if (prec == AVLEN_PREC_FP16) return AVLEN_ERR_ARG;             // no fp16 fallback
   }
   WsBump w(ws, ws_bytes);
   const size_t act = (size_t)B * H * W * 16;
@@ -348,7 +356,7 @@ extern "C" size_t avlen_resnet18_tv_workspace_bytes(int B, int H, int W) {
 namespace {
 // bf16 flow of the BatchNorm-folded torchvision ResNet: operands bf16 (x16 / t16), residual stream kept in fp32 beside it
 int tv_fwd_bf16(const avlen_resnet18* net, const float* x, int B, int H, int W, int C, float* out, int ld_out, void* ws,
-                size_t ws_bytes, hipStream_t st) {
+                size_t ws_bytes, hipStream_t st, int f16 = 0) {
   WsBump w(ws, ws_bytes);
   const size_t act = (size_t)B * ((H + 1) / 2 + 1) * ((W + 1) / 2 + 1) * 64;
   const avlen_conv& c1 = net->conv1;
@@ -360,10 +368,11 @@ int tv_fwd_bf16(const avlen_resnet18* net, const float* x, int B, int H, int W, 
   void* gws = w.take<char>(CONV_SCRATCH);
   if (!w.ok() || c1.cin16 != 8) return AVLEN_ERR_WS;
   auto conv = [&](const avlen_conv& k, const __bf16* in, const float* res, float* o32, __bf16* o16, int h, int wd, int act_) {
-    return avlen_conv2d_nhwc_bf16(in, k.w16, k.b, res, o32, o16, nullptr, B, h, wd, k.cin16, k.cout, k.kh, k.kw, k.stride, k.pad,
-                                  act_, gws, CONV_SCRATCH, st);
+    avlen_g2_opts go; go.f16 = f16;
+    return avlen_conv2d_nhwc_h16(in, k.w16, k.b, res, o32, o16, nullptr, B, h, wd, k.cin16, k.cout, k.kh, k.kw, k.stride, k.pad,
+                                 act_, gws, CONV_SCRATCH, st, &go);
   };
-  TRY(avlen_cast_bf16(x, C, x16, 8, (long)B * H * W, C, st));
+  TRY(avlen_cast_h16(x, C, x16, 8, (long)B * H * W, C, f16 ? 1 : 0, st));
   const int h1 = conv_out(H, c1), w1 = conv_out(W, c1);
   if (h1 <= 0 || w1 <= 0 || (size_t)B * h1 * w1 * c1.cout > act) return AVLEN_ERR_ARG;
   TRY(conv(c1, x16, nullptr, f32[0], nullptr, H, W, AVLEN_ACT_RELU));
@@ -372,7 +381,7 @@ int tv_fwd_bf16(const avlen_resnet18* net, const float* x, int B, int H, int W, 
   {
     long tot = (long)B * h * wd * ch;
     hipLaunchKernelGGL(maxpool_nhwc2_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, f32[0], cur32, cur16, B, h1, w1,
-                       ch, h, wd, 3, 2, 1);
+                       ch, h, wd, 3, 2, 1, f16);
     TRY(avlen_launch_status());
   }
   float* nxt32 = f32[0]; float* down32 = f32[2]; __bf16* t16 = h16[1]; __bf16* nxt16 = h16[2];
@@ -395,8 +404,8 @@ int tv_fwd_bf16(const avlen_resnet18* net, const float* x, int B, int H, int W, 
   if (net->fc.in_f != ch) return AVLEN_ERR_ARG;
   hipLaunchKernelGGL(avgpool_nhwc_kernel, dim3(B), dim3(256), 0, st, cur32, pooled, h * wd, ch);
   TRY(avlen_launch_status());
-  return avlen_gemm(pooled, ch, 0, net->fc.w, ch, 0, out, ld_out, net->fc.b, nullptr, 0, B, net->fc.out_f, ch, 0, AVLEN_PREC_BF16, 1,
-                    0.f, nullptr, 0, st);
+  return avlen_gemm(pooled, ch, 0, net->fc.w, ch, 0, out, ld_out, net->fc.b, nullptr, 0, B, net->fc.out_f, ch, 0,
+                    f16 ? AVLEN_PREC_BF16X3 : AVLEN_PREC_BF16, 1, 0.f, nullptr, 0, st);
 }
 }  // namespace
 
@@ -404,11 +413,12 @@ extern "C" int avlen_resnet18_tv_fwd(const avlen_resnet18* net, const float* x, 
                                      int ld_out, int prec, void* ws, size_t ws_bytes, hipStream_t st) {
   if (!net || !x || !out || B <= 0 || C != net->conv1.cin || !net->conv1.b || ws_bytes < avlen_resnet18_tv_workspace_bytes(B, H, W))
     return AVLEN_ERR_WS;
-  if (prec == AVLEN_PREC_BF16) {
+  if (prec == AVLEN_PREC_BF16 || prec == AVLEN_PREC_FP16) {
     bool ok = conv16_ok(net->conv1);
     for (int i = 0; i < 8 && ok; i++)
       ok = conv16_ok(net->block[i].conv1) && conv16_ok(net->block[i].conv2) && (!net->block[i].has_down || conv16_ok(net->block[i].down));
-    if (ok) return tv_fwd_bf16(net, x, B, H, W, C, out, ld_out, ws, ws_bytes, st);
+    if (ok) return tv_fwd_bf16(net, x, B, H, W, C, out, ld_out, ws, ws_bytes, st, prec == AVLEN_PREC_FP16);
+    if (prec == AVLEN_PREC_FP16) return AVLEN_ERR_ARG;
   }
   WsBump w(ws, ws_bytes);
   const size_t act = (size_t)B * ((H + 1) / 2 + 1) * ((W + 1) / 2 + 1) * 64;

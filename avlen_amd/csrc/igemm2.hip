@@ -623,18 +623,13 @@ int launch_cv(const G2& p, int m_tiles, int n_tiles, hipStream_t st) {
   hipLaunchKernelGGL((g2_kernel<BM, BN, WM, WN, NS, NTH, CONV, F16>), dim3(m_tiles * n_tiles, p.groups, p.splitk), dim3(NTH), lds, st, p);
   return avlen_launch_status();
 }
-// the implicit-GEMM gather (tap decode, bounds tests) is compiled out of the plain-GEMM instances; fp16 operands are
-// instantiated for the tiles their users reach: plain GEMMs on the 8-wave 128-column tiles (CLIP text tower, dialog_layer) and
-// convolutions on the 4-wave small-N tiles and the 8-wave 64-column tile (AudioCNN)
+// the implicit-GEMM gather (tap decode, bounds tests) is compiled out of the plain-GEMM instances; fp16 operands exist on every
+// tile (CLIP text tower, dialog_layer, AudioCNN, BeliefPredictor's ResNets incl. their 2-column fc)
 template <int BM, int BN, int WM, int WN, int NS, int NTH>
 int launch_ns(const G2& p, int m_tiles, int n_tiles, hipStream_t st) {
-  if (p.f16) {
-    if constexpr (NTH == 512 && BN == 128)
-      if (!p.conv) return launch_cv<BM, BN, WM, WN, NS, NTH, false, true>(p, m_tiles, n_tiles, st);
-    if constexpr (BN <= 64)
-      if (p.conv) return launch_cv<BM, BN, WM, WN, NS, NTH, true, true>(p, m_tiles, n_tiles, st);
-    return AVLEN_ERR_ARG;
-  }
+  if (p.f16)
+    return p.conv ? launch_cv<BM, BN, WM, WN, NS, NTH, true, true>(p, m_tiles, n_tiles, st)
+                  : launch_cv<BM, BN, WM, WN, NS, NTH, false, true>(p, m_tiles, n_tiles, st);
   return p.conv ? launch_cv<BM, BN, WM, WN, NS, NTH, true>(p, m_tiles, n_tiles, st)
                 : launch_cv<BM, BN, WM, WN, NS, NTH, false>(p, m_tiles, n_tiles, st);
 }
@@ -788,6 +783,13 @@ extern "C" int avlen_conv2d_nhwc_bf16(const void* X, const void* Wp, const float
                                       float* Y32, void* Y16, float* gn_stats, int Bn, int H, int W, int Cin, int Cout,
                                       int KH, int KW, int stride, int pad, int act, void* ws, size_t ws_bytes,
                                       hipStream_t stream) {
+  return avlen_conv2d_nhwc_h16(X, Wp, bias, residual, Y32, Y16, gn_stats, Bn, H, W, Cin, Cout, KH, KW, stride, pad, act, ws, ws_bytes,
+                               stream, nullptr);
+}
+// the same convolution with options (o->f16: fp16 operands / 16-bit output in IEEE half)
+int avlen_conv2d_nhwc_h16(const void* X, const void* Wp, const float* bias, const float* residual, float* Y32, void* Y16,
+                          float* gn_stats, int Bn, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int act,
+                          void* ws, size_t ws_bytes, hipStream_t stream, const avlen_g2_opts* o) {
   if (Cin < 8 || (Cin & (Cin - 1))) return AVLEN_ERR_ARG;       // power of two >= 8 (conv1 input is channel-padded)
   int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
   if (OH <= 0 || OW <= 0) return AVLEN_ERR_ARG;
@@ -802,6 +804,7 @@ extern "C" int avlen_conv2d_nhwc_bf16(const void* X, const void* Wp, const float
   }
   int l2 = 0; while ((1 << l2) < Cin) l2++;
   p.cin_log2 = l2; p.kw_magic = (65536 + KW - 1) / KW;
+  apply_opts(p, o);
   return run_g2(p, ws, ws_bytes, stream);
 }
 

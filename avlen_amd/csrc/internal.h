@@ -141,3 +141,6 @@ int avlen_clip_tower_stream_fwd(const avlen_clip_text* p, const int64_t* tokens,
                                 hipStream_t st);
 // fp32 rows -> compensated bf16 pair in one pass (hi plane at dst, lo plane `lo` elements behind it)
 int avlen_cast_pair(const float* src, int ld_src, void* dst, int ld_dst, long rows, int cols, long lo, hipStream_t stream);
+int avlen_conv2d_nhwc_h16(const void* X, const void* Wp, const float* bias, const float* residual, float* Y32, void* Y16,
+                          float* gn_stats, int Bn, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int act,
+                          void* ws, size_t ws_bytes, hipStream_t stream, const avlen_g2_opts* o);

@@ -170,7 +170,7 @@ class Packed:
             v.w16c = P(bufc)
         return v
 
-    def conv_bn(self, conv, bn):
+    def conv_bn(self, conv, bn, fmt=0):
         """conv followed by an eval-mode BatchNorm2d, folded: w' = w * gamma / sqrt(var + eps) per output channel,
         b' = beta - mean * gamma / sqrt(var + eps)  (torchvision BasicBlock, belief_predictor.py:79-81)."""
         O, I, KH, KW = conv.weight.shape
@@ -182,7 +182,7 @@ class Packed:
             c16 *= 2
         buf16 = torch.empty(O * KH * KW * c16, dtype=torch.bfloat16, device=self.device)
         self.bufs += [buf, wf, bias, buf16]
-        self.jobs.append(("convbn", conv.weight, buf, (bn, wf, bias, buf16), (O, I, KH, KW), c16))
+        self.jobs.append(("convbn", conv.weight, buf, (bn, wf, bias, buf16), (O, I, KH, KW), (c16, fmt)))
         v = L.Conv(P(buf), P(bias), I, O, KH, KW, conv.stride[0], conv.padding[0])
         v.w16, v.cin16 = P(buf16), c16
         return v
@@ -248,7 +248,7 @@ class Packed:
                     wf.copy_(w * scale[:, None, None, None])
                     bias.copy_(bn.bias - bn.running_mean * scale)
                 L.call("avlen_pack_conv_weight", P(wf), P(buf), *dims, st)
-                L.call("avlen_pack_conv_weight_bf16", P(wf), P(w16), *dims, c16, st)
+                L.call("avlen_pack_conv_weight_h16", P(wf), P(w16), *dims, c16[0], c16[1], st)
             elif kind == "frag":                      # queued after the conv's own job: w16 is up to date
                 L.call("avlen_pack_conv_weight_frag", P(w), P(buf16), dims[0], dims[1], st)
             elif kind == "clipstream":
@@ -291,41 +291,42 @@ def resnet18_view(net, packed):
     return s
 
 
-def resnet18_any_view(net, packed, fc_c, fc_hw):
-    """CustomResNet at a non-64x64 input (BeliefPredictor.predictor): fp32-staged kernels, fc packed for (fc_c, fc_hw)."""
+def resnet18_any_view(net, packed, fc_c, fc_hw, fmt=0):
+    """CustomResNet at a non-64x64 input (BeliefPredictor.predictor): fp32-staged kernels, fc packed for (fc_c, fc_hw).
+    fmt: format of the 16-bit weight copies (0 bf16, 1 fp16: AVLEN_PREC_FP16 calls)."""
     s = L.ResNet18()
-    s.conv1 = packed.conv(net.conv1, False)
+    s.conv1 = packed.conv(net.conv1, False, fmt=fmt)
     s.bn1 = affine_view(net.bn1)
     i = 0
     for layer in (net.layer1, net.layer2, net.layer3, net.layer4):
         for blk in layer:
             b = s.block[i]
-            b.conv1 = packed.conv(blk.conv1, False)
-            b.conv2 = packed.conv(blk.conv2, False)
+            b.conv1 = packed.conv(blk.conv1, False, fmt=fmt)
+            b.conv2 = packed.conv(blk.conv2, False, fmt=fmt)
             b.bn1, b.bn2 = affine_view(blk.bn1), affine_view(blk.bn2)
             b.has_down = 0
             if blk.downsample is not None:
-                b.down = packed.conv(blk.downsample[0], False)
+                b.down = packed.conv(blk.downsample[0], False, fmt=fmt)
                 b.bnd = affine_view(blk.downsample[1])
                 b.has_down = 1
             i += 1
-    s.fc = packed.fc_after_flatten(net.fc, fc_c, fc_hw)
+    s.fc = packed.fc_after_flatten(net.fc, fc_c, fc_hw, fmt=fmt)
     return s
 
 
-def resnet18_tv_view(net, packed):
-    """torchvision resnet18 with its BatchNorms folded into the convs (BeliefPredictor.classifier)."""
+def resnet18_tv_view(net, packed, fmt=0):
+    """torchvision resnet18 with its BatchNorms folded into the convs (BeliefPredictor.classifier); fmt as resnet18_any_view."""
     s = L.ResNet18()
-    s.conv1 = packed.conv_bn(net.conv1, net.bn1)
+    s.conv1 = packed.conv_bn(net.conv1, net.bn1, fmt)
     i = 0
     for layer in (net.layer1, net.layer2, net.layer3, net.layer4):
         for blk in layer:
             b = s.block[i]
-            b.conv1 = packed.conv_bn(blk.conv1, blk.bn1)
-            b.conv2 = packed.conv_bn(blk.conv2, blk.bn2)
+            b.conv1 = packed.conv_bn(blk.conv1, blk.bn1, fmt)
+            b.conv2 = packed.conv_bn(blk.conv2, blk.bn2, fmt)
             b.has_down = 0
             if blk.downsample is not None:
-                b.down = packed.conv_bn(blk.downsample[0], blk.downsample[1])
+                b.down = packed.conv_bn(blk.downsample[0], blk.downsample[1], fmt)
                 b.has_down = 1
             i += 1
     s.fc = linear_view(net.fc.weight, net.fc.bias)

@@ -90,7 +90,7 @@ def test_filter_alone_is_float32_exact_vs_oracle():
     assert [bool(h) for h in has_lab.cpu()] == [v is not None for v in filt.last_label]
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 2e-3), ("bf16", 6e-2)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-3), ("bf16", 6e-2), ("bf16x3", 8e-3)])     # bf16x3 policies: fp16 inference here
 def test_both_halves_vs_oracle(precision, tol):
     N = 4
     bp = BeliefPredictor(cfg(label=True), "cuda", None, None, 512, num_env=N, precision=precision, load_pretrained=False)
