@@ -151,13 +151,15 @@ __device__ __forceinline__ int clip_kv_lds(int idx16) {      // 16-byte chunk in
   return (kv ? VS_OFF + head * 96 * QK_ROW : KS_OFF + head * 80 * QK_ROW) + row * QK_ROW + col * 16;
 }
 __device__ __forceinline__ void clip_publish_kv(const ClipArgs& a, const char* lds, int b, int seq0, int tid) {
-  gu64* slot = (gu64*)(a.xchg + ((long)b * CT_SLOTS + seq0) * CT_SLOT);
+  char* slot = a.xchg + ((long)b * CT_SLOTS + seq0) * CT_SLOT;
+  unsigned lo16 = (unsigned)tid;
+  asm volatile("" : "+v"(lo16));
 #pragma unroll
-  for (int k = 0; k < CT_SLOT / 16 / CT_TH; k++) {
+  for (int k = 0; k < CT_SLOT / 16 / CT_TH; k++) {          // write-through (sc1) 16-byte stores, as the exchange below
     const int c = tid + k * CT_TH;
-    const uint4 v = *reinterpret_cast<const uint4*>(lds + clip_kv_lds(c));
-    __hip_atomic_store(slot + 2 * c, ((unsigned long long)v.y << 32) | v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(slot + 2 * c + 1, ((unsigned long long)v.w << 32) | v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(lds + clip_kv_lds(c));
+    const f32x4* dstp = reinterpret_cast<const f32x4*>(slot + (long)k * CT_TH * 16) + lo16;
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dstp), "v"(v) : "memory");
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave: its stores have left
   __syncthreads();
@@ -172,18 +174,24 @@ __device__ __forceinline__ bool clip_fetch_kv(const ClipArgs& a, char* lds, int 
       __builtin_amdgcn_s_sleep(8);
       if (++spins > (1u << 24)) { good = 0; break; }        // seconds without the producer: give up (garbage output) rather than hang
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     *ok = good;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    // sc1 form (see clip_exchange): every load of the slot is an sc1 load
   __syncthreads();
   if (*ok == 0) return false;
-  const uint4* slot = reinterpret_cast<const uint4*>(a.xchg + ((long)b * CT_SLOTS + seq0) * CT_SLOT);
+  const char* slot = a.xchg + ((long)b * CT_SLOTS + seq0) * CT_SLOT;
+  unsigned lo16 = (unsigned)tid;
+  asm volatile("" : "+v"(lo16));
+  f32x4 v[CT_SLOT / 16 / CT_TH];
 #pragma unroll
   for (int k = 0; k < CT_SLOT / 16 / CT_TH; k++) {
-    const int c = tid + k * CT_TH;
-    *reinterpret_cast<uint4*>(lds + clip_kv_lds(c)) = slot[c];
+    const f32x4* src = reinterpret_cast<const f32x4*>(slot + (long)k * CT_TH * 16) + lo16;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[k]) : "v"(src) : "memory");
   }
+  static_assert(CT_SLOT / 16 / CT_TH == 3, "operands of the wait below");
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]) :: "memory");
+#pragma unroll
+  for (int k = 0; k < CT_SLOT / 16 / CT_TH; k++) *reinterpret_cast<f32x4*>(lds + clip_kv_lds(tid + k * CT_TH)) = v[k];
   lds_barrier();
   return true;
 }
@@ -223,23 +231,31 @@ __device__ __forceinline__ bool clip_exchange(const ClipArgs& a, char* lds, f32x
       __builtin_amdgcn_s_sleep(4);
       if (++spins > (1u << 24)) { good = 0; break; }        // seconds without the partner: give up (garbage output) rather than hang
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     *ok = good;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    // (no instruction: keeps the compiler from moving loads above the poll)
   __syncthreads();
   if (*ok == 0) return false;
-  {                                                         // ALL loads in flight at once: one round trip, not one per row tile
-    float4 v[NT][4];
+  // Guideline 16, sc1 form: every byte of the slot was stored sc1 and drained before the flag, and EVERY load of it here is an sc1
+  // load to registers (they bypass this CU's L1, which may hold the slot's lines of two exchanges ago) -- so the agent-scope acquire
+  // (buffer_inv sc1, ~1.7 us) is not needed.  hipcc does not count the loads of an asm statement: the waits are explicit, and the
+  // registers are operands of the wait so that no use can be scheduled in front of it.
+  {
+    f32x4 v[NT][4];
 #pragma unroll
     for (int i = 0; i < NT; i++)
 #pragma unroll
-      for (int j = 0; j < 4; j++) v[i][j] = reinterpret_cast<const float4*>(theirs + (long)(i * 4 + j) * CT_TH * 16)[lo16];
-    __builtin_amdgcn_sched_barrier(0);
+      for (int j = 0; j < 4; j++) {
+        const float4* src = reinterpret_cast<const float4*>(theirs + (long)(i * 4 + j) * CT_TH * 16) + lo16;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[i][j]) : "v"(src) : "memory");
+      }
+#pragma unroll
+    for (int i = 0; i < NT; i++)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[i][0]), "+v"(v[i][1]), "+v"(v[i][2]), "+v"(v[i][3]) :: "memory");
 #pragma unroll
     for (int i = 0; i < NT; i++)
 #pragma unroll
-      for (int j = 0; j < 4; j++) { xr[i][j][0] += v[i][j].x; xr[i][j][1] += v[i][j].y; xr[i][j][2] += v[i][j].z; xr[i][j][3] += v[i][j].w; }
+      for (int j = 0; j < 4; j++) xr[i][j] += v[i][j];
   }
   __syncthreads();                                          // the flag word in LDS is free again
   return true;

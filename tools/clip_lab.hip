@@ -5,6 +5,8 @@
 #include "../avlen_amd/csrc/clip_tower.hip"
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <cmath>
 #include <vector>
 int avlen_zero_bytes(void* p, size_t bytes, hipStream_t s) { return hipMemsetAsync(p, 0, bytes, s) == hipSuccess ? 0 : 2; }
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
@@ -81,7 +83,14 @@ int main(int argc, char** argv) {
   printf("clip_tower_kernel: %d dialogs: %.1f us per launch\n", B, ms * 200.f);
   std::vector<long long> hp((size_t)4 * B * 8); CK(hipMemcpy(hp.data(), prof, hp.size() * 8, hipMemcpyDeviceToHost));
   std::vector<float> he((size_t)B * 512); CK(hipMemcpy(he.data(), E, he.size() * 4, hipMemcpyDeviceToHost));
-  double cs = 0; for (float v : he) cs += v; printf("  output checksum %.6f\n", cs);
+  double cs = 0; for (float v : he) cs += v; printf("  output checksum %.6f (the random inputs differ from process to process: rand() is shared with the runtime)\n", cs);
+  {   // run-to-run determinism inside this process: one more launch, bitwise comparison
+    run(); CK(hipDeviceSynchronize());
+    std::vector<float> he2((size_t)B * 512); CK(hipMemcpy(he2.data(), E, he2.size() * 4, hipMemcpyDeviceToHost));
+    size_t diff = 0; for (size_t i = 0; i < he.size(); i++) diff += memcmp(&he[i], &he2[i], 4) != 0;
+    double amax = 0; for (float v : he) amax = fabs(v) > amax ? fabs(v) : amax;
+    printf("  relaunch: %zu of %zu output words differ; max |output| %.3g\n", diff, he.size(), amax);
+  }
   static const char* NAME[8] = {"ln1", "in_proj", "attention", "out_proj", "ln2", "c_fc + gelu", "c_proj", "bias / loop"};
   double tot_mean = 0, tot_max = 0;
   for (int k = 0; k < 8; k++) {
