@@ -556,6 +556,10 @@ __device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, co
 #undef CT_STEP
 }
 
+// Measured and rejected: the MLP in 512-unit chunks (four column tiles per activation fragment, half the barriers; the hidden image
+// over Q | K | V) -- fully unrolled, an instance's layer body (~24 KB of code) grew to ~35 KB, two instances on the CUs that share a
+// 64 KB instruction cache no longer fitted: 700 -> 2000 us; with the k-steps in groups of four (non-unrolled group loop) it fitted
+// again but the ring spilled across the loop: 716 us against 698.  The unrolled bodies are sized for that cache.
 // Measured and rejected: the same body on FOUR waves (one per SIMD, 512 registers each: residual stream + projection accumulators in
 // the accumulator file, a 16-32 fragment ring, no spills at <= 3 tiles) -- 1060 / 1583 us at 40 / 72 tokens against 880 / 1200 on eight
 // waves: a lone wave per SIMD cannot hide its own LDS / waitcnt / MFMA-issue latencies.
