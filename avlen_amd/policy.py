@@ -490,6 +490,9 @@ class Policy(nn.Module):
         return _PREC[mp[module]] if mp and module in mp else _PREC[self.precision]
 
     def _engine(self):
+        eng = self._eng
+        if eng is not None and not self._dirty:          # the common case, several times per step: no parameter walk
+            return eng                                   # (moving the module resets _eng in _apply; weight changes set _dirty)
         p0 = next(self.parameters())
         if not p0.is_cuda:
             raise RuntimeError("avlen_amd policies run on an MI355X only: move the policy to a HIP device "

@@ -3,7 +3,7 @@ import sys, os, cProfile, pstats
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from avlen_amd.harness import Workload
-wl = Workload(64, 150, spectrogram=(257, 101, 2), precision="bf16", pretraining=True)
+wl = Workload(64, 150, spectrogram=(257, 101, 2), precision=os.environ.get("AVLEN_PREC", "bf16x3"), pretraining=True)
 wl.cycle()
 torch.cuda.synchronize()
 pr = cProfile.Profile()
