@@ -1,0 +1,286 @@
+// Direct convolution weight gradient for the 3-conv CNNs of the GRU baseline (BASELINE configs[1]; audio_cnn.py:62-94,
+// visual_cnn.py:82-107: valid convolutions, NHWC activations kept in fp32 by the training forward):
+//   dW[co][kh][kw][ci] = sum_{b, oh, ow} dY[b][oh][ow][co] * X[b][oh*s + kh][ow*s + kw][ci]        db[co] = sum dY[b][oh][ow][co]
+// The contraction runs over the output positions, so the MFMA's k index must walk positions while each lane keeps one channel --
+// the transposed layout of both operands.  The GEMM route (modules.hip:avlen_i_conv_dw16) materialises that layout in HBM: a
+// transposed bf16 im2col of X (K x M, up to 1.9 GB for one conv) and a transposed cast of dY, both read back by the GEMM; 14.8 % of
+// the cfg2 cycle was the im2col pass alone (profiles/r03_rocprof_gru.md).  Here nothing is materialised:
+//   * the k index of one MFMA is (4 output positions of one output row) x (8 IMAGES): a workgroup owns 8 images at a time and LDS
+//     holds every element as a 16-byte group of its 8 images' bf16 values, so an operand fragment of either matrix is ONE aligned
+//     ds_read_b128 whatever the stride, kernel size or width (no padded runs, no alignment cases);
+//   * a workgroup walks down the output rows of its 8 images with the KH input rows it needs in an LDS ring: moving one row down
+//     brings in `stride` new input rows and one dY row, fetched (fp32, coalesced along the NHWC rows, 8 images per lane) into
+//     registers while the MFMAs of the current row run, packed to bf16 and written as conflict-free 16-byte stores;
+//   * 8 waves split the K = KH*KW*C columns in 16-wide tiles, every wave holds all cout rows of its tiles in accumulators for the
+//     whole launch; one partial per workgroup, summed in fixed order by a second small kernel (deterministic), the bias gradient
+//     comes out of the fp32 dY values on their way into LDS.
+// X and dY are each read once: the kernel is bound by that traffic (fp32 activations), not by the products.
+#include "common.h"
+#include "../../include/avlen_hip.h"
+#include "internal.h"
+
+namespace {
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int DW_TH = 512;      // 8 waves
+constexpr int DW_XE = 8;        // 16-byte elements of new input rows per thread and row step   (stride * W * C <= DW_XE * DW_TH; template: 4 or 8)
+constexpr int DW_YE = 4;        // ... of one dY row                                             (OW * cout     <= DW_YE * DW_TH)
+
+struct DwArgs {
+  const float* X; const float* dY; float* part;
+  int R, H, Wc, C, OH, OW, KH, KW, s, cout, K, Kp;
+  int octets, TL;               // groups of 8 images; octets * OH row steps in all
+  unsigned xring_bytes, y_off, lds_bytes;
+};
+
+__device__ __forceinline__ bf16x8 pack8(const float (&v)[8]) {
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; e++) o[e] = (bf16)v[e];
+  return o;
+}
+
+template <int MT, int NTW, int XE>
+__global__ __launch_bounds__(DW_TH) void conv_dw_kernel(const DwArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int Wc = a.Wc, KH = a.KH, s = a.s, OW = a.OW, cout = a.cout;
+  // all of LDS finite: operand fragments of padded positions / columns read it
+  for (unsigned o = tid * 16u; o < a.lds_bytes; o += DW_TH * 16u) *reinterpret_cast<uint4*>(lds + o) = make_uint4(0, 0, 0, 0);
+  char* const ybase = lds + a.y_off;
+
+  // this wave's K columns: tiles wv, wv + 8, ...; lane li is column n (clamped: columns >= K are computed and dropped)
+  unsigned col_off[NTW]; int col_kh[NTW];
+#pragma unroll
+  for (int q = 0; q < NTW; q++) {
+    int n = (wv + 8 * q) * 16 + li;
+    n = n < a.K ? n : a.K - 1;
+    const int per = a.KW * a.C;
+    col_kh[q] = n / per;
+    col_off[q] = (unsigned)(n - col_kh[q] * per) * 16u + (unsigned)(lg * s * a.C) * 16u;
+  }
+  f32x4 acc[MT][NTW];
+#pragma unroll
+  for (int m = 0; m < MT; m++)
+#pragma unroll
+    for (int q = 0; q < NTW; q++) acc[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;                                    // bias gradient of channel tid % cout (DW_TH % cout == 0)
+
+  float xr[XE][8], yr[DW_YE][8];
+  auto load_x = [&](int o, int ih0, int nr) {
+    const int total = nr * Wc;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const int b = o * 8 + e;
+      const float* p = a.X + ((long)(b < a.R ? b : 0) * a.H + ih0) * Wc;
+      const float keep = b < a.R ? 1.f : 0.f;
+#pragma unroll
+      for (int j = 0; j < XE; j++) { const int idx = tid + DW_TH * j; xr[j][e] = idx < total ? p[idx] * keep : 0.f; }
+    }
+  };
+  auto store_x = [&](int ih0, int nr) {
+    const int total = nr * Wc;
+#pragma unroll
+    for (int j = 0; j < XE; j++) {
+      const int idx = tid + DW_TH * j;
+      if (idx < total) {
+        const int r = idx / Wc, col = idx - r * Wc;
+        const int slot = (ih0 + r) % KH;
+        *reinterpret_cast<bf16x8*>(lds + ((unsigned)(slot * Wc + col)) * 16u) = pack8(xr[j]);
+      }
+    }
+  };
+  auto load_y = [&](int o, int oh) {
+    const int total = OW * cout;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const int b = o * 8 + e;
+      const float* p = a.dY + ((long)(b < a.R ? b : 0) * a.OH + oh) * total;
+      const float keep = b < a.R ? 1.f : 0.f;
+#pragma unroll
+      for (int j = 0; j < DW_YE; j++) { const int idx = tid + DW_TH * j; yr[j][e] = idx < total ? p[idx] * keep : 0.f; }
+    }
+  };
+  auto store_y = [&]() {
+    const int total = OW * cout;
+#pragma unroll
+    for (int j = 0; j < DW_YE; j++) {
+      const int idx = tid + DW_TH * j;
+      if (idx < total) {
+        float t = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) t += yr[j][e];
+        bsum += t;
+        *reinterpret_cast<bf16x8*>(ybase + (unsigned)idx * 16u) = pack8(yr[j]);
+      }
+    }
+  };
+
+  const int L0 = (int)((long)blockIdx.x * a.TL / gridDim.x), L1 = (int)((long)(blockIdx.x + 1) * a.TL / gridDim.x);
+  const int nks = (OW + 3) >> 2;
+  const unsigned a_step = 4u * cout * 16u, b_step = 4u * s * a.C * 16u;
+  for (int L = L0; L < L1; L++) {
+    const int o = L / a.OH, oh = L - o * a.OH;
+    if (L == L0 || oh == 0) {                          // (re)fill the ring: rows oh*s .. oh*s + KH - 1, `s` at a time
+      __syncthreads();
+      for (int r0 = 0; r0 < KH; r0 += s) {
+        const int nr = KH - r0 < s ? KH - r0 : s;
+        load_x(o, oh * s + r0, nr);
+        store_x(oh * s + r0, nr);
+      }
+      load_y(o, oh);
+      store_y();
+      __syncthreads();
+    }
+    const bool pf = L + 1 < L1 && oh + 1 < a.OH;      // next row step: same images
+    if (pf) { load_x(o, oh * s + KH, s); load_y(o, oh + 1); }
+    // ---- the products of output row oh
+    unsigned ba[NTW];
+#pragma unroll
+    for (int q = 0; q < NTW; q++) ba[q] = (unsigned)(((oh * s + col_kh[q]) % KH) * Wc) * 16u + col_off[q];
+    unsigned aa = (unsigned)(lg * cout + li) * 16u;
+    bf16x8 af[2][MT], bfr[2][NTW];
+    auto fetch = [&](int buf) {
+#pragma unroll
+      for (int m = 0; m < MT; m++) af[buf][m] = *reinterpret_cast<const bf16x8*>(ybase + aa + m * 256u);
+#pragma unroll
+      for (int q = 0; q < NTW; q++) bfr[buf][q] = *reinterpret_cast<const bf16x8*>(lds + ba[q]);
+      aa += a_step;
+#pragma unroll
+      for (int q = 0; q < NTW; q++) ba[q] += b_step;
+    };
+    auto mma = [&](int buf) {
+#pragma unroll
+      for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int q = 0; q < NTW; q++) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[buf][m], bfr[buf][q], acc[m][q], 0, 0, 0);
+    };
+    fetch(0);
+    int ks = 0;
+    for (; ks + 2 <= nks; ks += 2) {
+      fetch(1); mma(0);
+      if (ks + 2 < nks) fetch(0);
+      mma(1);
+    }
+    if (ks < nks) mma(0);
+    if (pf) {
+      __syncthreads();
+      store_x(oh * s + KH, s);
+      store_y();
+      __syncthreads();
+    }
+  }
+
+  // ---- this workgroup's partial: [cout][Kp] then [cout] bias sums
+  float* const P = a.part + (size_t)blockIdx.x * ((size_t)cout * a.Kp + cout);
+#pragma unroll
+  for (int m = 0; m < MT; m++)
+#pragma unroll
+    for (int q = 0; q < NTW; q++) {
+      const int nt = wv + 8 * q;
+      if (nt * 16 < a.Kp) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) P[(size_t)(m * 16 + lg * 4 + r) * a.Kp + nt * 16 + li] = acc[m][q][r];
+      }
+    }
+  __syncthreads();
+  float* const sh = reinterpret_cast<float*>(lds);
+  sh[tid] = bsum;
+  __syncthreads();
+  if (tid < cout) {
+    float t = 0.f;
+    for (int j = tid; j < DW_TH; j += cout) t += sh[j];
+    P[(size_t)cout * a.Kp + tid] = t;
+  }
+}
+
+// gw[co][k] = sum over the workgroups' partials (fixed order); gb[co] += their bias sums
+__global__ void conv_dw_reduce_kernel(const float* __restrict__ part, int nparts, int cout, int K, int Kp, float* __restrict__ gw,
+                                      float* __restrict__ gb) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)cout * Kp + cout;
+  if (i < cout * K) {
+    const int co = i / K, k = i - co * K;
+    const float* p = part + (size_t)co * Kp + k;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    int w = 0;
+    for (; w + 4 <= nparts; w += 4) { t0 += p[w * stride]; t1 += p[(w + 1) * stride]; t2 += p[(w + 2) * stride]; t3 += p[(w + 3) * stride]; }
+    for (; w < nparts; w++) t0 += p[w * stride];
+    gw[i] = (t0 + t1) + (t2 + t3);
+  } else if (gb && i < cout * K + cout) {
+    const int co = i - cout * K;
+    const float* p = part + (size_t)cout * Kp + co;
+    float t = 0.f;
+    for (int w = 0; w < nparts; w++) t += p[w * stride];
+    gb[co] += t;
+  }
+}
+
+int n_cus() {
+  static int n[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (!n[dev]) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256; n[dev] = v; }
+  return n[dev];
+}
+
+template <int MT, int NTW, int XE>
+int launch_dw_x(const DwArgs& a, int grid, hipStream_t st) {
+  static unsigned long long done = 0;
+  if (avlen_set_dyn_lds(reinterpret_cast<const void*>(&conv_dw_kernel<MT, NTW, XE>), 160 * 1024, &done) != AVLEN_OK) return AVLEN_ERR_LAUNCH;
+  hipLaunchKernelGGL((conv_dw_kernel<MT, NTW, XE>), dim3(grid), dim3(DW_TH), a.lds_bytes, st, a);
+  return avlen_launch_status();
+}
+template <int MT, int NTW>
+int launch_dw(const DwArgs& a, int grid, hipStream_t st) {
+  return (long)a.s * a.Wc <= 4 * DW_TH ? launch_dw_x<MT, NTW, 4>(a, grid, st) : launch_dw_x<MT, NTW, DW_XE>(a, grid, st);
+}
+template <int MT>
+int launch_dw_n(const DwArgs& a, int ntw, int grid, hipStream_t st) {
+  switch (ntw) {
+    case 1: return launch_dw<MT, 1>(a, grid, st);
+    case 2: return launch_dw<MT, 2>(a, grid, st);
+    case 3: return launch_dw<MT, 3>(a, grid, st);
+    case 4: return launch_dw<MT, 4>(a, grid, st);
+    case 5: return launch_dw<MT, 5>(a, grid, st);
+  }
+  return AVLEN_NOT_BIG;
+}
+}  // namespace
+
+// gw [cout][KH*KW*C] (packed K order) = dY^T im2col(X), gb[cout] += column sums of dY (gb may be null).  bf16 operands, fp32
+// accumulation, valid convolution (no padding).  AVLEN_NOT_BIG: shape outside the kernel's limits (caller takes the GEMM route).
+// Scratch: c.gws (one partial per workgroup).
+int avlen_i_conv_dw_direct(const avlen_ctx& c, float* gw, float* gb, int cout, const float* dY, const float* X, long R, int H,
+                           int W, int C, int OH, int OW, int KH, int KW, int s) {
+  if (c.prec != AVLEN_PREC_BF16 || R <= 0 || R > (1L << 28) || (cout != 32 && cout != 64)) return AVLEN_NOT_BIG;
+  if (s < 1 || KH < s || (OH - 1) * s + KH > H || (OW - 1) * s + KW > W || OH < 1 || OW < 1) return AVLEN_NOT_BIG;
+  DwArgs a;
+  a.X = X; a.dY = dY; a.part = (float*)c.gws;
+  a.R = (int)R; a.H = H; a.Wc = W * C; a.C = C; a.OH = OH; a.OW = OW; a.KH = KH; a.KW = KW; a.s = s; a.cout = cout;
+  a.K = KH * KW * C; a.Kp = (a.K + 15) / 16 * 16;
+  const int ntw = (a.Kp / 16 + 7) / 8;
+  if (ntw > 5 || (long)s * a.Wc > DW_XE * DW_TH || (long)OW * cout > DW_YE * DW_TH) return AVLEN_NOT_BIG;
+  const int OWp = (OW + 3) & ~3;
+  const long over = ((long)(OWp - 1) * s + KW) * C - a.Wc;             // fragments of the padded positions read past the last ring row
+  a.xring_bytes = (unsigned)((long)KH * a.Wc * 16);
+  a.y_off = a.xring_bytes + (unsigned)((over > 0 ? over : 0) * 16);
+  a.lds_bytes = a.y_off + (unsigned)OWp * cout * 16u;
+  if (a.lds_bytes < DW_TH * 4u) a.lds_bytes = DW_TH * 4u;
+  if (a.lds_bytes > 160u * 1024u) return AVLEN_NOT_BIG;
+  a.octets = (int)((R + 7) / 8);
+  const long TL = (long)a.octets * OH;
+  if (TL > 0x7fffffffL) return AVLEN_NOT_BIG;
+  a.TL = (int)TL;
+  const int grid = (int)(TL < n_cus() ? TL : n_cus());
+  const size_t per = (size_t)cout * a.Kp + cout;
+  if (!c.gws || per * grid * 4 > c.gws_bytes) return AVLEN_NOT_BIG;
+  int rc = cout == 32 ? launch_dw_n<2>(a, ntw, grid, c.st) : launch_dw_n<4>(a, ntw, grid, c.st);
+  if (rc != AVLEN_OK) return rc;
+  const int tot = cout * a.K + cout;
+  hipLaunchKernelGGL(conv_dw_reduce_kernel, dim3((tot + 255) / 256), dim3(256), 0, c.st, a.part, grid, cout, a.K, a.Kp, gw, gb);
+  return avlen_launch_status();
+}

@@ -27,6 +27,10 @@ int avlen_i_colsum_acc(const avlen_ctx& c, const float* dY, int ld, float* out, 
 #define AVLEN_NOT_BIG 100
 int avlen_i_conv_dw16(const avlen_ctx& c, const avlen_linear& G, const float* dY, int ldy, const float* X, long B, int H, int W,
                       int C, int OH, int OW, int KH, int KW, int s, int pad);
+// the same gradient WITHOUT any materialised operand (conv_bwd.hip): gw [cout][KH*KW*C] = dY^T im2col(X) (overwritten), gb[cout] +=
+// column sums of dY (null: skipped); bf16 mode, valid convolutions, cout 32 / 64; partials in c.gws.  AVLEN_NOT_BIG: not applicable
+int avlen_i_conv_dw_direct(const avlen_ctx& c, float* gw, float* gb, int cout, const float* dY, const float* X, long R, int H,
+                           int W, int C, int OH, int OW, int KH, int KW, int s);
 
 // few-row Linear against a tall weight matrix (train_gru.hip): out = x W^T + b, one wave per output column
 bool avlen_i_skinny_linear_ok(int M, int K);

@@ -23,6 +23,11 @@
 namespace {
 
 constexpr size_t GEMM_SCRATCH = 96u << 20;
+bool conv_dw_direct_on() {      // AVLEN_CONV_DW_DIRECT=0 (lab builds): the GEMM route for the conv weight gradients (A/B knob)
+  static int v = -1;
+  if (v < 0) v = (int)avlen_knob("AVLEN_CONV_DW_DIRECT", 1);
+  return v != 0;
+}
 inline size_t zmax(size_t a, size_t b) { return a > b ? a : b; }
 
 struct Dims { int h[4], w[4], c[4]; };        // [0] = input, [i+1] = output of conv i
@@ -289,18 +294,23 @@ int cnn_bwd(const avlen_ctx& c, Ws& s, const avlen_cnn3* n, const avlen_cnn3* g,
     const int Kc = k.kh * k.kw * k.cin;
     const float* in = i == 0 ? x : a.a[i - 1];
     if (M > 0x7fffffffL) return AVLEN_ERR_ARG;
-    // weight / bias gradient
-    TRY(avlen_zero_bytes(s.gpack, (size_t)k.cout * Kc * 4, st));
-    avlen_linear G{s.gpack, nullptr, k.cout, Kc, nullptr, 0};
-    int rc = avlen_i_conv_dw16(c, G, dy, k.cout, in, R, d.h[i], d.w[i], k.cin, d.h[i + 1], d.w[i + 1], k.kh, k.kw, k.stride, 0);
+    // weight / bias gradient: the direct kernel (conv_bwd.hip: nothing materialised, bias sums included) where it applies
+    int rc = conv_dw_direct_on() ? avlen_i_conv_dw_direct(c, s.gpack, g->conv[i].b, k.cout, dy, in, R, d.h[i], d.w[i], k.cin, d.h[i + 1],
+                                                          d.w[i + 1], k.kh, k.kw, k.stride)
+                                 : AVLEN_NOT_BIG;
     if (rc == AVLEN_NOT_BIG) {
-      TRY(im2col(st, in, s.cols, R, d.h[i], d.w[i], k.cin, d.h[i + 1], d.w[i + 1], k.kh, k.kw, k.stride, 0));
-      TRY(avlen_i_linear_dw(c, G, dy, k.cout, s.cols, Kc, (int)M));
+      TRY(avlen_zero_bytes(s.gpack, (size_t)k.cout * Kc * 4, st));
+      avlen_linear G{s.gpack, nullptr, k.cout, Kc, nullptr, 0};
+      rc = avlen_i_conv_dw16(c, G, dy, k.cout, in, R, d.h[i], d.w[i], k.cin, d.h[i + 1], d.w[i + 1], k.kh, k.kw, k.stride, 0);
+      if (rc == AVLEN_NOT_BIG) {
+        TRY(im2col(st, in, s.cols, R, d.h[i], d.w[i], k.cin, d.h[i + 1], d.w[i + 1], k.kh, k.kw, k.stride, 0));
+        TRY(avlen_i_linear_dw(c, G, dy, k.cout, s.cols, Kc, (int)M));
+      } else TRY(rc);
+      TRY(avlen_i_colsum_acc(c, dy, k.cout, g->conv[i].b, (int)M, k.cout));
     } else TRY(rc);
     const long nw = (long)k.cout * Kc;
     hipLaunchKernelGGL(unpack_conv_grad_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, s.gpack, g->conv[i].w, k.cout,
                        k.cin, k.kh, k.kw);
-    TRY(avlen_i_colsum_acc(c, dy, k.cout, g->conv[i].b, (int)M, k.cout));
     if (i == 0) break;
     // data gradient: dcols = dY * Wp, gathered back onto the input pixels, masked by the ReLU of the layer below
     avlen_linear Wl{k.w, nullptr, k.cout, Kc, nullptr, 0};
