@@ -35,10 +35,10 @@ struct DwArgs {
   unsigned xring_bytes, y_off, lds_bytes;
 };
 
-__device__ __forceinline__ bf16x8 pack8(const float (&v)[8]) {
+__device__ __forceinline__ bf16x8 pack8(const float (&v)[8], int nv) {        // images nv .. 7 of the group do not exist: zero
   bf16x8 o;
 #pragma unroll
-  for (int e = 0; e < 8; e++) o[e] = (bf16)v[e];
+  for (int e = 0; e < 8; e++) o[e] = (bf16)(e < nv ? v[e] : 0.f);
   return o;
 }
 
@@ -75,21 +75,20 @@ __global__ __launch_bounds__(DW_TH) void conv_dw_kernel(const DwArgs a) {
 #pragma unroll
     for (int e = 0; e < 8; e++) {
       const int b = o * 8 + e;
-      const float* p = a.X + ((long)(b < a.R ? b : 0) * a.H + ih0) * Wc;
-      const float keep = b < a.R ? 1.f : 0.f;
+      const float* p = a.X + ((long)(b < a.R ? b : 0) * a.H + ih0) * Wc;          // images past R: image 0, zeroed on the way into LDS
 #pragma unroll
-      for (int j = 0; j < XE; j++) { const int idx = tid + DW_TH * j; xr[j][e] = idx < total ? p[idx] * keep : 0.f; }
+      for (int j = 0; j < XE; j++) { const int idx = tid + DW_TH * j; xr[j][e] = p[idx < total ? idx : 0]; }      // branch-free: all loads in flight
     }
   };
-  auto store_x = [&](int ih0, int nr) {
-    const int total = nr * Wc;
+  auto store_x = [&](int o, int ih0, int nr) {
+    const int total = nr * Wc, nv = a.R - o * 8;
 #pragma unroll
     for (int j = 0; j < XE; j++) {
       const int idx = tid + DW_TH * j;
       if (idx < total) {
         const int r = idx / Wc, col = idx - r * Wc;
         const int slot = (ih0 + r) % KH;
-        *reinterpret_cast<bf16x8*>(lds + ((unsigned)(slot * Wc + col)) * 16u) = pack8(xr[j]);
+        *reinterpret_cast<bf16x8*>(lds + ((unsigned)(slot * Wc + col)) * 16u) = pack8(xr[j], nv);
       }
     }
   };
@@ -99,22 +98,21 @@ __global__ __launch_bounds__(DW_TH) void conv_dw_kernel(const DwArgs a) {
     for (int e = 0; e < 8; e++) {
       const int b = o * 8 + e;
       const float* p = a.dY + ((long)(b < a.R ? b : 0) * a.OH + oh) * total;
-      const float keep = b < a.R ? 1.f : 0.f;
 #pragma unroll
-      for (int j = 0; j < DW_YE; j++) { const int idx = tid + DW_TH * j; yr[j][e] = idx < total ? p[idx] * keep : 0.f; }
+      for (int j = 0; j < DW_YE; j++) { const int idx = tid + DW_TH * j; yr[j][e] = p[idx < total ? idx : 0]; }
     }
   };
-  auto store_y = [&]() {
-    const int total = OW * cout;
+  auto store_y = [&](int o) {
+    const int total = OW * cout, nv = a.R - o * 8;
 #pragma unroll
     for (int j = 0; j < DW_YE; j++) {
       const int idx = tid + DW_TH * j;
       if (idx < total) {
         float t = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; e++) t += yr[j][e];
+        for (int e = 0; e < 8; e++) t += e < nv ? yr[j][e] : 0.f;
         bsum += t;
-        *reinterpret_cast<bf16x8*>(ybase + (unsigned)idx * 16u) = pack8(yr[j]);
+        *reinterpret_cast<bf16x8*>(ybase + (unsigned)idx * 16u) = pack8(yr[j], nv);
       }
     }
   };
@@ -129,10 +127,10 @@ __global__ __launch_bounds__(DW_TH) void conv_dw_kernel(const DwArgs a) {
       for (int r0 = 0; r0 < KH; r0 += s) {
         const int nr = KH - r0 < s ? KH - r0 : s;
         load_x(o, oh * s + r0, nr);
-        store_x(oh * s + r0, nr);
+        store_x(o, oh * s + r0, nr);
       }
       load_y(o, oh);
-      store_y();
+      store_y(o);
       __syncthreads();
     }
     const bool pf = L + 1 < L1 && oh + 1 < a.OH;      // next row step: same images
@@ -168,8 +166,8 @@ __global__ __launch_bounds__(DW_TH) void conv_dw_kernel(const DwArgs a) {
     if (ks < nks) mma(0);
     if (pf) {
       __syncthreads();
-      store_x(oh * s + KH, s);
-      store_y();
+      store_x(o, oh * s + KH, s);
+      store_y(o);
       __syncthreads();
     }
   }
@@ -197,25 +195,36 @@ __global__ __launch_bounds__(DW_TH) void conv_dw_kernel(const DwArgs a) {
   }
 }
 
-// gw[co][k] = sum over the workgroups' partials (fixed order); gb[co] += their bias sums
-__global__ void conv_dw_reduce_kernel(const float* __restrict__ part, int nparts, int cout, int K, int Kp, float* __restrict__ gw,
-                                      float* __restrict__ gb) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// gw[co][k] = sum over the workgroups' partials; gb[co] += their bias sums.  64 outputs per block, the partials dealt to 4 waves
+// (wave y: partials y, y + 4, ...; 8 independent chains each), combined in fixed order: deterministic.
+__global__ __launch_bounds__(256) void conv_dw_reduce_kernel(const float* __restrict__ part, int nparts, int cout, int K, int Kp,
+                                                             float* __restrict__ gw, float* __restrict__ gb) {
+  __shared__ float sh[4][64];
+  const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + x;
   const size_t stride = (size_t)cout * Kp + cout;
-  if (i < cout * K) {
-    const int co = i / K, k = i - co * K;
-    const float* p = part + (size_t)co * Kp + k;
-    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
-    int w = 0;
-    for (; w + 4 <= nparts; w += 4) { t0 += p[w * stride]; t1 += p[(w + 1) * stride]; t2 += p[(w + 2) * stride]; t3 += p[(w + 3) * stride]; }
-    for (; w < nparts; w++) t0 += p[w * stride];
-    gw[i] = (t0 + t1) + (t2 + t3);
-  } else if (gb && i < cout * K + cout) {
-    const int co = i - cout * K;
-    const float* p = part + (size_t)cout * Kp + co;
-    float t = 0.f;
-    for (int w = 0; w < nparts; w++) t += p[w * stride];
-    gb[co] += t;
+  const bool isw = i < cout * K, isb = !isw && i < cout * K + cout;
+  size_t off = 0;
+  if (isw) { const int co = i / K; off = (size_t)co * Kp + (i - co * K); }
+  else if (isb) off = (size_t)cout * Kp + (i - cout * K);
+  float t[8];
+#pragma unroll
+  for (int u = 0; u < 8; u++) t[u] = 0.f;
+  if (isw || isb) {
+    const float* p = part + off;
+    int w = y;
+    for (; w + 28 < nparts; w += 32) {
+#pragma unroll
+      for (int u = 0; u < 8; u++) t[u] += p[(size_t)(w + 4 * u) * stride];
+    }
+    for (; w < nparts; w += 4) t[0] += p[(size_t)w * stride];
+  }
+  sh[y][x] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+  __syncthreads();
+  if (y == 0) {
+    const float v = (sh[0][x] + sh[1][x]) + (sh[2][x] + sh[3][x]);
+    if (isw) gw[i] = v;
+    else if (isb && gb) gb[i - cout * K] += v;
   }
 }
 
@@ -281,6 +290,6 @@ int avlen_i_conv_dw_direct(const avlen_ctx& c, float* gw, float* gb, int cout, c
   int rc = cout == 32 ? launch_dw_n<2>(a, ntw, grid, c.st) : launch_dw_n<4>(a, ntw, grid, c.st);
   if (rc != AVLEN_OK) return rc;
   const int tot = cout * a.K + cout;
-  hipLaunchKernelGGL(conv_dw_reduce_kernel, dim3((tot + 255) / 256), dim3(256), 0, c.st, a.part, grid, cout, a.K, a.Kp, gw, gb);
+  hipLaunchKernelGGL(conv_dw_reduce_kernel, dim3((tot + 63) / 64), dim3(256), 0, c.st, a.part, grid, cout, a.K, a.Kp, gw, gb);
   return avlen_launch_status();
 }

@@ -23,6 +23,11 @@
 namespace {
 
 constexpr size_t GEMM_SCRATCH = 96u << 20;
+bool gru_seq_on() {             // AVLEN_GRU_SEQ=0 (lab builds): one launch per GRU step instead of the resident sequence kernels
+  static int v = -1;
+  if (v < 0) v = (int)avlen_knob("AVLEN_GRU_SEQ", 1);
+  return v != 0;
+}
 bool conv_dw_direct_on() {      // AVLEN_CONV_DW_DIRECT=0 (lab builds): the GEMM route for the conv weight gradients (A/B knob)
   static int v = -1;
   if (v < 0) v = (int)avlen_knob("AVLEN_CONV_DW_DIRECT", 1);
@@ -175,6 +180,176 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(const float* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The whole sequence in ONE launch (T steps of the minibatch's N <= 16 rows).  A per-step launch is bounded by what a step has to
+// do before its first product: stream W_hh (3 MB) out of L2 again and start 128 workgroups -- 9.2 us forward, 14.5 us backward
+// against ~1 us of arithmetic, 4,800 launches per update.  Here H/8 workgroups of 8 waves stay resident for all T steps: wave =
+// hidden unit j with its three W_hh rows (forward) / its W_hh^T row (backward) in registers for the whole sequence, and the only
+// per-step traffic is the exchange of the step's result between the workgroups:
+//   * every value a step hands to the next one (h_t forward, dGH_t backward) is stored with an agent-scope store (write-through)
+//     into a buffer the host pre-filled with a SENTINEL word (0xffffffff: a NaN pattern no arithmetic produces);
+//   * the next step's workgroups stage that buffer into LDS with agent-scope loads and simply repeat the load of a piece until
+//     none of its words is the sentinel -- the data is its own flag: one store and one load per hand-off, no barrier counter, no
+//     fence, and a 32-bit word is either the sentinel or final;
+//   * everything else (gi, masks, saved hm / gh, dGI) is plain traffic written before the launch or read after it.
+// The per-element arithmetic and summation order are those of the per-step kernels above (bit-identical results).
+// A workgroup never waits for a LATER step of another workgroup, the grid (H/8 <= 64 workgroups) is co-resident, and the wait is
+// bounded: after ~seconds without progress a workgroup raises *err and runs on -- the launch then poisons its result with NaN
+// (visible in the losses) instead of hanging the device.
+// ---------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) unsigned gu32;
+constexpr unsigned GRU_SENT = 0xffffffffu;
+constexpr int SEQ_TH = 512;
+__device__ __forceinline__ void st_agent(float* p, float v) {
+  __hip_atomic_store((gu32*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// stage n4 16-byte pieces of `src` (a hand-off buffer) into LDS; KMAX pieces per thread at most
+template <int KMAX>
+__device__ __forceinline__ void stage_polled(const float* src, float* dst, int n4, int tid, unsigned* err) {
+  unsigned w[KMAX][4];
+  unsigned spins = 0;
+  for (;;) {
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) {                     // branch-free (pieces past the end repeat the last one): all loads in flight
+      const int idx = tid + SEQ_TH * k < n4 ? tid + SEQ_TH * k : n4 - 1;
+#pragma unroll
+      for (int e = 0; e < 4; e++) w[k][e] = __hip_atomic_load((gu32*)src + (size_t)idx * 4 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    bool again = false;
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) again |= w[k][0] == GRU_SENT || w[k][1] == GRU_SENT || w[k][2] == GRU_SENT || w[k][3] == GRU_SENT;
+    if (!again) break;
+    if (++spins > (1u << 21)) { *err = 1u; break; }
+    __builtin_amdgcn_s_sleep(1);
+  }
+#pragma unroll
+  for (int k = 0; k < KMAX; k++) {
+    const int idx = tid + SEQ_TH * k;
+    if (idx < n4) *reinterpret_cast<uint4*>(dst + (size_t)idx * 4) = make_uint4(w[k][0], w[k][1], w[k][2], w[k][3]);
+  }
+}
+
+template <int MC>
+__global__ __launch_bounds__(SEQ_TH) void gru_seq_fwd_kernel(const float* __restrict__ w_hh, const float* __restrict__ b_hh,
+                                                             const float* __restrict__ gi_all, const float* __restrict__ h0,
+                                                             const float* __restrict__ masks, float* out, float* __restrict__ hm_save,
+                                                             float* __restrict__ gh_save, int T, int N, int H, unsigned* err) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];      // N x H: the previous hidden state
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int j = blockIdx.x * 8 + (tid >> 6);                      // H % 8 == 0 (launcher)
+  float w[3][GRU_HP];
+#pragma unroll
+  for (int g = 0; g < 3; g++)
+#pragma unroll
+    for (int i = 0; i < GRU_HP; i++) { const int k = lane + 64 * i; w[g][i] = k < H ? w_hh[((long)g * H + j) * H + k] : 0.f; }
+  const float b0 = b_hh[j], b1 = b_hh[H + j], b2 = b_hh[2 * H + j];
+  const int n4 = N * H / 4;
+  constexpr int KMAX = MC * GRU_HP * 64 / 4 / SEQ_TH;
+  for (int t = 0; t < T; t++) {
+    if (t == 0) {
+      for (int idx = tid; idx < n4; idx += SEQ_TH) reinterpret_cast<float4*>(sh)[idx] = reinterpret_cast<const float4*>(h0)[idx];
+    } else {
+      stage_polled<KMAX>(out + (size_t)(t - 1) * N * H, sh, n4, tid, err);
+    }
+    __syncthreads();
+    float a0[MC], a1[MC], a2[MC];
+#pragma unroll
+    for (int mm = 0; mm < MC; mm++) {
+      a0[mm] = a1[mm] = a2[mm] = 0.f;
+      if (mm < N) {
+#pragma unroll
+        for (int i = 0; i < GRU_HP; i++) {
+          const int k = lane + 64 * i;
+          const float h = k < H ? sh[mm * H + k] : 0.f;
+          a0[mm] += h * w[0][i]; a1[mm] += h * w[1][i]; a2[mm] += h * w[2][i];
+        }
+      }
+    }
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+#pragma unroll
+    for (int mm = 0; mm < MC; mm++) {
+      const float s0 = wave_sum(a0[mm]), s1 = wave_sum(a1[mm]), s2 = wave_sum(a2[mm]);
+      if (lane == mm) { r0 = s0; r1 = s1; r2 = s2; }
+    }
+    if (lane < N) {
+      const int m = lane;
+      const long row = (long)t * N + m;
+      const float mk = masks[row];
+      const float hj = sh[m * H + j] * mk;
+      r0 = r0 * mk + b0; r1 = r1 * mk + b1; r2 = r2 * mk + b2;
+      const float* a = gi_all + row * 3 * H;
+      const float r = 1.f / (1.f + expf(-(a[j] + r0)));
+      const float z = 1.f / (1.f + expf(-(a[H + j] + r1)));
+      const float nn = tanhf(a[2 * H + j] + r * r2);
+      st_agent(out + row * H + j, (1.f - z) * nn + z * hj);
+      hm_save[row * H + j] = hj;
+      float* g = gh_save + row * 3 * H;
+      g[j] = r0; g[H + j] = r1; g[2 * H + j] = r2;
+    }
+    __syncthreads();                                               // sh is rewritten by the next step
+  }
+  if (lane == 0 && __hip_atomic_load((gu32*)err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) out[((size_t)(T - 1) * N) * H + j] = __builtin_nanf("");
+}
+
+// BPTT, steps T-1 .. 0 (see gru_step_bwd_kernel): the carry of dz stays in lane m's register, dGH_t is the hand-off
+template <int MC>
+__global__ __launch_bounds__(SEQ_TH) void gru_seq_bwd_kernel(const float* __restrict__ whhT, const float* __restrict__ gi,
+                                                             const float* __restrict__ gh, const float* __restrict__ hm,
+                                                             const float* __restrict__ d_out, const float* __restrict__ masks,
+                                                             float* __restrict__ dgi, float* dgh, int T, int N, int H, unsigned* err) {
+  extern __shared__ __attribute__((aligned(16))) float sd[];      // N x 3H: dGH of step t + 1
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int j = blockIdx.x * 8 + (tid >> 6);
+  const int K = 3 * H;
+  float w[GRU_KP];
+#pragma unroll
+  for (int i = 0; i < GRU_KP; i++) { const int k = lane + 64 * i; w[i] = k < K ? whhT[(long)j * K + k] : 0.f; }
+  const int n4 = N * K / 4;
+  constexpr int KMAX = MC * GRU_KP * 64 / 4 / SEQ_TH;
+  float dz_keep = 0.f;
+  for (int t = T - 1; t >= 0; t--) {
+    float carry = 0.f;
+    if (t < T - 1) {
+      stage_polled<KMAX>(dgh + (size_t)(t + 1) * N * K, sd, n4, tid, err);
+      __syncthreads();
+      float acc[MC];
+#pragma unroll
+      for (int mm = 0; mm < MC; mm++) {
+        acc[mm] = 0.f;
+        if (mm < N) {
+#pragma unroll
+          for (int i = 0; i < GRU_KP; i++) { const int k = lane + 64 * i; if (k < K) acc[mm] += sd[mm * K + k] * w[i]; }
+        }
+      }
+#pragma unroll
+      for (int mm = 0; mm < MC; mm++) { const float sv = wave_sum(acc[mm]); if (lane == mm) carry = sv; }
+    }
+    if (lane < N) {
+      const int m = lane;
+      const long row = (long)t * N + m;
+      if (t < T - 1) carry = (carry + dz_keep) * masks[row + N];
+      const long o = row * K;
+      const float* a = gi + o; const float* b = gh + o;
+      const float r = 1.f / (1.f + expf(-(a[j] + b[j])));
+      const float z = 1.f / (1.f + expf(-(a[H + j] + b[H + j])));
+      const float ghn = b[2 * H + j];
+      const float nn = tanhf(a[2 * H + j] + r * ghn);
+      const float dh = d_out[row * H + j] + carry;
+      const float dn = dh * (1.f - z);
+      const float dzz = dh * (hm[row * H + j] - nn);
+      const float dpn = dn * (1.f - nn * nn);
+      const float dpr = dpn * ghn * r * (1.f - r);
+      const float dpz = dzz * z * (1.f - z);
+      dgi[o + j] = dpr; dgi[o + H + j] = dpz; dgi[o + 2 * H + j] = dpn;
+      st_agent(dgh + o + j, dpr); st_agent(dgh + o + H + j, dpz); st_agent(dgh + o + 2 * H + j, dpn * r);
+      dz_keep = dh * z;
+    }
+    __syncthreads();                                               // sd is rewritten by the next step
+  }
+  if (lane == 0 && __hip_atomic_load((gu32*)err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) dgi[j] = __builtin_nanf("");
+}
+bool gru_seq_ok(int N, int H) { return N >= 1 && N <= 16 && H % 8 == 0 && H <= 64 * GRU_HP && gru_seq_on(); }
+
 // [R][C] -> [C][R]
 __global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int C) {
   __shared__ float t[32][33];
@@ -203,6 +378,7 @@ struct Ws {
   CnnWs aud, vis;
   // backward scratch
   float *dX, *dGI, *dGH, *dh[2], *dpre, *da, *db, *cols, *gpack, *whhT;
+  unsigned* err;
   void* gws; void* xs; size_t xs_bytes;
 };
 size_t cnn_cols_max(const avlen_cnn3* n, const Dims& d, long R) {
@@ -230,6 +406,7 @@ bool layout(WsBump& w, Ws& s, const avlen_cnn3* au, const avlen_cnn3* vi, const 
   s.X = w.take<float>((size_t)R * F);
   s.GI = w.take<float>((size_t)R * 3 * H); s.GH = w.take<float>((size_t)R * 3 * H); s.HM = w.take<float>((size_t)R * H);
   s.hc = w.take<float>((size_t)N * H);
+  s.err = w.take<unsigned>(64);
   for (int i = 0; i < 3; i++) {
     s.aud.a[i] = w.take<float>((size_t)R * da.h[i + 1] * da.w[i + 1] * da.c[i + 1]);
     s.vis.a[i] = w.take<float>((size_t)R * dv.h[i + 1] * dv.w[i + 1] * dv.c[i + 1]);
@@ -402,12 +579,21 @@ extern "C" int avlen_baseline_train_fwd(const avlen_cnn3* audio, const avlen_cnn
   TRY(avlen_i_linear(c, ih, s.X, F, s.GI, 3 * H, (int)R, 0, nullptr, 0));
   if (H > 64 * GRU_HP) return AVLEN_ERR_ARG;
   const float* hprev = h0;
-  for (int t = 0; t < T; t++) {
-    auto kern = N <= 8 ? gru_step_fwd_kernel<8> : gru_step_fwd_kernel<16>;
-    hipLaunchKernelGGL(kern, dim3(ceil_div(H, 4)), dim3(256), 0, st, gru->w_hh, gru->b_hh,
-                       s.GI + (size_t)t * N * 3 * H, hprev, masks + (size_t)t * N, out + (size_t)t * N * H,
-                       s.HM + (size_t)t * N * H, s.GH + (size_t)t * N * 3 * H, N, H);
-    hprev = out + (size_t)t * N * H;
+  if (gru_seq_ok(N, H)) {                    // the whole sequence in one launch: `out` is the hand-off buffer (sentinel-filled)
+    if (hipMemsetAsync(out, 0xff, (size_t)R * H * sizeof(float), st) != hipSuccess) return AVLEN_ERR_LAUNCH;
+    TRY(avlen_zero_bytes(s.err, 64 * sizeof(unsigned), st));
+    auto kern = N <= 8 ? gru_seq_fwd_kernel<8> : gru_seq_fwd_kernel<16>;
+    hipLaunchKernelGGL(kern, dim3(H / 8), dim3(SEQ_TH), (size_t)N * H * sizeof(float), st, gru->w_hh, gru->b_hh, s.GI, h0, masks, out,
+                       s.HM, s.GH, T, N, H, s.err);
+    hprev = out + (size_t)(T - 1) * N * H;
+  } else {
+    for (int t = 0; t < T; t++) {
+      auto kern = N <= 8 ? gru_step_fwd_kernel<8> : gru_step_fwd_kernel<16>;
+      hipLaunchKernelGGL(kern, dim3(ceil_div(H, 4)), dim3(256), 0, st, gru->w_hh, gru->b_hh,
+                         s.GI + (size_t)t * N * 3 * H, hprev, masks + (size_t)t * N, out + (size_t)t * N * H,
+                         s.HM + (size_t)t * N * H, s.GH + (size_t)t * N * 3 * H, N, H);
+      hprev = out + (size_t)t * N * H;
+    }
   }
   TRY(avlen_launch_status());
   if (h_out) TRY(avlen_copy_rows(hprev, H, h_out, H, N, H, st));
@@ -429,14 +615,29 @@ extern "C" int avlen_baseline_train_bwd(const avlen_cnn3* audio, const avlen_cnn
   // ---- BPTT through the masked GRU: one launch per step (see gru_step_bwd_kernel)
   if (3 * H > 64 * GRU_KP || H % 4) return AVLEN_ERR_ARG;
   hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(3 * H, 32), ceil_div(H, 32)), dim3(32, 8), 0, st, gru->w_hh, s.whhT, 3 * H, H);
-  for (int t = T - 1; t >= 0; t--) {
-    const bool last = t == T - 1;
-    // 8 rows per pass: 8 x 3H floats of LDS (48 KB at H = 512)
-    hipLaunchKernelGGL(gru_step_bwd_kernel<8>, dim3(ceil_div(H, 4)), dim3(256), (size_t)8 * 3 * H * sizeof(float), st, s.whhT, s.GI + (size_t)t * N * 3 * H,
-                       s.GH + (size_t)t * N * 3 * H, s.HM + (size_t)t * N * H, d_out + (size_t)t * N * H,
-                       last ? nullptr : s.dGH + (size_t)(t + 1) * N * 3 * H, last ? nullptr : s.dh[(t + 1) & 1],
-                       last ? nullptr : masks + (size_t)(t + 1) * N, s.dGI + (size_t)t * N * 3 * H, s.dGH + (size_t)t * N * 3 * H,
-                       s.dh[t & 1], N, H);
+  if (gru_seq_ok(N, H)) {                    // one resident launch for all T steps: dGH is the hand-off buffer (sentinel-filled)
+    if (hipMemsetAsync(s.dGH, 0xff, (size_t)R * 3 * H * sizeof(float), st) != hipSuccess) return AVLEN_ERR_LAUNCH;
+    TRY(avlen_zero_bytes(s.err, 64 * sizeof(unsigned), st));
+    const int lds = N * 3 * H * (int)sizeof(float);
+    if (N <= 8) {
+      hipLaunchKernelGGL(gru_seq_bwd_kernel<8>, dim3(H / 8), dim3(SEQ_TH), lds, st, s.whhT, s.GI, s.GH, s.HM, d_out, masks, s.dGI, s.dGH,
+                         T, N, H, s.err);
+    } else {
+      static unsigned long long done = 0;
+      TRY(avlen_set_dyn_lds(reinterpret_cast<const void*>(&gru_seq_bwd_kernel<16>), 16 * 3 * 64 * GRU_HP * (int)sizeof(float), &done));
+      hipLaunchKernelGGL(gru_seq_bwd_kernel<16>, dim3(H / 8), dim3(SEQ_TH), lds, st, s.whhT, s.GI, s.GH, s.HM, d_out, masks, s.dGI, s.dGH,
+                         T, N, H, s.err);
+    }
+  } else {
+    for (int t = T - 1; t >= 0; t--) {
+      const bool last = t == T - 1;
+      // 8 rows per pass: 8 x 3H floats of LDS (48 KB at H = 512)
+      hipLaunchKernelGGL(gru_step_bwd_kernel<8>, dim3(ceil_div(H, 4)), dim3(256), (size_t)8 * 3 * H * sizeof(float), st, s.whhT, s.GI + (size_t)t * N * 3 * H,
+                         s.GH + (size_t)t * N * 3 * H, s.HM + (size_t)t * N * H, d_out + (size_t)t * N * H,
+                         last ? nullptr : s.dGH + (size_t)(t + 1) * N * 3 * H, last ? nullptr : s.dh[(t + 1) & 1],
+                         last ? nullptr : masks + (size_t)(t + 1) * N, s.dGI + (size_t)t * N * 3 * H, s.dGH + (size_t)t * N * 3 * H,
+                         s.dh[t & 1], N, H);
+    }
   }
   TRY(avlen_launch_status());
   avlen_linear Gih{g_gru->w_ih, nullptr, 3 * H, F, nullptr, 0}, Ghh{g_gru->w_hh, nullptr, 3 * H, H, nullptr, 0};

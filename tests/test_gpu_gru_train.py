@@ -86,13 +86,13 @@ def test_gru_cycle_matches_reference(tag, spectro, use_gae):
     assert torch.equal(sd["critic_option.fc.weight"], sd0["critic_option.fc.weight"])
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
-def test_gru_gradients_match_oracle_autograd(precision):
-    """One (T=6) x (N=3) minibatch with mask resets: the HIP backward (loss + heads, BPTT, Linear, conv wgrad/dgrad via
-    im2col/col2im) vs torch autograd on the oracle, per parameter tensor."""
+@pytest.mark.parametrize("precision,T,N", [("fp32", 6, 3), ("bf16", 6, 3), ("fp32", 20, 8), ("fp32", 4, 16), ("bf16", 5, 11)])
+def test_gru_gradients_match_oracle_autograd(precision, T, N):
+    """One T x N minibatch with mask resets: the HIP backward (loss + heads, BPTT in the resident sequence kernels -- 8- and 16-row
+    variants, ragged row counts --, Linear, conv weight gradient on the direct kernel in bf16 mode with partly filled 8-image groups,
+    conv data gradient via GEMM + col2im) vs torch autograd on the oracle, per parameter tensor."""
     tag, spectro = "gru_cycle_257_nogae", (257, 101)
     pol, sd, _ = build(tag, spectro, precision)
-    T, N = 6, 3
     R_ = T * N
     obs = fx.observations("grug", R_, spectro)
     h0 = fx.sym("grug.h0", (1, N, 512), 0.5)
@@ -127,7 +127,7 @@ def test_gru_gradients_match_oracle_autograd(precision):
         err = float((ours - ref).norm() / (ref.norm() + 1e-12))
         worst = max(worst, err)
         assert err < (2e-3 if fp else 0.12), (k, err)
-    print(f"{precision}: max relative L2 gradient error over {len(tr)} tensors: {worst:.3g}")
+    print(f"{precision} T={T} N={N}: max relative L2 gradient error over {len(tr)} tensors: {worst:.3g}")
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
