@@ -192,41 +192,79 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(const float* __restri
 //     none of its words is the sentinel -- the data is its own flag: one store and one load per hand-off, no barrier counter, no
 //     fence, and a 32-bit word is either the sentinel or final;
 //   * everything else (gi, masks, saved hm / gh, dGI) is plain traffic written before the launch or read after it.
-// The per-element arithmetic and summation order are those of the per-step kernels above (bit-identical results).
+// The per-element arithmetic and summation order are those of the per-step kernels above.
 // A workgroup never waits for a LATER step of another workgroup, the grid (H/8 <= 64 workgroups) is co-resident, and the wait is
 // bounded: after ~seconds without progress a workgroup raises *err and runs on -- the launch then poisons its result with NaN
 // (visible in the losses) instead of hanging the device.
 // ---------------------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(1))) unsigned gu32;
 constexpr unsigned GRU_SENT = 0xffffffffu;
+#ifdef AVLEN_SEQ_PROF             // lab builds (tools/gru_seq_lab.hip): per-phase wall-clock totals of every workgroup
+__device__ long long* g_seq_prof = nullptr;
+#define SEQ_STAMP(k) do { if (g_seq_prof && threadIdx.x == 0) { const long long n_ = wall_clock64(); g_seq_prof[blockIdx.x * 8 + (k)] += n_ - seq_t_; seq_t_ = n_; } } while (0)
+#define SEQ_STAMP_INIT long long seq_t_ = wall_clock64()
+#else
+#define SEQ_STAMP(k) do { } while (0)
+#define SEQ_STAMP_INIT do { } while (0)
+#endif
 constexpr int SEQ_TH = 512;
 __device__ __forceinline__ void st_agent(float* p, float v) {
   __hip_atomic_store((gu32*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// stage n4 16-byte pieces of `src` (a hand-off buffer) into LDS; KMAX pieces per thread at most
-template <int KMAX>
-__device__ __forceinline__ void stage_polled(const float* src, float* dst, int n4, int tid, unsigned* err) {
-  unsigned w[KMAX][4];
+// stage `nw` words of `src` (a hand-off buffer) into LDS; KW words per thread at most.  One load instruction of a wave covers 256
+// contiguous bytes: agent-scope loads are not cached, every 128-byte line a load touches is a request to the fabric (16-byte pieces
+// per lane, fetched as four dword loads, asked for every line four times: 5.8 us for the backward's 48 KB).
+template <int KW>
+__device__ __forceinline__ void stage_polled(const float* src, float* dst, int nw, int tid, unsigned* err) {
+  unsigned w[KW];
   unsigned spins = 0;
   for (;;) {
 #pragma unroll
-    for (int k = 0; k < KMAX; k++) {                     // branch-free (pieces past the end repeat the last one): all loads in flight
-      const int idx = tid + SEQ_TH * k < n4 ? tid + SEQ_TH * k : n4 - 1;
-#pragma unroll
-      for (int e = 0; e < 4; e++) w[k][e] = __hip_atomic_load((gu32*)src + (size_t)idx * 4 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int k = 0; k < KW; k++) {                       // branch-free (words past the end repeat the last one): all loads in flight
+      const int idx = tid + SEQ_TH * k < nw ? tid + SEQ_TH * k : nw - 1;
+      w[k] = __hip_atomic_load((gu32*)src + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     bool again = false;
 #pragma unroll
-    for (int k = 0; k < KMAX; k++) again |= w[k][0] == GRU_SENT || w[k][1] == GRU_SENT || w[k][2] == GRU_SENT || w[k][3] == GRU_SENT;
+    for (int k = 0; k < KW; k++) again |= w[k] == GRU_SENT;
     if (!again) break;
     if (++spins > (1u << 21)) { *err = 1u; break; }
     __builtin_amdgcn_s_sleep(1);
   }
 #pragma unroll
-  for (int k = 0; k < KMAX; k++) {
+  for (int k = 0; k < KW; k++) {
     const int idx = tid + SEQ_TH * k;
-    if (idx < n4) *reinterpret_cast<uint4*>(dst + (size_t)idx * 4) = make_uint4(w[k][0], w[k][1], w[k][2], w[k][3]);
+    if (idx < nw) dst[idx] = __uint_as_float(w[k]);
   }
+}
+
+// NV per-lane partial sums -> their 64-lane totals, value q in lane q (and lanes q + NVP, ...).  24 butterflies of 6 dependent
+// ds_bpermute steps cost a step 3 us (profiles/r03_gru_seq_phases.txt); here the wave transposes through its own LDS patch instead:
+// lane l writes row l ([lane][value], odd row stride: conflict-free), reader lane (part, q) adds the partials of 64 / LPV source lanes
+// for value q (consecutive q: conflict-free), log2(LPV) shuffles join the parts.
+template <int NV> struct RedGeom {
+  static constexpr int NVP = NV <= 8 ? 8 : NV <= 16 ? 16 : NV <= 32 ? 32 : 64;
+  static constexpr int LPV = 64 / NVP, PER = 64 / LPV, ROW = NV + 1;
+  static constexpr int FLOATS = 64 * ROW;
+};
+template <int NV>
+__device__ __forceinline__ float wave_reduce_many(const float (&val)[NV], float* red, int lane) {
+  using G = RedGeom<NV>;
+#pragma unroll
+  for (int q = 0; q < NV; q++) red[lane * G::ROW + q] = val[q];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int q = lane % G::NVP, part = lane / G::NVP;
+  const float* p = red + (part * G::PER) * G::ROW + (q < NV ? q : 0);
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < G::PER; i += 2) { s0 += p[i * G::ROW]; s1 += p[(i + 1) * G::ROW]; }
+  float s = s0 + s1;
+#pragma unroll
+  for (int o = G::LPV / 2; o > 0; o >>= 1) s += __shfl_xor(s, o * G::NVP, 64);
+  __builtin_amdgcn_wave_barrier();               // the patch is rewritten by the wave's next call
+  return s;
 }
 
 template <int MC>
@@ -234,59 +272,73 @@ __global__ __launch_bounds__(SEQ_TH) void gru_seq_fwd_kernel(const float* __rest
                                                              const float* __restrict__ gi_all, const float* __restrict__ h0,
                                                              const float* __restrict__ masks, float* out, float* __restrict__ hm_save,
                                                              float* __restrict__ gh_save, int T, int N, int H, unsigned* err) {
-  extern __shared__ __attribute__((aligned(16))) float sh[];      // N x H: the previous hidden state
+  extern __shared__ __attribute__((aligned(16))) float sh[];      // N x H: the previous hidden state, then one reduction patch per wave
   const int tid = threadIdx.x, lane = tid & 63;
   const int j = blockIdx.x * 8 + (tid >> 6);                      // H % 8 == 0 (launcher)
-  float w[3][GRU_HP];
+  float* const red = sh + MC * 64 * GRU_HP + (tid >> 6) * RedGeom<3 * MC>::FLOATS;
+  float w[3][GRU_HP];                                             // lane's columns: 4 * lane + 256 * (i / 4) + i % 4 (16-byte LDS reads)
 #pragma unroll
   for (int g = 0; g < 3; g++)
 #pragma unroll
-    for (int i = 0; i < GRU_HP; i++) { const int k = lane + 64 * i; w[g][i] = k < H ? w_hh[((long)g * H + j) * H + k] : 0.f; }
+    for (int i = 0; i < GRU_HP; i++) { const int k = 4 * lane + 256 * (i >> 2) + (i & 3); w[g][i] = k < H ? w_hh[((long)g * H + j) * H + k] : 0.f; }
   const float b0 = b_hh[j], b1 = b_hh[H + j], b2 = b_hh[2 * H + j];
   const int n4 = N * H / 4;
-  constexpr int KMAX = MC * GRU_HP * 64 / 4 / SEQ_TH;
+  constexpr int KW = MC * GRU_HP * 64 / SEQ_TH;
+  // what a step needs besides the hand-off (its gi row, its mask) does not depend on the recurrence: lane m fetches step t + 1's
+  // values while step t runs (loop-carried registers), so no memory round trip sits between the hand-off and the gate arithmetic
+  const int ml = lane < N ? lane : 0;
+  float p_mk = masks[ml], p_g0 = gi_all[(long)ml * 3 * H + j], p_g1 = gi_all[(long)ml * 3 * H + H + j], p_g2 = gi_all[(long)ml * 3 * H + 2 * H + j];
+  SEQ_STAMP_INIT;
   for (int t = 0; t < T; t++) {
     if (t == 0) {
       for (int idx = tid; idx < n4; idx += SEQ_TH) reinterpret_cast<float4*>(sh)[idx] = reinterpret_cast<const float4*>(h0)[idx];
     } else {
-      stage_polled<KMAX>(out + (size_t)(t - 1) * N * H, sh, n4, tid, err);
+      stage_polled<KW>(out + (size_t)(t - 1) * N * H, sh, n4 * 4, tid, err);
     }
     __syncthreads();
-    float a0[MC], a1[MC], a2[MC];
+    SEQ_STAMP(0);
+    float acc[3 * MC];                                              // [gate][row]
 #pragma unroll
-    for (int mm = 0; mm < MC; mm++) {
-      a0[mm] = a1[mm] = a2[mm] = 0.f;
-      if (mm < N) {
+    for (int mm = 0; mm < MC; mm++) {                              // branch-free (every LDS read in flight): rows >= N repeat row 0 and are
+      acc[mm] = acc[MC + mm] = acc[2 * MC + mm] = 0.f;             // dropped, columns >= H read column 0 against zero weights
+      const float* hrow = sh + (mm < N ? mm : 0) * H;
 #pragma unroll
-        for (int i = 0; i < GRU_HP; i++) {
-          const int k = lane + 64 * i;
-          const float h = k < H ? sh[mm * H + k] : 0.f;
-          a0[mm] += h * w[0][i]; a1[mm] += h * w[1][i]; a2[mm] += h * w[2][i];
+      for (int i4 = 0; i4 < GRU_HP / 4; i4++) {
+        const int k = 4 * lane + 256 * i4;                         // H % 4 == 0: a 16-byte piece is inside the row or past it
+        const float4 hv = *reinterpret_cast<const float4*>(hrow + (k < H ? k : 0));
+        const float h4[4] = {hv.x, hv.y, hv.z, hv.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int i = i4 * 4 + e;
+          acc[mm] = fmaf(h4[e], w[0][i], acc[mm]); acc[MC + mm] = fmaf(h4[e], w[1][i], acc[MC + mm]);
+          acc[2 * MC + mm] = fmaf(h4[e], w[2][i], acc[2 * MC + mm]);
         }
       }
     }
-    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
-#pragma unroll
-    for (int mm = 0; mm < MC; mm++) {
-      const float s0 = wave_sum(a0[mm]), s1 = wave_sum(a1[mm]), s2 = wave_sum(a2[mm]);
-      if (lane == mm) { r0 = s0; r1 = s1; r2 = s2; }
-    }
+    const float tot = wave_reduce_many<3 * MC>(acc, red, lane);    // lane q = gate * MC + row
+    float r0 = tot, r1 = __shfl(tot, MC + lane, 64), r2 = __shfl(tot, 2 * MC + lane, 64);
+    SEQ_STAMP(1);
     if (lane < N) {
       const int m = lane;
       const long row = (long)t * N + m;
-      const float mk = masks[row];
+      const float mk = p_mk;
       const float hj = sh[m * H + j] * mk;
       r0 = r0 * mk + b0; r1 = r1 * mk + b1; r2 = r2 * mk + b2;
-      const float* a = gi_all + row * 3 * H;
-      const float r = 1.f / (1.f + expf(-(a[j] + r0)));
-      const float z = 1.f / (1.f + expf(-(a[H + j] + r1)));
-      const float nn = tanhf(a[2 * H + j] + r * r2);
+      const float r = 1.f / (1.f + expf(-(p_g0 + r0)));
+      const float z = 1.f / (1.f + expf(-(p_g1 + r1)));
+      const float nn = tanhf(p_g2 + r * r2);
       st_agent(out + row * H + j, (1.f - z) * nn + z * hj);
       hm_save[row * H + j] = hj;
       float* g = gh_save + row * 3 * H;
       g[j] = r0; g[H + j] = r1; g[2 * H + j] = r2;
     }
+    if (t + 1 < T) {
+      const long nrow = (long)(t + 1) * N + ml;
+      p_mk = masks[nrow]; p_g0 = gi_all[nrow * 3 * H + j]; p_g1 = gi_all[nrow * 3 * H + H + j]; p_g2 = gi_all[nrow * 3 * H + 2 * H + j];
+    }
+    SEQ_STAMP(2);
     __syncthreads();                                               // sh is rewritten by the next step
+    SEQ_STAMP(3);
   }
   if (lane == 0 && __hip_atomic_load((gu32*)err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) out[((size_t)(T - 1) * N) * H + j] = __builtin_nanf("");
 }
@@ -297,46 +349,62 @@ __global__ __launch_bounds__(SEQ_TH) void gru_seq_bwd_kernel(const float* __rest
                                                              const float* __restrict__ gh, const float* __restrict__ hm,
                                                              const float* __restrict__ d_out, const float* __restrict__ masks,
                                                              float* __restrict__ dgi, float* dgh, int T, int N, int H, unsigned* err) {
-  extern __shared__ __attribute__((aligned(16))) float sd[];      // N x 3H: dGH of step t + 1
+  extern __shared__ __attribute__((aligned(16))) float sd[];      // N x 3H: dGH of step t + 1, then one reduction patch per wave
   const int tid = threadIdx.x, lane = tid & 63;
   const int j = blockIdx.x * 8 + (tid >> 6);
+  float* const red = sd + MC * 64 * GRU_KP + (tid >> 6) * RedGeom<MC>::FLOATS;
   const int K = 3 * H;
-  float w[GRU_KP];
+  float w[GRU_KP];                                                // lane's columns: 4 * lane + 256 * (i / 4) + i % 4
 #pragma unroll
-  for (int i = 0; i < GRU_KP; i++) { const int k = lane + 64 * i; w[i] = k < K ? whhT[(long)j * K + k] : 0.f; }
-  const int n4 = N * K / 4;
-  constexpr int KMAX = MC * GRU_KP * 64 / 4 / SEQ_TH;
+  for (int i = 0; i < GRU_KP; i++) { const int k = 4 * lane + 256 * (i >> 2) + (i & 3); w[i] = k < K ? whhT[(long)j * K + k] : 0.f; }
+  constexpr int KW = MC * GRU_KP * 64 / SEQ_TH;
   float dz_keep = 0.f;
+  // lane m's operands of step t (gi, gh, hm, d_out rows, the mask of step t + 1) are fetched one step ahead (see the forward)
+  const int ml = lane < N ? lane : 0;
+  float p_a0, p_a1, p_a2, p_b0, p_b1, p_b2, p_hm, p_do, p_mk;
+  auto prefetch = [&](int t) {
+    const long row = (long)t * N + ml, o = row * K;
+    p_a0 = gi[o + j]; p_a1 = gi[o + H + j]; p_a2 = gi[o + 2 * H + j];
+    p_b0 = gh[o + j]; p_b1 = gh[o + H + j]; p_b2 = gh[o + 2 * H + j];
+    p_hm = hm[row * H + j]; p_do = d_out[row * H + j];
+    p_mk = t < T - 1 ? masks[row + N] : 0.f;
+  };
+  prefetch(T - 1);
+  SEQ_STAMP_INIT;
   for (int t = T - 1; t >= 0; t--) {
     float carry = 0.f;
     if (t < T - 1) {
-      stage_polled<KMAX>(dgh + (size_t)(t + 1) * N * K, sd, n4, tid, err);
+      stage_polled<KW>(dgh + (size_t)(t + 1) * N * K, sd, N * K, tid, err);
       __syncthreads();
+      SEQ_STAMP(0);
       float acc[MC];
 #pragma unroll
-      for (int mm = 0; mm < MC; mm++) {
+      for (int mm = 0; mm < MC; mm++) {                            // branch-free, as in the forward
         acc[mm] = 0.f;
-        if (mm < N) {
+        const float* drow = sd + (mm < N ? mm : 0) * K;
 #pragma unroll
-          for (int i = 0; i < GRU_KP; i++) { const int k = lane + 64 * i; if (k < K) acc[mm] += sd[mm * K + k] * w[i]; }
+        for (int i4 = 0; i4 < GRU_KP / 4; i4++) {
+          const int k = 4 * lane + 256 * i4;
+          const float4 v = *reinterpret_cast<const float4*>(drow + (k < K ? k : 0));
+          acc[mm] = fmaf(v.x, w[i4 * 4], acc[mm]); acc[mm] = fmaf(v.y, w[i4 * 4 + 1], acc[mm]);
+          acc[mm] = fmaf(v.z, w[i4 * 4 + 2], acc[mm]); acc[mm] = fmaf(v.w, w[i4 * 4 + 3], acc[mm]);
         }
       }
-#pragma unroll
-      for (int mm = 0; mm < MC; mm++) { const float sv = wave_sum(acc[mm]); if (lane == mm) carry = sv; }
+      carry = wave_reduce_many<MC>(acc, red, lane);                // lane m: row m
     }
+    SEQ_STAMP(1);
     if (lane < N) {
       const int m = lane;
       const long row = (long)t * N + m;
-      if (t < T - 1) carry = (carry + dz_keep) * masks[row + N];
+      if (t < T - 1) carry = (carry + dz_keep) * p_mk;
       const long o = row * K;
-      const float* a = gi + o; const float* b = gh + o;
-      const float r = 1.f / (1.f + expf(-(a[j] + b[j])));
-      const float z = 1.f / (1.f + expf(-(a[H + j] + b[H + j])));
-      const float ghn = b[2 * H + j];
-      const float nn = tanhf(a[2 * H + j] + r * ghn);
-      const float dh = d_out[row * H + j] + carry;
+      const float r = 1.f / (1.f + expf(-(p_a0 + p_b0)));
+      const float z = 1.f / (1.f + expf(-(p_a1 + p_b1)));
+      const float ghn = p_b2;
+      const float nn = tanhf(p_a2 + r * ghn);
+      const float dh = p_do + carry;
       const float dn = dh * (1.f - z);
-      const float dzz = dh * (hm[row * H + j] - nn);
+      const float dzz = dh * (p_hm - nn);
       const float dpn = dn * (1.f - nn * nn);
       const float dpr = dpn * ghn * r * (1.f - r);
       const float dpz = dzz * z * (1.f - z);
@@ -344,9 +412,41 @@ __global__ __launch_bounds__(SEQ_TH) void gru_seq_bwd_kernel(const float* __rest
       st_agent(dgh + o + j, dpr); st_agent(dgh + o + H + j, dpz); st_agent(dgh + o + 2 * H + j, dpn * r);
       dz_keep = dh * z;
     }
+    if (t > 0) prefetch(t - 1);
+    SEQ_STAMP(2);
     __syncthreads();                                               // sd is rewritten by the next step
+    SEQ_STAMP(3);
   }
   if (lane == 0 && __hip_atomic_load((gu32*)err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) dgi[j] = __builtin_nanf("");
+}
+// launchers: LDS = the staged hand-off (sized for MC rows of the widest H) + 8 reduction patches
+template <int MC>
+int launch_gru_seq_fwd_t(const float* w_hh, const float* b_hh, const float* gi, const float* h0, const float* masks, float* out, float* hm,
+                         float* gh, int T, int N, int H, unsigned* err, hipStream_t st) {
+  static unsigned long long done = 0;
+  const int lds = (MC * 64 * GRU_HP + 8 * RedGeom<3 * MC>::FLOATS) * (int)sizeof(float);
+  TRY(avlen_set_dyn_lds(reinterpret_cast<const void*>(&gru_seq_fwd_kernel<MC>), lds, &done));
+  hipLaunchKernelGGL(gru_seq_fwd_kernel<MC>, dim3(H / 8), dim3(SEQ_TH), lds, st, w_hh, b_hh, gi, h0, masks, out, hm, gh, T, N, H, err);
+  return avlen_launch_status();
+}
+int launch_gru_seq_fwd(const float* w_hh, const float* b_hh, const float* gi, const float* h0, const float* masks, float* out, float* hm,
+                       float* gh, int T, int N, int H, unsigned* err, hipStream_t st) {
+  return N <= 8 ? launch_gru_seq_fwd_t<8>(w_hh, b_hh, gi, h0, masks, out, hm, gh, T, N, H, err, st)
+                : launch_gru_seq_fwd_t<16>(w_hh, b_hh, gi, h0, masks, out, hm, gh, T, N, H, err, st);
+}
+template <int MC>
+int launch_gru_seq_bwd_t(const float* whhT, const float* gi, const float* gh, const float* hm, const float* d_out, const float* masks,
+                         float* dgi, float* dgh, int T, int N, int H, unsigned* err, hipStream_t st) {
+  static unsigned long long done = 0;
+  const int lds = (MC * 64 * GRU_KP + 8 * RedGeom<MC>::FLOATS) * (int)sizeof(float);
+  TRY(avlen_set_dyn_lds(reinterpret_cast<const void*>(&gru_seq_bwd_kernel<MC>), lds, &done));
+  hipLaunchKernelGGL(gru_seq_bwd_kernel<MC>, dim3(H / 8), dim3(SEQ_TH), lds, st, whhT, gi, gh, hm, d_out, masks, dgi, dgh, T, N, H, err);
+  return avlen_launch_status();
+}
+int launch_gru_seq_bwd(const float* whhT, const float* gi, const float* gh, const float* hm, const float* d_out, const float* masks,
+                       float* dgi, float* dgh, int T, int N, int H, unsigned* err, hipStream_t st) {
+  return N <= 8 ? launch_gru_seq_bwd_t<8>(whhT, gi, gh, hm, d_out, masks, dgi, dgh, T, N, H, err, st)
+                : launch_gru_seq_bwd_t<16>(whhT, gi, gh, hm, d_out, masks, dgi, dgh, T, N, H, err, st);
 }
 bool gru_seq_ok(int N, int H) { return N >= 1 && N <= 16 && H % 8 == 0 && H <= 64 * GRU_HP && gru_seq_on(); }
 
@@ -582,9 +682,7 @@ extern "C" int avlen_baseline_train_fwd(const avlen_cnn3* audio, const avlen_cnn
   if (gru_seq_ok(N, H)) {                    // the whole sequence in one launch: `out` is the hand-off buffer (sentinel-filled)
     if (hipMemsetAsync(out, 0xff, (size_t)R * H * sizeof(float), st) != hipSuccess) return AVLEN_ERR_LAUNCH;
     TRY(avlen_zero_bytes(s.err, 64 * sizeof(unsigned), st));
-    auto kern = N <= 8 ? gru_seq_fwd_kernel<8> : gru_seq_fwd_kernel<16>;
-    hipLaunchKernelGGL(kern, dim3(H / 8), dim3(SEQ_TH), (size_t)N * H * sizeof(float), st, gru->w_hh, gru->b_hh, s.GI, h0, masks, out,
-                       s.HM, s.GH, T, N, H, s.err);
+    TRY(launch_gru_seq_fwd(gru->w_hh, gru->b_hh, s.GI, h0, masks, out, s.HM, s.GH, T, N, H, s.err, st));
     hprev = out + (size_t)(T - 1) * N * H;
   } else {
     for (int t = 0; t < T; t++) {
@@ -618,16 +716,7 @@ extern "C" int avlen_baseline_train_bwd(const avlen_cnn3* audio, const avlen_cnn
   if (gru_seq_ok(N, H)) {                    // one resident launch for all T steps: dGH is the hand-off buffer (sentinel-filled)
     if (hipMemsetAsync(s.dGH, 0xff, (size_t)R * 3 * H * sizeof(float), st) != hipSuccess) return AVLEN_ERR_LAUNCH;
     TRY(avlen_zero_bytes(s.err, 64 * sizeof(unsigned), st));
-    const int lds = N * 3 * H * (int)sizeof(float);
-    if (N <= 8) {
-      hipLaunchKernelGGL(gru_seq_bwd_kernel<8>, dim3(H / 8), dim3(SEQ_TH), lds, st, s.whhT, s.GI, s.GH, s.HM, d_out, masks, s.dGI, s.dGH,
-                         T, N, H, s.err);
-    } else {
-      static unsigned long long done = 0;
-      TRY(avlen_set_dyn_lds(reinterpret_cast<const void*>(&gru_seq_bwd_kernel<16>), 16 * 3 * 64 * GRU_HP * (int)sizeof(float), &done));
-      hipLaunchKernelGGL(gru_seq_bwd_kernel<16>, dim3(H / 8), dim3(SEQ_TH), lds, st, s.whhT, s.GI, s.GH, s.HM, d_out, masks, s.dGI, s.dGH,
-                         T, N, H, s.err);
-    }
+    TRY(launch_gru_seq_bwd(s.whhT, s.GI, s.GH, s.HM, d_out, masks, s.dGI, s.dGH, T, N, H, s.err, st));
   } else {
     for (int t = T - 1; t >= 0; t--) {
       const bool last = t == T - 1;
