@@ -27,6 +27,8 @@ if [ -x $R/tools/bin/clip_lab ]; then
   for m in "160 1" "160 2"; do set -- $m; $R/tools/bin/clip_lab 64 0 $1 $2 | grep "per launch" | sed "s/^/co-runner $1 workgroups, mode $2 (1 spin, 2 stream memory): /" >> $O/clip_tower_phases.txt; done
 fi
 python3 $R/tools/clip_stream_probe.py 2>&1 | grep "stream=" > $O/clip_tower_parity_and_time.txt || exit 1
+if [ -x $R/tools/bin/gru_seq_lab ]; then $R/tools/bin/gru_seq_lab 150 8 > $O/gru_seq_phases.txt || exit 1; fi
+if [ -x $R/tools/bin/seq_lab ]; then timeout -k 10 120 $R/tools/bin/seq_lab 64 4096 > $O/handoff_latency_probe.txt || exit 1; fi
 if [ -x $R/tools/bin/head_lab0 ]; then $R/tools/bin/head_lab0 64 6 128 1 > $O/tower_head_phases.txt || exit 1; fi
 if [ -x $R/tools/bin/tail_lab ]; then $R/tools/bin/tail_lab 64 6 > $O/tower_tail_phases.txt || exit 1; fi
 if [ -f $O/tower_head_phases.txt ] && [ -f $O/tower_tail_phases.txt ]; then python3 $R/tools/tower_phase_table.py $O/tower_head_phases.txt $O/tower_tail_phases.txt > $O/tower_phase_table.md || exit 1; fi
