@@ -218,18 +218,33 @@ __device__ __forceinline__ void l1_fill(const T* __restrict__ img, float scale, 
   constexpr int S = 64 * K, E = K * C;
   static_assert(E % 2 == 0 && C <= 4, "vector loads need an even span");
   typedef __attribute__((ext_vector_type(2))) T T2;
-#pragma unroll 5
-  for (int i = tid; i < S70 * S70 + 2; i += 512) {
-    const int hr = i / S70, col = i - hr * S70;
-    const int oy = hr - 3, ox = col - 3;
-    uint2 h = make_uint2(0u, 0u), l = h;
-    if (hr < S70 && oy >= 0 && oy < 64 && ox >= 0 && ox < 64) {
-      const T* p = img + ((long)oy * K * S + ox * K) * C;
-      T2 v[K][E / 2];
+  // One or two batches of frame pixels per thread (ten pixels in all): first ALL loads of a batch (coordinates clamped, no branch -- a load under
+  // `if (inside the image)` compiles to branch + loads + s_waitcnt per pixel, and even branch-free the scheduler keeps each unrolled
+  // iteration's loads next to its own arithmetic: ten dependent memory round trips per thread, 21.9k cycles for a 48 KB image),
+  // then the window sums, the split and the LDS stores.
+  constexpr int TOT = S70 * S70 + 2, NB = sizeof(T) * E <= 8 ? 10 : 5;     // one batch when a pixel's window is <= 8 bytes per row
+#pragma unroll 1
+  for (int i0 = tid; i0 < TOT; i0 += 512 * NB) {
+    T2 v[NB][K][E / 2];
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+      const int i = i0 + 512 * b < TOT ? i0 + 512 * b : TOT - 1;
+      const int hr = i / S70, col = i - hr * S70;
+      const int oy = hr - 3, ox = col - 3;
+      const int cy = oy < 0 ? 0 : oy > 63 ? 63 : oy, cx = ox < 0 ? 0 : ox > 63 ? 63 : ox;
+      const T* p = img + ((long)cy * K * S + cx * K) * C;
 #pragma unroll
       for (int dy = 0; dy < K; dy++)
 #pragma unroll
-        for (int j = 0; j < E / 2; j++) v[dy][j] = *reinterpret_cast<const T2*>(p + (long)dy * S * C + 2 * j);
+        for (int j = 0; j < E / 2; j++) v[b][dy][j] = *reinterpret_cast<const T2*>(p + (long)dy * S * C + 2 * j);
+    }
+    __builtin_amdgcn_sched_barrier(0);                      // the loads above are issued before any of the arithmetic below
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+      const int i = i0 + 512 * b;
+      const int hr = i / S70, col = i - hr * S70;
+      const int oy = hr - 3, ox = col - 3;
+      const bool ok = hr < S70 && oy >= 0 && oy < 64 && ox >= 0 && ox < 64;
       float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int c = 0; c < C; c++) {
@@ -237,13 +252,16 @@ __device__ __forceinline__ void l1_fill(const T* __restrict__ img, float scale, 
 #pragma unroll
         for (int dy = 0; dy < K; dy++)
 #pragma unroll
-          for (int dx = 0; dx < K; dx++) { const int e = dx * C + c; sm += (float)v[dy][e >> 1][e & 1]; }
-        o[c] = sm * scale;
+          for (int dx = 0; dx < K; dx++) { const int e = dx * C + c; sm += (float)v[b][dy][e >> 1][e & 1]; }
+        o[c] = ok ? sm * scale : 0.f;
       }
+      uint2 h, l;
       split4(o, h, l);
+      if (i < TOT) {
+        *reinterpret_cast<uint2*>(lds + i * 8) = h;
+        *reinterpret_cast<uint2*>(lds + L1_PLANE + i * 8) = l;
+      }
     }
-    *reinterpret_cast<uint2*>(lds + i * 8) = h;
-    *reinterpret_cast<uint2*>(lds + L1_PLANE + i * 8) = l;
   }
 }
 
