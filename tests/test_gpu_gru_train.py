@@ -86,12 +86,15 @@ def test_gru_cycle_matches_reference(tag, spectro, use_gae):
     assert torch.equal(sd["critic_option.fc.weight"], sd0["critic_option.fc.weight"])
 
 
-@pytest.mark.parametrize("precision,T,N", [("fp32", 6, 3), ("bf16", 6, 3), ("fp32", 20, 8), ("fp32", 4, 16), ("bf16", 5, 11)])
-def test_gru_gradients_match_oracle_autograd(precision, T, N):
+@pytest.mark.parametrize("precision,T,N,tag,spectro", [
+    ("fp32", 6, 3, "gru_cycle_257_nogae", (257, 101)), ("bf16", 6, 3, "gru_cycle_257_nogae", (257, 101)),
+    ("fp32", 20, 8, "gru_cycle_257_nogae", (257, 101)), ("fp32", 4, 16, "gru_cycle_257_nogae", (257, 101)),
+    ("bf16", 5, 11, "gru_cycle_257_nogae", (257, 101)),
+    ("bf16", 7, 5, "gru_cycle", (65, 26)), ("fp32", 7, 5, "gru_cycle", (65, 26))])      # (5,2) (3,2) (3,1) audio geometry
+def test_gru_gradients_match_oracle_autograd(precision, T, N, tag, spectro):
     """One T x N minibatch with mask resets: the HIP backward (loss + heads, BPTT in the resident sequence kernels -- 8- and 16-row
     variants, ragged row counts --, Linear, conv weight gradient on the direct kernel in bf16 mode with partly filled 8-image groups,
     conv data gradient via GEMM + col2im) vs torch autograd on the oracle, per parameter tensor."""
-    tag, spectro = "gru_cycle_257_nogae", (257, 101)
     pol, sd, _ = build(tag, spectro, precision)
     R_ = T * N
     obs = fx.observations("grug", R_, spectro)
