@@ -21,6 +21,10 @@ from .policy import SPECTROGRAM, POSE, LOCATION_BELIEF, CATEGORY_BELIEF, CATEGOR
 
 _TWO_STREAMS = True          # the two networks run on two streams (decided by measurement)
 _SHARED_CAPTURE = True
+# The two networks as TWO graphs replayed on two streams (classifier on a side stream, predictor + filter on the caller's): as two
+# branches of ONE captured graph they execute back to back (kernel trace of a replay: the predictor's first kernel starts when the
+# classifier's last one ends -- 350 + 435 us instead of max(350, 435)); separate graphs on separate streams do overlap.
+_TWO_GRAPHS = os.environ.get("AVLEN_BELIEF_TWO_GRAPHS", "1") != "0"
 LABEL_PREDICTOR_PATH = "data/pretrained_weights/semantic_audionav/savi/label_predictor.pth"    # belief_predictor.py:96
 
 
@@ -255,6 +259,8 @@ class BeliefPredictor(nn.Module):
         if not self.use_graphs:
             return self._update_eager(obs, d, outs)
         key = tuple((k, tuple(v.shape)) for k, v in sorted(obs.items()))
+        if _TWO_GRAPHS and _TWO_STREAMS and self.predict_location and self.predict_label:
+            return self._update_two_graphs(obs, d, outs, key)
         g = self._graph
         if g is None or g["key"] != key:
             self._engine(spec.shape[1], spec.shape[2])                    # packed weights exist before capture
@@ -285,6 +291,53 @@ class BeliefPredictor(nn.Module):
         pairs.append((g["dones"], d if d is not None else g["zero"]))
         L.multi_copy(pairs)
         g["graph"].replay()
+        L.multi_copy([(outs[k], g["out"][k]) for k in outs])
+
+    def _update_two_graphs(self, obs, d, outs, key):
+        """update() with the classifier and the predictor captured as separate graphs (see _TWO_GRAPHS)."""
+        spec = obs[SPECTROGRAM]
+        g = self._graph
+        if g is None or g["key"] != key or "cls" not in g:
+            self._engine(spec.shape[1], spec.shape[2])
+            s = self._filter_state(spec.shape[0])
+            st_in = {k: v.clone() for k, v in obs.items()}
+            st_d = torch.zeros(spec.shape[0], dtype=torch.uint8, device=spec.device)
+            st_out = {k: torch.zeros_like(v) for k, v in outs.items()}
+            run_cls = lambda: self._run("classifier", st_in[SPECTROGRAM], s["labels"])
+            run_pred = lambda: self._run("predictor", self._predictor_input(st_in), s["pg"])
+            from .policy import _capture_stream
+            cap = _capture_stream() if _SHARED_CAPTURE else torch.cuda.Stream()
+            cap.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cap):                                  # warm-up outside capture (the filter state is not touched)
+                run_cls(); run_pred()
+            torch.cuda.current_stream().wait_stream(cap)
+            torch.cuda.synchronize()
+            graphs = {}
+            for name, fn in (("cls", run_cls), ("pred", run_pred)):
+                graphs[name] = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graphs[name], stream=cap):
+                    fn()
+            g = self._graph = {"key": key, "cls": graphs["cls"], "pred": graphs["pred"], "in": st_in, "dones": st_d, "out": st_out,
+                               "zero": torch.zeros_like(st_d), "ev_in": torch.cuda.Event(), "ev_cls": torch.cuda.Event()}
+        cur, side = torch.cuda.current_stream(), self._side_stream()
+        pairs = [(g["in"][k], v) for k, v in obs.items()]
+        pairs.append((g["dones"], d if d is not None else g["zero"]))
+        L.multi_copy(pairs)
+        g["ev_in"].record(cur)
+        side.wait_event(g["ev_in"])
+        with torch.cuda.stream(side):
+            g["cls"].replay()
+            g["ev_cls"].record(side)
+        g["pred"].replay()
+        cur.wait_event(g["ev_cls"])
+        s, st_in, st_out = self._state, g["in"], g["out"]
+        loc, catb = st_out.get(LOCATION_BELIEF), st_out.get(CATEGORY_BELIEF)
+        pose = st_in[POSE]
+        sp = st_in[SPECTROGRAM]
+        L.call("avlen_belief_update", E.P(s["pg"]), 2, E.P(s["labels"]), self.NUM_LABELS, E.P(pose), pose.shape[1], E.P(sp), sp[0].numel(),
+               E.P(g["dones"]), E.P(s["last_pg"]), E.P(s["has_pg"]), E.P(s["last_label"]), E.P(s["has_label"]),
+               E.P(loc) if loc is not None else None, E.P(catb) if catb is not None else None, E.P(s["spec_sum"]), sp.shape[0],
+               self.NUM_LABELS, float(self.config.weighting_factor), int(bool(self.config.current_pred_only)), L.stream())
         L.multi_copy([(outs[k], g["out"][k]) for k in outs])
 
     def _update_eager(self, obs, d, outs):
