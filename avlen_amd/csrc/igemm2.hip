@@ -704,7 +704,9 @@ int run_g2(G2 p, void* ws, size_t ws_bytes, hipStream_t st) {
   int nk = ceil_div(p.K, BK) * (p.x3 ? 3 : 1);
   long tiles = (long)m_tiles * n_tiles * p.groups;
   int split = 1;
-  if (tiles < 128 && nk >= 8 && !has_stats && !p.ln_stats && !p.rowstats) {
+  static long split_min_nk = -1;                  // fewest k-steps worth a second (reduce) launch: 8 -> 24 measured +2..4 % on cfg2 and --belief (AVLEN_G2_SPLIT_MIN_NK in lab builds)
+  if (split_min_nk < 0) split_min_nk = avlen_knob("AVLEN_G2_SPLIT_MIN_NK", 24);
+  if (tiles < 128 && nk >= split_min_nk && !has_stats && !p.ln_stats && !p.rowstats) {
     long a = nk / 4, b = (256 + tiles - 1) / tiles;
     split = (int)(a < b ? a : b);
     if (split < 1) split = 1;
