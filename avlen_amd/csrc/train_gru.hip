@@ -328,9 +328,11 @@ __global__ __launch_bounds__(SEQ_TH) void gru_seq_fwd_kernel(const float* __rest
       const float z = 1.f / (1.f + expf(-(p_g1 + r1)));
       const float nn = tanhf(p_g2 + r * r2);
       st_agent(out + row * H + j, (1.f - z) * nn + z * hj);
-      hm_save[row * H + j] = hj;
-      float* g = gh_save + row * 3 * H;
-      g[j] = r0; g[H + j] = r1; g[2 * H + j] = r2;
+      if (hm_save) {                                     // training forward: what the backward reads
+        hm_save[row * H + j] = hj;
+        float* g = gh_save + row * 3 * H;
+        g[j] = r0; g[H + j] = r1; g[2 * H + j] = r2;
+      }
     }
     if (t + 1 < T) {
       const long nrow = (long)(t + 1) * N + ml;
@@ -640,10 +642,16 @@ int avlen_i_skinny_linear(const float* x, int ldx, const float* W, const float* 
 }
 
 // one GRU step for up to a few dozen rows (rollout `act`, modules.hip:avlen_gru_fwd): see gru_step_fwd_kernel
+namespace { __device__ unsigned g_seq_err_unused = 0; }          // T = 1 never waits: the sequence kernel only reads this word
 bool avlen_i_gru_step_ok(int N, int H) { return N <= 64 && H <= 64 * GRU_HP; }
 int avlen_i_gru_step_fwd(const avlen_gru* p, const float* gi, const float* hprev, const float* mask, float* out, int N,
                          hipStream_t st) {
   const int H = p->hidden;
+  if (gru_seq_ok(N, H)) {       // the sequence kernel with T = 1 (no hand-off): LDS-transposed reductions, fma products: 15 -> 5 us at N = 16
+    unsigned* err = nullptr;
+    if (hipGetSymbolAddress((void**)&err, HIP_SYMBOL(g_seq_err_unused)) != hipSuccess) return AVLEN_ERR_LAUNCH;
+    return launch_gru_seq_fwd(p->w_hh, p->b_hh, gi, hprev, mask, out, nullptr, nullptr, 1, N, H, err, st);
+  }
   auto kern = N <= 8 ? gru_step_fwd_kernel<8> : gru_step_fwd_kernel<16>;
   hipLaunchKernelGGL(kern, dim3(ceil_div(H, 4)), dim3(256), 0, st, p->w_hh, p->b_hh, gi, hprev, mask, out,
                      (float*)nullptr, (float*)nullptr, N, H);
