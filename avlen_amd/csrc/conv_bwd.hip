@@ -260,6 +260,151 @@ int launch_dw_n(const DwArgs& a, int ntw, int grid, hipStream_t st) {
 }
 }  // namespace
 
+// ========================================================================================================================
+// Direct data gradient (bf16 mode):  dX[b][ih][iw][ci] = [act > 0] * sum_{kh, kw, co} dY[b][(ih-kh)/s][(iw-kw)/s][co] * W[co][kh][kw][ci]
+// over the taps whose division is exact and lands inside the output.  The GEMM route writes dY * W as an fp32 im2col-shaped buffer
+// (M x K, 0.7 GB for one conv of a minibatch) and gathers it back (`col2im`); here a workgroup keeps the transposed weights
+// ([tap][ci][co] bf16, packed once per call) and ONE image's dY (bf16, zero halo) in LDS and forms 16-pixel x 16-channel output tiles
+// directly: the contraction index (tap, co) is channel-last in dY, so both operand fragments are aligned 16-byte LDS reads; with a
+// stride s the input pixels split into s*s parity classes, each with its own tap subset, and a tile is 16 pixels of one class along a
+// row (their dY positions are consecutive).  dY is read once, dX written once, the ReLU mask of the layer below applied on the way.
+// ========================================================================================================================
+namespace {
+constexpr int DX_TH = 512;
+constexpr int DX_PAD = 8;                        // bf16 elements of padding per LDS row of cout values (conflict-free 16-byte reads)
+struct DxArgs {
+  const float* dY; const float* act; float* dX; const bf16* wt;
+  int R, H, W, cin, OH, OW, KH, KW, s, cout, halo;
+  int yrows, ycols;                              // padded dY image in LDS: (OH + 2 halo) x (OW + 2 halo) pixels
+  unsigned wt_bytes, y_off, lds_bytes;
+};
+
+// W packed [co][kh][kw][ci] fp32 -> wt [tap][ci][cout + DX_PAD] bf16 (the LDS image of conv_dx_kernel)
+__global__ void conv_dx_pack_kernel(const float* __restrict__ w, bf16* __restrict__ wt, int cout, int taps, int cin) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int row = cout + DX_PAD;
+  if (i >= taps * cin * row) return;
+  const int co = i % row, tc = i / row;          // tc = tap * cin + ci
+  wt[i] = co < cout ? (bf16)w[(long)co * taps * cin + tc] : (bf16)0.f;
+}
+
+template <int NT>                                // cin / 16
+__global__ __launch_bounds__(DX_TH) void conv_dx_kernel(const DxArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, lg = lane >> 4;
+  const int cout = a.cout, rowb = (cout + DX_PAD) * 2, s = a.s, halo = a.halo;
+  for (unsigned o = tid * 16u; o < a.wt_bytes; o += DX_TH * 16u)
+    *reinterpret_cast<uint4*>(lds + o) = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.wt) + o);
+  for (unsigned o = a.y_off + tid * 16u; o < a.lds_bytes; o += DX_TH * 16u) *reinterpret_cast<uint4*>(lds + o) = make_uint4(0, 0, 0, 0);
+  char* const ybase = lds + a.y_off;
+  const int c8 = cout >> 3, units = a.OH * a.OW * c8;            // 8-channel pieces of one dY image
+  // tiles of an image: (parity class, input row of the class, 16 pixels of the class along the row)
+  const int per_row_max = (a.W + s - 1) / s, jt = (per_row_max + 15) >> 4;
+  const int rows_max = (a.H + s - 1) / s;
+  const int ntiles = s * s * rows_max * jt;
+  for (int b = blockIdx.x; b < a.R; b += gridDim.x) {
+    __syncthreads();                                             // the previous image's tiles are done with the dY image
+    const float* src = a.dY + (long)b * a.OH * a.OW * cout;
+    for (int u0 = 0; u0 < units; u0 += DX_TH * 4) {              // branch-free: 8 loads in flight per thread
+      float4 v[4][2];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int u = u0 + tid + DX_TH * k < units ? u0 + tid + DX_TH * k : units - 1;
+        v[k][0] = *reinterpret_cast<const float4*>(src + (long)u * 8); v[k][1] = *reinterpret_cast<const float4*>(src + (long)u * 8 + 4);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int u = u0 + tid + DX_TH * k;
+        if (u < units) {
+          const int pix = u / c8, cc = u - pix * c8, oh = pix / a.OW, ow = pix - oh * a.OW;
+          bf16x8 o;
+          o[0] = (bf16)v[k][0].x; o[1] = (bf16)v[k][0].y; o[2] = (bf16)v[k][0].z; o[3] = (bf16)v[k][0].w;
+          o[4] = (bf16)v[k][1].x; o[5] = (bf16)v[k][1].y; o[6] = (bf16)v[k][1].z; o[7] = (bf16)v[k][1].w;
+          *reinterpret_cast<bf16x8*>(ybase + ((oh + halo) * a.ycols + ow + halo) * rowb + cc * 16) = o;
+        }
+      }
+    }
+    __syncthreads();
+    for (int t = wv; t < ntiles; t += 8) {
+      const int cls = t / (rows_max * jt), rem = t - cls * rows_max * jt, r = rem / jt, j0 = (rem - r * jt) * 16;
+      const int py = cls / s, px = cls - py * s;
+      const int ih = py + r * s;
+      if (ih >= a.H || px + j0 * s >= a.W) continue;             // wave-uniform
+      f32x4 acc[NT];
+#pragma unroll
+      for (int n = 0; n < NT; n++) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int kh = py % s; kh < a.KH; kh += s) {                // ih - kh divisible by s  <=>  kh = py (mod s)
+        const int oh = (ih - kh) / s;                            // exact; may be negative / >= OH: the zero halo
+        if (oh < -halo || oh >= a.OH + halo) continue;
+        for (int kw = px % s; kw < a.KW; kw += s) {
+          const int ow0 = (px - kw) / s + j0;                    // exact: px - kw is a multiple of s (C division truncates toward 0, fine)
+          const int tap = kh * a.KW + kw;
+          const char* ya = ybase + ((oh + halo) * a.ycols + ow0 + li + halo) * rowb + lg * 16;
+          const char* wb = lds + ((tap * a.cin + li) * rowb) + lg * 16;
+          for (int kk = 0; kk < cout; kk += 32) {
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(ya + kk * 2);
+#pragma unroll
+            for (int n = 0; n < NT; n++) {
+              const bf16x8 bfv = *reinterpret_cast<const bf16x8*>(wb + n * 16 * rowb + kk * 2);
+              acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfv, acc[n], 0, 0, 0);
+            }
+          }
+        }
+      }
+      // D: row (pixel) lg * 4 + r, column (channel) li
+#pragma unroll
+      for (int r4 = 0; r4 < 4; r4++) {
+        const int iw = px + (j0 + lg * 4 + r4) * s;
+        if (iw < a.W) {
+          const long o = (((long)b * a.H + ih) * a.W + iw) * a.cin + li;
+#pragma unroll
+          for (int n = 0; n < NT; n++) {
+            const float m = a.act ? a.act[o + n * 16] : 1.f;
+            a.dX[o + n * 16] = m > 0.f ? acc[n][r4] : 0.f;
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// dX (B, H, W, cin) = [act > 0] * conv_transpose(dY, W); W packed [cout][KH][KW][cin] fp32.  AVLEN_NOT_BIG: not applicable.
+// Scratch: c.gws (the transposed bf16 weights).
+int avlen_i_conv_dx_direct(const avlen_ctx& c, const float* w, const float* dY, const float* act, float* dX, long R, int H, int W, int cin,
+                           int OH, int OW, int cout, int KH, int KW, int s) {
+  if (c.prec != AVLEN_PREC_BF16 || R <= 0 || R > (1L << 28) || (cin != 32 && cin != 64) || (cout & 31) || cout > 128) return AVLEN_NOT_BIG;
+  if (s < 1 || s > 2 || KH < s || KW < s || (OH - 1) * s + KH > H || (OW - 1) * s + KW > W) return AVLEN_NOT_BIG;
+  DxArgs a;
+  a.dY = dY; a.act = act; a.dX = dX;
+  a.R = (int)R; a.H = H; a.W = W; a.cin = cin; a.OH = OH; a.OW = OW; a.KH = KH; a.KW = KW; a.s = s; a.cout = cout;
+  const int hk = (KH > KW ? KH : KW);
+  a.halo = (hk - 1 + s - 1) / s;                 // positions (ih - kh) / s below 0 / past the end: zero
+  // A 16-pixel tile reads up to 15 positions past the last valid one of its row: they wrap into the next row of the LDS image (finite
+  // values, and only in rows of the product whose pixel does not exist); the last row needs 16 more positions behind the image.
+  a.yrows = OH + 2 * a.halo; a.ycols = OW + 2 * a.halo;
+  const int rowb = (cout + DX_PAD) * 2;
+  a.wt_bytes = (unsigned)(KH * KW * cin * rowb);
+  a.y_off = (a.wt_bytes + 15u) & ~15u;
+  a.lds_bytes = a.y_off + (unsigned)((a.yrows * a.ycols + 16) * rowb);
+  a.lds_bytes = (a.lds_bytes + 15u) & ~15u;
+  if (a.lds_bytes > 160u * 1024u || !c.gws || a.wt_bytes > c.gws_bytes) return AVLEN_NOT_BIG;
+  a.wt = (const bf16*)c.gws;
+  const int nw = KH * KW * cin * (cout + DX_PAD);
+  hipLaunchKernelGGL(conv_dx_pack_kernel, dim3((nw + 255) / 256), dim3(256), 0, c.st, w, (bf16*)c.gws, cout, KH * KW, cin);
+  const int grid = (int)(R < n_cus() ? R : n_cus());
+  static unsigned long long done2 = 0, done4 = 0;
+  if (cin == 32) {
+    if (avlen_set_dyn_lds(reinterpret_cast<const void*>(&conv_dx_kernel<2>), 160 * 1024, &done2) != AVLEN_OK) return AVLEN_ERR_LAUNCH;
+    hipLaunchKernelGGL(conv_dx_kernel<2>, dim3(grid), dim3(DX_TH), a.lds_bytes, c.st, a);
+  } else {
+    if (avlen_set_dyn_lds(reinterpret_cast<const void*>(&conv_dx_kernel<4>), 160 * 1024, &done4) != AVLEN_OK) return AVLEN_ERR_LAUNCH;
+    hipLaunchKernelGGL(conv_dx_kernel<4>, dim3(grid), dim3(DX_TH), a.lds_bytes, c.st, a);
+  }
+  return avlen_launch_status();
+}
+
 // gw [cout][KH*KW*C] (packed K order) = dY^T im2col(X), gb[cout] += column sums of dY (gb may be null).  bf16 operands, fp32
 // accumulation, valid convolution (no padding).  AVLEN_NOT_BIG: shape outside the kernel's limits (caller takes the GEMM route).
 // Scratch: c.gws (one partial per workgroup).

@@ -31,6 +31,10 @@ int avlen_i_conv_dw16(const avlen_ctx& c, const avlen_linear& G, const float* dY
 // column sums of dY (null: skipped); bf16 mode, valid convolutions, cout 32 / 64; partials in c.gws.  AVLEN_NOT_BIG: not applicable
 int avlen_i_conv_dw_direct(const avlen_ctx& c, float* gw, float* gb, int cout, const float* dY, const float* X, long R, int H,
                            int W, int C, int OH, int OW, int KH, int KW, int s);
+// conv data gradient without the im2col-shaped intermediate (conv_bwd.hip): dX = [act > 0] * conv_transpose(dY, W), W packed
+// [cout][KH][KW][cin]; bf16 mode, cin 32 / 64, stride 1 / 2, valid convolutions.  AVLEN_NOT_BIG: not applicable
+int avlen_i_conv_dx_direct(const avlen_ctx& c, const float* w, const float* dY, const float* act, float* dX, long R, int H, int W, int cin,
+                           int OH, int OW, int cout, int KH, int KW, int s);
 
 // few-row Linear against a tall weight matrix (train_gru.hip): out = x W^T + b, one wave per output column
 bool avlen_i_skinny_linear_ok(int M, int K);

@@ -591,10 +591,16 @@ int cnn_bwd(const avlen_ctx& c, Ws& s, const avlen_cnn3* n, const avlen_cnn3* g,
     hipLaunchKernelGGL(unpack_conv_grad_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, s.gpack, g->conv[i].w, k.cout,
                        k.cin, k.kh, k.kw);
     if (i == 0) break;
-    // data gradient: dcols = dY * Wp, gathered back onto the input pixels, masked by the ReLU of the layer below
-    avlen_linear Wl{k.w, nullptr, k.cout, Kc, nullptr, 0};
-    TRY(avlen_i_linear_dx(c, Wl, dy, k.cout, s.cols, Kc, (int)M, nullptr, 0));
-    TRY(col2im_relu(st, s.cols, a.a[i - 1], other, R, d.h[i], d.w[i], k.cin, d.h[i + 1], d.w[i + 1], k.kh, k.kw, k.stride, 0));
+    // data gradient, masked by the ReLU of the layer below: the direct kernel (conv_bwd.hip) where it applies, else dcols = dY * Wp
+    // gathered back onto the input pixels
+    rc = conv_dw_direct_on() ? avlen_i_conv_dx_direct(c, k.w, dy, a.a[i - 1], other, R, d.h[i], d.w[i], k.cin, d.h[i + 1], d.w[i + 1], k.cout,
+                                                      k.kh, k.kw, k.stride)
+                             : AVLEN_NOT_BIG;
+    if (rc == AVLEN_NOT_BIG) {
+      avlen_linear Wl{k.w, nullptr, k.cout, Kc, nullptr, 0};
+      TRY(avlen_i_linear_dx(c, Wl, dy, k.cout, s.cols, Kc, (int)M, nullptr, 0));
+      TRY(col2im_relu(st, s.cols, a.a[i - 1], other, R, d.h[i], d.w[i], k.cin, d.h[i + 1], d.w[i + 1], k.kh, k.kw, k.stride, 0));
+    } else TRY(rc);
     float* t = dy; dy = other; other = t;
   }
   return avlen_launch_status();
