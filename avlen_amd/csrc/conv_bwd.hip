@@ -288,6 +288,7 @@ __global__ void conv_dx_pack_kernel(const float* __restrict__ w, bf16* __restric
   wt[i] = co < cout ? (bf16)w[(long)co * taps * cin + tc] : (bf16)0.f;
 }
 
+constexpr int DX_UMAX = 6;                       // 8-channel pieces of one dY image per thread (OH * OW * cout / 8 <= DX_UMAX * DX_TH)
 template <int NT>                                // cin / 16
 __global__ __launch_bounds__(DX_TH) void conv_dx_kernel(const DxArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -302,42 +303,77 @@ __global__ __launch_bounds__(DX_TH) void conv_dx_kernel(const DxArgs a) {
   const int per_row_max = (a.W + s - 1) / s, jt = (per_row_max + 15) >> 4;
   const int rows_max = (a.H + s - 1) / s;
   const int ntiles = s * s * rows_max * jt;
-  for (int b = blockIdx.x; b < a.R; b += gridDim.x) {
-    __syncthreads();                                             // the previous image's tiles are done with the dY image
+  // the next image's dY travels in registers while this image's tiles run (branch-free loads: all in flight)
+  float4 yv[DX_UMAX][2];
+  auto fetch_y = [&](int b) {
     const float* src = a.dY + (long)b * a.OH * a.OW * cout;
-    for (int u0 = 0; u0 < units; u0 += DX_TH * 4) {              // branch-free: 8 loads in flight per thread
-      float4 v[4][2];
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int u = u0 + tid + DX_TH * k < units ? u0 + tid + DX_TH * k : units - 1;
-        v[k][0] = *reinterpret_cast<const float4*>(src + (long)u * 8); v[k][1] = *reinterpret_cast<const float4*>(src + (long)u * 8 + 4);
-      }
+    for (int k = 0; k < DX_UMAX; k++) {
+      const int u = tid + DX_TH * k < units ? tid + DX_TH * k : units - 1;
+      yv[k][0] = *reinterpret_cast<const float4*>(src + (long)u * 8); yv[k][1] = *reinterpret_cast<const float4*>(src + (long)u * 8 + 4);
+    }
+  };
+  auto store_y = [&]() {
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int u = u0 + tid + DX_TH * k;
-        if (u < units) {
-          const int pix = u / c8, cc = u - pix * c8, oh = pix / a.OW, ow = pix - oh * a.OW;
-          bf16x8 o;
-          o[0] = (bf16)v[k][0].x; o[1] = (bf16)v[k][0].y; o[2] = (bf16)v[k][0].z; o[3] = (bf16)v[k][0].w;
-          o[4] = (bf16)v[k][1].x; o[5] = (bf16)v[k][1].y; o[6] = (bf16)v[k][1].z; o[7] = (bf16)v[k][1].w;
-          *reinterpret_cast<bf16x8*>(ybase + ((oh + halo) * a.ycols + ow + halo) * rowb + cc * 16) = o;
-        }
+    for (int k = 0; k < DX_UMAX; k++) {
+      const int u = tid + DX_TH * k;
+      if (u < units) {
+        const int pix = u / c8, cc = u - pix * c8, oh = pix / a.OW, ow = pix - oh * a.OW;
+        bf16x8 o;
+        o[0] = (bf16)yv[k][0].x; o[1] = (bf16)yv[k][0].y; o[2] = (bf16)yv[k][0].z; o[3] = (bf16)yv[k][0].w;
+        o[4] = (bf16)yv[k][1].x; o[5] = (bf16)yv[k][1].y; o[6] = (bf16)yv[k][1].z; o[7] = (bf16)yv[k][1].w;
+        *reinterpret_cast<bf16x8*>(ybase + ((oh + halo) * a.ycols + ow + halo) * rowb + cc * 16) = o;
       }
     }
+  };
+  // a tile's geometry; `ok` false: no such tile (past the image)
+  struct Tile { int py, px, ih, j0; bool ok; };
+  auto tile_of = [&](int t) {
+    Tile q;
+    const int cls = t / (rows_max * jt), rem = t - cls * rows_max * jt, r = rem / jt;
+    q.py = cls / s; q.px = cls - q.py * s; q.ih = q.py + r * s; q.j0 = (rem - r * jt) * 16;
+    q.ok = t < ntiles && q.ih < a.H && q.px + q.j0 * s < a.W;
+    return q;
+  };
+  // the ReLU mask of a tile's outputs (act of the layer below), fetched one tile ahead: a load under `if (pixel exists)` is a
+  // dependent round trip per row of the tile (first version: 297 us for a conv whose traffic is worth 120 us)
+  float mk[4][NT];
+  auto fetch_mask = [&](int b, const Tile& q) {
+#pragma unroll
+    for (int r4 = 0; r4 < 4; r4++) {
+      int iw = q.px + (q.j0 + lg * 4 + r4) * s;
+      iw = iw < a.W ? iw : a.W - 1;
+      const long o = (((long)b * a.H + (q.ok ? q.ih : 0)) * a.W + iw) * a.cin + li;
+#pragma unroll
+      for (int n = 0; n < NT; n++) mk[r4][n] = a.act ? a.act[o + n * 16] : 1.f;
+    }
+  };
+  if ((int)blockIdx.x < a.R) fetch_y(blockIdx.x);
+  for (int b = blockIdx.x; b < a.R; b += gridDim.x) {
+    __syncthreads();                                             // the previous image's tiles are done with the dY image
+    store_y();
     __syncthreads();
+    if (b + (int)gridDim.x < a.R) fetch_y(b + gridDim.x);
+    Tile q = tile_of(wv);
+    fetch_mask(b, q);
     for (int t = wv; t < ntiles; t += 8) {
-      const int cls = t / (rows_max * jt), rem = t - cls * rows_max * jt, r = rem / jt, j0 = (rem - r * jt) * 16;
-      const int py = cls / s, px = cls - py * s;
-      const int ih = py + r * s;
-      if (ih >= a.H || px + j0 * s >= a.W) continue;             // wave-uniform
+      const Tile cur = q;
+      float mc[4][NT];
+#pragma unroll
+      for (int r4 = 0; r4 < 4; r4++)
+#pragma unroll
+        for (int n = 0; n < NT; n++) mc[r4][n] = mk[r4][n];
+      q = tile_of(t + 8);
+      fetch_mask(b, q);                                          // next tile's mask in flight during this tile's products
+      if (!cur.ok) continue;                                     // wave-uniform
+      const int py = cur.py, px = cur.px, ih = cur.ih, j0 = cur.j0;
       f32x4 acc[NT];
 #pragma unroll
       for (int n = 0; n < NT; n++) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int kh = py % s; kh < a.KH; kh += s) {                // ih - kh divisible by s  <=>  kh = py (mod s)
-        const int oh = (ih - kh) / s;                            // exact; may be negative / >= OH: the zero halo
-        if (oh < -halo || oh >= a.OH + halo) continue;
-        for (int kw = px % s; kw < a.KW; kw += s) {
-          const int ow0 = (px - kw) / s + j0;                    // exact: px - kw is a multiple of s (C division truncates toward 0, fine)
+      for (int kh = py; kh < a.KH; kh += s) {                    // ih - kh divisible by s  <=>  kh = py (mod s)
+        const int oh = (ih - kh) / s;                            // exact; negative / >= OH: the zero halo
+        for (int kw = px; kw < a.KW; kw += s) {
+          const int ow0 = (px - kw) / s + j0;                    // exact: px - kw is a multiple of s
           const int tap = kh * a.KW + kw;
           const char* ya = ybase + ((oh + halo) * a.ycols + ow0 + li + halo) * rowb + lg * 16;
           const char* wb = lds + ((tap * a.cin + li) * rowb) + lg * 16;
@@ -358,10 +394,7 @@ __global__ __launch_bounds__(DX_TH) void conv_dx_kernel(const DxArgs a) {
         if (iw < a.W) {
           const long o = (((long)b * a.H + ih) * a.W + iw) * a.cin + li;
 #pragma unroll
-          for (int n = 0; n < NT; n++) {
-            const float m = a.act ? a.act[o + n * 16] : 1.f;
-            a.dX[o + n * 16] = m > 0.f ? acc[n][r4] : 0.f;
-          }
+          for (int n = 0; n < NT; n++) a.dX[o + n * 16] = mc[r4][n] > 0.f ? acc[n][r4] : 0.f;
         }
       }
     }
@@ -389,7 +422,7 @@ int avlen_i_conv_dx_direct(const avlen_ctx& c, const float* w, const float* dY, 
   a.y_off = (a.wt_bytes + 15u) & ~15u;
   a.lds_bytes = a.y_off + (unsigned)((a.yrows * a.ycols + 16) * rowb);
   a.lds_bytes = (a.lds_bytes + 15u) & ~15u;
-  if (a.lds_bytes > 160u * 1024u || !c.gws || a.wt_bytes > c.gws_bytes) return AVLEN_NOT_BIG;
+  if (a.lds_bytes > 160u * 1024u || !c.gws || a.wt_bytes > c.gws_bytes || (long)OH * OW * (cout / 8) > DX_UMAX * DX_TH) return AVLEN_NOT_BIG;
   a.wt = (const bf16*)c.gws;
   const int nw = KH * KW * cin * (cout + DX_PAD);
   hipLaunchKernelGGL(conv_dx_pack_kernel, dim3((nw + 255) / 256), dim3(256), 0, c.st, w, (bf16*)c.gws, cout, KH * KW, cin);
