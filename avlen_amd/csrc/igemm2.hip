@@ -539,12 +539,12 @@ __global__ void cast_rows_kernel(const float* __restrict__ src, int lds_, bf16* 
 }
 
 __global__ void cast_rows_indexed_kernel(const float* __restrict__ src, int lds_, bf16* __restrict__ dst, int ldd, long rows, int cols,
-                                         const int* __restrict__ row_index, int rpi) {
+                                         const int* __restrict__ row_index, int rpi, int fmt) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * ldd) return;
   long r = i / ldd; int c = (int)(i - r * ldd);
   const long item = r / rpi, rs = (long)row_index[item] * rpi + (r - item * rpi);
-  dst[i] = c < cols ? (bf16)src[rs * lds_ + c] : (bf16)0.f;
+  dst[i] = c < cols ? cvt16(src[rs * lds_ + c], fmt) : (bf16)0.f;
 }
 
 // Same cast, 8 elements (32 B in, 16 B out) per thread: both leading dimensions multiples of 8 and 16-byte aligned bases
@@ -932,7 +932,7 @@ extern "C" int avlen_cast_bf16(const float* src, int ld_src, void* dst, int ld_d
 
 // 8 output elements per thread, 8-byte loads (source rows only need an even leading dimension: 202 floats for the spectrogram)
 __global__ void cast_rows_indexed8_kernel(const float* __restrict__ src, int lds_, bf16* __restrict__ dst, int ldd, long rows, int cols,
-                                          const int* __restrict__ row_index, int rpi) {
+                                          const int* __restrict__ row_index, int rpi, int fmt) {
   const int per_row = ldd >> 3;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * per_row) return;
@@ -942,27 +942,27 @@ __global__ void cast_rows_indexed8_kernel(const float* __restrict__ src, int lds
   bf16x8 o;
   if (c + 8 <= cols) {
 #pragma unroll
-    for (int e = 0; e < 4; e++) { const float2 v = *reinterpret_cast<const float2*>(s + 2 * e); o[2 * e] = (bf16)v.x; o[2 * e + 1] = (bf16)v.y; }
+    for (int e = 0; e < 4; e++) { const float2 v = *reinterpret_cast<const float2*>(s + 2 * e); o[2 * e] = cvt16(v.x, fmt); o[2 * e + 1] = cvt16(v.y, fmt); }
   } else {
 #pragma unroll
-    for (int e = 0; e < 8; e++) o[e] = c + e < cols ? (bf16)s[e] : (bf16)0.f;
+    for (int e = 0; e < 8; e++) o[e] = c + e < cols ? cvt16(s[e], fmt) : (bf16)0.f;
   }
   *reinterpret_cast<bf16x8*>(dst + r * ldd + c) = o;
 }
 
 int avlen_cast_bf16_indexed(const float* src, int ld_src, void* dst, int ld_dst, long rows, int cols, const int* row_index,
-                            int rows_per_item, hipStream_t stream) {
-  if (!row_index) return avlen_cast_bf16(src, ld_src, dst, ld_dst, rows, cols, stream);
+                            int rows_per_item, hipStream_t stream, int fmt) {
+  if (!row_index) return avlen_cast_h16(src, ld_src, dst, ld_dst, rows, cols, fmt, stream);
   long tot = rows * ld_dst;
   if (tot <= 0 || rows_per_item <= 0) return AVLEN_ERR_ARG;
   if (!(ld_src & 1) && !(ld_dst & 7) && !((uintptr_t)src & 7) && !((uintptr_t)dst & 15)) {
     long t8 = tot >> 3;
     hipLaunchKernelGGL(cast_rows_indexed8_kernel, dim3((unsigned)((t8 + 255) / 256)), dim3(256), 0, stream, src, ld_src, (bf16*)dst,
-                       ld_dst, rows, cols, row_index, rows_per_item);
+                       ld_dst, rows, cols, row_index, rows_per_item, fmt);
     return avlen_launch_status();
   }
   hipLaunchKernelGGL(cast_rows_indexed_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, src, ld_src, (bf16*)dst,
-                     ld_dst, rows, cols, row_index, rows_per_item);
+                     ld_dst, rows, cols, row_index, rows_per_item, fmt);
   return avlen_launch_status();
 }
 

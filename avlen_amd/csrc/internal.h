@@ -60,7 +60,7 @@ int avlen_preprocess_image_bf16(const void* x, int x_u8, void* y16, int B, int S
                                 const int* row_index = nullptr);
 // rows are grouped in items of `rows_per_item`; item i of the batch is item row_index[i] of src
 int avlen_cast_bf16_indexed(const float* src, int ld_src, void* dst, int ld_dst, long rows, int cols, const int* row_index,
-                            int rows_per_item, hipStream_t stream);
+                            int rows_per_item, hipStream_t stream, int fmt = 0);       // fmt: 0 bf16, 1 fp16
 int avlen_groupnorm_apply_bf16_grouped(const void* const* x, int raw16, const float* const* stats,
                                        const float* const* gamma, const float* const* beta, const void* const* res16,
                                        void* const* y16, int groups, int B, int HW, int C, int G, int relu, float eps,

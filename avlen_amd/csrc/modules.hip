@@ -859,7 +859,7 @@ size_t cnn3_ws_bf16(const avlen_cnn3* n, int B, int H, int W) {
 int cnn3_fwd_bf16(const avlen_cnn3* n, const float* x, int B, int H, int W, float* out, int ld_out, void* ws,
                   size_t ws_bytes, hipStream_t st, const int* row_index = nullptr, bool f16 = false) {
   if (ws_bytes < cnn3_ws_bf16(n, B, H, W)) return AVLEN_ERR_WS;
-  if (f16 != (n->half_fmt == 1) || (f16 && row_index)) return AVLEN_ERR_ARG;
+  if (f16 != (n->half_fmt == 1)) return AVLEN_ERR_ARG;
   avlen_g2_opts go; go.f16 = f16;
   const int fmt = f16 ? 1 : 0;
   int oh[3], ow[3]; cnn3_dims2(n, H, W, oh, ow);
@@ -874,11 +874,8 @@ int cnn3_fwd_bf16(const avlen_cnn3* n, const float* x, int B, int H, int W, floa
   void* gws = w.take<char>(mx);
   const bool sp = cnn3_superpixel(n, W);
   const int wsp = sp ? ((ow[0] - 1) * n->conv[0].stride + n->conv[0].kw) / n->conv[0].stride : 0;   // super-pixels per row
-  if (f16) {
-    if (sp) TRY(avlen_cast_h16(x, W * n->conv[0].cin, x16, wsp * 8, (long)B * H, wsp * 8, fmt, st));
-    else TRY(avlen_cast_h16(x, n->conv[0].cin, x16, 8, (long)B * H * W, n->conv[0].cin, fmt, st));
-  } else if (sp) TRY(avlen_cast_bf16_indexed(x, W * n->conv[0].cin, x16, wsp * 8, (long)B * H, wsp * 8, row_index, H, st));     // drop the unused columns
-  else TRY(avlen_cast_bf16_indexed(x, n->conv[0].cin, x16, 8, (long)B * H * W, n->conv[0].cin, row_index, H * W, st));         // channel-pad to 8
+  if (sp) TRY(avlen_cast_bf16_indexed(x, W * n->conv[0].cin, x16, wsp * 8, (long)B * H, wsp * 8, row_index, H, st, fmt));     // drop the unused columns
+  else TRY(avlen_cast_bf16_indexed(x, n->conv[0].cin, x16, 8, (long)B * H * W, n->conv[0].cin, row_index, H * W, st, fmt));         // channel-pad to 8
   const bf16* cur = x16; int h = H, wd = W;
   for (int i = 0; i < 3; i++) {
     const avlen_conv& k = n->conv[i];
@@ -1082,8 +1079,8 @@ extern "C" int avlen_cnn3_fwd_indexed(const avlen_cnn3* n, const float* x, const
   if (!n || B <= 0 || ws_bytes < avlen_cnn3_workspace_bytes(n, B, H, W)) return AVLEN_ERR_WS;
   int oh[3], ow[3]; cnn3_dims(n, H, W, oh, ow);
   if (oh[2] <= 0 || ow[2] <= 0 || n->fc.in_f != oh[2] * ow[2] * n->conv[2].cout) return AVLEN_ERR_ARG;
-  if (!(cnn3_has16(n) && n->conv[0].cin <= 8)) return AVLEN_ERR_ARG;          // bf16 fast path only
-  return cnn3_fwd_bf16(n, x, B, H, W, out, ld_out, ws, ws_bytes, st, row_index);
+  if (!(cnn3_has16(n) && n->conv[0].cin <= 8)) return AVLEN_ERR_ARG;          // 16-bit fast paths only (bf16, or fp16 shadows: half_fmt 1)
+  return cnn3_fwd_bf16(n, x, B, H, W, out, ld_out, ws, ws_bytes, st, row_index, n->half_fmt == 1);
 }
 
 extern "C" int avlen_cnn3_fwd(const avlen_cnn3* n, const float* x, int B, int H, int W, float* out, int ld_out,

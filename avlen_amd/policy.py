@@ -874,7 +874,7 @@ class _SMTBase(Net):
             if pol.prec_of("towers") in (L.PREC_BF16, L.PREC_BF16X3) and pol._shared_mode is None and isinstance(depth, RowsOf) \
                     and isinstance(spec, RowsOf) and depth.index is rgb.index and spec.index is rgb.index:
                 idx = rgb.index
-                if pol.prec_of("audio") != L.PREC_BF16:  # the indexed AudioCNN exists on the bf16 path only
+                if pol.prec_of("audio") not in (L.PREC_BF16, L.PREC_FP16):  # the indexed AudioCNN exists on the 16-bit paths only
                     spec = spec.materialise()
             else:
                 rgb, depth, spec = (t.materialise() if isinstance(t, RowsOf) else t for t in (rgb, depth, spec))
