@@ -31,6 +31,9 @@ int avlen_i_conv_dw16(const avlen_ctx& c, const avlen_linear& G, const float* dY
 // column sums of dY (null: skipped); bf16 mode, valid convolutions, cout 32 / 64; partials in c.gws.  AVLEN_NOT_BIG: not applicable
 int avlen_i_conv_dw_direct(const avlen_ctx& c, float* gw, float* gb, int cout, const float* dY, const float* X, long R, int H,
                            int W, int C, int OH, int OW, int KH, int KW, int s);
+// 3-conv CNN forward on the 16-bit conv kernels that also keeps every conv's fp32 output (modules.hip; the training forward)
+int avlen_i_cnn3_fwd16_keep(const avlen_cnn3* n, const float* x, int B, int H, int W, float* const* keep, float* out, int ld_out,
+                            void* x16, void* const* a16, void* gws, size_t gws_bytes, hipStream_t st);
 // conv data gradient without the im2col-shaped intermediate (conv_bwd.hip): dX = [act > 0] * conv_transpose(dY, W), W packed
 // [cout][KH][KW][cin]; bf16 mode, cin 32 / 64, stride 1 / 2, valid convolutions.  AVLEN_NOT_BIG: not applicable
 int avlen_i_conv_dx_direct(const avlen_ctx& c, const float* w, const float* dY, const float* act, float* dX, long R, int H, int W, int cin,

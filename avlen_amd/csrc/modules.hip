@@ -895,6 +895,42 @@ int cnn3_fwd_bf16(const avlen_cnn3* n, const float* x, int B, int H, int W, floa
                              n->fc.out_f, n->fc.ld16, AVLEN_ACT_RELU, gws, mx, st, &go);
 }
 
+}  // namespace
+// The TRAINING forward of a 3-conv CNN on the same 16-bit kernels (train_gru.hip, bf16 mode): every conv stores its fp32 output
+// (keep[i], what the backward reads) next to the bf16 copy the next layer consumes; x16 / a16: caller's scratch (B*H*W*8 and the
+// three activation sizes, bf16).  The fp32-staged implicit GEMM it replaces gathers fp32 patches in the kernel: 244 us for the
+// audio conv 1 of a 1200-row minibatch.  AVLEN_NOT_BIG: no 16-bit shadows / unsupported geometry.
+int avlen_i_cnn3_fwd16_keep(const avlen_cnn3* n, const float* x, int B, int H, int W, float* const* keep, float* out, int ld_out,
+                            void* x16v, void* const* a16v, void* gws, size_t gws_bytes, hipStream_t st) {
+  if (!cnn3_has16(n) || n->half_fmt != 0 || n->conv[0].cin > 8 || !x16v || !a16v) return AVLEN_NOT_BIG;
+  avlen_g2_opts go;
+  int oh[3], ow[3]; cnn3_dims2(n, H, W, oh, ow);
+  if (oh[2] <= 0 || ow[2] <= 0) return AVLEN_ERR_ARG;
+  bf16* x16 = (bf16*)x16v;
+  const bool sp = cnn3_superpixel(n, W);
+  const int wsp = sp ? ((ow[0] - 1) * n->conv[0].stride + n->conv[0].kw) / n->conv[0].stride : 0;
+  if (sp) TRY(avlen_cast_bf16_indexed(x, W * n->conv[0].cin, x16, wsp * 8, (long)B * H, wsp * 8, nullptr, H, st, 0));
+  else TRY(avlen_cast_bf16_indexed(x, n->conv[0].cin, x16, 8, (long)B * H * W, n->conv[0].cin, nullptr, H * W, st, 0));
+  const bf16* cur = x16; int h = H, wd = W;
+  for (int i = 0; i < 3; i++) {
+    const avlen_conv& k = n->conv[i];
+    const void* X1 = cur; void* Y1 = a16v[i]; float* Y32 = keep[i]; const float* B1 = k.b;
+    if (i == 0 && sp) {
+      const void* W1 = k.w16c;
+      TRY(avlen_conv2d_nhwc_bf16_grouped(&X1, &W1, &Y32, &Y1, nullptr, 1, B, h, wsp, 8, k.cout, k.kh, k.kw / k.stride, k.stride,
+                                         0, gws, gws_bytes, st, &B1, AVLEN_ACT_RELU, 1, &go));
+    } else {
+      const void* W1 = k.w16;
+      TRY(avlen_conv2d_nhwc_bf16_grouped(&X1, &W1, &Y32, &Y1, nullptr, 1, B, h, wd, k.cin16, k.cout, k.kh, k.kw, k.stride, 0, gws,
+                                         gws_bytes, st, &B1, i < 2 ? AVLEN_ACT_RELU : AVLEN_ACT_NONE, 0, &go));
+    }
+    cur = (const bf16*)a16v[i]; h = oh[i]; wd = ow[i];
+  }
+  return avlen_gemm_bf16_dyn(cur, n->fc.ld16, n->fc.w16, n->fc.ld16, out, ld_out, nullptr, 0, n->fc.b, nullptr, 0, B, nullptr,
+                             n->fc.out_f, n->fc.ld16, AVLEN_ACT_RELU, gws, gws_bytes, st, &go);
+}
+namespace {
+
 // `G` CNNs of identical architecture (the audio encoders of pi_q / pi_g / pi_l) on the SAME input: one cast, one grouped
 // launch per layer.
 int cnn3_group_fwd_bf16(const avlen_cnn3* const* nets, const float* x, int G, int B, int H, int W, float* const* outs,

@@ -481,6 +481,7 @@ struct Ws {
   // backward scratch
   float *dX, *dGI, *dGH, *dh[2], *dpre, *da, *db, *cols, *gpack, *whhT;
   unsigned* err;
+  void* x16; void* a16[3];       // bf16 mode: 16-bit input / activations of the training forward (avlen_i_cnn3_fwd16_keep)
   void* gws; void* xs; size_t xs_bytes;
 };
 size_t cnn_cols_max(const avlen_cnn3* n, const Dims& d, long R) {
@@ -527,16 +528,26 @@ bool layout(WsBump& w, Ws& s, const avlen_cnn3* au, const avlen_cnn3* vi, const 
   // operand scratch of the large-M bf16 products (modules.hip: cast / transposed-cast copies of both operands): the largest
   // product is a conv's weight gradient, dY^T (cout x M) and cols^T (K x M)
   s.xs = nullptr; s.xs_bytes = 0;
+  s.x16 = nullptr; s.a16[0] = s.a16[1] = s.a16[2] = nullptr;
   if (prec == AVLEN_PREC_BF16) {
     s.xs_bytes = (cm + am + (size_t)64 * 1024 * 1024) * 2 + (1u << 20);
     s.xs = w.take<char>(s.xs_bytes);
+    const size_t px = zmax((size_t)R * Ha * Wa, (size_t)R * S * S);
+    s.x16 = w.take<short>(px * 8);
+    for (int i = 0; i < 3; i++)
+      s.a16[i] = w.take<short>(zmax((size_t)R * da.h[i + 1] * da.w[i + 1] * da.c[i + 1], (size_t)R * dv.h[i + 1] * dv.w[i + 1] * dv.c[i + 1]));
   }
   return w.ok();
 }
 
-int cnn_fwd(const avlen_ctx& c, const avlen_cnn3* n, const float* x, long R, int H, int W, CnnWs& a, float* out, int ld_out) {
+int cnn_fwd(const avlen_ctx& c, const avlen_cnn3* n, const float* x, long R, int H, int W, CnnWs& a, float* out, int ld_out,
+            void* x16 = nullptr, void* const* a16 = nullptr) {
   const Dims d = cnn_dims(n, H, W);
   if (d.h[3] <= 0 || d.w[3] <= 0 || n->fc.in_f != d.h[3] * d.w[3] * d.c[3]) return AVLEN_ERR_ARG;
+  if (c.prec == AVLEN_PREC_BF16 && x16 && conv_dw_direct_on()) {      // the 16-bit conv kernels, fp32 outputs kept for the backward
+    const int rc = avlen_i_cnn3_fwd16_keep(n, x, (int)R, H, W, a.a, out, ld_out, x16, a16, c.gws, c.gws_bytes, c.st);
+    if (rc != AVLEN_NOT_BIG) return rc;
+  }
   const float* cur = x;
   for (int i = 0; i < 3; i++) {
     const avlen_conv& k = n->conv[i];
@@ -686,8 +697,8 @@ extern "C" int avlen_baseline_train_fwd(const avlen_cnn3* audio, const avlen_cnn
   avlen_ctx c{st, prec, s.gws, GEMM_SCRATCH};
   c.xs = s.xs; c.xs_bytes = s.xs_bytes;
   TRY(avlen_rgbd_concat(rgb, rgb_u8, depth, s.rgbd, (int)R, S * S, st));
-  TRY(cnn_fwd(c, audio, spec, R, Ha, Wa, s.aud, s.X, F));
-  TRY(cnn_fwd(c, visual, s.rgbd, R, S, S, s.vis, s.X + audio->fc.out_f, F));
+  TRY(cnn_fwd(c, audio, spec, R, Ha, Wa, s.aud, s.X, F, s.x16, s.a16));
+  TRY(cnn_fwd(c, visual, s.rgbd, R, S, S, s.vis, s.X + audio->fc.out_f, F, s.x16, s.a16));
   if (ncat) TRY(avlen_copy_rows(category, ncat, s.X + audio->fc.out_f + visual->fc.out_f, F, (int)R, ncat, st));
   avlen_linear ih{gru->w_ih, gru->b_ih, 3 * H, F, nullptr, 0};
   TRY(avlen_i_linear(c, ih, s.X, F, s.GI, 3 * H, (int)R, 0, nullptr, 0));
