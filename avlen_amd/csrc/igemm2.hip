@@ -883,12 +883,20 @@ extern "C" int avlen_gemm_h16(const void* A, int lda, const void* B, int ldb, fl
   return avlen_gemm_bf16_dyn(A, lda, B, ldb, C32, ldc32, C16, ldc16, bias, residual, ldr, M, nullptr, N, K, act, ws, ws_bytes, stream, &o);
 }
 
+__global__ void cast_rows_indexed8_kernel(const float* __restrict__ src, int lds_, bf16* __restrict__ dst, int ldd, long rows, int cols,
+                                          const int* __restrict__ row_index, int rpi, int fmt);
 extern "C" int avlen_cast_h16(const float* src, int ld_src, void* dst, int ld_dst, long rows, int cols, int fmt, hipStream_t stream) {
   long tot = rows * ld_dst;
   if (tot <= 0 || fmt < 0 || fmt > 2) return AVLEN_ERR_ARG;
   if (!(ld_src & 3) && !(ld_dst & 7) && !((uintptr_t)src & 15) && !((uintptr_t)dst & 15)) {
     long t8 = tot >> 3;
     hipLaunchKernelGGL(cast_rows8_kernel, dim3((unsigned)((t8 + 255) / 256)), dim3(256), 0, stream, src, ld_src, (bf16*)dst, ld_dst, rows, cols, fmt);
+    return avlen_launch_status();
+  }
+  if (!(ld_src & 1) && !(ld_dst & 7) && !((uintptr_t)src & 7) && !((uintptr_t)dst & 15)) {      // even row stride (a 101 x 2 spectrogram row): 8-byte loads
+    long t8 = tot >> 3;
+    hipLaunchKernelGGL(cast_rows_indexed8_kernel, dim3((unsigned)((t8 + 255) / 256)), dim3(256), 0, stream, src, ld_src, (bf16*)dst, ld_dst, rows,
+                       cols, (const int*)nullptr, 1, fmt);
     return avlen_launch_status();
   }
   hipLaunchKernelGGL(cast_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, src, ld_src, (bf16*)dst, ld_dst, rows, cols, fmt);
@@ -937,7 +945,7 @@ __global__ void cast_rows_indexed8_kernel(const float* __restrict__ src, int lds
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * per_row) return;
   const long r = i / per_row; const int c = (int)(i - r * per_row) << 3;
-  const long item = r / rpi, rs = (long)row_index[item] * rpi + (r - item * rpi);
+  const long item = r / rpi, rs = row_index ? (long)row_index[item] * rpi + (r - item * rpi) : r;
   const float* s = src + rs * lds_ + c;
   bf16x8 o;
   if (c + 8 <= cols) {
