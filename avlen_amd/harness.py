@@ -42,6 +42,11 @@ class Workload:
         self.distractor = distractor
         self.text_ahead = os.environ.get("AVLEN_TEXT_AHEAD", "1") != "0"      # A/B knob
         self._g_stream = int(os.environ.get("AVLEN_G_STREAM", "1"))
+        # pi_l runs BEHIND pi_q on the current stream (AVLEN_L_STREAM=side: on _side[1], which it shared with pi_g): on the shared
+        # stream the first half of its graph (its state encoder, 0.16 ms, needs the towers only) queued behind all of pi_g (0.6 ms)
+        # and so ran after the text tower it should have overlapped; behind pi_q it starts at 0.68 ms and only the dialog half is
+        # left when the text embedding arrives: 30.3 k -> 33.2 k env-steps/s (kernel trace of a step: DESIGN section 0)
+        self._l_main = os.environ.get("AVLEN_L_STREAM", "main") == "main"
         self._text_after = os.environ.get("AVLEN_TEXT_AHEAD", "1") == "2"     # 2: ordered after the current stream (debug)
         # 1: launch it BEFORE pi_q's graph -- measured slower (22.8k vs 27.5k env-steps/s): the GEMM blocks that get the CUs first
         # squeeze the towers; launched second, the text tower fills the gaps the memory-bound tower kernels leave
@@ -170,7 +175,7 @@ class Workload:
                 self.pi_g.prefetch_act(obs, h, prev, v["masks"], em_goal, em_masks, stream=self._side[self._g_stream])
             if self.pi_l is not None:
                 self.pi_l.prefetch_act_dialog(obs, h, prev, v["masks_vln"], em_vln, em_dlg, v["em_vln_masks"], v["dialog"],
-                                              v["astep"], stream=self._side[1])
+                                              v["astep"], stream=None if self._l_main else self._side[1])
         values, unct, a_opt, lp_opt, h, row_opt, probs_opt = self.pi_q.act_option(
             obs, h, prev, v["masks"], em_opt, em_masks, v["qs"], v["lqi"])
         dg = ro.em_dim_goal
