@@ -97,7 +97,7 @@ class ClipBlock(C.Structure):
 class ClipText(C.Structure):
     _fields_ = [("tok_emb", f32p), ("pos_emb", f32p), ("block", ClipBlock * 12), ("ln_final", Affine),
                 ("text_proj", f32p), ("vocab", C.c_int), ("ctx", C.c_int), ("width", C.c_int), ("heads", C.c_int),
-                ("layers", C.c_int), ("out_dim", C.c_int), ("half_fmt", C.c_int), ("wstream", vp)]
+                ("layers", C.c_int), ("out_dim", C.c_int), ("half_fmt", C.c_int), ("wstream", vp), ("text_proj_t", f32p)]
 
 
 class Gru(C.Structure):

@@ -239,6 +239,9 @@ class Packed:
                        P(c), dims[0], dims[1], c16, st)
             elif kind == "pad16":
                 L.call("avlen_cast_h16", P(w), dims[1], P(buf16), c16, dims[0], dims[1], buf or 0, st)
+            elif kind == "t32":                       # derived data: a transposed fp32 copy
+                with torch.no_grad():
+                    buf.copy_(w.t())
             elif kind == "conv32":
                 L.call("avlen_pack_conv_weight", P(w), P(buf), *dims, st)
             elif kind == "convbn":
@@ -400,6 +403,12 @@ def clip_view(clip, flat=None, packed=None, fmt=0):
     s.vocab, s.ctx = clip.vocab_size, clip.context_length
     s.width, s.heads, s.layers = clip.transformer.width, clip.heads, clip.transformer.layers
     s.out_dim = clip.text_projection.shape[1]
+    if packed is not None:
+        # [out][width] copy of the projection: the few-row form (one wave per output column) reads rows, not columns
+        tp = torch.empty(clip.text_projection.shape[1], clip.text_projection.shape[0], dtype=torch.float32, device=packed.device)
+        packed.bufs.append(tp)
+        packed.jobs.append(("t32", clip.text_projection, tp, None, None, 0))
+        s.text_proj_t = P(tp)
     if packed is not None and os.environ.get("AVLEN_CLIP_STREAM", "1") != "0":
         # per-wave weight streams of the one-launch sequence-stationary tower (csrc/clip_tower.hip): 0.76 ms for 64 dialogs against
         # 0.93 ms for the launch-per-GEMM tower (AVLEN_CLIP_STREAM=0 keeps that one).  0 bytes: shape not supported.

@@ -33,9 +33,10 @@ for it in range(STEPS):
     mark("txt_end", wl._side[2]); host_t = time.perf_counter()
     wl.pi_g.prefetch_act(obs, h, prev, v["masks"], em_goal, em_masks, stream=wl._side[wl._g_stream])
     mark("g_end", wl._side[wl._g_stream]); host_g = time.perf_counter()
+    l_stream = None if wl._l_main else wl._side[1]       # the harness default: pi_l behind pi_q on the current stream
     wl.pi_l.prefetch_act_dialog(obs, h, prev, v["masks_vln"], em_vln, em_dlg, v["em_vln_masks"], v["dialog"], v["astep"],
-                                stream=wl._side[1])
-    mark("l_end", wl._side[1]); host_l = time.perf_counter()
+                                stream=l_stream)
+    mark("l_end", cur if l_stream is None else l_stream); host_l = time.perf_counter()
     values, unct, a_opt, lp_opt, h2, row_opt, probs_opt = wl.pi_q.act_option(obs, h, prev, v["masks"], em_opt, em_masks, v["qs"], v["lqi"])
     host_aq = time.perf_counter()
     _, a_goal, _, _, row_goal, _ = wl.pi_g.act(obs, h2, prev, v["masks"], em_goal, em_masks)
