@@ -75,6 +75,7 @@ def _i64(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+_TOWERS_FIRST = os.environ.get("AVLEN_TOWERS_FIRST", "1") != "0"
 _SPLIT = True        # pi_l's captured forward is cut in two around the text embedding (decided by measurement: DESIGN section 3)
 
 
@@ -899,6 +900,11 @@ class _SMTBase(Net):
             s_aud = pol.side_streams()[0] if fork else cur
             if fork:
                 s_aud.wait_stream(cur)
+            vis_early = None
+            if mode == "lead" and fork and _TOWERS_FIRST:
+                # capture order = submission order of the replay: the towers' persistent launch is the step's critical path and goes
+                # first; the audio branch (enqueued first, it delayed that launch by its own five submissions) runs behind it
+                vis_early = grp.run_all(pol, rgb, depth)
             with torch.cuda.stream(s_aud):
                 if mode == "lead":
                     aud = grp.run_audio(pol, spec)
@@ -917,7 +923,7 @@ class _SMTBase(Net):
             if mode == "follow":
                 vis = grp.buffers(B, dev)[grp.members.index(pol)]
             elif mode == "lead":
-                vis = grp.run_all(pol, rgb, depth)
+                vis = vis_early if vis_early is not None else grp.run_all(pol, rgb, depth)
                 # the followers need nothing else of this forward: cut the captured graph here (the replay records grp.ready
                 # between the two halves, see Policy._forward); eager: record it now
                 if fork:
