@@ -1940,9 +1940,9 @@ extern "C" size_t avlen_clip_text_workspace_bytes(const avlen_clip_text* p, int 
 
 // out = E2 @ text_proj   (text_proj stored [width][out_dim]); a handful of row tiles -> split K over the chip
 static int clip_project(const avlen_clip_text* p, const float* E2, float* out, int B, int prec, void* gws, hipStream_t st) {
-  // a rollout batch (<= 64 rows) on the critical path behind the text tower: one wave per output column, fp32 FMA, one launch
-  // (the split-K tile GEMM + its reduce: 37 us; this: latency only)
-  if (p->text_proj_t && avlen_i_skinny_linear_ok(B, p->width))
+  // a handful of rows (<= 16): one wave per output column, fp32 FMA, one launch.  Not for the 64-row rollout batch: the kernel
+  // walks 16 rows at a time, every wave re-reads all of x, and a kernel trace showed 92 us against 37 us for the split-K tile GEMM
+  if (p->text_proj_t && B <= 16 && avlen_i_skinny_linear_ok(B, p->width))
     return avlen_i_skinny_linear(E2, p->width, p->text_proj_t, nullptr, out, p->out_dim, B, p->out_dim, p->width, st);
   int sk = avlen_gemm_pick_splitk(B, p->out_dim, p->width);
   while (sk > 1 && avlen_gemm_workspace_bytes(B, p->out_dim, p->width, sk) > GEMM_SCRATCH) sk /= 2;
