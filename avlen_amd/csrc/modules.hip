@@ -1978,6 +1978,8 @@ extern "C" int avlen_clip_text_fwd(const avlen_clip_text* p, const int64_t* toke
     void* sws = w.take<char>(sb);
     if (!w.ok()) return AVLEN_ERR_WS;
     TRY(avlen_clip_tower_stream_fwd(p, tokens, E, B, f16 ? 1 : 0, sws, sb, st));
+    if (!p->text_proj)            // caller folded the projection into the Linear that follows (policy.py: dialog_layer): out = ln_final(E)
+      return avlen_layernorm_fwd(E, nullptr, p->ln_final.g, p->ln_final.b, out, nullptr, nullptr, B, wd, 1e-5f, st);
     TRY(avlen_layernorm_fwd(E, nullptr, p->ln_final.g, p->ln_final.b, E2, nullptr, nullptr, B, wd, 1e-5f, st));
     return clip_project(p, E2, out, B, f16 ? AVLEN_PREC_BF16X3 : prec, gws, st);
   }

@@ -220,6 +220,19 @@ class Packed:
             if kind == "pad16":
                 L.call("avlen_cast_h16", P(w), dims[1], P(buf16), c16, dims[0], dims[1], buf or 0, st)
 
+    def proj_fold(self, lin, proj, fmt=0):
+        """Linear `lin` (out, k) behind a bias-free projection `proj` (in, k): lin(x @ proj) = x @ (lin.weight @ proj.T).T + b.
+        -> L.Linear over the folded fp32 weight (out, in) with its 16-bit shadow (fmt 0 bf16, 1 fp16); refreshed with the other
+        derived copies."""
+        out_f, in_f = lin.weight.shape[0], proj.shape[0]
+        wf = torch.empty(out_f, in_f, dtype=torch.float32, device=self.device)
+        wf16 = torch.empty(out_f, in_f, dtype=torch.bfloat16, device=self.device)
+        self.bufs += [wf, wf16]
+        self.jobs.append(("projfold", (lin.weight, proj), wf, wf16, (out_f, in_f), fmt))
+        v = L.Linear(P(wf), P(lin.bias) if lin.bias is not None else None, out_f, in_f)
+        v.w16, v.ld16 = P(wf16), in_f
+        return v
+
     def ln_fold(self, lin_w, lin_b, ln, fmt=0):
         """LayerNorm `ln` folded into the Linear (lin_w, lin_b) that follows it (avlen_ln_fold_weights); fmt 1: fp16 weights."""
         N_, K = lin_w.shape
@@ -239,6 +252,10 @@ class Packed:
                        P(c), dims[0], dims[1], c16, st)
             elif kind == "pad16":
                 L.call("avlen_cast_h16", P(w), dims[1], P(buf16), c16, dims[0], dims[1], buf or 0, st)
+            elif kind == "projfold":                  # derived data: Linear weight x projection, then its 16-bit shadow
+                with torch.no_grad():
+                    torch.matmul(w[0].detach().float(), w[1].detach().float().t(), out=buf)
+                L.call("avlen_cast_h16", P(buf), dims[1], P(buf16), dims[1], dims[0], dims[1], c16, st)
             elif kind == "t32":                       # derived data: a transposed fp32 copy
                 with torch.no_grad():
                     buf.copy_(w.t())

@@ -76,6 +76,7 @@ def _i64(t):
 
 
 _TOWERS_FIRST = os.environ.get("AVLEN_TOWERS_FIRST", "1") != "0"
+_FOLD_TEXT = os.environ.get("AVLEN_FOLD_TEXT", "1") != "0"     # A/B knob: text_projection folded into dialog_layer in the rollout's text graph
 _SPLIT = True        # pi_l's captured forward is cut in two around the text embedding (decided by measurement: DESIGN section 3)
 
 
@@ -1089,28 +1090,44 @@ class AudioNavDialogNet(_SMTBase):
         eng["clip"] = E.clip_view(self.clip, eng["flat"], packed, fmt=eng.get("clip_fmt", 0))
         eng["dialog_layer"] = E.linear_view(self.dialog_layer.weight, self.dialog_layer.bias, eng["flat"], fmt=eng.get("clip_fmt", 0))
         eng["dialog"] = E.dialog_view(self.dialog_state_encoder, eng["flat"], lo=packed.lo)
+        # rollout text graph in the 16-bit modes: dialog_layer(ln_final(x) @ text_projection) as ONE few-row GEMM on the folded weight
+        # (policy.py:847-849 puts nothing between the two); the tower then stops at ln_final (struct copy without the projection)
+        if eng["clip"].wstream and _FOLD_TEXT:
+            eng["dialog_fold"] = packed.proj_fold(self.dialog_layer, self.clip.text_projection, fmt=eng.get("clip_fmt", 0))
+            nop = L.ClipText.from_buffer_copy(eng["clip"])
+            nop.text_proj, nop.text_proj_t = None, None
+            eng["clip_noproj"] = nop
 
-    def encode_text(self, pol, tokens):
+    def encode_text(self, pol, tokens, project=True):
+        """project=False (needs eng["clip_noproj"]): ln_final(EOT rows), (B, width), for the folded dialog_layer."""
         eng = pol._engine()
         tok = _i64(tokens)
         B = tok.shape[0]
-        out = torch.empty(B, self.clip.text_projection.shape[1], device=tok.device)
-        nb = L.lib.avlen_clip_text_workspace_bytes(C.byref(eng["clip"]), B)
+        clip = eng["clip"] if project else eng["clip_noproj"]
+        out = torch.empty(B, self.clip.text_projection.shape[1 if project else 0], device=tok.device)
+        nb = L.lib.avlen_clip_text_workspace_bytes(C.byref(clip), B)
         ws = pol._ws.get("clip", nb, tok.device)
-        L.call("avlen_clip_text_fwd", C.byref(eng["clip"]), E.P(tok), E.P(out), B, pol.prec_of("clip"), E.P(ws), nb, L.stream())
+        L.call("avlen_clip_text_fwd", C.byref(clip), E.P(tok), E.P(out), B, pol.prec_of("clip"), E.P(ws), nb, L.stream())
         return out
+
+    def _text_to_dialog(self, pol, tokens):
+        """tokens -> dialog_layer(CLIP.encode_text(tokens)) (policy.py:847-849); folded form in the 16-bit modes."""
+        eng = pol._engine()
+        if "dialog_fold" in eng and pol.prec_of("clip") in (L.PREC_BF16, L.PREC_FP16):
+            return self._dialog_embed(pol, self.encode_text(pol, tokens, project=False), eng["dialog_fold"])
+        return self._dialog_embed(pol, self.encode_text(pol, tokens))
 
     text_encoder_override = None      # tests: callable(tokens)->(B,512) replacing the CLIP tower (unpinned, SURVEY §8c)
     _text = None                      # (tokens ptr, shape, static embedding, event) of the last prefetch_text
     _text_key = None                  # part of the graph key: a forward captured against the static embedding buffer
     _text_read = None                 # event: the last forward that read the static embedding has been enqueued up to here
 
-    def _dialog_embed(self, pol, e):
-        """dialog_layer(CLIP embedding) (policy.py:849): (B, 512) -> (B, d)."""
+    def _dialog_embed(self, pol, e, dl=None):
+        """dialog_layer(CLIP embedding) (policy.py:849): (B, 512) -> (B, d).  dl: another Linear view (the folded one)."""
         eng = pol._engine()
         B, d, dev, st = e.shape[0], self._hidden_size, e.device, L.stream()
         d_emb = torch.empty(B, d, device=dev)
-        dl = eng["dialog_layer"]
+        dl = eng["dialog_layer"] if dl is None else dl
         pc = pol.prec_of("clip")
         if pc in (L.PREC_BF16, L.PREC_FP16) and dl.w16:
             fmt = 1 if pc == L.PREC_FP16 else 0
@@ -1145,7 +1162,7 @@ class AudioNavDialogNet(_SMTBase):
             if g is None:
                 pol._engine()
                 # the graph ends with dialog_layer: what the forward picks up is the (B, d) dialog embedding
-                g = pol._graphs[key] = _Graph(pol, lambda t: self._dialog_embed(pol, self.encode_text(pol, t)), [tok])
+                g = pol._graphs[key] = _Graph(pol, lambda t: self._text_to_dialog(pol, t), [tok])
             emb = g([tok])
             ev = torch.cuda.Event()
             ev.record(stream)
@@ -1170,15 +1187,18 @@ class AudioNavDialogNet(_SMTBase):
         fork = torch.cuda.is_current_stream_capturing()
         s_txt = pol.side_streams()[2] if fork else cur
         pre = self._text_ready(all_dialog)
+        embedded = pre is not None                       # e is already dialog_layer(embedding)
         if pre is not None:                              # embedding enqueued earlier by prefetch_text (static buffer)
             e = pre
         elif all_dialog is not None:                     # frozen CLIP text tower: a parallel branch under capture
             if fork:
                 s_txt.wait_stream(cur)
             with torch.cuda.stream(s_txt):
-                e = (self.text_encoder_override(all_dialog) if self.text_encoder_override is not None
-                     else self.encode_text(pol, all_dialog))
-                e = _f32(e)
+                if self.text_encoder_override is not None:
+                    e = _f32(self.text_encoder_override(all_dialog))
+                else:                                    # the same arithmetic as the prefetched text graph (folded in the 16-bit modes)
+                    e = self._text_to_dialog(pol, all_dialog)
+                    embedded = True
         feats, goal = self.features(pol, observations, prev_actions)
         x_att, _ = self.smt(pol, feats, goal, ext_memory, ext_memory_masks)
         B, d = x_att.shape
@@ -1191,7 +1211,7 @@ class AudioNavDialogNet(_SMTBase):
             if fork and pre is not None and getattr(pol, "_capture", None) is not None and _SPLIT:
                 pol._capture.split()                     # everything above does not need the text embedding
             # prefetch_text already applied dialog_layer inside the text graph; otherwise do it here
-            d_emb = e if pre is not None else self._dialog_embed(pol, e)
+            d_emb = e if embedded else self._dialog_embed(pol, e)
         memd = _f32(ext_memory_dialog)
         mk = _f32(ext_memory_masks)
         M = memd.shape[0]

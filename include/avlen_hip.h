@@ -82,7 +82,9 @@ typedef struct { avlen_affine ln1, ln2; avlen_mha attn; avlen_linear fc, proj; a
  * with it the 16-bit forward runs the blocks as ONE sequence-stationary launch (csrc/clip_tower.hip). */
 typedef struct { float* tok_emb; float* pos_emb; avlen_clip_block block[12]; avlen_affine ln_final;
                  float* text_proj; int vocab, ctx, width, heads, layers, out_dim, half_fmt; void* wstream;
-                 float* text_proj_t; } avlen_clip_text;     /* text_proj_t: optional [out][width] copy (few-row projection: one wave per column) */
+                 float* text_proj_t; } avlen_clip_text;     /* text_proj_t: optional [out][width] copy (few-row projection: one wave per column).
+                                                               text_proj NULL (one-launch tower only): out = ln_final(EOT rows), (B, width) --
+                                                               for a caller that folded the projection into the Linear behind it */
 /* nn.GRU(in, H, 1 layer) (av_nav/models/rnn_state_encoder.py:36-40): w_ih[3H][in], w_hh[3H][H], r|z|n. */
 typedef struct { float* w_ih; float* w_hh; float* b_ih; float* b_hh; int in_f, hidden; } avlen_gru;
 /* CategoricalNet + CriticHead (+ CriticHead2) of one policy (policy.py:46-61, 279-297). */
