@@ -39,7 +39,8 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero_page_ch[4096];     /
 namespace {
 
 constexpr int D = 256;            // feature width of every step's output
-constexpr int KMAX = 320;         // widest input (pi_q fusion: features + pose encoding = 320)
+constexpr int KMAX = 352;         // widest input (pi_q fusion: features + pose encoding = 320; with the distractor's category input 341 -> 344).
+constexpr int KMAX64 = 320;       // ... of a plain-bf16 program: its k blocks are 64 wide and the activation image is zero-filled to whole blocks
 constexpr int XLD = KMAX + 8;     // LDS row stride (elements) of the bf16 activation image
 constexpr int NTH = 1024, NW = 16;
 constexpr int TILE_BYTES = D * 128;            // one ring stage: [256 features][64 k] bf16
@@ -50,7 +51,7 @@ constexpr int NIMG = 2;           // activation images (a third operand is parke
 // weight stream carries [16][32] hi + [16][32] lo per ring stage (the same 2 KiB) and a k-step is three MFMAs.
 constexpr int XS_BYTES = NIMG * 16 * XLD * 2;
 constexpr int RED_BYTES = NW * 16 * 2 * 4;
-constexpr int MAX_LIN = 24, MAX_PAR = 32;      // Linear steps / 256-float parameter vectors per program
+constexpr int MAX_LIN = 22, MAX_PAR = 32;      // Linear steps (largest program: 16) / 256-float parameter vectors per program
 constexpr int ATT_BYTES = NW * 16 * 4 * 4;     // attention score partials [wave][row][key]
 
 // what the kernel reads: compiled from avlen_chain on the host
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(NTH) void chain_kernel(DevProg kprog, int B) {
         bar();
         const bf16* src = (const bf16*)op.p0;
         const bf16* srcl = (const bf16*)op.p1;         // X3: the low plane (same layout)
-        const int cpr = ((op.k + 63) >> 6) << 3;       // 16-byte chunks per row, zero-filled up to a whole 64-wide k block
+        const int cpr = X3 ? ((op.k + 31) >> 5) << 2 : ((op.k + 63) >> 6) << 3;   // 16-byte chunks per row, zero-filled up to a whole k block (32 / 64 wide)
         for (int i = tid; i < RB * cpr; i += NTH) {
           int rr = i / cpr, ch = i - rr * cpr;
           int gr = blockIdx.x * RB + rr;
@@ -402,7 +403,7 @@ int avlen_chain_run(const avlen_chain* prog, int B, hipStream_t stream, int x3) 
       return AVLEN_ERR_ARG;
     if (o.kind == AVLEN_CH_ADD_PE && (!o.p0 || !o.p1 || o.k < 1)) return AVLEN_ERR_ARG;
     if (o.kind == AVLEN_CH_LINEAR) {
-      if (o.k % 8 || o.k > KMAX || o.k < 8 || o.ld < o.k || o.ld % 8 || !o.p0 || dp.n_lin >= MAX_LIN) return AVLEN_ERR_ARG;
+      if (o.k % 8 || o.k > (x3 ? KMAX : KMAX64) || o.k < 8 || o.ld < o.k || o.ld % 8 || !o.p0 || dp.n_lin >= MAX_LIN) return AVLEN_ERR_ARG;
       if (x3 && !o.p2) return AVLEN_ERR_ARG;
       dp.lin[dp.n_lin++] = DevLin{(const char*)o.p0, (const char*)o.p2, o.ld, x3 ? (o.k + 31) >> 5 : (o.k + 63) >> 6, o.k, 0};
       if (o.p1) {
@@ -413,7 +414,7 @@ int avlen_chain_run(const avlen_chain* prog, int B, hipStream_t stream, int x3) 
       if (!o.p0 || !o.p1 || dp.n_par + 2 > MAX_PAR || (((uintptr_t)o.p0 | (uintptr_t)o.p1) & 15)) return AVLEN_ERR_ARG;
       d.par = dp.n_par; dp.par_src[dp.n_par++] = (const float*)o.p0; dp.par_src[dp.n_par++] = (const float*)o.p1;
     } else if (o.kind == AVLEN_CH_LOAD_X16) {
-      if (o.k % 8 || o.k > KMAX || o.ld % 8 || (x3 && !o.p1)) return AVLEN_ERR_ARG;
+      if (o.k % 8 || o.k > (x3 ? KMAX : KMAX64) || o.ld % 8 || (x3 && !o.p1)) return AVLEN_ERR_ARG;
     }
   }
   static unsigned long long done0 = 0, done1 = 0;

@@ -526,7 +526,7 @@ struct ChainB {
     o.p0 = (const char*)L.w16 + (size_t)r0 * L.ld16 * 2; o.p1 = L.b ? L.b + r0 : nullptr;
     o.p2 = L.w16lo ? (const char*)L.w16lo + (size_t)r0 * L.ld16 * 2 : nullptr;
     o.k = L.ld16; o.ld = L.ld16; o.act = act; o.res = res; o.buf = buf; o.out_buf = out_buf;
-    if (!L.w16 || (L.ld16 % 8) || L.ld16 > 320 || L.out_f < r0 + 256 || (x3 && !L.w16lo)) ok = false;
+    if (!L.w16 || (L.ld16 % 8) || L.ld16 > (x3 ? 352 : 320) || L.out_f < r0 + 256 || (x3 && !L.w16lo)) ok = false;    // chain.hip: KMAX / KMAX64
   }
   void ln(const avlen_affine& a, int out_buf) { auto& o = next(AVLEN_CH_LAYERNORM); o.p0 = a.g; o.p1 = a.b; o.out_buf = out_buf; }
   void save(int slot = 0) { auto& o = next(AVLEN_CH_SAVE); o.res = slot; }
