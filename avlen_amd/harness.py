@@ -47,6 +47,8 @@ class Workload:
         # and so ran after the text tower it should have overlapped; behind pi_q it starts at 0.68 ms and only the dialog half is
         # left when the text embedding arrives: 30.3 k -> 33.2 k env-steps/s (kernel trace of a step: DESIGN section 0)
         self._l_main = os.environ.get("AVLEN_L_STREAM", "main") == "main"
+        self._views_ahead = os.environ.get("AVLEN_VIEWS_AHEAD", "1") != "0"       # A/B knob
+        self._next_views = None
         self._text_after = os.environ.get("AVLEN_TEXT_AHEAD", "1") == "2"     # 2: ordered after the current stream (debug)
         # 1: launch it BEFORE pi_q's graph -- measured slower (22.8k vs 27.5k env-steps/s): the GEMM blocks that get the CUs first
         # squeeze the towers; launched second, the text tower fills the gaps the memory-bound tower kernels leave
@@ -176,6 +178,10 @@ class Workload:
             if self.pi_l is not None:
                 self.pi_l.prefetch_act_dialog(obs, h, prev, v["masks_vln"], em_vln, em_dlg, v["em_vln_masks"], v["dialog"],
                                               v["astep"], stream=None if self._l_main else self._side[1])
+        if self.launch_ahead and self._views_ahead and t + 1 < self.T:
+            # the host is about to wait for pi_q's probabilities: slice the NEXT step's views now (fresh tensor objects every step,
+            # as the trainer makes them; only the moment moves off the path between insert and the next forward's launch)
+            self._next_views = (t + 1, self._step_views(t + 1))
         values, unct, a_opt, lp_opt, h, row_opt, probs_opt = self.pi_q.act_option(
             obs, h, prev, v["masks"], em_opt, em_masks, v["qs"], v["lqi"])
         dg = ro.em_dim_goal
@@ -197,7 +203,9 @@ class Workload:
 
     def rollout_step(self, return_outs=False):
         ro, t = self.rollouts, self.rollouts.step
-        v = self._step_views(t)
+        nv = self._next_views
+        self._next_views = None
+        v = nv[1] if nv is not None and nv[0] == t else self._step_views(t)
         o = self._forward_all(ro, v, t)
         a_opt, actions = o["a_q"], o["a_q"]
         if self.pi_g is not None:
