@@ -153,7 +153,7 @@ __global__ __launch_bounds__(1024) void gn_any16_kernel(const float* __restrict_
                                                        const float* __restrict__ beta, const __bf16* __restrict__ res,
                                                        __bf16* __restrict__ y, int HW, int C, int G, int relu, float eps, int f16) {
   __shared__ float s_sum[128], s_sq[128], s_scale[128], s_shift[128];
-  __shared__ float part[2][1024][4];                   // per-thread partials, reduced in a FIXED order (bit-reproducible)
+  __shared__ float part[2][16][128];                   // per-wave channel sums; every reduction below runs in a FIXED order (bit-reproducible)
   const int b = blockIdx.x, tid = threadIdx.x;
   const float* xb = x + (long)b * HW * C;
   const long n4 = (long)HW * C / 4;
@@ -164,12 +164,26 @@ __global__ __launch_bounds__(1024) void gn_any16_kernel(const float* __restrict_
     a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
     q[0] += v.x * v.x; q[1] += v.y * v.y; q[2] += v.z * v.z; q[3] += v.w * v.w;
   }
+  // lanes l and l + C/4 (+ 2C/4 ...) of a wave own the same 4 channels (64 % (C/4) == 0 for C <= 128, C % 16 == 0): butterfly
+  // over those lane bits, then one row of C sums per wave -- a serial walk over 1024 per-thread partials per channel cost
+  // 10-17 us per launch for a tensor worth 2 us (20 launches per step of the BeliefPredictor)
+  const int lane = tid & 63, wv = tid >> 6, per = C >> 2;          // per: lanes that cover all channels once (4 .. 32)
 #pragma unroll
-  for (int i = 0; i < 4; i++) { part[0][tid][i] = a[i]; part[1][tid][i] = q[i]; }
+  for (int o = 32; o >= 4; o >>= 1) {
+    if (o >= per) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) { a[i] += __shfl_xor(a[i], o, 64); q[i] += __shfl_xor(q[i], o, 64); }
+    }
+  }
+  if (lane < per) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) { part[0][wv][lane * 4 + i] = a[i]; part[1][wv][lane * 4 + i] = q[i]; }
+  }
   __syncthreads();
-  if (tid < C) {                                      // channel tid: owners are threads (tid/4) + k*(C/4), component tid%4
+  if (tid < C) {
     float s1 = 0.f, s2 = 0.f;
-    for (int u = tid >> 2; u < 1024; u += C >> 2) { s1 += part[0][u][tid & 3]; s2 += part[1][u][tid & 3]; }
+#pragma unroll
+    for (int w = 0; w < 16; w++) { s1 += part[0][w][tid]; s2 += part[1][w][tid]; }
     s_sum[tid] = s1; s_sq[tid] = s2;
   }
   __syncthreads();
