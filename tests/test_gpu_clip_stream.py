@@ -57,3 +57,29 @@ def test_stream_tower_matches_the_gemm_chain_tower(mode):
     print(f"{mode}: |chain - fp32| {e_chain:.3e}  |stream - fp32| {e_stream:.3e}  |stream - chain| {float((out - chain).abs().max()):.3e}  (max |ref| {scale:.3f})")
     tol = (1e-2 if mode == "bf16x3" else 6e-2) * max(1.0, scale)     # fp16 / bf16 operands through 12 blocks
     assert e_stream < tol and e_stream < 2.0 * e_chain + 1e-3
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
+def test_folded_dialog_layer_matches_the_two_step_form_and_follows_weight_updates(mode):
+    """The rollout's text graph folds text_projection into dialog_layer (policy.py:847-849: dialog_layer(encode_text(x)), nothing
+    in between): folded vs two-step on the same policy, against the fp32 policy, and again after dialog_layer moved (an optimiser
+    step marks the parameters changed: the folded weight is derived data and must follow)."""
+    gen = torch.Generator().manual_seed(5)
+    tok = _tokens(20, gen)
+    ref_pol = _policy("fp32", False)
+    pol = _policy(mode, True, ref_pol.state_dict())
+    assert "dialog_fold" in pol._engine()
+    for rnd in range(2):
+        ref = ref_pol.net._dialog_embed(ref_pol, ref_pol.net.encode_text(ref_pol, tok)).clone()
+        two = pol.net._dialog_embed(pol, pol.net.encode_text(pol, tok)).clone()
+        fold = pol.net._text_to_dialog(pol, tok).clone()
+        torch.cuda.synchronize()
+        scale = max(1.0, float(ref.abs().max()))
+        e_two, e_fold = float((two - ref).abs().max()), float((fold - ref).abs().max())
+        print(f"{mode} round {rnd}: |two-step - fp32| {e_two:.3e}  |folded - fp32| {e_fold:.3e}  (max |ref| {scale:.3f})")
+        assert e_fold < (1e-2 if mode == "bf16x3" else 6e-2) * scale and e_fold < 2.0 * e_two + 2e-3
+        with torch.no_grad():                              # "training": dialog_layer moves in both policies
+            for p_ in (ref_pol, pol):
+                p_.net.dialog_layer.weight.mul_(0.5).add_(0.01)
+                p_.net.dialog_layer.bias.add_(0.1)
+                p_.mark_params_changed()
