@@ -185,6 +185,8 @@ SIGNATURES = {
     "avlen_dialog_fwd": (i32, [C.POINTER(Dialog), vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, sz, vp]),
     "avlen_clip_text_workspace_bytes": (sz, [C.POINTER(ClipText), i32]),
     "avlen_clip_text_fwd": (i32, [C.POINTER(ClipText), vp, vp, i32, i32, vp, sz, vp]),
+    "avlen_clip_text_cache_bytes": (sz, [C.POINTER(ClipText), i32]),
+    "avlen_clip_text_cached_fwd": (i32, [C.POINTER(ClipText), vp, vp, sz, vp, i32, i32, vp, sz, vp]),
     "avlen_clip_stream_bytes": (sz, [C.POINTER(ClipText)]),
     "avlen_clip_pack_stream": (i32, [C.POINTER(ClipText), vp, i32, vp]),
     "avlen_gru_workspace_bytes": (sz, [C.POINTER(Gru), i32, i32]),

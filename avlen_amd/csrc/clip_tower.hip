@@ -48,7 +48,13 @@ struct ClipArgs {
   long long* prof;                                          // lab builds (AVLEN_CT_PROF): per-workgroup phase cycle totals [2 B][8]
   unsigned* flags; char* xchg; int B;                       // K / V hand-off of the 5-tile dialogs: flag word per (dialog, column half), slots
   unsigned* xflags; char* xslots;                           // partial-sum exchange between the two column halves: flag per workgroup, 2 slots each
+  // device-side work list (memoised tower, avlen_clip_text_cached_fwd): pair i < *count carries dialog row_idx[i]; null = all B rows
+  const int* row_idx; const int* count;
 };
+// A hand-off that never arrives (partner workgroup lost): the dialog's output row is poisoned with NaN -- a stale or garbage
+// embedding would flow into the rollout unnoticed (the GRU sequence kernels do the same, train_gru.hip)
+#define CT_GIVE_UP() do { if (threadIdx.x < 128) *reinterpret_cast<float4*>(a.E + (long)b * 512 + 4 * threadIdx.x) = \
+    make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")); return; } while (0)
 #ifdef AVLEN_CT_PROF
 #define CT_T0() long long ct_t = __builtin_amdgcn_s_memtime(); long long ct_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define CT_PH(k) do { const long long n_ = __builtin_amdgcn_s_memtime(); ct_acc[k] += n_ - ct_t; ct_t = n_; } while (0)
@@ -416,7 +422,7 @@ __device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, co
       }
       lds_barrier();
       if (PUB) clip_publish_kv(a, lds, 2 * b + h, layer * 2 + jp, tid);
-      if (I0 > 0) { if (!clip_fetch_kv(a, lds, 2 * b + h, layer * 2 + jp, tid)) return; }
+      if (I0 > 0) { if (!clip_fetch_kv(a, lds, 2 * b + h, layer * 2 + jp, tid)) CT_GIVE_UP(); }
       CT_PH(1);
       // ---- causal attention: units (head of the pair, 16-query tile), one per wave and round (two units of a wave in one basic block
       // -- for the scheduler to interleave -- spilled at 5 tiles and ran slower)
@@ -457,7 +463,7 @@ __device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, co
 #pragma unroll
         for (int j = 0; j < 4; j++) { xr[i][j][0] += bo[j].x; xr[i][j][1] += bo[j].y; xr[i][j][2] += bo[j].z; xr[i][j][3] += bo[j].w; }
     }
-    if (!clip_exchange<NT>(a, lds, xr, unit, 2u * layer + 1u, tid)) return;
+    if (!clip_exchange<NT>(a, lds, xr, unit, 2u * layer + 1u, tid)) CT_GIVE_UP();
     // ======================================================= MLP, 256 hidden units at a time =======================================================
     layer_norm(P.ln2g, P.ln2b);
     CT_PH(4);
@@ -541,7 +547,7 @@ __device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, co
 #pragma unroll
         for (int j = 0; j < 4; j++) { xr[i][j][0] += bp[j].x; xr[i][j][1] += bp[j].y; xr[i][j][2] += bp[j].z; xr[i][j][3] += bp[j].w; }
     }
-    if (!clip_exchange<NT>(a, lds, xr, unit, 2u * layer + 2u, tid)) return;
+    if (!clip_exchange<NT>(a, lds, xr, unit, 2u * layer + 2u, tid)) CT_GIVE_UP();
   }
   // ---- the EOT row of the residual stream (ln_final and the projection follow as their own small launches)
 #pragma unroll
@@ -576,7 +582,12 @@ __global__ __launch_bounds__(CT_TH) void clip_tower_kernel(ClipArgs a) {
   // workgroup waits for (its column partner, the first row half's K / V) has a smaller or neighbouring id and never waits for it.
   const int id = (int)blockIdx.x, h = (id >> 3) & 1, p = (id >> 4) * 8 + (id & 7);
   if (p >= 2 * a.B) return;
-  const int row_half = p >= a.B ? 1 : 0, b = p - row_half * a.B, ctx = a.ctx;
+  const int row_half = p >= a.B ? 1 : 0, ctx = a.ctx;
+  int b = p - row_half * a.B;
+  if (a.row_idx) {                                          // memoised tower: only the rows whose tokens changed (uniform loads)
+    if (b >= *a.count) return;
+    b = a.row_idx[b];
+  }
   const int unit = (b * 2 + row_half) * 2 + h;                // exchange partner: unit ^ 1
   const int64_t* __restrict__ tk = a.tokens + (long)b * ctx;
   // ---- live length: tokens up to the EOT (= first position of the largest id, as torch.argmax) -- nothing after it can reach
@@ -684,7 +695,7 @@ extern "C" int avlen_clip_pack_stream(const avlen_clip_text* p, void* dst, int f
 size_t avlen_clip_tower_stream_ws_bytes(int B) { return 16384 + (size_t)B * 2 * CT_SLOTS * CT_SLOT + (size_t)B * 4 * 2 * CT_XSLOT; }
 
 int avlen_clip_tower_stream_fwd(const avlen_clip_text* p, const int64_t* tokens, float* E, int B, int f16, void* ws, size_t ws_bytes,
-                                hipStream_t st) {
+                                hipStream_t st, const int* row_idx, const int* count) {
   if (!clip_stream_shape_ok(p) || !p->wstream || B <= 0 || B > 1024 || !ws || ws_bytes < avlen_clip_tower_stream_ws_bytes(B)) return AVLEN_ERR_ARG;
   if (B > 512) return AVLEN_ERR_ARG;
   if (avlen_zero_bytes(ws, 16384, st) != AVLEN_OK) return AVLEN_ERR_LAUNCH;      // the flag words (own block at the workspace's start)
@@ -693,6 +704,7 @@ int avlen_clip_tower_stream_fwd(const avlen_clip_text* p, const int64_t* tokens,
   a.ctx = p->ctx; a.vocab = p->vocab; a.layers = p->layers; a.frags_per_wave = clip_frags_per_wave(p->layers);
   a.flags = (unsigned*)ws; a.xflags = a.flags + 2 * B; a.xchg = (char*)ws + 16384; a.B = B;
   a.xslots = a.xchg + (size_t)B * 2 * CT_SLOTS * CT_SLOT;
+  a.row_idx = row_idx; a.count = count;
   const int grid = ((2 * B + 7) / 8) * 16;
   for (int l = 0; l < p->layers; l++) {
     const avlen_clip_block& b = p->block[l];

@@ -1950,9 +1950,21 @@ static int clip_project(const avlen_clip_text* p, const float* E2, float* out, i
                     0, prec, sk, 0.f, gws, GEMM_SCRATCH, st);
 }
 
+// Largest batch one pass takes: the one-launch tower's flag block holds 6 words per dialog (clip_tower.hip) and the ragged
+// launch-per-GEMM path scans the EOT positions in one 1024-thread block; larger batches (PPO.update_dialog evaluates T * N rows,
+// ppo.py:99-154) run as consecutive passes over the same workspace -- same kernels, same per-row arithmetic.
+constexpr int CLIP_PASS_ROWS = 512;
 extern "C" int avlen_clip_text_fwd(const avlen_clip_text* p, const int64_t* tokens, float* out, int B, int prec,
                                    void* ws, size_t ws_bytes, hipStream_t st) {
   if (!p || B <= 0 || p->width % p->heads || ws_bytes < avlen_clip_text_workspace_bytes(p, B)) return AVLEN_ERR_WS;
+  if (B > CLIP_PASS_ROWS) {
+    const int od = p->text_proj ? p->out_dim : p->width;
+    for (int b0 = 0; b0 < B; b0 += CLIP_PASS_ROWS) {
+      const int nb = B - b0 < CLIP_PASS_ROWS ? B - b0 : CLIP_PASS_ROWS;
+      TRY(avlen_clip_text_fwd(p, tokens + (long)b0 * p->ctx, out + (long)b0 * od, nb, prec, ws, ws_bytes, st));
+    }
+    return AVLEN_OK;
+  }
   const int wd = p->width, H = p->heads, D = wd / H, ctx = p->ctx;
   const long R = (long)B * ctx;
   WsBump w(ws, ws_bytes);
@@ -2086,6 +2098,97 @@ extern "C" int avlen_clip_text_fwd(const avlen_clip_text* p, const int64_t* toke
   TRY(avlen_launch_status());
   TRY(avlen_layernorm_fwd(E, nullptr, p->ln_final.g, p->ln_final.b, E2, nullptr, nullptr, B, wd, 1e-5f, st));
   return clip_project(p, E2, out, B, prec, gws, st);
+}
+
+// ---- memoised tower: the text tower is frozen and a dialog is constant for NUM_DIALOG_STEPS steps, all-zero for an env without a
+// query (ppo_trainer.py:347, 582-586) -- only rows whose tokens differ from the previous call's go through the 12 blocks.  The memo
+// is keyed on the CONTENT of a row (its 77 tokens), not on the env it belongs to: a row that compares equal holds, by construction,
+// the embedding of exactly these tokens, so shrinking / reordering the batch (pop_at) cannot make it stale; only a weight change
+// does (the caller zero-fills the state block: valid = 0).
+// State block: [valid | count | zcount | pad to 256 B] [tokens of the last call (B + 1) x ctx, row B all zero] [E (B + 1) x width:
+// residual row at the EOT token, BEFORE ln_final] [work list (B + 1)] [zero-row list (B + 1)].  Row B is the all-zero dialog: every
+// all-zero row of the batch copies its E instead of running the tower.
+namespace {
+struct TextCache { int* hdr; int64_t* prev; float* E; int* idx; int* zidx; };
+inline size_t text_cache_bytes(int B, int ctx, int wd) {
+  return 256 + align_up((size_t)(B + 1) * ctx * 8, 256) + align_up((size_t)(B + 1) * wd * 4, 256) + 2 * align_up((size_t)(B + 1) * 4, 256);
+}
+inline TextCache text_cache_map(void* state, int B, int ctx, int wd) {
+  TextCache c;
+  char* s = (char*)state;
+  c.hdr = (int*)s; s += 256;
+  c.prev = (int64_t*)s; s += align_up((size_t)(B + 1) * ctx * 8, 256);
+  c.E = (float*)s; s += align_up((size_t)(B + 1) * wd * 4, 256);
+  c.idx = (int*)s; s += align_up((size_t)(B + 1) * 4, 256);
+  c.zidx = (int*)s;
+  return c;
+}
+// one block; wave w compares rows w, w + 16, ... (lane k: tokens k and k + 64); ordered compaction by thread 0 -> the work list
+// is in row order whatever the hardware does (deterministic launch shape)
+__global__ __launch_bounds__(1024) void text_cache_detect_kernel(const int64_t* __restrict__ tokens, int64_t* __restrict__ prev,
+                                                                 int* __restrict__ hdr, int* __restrict__ idx, int* __restrict__ zidx,
+                                                                 int B, int ctx) {
+  __shared__ int flag[1024];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int valid = hdr[0];
+  for (int r = wave; r <= B; r += 16) {
+    bool diff = false, nz = false;
+    for (int k = lane; k < ctx; k += 64) {
+      const int64_t v = r < B ? tokens[(long)r * ctx + k] : 0;
+      const int64_t o = prev[(long)r * ctx + k];
+      diff = diff || v != o; nz = nz || v != 0;
+      prev[(long)r * ctx + k] = v;
+    }
+    const bool d = __any(diff) || !valid, z = !__any(nz);
+    if (lane == 0) flag[r] = d ? ((z && r < B) ? 2 : 1) : 0;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int n = 0, zc = 0;
+    for (int r = 0; r <= B; r++) {
+      if (flag[r] == 1) idx[n++] = r;
+      else if (flag[r] == 2) zidx[zc++] = r;
+    }
+    hdr[1] = n; hdr[2] = zc; hdr[0] = 1;
+  }
+}
+__global__ __launch_bounds__(128) void text_cache_zero_rows_kernel(float* __restrict__ E, const int* __restrict__ hdr,
+                                                                   const int* __restrict__ zidx, int B, int wd) {
+  if ((int)blockIdx.x >= hdr[2]) return;
+  const int r = zidx[blockIdx.x];
+  for (int c = threadIdx.x * 4; c < wd; c += 512)
+    *reinterpret_cast<float4*>(E + (long)r * wd + c) = *reinterpret_cast<const float4*>(E + (long)B * wd + c);
+}
+}  // namespace
+extern "C" size_t avlen_clip_text_cache_bytes(const avlen_clip_text* p, int B) {
+  return p && B > 0 ? text_cache_bytes(B, p->ctx, p->width) : 0;
+}
+extern "C" int avlen_clip_text_cached_fwd(const avlen_clip_text* p, const int64_t* tokens, void* state, size_t state_bytes, float* out,
+                                          int B, int prec, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!p || !tokens || !state || !out || B <= 0) return AVLEN_ERR_ARG;
+  const int wd = p->width;
+  const bool f16 = prec == AVLEN_PREC_FP16;
+  bool fast = ((prec == AVLEN_PREC_BF16 && p->half_fmt == 0) || (f16 && p->half_fmt == 1)) && B + 1 <= CLIP_PASS_ROWS &&
+              p->wstream && avlen_clip_stream_bytes(p);
+  // the memo exists for the one-launch tower (16-bit modes, <= 511 rows); anything else computes every row
+  if (!fast) return avlen_clip_text_fwd(p, tokens, out, B, prec, ws, ws_bytes, st);
+  if (state_bytes < text_cache_bytes(B, p->ctx, wd) || ws_bytes < avlen_clip_text_workspace_bytes(p, B + 1)) return AVLEN_ERR_WS;
+  const TextCache c = text_cache_map(state, B, p->ctx, wd);
+  hipLaunchKernelGGL(text_cache_detect_kernel, dim3(1), dim3(1024), 0, st, tokens, c.prev, c.hdr, c.idx, c.zidx, B, p->ctx);
+  TRY(avlen_launch_status());
+  WsBump w(ws, ws_bytes);
+  float* E2 = w.take<float>((size_t)B * wd);
+  void* gws = w.take<char>(GEMM_SCRATCH);
+  const size_t sb = avlen_clip_tower_stream_ws_bytes(B + 1);
+  void* sws = w.take<char>(sb);
+  if (!w.ok()) return AVLEN_ERR_WS;
+  TRY(avlen_clip_tower_stream_fwd(p, c.prev, c.E, B + 1, f16 ? 1 : 0, sws, sb, st, c.idx, c.hdr + 1));
+  hipLaunchKernelGGL(text_cache_zero_rows_kernel, dim3(B), dim3(128), 0, st, c.E, c.hdr, c.zidx, B, wd);
+  TRY(avlen_launch_status());
+  if (!p->text_proj)
+    return avlen_layernorm_fwd(c.E, nullptr, p->ln_final.g, p->ln_final.b, out, nullptr, nullptr, B, wd, 1e-5f, st);
+  TRY(avlen_layernorm_fwd(c.E, nullptr, p->ln_final.g, p->ln_final.b, E2, nullptr, nullptr, B, wd, 1e-5f, st));
+  return clip_project(p, E2, out, B, f16 ? AVLEN_PREC_BF16X3 : prec, gws, st);
 }
 
 // =====================================================================================================

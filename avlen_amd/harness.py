@@ -27,12 +27,26 @@ def sinusoid_table(n, d):
 
 
 class Workload:
-    def __init__(self, num_envs, num_steps=150, spectrogram=(257, 101, 2), precision="bf16", pretraining=True,
+    def __init__(self, num_envs, num_steps=150, spectrogram=(257, 101, 2), precision="bf16x3", pretraining=True,
                  em_capacity=150, ppo_epoch=2, num_mini_batch=2, device="cuda", seed=0, sampling="host",
                  with_dialog_policy=True, with_goal_policy=True, use_graphs=True, share_encoders=True, weight_seed=0,
-                 launch_ahead=True, belief_predictor=False, cached_views=False, distractor=False):
+                 launch_ahead=True, belief_predictor=False, cached_views=False, distractor=False,
+                 dialog_tokens="after_option", dialog_process="fresh"):
         self.N, self.T, self.dev = num_envs, num_steps, torch.device(device)
         self.spec = spectrogram
+        # WHEN the step's dialog tokens exist.  "after_option" (default) = the reference's data flow: `current_dialog` and
+        # `agent_step` are written by the host loop that follows `act_option` (new query -> Speaker -> clip.tokenize,
+        # ppo_trainer.py:347, 449-593), so the text tower and the dialog half of pi_l are issued only after pi_q's action has been
+        # sampled; pi_g and pi_l's state-encoder half stay ahead.  "ahead" = the tokens are known at the start of the step (text
+        # tower launched beside the visual towers): a synthetic ordering the reference trainer cannot provide.
+        assert dialog_tokens in ("after_option", "ahead") and dialog_process in ("fresh", "reference")
+        self.dialog_tokens = dialog_tokens
+        # WHAT the tokens are.  "fresh": every env presents a new random dialog every step (SURVEY 8d's synthetic input; the memo of
+        # the text tower never hits).  "reference": the trainer's dialog process -- an env that is not in a dialog and samples
+        # a_q == 1 gets a new dialog, keeps it for NUM_DIALOG_STEPS = 3 steps (agent_step 0, 1, 2), then leaves the dialog; every other
+        # env presents all-zero tokens (ppo_trainer.py:347, 463-469, 582-587, 763-765).  Needs the tokens after act_option.
+        self.dialog_process = dialog_process
+        assert dialog_process == "fresh" or dialog_tokens == "after_option"
         # enqueue all three policies' forwards before the first host-side sampling; pi_g and pi_l run on their own streams,
         # overlap on the GPU and hand their probabilities to the host as each finishes (3.13 -> 2.73 ms per step)
         self.launch_ahead = launch_ahead
@@ -140,6 +154,50 @@ class Workload:
         self._views = {}
         for k in self.rollouts.observations:
             self.rollouts.observations[k][0].copy_(self.sim[k][0])
+        if self.dialog_process == "reference":
+            # host-side query bookkeeping of the trainer (track_query[idx]: 'queried', 'step', 'dialog') + the two tensors it writes
+            self._dones_h = self.dones.cpu().numpy()
+            self._pool = toks.numpy()                                       # what Speaker + clip.tokenize would return
+            self._queried = torch.zeros(N, dtype=torch.bool).numpy()
+            self._qstep = torch.zeros(N, dtype=torch.int64).numpy()
+            self._qdialog = torch.zeros(N, 77, dtype=torch.int64).numpy()
+            self._cur_dialog_h = [torch.zeros(N, 77, dtype=torch.long, pin_memory=True) for _ in range(4)]
+            self._cur_astep_h = [torch.zeros(N, pin_memory=True) for _ in range(4)]
+            self._cur_dialog = torch.zeros(N, 77, dtype=torch.long, device=dev)     # `current_dialog` (ppo_trainer.py:347)
+            self._cur_astep = torch.zeros(N, device=dev)                            # `rollouts.agent_step[step]` (:590)
+            self._ring = 0
+            self.dialog_stats = {"steps": 0, "new_dialogs": 0, "active_rows": 0}
+
+    def _host_dialog_loop(self, t, a_q):
+        """ppo_trainer.py:463-469, 519-587 for the synthetic envs: returns after `current_dialog` / `agent_step` are on their way
+        to the device.  a_q: (N,) host int64."""
+        q, st = self._queried, self._qstep
+        if t > 0:                                         # :390-397: a new episode starts outside any dialog
+            ended = self._dones_h[t - 1] != 0
+            q[ended] = False
+            st[ended] = 0
+        new = (~q) & (a_q == 1)
+        q |= new
+        st[new] = 0
+        self._qdialog[new] = self._pool[t][new]
+        act = q & (st < 3)
+        self._ring = (self._ring + 1) % 4
+        dh, ah = self._cur_dialog_h[self._ring], self._cur_astep_h[self._ring]
+        dn, an = dh.numpy(), ah.numpy()
+        dn[:] = 0
+        an[:] = 0
+        dn[act] = self._qdialog[act]
+        an[act] = st[act]
+        st[act] += 1
+        self._cur_dialog.copy_(dh, non_blocking=True)
+        self._cur_astep.copy_(ah, non_blocking=True)
+        fin = q & (st >= 3)                               # :763-765 (after the env step): the dialog is over
+        q[fin] = False
+        st[fin] = 0
+        ds = self.dialog_stats
+        ds["steps"] += 1
+        ds["new_dialogs"] += int(new.sum())
+        ds["active_rows"] += int(act.sum())
 
     # -- one rollout step (ppo_trainer.py:375-391, 449, 608-636, 864-888) -----------------------------------
     def _step_views(self, t):
@@ -164,12 +222,17 @@ class Workload:
         obs, h, prev, em_masks = v["obs"], v["h"], v["prev"], v["em_masks"]
         em_opt, em_goal = ro.external_memory_option[:, t], ro.external_memory_goal[:, t]
         em_vln, em_dlg = ro.external_memory_vln[:, t], ro.external_memory_vln_dialog[:, t]
+        later = self.dialog_tokens == "after_option"
+        ref = self.dialog_process == "reference"
+        if ref:                                          # the tensors the host loop fills after act_option
+            v = dict(v, dialog=self._cur_dialog, astep=self._cur_astep)
         if self.launch_ahead:
-            if self.pi_l is not None and self.text_ahead and self._text_first:
+            ahead = self.pi_l is not None and self.text_ahead and not later
+            if ahead and self._text_first:
                 # the text tower needs only the tokens: it runs beside pi_q's graph (the towers) instead of after it
                 self.pi_l.prefetch_text(v["dialog"], self._side[2], after_current=self._text_after)
             self.pi_q.prefetch_act_option(obs, h, prev, v["masks"], em_opt, em_masks, v["qs"], v["lqi"])
-            if self.pi_l is not None and self.text_ahead and not self._text_first:
+            if ahead and not self._text_first:
                 self.pi_l.prefetch_text(v["dialog"], self._side[2], after_current=self._text_after)
             if self.pi_g is not None:
                 # pi_g shares pi_l's stream: both wait for pi_q's towers anyway, and a fourth busy stream ends up sharing a
@@ -177,13 +240,18 @@ class Workload:
                 self.pi_g.prefetch_act(obs, h, prev, v["masks"], em_goal, em_masks, stream=self._side[self._g_stream])
             if self.pi_l is not None:
                 self.pi_l.prefetch_act_dialog(obs, h, prev, v["masks_vln"], em_vln, em_dlg, v["em_vln_masks"], v["dialog"],
-                                              v["astep"], stream=None if self._l_main else self._side[1])
+                                              v["astep"], stream=None if self._l_main else self._side[1], dialog_later=later)
         if self.launch_ahead and self._views_ahead and t + 1 < self.T:
             # the host is about to wait for pi_q's probabilities: slice the NEXT step's views now (fresh tensor objects every step,
             # as the trainer makes them; only the moment moves off the path between insert and the next forward's launch)
             self._next_views = (t + 1, self._step_views(t + 1))
         values, unct, a_opt, lp_opt, h, row_opt, probs_opt = self.pi_q.act_option(
             obs, h, prev, v["masks"], em_opt, em_masks, v["qs"], v["lqi"])
+        if ref:                                          # ppo_trainer.py:463-593: the host loop between act_option and act / act_dialog
+            ah = self.pi_q.last_host_action
+            self._host_dialog_loop(t, (ah if ah is not None else a_opt.cpu()).view(-1).numpy())
+        if self.launch_ahead and later and self.pi_l is not None:
+            self.pi_l.dialog_ready()                     # current_dialog / agent_step hold this step's values from here on
         dg = ro.em_dim_goal
         o = dict(q_value=values, q_prob=probs_opt, a_q=a_opt, lp_q=lp_opt, h=h, row_q=row_opt, row_g=row_opt[:, :dg],
                  row_l=row_opt[:, :276], row_d=self.zero_dialog_feats, l_prob=self.zero_probs, a_g=a_opt, a_l=a_opt,
@@ -199,6 +267,7 @@ class Workload:
         """This workload's policies evaluated on ANOTHER workload's current state (its storage, memories, step inputs): the
         bf16-vs-fp32 comparison of bench.py and the harness-vs-oracle tests.  Nothing is stored."""
         t = other.rollouts.step if t is None else t
+        assert self.dialog_process == "fresh" and other.dialog_process == "fresh", "the reference dialog process is stateful per workload"
         return self._forward_all(other.rollouts, other._step_views(t), t)
 
     def rollout_step(self, return_outs=False):
@@ -219,9 +288,10 @@ class Workload:
         if return_outs:                             # graph outputs are overwritten by the next replay
             o = {k: (x.clone() if torch.is_tensor(x) else x) for k, x in o.items()}
             o["actions"] = actions.clone()
+        dlg, astep = (self._cur_dialog, self._cur_astep) if self.dialog_process == "reference" else (v["dialog"], v["astep"])
         ro.insert(v["nxt"], o["h"], actions, a_opt, o["lp_q"], o["q_value"], v["rew"], v["nd"], v["nd"], o["row_g"], o["row_q"],
-                  o["row_l"], o["row_d"], v["dialog"], self.o_action, self.o_mask, v["rl"], v["ucnt"], o["l_prob"], v["qs"],
-                  v["lqi"], v["astep"])
+                  o["row_l"], o["row_d"], dlg, self.o_action, self.o_mask, v["rl"], v["ucnt"], o["l_prob"], v["qs"],
+                  v["lqi"], astep)
         return o if return_outs else None
 
     def finite(self):

@@ -152,6 +152,17 @@ class _Graph:
                 return None
         return [(d, s_) for d, s_ in pairs if s_.numel() and s_.data_ptr() != d.data_ptr()]
 
+    def staging_pairs_any(self, args):
+        """(dst, src) refreshes of the static inputs from `args` (any source: L.multi_copy falls back to copy_ where needed)."""
+        pairs = []
+        for s, a in zip(self.static, args):
+            if torch.is_tensor(s):
+                if s.data_ptr() != a.data_ptr():
+                    pairs.append((s, a))
+            elif isinstance(s, dict) and s is not a:
+                pairs += [(s[k], a[k]) for k in s]
+        return pairs
+
     def replay_only(self):
         if self.graph2 is None:
             if self.between is not None:
@@ -244,7 +255,12 @@ def _graphed(pol, which, fn, args, mode=None):
             L.call("avlen_multi_copy", m.srcs, m.dsts, m.sizes, m.n, L.stream())
         g.between = getattr(pol, "_between", None)
         g.mid = getattr(pol, "_mid", None)
-        outs, heads = g.replay_only()
+        if pol._defer_second and g.graph2 is not None:
+            g.graph.replay()                             # the half that does not read the dialog; dialog_ready() replays the rest
+            pol._deferred = g
+            outs, heads = g.outs
+        else:
+            outs, heads = g.replay_only()
         outs = list(outs)
         if not keep_rnn:
             outs[1] = raw[1]
@@ -297,7 +313,13 @@ def _graphed(pol, which, fn, args, mode=None):
             while len(pol._memos) >= 512:
                 pol._memos.pop(next(iter(pol._memos)))
             pol._memos[mk] = mm
-    outs, heads = g(args)
+    if pol._defer_second and g.graph2 is not None:
+        L.multi_copy(g.staging_pairs_any(args))
+        g.graph.replay()
+        pol._deferred = g
+        outs, heads = g.outs
+    else:
+        outs, heads = g(args)
     outs = list(outs)
     if not keep_rnn:
         outs[1] = rnn
@@ -447,6 +469,11 @@ class Policy(nn.Module):
         self._capture = None                  # the _Graph being captured (lets a forward cut itself in two, see _Graph.split)
         self._between = None                  # host action between the two halves of a split graph
         self._mid = None                      # leader of an EncoderGroup: EncoderGroup.signal between the halves of its cut graph
+        self._defer_second = False            # prefetch_act_dialog(dialog_later=True): replay only the first half of the cut graph
+        self._deferred = None                 # ... the graph whose second half dialog_ready() replays
+        self._later = None                    # ... (which, arg key, outputs, stream, all_dialog, agent_step) of that prefetch
+        self.last_host_action = None          # sampling="host": pinned (B,1) int64 of the most recent draw
+        self._param_epoch = 0                 # bumped by mark_params_changed (derived state keyed on the weights: the text memo)
         self._pinned = {}
         self._eng = None
         self._ws = E.Workspaces()
@@ -477,6 +504,7 @@ class Policy(nn.Module):
     def mark_params_changed(self):
         """Call after modifying encoder weights in place (load_state_dict does it automatically)."""
         self._dirty = True
+        self._param_epoch += 1
 
     @property
     def prec(self):
@@ -562,6 +590,7 @@ class Policy(nn.Module):
                     pc = probs.cpu()                                    # sync; (B,A) floats
                 ah = self._host_action(B)
                 torch.argmax(pc / q, dim=-1, keepdim=True, out=ah)
+                self.last_host_action = ah               # the trainer's host loop reads the option actions (ppo_trainer.py:463)
                 action = self._result_bufs(which, B, dev)[0]
                 action.copy_(ah, non_blocking=True)
             else:
@@ -623,7 +652,9 @@ class Policy(nn.Module):
         txt = getattr(self.net, "_text", None)
         if which == "vln" and txt is not None:
             tok = net_args[7]
-            if tok is not None and txt[0] == tok.data_ptr() and txt[1] == tuple(tok.shape):
+            if self._defer_second:
+                pass                                     # the text graph is replayed by dialog_ready(), in stream order before half 2
+            elif tok is not None and txt[0] == tok.data_ptr() and txt[1] == tuple(tok.shape):
                 ev = txt[3]
                 if self.use_graphs:                      # the wait sits between the two halves of the captured forward
                     self._between = lambda: torch.cuda.current_stream().wait_event(ev)
@@ -650,7 +681,7 @@ class Policy(nn.Module):
                 self._mid = None
             if mode == "lead" and grp.ready_key != grp.key:
                 grp.signal()                             # the forward was not cut (no capture fork): the whole graph is the wait
-            if which == "vln" and getattr(self.net, "_text", None) is not None:
+            if which == "vln" and getattr(self.net, "_text", None) is not None and self._deferred is None:
                 self.net._text_read = torch.cuda.Event()
                 self.net._text_read.record(torch.cuda.current_stream())
             return out
@@ -670,7 +701,7 @@ class Policy(nn.Module):
                 k.append(a)
         return tuple(k)
 
-    def _prefetch(self, which, *net_args, stream=None):
+    def _prefetch(self, which, *net_args, stream=None, dialog_later=False):
         """Enqueue the forward of a later act*/get_value* call now (no host synchronisation).  The matching call, made
         with the same tensors, picks the result up instead of launching again; a trainer that evaluates pi_q, pi_g and
         pi_l on one observation (ppo_trainer.py:375-636) can enqueue all three before the first host-side sampling.
@@ -690,6 +721,26 @@ class Policy(nn.Module):
             else:
                 stream.wait_stream(cur)
         ctx = torch.cuda.stream(run_on) if stream is not None else contextlib.nullcontext()
+        if dialog_later:
+            # pi_l, reference order (ppo_trainer.py:347, 449-593): the step's dialog tokens and agent_step are written AFTER act_option
+            # returned.  Only the half of the cut forward that reads neither (encoders + SMT state encoder) goes out now.
+            self._deferred = self._later = None
+            if self.use_graphs and net_args[7] is not None and self.net.text_encoder_override is None:
+                with ctx:
+                    if self.net._text is None:           # first call: the forward is captured against the text graph's static output
+                        self.net.prefetch_text(self, net_args[7], run_on, after_current=True)
+                    self._defer_second = True
+                    try:
+                        out = self._forward(which, *net_args)
+                    finally:
+                        self._defer_second = False
+                if self._deferred is not None:
+                    self._later = (which, self._arg_key(net_args), out, stream, net_args[7], net_args[8])
+                    return
+                # the forward was not cut (no split capture): it ran whole, with whatever the tensors held -- run it again, whole,
+                # at dialog_ready()
+            self._later = ("whole", net_args, stream)
+            return
         with ctx:
             out = self._forward(which, *net_args)
             done = torch.cuda.Event()
@@ -724,9 +775,50 @@ class Policy(nn.Module):
             self.net.prefetch_text(self, all_dialog, stream, after_current)
 
     def prefetch_act_dialog(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_dialog,
-                            ext_memory_masks, all_dialog, agent_step, stream=None):
+                            ext_memory_masks, all_dialog, agent_step, stream=None, dialog_later=False):
+        """dialog_later=True: `all_dialog` and `agent_step` are the tensors the trainer fills only after `act_option` has returned
+        (`current_dialog`, `rollouts.agent_step[step]`: ppo_trainer.py:347, 582-593).  Only the half of the forward that reads
+        neither is enqueued now; call `dialog_ready()` once both hold this step's values."""
         self._prefetch("vln", observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_dialog,
-                       ext_memory_masks, all_dialog, agent_step, stream=stream)
+                       ext_memory_masks, all_dialog, agent_step, stream=stream, dialog_later=dialog_later)
+
+    def dialog_ready(self):
+        """Second half of `prefetch_act_dialog(..., dialog_later=True)`: the frozen text tower on the tensors passed there (memoised
+        per row: only dialogs that changed since the last call run it), agent_step, the dialog state encoder and the heads.  The
+        matching `act_dialog` call picks the result up."""
+        lt = self._later
+        self._later = None
+        if lt is None:
+            return
+        if lt[0] == "whole":
+            self._prefetch("vln", *lt[1], stream=lt[2])
+            return
+        which, key, out, stream, tokens, agent_step = lt
+        g, self._deferred = self._deferred, None
+        cur = torch.cuda.current_stream()
+        run_on = stream if stream is not None else cur
+        ctx = torch.cuda.stream(run_on) if stream is not None else contextlib.nullcontext()
+        with ctx:
+            # everything in stream order on pi_l's own stream: text graph -> agent_step refresh -> second half
+            self.net.prefetch_text(self, tokens, run_on, after_current=False, same_stream=True)
+            if torch.is_tensor(g.static[8]) and g.static[8].data_ptr() != agent_step.data_ptr():
+                L.multi_copy([(g.static[8], _f32(agent_step))])
+            g.graph2.replay()
+            self.net._text_read = torch.cuda.Event()
+            self.net._text_read.record(run_on)
+            done = torch.cuda.Event()
+            if self.sampling == "host":
+                probs = out[1]["probs"]
+                pk = (which, tuple(probs.shape))
+                if pk not in self._pinned:
+                    self._pinned[pk] = torch.empty(probs.shape, dtype=probs.dtype, pin_memory=True)
+                pc = self._pinned[pk]
+                pc.copy_(probs, non_blocking=True)
+                done.record(run_on)
+                out[1]["probs_host"] = (pc, done)
+            else:
+                done.record(run_on)
+        self._stash = (which, key, out, done)
 
     # ------------------------------------------------------------------ reference API
     def act(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks,
@@ -1110,12 +1202,54 @@ class AudioNavDialogNet(_SMTBase):
         L.call("avlen_clip_text_fwd", C.byref(clip), E.P(tok), E.P(out), B, pol.prec_of("clip"), E.P(ws), nb, L.stream())
         return out
 
+    # Per-row memo of the frozen text tower (avlen_clip_text_cached_fwd): in the reference a dialog is constant for NUM_DIALOG_STEPS
+    # steps after a query and all-zero for every other env (ppo_trainer.py:347, 582-586), so most rows of `all_dialog` equal the
+    # previous step's.  What is kept is the tower's output BEFORE ln_final / text_projection / dialog_layer -- dialog_layer is
+    # trained by update_dialog and is applied fresh every call.  Keyed on a row's tokens (content), one state block per batch size;
+    # emptied when the weights change (mark_params_changed / load_state_dict bump pol._param_epoch).
+    text_cache = os.environ.get("AVLEN_TEXT_CACHE", "1") != "0"
+
+    def _text_state(self, pol, clip, B, dev):
+        st = self.__dict__.setdefault("_text_states", {})
+        key = (B, bool(clip.text_proj))
+        t = st.get(key)
+        if t is None or t.device != dev:
+            nb = L.lib.avlen_clip_text_cache_bytes(C.byref(clip), B)
+            t = st[key] = torch.zeros(nb, dtype=torch.uint8, device=dev)
+        return t
+
+    def _sync_text_cache(self, pol):
+        """Outside capture, on the stream the next text forward runs on: empty the memo if the weights changed since it was filled."""
+        if self.__dict__.get("_text_epoch") != pol._param_epoch:
+            self.__dict__["_text_epoch"] = pol._param_epoch
+            for t in self.__dict__.get("_text_states", {}).values():
+                t.zero_()
+
+    def invalidate_text_cache(self):
+        self.__dict__["_text_epoch"] = None
+
+    def encode_text_cached(self, pol, tokens, project=True):
+        eng = pol._engine()
+        tok = _i64(tokens)
+        B = tok.shape[0]
+        clip = eng["clip"] if project else eng["clip_noproj"]
+        if not torch.cuda.is_current_stream_capturing():
+            self._sync_text_cache(pol)
+        state = self._text_state(pol, clip, B, tok.device)
+        out = torch.empty(B, self.clip.text_projection.shape[1 if project else 0], device=tok.device)
+        nb = L.lib.avlen_clip_text_workspace_bytes(C.byref(clip), B + 1)
+        ws = pol._ws.get("clip_cached", nb, tok.device)
+        L.call("avlen_clip_text_cached_fwd", C.byref(clip), E.P(tok), E.P(state), state.numel(), E.P(out), B, pol.prec_of("clip"),
+               E.P(ws), nb, L.stream())
+        return out
+
     def _text_to_dialog(self, pol, tokens):
         """tokens -> dialog_layer(CLIP.encode_text(tokens)) (policy.py:847-849); folded form in the 16-bit modes."""
         eng = pol._engine()
+        enc = self.encode_text_cached if self.text_cache else self.encode_text
         if "dialog_fold" in eng and pol.prec_of("clip") in (L.PREC_BF16, L.PREC_FP16):
-            return self._dialog_embed(pol, self.encode_text(pol, tokens, project=False), eng["dialog_fold"])
-        return self._dialog_embed(pol, self.encode_text(pol, tokens))
+            return self._dialog_embed(pol, enc(pol, tokens, project=False), eng["dialog_fold"])
+        return self._dialog_embed(pol, enc(pol, tokens))
 
     text_encoder_override = None      # tests: callable(tokens)->(B,512) replacing the CLIP tower (unpinned, SURVEY §8c)
     _text = None                      # (tokens ptr, shape, static embedding, event) of the last prefetch_text
@@ -1144,23 +1278,28 @@ class AudioNavDialogNet(_SMTBase):
                    e.shape[1], 0, pol.prec_of("clip"), 1, 0.0, E.P(wsg), nbg, st)
         return d_emb
 
-    def prefetch_text(self, pol, tokens, stream, after_current=True):
+    def prefetch_text(self, pol, tokens, stream, after_current=True, same_stream=False):
         """Enqueue CLIP.encode_text(tokens) NOW on `stream`: the text tower depends on nothing but the dialog tokens, so it
         can run under the visual towers of the same step instead of after them.  The next run() with the same token tensor
-        reads the embedding from this call's static buffer."""
+        reads the embedding from this call's static buffer.  same_stream: `stream` is the current stream and every reader of the
+        embedding buffer runs on it too (dialog_ready): stream order is the only ordering needed."""
         if self.text_encoder_override is not None or tokens is None:
             return
         tok = _i64(tokens)
         cur = torch.cuda.current_stream()
-        if after_current:
+        if same_stream:
+            pass
+        elif after_current:
             stream.wait_stream(cur)                      # after every earlier reader of the embedding buffer
         elif self._text_read is not None:
             stream.wait_event(self._text_read)           # the last forward that read the embedding buffer
-        with torch.cuda.stream(stream):
+        with (contextlib.nullcontext() if same_stream else torch.cuda.stream(stream)):
             key = ("text", tuple(tok.shape))
             g = pol._graphs.get(key)
+            pol._engine()                                # derived weights current (a weight change also empties the text memo below)
+            if self.text_cache:
+                self._sync_text_cache(pol)
             if g is None:
-                pol._engine()
                 # the graph ends with dialog_layer: what the forward picks up is the (B, d) dialog embedding
                 g = pol._graphs[key] = _Graph(pol, lambda t: self._text_to_dialog(pol, t), [tok])
             emb = g([tok])

@@ -316,6 +316,14 @@ int avlen_dialog_fwd(const avlen_dialog* p, const float* x_att, const float* mem
 size_t avlen_clip_text_workspace_bytes(const avlen_clip_text* p, int B);
 int avlen_clip_text_fwd(const avlen_clip_text* p, const int64_t* tokens, float* out, int B, int prec, void* ws,
                         size_t ws_bytes, avlen_stream_t stream);
+/* The same function with a per-row memo of the frozen tower (ppo_trainer.py:347,582-586: a dialog is constant for NUM_DIALOG_STEPS
+ * steps and all-zero for an env without a query): only rows whose 77 tokens differ from the previous call's run the 12 blocks,
+ * all-zero rows share one embedding.  `state`: caller-owned device block of avlen_clip_text_cache_bytes(p, B) bytes, one per batch
+ * size; zero-filled = empty (do that after the tower's weights change).  Workspace: avlen_clip_text_workspace_bytes(p, B + 1).
+ * Without the one-launch tower (fp32, no weight stream, B > 511) every row is computed (== avlen_clip_text_fwd). */
+size_t avlen_clip_text_cache_bytes(const avlen_clip_text* p, int B);
+int avlen_clip_text_cached_fwd(const avlen_clip_text* p, const int64_t* tokens, void* state, size_t state_bytes, float* out, int B,
+                               int prec, void* ws, size_t ws_bytes, avlen_stream_t stream);
 /* The one-launch tower's weight stream (csrc/clip_tower.hip): bytes for `p` (0: shape not supported -- width 512, 8 heads,
  * ctx <= 80, 4x MLP, biases present) and the packer (fmt 0 bf16, 1 fp16; from the fp32 weights; derived data). */
 size_t avlen_clip_stream_bytes(const avlen_clip_text* p);

@@ -1,0 +1,145 @@
+"""The per-row memo of the frozen CLIP text tower (avlen_clip_text_cached_fwd; AudioNavDialogNet.encode_text_cached) and the
+reference's dialog data flow (ss_baselines/savi/ppo/ppo_trainer.py:347, 449-625; policy.py:844-851):
+
+* `current_dialog` is all-zero for an env without a query, holds the tokenised instruction for NUM_DIALOG_STEPS = 3 steps after a
+  query, then is zero again -- the memo must return, bit for bit, what the uncached tower returns over such a scenario while running
+  the 12 blocks only for the rows that changed;
+* the tokens exist only after `act_option` returned: the harness' default ("after_option": pi_l's dialog half issued by
+  `dialog_ready()`) must produce exactly what the tokens-known-ahead ordering produces.
+"""
+import numpy as np
+import pytest
+import torch
+
+from avlen_amd import policy as P
+from avlen_amd.spaces import savi_observation_space, ActionSpace, SMT_KW
+
+pytestmark = pytest.mark.gpu
+
+
+def _dialog(gen, ln):
+    t = torch.zeros(77, dtype=torch.long)
+    t[:ln] = torch.randint(1, 49406, (ln,), generator=gen)
+    t[0] = 49406
+    t[ln] = 49407
+    return t
+
+
+def _policy(mode):
+    torch.manual_seed(3)
+    pol = P.AudioNavDialogPolicy(savi_observation_space((65, 26, 2)), ActionSpace(4), pretraining=False, num_steps=3,
+                                 precision=mode, **SMT_KW).to("cuda")
+    pol._engine()
+    return pol
+
+
+def _tower_rows(net, B, project):
+    """rows the last cached call sent through the 12 blocks (header word 1 of the state block)."""
+    st = net._text_states[(B, project)]
+    return int(st[:12].view(torch.int32)[1])
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
+def test_memo_is_bit_equal_to_the_uncached_tower_over_a_query_scenario(mode):
+    """query -> 3 steps -> pause, two envs out of phase, a repeated instruction, an env whose dialog is replaced mid-way."""
+    pol = _policy(mode)
+    net = pol.net
+    assert net.text_cache and pol._engine()["clip"].wstream
+    gen = torch.Generator().manual_seed(7)
+    B = 6
+    d = [_dialog(gen, ln) for ln in (9, 33, 70, 17, 48)]
+    Z = torch.zeros(77, dtype=torch.long)
+    #            env0  env1  env2  env3  env4  env5        expected rows through the tower
+    steps = [([Z, Z, Z, Z, Z, Z], 1),                      # first call: only the shared all-zero row
+             ([d[0], Z, Z, Z, Z, Z], 1),                   # env 0 queries
+             ([d[0], Z, d[1], Z, Z, Z], 1),                # env 2 queries one step later
+             ([d[0], Z, d[1], Z, Z, Z], 0),                # nothing changed: no tower work at all
+             ([Z, Z, d[1], Z, Z, d[2]], 1),                # env 0's dialog is over (zero row: no tower), env 5 queries (5 row tiles)
+             ([Z, d[0], Z, Z, Z, d[2]], 1),                # env 1 gets the instruction env 0 had: its row changed -> recomputed
+             ([d[3], d[0], Z, d[4], Z, d[3]], 3),          # three new rows at once (two of them the same instruction)
+             ([Z, Z, Z, Z, Z, Z], 0)]                      # pause: every row back to the shared zero embedding
+    for project in (True, False):
+        if not project and "clip_noproj" not in pol._engine():
+            continue
+        net.invalidate_text_cache()
+        for i, (rows, want) in enumerate(steps):
+            tok = torch.stack(rows).cuda()
+            got = net.encode_text_cached(pol, tok, project=project).clone()
+            ref = net.encode_text(pol, tok, project=project).clone()
+            torch.cuda.synchronize()
+            assert torch.isfinite(got).all()
+            assert torch.equal(got, ref), (mode, project, i, float((got - ref).abs().max()))
+            assert _tower_rows(net, B, project) == want, (mode, project, i, _tower_rows(net, B, project), want)
+    # a weight change empties the memo: every non-zero row + the zero row run again, and the result follows the new weights
+    tok = torch.stack([d[0], Z, d[1], Z, Z, d[2]]).cuda()
+    a = net.encode_text_cached(pol, tok).clone()
+    with torch.no_grad():
+        pol.net.clip.ln_final.weight.mul_(1.5)
+        pol.net.clip.transformer.resblocks[3].mlp.c_fc.bias.add_(0.05)
+    pol.mark_params_changed()
+    b = net.encode_text_cached(pol, tok).clone()
+    ref = net.encode_text(pol, tok).clone()
+    torch.cuda.synchronize()
+    assert _tower_rows(net, B, True) == 4
+    assert torch.equal(b, ref) and not torch.equal(a, b)
+
+
+def _storage_snapshot(wl):
+    ro = wl.rollouts
+    keys = ("value_preds", "actions", "actions_option", "action_log_probs", "action_probs", "all_dialog", "agent_step")
+    snap = {k: getattr(ro, k).clone() for k in keys}
+    snap["em_goal"] = ro.em.memory.clone()
+    snap["em_option"] = ro.em_option.memory.clone()
+    snap["em_vln"] = ro.em_vln.memory.clone()
+    snap["em_vln_dialog"] = ro.em_vln_dialog.memory.clone()
+    return snap
+
+
+def _run(N, T, **kw):
+    from avlen_amd.harness import Workload
+    torch.manual_seed(99)                                   # host RNG of the action sampling
+    wl = Workload(N, T, spectrogram=(65, 26, 2), em_capacity=T, **kw)
+    return wl
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "fp32"])
+def test_after_option_ordering_equals_tokens_ahead(mode):
+    """Same arithmetic, different issue order: the storage after a rollout is bit-equal (the update's loss scalars are sums whose
+    last bits depend on the atomics' arrival order in fp32 mode: compared to 1e-6)."""
+    N, T = 4, 6
+    outs = []
+    for order in ("ahead", "after_option"):
+        wl = _run(N, T, precision=mode, dialog_tokens=order, share_encoders=(mode != "fp32"))
+        for _ in range(T):
+            wl.rollout_step()
+        snap = _storage_snapshot(wl)
+        losses = [float(x) for x in wl.update()]
+        torch.cuda.synchronize()
+        outs.append((snap, losses))
+        del wl
+    (s0, l0), (s1, l1) = outs
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), (mode, k)
+    assert np.allclose(l0, l1, rtol=1e-6, atol=1e-7), (l0, l1)
+
+
+def test_reference_dialog_process_memo_on_equals_memo_off():
+    """The trainer's dialog process (tokens persist 3 steps after a_q == 1, zeros otherwise) through the whole harness: the stored
+    rollout with the memo equals the one without it, and the memo did skip most of the tower work."""
+    N, T = 8, 12
+    outs = []
+    for cache in (True, False):
+        wl = _run(N, T, precision="bf16x3", dialog_process="reference")
+        wl.pi_l.net.text_cache = cache
+        for _ in range(T):
+            wl.rollout_step()
+        snap = _storage_snapshot(wl)
+        torch.cuda.synchronize()
+        outs.append((snap, dict(wl.dialog_stats)))
+        del wl
+    (s0, st0), (s1, st1) = outs
+    assert st0 == st1 and st0["steps"] == T and st0["new_dialogs"] > 0
+    # a dialog lasts 3 steps: active rows ~ 3 x new dialogs (fewer at the end of the rollout / at episode ends)
+    assert st0["new_dialogs"] <= st0["active_rows"] <= 3 * st0["new_dialogs"]
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
