@@ -19,8 +19,10 @@ Besides the headline line, rank 0 of a 1-GPU run adds (each skippable, see the f
   bf16_vs_fp32      observations / seeds: max |value|, |prob| differences and the sampled-action flips, per step on the SAME state
   bf16_fast_mode    env-steps/s of the same cycle with precision="bf16" (plain bf16 operands: faster, outside the 1e-3 tolerance)
   fp32_parity_mode  env-steps/s of the same cycle with precision="fp32" (the mode the bit-exact tests run)
-  integration       env-steps/s with cached step views (round-1 harness) and of the imports-only integration
-                    (no encoder sharing, no launch-ahead)
+  integration       env-steps/s with the tokens-known-ahead ordering of round 3 (text_ahead_synthetic), cached step views
+                    (round-1 harness), share_encoders only, and the imports-only integration (no sharing, no launch-ahead)
+  reference_dialog_process   the same cycle when the tokens follow the trainer's dialog process (3 steps after a_q == 1, else
+                    zeros): the memoised text tower runs only the rows that changed
   gru_baseline      BASELINE configs[1]: N=16 GRU policy rollout + PPO 4x2 update
 """
 import argparse
@@ -65,6 +67,12 @@ def parse():
     ap.add_argument("--stage", type=int, default=1, choices=[1, 2],
                     help="1 = savi_interactive_1st_stage (pretraining=True, the metric's config); 2 = 2nd stage: pi_q attends over "
                          "its 300-slot memory history in rollout and update (BASELINE configs[3] runs it at 32 envs per GPU)")
+    ap.add_argument("--dialog-tokens", default="after_option", choices=["after_option", "ahead"],
+                    help="after_option (default) = the reference's data flow: the step's dialog tokens exist only after pi_q's "
+                         "action was sampled (ppo_trainer.py:347, 449-593); ahead = tokens known at the start of the step (synthetic)")
+    ap.add_argument("--dialog-process", default="fresh", choices=["fresh", "reference"],
+                    help="fresh = a new random dialog for every env every step (SURVEY 8d input); reference = the trainer's process: "
+                         "tokens persist NUM_DIALOG_STEPS = 3 steps after a_q == 1, zeros otherwise")
     ap.add_argument("--belief", action="store_true",
                     help="also run BeliefPredictor.update every step (SURVEY 8f rank 1; needs --spectrogram 65x26, the only size "
                          "the reference's predictor.fc accepts)")
@@ -359,23 +367,53 @@ def integration_records(a, H, W):
     import torch
     from avlen_amd.harness import Workload
     out = {}
-    for name, kw in (("cached_views", dict(cached_views=True)),
+    for name, kw in (("text_ahead_synthetic", dict(dialog_tokens="ahead")),
+                     ("cached_views", dict(cached_views=True)),
                      ("share_only", dict(share_encoders=True, launch_ahead=False)),
                      ("imports_only", dict(share_encoders=False, launch_ahead=False))):
         kws = dict(spectrogram=(H, W, 2), precision=a.precision, pretraining=(a.stage == 1), seed=0, use_graphs=not a.no_graphs,
-                   share_encoders=not a.no_share, launch_ahead=not a.no_launch_ahead, distractor=a.distractor)
+                   share_encoders=not a.no_share, launch_ahead=not a.no_launch_ahead, distractor=a.distractor,
+                   dialog_tokens=a.dialog_tokens, dialog_process=a.dialog_process)
         kws.update(kw)
+        if kws["dialog_tokens"] == "ahead":
+            kws["dialog_process"] = "fresh"
         wl = Workload(a.envs, a.rollout, **kws)
         dt = time_cycles(wl, 2, 3)
         out[name] = {"value": round(a.envs * a.rollout / dt, 2), "unit": "env-steps/s", "ms_per_step": round(dt * 1e3, 2)}
         del wl
         torch.cuda.empty_cache()
     out["what"] = ("headline = fresh storage views every step (as ppo_trainer.py:375-391 slices them), encoder sharing + "
-                   "launch-ahead calls added to the trainer; cached_views = the round-1 harness (view objects kept per step "
+                   "launch-ahead calls added to the trainer, dialog tokens issued after act_option as the reference's data flow "
+                   "dictates; text_ahead_synthetic = the round-3 ordering: the step's tokens are known before act_option and the "
+                   "text tower is launched beside the visual towers (NOT obtainable from the reference trainer, "
+                   "ppo_trainer.py:449-593); cached_views = the round-1 harness (view objects kept per step "
                    "slot); share_only = the imports + ONE share_encoders(pi_q, pi_g, pi_l) call where the trainer builds the policies, "
                    "no per-step prefetch_* calls; imports_only = the three-import-lines integration: no share_encoders, no "
                    "prefetch_* calls")
     return out
+
+
+def reference_dialog_record(a, H, W):
+    """The same cycle under the reference's dialog PROCESS (ppo_trainer.py:347, 463-469, 582-587, 763-765): an env outside a dialog
+    that samples a_q == 1 gets a new instruction, keeps it for NUM_DIALOG_STEPS = 3 steps, every other env presents all-zero
+    tokens -- so the memoised text tower runs only the rows that changed.  pi_q is untrained here (p(query) ~ 0.5): about one env in
+    five starts a dialog per step, far more than a trained pi_q asks for."""
+    import torch
+    from avlen_amd.harness import Workload
+    wl = Workload(a.envs, a.rollout, spectrogram=(H, W, 2), precision=a.precision, pretraining=(a.stage == 1), seed=0,
+                  use_graphs=not a.no_graphs, share_encoders=not a.no_share, launch_ahead=not a.no_launch_ahead,
+                  distractor=a.distractor, dialog_tokens="after_option", dialog_process="reference")
+    dt = time_cycles(wl, 2, 3)
+    ds = wl.dialog_stats
+    rec = {"value": round(a.envs * a.rollout / dt, 2), "unit": "env-steps/s", "ms_per_step": round(dt * 1e3, 2),
+           "new_dialogs_per_step": round(ds["new_dialogs"] / max(ds["steps"], 1), 2),
+           "rows_with_a_dialog_per_step": round(ds["active_rows"] / max(ds["steps"], 1), 2), "num_envs": a.envs,
+           "what": "dialog tokens persist 3 steps after a_q == 1 and are zero otherwise, written by a host loop after act_option "
+                   "(H2D of current_dialog / agent_step per step); the text tower is memoised per row "
+                   "(avlen_clip_text_cached_fwd): only the new dialogs of a step run the 12 blocks"}
+    del wl
+    torch.cuda.empty_cache()
+    return rec
 
 
 def gru_record(a):
@@ -424,7 +462,8 @@ def main():
     else:
         wl = Workload(a.envs, a.rollout, spectrogram=(H, W, 2), precision=a.precision, pretraining=(a.stage == 1), seed=rank,
                       use_graphs=not a.no_graphs, share_encoders=not a.no_share, launch_ahead=not a.no_launch_ahead,
-                      belief_predictor=a.belief, cached_views=a.cached_views, distractor=a.distractor)
+                      belief_predictor=a.belief, cached_views=a.cached_views, distractor=a.distractor,
+                      dialog_tokens=a.dialog_tokens, dialog_process=a.dialog_process if a.dialog_tokens == "after_option" else "fresh")
 
     def barrier():
         torch.cuda.synchronize()
@@ -468,7 +507,8 @@ def main():
                    "spectrogram": a.spectrogram, "parallelism": f"env-shard x{world}, RCCL grad all-reduce",
                    "rollout_fraction_of_time": round(t_roll / dt, 3), "belief_predictor": bool(a.belief),
                    "step_views": "cached" if a.cached_views else "fresh", "encoder_sharing": not a.no_share,
-                   "launch_ahead": not a.no_launch_ahead},
+                   "launch_ahead": not a.no_launch_ahead, "dialog_tokens": a.dialog_tokens,
+                   "dialog_process": a.dialog_process},
     }
     if rank == 0:
         interactive = a.config == "interactive"
@@ -484,7 +524,7 @@ def main():
             other = "bf16" if a.precision == "bf16x3" else "bf16x3"
             wlo = Workload(a.envs, a.rollout, spectrogram=(H, W, 2), precision=other, pretraining=(a.stage == 1), seed=0,
                            use_graphs=not a.no_graphs, share_encoders=not a.no_share, launch_ahead=not a.no_launch_ahead,
-                           distractor=a.distractor)
+                           distractor=a.distractor, dialog_tokens=a.dialog_tokens)
             wlo.pi_q.load_state_dict(wl.pi_q.state_dict())      # the timed cycles have trained pi_q: every mode holds the SAME weights
             wls[other] = wlo
             recs, out["fp32_parity_mode"] = modes_vs_fp32(a, H, W, wls)
@@ -497,6 +537,7 @@ def main():
             del wl, wlo, wls
             torch.cuda.empty_cache()
             out["integration"] = integration_records(a, H, W)
+            out["reference_dialog_process"] = reference_dialog_record(a, H, W)
             import avlen_amd.harness as hz
             if hasattr(hz, "GruWorkload"):
                 out["gru_baseline"] = gru_record(a)
