@@ -796,11 +796,8 @@ int avlen_attention_smt16(const void* QKV16, int ld, void* O16, int ldo16, int B
     hipLaunchKernelGGL((attn_smt16_kernel<160, false>), dim3(H, B), dim3(256), 0, stream, (const __bf16*)QKV16, ld, H * 32, 2 * H * 32,
                        (__bf16*)O16, ldo16, S, scale, key_mask, seg_off, 0L, 0L);
   else {
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_smt16_kernel<320, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 0);
-      attr_set = true;
-    }
+    static unsigned long long attr_done = 0;             // per-device bit mask (a process may drive several devices)
+    if (avlen_set_dyn_lds(reinterpret_cast<const void*>(&attn_smt16_kernel<320, false>), 0, &attr_done) != AVLEN_OK) return AVLEN_ERR_LAUNCH;
     hipLaunchKernelGGL((attn_smt16_kernel<320, false>), dim3(H, B), dim3(256), 0, stream, (const __bf16*)QKV16, ld, H * 32, 2 * H * 32,
                        (__bf16*)O16, ldo16, S, scale, key_mask, seg_off, 0L, 0L);
   }

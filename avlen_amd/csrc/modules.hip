@@ -902,15 +902,16 @@ int cnn3_fwd_bf16(const avlen_cnn3* n, const float* x, int B, int H, int W, floa
 // audio conv 1 of a 1200-row minibatch.  AVLEN_NOT_BIG: no 16-bit shadows / unsupported geometry.
 int avlen_i_cnn3_fwd16_keep(const avlen_cnn3* n, const float* x, int B, int H, int W, float* const* keep, float* out, int ld_out,
                             void* x16v, void* const* a16v, void* gws, size_t gws_bytes, hipStream_t st) {
-  if (!cnn3_has16(n) || n->half_fmt != 0 || n->conv[0].cin > 8 || !x16v || !a16v) return AVLEN_NOT_BIG;
-  avlen_g2_opts go;
+  if (!cnn3_has16(n) || n->conv[0].cin > 8 || !x16v || !a16v) return AVLEN_NOT_BIG;
+  const int fmt = n->half_fmt == 1 ? 1 : 0;            // the net's 16-bit shadows: bf16, or fp16 (the accurate mode of the GRU baseline)
+  avlen_g2_opts go; go.f16 = fmt;
   int oh[3], ow[3]; cnn3_dims2(n, H, W, oh, ow);
   if (oh[2] <= 0 || ow[2] <= 0) return AVLEN_ERR_ARG;
   bf16* x16 = (bf16*)x16v;
   const bool sp = cnn3_superpixel(n, W);
   const int wsp = sp ? ((ow[0] - 1) * n->conv[0].stride + n->conv[0].kw) / n->conv[0].stride : 0;
-  if (sp) TRY(avlen_cast_bf16_indexed(x, W * n->conv[0].cin, x16, wsp * 8, (long)B * H, wsp * 8, nullptr, H, st, 0));
-  else TRY(avlen_cast_bf16_indexed(x, n->conv[0].cin, x16, 8, (long)B * H * W, n->conv[0].cin, nullptr, H * W, st, 0));
+  if (sp) TRY(avlen_cast_bf16_indexed(x, W * n->conv[0].cin, x16, wsp * 8, (long)B * H, wsp * 8, nullptr, H, st, fmt));
+  else TRY(avlen_cast_bf16_indexed(x, n->conv[0].cin, x16, 8, (long)B * H * W, n->conv[0].cin, nullptr, H * W, st, fmt));
   const bf16* cur = x16; int h = H, wd = W;
   for (int i = 0; i < 3; i++) {
     const avlen_conv& k = n->conv[i];

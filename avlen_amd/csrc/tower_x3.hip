@@ -1064,8 +1064,8 @@ __global__ __launch_bounds__(RTH) void tower_x3_kernel(TowerArgs args) {
         bool ok = true;
         while (__hip_atomic_load(qw + 4 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
           __builtin_amdgcn_s_sleep(32);
-          // ~2^22 polls (seconds) without the producer: give up rather than hang the GPU -- the outputs are then garbage and
-          // the give-up word is left set for the host
+          // ~2^22 polls (seconds) without the producer: give up rather than hang the GPU -- the image's output is poisoned
+          // below and the give-up word tells every later item to do the same at once
           if (++spins > (1u << 22) || __hip_atomic_load(qw + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = false; break; }
         }
         if (!ok) { __hip_atomic_store(qw + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *slot = -1; }
@@ -1073,9 +1073,19 @@ __global__ __launch_bounds__(RTH) void tower_x3_kernel(TowerArgs args) {
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (__builtin_amdgcn_readfirstlane(*slot) == -1) break;
-      X3_WALL(30);
-      rest_body(args.rest, j / args.B, j % args.B, lds, args.prof, item);
+      if (__builtin_amdgcn_readfirstlane(*slot) == -1) {
+        // the producer never arrived: this image's output is poisoned with NaN (both planes) instead of being left stale, and the
+        // loop goes on -- every remaining layer 2-4 item sees the give-up word at its first poll and does the same, so after a
+        // lost hand-off each output row is either valid or NaN (as the GRU sequence kernels and the CLIP tower do)
+        bf16* y = args.rest.t[j / args.B].y + (long)(j % args.B) * 8192;
+        for (int i = tid; i < 4096; i += RTH) {
+          reinterpret_cast<unsigned*>(y)[i] = 0x7fc07fc0u;
+          reinterpret_cast<unsigned*>(y + args.rest.y_lo)[i] = 0x7fc07fc0u;
+        }
+      } else {
+        X3_WALL(30);
+        rest_body(args.rest, j / args.B, j % args.B, lds, args.prof, item);
+      }
     }
     X3_WALL(31);
     __syncthreads();                                        // LDS (and the slot) are free for the next item

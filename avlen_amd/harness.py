@@ -322,7 +322,7 @@ class GruWorkload:
     minibatches, in the av_nav call pattern: act -> insert per step, then get_value -> compute_returns -> update ->
     after_update.  Synthetic observations as in `Workload`, resident in HBM."""
 
-    def __init__(self, num_envs=16, num_steps=150, spectrogram=(257, 101, 2), precision="bf16", ppo_epoch=4, num_mini_batch=2,
+    def __init__(self, num_envs=16, num_steps=150, spectrogram=(257, 101, 2), precision="bf16x3", ppo_epoch=4, num_mini_batch=2,
                  device="cuda", seed=0, weight_seed=0, sampling="host", use_graphs=True):
         from . import av_nav
         self.N, self.T, self.dev = num_envs, num_steps, torch.device(device)

@@ -1467,6 +1467,9 @@ class AudioNavBaselineNet(Net):
         return 1
 
     def build_views(self, eng, packed):
+        # precision="bf16x3" (the mode that keeps values / probabilities / hidden states within 1e-3 of fp32): both CNNs on
+        # compensated bf16 pairs (three MFMAs per product; fp16 operands measured 3e-3 on the hidden state against the reference's
+        # goldens), the GRU and every Linear product in exact fp32; "bf16": bf16 operands everywhere
         eng["visual"] = E.cnn3_view(self.visual_encoder, packed)
         eng["audio"] = E.cnn3_view(self.audio_encoder, packed)
         eng["gru"] = E.gru_view(self.state_encoder.rnn)
@@ -1482,13 +1485,15 @@ class AudioNavBaselineNet(Net):
         H, W = spec.shape[1], spec.shape[2]
         nb = L.lib.avlen_cnn3_workspace_bytes(C.byref(eng["audio"]), R, H, W)
         ws = pol._ws.get("audio", nb, dev)
-        L.call("avlen_cnn3_fwd", C.byref(eng["audio"]), E.P(spec), R, H, W, E.P(x, 0), F, pol.prec, E.P(ws), nb, st)
+        pc = pol.prec                                    # both CNNs (bf16x3: compensated pairs on the fp32-staged implicit GEMM)
+        pg = L.PREC_FP32 if pol.prec == L.PREC_BF16X3 else pol.prec
+        L.call("avlen_cnn3_fwd", C.byref(eng["audio"]), E.P(spec), R, H, W, E.P(x, 0), F, pc, E.P(ws), nb, st)
         S = rgb.shape[1]
         rgbd = torch.empty(R, S, S, 4, device=dev)
         L.call("avlen_rgbd_concat", E.P(rgb), _u8(rgb), E.P(depth), E.P(rgbd), R, S * S, st)
         nb2 = L.lib.avlen_cnn3_workspace_bytes(C.byref(eng["visual"]), R, S, S)
         ws2 = pol._ws.get("visual", nb2, dev)
-        L.call("avlen_cnn3_fwd", C.byref(eng["visual"]), E.P(rgbd), R, S, S, E.P(x, self._hidden_size), F, pol.prec,
+        L.call("avlen_cnn3_fwd", C.byref(eng["visual"]), E.P(rgbd), R, S, S, E.P(x, self._hidden_size), F, pc,
                E.P(ws2), nb2, st)
         if self._label:
             cat = _f32(observations[CATEGORY])
@@ -1501,7 +1506,7 @@ class AudioNavBaselineNet(Net):
         h_out = torch.empty(1, Nn, self._hidden_size, device=dev)
         nb3 = L.lib.avlen_gru_workspace_bytes(C.byref(eng["gru"]), T, Nn)
         ws3 = pol._ws.get("gru", nb3, dev)
-        L.call("avlen_gru_fwd", C.byref(eng["gru"]), E.P(x), E.P(h0), E.P(mk), E.P(out), E.P(h_out), T, Nn, pol.prec,
+        L.call("avlen_gru_fwd", C.byref(eng["gru"]), E.P(x), E.P(h0), E.P(mk), E.P(out), E.P(h_out), T, Nn, pg,
                E.P(ws3), nb3, st)
         return out, h_out, None
 

@@ -48,8 +48,12 @@ class _RingTensor(torch.Tensor):
 
     def __getitem__(self, idx):
         if isinstance(idx, tuple) and len(idx) == 2 and isinstance(idx[0], slice) and idx[0] == slice(None) and isinstance(idx[1], int):
+            if idx[1] not in (0, -1):                    # the reference's tensor has ONE copy: memory[:, 1] raises there too
+                raise IndexError(f"index {idx[1]} is out of bounds for the copy axis of an ExternalMemory with 1 copy")
             return self.as_subclass(torch.Tensor)
-        return super().__getitem__(idx)
+        r = super().__getitem__(idx)
+        # derived views are plain tensors: only the ring itself answers to the copy-axis pattern
+        return r.as_subclass(torch.Tensor) if isinstance(r, _RingTensor) else r
 
 
 class ExternalMemory:

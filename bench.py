@@ -421,15 +421,56 @@ def gru_record(a):
     import torch
     from avlen_amd.harness import GruWorkload
     H, W = (int(x) for x in a.spectrogram.split("x"))
-    prec = "bf16" if a.precision == "bf16x3" else a.precision       # BASELINE configs[1] names bf16; the GRU baseline has no bf16x3 path
+    prec = a.precision
     wl = GruWorkload(16, a.rollout, spectrogram=(H, W, 2), precision=prec)
     dt = time_cycles(wl, 1, 3)
     rec = {"value": round(16 * a.rollout / dt, 2), "unit": "env-steps/s", "ms_per_step": round(dt * 1e3, 2),
            "config": {"workload": "AudioNavBaselinePolicy (AudioCNN + VisualCNN + GRU-512) rollout + PPO 4 epochs x 2 minibatches",
                       "num_envs": 16, "rollout_steps": a.rollout, "spectrogram": a.spectrogram, "dtype": prec}}
+    if prec != "fp32":
+        rec["vs_fp32"] = gru_vs_fp32(wl, a, H, W)
+        other = "bf16" if prec == "bf16x3" else "bf16x3"
+        wlo = GruWorkload(16, a.rollout, spectrogram=(H, W, 2), precision=other)
+        dto = time_cycles(wlo, 1, 3)
+        rec[other + "_mode"] = {"value": round(16 * a.rollout / dto, 2), "unit": "env-steps/s", "ms_per_step": round(dto * 1e3, 2)}
+        del wlo
     del wl
     torch.cuda.empty_cache()
     return rec
+
+
+def gru_vs_fp32(wl, a, H, W):
+    """cfg2's benched mode against the fp32 parity mode on identical weights (incl. what the timed cycles trained), observations and
+    host RNG: a whole rollout of the fp32 workload, the fast policy evaluated on the fp32 workload's state at every step."""
+    import torch
+    from avlen_amd.harness import GruWorkload
+    w32 = GruWorkload(16, a.rollout, spectrogram=(H, W, 2), precision="fp32")
+    w32.pol.load_state_dict(wl.pol.state_dict())
+    mv = {"value": 0.0, "prob": 0.0, "hidden": 0.0}
+    flips = 0
+    torch.manual_seed(777)
+    for t in range(w32.T):
+        ro = w32.rollouts
+        obs = {k: v[t] for k, v in ro.observations.items()}
+        rng = torch.get_rng_state()
+        v1, a1, _, h1, _, p1 = wl.pol.act(obs, ro.recurrent_hidden_states[t], ro.prev_actions[t], ro.masks[t], None, None)
+        v1, a1, h1, p1 = v1.clone(), a1.clone(), h1.clone(), p1.clone()
+        torch.set_rng_state(rng)
+        v0, a0, lp0, h0, _, p0 = w32.pol.act(obs, ro.recurrent_hidden_states[t], ro.prev_actions[t], ro.masks[t], None, None)
+        mv["value"] = max(mv["value"], float((v1 - v0).abs().max()))
+        mv["prob"] = max(mv["prob"], float((p1 - p0).abs().max()))
+        mv["hidden"] = max(mv["hidden"], float((h1 - h0).abs().max()))
+        flips += int((a1 != a0).sum())
+        ro.insert({k: w32.sim[k][t + 1] for k in ro.observations}, h0, a0, lp0, v0, w32.rewards[t], w32.not_done[t])
+    torch.cuda.synchronize()
+    n = w32.T * 16
+    del w32
+    torch.cuda.empty_cache()
+    return {"samples": n, "max_abs_value": round(mv["value"], 6), "max_abs_prob": round(mv["prob"], 7),
+            "max_abs_hidden": round(mv["hidden"], 6), "sampled_action_flips": flips,
+            "within_1e-3_and_no_flips": bool(max(mv.values()) <= 1e-3 and flips == 0),
+            "how": "per step on the fp32 workload's state (N = 16, T as benched), host RNG rewound between the modes; both hold the "
+                   "weights the timed cycles trained"}
 
 
 def main():
@@ -455,8 +496,6 @@ def main():
     H, W = (int(x) for x in a.spectrogram.split("x"))
     if a.config == "gru":
         from avlen_amd.harness import GruWorkload
-        if a.precision == "bf16x3":
-            a.precision = "bf16"                         # BASELINE configs[1] names bf16; the GRU baseline has no bf16x3 fast path
         wl = GruWorkload(a.envs if a.envs != 64 else 16, a.rollout, spectrogram=(H, W, 2), precision=a.precision, seed=rank)
         a.envs = wl.N
     else:

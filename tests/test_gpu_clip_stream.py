@@ -83,3 +83,23 @@ def test_folded_dialog_layer_matches_the_two_step_form_and_follows_weight_update
                 p_.net.dialog_layer.weight.mul_(0.5).add_(0.01)
                 p_.net.dialog_layer.bias.add_(0.1)
                 p_.mark_params_changed()
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("B", [600, 1100])
+def test_encode_text_above_one_pass(mode, B):
+    """PPO.update_dialog evaluates the frozen tower on T * N rows (ppo.py:99-154; policy.py:847-849): batches above the one-launch
+    tower's 512 dialogs run as consecutive passes -- the same rows as separate <= 512-row calls, bit for bit."""
+    gen = torch.Generator().manual_seed(21)
+    tok = _tokens(B, gen)
+    pol = _policy(mode, True)
+    out = pol.net.encode_text(pol, tok).clone()
+    parts = torch.cat([pol.net.encode_text(pol, tok[i:i + 512].contiguous()).clone() for i in range(0, B, 512)])
+    torch.cuda.synchronize()
+    assert out.shape == (B, 512) and torch.isfinite(out).all()
+    assert torch.equal(out, parts)
+    ref_pol = _policy("fp32", False, pol.state_dict())
+    ref = ref_pol.net.encode_text(ref_pol, tok[-40:].contiguous()).clone()        # the last rows belong to the last pass
+    torch.cuda.synchronize()
+    err = float((out[-40:] - ref).abs().max())
+    assert err < (1e-2 if mode == "bf16x3" else 6e-2) * max(1.0, float(ref.abs().max())), err

@@ -1,18 +1,20 @@
 """Full-size run of the benchmarked configuration (BASELINE cfg3: N=64 envs, T=150, 128x128 RGB-D, 257x101 spectrogram,
-three policies + pi_q update, bf16 fast path, HIP graphs, shared towers, launch-ahead) checked through size-independent
-properties -- the oracle cannot run this size in seconds."""
+three policies + pi_q update, HIP graphs, shared towers, launch-ahead with the dialog tokens issued after act_option) in BOTH fast
+modes -- bf16x3 (the harness / bench default, the mode that meets 1e-3) and plain bf16 -- checked through size-independent
+properties: the oracle cannot run this size in seconds."""
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def cycle():
+@pytest.fixture(scope="module", params=["bf16x3", "bf16"])
+def cycle(request):
     assert torch.cuda.is_available(), "GPU tests need a HIP device"
     from avlen_amd.harness import Workload
     torch.manual_seed(123)
-    wl = Workload(64, 150)
+    wl = Workload(64, 150, precision=request.param)
+    assert wl.pi_q.precision == request.param and wl.dialog_tokens == "after_option"
     before = {n: p.detach().clone() for n, p in wl.pi_q.named_parameters()}
     step_checks = []
     for t in range(wl.T):
@@ -76,14 +78,15 @@ def test_gae_identity_and_update_touches_only_trained_parameters(cycle):
     ro.after_update()
 
 
-def test_gru_baseline_full_size_sequence_equals_stepwise():
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_gru_baseline_full_size_sequence_equals_stepwise(precision):
     """BASELINE configs[1] at full size (N=16, T=150, 257x101, bf16): the masked-GRU SEQUENCE forward of the update (T-major rows,
     avlen_baseline_train_fwd: fused step kernels, saved activations) reproduces the hidden states the 150 single-step rollout
     calls produced -- the reference's own RNN test pattern (habitat-lab-dialog/test/test_rnn_state_encoder.py:16-75, 1e-3) at
     the benched size -- and one PPO update moves exactly the parameters that receive a gradient."""
     from avlen_amd.harness import GruWorkload
     torch.manual_seed(7)
-    wl = GruWorkload(16, 150)
+    wl = GruWorkload(16, 150, precision=precision)
     for _ in range(wl.T):
         wl.rollout_step()
     ro, pol = wl.rollouts, wl.pol
@@ -95,7 +98,9 @@ def test_gru_baseline_full_size_sequence_equals_stepwise():
     torch.cuda.synchronize()
     stepwise = ro.recurrent_hidden_states[1:, 0].reshape(150 * 16, -1)           # hidden after step t, T-major
     err = float((out - stepwise).abs().max())
-    assert err < 2e-2, err            # bf16 operands on both sides, different GEMM tilings (step: 16 rows, sequence: 2400 rows)
+    # bf16: bf16 operands on both sides, different GEMM tilings (step: 16 rows, sequence: 2400 rows); bf16x3: compensated convs +
+    # fp32 GRU on both sides (summation orders differ)
+    assert err < (2e-2 if precision == "bf16" else 1e-3), err
     before = {n: p.detach().clone() for n, p in pol.named_parameters()}
     vals = wl.update()
     assert all(v == v and abs(v) < 1e4 for v in vals)
@@ -104,13 +109,14 @@ def test_gru_baseline_full_size_sequence_equals_stepwise():
     assert wl.finite()
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
 @pytest.mark.parametrize("stage,distractor,envs", [(2, False, 32), (1, True, 32)])
-def test_per_gpu_share_of_the_sharded_configs(stage, distractor, envs):
+def test_per_gpu_share_of_the_sharded_configs(stage, distractor, envs, precision):
     """BASELINE configs[3] / configs[4] shard 256 environments as 8 x 32: one rank's share at full rollout length through the
     benched harness (2nd stage: pi_q attends over its memory history in rollout and update; distractor: F = 297 / 329)."""
     from avlen_amd.harness import Workload
     torch.manual_seed(11)
-    wl = Workload(envs, 150, pretraining=(stage == 1), distractor=distractor)
+    wl = Workload(envs, 150, pretraining=(stage == 1), distractor=distractor, precision=precision)
     out = wl.cycle()
     torch.cuda.synchronize()
     ro = wl.rollouts

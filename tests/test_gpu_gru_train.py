@@ -90,7 +90,9 @@ def test_gru_cycle_matches_reference(tag, spectro, use_gae):
     ("fp32", 6, 3, "gru_cycle_257_nogae", (257, 101)), ("bf16", 6, 3, "gru_cycle_257_nogae", (257, 101)),
     ("fp32", 20, 8, "gru_cycle_257_nogae", (257, 101)), ("fp32", 4, 16, "gru_cycle_257_nogae", (257, 101)),
     ("bf16", 5, 11, "gru_cycle_257_nogae", (257, 101)),
-    ("bf16", 7, 5, "gru_cycle", (65, 26)), ("fp32", 7, 5, "gru_cycle", (65, 26))])      # (5,2) (3,2) (3,1) audio geometry
+    ("bf16", 7, 5, "gru_cycle", (65, 26)), ("fp32", 7, 5, "gru_cycle", (65, 26)),       # (5,2) (3,2) (3,1) audio geometry
+    ("bf16x3", 6, 3, "gru_cycle_257_nogae", (257, 101)), ("bf16x3", 5, 11, "gru_cycle_257_nogae", (257, 101)),
+    ("bf16x3", 7, 5, "gru_cycle", (65, 26))])
 def test_gru_gradients_match_oracle_autograd(precision, T, N, tag, spectro):
     """One T x N minibatch with mask resets: the HIP backward (loss + heads, BPTT in the resident sequence kernels -- 8- and 16-row
     variants, ragged row counts --, Linear, conv weight gradient on the direct kernel in bf16 mode with partly filled 8-image groups,
@@ -121,8 +123,9 @@ def test_gru_gradients_match_oracle_autograd(precision, T, N, tag, spectro):
     torch.cuda.synchronize()
     lv = loss.cpu().numpy()
     fp = precision == "fp32"
-    np.testing.assert_allclose(lv[[0, 1, 2]], [float(vl), float(al), float(h["entropy"])], rtol=1e-3 if fp else 5e-2,
-                               atol=1e-5 if fp else 5e-3)
+    # bf16x3 (compensated CNN operands, fp32 GRU / Linear products): the losses sit within the north-star's 1e-3 of the oracle's
+    ltol = dict(rtol=1e-3, atol=1e-5) if fp else (dict(rtol=1e-3, atol=1e-3) if precision == "bf16x3" else dict(rtol=5e-2, atol=5e-3))
+    np.testing.assert_allclose(lv[[0, 1, 2]], [float(vl), float(al), float(h["entropy"])], **ltol)
     worst, worst_conv = 0.0, 0.0
     for k in tr:
         ours = flat.grad_view(k, osd[k].shape).cpu().double()
@@ -139,7 +142,59 @@ def test_gru_gradients_match_oracle_autograd(precision, T, N, tag, spectro):
     print(f"{precision} T={T} N={N}: max relative L2 gradient error over {len(tr)} tensors: {worst:.3g} (conv weights: {worst_conv:.3g})")
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision,tag,spectro,use_gae", [("bf16x3", "gru_cycle", (65, 26), True),
+                                                           ("bf16x3", "gru_cycle_257_nogae", (257, 101), False),
+                                                           ("bf16", "gru_cycle", (65, 26), True),
+                                                           ("bf16", "gru_cycle_257_nogae", (257, 101), False)])
+def test_gru_fast_modes_against_reference_goldens(precision, tag, spectro, use_gae):
+    """The benched modes of BASELINE configs[1] against the goldens of the reference's own av_nav PPO / RolloutStorage /
+    AudioNavBaselinePolicy: value, probabilities and hidden state of every rollout step (the reference's RNN test holds 1e-3,
+    habitat-lab-dialog/test/test_rnn_state_encoder.py:16-75).  Tolerances, stated: bf16x3 (compensated bf16 CNN operands, fp32 GRU) 1e-3 --
+    the north-star's; bf16 (bf16 CNN operands) 3e-2 on values / hidden, 3e-3 on probabilities -- NOT inside 1e-3, which is why
+    bf16x3 is the default of the harness."""
+    g = golden(tag)
+    T, N = 5, 4
+    pol, sd0, keys = build(tag, spectro, precision)
+    agent = av_nav.PPO(pol, **CFG)
+    st = av_nav.RolloutStorage(T, N, savi_observation_space(spectro + (2,)), ActionSpace(4), 512, num_recurrent_layers=1)
+    o0 = cyc.first_obs(N, spectro, tag="gru")
+    for k in st.observations:
+        st.observations[k][0].copy_(o0[k])
+    st.recurrent_hidden_states[0].copy_(fx.sym("gru.h0", (1, N, 512), 0.5))
+    torch.manual_seed(777)
+    x3 = precision == "bf16x3"
+    tv, tp = (1e-3, 1e-3) if x3 else (3e-2, 3e-3)
+    worst = {"value": 0.0, "probs": 0.0, "hidden": 0.0}
+    for t in range(T):
+        si = cyc.step_inputs(t, N, spectro, tag="gru")
+        so = {k: v[st.step] for k, v in st.observations.items()}
+        v, a, lp, h, _, probs = pol.act(so, st.recurrent_hidden_states[st.step], st.prev_actions[st.step], st.masks[st.step],
+                                        None, None)
+        for name, ours, tol in (("value", v, tv), ("probs", probs, tp), ("hidden", h, tv)):
+            err = float(np.abs(ours.cpu().numpy() - g[name][t]).max())
+            worst[name] = max(worst[name], err)
+            assert err <= tol, (precision, tag, t, name, err)
+        if x3:
+            assert np.array_equal(a.cpu().numpy(), g["action"][t])                 # the sampled actions are the reference's
+        # teacher forcing on the reference's trajectory: the next step starts from the golden hidden state
+        st.insert(cu(si["next_obs"]), torch.from_numpy(g["hidden"][t]).cuda(), torch.from_numpy(g["action"][t]).cuda(), lp, v,
+                  si["rewards"].cuda(), si["not_done"].cuda())
+    print(f"{precision} {tag}: max |d value| {worst['value']:.2e}  |d probs| {worst['probs']:.2e}  |d hidden| {worst['hidden']:.2e}")
+    nv = pol.get_value({k: v[-1] for k, v in st.observations.items()}, st.recurrent_hidden_states[-1], st.prev_actions[-1],
+                       st.masks[-1], None, None)
+    st.compute_returns(nv, use_gae, 0.99, 0.95)
+    out = agent.update(st)
+    torch.cuda.synchronize()
+    # the update's 3-tuple, averaged over 8 optimiser steps at lr 7e-4: the FORWARD of the update is the rollout's arithmetic, the
+    # conv gradients run on bf16 operands in both fast modes (direct kernels, ~0.09 relative per conv tensor, test above), so the
+    # later steps drift from the reference's: 6 % (measured 4.3 % on the entropy) / 10 %
+    np.testing.assert_allclose(np.array(out), g["update"], rtol=6e-2 if x3 else 0.1, atol=2e-3 if x3 else 2e-2)
+    sd = {k: v.detach().cpu() for k, v in pol.state_dict().items()}
+    assert all(torch.isfinite(v).all() for v in sd.values() if v.is_floating_point())
+    assert torch.equal(sd["critic_option.fc.weight"], sd0["critic_option.fc.weight"])
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16x3"])
 def test_gru_rollout_graph_replay_equals_eager(precision):
     """`use_graphs=True` on the GRU baseline: the captured forward stages rnn_hidden_states and masks (the SMT nets ignore both) and
     returns the graph's new hidden state; three chained steps equal the eager policy bit for bit."""

@@ -91,3 +91,58 @@ def test_fragment_order_weight_copy():
     assert torch.equal(f.view(-1), ref.view(-1))
     with pytest.raises(L.AvlenHipError):
         L.call("avlen_pack_conv_weight_frag", E.P(w), E.P(f), 60, K, L.stream())            # cout % 16 != 0
+
+
+# ---- the benched mode: compensated bf16 towers (tower_x3.hip: one persistent launch, stem + layer 1 / layers 2-4 work items) ----
+@pytest.fixture(scope="module")
+def towers_x3():
+    specs = param_specs()
+    pol = P.AudioNavOptionPolicy(savi_observation_space((65, 26, 2)), ActionSpace(4), pretraining=True, precision="bf16x3",
+                                 use_category_input=False, query_count_emb_size=32, **SMT_KW)
+    sd = fx.state_dict_for({k: tuple(v) for k, v in specs["option"].items()})
+    pol.load_state_dict(sd, strict=False)
+    pol.cuda()
+    return pol, sd
+
+
+def run_group_x3(pol, rgb, depth, index=None, rows=None):
+    eng = pol._engine()
+    B = rows if rows is not None else rgb.shape[0]
+    out = torch.full((B, 128), float("nan"), device="cuda")
+    nets = (C.POINTER(L.ResNet18) * 2)(C.pointer(eng["rgb"]), C.pointer(eng["depth"]))
+    imgs = (C.c_void_p * 2)(rgb.data_ptr(), depth.data_ptr())
+    outs = (C.c_void_p * 2)(out.data_ptr(), out.data_ptr() + 4 * 64)
+    chans, divs = (C.c_int * 2)(rgb.shape[3], depth.shape[3]), (C.c_float * 2)(255.0, 1.0)
+    u8 = (C.c_int * 2)(int(rgb.dtype == torch.uint8), 0)
+    nb = L.lib.avlen_resnet18_group_x3_workspace_bytes(2, B)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    L.call("avlen_resnet18_group_fwd_x3", nets, imgs, u8, chans, divs, outs, 128, 2, B, rgb.shape[1],
+           E.P(index) if index is not None else None, E.P(ws), nb, L.stream())
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("S", [64, 128, 256])
+@pytest.mark.parametrize("u8", [True, False])
+def test_x3_towers_match_oracle_on_white_noise(towers_x3, S, u8):
+    """`avlen_resnet18_group_fwd_x3` against the oracle's fp32 SMTCNN (smt_cnn.py:78-115) on WHITE-NOISE images -- what bench.py
+    feeds (uniform uint8 rgb, U[0,1) depth): the hardest input for the per-channel GroupNorm after the block mean.  Tolerance: 1e-3
+    of the feature scale (the north-star's), plain and row-indexed forms, bit-reproducible."""
+    pol, sd = towers_x3
+    g = torch.Generator().manual_seed(100 + S + int(u8))
+    B = 7
+    rgb8 = torch.randint(0, 256, (B, S, S, 3), generator=g, dtype=torch.uint8)
+    depth = torch.rand(B, S, S, 1, generator=g)
+    ref = R.smt_cnn(sd, "net.visual_encoder", {"rgb": rgb8.float(), "depth": depth})
+    rgb = rgb8.cuda() if u8 else rgb8.float().cuda()
+    out = run_group_x3(pol, rgb, depth.cuda())
+    assert torch.isfinite(out).all()
+    scale = float(ref.abs().max())
+    err = float((out.cpu() - ref).abs().max())
+    print(f"x3 towers S={S} u8={u8}: max |d| {err:.3e} on scale {scale:.3f}")
+    assert err <= 1e-3 * max(1.0, scale), (S, u8, err, scale)
+    assert torch.equal(out, run_group_x3(pol, rgb, depth.cuda()))                       # fixed-order statistics
+    # the PPO minibatch form: rows `idx` of the buffers read in place == the same rows gathered first
+    idx = torch.tensor([5, 0, 6, 2, 2], dtype=torch.int32, device="cuda")
+    a = run_group_x3(pol, rgb, depth.cuda(), index=idx, rows=5)
+    assert torch.equal(a, out[idx.long()])

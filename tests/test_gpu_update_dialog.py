@@ -157,3 +157,36 @@ def test_derived_weights_follow_a_dialog_update():
     torch.cuda.synchronize()
     assert float((after - before).abs().max()) > 1e-3            # the step reached the towers
     assert torch.equal(after, ref[:, :276])                       # and every derived copy followed it
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_update_dialog_with_the_text_tower_above_512_rows(precision):
+    """T * N = 608 stored steps: the frozen CLIP tower (no stub) sees more rows than one pass of the one-launch tower takes."""
+    Tb, Nb = 76, 8
+    torch.manual_seed(5)
+    pol = P.AudioNavDialogPolicy(savi_observation_space(), ActionSpace(4), pretraining=False, use_category_input=False,
+                                 num_steps=3, precision=precision, **SMT_KW).cuda()
+    agent = DDPPO(pol, 0.2, 2, 2, 0.5, 0.05, lr=2.5e-4, eps=1e-5, max_grad_norm=0.2, use_normalized_advantage=False)
+    st = RolloutStorage(Tb, Nb, savi_observation_space(), ActionSpace(4), 512, True, 3, 3, 3, 3, 3, 3, 276, 276, 308, 256,
+                        num_recurrent_layers=-1, max_dialog_len=77, use_state_memory=True, device="cuda")
+    g = torch.Generator().manual_seed(1)
+    for k, v in st.observations.items():
+        v[:Tb].copy_((torch.rand(v[:Tb].shape, generator=g) * (255 if k == "rgb" else 1)).to(v.dtype))
+    toks = torch.zeros(Tb, Nb, 77, dtype=torch.long)
+    ln = torch.randint(2, 73, (Tb, Nb), generator=g)
+    toks = torch.where(torch.arange(77).view(1, 1, 77) < ln.unsqueeze(-1), torch.randint(1, 49406, (Tb, Nb, 77), generator=g), toks)
+    toks[..., 0] = 49406
+    toks.scatter_(-1, ln.unsqueeze(-1), 49407)
+    st.all_dialog.copy_(toks)
+    st.o_actions.copy_(torch.randint(1, 4, (Tb, Nb), generator=g).float())
+    st.o_masks.fill_(1)
+    st.em_vln_masks.fill_(1.0)
+    st.step = Tb
+    sd0 = {k: v.detach().clone() for k, v in pol.state_dict().items()}
+    loss = agent.update_dialog(st)
+    torch.cuda.synchronize()
+    assert np.isfinite(float(loss)) and float(loss) > 0
+    sd = pol.state_dict()
+    assert all(torch.isfinite(v).all() for v in sd.values() if v.is_floating_point())
+    assert not torch.equal(sd["net.dialog_layer.weight"], sd0["net.dialog_layer.weight"])
+    assert torch.equal(sd["net.clip.text_projection"], sd0["net.clip.text_projection"])
