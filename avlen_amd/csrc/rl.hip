@@ -361,6 +361,31 @@ extern "C" int avlen_heads_fwd(const avlen_heads* h, const float* feats, int d, 
   return avlen_launch_status();
 }
 
+// CustomFixedCategorical.sample (common/utils.py:48-49 -> torch.multinomial, one draw per row) is the exponential race
+// argmax_a(p[a] / q[a]) with q ~ Exp(1) drawn from the HOST generator.  The noise does not depend on the
+// probabilities: the host draws it in the reference's order and uploads it, the race runs here -- IEEE fp32 division (-ffp-contract
+// off, no fast-math: the same quotient bits as the host's `probs / q`), first maximum wins (torch.argmax on the host) -- so the
+// action is the reference's for the same generator state, without the probabilities ever leaving the device.
+namespace {
+__global__ void sample_race_kernel(const float* __restrict__ probs, const float* __restrict__ noise, int64_t* __restrict__ action,
+                                   int B, int A) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float best = __fdiv_rn(probs[(long)b * A], noise[(long)b * A]);
+  int bi = 0;
+  for (int a = 1; a < A; a++) {
+    const float v = __fdiv_rn(probs[(long)b * A + a], noise[(long)b * A + a]);
+    if (v > best || (v != v && best == best)) { best = v; bi = a; }      // NaN ranks highest, as in torch.argmax
+  }
+  action[b] = bi;
+}
+}  // namespace
+extern "C" int avlen_sample_race(const float* probs, const float* noise, int64_t* action, int B, int A, hipStream_t stream) {
+  if (!probs || !noise || !action || B <= 0 || A <= 0) return AVLEN_ERR_ARG;
+  hipLaunchKernelGGL(sample_race_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, stream, probs, noise, action, B, A);
+  return avlen_launch_status();
+}
+
 extern "C" int avlen_ppo_loss_heads_bwd(const avlen_heads* h, const avlen_heads* g, const float* feats, int d, int A,
                                         const int64_t* actions, const float* old_log_probs, const float* adv,
                                         const int64_t* rl_masks, const float* value_preds, const float* returns,

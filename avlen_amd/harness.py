@@ -28,12 +28,13 @@ def sinusoid_table(n, d):
 
 class Workload:
     def __init__(self, num_envs, num_steps=150, spectrogram=(257, 101, 2), precision="bf16x3", pretraining=True,
-                 em_capacity=150, ppo_epoch=2, num_mini_batch=2, device="cuda", seed=0, sampling="host",
+                 em_capacity=150, ppo_epoch=2, num_mini_batch=2, device="cuda", seed=0, sampling="race",
                  with_dialog_policy=True, with_goal_policy=True, use_graphs=True, share_encoders=True, weight_seed=0,
                  launch_ahead=True, belief_predictor=False, cached_views=False, distractor=False,
                  dialog_tokens="after_option", dialog_process="fresh"):
         self.N, self.T, self.dev = num_envs, num_steps, torch.device(device)
         self.spec = spectrogram
+        sampling = os.environ.get("AVLEN_SAMPLING", sampling)          # A/B knob
         # WHEN the step's dialog tokens exist.  "after_option" (default) = the reference's data flow: `current_dialog` and
         # `agent_step` are written by the host loop that follows `act_option` (new query -> Speaker -> clip.tokenize,
         # ppo_trainer.py:347, 449-593), so the text tower and the dialog half of pi_l are issued only after pi_q's action has been
@@ -60,7 +61,11 @@ class Workload:
         # stream the first half of its graph (its state encoder, 0.16 ms, needs the towers only) queued behind all of pi_g (0.6 ms)
         # and so ran after the text tower it should have overlapped; behind pi_q it starts at 0.68 ms and only the dialog half is
         # left when the text embedding arrives: 30.3 k -> 33.2 k env-steps/s (kernel trace of a step: DESIGN section 0)
-        self._l_main = os.environ.get("AVLEN_L_STREAM", "main") == "main"
+        # dialog_tokens="after_option": the text tower cannot start before pi_q's action is known, so pi_l's state-encoder half should
+        # NOT sit on the caller's stream between pi_q and the text tower: there pi_l gets its own stream (AVLEN_L_STREAM=main / side
+        # = pi_g's / own)
+        self._l_where = os.environ.get("AVLEN_L_STREAM", "side" if dialog_tokens == "after_option" else "main")
+        self._l_main = self._l_where == "main"
         self._views_ahead = os.environ.get("AVLEN_VIEWS_AHEAD", "1") != "0"       # A/B knob
         self._next_views = None
         self._text_after = os.environ.get("AVLEN_TEXT_AHEAD", "1") == "2"     # 2: ordered after the current stream (debug)
@@ -102,6 +107,8 @@ class Workload:
                                        device=self.dev)
         self.belief = None
         self._act_buf = None
+        self._act_host = None
+        self.sampling = sampling
         if belief_predictor:        # use_belief_predictor: True in the interactive yamls (ppo_trainer.py:892); 65x26 spectrogram only
             import types
             from .belief_predictor import BeliefPredictor
@@ -240,7 +247,8 @@ class Workload:
                 self.pi_g.prefetch_act(obs, h, prev, v["masks"], em_goal, em_masks, stream=self._side[self._g_stream])
             if self.pi_l is not None:
                 self.pi_l.prefetch_act_dialog(obs, h, prev, v["masks_vln"], em_vln, em_dlg, v["em_vln_masks"], v["dialog"],
-                                              v["astep"], stream=None if self._l_main else self._side[1], dialog_later=later)
+                                              v["astep"], stream=None if self._l_main else self._side[0 if self._l_where == "own" else 1],
+                                              dialog_later=later)
         if self.launch_ahead and self._views_ahead and t + 1 < self.T:
             # the host is about to wait for pi_q's probabilities: slice the NEXT step's views now (fresh tensor objects every step,
             # as the trainer makes them; only the moment moves off the path between insert and the next forward's launch)
@@ -248,8 +256,7 @@ class Workload:
         values, unct, a_opt, lp_opt, h, row_opt, probs_opt = self.pi_q.act_option(
             obs, h, prev, v["masks"], em_opt, em_masks, v["qs"], v["lqi"])
         if ref:                                          # ppo_trainer.py:463-593: the host loop between act_option and act / act_dialog
-            ah = self.pi_q.last_host_action
-            self._host_dialog_loop(t, (ah if ah is not None else a_opt.cpu()).view(-1).numpy())
+            self._host_dialog_loop(t, self.pi_q.host_actions("option").view(-1).numpy())
         if self.launch_ahead and later and self.pi_l is not None:
             self.pi_l.dialog_ready()                     # current_dialog / agent_step hold this step's values from here on
         dg = ro.em_dim_goal
@@ -283,6 +290,14 @@ class Workload:
             if self._act_buf is None:
                 self._act_buf = torch.empty_like(o["a_l"])
             actions = torch.where(a_opt == 1, o["a_l"], actions, out=self._act_buf)       # queried envs follow pi_l
+        if self.sampling != "host":
+            # the simulator needs the step's actions on the host (envs.step, ppo_trainer.py:864): ONE device-to-host copy per step;
+            # with sampling="host" the three policies' actions were drawn there already (three probability round trips instead)
+            if self._act_host is None:
+                self._act_host = [torch.empty(actions.shape, dtype=actions.dtype, pin_memory=True) for _ in range(4)]
+            ah = self._act_host[t & 3]
+            ah.copy_(actions, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
         if self.belief is not None:                 # beliefs of the NEW observation, written in place before it is stored
             self.belief.update(v["nxt"], v["dones"])
         if return_outs:                             # graph outputs are overwritten by the next replay

@@ -7,7 +7,8 @@ operation below `act* / evaluate_actions* / get_value*` is a HIP kernel launched
 (include/avlen_hip.h); PyTorch provides device memory, the stream and the host RNG.
 
 Sampling: `Categorical.sample()` of the reference CPU path consumes the torch CPU generator
-(SURVEY App. B).  With sampling="host" (default) the (B,A) probabilities are brought to the host and the
+(SURVEY App. B).  sampling="race": the host draws the race's noise in the reference's order, the race runs on the device
+(avlen_sample_race) -- same actions, no host round trip.  With sampling="host" (default) the (B,A) probabilities are brought to the host and the
 action is drawn from that generator in the same order -> bit-exact actions for a fixed seed;
 sampling="device" keeps everything on the GPU (like the reference would on a CUDA device).
 """
@@ -473,6 +474,7 @@ class Policy(nn.Module):
         self._deferred = None                 # ... the graph whose second half dialog_ready() replays
         self._later = None                    # ... (which, arg key, outputs, stream, all_dialog, agent_step) of that prefetch
         self.last_host_action = None          # sampling="host": pinned (B,1) int64 of the most recent draw
+        self._act_host = {}                   # head set -> (pinned actions, event or None): see host_actions()
         self._param_epoch = 0                 # bumped by mark_params_changed (derived state keyed on the weights: the text memo)
         self._pinned = {}
         self._eng = None
@@ -576,9 +578,26 @@ class Policy(nn.Module):
         A = self.dim_actions_option if which == "option" else self.dim_actions
         dev = feats.device
         probs = out["probs"]
+        if out.get("finished") and action is None and need_sample and not deterministic:
+            return out                                   # sampled right behind the forward at prefetch time (sampling="race")
         if action is None and need_sample:
             if deterministic:
                 action = probs.argmax(dim=-1, keepdim=True)
+            elif self.sampling == "race":
+                # the host draws the noise in the reference's order (it does not depend on the probabilities) and uploads it; the
+                # race argmax(p / q) runs on the device (avlen_sample_race: IEEE division, first maximum): the reference's action for
+                # the same generator state, and no probabilities cross PCIe, no host synchronisation
+                qh, qd = self._noise_bufs(which, B, A, dev)
+                qh.exponential_(1)
+                qd.copy_(qh, non_blocking=True)
+                action = self._result_bufs(which, B, dev)[0]
+                L.call("avlen_sample_race", E.P(probs), E.P(qd), E.P(action), B, A, L.stream())
+                ah = self._host_action(B)                # the actions start their way to the host right behind the race (512 B)
+                ah.copy_(action, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                self._act_host[which] = (ah, ev)
+                self.last_host_action = None
             elif self.sampling == "host":
                 # == torch.multinomial's exponential race on the host generator; the noise does not depend on the
                 # probabilities, so it is drawn BEFORE waiting for them (same generator order as the reference)
@@ -591,6 +610,7 @@ class Policy(nn.Module):
                 ah = self._host_action(B)
                 torch.argmax(pc / q, dim=-1, keepdim=True, out=ah)
                 self.last_host_action = ah               # the trainer's host loop reads the option actions (ppo_trainer.py:463)
+                self._act_host[which] = (ah, None)
                 action = self._result_bufs(which, B, dev)[0]
                 action.copy_(ah, non_blocking=True)
             else:
@@ -624,6 +644,27 @@ class Policy(nn.Module):
         if t is None:
             t = self._pinned[("ones", R)] = torch.ones(R, dtype=torch.int64, device=next(self.parameters()).device)
         return t
+
+    def _noise_bufs(self, which, B, A, dev):
+        """(pinned host, device) noise buffers of one head set: a ring of 8 host slots (an upload is consumed long before its slot
+        returns), one device buffer per slot."""
+        ring = self._pinned.get(("noise", which, B))
+        if ring is None:
+            ring = self._pinned[("noise", which, B)] = [[(torch.empty(B, A, pin_memory=True), torch.empty(B, A, device=dev))
+                                                         for _ in range(8)], 0]
+        ring[1] = (ring[1] + 1) % 8
+        return ring[0][ring[1]]
+
+    def host_actions(self, which="option"):
+        """The most recent SAMPLED actions of head set `which` on the host ((B,1) int64, pinned; overwritten eight draws later).
+        sampling="host": drawn there; sampling="race": copied right behind the race kernel -- this waits for that copy only (the
+        trainer's query loop, ppo_trainer.py:463, reads the option actions)."""
+        r = self._act_host.get(which)
+        if r is None:
+            return None
+        if r[1] is not None:
+            r[1].synchronize()
+        return r[0]
 
     def _host_action(self, B):
         """Pinned staging buffer for the sampled actions (ring of 8: an upload is consumed long before its slot returns)."""
@@ -744,6 +785,11 @@ class Policy(nn.Module):
         with ctx:
             out = self._forward(which, *net_args)
             done = torch.cuda.Event()
+            if self.sampling == "race":
+                # the race goes out right behind the forward on ITS stream (noise drawn now: prefetch_* calls are made in the order
+                # of the act* calls that follow, so the host generator is consumed in the reference's order)
+                out = (out[0], self._finish(which, out[0][0], out[1]))
+                out[1]["finished"] = True
             if self.sampling == "host":
                 # the probabilities start their way to the host right behind this forward (pinned buffer + event)
                 probs = out[1]["probs"]
@@ -798,15 +844,24 @@ class Policy(nn.Module):
         cur = torch.cuda.current_stream()
         run_on = stream if stream is not None else cur
         ctx = torch.cuda.stream(run_on) if stream is not None else contextlib.nullcontext()
+        # The text tower runs on the CALLER's stream -- the one the host loop wrote the tokens on, behind pi_q's forward and nothing
+        # else if pi_l was given its own stream -- and pi_l's stream waits for its event before the second half: the tower then
+        # overlaps pi_g and pi_l's state-encoder half instead of queueing behind them.
+        if stream is not None and self.net._text_read is not None:
+            cur.wait_event(self.net._text_read)          # the previous step's reader of the static embedding buffer
+        self.net.prefetch_text(self, tokens, cur, after_current=False, same_stream=True)
+        if stream is not None:
+            stream.wait_event(self.net._text[3])
         with ctx:
-            # everything in stream order on pi_l's own stream: text graph -> agent_step refresh -> second half
-            self.net.prefetch_text(self, tokens, run_on, after_current=False, same_stream=True)
             if torch.is_tensor(g.static[8]) and g.static[8].data_ptr() != agent_step.data_ptr():
                 L.multi_copy([(g.static[8], _f32(agent_step))])
             g.graph2.replay()
             self.net._text_read = torch.cuda.Event()
             self.net._text_read.record(run_on)
             done = torch.cuda.Event()
+            if self.sampling == "race":
+                out = (out[0], self._finish(which, out[0][0], out[1]))
+                out[1]["finished"] = True
             if self.sampling == "host":
                 probs = out[1]["probs"]
                 pk = (which, tuple(probs.shape))

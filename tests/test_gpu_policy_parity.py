@@ -117,6 +117,17 @@ def test_option_policy_matches_reference(specs, pre, M):
     det = pol.act_option(obs, h0, pa, ones, mem, mk, qs, lqi, deterministic=True)[2]
     assert np.array_equal(det.cpu().numpy(), g["mode"])
     close(pol.get_value_option(obs, h0, pa, ones, mem, mk, qs, lqi), g["get_value"])
+    # sampling="race": the host draws the race's noise in the same order, the race itself runs on the device (avlen_sample_race):
+    # the same action for the same generator state, and the generator ends in the same state
+    torch.manual_seed(1234)
+    pol.act_option(obs, h0, pa, ones, mem, mk, qs, lqi)
+    end_host = torch.get_rng_state()
+    pol.sampling = "race"
+    torch.manual_seed(1234)
+    a3, lp3 = pol.act_option(obs, h0, pa, ones, mem, mk, qs, lqi)[2:4]
+    assert np.array_equal(a3.cpu().numpy(), g["sampled"]) and torch.equal(torch.get_rng_state(), end_host)
+    close(lp3, g["sampled_log_prob"])
+    assert np.array_equal(pol.host_actions("option").numpy(), g["sampled"])
 
 
 @pytest.mark.parametrize("pre", [False, True])
