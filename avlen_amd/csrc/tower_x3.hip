@@ -69,17 +69,22 @@ __device__ __forceinline__ void l1_fill(const T* __restrict__ img, float scale, 
 // ========================================================================================================================
 // The 64 x 64 x 16 activation as a compensated pair is 256 KiB: twice a CU's LDS.  The workgroup therefore walks every conv in
 // two half-image passes over ONE LDS frame (34 rows x 66 pixels x 32 B per plane, hi + lo): the top half of a conv's input is
-// written into the frame by the previous conv's normalise-and-split pass (registers -> LDS, never leaves the CU), the bottom
-// half comes back from a per-image scratch image (the only global round trip: ~135 KB out + ~135 KB in per conv, L2 / Infinity
-// Cache resident) by LDS-DMA.  Raw outputs of both halves stay in registers (128 fp32 per lane) until the GroupNorm statistics
-// of the whole image are known.  The residual (block input) is an fp32 scratch image read and written in place by its owner lane.
+// written into the frame by the previous conv's normalise-and-split pass (registers -> LDS), and the BOTTOM half never leaves the
+// CU either: the normalised, split values of rows 32 .. 63 stay in the 64 registers their raw accumulators occupied (a packed
+// hi | lo pair takes the space of the fp32 value) until the next conv's bottom pass writes them into the frame (image row 31, its
+// halo, waits in a one-row side buffer).  (Until round 4 the bottom half made a global round trip per conv -- 128 KB out, 128 KB
+// back by LDS-DMA, ~10 k cycles of exposed latency each.)  Raw outputs of both halves stay in registers (128 fp32 per lane) until
+// the GroupNorm statistics of the whole image are known.  Only BLOCK outputs (stem, block 0, block 1) are written to the scratch
+// images: the next block's residual re-reads them, the layer 2-4 body reads the last one.
 constexpr int RTH = 512;
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page_x3[4096];
 constexpr int L1_PLANE = 71 * 1024;                         // 34 x 66 x 32 B = 71,808 B, rounded up to whole 1 KiB DMA pieces
 constexpr int L1_PART_OFF = 2 * L1_PLANE;                   // [8 waves][16 ch][2] fp32
 constexpr int L1_COEF_OFF = L1_PART_OFF + 8 * 16 * 2 * 4;   // scale[16] shift[16]
 constexpr int L1_GB_OFF = L1_COEF_OFF + 32 * 4;             // gamma | beta of the 5 GroupNorms
-constexpr int L1_LDS = L1_GB_OFF + 5 * 32 * 4;
+constexpr int L1_SIDE_OFF = L1_GB_OFF + 5 * 32 * 4;         // image row 31 of the current activation (one frame row, hi | lo): the halo
+constexpr int L1_SIDE_PLANE = HCOLS * 32;                   // row of the bottom-half pass
+constexpr int L1_LDS = L1_SIDE_OFF + 2 * L1_SIDE_PLANE;
 constexpr int S70 = 70;
 static_assert((S70 * S70 + 2) * 8 <= L1_PLANE && L1_LDS <= 160 * 1024, "layer-1 LDS budget");
 constexpr long APLANE = 64L * 64 * 16;                      // elements of one plane of the scratch activation image
@@ -165,7 +170,7 @@ __device__ __forceinline__ void l1_res_prefetch(L1Ring& ring, const bf16* __rest
 }
 
 template <bool RES, bool ALLROWS, bool TOLDS>
-__device__ __forceinline__ void l1_apply(const f32x4 (&acc)[32], L1Ring& ring, char* lds, bf16* __restrict__ dst, int wave, int r16, int q) {
+__device__ __forceinline__ void l1_apply(f32x4 (&acc)[32], L1Ring& ring, char* lds, bf16* __restrict__ dst, int wave, int r16, int q) {
   const float* coef = reinterpret_cast<const float*>(lds + L1_COEF_OFF);
   float sc[4], sh[4];
 #pragma unroll
@@ -177,8 +182,8 @@ __device__ __forceinline__ void l1_apply(const f32x4 (&acc)[32], L1Ring& ring, c
   for (int g = 0; g < 8; g++) {                             // g = (h, rr): image row 32 h + 4 wave + rr
     const int h = g >> 2, rr = g & 3;
     if (RES && g + 3 < 8) l1_res_fetch(ring, dst, le, g + 3);
-    // rows 0 .. 30 of an intermediate activation never leave the CU (the next conv's top half is written to LDS below)
-    const bool to_global = ALLROWS || h == 1 || (rr == 3 && wave == 7);
+    // an intermediate activation (a block's conv1 output) never leaves the CU: top half -> LDS frame, bottom half -> registers
+    const bool to_global = ALLROWS;
 #pragma unroll
     for (int mt = 0; mt < 4; mt++) {
       const int te = ((32 * h + rr) * 64 + mt * 16) * 16;
@@ -207,8 +212,41 @@ __device__ __forceinline__ void l1_apply(const f32x4 (&acc)[32], L1Ring& ring, c
         *reinterpret_cast<uint2*>(lds + ll0 + tl) = hh;
         *reinterpret_cast<uint2*>(lds + ll0 + tl + L1_PLANE) = ll;
       }
+      if (TOLDS && h == 0 && rr == 3 && wave == 7) {        // image row 31: the halo row of the next conv's bottom pass
+        const int sl = L1_SIDE_OFF + h16(0, r16 + 1, q >> 1) + (q & 1) * 8 + mt * 16 * 32;
+        *reinterpret_cast<uint2*>(lds + sl) = hh;
+        *reinterpret_cast<uint2*>(lds + sl + L1_SIDE_PLANE) = ll;
+      }
+      // the bottom half of the next conv's input waits in the registers of its own raw values (l1_store_bottom)
+      if (TOLDS && h == 1) acc[(h * 4 + rr) * 4 + mt] = (f32x4){__uint_as_float(hh.x), __uint_as_float(hh.y), __uint_as_float(ll.x), __uint_as_float(ll.y)};
     }
     __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// Bottom pass of a conv: the packed pairs of image rows 32 .. 63 (acc[16 .. 31], see l1_apply) -> frame rows 1 .. 32; image row 31
+// (side buffer) -> frame row 0; frame row 33 (image row 64) = zero.  The left / right border pixels of rows 1 .. 33 are still zero
+// from zero_top_border (nothing but that and the direct writes of pixels 1 .. 64 ever touches the frame).
+__device__ __forceinline__ void l1_store_bottom(const f32x4 (&acc)[32], char* lds, int tid, int wave, int r16, int q) {
+  unsigned ll0 = (unsigned)(h16(4 * wave + 1, r16 + 1, q >> 1) + (q & 1) * 8);
+  asm volatile("" : "+v"(ll0));
+#pragma unroll
+  for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) {
+      const f32x4& a = acc[(4 + rr) * 4 + mt];
+      const int tl = (rr * HCOLS + mt * 16) * 32;
+      *reinterpret_cast<uint2*>(lds + ll0 + tl) = make_uint2(__float_as_uint(a[0]), __float_as_uint(a[1]));
+      *reinterpret_cast<uint2*>(lds + ll0 + tl + L1_PLANE) = make_uint2(__float_as_uint(a[2]), __float_as_uint(a[3]));
+    }
+  for (int i = tid; i < 4 * 132; i += RTH) {                // 16-byte chunks: 132 per frame row and plane
+    const int zero = i >= 2 * 132, j = i - zero * 2 * 132, pl = j >= 132, c = j - pl * 132;
+    if (!zero) {                                            // frame row 0 <- side buffer (whose border pixels 0 / 65 are never written)
+      uint4 v = *reinterpret_cast<const uint4*>(lds + L1_SIDE_OFF + pl * L1_SIDE_PLANE + c * 16);
+      if (c < 2 || c >= 130) v = make_uint4(0u, 0u, 0u, 0u);
+      *reinterpret_cast<uint4*>(lds + pl * L1_PLANE + c * 16) = v;
+    } else                                                    // frame row 33 (image row 64) <- zero
+      *reinterpret_cast<uint4*>(lds + pl * L1_PLANE + 33 * HCOLS * 32 + c * 16) = make_uint4(0u, 0u, 0u, 0u);
   }
 }
 
@@ -384,48 +422,56 @@ __device__ __forceinline__ void l1_body(const L1Args& args, int g, int img, char
 #pragma unroll
   for (int cj = 0; cj < 2; cj++) {                          // cj is static: the residual ring lives only inside a block's conv2
     const int ci = 2 * blk + cj;
-    bf16x8 wh[5], wl[5];
+    // INPUT-ROW-STATIONARY k-steps (K = 9 taps x 16 channels = 4.5 steps of 32): a step pairs two taps through the lane quarter
+    // (q >> 1 selects the tap, q & 1 the 8-channel chunk).  Pairing taps of ONE kernel row makes a fragment of input row R serve
+    // three output rows:
+    //   A(R) = row R, pixels x | x + 1   -> output rows R, R - 1, R - 2 with the weights of (ky, 0 | 1), ky = 0, 1, 2
+    //   B(R) = row R | row R + 1, pixel x + 2 -> output row R with the weights of (0, 2) | (1, 2); its first half is all step
+    //          C = (2, 2) | zero needs: output row R - 2 reuses B(R)'s registers with the weights [(2, 2) | 0]
+    // 12 fragment pairs (hi + lo) per 16-pixel column of a wave's four output rows instead of 20 -- the output-stationary loop was
+    // LDS-bandwidth-bound (2 KB of fragments per three MFMAs) -- and still 5 steps per output tile.
+    bf16x8 wh[5], wl[5];                                    // A0 A1 A2 B C
 #pragma unroll
     for (int s = 0; s < 5; s++) {
-      const int k = 32 * s + 8 * q;
-      if (k < 144) {
-        wh[s] = *reinterpret_cast<const bf16x8*>(t.wh[1 + ci] + (long)r16 * 144 + k);
-        wl[s] = *reinterpret_cast<const bf16x8*>(t.wl[1 + ci] + (long)r16 * 144 + k);
+      const int hi_tap = q >> 1;
+      const int tap = s < 3 ? 3 * s + hi_tap : s == 3 ? (hi_tap ? 5 : 2) : 8;
+      if (s < 4 || hi_tap == 0) {
+        wh[s] = *reinterpret_cast<const bf16x8*>(t.wh[1 + ci] + (long)r16 * 144 + tap * 16 + (q & 1) * 8);
+        wl[s] = *reinterpret_cast<const bf16x8*>(t.wl[1 + ci] + (long)r16 * 144 + tap * 16 + (q & 1) * 8);
       } else { wh[s] = zero_frag(); wl[s] = zero_frag(); }
     }
-    int rd[5];
-#pragma unroll
-    for (int s = 0; s < 5; s++) {
-      int tap = 2 * s + (q >> 1);
-      if (tap > 8) tap = 8;
-      const int ky = tap / 3, kx = tap - ky * 3;
-      rd[s] = h16(4 * wave + ky, r16 + kx, q & 1);
-    }
+    const int rdA = h16(4 * wave, r16 + (q >> 1), q & 1);   // + (R * HCOLS + 16 mt) * 32: input row R of the wave, column tile mt
+    const int rdB = h16(4 * wave + (q >> 1), r16 + 2, q & 1);
+    const int rdC = h16(4 * wave, r16 + 2, q & 1);
 #pragma unroll
     for (int h = 0; h < 2; h++) {
       if (h == 1) {
-        // the scratch image was written by this workgroup's previous normalise pass: stores retired, then everyone has left the
-        // top half before the DMA overwrites the frame
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        l1_load_half<L1_PLANE>(src, 1, lds, wave, lane);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();                                      // everyone has left the top half
+        l1_store_bottom(acc, lds, tid, wave, r16, q);
       }
-      __syncthreads();
+      lds_barrier();
       if (h == 1) X3_STAMP(6 + 5 * ci);
 #pragma unroll
-      for (int rr = 0; rr < 4; rr++)
+      for (int mt = 0; mt < 4; mt++) {
+        f32x4 a[4];
 #pragma unroll
-        for (int mt = 0; mt < 4; mt++) {
-          f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int rr = 0; rr < 4; rr++) a[rr] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int s = 0; s < 5; s++) {
-            const int off = rd[s] + (rr * HCOLS + mt * 16) * 32;
-            a = mma3(wh[s], wl[s], *reinterpret_cast<const bf16x8*>(lds + off), *reinterpret_cast<const bf16x8*>(lds + L1_PLANE + off), a);
-          }
-          acc[(h * 4 + rr) * 4 + mt] = a;
-          __builtin_amdgcn_sched_barrier(0);
+        for (int R = 0; R < 6; R++) {
+          const int off = (R * HCOLS + mt * 16) * 32;
+          const bf16x8 xah = *reinterpret_cast<const bf16x8*>(lds + rdA + off), xal = *reinterpret_cast<const bf16x8*>(lds + L1_PLANE + rdA + off);
+          const int rb = (R < 4 ? rdB : rdC) + off;         // rows 4, 5 are read for step C only (its second half has zero weights)
+          const bf16x8 xbh = *reinterpret_cast<const bf16x8*>(lds + rb), xbl = *reinterpret_cast<const bf16x8*>(lds + L1_PLANE + rb);
+#pragma unroll
+          for (int ky = 0; ky < 3; ky++)
+            if (R - ky >= 0 && R - ky < 4) a[R - ky] = mma3(wh[ky], wl[ky], xah, xal, a[R - ky]);
+          if (R < 4) a[R] = mma3(wh[3], wl[3], xbh, xbl, a[R]);
+          if (R >= 2) a[R - 2] = mma3(wh[4], wl[4], xbh, xbl, a[R - 2]);
         }
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) acc[(h * 4 + rr) * 4 + mt] = a[rr];
+        __builtin_amdgcn_sched_barrier(0);
+      }
       X3_STAMP(5 + 5 * ci + 2 * h);
     }
     if (cj == 1) l1_res_prefetch(ring, dst, wave, r16, q);
