@@ -48,12 +48,21 @@ struct ClipArgs {
   long long* prof;                                          // lab builds (AVLEN_CT_PROF): per-workgroup phase cycle totals [2 B][8]
   unsigned* flags; char* xchg; int B;                       // K / V hand-off of the 5-tile dialogs: flag word per (dialog, column half), slots
   unsigned* xflags; char* xslots;                           // partial-sum exchange between the two column halves: flag per workgroup, 2 slots each
-  // device-side work list (memoised tower, avlen_clip_text_cached_fwd): pair i < *count carries dialog row_idx[i]; null = all B rows
-  const int* row_idx; const int* count;
+  // work list built on the device by clip_group_kernel: groups[g], g < ngroups[0]; the launch whose column split matches
+  // (ngroups * 4 <= max_wg4: the 4-way launch, else the 2-way one) runs, the other one's workgroups exit at once
+  const struct ClipGroup* groups; const int* ngroups; int max_wg4;
+  const uint4* wstream4; long frags_per_wave4;              // the 4-way column split's weight streams (32 of them)
+  char* xslots2;                                            // 4-way exchange: finished column tiles (2 x 32 KB per workgroup)
 };
+// A workgroup set carries up to four 16-row tiles.  kind 0: whole dialogs PACKED into the tiles (dialog d[i], its tile lt[i], its
+// live length L[i] for tile i; nt tiles) -- the attention of a tile sees the keys of its own dialog only; kind 1 / 2: the first
+// (tiles 0 .. 2, publishes K / V) / second (tiles 3 .. 4, fetches them) row half of a 5-tile dialog.
+struct ClipGroup { int nt, kind, d[4], lt[4], L[4], pad[2]; };
+static_assert(sizeof(ClipGroup) == 64, "group table stride");
 // A hand-off that never arrives (partner workgroup lost): the dialog's output row is poisoned with NaN -- a stale or garbage
 // embedding would flow into the rollout unnoticed (the GRU sequence kernels do the same, train_gru.hip)
-#define CT_GIVE_UP() do { if (threadIdx.x < 128) *reinterpret_cast<float4*>(a.E + (long)b * 512 + 4 * threadIdx.x) = \
+#define CT_GIVE_UP() do { if (threadIdx.x < 128) for (int i_ = 0; i_ < NT; i_++) \
+    *reinterpret_cast<float4*>(a.E + (long)td[i_] * 512 + 4 * threadIdx.x) = \
     make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")); return; } while (0)
 #ifdef AVLEN_CT_PROF
 #define CT_T0() long long ct_t = __builtin_amdgcn_s_memtime(); long long ct_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
@@ -80,7 +89,7 @@ __device__ __forceinline__ uint4 lds16(const char* p) { return *reinterpret_cast
 // 16 nt + 4 q + r) so P stays in registers; every key tile is computed and the causal mask does the rest (no branches: a masked
 // tile costs two MFMAs, a branch would cut the block).  The output overwrites the unit's own Q rows.
 template <bool F16, int CT_MT>
-__device__ __forceinline__ void clip_attn_unit(char* lds, int ah, int mt, int r16, int q) {
+__device__ __forceinline__ void clip_attn_unit(char* lds, int ah, int mt, int r16, int q, int kstart) {
   const char* Qb = lds + QO_OFF + ah * 80 * QK_ROW;
   const char* Kb = lds + KS_OFF + ah * 80 * QK_ROW;
   const char* Vb = lds + VS_OFF + ah * 96 * QK_ROW;
@@ -101,7 +110,8 @@ __device__ __forceinline__ void clip_attn_unit(char* lds, int ah, int mt, int r1
   for (int nt = 0; nt < CT_MT; nt++)
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-      const float v = (16 * nt + 4 * q + r <= qi) ? sacc[nt][r] : -INFINITY;
+      const int kidx = 16 * nt + 4 * q + r;               // causal, and (packed dialogs) only the query's own dialog: rows >= kstart
+      const float v = (kidx <= qi && kidx >= kstart) ? sacc[nt][r] : -INFINITY;
       sacc[nt][r] = v;
       mx = fmaxf(mx, v);
     }
@@ -156,8 +166,10 @@ __device__ __forceinline__ int clip_kv_lds(int idx16) {      // 16-byte chunk in
   const int col = idx16 & 7, row = (idx16 >> 3) % CT_XROWS, head = (idx16 / (8 * CT_XROWS)) & 1, kv = idx16 / (16 * CT_XROWS);
   return (kv ? VS_OFF + head * 96 * QK_ROW : KS_OFF + head * 80 * QK_ROW) + row * QK_ROW + col * 16;
 }
-__device__ __forceinline__ void clip_publish_kv(const ClipArgs& a, const char* lds, int b, int seq0, int tid) {
-  char* slot = a.xchg + ((long)b * CT_SLOTS + seq0) * CT_SLOT;
+// bslot: flag word of the (dialog, column part); slot: index of the 24 KB slot (dialog, column part, layer, head pair)
+__device__ __forceinline__ void clip_publish_kv(const ClipArgs& a, const char* lds, int bslot, long slot_i, int seq0, int tid) {
+  const int b = bslot;
+  char* slot = a.xchg + slot_i * CT_SLOT;
   unsigned lo16 = (unsigned)tid;
   asm volatile("" : "+v"(lo16));
 #pragma unroll
@@ -171,7 +183,7 @@ __device__ __forceinline__ void clip_publish_kv(const ClipArgs& a, const char* l
   __syncthreads();
   if (tid == 0) __hip_atomic_store((gu32*)(a.flags + b), (unsigned)(seq0 + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ bool clip_fetch_kv(const ClipArgs& a, char* lds, int b, int seq0, int tid) {
+__device__ __forceinline__ bool clip_fetch_kv(const ClipArgs& a, char* lds, int b, long slot_i, int seq0, int tid) {
   volatile int* ok = reinterpret_cast<volatile int*>(lds + PART_OFF);      // the LayerNorm partials are idle here
   if (tid == 0) {
     unsigned spins = 0;
@@ -185,7 +197,7 @@ __device__ __forceinline__ bool clip_fetch_kv(const ClipArgs& a, char* lds, int 
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    // sc1 form (see clip_exchange): every load of the slot is an sc1 load
   __syncthreads();
   if (*ok == 0) return false;
-  const char* slot = a.xchg + ((long)b * CT_SLOTS + seq0) * CT_SLOT;
+  const char* slot = a.xchg + slot_i * CT_SLOT;
   unsigned lo16 = (unsigned)tid;
   asm volatile("" : "+v"(lo16));
   f32x4 v[CT_SLOT / 16 / CT_TH];
@@ -209,13 +221,13 @@ __device__ __forceinline__ bool clip_fetch_kv(const ClipArgs& a, char* lds, int 
 // registers to its own slot (two slots, ping-pong: the partner publishes exchange k + 1 only after it has read slot k), raises its
 // flag, waits for the partner's and adds the partner's slot: both end with the same x (one commutative addition).
 constexpr int CT_XSLOT = 4 * 4 * CT_TH * 16;                // up to 4 row tiles x 4 column tiles x 512 lanes x 16 B = 128 KB
-template <int NT>
-__device__ __forceinline__ bool clip_exchange(const ClipArgs& a, char* lds, f32x4 (&xr)[NT][4], int unit, unsigned seq, int tid) {
+template <int NT, int SPLIT>
+__device__ __forceinline__ bool clip_exchange_pair(const ClipArgs& a, char* lds, f32x4 (&xr)[NT][4], int unit, unsigned seq, int tid) {
   static_assert(NT <= 4, "exchange slot size");
+  const int ubase = unit & ~(SPLIT - 1), me = unit & (SPLIT - 1);      // the SPLIT column parts of a group have consecutive units
   // uniform slot bases (SGPRs) + ONE laundered 32-bit lane offset: the per-access addresses are invariant across the layer loop
   // and would otherwise be hoisted out of it and kept alive (96 address pairs: 600 spilled registers)
   char* mine = a.xslots + ((long)unit * 2 + (seq & 1)) * CT_XSLOT;
-  const char* theirs = a.xslots + ((long)(unit ^ 1) * 2 + (seq & 1)) * CT_XSLOT;
   unsigned lo8 = (unsigned)tid * 2u, lo16 = (unsigned)tid;
   asm volatile("" : "+v"(lo8), "+v"(lo16));
 #pragma unroll
@@ -233,9 +245,13 @@ __device__ __forceinline__ bool clip_exchange(const ClipArgs& a, char* lds, f32x
     __hip_atomic_store((gu32*)(a.xflags + unit), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned spins = 0;
     int good = 1;
-    while (__hip_atomic_load((gu32*)(a.xflags + (unit ^ 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seq) {
-      __builtin_amdgcn_s_sleep(4);
-      if (++spins > (1u << 24)) { good = 0; break; }        // seconds without the partner: give up (garbage output) rather than hang
+#pragma unroll
+    for (int k = 1; k < SPLIT; k++) {
+      const int other = ubase + ((me + k) & (SPLIT - 1));
+      while (good && __hip_atomic_load((gu32*)(a.xflags + other), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seq) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > (1u << 24)) good = 0;                 // seconds without a partner: give up (NaN output) rather than hang
+      }
     }
     *ok = good;
   }
@@ -246,7 +262,9 @@ __device__ __forceinline__ bool clip_exchange(const ClipArgs& a, char* lds, f32x
   // load to registers (they bypass this CU's L1, which may hold the slot's lines of two exchanges ago) -- so the agent-scope acquire
   // (buffer_inv sc1, ~1.7 us) is not needed.  hipcc does not count the loads of an asm statement: the waits are explicit, and the
   // registers are operands of the wait so that no use can be scheduled in front of it.
-  {
+#pragma unroll
+  for (int k = 1; k < SPLIT; k++) {                          // the partners in a fixed order per workgroup: run-to-run bit-reproducible
+    const char* theirs = a.xslots + ((long)(ubase + ((me + k) & (SPLIT - 1))) * 2 + (seq & 1)) * CT_XSLOT;
     f32x4 v[NT][4];
 #pragma unroll
     for (int i = 0; i < NT; i++)
@@ -267,15 +285,138 @@ __device__ __forceinline__ bool clip_exchange(const ClipArgs& a, char* lds, f32x
   return true;
 }
 
+
+// ---- the same among FOUR column parts: reduce-scatter + all-gather ----
+// A part would have to read three whole partials (3 x NT x 32 KB) one after the other -- measured 11 us per exchange.  Instead part k
+// OWNS column tile j == k of every wave: (1) everybody writes its whole partial and raises its flag (sequence 2 s - 1), (2) the owner
+// reads the three partners' copies of ITS column tile -- 3 NT loads per lane, all in flight -- adds them in a fixed order and writes
+// the finished tile to its second slot, flag 2 s, (3) everybody reads the three finished tiles it does not own.  Two round trips with
+// every load of a round in flight at once, and all four parts end with bit-identical residual rows (each column is summed once).
+constexpr int CT_XSLOT2 = 4 * CT_TH * 16;                   // finished column tile: up to 4 row tiles x 512 lanes x 16 B = 32 KB
+template <int NT>
+__device__ __forceinline__ bool clip_exchange4(const ClipArgs& a, char* lds, f32x4 (&xr)[NT][4], int unit, unsigned seq, int tid) {
+  static_assert(NT <= 4, "exchange slot size");
+  const int ubase = unit & ~3, me = unit & 3;
+  char* mine = a.xslots + ((long)unit * 2 + (seq & 1)) * CT_XSLOT;
+  char* mine2 = a.xslots2 + ((long)unit * 2 + (seq & 1)) * CT_XSLOT2;
+  unsigned lo16 = (unsigned)tid;
+  asm volatile("" : "+v"(lo16));
+  volatile int* ok = reinterpret_cast<volatile int*>(lds + PART_OFF);
+  auto wait_all = [&](unsigned want) {                       // lanes 0 .. 2 of wave 0 poll one partner each
+    if (tid < 3) {
+      const int other = ubase + ((me + 1 + tid) & 3);
+      unsigned spins = 0;
+      int good = 1;
+      while (__hip_atomic_load((gu32*)(a.xflags + other), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1u << 24)) { good = 0; break; }
+      }
+      if (!good) *ok = 0;
+    }
+  };
+  // ---- round 1: whole partials out
+#pragma unroll
+  for (int i = 0; i < NT; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (j == me) continue;                                 // (uniform) the tile this part owns stays in its registers
+      const float4* dstp = reinterpret_cast<const float4*>(mine + (long)(i * 4 + j) * CT_TH * 16) + lo16;
+      asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dstp), "v"(xr[i][j]) : "memory");
+    }
+  if (tid == 0) *ok = 1;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store((gu32*)(a.xflags + unit), 2u * seq - 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  wait_all(2u * seq - 1u);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  __syncthreads();
+  if (*ok == 0) return false;
+  {
+    f32x4 v[3][NT];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int other = ubase + ((me + 1 + k) & 3);
+      const char* theirs = a.xslots + ((long)other * 2 + (seq & 1)) * CT_XSLOT;
+#pragma unroll
+      for (int i = 0; i < NT; i++) {
+        // xr[i][me] lives at tile index i * 4 + me; `me` is uniform but not a compile-time constant: the offset is scalar arithmetic
+        const float4* src = reinterpret_cast<const float4*>(theirs + (long)(i * 4 + me) * CT_TH * 16) + lo16;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[k][i]) : "v"(src) : "memory");
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NT; i++)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0][i]), "+v"(v[1][i]), "+v"(v[2][i]) :: "memory");
+    // own tile + partners me+1, me+2, me+3: a fixed order for this owner; nobody else sums this tile
+#pragma unroll
+    for (int i = 0; i < NT; i++) {
+      f32x4 own;
+      own = me == 0 ? xr[i][0] : me == 1 ? xr[i][1] : me == 2 ? xr[i][2] : xr[i][3];
+      own += v[0][i]; own += v[1][i]; own += v[2][i];
+      if (me == 0) xr[i][0] = own; else if (me == 1) xr[i][1] = own; else if (me == 2) xr[i][2] = own; else xr[i][3] = own;
+      const float4* dstp = reinterpret_cast<const float4*>(mine2 + (long)i * CT_TH * 16) + lo16;
+      asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dstp), "v"(own) : "memory");
+    }
+  }
+  // ---- round 2: finished tiles
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store((gu32*)(a.xflags + unit), 2u * seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  wait_all(2u * seq);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  __syncthreads();
+  if (*ok == 0) return false;
+  {
+    f32x4 v[3][NT];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int other = ubase + ((me + 1 + k) & 3);
+      const char* theirs2 = a.xslots2 + ((long)other * 2 + (seq & 1)) * CT_XSLOT2;
+#pragma unroll
+      for (int i = 0; i < NT; i++) {
+        const float4* src = reinterpret_cast<const float4*>(theirs2 + (long)i * CT_TH * 16) + lo16;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[k][i]) : "v"(src) : "memory");
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NT; i++)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0][i]), "+v"(v[1][i]), "+v"(v[2][i]) :: "memory");
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int oj = (me + 1 + k) & 3;                       // the column tile partner k owns
+#pragma unroll
+      for (int i = 0; i < NT; i++) {
+        if (oj == 0) xr[i][0] = v[k][i]; else if (oj == 1) xr[i][1] = v[k][i]; else if (oj == 2) xr[i][2] = v[k][i]; else xr[i][3] = v[k][i];
+      }
+    }
+  }
+  __syncthreads();
+  return true;
+}
+template <int NT, int SPLIT>
+__device__ __forceinline__ bool clip_exchange(const ClipArgs& a, char* lds, f32x4 (&xr)[NT][4], int unit, unsigned seq, int tid) {
+  if constexpr (SPLIT == 4) return clip_exchange4<NT>(a, lds, xr, unit, seq, tid);
+  else return clip_exchange_pair<NT, SPLIT>(a, lds, xr, unit, seq, tid);
+}
+
 // the whole tower for the 16-row tiles [I0, CT_MT) of one dialog (CT_MT = ceil(L / 16) live tiles: a shorter dialog skips the dead
 // tiles' work -- one straight-line instance per tile range).  A dialog of 5 tiles is carried by TWO workgroups: rows 0 .. 47 (I0 = 0,
 // CT_MT = 3, PUB: after every head pair's in_proj it publishes its K / V rows) and rows 48 .. 79 (I0 = 3, CT_MT = 5: it fetches those
 // rows before its attention) -- the mask is causal, so the hand-off is one-directional and the first workgroup never waits.
-template <bool F16, int I0, int CT_MT, bool PUB>
-__device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, const int64_t* __restrict__ tk, int L, int b, int h, int unit) {
+template <bool F16, int I0, int CT_MT, bool PUB, int SPLIT>
+__device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, const ClipGroup& grp, int h, int unit) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, q = lane >> 4;
-  const int eot = L - 1;
   constexpr int NT = CT_MT - I0;                            // this workgroup's tiles: rows 16 (I0 + i) + r16
+  // tile i: dialog td[i], token positions tp[i] .. tp[i] + 15 of it, its live length tL[i]; kspack: per tile, the first tile of its
+  // dialog inside this workgroup's row space (the attention's key range starts there)
+  int td[NT], tp[NT], tL[NT];
+  unsigned kspack = 0;
+#pragma unroll
+  for (int i = 0; i < NT; i++) {
+    td[i] = grp.d[i]; tp[i] = 16 * grp.lt[i]; tL[i] = grp.L[i];
+    kspack |= (unsigned)((I0 + i) - grp.lt[i]) << (8 * i);
+  }
+  const int b = td[0];                                      // row halves of a 5-tile dialog: the dialog of the K / V hand-off
   // weight fragments in flight per wave (every phase's length is a multiple of it): the short-dialog instances have the registers
   // for a deeper ring
   constexpr int CT_RING = NT <= 3 ? 16 : 8;
@@ -285,14 +426,15 @@ __device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, co
   f32x4 xr[NT][4];
 #pragma unroll
   for (int i = 0; i < NT; i++) {
-    const int m = 16 * (I0 + i) + r16;
-    long id = m < L ? tk[m] : 0;
+    const int m = tp[i] + r16;                              // token position inside the tile's dialog
+    const bool live = m < tL[i];
+    long id = live ? a.tokens[(long)td[i] * a.ctx + m] : 0;
     id = id < 0 ? 0 : (id >= a.vocab ? a.vocab - 1 : id);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const int col = 64 * wave + 16 * j + 4 * q;
       float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < L) {
+      if (live) {
         const float4 t = *reinterpret_cast<const float4*>(a.tok_emb + id * 512 + col);
         const float4 p = *reinterpret_cast<const float4*>(a.pos_emb + (long)m * 512 + col);
         e = make_float4(t.x + p.x, t.y + p.y, t.z + p.z, t.w + p.w);
@@ -302,7 +444,8 @@ __device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, co
   }
   // ---- weight ring: CT_RING fragments in flight; fragment f of this wave's stream is wp[f * 64] (64 lanes x 16 B, coalesced)
   // (uniform base in SGPRs + one 32-bit lane offset: the per-fragment offsets are scalar adds, not per-lane 64-bit addresses)
-  const uint4* __restrict__ wp = a.wstream + (long)(h * 8 + __builtin_amdgcn_readfirstlane(wave)) * a.frags_per_wave * 64;
+  const uint4* __restrict__ wp = (SPLIT == 4 ? a.wstream4 : a.wstream) +
+                                 (long)(h * 8 + __builtin_amdgcn_readfirstlane(wave)) * (SPLIT == 4 ? a.frags_per_wave4 : a.frags_per_wave) * 64;
   const unsigned wl = (unsigned)lane;
   uint4 wq[CT_RING];
 #pragma unroll
@@ -374,8 +517,8 @@ __device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, co
         for (int j = 0; j < 4; j++) xr[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll 1
-    for (int jp = 0; jp < 2; jp++) {
-      const int hp = 2 * h + jp;                              // this column half's head pairs
+    for (int jp = 0; jp < 4 / SPLIT; jp++) {
+      const int hp = (4 / SPLIT) * h + jp;                    // this column part's head pairs
       // ---- in_proj of the pair: 24 column tiles (head a: q 4 | k 4 | v 4), wave w takes tiles 3 w .. 3 w + 2; K = 512
       {
         f32x4 acc[NT][3];
@@ -421,12 +564,16 @@ __device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, co
         }
       }
       lds_barrier();
-      if (PUB) clip_publish_kv(a, lds, 2 * b + h, layer * 2 + jp, tid);
-      if (I0 > 0) { if (!clip_fetch_kv(a, lds, 2 * b + h, layer * 2 + jp, tid)) CT_GIVE_UP(); }
+      // K / V slots: (dialog, column part) x (layer, head pair of the part) -- SPLIT * (4 / SPLIT) * layers = 48 per dialog either way
+      const int kv_seq = layer * (4 / SPLIT) + jp;
+      const long kv_slot = ((long)(SPLIT * b + h) * (CT_SLOTS * 2 / SPLIT)) + kv_seq;
+      if (PUB) clip_publish_kv(a, lds, SPLIT * b + h, kv_slot, kv_seq, tid);
+      if (I0 > 0) { if (!clip_fetch_kv(a, lds, SPLIT * b + h, kv_slot, kv_seq, tid)) CT_GIVE_UP(); }
       CT_PH(1);
       // ---- causal attention: units (head of the pair, 16-query tile), one per wave and round (two units of a wave in one basic block
       // -- for the scheduler to interleave -- spilled at 5 tiles and ran slower)
-      for (int u = wave; u < 2 * NT; u += 8) clip_attn_unit<F16, CT_MT>(lds, u / NT, I0 + u % NT, r16, q);
+      for (int u = wave; u < 2 * NT; u += 8)
+        clip_attn_unit<F16, CT_MT>(lds, u / NT, I0 + u % NT, r16, q, 16 * (int)((kspack >> (8 * (u % NT))) & 0xffu));
       lds_barrier();
       CT_PH(2);
       // ---- out_proj, the pair's 128 input columns: x += O_pair W_out[:, 128 hp ..]^T (wave w: its 64 output columns, 4 tiles)
@@ -463,7 +610,7 @@ __device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, co
 #pragma unroll
         for (int j = 0; j < 4; j++) { xr[i][j][0] += bo[j].x; xr[i][j][1] += bo[j].y; xr[i][j][2] += bo[j].z; xr[i][j][3] += bo[j].w; }
     }
-    if (!clip_exchange<NT>(a, lds, xr, unit, 2u * layer + 1u, tid)) CT_GIVE_UP();
+    if (!clip_exchange<NT, SPLIT>(a, lds, xr, unit, 2u * layer + 1u, tid)) CT_GIVE_UP();
     // ======================================================= MLP, 256 hidden units at a time =======================================================
     layer_norm(P.ln2g, P.ln2b);
     CT_PH(4);
@@ -474,8 +621,8 @@ __device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, co
         for (int j = 0; j < 4; j++) xr[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll 1
-    for (int jc = 0; jc < 4; jc++) {
-      const int c = 4 * h + jc;                               // this column half's hidden-unit chunks
+    for (int jc = 0; jc < 8 / SPLIT; jc++) {
+      const int c = (8 / SPLIT) * h + jc;                     // this column part's hidden-unit chunks
       {
         f32x4 acc[NT][2];
 #pragma unroll
@@ -547,19 +694,91 @@ __device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, co
 #pragma unroll
         for (int j = 0; j < 4; j++) { xr[i][j][0] += bp[j].x; xr[i][j][1] += bp[j].y; xr[i][j][2] += bp[j].z; xr[i][j][3] += bp[j].w; }
     }
-    if (!clip_exchange<NT>(a, lds, xr, unit, 2u * layer + 2u, tid)) CT_GIVE_UP();
+    if (!clip_exchange<NT, SPLIT>(a, lds, xr, unit, 2u * layer + 2u, tid)) CT_GIVE_UP();
   }
   // ---- the EOT row of the residual stream (ln_final and the projection follow as their own small launches)
 #pragma unroll
   for (int i = 0; i < NT; i++)
-    if (h == 0 && 16 * (I0 + i) + r16 == eot) {
+    if (h == 0 && tp[i] + r16 == tL[i] - 1) {                 // the EOT row of the tile's dialog
 #pragma unroll
       for (int j = 0; j < 4; j++)
-        *reinterpret_cast<float4*>(a.E + (long)b * 512 + 64 * wave + 16 * j + 4 * q) = make_float4(xr[i][j][0], xr[i][j][1], xr[i][j][2], xr[i][j][3]);
+        *reinterpret_cast<float4*>(a.E + (long)td[i] * 512 + 64 * wave + 16 * j + 4 * q) = make_float4(xr[i][j][0], xr[i][j][1], xr[i][j][2], xr[i][j][3]);
     }
   CT_DUMP();
 #undef CT_TAKE
 #undef CT_STEP
+}
+
+// ---- work list: live lengths, tile counts, packing.  One block; wave per dialog for the EOT scan (first position of the largest id,
+// as torch.argmax: nothing after it can reach the output through the causal mask), then one thread packs whole dialogs into groups
+// of <= 4 tiles, in row order per class (deterministic): [4] | [3 + 1] | [2 + 2], [2 + 1 + 1] | [1 + 1 + 1 + 1] | first row halves
+// of the 5-tile dialogs, then their second halves (whatever a workgroup waits for has a smaller id).  64 dialogs of the benched
+// length mix (2.9 tiles on average) become ~52 groups: each streamed weight fragment feeds more rows, and 52 x 4 column parts still
+// fit the chip in one wave of workgroups.
+constexpr int CT_MAXB = 512;
+__global__ __launch_bounds__(1024) void clip_group_kernel(const int64_t* __restrict__ tokens, const int* __restrict__ row_idx,
+                                                           const int* __restrict__ count, int B, int ctx, int vocab_unused,
+                                                           ClipGroup* __restrict__ groups, int* __restrict__ ngroups) {
+  __shared__ int Ls[CT_MAXB], lst[5][CT_MAXB], cnt[5], ng_sh;
+  __shared__ ClipGroup sg[2 * CT_MAXB];                     // built by one thread in LDS, copied out by all
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = count ? *count : B;
+  for (int r = wave; r < n; r += 16) {
+    const int b = row_idx ? row_idx[r] : r;
+    const int64_t* tk = tokens + (long)b * ctx;
+    long best = -1; int bi = 0x7fffffff;
+    for (int k = lane; k < ctx; k += 64) { const long v = tk[k]; if (v > best) { best = v; bi = k; } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const long ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) Ls[r] = bi + 1;
+  }
+  __syncthreads();
+  if (tid == 0) {
+  for (int c = 0; c < 5; c++) cnt[c] = 0;
+  for (int r = 0; r < n; r++) { int t = (Ls[r] + 15) >> 4; t = t > 5 ? 5 : t; lst[t - 1][cnt[t - 1]++] = r; }
+  int ng = 0, p1 = 0;                                       // p1: next unused 1-tile dialog
+  auto dlg = [&](int r) { return row_idx ? row_idx[r] : r; };
+  auto put = [&](ClipGroup& g, int& t0, int r) {            // append dialog row r (all its tiles) to group g
+    const int L = Ls[r], t = (L + 15) >> 4, b = dlg(r);
+    for (int k = 0; k < t; k++) { g.d[t0] = b; g.lt[t0] = k; g.L[t0] = L; t0++; }
+  };
+  auto fresh = [&]() { ClipGroup g; g.nt = 0; g.kind = 0; for (int k = 0; k < 4; k++) { g.d[k] = 0; g.lt[k] = 0; g.L[k] = 0; } g.pad[0] = g.pad[1] = 0; return g; };
+  for (int i = 0; i < cnt[3]; i++) { ClipGroup g = fresh(); int t0 = 0; put(g, t0, lst[3][i]); g.nt = t0; sg[ng++] = g; }
+  for (int i = 0; i < cnt[2]; i++) {
+    ClipGroup g = fresh(); int t0 = 0; put(g, t0, lst[2][i]);
+    if (p1 < cnt[0]) put(g, t0, lst[0][p1++]);
+    g.nt = t0; sg[ng++] = g;
+  }
+  for (int i = 0; i < cnt[1]; i += 2) {
+    ClipGroup g = fresh(); int t0 = 0; put(g, t0, lst[1][i]);
+    if (i + 1 < cnt[1]) put(g, t0, lst[1][i + 1]);
+    else { for (int k = 0; k < 2 && p1 < cnt[0]; k++) put(g, t0, lst[0][p1++]); }
+    g.nt = t0; sg[ng++] = g;
+  }
+  while (p1 < cnt[0]) {
+    ClipGroup g = fresh(); int t0 = 0;
+    for (int k = 0; k < 4 && p1 < cnt[0]; k++) put(g, t0, lst[0][p1++]);
+    g.nt = t0; sg[ng++] = g;
+  }
+  for (int half = 0; half < 2; half++)
+    for (int i = 0; i < cnt[4]; i++) {
+      ClipGroup g = fresh();
+      const int r = lst[4][i], b = dlg(r), L = Ls[r];
+      g.kind = 1 + half; g.nt = half ? 2 : 3;
+      for (int k = 0; k < g.nt; k++) { g.d[k] = b; g.lt[k] = (half ? 3 : 0) + k; g.L[k] = L; }
+      sg[ng++] = g;
+    }
+  ng_sh = ng;
+  }
+  __syncthreads();
+  const int ng = ng_sh;
+  const int4* src = reinterpret_cast<const int4*>(sg);
+  int4* dst = reinterpret_cast<int4*>(groups);
+  for (int i = tid; i < ng * 4; i += 1024) dst[i] = src[i];
+  if (tid == 0) ngroups[0] = ng;
 }
 
 // Measured and rejected: the MLP in 512-unit chunks (four column tiles per activation fragment, half the barriers; the hidden image
@@ -572,66 +791,45 @@ __device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, co
 // Measured and rejected (tools/clip_lab.hip, 64 dialogs): eight extra "L2 warmer" workgroups (one per XCD) streaming the same bytes
 // 0.75 MB ahead of the dialogs, paced by per-dialog progress words -- 925 -> 1236 us: a dialog's stream already runs at the CU's
 // ingest ceiling (~43 of ~51 B/clk), not at the Infinity-Cache latency, and the progress stores cost more than the warm lines save.
-template <bool F16>
+template <bool F16, int SPLIT>
 __global__ __launch_bounds__(CT_TH) void clip_tower_kernel(ClipArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int lane = threadIdx.x & 63;
-  // workgroup id -> (pair p, column half h): blocks of 16 ids hold 8 pairs, half 0 in ids 0 .. 7 and half 1 in ids 8 .. 15 of the block --
-  // the two halves of a pair are dispatched within 16 ids of each other and share id % 8, i.e. (round-robin placement) an XCD.
-  // Pairs [0, B) are the dialogs / the FIRST row halves of the 5-tile dialogs, pairs [B, 2 B) the second row halves: whatever a
-  // workgroup waits for (its column partner, the first row half's K / V) has a smaller or neighbouring id and never waits for it.
-  const int id = (int)blockIdx.x, h = (id >> 3) & 1, p = (id >> 4) * 8 + (id & 7);
-  if (p >= 2 * a.B) return;
-  const int row_half = p >= a.B ? 1 : 0, ctx = a.ctx;
-  int b = p - row_half * a.B;
-  if (a.row_idx) {                                          // memoised tower: only the rows whose tokens changed (uniform loads)
-    if (b >= *a.count) return;
-    b = a.row_idx[b];
-  }
-  const int unit = (b * 2 + row_half) * 2 + h;                // exchange partner: unit ^ 1
-  const int64_t* __restrict__ tk = a.tokens + (long)b * ctx;
-  // ---- live length: tokens up to the EOT (= first position of the largest id, as torch.argmax) -- nothing after it can reach
-  // the output through the causal mask
-  int L;
-  {
-    long best = -1; int bi = 0x7fffffff;
-    for (int k = lane; k < ctx; k += 64) { const long v = tk[k]; if (v > best) { best = v; bi = k; } }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const long ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
-      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-    }
-    L = __builtin_amdgcn_readfirstlane(bi) + 1;
-  }
-  const int mt = (L + 15) >> 4;
-  if (row_half) {
-    if (mt >= 5) clip_tower_body<F16, 3, 5, false>(a, lds, tk, L, b, h, unit);
-    return;
-  }
-  switch (mt) {
-    case 1: clip_tower_body<F16, 0, 1, false>(a, lds, tk, L, b, h, unit); break;
-    case 2: clip_tower_body<F16, 0, 2, false>(a, lds, tk, L, b, h, unit); break;
-    case 3: clip_tower_body<F16, 0, 3, false>(a, lds, tk, L, b, h, unit); break;
-    case 4: clip_tower_body<F16, 0, 4, false>(a, lds, tk, L, b, h, unit); break;
-    default: clip_tower_body<F16, 0, 3, true>(a, lds, tk, L, b, h, unit); break;
+  // workgroup id -> (group g, column part h): blocks of 8 SPLIT ids hold 8 groups, part k in ids 8 k .. 8 k + 7 of the block -- the
+  // parts of a group are dispatched within 8 SPLIT ids of each other and share id % 8, i.e. (round-robin placement) an XCD.
+  const int id = (int)blockIdx.x, h = (id >> 3) & (SPLIT - 1), g = (id / (8 * SPLIT)) * 8 + (id & 7);
+  const int ng = a.ngroups[0];
+  // 4-way column split when every workgroup of the launch is resident at once (a partner that waits for a later dispatch round
+  // would stall the exchange): otherwise -- large batches, e.g. the 512-row passes of update_dialog -- the 2-way launch runs
+  const bool use4 = ng * 4 <= a.max_wg4;
+  if ((SPLIT == 4) != use4 || g >= ng) return;
+  const ClipGroup grp = a.groups[g];
+  const int unit = g * SPLIT + h;
+  if (grp.kind == 2) { clip_tower_body<F16, 3, 5, false, SPLIT>(a, lds, grp, h, unit); return; }
+  if (grp.kind == 1) { clip_tower_body<F16, 0, 3, true, SPLIT>(a, lds, grp, h, unit); return; }
+  switch (grp.nt) {
+    case 1: clip_tower_body<F16, 0, 1, false, SPLIT>(a, lds, grp, h, unit); break;
+    case 2: clip_tower_body<F16, 0, 2, false, SPLIT>(a, lds, grp, h, unit); break;
+    case 3: clip_tower_body<F16, 0, 3, false, SPLIT>(a, lds, grp, h, unit); break;
+    default: clip_tower_body<F16, 0, 4, false, SPLIT>(a, lds, grp, h, unit); break;
   }
 }
 
 struct ClipLayerWeights { const float* w_in[12]; const float* w_out[12]; const float* w_fc[12]; const float* w_proj[12]; };
 // ---- weight stream packer: fragment f of wave w of layer l, lane (r16, q), element e = W[n][k] of the matrix / tile / k-step the
 // kernel consumes at that point (see the kernel's loops)
-__global__ void clip_pack_stream_kernel(ClipLayerWeights wts, uint4* __restrict__ dst, int layers, long frags_per_wave, int fmt) {
-  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;           // one thread per (layer, half, wave, fragment, lane)
-  const long total = (long)layers * 16 * CT_FRAGS * 64;
+__global__ void clip_pack_stream_kernel(ClipLayerWeights wts, uint4* __restrict__ dst, int layers, long frags_per_wave, int fmt, int split) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;           // one thread per (layer, column part, wave, fragment, lane)
+  const int FR = 768 / split, ATT = 64 * (4 / split);                      // fragments per wave, layer and part; its attention share
+  const long total = (long)layers * split * 8 * FR * 64;
   if (gid >= total) return;
   const int lane = (int)(gid & 63);
   long rest = gid >> 6;
-  const int fp = (int)(rest % CT_FRAGS); rest /= CT_FRAGS;
-  const int wave = (int)(rest & 7), h = (int)((rest >> 3) & 1), layer = (int)(rest >> 4);
+  const int fp = (int)(rest % FR); rest /= FR;
+  const int wave = (int)(rest & 7), h = (int)((rest >> 3) % split), layer = (int)((rest >> 3) / split);
   const int r16 = lane & 15, q = lane >> 4;
   const float* W; int ld, n, k;
-  if (fp < 128) {                                           // attention: this half's 2 pairs x (48 in_proj + 16 out_proj)
-    const int hp = 2 * h + (fp >> 6), g = fp & 63;
+  if (fp < ATT) {                                           // attention: this part's head pairs x (48 in_proj + 16 out_proj)
+    const int hp = (4 / split) * h + (fp >> 6), g = fp & 63;
     if (g < 48) {
       const int ks = g / 3, t = g % 3, gt = 3 * wave + t, ah = gt / 12, ty = (gt % 12) >> 2, sub = gt & 3;
       W = wts.w_in[layer]; ld = 512; n = ty * 512 + (2 * hp + ah) * 64 + sub * 16 + r16; k = 32 * ks + 8 * q;
@@ -639,8 +837,8 @@ __global__ void clip_pack_stream_kernel(ClipLayerWeights wts, uint4* __restrict_
       const int ks = (g - 48) >> 2, t = (g - 48) & 3;
       W = wts.w_out[layer]; ld = 512; n = 64 * wave + 16 * t + r16; k = 128 * hp + 32 * ks + 8 * q;
     }
-  } else {                                                  // MLP: this half's 4 chunks x (32 c_fc + 32 c_proj)
-    const int c = 4 * h + ((fp - 128) >> 6), g = (fp - 128) & 63;
+  } else {                                                  // MLP: this part's hidden chunks x (32 c_fc + 32 c_proj)
+    const int c = (8 / split) * h + ((fp - ATT) >> 6), g = (fp - ATT) & 63;
     if (g < 32) {
       const int ks = g >> 1, t = g & 1;
       W = wts.w_fc[layer]; ld = 512; n = 256 * c + 32 * wave + 16 * t + r16; k = 32 * ks + 8 * q;
@@ -653,7 +851,7 @@ __global__ void clip_pack_stream_kernel(ClipLayerWeights wts, uint4* __restrict_
   uint2 lo, hi;
   if (fmt == 1) { lo = cvt4<true>(v0.x, v0.y, v0.z, v0.w); hi = cvt4<true>(v1.x, v1.y, v1.z, v1.w); }
   else { lo = cvt4<false>(v0.x, v0.y, v0.z, v0.w); hi = cvt4<false>(v1.x, v1.y, v1.z, v1.w); }
-  dst[((long)(h * 8 + wave) * frags_per_wave + (long)layer * CT_FRAGS + fp) * 64 + lane] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+  dst[((long)(h * 8 + wave) * frags_per_wave + (long)layer * FR + fp) * 64 + lane] = make_uint4(lo.x, lo.y, hi.x, hi.y);
 }
 
 bool clip_stream_shape_ok(const avlen_clip_text* p) {
@@ -666,15 +864,18 @@ bool clip_stream_shape_ok(const avlen_clip_text* p) {
   }
   return true;
 }
-inline long clip_frags_per_wave(int layers) { return (long)layers * CT_FRAGS + CT_PAD; }
+inline long clip_frags_per_wave(int layers, int split) { return (long)layers * (768 / split) + CT_PAD; }
+inline size_t clip_stream_bytes_split(int layers, int split) { return (size_t)split * 8 * clip_frags_per_wave(layers, split) * 1024; }
+constexpr size_t CT_FLAG_BYTES = 32768;                     // K / V flags (4 B words) + exchange flags (8 B words) of <= 512 dialogs
 
 }  // namespace
 
+// both column splits' streams, one behind the other: [2-way: 16 streams][4-way: 32 streams]
 extern "C" size_t avlen_clip_stream_bytes(const avlen_clip_text* p) {
-  return clip_stream_shape_ok(p) ? (size_t)16 * clip_frags_per_wave(p->layers) * 1024 : 0;
+  return clip_stream_shape_ok(p) ? clip_stream_bytes_split(p->layers, 2) + clip_stream_bytes_split(p->layers, 4) : 0;
 }
 
-// Builds the per-wave weight stream of the one-launch tower from the fp32 weights (fmt 0: bf16, 1: fp16).  Derived data: call
+// Builds the per-wave weight streams of the one-launch tower from the fp32 weights (fmt 0: bf16, 1: fp16).  Derived data: call
 // again whenever the weights change (CLIP is frozen in the reference: once).
 extern "C" int avlen_clip_pack_stream(const avlen_clip_text* p, void* dst, int fmt, hipStream_t st) {
   if (!clip_stream_shape_ok(p) || !dst) return AVLEN_ERR_ARG;
@@ -683,40 +884,75 @@ extern "C" int avlen_clip_pack_stream(const avlen_clip_text* p, void* dst, int f
     w.w_in[l] = p->block[l].attn.in_proj.w; w.w_out[l] = p->block[l].attn.out_proj.w;
     w.w_fc[l] = p->block[l].fc.w; w.w_proj[l] = p->block[l].proj.w;
   }
-  const long fpw = clip_frags_per_wave(p->layers);
-  if (avlen_zero_bytes(dst, (size_t)16 * fpw * 1024, st) != AVLEN_OK) return AVLEN_ERR_LAUNCH;      // the 16 padding fragments per wave
-  const long total = (long)p->layers * 16 * CT_FRAGS * 64;
-  hipLaunchKernelGGL(clip_pack_stream_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, (uint4*)dst, p->layers, fpw, fmt);
+  if (avlen_zero_bytes(dst, avlen_clip_stream_bytes(p), st) != AVLEN_OK) return AVLEN_ERR_LAUNCH;      // the padding fragments per wave
+  char* at = (char*)dst;
+  for (int split = 2; split <= 4; split += 2) {
+    const long fpw = clip_frags_per_wave(p->layers, split);
+    const long total = (long)p->layers * split * 8 * (768 / split) * 64;
+    hipLaunchKernelGGL(clip_pack_stream_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, (uint4*)at, p->layers, fpw, fmt, split);
+    at += clip_stream_bytes_split(p->layers, split);
+  }
   return avlen_launch_status();
 }
 
+// Scheduling knob: the 4-way column split serves a call whose groups x 4 workgroups fit this many resident workgroups (default -1 =
+// the device's CU count; 0 = always the 2-way split).
+static int g_split4_wgs = -1;
+extern "C" void avlen_set_clip_tower_split4_wgs(int n) { g_split4_wgs = n; }
+
 // X rows of the residual stream at each dialog's EOT token (B x 512 fp32) through the 12 blocks in one launch
-// flag block (16 KB: zeroed before every launch) | K / V slots (dialog, column half) | exchange slots (4 workgroups per dialog x 2)
-size_t avlen_clip_tower_stream_ws_bytes(int B) { return 16384 + (size_t)B * 2 * CT_SLOTS * CT_SLOT + (size_t)B * 4 * 2 * CT_XSLOT; }
+// flag block (zeroed before every launch) | group table + count | K / V slots (dialog, column part) | exchange slots (2 per unit)
+static inline int clip_max_units(int B) { const int u = 4 * B; return u > 256 ? u : 256; }
+size_t avlen_clip_tower_stream_ws_bytes(int B) {
+  return CT_FLAG_BYTES + align_up((size_t)(2 * B + 1) * sizeof(ClipGroup) + 256, 256) + (size_t)B * 2 * CT_SLOTS * CT_SLOT +
+         (size_t)clip_max_units(B) * 2 * CT_XSLOT + (size_t)256 * 2 * CT_XSLOT2;
+}
 
 int avlen_clip_tower_stream_fwd(const avlen_clip_text* p, const int64_t* tokens, float* E, int B, int f16, void* ws, size_t ws_bytes,
                                 hipStream_t st, const int* row_idx, const int* count) {
-  if (!clip_stream_shape_ok(p) || !p->wstream || B <= 0 || B > 1024 || !ws || ws_bytes < avlen_clip_tower_stream_ws_bytes(B)) return AVLEN_ERR_ARG;
-  if (B > 512) return AVLEN_ERR_ARG;
-  if (avlen_zero_bytes(ws, 16384, st) != AVLEN_OK) return AVLEN_ERR_LAUNCH;      // the flag words (own block at the workspace's start)
+  if (!clip_stream_shape_ok(p) || !p->wstream || B <= 0 || B > CT_MAXB || !ws || ws_bytes < avlen_clip_tower_stream_ws_bytes(B)) return AVLEN_ERR_ARG;
+  if (avlen_zero_bytes(ws, CT_FLAG_BYTES, st) != AVLEN_OK) return AVLEN_ERR_LAUNCH;      // the flag words (own block at the workspace's start)
   ClipArgs a = {};
   a.tokens = tokens; a.tok_emb = p->tok_emb; a.pos_emb = p->pos_emb; a.wstream = (const uint4*)p->wstream; a.E = E;
-  a.ctx = p->ctx; a.vocab = p->vocab; a.layers = p->layers; a.frags_per_wave = clip_frags_per_wave(p->layers);
-  a.flags = (unsigned*)ws; a.xflags = a.flags + 2 * B; a.xchg = (char*)ws + 16384; a.B = B;
-  a.xslots = a.xchg + (size_t)B * 2 * CT_SLOTS * CT_SLOT;
-  a.row_idx = row_idx; a.count = count;
-  const int grid = ((2 * B + 7) / 8) * 16;
+  a.ctx = p->ctx; a.vocab = p->vocab; a.layers = p->layers; a.frags_per_wave = clip_frags_per_wave(p->layers, 2);
+  a.wstream4 = (const uint4*)((const char*)p->wstream + clip_stream_bytes_split(p->layers, 2));
+  a.frags_per_wave4 = clip_frags_per_wave(p->layers, 4);
+  a.B = B;
+  // flags: K / V hand-off words [4 B] (indexed SPLIT * dialog + part), then the exchange words [8 B max] (indexed by unit)
+  a.flags = (unsigned*)ws; a.xflags = a.flags + 4 * B;
+  char* at = (char*)ws + CT_FLAG_BYTES;
+  ClipGroup* groups = (ClipGroup*)at;
+  int* ngroups = (int*)(at + (size_t)(2 * B + 1) * sizeof(ClipGroup));
+  at += align_up((size_t)(2 * B + 1) * sizeof(ClipGroup) + 256, 256);
+  a.groups = groups; a.ngroups = ngroups;
+  a.xchg = at; a.xslots = a.xchg + (size_t)B * 2 * CT_SLOTS * CT_SLOT;
+  a.xslots2 = a.xslots + (size_t)clip_max_units(B) * 2 * CT_XSLOT;            // the 4-way launch has <= 256 workgroups
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+  }
+  a.max_wg4 = g_split4_wgs >= 0 ? g_split4_wgs : n_cu;
+  if (a.max_wg4 > 256) a.max_wg4 = 256;                    // the second exchange slots are sized for 256 workgroups
+  hipLaunchKernelGGL(clip_group_kernel, dim3(1), dim3(1024), 0, st, tokens, row_idx, count, B, p->ctx, p->vocab, groups, ngroups);
   for (int l = 0; l < p->layers; l++) {
     const avlen_clip_block& b = p->block[l];
     a.L[l] = ClipLayerP{b.ln1.g, b.ln1.b, b.ln2.g, b.ln2.b, b.attn.in_proj.b, b.attn.out_proj.b, b.fc.b, b.proj.b};
   }
-  static unsigned long long done0 = 0, done1 = 0;
+  // both launches go out; the work list decides on the device which one runs (see the kernel)
+  const int ng4 = a.max_wg4 / 4 < 2 * B ? a.max_wg4 / 4 : 2 * B;           // groups the 4-way launch can be asked to carry
+  const int grid4 = ((ng4 + 7) / 8) * 32, grid2 = ((2 * B + 7) / 8) * 16;
+  static unsigned long long d20 = 0, d21 = 0, d40 = 0, d41 = 0;
   if (f16) {
-    if (avlen_set_dyn_lds(reinterpret_cast<const void*>(&clip_tower_kernel<true>), CT_LDS, &done1) != AVLEN_OK) return AVLEN_ERR_LAUNCH;
-    hipLaunchKernelGGL(clip_tower_kernel<true>, dim3(grid), dim3(CT_TH), CT_LDS, st, a);
+    if (avlen_set_dyn_lds(reinterpret_cast<const void*>(&clip_tower_kernel<true, 4>), CT_LDS, &d41) != AVLEN_OK) return AVLEN_ERR_LAUNCH;
+    if (avlen_set_dyn_lds(reinterpret_cast<const void*>(&clip_tower_kernel<true, 2>), CT_LDS, &d21) != AVLEN_OK) return AVLEN_ERR_LAUNCH;
+    if (grid4 > 0) hipLaunchKernelGGL((clip_tower_kernel<true, 4>), dim3(grid4), dim3(CT_TH), CT_LDS, st, a);
+    hipLaunchKernelGGL((clip_tower_kernel<true, 2>), dim3(grid2), dim3(CT_TH), CT_LDS, st, a);
   } else {
-    if (avlen_set_dyn_lds(reinterpret_cast<const void*>(&clip_tower_kernel<false>), CT_LDS, &done0) != AVLEN_OK) return AVLEN_ERR_LAUNCH;
-    hipLaunchKernelGGL(clip_tower_kernel<false>, dim3(grid), dim3(CT_TH), CT_LDS, st, a);
+    if (avlen_set_dyn_lds(reinterpret_cast<const void*>(&clip_tower_kernel<false, 4>), CT_LDS, &d40) != AVLEN_OK) return AVLEN_ERR_LAUNCH;
+    if (avlen_set_dyn_lds(reinterpret_cast<const void*>(&clip_tower_kernel<false, 2>), CT_LDS, &d20) != AVLEN_OK) return AVLEN_ERR_LAUNCH;
+    if (grid4 > 0) hipLaunchKernelGGL((clip_tower_kernel<false, 4>), dim3(grid4), dim3(CT_TH), CT_LDS, st, a);
+    hipLaunchKernelGGL((clip_tower_kernel<false, 2>), dim3(grid2), dim3(CT_TH), CT_LDS, st, a);
   }
   return avlen_launch_status();
 }
