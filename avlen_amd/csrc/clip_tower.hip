@@ -896,7 +896,7 @@ extern "C" int avlen_clip_pack_stream(const avlen_clip_text* p, void* dst, int f
 }
 
 // Scheduling knob: the 4-way column split serves a call whose groups x 4 workgroups fit this many resident workgroups (default -1 =
-// the device's CU count; 0 = always the 2-way split).
+// half the device's CUs; 0 = always the 2-way split; at most 256).
 static int g_split4_wgs = -1;
 extern "C" void avlen_set_clip_tower_split4_wgs(int n) { g_split4_wgs = n; }
 
@@ -932,7 +932,9 @@ int avlen_clip_tower_stream_fwd(const avlen_clip_text* p, const int64_t* tokens,
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
   }
-  a.max_wg4 = g_split4_wgs >= 0 ? g_split4_wgs : n_cu;
+  // default: half the chip -- a 4-way launch that fills every CU runs alone faster (64 dialogs: 628 vs 676 us) but squeezes the other
+  // policies' kernels of the same rollout step (measured: 26.6 k vs 28.5 k env-steps/s)
+  a.max_wg4 = g_split4_wgs >= 0 ? g_split4_wgs : n_cu / 2;
   if (a.max_wg4 > 256) a.max_wg4 = 256;                    // the second exchange slots are sized for 256 workgroups
   hipLaunchKernelGGL(clip_group_kernel, dim3(1), dim3(1024), 0, st, tokens, row_idx, count, B, p->ctx, p->vocab, groups, ngroups);
   for (int l = 0; l < p->layers; l++) {

@@ -66,6 +66,7 @@ class Workload:
         # = pi_g's / own)
         self._l_where = os.environ.get("AVLEN_L_STREAM", "side" if dialog_tokens == "after_option" else "main")
         self._l_main = self._l_where == "main"
+        self._l_first = os.environ.get("AVLEN_L_FIRST", "1") != "0"              # A/B knob
         self._views_ahead = os.environ.get("AVLEN_VIEWS_AHEAD", "1") != "0"       # A/B knob
         self._next_views = None
         self._text_after = os.environ.get("AVLEN_TEXT_AHEAD", "1") == "2"     # 2: ordered after the current stream (debug)
@@ -91,6 +92,9 @@ class Workload:
         # stream starts when the towers end.  Reserving CUs (avlen_set_tower_x3_reserved_cus) was measured: 64 reserved CUs bring the
         # synchronised step from 1.97 to 1.87 ms but the free-running cycle only from 354 to ~348 ms (towers 0.50 -> 0.62 ms, and
         # the update's tower calls slow down with it) -- inside the noise, so the default stays 0; AVLEN_TOWER_RESERVE=n re-measures.
+        if os.environ.get("AVLEN_CLIP_SPLIT4_WGS") is not None:           # lab knob (see avlen_set_clip_tower_split4_wgs)
+            from . import _lib as L
+            L.lib.avlen_set_clip_tower_split4_wgs(int(os.environ["AVLEN_CLIP_SPLIT4_WGS"]))
         reserve = int(os.environ.get("AVLEN_TOWER_RESERVE", "0"))
         if reserve:
             from . import _lib as L
@@ -241,14 +245,22 @@ class Workload:
             self.pi_q.prefetch_act_option(obs, h, prev, v["masks"], em_opt, em_masks, v["qs"], v["lqi"])
             if ahead and not self._text_first:
                 self.pi_l.prefetch_text(v["dialog"], self._side[2], after_current=self._text_after)
-            if self.pi_g is not None:
+            def launch_g():
                 # pi_g shares pi_l's stream: both wait for pi_q's towers anyway, and a fourth busy stream ends up sharing a
                 # hardware queue with the text tower (pi_g then finished only after it)
                 self.pi_g.prefetch_act(obs, h, prev, v["masks"], em_goal, em_masks, stream=self._side[self._g_stream])
-            if self.pi_l is not None:
+
+            def launch_l():
                 self.pi_l.prefetch_act_dialog(obs, h, prev, v["masks_vln"], em_vln, em_dlg, v["em_vln_masks"], v["dialog"],
                                               v["astep"], stream=None if self._l_main else self._side[0 if self._l_where == "own" else 1],
                                               dialog_later=later)
+            # after_option: pi_l's state-encoder half goes out BEFORE pi_g on their shared stream -- the dialog half waits for it and
+            # for the text tower, pi_g only has to be done by the end of the step (host noise order unchanged: pi_l draws in
+            # dialog_ready, after pi_g's prefetch)
+            order = (launch_l, launch_g) if (later and self._l_first) else (launch_g, launch_l)
+            for fn, pol in zip(order, (self.pi_l, self.pi_g) if order[0] is launch_l else (self.pi_g, self.pi_l)):
+                if pol is not None:
+                    fn()
         if self.launch_ahead and self._views_ahead and t + 1 < self.T:
             # the host is about to wait for pi_q's probabilities: slice the NEXT step's views now (fresh tensor objects every step,
             # as the trainer makes them; only the moment moves off the path between insert and the next forward's launch)

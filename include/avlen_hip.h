@@ -328,7 +328,7 @@ int avlen_clip_text_cached_fwd(const avlen_clip_text* p, const int64_t* tokens, 
  * ctx <= 80, 4x MLP, biases present) and the packer (fmt 0 bf16, 1 fp16; from the fp32 weights; derived data). */
 size_t avlen_clip_stream_bytes(const avlen_clip_text* p);
 /* Scheduling knob of the one-launch tower: it packs whole dialogs into groups of <= 4 row tiles and splits a group's weight stream
- * over 4 workgroups when groups x 4 <= n resident workgroups (default -1: the CU count), over 2 otherwise; 0 = always 2. */
+ * over 4 workgroups when groups x 4 <= n resident workgroups (default -1: half the CUs), over 2 otherwise; 0 = always 2. */
 void avlen_set_clip_tower_split4_wgs(int n);
 int avlen_clip_pack_stream(const avlen_clip_text* p, void* dst, int fmt, avlen_stream_t stream);
 
