@@ -281,4 +281,20 @@ extern "C" int avlen_copy_rows(const float* src, int lds, float* dst, int ldd, i
   return avlen_launch_status();
 }
 
+// dst[r][0 .. cols) = src[index[r]][0 .. cols)  (fp32 rows; cols % 4 == 0, 16-byte aligned rows)
+namespace {
+__global__ void gather_rows_kernel(const float* __restrict__ src, int lds, const int* __restrict__ index, float* __restrict__ dst,
+                                   int ldd, long rows, int c4) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * c4) return;
+  const long r = i / c4; const int c = (int)(i - r * c4) * 4;
+  *reinterpret_cast<float4*>(dst + r * ldd + c) = *reinterpret_cast<const float4*>(src + (long)index[r] * lds + c);
+}
+}  // namespace
+extern "C" int avlen_gather_rows(const float* src, int lds, const int* index, float* dst, int ldd, int rows, int cols, hipStream_t stream) {
+  if (!src || !index || !dst || rows <= 0 || cols <= 0 || (cols & 3) || (lds & 3) || (ldd & 3)) return AVLEN_ERR_ARG;
+  hipLaunchKernelGGL(gather_rows_kernel, grid1d((long)rows * (cols / 4)), dim3(256), 0, stream, src, lds, index, dst, ldd, (long)rows, cols / 4);
+  return avlen_launch_status();
+}
+
 extern "C" const char* avlen_build_info(void) { return "avlen_hip gfx950 (CDNA4) " __DATE__ " " __TIME__; }

@@ -1014,9 +1014,13 @@ class _SMTBase(Net):
         eng["action"] = E.linear_view(self.action_encoder.weight, self.action_encoder.bias)
         eng["smt"] = E.smt_view(self.smt_state_encoder, eng["flat"], packed, lo=packed.lo)
 
-    def features(self, pol, obs, prev_actions, extra=None):
-        """-> feats (B, F) = [visual 128 | action 16 | audio 128 | (category 21) | pose 4 | (extra)], goal (B,d)."""
+    def features(self, pol, obs, prev_actions, extra=None, stored=None):
+        """-> feats (B, F) = [visual 128 | action 16 | audio 128 | (category 21) | pose 4 | (extra)], goal (B,d).
+        stored = (rows2d (R, >= 272) fp32, index (B,) int32): the visual / audio columns are READ from rows of the external-memory
+        ring written at rollout time instead of re-running the frozen encoders (PPO.update(feature_reuse=True))."""
         eng = pol._engine()
+        if stored is not None:
+            return self._features_from_rows(pol, eng, obs, prev_actions, extra, stored)
         rgb, depth, spec = _img(obs["rgb"]), _f32(obs["depth"]), _f32(obs[SPECTROGRAM])
         idx = None
         if isinstance(rgb, RowsOf):                      # minibatch rows of the storage, read in place (grouped fast encoders only)
@@ -1135,6 +1139,23 @@ class _SMTBase(Net):
             cur.wait_stream(s_dep)
         return feats, goal
 
+    def _features_from_rows(self, pol, eng, obs, prev_actions, extra, stored):
+        base, index = stored
+        B, dev, F, st = index.numel(), base.device, self._feature_size, L.stream()
+        feats = torch.empty(B, F, device=dev)
+        goal = torch.empty(B, self._hidden_size, device=dev)
+        # [visual 128 | action 16 | audio 128] as the rollout's forward computed them for exactly these observations
+        L.call("avlen_gather_rows", E.P(base), base.shape[1], E.P(index), E.P(feats), F, B, 272, st)
+        pa = _i64(prev_actions.view(B, -1)[:, :1])
+        cat = _f32(obs[CATEGORY]) if self._use_category_input else None
+        pose, cb, lb = _f32(obs[POSE]), _f32(obs[CATEGORY_BELIEF]), _f32(obs[LOCATION_BELIEF])
+        ex = _f32(extra) if extra is not None else None
+        L.call("avlen_feature_assemble", E.P(feats), F, C.byref(eng["action"]), E.P(pa), 128,
+               E.P(cat) if cat is not None else None, self._col_cat, E.P(pose), self._x_dims - 4,
+               E.P(ex) if ex is not None else None, ex.shape[1] if ex is not None else 0, self._x_dims, E.P(cb), E.P(lb),
+               E.P(goal), self._hidden_size, B, st)
+        return feats, goal
+
     def smt(self, pol, feats, goal, ext_memory, ext_memory_masks, save_key="smt", mem_index=None, save=False):
         eng = pol._engine()
         B, F = feats.shape
@@ -1200,8 +1221,8 @@ class AudioNavOptionNet(_SMTBase):
         return self._qcnt_emb
 
     def run(self, pol, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks,
-            query_state, last_query_info, mem_index=None, save_key="smt", save=False):
-        feats, goal = self.features(pol, observations, prev_actions, extra=query_state)      # [x | query_state]
+            query_state, last_query_info, mem_index=None, save_key="smt", save=False, stored=None):
+        feats, goal = self.features(pol, observations, prev_actions, extra=query_state, stored=stored)      # [x | query_state]
         x_att, saved = self.smt(pol, feats, goal, ext_memory, ext_memory_masks, save_key, mem_index, save)
         B = feats.shape[0]
         lqi = _f32(last_query_info)

@@ -36,6 +36,11 @@ class PPO(nn.Module):
         self.device = next(actor_critic.parameters()).device
         self._adam = None
         self._distributed = False
+        # Opt-in, NOT the reference's work count: pi_q's update re-runs the frozen encoders on the stored observations exactly as
+        # ppo.py:207-262 does unless this is set -- then the visual / audio feature columns are read back from the rows the rollout
+        # wrote into the option memory ring (policy.py:1062-1065 `x_for_memory`; policy.py:1035-1036 detaches them: same values,
+        # no gradient either way).  bench.py reports it as `update_feature_reuse`, never as the headline.
+        self.feature_reuse = False
 
     def forward(self, *x):
         raise NotImplementedError
@@ -82,7 +87,7 @@ class PPO(nn.Module):
         flat.grad.zero_()
         x_att, _, _ = net.run(pol, b["obs"], None, b["prev_actions"], b["masks"], rollouts.em_option.memory,
                               b["em_masks"], b["query_state"], b["last_query_info"], mem_index=b["mem_index"],
-                              save_key="smt_train", save=True)
+                              save_key="smt_train", save=True, stored=b.get("stored"))
         feats, goal, (ws, nb, B, M, F, cto) = net._last
         R, d = x_att.shape
         dev = x_att.device
@@ -122,7 +127,8 @@ class PPO(nn.Module):
             perm = torch.randperm(N)                                   # host RNG, same draw as the reference
             for start in range(0, N, per):
                 env = perm[start:start + per].to(log.device)
-                b = rollouts.gather_minibatch(env, advantages, in_place=self.actor_critic.precision in ("bf16", "bf16x3"))
+                b = rollouts.gather_minibatch(env, advantages, in_place=self.actor_critic.precision in ("bf16", "bf16x3"),
+                                              feature_rows=self.feature_reuse)
                 self._minibatch_step(rollouts, b, log[n_updates])
                 n_updates += 1
         s = log[:n_updates].double().sum(0).cpu()                      # one sync per update()

@@ -423,9 +423,12 @@ class RolloutStorage:
         L.call("avlen_minibatch_gather", P(src), P(dst), P(env), T, self.num_envs, n_mb, D, es, L.stream())
         return dst
 
-    def gather_minibatch(self, env, advantages=None, in_place=False):
+    def gather_minibatch(self, env, advantages=None, in_place=False, feature_rows=False):
         """The tensors PPO.update needs for the env subset `env` (int64, device), WITHOUT materialising the
-        (em_size, T*n_mb, dim) memory: rows index the ring through `mem_index`."""
+        (em_size, T*n_mb, dim) memory: rows index the ring through `mem_index`.
+        feature_rows: also `stored` = (option ring as (total * N, dim) rows, row index of sample (t, env[j])): the feature row the
+        rollout's forward inserted at step t sits in ring slot (idx - T + t) mod total -- total = capacity + T, so none of the
+        rollout's T rows has been overwritten."""
         T = self.step
         g = lambda x: self._gather(x, env, T)
         adv = self.advantages if advantages is None else advantages
@@ -443,8 +446,15 @@ class RolloutStorage:
                 obs[k] = RowsOf(v.view((-1,) + tuple(v.shape[2:])), rows) if big else g(v)
         else:
             obs = {k: g(v) for k, v in self.observations.items()}
+        stored = None
+        if feature_rows:
+            em = self.em_option
+            assert T <= em.total_size, "the rollout's rows must still be in the ring"
+            slot = (torch.arange(T, device=env.device, dtype=torch.int32) + (em.idx - T)) % em.total_size
+            srow = (slot.view(T, 1) * em.num_envs + env.to(torch.int32).view(1, n_mb)).reshape(-1).contiguous()
+            stored = (em.memory.as_subclass(torch.Tensor).view(em.total_size * em.num_envs, em.dim), srow)
         return {
-            "obs": obs,
+            "obs": obs, "stored": stored,
             "actions_option": g(self.actions_option), "prev_actions": g(self.prev_actions),
             "value_preds": g(self.value_preds), "returns": g(self.returns), "masks": g(self.masks),
             "old_log_probs": g(self.action_log_probs), "adv": g(adv), "rl_masks": g(self.rl_masks),

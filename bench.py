@@ -108,12 +108,11 @@ def kernel_roofline(prec_name, in_situ=None, towers=None):
     CLIP text MLP up-projection c_fc of one rollout step on the ragged batch (M = 2464 live rows, N = 2048, K = 512, bias +
     QuickGELU, bf16 out); the block's other three GEMMs are listed under `other_call_sites`.  `achieved` = 2*M*N*K / duration
     measured live with HIP events on the launch stream; `peak` = dense bf16 MFMA; `traffic` = HBM bytes per launch from the
-    rocprofv3 PMC passes (profiles/*_pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction).  The HBM-bound kernel
-    class (direct 3x3 conv of the towers' layer 1) is reported beside it as `hbm_conv`."""
+    rocprofv3 PMC passes (profiles/*_pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction)."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import roofline_probe as rp
     pmc = {}
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             break
@@ -123,21 +122,18 @@ def kernel_roofline(prec_name, in_situ=None, towers=None):
         return None
     rp.FMT = 1 if prec_name == "bf16x3" else 0          # the CLIP GEMMs of the bf16x3 mode run on fp16 operands
     h16 = "fp16" if rp.FMT else "bf16"
-    sg, sc = rp.measure(rp.make_gemm), rp.measure(rp.make_conv)
-    gw, cw = rp.gemm_work(), rp.conv_work()
+    sg = rp.measure(rp.make_gemm)
+    gw = rp.gemm_work()
     tf = gw["flops"] / sg / 1e12
-    gb = cw["bytes"] / sc / 1e9
     out = {"bound": "mfma", "kernel": rp.GEMM_KERNEL_NAME + f" {h16} glds GEMM (CLIP c_fc, ragged M=2464 N=2048 K=512)",
            "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
            "traffic": pmc.get("gemm", {}).get("traffic_bytes"), "mfma_util_pmc_percent": pmc.get("gemm", {}).get("MfmaUtil_percent"),
            "algorithmic_flops": gw["flops"],
            "algorithmic_bytes": gw["bytes"], "us_per_launch": round(sg * 1e6, 2),
-           "other_call_sites": rp.clip_call_sites(),
-           "hbm_conv": {"bound": "hbm", "kernel": "dconv3x3_kernel<16,16,64,3> (tower layer-1 conv as a standalone launch, 384 "
-                                                  "images, bf16 in/out, fused GN statistics; the product runs it inside tower_head)", "achieved": round(gb, 1), "peak": 8000.0,
-                        "unit": "GB/s", "frac": round(gb / 8000.0, 4), "traffic": pmc.get("dconv", {}).get("traffic_bytes"),
-                        "algorithmic_bytes": cw["bytes"], "us_per_launch": round(sc * 1e6, 2)}}
+           "other_call_sites": rp.clip_call_sites()}
     if in_situ:
+        ct = pmc.get("clip_tower", {})
+        in_situ = dict(in_situ, traffic=ct.get("traffic_bytes"), mfma_util_pmc_percent=ct.get("MfmaUtil_percent"))
         out["in_situ"] = in_situ
     if towers:
         out["towers_fused"] = towers
@@ -163,8 +159,8 @@ def kernel_roofline(prec_name, in_situ=None, towers=None):
             top["mfma_issue_frac"] = round(3 * towers["frac_of_bf16_peak"], 4)
             try:                                     # per conv INSIDE the fused bodies: from the committed phase-stamp profile (a lab
                 import tower_x3_phase_table as tpt   # build of the same kernel, tools/x3_lab.hip), not re-measured by this run
-                t = tpt.table(os.path.join(ROOT, "profiles", "r03_tower_x3_phases.txt"))
-                top["tower_convs_in_situ"] = {"source": "profiles/r03_tower_x3_phases.txt (tools/x3_lab: phase stamps of the product kernel, "
+                t = tpt.table(os.path.join(ROOT, "profiles", "r04_tower_x3_phases.txt" if os.path.exists(os.path.join(ROOT, "profiles", "r04_tower_x3_phases.txt")) else "r03_tower_x3_phases.txt"))
+                top["tower_convs_in_situ"] = {"source": "profiles/r0[34]_tower_x3_phases.txt, the newest (tools/x3_lab: phase stamps of the product kernel, "
                                                         "384 images; algorithmic FLOPs of a conv over its whole phase incl. GroupNorm "
                                                         "statistics and the normalise / split pass, per CU)",
                                               "whole_tower_frac_mfma_algorithmic": t["whole_tower_frac_mfma_algorithmic"],
@@ -176,10 +172,6 @@ def kernel_roofline(prec_name, in_situ=None, towers=None):
         top.update(out)
         top["gemm_probe"] = probe
         out = top
-    try:                                         # the convs as STANDALONE launches (the fallback path; the product runs them fused)
-        out["tower_convs"] = rp.tower_conv_table()
-    except Exception as e:                       # the table is an extra: never lose the headline line over it
-        out["tower_convs_error"] = repr(e)
     return out
 
 
@@ -231,20 +223,24 @@ def text_tower_in_situ(wl):
     # per live row and layer: in_proj 3w^2, out_proj w^2, c_fc 4w^2, c_proj 4w^2 MACs; the last layer's MLP and out_proj run on
     # the N pooled rows only
     flops = 2.0 * (11 * live * 12 * w * w + live * 3 * w * w + N * 9 * w * w)
+    def once(after):
+        pol.net.invalidate_text_cache()                  # every dialog new, as in the fresh-token rollout (the memo would skip them all)
+        pol.prefetch_text(toks, st, after_current=after)
     for _ in range(3):
-        pol.prefetch_text(toks, st, after_current=True)
+        once(True)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     it = 20
     with torch.cuda.stream(st):
         e0.record(st)
     for _ in range(it):
-        pol.prefetch_text(toks, st, after_current=False)
+        once(False)
     with torch.cuda.stream(st):
         e1.record(st)
     torch.cuda.synchronize()
     sec = e0.elapsed_time(e1) / 1e3 / it
-    impl = ("one sequence-stationary launch (clip_tower_kernel) + ln_final + projection" if pol._engine()["clip"].wstream
+    impl = ("work list + one sequence-stationary launch (clip_tower_kernel: dialogs packed into <= 4-tile groups, 2- or 4-way column "
+            "split) + ln_final + folded projection; memo emptied before every call" if pol._engine()["clip"].wstream
             else "launch-per-GEMM chain")
     return {"what": "CLIP text tower graph of one rollout step (" + impl + "), alone on its stream", "live_rows": live, "ms": round(sec * 1e3, 4),
             "gemm_flops": flops, "TFLOPs": round(flops / sec / 1e12, 1), "frac_of_bf16_peak": round(flops / sec / 2.5e15, 4)}
@@ -416,6 +412,83 @@ def reference_dialog_record(a, H, W):
     return rec
 
 
+def feature_reuse_record(a, H, W):
+    """Opt-in, reported beside the headline and never as it: pi_q's update reads the encoder feature columns back from the rows the
+    rollout wrote into the option memory ring instead of re-running the frozen towers on the 4 x 4800 stored observations
+    (PPO.feature_reuse; exact up to GEMM tiling order: tests/test_gpu_feature_reuse.py).  The reference recomputes them
+    (ppo.py:207-262), and so does the headline."""
+    import torch
+    from avlen_amd.harness import Workload
+    wl = Workload(a.envs, a.rollout, spectrogram=(H, W, 2), precision=a.precision, pretraining=(a.stage == 1), seed=0,
+                  use_graphs=not a.no_graphs, share_encoders=not a.no_share, launch_ahead=not a.no_launch_ahead,
+                  distractor=a.distractor, dialog_tokens=a.dialog_tokens)
+    wl.agent.feature_reuse = True
+    dt = time_cycles(wl, 2, 3)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    wl.update()
+    torch.cuda.synchronize()
+    up = time.perf_counter() - t0
+    rec = {"value": round(a.envs * a.rollout / dt, 2), "unit": "env-steps/s", "ms_per_step": round(dt * 1e3, 2),
+           "update_ms": round(up * 1e3, 2),
+           "what": "same cycle with PPO.feature_reuse = True: the update's frozen-encoder features come from the stored memory rows "
+                   "(policy.py:1062-1065) instead of a recompute; skips work the metric names, hence not the headline"}
+    del wl
+    torch.cuda.empty_cache()
+    return rec
+
+
+def stage2_record(a, H, W):
+    """BASELINE configs[3]'s per-GPU share: 2nd stage (pi_q attends over its 300-slot memory history in rollout AND update), 32 envs.
+    The update is the SMT transformer forward / backward over (M + 1) x T x N_mb = 722 k token rows per minibatch: 9600 sample-passes
+    x 3 (fwd + bwd) x 498.6 MF = 14.4 TFLOP per update."""
+    import torch
+    from avlen_amd.harness import Workload
+    N = 32
+    wl = Workload(N, a.rollout, spectrogram=(H, W, 2), precision=a.precision, pretraining=False, seed=0,
+                  use_graphs=not a.no_graphs, share_encoders=not a.no_share, launch_ahead=not a.no_launch_ahead,
+                  dialog_tokens=a.dialog_tokens)
+    dt = time_cycles(wl, 1, 2)
+    for _ in range(wl.T):
+        wl.rollout_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    wl.update()
+    torch.cuda.synchronize()
+    up = time.perf_counter() - t0
+    flops = 2 * 2 * (N // 2) * a.rollout * 3 * 498.6e6           # epochs x minibatches x samples x (fwd + bwd) x SMT block
+    rec = {"value": round(N * a.rollout / dt, 2), "unit": "env-steps/s", "ms_per_step": round(dt * 1e3, 2), "num_envs": N,
+           "update_ms": round(up * 1e3, 2),
+           "update_roofline": {"bound": "mfma", "achieved": round(flops / up / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                               "frac": round(flops / up / 2.5e15, 4), "algorithmic_flops": flops,
+                               "what": "pi_q PPO update 2 x 2 over 32 x 150 samples with M = 300 memory rows each (SMT fusion MLP + "
+                                       "encoder / decoder layer forward + backward), whole update incl. the frozen towers' forward, "
+                                       "GAE, losses, Adam"},
+           "what": "savi_interactive_2nd_stage at NUM_ENVS = 32 (one rank's share of BASELINE configs[3]), dtype as the headline"}
+    del wl
+    torch.cuda.empty_cache()
+    return rec
+
+
+def belief_record(a):
+    """BeliefPredictor.update every rollout step (65x26 spectrogram: the only size the reference's predictor.fc
+    accepts), with and without it."""
+    import torch
+    from avlen_amd.harness import Workload
+    out = {}
+    for name, on in (("without", False), ("with_belief_predictor", True)):
+        wl = Workload(a.envs, a.rollout, spectrogram=(65, 26, 2), precision=a.precision, pretraining=(a.stage == 1), seed=0,
+                      use_graphs=not a.no_graphs, share_encoders=not a.no_share, launch_ahead=not a.no_launch_ahead,
+                      belief_predictor=on, dialog_tokens=a.dialog_tokens)
+        dt = time_cycles(wl, 1, 2)
+        out[name] = {"value": round(a.envs * a.rollout / dt, 2), "unit": "env-steps/s", "ms_per_step": round(dt * 1e3, 2)}
+        del wl
+        torch.cuda.empty_cache()
+    out["cost_percent"] = round(100.0 * (1.0 - out["with_belief_predictor"]["value"] / out["without"]["value"]), 1)
+    out["what"] = "same cycle at the 65x26 spectrogram, BeliefPredictor.update (two ResNet-18s + the per-env filter) between the env step and insert"
+    return out
+
+
 def gru_record(a):
     """BASELINE configs[1]: NUM_ENVS=16, AudioCNN + VisualCNN + single-layer GRU pi_g, PPO 4 epochs x 2 minibatches, bf16."""
     import torch
@@ -577,6 +650,10 @@ def main():
             torch.cuda.empty_cache()
             out["integration"] = integration_records(a, H, W)
             out["reference_dialog_process"] = reference_dialog_record(a, H, W)
+            out["update_feature_reuse"] = feature_reuse_record(a, H, W)
+            if a.stage == 1 and not a.distractor:
+                out["stage2_envs32"] = stage2_record(a, H, W)
+                out["belief_65x26"] = belief_record(a)
             import avlen_amd.harness as hz
             if hasattr(hz, "GruWorkload"):
                 out["gru_baseline"] = gru_record(a)

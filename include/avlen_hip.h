@@ -462,6 +462,9 @@ int avlen_minibatch_gather(const void* src, void* dst, const int64_t* env, int T
                            int elem_bytes, avlen_stream_t stream);
 /* out[i] = a[i] (fp32 copy on stream; strided rows) -- storage insert helper. */
 int avlen_copy_rows(const float* src, int lds, float* dst, int ldd, int rows, int cols, avlen_stream_t stream);
+/* dst[r][0 .. cols) = src[index[r]][0 .. cols): rows of the external-memory ring read back as encoder features (PPO.update with
+ * feature_reuse: policy.py:1035-1036 cuts the gradient in front of them, so the stored rows ARE what a recompute would give). */
+int avlen_gather_rows(const float* src, int lds, const int* index, float* dst, int ldd, int rows, int cols, avlen_stream_t stream);
 /* dst[i][0..nbytes[i]) = src[i][0..nbytes[i]) for i < n, in ONE launch per 32 pairs (host arrays of device pointers).
  * RolloutStorage.insert (rollout_storage.py:223-330 of the reference: ~25 `tensor[step].copy_()` calls per step). */
 int avlen_multi_copy(const void* const* src, void* const* dst, const int64_t* nbytes, int n, avlen_stream_t stream);

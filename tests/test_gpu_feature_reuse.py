@@ -1,0 +1,37 @@
+"""`PPO.update(feature_reuse=True)` (opt-in; bench record `update_feature_reuse`): pi_q's update reads the visual / audio feature
+columns back from the rows the rollout wrote into the option memory ring (ss_baselines/savi/ppo/policy.py:1062-1065 `x_for_memory`)
+instead of re-running the frozen encoders on the stored observations as ppo.py:207-262 does.  policy.py:1035-1036 detaches those
+features, so the stored rows are what the recompute produces (up to the summation order of batch-size-dependent GEMM tilings): the
+update's 6-tuple and every parameter after the step are compared against the recompute path on an identical rollout."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cycle(reuse, precision, pre, N=6, T=7):
+    from avlen_amd.harness import Workload
+    torch.manual_seed(31)
+    wl = Workload(N, T, spectrogram=(65, 26, 2), precision=precision, pretraining=pre, em_capacity=5, seed=2,
+                  share_encoders=(precision != "fp32"))
+    wl.agent.feature_reuse = reuse
+    for _ in range(T):
+        wl.rollout_step()
+    torch.manual_seed(77)                                   # the minibatch permutations
+    out = wl.update()
+    torch.cuda.synchronize()
+    return [float(x) for x in out], {k: v.detach().clone() for k, v in wl.pi_q.state_dict().items()}
+
+
+@pytest.mark.parametrize("precision,pre", [("bf16x3", True), ("bf16x3", False), ("bf16", True), ("fp32", False)])
+def test_feature_reuse_equals_recompute(precision, pre):
+    a, sa = _cycle(False, precision, pre)
+    b, sb = _cycle(True, precision, pre)
+    worst = max(float((sa[k].double() - sb[k].double()).abs().max()) for k in sa if sa[k].is_floating_point())
+    print(f"{precision} pretraining={pre}: 6-tuple recompute {a} reuse {b}; max |d param| {worst:.3e}")
+    # The stored features come from the rollout's grouped encoder call (batch N), the recompute from the update's row-indexed call
+    # (batch T * N / 2): the same kernels, but the fc / AudioCNN GEMMs tile (and split K) by the batch size, so a feature may
+    # differ in its last bit -- measured: parameters after the step agree to 1.2e-7, the losses to 1e-6 relative.
+    np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-6)
+    assert worst <= 1e-6, worst

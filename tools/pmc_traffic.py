@@ -12,8 +12,13 @@ def per_kernel(path, counter):
             continue
         name = r["Kernel_Name"]
         probe_gemm = "g2_kernel" in name and ("ILi64ELi128ELi2ELi4ELi2ELi512ELb0E" in name or "<64, 128, 2, 4, 2, 512, false" in name)
+        # the text tower goes out as two launches (4-way and 2-way column split); the work list lets one of them run, the other
+        # one's workgroups exit at once -- keyed apart, the busy one is reported as `clip_tower`
+        clip = None
+        if "clip_tower_kernel" in name:
+            clip = "clip_tower_4way" if ("ELi4E" in name or ", 4>" in name) else "clip_tower_2way"
         key = ("gemm" if probe_gemm else "dconv" if "dconv3x3_kernel" in name else
-               "tower_x3" if "tower_x3_kernel" in name else "clip_tower" if "clip_tower_kernel" in name else None)
+               "tower_x3" if "tower_x3_kernel" in name else clip)
         if key is None:
             continue
         a = acc.setdefault(key, [0.0, 0, name])
@@ -25,7 +30,11 @@ def mfma_util(path):
     """MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (cycles x 1024 SIMDs) with cycles = GRBM_GUI_ACTIVE / 8 (rocprofv3 reports the
     sum over the 8 XCDs, MI355X_MICROARCH.md), per kernel class, from the third pass."""
     busy, act = per_kernel(path, "SQ_VALU_MFMA_BUSY_CYCLES"), per_kernel(path, "GRBM_GUI_ACTIVE")
-    return {k: 100.0 * busy[k][0] / (act[k][0] / 8.0 * 1024.0) for k in busy if k in act and act[k][0] > 0}
+    out = {k: 100.0 * busy[k][0] / (act[k][0] / 8.0 * 1024.0) for k in busy if k in act and act[k][0] > 0}
+    hot = max((k for k in busy if k.startswith("clip_tower_")), key=lambda k: busy[k][0], default=None)
+    if hot in out:
+        out["clip_tower"] = out[hot]
+    return out
 
 
 def main(fetch_csv, write_csv, out, mfma_csv=None):
@@ -39,6 +48,10 @@ def main(fetch_csv, write_csv, out, mfma_csv=None):
                       "(two separate passes), summarised by tools/pmc_traffic.py",
            "gfx950_note": "MI355X_MICROARCH.md HBM section: FETCH_SIZE (KB) reports half the bytes of wide (16 B/lane) coalesced "
                           "reads incl. global_load...lds -> x2; WRITE_SIZE (KB) is exact for wide stores"}
+    for side in (f, w):
+        busy = max((k for k in side if k.startswith("clip_tower_")), key=lambda k: f.get(k, (0,))[0], default=None)
+        if busy is not None:
+            side["clip_tower"] = side[busy]
     for k in ("gemm", "dconv", "tower_x3", "clip_tower"):
         if k not in f or k not in w:
             continue
