@@ -798,9 +798,12 @@ __global__ __launch_bounds__(CT_TH) void clip_tower_kernel(ClipArgs a) {
   // parts of a group are dispatched within 8 SPLIT ids of each other and share id % 8, i.e. (round-robin placement) an XCD.
   const int id = (int)blockIdx.x, h = (id >> 3) & (SPLIT - 1), g = (id / (8 * SPLIT)) * 8 + (id & 7);
   const int ng = a.ngroups[0];
-  // 4-way column split when every workgroup of the launch is resident at once (a partner that waits for a later dispatch round
-  // would stall the exchange): otherwise -- large batches, e.g. the 512-row passes of update_dialog -- the 2-way launch runs
-  const bool use4 = ng * 4 <= a.max_wg4;
+  // Which split serves the call is a property of the BUILD / knob, never of the batch: a dialog's embedding must not depend on how
+  // many other dialogs share the call (the two splits round the fp16 operands of later layers at different points: 2e-3 apart) --
+  // the memoised tower recomputes one changed row and must reproduce what the full batch gave.  Default: always 4-way (max_wg4 < 0).
+  // Grids beyond the chip's residency are fine: the parts of a group lie within 32 consecutive ids and ids are dispatched in order,
+  // so the resident set always holds complete groups that make progress.
+  const bool use4 = a.max_wg4 < 0 || ng * 4 <= a.max_wg4;
   if ((SPLIT == 4) != use4 || g >= ng) return;
   const ClipGroup grp = a.groups[g];
   const int unit = g * SPLIT + h;
@@ -895,17 +898,20 @@ extern "C" int avlen_clip_pack_stream(const avlen_clip_text* p, void* dst, int f
   return avlen_launch_status();
 }
 
-// Scheduling knob: the 4-way column split serves a call whose groups x 4 workgroups fit this many resident workgroups (default -1 =
-// half the device's CUs; 0 = always the 2-way split; at most 256).
+// Knob: -1 (default) = every call on the 4-way column split; 0 = every call on the 2-way split; n > 0 (lab) = 4-way when a call's
+// groups x 4 workgroups <= n, else 2-way -- then a dialog's embedding depends (2e-3) on the size of the call it is part of.
 static int g_split4_wgs = -1;
+#ifdef AVLEN_CT_PROF
+static long long* g_ct_prof = nullptr;                      // lab builds (tools/clip_lab.hip): per-workgroup phase totals [grid][8]
+#endif
 extern "C" void avlen_set_clip_tower_split4_wgs(int n) { g_split4_wgs = n; }
 
 // X rows of the residual stream at each dialog's EOT token (B x 512 fp32) through the 12 blocks in one launch
 // flag block (zeroed before every launch) | group table + count | K / V slots (dialog, column part) | exchange slots (2 per unit)
-static inline int clip_max_units(int B) { const int u = 4 * B; return u > 256 ? u : 256; }
+static inline int clip_max_units(int B) { const int u = 8 * B; return u > 256 ? u : 256; }    // <= 2 B groups x 4 column parts
 size_t avlen_clip_tower_stream_ws_bytes(int B) {
   return CT_FLAG_BYTES + align_up((size_t)(2 * B + 1) * sizeof(ClipGroup) + 256, 256) + (size_t)B * 2 * CT_SLOTS * CT_SLOT +
-         (size_t)clip_max_units(B) * 2 * CT_XSLOT + (size_t)256 * 2 * CT_XSLOT2;
+         (size_t)clip_max_units(B) * 2 * (CT_XSLOT + CT_XSLOT2);
 }
 
 int avlen_clip_tower_stream_fwd(const avlen_clip_text* p, const int64_t* tokens, float* E, int B, int f16, void* ws, size_t ws_bytes,
@@ -918,6 +924,9 @@ int avlen_clip_tower_stream_fwd(const avlen_clip_text* p, const int64_t* tokens,
   a.wstream4 = (const uint4*)((const char*)p->wstream + clip_stream_bytes_split(p->layers, 2));
   a.frags_per_wave4 = clip_frags_per_wave(p->layers, 4);
   a.B = B;
+#ifdef AVLEN_CT_PROF
+  a.prof = g_ct_prof;
+#endif
   // flags: K / V hand-off words [4 B] (indexed SPLIT * dialog + part), then the exchange words [8 B max] (indexed by unit)
   a.flags = (unsigned*)ws; a.xflags = a.flags + 4 * B;
   char* at = (char*)ws + CT_FLAG_BYTES;
@@ -926,35 +935,33 @@ int avlen_clip_tower_stream_fwd(const avlen_clip_text* p, const int64_t* tokens,
   at += align_up((size_t)(2 * B + 1) * sizeof(ClipGroup) + 256, 256);
   a.groups = groups; a.ngroups = ngroups;
   a.xchg = at; a.xslots = a.xchg + (size_t)B * 2 * CT_SLOTS * CT_SLOT;
-  a.xslots2 = a.xslots + (size_t)clip_max_units(B) * 2 * CT_XSLOT;            // the 4-way launch has <= 256 workgroups
+  a.xslots2 = a.xslots + (size_t)clip_max_units(B) * 2 * CT_XSLOT;
   static int n_cu = 0;
   if (!n_cu) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
   }
-  // default: half the chip -- a 4-way launch that fills every CU runs alone faster (64 dialogs: 628 vs 676 us) but squeezes the other
-  // policies' kernels of the same rollout step (measured: 26.6 k vs 28.5 k env-steps/s)
-  a.max_wg4 = g_split4_wgs >= 0 ? g_split4_wgs : n_cu / 2;
-  if (a.max_wg4 > 256) a.max_wg4 = 256;                    // the second exchange slots are sized for 256 workgroups
+  a.max_wg4 = g_split4_wgs;                                // < 0: always the 4-way split (default); 0: always 2-way; n: lab (mixed)
+  (void)n_cu;
   hipLaunchKernelGGL(clip_group_kernel, dim3(1), dim3(1024), 0, st, tokens, row_idx, count, B, p->ctx, p->vocab, groups, ngroups);
   for (int l = 0; l < p->layers; l++) {
     const avlen_clip_block& b = p->block[l];
     a.L[l] = ClipLayerP{b.ln1.g, b.ln1.b, b.ln2.g, b.ln2.b, b.attn.in_proj.b, b.attn.out_proj.b, b.fc.b, b.proj.b};
   }
-  // both launches go out; the work list decides on the device which one runs (see the kernel)
-  const int ng4 = a.max_wg4 / 4 < 2 * B ? a.max_wg4 / 4 : 2 * B;           // groups the 4-way launch can be asked to carry
-  const int grid4 = ((ng4 + 7) / 8) * 32, grid2 = ((2 * B + 7) / 8) * 16;
+  // the launch(es) the knob allows go out; with a mixed knob the work list decides on the device which one runs (see the kernel)
+  const int ng4 = a.max_wg4 < 0 ? 2 * B : (a.max_wg4 / 4 < 2 * B ? a.max_wg4 / 4 : 2 * B);      // groups the 4-way launch may carry
+  const int grid4 = ((ng4 + 7) / 8) * 32, grid2 = a.max_wg4 < 0 ? 0 : ((2 * B + 7) / 8) * 16;
   static unsigned long long d20 = 0, d21 = 0, d40 = 0, d41 = 0;
   if (f16) {
     if (avlen_set_dyn_lds(reinterpret_cast<const void*>(&clip_tower_kernel<true, 4>), CT_LDS, &d41) != AVLEN_OK) return AVLEN_ERR_LAUNCH;
     if (avlen_set_dyn_lds(reinterpret_cast<const void*>(&clip_tower_kernel<true, 2>), CT_LDS, &d21) != AVLEN_OK) return AVLEN_ERR_LAUNCH;
     if (grid4 > 0) hipLaunchKernelGGL((clip_tower_kernel<true, 4>), dim3(grid4), dim3(CT_TH), CT_LDS, st, a);
-    hipLaunchKernelGGL((clip_tower_kernel<true, 2>), dim3(grid2), dim3(CT_TH), CT_LDS, st, a);
+    if (grid2 > 0) hipLaunchKernelGGL((clip_tower_kernel<true, 2>), dim3(grid2), dim3(CT_TH), CT_LDS, st, a);
   } else {
     if (avlen_set_dyn_lds(reinterpret_cast<const void*>(&clip_tower_kernel<false, 4>), CT_LDS, &d40) != AVLEN_OK) return AVLEN_ERR_LAUNCH;
     if (avlen_set_dyn_lds(reinterpret_cast<const void*>(&clip_tower_kernel<false, 2>), CT_LDS, &d20) != AVLEN_OK) return AVLEN_ERR_LAUNCH;
     if (grid4 > 0) hipLaunchKernelGGL((clip_tower_kernel<false, 4>), dim3(grid4), dim3(CT_TH), CT_LDS, st, a);
-    hipLaunchKernelGGL((clip_tower_kernel<false, 2>), dim3(grid2), dim3(CT_TH), CT_LDS, st, a);
+    if (grid2 > 0) hipLaunchKernelGGL((clip_tower_kernel<false, 2>), dim3(grid2), dim3(CT_TH), CT_LDS, st, a);
   }
   return avlen_launch_status();
 }

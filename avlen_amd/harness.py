@@ -67,6 +67,8 @@ class Workload:
         self._l_where = os.environ.get("AVLEN_L_STREAM", "side" if dialog_tokens == "after_option" else "main")
         self._l_main = self._l_where == "main"
         self._l_first = os.environ.get("AVLEN_L_FIRST", "1") != "0"              # A/B knob
+        tpr = os.environ.get("AVLEN_TEXT_STREAM")                                # lab knob: "hi" / "own" = text tower on its own stream
+        self._text_stream = None if tpr is None else torch.cuda.Stream(priority=-1 if tpr == "hi" else 0)
         self._views_ahead = os.environ.get("AVLEN_VIEWS_AHEAD", "1") != "0"       # A/B knob
         self._next_views = None
         self._text_after = os.environ.get("AVLEN_TEXT_AHEAD", "1") == "2"     # 2: ordered after the current stream (debug)
@@ -270,7 +272,7 @@ class Workload:
         if ref:                                          # ppo_trainer.py:463-593: the host loop between act_option and act / act_dialog
             self._host_dialog_loop(t, self.pi_q.host_actions("option").view(-1).numpy())
         if self.launch_ahead and later and self.pi_l is not None:
-            self.pi_l.dialog_ready()                     # current_dialog / agent_step hold this step's values from here on
+            self.pi_l.dialog_ready(self._text_stream)    # current_dialog / agent_step hold this step's values from here on
         dg = ro.em_dim_goal
         o = dict(q_value=values, q_prob=probs_opt, a_q=a_opt, lp_q=lp_opt, h=h, row_q=row_opt, row_g=row_opt[:, :dg],
                  row_l=row_opt[:, :276], row_d=self.zero_dialog_feats, l_prob=self.zero_probs, a_g=a_opt, a_l=a_opt,

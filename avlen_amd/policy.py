@@ -828,7 +828,7 @@ class Policy(nn.Module):
         self._prefetch("vln", observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_dialog,
                        ext_memory_masks, all_dialog, agent_step, stream=stream, dialog_later=dialog_later)
 
-    def dialog_ready(self):
+    def dialog_ready(self, text_stream=None):
         """Second half of `prefetch_act_dialog(..., dialog_later=True)`: the frozen text tower on the tensors passed there (memoised
         per row: only dialogs that changed since the last call run it), agent_step, the dialog state encoder and the heads.  The
         matching `act_dialog` call picks the result up."""
@@ -847,11 +847,20 @@ class Policy(nn.Module):
         # The text tower runs on the CALLER's stream -- the one the host loop wrote the tokens on, behind pi_q's forward and nothing
         # else if pi_l was given its own stream -- and pi_l's stream waits for its event before the second half: the tower then
         # overlaps pi_g and pi_l's state-encoder half instead of queueing behind them.
-        if stream is not None and self.net._text_read is not None:
-            cur.wait_event(self.net._text_read)          # the previous step's reader of the static embedding buffer
-        self.net.prefetch_text(self, tokens, cur, after_current=False, same_stream=True)
-        if stream is not None:
-            stream.wait_event(self.net._text[3])
+        if text_stream is not None:
+            # the tower on a stream of its own (e.g. a high-priority one): ordered after the caller's stream (the tokens' writes)
+            text_stream.wait_stream(cur)
+            if self.net._text_read is not None:
+                text_stream.wait_event(self.net._text_read)
+            with torch.cuda.stream(text_stream):
+                self.net.prefetch_text(self, tokens, text_stream, after_current=False, same_stream=True)
+            (stream if stream is not None else cur).wait_event(self.net._text[3])
+        else:
+            if stream is not None and self.net._text_read is not None:
+                cur.wait_event(self.net._text_read)          # the previous step's reader of the static embedding buffer
+            self.net.prefetch_text(self, tokens, cur, after_current=False, same_stream=True)
+            if stream is not None:
+                stream.wait_event(self.net._text[3])
         with ctx:
             if torch.is_tensor(g.static[8]) and g.static[8].data_ptr() != agent_step.data_ptr():
                 L.multi_copy([(g.static[8], _f32(agent_step))])

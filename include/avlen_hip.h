@@ -327,8 +327,10 @@ int avlen_clip_text_cached_fwd(const avlen_clip_text* p, const int64_t* tokens, 
 /* The one-launch tower's weight stream (csrc/clip_tower.hip): bytes for `p` (0: shape not supported -- width 512, 8 heads,
  * ctx <= 80, 4x MLP, biases present) and the packer (fmt 0 bf16, 1 fp16; from the fp32 weights; derived data). */
 size_t avlen_clip_stream_bytes(const avlen_clip_text* p);
-/* Scheduling knob of the one-launch tower: it packs whole dialogs into groups of <= 4 row tiles and splits a group's weight stream
- * over 4 workgroups when groups x 4 <= n resident workgroups (default -1: half the CUs), over 2 otherwise; 0 = always 2. */
+/* Knob of the one-launch tower (it packs whole dialogs into groups of <= 4 row tiles and splits a group's weight stream over 4
+ * workgroups): n = -1 (default) every call 4-way; 0 every call 2-way; n > 0 (lab) 4-way when groups x 4 <= n, else 2-way -- the two
+ * splits round later layers' fp16 operands at different points (2e-3 apart), so only the first two keep a dialog's embedding
+ * independent of the other dialogs of the call. */
 void avlen_set_clip_tower_split4_wgs(int n);
 int avlen_clip_pack_stream(const avlen_clip_text* p, void* dst, int fmt, avlen_stream_t stream);
 

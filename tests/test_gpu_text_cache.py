@@ -143,3 +143,23 @@ def test_reference_dialog_process_memo_on_equals_memo_off():
     assert st0["new_dialogs"] <= st0["active_rows"] <= 3 * st0["new_dialogs"]
     for k in s0:
         assert torch.equal(s0[k], s1[k]), k
+
+
+def test_memo_at_the_benched_batch_is_independent_of_how_many_rows_changed():
+    """64 dialogs of the benched length mix: a call in which 5 rows changed reproduces, bit for bit, what the full uncached batch
+    gives -- the tower's column split must not depend on the number of dialogs it is asked to compute."""
+    pol = _policy("bf16x3")
+    net = pol.net
+    gen = torch.Generator().manual_seed(9)
+    lens = [int(x) for x in torch.randint(2, 73, (64,), generator=gen)]
+    tok = torch.stack([_dialog(gen, ln) for ln in lens]).cuda()
+    net.invalidate_text_cache()
+    first = net.encode_text_cached(pol, tok).clone()
+    tok2 = tok.clone()
+    for r, ln in ((3, 70), (17, 5), (40, 33), (41, 64), (63, 18)):
+        tok2[r] = _dialog(gen, ln).cuda()
+    got = net.encode_text_cached(pol, tok2).clone()
+    torch.cuda.synchronize()
+    assert _tower_rows(net, 64, True) == 5
+    ref = net.encode_text(pol, tok2).clone()
+    assert torch.equal(first, net.encode_text(pol, tok).clone()) and torch.equal(got, ref)
