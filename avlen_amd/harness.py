@@ -254,7 +254,7 @@ class Workload:
 
             def launch_l():
                 self.pi_l.prefetch_act_dialog(obs, h, prev, v["masks_vln"], em_vln, em_dlg, v["em_vln_masks"], v["dialog"],
-                                              v["astep"], stream=None if self._l_main else self._side[0 if self._l_where == "own" else 1],
+                                              v["astep"], stream=None if self._l_main else self._side[0 if self._l_where == "own" else self._g_stream],
                                               dialog_later=later)
             # after_option: pi_l's state-encoder half goes out BEFORE pi_g on their shared stream -- the dialog half waits for it and
             # for the text tower, pi_g only has to be done by the end of the step (host noise order unchanged: pi_l draws in

@@ -1058,8 +1058,11 @@ class _SMTBase(Net):
         if prec == L.PREC_BF16 or x3:
             # bf16 fast path: the towers run as grouped launches (rgb+depth of this policy, or -- leader of an
             # EncoderGroup -- all towers of all member policies); the audio CNN is a parallel branch under capture
-            s_aud = pol.side_streams()[0] if fork else cur
-            if fork:
+            # a follower only copies its audio features out of the group's buffers: no parallel branch for that (every branch of a
+            # captured graph is one more busy hardware queue at replay, and the process has four)
+            fork_aud = fork and mode != "follow"
+            s_aud = pol.side_streams()[0] if fork_aud else cur
+            if fork_aud:
                 s_aud.wait_stream(cur)
             vis_early = None
             if mode == "lead" and fork and _TOWERS_FIRST:
@@ -1144,8 +1147,9 @@ class _SMTBase(Net):
                E.P(ex) if ex is not None else None, ex.shape[1] if ex is not None else 0, self._x_dims, E.P(cb), E.P(lb),
                E.P(goal), self._hidden_size, B, st)
         if fork:
-            cur.wait_stream(s_rgb)
-            cur.wait_stream(s_dep)
+            for s_ in (s_rgb, s_dep):
+                if s_ is not cur:
+                    cur.wait_stream(s_)
         return feats, goal
 
     def _features_from_rows(self, pol, eng, obs, prev_actions, extra, stored):

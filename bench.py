@@ -424,6 +424,8 @@ def feature_reuse_record(a, H, W):
                   distractor=a.distractor, dialog_tokens=a.dialog_tokens)
     wl.agent.feature_reuse = True
     dt = time_cycles(wl, 2, 3)
+    for _ in range(wl.T):
+        wl.rollout_step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     wl.update()

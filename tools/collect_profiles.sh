@@ -16,16 +16,20 @@ DB=$(find /tmp/ps -name "*.db" | head -1)
 python3 $R/tools/prof_summary.py $DB > $O/rocprof_summary_head.md || exit 1
 python3 $R/tools/step_breakdown.py $DB 150 > $O/step_breakdown.md || exit 1
 python3 $R/tools/update_breakdown.py $DB > $O/update_breakdown.md || exit 1
-python3 $R/tools/step_timeline.py 2>&1 | grep "times since" > $O/step_timeline.txt || exit 1
+python3 $R/tools/step_timeline.py 64 fresh 2>&1 | grep -E "^N=|times since|dialog stats" > $O/step_timeline.txt || exit 1
+python3 $R/tools/step_timeline.py 64 reference 2>&1 | grep -E "^N=|times since|dialog stats" >> $O/step_timeline.txt || exit 1
 python3 $R/tools/step_trace.py $DB 150 40 > $O/step_trace.txt || exit 1
 # phase tables of the persistent tower launch and of the one-launch text tower (lab binaries built here: tools/bin is not tracked)
 if [ -x $R/tools/bin/x3_lab ]; then $R/tools/bin/x3_lab 64 6 > $O/tower_x3_phases.txt || exit 1; fi
 if [ -x $R/tools/bin/clip_lab ]; then
-  $R/tools/bin/clip_lab 64 > $O/clip_tower_phases.txt || exit 1
-  $R/tools/bin/clip_lab 64 72 >> $O/clip_tower_phases.txt || exit 1
-  $R/tools/bin/clip_lab 64 40 >> $O/clip_tower_phases.txt || exit 1
-  for m in "160 1" "160 2"; do set -- $m; $R/tools/bin/clip_lab 64 0 $1 $2 | grep "per launch" | sed "s/^/co-runner $1 workgroups, mode $2 (1 spin, 2 stream memory): /" >> $O/clip_tower_phases.txt; done
+  # the lab build carries phase timers (it runs ~2x slower than the product and is not bit-reproducible across launches in the
+  # 4-way split: the timers change the exchange's timing, not its arithmetic -- the product build is, tools/clip_det_probe.py)
+  $R/tools/bin/clip_lab 64 0 0 1 0 > $O/clip_tower_phases.txt || exit 1
+  $R/tools/bin/clip_lab 64 >> $O/clip_tower_phases.txt || exit 1
+  $R/tools/bin/clip_lab 16 >> $O/clip_tower_phases.txt || exit 1
 fi
+python3 $R/tools/clip_det_probe.py 2>&1 | grep -E "n=|4-way" > $O/clip_tower_splits.txt || exit 1
+for n in 64 32 16 8; do python3 $R/tools/clip_time.py $n 2>&1 | grep "per call" >> $O/clip_tower_splits.txt; done
 python3 $R/tools/clip_stream_probe.py 2>&1 | grep "stream=" > $O/clip_tower_parity_and_time.txt || exit 1
 if [ -x $R/tools/bin/gru_seq_lab ]; then $R/tools/bin/gru_seq_lab 150 8 > $O/gru_seq_phases.txt || exit 1; fi
 if [ -x $R/tools/bin/seq_lab ]; then timeout -k 10 120 $R/tools/bin/seq_lab 64 4096 > $O/handoff_latency_probe.txt || exit 1; fi
@@ -47,6 +51,8 @@ python3 $R/bench.py --config gru --steps 3 --no-roofline --no-cpu-baseline 2>/de
 python3 $R/bench.py --distractor --steps 3 --no-roofline --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/bench_distractor.log
 python3 $R/bench.py --stage 2 --envs 32 --steps 2 --no-roofline --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/bench_stage2_envs32.log
 python3 $R/bench.py --stage 2 --envs 32 --steps 2 --no-roofline --no-cpu-baseline --no-extras --precision bf16 2>/dev/null | tail -1 > $O/bench_stage2_envs32_bf16.log
+rocprofv3 --kernel-trace --stats -d /tmp/p2 -o res -- python3 $R/bench.py --stage 2 --envs 32 --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-extras > /tmp/p2.log 2>&1 || exit 1
+( echo "# 2nd stage (BASELINE configs[3] per-GPU share: 32 envs, M = 300 memory history), bf16x3: kernels of ONE PPO update (2 x 2)"; echo; echo '`rocprofv3 --kernel-trace --stats -- python bench.py --stage 2 --envs 32 --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-extras`, everything after the last `gae_kernel`:'; echo; python3 $R/tools/update_breakdown.py $(find /tmp/p2 -name "*.db" | head -1) ) > $O/update_stage2.md || exit 1
 python3 $R/bench.py --precision bf16 --steps 3 --no-roofline --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/bench_bf16.log
 python3 $R/bench.py --belief --spectrogram 65x26 --steps 3 --no-roofline --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/bench_belief_65x26.log
 rocprofv3 --kernel-trace --stats -d /tmp/pg -o res -- python3 $R/bench.py --config gru --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > /tmp/pg.log 2>&1 || exit 1

@@ -36,12 +36,16 @@ for it in range(STEPS):
     wl.pi_q.prefetch_act_option(obs, h, prev, v["masks"], em_opt, em_masks, v["qs"], v["lqi"])
     mark("q_end", cur); hmark("launch_q")
     gs = wl._side[wl._g_stream]
-    wl.pi_g.prefetch_act(obs, h, prev, v["masks"], em_goal, em_masks, stream=gs)
-    mark("g_end", gs); hmark("launch_g")
-    ls = None if wl._l_main else wl._side[0 if wl._l_where == "own" else 1]
-    wl.pi_l.prefetch_act_dialog(obs, h, prev, v["masks_vln"], em_vln, em_dlg, v["em_vln_masks"], v["dialog"], v["astep"], stream=ls,
-                                dialog_later=True)
-    mark("l_half1_end", cur if ls is None else ls); hmark("launch_l1")
+    ls = None if wl._l_main else wl._side[0 if wl._l_where == "own" else wl._g_stream]
+    def launch_g():
+        wl.pi_g.prefetch_act(obs, h, prev, v["masks"], em_goal, em_masks, stream=gs)
+        mark("g_end", gs); hmark("launch_g")
+    def launch_l1():
+        wl.pi_l.prefetch_act_dialog(obs, h, prev, v["masks_vln"], em_vln, em_dlg, v["em_vln_masks"], v["dialog"], v["astep"], stream=ls,
+                                    dialog_later=True)
+        mark("l_half1_end", cur if ls is None else ls); hmark("launch_l1")
+    for fn in ((launch_l1, launch_g) if wl._l_first else (launch_g, launch_l1)):      # the harness' order
+        fn()
     values, unct, a_opt, lp_opt, h2, row_opt, probs_opt = wl.pi_q.act_option(obs, h, prev, v["masks"], em_opt, em_masks, v["qs"], v["lqi"])
     hmark("act_q_done")
     if ref:
