@@ -347,6 +347,13 @@ class EncoderGroup:
         self.ready_key = None
         for m in self.members:
             m._enc_group = self
+        # Launch-ahead WITHOUT trainer changes: when the leader's act* call returns, the group enqueues the followers' forwards itself
+        # on a side stream -- with the arguments the followers are about to be called with, predicted from their previous calls
+        # (see auto_launch) -- and the followers' own calls pick the results up after validating every address.  AVLEN_AUTO_AHEAD=0
+        # switches it off; explicit prefetch_* calls by the caller take precedence.
+        self.auto = os.environ.get("AVLEN_AUTO_AHEAD", "1") != "0"
+        self._auto_stream = None
+        self.auto_hits = self.auto_misses = 0
 
     @staticmethod
     def _key(obs):
@@ -371,6 +378,69 @@ class EncoderGroup:
             self.pending.discard(id(pol))
             return True
         return False
+
+    # ---- automatic launch-ahead --------------------------------------------------------------------------------------------
+    @staticmethod
+    def _same(a, b):
+        if torch.is_tensor(a) and torch.is_tensor(b):
+            return a.data_ptr() == b.data_ptr() and a.shape == b.shape and a.dtype == b.dtype
+        if isinstance(a, dict) and isinstance(b, dict):
+            return a.keys() == b.keys() and all(EncoderGroup._same(a[k], b[k]) for k in a)
+        return a is b
+
+    @staticmethod
+    def _next_view(cur, prev):
+        """The view the caller will pass next if `prev`, `cur` were `base[t - 1]`, `base[t]` of one storage tensor, else None."""
+        if not (torch.is_tensor(cur) and torch.is_tensor(prev)) or cur._base is None or cur._base is not prev._base:
+            return None
+        base = cur._base
+        if base.dim() < 1 or cur.shape != base.shape[1:] or cur.dtype != base.dtype:
+            return None
+        step = base.stride(0) * base.element_size()
+        if step <= 0 or cur.data_ptr() - prev.data_ptr() != step:
+            return None
+        t = (cur.data_ptr() - base.data_ptr()) // step
+        return base[t + 1] if 0 <= t + 1 < base.shape[0] else None
+
+    def auto_launch(self, leader, lead_args):
+        """Called when the leader's direct act* call has enqueued its forward (and drawn its sampling noise).  Every follower that
+        has been called directly before gets its next forward enqueued on the group's side stream.  Its arguments are predicted:
+        an argument that had the address of one of the LEADER's arguments last time (the step's observation dict, hidden state,
+        previous actions, masks -- the trainer passes the same tensors to all three policies, ppo_trainer.py:449-636) becomes the
+        leader's current one; an address that did not move between the follower's last two calls (external-memory rings) is kept;
+        `storage[t]` views advance to `storage[t + 1]`.  The follower's real call validates every address (Policy._arg_key): a
+        wrong guess costs one discarded forward, never a wrong result."""
+        lead_prev = leader._call_hist[-2][1] if len(leader._call_hist) > 1 else None
+        if lead_prev is None or not self.auto:
+            return
+        if self._auto_stream is None:
+            self._auto_stream = torch.cuda.Stream()
+        for f in self.members[1:]:
+            h = f._call_hist
+            if len(h) < 2 or h[-1][0] != h[-2][0] or f._stash is not None or f._later is not None:
+                continue
+            which, last = h[-1]
+            before = h[-2][1]
+            pred = []
+            for i, a in enumerate(last):
+                j = next((j for j, b in enumerate(lead_prev) if a is not None and self._same(a, b)), None)
+                if which == "vln" and i in (7, 8):
+                    pred.append(a)                       # dialog tokens / agent_step: placeholders, read by the second half only
+                elif j is not None and j < len(lead_args):
+                    pred.append(lead_args[j])
+                elif a is None or not torch.is_tensor(a):
+                    pred.append(a)
+                elif self._same(a, before[i]):
+                    pred.append(a)
+                else:
+                    pred.append(self._next_view(a, before[i]))
+                    if pred[-1] is None:
+                        pred = None
+                        break
+            if pred is None:
+                continue
+            f._auto_pending = True
+            f._prefetch(which, *pred, stream=self._auto_stream, dialog_later=(which == "vln" and pred[7] is not None))
 
     def buffers(self, B, dev):
         if B not in self.out:
@@ -475,6 +545,8 @@ class Policy(nn.Module):
         self._later = None                    # ... (which, arg key, outputs, stream, all_dialog, agent_step) of that prefetch
         self.last_host_action = None          # sampling="host": pinned (B,1) int64 of the most recent draw
         self._act_host = {}                   # head set -> (pinned actions, event or None): see host_actions()
+        self._call_hist = []                  # the last two DIRECT act* calls (which, net_args): EncoderGroup.auto_launch
+        self._auto_pending = False            # a forward enqueued by EncoderGroup.auto_launch is waiting for its call
         self._param_epoch = 0                 # bumped by mark_params_changed (derived state keyed on the weights: the text memo)
         self._pinned = {}
         self._eng = None
@@ -587,6 +659,8 @@ class Policy(nn.Module):
                 # the host draws the noise in the reference's order (it does not depend on the probabilities) and uploads it; the
                 # race argmax(p / q) runs on the device (avlen_sample_race: IEEE division, first maximum): the reference's action for
                 # the same generator state, and no probabilities cross PCIe, no host synchronisation
+                if self._auto_pending:                   # a guessed forward may be discarded: its draw must then be undone
+                    out["rng_before"] = torch.get_rng_state()
                 qh, qd = self._noise_bufs(which, B, A, dev)
                 qh.exponential_(1)
                 qd.copy_(qh, non_blocking=True)
@@ -687,9 +761,17 @@ class Policy(nn.Module):
         st = self._stash
         if st is not None:
             self._stash = None
-            if st[0] == which and st[1] == self._arg_key(net_args):
+            hit = st[0] == which and st[1] == self._arg_key(net_args)
+            if self._auto_pending:
+                self._auto_pending = False
+                grp_ = self._enc_group
+                if grp_ is not None:
+                    grp_.auto_hits += int(hit); grp_.auto_misses += int(not hit)
+            if hit:
                 torch.cuda.current_stream().wait_event(st[3])        # later kernels of the caller read this forward's outputs
                 return st[2]
+            if st[2][1].get("rng_before") is not None:
+                torch.set_rng_state(st[2][1]["rng_before"])          # the discarded forward's noise draw never happened
         txt = getattr(self.net, "_text", None)
         if which == "vln" and txt is not None:
             tok = net_args[7]
@@ -741,6 +823,8 @@ class Policy(nn.Module):
             else:
                 k.append(a)
         return tuple(k)
+
+    _in_prefetch_flow = False             # the caller issues prefetch_* itself: no automatic launch-ahead on top
 
     def _prefetch(self, which, *net_args, stream=None, dialog_later=False):
         """Enqueue the forward of a later act*/get_value* call now (no host synchronisation).  The matching call, made
@@ -805,13 +889,19 @@ class Policy(nn.Module):
         self._stash = (which, self._arg_key(net_args), out, done)
 
     def prefetch_act(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks, stream=None):
+        self._mark_explicit()
         self._prefetch("goal", observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks,
                        stream=stream)
 
     def prefetch_act_option(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks,
                             query_state, last_query_info, stream=None):
+        self._mark_explicit()
         self._prefetch("option", observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks,
                        query_state, last_query_info, stream=stream)
+
+    def _mark_explicit(self):
+        for m in ([self] if self._enc_group is None else self._enc_group.members):
+            m._in_prefetch_flow = True
 
     def prefetch_text(self, all_dialog, stream, after_current=True):
         """pi_l only: start the frozen CLIP text tower for this step's dialog on `stream` right away (see net.prefetch_text).
@@ -825,6 +915,7 @@ class Policy(nn.Module):
         """dialog_later=True: `all_dialog` and `agent_step` are the tensors the trainer fills only after `act_option` has returned
         (`current_dialog`, `rollouts.agent_step[step]`: ppo_trainer.py:347, 582-593).  Only the half of the forward that reads
         neither is enqueued now; call `dialog_ready()` once both hold this step's values."""
+        self._mark_explicit()
         self._prefetch("vln", observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_dialog,
                        ext_memory_masks, all_dialog, agent_step, stream=stream, dialog_later=dialog_later)
 
@@ -887,29 +978,55 @@ class Policy(nn.Module):
     # ------------------------------------------------------------------ reference API
     def act(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks,
             deterministic=False):
-        (features, rnn_hidden_states, ext_memory_feats), h = self._forward(
-            "goal", observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks)
+        args = (observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks)
+        (features, rnn_hidden_states, ext_memory_feats), h = self._forward("goal", *args)
         h = self._finish("goal", features, h, deterministic=deterministic)
+        self._after_act("goal", args)
         return h["value"], h["action"], h["log_prob"], rnn_hidden_states, ext_memory_feats, h["probs"]
 
     def act_option(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks,
                    query_state, last_query_info, deterministic=False):
-        (features, rnn_hidden_states, ext_memory_feats), h = self._forward(
-            "option", observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks, query_state,
-            last_query_info)
+        args = (observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks, query_state, last_query_info)
+        (features, rnn_hidden_states, ext_memory_feats), h = self._forward("option", *args)
         h = self._finish("option", features, h, deterministic=deterministic)
+        self._after_act("option", args)
         return (h["value"], h["unct"], h["action"], h["log_prob"], rnn_hidden_states, ext_memory_feats, h["probs"])
 
     def act_dialog(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_dialog,
                    ext_memory_masks, all_dialog, agent_step, deterministic=False, without_dialog=False):
         if without_dialog:
             all_dialog = None
-        (features, rnn_hidden_states, ext_memory_feats, ext_memory_dialog_feats), h = self._forward(
-            "vln", observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_dialog,
-            ext_memory_masks, all_dialog, agent_step)
+        args = (observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_dialog, ext_memory_masks, all_dialog,
+                agent_step)
+        lt = self._later
+        if lt is not None and self._auto_pending and lt[0] == "vln":
+            # the first half was enqueued by EncoderGroup.auto_launch: if it ran on the tensors of THIS call, the text tower and the
+            # second half follow now, on the call's own dialog tokens / agent_step
+            if all_dialog is not None and lt[1][:7] == self._arg_key(args[:7]):
+                self._later = (lt[0], self._arg_key(args), lt[2], lt[3], all_dialog, agent_step)
+                self.dialog_ready()
+            else:
+                self._later = self._deferred = None
+                self._auto_pending = False
+                if self._enc_group is not None:
+                    self._enc_group.auto_misses += 1
+        (features, rnn_hidden_states, ext_memory_feats, ext_memory_dialog_feats), h = self._forward("vln", *args)
         h = self._finish("vln", features, h, deterministic=deterministic)
+        self._after_act("vln", args)
         return (h["value"], h["action"], h["log_prob"], rnn_hidden_states, ext_memory_feats,
                 ext_memory_dialog_feats, h["probs"])
+
+    def _after_act(self, which, args):
+        """Bookkeeping of a direct act* call for the group's automatic launch-ahead (EncoderGroup.auto_launch)."""
+        grp = self._enc_group
+        if grp is None or not grp.auto or not self.use_graphs or self.precision not in ("bf16", "bf16x3"):
+            return
+        h = self._call_hist
+        h.append((which, args))
+        if len(h) > 2:
+            del h[0]
+        if grp.leader is self and not self._in_prefetch_flow:
+            grp.auto_launch(self, args)
 
     def get_value(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks):
         features, _, _ = self.net.run(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory,

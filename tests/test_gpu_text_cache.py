@@ -163,3 +163,34 @@ def test_memo_at_the_benched_batch_is_independent_of_how_many_rows_changed():
     assert _tower_rows(net, 64, True) == 5
     ref = net.encode_text(pol, tok2).clone()
     assert torch.equal(first, net.encode_text(pol, tok).clone()) and torch.equal(got, ref)
+
+
+def test_automatic_launch_ahead_equals_explicit_and_plain_calls():
+    """share_encoders alone (no prefetch_* calls in the trainer): the leader's act_option enqueues the followers' forwards itself on
+    predicted arguments, the followers' calls validate the addresses and pick the results up.  Same storage, bit for bit, as the
+    explicit launch-ahead flow and as the fully serial flow (AVLEN_AUTO_AHEAD off), incl. the rollout wrap-around where the guess
+    is wrong; and the guesses are right on all other steps."""
+    N, T = 4, 5
+    outs = {}
+    for name, kw, auto in (("explicit", dict(launch_ahead=True), True), ("auto", dict(launch_ahead=False), True),
+                           ("serial", dict(launch_ahead=False), False)):
+        wl = _run(N, T, precision="bf16x3", **kw)
+        wl.pi_q._enc_group.auto = auto
+        for _ in range(T):
+            wl.rollout_step()
+        first = _storage_snapshot(wl)
+        wl.rollouts.after_update()                          # (no optimiser step: its loss sums are not bit-reproducible run to run)
+        for _ in range(3):                                  # past the wrap-around: slot 0 again after after_update
+            wl.rollout_step()
+        torch.cuda.synchronize()
+        grp = wl.pi_q._enc_group
+        outs[name] = (first, _storage_snapshot(wl), grp.auto_hits, grp.auto_misses, torch.get_rng_state())
+        del wl
+    for name in ("auto", "serial"):
+        for part in (0, 1):
+            for k in outs["explicit"][part]:
+                assert torch.equal(outs["explicit"][part][k], outs[name][part][k]), (name, part, k)
+        assert torch.equal(outs["explicit"][4], outs[name][4]), name          # the host generator ends in the same state
+    assert outs["serial"][2] == 0 and outs["explicit"][2] == 0
+    # two followers x (T + 3) steps; no guess on the first two steps (no history), wrong or absent around the wrap-around
+    assert outs["auto"][2] >= 2 * (T + 3) - 8 and outs["auto"][3] <= 2, outs["auto"][2:4]
