@@ -293,6 +293,20 @@ class BeliefPredictor(nn.Module):
         g["graph"].replay()
         L.multi_copy([(outs[k], g["out"][k]) for k in outs])
 
+    def update_async(self, observations, dones, stream):
+        """`update` on `stream` (ordered after everything enqueued so far on the caller's stream): the beliefs are written into
+        `observations[...]` -- pass the views of the rollout storage's slot, AFTER `rollouts.insert` -- while the caller goes on to
+        launch the next step's policies; `self.done` (an event) fires when they are in place: hand it to the leader policy
+        (`policy.late_inputs((location_belief, category_belief), predictor.done)`), whose visual towers then run beside the two
+        belief networks instead of after them."""
+        stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream):
+            self.update(observations, dones)
+            if getattr(self, "done", None) is None:
+                self.done = torch.cuda.Event()
+            self.done.record(stream)
+        return self.done
+
     def _update_two_graphs(self, obs, d, outs, key):
         """update() with the classifier and the predictor captured as separate graphs (see _TWO_GRAPHS)."""
         spec = obs[SPECTROGRAM]

@@ -122,6 +122,15 @@ class Workload:
                                          current_pred_only=False, weighting_factor=0.5)
             self.belief = BeliefPredictor(bcfg, self.dev, None, None, 512, num_env=num_envs, precision=precision,
                                           load_pretrained=False, use_graphs=use_graphs).to(self.dev)
+        self._belief_async = self.belief is not None and use_graphs and launch_ahead and share_encoders and precision == "bf16x3" \
+            and os.environ.get("AVLEN_BELIEF_ASYNC", "0") != "0"
+        # Measured (65x26, 64 envs, bf16x3): 24.9 k env-steps/s asynchronous vs 24.8 k synchronous at 4 hardware queues, 25.6 k vs 24.7 k
+        # at 8 -- the two belief ResNet-18s are ~85 chip-wide launches of 5-12 us; on the 16-64 CUs the persistent tower launch can
+        # spare they run 4-8x longer, so the 0.6 ms they cost barely hides.  Off by default (AVLEN_BELIEF_ASYNC=1 enables).
+        if self._belief_async:
+            self._belief_stream = torch.cuda.Stream()
+            from . import _lib as L
+            L.lib.avlen_set_tower_x3_reserved_cus(int(os.environ.get("AVLEN_BELIEF_CUS", "32")))
         self._make_simulator_output(seed)
 
     # -- what the CPU simulator + trainer bookkeeping would have produced, resident in HBM ------------------
@@ -312,7 +321,7 @@ class Workload:
             ah = self._act_host[t & 3]
             ah.copy_(actions, non_blocking=True)
             torch.cuda.current_stream().synchronize()
-        if self.belief is not None:                 # beliefs of the NEW observation, written in place before it is stored
+        if self.belief is not None and not self._belief_async:   # beliefs of the NEW observation, written in place before it is stored
             self.belief.update(v["nxt"], v["dones"])
         if return_outs:                             # graph outputs are overwritten by the next replay
             o = {k: (x.clone() if torch.is_tensor(x) else x) for k, x in o.items()}
@@ -321,6 +330,13 @@ class Workload:
         ro.insert(v["nxt"], o["h"], actions, a_opt, o["lp_q"], o["q_value"], v["rew"], v["nd"], v["nd"], o["row_g"], o["row_q"],
                   o["row_l"], o["row_d"], dlg, self.o_action, self.o_mask, v["rl"], v["ucnt"], o["l_prob"], v["qs"],
                   v["lqi"], astep)
+        if self.belief is not None and self._belief_async:
+            # asynchronous form: the new observation is stored first, the two belief networks then write their beliefs into the
+            # storage slot on their own stream while the next step's visual towers already run (which leave them a few CUs:
+            # avlen_set_tower_x3_reserved_cus); the rest of the next forward waits for the event (Policy.late_inputs)
+            slot = {k: x[ro.step] for k, x in ro.observations.items()}
+            ev = self.belief.update_async(slot, v["dones"], self._belief_stream)
+            self.pi_q.late_inputs(("location_belief", "category_belief"), ev)
         return o if return_outs else None
 
     def finite(self):
@@ -331,6 +347,9 @@ class Workload:
     # -- _update_agent (ppo_trainer.py:1045-1093) -------------------------------------------------------------
     def update(self):
         ro, s = self.rollouts, self.rollouts.step
+        if self.belief is not None and self._belief_async and getattr(self.belief, "done", None) is not None:
+            torch.cuda.current_stream().wait_event(self.belief.done)       # the last slot's beliefs
+            self.pi_q.late_inputs((), None)
         last = {k: v[s] for k, v in ro.observations.items()}
         nv = self.pi_q.get_value_option(last, ro.recurrent_hidden_states[s], ro.prev_actions[s], ro.masks[s],
                                         ro.external_memory_option[:, s], ro.external_memory_masks[s],

@@ -540,6 +540,7 @@ class Policy(nn.Module):
         self._capture = None                  # the _Graph being captured (lets a forward cut itself in two, see _Graph.split)
         self._between = None                  # host action between the two halves of a split graph
         self._mid = None                      # leader of an EncoderGroup: EncoderGroup.signal between the halves of its cut graph
+        self._late_inputs = None              # (observation keys, event): see late_inputs()
         self._defer_second = False            # prefetch_act_dialog(dialog_later=True): replay only the first half of the cut graph
         self._deferred = None                 # ... the graph whose second half dialog_ready() replays
         self._later = None                    # ... (which, arg key, outputs, stream, all_dialog, agent_step) of that prefetch
@@ -791,6 +792,20 @@ class Policy(nn.Module):
                 grp.mark(net_args[0])
                 mode = "lead"
                 self._mid = grp.signal if self.use_graphs else None      # between the halves of the leader's graph (cut in net.features)
+                late = self._late_inputs
+                if late is not None and self.use_graphs:
+                    # observation entries that are still being written when this forward starts (the BeliefPredictor's beliefs,
+                    # updated on its own stream beside the visual towers): the first half -- towers, AudioCNNs -- does not read them;
+                    # between the halves the stream waits for their event and their static copies are refreshed
+                    keys, ev, obs_now = late[0], late[1], net_args[0]
+
+                    def mid(keys=keys, ev=ev, obs_now=obs_now, grp=grp):
+                        torch.cuda.current_stream().wait_event(ev)
+                        so = grp.static_obs
+                        if so is not None and so is not obs_now:
+                            L.multi_copy([(so[k], _f32(obs_now[k])) for k in keys if k in so])
+                        grp.signal()
+                    self._mid = mid
             elif grp.claim(self, net_args[0]):
                 mode = "follow"
         self._shared_mode = mode
@@ -1015,6 +1030,13 @@ class Policy(nn.Module):
         self._after_act("vln", args)
         return (h["value"], h["action"], h["log_prob"], rnn_hidden_states, ext_memory_feats,
                 ext_memory_dialog_feats, h["probs"])
+
+    def late_inputs(self, keys, event):
+        """Leader of an EncoderGroup with `use_graphs`: the observation entries `keys` of the NEXT act* call are complete only when
+        `event` has fired (e.g. `BeliefPredictor.update_async` writing `location_belief` / `category_belief` into the storage slot
+        while this step's visual towers already run).  The towers / AudioCNNs start at once; the rest of the forward -- and the
+        followers -- wait for the event.  Pass event=None to clear."""
+        self._late_inputs = None if event is None else (tuple(keys), event)
 
     def _after_act(self, which, args):
         """Bookkeeping of a direct act* call for the group's automatic launch-ahead (EncoderGroup.auto_launch)."""

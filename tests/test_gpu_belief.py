@@ -284,3 +284,38 @@ def test_predictor_gradients_match_oracle_autograd(precision, distractor):
     # bf16 operands through 20 convolutions and 20 GroupNorms of a random-weight network: single small tensors (cancelling sums
     # such as a GroupNorm bias) deviate by tens of percent; the gradient as a whole must still point the same way
     assert cos > (0.999999 if fp else 0.97), cos
+
+
+def test_asynchronous_belief_update_equals_the_synchronous_one():
+    """`BeliefPredictor.update_async` + `Policy.late_inputs` (the two belief networks write into the storage slot on their own stream
+    beside the next step's visual towers; the rest of the forward waits for their event) against the reference's order (beliefs
+    written before the observation is stored, belief_predictor.py:139-206 / ppo_trainer.py:890-894): the same rollout, bit for bit."""
+    import os
+    from avlen_amd.harness import Workload
+    from avlen_amd import _lib as L
+    snaps = []
+    try:
+        for mode in ("1", "0"):
+            os.environ["AVLEN_BELIEF_ASYNC"] = mode
+            torch.manual_seed(5)
+            wl = Workload(6, 7, spectrogram=(65, 26, 2), precision="bf16x3", belief_predictor=True, em_capacity=5)
+            assert wl._belief_async == (mode == "1")
+            for _ in range(7):
+                wl.rollout_step()
+            torch.cuda.synchronize()                         # (no optimiser step: its loss sums are not bit-reproducible run to run)
+            wl.rollouts.after_update()
+            for _ in range(2):
+                wl.rollout_step()
+            torch.cuda.synchronize()
+            ro = wl.rollouts
+            snaps.append(({k: v.clone() for k, v in ro.observations.items() if k.endswith("belief")},
+                          ro.value_preds.clone(), ro.actions.clone(), ro.em.memory.clone(), ro.em_option.memory.clone()))
+            del wl
+    finally:
+        os.environ.pop("AVLEN_BELIEF_ASYNC", None)
+        L.lib.avlen_set_tower_x3_reserved_cus(0)
+    a, b = snaps
+    for k in a[0]:
+        assert float(a[0][k].abs().sum()) > 0 and torch.equal(a[0][k], b[0][k]), k
+    for x, y in zip(a[1:], b[1:]):
+        assert torch.equal(x, y)
