@@ -36,6 +36,7 @@ bool attn_bwd16_on() {          // AVLEN_ATTN_BWD16=0: fp32 attention backward i
   return v != 0;
 }
 long g_big_m = -1;
+long g_mixed_rows = 65536;     // bf16x3: token rows from which avlen_smt_bwd runs its products on plain bf16 operands (0 = never)
 long big_m() {
   if (g_big_m < 0) g_big_m = (long)avlen_knob("AVLEN_BIGM", 4096);
   return g_big_m;
@@ -1732,10 +1733,15 @@ extern "C" int avlen_smt_bwd(const avlen_smt* p, const avlen_smt* g, const float
   if (!p || !g || ws_bytes < avlen_smt_workspace_bytes(p, B, M, F, cto)) return AVLEN_ERR_WS;
   WsBump w(ws, ws_bytes); SmtWs s;
   smt_layout(w, s, p, B, M, F, cto != 0);
-  Ctx c{st, prec, s.gws, GEMM_SCRATCH};
-  c.xs = s.xs; c.xs_bytes = s.xs_bytes;
   const int S = cto ? 1 : M + 1, d = p->tr.d;
   const long R = (long)B * S;
+  // Compensated mode at scale (2nd stage: 722 k token rows per minibatch): the FORWARD stays compensated -- it decides the logits,
+  // the ratio, the losses -- while the backward's products and its attention run on plain bf16 operands with fp32 accumulation
+  // (standard mixed-precision training: gradient terms carry ~1e-2 relative instead of ~1e-4), 1 pass instead of 3 and the
+  // matrix-core attention backward instead of the fp32 VALU one: 257 -> ~170 ms per update.  Below g_mixed_rows nothing changes.
+  const bool mixed = prec == AVLEN_PREC_BF16X3 && g_mixed_rows > 0 && R >= g_mixed_rows;
+  Ctx c{st, mixed ? AVLEN_PREC_BF16 : prec, s.gws, GEMM_SCRATCH};
+  c.xs = s.xs; c.xs_bytes = s.xs_bytes;
   TRY(transformer_bwd(c, p->tr, g->tr, s.tr, s.tb, s.Z, s.maskx, goal, d_out, s.dZ, B, S, cto != 0));
   // fusion MLP
   TRY(linear_dw(c, g->fus2, s.dZ, d, s.H1, d, (int)R));
@@ -1749,7 +1755,7 @@ extern "C" int avlen_smt_bwd(const avlen_smt* p, const avlen_smt* g, const float
   }
   // pose encoder: dPE[R,16] = dH1 * W0[:, pc:pc+16]
   TRY(avlen_gemm(s.dH1, d, 0, p->fus0.w + pose_col, p->fus0.in_f, 1, s.dPE, 16, nullptr, nullptr, 0, (int)R, 16, d, 0,
-                 prec, 1, 0.f, s.gws, GEMM_SCRATCH, st));
+                 c.prec, 1, 0.f, s.gws, GEMM_SCRATCH, st));
   int rpb = R >= 65536 ? 2048 : 256;
   hipLaunchKernelGGL(pose_grad_kernel, dim3((unsigned)((R + rpb - 1) / rpb)), dim3(96), 0, st, s.dPE, s.FMT, g->pose.w,
                      g->pose.b, R, rpb);
@@ -2238,3 +2244,6 @@ extern "C" int avlen_gru_fwd(const avlen_gru* p, const float* x, const float* h0
 // minibatch of 4800 rows runs 2.5 ms per update faster on it than on the fp32-staged kernel; lab env AVLEN_BIGM); <= 0 restores
 // the default.  A tuning / test knob, not part of the reference's interface.
 extern "C" void avlen_set_big_m(long rows) { g_big_m = rows > 0 ? rows : 4096; }
+// bf16x3: token rows (B x (M + 1)) from which the SMT backward uses plain bf16 operands (forward stays compensated); 0 = never,
+// < 0 restores the default (65536).
+extern "C" void avlen_set_x3_mixed_backward_rows(long rows) { g_mixed_rows = rows < 0 ? 65536 : rows; }

@@ -303,6 +303,10 @@ int avlen_smt_bwd(const avlen_smt* p, const avlen_smt* g, const float* goal, con
 /* Tuning knob: row count from which the training path's Linear products (avlen_smt_fwd with save_for_backward,
  * avlen_smt_bwd, bf16 mode) cast their fp32 operands to bf16 once and run the glds/MFMA GEMM (default 4096 rows). */
 void avlen_set_big_m(long rows);
+/* bf16x3 training at scale: from `rows` token rows (B x (M + 1); default 65536, 0 = never, < 0 = default) avlen_smt_bwd runs the
+ * backward's products and attention on plain bf16 operands with fp32 accumulation (mixed-precision training); the forward -- the
+ * logits, the PPO ratio, the losses -- stays compensated at every size. */
+void avlen_set_x3_mixed_backward_rows(long rows);
 /* Scheduling knob of the bf16x3 tower group (one persistent work-queue launch, one workgroup per CU): CUs it leaves free for the
  * other streams of the step (default 0 = every CU). */
 void avlen_set_tower_x3_reserved_cus(int n);
