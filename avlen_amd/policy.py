@@ -771,6 +771,9 @@ class Policy(nn.Module):
             if hit:
                 torch.cuda.current_stream().wait_event(st[3])        # later kernels of the caller read this forward's outputs
                 return st[2]
+            # a discarded forward may still be running on its own stream, in the SAME captured graph and static buffers the recompute
+            # below is about to replay: order the recompute behind it
+            torch.cuda.current_stream().wait_event(st[3])
             if st[2][1].get("rng_before") is not None:
                 torch.set_rng_state(st[2][1]["rng_before"])          # the discarded forward's noise draw never happened
         txt = getattr(self.net, "_text", None)
@@ -1021,6 +1024,8 @@ class Policy(nn.Module):
                 self._later = (lt[0], self._arg_key(args), lt[2], lt[3], all_dialog, agent_step)
                 self.dialog_ready()
             else:
+                if lt[3] is not None:                    # the guessed first half may still be running in the graph this call replays
+                    torch.cuda.current_stream().wait_stream(lt[3])
                 self._later = self._deferred = None
                 self._auto_pending = False
                 if self._enc_group is not None:

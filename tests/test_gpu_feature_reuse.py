@@ -32,6 +32,7 @@ def test_feature_reuse_equals_recompute(precision, pre):
     print(f"{precision} pretraining={pre}: 6-tuple recompute {a} reuse {b}; max |d param| {worst:.3e}")
     # The stored features come from the rollout's grouped encoder call (batch N), the recompute from the update's row-indexed call
     # (batch T * N / 2): the same kernels, but the fc / AudioCNN GEMMs tile (and split K) by the batch size, so a feature may
-    # differ in its last bit -- measured: parameters after the step agree to 1.2e-7, the losses to 1e-6 relative.
-    np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-6)
-    assert worst <= 1e-6, worst
+    # differ in its last bit.  The losses agree to 1e-6 relative; Adam's normalised step turns a last-bit change of a near-zero
+    # gradient element into a step difference of up to lr (2.5e-4): measured 1.2e-7 .. 2.6e-5 on the parameters after 4 steps.
+    np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-5)
+    assert worst <= 1e-4, worst
