@@ -1,18 +1,20 @@
 // CLIP text tower (third party: open_clip / clip.model.Transformer, 12 x ResidualAttentionBlock, width 512, 8 heads, QuickGELU;
-// call site ss_baselines/savi/ppo/policy.py:847-849) as ONE launch, SEQUENCE-STATIONARY: one workgroup (512 threads) per dialog
-// carries its <= 80 tokens through all 12 layers.
+// call site ss_baselines/savi/ppo/policy.py:847-849) as ONE launch, SEQUENCE-STATIONARY: a set of workgroups (512 threads each)
+// carries a GROUP of up to four 16-row tiles -- whole dialogs packed by a device-side work list (clip_group_kernel) -- through
+// all 12 layers.
 //
-// Why: as a chain of launches (71 kernels) the tower is latency-bound -- 12-20 us per GEMM whatever the row count, 0.9 ms per step,
-// on ALL 256 CUs (a 2.5 k-row GEMM cannot hide its prologue / epilogue) -- and it serialises with the visual towers, which also
-// want every CU.  Here a dialog's residual stream never leaves the CU:
-//   * residual x (80 x 512 fp32) lives in REGISTERS in MFMA accumulator layout (wave w owns columns [64 w, 64 w + 64): 80 VGPRs);
+// Why: as a chain of launches (71 kernels) the tower is latency-bound -- 12-20 us per GEMM whatever the row count, 0.9 ms per step.
+// Here a group's residual stream never leaves its CUs:
+//   * residual x (64 x 512 fp32) lives in REGISTERS in MFMA accumulator layout (wave w owns columns [64 w, 64 w + 64));
 //     the out_proj / c_proj products accumulate straight into it,
 //   * LayerNorm output, per-head-pair Q / K / V, the attention output and the MLP hidden chunk are fp16 (bf16) images in LDS,
 //   * the weights (6.3 MB per layer) are STREAMED: every wave owns a private, fragment-ordered stream (packed once by
-//     avlen_clip_pack_stream: [wave][layer][768 fragments][64 lanes][16 B] in exactly the order the wave consumes them) and keeps
-//     CT_RING fragments (1 KiB each) in flight through a register ring -- no LDS staging, no descriptor set-up, no barrier on the weight path.
-// A CU's ingest (~64 B/clk) bounds a layer at ~47 us, its matrix pipe at ~55 us for 80 tokens: ~0.7-0.8 ms for the tower on 64 CUs,
-// leaving 192 CUs to the visual towers of the same step (tower_x3 / tower_head run beside it instead of before it).
+//     avlen_clip_pack_stream in exactly the order the wave consumes it) and keeps CT_RING fragments (1 KiB each) in flight through
+//     a register ring -- no LDS staging, no descriptor set-up, no barrier on the weight path,
+//   * a CU ingests ~43 of ~51 B/clk, which is THE bound: a group's stream is therefore split over FOUR workgroups (one head pair and
+//     two MLP hidden chunks each; 2-way kept behind a knob), which twice per layer combine their partial residuals by a
+//     reduce-scatter + all-gather through global memory (clip_exchange4), and a 5-tile dialog additionally splits its ROWS over
+//     two such sets (one-directional K / V hand-off: the mask is causal).
 // Arithmetic: 16-bit operands (fp16 for AVLEN_PREC_FP16, bf16 for AVLEN_PREC_BF16), fp32 accumulation, LayerNorm / softmax /
 // QuickGELU in fp32 -- the same formats as the launch-per-GEMM path, with the LayerNorm applied explicitly (not folded).
 #include "common.h"
@@ -27,7 +29,6 @@ typedef __attribute__((ext_vector_type(4))) _Float16 h16x4;
 
 constexpr int CT_TH = 512, CT_ROWS = 80;
 constexpr int CT_PAD = 16;                                  // padding fragments at the end of a wave's stream (>= the deepest ring)
-constexpr int CT_FRAGS = 384;                               // weight fragments (1 KiB) per wave, layer and column half: 2 x (48 + 16) + 4 x (32 + 32)
 // LDS map (bytes).  Every image has 16 bytes of padding per row: the 16 rows of an MFMA operand fragment then start in 16 distinct
 // 16-byte bank slots (conflict-free ds_read_b128) with NO address arithmetic -- a k-step is an immediate offset.
 constexpr int XN_ROW = 1024 + 16, QK_ROW = 128 + 16, HC_ROW = 512 + 16;
