@@ -198,7 +198,8 @@ class BeliefPredictor(nn.Module):
 
     def _side_stream(self):
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream()
+            from .policy import process_stream
+            self._side = process_stream("belief_side")
         return self._side
 
     def _filter_state(self, B):
@@ -269,7 +270,8 @@ class BeliefPredictor(nn.Module):
             st_d = torch.zeros(spec.shape[0], dtype=torch.uint8, device=spec.device)
             st_out = {k: torch.zeros_like(v) for k, v in outs.items()}
             saved = {k: v.clone() for k, v in self._state.items() if torch.is_tensor(v)}
-            side = torch.cuda.Stream()
+            from .policy import process_stream
+            side = process_stream("belief_warmup")
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                                 # warm-up outside capture
                 self._update_eager(st_in, st_d, st_out)
@@ -320,7 +322,7 @@ class BeliefPredictor(nn.Module):
             run_cls = lambda: self._run("classifier", st_in[SPECTROGRAM], s["labels"])
             run_pred = lambda: self._run("predictor", self._predictor_input(st_in), s["pg"])
             from .policy import _capture_stream
-            cap = _capture_stream() if _SHARED_CAPTURE else torch.cuda.Stream()
+            cap = _capture_stream()
             cap.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(cap):                                  # warm-up outside capture (the filter state is not touched)
                 run_cls(); run_pred()

@@ -26,9 +26,6 @@ def sinusoid_table(n, d):
     return pe
 
 
-_SIDE = None
-
-
 class Workload:
     def __init__(self, num_envs, num_steps=150, spectrogram=(257, 101, 2), precision="bf16x3", pretraining=True,
                  em_capacity=150, ppo_epoch=2, num_mini_batch=2, device="cuda", seed=0, sampling="race",
@@ -71,7 +68,7 @@ class Workload:
         self._l_main = self._l_where == "main"
         self._l_first = os.environ.get("AVLEN_L_FIRST", "1") != "0"              # A/B knob
         tpr = os.environ.get("AVLEN_TEXT_STREAM")                                # lab knob: "hi" / "own" = text tower on its own stream
-        self._text_stream = None if tpr is None else torch.cuda.Stream(priority=-1 if tpr == "hi" else 0)
+        self._text_stream = None if tpr is None else P.process_stream("harness_text_own", -1 if tpr == "hi" else 0)
         self._views_ahead = os.environ.get("AVLEN_VIEWS_AHEAD", "1") != "0"       # A/B knob
         self._next_views = None
         self._text_after = os.environ.get("AVLEN_TEXT_AHEAD", "1") == "2"     # 2: ordered after the current stream (debug)
@@ -79,13 +76,11 @@ class Workload:
         # squeeze the towers; launched second, the text tower fills the gaps the memory-bound tower kernels leave
         self._text_first = os.environ.get("AVLEN_TEXT_FIRST", "0") != "0"
         tp = int(os.environ.get("AVLEN_TEXT_PRIORITY", "0"))            # lab knob: stream priority of the text tower's stream
-        # ONE set of side streams per process: the runtime maps streams to its 4 hardware queues in creation order, so a second
-        # Workload with fresh streams can land pi_g's stream on the text tower's queue (seen as records of one bench run that
-        # differ by 10 % for no other reason)
-        global _SIDE
-        if launch_ahead and (_SIDE is None or _SIDE[1] != tp):
-            _SIDE = ([torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream(priority=tp)], tp)
-        self._side = _SIDE[0] if launch_ahead else None
+        # ONE set of side streams per process (policy.process_stream): the runtime maps streams to its 4 hardware queues in creation
+        # order, so a second Workload with fresh streams can land pi_g's stream on the text tower's queue (seen as records of one
+        # bench run that differ by 10 % for no other reason) -- and torch's stream pool wraps around after 32 creations
+        self._side = [P.process_stream("harness0"), P.process_stream("harness1"), P.process_stream("harness_text", tp)] \
+            if launch_ahead else None
         osp, asp = savi_observation_space(spectrogram), ActionSpace(4)
         torch.manual_seed(weight_seed)          # identical initial weights on every rank (data-parallel replicas)
         kw = dict(SMT_KW, precision=precision, sampling=sampling, use_graphs=use_graphs)
@@ -137,7 +132,7 @@ class Workload:
         # at 8 -- the two belief ResNet-18s are ~85 chip-wide launches of 5-12 us; on the 16-64 CUs the persistent tower launch can
         # spare they run 4-8x longer, so the 0.6 ms they cost barely hides.  Off by default (AVLEN_BELIEF_ASYNC=1 enables).
         if self._belief_async:
-            self._belief_stream = torch.cuda.Stream()
+            self._belief_stream = P.process_stream("belief_async")
             from . import _lib as L
             L.lib.avlen_set_tower_x3_reserved_cus(int(os.environ.get("AVLEN_BELIEF_CUS", "32")))
         self._make_simulator_output(seed)
@@ -329,7 +324,7 @@ class Workload:
                 self._act_host = [torch.empty(actions.shape, dtype=actions.dtype, pin_memory=True) for _ in range(4)]
             ah = self._act_host[t & 3]
             ah.copy_(actions, non_blocking=True)
-            torch.cuda.current_stream().synchronize()
+            P._cur_stream().synchronize()
         if self.belief is not None and not self._belief_async:   # beliefs of the NEW observation, written in place before it is stored
             self.belief.update(v["nxt"], v["dones"])
         if return_outs:                             # graph outputs are overwritten by the next replay

@@ -82,15 +82,39 @@ _SPLIT = True        # pi_l's captured forward is cut in two around the text emb
 
 
 _CAP = None
+_STREAM_OBJ = {}
+_NAMED = {}
+
+
+def process_stream(name, priority=0):
+    """A process-wide stream by role name.  torch hands out streams from a pool of 32 per device and priority, ROUND-ROBIN and
+    without tracking who still uses them: a process that keeps creating streams (one set per policy, per workload, per test)
+    eventually gets the pool slot of a stream that is still in use -- e.g. a policy's capture-fork stream that IS the shared
+    capture stream, so the captured forward forks onto the very stream it is being captured on (seen as a segmentation fault
+    at the first replay of such a graph, after ~30 policies in one process).  Every auxiliary stream of this package therefore
+    exists once per process and role."""
+    key = (name, priority, torch._C._cuda_getDevice())
+    st = _NAMED.get(key)
+    if st is None:
+        st = _NAMED[key] = torch.cuda.Stream(priority=priority)
+    return st
+
+
+def _cur_stream():
+    """_cur_stream() without building a Stream object per call (3 us each, 16 calls per rollout step): the raw
+    handle of the current stream is one C call, the Stream object for it is cached."""
+    dev = torch._C._cuda_getDevice()
+    raw = torch._C._cuda_getCurrentRawStream(dev)
+    s = _STREAM_OBJ.get((dev, raw))
+    if s is None:
+        s = _STREAM_OBJ[(dev, raw)] = torch.cuda.current_stream()
+    return s
 
 
 def _capture_stream():
     """ONE capture stream for every graph (as torch.cuda.graph does): each extra stream shifts the round-robin mapping of
     streams to the 4 hardware queues, and with it which replaying graphs end up serialised behind each other."""
-    global _CAP
-    if _CAP is None:
-        _CAP = torch.cuda.Stream()
-    return _CAP
+    return process_stream("capture")
 
 
 class _Graph:
@@ -106,16 +130,16 @@ class _Graph:
         pol._ws = E.Workspaces()                         # this graph owns its scratch
         try:
             side = _capture_stream()
-            side.wait_stream(torch.cuda.current_stream())
+            side.wait_stream(_cur_stream())
             with torch.cuda.stream(side):                # warm-up outside capture (lazy HIP init, attributes)
                 fn(*self.static)
-            torch.cuda.current_stream().wait_stream(side)
+            _cur_stream().wait_stream(side)
             torch.cuda.synchronize()
             # Captured by hand (not `with torch.cuda.graph`) so that the forward may cut itself into TWO graphs at
             # `split()`: the host can then wait for an outside event (pi_l's text tower) between the two replays.
             self.graph, self.graph2, self.between, self.mid = torch.cuda.CUDAGraph(), None, None, None
             cap = _capture_stream()
-            cap.wait_stream(torch.cuda.current_stream())
+            cap.wait_stream(_cur_stream())
             pol._capture = self
             try:
                 with torch.cuda.stream(cap):
@@ -126,7 +150,7 @@ class _Graph:
                         (self.graph2 if self.graph2 is not None else self.graph).capture_end()
             finally:
                 pol._capture = None
-            torch.cuda.current_stream().wait_stream(cap)
+            _cur_stream().wait_stream(cap)
             self.ws = pol._ws
         finally:
             pol._ws = ws_saved
@@ -368,7 +392,7 @@ class EncoderGroup:
         """The shared encoders of the marked observation are enqueued on the current stream."""
         if self.ready is None:
             self.ready = torch.cuda.Event()
-        self.ready.record(torch.cuda.current_stream())
+        self.ready.record(_cur_stream())
         self.ready_key = self.key
 
     def claim(self, pol, obs):
@@ -414,7 +438,7 @@ class EncoderGroup:
         if lead_prev is None or not self.auto:
             return
         if self._auto_stream is None:
-            self._auto_stream = torch.cuda.Stream()
+            self._auto_stream = process_stream("auto_followers")
         for f in self.members[1:]:
             h = f._call_hist
             if len(h) < 2 or h[-1][0] != h[-2][0] or f._stash is not None or f._later is not None:
@@ -556,6 +580,14 @@ class Policy(nn.Module):
         for m in self.modules():
             m.register_load_state_dict_post_hook(lambda mod, keys, p=self: p.mark_params_changed())
 
+    def __setattr__(self, name, value):
+        # the per-call bookkeeping (_stash, _mid, _later, ...: ~45 assignments per rollout step) does not need nn.Module's
+        # parameter / buffer / sub-module registration walk
+        if name[0] == "_" and not isinstance(value, (torch.Tensor, nn.Module)) and name not in self.__dict__.get("_modules", ()):
+            object.__setattr__(self, name, value)
+        else:
+            super().__setattr__(name, value)
+
     # ------------------------------------------------------------------ engine state
     TRAINED_PREFIXES = ()
 
@@ -572,8 +604,8 @@ class Policy(nn.Module):
         return r
 
     def side_streams(self):
-        if self._side is None:
-            self._side = [torch.cuda.Stream() for _ in range(3)]
+        if self._side is None:                           # capture-fork branches: shared by every policy (captures never overlap)
+            self._side = [process_stream("fork%d" % i) for i in range(3)]
         return self._side
 
     def mark_params_changed(self):
@@ -670,7 +702,7 @@ class Policy(nn.Module):
                 ah = self._host_action(B)                # the actions start their way to the host right behind the race (512 B)
                 ah.copy_(action, non_blocking=True)
                 ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream())
+                ev.record(_cur_stream())
                 self._act_host[which] = (ah, ev)
                 self.last_host_action = None
             elif self.sampling == "host":
@@ -769,11 +801,11 @@ class Policy(nn.Module):
                 if grp_ is not None:
                     grp_.auto_hits += int(hit); grp_.auto_misses += int(not hit)
             if hit:
-                torch.cuda.current_stream().wait_event(st[3])        # later kernels of the caller read this forward's outputs
+                _cur_stream().wait_event(st[3])        # later kernels of the caller read this forward's outputs
                 return st[2]
             # a discarded forward may still be running on its own stream, in the SAME captured graph and static buffers the recompute
             # below is about to replay: order the recompute behind it
-            torch.cuda.current_stream().wait_event(st[3])
+            _cur_stream().wait_event(st[3])
             if st[2][1].get("rng_before") is not None:
                 torch.set_rng_state(st[2][1]["rng_before"])          # the discarded forward's noise draw never happened
         txt = getattr(self.net, "_text", None)
@@ -784,9 +816,9 @@ class Policy(nn.Module):
             elif tok is not None and txt[0] == tok.data_ptr() and txt[1] == tuple(tok.shape):
                 ev = txt[3]
                 if self.use_graphs:                      # the wait sits between the two halves of the captured forward
-                    self._between = lambda: torch.cuda.current_stream().wait_event(ev)
+                    self._between = lambda: _cur_stream().wait_event(ev)
                 else:
-                    torch.cuda.current_stream().wait_event(ev)
+                    _cur_stream().wait_event(ev)
             else:
                 self.net._text, self.net._text_key = None, None
         mode, grp = None, self._enc_group
@@ -803,7 +835,7 @@ class Policy(nn.Module):
                     keys, ev, obs_now = late[0], late[1], net_args[0]
 
                     def mid(keys=keys, ev=ev, obs_now=obs_now, grp=grp):
-                        torch.cuda.current_stream().wait_event(ev)
+                        _cur_stream().wait_event(ev)
                         so = grp.static_obs
                         if so is not None and so is not obs_now:
                             L.multi_copy([(so[k], _f32(obs_now[k])) for k in keys if k in so])
@@ -824,7 +856,7 @@ class Policy(nn.Module):
                 grp.signal()                             # the forward was not cut (no capture fork): the whole graph is the wait
             if which == "vln" and getattr(self.net, "_text", None) is not None and self._deferred is None:
                 self.net._text_read = torch.cuda.Event()
-                self.net._text_read.record(torch.cuda.current_stream())
+                self.net._text_read.record(_cur_stream())
             return out
         finally:
             self._shared_mode = None
@@ -851,7 +883,7 @@ class Policy(nn.Module):
         `stream`: run this forward on its own HIP stream (ordered after everything enqueued so far on the current one), so
         that independent policies overlap on the GPU and each one's probabilities reach the host as soon as IT is done."""
         self._stash = None
-        cur = torch.cuda.current_stream()
+        cur = _cur_stream()
         run_on = stream if stream is not None else cur
         if stream is not None:
             grp = self._enc_group
@@ -950,7 +982,7 @@ class Policy(nn.Module):
             return
         which, key, out, stream, tokens, agent_step = lt
         g, self._deferred = self._deferred, None
-        cur = torch.cuda.current_stream()
+        cur = _cur_stream()
         run_on = stream if stream is not None else cur
         ctx = torch.cuda.stream(run_on) if stream is not None else contextlib.nullcontext()
         # The text tower runs on the CALLER's stream -- the one the host loop wrote the tokens on, behind pi_q's forward and nothing
@@ -1025,7 +1057,7 @@ class Policy(nn.Module):
                 self.dialog_ready()
             else:
                 if lt[3] is not None:                    # the guessed first half may still be running in the graph this call replays
-                    torch.cuda.current_stream().wait_stream(lt[3])
+                    _cur_stream().wait_stream(lt[3])
                 self._later = self._deferred = None
                 self._auto_pending = False
                 if self._enc_group is not None:
@@ -1195,7 +1227,7 @@ class _SMTBase(Net):
         H, W = spec.shape[1], spec.shape[2]
         nb2 = L.lib.avlen_cnn3_workspace_bytes(C.byref(eng["audio"]), B, H, W)
         ws2 = pol._ws.get("audio", nb2, dev)
-        cur = torch.cuda.current_stream()
+        cur = _cur_stream()
         fork = torch.cuda.is_current_stream_capturing()
         mode, grp = pol._shared_mode, pol._enc_group
         x3 = prec == L.PREC_BF16X3 and bool(eng["rgb"].conv1.w16lo)
@@ -1519,7 +1551,7 @@ class AudioNavDialogNet(_SMTBase):
         if self.text_encoder_override is not None or tokens is None:
             return
         tok = _i64(tokens)
-        cur = torch.cuda.current_stream()
+        cur = _cur_stream()
         if same_stream:
             pass
         elif after_current:
@@ -1555,7 +1587,7 @@ class AudioNavDialogNet(_SMTBase):
             ext_memory_masks, all_dialog, agent_step):
         eng = pol._engine()
         e = None
-        cur = torch.cuda.current_stream()
+        cur = _cur_stream()
         fork = torch.cuda.is_current_stream_capturing()
         s_txt = pol.side_streams()[2] if fork else cur
         pre = self._text_ready(all_dialog)
