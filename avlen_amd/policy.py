@@ -804,8 +804,11 @@ class Policy(nn.Module):
                 _cur_stream().wait_event(st[3])        # later kernels of the caller read this forward's outputs
                 return st[2]
             # a discarded forward may still be running on its own stream, in the SAME captured graph and static buffers the recompute
-            # below is about to replay: order the recompute behind it
+            # below is about to replay: order the recompute behind it; and give the follower its claim on the leader's encoders back
+            # (the discarded forward used it up: the recompute would run its own towers -- same values up to the fc GEMM's tiling)
             _cur_stream().wait_event(st[3])
+            if self._enc_group is not None and self._enc_group.leader is not self:
+                self._enc_group.pending.add(id(self))
             if st[2][1].get("rng_before") is not None:
                 torch.set_rng_state(st[2][1]["rng_before"])          # the discarded forward's noise draw never happened
         txt = getattr(self.net, "_text", None)
@@ -1058,6 +1061,8 @@ class Policy(nn.Module):
             else:
                 if lt[3] is not None:                    # the guessed first half may still be running in the graph this call replays
                     _cur_stream().wait_stream(lt[3])
+                if self._enc_group is not None:          # ... and it used up this follower's claim on the leader's encoders
+                    self._enc_group.pending.add(id(self))
                 self._later = self._deferred = None
                 self._auto_pending = False
                 if self._enc_group is not None:
@@ -1558,6 +1563,10 @@ class AudioNavDialogNet(_SMTBase):
             stream.wait_stream(cur)                      # after every earlier reader of the embedding buffer
         elif self._text_read is not None:
             stream.wait_event(self._text_read)           # the last forward that read the embedding buffer
+        if self._text is not None:
+            # the previous replay of the text graph (same captured graph, same static buffers, possibly another stream -- e.g. the
+            # priming replay of an automatically launched first half) must have finished
+            stream.wait_event(self._text[3])
         with (contextlib.nullcontext() if same_stream else torch.cuda.stream(stream)):
             key = ("text", tuple(tok.shape))
             g = pol._graphs.get(key)

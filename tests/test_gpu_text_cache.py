@@ -189,7 +189,10 @@ def test_automatic_launch_ahead_equals_explicit_and_plain_calls():
     for name in ("auto", "serial"):
         for part in (0, 1):
             for k in outs["explicit"][part]:
-                assert torch.equal(outs["explicit"][part][k], outs[name][part][k]), (name, part, k)
+                a_, b_ = outs["explicit"][part][k], outs[name][part][k]
+                if not torch.equal(a_, b_):
+                    d_ = (a_.double() - b_.double()).abs().reshape(a_.shape[0], -1).max(1).values
+                    raise AssertionError((name, part, k, [(i, float(x)) for i, x in enumerate(d_) if x > 0][:12]))
         assert torch.equal(outs["explicit"][4], outs[name][4]), name          # the host generator ends in the same state
     assert outs["serial"][2] == 0 and outs["explicit"][2] == 0
     # two followers x (T + 3) steps; no guess on the first two steps (no history), wrong or absent around the wrap-around
