@@ -67,6 +67,8 @@ class Workload:
         self._l_where = os.environ.get("AVLEN_L_STREAM", "side" if dialog_tokens == "after_option" else "main")
         self._l_main = self._l_where == "main"
         self._l_first = os.environ.get("AVLEN_L_FIRST", "1") != "0"              # A/B knob
+        self._early_enc = os.environ.get("AVLEN_EARLY_ENC", "1") != "0" and use_graphs and share_encoders and \
+            precision in ("bf16", "bf16x3") and not belief_predictor                # A/B knob: Policy.prefetch_encoders before insert
         tpr = os.environ.get("AVLEN_TEXT_STREAM")                                # lab knob: "hi" / "own" = text tower on its own stream
         self._text_stream = None if tpr is None else P.process_stream("harness_text_own", -1 if tpr == "hi" else 0)
         self._views_ahead = os.environ.get("AVLEN_VIEWS_AHEAD", "1") != "0"       # A/B knob
@@ -330,6 +332,9 @@ class Workload:
         if return_outs:                             # graph outputs are overwritten by the next replay
             o = {k: (x.clone() if torch.is_tensor(x) else x) for k, x in o.items()}
             o["actions"] = actions.clone()
+        if self._early_enc and self.launch_ahead:
+            # the new observation exists: its towers start now and hide the storage bookkeeping + the next step's launch path
+            self.pi_q.prefetch_encoders(v["nxt"], will_be={k: x[t + 1] for k, x in ro.observations.items()})
         dlg, astep = (self._cur_dialog, self._cur_astep) if self.dialog_process == "reference" else (v["dialog"], v["astep"])
         ro.insert(v["nxt"], o["h"], actions, a_opt, o["lp_q"], o["q_value"], v["rew"], v["nd"], v["nd"], o["row_g"], o["row_q"],
                   o["row_l"], o["row_d"], dlg, self.o_action, self.o_mask, v["rl"], v["ucnt"], o["l_prob"], v["qs"],

@@ -239,7 +239,7 @@ class _Memo:
     that slices fresh views of its storage every step (ppo_trainer.py:375-391) presents new objects over the same memory, and an
     `id()` can be recycled by an unrelated object.  The memo holds no tensors: the copy reads whatever lives at the source
     addresses at replay time, which is exactly what the caller passed."""
-    __slots__ = ("g", "srcs", "dsts", "sizes", "n", "lead_static")
+    __slots__ = ("g", "srcs", "dsts", "sizes", "n", "lead_static", "late")     # late: (srcs, dsts, sizes, n) without the big sensors
 
 
 def _tsig(a):
@@ -276,10 +276,29 @@ def _graphed(pol, which, fn, args, mode=None):
         g = m.g
         if mode == "lead":
             pol._enc_group.static_obs = g.static[0]
+        early = pol._enc_early
+        pol._enc_early = None
+        if early is not None and early[0] is g and mode == "lead" and g.graph2 is not None and m.late is not None and \
+                (early[1] is None or early[1] == tuple(raw[0][k].data_ptr() for k in ("rgb", "depth", SPECTROGRAM))):
+            # prefetch_encoders() already staged this observation's sensors and replayed the encoder half: the small inputs, then
+            # the rest of the forward
+            if m.late[3]:
+                L.call("avlen_multi_copy", m.late[0], m.late[1], m.late[2], m.late[3], L.stream())
+            g.mid = getattr(pol, "_mid", None)
+            if g.mid is not None:
+                g.mid()
+            g.graph2.replay()
+            outs, heads = g.outs
+            outs = list(outs)
+            if not keep_rnn:
+                outs[1] = raw[1]
+            return tuple(outs), dict(heads)
         if m.n:
             L.call("avlen_multi_copy", m.srcs, m.dsts, m.sizes, m.n, L.stream())
         g.between = getattr(pol, "_between", None)
         g.mid = getattr(pol, "_mid", None)
+        if mode == "lead":
+            pol._last_lead = g
         if pol._defer_second and g.graph2 is not None:
             g.graph.replay()                             # the half that does not read the dialog; dialog_ready() replays the rest
             pol._deferred = g
@@ -317,6 +336,8 @@ def _graphed(pol, which, fn, args, mode=None):
         g = pol._graphs[key] = _Graph(pol, fn, args, by_ptr)
     if mode == "lead":
         grp.static_obs = g.static[0]
+        pol._last_lead = g
+    pol._enc_early = None
     g.between = getattr(pol, "_between", None)
     g.mid = getattr(pol, "_mid", None)
     if mk is not None:
@@ -333,6 +354,13 @@ def _graphed(pol, which, fn, args, mode=None):
             mm.dsts = (C.c_void_p * max(mm.n, 1))(*[d_.data_ptr() for d_, _ in pairs])
             mm.sizes = (C.c_int64 * max(mm.n, 1))(*[d_.numel() * d_.element_size() for d_, _ in pairs])
             mm.lead_static = grp.static_obs if mode == "follow" else None
+            big = set()
+            if mode == "lead" and isinstance(g.static[0], dict):
+                big = {g.static[0][k].data_ptr() for k in ("rgb", "depth", SPECTROGRAM) if k in g.static[0]}
+            lp = [(d_, s_) for d_, s_ in pairs if d_.data_ptr() not in big]
+            mm.late = ((C.c_void_p * max(len(lp), 1))(*[s_.data_ptr() for _, s_ in lp]),
+                       (C.c_void_p * max(len(lp), 1))(*[d_.data_ptr() for d_, _ in lp]),
+                       (C.c_int64 * max(len(lp), 1))(*[d_.numel() * d_.element_size() for d_, _ in lp]), len(lp)) if mode == "lead" else None
             # bounded: a caller that presents freshly allocated observation tensors every step (eval: batch_obs) would otherwise
             # add one memo per distinct address tuple for ever; the oldest entries go first (dicts keep insertion order)
             while len(pol._memos) >= 512:
@@ -565,6 +593,9 @@ class Policy(nn.Module):
         self._between = None                  # host action between the two halves of a split graph
         self._mid = None                      # leader of an EncoderGroup: EncoderGroup.signal between the halves of its cut graph
         self._late_inputs = None              # (observation keys, event): see late_inputs()
+        self._last_lead = None                # leader: the captured graph of its last act* forward
+        self._enc_early = None                # leader: that graph, if prefetch_encoders() has run its encoder half for the next call
+        self._enc_plans = {}                  # staging plans of prefetch_encoders per source address set
         self._defer_second = False            # prefetch_act_dialog(dialog_later=True): replay only the first half of the cut graph
         self._deferred = None                 # ... the graph whose second half dialog_ready() replays
         self._later = None                    # ... (which, arg key, outputs, stream, all_dialog, agent_step) of that prefetch
@@ -1072,6 +1103,48 @@ class Policy(nn.Module):
         self._after_act("vln", args)
         return (h["value"], h["action"], h["log_prob"], rnn_hidden_states, ext_memory_feats,
                 ext_memory_dialog_feats, h["probs"])
+
+    def prefetch_encoders(self, observations, will_be=None):
+        """Leader of an EncoderGroup with `use_graphs`: start the shared encoders -- every member's visual towers and AudioCNN -- on
+        `observations` NOW.  Meant for the new observation batch right before it is handed to `rollouts.insert` (ppo_trainer.py:
+        864-897: env.step -> batch_obs -> insert -> next step's act_option): the towers read nothing but the sensors, so the ~0.45 ms
+        they take hides the host's storage bookkeeping and the next step's launch path instead of following them.  The next
+        act_option / get_value_option call of this policy must be made on that same observation (the storage slot it was copied
+        to): it then stages only the small inputs and replays the rest of the captured forward.  `will_be`: the tensors that call
+        will pass (the storage slot's views) -- their addresses are checked then, and a call on anything else runs the whole forward.
+        A no-op until that forward has been captured once (first step) or if the batch shape changed."""
+        g = self._last_lead
+        grp = self._enc_group
+        self._enc_early = None
+        if g is None or g.graph2 is None or grp is None or grp.leader is not self or not isinstance(g.static[0], dict):
+            return False
+        so = g.static[0]
+        try:
+            key = (id(g),) + tuple(observations[k].data_ptr() for k in so)
+        except KeyError:
+            return False
+        plan = self._enc_plans.get(key)
+        if plan is None:
+            pairs = []
+            for k, d in so.items():
+                a = observations[k]
+                if not (a.is_cuda and a.is_contiguous() and a.dtype == d.dtype and tuple(a.shape) == tuple(d.shape)):
+                    return False                         # a dtype / layout conversion would be needed: let the act* call do everything
+                pairs.append((d, a))
+            n = len(pairs)
+            plan = ((C.c_void_p * n)(*[a.data_ptr() for _, a in pairs]), (C.c_void_p * n)(*[d.data_ptr() for d, _ in pairs]),
+                    (C.c_int64 * n)(*[d.numel() * d.element_size() for d, _ in pairs]), n)
+            while len(self._enc_plans) >= 512:
+                self._enc_plans.pop(next(iter(self._enc_plans)))
+            self._enc_plans[key] = plan
+        self._engine()
+        for m_ in grp.members:
+            if m_ is not self:
+                m_._engine()
+        L.call("avlen_multi_copy", plan[0], plan[1], plan[2], plan[3], L.stream())
+        g.graph.replay()
+        self._enc_early = (g, None if will_be is None else tuple(will_be[k].data_ptr() for k in ("rgb", "depth", SPECTROGRAM)))
+        return True
 
     def late_inputs(self, keys, event):
         """Leader of an EncoderGroup with `use_graphs`: the observation entries `keys` of the NEXT act* call are complete only when

@@ -197,3 +197,36 @@ def test_automatic_launch_ahead_equals_explicit_and_plain_calls():
     assert outs["serial"][2] == 0 and outs["explicit"][2] == 0
     # two followers x (T + 3) steps; no guess on the first two steps (no history), wrong or absent around the wrap-around
     assert outs["auto"][2] >= 2 * (T + 3) - 8 and outs["auto"][3] <= 2, outs["auto"][2:4]
+
+
+def test_encoders_started_before_insert_equal_the_plain_order():
+    """`Policy.prefetch_encoders(new_obs)` right before `rollouts.insert(new_obs, ...)` (the towers hide the storage bookkeeping and
+    the next step's launch path) against the plain order: same storage bit for bit over a rollout, the wrap-around and the update's
+    `get_value_option`."""
+    import os
+    N, T = 4, 5
+    snaps = []
+    try:
+        for early in ("1", "0"):
+            os.environ["AVLEN_EARLY_ENC"] = early
+            wl = _run(N, T, precision="bf16x3")
+            assert wl._early_enc == (early == "1")
+            for _ in range(T):
+                wl.rollout_step()
+            ro = wl.rollouts
+            last = {k: v[ro.step] for k, v in ro.observations.items()}
+            nv = wl.pi_q.get_value_option(last, ro.recurrent_hidden_states[ro.step], ro.prev_actions[ro.step], ro.masks[ro.step],
+                                          ro.external_memory_option[:, ro.step], ro.external_memory_masks[ro.step],
+                                          ro.query_state[ro.step - 1], ro.last_query_info[ro.step - 1]).clone()
+            ro.after_update()
+            for _ in range(2):
+                wl.rollout_step()
+            torch.cuda.synchronize()
+            snaps.append((_storage_snapshot(wl), nv))
+            del wl
+    finally:
+        os.environ.pop("AVLEN_EARLY_ENC", None)
+    (a, va), (b, vb) = snaps
+    assert torch.equal(va, vb)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
