@@ -19,7 +19,8 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(avlen_heads h, const flo
                                                         float* __restrict__ logits, float* __restrict__ probs,
                                                         float* __restrict__ value, float* __restrict__ unct,
                                                         const int64_t* __restrict__ actions, float* __restrict__ log_prob,
-                                                        float* __restrict__ entropy, int B) {
+                                                        float* __restrict__ entropy, int B,
+                                                        const float* __restrict__ noise = nullptr, int64_t* __restrict__ action_out = nullptr) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= B) return;
@@ -71,8 +72,22 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(avlen_heads h, const flo
     if (value) value[row] = v;
     if (unct && h.has_unct) { unct[(long)row * 2] = u0; unct[(long)row * 2 + 1] = u1; }
     if (entropy) entropy[row] = ent;
-    if (actions && log_prob) {
-      long a = actions[row];
+    long sampled = -1;
+    if (noise && action_out) {
+      // the exponential race of CustomFixedCategorical.sample on host-drawn noise (see avlen_sample_race: same quotients, same
+      // first-maximum rule, on the probabilities just written) -- fused here so that a rollout forward needs no second pass
+      float best = 0.f; int bi = 0;
+#pragma unroll
+      for (int a = 0; a < MAXA; a++)
+        if (a < A) {
+          const float v_ = __fdiv_rn(expf(z[a] - lse), noise[(long)row * A + a]);
+          if (a == 0 || v_ > best || (v_ != v_ && best == best)) { best = v_; bi = a; }
+        }
+      sampled = bi;
+      action_out[row] = bi;
+    }
+    if ((actions || sampled >= 0) && log_prob) {
+      long a = sampled >= 0 ? sampled : actions[row];
       float za = 0.f;
 #pragma unroll
       for (int k = 0; k < MAXA; k++) if (k == a) za = z[k];
@@ -358,6 +373,17 @@ extern "C" int avlen_heads_fwd(const avlen_heads* h, const float* feats, int d, 
   if (!h || B <= 0 || A > MAXA || d % 64) return AVLEN_ERR_ARG;
   hipLaunchKernelGGL(heads_fwd_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, stream, *h, feats, d, A, logits, probs, value,
                      unct, actions, log_prob, entropy, B);
+  return avlen_launch_status();
+}
+
+// avlen_heads_fwd with the sampling fused in: action_out[b] = the race's winner on `noise` (B x A, host-drawn Exp(1)), log_prob /
+// entropy of that action; everything else as avlen_heads_fwd.
+extern "C" int avlen_heads_act_fwd(const avlen_heads* h, const float* feats, int d, int A, float* logits, float* probs, float* value,
+                                   float* unct, const float* noise, int64_t* action_out, float* log_prob, float* entropy, int B,
+                                   hipStream_t stream) {
+  if (!h || !noise || !action_out || B <= 0 || A > MAXA || d % 64) return AVLEN_ERR_ARG;
+  hipLaunchKernelGGL(heads_fwd_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, stream, *h, feats, d, A, logits, probs, value, unct,
+                     (const int64_t*)nullptr, log_prob, entropy, B, noise, action_out);
   return avlen_launch_status();
 }
 

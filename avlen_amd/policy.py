@@ -694,8 +694,10 @@ class Policy(nn.Module):
         return eng[key]
 
     # ------------------------------------------------------------------ heads + sampling
-    def _heads_first(self, which, feats):
-        """logits / probs / value / unct of one head set (one kernel; capturable)."""
+    def _heads_first(self, which, feats, race=False):
+        """logits / probs / value / unct of one head set (one kernel; capturable).  race (sampling="race" forwards): the same launch
+        also runs the exponential race on the head set's noise buffer (filled by _draw_noise before the forward is enqueued) and
+        returns the sampled action with its log-prob / entropy -- a rollout forward then ends with ONE small kernel, not three."""
         B, d = feats.shape
         A = self.dim_actions_option if which == "option" else self.dim_actions
         dev = feats.device
@@ -704,9 +706,34 @@ class Policy(nn.Module):
         probs = torch.empty(B, A, device=dev)
         value = torch.empty(B, 1, device=dev)
         unct = torch.empty(B, 2, device=dev) if which == "option" else None
+        if race:
+            nz = self._noise_dev(which, B, A, dev)
+            action, logp, ent = self._result_bufs(which, B, dev)
+            L.call("avlen_heads_act_fwd", C.byref(h), E.P(feats), d, A, E.P(logits), E.P(probs), E.P(value),
+                   E.P(unct) if unct is not None else None, E.P(nz), E.P(action), E.P(logp), E.P(ent), B, L.stream())
+            return {"logits": logits, "probs": probs, "value": value, "unct": unct, "raced": (action, logp, ent)}
         L.call("avlen_heads_fwd", C.byref(h), E.P(feats), d, A, E.P(logits), E.P(probs), E.P(value),
                E.P(unct) if unct is not None else None, None, None, None, B, L.stream())
         return {"logits": logits, "probs": probs, "value": value, "unct": unct}
+
+    def _noise_dev(self, which, B, A, dev):
+        """The head set's device-side noise buffer (persistent: captured graphs read it in place)."""
+        t = self._pinned.get(("noise_dev", which, B))
+        if t is None or t.device != dev:
+            t = self._pinned[("noise_dev", which, B)] = torch.ones(B, A, device=dev)
+        return t
+
+    def _draw_noise(self, which, B, dev):
+        """Draw the race's Exp(1) noise of one act* call on the HOST generator (the reference's draw: CustomFixedCategorical.sample ->
+        torch.multinomial) and upload it, on the current stream, in front of the forward that will consume it."""
+        A = self.dim_actions_option if which == "option" else self.dim_actions
+        ring = self._pinned.get(("noise", which, B))
+        if ring is None:
+            ring = self._pinned[("noise", which, B)] = [[torch.empty(B, A, pin_memory=True) for _ in range(8)], 0]
+        ring[1] = (ring[1] + 1) % 8
+        qh = ring[0][ring[1]]
+        qh.exponential_(1)
+        self._noise_dev(which, B, A, dev).copy_(qh, non_blocking=True)
 
     def _finish(self, which, feats, out, action=None, deterministic=False, need_sample=True):
         """Action selection (host or device RNG) and the log-prob / entropy of the chosen actions."""
@@ -719,12 +746,20 @@ class Policy(nn.Module):
         if action is None and need_sample:
             if deterministic:
                 action = probs.argmax(dim=-1, keepdim=True)
+            elif self.sampling == "race" and out.get("raced") is not None and out.get("noise_drawn"):
+                # the forward's last kernel ran the race on the noise drawn for this call (_draw_noise, _heads_first): the reference's
+                # action for the same generator state; no probabilities cross PCIe, no host synchronisation
+                action, logp, ent = out["raced"]
+                ah = self._host_action(B)                # the actions start their way to the host right behind the forward (512 B)
+                ah.copy_(action, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(_cur_stream())
+                self._act_host[which] = (ah, ev)
+                self.last_host_action = None
+                out.update(action=_i64(action.view(B, 1)), log_prob=logp, entropy_rows=ent)
+                return out
             elif self.sampling == "race":
-                # the host draws the noise in the reference's order (it does not depend on the probabilities) and uploads it; the
-                # race argmax(p / q) runs on the device (avlen_sample_race: IEEE division, first maximum): the reference's action for
-                # the same generator state, and no probabilities cross PCIe, no host synchronisation
-                if self._auto_pending:                   # a guessed forward may be discarded: its draw must then be undone
-                    out["rng_before"] = torch.get_rng_state()
+                # (a forward whose noise was not drawn ahead -- e.g. deterministic=False on a get_value-style path: race as its own launch)
                 qh, qd = self._noise_bufs(which, B, A, dev)
                 qh.exponential_(1)
                 qd.copy_(qh, non_blocking=True)
@@ -815,13 +850,16 @@ class Policy(nn.Module):
     def _run_heads(self, which, feats, action=None, deterministic=False, need_sample=True):
         return self._finish(which, feats, self._heads_first(which, feats), action, deterministic, need_sample)
 
-    def _forward(self, which, *net_args):
+    def _forward(self, which, *net_args, sample=False):
         """net.run(...) + first heads kernel -> (net outputs tuple, heads dict); replayed from a HIP graph when
         use_graphs is set (inputs are copied into the graph's static buffers; outputs are overwritten by the
-        next replay, so callers copy what they keep -- RolloutStorage.insert does)."""
+        next replay, so callers copy what they keep -- RolloutStorage.insert does).  sample: an act* call that will draw an action
+        (sampling="race": the noise is drawn and uploaded here, in front of the forward whose last kernel runs the race)."""
+        race = self.sampling == "race"
+
         def eager(*args):
             outs = self.net.run(self, *args)
-            return outs, self._heads_first(which, outs[0])
+            return outs, self._heads_first(which, outs[0], race=race)
         st = self._stash
         if st is not None:
             self._stash = None
@@ -842,6 +880,15 @@ class Policy(nn.Module):
                 self._enc_group.pending.add(id(self))
             if st[2][1].get("rng_before") is not None:
                 torch.set_rng_state(st[2][1]["rng_before"])          # the discarded forward's noise draw never happened
+        drawn, rng_before = False, None
+        if sample and race and not self._defer_second:
+            if self._auto_pending:                       # a guessed forward may be discarded: its draw must then be undone
+                rng_before = torch.get_rng_state()
+            obs0 = net_args[0]
+            B0 = next(iter(obs0.values())).shape[0] if isinstance(obs0, dict) else obs0.shape[0]
+            dev0 = next(iter(obs0.values())).device if isinstance(obs0, dict) else obs0.device
+            self._draw_noise(which, B0, dev0)
+            drawn = True
         txt = getattr(self.net, "_text", None)
         if which == "vln" and txt is not None:
             tok = net_args[7]
@@ -878,9 +925,15 @@ class Policy(nn.Module):
             elif grp.claim(self, net_args[0]):
                 mode = "follow"
         self._shared_mode = mode
+        def tag(o):
+            if drawn:
+                o[1]["noise_drawn"] = True
+            if rng_before is not None:
+                o[1]["rng_before"] = rng_before
+            return o
         try:
             if not self.use_graphs:
-                return eager(*net_args)
+                return tag(eager(*net_args))
             try:
                 out = _graphed(self, which, eager, net_args, mode)
             finally:
@@ -891,7 +944,7 @@ class Policy(nn.Module):
             if which == "vln" and getattr(self.net, "_text", None) is not None and self._deferred is None:
                 self.net._text_read = torch.cuda.Event()
                 self.net._text_read.record(_cur_stream())
-            return out
+            return tag(out)
         finally:
             self._shared_mode = None
 
@@ -940,7 +993,7 @@ class Policy(nn.Module):
                         self.net.prefetch_text(self, net_args[7], run_on, after_current=True)
                     self._defer_second = True
                     try:
-                        out = self._forward(which, *net_args)
+                        out = self._forward(which, *net_args, sample=True)       # (no draw: the heads sit in the second half)
                     finally:
                         self._defer_second = False
                 if self._deferred is not None:
@@ -951,7 +1004,7 @@ class Policy(nn.Module):
             self._later = ("whole", net_args, stream)
             return
         with ctx:
-            out = self._forward(which, *net_args)
+            out = self._forward(which, *net_args, sample=True)
             done = torch.cuda.Event()
             if self.sampling == "race":
                 # the race goes out right behind the forward on ITS stream (noise drawn now: prefetch_* calls are made in the order
@@ -1039,6 +1092,9 @@ class Policy(nn.Module):
         with ctx:
             if torch.is_tensor(g.static[8]) and g.static[8].data_ptr() != agent_step.data_ptr():
                 L.multi_copy([(g.static[8], _f32(agent_step))])
+            if self.sampling == "race":                  # pi_l's draw: third in the step, as in the reference
+                self._draw_noise(which, out[1]["probs"].shape[0], out[1]["probs"].device)
+                out[1]["noise_drawn"] = True
             g.graph2.replay()
             self.net._text_read = torch.cuda.Event()
             self.net._text_read.record(run_on)
@@ -1063,7 +1119,7 @@ class Policy(nn.Module):
     def act(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks,
             deterministic=False):
         args = (observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks)
-        (features, rnn_hidden_states, ext_memory_feats), h = self._forward("goal", *args)
+        (features, rnn_hidden_states, ext_memory_feats), h = self._forward("goal", *args, sample=not deterministic)
         h = self._finish("goal", features, h, deterministic=deterministic)
         self._after_act("goal", args)
         return h["value"], h["action"], h["log_prob"], rnn_hidden_states, ext_memory_feats, h["probs"]
@@ -1071,7 +1127,7 @@ class Policy(nn.Module):
     def act_option(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks,
                    query_state, last_query_info, deterministic=False):
         args = (observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks, query_state, last_query_info)
-        (features, rnn_hidden_states, ext_memory_feats), h = self._forward("option", *args)
+        (features, rnn_hidden_states, ext_memory_feats), h = self._forward("option", *args, sample=not deterministic)
         h = self._finish("option", features, h, deterministic=deterministic)
         self._after_act("option", args)
         return (h["value"], h["unct"], h["action"], h["log_prob"], rnn_hidden_states, ext_memory_feats, h["probs"])
@@ -1098,7 +1154,8 @@ class Policy(nn.Module):
                 self._auto_pending = False
                 if self._enc_group is not None:
                     self._enc_group.auto_misses += 1
-        (features, rnn_hidden_states, ext_memory_feats, ext_memory_dialog_feats), h = self._forward("vln", *args)
+        (features, rnn_hidden_states, ext_memory_feats, ext_memory_dialog_feats), h = self._forward("vln", *args,
+                                                                                                     sample=not deterministic)
         h = self._finish("vln", features, h, deterministic=deterministic)
         self._after_act("vln", args)
         return (h["value"], h["action"], h["log_prob"], rnn_hidden_states, ext_memory_feats,

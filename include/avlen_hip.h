@@ -352,6 +352,10 @@ int avlen_gru_fwd(const avlen_gru* p, const float* x, const float* h0, const flo
 int avlen_heads_fwd(const avlen_heads* h, const float* feats, int d, int A, float* logits, float* probs,
                     float* value, float* unct, const int64_t* actions, float* log_prob, float* entropy, int B,
                     avlen_stream_t stream);
+/* avlen_heads_fwd + avlen_sample_race + the chosen action's log-prob / entropy in one launch (a rollout forward's tail). */
+int avlen_heads_act_fwd(const avlen_heads* h, const float* feats, int d, int A, float* logits, float* probs, float* value,
+                        float* unct, const float* noise, int64_t* action_out, float* log_prob, float* entropy, int B,
+                        avlen_stream_t stream);
 /* CustomFixedCategorical.sample (common/utils.py:48-49; torch.multinomial's exponential race) with HOST-drawn noise: action[b] =
  * first argmax_a probs[b,a] / noise[b,a] (IEEE fp32 division) -- the reference's action for the same host generator state. */
 int avlen_sample_race(const float* probs, const float* noise, int64_t* action, int B, int A, avlen_stream_t stream);

@@ -66,6 +66,9 @@ for it in range(STEPS):
         ah.copy_(actions, non_blocking=True)
         cur.synchronize()
     hmark("actions_on_host")
+    if wl._early_enc:
+        wl.pi_q.prefetch_encoders(v["nxt"], will_be={k: x[t + 1] for k, x in ro.observations.items()})
+        hmark("next_towers_launched")
     ro.insert(v["nxt"], h2, actions, a_opt, lp_opt, values, v["rew"], v["nd"], v["nd"], row_goal, row_opt, row_vln, row_dlg,
               v["dialog"], wl.o_action, wl.o_mask, v["rl"], v["ucnt"], probs_vln, v["qs"], v["lqi"], v["astep"])
     mark("insert_end", cur); hmark("insert_done")
