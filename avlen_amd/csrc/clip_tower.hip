@@ -66,9 +66,14 @@ static_assert(sizeof(ClipGroup) == 64, "group table stride");
     *reinterpret_cast<float4*>(a.E + (long)td[i_] * 512 + 4 * threadIdx.x) = \
     make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")); return; } while (0)
 #ifdef AVLEN_CT_PROF
-#define CT_T0() long long ct_t = __builtin_amdgcn_s_memtime(); long long ct_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define CT_PH(k) do { const long long n_ = __builtin_amdgcn_s_memtime(); ct_acc[k] += n_ - ct_t; ct_t = n_; } while (0)
-#define CT_DUMP() do { if (a.prof && tid == 0) for (int k_ = 0; k_ < 8; k_++) a.prof[(long)blockIdx.x * 8 + k_] = ct_acc[k_]; } while (0)
+// lab builds: phase k's cycles are ADDED to prof[workgroup][k] as the phase ends (the lab zeroes the table and divides by its launch
+// count).  Accumulators kept in registers for the whole body (the first version) cost the 4-way instance 1300 spilled registers and
+// half its speed -- the profile no longer described the product's kernel.
+#define CT_T0() long long ct_t = __builtin_amdgcn_s_memtime()
+#define CT_PH(k) do { const long long n_ = __builtin_amdgcn_s_memtime(); \
+    if (a.prof && threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.prof) + (long)blockIdx.x * 8 + (k), (unsigned long long)(n_ - ct_t)); \
+    ct_t = n_; } while (0)
+#define CT_DUMP() do { } while (0)
 #else
 #define CT_T0() do { } while (0)
 #define CT_PH(k) do { } while (0)
@@ -178,7 +183,10 @@ __device__ __forceinline__ void clip_publish_kv(const ClipArgs& a, const char* l
     const int c = tid + k * CT_TH;
     const f32x4 v = *reinterpret_cast<const f32x4*>(lds + clip_kv_lds(c));
     const f32x4* dstp = reinterpret_cast<const f32x4*>(slot + (long)k * CT_TH * 16) + lo16;
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dstp), "v"(v) : "memory");
+    // the s_nop: a VALU write of a > 64-bit store's data registers needs one wait state after the store, and the compiler's hazard
+    // recognizer does not look inside an asm statement (a lab build under register pressure reused the registers in the very next
+    // instruction: run-to-run different exchange data; tools/asm_wait_check.py now walks the ISA for this)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" :: "v"(dstp), "v"(v) : "memory");
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave: its stores have left
   __syncthreads();
@@ -237,7 +245,7 @@ __device__ __forceinline__ bool clip_exchange_pair(const ClipArgs& a, char* lds,
     for (int j = 0; j < 4; j++) {                           // write-through (agent-scope, sc1) 16-byte stores: no release fence; one
       // fabric write per lane -- as 8-byte atomic stores (twice the writes) an exchange took 8 us
       const float4* dstp = reinterpret_cast<const float4*>(mine + (long)(i * 4 + j) * CT_TH * 16) + lo16;
-      asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dstp), "v"(xr[i][j]) : "memory");
+      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" :: "v"(dstp), "v"(xr[i][j]) : "memory");
     }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave: its stores have left
   __syncthreads();
@@ -322,7 +330,7 @@ __device__ __forceinline__ bool clip_exchange4(const ClipArgs& a, char* lds, f32
     for (int j = 0; j < 4; j++) {
       if (j == me) continue;                                 // (uniform) the tile this part owns stays in its registers
       const float4* dstp = reinterpret_cast<const float4*>(mine + (long)(i * 4 + j) * CT_TH * 16) + lo16;
-      asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dstp), "v"(xr[i][j]) : "memory");
+      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" :: "v"(dstp), "v"(xr[i][j]) : "memory");
     }
   if (tid == 0) *ok = 1;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -356,7 +364,7 @@ __device__ __forceinline__ bool clip_exchange4(const ClipArgs& a, char* lds, f32
       own += v[0][i]; own += v[1][i]; own += v[2][i];
       if (me == 0) xr[i][0] = own; else if (me == 1) xr[i][1] = own; else if (me == 2) xr[i][2] = own; else xr[i][3] = own;
       const float4* dstp = reinterpret_cast<const float4*>(mine2 + (long)i * CT_TH * 16) + lo16;
-      asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dstp), "v"(own) : "memory");
+      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" :: "v"(dstp), "v"(own) : "memory");
     }
   }
   // ---- round 2: finished tiles
@@ -710,76 +718,121 @@ __device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, co
 #undef CT_STEP
 }
 
-// ---- work list: live lengths, tile counts, packing.  One block; wave per dialog for the EOT scan (first position of the largest id,
-// as torch.argmax: nothing after it can reach the output through the causal mask), then one thread packs whole dialogs into groups
-// of <= 4 tiles, in row order per class (deterministic): [4] | [3 + 1] | [2 + 2], [2 + 1 + 1] | [1 + 1 + 1 + 1] | first row halves
-// of the 5-tile dialogs, then their second halves (whatever a workgroup waits for has a smaller id).  64 dialogs of the benched
-// length mix (2.9 tiles on average) become ~52 groups: each streamed weight fragment feeds more rows, and 52 x 4 column parts still
-// fit the chip in one wave of workgroups.
+// ---- work list (ONE launch in front of the tower): [memo: which rows changed] -> live lengths -> tile classes -> groups -> flags.
+// One block of 16 waves.  (A) wave per row: the EOT scan (first position of the largest id, as torch.argmax: nothing after it can
+// reach the output through the causal mask) and, for the memoised tower (avlen_clip_text_cached_fwd), the comparison with the
+// previous call's tokens, which are updated in place (row B of that buffer is the all-zero dialog).  (B) per tile class, the rows in
+// row order: ranks by wave ballots + a prefix over the 64-row chunks.  (C) groups in CLOSED FORM, one thread per group -- whole
+// dialogs packed into <= 4 tiles: [4] | [3 + 1] | [2 + 2], and a last odd [2 (+ 1 + 1)] | [1 + 1 + 1 + 1] | the first row halves of
+// the 5-tile dialogs, then their second halves (whatever a workgroup waits for has a smaller id).  Multi-tile dialogs always start at
+// an even tile of their group: their P V products pair key tiles exactly as they do alone.  (D) the flag words of the launch are
+// zeroed here (no separate fill).  Until round 4 these were three launches (memo scan, fill, a one-thread packing loop: ~50 us on the
+// step's critical path); this one takes ~10.
 constexpr int CT_MAXB = 512;
-__global__ __launch_bounds__(1024) void clip_group_kernel(const int64_t* __restrict__ tokens, const int* __restrict__ row_idx,
-                                                           const int* __restrict__ count, int B, int ctx, int vocab_unused,
-                                                           ClipGroup* __restrict__ groups, int* __restrict__ ngroups) {
-  __shared__ int Ls[CT_MAXB], lst[5][CT_MAXB], cnt[5], ng_sh;
-  __shared__ ClipGroup sg[2 * CT_MAXB];                     // built by one thread in LDS, copied out by all
+using ClipMemo = avlen_clip_memo;                          // internal.h: {tokens_new, prev, hdr [valid, tower rows, zero rows], zidx}
+__global__ __launch_bounds__(1024) void clip_worklist_kernel(const int64_t* __restrict__ tokens, ClipMemo memo, int B, int ctx,
+                                                              ClipGroup* __restrict__ groups, int* __restrict__ ngroups,
+                                                              unsigned* __restrict__ flags, int flag_words) {
+  __shared__ int Ls[CT_MAXB], cls[CT_MAXB], lst[6][CT_MAXB], chunk_cnt[8][6], base[8][6], cnt[6];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n = count ? *count : B;
-  for (int r = wave; r < n; r += 16) {
-    const int b = row_idx ? row_idx[r] : r;
-    const int64_t* tk = tokens + (long)b * ctx;
+  const bool cached = memo.prev != nullptr;
+  const int valid = cached ? memo.hdr[0] : 1;
+  for (int i = tid; i < flag_words; i += 1024) flags[i] = 0u;
+  // ---- (A)
+  for (int r = wave; r < B; r += 16) {
     long best = -1; int bi = 0x7fffffff;
-    for (int k = lane; k < ctx; k += 64) { const long v = tk[k]; if (v > best) { best = v; bi = k; } }
+    bool diff = false, nz = false;
+    for (int k = lane; k < ctx; k += 64) {
+      long v;
+      if (cached) {
+        v = r < B - 1 ? memo.tokens_new[(long)r * ctx + k] : 0;              // the memo's buffer has one more row: all zero
+        const long o = memo.prev[(long)r * ctx + k];
+        diff = diff || v != o; nz = nz || v != 0;
+        memo.prev[(long)r * ctx + k] = v;
+      } else v = tokens[(long)r * ctx + k];
+      if (v > best) { best = v; bi = k; }
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const long ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
       if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
     }
-    if (lane == 0) Ls[r] = bi + 1;
-  }
-  __syncthreads();
-  if (tid == 0) {
-  for (int c = 0; c < 5; c++) cnt[c] = 0;
-  for (int r = 0; r < n; r++) { int t = (Ls[r] + 15) >> 4; t = t > 5 ? 5 : t; lst[t - 1][cnt[t - 1]++] = r; }
-  int ng = 0, p1 = 0;                                       // p1: next unused 1-tile dialog
-  auto dlg = [&](int r) { return row_idx ? row_idx[r] : r; };
-  auto put = [&](ClipGroup& g, int& t0, int r) {            // append dialog row r (all its tiles) to group g
-    const int L = Ls[r], t = (L + 15) >> 4, b = dlg(r);
-    for (int k = 0; k < t; k++) { g.d[t0] = b; g.lt[t0] = k; g.L[t0] = L; t0++; }
-  };
-  auto fresh = [&]() { ClipGroup g; g.nt = 0; g.kind = 0; for (int k = 0; k < 4; k++) { g.d[k] = 0; g.lt[k] = 0; g.L[k] = 0; } g.pad[0] = g.pad[1] = 0; return g; };
-  for (int i = 0; i < cnt[3]; i++) { ClipGroup g = fresh(); int t0 = 0; put(g, t0, lst[3][i]); g.nt = t0; sg[ng++] = g; }
-  for (int i = 0; i < cnt[2]; i++) {
-    ClipGroup g = fresh(); int t0 = 0; put(g, t0, lst[2][i]);
-    if (p1 < cnt[0]) put(g, t0, lst[0][p1++]);
-    g.nt = t0; sg[ng++] = g;
-  }
-  for (int i = 0; i < cnt[1]; i += 2) {
-    ClipGroup g = fresh(); int t0 = 0; put(g, t0, lst[1][i]);
-    if (i + 1 < cnt[1]) put(g, t0, lst[1][i + 1]);
-    else { for (int k = 0; k < 2 && p1 < cnt[0]; k++) put(g, t0, lst[0][p1++]); }
-    g.nt = t0; sg[ng++] = g;
-  }
-  while (p1 < cnt[0]) {
-    ClipGroup g = fresh(); int t0 = 0;
-    for (int k = 0; k < 4 && p1 < cnt[0]; k++) put(g, t0, lst[0][p1++]);
-    g.nt = t0; sg[ng++] = g;
-  }
-  for (int half = 0; half < 2; half++)
-    for (int i = 0; i < cnt[4]; i++) {
-      ClipGroup g = fresh();
-      const int r = lst[4][i], b = dlg(r), L = Ls[r];
-      g.kind = 1 + half; g.nt = half ? 2 : 3;
-      for (int k = 0; k < g.nt; k++) { g.d[k] = b; g.lt[k] = (half ? 3 : 0) + k; g.L[k] = L; }
-      sg[ng++] = g;
+    const bool any_diff = __any(diff), any_nz = __any(nz);
+    if (lane == 0) {
+      const int L = bi + 1;
+      int t = (L + 15) >> 4; t = t > 5 ? 5 : t;
+      int c = t;                                                             // 1 .. 5: tiles
+      if (cached) c = !(any_diff || !valid) ? 0 : ((!any_nz && r < B - 1) ? 6 : t);   // 0: unchanged, 6: copies the shared zero embedding
+      Ls[r] = L; cls[r] = c;
     }
-  ng_sh = ng;
   }
   __syncthreads();
-  const int ng = ng_sh;
-  const int4* src = reinterpret_cast<const int4*>(sg);
-  int4* dst = reinterpret_cast<int4*>(groups);
-  for (int i = tid; i < ng * 4; i += 1024) dst[i] = src[i];
-  if (tid == 0) ngroups[0] = ng;
+  // ---- (B) rows per class in row order (classes 1 .. 5 -> lst[0 .. 4], class 6 -> lst[5])
+  if (wave < 8) {
+    const int r = 64 * wave + lane;
+    const int c = r < B ? cls[r] : 0;
+#pragma unroll
+    for (int k = 1; k <= 6; k++) {
+      const unsigned long long m = __ballot(c == k);
+      if (lane == 0) chunk_cnt[wave][k - 1] = __popcll(m);
+    }
+  }
+  __syncthreads();
+  if (tid < 6) {
+    int run = 0;
+    for (int w = 0; w < 8; w++) { base[w][tid] = run; run += chunk_cnt[w][tid]; }
+    cnt[tid] = run;
+  }
+  __syncthreads();
+  if (wave < 8) {
+    const int r = 64 * wave + lane;
+    const int c = r < B ? cls[r] : 0;
+#pragma unroll
+    for (int k = 1; k <= 6; k++) {
+      const unsigned long long m = __ballot(c == k);
+      if (c == k) lst[k - 1][base[wave][k - 1] + __popcll(m & ((1ull << lane) - 1ull))] = r;
+    }
+  }
+  __syncthreads();
+  // ---- (C)
+  const int n1 = cnt[0], n2 = cnt[1], n3 = cnt[2], n4 = cnt[3], n5 = cnt[4], nzr = cnt[5];
+  const int u3 = n3 < n1 ? n3 : n1;                                          // 1-tile dialogs that ride with a 3-tile one
+  const int G2 = (n2 + 1) >> 1;
+  const int left = n1 - u3;
+  const int u2 = (n2 & 1) ? (left < 2 ? left : 2) : 0;                       // ... with the odd last 2-tile one
+  const int r1 = left - u2, G1 = (r1 + 3) >> 2;
+  const int o3 = n4, o2 = o3 + n3, o1 = o2 + G2, o5a = o1 + G1, o5b = o5a + n5, ng = o5b + n5;
+  for (int g = tid; g < ng; g += 1024) {
+    int gd[4] = {0, 0, 0, 0}, glt[4] = {0, 0, 0, 0}, gL[4] = {0, 0, 0, 0}, t0 = 0, kind = 0;
+    auto put = [&](int r) {
+      const int L = Ls[r], t = (L + 15) >> 4;
+      for (int k = 0; k < t && t0 < 4; k++) { gd[t0] = r; glt[t0] = k; gL[t0] = L; t0++; }
+    };
+    if (g < o3) put(lst[3][g]);
+    else if (g < o2) { const int i = g - o3; put(lst[2][i]); if (i < u3) put(lst[0][i]); }
+    else if (g < o1) {
+      const int i = g - o2; put(lst[1][2 * i]);
+      if (2 * i + 1 < n2) put(lst[1][2 * i + 1]);
+      else for (int k = 0; k < u2; k++) put(lst[0][u3 + k]);
+    } else if (g < o5a) {
+      const int i = g - o1;
+      for (int k = 0; k < 4 && 4 * i + k < r1; k++) put(lst[0][u3 + u2 + 4 * i + k]);
+    } else {
+      const int half = g >= o5b, r = lst[4][g - (half ? o5b : o5a)], L = Ls[r];
+      kind = 1 + half; t0 = half ? 2 : 3;
+      for (int k = 0; k < t0; k++) { gd[k] = r; glt[k] = (half ? 3 : 0) + k; gL[k] = L; }
+    }
+    int4* dst = reinterpret_cast<int4*>(groups + g);
+    dst[0] = make_int4(t0, kind, gd[0], gd[1]);
+    dst[1] = make_int4(gd[2], gd[3], glt[0], glt[1]);
+    dst[2] = make_int4(glt[2], glt[3], gL[0], gL[1]);
+    dst[3] = make_int4(gL[2], gL[3], 0, 0);
+  }
+  if (tid == 0) {
+    ngroups[0] = ng;
+    if (cached) { memo.hdr[1] = n1 + n2 + n3 + n4 + n5; memo.hdr[2] = nzr; memo.hdr[0] = 1; }
+  }
+  if (cached) for (int i = tid; i < nzr; i += 1024) memo.zidx[i] = lst[5][i];
 }
 
 // Measured and rejected: the MLP in 512-unit chunks (four column tiles per activation fragment, half the barriers; the hidden image
@@ -915,10 +968,11 @@ size_t avlen_clip_tower_stream_ws_bytes(int B) {
          (size_t)clip_max_units(B) * 2 * (CT_XSLOT + CT_XSLOT2);
 }
 
+// memo (optional; avlen_clip_text_cached_fwd): {new tokens (B - 1 rows), previous tokens (B rows, updated in place; the tower reads
+// THEM: pass them as `tokens`), header, zero-row list}: only rows that differ from the previous call run the tower
 int avlen_clip_tower_stream_fwd(const avlen_clip_text* p, const int64_t* tokens, float* E, int B, int f16, void* ws, size_t ws_bytes,
-                                hipStream_t st, const int* row_idx, const int* count) {
+                                hipStream_t st, const avlen_clip_memo* memo) {
   if (!clip_stream_shape_ok(p) || !p->wstream || B <= 0 || B > CT_MAXB || !ws || ws_bytes < avlen_clip_tower_stream_ws_bytes(B)) return AVLEN_ERR_ARG;
-  if (avlen_zero_bytes(ws, CT_FLAG_BYTES, st) != AVLEN_OK) return AVLEN_ERR_LAUNCH;      // the flag words (own block at the workspace's start)
   ClipArgs a = {};
   a.tokens = tokens; a.tok_emb = p->tok_emb; a.pos_emb = p->pos_emb; a.wstream = (const uint4*)p->wstream; a.E = E;
   a.ctx = p->ctx; a.vocab = p->vocab; a.layers = p->layers; a.frags_per_wave = clip_frags_per_wave(p->layers, 2);
@@ -944,7 +998,10 @@ int avlen_clip_tower_stream_fwd(const avlen_clip_text* p, const int64_t* tokens,
   }
   a.max_wg4 = g_split4_wgs;                                // < 0: always the 4-way split (default); 0: always 2-way; n: lab (mixed)
   (void)n_cu;
-  hipLaunchKernelGGL(clip_group_kernel, dim3(1), dim3(1024), 0, st, tokens, row_idx, count, B, p->ctx, p->vocab, groups, ngroups);
+  ClipMemo mm = {};
+  if (memo) mm = *memo;
+  hipLaunchKernelGGL(clip_worklist_kernel, dim3(1), dim3(1024), 0, st, tokens, mm, B, p->ctx, groups, ngroups, (unsigned*)ws,
+                     (int)(CT_FLAG_BYTES / 4));
   for (int l = 0; l < p->layers; l++) {
     const avlen_clip_block& b = p->block[l];
     a.L[l] = ClipLayerP{b.ln1.g, b.ln1.b, b.ln2.g, b.ln2.b, b.attn.in_proj.b, b.attn.out_proj.b, b.fc.b, b.proj.b};

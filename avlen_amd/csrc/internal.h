@@ -148,9 +148,12 @@ int avlen_tower_x3_fwd(const avlen_resnet18* const* nets, const void* const* img
                        size_t ws_bytes, hipStream_t stream);
 // clip_tower.hip: the 12 blocks of the CLIP text tower in one sequence-stationary launch -> E[b] = residual row at the EOT token
 size_t avlen_clip_tower_stream_ws_bytes(int B);
-// row_idx / count (device, optional): only the dialogs row_idx[0 .. *count) are computed (E rows of the others stay untouched)
+// memo (device pointers, optional -- the memoised tower of avlen_clip_text_cached_fwd): the launch's work-list kernel compares
+// tokens_new (B - 1 rows) with prev (B rows, the last one all zero; updated in place -- pass it as `tokens`) and only rows that differ
+// go through the tower (E rows of the others stay untouched); hdr = [valid, rows through the tower, all-zero rows], zidx = the latter
+struct avlen_clip_memo { const int64_t* tokens_new; int64_t* prev; int* hdr; int* zidx; };
 int avlen_clip_tower_stream_fwd(const avlen_clip_text* p, const int64_t* tokens, float* E, int B, int f16, void* ws, size_t ws_bytes,
-                                hipStream_t st, const int* row_idx = nullptr, const int* count = nullptr);
+                                hipStream_t st, const avlen_clip_memo* memo = nullptr);
 // fp32 rows -> compensated bf16 pair in one pass (hi plane at dst, lo plane `lo` elements behind it)
 int avlen_cast_pair(const float* src, int ld_src, void* dst, int ld_dst, long rows, int cols, long lo, hipStream_t stream);
 int avlen_conv2d_nhwc_h16(const void* X, const void* Wp, const float* bias, const float* residual, float* Y32, void* Y16,

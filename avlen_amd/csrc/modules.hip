@@ -2130,35 +2130,7 @@ inline TextCache text_cache_map(void* state, int B, int ctx, int wd) {
   c.zidx = (int*)s;
   return c;
 }
-// one block; wave w compares rows w, w + 16, ... (lane k: tokens k and k + 64); ordered compaction by thread 0 -> the work list
-// is in row order whatever the hardware does (deterministic launch shape)
-__global__ __launch_bounds__(1024) void text_cache_detect_kernel(const int64_t* __restrict__ tokens, int64_t* __restrict__ prev,
-                                                                 int* __restrict__ hdr, int* __restrict__ idx, int* __restrict__ zidx,
-                                                                 int B, int ctx) {
-  __shared__ int flag[1024];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int valid = hdr[0];
-  for (int r = wave; r <= B; r += 16) {
-    bool diff = false, nz = false;
-    for (int k = lane; k < ctx; k += 64) {
-      const int64_t v = r < B ? tokens[(long)r * ctx + k] : 0;
-      const int64_t o = prev[(long)r * ctx + k];
-      diff = diff || v != o; nz = nz || v != 0;
-      prev[(long)r * ctx + k] = v;
-    }
-    const bool d = __any(diff) || !valid, z = !__any(nz);
-    if (lane == 0) flag[r] = d ? ((z && r < B) ? 2 : 1) : 0;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    int n = 0, zc = 0;
-    for (int r = 0; r <= B; r++) {
-      if (flag[r] == 1) idx[n++] = r;
-      else if (flag[r] == 2) zidx[zc++] = r;
-    }
-    hdr[1] = n; hdr[2] = zc; hdr[0] = 1;
-  }
-}
+// (which rows changed is decided by the tower launch's own work-list kernel: clip_tower.hip, clip_worklist_kernel)
 __global__ __launch_bounds__(128) void text_cache_zero_rows_kernel(float* __restrict__ E, const int* __restrict__ hdr,
                                                                    const int* __restrict__ zidx, int B, int wd) {
   if ((int)blockIdx.x >= hdr[2]) return;
@@ -2181,15 +2153,14 @@ extern "C" int avlen_clip_text_cached_fwd(const avlen_clip_text* p, const int64_
   if (!fast) return avlen_clip_text_fwd(p, tokens, out, B, prec, ws, ws_bytes, st);
   if (state_bytes < text_cache_bytes(B, p->ctx, wd) || ws_bytes < avlen_clip_text_workspace_bytes(p, B + 1)) return AVLEN_ERR_WS;
   const TextCache c = text_cache_map(state, B, p->ctx, wd);
-  hipLaunchKernelGGL(text_cache_detect_kernel, dim3(1), dim3(1024), 0, st, tokens, c.prev, c.hdr, c.idx, c.zidx, B, p->ctx);
-  TRY(avlen_launch_status());
   WsBump w(ws, ws_bytes);
   float* E2 = w.take<float>((size_t)B * wd);
   void* gws = w.take<char>(GEMM_SCRATCH);
   const size_t sb = avlen_clip_tower_stream_ws_bytes(B + 1);
   void* sws = w.take<char>(sb);
   if (!w.ok()) return AVLEN_ERR_WS;
-  TRY(avlen_clip_tower_stream_fwd(p, c.prev, c.E, B + 1, f16 ? 1 : 0, sws, sb, st, c.idx, c.hdr + 1));
+  const avlen_clip_memo memo{tokens, c.prev, c.hdr, c.zidx};
+  TRY(avlen_clip_tower_stream_fwd(p, c.prev, c.E, B + 1, f16 ? 1 : 0, sws, sb, st, &memo));
   hipLaunchKernelGGL(text_cache_zero_rows_kernel, dim3(B), dim3(128), 0, st, c.E, c.hdr, c.zidx, B, wd);
   TRY(avlen_launch_status());
   if (!p->text_proj)
