@@ -20,6 +20,7 @@ static inline size_t zmax(size_t a, size_t b) { return a > b ? a : b; }
 namespace {
 
 typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 constexpr size_t GEMM_SCRATCH = 96u << 20;       // split-K / accumulate slabs shared by one module call
 
 typedef avlen_ctx Ctx;      // internal.h (xs: operand scratch of the large-M bf16 products below)
@@ -33,6 +34,11 @@ typedef avlen_ctx Ctx;      // internal.h (xs: operand scratch of the large-M bf
 bool attn_bwd16_on() {          // AVLEN_ATTN_BWD16=0: fp32 attention backward in bf16 mode too (A/B knob)
   static int v = -1;
   if (v < 0) v = (int)avlen_knob("AVLEN_ATTN_BWD16", 1);
+  return v != 0;
+}
+bool fused_dy_on() {             // AVLEN_FUSED_DY=0: the three separate passes over dY (A/B knob)
+  static int v = -1;
+  if (v < 0) v = (int)avlen_knob("AVLEN_FUSED_DY", 1);
   return v != 0;
 }
 long g_big_m = -1;
@@ -70,6 +76,65 @@ int tcast(const Ctx& c, const float* src, int ld, bf16* dst, long ldt, long R, i
   const long Rp = ldt;
   hipLaunchKernelGGL(tcast_kernel, dim3((unsigned)((Rp + 31) / 32), ceil_div(C, 32)), dim3(32, 8), 0, c.st, src, ld, dst, ldt, R, C, Rp, lo);
   return avlen_launch_status();
+}
+// ONE pass over an upstream gradient dY [M][N] fp32 for everything a Linear's backward needs of it: the row-major 16-bit operand
+// [M][Np] of dX = dY W (columns N .. Np-1 zero), the transposed operand [N][Mp] of dW = dY^T X (columns M .. Mp-1 zero) -- both with
+// the low plane of the compensated pair `*_lo` elements behind the high one when NP == 2 -- and the column sums (bias gradient,
+// added to `colsum`).  Replaces cast_pair + tcast + colsum_acc, i.e. three reads of dY (the 2nd-stage update's dY are 0.7 GB each).
+template <int NP>
+__global__ __launch_bounds__(256) void dy_prep_kernel(const float* __restrict__ src, int ld, bf16* __restrict__ rows16, int Np, long rows_lo,
+                                                      bf16* __restrict__ t16, long Mp, long t_lo, float* __restrict__ colsum, long M, int N, int tiles) {
+  __shared__ float t[64][65];
+  const int c0 = blockIdx.y * 64;
+  const int tid = threadIdx.x;
+  float csum = 0.f;                                       // threads 0 .. 63: this block's column sums (ONE atomic per column per block:
+  for (int it = 0; it < tiles; it++) {                 // 64-row blocks hammered the same N addresses with 3 M atomics per call)
+    const long r0 = ((long)blockIdx.x * tiles + it) * 64;
+    if (r0 >= Mp) break;
+    if (it) __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int idx = tid + 256 * j, row = idx >> 4, c4 = (idx & 15) * 4;
+      const long r = r0 + row; const int cc = c0 + c4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < M) {
+        if (cc + 4 <= N) v = *reinterpret_cast<const float4*>(src + r * ld + cc);
+        else { if (cc < N) v.x = src[r * ld + cc]; if (cc + 1 < N) v.y = src[r * ld + cc + 1]; if (cc + 2 < N) v.z = src[r * ld + cc + 2]; }
+      }
+      t[row][c4] = v.x; t[row][c4 + 1] = v.y; t[row][c4 + 2] = v.z; t[row][c4 + 3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; j++) {                          // row-major: 64 rows x 8 chunks of 8 columns
+      const int idx = tid + 256 * j, row = idx >> 3, ch = (idx & 7) * 8;
+      const long r = r0 + row;
+      if (r < M && c0 + ch < Np) {
+        bf16x8 h, l;
+#pragma unroll
+        for (int e = 0; e < 8; e++) { const float v = t[row][ch + e]; h[e] = (bf16)v; if (NP == 2) l[e] = (bf16)(v - (float)h[e]); }
+        *reinterpret_cast<bf16x8*>(rows16 + r * Np + c0 + ch) = h;
+        if (NP == 2) *reinterpret_cast<bf16x8*>(rows16 + rows_lo + r * Np + c0 + ch) = l;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {                          // transposed: 64 columns x 8 chunks of 8 rows (rows past M were loaded as zero)
+      const int idx = tid + 256 * j, col = idx >> 3, rch = (idx & 7) * 8;
+      if (c0 + col < N && r0 + rch < Mp) {
+        bf16x8 h, l;
+#pragma unroll
+        for (int e = 0; e < 8; e++) { const float v = t[rch + e][col]; h[e] = (bf16)v; if (NP == 2) l[e] = (bf16)(v - (float)h[e]); }
+        *reinterpret_cast<bf16x8*>(t16 + (long)(c0 + col) * Mp + r0 + rch) = h;
+        if (NP == 2) *reinterpret_cast<bf16x8*>(t16 + t_lo + (long)(c0 + col) * Mp + r0 + rch) = l;
+      }
+    }
+    if (tid < 64) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 64; r += 4) { a0 += t[r][tid]; a1 += t[r + 1][tid]; a2 += t[r + 2][tid]; a3 += t[r + 3][tid]; }
+      csum += (a0 + a1) + (a2 + a3);
+    }
+  }
+  if (colsum && tid < 64 && c0 + tid < N) atomicAdd(&colsum[c0 + tid], csum);
 }
 // fp32 rows -> 16-bit operand (compensated: high plane + low plane `lo` elements behind it)
 int cast_pair(const Ctx& c, const float* src, int ld, bf16* dst, int ldd, long rows, int cols, long lo) {
@@ -159,6 +224,42 @@ int linear_dw(const Ctx& c, const avlen_linear& G, const float* dY, int ldy, con
   while (sk > 1 && avlen_gemm_workspace_bytes(G.out_f, G.in_f, M, sk) > c.gws_bytes) sk /= 2;
   return avlen_gemm(dY, ldy, 1, X, ldx, 1, G.w, G.in_f, nullptr, nullptr, 0, G.out_f, G.in_f, M, 0, c.prec, sk, 1.f,
                     c.gws, c.gws_bytes, c.st);
+}
+
+int colsum_acc(const Ctx& c, const float* dY, int ld, float* out, int rows, int N);
+// The whole backward of Y = X W^T + b for one upstream gradient: G.w += dY^T X, G.b += colsum(dY), dX = dY W (+ add) when dX is
+// given.  Large M (the 16-bit glds route): dY is read ONCE (dy_prep_kernel); otherwise -- or when the operand scratch cannot hold all
+// four operands at a time -- the three separate steps, in the order the call sites always used.
+int linear_bwd(const Ctx& c, const avlen_linear& L, const avlen_linear& G, const float* dY, int ldy, const float* X, int ldx, float* dX,
+               int lddx, int M, const float* add, int ldadd) {
+  if (big_path(c, M) && !(ldy & 3) && !((uintptr_t)dY & 15) && fused_dy_on()) {
+    const int Np = pad8(L.out_f);
+    const long Mp = pad8(M);
+    const int np = c.prec == AVLEN_PREC_BF16X3 ? 2 : 1;
+    XsBump b(c);
+    bf16* dY16 = dX ? b.take((size_t)np * M * Np) : nullptr;
+    bf16* dYT = b.take((size_t)np * L.out_f * Mp); bf16* XT = b.take((size_t)np * L.in_f * Mp);
+    bf16* WT16 = dX ? b.take((size_t)np * L.in_f * Np) : nullptr;
+    if (b.good) {
+      const long yl = np > 1 ? (long)M * Np : 0, tl = np > 1 ? (long)L.out_f * Mp : 0, xl = np > 1 ? (long)L.in_f * Mp : 0,
+                 wl = np > 1 ? (long)L.in_f * Np : 0;
+      const long rt = (Mp + 63) / 64;                       // 64-row tiles; up to 16 per block once the grid fills the chip anyway
+      const int tiles = (int)(rt / 64 < 1 ? 1 : (rt / 64 > 16 ? 16 : rt / 64));
+      const dim3 grid((unsigned)((rt + tiles - 1) / tiles), ceil_div(L.out_f, 64));
+      // without dX only the transposed operand is wanted: the row-major stores are skipped by an empty column range (Np = 0)
+      if (np > 1) hipLaunchKernelGGL(dy_prep_kernel<2>, grid, dim3(256), 0, c.st, dY, ldy, dY16, dX ? Np : 0, yl, dYT, Mp, tl, G.b, (long)M, L.out_f, tiles);
+      else hipLaunchKernelGGL(dy_prep_kernel<1>, grid, dim3(256), 0, c.st, dY, ldy, dY16, dX ? Np : 0, yl, dYT, Mp, tl, G.b, (long)M, L.out_f, tiles);
+      TRY(avlen_launch_status());
+      TRY(tcast(c, X, ldx, XT, Mp, M, L.in_f, xl));
+      TRY(big_gemm(c, dYT, (int)Mp, tl, XT, (int)Mp, xl, G.w, L.in_f, nullptr, G.w, L.in_f, L.out_f, L.in_f, (int)Mp, 0));
+      if (!dX) return AVLEN_OK;
+      TRY(tcast(c, L.w, L.in_f, WT16, Np, L.out_f, L.in_f, wl));
+      return big_gemm(c, dY16, Np, yl, WT16, Np, wl, dX, lddx, nullptr, add, ldadd, M, L.in_f, Np, 0);
+    }
+  }
+  TRY(linear_dw(c, G, dY, ldy, X, ldx, M));
+  TRY(colsum_acc(c, dY, ldy, G.b, M, L.out_f));
+  return dX ? linear_dx(c, L, dY, ldy, dX, lddx, M, add, ldadd) : AVLEN_OK;
 }
 
 // Convolution weight gradient on the large-M bf16 route WITHOUT materialising im2col(X) in fp32: the gather is fused into the
@@ -1255,20 +1356,14 @@ int transformer_bwd(const Ctx& c, const avlen_transformer& tr, const avlen_trans
   TRY(avlen_layernorm_bwd(d_out, t.Y3, tr.dec_norm.g, t.mf, t.rf, dY3, g.dec_norm.g, g.dec_norm.b, B, d, c.st));
   TRY(avlen_layernorm_bwd(dY3, t.U3, q.norm3.g, t.md3, t.rd3, dU3, gq.norm3.g, gq.norm3.b, B, d, c.st));
   float* dG1 = s.dD; float* dY2 = s.dE;
-  TRY(linear_dw(c, gq.lin2, dU3, d, t.G1, q.lin1.out_f, B));
-  TRY(colsum_acc(c, dU3, d, gq.lin2.b, B, d));
-  TRY(linear_dx(c, q.lin2, dU3, d, dG1, q.lin1.out_f, B, nullptr, 0));
+  TRY(linear_bwd(c, q.lin2, gq.lin2, dU3, d, t.G1, q.lin1.out_f, dG1, q.lin1.out_f, B, nullptr, 0));
   TRY(relu_bwd(c, dG1, t.G1, (long)B * q.lin1.out_f));
-  TRY(linear_dw(c, gq.lin1, dG1, q.lin1.out_f, t.Y2, d, B));
-  TRY(colsum_acc(c, dG1, q.lin1.out_f, gq.lin1.b, B, q.lin1.out_f));
-  TRY(linear_dx(c, q.lin1, dG1, q.lin1.out_f, dY2, d, B, dU3, d));               // dY2 = dU3 + dG1 W1
+  TRY(linear_bwd(c, q.lin1, gq.lin1, dG1, q.lin1.out_f, t.Y2, d, dY2, d, B, dU3, d));               // dY2 = dU3 + dG1 W1
   // ---- decoder: norm2, cross attention
   float* dU2 = s.dB;
   TRY(avlen_layernorm_bwd(dY2, t.U2, q.norm2.g, t.md2, t.rd2, dU2, gq.norm2.g, gq.norm2.b, B, d, c.st));
   float* dAOc = s.dC;
-  TRY(linear_dw(c, gq.cross_attn.out_proj, dU2, d, t.AOc, d, B));
-  TRY(colsum_acc(c, dU2, d, gq.cross_attn.out_proj.b, B, d));
-  TRY(linear_dx(c, q.cross_attn.out_proj, dU2, d, dAOc, d, B, nullptr, 0));
+  TRY(linear_bwd(c, q.cross_attn.out_proj, gq.cross_attn.out_proj, dU2, d, t.AOc, d, dAOc, d, B, nullptr, 0));
   float* dMEM = s.dD;                    // [R, d]
   float* dY1 = s.dE;                     // [B, d]
   avlen_linear gin = gq.cross_attn.in_proj; const avlen_linear& win = q.cross_attn.in_proj;
@@ -1276,9 +1371,7 @@ int transformer_bwd(const Ctx& c, const avlen_transformer& tr, const avlen_trans
     // AOc == Vc(MEM): dVc = dAOc ; q,k projections get exactly zero gradient (softmax over one key)
     avlen_linear gv = gin; gv.w = gin.w + (size_t)2 * d * d; gv.b = gin.b + 2 * d; gv.out_f = d;
     avlen_linear wv = win; wv.w = win.w + (size_t)2 * d * d; wv.out_f = d;
-    TRY(linear_dw(c, gv, dAOc, d, t.MEM, d, (int)R));
-    TRY(colsum_acc(c, dAOc, d, gv.b, (int)R, d));
-    TRY(linear_dx(c, wv, dAOc, d, dMEM, d, (int)R, nullptr, 0));
+    TRY(linear_bwd(c, wv, gv, dAOc, d, t.MEM, d, dMEM, d, (int)R, nullptr, 0));
     TRY(avlen_copy_rows(dU2, d, dY1, d, B, d, c.st));                          // dY1 = dU2 (residual)
   } else {
     float* dQc = s.dA;                   // [B, d]
@@ -1287,26 +1380,19 @@ int transformer_bwd(const Ctx& c, const avlen_transformer& tr, const avlen_trans
                             dKVc, 2 * d, dKVc + d, 2 * d, B, H, 1, S, D, 0, scale, c.st));
     avlen_linear gqp = gin; gqp.out_f = d;
     avlen_linear wqp = win; wqp.out_f = d;
-    TRY(linear_dw(c, gqp, dQc, d, t.Y1, d, B));
-    TRY(colsum_acc(c, dQc, d, gqp.b, B, d));
-    TRY(linear_dx(c, wqp, dQc, d, dY1, d, B, dU2, d));                         // dY1 = dU2 + dQc Wq
+    TRY(linear_bwd(c, wqp, gqp, dQc, d, t.Y1, d, dY1, d, B, dU2, d));                         // dY1 = dU2 + dQc Wq
     avlen_linear gkv = gin; gkv.w = gin.w + (size_t)d * d; gkv.b = gin.b + d; gkv.out_f = 2 * d;
     avlen_linear wkv = win; wkv.w = win.w + (size_t)d * d; wkv.out_f = 2 * d;
-    TRY(linear_dw(c, gkv, dKVc, 2 * d, t.MEM, d, (int)R));
-    TRY(colsum_acc(c, dKVc, 2 * d, gkv.b, (int)R, 2 * d));
-    TRY(linear_dx(c, wkv, dKVc, 2 * d, dMEM, d, (int)R, nullptr, 0));
+    TRY(linear_bwd(c, wkv, gkv, dKVc, 2 * d, t.MEM, d, dMEM, d, (int)R, nullptr, 0));
   }
   // ---- decoder: norm1, self attention over the single target token
   float* dU1 = s.dB;
   TRY(avlen_layernorm_bwd(dY1, t.U1, q.norm1.g, t.md1, t.rd1, dU1, gq.norm1.g, gq.norm1.b, B, d, c.st));
   float* dV0 = s.dC;
-  TRY(linear_dw(c, gq.self_attn.out_proj, dU1, d, t.V0, d, B));
-  TRY(colsum_acc(c, dU1, d, gq.self_attn.out_proj.b, B, d));
-  TRY(linear_dx(c, q.self_attn.out_proj, dU1, d, dV0, d, B, nullptr, 0));
+  TRY(linear_bwd(c, q.self_attn.out_proj, gq.self_attn.out_proj, dU1, d, t.V0, d, dV0, d, B, nullptr, 0));
   {
     avlen_linear gv = gq.self_attn.in_proj; gv.w += (size_t)2 * d * d; gv.b += 2 * d; gv.out_f = d;
-    TRY(linear_dw(c, gv, dV0, d, tgt, d, B));
-    TRY(colsum_acc(c, dV0, d, gv.b, B, d));
+    TRY(linear_bwd(c, gv, gv, dV0, d, tgt, d, nullptr, 0, B, nullptr, 0));
   }
   // ---- encoder: final norm, norm2, FFN
   const avlen_enc_layer& e = tr.enc; const avlen_enc_layer& ge = g.enc;
@@ -1314,26 +1400,18 @@ int transformer_bwd(const Ctx& c, const avlen_transformer& tr, const avlen_trans
   TRY(avlen_layernorm_bwd(dMEM, t.X2, tr.enc_norm.g, t.me, t.re, dX2, g.enc_norm.g, g.enc_norm.b, (int)R, d, c.st));
   TRY(avlen_layernorm_bwd(dX2, t.T2, e.norm2.g, t.m2, t.r2, dT2, ge.norm2.g, ge.norm2.b, (int)R, d, c.st));
   float* dF1 = s.dD; float* dX1 = s.dE;
-  TRY(linear_dw(c, ge.lin2, dT2, d, t.F1, e.lin1.out_f, (int)R));
-  TRY(colsum_acc(c, dT2, d, ge.lin2.b, (int)R, d));
-  TRY(linear_dx(c, e.lin2, dT2, d, dF1, e.lin1.out_f, (int)R, nullptr, 0));
+  TRY(linear_bwd(c, e.lin2, ge.lin2, dT2, d, t.F1, e.lin1.out_f, dF1, e.lin1.out_f, (int)R, nullptr, 0));
   TRY(relu_bwd(c, dF1, t.F1, R * e.lin1.out_f));
-  TRY(linear_dw(c, ge.lin1, dF1, e.lin1.out_f, t.X1, d, (int)R));
-  TRY(colsum_acc(c, dF1, e.lin1.out_f, ge.lin1.b, (int)R, e.lin1.out_f));
-  TRY(linear_dx(c, e.lin1, dF1, e.lin1.out_f, dX1, d, (int)R, dT2, d));          // dX1 = dT2 + dF1 W1
+  TRY(linear_bwd(c, e.lin1, ge.lin1, dF1, e.lin1.out_f, t.X1, d, dX1, d, (int)R, dT2, d));          // dX1 = dT2 + dF1 W1
   // ---- encoder: norm1, self attention
   float* dT1 = s.dB;
   TRY(avlen_layernorm_bwd(dX1, t.T1, e.norm1.g, t.m1, t.r1, dT1, ge.norm1.g, ge.norm1.b, (int)R, d, c.st));
   float* dAO = s.dC;
-  TRY(linear_dw(c, ge.self_attn.out_proj, dT1, d, t.AO, d, (int)R));
-  TRY(colsum_acc(c, dT1, d, ge.self_attn.out_proj.b, (int)R, d));
-  TRY(linear_dx(c, e.self_attn.out_proj, dT1, d, dAO, d, (int)R, nullptr, 0));
+  TRY(linear_bwd(c, e.self_attn.out_proj, ge.self_attn.out_proj, dT1, d, t.AO, d, dAO, d, (int)R, nullptr, 0));
   if (cto) {
     avlen_linear gv = ge.self_attn.in_proj; gv.w += (size_t)2 * d * d; gv.b += 2 * d; gv.out_f = d;
     avlen_linear wv = e.self_attn.in_proj; wv.w += (size_t)2 * d * d; wv.out_f = d;
-    TRY(linear_dw(c, gv, dAO, d, Z, d, (int)R));
-    TRY(colsum_acc(c, dAO, d, gv.b, (int)R, d));
-    TRY(linear_dx(c, wv, dAO, d, dZ, d, (int)R, dT1, d));                         // dZ = dT1 + dV Wv
+    TRY(linear_bwd(c, wv, gv, dAO, d, Z, d, dZ, d, (int)R, dT1, d));                         // dZ = dT1 + dV Wv
   } else {
     float* dQKV = s.dA;
     // bf16 mode: the matrix-core backward (P / dS in registers); shapes outside its envelope take the fp32 kernels
@@ -1345,9 +1423,7 @@ int transformer_bwd(const Ctx& c, const avlen_transformer& tr, const avlen_trans
       rc = avlen_attention_bwd(t.QKV, 3 * d, t.QKV + d, 3 * d, t.QKV + 2 * d, 3 * d, t.AO, d, dAO, d, maskx, t.LSE, s.delta,
                                dQKV, 3 * d, dQKV + d, 3 * d, dQKV + 2 * d, 3 * d, B, H, S, S, D, 0, scale, c.st);
     TRY(rc);
-    TRY(linear_dw(c, ge.self_attn.in_proj, dQKV, 3 * d, Z, d, (int)R));
-    TRY(colsum_acc(c, dQKV, 3 * d, ge.self_attn.in_proj.b, (int)R, 3 * d));
-    TRY(linear_dx(c, e.self_attn.in_proj, dQKV, 3 * d, dZ, d, (int)R, dT1, d));   // dZ = dT1 + dQKV Win
+    TRY(linear_bwd(c, e.self_attn.in_proj, ge.self_attn.in_proj, dQKV, 3 * d, Z, d, dZ, d, (int)R, dT1, d));   // dZ = dT1 + dQKV Win
   }
   return AVLEN_OK;
 }
@@ -1744,14 +1820,11 @@ extern "C" int avlen_smt_bwd(const avlen_smt* p, const avlen_smt* g, const float
   c.xs = s.xs; c.xs_bytes = s.xs_bytes;
   TRY(transformer_bwd(c, p->tr, g->tr, s.tr, s.tb, s.Z, s.maskx, goal, d_out, s.dZ, B, S, cto != 0));
   // fusion MLP
-  TRY(linear_dw(c, g->fus2, s.dZ, d, s.H1, d, (int)R));
-  TRY(colsum_acc(c, s.dZ, d, g->fus2.b, (int)R, d));
-  TRY(linear_dx(c, p->fus2, s.dZ, d, s.dH1, d, (int)R, nullptr, 0));
+  TRY(linear_bwd(c, p->fus2, g->fus2, s.dZ, d, s.H1, d, s.dH1, d, (int)R, nullptr, 0));
   TRY(relu_bwd(c, s.dH1, s.H1, R * d));
   {
     avlen_linear g0 = g->fus0;            // dW0[d][F+12] += dH1^T XF  (XF rows are ldxf apart)
-    TRY(linear_dw(c, g0, s.dH1, d, s.XF, s.ldxf, (int)R));
-    TRY(colsum_acc(c, s.dH1, d, g0.b, (int)R, d));
+    TRY(linear_bwd(c, g0, g0, s.dH1, d, s.XF, s.ldxf, nullptr, 0, (int)R, nullptr, 0));
   }
   // pose encoder: dPE[R,16] = dH1 * W0[:, pc:pc+16]
   TRY(avlen_gemm(s.dH1, d, 0, p->fus0.w + pose_col, p->fus0.in_f, 1, s.dPE, 16, nullptr, nullptr, 0, (int)R, 16, d, 0,
@@ -1873,13 +1946,9 @@ extern "C" int avlen_dialog_bwd(const avlen_dialog* p, const avlen_dialog* g, co
   // the positional encoding is an additive constant: dZ is the gradient of the fusion output as well
   TRY(transformer_bwd(c, p->tr, g->tr, s.tr, s.tb, s.Z, s.maskx, goal, d_out, s.dZ, B, S, false));
   if (has_dialog) {
-    TRY(linear_dw(c, g->fus2, s.dZ, d, s.H1, d, (int)R));
-    TRY(colsum_acc(c, s.dZ, d, g->fus2.b, (int)R, d));
-    TRY(linear_dx(c, p->fus2, s.dZ, d, s.dH1, d, (int)R, nullptr, 0));
+    TRY(linear_bwd(c, p->fus2, g->fus2, s.dZ, d, s.H1, d, s.dH1, d, (int)R, nullptr, 0));
     TRY(relu_bwd(c, s.dH1, s.H1, R * d));
-    TRY(linear_dw(c, g->fus0, s.dH1, d, s.SEQ, 2 * d, (int)R));
-    TRY(colsum_acc(c, s.dH1, d, g->fus0.b, (int)R, d));
-    TRY(linear_dx(c, p->fus0, s.dH1, d, s.dSEQ, 2 * d, (int)R, nullptr, 0));
+    TRY(linear_bwd(c, p->fus0, g->fus0, s.dH1, d, s.SEQ, 2 * d, s.dSEQ, 2 * d, (int)R, nullptr, 0));
     hipLaunchKernelGGL(dialog_split_grad_kernel, dim3((unsigned)B), dim3(128), 0, st, s.dSEQ, 2 * d, d_x_att, d_demb, S, d);
   } else {
     hipLaunchKernelGGL(dialog_split_grad_kernel, dim3((unsigned)B), dim3(128), 0, st, s.dZ, d, d_x_att, (float*)nullptr, S, d);
@@ -1893,9 +1962,7 @@ extern "C" int avlen_linear_bwd(const avlen_linear* L, const avlen_linear* G, co
                                 float* dX, int lddx, int M, int prec, void* ws, size_t ws_bytes, hipStream_t st) {
   if (!L || !G || !X || !dY || M <= 0 || ws_bytes < GEMM_SCRATCH) return AVLEN_ERR_WS;
   Ctx c{st, prec, ws, GEMM_SCRATCH};
-  TRY(linear_dw(c, *G, dY, ldy, X, ldx, M));
-  TRY(colsum_acc(c, dY, ldy, G->b, M, L->out_f));
-  if (dX) TRY(linear_dx(c, *L, dY, ldy, dX, lddx, M, nullptr, 0));
+  TRY(linear_bwd(c, *L, *G, dY, ldy, X, ldx, dX, lddx, M, nullptr, 0));
   return AVLEN_OK;
 }
 extern "C" size_t avlen_linear_bwd_workspace_bytes(void) { return GEMM_SCRATCH; }
