@@ -22,13 +22,14 @@ python3 $R/tools/step_trace.py $DB 150 40 > $O/step_trace.txt || exit 1
 # phase tables of the persistent tower launch and of the one-launch text tower (lab binaries built here: tools/bin is not tracked)
 if [ -x $R/tools/bin/x3_lab ]; then $R/tools/bin/x3_lab 64 6 > $O/tower_x3_phases.txt || exit 1; fi
 if [ -x $R/tools/bin/clip_lab ]; then
-  # the lab build carries phase timers (it runs ~2x slower than the product and is not bit-reproducible across launches in the
-  # 4-way split: the timers change the exchange's timing, not its arithmetic -- the product build is, tools/clip_det_probe.py)
+  # the lab build carries phase timers (cycle counts added to a table as each phase ends: same speed and, launch for launch, the
+  # same bits as the product build -- the output checksum is printed)
   $R/tools/bin/clip_lab 64 0 0 1 0 > $O/clip_tower_phases.txt || exit 1
   $R/tools/bin/clip_lab 64 >> $O/clip_tower_phases.txt || exit 1
   $R/tools/bin/clip_lab 16 >> $O/clip_tower_phases.txt || exit 1
 fi
 python3 $R/tools/clip_det_probe.py 2>&1 | grep -E "n=|4-way" > $O/clip_tower_splits.txt || exit 1
+python3 $R/tools/clip_xproc_probe.py 2>&1 | grep -E "^n=" >> $O/clip_tower_splits.txt || exit 1     # digests: equal from process to process
 for n in 64 32 16 8; do python3 $R/tools/clip_time.py $n 2>&1 | grep "per call" >> $O/clip_tower_splits.txt; done
 python3 $R/tools/clip_stream_probe.py 2>&1 | grep "stream=" > $O/clip_tower_parity_and_time.txt || exit 1
 if [ -x $R/tools/bin/gru_seq_lab ]; then $R/tools/bin/gru_seq_lab 150 8 > $O/gru_seq_phases.txt || exit 1; fi
