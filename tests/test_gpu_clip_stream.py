@@ -103,3 +103,26 @@ def test_encode_text_above_one_pass(mode, B):
     torch.cuda.synchronize()
     err = float((out[-40:] - ref).abs().max())
     assert err < (1e-2 if mode == "bf16x3" else 6e-2) * max(1.0, float(ref.abs().max())), err
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
+def test_embedding_does_not_depend_on_the_batch_it_is_packed_in(mode):
+    """The work list packs whole dialogs into groups of <= 4 row tiles ([4] | [3+1] | [2+2] | [2+1+1] | [1+1+1+1] | 5-tile halves);
+    a tile attends to its own dialog's keys only, the column split is fixed: a dialog alone in a call, in a reversed batch, or
+    among other tile classes must produce the same bits (the per-row memo recomputes single rows and relies on it)."""
+    gen = torch.Generator().manual_seed(12)
+    tok = _tokens(24, gen)
+    pol = _policy(mode, True)
+    # ln_final(tower output), without the text projection: that GEMM's summation order legitimately depends on the row count
+    enc = lambda t: pol.net.encode_text(pol, t, project=False)
+    full = enc(tok).clone()
+    rev = enc(tok.flip(0).contiguous()).clone().flip(0)
+    assert torch.equal(full, rev)
+    for b in (0, 1, 2, 5, 8, 11, 13, 14, 23):                       # 1 .. 5 tiles, alone
+        one = enc(tok[b:b + 1].contiguous()).clone()
+        assert torch.equal(one[0], full[b]), b
+    ones = [b for b in range(24) if int((tok[b] == 49407).nonzero()[0]) < 16]                 # only 1-tile dialogs: [1+1+1+1] groups
+    sub = enc(tok[ones].contiguous()).clone()
+    assert torch.equal(sub, full[ones])
+    for pick in ([4, 0, 2], [4, 5, 6, 0, 2], [6, 7, 0]):              # [2+1+1] | [3+1] [2+2] [1] | [3+1] [3]
+        assert torch.equal(enc(tok[pick].contiguous()).clone(), full[pick]), pick
