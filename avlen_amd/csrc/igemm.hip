@@ -402,7 +402,15 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __re
   if (i >= tot) return;
   int row = (int)(i / N), col = (int)(i - (long)row * N);
   float s = 0.f;
-  for (int z = 0; z < splits; z++) s += part[(long)z * tot + i];
+  int z = 0;
+  for (; z + 8 <= splits; z += 8) {                       // eight loads in flight, added in split order (same sum as one by one)
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = part[(long)(z + u) * tot + i];
+#pragma unroll
+    for (int u = 0; u < 8; u++) s += v[u];
+  }
+  for (; z < splits; z++) s += part[(long)z * tot + i];
   if (bias) s += bias[col];
   s = act_apply(s, act);
   if (residual) s += residual[(long)row * ldr + col];
