@@ -302,6 +302,9 @@ __device__ __forceinline__ bool clip_exchange_pair(const ClipArgs& a, char* lds,
 // the finished tile to its second slot, flag 2 s, (3) everybody reads the three finished tiles it does not own.  Two round trips with
 // every load of a round in flight at once, and all four parts end with bit-identical residual rows (each column is summed once).
 constexpr int CT_XSLOT2 = 4 * CT_TH * 16;                   // finished column tile: up to 4 row tiles x 512 lanes x 16 B = 32 KB
+// Measured and rejected (tools/clip_lab.hip, 64 dialogs, groups on one XCD): the exchange at a narrower scope.  Workgroup-scope (sc0)
+// loads hit the CU's own L1 and never see the partner's flag (every hand-off timed out); plain (write-back) stores with sc1 loads
+// gave the right bits and 580-597 us against 595-601: the exchange is not bound by the stores' write-through.
 template <int NT>
 __device__ __forceinline__ bool clip_exchange4(const ClipArgs& a, char* lds, f32x4 (&xr)[NT][4], int unit, unsigned seq, int tid) {
   static_assert(NT <= 4, "exchange slot size");
