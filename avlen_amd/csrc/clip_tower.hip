@@ -722,7 +722,7 @@ __device__ __forceinline__ void clip_tower_body(const ClipArgs& a, char* lds, co
 }
 
 // ---- work list (ONE launch in front of the tower): [memo: which rows changed] -> live lengths -> tile classes -> groups -> flags.
-// One block of 16 waves.  (A) wave per row: the EOT scan (first position of the largest id, as torch.argmax: nothing after it can
+// One block of 16 waves.  (A) sixteen lanes per row: the EOT scan (first position of the largest id, as torch.argmax: nothing after it can
 // reach the output through the causal mask) and, for the memoised tower (avlen_clip_text_cached_fwd), the comparison with the
 // previous call's tokens, which are updated in place (row B of that buffer is the all-zero dialog).  (B) per tile class, the rows in
 // row order: ranks by wave ballots + a prefix over the 64-row chunks.  (C) groups in CLOSED FORM, one thread per group -- whole
@@ -741,27 +741,33 @@ __global__ __launch_bounds__(1024) void clip_worklist_kernel(const int64_t* __re
   const bool cached = memo.prev != nullptr;
   const int valid = cached ? memo.hdr[0] : 1;
   for (int i = tid; i < flag_words; i += 1024) flags[i] = 0u;
-  // ---- (A)
-  for (int r = wave; r < B; r += 16) {
+  // ---- (A) sixteen lanes per row, 64 rows per pass: all of a row's loads are in flight together (a wave per row took five
+  // dependent passes of ~2 us for the benched 65 rows)
+  const int sub = lane >> 4, l16 = lane & 15;
+  for (int r0 = 0; r0 < B; r0 += 64) {
+    const int r = r0 + 4 * wave + sub;
     long best = -1; int bi = 0x7fffffff;
     bool diff = false, nz = false;
-    for (int k = lane; k < ctx; k += 64) {
-      long v;
-      if (cached) {
-        v = r < B - 1 ? memo.tokens_new[(long)r * ctx + k] : 0;              // the memo's buffer has one more row: all zero
-        const long o = memo.prev[(long)r * ctx + k];
-        diff = diff || v != o; nz = nz || v != 0;
-        memo.prev[(long)r * ctx + k] = v;
-      } else v = tokens[(long)r * ctx + k];
-      if (v > best) { best = v; bi = k; }
+    if (r < B) {
+      for (int k = l16; k < ctx; k += 16) {
+        long v;
+        if (cached) {
+          v = r < B - 1 ? memo.tokens_new[(long)r * ctx + k] : 0;            // the memo's buffer has one more row: all zero
+          const long o = memo.prev[(long)r * ctx + k];
+          diff = diff || v != o; nz = nz || v != 0;
+          memo.prev[(long)r * ctx + k] = v;
+        } else v = tokens[(long)r * ctx + k];
+        if (v > best) { best = v; bi = k; }
+      }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
+    for (int o = 8; o > 0; o >>= 1) {
       const long ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
       if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
     }
-    const bool any_diff = __any(diff), any_nz = __any(nz);
-    if (lane == 0) {
+    const unsigned long long bd = __ballot(diff), bz = __ballot(nz);
+    const bool any_diff = ((bd >> (16 * sub)) & 0xffffull) != 0, any_nz = ((bz >> (16 * sub)) & 0xffffull) != 0;
+    if (l16 == 0 && r < B) {
       const int L = bi + 1;
       int t = (L + 15) >> 4; t = t > 5 ? 5 : t;
       int c = t;                                                             // 1 .. 5: tiles
