@@ -120,6 +120,7 @@ class Workload:
         self.belief = None
         self._act_buf = None
         self._act_host = None
+        self._host_select = sampling == "race" and os.environ.get("AVLEN_HOST_SELECT", "1") != "0"
         self.sampling = sampling
         if belief_predictor:        # use_belief_predictor: True in the interactive yamls (ppo_trainer.py:892); 65x26 spectrogram only
             import types
@@ -315,18 +316,35 @@ class Workload:
         a_opt, actions = o["a_q"], o["a_q"]
         if self.pi_g is not None:
             actions = o["a_g"]
-        if self.pi_l is not None:
-            if self._act_buf is None:
-                self._act_buf = torch.empty_like(o["a_l"])
-            actions = torch.where(a_opt == 1, o["a_l"], actions, out=self._act_buf)       # queried envs follow pi_l
+
+        def select_on_device(actions=actions):
+            if self.pi_l is not None:
+                if self._act_buf is None:
+                    self._act_buf = torch.empty_like(o["a_l"])
+                return torch.where(a_opt == 1, o["a_l"], actions, out=self._act_buf)     # queried envs follow pi_l
+            return actions
+        late_select = False
         if self.sampling != "host":
-            # the simulator needs the step's actions on the host (envs.step, ppo_trainer.py:864): ONE device-to-host copy per step;
-            # with sampling="host" the three policies' actions were drawn there already (three probability round trips instead)
+            # the simulator needs the step's actions on the host (envs.step, ppo_trainer.py:864).  sampling="race": every policy's
+            # sampled actions are already on their way to pinned memory right behind its heads kernel (Policy.host_actions), so the
+            # step's actions are selected THERE (64 integers) as soon as pi_l's copy has landed -- the device-side select only feeds
+            # the storage and is enqueued behind the next step's towers instead of in front of them (it and its device-to-host
+            # copy were ~30 us of idle GPU per step).  Otherwise: select on the device, ONE device-to-host copy.
             if self._act_host is None:
-                self._act_host = [torch.empty(actions.shape, dtype=actions.dtype, pin_memory=True) for _ in range(4)]
+                self._act_host = [torch.empty(o["a_q"].shape, dtype=o["a_q"].dtype, pin_memory=True) for _ in range(4)]
             ah = self._act_host[t & 3]
-            ah.copy_(actions, non_blocking=True)
-            P._cur_stream().synchronize()
+            hq = self.pi_q.host_actions("option") if self._host_select else None
+            hg = self.pi_g.host_actions("goal") if hq is not None and self.pi_g is not None else None
+            hl = self.pi_l.host_actions("vln") if hg is not None and self.pi_l is not None else None
+            if hl is not None and not return_outs:
+                torch.where(hq == 1, hl, hg, out=ah)
+                late_select = True
+            else:
+                actions = select_on_device()
+                ah.copy_(actions, non_blocking=True)
+                P._cur_stream().synchronize()
+        else:
+            actions = select_on_device()
         if self.belief is not None and not self._belief_async:   # beliefs of the NEW observation, written in place before it is stored
             self.belief.update(v["nxt"], v["dones"])
         if return_outs:                             # graph outputs are overwritten by the next replay
@@ -335,6 +353,8 @@ class Workload:
         if self._early_enc and self.launch_ahead:
             # the new observation exists: its towers start now and hide the storage bookkeeping + the next step's launch path
             self.pi_q.prefetch_encoders(v["nxt"], will_be={k: x[t + 1] for k, x in ro.observations.items()})
+        if late_select:
+            actions = select_on_device()
         dlg, astep = (self._cur_dialog, self._cur_astep) if self.dialog_process == "reference" else (v["dialog"], v["astep"])
         ro.insert(v["nxt"], o["h"], actions, a_opt, o["lp_q"], o["q_value"], v["rew"], v["nd"], v["nd"], o["row_g"], o["row_q"],
                   o["row_l"], o["row_d"], dlg, self.o_action, self.o_mask, v["rl"], v["ucnt"], o["l_prob"], v["qs"],

@@ -230,3 +230,35 @@ def test_encoders_started_before_insert_equal_the_plain_order():
     assert torch.equal(va, vb)
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+def test_actions_selected_on_the_host_equal_the_device_select():
+    """sampling="race": the step's actions for the simulator are selected on the host from the three policies' pinned copies
+    (`Policy.host_actions`); the device-side select feeds the storage later.  Both must be the device select of the plain order,
+    step by step, over a rollout, the wrap-around and beyond."""
+    import os
+    N, T = 4, 5
+    snaps = []
+    try:
+        for sel in ("1", "0"):
+            os.environ["AVLEN_HOST_SELECT"] = sel
+            wl = _run(N, T, precision="bf16x3")
+            assert wl._host_select == (sel == "1") and wl.sampling == "race"
+            host = []
+            for i in range(T + 2):
+                if i == T:
+                    wl.rollouts.after_update()
+                t = wl.rollouts.step
+                wl.rollout_step()
+                host.append(wl._act_host[t & 3].clone())
+                torch.cuda.synchronize()
+                assert torch.equal(host[-1], wl.rollouts.actions[t].cpu()), (sel, i)       # what the simulator got == what was stored
+            snaps.append((_storage_snapshot(wl), host))
+            del wl
+    finally:
+        os.environ.pop("AVLEN_HOST_SELECT", None)
+    (a, ha), (b, hb) = snaps
+    for x, y in zip(ha, hb):
+        assert torch.equal(x, y)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k

@@ -59,16 +59,24 @@ for it in range(STEPS):
     _, a_vln, _, _, row_vln, row_dlg, probs_vln = wl.pi_l.act_dialog(obs, h2, prev, v["masks_vln"], em_vln, em_dlg, v["em_vln_masks"],
                                                                      v["dialog"], v["astep"])
     hmark("act_l_done")
-    actions = torch.where(a_opt == 1, a_vln, a_goal)
-    mark("actions", cur)
-    if wl.sampling != "host":
-        ah = torch.empty(actions.shape, dtype=actions.dtype, pin_memory=True)
-        ah.copy_(actions, non_blocking=True)
-        cur.synchronize()
+    host_sel = wl._host_select and wl.sampling == "race"
+    if host_sel:                                      # the harness' default: select on the host from the policies' pinned copies
+        hq, hg, hl = wl.pi_q.host_actions("option"), wl.pi_g.host_actions("goal"), wl.pi_l.host_actions("vln")
+        ah = torch.where(hq == 1, hl, hg)
+        mark("actions", cur)
+    else:
+        actions = torch.where(a_opt == 1, a_vln, a_goal)
+        mark("actions", cur)
+        if wl.sampling != "host":
+            ah = torch.empty(actions.shape, dtype=actions.dtype, pin_memory=True)
+            ah.copy_(actions, non_blocking=True)
+            cur.synchronize()
     hmark("actions_on_host")
     if wl._early_enc:
         wl.pi_q.prefetch_encoders(v["nxt"], will_be={k: x[t + 1] for k, x in ro.observations.items()})
         hmark("next_towers_launched")
+    if host_sel:
+        actions = torch.where(a_opt == 1, a_vln, a_goal)
     ro.insert(v["nxt"], h2, actions, a_opt, lp_opt, values, v["rew"], v["nd"], v["nd"], row_goal, row_opt, row_vln, row_dlg,
               v["dialog"], wl.o_action, wl.o_mask, v["rl"], v["ucnt"], probs_vln, v["qs"], v["lqi"], v["astep"])
     mark("insert_end", cur); hmark("insert_done")
