@@ -194,6 +194,7 @@ SIGNATURES = {
     "avlen_heads_fwd": (i32, [C.POINTER(Heads), vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     "avlen_sample_race": (i32, [vp, vp, vp, i32, i32, vp]),
     "avlen_heads_act_fwd": (i32, [C.POINTER(Heads), vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "avlen_heads_act_host_fwd": (i32, [C.POINTER(Heads), vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     "avlen_ppo_loss_heads_bwd": (i32, [C.POINTER(Heads), C.POINTER(Heads), vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp,
                                        f32, f32, f32, f32, vp, vp, i32, vp]),
     "avlen_rl_mask_norm": (i32, [vp, i32, vp, vp]),

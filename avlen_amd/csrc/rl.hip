@@ -20,7 +20,8 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(avlen_heads h, const flo
                                                         float* __restrict__ value, float* __restrict__ unct,
                                                         const int64_t* __restrict__ actions, float* __restrict__ log_prob,
                                                         float* __restrict__ entropy, int B,
-                                                        const float* __restrict__ noise = nullptr, int64_t* __restrict__ action_out = nullptr) {
+                                                        const float* __restrict__ noise = nullptr, int64_t* __restrict__ action_out = nullptr,
+                                                        int64_t* __restrict__ action_host = nullptr) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= B) return;
@@ -85,6 +86,7 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(avlen_heads h, const flo
         }
       sampled = bi;
       action_out[row] = bi;
+      if (action_host) action_host[row] = bi;          // pinned host memory, mapped: the simulator's copy needs no second launch
     }
     if ((actions || sampled >= 0) && log_prob) {
       long a = sampled >= 0 ? sampled : actions[row];
@@ -378,13 +380,18 @@ extern "C" int avlen_heads_fwd(const avlen_heads* h, const float* feats, int d, 
 
 // avlen_heads_fwd with the sampling fused in: action_out[b] = the race's winner on `noise` (B x A, host-drawn Exp(1)), log_prob /
 // entropy of that action; everything else as avlen_heads_fwd.
+extern "C" int avlen_heads_act_host_fwd(const avlen_heads* h, const float* feats, int d, int A, float* logits, float* probs, float* value,
+                                        float* unct, const float* noise, int64_t* action_out, int64_t* action_host, float* log_prob,
+                                        float* entropy, int B, hipStream_t stream) {
+  if (!h || !noise || !action_out || B <= 0 || A > MAXA || d % 64) return AVLEN_ERR_ARG;
+  hipLaunchKernelGGL(heads_fwd_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, stream, *h, feats, d, A, logits, probs, value, unct,
+                     (const int64_t*)nullptr, log_prob, entropy, B, noise, action_out, action_host);
+  return avlen_launch_status();
+}
 extern "C" int avlen_heads_act_fwd(const avlen_heads* h, const float* feats, int d, int A, float* logits, float* probs, float* value,
                                    float* unct, const float* noise, int64_t* action_out, float* log_prob, float* entropy, int B,
                                    hipStream_t stream) {
-  if (!h || !noise || !action_out || B <= 0 || A > MAXA || d % 64) return AVLEN_ERR_ARG;
-  hipLaunchKernelGGL(heads_fwd_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, stream, *h, feats, d, A, logits, probs, value, unct,
-                     (const int64_t*)nullptr, log_prob, entropy, B, noise, action_out);
-  return avlen_launch_status();
+  return avlen_heads_act_host_fwd(h, feats, d, A, logits, probs, value, unct, noise, action_out, nullptr, log_prob, entropy, B, stream);
 }
 
 // CustomFixedCategorical.sample (common/utils.py:48-49 -> torch.multinomial, one draw per row) is the exponential race

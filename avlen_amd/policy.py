@@ -77,6 +77,7 @@ def _i64(t):
 
 
 _TOWERS_FIRST = os.environ.get("AVLEN_TOWERS_FIRST", "1") != "0"
+_MAPPED_ACTIONS = os.environ.get("AVLEN_MAPPED_ACTIONS", "1") != "0"     # heads kernel stores the sampled actions into mapped pinned memory
 _FOLD_TEXT = os.environ.get("AVLEN_FOLD_TEXT", "1") != "0"     # A/B knob: text_projection folded into dialog_layer in the rollout's text graph
 _SPLIT = True        # pi_l's captured forward is cut in two around the text embedding (decided by measurement: DESIGN section 3)
 
@@ -709,9 +710,15 @@ class Policy(nn.Module):
         if race:
             nz = self._noise_dev(which, B, A, dev)
             action, logp, ent = self._result_bufs(which, B, dev)
-            L.call("avlen_heads_act_fwd", C.byref(h), E.P(feats), d, A, E.P(logits), E.P(probs), E.P(value),
-                   E.P(unct) if unct is not None else None, E.P(nz), E.P(action), E.P(logp), E.P(ent), B, L.stream())
-            return {"logits": logits, "probs": probs, "value": value, "unct": unct, "raced": (action, logp, ent)}
+            # the simulator's / query loop's copy of the actions: the kernel stores it straight into mapped pinned memory (one
+            # persistent buffer per head set and batch: captured graphs hold its address; read it before the next forward)
+            ah = self._pinned.get(("act_mapped", which, B))
+            if ah is None and _MAPPED_ACTIONS:
+                ah = self._pinned[("act_mapped", which, B)] = torch.zeros(B, 1, dtype=torch.int64, pin_memory=True)
+            L.call("avlen_heads_act_host_fwd", C.byref(h), E.P(feats), d, A, E.P(logits), E.P(probs), E.P(value),
+                   E.P(unct) if unct is not None else None, E.P(nz), E.P(action), C.c_void_p(ah.data_ptr()) if ah is not None else None,
+                   E.P(logp), E.P(ent), B, L.stream())
+            return {"logits": logits, "probs": probs, "value": value, "unct": unct, "raced": (action, logp, ent), "action_host": ah}
         L.call("avlen_heads_fwd", C.byref(h), E.P(feats), d, A, E.P(logits), E.P(probs), E.P(value),
                E.P(unct) if unct is not None else None, None, None, None, B, L.stream())
         return {"logits": logits, "probs": probs, "value": value, "unct": unct}
@@ -750,8 +757,10 @@ class Policy(nn.Module):
                 # the forward's last kernel ran the race on the noise drawn for this call (_draw_noise, _heads_first): the reference's
                 # action for the same generator state; no probabilities cross PCIe, no host synchronisation
                 action, logp, ent = out["raced"]
-                ah = self._host_action(B)                # the actions start their way to the host right behind the forward (512 B)
-                ah.copy_(action, non_blocking=True)
+                ah = out.get("action_host")              # stored there by the heads kernel itself (mapped pinned memory) ...
+                if ah is None:
+                    ah = self._host_action(B)            # ... or copied right behind the forward (512 B)
+                    ah.copy_(action, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(_cur_stream())
                 self._act_host[which] = (ah, ev)

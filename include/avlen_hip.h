@@ -356,6 +356,12 @@ int avlen_heads_fwd(const avlen_heads* h, const float* feats, int d, int A, floa
 int avlen_heads_act_fwd(const avlen_heads* h, const float* feats, int d, int A, float* logits, float* probs, float* value,
                         float* unct, const float* noise, int64_t* action_out, float* log_prob, float* entropy, int B,
                         avlen_stream_t stream);
+/* ... and a second copy of the sampled actions stored straight into `action_host` (optional): PINNED host memory mapped into the
+ * device's address space (hipHostMalloc / torch pin_memory) -- what the trainer's query loop (ppo_trainer.py:463) and envs.step
+ * (:864) read, valid once the stream has passed the launch; no device-to-host copy launch. */
+int avlen_heads_act_host_fwd(const avlen_heads* h, const float* feats, int d, int A, float* logits, float* probs, float* value,
+                             float* unct, const float* noise, int64_t* action_out, int64_t* action_host, float* log_prob,
+                             float* entropy, int B, avlen_stream_t stream);
 /* CustomFixedCategorical.sample (common/utils.py:48-49; torch.multinomial's exponential race) with HOST-drawn noise: action[b] =
  * first argmax_a probs[b,a] / noise[b,a] (IEEE fp32 division) -- the reference's action for the same host generator state. */
 int avlen_sample_race(const float* probs, const float* noise, int64_t* action, int B, int A, avlen_stream_t stream);
