@@ -352,7 +352,7 @@ class Workload:
             o["actions"] = actions.clone()
         if self._early_enc and self.launch_ahead:
             # the new observation exists: its towers start now and hide the storage bookkeeping + the next step's launch path
-            self.pi_q.prefetch_encoders(v["nxt"], will_be={k: x[t + 1] for k, x in ro.observations.items()})
+            self.pi_q.prefetch_encoders(v["nxt"], will_be={k: ro.observations[k][t + 1] for k in ("rgb", "depth", P.SPECTROGRAM)})   # the three addresses it checks
         if late_select:
             actions = select_on_device()
         dlg, astep = (self._cur_dialog, self._cur_astep) if self.dialog_process == "reference" else (v["dialog"], v["astep"])

@@ -5,6 +5,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from avlen_amd.harness import Workload
+from avlen_amd import policy as P
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 proc = sys.argv[2] if len(sys.argv) > 2 else "fresh"
@@ -73,7 +74,7 @@ for it in range(STEPS):
             cur.synchronize()
     hmark("actions_on_host")
     if wl._early_enc:
-        wl.pi_q.prefetch_encoders(v["nxt"], will_be={k: x[t + 1] for k, x in ro.observations.items()})
+        wl.pi_q.prefetch_encoders(v["nxt"], will_be={k: ro.observations[k][t + 1] for k in ("rgb", "depth", P.SPECTROGRAM)})   # the three addresses it checks
         hmark("next_towers_launched")
     if host_sel:
         actions = torch.where(a_opt == 1, a_vln, a_goal)
