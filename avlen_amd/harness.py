@@ -121,6 +121,13 @@ class Workload:
         self._act_buf = None
         self._act_host = None
         self._host_select = sampling == "race" and os.environ.get("AVLEN_HOST_SELECT", "1") != "0"
+        self._small = self._small_ev = self._fwd_ev = None
+        self._small_pending = False
+        if self._side is not None and self._host_select and os.environ.get("AVLEN_SMALL_STREAM", "1") != "0" and \
+                dialog_tokens == "after_option":
+            # the side stream the after_option flow leaves idle (pi_g and pi_l share the other one, the text tower runs on the caller's)
+            self._small = self._side[1 - self._g_stream] if self._g_stream in (0, 1) and self._l_where != "own" else self._side[2]
+            self._small_ev, self._fwd_ev = torch.cuda.Event(), torch.cuda.Event()
         self.sampling = sampling
         if belief_predictor:        # use_belief_predictor: True in the interactive yamls (ppo_trainer.py:892); 65x26 spectrogram only
             import types
@@ -309,6 +316,7 @@ class Workload:
 
     def rollout_step(self, return_outs=False):
         ro, t = self.rollouts, self.rollouts.step
+        self._join_small()
         nv = self._next_views
         self._next_views = None
         v = nv[1] if nv is not None and nv[0] == t else self._step_views(t)
@@ -350,15 +358,32 @@ class Workload:
         if return_outs:                             # graph outputs are overwritten by the next replay
             o = {k: (x.clone() if torch.is_tensor(x) else x) for k, x in o.items()}
             o["actions"] = actions.clone()
+        small = self._small if (late_select and self._early_enc and self.launch_ahead and self.belief is None) else None
+        if small is not None:
+            self._fwd_ev.record(P._cur_stream())        # the three forwards of this step are complete behind this point
+        started = False
         if self._early_enc and self.launch_ahead:
             # the new observation exists: its towers start now and hide the storage bookkeeping + the next step's launch path
-            self.pi_q.prefetch_encoders(v["nxt"], will_be={k: ro.observations[k][t + 1] for k in ("rgb", "depth", P.SPECTROGRAM)})   # the three addresses it checks
-        if late_select:
-            actions = select_on_device()
+            started = self.pi_q.prefetch_encoders(v["nxt"], will_be={k: ro.observations[k][t + 1] for k in ("rgb", "depth", P.SPECTROGRAM)})   # the three addresses it checks
         dlg, astep = (self._cur_dialog, self._cur_astep) if self.dialog_process == "reference" else (v["dialog"], v["astep"])
-        ro.insert(v["nxt"], o["h"], actions, a_opt, o["lp_q"], o["q_value"], v["rew"], v["nd"], v["nd"], o["row_g"], o["row_q"],
-                  o["row_l"], o["row_d"], dlg, self.o_action, self.o_mask, v["rl"], v["ucnt"], o["l_prob"], v["qs"],
-                  v["lqi"], astep)
+
+        def store():
+            acts = select_on_device() if late_select else actions
+            ro.insert(v["nxt"], o["h"], acts, a_opt, o["lp_q"], o["q_value"], v["rew"], v["nd"], v["nd"], o["row_g"], o["row_q"],
+                      o["row_l"], o["row_d"], dlg, self.o_action, self.o_mask, v["rl"], v["ucnt"], o["l_prob"], v["qs"],
+                      v["lqi"], astep)
+        if small is not None and started:
+            # The step's storage writes (device-side action select + the two insert launches) go out on a side stream: enqueued on
+            # the main one they would run BEHIND the towers just launched, i.e. between the towers and pi_q's state encoder (~30 us of
+            # the next step's critical path); here they run as soon as the persistent tower launch frees a CU -- beside the
+            # towers' fc / the audio convs.  The next step's forwards wait for `_small_ev` (top of rollout_step / update).
+            small.wait_event(self._fwd_ev)
+            with torch.cuda.stream(small):
+                store()
+                self._small_ev.record(small)
+            self._small_pending = True
+        else:
+            store()
         if self.belief is not None and self._belief_async:
             # asynchronous form: the new observation is stored first, the two belief networks then write their beliefs into the
             # storage slot on their own stream while the next step's visual towers already run (which leave them a few CUs:
@@ -368,6 +393,12 @@ class Workload:
             self.pi_q.late_inputs(("location_belief", "category_belief"), ev)
         return o if return_outs else None
 
+    def _join_small(self):
+        """Order the current stream behind the previous step's storage writes (see `store` in rollout_step)."""
+        if self._small_pending:
+            P._cur_stream().wait_event(self._small_ev)
+            self._small_pending = False
+
     def finite(self):
         ro = self.rollouts
         return bool(torch.isfinite(ro.value_preds).all()) and bool(torch.isfinite(ro.em_vln_dialog.memory).all()) and \
@@ -376,6 +407,7 @@ class Workload:
     # -- _update_agent (ppo_trainer.py:1045-1093) -------------------------------------------------------------
     def update(self):
         ro, s = self.rollouts, self.rollouts.step
+        self._join_small()
         if self.belief is not None and self._belief_async and getattr(self.belief, "done", None) is not None:
             torch.cuda.current_stream().wait_event(self.belief.done)       # the last slot's beliefs
             self.pi_q.late_inputs((), None)

@@ -262,3 +262,37 @@ def test_actions_selected_on_the_host_equal_the_device_select():
         assert torch.equal(x, y)
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+def test_storage_writes_on_the_side_stream_equal_the_plain_order():
+    """The step's storage writes (device-side action select + insert) on a side stream beside the next step's towers against the
+    same writes on the caller's stream: same storage bit for bit over a rollout, the update's value call, the wrap-around."""
+    import os
+    N, T = 4, 5
+    snaps = []
+    try:
+        for side in ("1", "0"):
+            os.environ["AVLEN_SMALL_STREAM"] = side
+            wl = _run(N, T, precision="bf16x3")
+            assert (wl._small is not None) == (side == "1")
+            for _ in range(T):
+                wl.rollout_step()
+            assert wl._small_pending == (side == "1")
+            wl._join_small()
+            ro = wl.rollouts
+            last = {k: v[ro.step] for k, v in ro.observations.items()}
+            nv = wl.pi_q.get_value_option(last, ro.recurrent_hidden_states[ro.step], ro.prev_actions[ro.step], ro.masks[ro.step],
+                                          ro.external_memory_option[:, ro.step], ro.external_memory_masks[ro.step],
+                                          ro.query_state[ro.step - 1], ro.last_query_info[ro.step - 1]).clone()
+            ro.after_update()
+            for _ in range(3):
+                wl.rollout_step()
+            torch.cuda.synchronize()
+            snaps.append((_storage_snapshot(wl), nv))
+            del wl
+    finally:
+        os.environ.pop("AVLEN_SMALL_STREAM", None)
+    (a, va), (b, vb) = snaps
+    assert torch.equal(va, vb)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
