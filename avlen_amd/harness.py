@@ -64,7 +64,14 @@ class Workload:
         # dialog_tokens="after_option": the text tower cannot start before pi_q's action is known, so pi_l's state-encoder half should
         # NOT sit on the caller's stream between pi_q and the text tower: there pi_l gets its own stream (AVLEN_L_STREAM=main / side
         # = pi_g's / own)
-        self._l_where = os.environ.get("AVLEN_L_STREAM", "side" if dialog_tokens == "after_option" else "main")
+        # Which stream beside pi_g's: measured at the end of round 4 (alternating runs on one box, ms per cycle) -- a NEW dialog for every
+        # env every step (the text tower's 208 co-resident workgroups): own 306-309, shared 318-322: pi_g has to be out of the text
+        # tower's way, i.e. beside pi_q's state encoder; the trainer's dialog process (~17 new dialogs = 52 workgroups): own 303-304,
+        # shared 296-297: there pi_g fits beside the text tower and should not compete with pi_q's chain, which is the critical path
+        # (32 envs, 2nd stage, fresh: own 400, shared 386 -- the tower's ~104 workgroups leave room): own stream only when the text tower
+        # fills the chip
+        self._l_where = os.environ.get("AVLEN_L_STREAM", ("own" if dialog_process == "fresh" and num_envs >= 48 else "side")
+                                       if dialog_tokens == "after_option" else "main")
         self._l_main = self._l_where == "main"
         self._l_first = os.environ.get("AVLEN_L_FIRST", "1") != "0"              # A/B knob
         self._early_enc = os.environ.get("AVLEN_EARLY_ENC", "1") != "0" and use_graphs and share_encoders and \
