@@ -130,10 +130,12 @@ class Workload:
         self._host_select = sampling == "race" and os.environ.get("AVLEN_HOST_SELECT", "1") != "0"
         self._small = self._small_ev = self._fwd_ev = None
         self._small_pending = False
-        if self._side is not None and self._host_select and os.environ.get("AVLEN_SMALL_STREAM", "1") != "0" and \
-                dialog_tokens == "after_option":
-            # the side stream the after_option flow leaves idle (pi_g and pi_l share the other one, the text tower runs on the caller's)
-            self._small = self._side[1 - self._g_stream] if self._g_stream in (0, 1) and self._l_where != "own" else self._side[2]
+        if self._side is not None and self._host_select and dialog_tokens == "after_option" and self._g_stream in (0, 1) and \
+                os.environ.get("AVLEN_SMALL_STREAM", "0" if self._l_where == "own" else "1") != "0":
+            # the side stream the after_option flow leaves idle (pi_g and pi_l share the other one, the text tower runs on the caller's).
+            # With pi_l on its own stream there is none: a fifth busy stream shares one of the process's four hardware queues
+            # (measured: 302-305 ms per cycle with it, 296 without), so the writes stay on the caller's stream there.
+            self._small = self._side[1 - self._g_stream] if self._l_where != "own" else self._side[2]
             self._small_ev, self._fwd_ev = torch.cuda.Event(), torch.cuda.Event()
         self.sampling = sampling
         if belief_predictor:        # use_belief_predictor: True in the interactive yamls (ppo_trainer.py:892); 65x26 spectrogram only

@@ -296,3 +296,30 @@ def test_storage_writes_on_the_side_stream_equal_the_plain_order():
     assert torch.equal(va, vb)
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+def test_stream_placement_of_the_followers_does_not_change_the_storage():
+    """pi_l's state-encoder half on pi_g's stream ("side", the default below 48 envs) or on its own ("own", the default when the text
+    tower fills the chip): scheduling only -- the storage after a rollout, the wrap-around and three more steps is bit-equal."""
+    import os
+    N, T = 4, 5
+    snaps = []
+    try:
+        for where in ("side", "own"):
+            os.environ["AVLEN_L_STREAM"] = where
+            wl = _run(N, T, precision="bf16x3")
+            assert wl._l_where == where and (wl._small is None) == (where == "own")
+            for i in range(T + 3):
+                if i == T:
+                    wl._join_small()
+                    wl.rollouts.after_update()
+                wl.rollout_step()
+            wl._join_small()
+            torch.cuda.synchronize()
+            snaps.append(_storage_snapshot(wl))
+            del wl
+    finally:
+        os.environ.pop("AVLEN_L_STREAM", None)
+    a, b = snaps
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
