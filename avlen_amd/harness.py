@@ -70,7 +70,9 @@ class Workload:
         # shared 296-297: there pi_g fits beside the text tower and should not compete with pi_q's chain, which is the critical path
         # (32 envs, 2nd stage, fresh: own 400, shared 386 -- the tower's ~104 workgroups leave room): own stream only when the text tower
         # fills the chip
-        self._l_where = os.environ.get("AVLEN_L_STREAM", ("own" if dialog_process == "fresh" and num_envs >= 48 else "side")
+        # fills the chip -- and not with the belief predictor's launches on the caller's stream as well (own 423-425, shared 384-387)
+        self._l_where = os.environ.get("AVLEN_L_STREAM", ("own" if dialog_process == "fresh" and num_envs >= 48 and not belief_predictor
+                                                          else "side")
                                        if dialog_tokens == "after_option" else "main")
         self._l_main = self._l_where == "main"
         self._l_first = os.environ.get("AVLEN_L_FIRST", "1") != "0"              # A/B knob
