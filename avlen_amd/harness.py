@@ -64,18 +64,14 @@ class Workload:
         # dialog_tokens="after_option": the text tower cannot start before pi_q's action is known, so pi_l's state-encoder half should
         # NOT sit on the caller's stream between pi_q and the text tower: there pi_l gets its own stream (AVLEN_L_STREAM=main / side
         # = pi_g's / own)
-        # Which stream beside pi_g's: measured at the end of round 4 (alternating runs on one box, ms per cycle) -- a NEW dialog for every
-        # env every step (the text tower's 208 co-resident workgroups): own 306-309, shared 318-322: pi_g has to be out of the text
-        # tower's way, i.e. beside pi_q's state encoder; the trainer's dialog process (~17 new dialogs = 52 workgroups): own 303-304,
-        # shared 296-297: there pi_g fits beside the text tower and should not compete with pi_q's chain, which is the critical path
-        # (32 envs, 2nd stage, fresh: own 400, shared 386 -- the tower's ~104 workgroups leave room): own stream only when the text tower
-        # fills the chip
-        # fills the chip -- and not with the belief predictor's launches on the caller's stream as well (own 423-425, shared 384-387)
-        self._l_where = os.environ.get("AVLEN_L_STREAM", ("own" if dialog_process == "fresh" and num_envs >= 48 and not belief_predictor
-                                                          else "side")
-                                       if dialog_tokens == "after_option" else "main")
+        # Order on the shared side stream, measured at the end of round 4 (alternating runs on one box, ms per cycle): pi_g FIRST.  With
+        # pi_l's half first, pi_g ran beside the text tower -- with a new dialog for every env (208 co-resident workgroups) it crawled on the
+        # 48 CUs left and delayed the tower's start: 318-322 -> 302 (a stream of its own for pi_l does the same: 298-306, but is a fifth
+        # busy stream once the storage writes have theirs); the trainer's dialog process 296-299 -> 291; 2nd stage at 32 envs 386-390 ->
+        # 383-384; with the belief predictor 384-391 -> 373-378.  pi_l's half (0.14 ms) is still done long before the text tower.
+        self._l_where = os.environ.get("AVLEN_L_STREAM", "side" if dialog_tokens == "after_option" else "main")
         self._l_main = self._l_where == "main"
-        self._l_first = os.environ.get("AVLEN_L_FIRST", "1") != "0"              # A/B knob
+        self._l_first = os.environ.get("AVLEN_L_FIRST", "0") != "0"              # A/B knob
         self._early_enc = os.environ.get("AVLEN_EARLY_ENC", "1") != "0" and use_graphs and share_encoders and \
             precision in ("bf16", "bf16x3") and not belief_predictor                # A/B knob: Policy.prefetch_encoders before insert
         tpr = os.environ.get("AVLEN_TEXT_STREAM")                                # lab knob: "hi" / "own" = text tower on its own stream
@@ -135,8 +131,8 @@ class Workload:
         if self._side is not None and self._host_select and dialog_tokens == "after_option" and self._g_stream in (0, 1) and \
                 os.environ.get("AVLEN_SMALL_STREAM", "0" if self._l_where == "own" else "1") != "0":
             # the side stream the after_option flow leaves idle (pi_g and pi_l share the other one, the text tower runs on the caller's).
-            # With pi_l on its own stream there is none: a fifth busy stream shares one of the process's four hardware queues
-            # (measured: 302-305 ms per cycle with it, 296 without), so the writes stay on the caller's stream there.
+            # With pi_l on a stream of its own (lab knob) there is none: a fifth busy stream shares one of the process's four hardware
+            # queues (measured: 302-305 ms per cycle with it, 296 without), so the writes stay on the caller's stream there.
             self._small = self._side[1 - self._g_stream] if self._l_where != "own" else self._side[2]
             self._small_ev, self._fwd_ev = torch.cuda.Event(), torch.cuda.Event()
         self.sampling = sampling
@@ -290,9 +286,9 @@ class Workload:
                 self.pi_l.prefetch_act_dialog(obs, h, prev, v["masks_vln"], em_vln, em_dlg, v["em_vln_masks"], v["dialog"],
                                               v["astep"], stream=None if self._l_main else self._side[0 if self._l_where == "own" else self._g_stream],
                                               dialog_later=later)
-            # after_option: pi_l's state-encoder half goes out BEFORE pi_g on their shared stream -- the dialog half waits for it and
-            # for the text tower, pi_g only has to be done by the end of the step (host noise order unchanged: pi_l draws in
-            # dialog_ready, after pi_g's prefetch)
+            # after_option: pi_g goes out BEFORE pi_l's state-encoder half on their shared stream (see _l_where above: pi_g then runs
+            # beside pi_q's state encoder, not beside the text tower; AVLEN_L_FIRST=1 is the old order).  Host noise order unchanged
+            # either way: pi_l draws in dialog_ready, after pi_g's prefetch
             order = (launch_l, launch_g) if (later and self._l_first) else (launch_g, launch_l)
             for fn, pol in zip(order, (self.pi_l, self.pi_g) if order[0] is launch_l else (self.pi_g, self.pi_l)):
                 if pol is not None:
