@@ -130,6 +130,12 @@ __global__ __launch_bounds__(NTH) void chain_kernel(DevProg kprog, int B) {
   DevLin ldl = sp->lin[0];
   int issued = 0, consumed = 0;        // tiles issued / tiles whose data has been waited for
   int st_issue = 0, st_cons = 0;       // their ring stages (issued % NS, consumed % NS)
+  // Measured and rejected (end of round 4): a third tile in flight per wave through registers.  The X3 stream is bound by its 64 KiB
+  // in flight (256 KiB per step in 6.4 us = 19 B/clk) and LDS is full, so every third tile went by fragment-shaped 16-byte loads
+  // straight into registers -- held in C++ variables the compiler moved them (or parked them in scratch) while the load was in
+  // flight; held in the top accumulator registers a56 .. a63 from asm it was correct (131 parity tests) and SLOWER: 83 -> 96 us per
+  // launch.  Vector-memory results return in order, and the 64-byte-row fragment loads (13 B/clk on their own) hold back the DMA
+  // tiles queued behind them.
   // Each wave streams ONLY the 16 weight rows it multiplies (2 KiB per 64-wide k block = two 1 KiB pieces) into a private
   // 3-stage ring, so the weight stream needs no workgroup barrier at all: the issuing wave's own counted vmcnt orders its
   // ds_reads behind its LDS-DMA, and the waves drift freely inside a step.
