@@ -122,6 +122,10 @@ class Workload:
         self.rollouts = RolloutStorage(T, N, osp, asp, 512, True, ems, em_capacity, ems, em_capacity, 3, 3, dg, 276,
                                        self.pi_q.net.memory_dim, 256, num_recurrent_layers=-1, max_dialog_len=77, use_state_memory=True,
                                        device=self.dev)
+        if share_encoders and not launch_ahead and use_graphs and not belief_predictor and precision in ("bf16", "bf16x3") and \
+                self.pi_g is not None and self.pi_l is not None and os.environ.get("AVLEN_INSERT_HOOK", "1") != "0":
+            # the one-line integration (`share_only`): share_encoders(pi_q, pi_g, pi_l, rollouts=rollouts)
+            self.rollouts.attach_encoders(self.pi_q)
         self.belief = None
         self._act_buf = None
         self._act_host = None

@@ -552,11 +552,17 @@ class EncoderGroup:
         return bufs[0]
 
 
-def share_encoders(leader, *followers):
-    """Opt-in cross-policy tower batching (see EncoderGroup).  All members must use the same fast precision ("bf16" / "bf16x3")."""
+def share_encoders(leader, *followers, rollouts=None):
+    """Opt-in cross-policy tower batching (see EncoderGroup).  All members must use the same fast precision ("bf16" / "bf16x3").
+    `rollouts` (optional, the trainer's RolloutStorage): `rollouts.insert(batch, ...)` then starts the NEXT step's shared encoders on
+    `batch` before it copies anything (Policy.prefetch_encoders, validated by address at the next act_option as always) -- the
+    towers hide the storage bookkeeping and the next step's launch path without another line in the trainer."""
     assert leader.precision in ("bf16", "bf16x3") and all(m.precision == leader.precision for m in followers), \
         "encoder sharing runs on the grouped fast paths (bf16 / bf16x3), one precision for all members"
-    return EncoderGroup(leader, followers)
+    grp = EncoderGroup(leader, followers)
+    if rollouts is not None:
+        rollouts.attach_encoders(leader)
+    return grp
 
 
 class _Dist:

@@ -196,12 +196,23 @@ class RolloutStorage:
         self._src_plans = {}
 
     # ---------------------------------------------------------------- insert (rollout_storage.py:214-297)
+    _enc_leader = None
+
+    def attach_encoders(self, leader):
+        """See policy.share_encoders(..., rollouts=): `insert` starts the leader's shared encoders for the batch it is given."""
+        self._enc_leader = leader
+
     def insert(self, observations, recurrent_hidden_states, actions, actions_option, action_log_probs, value_preds,
                rewards, not_done_masks, not_done_masks_vln, em_features, em_features_option, em_features_vln,
                em_features_dialog, all_dialog, o_action, o_mask, rl_masks, ucnt_gt, action_prob, query_state,
                last_query_info, agent_step):
         s = self.step
         dev = self.device
+        lead = self._enc_leader
+        if lead is not None and lead._enc_early is None and "rgb" in self.observations:
+            # share_encoders(..., rollouts=self): the next act_option will read this batch out of slot s + 1 -- its towers start now
+            lead.prefetch_encoders(observations, will_be={k: self.observations[k][s + 1] for k in ("rgb", "depth", "spectrogram")
+                                                          if k in self.observations})
         # All of the step's storage writes go out as ONE batched copy launch.  The destination side (views, pointers,
         # byte counts) depends only on the step index and is planned once per step slot; a source that is already a
         # contiguous device tensor of the right dtype and size is passed by pointer, anything else (host values, dtype

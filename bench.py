@@ -383,7 +383,7 @@ def integration_records(a, H, W):
                    "dictates; text_ahead_synthetic = the round-3 ordering: the step's tokens are known before act_option and the "
                    "text tower is launched beside the visual towers (NOT obtainable from the reference trainer, "
                    "ppo_trainer.py:449-593); cached_views = the round-1 harness (view objects kept per step "
-                   "slot); share_only = the imports + ONE share_encoders(pi_q, pi_g, pi_l) call where the trainer builds the policies, "
+                   "slot); share_only = the imports + ONE share_encoders(pi_q, pi_g, pi_l, rollouts=rollouts) call where the trainer builds the policies, "
                    "no per-step prefetch_* calls; imports_only = the three-import-lines integration: no share_encoders, no "
                    "prefetch_* calls")
     return out

@@ -323,3 +323,37 @@ def test_stream_placement_of_the_followers_does_not_change_the_storage():
     a, b = snaps
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+def test_one_line_integration_with_the_storage_hook_equals_without():
+    """`share_encoders(pi_q, pi_g, pi_l, rollouts=rollouts)`: `rollouts.insert(batch, ...)` starts the next step's shared encoders on
+    the batch it is given.  Plain act* calls, no prefetch_* anywhere: same storage bit for bit as without the hook over a rollout,
+    the update's value call, the wrap-around."""
+    import os
+    N, T = 4, 5
+    snaps = []
+    try:
+        for hook in ("1", "0"):
+            os.environ["AVLEN_INSERT_HOOK"] = hook
+            wl = _run(N, T, precision="bf16x3", launch_ahead=False)
+            assert (wl.rollouts._enc_leader is not None) == (hook == "1")
+            for _ in range(T):
+                wl.rollout_step()
+            ro = wl.rollouts
+            assert (wl.pi_q._enc_early is not None) == (hook == "1")             # the last insert started slot T's encoders
+            last = {k: v[ro.step] for k, v in ro.observations.items()}
+            nv = wl.pi_q.get_value_option(last, ro.recurrent_hidden_states[ro.step], ro.prev_actions[ro.step], ro.masks[ro.step],
+                                          ro.external_memory_option[:, ro.step], ro.external_memory_masks[ro.step],
+                                          ro.query_state[ro.step - 1], ro.last_query_info[ro.step - 1]).clone()
+            ro.after_update()
+            for _ in range(3):
+                wl.rollout_step()
+            torch.cuda.synchronize()
+            snaps.append((_storage_snapshot(wl), nv))
+            del wl
+    finally:
+        os.environ.pop("AVLEN_INSERT_HOOK", None)
+    (a, va), (b, vb) = snaps
+    assert torch.equal(va, vb)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
