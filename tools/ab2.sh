@@ -1,4 +1,5 @@
 #!/bin/bash
+# A/B harness for scheduling knobs: alternating bench.py runs under different environments (run it on the GPU box via gpurun).
 # usage: ab2.sh "ENV1=a ENV2=b" "ENV1=c" ... -- [bench args]   (alternating runs, prints ms per cycle)
 cfgs=(); while [ "$1" != "--" ] && [ $# -gt 0 ]; do cfgs+=("$1"); shift; done; shift
 for r in 1 2; do for c in "${cfgs[@]}"; do
