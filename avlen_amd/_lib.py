@@ -114,6 +114,13 @@ class ExtMemOp(C.Structure):
                 ("capacity", C.c_int), ("N", C.c_int), ("dim", C.c_int)]
 
 
+class Cmd(C.Structure):
+    """avlen_cmd (csrc/sequencer.hip): one stream operation of a recorded launch sequence."""
+    _fields_ = [("op", C.c_int), ("n", C.c_int), ("a", C.c_void_p), ("b", C.c_void_p), ("c", C.c_void_p), ("d", C.c_void_p)]
+
+
+CMD_GRAPH, CMD_RECORD, CMD_WAIT, CMD_MULTICOPY = 1, 2, 3, 4
+
 i32, f32, sz = C.c_int, C.c_float, C.c_size_t
 
 # name -> (restype, argtypes); every symbol declared in include/avlen_hip.h
@@ -223,6 +230,7 @@ SIGNATURES = {
     "avlen_copy_rows": (i32, [vp, i32, vp, i32, i32, i32, vp]),
     "avlen_gather_rows": (i32, [vp, i32, vp, vp, i32, i32, i32, vp]),
     "avlen_multi_copy": (i32, [vp, vp, vp, i32, vp]),
+    "avlen_cmds_run": (i32, [vp, i32]),
     "avlen_ln_fold_weights": (i32, [vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, vp]),
     "avlen_ln_fold_weights_h16": (i32, [vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, vp]),
     "avlen_build_info": (C.c_char_p, []),

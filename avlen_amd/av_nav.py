@@ -118,7 +118,8 @@ class PPO(nn.Module):
         self.optimizer = torch.optim.Adam(actor_critic.parameters(), lr=lr, eps=eps)
         self.device = next(actor_critic.parameters()).device
         self.use_normalized_advantage = use_normalized_advantage
-        self._adam = None
+        from .engine import FlatAdam                     # optimizer.state = views into the flat moments (checkpoint round trip)
+        self._adam = FlatAdam(self.optimizer, actor_critic, with_norm=True)
         self._distributed = False
 
     def forward(self, *x):
@@ -146,11 +147,7 @@ class PPO(nn.Module):
         pass
 
     def _adam_state(self, flat):
-        if self._adam is None or self._adam["m"].numel() != flat.n_trained or self._adam["m"].device != flat.flat.device:
-            dev = flat.flat.device
-            self._adam = {"m": torch.zeros(flat.n_trained, device=dev), "v": torch.zeros(flat.n_trained, device=dev),
-                          "step": 0, "norm_sq": torch.zeros(1, dtype=torch.float64, device=dev)}
-        return self._adam
+        return self._adam.state(flat)
 
     def _minibatch_step(self, sample, loss_row):
         flat = self._forward_backward(sample, loss_row)
@@ -182,12 +179,12 @@ class PPO(nn.Module):
         pol, st = self.actor_critic, L.stream()
         self.reduce_gradients(flat)
         ad = self._adam_state(flat)
-        ad["step"] += 1
-        ad["norm_sq"].zero_()
+        step = ad.advance()
+        ad.norm_sq.zero_()
         lr, eps = self.optimizer.param_groups[0]["lr"], self.optimizer.param_groups[0]["eps"]
-        L.call("avlen_grad_sumsq", P(flat.grad), flat.n_trained, P(ad["norm_sq"]), st)
-        L.call("avlen_adam_step", P(flat.flat), P(flat.grad), P(ad["m"]), P(ad["v"]), flat.n_trained, float(lr), 0.9, 0.999,
-               float(eps), ad["step"], float(self.max_grad_norm), P(ad["norm_sq"]), st)
+        L.call("avlen_grad_sumsq", P(flat.grad), flat.n_trained, P(ad.norm_sq), st)
+        L.call("avlen_adam_step", P(flat.flat), P(flat.grad), P(ad.m), P(ad.v), flat.n_trained, float(lr), 0.9, 0.999,
+               float(eps), step, float(self.max_grad_norm), P(ad.norm_sq), st)
         pol.mark_params_changed()                        # conv / fc weights moved: packed copies + bf16 shadows are stale
         pol._engine()
 

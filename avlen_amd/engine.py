@@ -83,6 +83,77 @@ class FlatParams:
         return self.grad.data_ptr() + 4 * o
 
 
+class FlatAdam:
+    """Adam's moments for the trained range of a FlatParams: two flat fp32 buffers the HIP optimiser step walks in one launch,
+    exposed through the torch optimiser object the trainer checkpoints.
+
+    The reference saves and restores `agent.optimizer.state_dict()` (ddppo_trainer.py:812-817, 857-862; ppo_trainer.py:1184-1187,
+    1224).  `optimizer.state[p]` of every trained parameter therefore holds torch.optim.Adam's own keys -- `step`, `exp_avg`,
+    `exp_avg_sq` -- as VIEWS into the flat buffers (the parameters themselves are views into FlatParams.flat the same way), so
+    `state_dict()` sees the live moments, and a `load_state_dict()` (which replaces the entries by copies of the checkpoint's
+    tensors) is folded back into the flat buffers by a post-hook, or at the next optimiser step if the policy had no engine yet.
+    As in the reference, parameters the loss never reaches have no entry, and the state is empty before the first step."""
+
+    def __init__(self, optimizer, module, with_norm=False):
+        self.optimizer, self.module, self.with_norm = optimizer, module, with_norm
+        self.m = self.v = self.norm_sq = None
+        self.step = 0
+        self._step_t = torch.zeros((), dtype=torch.float32)      # ONE host scalar shared by every entry (torch keeps `step` on the host)
+        self._flat = None
+        optimizer.register_load_state_dict_post_hook(self._loaded)
+
+    def _loaded(self, optimizer):
+        eng = getattr(self.module, "_eng", None)
+        if eng is not None and eng["flat"].flat.is_cuda:
+            self.state(eng["flat"], adopt=True)
+        else:
+            self._flat = None                                    # adopted by the first state() call
+
+    def state(self, flat, adopt=False):
+        """The moments for `flat` (allocated on first use / when the policy moved); entries the optimiser holds that are not views
+        into them (a loaded checkpoint) are copied in first."""
+        fresh = self.m is None or self.m.numel() != flat.n_trained or self.m.device != flat.flat.device
+        if fresh:
+            dev = flat.flat.device
+            self.m, self.v = torch.zeros(flat.n_trained, device=dev), torch.zeros(flat.n_trained, device=dev)
+            if self.with_norm:
+                self.norm_sq = torch.zeros(1, dtype=torch.float64, device=dev)
+        if fresh or adopt or self._flat is not flat:
+            self._bind(flat)
+        return self
+
+    def _bind(self, flat):
+        name_of = {id(p): n for n, p in self.module.named_parameters()}
+        trained = set(flat.trained_names)
+        lo, hi = self.m.data_ptr(), self.m.data_ptr() + 4 * self.m.numel()
+        loaded_step = None
+        st_all = self.optimizer.state
+        for group in self.optimizer.param_groups:
+            for p in group["params"]:
+                n = name_of.get(id(p))
+                if n not in trained:
+                    continue
+                o, k = flat.offsets[n]
+                st = st_all.get(p)
+                if st and "exp_avg" in st and not (lo <= st["exp_avg"].data_ptr() < hi and st["exp_avg"].is_cuda):
+                    with torch.no_grad():
+                        self.m[o:o + k].copy_(st["exp_avg"].reshape(-1))
+                        self.v[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
+                    s = int(float(st["step"]))
+                    loaded_step = s if loaded_step is None else max(loaded_step, s)
+                st_all[p] = {"step": self._step_t, "exp_avg": self.m[o:o + k].view(p.shape),
+                             "exp_avg_sq": self.v[o:o + k].view(p.shape)}
+        if loaded_step is not None:
+            self.step = loaded_step
+        self._step_t.fill_(self.step)
+        self._flat = flat
+
+    def advance(self):
+        self.step += 1
+        self._step_t.fill_(self.step)
+        return self.step
+
+
 class Workspaces:
     def __init__(self):
         self._bufs = {}

@@ -8,7 +8,7 @@ binaural spectrogram, pose, beliefs, 77-token dialog; everything is generated on
 HBM before timing starts ("simulator output").
 """
 import math
-import os
+import time
 import torch
 
 from . import policy as P
@@ -31,15 +31,14 @@ class Workload:
                  em_capacity=150, ppo_epoch=2, num_mini_batch=2, device="cuda", seed=0, sampling="race",
                  with_dialog_policy=True, with_goal_policy=True, use_graphs=True, share_encoders=True, weight_seed=0,
                  launch_ahead=True, belief_predictor=False, cached_views=False, distractor=False,
-                 dialog_tokens="after_option", dialog_process="fresh"):
+                 dialog_tokens="after_option", dialog_process="fresh", belief_async=False):
         self.N, self.T, self.dev = num_envs, num_steps, torch.device(device)
         self.spec = spectrogram
-        sampling = os.environ.get("AVLEN_SAMPLING", sampling)          # A/B knob
         # WHEN the step's dialog tokens exist.  "after_option" (default) = the reference's data flow: `current_dialog` and
         # `agent_step` are written by the host loop that follows `act_option` (new query -> Speaker -> clip.tokenize,
-        # ppo_trainer.py:347, 449-593), so the text tower and the dialog half of pi_l are issued only after pi_q's action has been
-        # sampled; pi_g and pi_l's state-encoder half stay ahead.  "ahead" = the tokens are known at the start of the step (text
-        # tower launched beside the visual towers): a synthetic ordering the reference trainer cannot provide.
+        # ppo_trainer.py:347, 449-593), so the host WAITS for pi_q's sampled actions, and the text tower and the dialog half of pi_l
+        # are issued only then; pi_g and pi_l's state-encoder half stay ahead.  "ahead" = the tokens are known at the start of the step
+        # (text tower launched beside the visual towers): a synthetic ordering the reference trainer cannot provide.
         assert dialog_tokens in ("after_option", "ahead") and dialog_process in ("fresh", "reference")
         self.dialog_tokens = dialog_tokens
         # WHAT the tokens are.  "fresh": every env presents a new random dialog every step (SURVEY 8d's synthetic input; the memo of
@@ -48,45 +47,23 @@ class Workload:
         # env presents all-zero tokens (ppo_trainer.py:347, 463-469, 582-587, 763-765).  Needs the tokens after act_option.
         self.dialog_process = dialog_process
         assert dialog_process == "fresh" or dialog_tokens == "after_option"
-        # enqueue all three policies' forwards before the first host-side sampling; pi_g and pi_l run on their own streams,
-        # overlap on the GPU and hand their probabilities to the host as each finishes (3.13 -> 2.73 ms per step)
+        # launch_ahead: all three policies' forwards are enqueued before the first host-side wait (the two / three extra calls a trainer
+        # adds per step): pi_q on the caller's stream, pi_g and pi_l's state-encoder half on ONE side stream, pi_g first
+        # (with pi_l's half first, pi_g ran beside the text tower and crawled on the CUs it left: 318-322 -> 302 ms per cycle, round 4),
+        # the text tower on the caller's stream behind pi_q.  Four busy streams is the limit of the process's four hardware queues.
         self.launch_ahead = launch_ahead
         # The reference trainer slices fresh views of the storage every step (ppo_trainer.py:375-391): so does this driver, unless
         # `cached_views` keeps the view objects per step slot (saves the host ~30 tensor-indexing calls per step).
         self.cached_views = cached_views
         self.distractor = distractor
-        self.text_ahead = os.environ.get("AVLEN_TEXT_AHEAD", "1") != "0"      # A/B knob
-        self._g_stream = int(os.environ.get("AVLEN_G_STREAM", "1"))
-        # pi_l runs BEHIND pi_q on the current stream (AVLEN_L_STREAM=side: on _side[1], which it shared with pi_g): on the shared
-        # stream the first half of its graph (its state encoder, 0.16 ms, needs the towers only) queued behind all of pi_g (0.6 ms)
-        # and so ran after the text tower it should have overlapped; behind pi_q it starts at 0.68 ms and only the dialog half is
-        # left when the text embedding arrives: 30.3 k -> 33.2 k env-steps/s (kernel trace of a step: DESIGN section 0)
-        # dialog_tokens="after_option": the text tower cannot start before pi_q's action is known, so pi_l's state-encoder half should
-        # NOT sit on the caller's stream between pi_q and the text tower: there pi_l gets its own stream (AVLEN_L_STREAM=main / side
-        # = pi_g's / own)
-        # Order on the shared side stream, measured at the end of round 4 (alternating runs on one box, ms per cycle): pi_g FIRST.  With
-        # pi_l's half first, pi_g ran beside the text tower -- with a new dialog for every env (208 co-resident workgroups) it crawled on the
-        # 48 CUs left and delayed the tower's start: 318-322 -> 302 (a stream of its own for pi_l does the same: 298-306, but is a fifth
-        # busy stream once the storage writes have theirs); the trainer's dialog process 296-299 -> 291; 2nd stage at 32 envs 386-390 ->
-        # 383-384; with the belief predictor 384-391 -> 373-378.  pi_l's half (0.14 ms) is still done long before the text tower.
-        self._l_where = os.environ.get("AVLEN_L_STREAM", "side" if dialog_tokens == "after_option" else "main")
-        self._l_main = self._l_where == "main"
-        self._l_first = os.environ.get("AVLEN_L_FIRST", "0") != "0"              # A/B knob
-        self._early_enc = os.environ.get("AVLEN_EARLY_ENC", "1") != "0" and use_graphs and share_encoders and \
-            precision in ("bf16", "bf16x3") and not belief_predictor                # A/B knob: Policy.prefetch_encoders before insert
-        tpr = os.environ.get("AVLEN_TEXT_STREAM")                                # lab knob: "hi" / "own" = text tower on its own stream
-        self._text_stream = None if tpr is None else P.process_stream("harness_text_own", -1 if tpr == "hi" else 0)
-        self._views_ahead = os.environ.get("AVLEN_VIEWS_AHEAD", "1") != "0"       # A/B knob
+        # Policy.prefetch_encoders on the new observation before `insert` copies it (the towers hide the storage bookkeeping)
+        self._early_enc = use_graphs and share_encoders and precision in ("bf16", "bf16x3") and not belief_predictor
         self._next_views = None
-        self._text_after = os.environ.get("AVLEN_TEXT_AHEAD", "1") == "2"     # 2: ordered after the current stream (debug)
-        # 1: launch it BEFORE pi_q's graph -- measured slower (22.8k vs 27.5k env-steps/s): the GEMM blocks that get the CUs first
-        # squeeze the towers; launched second, the text tower fills the gaps the memory-bound tower kernels leave
-        self._text_first = os.environ.get("AVLEN_TEXT_FIRST", "0") != "0"
-        tp = int(os.environ.get("AVLEN_TEXT_PRIORITY", "0"))            # lab knob: stream priority of the text tower's stream
+        self.trace = None                               # tools/step_timeline.py: a list collects (mark, host time) pairs of every step
         # ONE set of side streams per process (policy.process_stream): the runtime maps streams to its 4 hardware queues in creation
         # order, so a second Workload with fresh streams can land pi_g's stream on the text tower's queue (seen as records of one
         # bench run that differ by 10 % for no other reason) -- and torch's stream pool wraps around after 32 creations
-        self._side = [P.process_stream("harness0"), P.process_stream("harness1"), P.process_stream("harness_text", tp)] \
+        self._side = [P.process_stream("harness0"), P.process_stream("harness1"), P.process_stream("harness_text")] \
             if launch_ahead else None
         osp, asp = savi_observation_space(spectrogram), ActionSpace(4)
         torch.manual_seed(weight_seed)          # identical initial weights on every rank (data-parallel replicas)
@@ -99,19 +76,13 @@ class Workload:
                      if with_goal_policy else None)
         self.pi_l = (P.AudioNavDialogPolicy(osp, asp, pretraining=False, use_category_input=distractor, num_steps=3,
                                             **kw).to(self.dev) if with_dialog_policy else None)
+        self.seq = None
         if share_encoders and precision in ("bf16", "bf16x3") and self.pi_g is not None and self.pi_l is not None:
             P.share_encoders(self.pi_q, self.pi_g, self.pi_l)
-        # bf16x3: the tower group is ONE persistent launch holding a CU per workgroup, so the text tower launched ahead on its own
-        # stream starts when the towers end.  Reserving CUs (avlen_set_tower_x3_reserved_cus) was measured: 64 reserved CUs bring the
-        # synchronised step from 1.97 to 1.87 ms but the free-running cycle only from 354 to ~348 ms (towers 0.50 -> 0.62 ms, and
-        # the update's tower calls slow down with it) -- inside the noise, so the default stays 0; AVLEN_TOWER_RESERVE=n re-measures.
-        if os.environ.get("AVLEN_CLIP_SPLIT4_WGS") is not None:           # lab knob (see avlen_set_clip_tower_split4_wgs)
-            from . import _lib as L
-            L.lib.avlen_set_clip_tower_split4_wgs(int(os.environ["AVLEN_CLIP_SPLIT4_WGS"]))
-        reserve = int(os.environ.get("AVLEN_TOWER_RESERVE", "0"))
-        if reserve:
-            from . import _lib as L
-            L.lib.avlen_set_tower_x3_reserved_cus(reserve)
+            if launch_ahead and use_graphs and sampling == "race" and dialog_tokens == "after_option":
+                # the step's launch-ahead calls as recorded command lists (one C call per phase): avlen_amd/sequencer.py
+                from .sequencer import StepSequencer
+                self.seq = StepSequencer(self.pi_q, self.pi_g, self.pi_l, self._side[1])
         self.agent = DDPPO(self.pi_q, clip_param=0.2, ppo_epoch=ppo_epoch, num_mini_batch=num_mini_batch,
                            value_loss_coef=0.5, entropy_coef=0.05, lr=2.5e-4, eps=1e-5, max_grad_norm=0.2,
                            use_normalized_advantage=False)
@@ -123,21 +94,19 @@ class Workload:
                                        self.pi_q.net.memory_dim, 256, num_recurrent_layers=-1, max_dialog_len=77, use_state_memory=True,
                                        device=self.dev)
         if share_encoders and not launch_ahead and use_graphs and not belief_predictor and precision in ("bf16", "bf16x3") and \
-                self.pi_g is not None and self.pi_l is not None and os.environ.get("AVLEN_INSERT_HOOK", "1") != "0":
+                self.pi_g is not None and self.pi_l is not None:
             # the one-line integration (`share_only`): share_encoders(pi_q, pi_g, pi_l, rollouts=rollouts)
             self.rollouts.attach_encoders(self.pi_q)
         self.belief = None
         self._act_buf = None
         self._act_host = None
-        self._host_select = sampling == "race" and os.environ.get("AVLEN_HOST_SELECT", "1") != "0"
+        self._host_select = sampling == "race"
         self._small = self._small_ev = self._fwd_ev = None
         self._small_pending = False
-        if self._side is not None and self._host_select and dialog_tokens == "after_option" and self._g_stream in (0, 1) and \
-                os.environ.get("AVLEN_SMALL_STREAM", "0" if self._l_where == "own" else "1") != "0":
-            # the side stream the after_option flow leaves idle (pi_g and pi_l share the other one, the text tower runs on the caller's).
-            # With pi_l on a stream of its own (lab knob) there is none: a fifth busy stream shares one of the process's four hardware
-            # queues (measured: 302-305 ms per cycle with it, 296 without), so the writes stay on the caller's stream there.
-            self._small = self._side[1 - self._g_stream] if self._l_where != "own" else self._side[2]
+        if self._side is not None and self._host_select and dialog_tokens == "after_option":
+            # the side stream the after_option flow leaves idle (pi_g and pi_l share the other one, the text tower runs on the
+            # caller's): the step's storage writes go there
+            self._small = self._side[0]
             self._small_ev, self._fwd_ev = torch.cuda.Event(), torch.cuda.Event()
         self.sampling = sampling
         if belief_predictor:        # use_belief_predictor: True in the interactive yamls (ppo_trainer.py:892); 65x26 spectrogram only
@@ -147,15 +116,16 @@ class Workload:
                                          current_pred_only=False, weighting_factor=0.5)
             self.belief = BeliefPredictor(bcfg, self.dev, None, None, 512, num_env=num_envs, precision=precision,
                                           load_pretrained=False, use_graphs=use_graphs).to(self.dev)
+        # belief_async: the two belief networks write their beliefs into the storage slot on their own stream while the next step's
+        # visual towers already run (Policy.late_inputs).  Measured (65x26, 64 envs, bf16x3): 24.9 k env-steps/s asynchronous vs 24.8 k
+        # synchronous -- the two ResNet-18s are ~85 chip-wide launches of 5-12 us; on the CUs the persistent tower launch can spare
+        # they run 4-8x longer, so the 0.6 ms they cost barely hides.  Off by default.
         self._belief_async = self.belief is not None and use_graphs and launch_ahead and share_encoders and precision == "bf16x3" \
-            and os.environ.get("AVLEN_BELIEF_ASYNC", "0") != "0"
-        # Measured (65x26, 64 envs, bf16x3): 24.9 k env-steps/s asynchronous vs 24.8 k synchronous at 4 hardware queues, 25.6 k vs 24.7 k
-        # at 8 -- the two belief ResNet-18s are ~85 chip-wide launches of 5-12 us; on the 16-64 CUs the persistent tower launch can
-        # spare they run 4-8x longer, so the 0.6 ms they cost barely hides.  Off by default (AVLEN_BELIEF_ASYNC=1 enables).
+            and belief_async
         if self._belief_async:
             self._belief_stream = P.process_stream("belief_async")
             from . import _lib as L
-            L.lib.avlen_set_tower_x3_reserved_cus(int(os.environ.get("AVLEN_BELIEF_CUS", "32")))
+            L.lib.avlen_set_tower_x3_reserved_cus(32)
         self._make_simulator_output(seed)
 
     # -- what the CPU simulator + trainer bookkeeping would have produced, resident in HBM ------------------
@@ -273,49 +243,58 @@ class Workload:
         ref = self.dialog_process == "reference"
         if ref:                                          # the tensors the host loop fills after act_option
             v = dict(v, dialog=self._cur_dialog, astep=self._cur_astep)
-        if self.launch_ahead:
-            ahead = self.pi_l is not None and self.text_ahead and not later
-            if ahead and self._text_first:
-                # the text tower needs only the tokens: it runs beside pi_q's graph (the towers) instead of after it
-                self.pi_l.prefetch_text(v["dialog"], self._side[2], after_current=self._text_after)
-            self.pi_q.prefetch_act_option(obs, h, prev, v["masks"], em_opt, em_masks, v["qs"], v["lqi"])
-            if ahead and not self._text_first:
-                self.pi_l.prefetch_text(v["dialog"], self._side[2], after_current=self._text_after)
-            def launch_g():
-                # pi_g shares pi_l's stream: both wait for pi_q's towers anyway, and a fourth busy stream ends up sharing a
-                # hardware queue with the text tower (pi_g then finished only after it)
-                self.pi_g.prefetch_act(obs, h, prev, v["masks"], em_goal, em_masks, stream=self._side[self._g_stream])
-
-            def launch_l():
-                self.pi_l.prefetch_act_dialog(obs, h, prev, v["masks_vln"], em_vln, em_dlg, v["em_vln_masks"], v["dialog"],
-                                              v["astep"], stream=None if self._l_main else self._side[0 if self._l_where == "own" else self._g_stream],
-                                              dialog_later=later)
-            # after_option: pi_g goes out BEFORE pi_l's state-encoder half on their shared stream (see _l_where above: pi_g then runs
-            # beside pi_q's state encoder, not beside the text tower; AVLEN_L_FIRST=1 is the old order).  Host noise order unchanged
-            # either way: pi_l draws in dialog_ready, after pi_g's prefetch
-            order = (launch_l, launch_g) if (later and self._l_first) else (launch_g, launch_l)
-            for fn, pol in zip(order, (self.pi_l, self.pi_g) if order[0] is launch_l else (self.pi_g, self.pi_l)):
-                if pol is not None:
-                    fn()
-        if self.launch_ahead and self._views_ahead and t + 1 < self.T:
-            # the host is about to wait for pi_q's probabilities: slice the NEXT step's views now (fresh tensor objects every step,
-            # as the trainer makes them; only the moment moves off the path between insert and the next forward's launch)
+        q_args = (obs, h, prev, v["masks"], em_opt, em_masks, v["qs"], v["lqi"])
+        g_args = (obs, h, prev, v["masks"], em_goal, em_masks)
+        l_args = (obs, h, prev, v["masks_vln"], em_vln, em_dlg, v["em_vln_masks"], v["dialog"], v["astep"])
+        seq = self.seq if (self.launch_ahead and later) else None
+        tr = self.trace
+        if tr is not None:
+            tr.append(("launch_begin", time.perf_counter()))
+        if seq is not None:
+            seq.launch(q_args, g_args, l_args)           # pi_q | pi_g, pi_l's state-encoder half: one recorded command list
+        elif self.launch_ahead:
+            if self.pi_l is not None and not later:
+                # tokens known ahead (synthetic): the text tower needs only them and runs beside pi_q's graph (the towers)
+                self.pi_q.prefetch_act_option(*q_args)
+                self.pi_l.prefetch_text(v["dialog"], self._side[2], after_current=False)
+            else:
+                self.pi_q.prefetch_act_option(*q_args)
+            if self.pi_g is not None:                    # pi_g FIRST on the followers' shared stream (see __init__)
+                self.pi_g.prefetch_act(*g_args, stream=self._side[1])
+            if self.pi_l is not None:
+                self.pi_l.prefetch_act_dialog(*l_args, stream=self._side[1] if later else None, dialog_later=later)
+        if self.launch_ahead and t + 1 < self.T:
+            # the host is about to wait for pi_q's actions: slice the NEXT step's views now (fresh tensor objects every step, as the
+            # trainer makes them; only the moment moves off the path between insert and the next forward's launch)
             self._next_views = (t + 1, self._step_views(t + 1))
-        values, unct, a_opt, lp_opt, h, row_opt, probs_opt = self.pi_q.act_option(
-            obs, h, prev, v["masks"], em_opt, em_masks, v["qs"], v["lqi"])
-        if ref:                                          # ppo_trainer.py:463-593: the host loop between act_option and act / act_dialog
-            self._host_dialog_loop(t, self.pi_q.host_actions("option").view(-1).numpy())
-        if self.launch_ahead and later and self.pi_l is not None:
-            self.pi_l.dialog_ready(self._text_stream)    # current_dialog / agent_step hold this step's values from here on
+        if tr is not None:
+            tr.append(("launched", time.perf_counter()))
+        values, unct, a_opt, lp_opt, h, row_opt, probs_opt = self.pi_q.act_option(*q_args)
+        if later and self.pi_l is not None:
+            # ppo_trainer.py:463-593: the host loop between act_option and act / act_dialog READS the option actions (a new query
+            # -> Speaker -> clip.tokenize -> `current_dialog`): the step's tokens exist only once a_q is on the host -- waited for
+            # here in BOTH dialog processes
+            a_q_host = self.pi_q.host_actions("option")
+            if a_q_host is None:                         # sampling="host" / "device": the actions as the call returned them
+                a_q_host = a_opt.cpu()
+            if tr is not None:
+                tr.append(("a_q_on_host", time.perf_counter()))
+            if ref:
+                self._host_dialog_loop(t, a_q_host.view(-1).numpy())
+            if seq is not None:
+                seq.dialog_ready()
+            elif self.launch_ahead:
+                self.pi_l.dialog_ready()                 # current_dialog / agent_step hold this step's values from here on
+            if tr is not None:
+                tr.append(("dialog_ready_done", time.perf_counter()))
         dg = ro.em_dim_goal
         o = dict(q_value=values, q_prob=probs_opt, a_q=a_opt, lp_q=lp_opt, h=h, row_q=row_opt, row_g=row_opt[:, :dg],
                  row_l=row_opt[:, :276], row_d=self.zero_dialog_feats, l_prob=self.zero_probs, a_g=a_opt, a_l=a_opt,
                  g_value=values, l_value=values, g_prob=self.zero_probs)
         if self.pi_g is not None:
-            o["g_value"], o["a_g"], _, _, o["row_g"], o["g_prob"] = self.pi_g.act(obs, h, prev, v["masks"], em_goal, em_masks)
+            o["g_value"], o["a_g"], _, _, o["row_g"], o["g_prob"] = self.pi_g.act(*g_args)
         if self.pi_l is not None:
-            o["l_value"], o["a_l"], _, _, o["row_l"], o["row_d"], o["l_prob"] = self.pi_l.act_dialog(
-                obs, h, prev, v["masks_vln"], em_vln, em_dlg, v["em_vln_masks"], v["dialog"], v["astep"])
+            o["l_value"], o["a_l"], _, _, o["row_l"], o["row_d"], o["l_prob"] = self.pi_l.act_dialog(*l_args)
         return o
 
     def policies_on(self, other, t=None):
@@ -358,6 +337,8 @@ class Workload:
             if hl is not None and not return_outs:
                 torch.where(hq == 1, hl, hg, out=ah)
                 late_select = True
+                if self.trace is not None:
+                    self.trace.append(("actions_on_host", time.perf_counter()))
             else:
                 actions = select_on_device()
                 ah.copy_(actions, non_blocking=True)
@@ -376,6 +357,8 @@ class Workload:
         if self._early_enc and self.launch_ahead:
             # the new observation exists: its towers start now and hide the storage bookkeeping + the next step's launch path
             started = self.pi_q.prefetch_encoders(v["nxt"], will_be={k: ro.observations[k][t + 1] for k in ("rgb", "depth", P.SPECTROGRAM)})   # the three addresses it checks
+            if self.trace is not None:
+                self.trace.append(("next_towers_launched", time.perf_counter()))
         dlg, astep = (self._cur_dialog, self._cur_astep) if self.dialog_process == "reference" else (v["dialog"], v["astep"])
 
         def store():

@@ -15,6 +15,7 @@ sampling="device" keeps everything on the GPU (like the reference would on a CUD
 import contextlib
 import ctypes as C
 import os
+import time
 import torch
 import torch.nn as nn
 
@@ -153,6 +154,9 @@ class _Graph:
                 pol._capture = None
             _cur_stream().wait_stream(cap)
             self.ws = pol._ws
+            # raw hipGraphExec_t handles: the step sequencer (sequencer.py) launches them from its recorded command lists
+            self.exec1 = self.graph.raw_cuda_graph_exec()
+            self.exec2 = self.graph2.raw_cuda_graph_exec() if self.graph2 is not None else None
         finally:
             pol._ws = ws_saved
 
@@ -334,6 +338,7 @@ def _graphed(pol, which, fn, args, mode=None):
             torch.cuda.synchronize()                     # a graph that is still executing must not be destroyed under the GPU
             pol._graphs.clear()
             pol._memos.clear()
+            pol._graph_gen += 1
         g = pol._graphs[key] = _Graph(pol, fn, args, by_ptr)
     if mode == "lead":
         grp.static_obs = g.static[0]
@@ -472,7 +477,7 @@ class EncoderGroup:
             h = f._call_hist
             if len(h) < 2 or h[-1][0] != h[-2][0] or f._stash is not None or f._later is not None:
                 continue
-            which, last = h[-1]
+            which, last, det = h[-1]                     # the follower is expected to pass the `deterministic` it passed last time
             before = h[-2][1]
             pred = []
             for i, a in enumerate(last):
@@ -493,7 +498,8 @@ class EncoderGroup:
             if pred is None:
                 continue
             f._auto_pending = True
-            f._prefetch(which, *pred, stream=self._auto_stream, dialog_later=(which == "vln" and pred[7] is not None))
+            f._prefetch(which, *pred, stream=self._auto_stream, dialog_later=(which == "vln" and pred[7] is not None),
+                        deterministic=det)
 
     def buffers(self, B, dev):
         if B not in self.out:
@@ -611,7 +617,9 @@ class Policy(nn.Module):
         self._call_hist = []                  # the last two DIRECT act* calls (which, net_args): EncoderGroup.auto_launch
         self._auto_pending = False            # a forward enqueued by EncoderGroup.auto_launch is waiting for its call
         self._param_epoch = 0                 # bumped by mark_params_changed (derived state keyed on the weights: the text memo)
+        self._graph_gen = 0                   # bumped whenever captured graphs are dropped (plans that hold their handles die with them)
         self._pinned = {}
+        self._poll_views = {}
         self._eng = None
         self._ws = E.Workspaces()
         self._dirty = True
@@ -639,6 +647,7 @@ class Policy(nn.Module):
         for m in ([self] if self._enc_group is None else self._enc_group.members):
             m._graphs = {}
             m._memos = {}
+            m._graph_gen += 1
         return r
 
     def side_streams(self):
@@ -730,23 +739,28 @@ class Policy(nn.Module):
         return {"logits": logits, "probs": probs, "value": value, "unct": unct}
 
     def _noise_dev(self, which, B, A, dev):
-        """The head set's device-side noise buffer (persistent: captured graphs read it in place)."""
+        """The head set's noise buffer as the heads kernel reads it (persistent: captured graphs hold its address): PINNED host
+        memory mapped into the device's address space -- the host draws straight into it and the kernel reads its B x A floats over
+        the link, so a sampled forward costs no upload launch on its stream (was: pinned ring -> copy_ -> device buffer, ~6 us of
+        every forward's critical path)."""
         t = self._pinned.get(("noise_dev", which, B))
-        if t is None or t.device != dev:
-            t = self._pinned[("noise_dev", which, B)] = torch.ones(B, A, device=dev)
+        if t is None:
+            t = self._pinned[("noise_dev", which, B)] = torch.ones(B, A, pin_memory=True)
         return t
 
     def _draw_noise(self, which, B, dev):
         """Draw the race's Exp(1) noise of one act* call on the HOST generator (the reference's draw: CustomFixedCategorical.sample ->
-        torch.multinomial) and upload it, on the current stream, in front of the forward that will consume it."""
+        torch.multinomial), in front of the forward that will consume it.  The buffer is shared with the device, so the previous
+        forward of this head set must have finished reading it: true by construction in a trainer (the step's actions have been
+        waited for), checked here for callers that launch the same head set back to back."""
         A = self.dim_actions_option if which == "option" else self.dim_actions
-        ring = self._pinned.get(("noise", which, B))
-        if ring is None:
-            ring = self._pinned[("noise", which, B)] = [[torch.empty(B, A, pin_memory=True) for _ in range(8)], 0]
-        ring[1] = (ring[1] + 1) % 8
-        qh = ring[0][ring[1]]
-        qh.exponential_(1)
-        self._noise_dev(which, B, A, dev).copy_(qh, non_blocking=True)
+        r = self._act_host.get(which)
+        if r is not None and r[1] is not None and not r[1].query():
+            r[1].synchronize()
+        self._noise_dev(which, B, A, dev).exponential_(1)
+        ah = self._pinned.get(("act_mapped", which, B))
+        if ah is not None:
+            ah.fill_(-1)                                 # host_actions() polls these entries: each is stored whole by the heads kernel
 
     def _finish(self, which, feats, out, action=None, deterministic=False, need_sample=True):
         """Action selection (host or device RNG) and the log-prob / entropy of the chosen actions."""
@@ -758,18 +772,23 @@ class Policy(nn.Module):
             return out                                   # sampled right behind the forward at prefetch time (sampling="race")
         if action is None and need_sample:
             if deterministic:
+                # the reference consumes no generator state here (CustomFixedCategorical.mode; the eval loop's act_dialog,
+                # ppo_trainer.py:1917, 2156): a draw made AHEAD of this call for a sampled action that is now not wanted is undone
+                self._undo_draw(out)
+                self._act_host.pop(which, None)          # host_actions() must not hand out the previous call's sampled actions
                 action = probs.argmax(dim=-1, keepdim=True)
             elif self.sampling == "race" and out.get("raced") is not None and out.get("noise_drawn"):
                 # the forward's last kernel ran the race on the noise drawn for this call (_draw_noise, _heads_first): the reference's
                 # action for the same generator state; no probabilities cross PCIe, no host synchronisation
                 action, logp, ent = out["raced"]
                 ah = out.get("action_host")              # stored there by the heads kernel itself (mapped pinned memory) ...
+                poll = ah is not None                    # ... cleared to -1 by _draw_noise: host_actions() may poll it
                 if ah is None:
                     ah = self._host_action(B)            # ... or copied right behind the forward (512 B)
                     ah.copy_(action, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(_cur_stream())
-                self._act_host[which] = (ah, ev)
+                self._act_host[which] = (ah, ev, poll)
                 self.last_host_action = None
                 out.update(action=_i64(action.view(B, 1)), log_prob=logp, entropy_rows=ent)
                 return out
@@ -784,7 +803,7 @@ class Policy(nn.Module):
                 ah.copy_(action, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(_cur_stream())
-                self._act_host[which] = (ah, ev)
+                self._act_host[which] = (ah, ev, False)
                 self.last_host_action = None
             elif self.sampling == "host":
                 # == torch.multinomial's exponential race on the host generator; the noise does not depend on the
@@ -798,7 +817,7 @@ class Policy(nn.Module):
                 ah = self._host_action(B)
                 torch.argmax(pc / q, dim=-1, keepdim=True, out=ah)
                 self.last_host_action = ah               # the trainer's host loop reads the option actions (ppo_trainer.py:463)
-                self._act_host[which] = (ah, None)
+                self._act_host[which] = (ah, None, False)
                 action = self._result_bufs(which, B, dev)[0]
                 action.copy_(ah, non_blocking=True)
             else:
@@ -812,6 +831,23 @@ class Policy(nn.Module):
                    E.P(ent), B, L.stream())
             out.update(action=action, log_prob=logp, entropy_rows=ent)
         return out
+
+    @staticmethod
+    def _undo_draw(heads_out):
+        """Take back the host-generator draw a launched-ahead forward made (`rng_spec` = generator state before / after it) when its
+        sampled action turns out not to be used: a discarded guess, or a call with deterministic=True.  Only the LAST draw of the
+        generator can be taken back; if anything else has drawn since, the state is left alone and the caller is told."""
+        spec = heads_out.pop("rng_spec", None)
+        heads_out.pop("noise_drawn", None)
+        if spec is None:
+            return
+        if torch.equal(torch.get_rng_state(), spec[1]):
+            torch.set_rng_state(spec[0])
+        else:
+            import warnings
+            warnings.warn("avlen_amd: a launched-ahead forward drew sampling noise for a call that then asked for deterministic / "
+                          "other arguments, and the host generator has advanced since: the draw cannot be undone (pass "
+                          "deterministic=True to the prefetch_* call to avoid it)", RuntimeWarning)
 
     def _result_bufs(self, which, B, dev):
         """Persistent (action, log_prob, entropy_rows) tensors of one head set and batch size: like the graph outputs they are
@@ -836,23 +872,41 @@ class Policy(nn.Module):
     def _noise_bufs(self, which, B, A, dev):
         """(pinned host, device) noise buffers of one head set: a ring of 8 host slots (an upload is consumed long before its slot
         returns), one device buffer per slot."""
-        ring = self._pinned.get(("noise", which, B))
+        ring = self._pinned.get(("noise_pair", which, B))      # (not _draw_noise's ring of plain pinned tensors)
         if ring is None:
-            ring = self._pinned[("noise", which, B)] = [[(torch.empty(B, A, pin_memory=True), torch.empty(B, A, device=dev))
-                                                         for _ in range(8)], 0]
+            ring = self._pinned[("noise_pair", which, B)] = [[(torch.empty(B, A, pin_memory=True), torch.empty(B, A, device=dev))
+                                                              for _ in range(8)], 0]
         ring[1] = (ring[1] + 1) % 8
         return ring[0][ring[1]]
 
     def host_actions(self, which="option"):
-        """The most recent SAMPLED actions of head set `which` on the host ((B,1) int64, pinned; overwritten eight draws later).
-        sampling="host": drawn there; sampling="race": copied right behind the race kernel -- this waits for that copy only (the
-        trainer's query loop, ppo_trainer.py:463, reads the option actions)."""
+        """The most recent SAMPLED actions of head set `which` on the host ((B,1) int64, pinned), or None if the last call of that
+        head set was deterministic.  sampling="host": drawn there (ring of 8 buffers); sampling="race": stored by the heads kernel
+        into ONE mapped buffer per head set and batch size -- read it before the next forward of that head set; this waits for
+        that forward only (the trainer's query loop, ppo_trainer.py:463, reads the option actions)."""
         r = self._act_host.get(which)
         if r is None:
             return None
-        if r[1] is not None:
-            r[1].synchronize()
-        return r[0]
+        ah, ev, poll = r
+        if ev is not None:
+            if poll:
+                # the heads kernel stores each sampled action (one aligned 8-byte word per row) straight into this mapped buffer,
+                # which _draw_noise set to -1 before the forward went out: the words are complete as soon as none is negative --
+                # no completion packet, no signal, no wake-up (hipEventSynchronize: 15-40 us after the kernel's end, measured).
+                # Bounded: falls back to the event.
+                v = self._poll_views.get(ah.data_ptr())
+                if v is None:
+                    v = self._poll_views[ah.data_ptr()] = ah.numpy().reshape(-1)
+                t_end = None
+                while v.min() < 0:
+                    if t_end is None:
+                        t_end = time.perf_counter() + 0.02
+                    elif time.perf_counter() > t_end:
+                        ev.synchronize()
+                        break
+            else:
+                ev.synchronize()
+        return ah
 
     def _host_action(self, B):
         """Pinned staging buffer for the sampled actions (ring of 8: an upload is consumed long before its slot returns)."""
@@ -865,11 +919,13 @@ class Policy(nn.Module):
     def _run_heads(self, which, feats, action=None, deterministic=False, need_sample=True):
         return self._finish(which, feats, self._heads_first(which, feats), action, deterministic, need_sample)
 
-    def _forward(self, which, *net_args, sample=False):
+    def _forward(self, which, *net_args, sample=False, speculative=False):
         """net.run(...) + first heads kernel -> (net outputs tuple, heads dict); replayed from a HIP graph when
         use_graphs is set (inputs are copied into the graph's static buffers; outputs are overwritten by the
         next replay, so callers copy what they keep -- RolloutStorage.insert does).  sample: an act* call that will draw an action
-        (sampling="race": the noise is drawn and uploaded here, in front of the forward whose last kernel runs the race)."""
+        (sampling="race": the noise is drawn and uploaded here, in front of the forward whose last kernel runs the race).
+        speculative: the forward is launched AHEAD of its act* call (prefetch_* / automatic launch-ahead): the generator state around
+        the draw is kept so that the draw can be taken back (_undo_draw)."""
         race = self.sampling == "race"
 
         def eager(*args):
@@ -893,17 +949,17 @@ class Policy(nn.Module):
             _cur_stream().wait_event(st[3])
             if self._enc_group is not None and self._enc_group.leader is not self:
                 self._enc_group.pending.add(id(self))
-            if st[2][1].get("rng_before") is not None:
-                torch.set_rng_state(st[2][1]["rng_before"])          # the discarded forward's noise draw never happened
-        drawn, rng_before = False, None
+            self._undo_draw(st[2][1])                  # the discarded forward's noise draw never happened
+        drawn, rng_spec = False, None
         if sample and race and not self._defer_second:
-            if self._auto_pending:                       # a guessed forward may be discarded: its draw must then be undone
-                rng_before = torch.get_rng_state()
+            rng_before = torch.get_rng_state() if speculative else None
             obs0 = net_args[0]
             B0 = next(iter(obs0.values())).shape[0] if isinstance(obs0, dict) else obs0.shape[0]
             dev0 = next(iter(obs0.values())).device if isinstance(obs0, dict) else obs0.device
             self._draw_noise(which, B0, dev0)
             drawn = True
+            if speculative:
+                rng_spec = (rng_before, torch.get_rng_state())
         txt = getattr(self.net, "_text", None)
         if which == "vln" and txt is not None:
             tok = net_args[7]
@@ -917,6 +973,11 @@ class Policy(nn.Module):
                     _cur_stream().wait_event(ev)
             else:
                 self.net._text, self.net._text_key = None, None
+        if which == "vln" and self.use_graphs and getattr(self.net, "text_cache", False):
+            # a captured forward holds the memoised text tower (avlen_clip_text_cached_fwd): its replay checks nothing, so a weight
+            # change since the memo was filled (load_state_dict / mark_params_changed) empties the memo here, outside capture,
+            # on the stream the replay is about to run on
+            self.net._sync_text_cache(self)
         mode, grp = None, self._enc_group
         if grp is not None and self.precision in ("bf16", "bf16x3"):
             if grp.leader is self:
@@ -943,8 +1004,8 @@ class Policy(nn.Module):
         def tag(o):
             if drawn:
                 o[1]["noise_drawn"] = True
-            if rng_before is not None:
-                o[1]["rng_before"] = rng_before
+            if rng_spec is not None:
+                o[1]["rng_spec"] = rng_spec
             return o
         try:
             if not self.use_graphs:
@@ -978,12 +1039,14 @@ class Policy(nn.Module):
 
     _in_prefetch_flow = False             # the caller issues prefetch_* itself: no automatic launch-ahead on top
 
-    def _prefetch(self, which, *net_args, stream=None, dialog_later=False):
+    def _prefetch(self, which, *net_args, stream=None, dialog_later=False, deterministic=False):
         """Enqueue the forward of a later act*/get_value* call now (no host synchronisation).  The matching call, made
         with the same tensors, picks the result up instead of launching again; a trainer that evaluates pi_q, pi_g and
         pi_l on one observation (ppo_trainer.py:375-636) can enqueue all three before the first host-side sampling.
         `stream`: run this forward on its own HIP stream (ordered after everything enqueued so far on the current one), so
-        that independent policies overlap on the GPU and each one's probabilities reach the host as soon as IT is done."""
+        that independent policies overlap on the GPU and each one's probabilities reach the host as soon as IT is done.
+        `deterministic`: the flag the act* call will pass -- with True no sampling noise is drawn for it (the reference's eval loop
+        calls act_dialog(deterministic=True), which consumes no generator state)."""
         self._stash = None
         cur = _cur_stream()
         run_on = stream if stream is not None else cur
@@ -1012,16 +1075,16 @@ class Policy(nn.Module):
                     finally:
                         self._defer_second = False
                 if self._deferred is not None:
-                    self._later = (which, self._arg_key(net_args), out, stream, net_args[7], net_args[8])
+                    self._later = (which, self._arg_key(net_args), out, stream, net_args[7], net_args[8], deterministic)
                     return
                 # the forward was not cut (no split capture): it ran whole, with whatever the tensors held -- run it again, whole,
                 # at dialog_ready()
-            self._later = ("whole", net_args, stream)
+            self._later = ("whole", net_args, stream, deterministic)
             return
         with ctx:
-            out = self._forward(which, *net_args, sample=True)
+            out = self._forward(which, *net_args, sample=not deterministic, speculative=True)
             done = torch.cuda.Event()
-            if self.sampling == "race":
+            if self.sampling == "race" and not deterministic:
                 # the race goes out right behind the forward on ITS stream (noise drawn now: prefetch_* calls are made in the order
                 # of the act* calls that follow, so the host generator is consumed in the reference's order)
                 out = (out[0], self._finish(which, out[0][0], out[1]))
@@ -1040,16 +1103,17 @@ class Policy(nn.Module):
                 done.record(run_on)
         self._stash = (which, self._arg_key(net_args), out, done)
 
-    def prefetch_act(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks, stream=None):
+    def prefetch_act(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks, stream=None,
+                     deterministic=False):
         self._mark_explicit()
         self._prefetch("goal", observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks,
-                       stream=stream)
+                       stream=stream, deterministic=deterministic)
 
     def prefetch_act_option(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks,
-                            query_state, last_query_info, stream=None):
+                            query_state, last_query_info, stream=None, deterministic=False):
         self._mark_explicit()
         self._prefetch("option", observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks,
-                       query_state, last_query_info, stream=stream)
+                       query_state, last_query_info, stream=stream, deterministic=deterministic)
 
     def _mark_explicit(self):
         for m in ([self] if self._enc_group is None else self._enc_group.members):
@@ -1063,13 +1127,13 @@ class Policy(nn.Module):
             self.net.prefetch_text(self, all_dialog, stream, after_current)
 
     def prefetch_act_dialog(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_dialog,
-                            ext_memory_masks, all_dialog, agent_step, stream=None, dialog_later=False):
+                            ext_memory_masks, all_dialog, agent_step, stream=None, dialog_later=False, deterministic=False):
         """dialog_later=True: `all_dialog` and `agent_step` are the tensors the trainer fills only after `act_option` has returned
         (`current_dialog`, `rollouts.agent_step[step]`: ppo_trainer.py:347, 582-593).  Only the half of the forward that reads
         neither is enqueued now; call `dialog_ready()` once both hold this step's values."""
         self._mark_explicit()
         self._prefetch("vln", observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_dialog,
-                       ext_memory_masks, all_dialog, agent_step, stream=stream, dialog_later=dialog_later)
+                       ext_memory_masks, all_dialog, agent_step, stream=stream, dialog_later=dialog_later, deterministic=deterministic)
 
     def dialog_ready(self, text_stream=None):
         """Second half of `prefetch_act_dialog(..., dialog_later=True)`: the frozen text tower on the tensors passed there (memoised
@@ -1080,9 +1144,9 @@ class Policy(nn.Module):
         if lt is None:
             return
         if lt[0] == "whole":
-            self._prefetch("vln", *lt[1], stream=lt[2])
+            self._prefetch("vln", *lt[1], stream=lt[2], deterministic=lt[3])
             return
-        which, key, out, stream, tokens, agent_step = lt
+        which, key, out, stream, tokens, agent_step, deterministic = lt
         g, self._deferred = self._deferred, None
         cur = _cur_stream()
         run_on = stream if stream is not None else cur
@@ -1107,14 +1171,17 @@ class Policy(nn.Module):
         with ctx:
             if torch.is_tensor(g.static[8]) and g.static[8].data_ptr() != agent_step.data_ptr():
                 L.multi_copy([(g.static[8], _f32(agent_step))])
-            if self.sampling == "race":                  # pi_l's draw: third in the step, as in the reference
+            race = self.sampling == "race" and not deterministic
+            if race:                                     # pi_l's draw: third in the step, as in the reference
+                before = torch.get_rng_state()
                 self._draw_noise(which, out[1]["probs"].shape[0], out[1]["probs"].device)
                 out[1]["noise_drawn"] = True
+                out[1]["rng_spec"] = (before, torch.get_rng_state())
             g.graph2.replay()
             self.net._text_read = torch.cuda.Event()
             self.net._text_read.record(run_on)
             done = torch.cuda.Event()
-            if self.sampling == "race":
+            if race:
                 out = (out[0], self._finish(which, out[0][0], out[1]))
                 out[1]["finished"] = True
             if self.sampling == "host":
@@ -1136,7 +1203,7 @@ class Policy(nn.Module):
         args = (observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks)
         (features, rnn_hidden_states, ext_memory_feats), h = self._forward("goal", *args, sample=not deterministic)
         h = self._finish("goal", features, h, deterministic=deterministic)
-        self._after_act("goal", args)
+        self._after_act("goal", args, deterministic)
         return h["value"], h["action"], h["log_prob"], rnn_hidden_states, ext_memory_feats, h["probs"]
 
     def act_option(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks,
@@ -1144,7 +1211,7 @@ class Policy(nn.Module):
         args = (observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks, query_state, last_query_info)
         (features, rnn_hidden_states, ext_memory_feats), h = self._forward("option", *args, sample=not deterministic)
         h = self._finish("option", features, h, deterministic=deterministic)
-        self._after_act("option", args)
+        self._after_act("option", args, deterministic)
         return (h["value"], h["unct"], h["action"], h["log_prob"], rnn_hidden_states, ext_memory_feats, h["probs"])
 
     def act_dialog(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_dialog,
@@ -1158,7 +1225,7 @@ class Policy(nn.Module):
             # the first half was enqueued by EncoderGroup.auto_launch: if it ran on the tensors of THIS call, the text tower and the
             # second half follow now, on the call's own dialog tokens / agent_step
             if all_dialog is not None and lt[1][:7] == self._arg_key(args[:7]):
-                self._later = (lt[0], self._arg_key(args), lt[2], lt[3], all_dialog, agent_step)
+                self._later = (lt[0], self._arg_key(args), lt[2], lt[3], all_dialog, agent_step, deterministic)
                 self.dialog_ready()
             else:
                 if lt[3] is not None:                    # the guessed first half may still be running in the graph this call replays
@@ -1172,7 +1239,7 @@ class Policy(nn.Module):
         (features, rnn_hidden_states, ext_memory_feats, ext_memory_dialog_feats), h = self._forward("vln", *args,
                                                                                                      sample=not deterministic)
         h = self._finish("vln", features, h, deterministic=deterministic)
-        self._after_act("vln", args)
+        self._after_act("vln", args, deterministic)
         return (h["value"], h["action"], h["log_prob"], rnn_hidden_states, ext_memory_feats,
                 ext_memory_dialog_feats, h["probs"])
 
@@ -1191,8 +1258,9 @@ class Policy(nn.Module):
         if g is None or g.graph2 is None or grp is None or grp.leader is not self or not isinstance(g.static[0], dict):
             return False
         so = g.static[0]
+        raw = torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
         try:
-            key = (id(g),) + tuple(observations[k].data_ptr() for k in so)
+            key = (id(g), raw) + tuple(observations[k].data_ptr() for k in so)
         except KeyError:
             return False
         plan = self._enc_plans.get(key)
@@ -1204,8 +1272,15 @@ class Policy(nn.Module):
                     return False                         # a dtype / layout conversion would be needed: let the act* call do everything
                 pairs.append((d, a))
             n = len(pairs)
-            plan = ((C.c_void_p * n)(*[a.data_ptr() for _, a in pairs]), (C.c_void_p * n)(*[d.data_ptr() for d, _ in pairs]),
-                    (C.c_int64 * n)(*[d.numel() * d.element_size() for d, _ in pairs]), n)
+            arrs = ((C.c_void_p * n)(*[a.data_ptr() for _, a in pairs]), (C.c_void_p * n)(*[d.data_ptr() for d, _ in pairs]),
+                    (C.c_int64 * n)(*[d.numel() * d.element_size() for d, _ in pairs]))
+            # staging copy + the encoder half of the captured forward as ONE call (csrc/sequencer.hip): this runs between "the
+            # step's actions are on the host" and "the next towers are in the queue"
+            cmds = (L.Cmd * 2)()
+            cmds[0].op, cmds[0].n, cmds[0].d = L.CMD_MULTICOPY, n, raw
+            cmds[0].a, cmds[0].b, cmds[0].c = (C.cast(x, C.c_void_p).value for x in arrs)
+            cmds[1].op, cmds[1].a, cmds[1].b = L.CMD_GRAPH, g.exec1, raw
+            plan = (cmds, arrs, g)
             while len(self._enc_plans) >= 512:
                 self._enc_plans.pop(next(iter(self._enc_plans)))
             self._enc_plans[key] = plan
@@ -1213,8 +1288,7 @@ class Policy(nn.Module):
         for m_ in grp.members:
             if m_ is not self:
                 m_._engine()
-        L.call("avlen_multi_copy", plan[0], plan[1], plan[2], plan[3], L.stream())
-        g.graph.replay()
+        L.call("avlen_cmds_run", plan[0], 2)
         self._enc_early = (g, None if will_be is None else tuple(will_be[k].data_ptr() for k in ("rgb", "depth", SPECTROGRAM)))
         return True
 
@@ -1225,13 +1299,13 @@ class Policy(nn.Module):
         followers -- wait for the event.  Pass event=None to clear."""
         self._late_inputs = None if event is None else (tuple(keys), event)
 
-    def _after_act(self, which, args):
+    def _after_act(self, which, args, deterministic=False):
         """Bookkeeping of a direct act* call for the group's automatic launch-ahead (EncoderGroup.auto_launch)."""
         grp = self._enc_group
         if grp is None or not grp.auto or not self.use_graphs or self.precision not in ("bf16", "bf16x3"):
             return
         h = self._call_hist
-        h.append((which, args))
+        h.append((which, args, deterministic))
         if len(h) > 2:
             del h[0]
         if grp.leader is self and not self._in_prefetch_flow:

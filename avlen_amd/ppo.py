@@ -34,13 +34,27 @@ class PPO(nn.Module):
         self.optimizer = torch.optim.Adam(actor_critic.parameters(), lr=lr, eps=eps)
         self.dialog_optimizer = torch.optim.Adam(actor_critic.parameters(), lr=.00001, eps=eps)
         self.device = next(actor_critic.parameters()).device
-        self._adam = None
+        # the moments live in flat buffers stepped by ONE HIP launch; `optimizer.state` holds views into them (E.FlatAdam), so the
+        # trainer's `optimizer.state_dict()` / `load_state_dict()` checkpoint round trip carries them (ddppo_trainer.py:812-817, 857-862)
+        self._adam = E.FlatAdam(self.optimizer, actor_critic, with_norm=True)
+        self._adam_dialog = E.FlatAdam(self.dialog_optimizer, actor_critic)
         self._distributed = False
         # Opt-in, NOT the reference's work count: pi_q's update re-runs the frozen encoders on the stored observations exactly as
         # ppo.py:207-262 does unless this is set -- then the visual / audio feature columns are read back from the rows the rollout
         # wrote into the option memory ring (policy.py:1062-1065 `x_for_memory`; policy.py:1035-1036 detaches them: same values,
         # no gradient either way).  bench.py reports it as `update_feature_reuse`, never as the headline.
         self.feature_reuse = False
+
+    @staticmethod
+    def set_x3_mixed_backward_rows(rows):
+        """precision="bf16x3" only: the number of SMT token rows per minibatch (B x (M + 1)) from which `update` runs the BACKWARD's
+        products and attention on plain bf16 operands (the forward -- logits, ratio, losses -- stays compensated).  Default 65536:
+        every 2nd-stage minibatch of the AVLEN configs (1200 samples x 151 .. 301 rows) takes it, the 1st stage never does; 0
+        switches it off (compensated backward everywhere, 1.7x the update time at 32 envs); a negative value restores the default.
+        Held to the oracle by tests/test_gpu_policy_parity.py::test_gradients_bf16x3_vs_oracle_autograd_per_class[mixed] (per tensor
+        class) and tests/test_gpu_harness_parity.py::test_benched_harness_mixed_backward_update_matches_oracle (the parameter step).
+        Process-wide (a library setting)."""
+        L.lib.avlen_set_x3_mixed_backward_rows(int(rows))
 
     def forward(self, *x):
         raise NotImplementedError
@@ -53,11 +67,7 @@ class PPO(nn.Module):
         return (adv - adv.mean()) / (adv.std() + EPS_PPO)
 
     def _adam_state(self, flat):
-        if self._adam is None or self._adam["m"].numel() != flat.n_trained or self._adam["m"].device != flat.flat.device:
-            dev = flat.flat.device
-            self._adam = {"m": torch.zeros(flat.n_trained, device=dev), "v": torch.zeros(flat.n_trained, device=dev),
-                          "step": 0, "norm_sq": torch.zeros(1, dtype=torch.float64, device=dev)}
-        return self._adam
+        return self._adam.state(flat)
 
     def _grad_views(self, eng):
         if "smt_grad" not in eng:
@@ -104,13 +114,13 @@ class PPO(nn.Module):
                cto, pol.prec, None, 0, E.P(ws), nb, st)
         self.reduce_gradients(flat)
         ad = self._adam_state(flat)
-        ad["step"] += 1
-        ad["norm_sq"].zero_()
+        step = ad.advance()
+        ad.norm_sq.zero_()
         lr = self.optimizer.param_groups[0]["lr"]
         eps = self.optimizer.param_groups[0]["eps"]
-        L.call("avlen_grad_sumsq", E.P(flat.grad), flat.n_trained, E.P(ad["norm_sq"]), st)
-        L.call("avlen_adam_step", E.P(flat.flat), E.P(flat.grad), E.P(ad["m"]), E.P(ad["v"]), flat.n_trained, float(lr),
-               0.9, 0.999, float(eps), ad["step"], float(self.max_grad_norm), E.P(ad["norm_sq"]), st)
+        L.call("avlen_grad_sumsq", E.P(flat.grad), flat.n_trained, E.P(ad.norm_sq), st)
+        L.call("avlen_adam_step", E.P(flat.flat), E.P(flat.grad), E.P(ad.m), E.P(ad.v), flat.n_trained, float(lr),
+               0.9, 0.999, float(eps), step, float(self.max_grad_norm), E.P(ad.norm_sq), st)
         flat.refresh16(trained_only=True)                 # bf16 shadows of the updated weights (rollout fast path)
         eng["packed"].refresh_pads()                      # ... and the padded shadow of a fusion input that is not 8-aligned
 
@@ -149,13 +159,11 @@ class PPO(nn.Module):
         pol = self.actor_critic
         dev, st = flat.flat.device, L.stream()
         self.reduce_gradients(flat)
-        if getattr(self, "_adam_dialog", None) is None or self._adam_dialog["m"].numel() != flat.n_trained:
-            self._adam_dialog = {"m": torch.zeros(flat.n_trained, device=dev), "v": torch.zeros(flat.n_trained, device=dev), "step": 0}
-        ad = self._adam_dialog
-        ad["step"] += 1
+        ad = self._adam_dialog.state(flat)
+        step = ad.advance()
         pg = self.dialog_optimizer.param_groups[0]
-        L.call("avlen_adam_step", E.P(flat.flat), E.P(flat.grad), E.P(ad["m"]), E.P(ad["v"]), flat.n_trained, float(pg["lr"]), 0.9,
-               0.999, float(pg["eps"]), ad["step"], 0.0, None, st)
+        L.call("avlen_adam_step", E.P(flat.flat), E.P(flat.grad), E.P(ad.m), E.P(ad.v), flat.n_trained, float(pg["lr"]), 0.9,
+               0.999, float(pg["eps"]), step, 0.0, None, st)
         pol.mark_params_changed()                 # conv / fc weights moved: packed copies and bf16 shadows follow
         pol._engine()
         return loss

@@ -485,6 +485,21 @@ int avlen_gather_rows(const float* src, int lds, const int* index, float* dst, i
  * RolloutStorage.insert (rollout_storage.py:223-330 of the reference: ~25 `tensor[step].copy_()` calls per step). */
 int avlen_multi_copy(const void* const* src, void* const* dst, const int64_t* nbytes, int n, avlen_stream_t stream);
 
+/* Step sequencer (csrc/sequencer.hip): a list of stream operations run by ONE call, in order.  The reference's rollout step has
+ * two host round trips on its critical path (ppo_trainer.py:449-636: act_option -> host reads the option actions -> tokens ->
+ * act_dialog -> envs.step); what the host enqueues after each of them is fixed once the argument buffers are known.
+ *   AVLEN_CMD_GRAPH      launch the instantiated graph a (hipGraphExec_t) on stream b
+ *   AVLEN_CMD_RECORD     record event a (hipEvent_t) on stream b
+ *   AVLEN_CMD_WAIT       make stream a wait for event b
+ *   AVLEN_CMD_MULTICOPY  avlen_multi_copy(a = src pointer array, b = dst pointer array, c = byte counts, n pairs) on stream d
+ * All handles are HOST values (HIP runtime handles / host arrays of device pointers); nothing is allocated or synchronised. */
+#define AVLEN_CMD_GRAPH 1
+#define AVLEN_CMD_RECORD 2
+#define AVLEN_CMD_WAIT 3
+#define AVLEN_CMD_MULTICOPY 4
+typedef struct { int op; int n; void* a; void* b; void* c; void* d; } avlen_cmd;
+int avlen_cmds_run(const avlen_cmd* cmds, int n);
+
 /* build / device info */
 const char* avlen_build_info(void);
 

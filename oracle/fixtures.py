@@ -153,3 +153,18 @@ def belief_scenario(tag, N=3, T=7, spectrogram=(65, 26)):
         dones = None if t == 0 else [(t, i) in done for i in range(N)]
         steps.append((o, dones))
     return steps
+
+
+def delta_stats(post, pre, keys):
+    """What the `cycle_*` goldens keep of a PPO.update's parameter step, per float tensor in `keys`: the L2 norm of the step
+    (post - pre) and a SIGNED weighted checksum of it, sum_i w_i * (post - pre)_i with closed-form weights w (sym of the tensor's
+    name): a transposed / shifted / sign-flipped step of the right size changes the checksum, which sum(|p|) does not see.
+    float64 accumulation; `pre` is the closed-form fixture state (regenerated wherever the test runs)."""
+    import numpy as np
+    l2, chk = [], []
+    for k in keys:
+        d = (post[k].detach().double().cpu() - pre[k].detach().double().cpu()).reshape(-1)
+        w = sym("chk." + k, (d.numel(),), 1.0).double()
+        l2.append(float(d.norm()))
+        chk.append(float((d * w).sum()))
+    return np.array(l2), np.array(chk)

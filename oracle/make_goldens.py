@@ -21,7 +21,7 @@ import ref_harness as rh       # noqa: E402
 import cycle as cyc            # noqa: E402
 
 warnings.filterwarnings("ignore")
-OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+OUT = os.environ.get("AVLEN_GOLDEN_OUT", os.path.join(os.path.dirname(HERE), "tests", "golden"))
 os.makedirs(OUT, exist_ok=True)
 torch.set_num_threads(8)
 
@@ -206,6 +206,7 @@ def main():
     for pre in (True, False):
         T, N, EMS, EMC = 6, 4, 12, 6
         pol, _ = build(ns, "option", pretraining=pre)
+        sd_pre = {k: v.detach().clone() for k, v in pol.state_dict().items()}
         agent = ns.PPO(pol, 0.2, 2, 2, 0.5, 0.05, lr=2.5e-4, eps=1e-5, max_grad_norm=0.2,
                        use_normalized_advantage=False)
         st = ns.RolloutStorage(T, N, rh.observation_space(), rh.ActionSpace(4), 512, True, EMS, EMC, EMS, EMC,
@@ -244,8 +245,9 @@ def main():
         st.after_update()
         sd = pol.state_dict()
         keys = sorted(k for k in sd if sd[k].dtype == torch.float32)
+        d_l2, d_chk = fx.delta_stats(sd, sd_pre, keys)        # the step of EVERY tensor: norm + signed weighted checksum
         save(f"cycle_p{int(pre)}", next_value=nv, returns=returns, update=np.array(out, dtype=np.float64),
-             em_masks=st.em_masks, **{k: torch.stack(v) for k, v in rec.items()},
+             em_masks=st.em_masks, **{k: torch.stack(v) for k, v in rec.items()}, delta_l2=d_l2, delta_chk=d_chk,
              param_sum=np.array([float(sd[k].double().sum()) for k in keys]),
              param_abs=np.array([float(sd[k].double().abs().sum()) for k in keys]),
              fusion2_w=sd["net.smt_state_encoder.fusion_encoder.2.weight"][:4, :8],

@@ -23,6 +23,7 @@ def main():
     pre = True
     T, N, EMS, EMC = 6, 4, 12, 6
     pol, spec = build(ns, "option", pretraining=pre, distractor=True)
+    sd_pre = {k: v.detach().clone() for k, v in pol.state_dict().items()}
     agent = ns.PPO(pol, 0.2, 2, 2, 0.5, 0.05, lr=2.5e-4, eps=1e-5, max_grad_norm=0.2, use_normalized_advantage=False)
     st = ns.RolloutStorage(T, N, rh.observation_space(), rh.ActionSpace(4), 512, True, EMS, EMC, EMS, EMC, 3, 3, 297, 276, 329,
                            256, num_recurrent_layers=-1, max_dialog_len=77, use_state_memory=True)
@@ -58,8 +59,9 @@ def main():
     st.after_update()
     sd = pol.state_dict()
     keys = sorted(k for k in sd if sd[k].dtype == torch.float32)
+    d_l2, d_chk = fx.delta_stats(sd, sd_pre, keys)
     save("cycle_dis", next_value=nv, returns=returns, update=np.array(out, dtype=np.float64), em_masks=st.em_masks,
-         **{k: torch.stack(v) for k, v in rec.items()},
+         **{k: torch.stack(v) for k, v in rec.items()}, delta_l2=d_l2, delta_chk=d_chk,
          param_abs=np.array([float(sd[k].double().abs().sum()) for k in keys]),
          fusion0_w=sd["net.smt_state_encoder.fusion_encoder.0.weight"][:4, 270:300])
     with open(os.path.join(OUT, "cycle_dis_keys.json"), "w") as f:

@@ -47,7 +47,8 @@ def test_struct_sizes_against_c_compiler(tmp_path):
              "avlen_mha": _lib.Mha, "avlen_enc_layer": _lib.EncLayer, "avlen_dec_layer": _lib.DecLayer,
              "avlen_transformer": _lib.Transformer, "avlen_smt": _lib.Smt, "avlen_dialog": _lib.Dialog,
              "avlen_clip_block": _lib.ClipBlock, "avlen_clip_text": _lib.ClipText, "avlen_gru": _lib.Gru,
-             "avlen_heads": _lib.Heads, "avlen_ln_fold": _lib.LnFold, "avlen_extmem_op": _lib.ExtMemOp}
+             "avlen_heads": _lib.Heads, "avlen_ln_fold": _lib.LnFold, "avlen_extmem_op": _lib.ExtMemOp,
+             "avlen_cmd": _lib.Cmd}
     src = tmp_path / "s.c"
     body = "\n".join(f'  printf("{n} %zu\\n", sizeof({n}));' for n in names)
     src.write_text(f'#include <stdio.h>\n#include "avlen_hip.h"\nint main(void) {{\n{body}\n  return 0; }}\n')

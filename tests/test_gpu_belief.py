@@ -295,11 +295,10 @@ def test_asynchronous_belief_update_equals_the_synchronous_one():
     from avlen_amd import _lib as L
     snaps = []
     try:
-        for mode in ("1", "0"):
-            os.environ["AVLEN_BELIEF_ASYNC"] = mode
+        for mode in (True, False):
             torch.manual_seed(5)
-            wl = Workload(6, 7, spectrogram=(65, 26, 2), precision="bf16x3", belief_predictor=True, em_capacity=5)
-            assert wl._belief_async == (mode == "1")
+            wl = Workload(6, 7, spectrogram=(65, 26, 2), precision="bf16x3", belief_predictor=True, em_capacity=5, belief_async=mode)
+            assert wl._belief_async == mode
             for _ in range(7):
                 wl.rollout_step()
             torch.cuda.synchronize()                         # (no optimiser step: its loss sums are not bit-reproducible run to run)
@@ -312,7 +311,6 @@ def test_asynchronous_belief_update_equals_the_synchronous_one():
                           ro.value_preds.clone(), ro.actions.clone(), ro.em.memory.clone(), ro.em_option.memory.clone()))
             del wl
     finally:
-        os.environ.pop("AVLEN_BELIEF_ASYNC", None)
         L.lib.avlen_set_tower_x3_reserved_cus(0)
     a, b = snaps
     for k in a[0]:

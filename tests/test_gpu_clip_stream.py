@@ -126,3 +126,58 @@ def test_embedding_does_not_depend_on_the_batch_it_is_packed_in(mode):
     assert torch.equal(sub, full[ones])
     for pick in ([4, 0, 2], [4, 5, 6, 0, 2], [6, 7, 0]):              # [2+1+1] | [3+1] [2+2] [1] | [3+1] [3]
         assert torch.equal(enc(tok[pick].contiguous()).clone(), full[pick]), pick
+
+
+def test_benched_fp16_split_tower_against_the_oracle():
+    """The tower the bench runs (precision="bf16x3": fp16 operands, packed groups, 4-way column split, one launch) directly against
+    the ORACLE's CLIP text transformer (oracle/restate.py clip_encode_text: the published definition, equal to Hugging Face's
+    CLIPTextModelWithProjection to 2e-5, tests/test_clip_independent.py) on every tile class (1 .. 5 row tiles, EOT at 1 and 76):
+    <= 5e-3 of the embedding scale (measured 1.0e-3: 3.7e-3 on a scale of 3.6).  And what that error does to pi_l: with the
+    reference-golden weights of `policy_dlg` -- whose heads are He-scaled, logits O(1), not the reference's gain-0.01 initialisation
+    -- the action logits computed from the HIP tower's embedding and from the oracle's embedding differ by <= 1e-3 of the logit
+    scale (measured 1.9e-3 on logits up to 2.35, i.e. 8e-4)."""
+    import numpy as np
+    import fixtures as fx
+    import restate as R
+    from conftest import param_specs
+    gen = torch.Generator().manual_seed(11)
+    tok = _tokens(24, gen)
+    pol = _policy("bf16x3", True)
+    assert pol._engine()["clip"].wstream and pol.prec_of("clip") == P.L.PREC_FP16
+    sd = {k: v.detach().cpu().clone() for k, v in pol.state_dict().items() if k.startswith("net.clip.")}
+    with torch.no_grad():
+        ref = R.clip_encode_text(sd, "net.clip", tok.cpu())
+    out = pol.net.encode_text(pol, tok).clone()
+    noproj = pol.net.encode_text(pol, tok, project=False).clone()
+    torch.cuda.synchronize()
+    scale = max(1.0, float(ref.abs().max()))
+    err = float((out.cpu() - ref).abs().max())
+    print(f"fp16 4-way tower vs oracle: max |diff| {err:.3e} on scale {scale:.3f} ({err / scale:.3e} of scale); rows {tuple(out.shape)}")
+    assert torch.isfinite(out).all() and torch.isfinite(noproj).all()
+    assert err < 5e-3 * scale, err
+    # --- induced error on pi_l's logits, reference-golden weights (tests/golden/policy_dlg) ---
+    specs = param_specs()
+    B, M, tag = 3, 3, "dlg"
+    torch.manual_seed(3)                                         # the CLIP tower keeps its seeded initialisation (no reference fixture holds it)
+    pl = P.AudioNavDialogPolicy(savi_observation_space((65, 26, 2)), ActionSpace(4), pretraining=False, num_steps=3,
+                                precision="bf16x3", **SMT_KW)
+    fsd = fx.state_dict_for({k: tuple(v) for k, v in specs["dialog"].items()})
+    assert not pl.load_state_dict(fsd, strict=False).unexpected_keys
+    pl.cuda()
+    obs = {k: v.cuda() for k, v in fx.observations(tag, B).items()}
+    mem, memd = fx.memory(tag, M, B, 276, 272).cuda(), fx.sym(tag + ".memd", (M, B, 256)).cuda()
+    mk = fx.mask_patterns(tag, B, M).cuda()
+    pa, act = fx.ints(tag + ".pa", (B, 1), 4).cuda(), fx.ints(tag + ".a", (B, 1), 4).cuda()
+    toks = fx.dialog_tokens(tag, B).cuda()
+    astep = fx.ints(tag + ".as", (B,), 3).float().cuda()
+    h0, ones = torch.zeros(1, B, 512, device="cuda"), torch.ones(B, 1, device="cuda")
+    hip = pl.evaluate_actions_dialog(obs, h0, pa, ones, act, mem, memd, mk, toks, astep)[6].clone()
+    csd = {k: v.detach().cpu() for k, v in pl.state_dict().items() if k.startswith("net.clip.")}
+    with torch.no_grad():
+        e_ref = R.clip_encode_text(csd, "net.clip", toks.cpu()).cuda()
+    pl.net.text_encoder_override = lambda t: e_ref
+    orc = pl.evaluate_actions_dialog(obs, h0, pa, ones, act, mem, memd, mk, toks, astep)[6].clone()
+    torch.cuda.synchronize()
+    dl = float((hip - orc).abs().max())
+    print(f"pi_l logits, HIP fp16 tower vs oracle embedding (fixture weights): max |diff| {dl:.3e} (logit scale {float(orc.abs().max()):.3f})")
+    assert dl < 1e-3 * max(1.0, float(orc.abs().max())), dl

@@ -41,6 +41,26 @@ CASES = [("bf16", True, False), ("bf16", False, False), ("fp32", True, False), (
 
 @pytest.mark.parametrize("precision,pre,distractor", CASES)
 def test_benched_harness_matches_oracle(precision, pre, distractor):
+    _harness_case(precision, pre, distractor)
+
+
+def test_benched_harness_mixed_backward_update_matches_oracle():
+    """bf16x3 at scale runs the SMT BACKWARD on plain bf16 operands (from `avlen_set_x3_mixed_backward_rows` token rows on, 64 k by
+    default: every real 2nd-stage minibatch; the forward -- logits, ratio, losses -- stays compensated).  Forced here from the
+    first row, on the large-M GEMM route it belongs to: the same rollout + PPO.update against the oracle; the parameter step of the
+    whole update (2 epochs x 2 minibatches through Adam) stays within 3e-2 relative L2 of the oracle's (measured 1.0e-2; the
+    compensated backward: 2.4e-3 measured, 1e-2 asserted above)."""
+    from avlen_amd import _lib as L
+    try:
+        L.lib.avlen_set_big_m(32)
+        L.lib.avlen_set_x3_mixed_backward_rows(1)
+        _harness_case("bf16x3", False, False, step_tol=3e-2)
+    finally:
+        L.lib.avlen_set_big_m(0)
+        L.lib.avlen_set_x3_mixed_backward_rows(-1)
+
+
+def _harness_case(precision, pre, distractor, step_tol=None):
     N, T, CAP = 4, 5, 3
     bf = precision == "bf16"
     wl = Workload(N, T, spectrogram=(257, 101, 2), precision=precision, pretraining=pre, em_capacity=CAP, seed=3,
@@ -127,7 +147,7 @@ def test_benched_harness_matches_oracle(precision, pre, distractor):
         den += float((d_ref ** 2).sum())
     rel = (num / den) ** 0.5
     print(f"parameter step: relative L2 difference {rel:.3g} over {len(sd0)} trained tensors")
-    assert den > 0 and rel < (0.35 if bf else 2e-2), rel
+    assert den > 0 and rel < (step_tol if step_tol is not None else (0.35 if bf else (1e-2 if precision == "bf16x3" else 2e-2))), rel
     # encoders are not touched by the update (policy.py:1035-1036)
     k = "net.visual_encoder.rgb_encoder.conv1.weight"
     assert torch.equal(new[k], sd_q[k])

@@ -55,6 +55,21 @@ def close(a, b, **kw):
     np.testing.assert_allclose(a.detach().float().cpu().numpy() if torch.is_tensor(a) else a, b, **tol)
 
 
+def close_row(row, gold, precision):
+    """The memory row [visual 128 | action 16 | audio 128 | pose 4 | ...] a policy hands to the storage.  fp32: 1e-3 everywhere.
+    bf16x3: the compensated-bf16 columns (towers: measured 2e-4 absolute on features up to 5.8) at the same 1e-3; the AudioCNN's
+    128 columns run on fp16 operands in this mode (policy._MODE_MODULES) and sit at 6e-4 of the feature SCALE (measured 5.8e-3
+    absolute on features up to 9.1, tools/row_probe.py): held to 1e-3 of the scale.  The logits / values computed from the row
+    meet 1e-3 absolutely (asserted by the callers)."""
+    if precision == "fp32":
+        return close(row, gold)
+    r = row.detach().float().cpu().numpy()
+    close(r[:, :144], gold[:, :144]); close(r[:, 272:], gold[:, 272:])
+    scale = max(1.0, float(np.abs(gold[:, 144:272]).max()))
+    err = float(np.abs(r[:, 144:272] - gold[:, 144:272]).max())
+    assert err < 1e-3 * scale, (err, scale)
+
+
 @pytest.fixture(scope="module")
 def specs():
     return param_specs()
@@ -93,11 +108,15 @@ def test_audio_encoder_257_bf16_superpixel_conv(specs):
     assert err < 2e-2, err
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("pre", [True, False])
 @pytest.mark.parametrize("M", [4, 300])
-def test_option_policy_matches_reference(specs, pre, M):
+def test_option_policy_matches_reference(specs, pre, M, precision):
+    """fp32 = the parity mode; bf16x3 = the BENCHED mode (compensated bf16 towers and SMT encoder, fp16 AudioCNN), held to the
+    same goldens of the reference at the same 1e-3 -- at the full 300-slot memory too (301-token softmax, compensated GEMMs over
+    301 * B rows) -- and to the reference's sampled actions for the fixed seed."""
     B = 3
-    pol = build("option", pretraining=pre)
+    pol = build("option", precision=precision, pretraining=pre)
     load_fixture(pol, "option", specs)
     pol.cuda()
     tag = f"opt_p{int(pre)}_m{M}"
@@ -109,7 +128,7 @@ def test_option_policy_matches_reference(specs, pre, M):
     h0, ones = torch.zeros(1, B, 512, device="cuda"), torch.ones(B, 1, device="cuda")
     v, u, lp, ent, _, row, probs = pol.evaluate_actions_option(obs, h0, pa, ones, act, mem, mk, qs, lqi)
     close(v, g["value"]); close(u, g["unct"]); close(lp, g["log_prob"]); close(ent, g["entropy"])
-    close(probs, g["probs"]); close(row, g["row"])
+    close(probs, g["probs"]); close_row(row, g["row"], precision)
     torch.manual_seed(1234)
     v2, u2, a2, lp2, _, row2, probs2 = pol.act_option(obs, h0, pa, ones, mem, mk, qs, lqi)
     assert np.array_equal(a2.cpu().numpy(), g["sampled"])            # bit-exact sampling for the fixed seed
@@ -222,10 +241,11 @@ def test_option_distractor(specs):
     close(v, g["value"]); close(probs, g["probs"]); close(row, g["row"]); close(lp, g["log_prob"]); close(u, g["unct"])
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("M", [4, 300])
-def test_goal_policy_matches_reference(specs, M):
+def test_goal_policy_matches_reference(specs, M, precision):
     B = 3
-    pol = build("goal")
+    pol = build("goal", precision=precision)
     load_fixture(pol, "goal", specs)
     pol.cuda()
     tag = f"goal_m{M}"
@@ -235,7 +255,7 @@ def test_goal_policy_matches_reference(specs, M):
     pa, act = fx.ints(tag + ".pa", (B, 1), 4).cuda(), fx.ints(tag + ".a", (B, 1), 4).cuda()
     h0, ones = torch.zeros(1, B, 512, device="cuda"), torch.ones(B, 1, device="cuda")
     v, lp, ent, _, row = pol.evaluate_actions(obs, h0, pa, ones, act, mem, mk)
-    close(v, g["value"]); close(lp, g["log_prob"]); close(ent, g["entropy"]); close(row, g["row"])
+    close(v, g["value"]); close(lp, g["log_prob"]); close(ent, g["entropy"]); close_row(row, g["row"], precision)
     torch.manual_seed(77)
     v2, a2, lp2, _, row2, probs = pol.act(obs, h0, pa, ones, mem, mk)
     close(probs, g["probs"])
@@ -393,6 +413,24 @@ def test_full_cycle_matches_reference(specs, pre):
         d_ours = (sd[name][:4, :8] - sd0[name][:4, :8]).numpy()
         d_ref = gold - sd0[name][:4, :8].numpy()
         np.testing.assert_allclose(d_ours, d_ref, rtol=5e-2, atol=2e-5)
+    # ... and the step of EVERY trained tensor: norm and signed weighted checksum against the reference's (2 epochs x 2 minibatches
+    # through Adam on the HIP path; fp32 mode)
+    print("cycle pre=%s: worst per-tensor step error (norm / signed checksum, relative to the step's norm): %.3g"
+          % (pre, _check_step(sd, sd0, keys, g, 5e-3)))
+
+
+def _check_step(post, pre, keys, g, tol):
+    """tests/test_oracle_vs_golden.py::check_step for the HIP path."""
+    l2, chk = fx.delta_stats(post, pre, keys)
+    worst = 0.0
+    for k, a, c, ga, gc in zip(keys, l2, chk, g["delta_l2"], g["delta_chk"]):
+        if ga == 0.0:
+            assert a == 0.0, (k, a)                     # untouched by the reference: encoders, unused heads
+            continue
+        e = max(abs(a - ga), abs(c - gc)) / ga
+        worst = max(worst, e)
+        assert e < tol, (k, a, ga, c, gc)
+    return worst
 
 
 def test_gradients_match_oracle_autograd(specs):
@@ -481,11 +519,64 @@ def test_gradients_bf16x3_mixed_backward_at_scale(specs):
             continue
         err = float((a - b).norm() / a.norm())
         worst = max(worst, err)
-        assert err < 0.1, (k, err)
+        assert err < 2e-2, (k, err)
     print("bf16x3 mixed-precision backward vs compensated backward on the same saved forward, max relative L2 difference:", worst)
 
 
-def _gradient_check(specs, precision, tol, loss_rtol=1e-3, rerun_bwd=None):
+# bf16x3 gradients against torch autograd on the oracle (fp32), per tensor class; metric: max |ours - ref| / max |ref| of a tensor
+# (and its relative L2).  Measured on the (B = 6, M = 9) case below (profiles/r05_gpu_parity_tests.log):
+#   * "smooth" -- the heads, the whole decoder layer and the encoder's linear2 / norm2 / final norm: <= 4.2e-4 with the compensated
+#     backward (the forward's features carry the compensated towers' ~2e-4), <= 3.8e-3 with the mixed (plain-bf16 products) backward;
+#   * "encoder_side" -- every tensor whose gradient passes the ENCODER layer's ReLU over the (M + 1) * B memory-token rows, in
+#     backward order: encoder linear1, norm1, self-attention, the fusion MLP, the pose encoder: 0.6 .. 1.4e-2 relative L2, up to
+#     5.2e-2 on single elements, the same on the staged, the large-M and the mixed route (so it is a property of the saved
+#     forward, not of the backward's products).  The towers' rounding does not explain it (perturbing the oracle's feature columns
+#     by 2e-4 of scale moves these tensors by 1.5e-3: oracle-side experiment), a few elements dominate (max error 4x the L2
+#     error): pre-activations within the forward's rounding of zero take the other branch of relu'.  The whole update through Adam
+#     is held to the oracle's parameter step by tests/test_gpu_harness_parity.py (2.4e-3 compensated, 1.0e-2 mixed).
+#   The cancelling-sum biases (pose encoder bias; the attention K bias inside in_proj_bias, whose analytic gradient is zero) belong
+#   to the encoder side and need no bound of their own at this size.
+_X3_GRAD_BOUNDS = {"smooth": (2e-3, 2e-3), "encoder_side": (8e-2, 3e-2)}            # class -> (max-relative, relative L2)
+_X3_MIXED_GRAD_BOUNDS = {"smooth": (1e-2, 1e-2), "encoder_side": (8e-2, 3e-2)}
+_ENCODER_SIDE = ("fusion_encoder.", "pose_encoder.", "encoder.layers.0.linear1.", "encoder.layers.0.norm1.",
+                 "encoder.layers.0.self_attn.")
+
+
+def _grad_class(name):
+    return "encoder_side" if any(t in name for t in _ENCODER_SIDE) else "smooth"
+
+
+@pytest.mark.parametrize("route", ["staged", "large_m", "mixed"])
+def test_gradients_bf16x3_vs_oracle_autograd_per_class(specs, route):
+    """The benched mode's training gradient held to the oracle's autograd, per tensor class (bounds above): the staged compensated
+    backward, the large-M compensated route (forced from 32 rows) and the mixed backward (plain bf16 products in the backward
+    from `avlen_set_x3_mixed_backward_rows` rows on: forced from 1 row)."""
+    from avlen_amd import _lib as L
+    bounds = _X3_MIXED_GRAD_BOUNDS if route == "mixed" else _X3_GRAD_BOUNDS
+    rep = {}
+    try:
+        if route != "staged":
+            L.lib.avlen_set_big_m(32)
+        if route == "mixed":
+            L.lib.avlen_set_x3_mixed_backward_rows(1)
+        _gradient_check(specs, "bf16x3", lambda k: float("inf"), loss_rtol=2e-3, report=rep)
+    finally:
+        L.lib.avlen_set_big_m(0)
+        L.lib.avlen_set_x3_mixed_backward_rows(-1)
+    worst = {}
+    for k, (emax, el2, nref) in sorted(rep.items()):
+        c = _grad_class(k)
+        worst[c] = max(worst.get(c, 0.0), emax)
+        print(f"  {route:8s} {c:12s} max-rel {emax:9.3e}  rel-L2 {el2:9.3e}  |ref| {nref:9.3e}  {k}")
+    print(f"bf16x3 ({route}) gradient vs oracle autograd, worst per class: {worst}")
+    for k, (emax, el2, nref) in rep.items():
+        bm, bl = bounds[_grad_class(k)]
+        assert emax < bm and el2 < bl, (route, k, emax, el2, bm, bl)
+
+
+def _gradient_check(specs, precision, tol, loss_rtol=1e-3, rerun_bwd=None, report=None):
+    """tol: one bound on max |ours - ref| / max |ref| for every trained tensor, or a callable name -> bound.
+    report (dict): filled with name -> (max-relative error, relative L2 error, ||ref||) against the oracle's autograd."""
     import flow
     B, M = 6, 9
     pre = False
@@ -539,7 +630,9 @@ def _gradient_check(specs, precision, tol, loss_rtol=1e-3, rerun_bwd=None):
         ref = osd[k].grad.double()
         err = float((ours - ref).abs().max() / (ref.abs().max() + 1e-8))
         worst = max(worst, err)
-        assert err < tol, (k, err)
+        if report is not None:
+            report[k] = (err, float((ours - ref).norm() / (ref.norm() + 1e-30)), float(ref.norm()))
+        assert err < (tol(k) if callable(tol) else tol), (k, err)
         out_grads[k] = ours
     print("max relative gradient error over trained params:", worst)
     if rerun_bwd is not None:
@@ -705,3 +798,5 @@ def test_full_cycle_distractor_matches_reference(specs):
     pabs = np.array([float(sd[k].double().abs().sum()) for k in keys])
     np.testing.assert_allclose(pabs, g["param_abs"], rtol=2e-5)
     close(sd["net.smt_state_encoder.fusion_encoder.0.weight"][:4, 270:300], g["fusion0_w"], rtol=2e-3, atol=2e-5)
+    sd0 = fx.state_dict_for({k: tuple(v) for k, v in specs["option_distractor"].items()})
+    print("cycle_dis: worst per-tensor step error: %.3g" % _check_step(sd, sd0, keys, g, 5e-3))

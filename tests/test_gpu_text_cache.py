@@ -203,14 +203,13 @@ def test_encoders_started_before_insert_equal_the_plain_order():
     """`Policy.prefetch_encoders(new_obs)` right before `rollouts.insert(new_obs, ...)` (the towers hide the storage bookkeeping and
     the next step's launch path) against the plain order: same storage bit for bit over a rollout, the wrap-around and the update's
     `get_value_option`."""
-    import os
     N, T = 4, 5
     snaps = []
-    try:
-        for early in ("1", "0"):
-            os.environ["AVLEN_EARLY_ENC"] = early
+    if True:
+        for early in (True, False):
             wl = _run(N, T, precision="bf16x3")
-            assert wl._early_enc == (early == "1")
+            assert wl._early_enc
+            wl._early_enc = early
             for _ in range(T):
                 wl.rollout_step()
             ro = wl.rollouts
@@ -224,8 +223,6 @@ def test_encoders_started_before_insert_equal_the_plain_order():
             torch.cuda.synchronize()
             snaps.append((_storage_snapshot(wl), nv))
             del wl
-    finally:
-        os.environ.pop("AVLEN_EARLY_ENC", None)
     (a, va), (b, vb) = snaps
     assert torch.equal(va, vb)
     for k in a:
@@ -236,14 +233,13 @@ def test_actions_selected_on_the_host_equal_the_device_select():
     """sampling="race": the step's actions for the simulator are selected on the host from the three policies' pinned copies
     (`Policy.host_actions`); the device-side select feeds the storage later.  Both must be the device select of the plain order,
     step by step, over a rollout, the wrap-around and beyond."""
-    import os
     N, T = 4, 5
     snaps = []
-    try:
-        for sel in ("1", "0"):
-            os.environ["AVLEN_HOST_SELECT"] = sel
+    if True:
+        for sel in (True, False):
             wl = _run(N, T, precision="bf16x3")
-            assert wl._host_select == (sel == "1") and wl.sampling == "race"
+            assert wl._host_select and wl.sampling == "race"
+            wl._host_select = sel
             host = []
             for i in range(T + 2):
                 if i == T:
@@ -255,8 +251,6 @@ def test_actions_selected_on_the_host_equal_the_device_select():
                 assert torch.equal(host[-1], wl.rollouts.actions[t].cpu()), (sel, i)       # what the simulator got == what was stored
             snaps.append((_storage_snapshot(wl), host))
             del wl
-    finally:
-        os.environ.pop("AVLEN_HOST_SELECT", None)
     (a, ha), (b, hb) = snaps
     for x, y in zip(ha, hb):
         assert torch.equal(x, y)
@@ -267,17 +261,17 @@ def test_actions_selected_on_the_host_equal_the_device_select():
 def test_storage_writes_on_the_side_stream_equal_the_plain_order():
     """The step's storage writes (device-side action select + insert) on a side stream beside the next step's towers against the
     same writes on the caller's stream: same storage bit for bit over a rollout, the update's value call, the wrap-around."""
-    import os
     N, T = 4, 5
     snaps = []
-    try:
-        for side in ("1", "0"):
-            os.environ["AVLEN_SMALL_STREAM"] = side
+    if True:
+        for side in (True, False):
             wl = _run(N, T, precision="bf16x3")
-            assert (wl._small is not None) == (side == "1")
+            assert wl._small is not None
+            if not side:
+                wl._small = None
             for _ in range(T):
                 wl.rollout_step()
-            assert wl._small_pending == (side == "1")
+            assert wl._small_pending == side
             wl._join_small()
             ro = wl.rollouts
             last = {k: v[ro.step] for k, v in ro.observations.items()}
@@ -290,37 +284,38 @@ def test_storage_writes_on_the_side_stream_equal_the_plain_order():
             torch.cuda.synchronize()
             snaps.append((_storage_snapshot(wl), nv))
             del wl
-    finally:
-        os.environ.pop("AVLEN_SMALL_STREAM", None)
     (a, va), (b, vb) = snaps
     assert torch.equal(va, vb)
     for k in a:
         assert torch.equal(a[k], b[k]), k
 
 
-def test_stream_placement_of_the_followers_does_not_change_the_storage():
-    """pi_l's state-encoder half on pi_g's stream ("side", the default below 48 envs) or on its own ("own", the default when the text
-    tower fills the chip): scheduling only -- the storage after a rollout, the wrap-around and three more steps is bit-equal."""
-    import os
+def test_sequencer_command_lists_equal_the_python_launch_ahead_flow():
+    """avlen_amd/sequencer.py: after one pass through `prefetch_act_option` / `prefetch_act` / `prefetch_act_dialog` / `dialog_ready`
+    per set of argument buffers, a step's launches are two recorded command lists run by `avlen_cmds_run`.  Scheduling only: the
+    storage after two rollouts (the second one entirely on the recorded lists), the wrap-around in between, the sampled actions
+    and the host generator's end state equal the Python flow's bit for bit."""
     N, T = 4, 5
     snaps = []
-    try:
-        for where in ("side", "own"):
-            os.environ["AVLEN_L_STREAM"] = where
-            wl = _run(N, T, precision="bf16x3")
-            assert wl._l_where == where and (wl._small is None) == (where == "own")
-            for i in range(T + 3):
-                if i == T:
-                    wl._join_small()
-                    wl.rollouts.after_update()
-                wl.rollout_step()
-            wl._join_small()
-            torch.cuda.synchronize()
-            snaps.append(_storage_snapshot(wl))
-            del wl
-    finally:
-        os.environ.pop("AVLEN_L_STREAM", None)
-    a, b = snaps
+    for use_seq in (True, False):
+        wl = _run(N, T, precision="bf16x3")
+        assert wl.seq is not None
+        seq = wl.seq
+        if not use_seq:
+            wl.seq = None
+        for i in range(2 * T + 2):
+            if i in (T, 2 * T):
+                wl._join_small()
+                wl.rollouts.after_update()
+            wl.rollout_step()
+        wl._join_small()
+        torch.cuda.synchronize()
+        snaps.append((_storage_snapshot(wl), torch.get_rng_state().clone()))
+        if use_seq:
+            assert seq.slow == T and seq.fast == T + 2, (seq.slow, seq.fast)     # every step slot recorded once, then replayed
+        del wl
+    (a, ra), (b, rb) = snaps
+    assert torch.equal(ra, rb)
     for k in a:
         assert torch.equal(a[k], b[k]), k
 
@@ -329,18 +324,18 @@ def test_one_line_integration_with_the_storage_hook_equals_without():
     """`share_encoders(pi_q, pi_g, pi_l, rollouts=rollouts)`: `rollouts.insert(batch, ...)` starts the next step's shared encoders on
     the batch it is given.  Plain act* calls, no prefetch_* anywhere: same storage bit for bit as without the hook over a rollout,
     the update's value call, the wrap-around."""
-    import os
     N, T = 4, 5
     snaps = []
-    try:
-        for hook in ("1", "0"):
-            os.environ["AVLEN_INSERT_HOOK"] = hook
+    if True:
+        for hook in (True, False):
             wl = _run(N, T, precision="bf16x3", launch_ahead=False)
-            assert (wl.rollouts._enc_leader is not None) == (hook == "1")
+            assert wl.rollouts._enc_leader is wl.pi_q
+            if not hook:
+                wl.rollouts._enc_leader = None
             for _ in range(T):
                 wl.rollout_step()
             ro = wl.rollouts
-            assert (wl.pi_q._enc_early is not None) == (hook == "1")             # the last insert started slot T's encoders
+            assert (wl.pi_q._enc_early is not None) == hook                    # the last insert started slot T's encoders
             last = {k: v[ro.step] for k, v in ro.observations.items()}
             nv = wl.pi_q.get_value_option(last, ro.recurrent_hidden_states[ro.step], ro.prev_actions[ro.step], ro.masks[ro.step],
                                           ro.external_memory_option[:, ro.step], ro.external_memory_masks[ro.step],
@@ -351,9 +346,73 @@ def test_one_line_integration_with_the_storage_hook_equals_without():
             torch.cuda.synchronize()
             snaps.append((_storage_snapshot(wl), nv))
             del wl
-    finally:
-        os.environ.pop("AVLEN_INSERT_HOOK", None)
     (a, va), (b, vb) = snaps
     assert torch.equal(va, vb)
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("mode", ["bf16x3"])
+def test_replayed_graph_follows_a_clip_weight_change(mode):
+    """a plain act_dialog with use_graphs=True and no prefetch captures the MEMOISED tower inside the forward graph; the
+    replay must not hand out embeddings computed with the old CLIP weights for rows whose tokens did not change."""
+    import json
+    import os
+    import fixtures as fx
+    torch.manual_seed(4)
+    pol = P.AudioNavDialogPolicy(savi_observation_space((65, 26, 2)), ActionSpace(4), pretraining=False, num_steps=3, precision=mode,
+                                 use_graphs=True, **SMT_KW).to("cuda")
+    B, dev = 3, "cuda"
+    gen = torch.Generator().manual_seed(11)
+    obs = {k: v.to(dev) for k, v in fx.observations("tc", B).items()}
+    prev = torch.zeros(B, 1, dtype=torch.long, device=dev)
+    mem, memd = torch.zeros(3, B, 276, device=dev), torch.zeros(3, B, 256, device=dev)
+    mk = torch.zeros(B, 3, device=dev)
+    tok = torch.stack([_dialog(gen, 12), torch.zeros(77, dtype=torch.long), _dialog(gen, 40)]).to(dev)
+    astep = torch.zeros(B, device=dev)
+    call = lambda p: [t.clone() for t in p.act_dialog(obs, None, prev, mk[:, :1], mem, memd, mk, tok, astep, deterministic=True)
+                      if torch.is_tensor(t)]
+    first = call(pol)
+    again = call(pol)                                            # replay: every row comes out of the memo
+    assert all(torch.equal(a, b) for a, b in zip(first, again))
+    with torch.no_grad():                                        # "a checkpoint with another CLIP tower"
+        sd = {k: v.clone() for k, v in pol.state_dict().items()}
+        for k in sd:
+            if k.startswith("net.clip.transformer.resblocks.5.") or k == "net.clip.ln_final.bias":
+                sd[k] = sd[k] + 0.02 * torch.randn(sd[k].shape, generator=gen).to(dev)
+    pol.load_state_dict(sd)
+    moved = call(pol)                                            # same tokens, same graph
+    torch.cuda.synchronize()
+    fresh = P.AudioNavDialogPolicy(savi_observation_space((65, 26, 2)), ActionSpace(4), pretraining=False, num_steps=3,
+                                   precision=mode, use_graphs=False, **SMT_KW).to("cuda")
+    fresh.load_state_dict(sd)
+    fresh.net.text_cache = False                                 # the uncached tower, eager
+    want = call(fresh)
+    torch.cuda.synchronize()
+    assert not torch.equal(moved[0], first[0])
+    for a, b in zip(moved, want):
+        assert torch.equal(a, b), float((a.float() - b.float()).abs().max())
+
+
+def test_deterministic_follower_under_auto_ahead_keeps_the_host_generator_in_step():
+    """the eval loop samples pi_q and pi_g but calls act_dialog(deterministic=True) (ppo_trainer.py:1917-2156), which
+    consumes no generator state.  With sampling="race" and the automatic launch-ahead, no speculative draw may be left behind:
+    the sampled actions and the generator's end state equal the plain host-sampling flow without any launch-ahead."""
+    import functools
+    N, T = 4, 7
+    res = []
+    for kw in (dict(sampling="race", share_encoders=True, launch_ahead=False),
+               dict(sampling="host", share_encoders=False, launch_ahead=False)):
+        wl = _run(N, T, precision="bf16x3", **kw)
+        wl.pi_l.act_dialog = functools.partial(wl.pi_l.act_dialog, deterministic=True)
+        for _ in range(T):
+            wl.rollout_step()
+        torch.cuda.synchronize()
+        grp = wl.pi_q._enc_group
+        res.append((wl.rollouts.actions_option.clone(), wl.rollouts.actions.clone(), torch.get_rng_state().clone(),
+                    None if grp is None else (grp.auto_hits, grp.auto_misses)))
+        del wl
+    (q0, a0, r0, auto), (q1, a1, r1, _) = res
+    assert auto is not None and auto[0] >= 2 * (T - 3), auto          # the followers really were launched ahead
+    assert torch.equal(q0, q1) and torch.equal(a0, a1)
+    assert torch.equal(r0, r1), "the host generator drifted: a speculative draw for a deterministic call was not undone"

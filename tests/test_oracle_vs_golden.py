@@ -206,6 +206,23 @@ def test_full_cycle(specs, pre):
     np.testing.assert_allclose(psum, g["param_sum"], rtol=1e-3, atol=2e-3)
     close(sd["net.smt_state_encoder.fusion_encoder.2.weight"][:4, :8], g["fusion2_w"], rtol=1e-4, atol=1e-6)
     close(sd["critic_option.fc.weight"], g["critic_w"], rtol=1e-4, atol=1e-6)
+    check_step(sd, sd_for(specs, "option"), keys, g, 2e-3)
+
+
+def check_step(post, pre, keys, g, tol):
+    """The parameter step of EVERY tensor against the reference's (goldens `delta_l2`, `delta_chk`: fixtures.delta_stats): its
+    norm within `tol` (relative) and its signed weighted checksum within tol * norm; tensors the reference left untouched
+    (encoders, unused heads) must not have moved at all."""
+    l2, chk = fx.delta_stats(post, pre, keys)
+    worst = 0.0
+    for k, a, c, ga, gc in zip(keys, l2, chk, g["delta_l2"], g["delta_chk"]):
+        if ga == 0.0:
+            assert a == 0.0, (k, a)
+            continue
+        e = max(abs(a - ga), abs(c - gc)) / ga
+        worst = max(worst, e)
+        assert e < tol, (k, a, ga, c, gc)
+    return worst
 
 
 def test_param_counts(specs):
