@@ -226,11 +226,13 @@ SIGNATURES = {
     "avlen_set_x3_mixed_backward_rows": (None, [C.c_long]),
     "avlen_set_tower_x3_reserved_cus": (None, [i32]),
     "avlen_set_clip_tower_split4_wgs": (None, [i32]),
+    "avlen_set_chain_one_xcd": (None, [i32]),
     "avlen_minibatch_gather": (i32, [vp, vp, vp, i32, i32, i32, sz, i32, vp]),
     "avlen_copy_rows": (i32, [vp, i32, vp, i32, i32, i32, vp]),
     "avlen_gather_rows": (i32, [vp, i32, vp, vp, i32, i32, i32, vp]),
     "avlen_multi_copy": (i32, [vp, vp, vp, i32, vp]),
     "avlen_cmds_run": (i32, [vp, i32]),
+    "avlen_prefetch_l2": (i32, [vp, vp, i32, vp]),
     "avlen_ln_fold_weights": (i32, [vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, vp]),
     "avlen_ln_fold_weights_h16": (i32, [vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, vp]),
     "avlen_build_info": (C.c_char_p, []),

@@ -77,9 +77,15 @@ __device__ __forceinline__ void bar() {
   __builtin_amdgcn_s_barrier();
 }
 
+// XS = log2 of the grid's stride between WORKING blocks: with XS = 3 only every 8th block of the grid works (the others return at
+// once), so that -- blocks being dealt round-robin over the 8 XCDs -- all working blocks sit on ONE XCD and stream the program's
+// weights out of that XCD's L2 after the first of them has missed, instead of eight L2s each fetching all of it from the fabric
+// (placement is a speed assumption only: MI355X_MICROARCH.md, Workgroup dispatch).
 template <bool X3>
-__global__ __launch_bounds__(NTH) void chain_kernel(DevProg kprog, int B) {
+__global__ __launch_bounds__(NTH) void chain_kernel(DevProg kprog, int B, int XS) {
   constexpr int RB = X3 ? 8 : 16;                                            // batch rows per block
+  if (blockIdx.x & ((1u << XS) - 1)) return;
+  const int blk = blockIdx.x >> XS;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* ring = lds;                                                          // [NS][256][128 B]
   bf16* xs = reinterpret_cast<bf16*>(lds + NS * TILE_BYTES);                 // [NIMG][RB][XLD] (X3: hi planes, then the lo planes)
@@ -90,7 +96,7 @@ __global__ __launch_bounds__(NTH) void chain_kernel(DevProg kprog, int B) {
   float* par = reinterpret_cast<float*>(lds + NS * TILE_BYTES + XS_BYTES + RED_BYTES + ATT_BYTES + PROG_BYTES);   // [MAX_PAR][256]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, q = lane >> 4;
   const int cr = c & (RB - 1);                         // X3: lanes 8..15 mirror rows 0..7 (their results are never stored)
-  const int row = blockIdx.x * RB + cr;                // this lane's batch row
+  const int row = blk * RB + cr;                // this lane's batch row
   const bool rok = c < RB && row < B;
   const int n0 = wave * 16;
 
@@ -151,8 +157,15 @@ __global__ __launch_bounds__(NTH) void chain_kernel(DevProg kprog, int B) {
       const long off = ((long)frow * ldl.ld + kcol) * 2;
       const bool ok = kcol < ldl.k;
       const char* zp = (const char*)g_zero_page_ch + tid * 16;
+#if defined(AVLEN_CHAIN_LAB) && AVLEN_CHAIN_LAB == 4
+      // lab: what a pre-packed stream would cost -- each piece ONE contiguous KiB (8 whole lines) instead of 16 half lines
+      const long offc = ((long)n0 * ldl.ld) * 2 + (long)ld_kt * 1024 + lane * 16;
+      __builtin_amdgcn_global_load_lds((const void*)(ldl.w + offc), (__attribute__((address_space(3))) void*)(stage), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const void*)(ldl.wl + offc), (__attribute__((address_space(3))) void*)(stage + 1024), 16, 0, 0);
+#else
       __builtin_amdgcn_global_load_lds((const void*)(ok ? ldl.w + off : zp), (__attribute__((address_space(3))) void*)(stage), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((const void*)(ok ? ldl.wl + off : zp), (__attribute__((address_space(3))) void*)(stage + 1024), 16, 0, 0);
+#endif
     } else {
 #pragma unroll
     for (int r = 0; r < 2; r++) {
@@ -172,7 +185,7 @@ __global__ __launch_bounds__(NTH) void chain_kernel(DevProg kprog, int B) {
   for (int s = 0; s < n_ops; s++) {
     const DevOp nxt_op = sp->op[s + 1 < n_ops ? s + 1 : s];        // next step's descriptor: in flight during this step
 #ifdef AVLEN_CHAIN_LAB
-    if (tid == 0 && blockIdx.x == 0) g_chain_stamps[s] = clock64();
+    if (tid == 0 && blk == 0) g_chain_stamps[s] = clock64();
 #endif
     switch (op.kind) {
       case AVLEN_CH_LOAD_X16: {                        // bf16 global rows [B][ld] -> xs[buf][.][0:K)
@@ -182,7 +195,7 @@ __global__ __launch_bounds__(NTH) void chain_kernel(DevProg kprog, int B) {
         const int cpr = X3 ? ((op.k + 31) >> 5) << 2 : ((op.k + 63) >> 6) << 3;   // 16-byte chunks per row, zero-filled up to a whole k block (32 / 64 wide)
         for (int i = tid; i < RB * cpr; i += NTH) {
           int rr = i / cpr, ch = i - rr * cpr;
-          int gr = blockIdx.x * RB + rr;
+          int gr = blk * RB + rr;
           uint4 v = make_uint4(0, 0, 0, 0), vl = v;
           if (gr < B && ch * 8 < op.k) {
             v = *reinterpret_cast<const uint4*>(src + (long)gr * op.ld + ch * 8);
@@ -339,7 +352,7 @@ __global__ __launch_bounds__(NTH) void chain_kernel(DevProg kprog, int B) {
         const float4 pb = *reinterpret_cast<const float4*>(&att[((wave | 1) * 16 + cr) * 4]);
         float sc[4] = {pa.x + pb.x, pa.y + pb.y, pa.z + pb.z, pa.w + pb.w};
         const float* km = (const float*)op.p0;
-        const long grp = (long)(blockIdx.x * RB + cr) / S;
+        const long grp = (long)(blk * RB + cr) / S;
         float mx = -INFINITY;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -388,11 +401,14 @@ __global__ __launch_bounds__(NTH) void chain_kernel(DevProg kprog, int B) {
     op = nxt_op;
   }
 #ifdef AVLEN_CHAIN_LAB
-  if (tid == 0 && blockIdx.x == 0) g_chain_stamps[n_ops] = clock64();
+  if (tid == 0 && blk == 0) g_chain_stamps[n_ops] = clock64();
 #endif
 }
 
 }  // namespace
+
+static int g_chain_one_xcd = 1;
+extern "C" void avlen_set_chain_one_xcd(int on) { g_chain_one_xcd = on ? 1 : 0; }
 
 int avlen_chain_run(const avlen_chain* prog, int B, hipStream_t stream, int x3) {
   if (!prog || prog->n < 1 || prog->n > AVLEN_CHAIN_MAX_OPS || B <= 0) return AVLEN_ERR_ARG;
@@ -426,7 +442,10 @@ int avlen_chain_run(const avlen_chain* prog, int B, hipStream_t stream, int x3) 
   static unsigned long long done0 = 0, done1 = 0;
   if (avlen_set_dyn_lds(reinterpret_cast<const void*>(&chain_kernel<false>), LDS_BYTES, &done0) != AVLEN_OK ||
       avlen_set_dyn_lds(reinterpret_cast<const void*>(&chain_kernel<true>), LDS_BYTES, &done1) != AVLEN_OK) return AVLEN_ERR_LAUNCH;
-  if (x3) hipLaunchKernelGGL(chain_kernel<true>, dim3(ceil_div(B, 8)), dim3(NTH), LDS_BYTES, stream, dp, B);
-  else hipLaunchKernelGGL(chain_kernel<false>, dim3(ceil_div(B, 16)), dim3(NTH), LDS_BYTES, stream, dp, B);
+  // up to 32 working blocks fit one XCD (32 CUs, one 160 KB block each); larger batches use the plain grid
+  const int nblk = ceil_div(B, x3 ? 8 : 16);
+  const int xs = (g_chain_one_xcd && nblk > 1 && nblk <= 32) ? 3 : 0;
+  if (x3) hipLaunchKernelGGL(chain_kernel<true>, dim3(nblk << xs), dim3(NTH), LDS_BYTES, stream, dp, B, xs);
+  else hipLaunchKernelGGL(chain_kernel<false>, dim3(nblk << xs), dim3(NTH), LDS_BYTES, stream, dp, B, xs);
   return avlen_launch_status();
 }

@@ -276,6 +276,49 @@ int avlen_zero_bytes(void* p, size_t bytes, hipStream_t stream) {
   return avlen_launch_status();
 }
 
+// L2 warm-up of weights a latency-bound kernel is about to stream (the fused row-batch chains, csrc/chain.hip: 8 .. 32 workgroups,
+// 64 KiB in flight each -- 62 us with the weights in the L2s, 97-100 us from HBM, tools/chain_lab.hip; in the rollout step they
+// run cold: the visual towers and the text tower have moved 3 GB through the caches since their last use).  Block b serves the XCD
+// it lands on (blocks are dealt round-robin over the 8 XCDs: b % 8 labels the XCD, b / 8 the slice), so EVERY XCD's L2 ends up
+// with every byte; the loads are plain (the lines stay), their values go nowhere.  Speed only: a wrong placement guess warms less.
+namespace {
+struct PrefetchArgs { const char* p[8]; long n16[8]; int n; };
+__global__ __launch_bounds__(256) void prefetch_l2_kernel(PrefetchArgs a, unsigned* __restrict__ sink) {
+  const int slices = gridDim.x >> 3, slice = blockIdx.x >> 3;
+  unsigned acc = 0;
+  for (int r = 0; r < a.n; r++) {
+    const uint4* src = reinterpret_cast<const uint4*>(a.p[r]);
+    const long per = (a.n16[r] + slices - 1) / slices, lo = per * slice, hi = lo + per < a.n16[r] ? lo + per : a.n16[r];
+    long i = lo + threadIdx.x;
+    for (; i + 3 * 256 < hi; i += 4 * 256) {              // four independent 16-byte loads in flight per lane
+      const uint4 v0 = src[i], v1 = src[i + 256], v2 = src[i + 512], v3 = src[i + 768];
+      acc ^= v0.x ^ v1.x ^ v2.x ^ v3.x;
+    }
+    for (; i < hi; i += 256) acc ^= src[i].x;
+  }
+  if (acc == 0x9e3779b9u && sink) *sink = acc;            // keeps the loads alive; practically never taken, harmless if it is
+}
+__device__ unsigned g_prefetch_sink;
+}  // namespace
+extern "C" int avlen_prefetch_l2(const void* const* ptrs, const int64_t* nbytes, int n, hipStream_t stream) {
+  if (n < 0 || n > 8 || (n > 0 && (!ptrs || !nbytes))) return AVLEN_ERR_ARG;
+  PrefetchArgs a = {};
+  long total = 0;
+  for (int i = 0; i < n; i++) {
+    if (!ptrs[i] || nbytes[i] < 0 || ((uintptr_t)ptrs[i] & 15)) return AVLEN_ERR_ARG;
+    a.p[a.n] = (const char*)ptrs[i]; a.n16[a.n] = nbytes[i] >> 4; total += a.n16[a.n]; a.n++;
+  }
+  if (total == 0) return AVLEN_OK;
+  static unsigned* sinks[64];                              // per device, looked up once (a symbol lookup per launch is microseconds)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return AVLEN_ERR_LAUNCH;
+  if (!sinks[dev] && hipGetSymbolAddress((void**)&sinks[dev], HIP_SYMBOL(g_prefetch_sink)) != hipSuccess) sinks[dev] = nullptr;
+  unsigned* sink = sinks[dev];
+  // 32 slices per XCD: a slice of a 5 MB set is ~10 wave-iterations of 4 KiB x 4
+  hipLaunchKernelGGL(prefetch_l2_kernel, dim3(8 * 32), dim3(256), 0, stream, a, sink);
+  return avlen_launch_status();
+}
+
 extern "C" int avlen_copy_rows(const float* src, int lds, float* dst, int ldd, int rows, int cols, hipStream_t stream) {
   hipLaunchKernelGGL(copy_rows_kernel, grid1d((long)rows * cols), dim3(256), 0, stream, src, lds, dst, ldd, rows, cols);
   return avlen_launch_status();

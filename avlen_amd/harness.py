@@ -9,6 +9,7 @@ HBM before timing starts ("simulator output").
 """
 import math
 import time
+import numpy as np
 import torch
 
 from . import policy as P
@@ -63,8 +64,8 @@ class Workload:
         # ONE set of side streams per process (policy.process_stream): the runtime maps streams to its 4 hardware queues in creation
         # order, so a second Workload with fresh streams can land pi_g's stream on the text tower's queue (seen as records of one
         # bench run that differ by 10 % for no other reason) -- and torch's stream pool wraps around after 32 creations
-        self._side = [P.process_stream("harness0"), P.process_stream("harness1"), P.process_stream("harness_text")] \
-            if launch_ahead else None
+        self._side = [P.process_stream("harness0"), P.process_stream("followers"), P.process_stream("harness_text")] \
+            if launch_ahead else None                   # [1] = EncoderGroup.side_stream(): the followers' (and the audio piece's) stream
         osp, asp = savi_observation_space(spectrogram), ActionSpace(4)
         torch.manual_seed(weight_seed)          # identical initial weights on every rank (data-parallel replicas)
         kw = dict(SMT_KW, precision=precision, sampling=sampling, use_graphs=use_graphs)
@@ -78,11 +79,12 @@ class Workload:
                                             **kw).to(self.dev) if with_dialog_policy else None)
         self.seq = None
         if share_encoders and precision in ("bf16", "bf16x3") and self.pi_g is not None and self.pi_l is not None:
-            P.share_encoders(self.pi_q, self.pi_g, self.pi_l)
+            grp = P.share_encoders(self.pi_q, self.pi_g, self.pi_l)
+            assert self._side is None or self._side[1] is grp.side_stream()
             if launch_ahead and use_graphs and sampling == "race" and dialog_tokens == "after_option":
                 # the step's launch-ahead calls as recorded command lists (one C call per phase): avlen_amd/sequencer.py
                 from .sequencer import StepSequencer
-                self.seq = StepSequencer(self.pi_q, self.pi_g, self.pi_l, self._side[1])
+                self.seq = StepSequencer(self.pi_q, self.pi_g, self.pi_l)
         self.agent = DDPPO(self.pi_q, clip_param=0.2, ppo_epoch=ppo_epoch, num_mini_batch=num_mini_batch,
                            value_loss_coef=0.5, entropy_coef=0.05, lr=2.5e-4, eps=1e-5, max_grad_norm=0.2,
                            use_normalized_advantage=False)
@@ -100,6 +102,7 @@ class Workload:
         self.belief = None
         self._act_buf = None
         self._act_host = None
+        self._act_np = {}
         self._host_select = sampling == "race"
         self._small = self._small_ev = self._fwd_ev = None
         self._small_pending = False
@@ -335,7 +338,10 @@ class Workload:
             hg = self.pi_g.host_actions("goal") if hq is not None and self.pi_g is not None else None
             hl = self.pi_l.host_actions("vln") if hg is not None and self.pi_l is not None else None
             if hl is not None and not return_outs:
-                torch.where(hq == 1, hl, hg, out=ah)
+                ahn = self._act_np.get(ah.data_ptr())
+                if ahn is None:
+                    ahn = self._act_np[ah.data_ptr()] = ah.numpy()
+                np.copyto(ahn, np.where(hq.numpy() == 1, hl.numpy(), hg.numpy()))       # 64 integers: numpy, not a torch dispatch
                 late_select = True
                 if self.trace is not None:
                     self.trace.append(("actions_on_host", time.perf_counter()))

@@ -77,7 +77,7 @@ def _i64(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-_TOWERS_FIRST = os.environ.get("AVLEN_TOWERS_FIRST", "1") != "0"
+_LAB_NO_PREFETCH = os.environ.get("AVLEN_LAB_NO_PREFETCH", "0") != "0"
 _MAPPED_ACTIONS = os.environ.get("AVLEN_MAPPED_ACTIONS", "1") != "0"     # heads kernel stores the sampled actions into mapped pinned memory
 _FOLD_TEXT = os.environ.get("AVLEN_FOLD_TEXT", "1") != "0"     # A/B knob: text_projection folded into dialog_layer in the rollout's text graph
 _SPLIT = True        # pi_l's captured forward is cut in two around the text embedding (decided by measurement: DESIGN section 3)
@@ -138,35 +138,57 @@ class _Graph:
             _cur_stream().wait_stream(side)
             torch.cuda.synchronize()
             # Captured by hand (not `with torch.cuda.graph`) so that the forward may cut itself into TWO graphs at
-            # `split()`: the host can then wait for an outside event (pi_l's text tower) between the two replays.
-            self.graph, self.graph2, self.between, self.mid = torch.cuda.CUDAGraph(), None, None, None
+            # `split()`: the host can then wait for an outside event (pi_l's text tower) between the two replays.  The leader of an
+            # EncoderGroup cuts a third, LINEAR piece out (`split_audio()`: the AudioCNNs, between the towers and the rest): a
+            # forked branch inside one graph made its launch cost 54 us on the step's critical path (the towers' launch: 11 us as a
+            # linear graph), and as a graph of its own the audio branch can be replayed on another stream.
+            self.graph, self.graph_a, self.graph2, self.between, self.mid = torch.cuda.CUDAGraph(), None, None, None, None
             cap = _capture_stream()
             cap.wait_stream(_cur_stream())
             pol._capture = self
             try:
                 with torch.cuda.stream(cap):
                     self.graph.capture_begin()
+                    self._capturing = self.graph
                     try:
                         self.outs = fn(*self.static)
                     finally:
-                        (self.graph2 if self.graph2 is not None else self.graph).capture_end()
+                        self._capturing.capture_end()
+                        self._capturing = None
             finally:
                 pol._capture = None
             _cur_stream().wait_stream(cap)
             self.ws = pol._ws
             # raw hipGraphExec_t handles: the step sequencer (sequencer.py) launches them from its recorded command lists
             self.exec1 = self.graph.raw_cuda_graph_exec()
+            self.exec_a = self.graph_a.raw_cuda_graph_exec() if self.graph_a is not None else None
             self.exec2 = self.graph2.raw_cuda_graph_exec() if self.graph2 is not None else None
         finally:
             pol._ws = ws_saved
 
     def split(self):
-        """Called by the forward under capture: everything enqueued so far becomes graph 1, the rest graph 2 (same pool)."""
+        """Called by the forward under capture: everything enqueued so far becomes graph 1 (+ the audio piece), the rest graph 2
+        (same pool)."""
         if self.graph2 is not None:
             return
-        self.graph.capture_end()
-        self.graph2 = torch.cuda.CUDAGraph()
+        self._capturing.capture_end()
+        self.graph2 = self._capturing = torch.cuda.CUDAGraph()
         self.graph2.capture_begin(self.graph.pool())
+
+    def split_audio(self):
+        """Called by the leader's forward under capture right behind the visual towers: what follows up to `split()` (the
+        AudioCNNs) becomes a graph of its own."""
+        if self.graph_a is not None or self.graph2 is not None:
+            return
+        self.graph.capture_end()
+        self.graph_a = self._capturing = torch.cuda.CUDAGraph()
+        self.graph_a.capture_begin(self.graph.pool())
+
+    def replay_first(self):
+        """Everything in front of the cut, on the current stream."""
+        self.graph.replay()
+        if self.graph_a is not None:
+            self.graph_a.replay()
 
     def staging_pairs(self, args):
         """(dst, src) copies that refresh the static inputs from `args`, or None if one of them is not a plain device copy."""
@@ -199,7 +221,7 @@ class _Graph:
                 self.between()
             self.graph.replay()
         else:
-            self.graph.replay()
+            self.replay_first()
             if self.between is not None:
                 self.between()
             if self.mid is not None:
@@ -221,7 +243,7 @@ class _Graph:
                 self.between()
             self.graph.replay()
         else:
-            self.graph.replay()
+            self.replay_first()
             if self.between is not None:
                 self.between()                           # e.g. wait for the text tower's event on this stream
             if self.mid is not None:
@@ -287,6 +309,8 @@ def _graphed(pol, which, fn, args, mode=None):
                 (early[1] is None or early[1] == tuple(raw[0][k].data_ptr() for k in ("rgb", "depth", SPECTROGRAM))):
             # prefetch_encoders() already staged this observation's sensors and replayed the encoder half: the small inputs, then
             # the rest of the forward
+            if len(early) > 2 and early[2] is not None:
+                _cur_stream().wait_event(early[2])       # the audio piece ran on the group's side stream
             if m.late[3]:
                 L.call("avlen_multi_copy", m.late[0], m.late[1], m.late[2], m.late[3], L.stream())
             g.mid = getattr(pol, "_mid", None)
@@ -305,7 +329,7 @@ def _graphed(pol, which, fn, args, mode=None):
         if mode == "lead":
             pol._last_lead = g
         if pol._defer_second and g.graph2 is not None:
-            g.graph.replay()                             # the half that does not read the dialog; dialog_ready() replays the rest
+            g.replay_first()                             # the half that does not read the dialog; dialog_ready() replays the rest
             pol._deferred = g
             outs, heads = g.outs
         else:
@@ -374,7 +398,7 @@ def _graphed(pol, which, fn, args, mode=None):
             pol._memos[mk] = mm
     if pol._defer_second and g.graph2 is not None:
         L.multi_copy(g.staging_pairs_any(args))
-        g.graph.replay()
+        g.replay_first()
         pol._deferred = g
         outs, heads = g.outs
     else:
@@ -412,6 +436,24 @@ class EncoderGroup:
         self.auto = os.environ.get("AVLEN_AUTO_AHEAD", "1") != "0"
         self._auto_stream = None
         self.auto_hits = self.auto_misses = 0
+        self._side = None
+        self._aud_ev = self._stage_ev = None
+
+    def side_stream(self):
+        """The ONE side stream of the group: the followers' forwards (launched ahead by the trainer, by auto_launch or by the step
+        sequencer) and the leader's audio piece when the encoders are started early (Policy.prefetch_encoders).  One stream for all
+        of them: the process has four hardware queues, and the caller's stream, this one and the storage's are three."""
+        if self._side is None:
+            self._side = process_stream("followers")
+        return self._side
+
+    def audio_events(self):
+        """(staged, done): persistent events around the leader's audio piece when it runs on the side stream."""
+        if self._aud_ev is None:
+            self._aud_ev, self._stage_ev = torch.cuda.Event(), torch.cuda.Event()
+            self._aud_ev.record(_cur_stream())
+            self._stage_ev.record(_cur_stream())
+        return self._stage_ev, self._aud_ev
 
     @staticmethod
     def _key(obs):
@@ -472,7 +514,7 @@ class EncoderGroup:
         if lead_prev is None or not self.auto:
             return
         if self._auto_stream is None:
-            self._auto_stream = process_stream("auto_followers")
+            self._auto_stream = self.side_stream()
         for f in self.members[1:]:
             h = f._call_hist
             if len(h) < 2 or h[-1][0] != h[-2][0] or f._stash is not None or f._later is not None:
@@ -1276,11 +1318,20 @@ class Policy(nn.Module):
                     (C.c_int64 * n)(*[d.numel() * d.element_size() for d, _ in pairs]))
             # staging copy + the encoder half of the captured forward as ONE call (csrc/sequencer.hip): this runs between "the
             # step's actions are on the host" and "the next towers are in the queue"
-            cmds = (L.Cmd * 2)()
-            cmds[0].op, cmds[0].n, cmds[0].d = L.CMD_MULTICOPY, n, raw
-            cmds[0].a, cmds[0].b, cmds[0].c = (C.cast(x, C.c_void_p).value for x in arrs)
-            cmds[1].op, cmds[1].a, cmds[1].b = L.CMD_GRAPH, g.exec1, raw
-            plan = (cmds, arrs, g)
+            # ... the towers first (the critical path), then the audio piece on the group's side stream: it depends on the staged
+            # spectrogram only (stage event) and is waited for by the rest of the forward (audio event, checked in _graphed)
+            side, (stage_ev, aud_ev) = grp.side_stream().cuda_stream, grp.audio_events()
+            lst = [(L.CMD_MULTICOPY, n) + tuple(C.cast(x, C.c_void_p).value for x in arrs) + (raw,)]
+            if g.exec_a is not None:
+                lst += [(L.CMD_RECORD, 0, stage_ev.cuda_event, raw, None, None), (L.CMD_GRAPH, 0, g.exec1, raw, None, None),
+                        (L.CMD_WAIT, 0, side, stage_ev.cuda_event, None, None), (L.CMD_GRAPH, 0, g.exec_a, side, None, None),
+                        (L.CMD_RECORD, 0, aud_ev.cuda_event, side, None, None)]
+            else:
+                lst += [(L.CMD_GRAPH, 0, g.exec1, raw, None, None)]
+            cmds = (L.Cmd * len(lst))()
+            for i, (op, n_, a_, b_, c_, d_) in enumerate(lst):
+                cmds[i].op, cmds[i].n, cmds[i].a, cmds[i].b, cmds[i].c, cmds[i].d = op, n_, a_, b_, c_, d_
+            plan = (cmds, arrs, g, aud_ev if g.exec_a is not None else None)
             while len(self._enc_plans) >= 512:
                 self._enc_plans.pop(next(iter(self._enc_plans)))
             self._enc_plans[key] = plan
@@ -1288,8 +1339,8 @@ class Policy(nn.Module):
         for m_ in grp.members:
             if m_ is not self:
                 m_._engine()
-        L.call("avlen_cmds_run", plan[0], 2)
-        self._enc_early = (g, None if will_be is None else tuple(will_be[k].data_ptr() for k in ("rgb", "depth", SPECTROGRAM)))
+        L.call("avlen_cmds_run", plan[0], len(plan[0]))
+        self._enc_early = (g, None if will_be is None else tuple(will_be[k].data_ptr() for k in ("rgb", "depth", SPECTROGRAM)), plan[3])
         return True
 
     def late_inputs(self, keys, event):
@@ -1460,15 +1511,21 @@ class _SMTBase(Net):
             # EncoderGroup -- all towers of all member policies); the audio CNN is a parallel branch under capture
             # a follower only copies its audio features out of the group's buffers: no parallel branch for that (every branch of a
             # captured graph is one more busy hardware queue at replay, and the process has four)
-            fork_aud = fork and mode != "follow"
+            # ... and the LEADER's audio branch is not a fork either: it is captured as a linear graph of its own between the towers
+            # and the rest (_Graph.split_audio), so each piece launches cheaply and the replay decides the stream it runs on
+            fork_aud = fork and mode is None
             s_aud = pol.side_streams()[0] if fork_aud else cur
             if fork_aud:
                 s_aud.wait_stream(cur)
             vis_early = None
-            if mode == "lead" and fork and _TOWERS_FIRST:
+            if mode == "lead" and fork:
                 # capture order = submission order of the replay: the towers' persistent launch is the step's critical path and goes
-                # first; the audio branch (enqueued first, it delayed that launch by its own five submissions) runs behind it
+                # first; the audio piece runs behind / beside it
                 vis_early = grp.run_all(pol, rgb, depth)
+                if pol._capture is not None:
+                    # the caller's stream now waits for the audio piece: the state encoder's weights come into the L2s meanwhile
+                    self.prefetch_weights(pol, ("net.smt_state_encoder.",))
+                    pol._capture.split_audio()
             with torch.cuda.stream(s_aud):
                 if mode == "lead":
                     aud = grp.run_audio(pol, spec)
@@ -1492,7 +1549,6 @@ class _SMTBase(Net):
                 # between the two halves, see Policy._forward); eager: record it now
                 if fork:
                     if pol._capture is not None and pol._capture.graph2 is None:
-                        cur.wait_stream(s_aud)
                         pol._capture.split()
                 else:
                     grp.signal()
@@ -1551,6 +1607,30 @@ class _SMTBase(Net):
                 if s_ is not cur:
                     cur.wait_stream(s_)
         return feats, goal
+
+    def prefetch_weights(self, pol, prefixes):
+        """Warm every XCD's L2 with the 16-bit weight planes of the parameters under `prefixes` (avlen_prefetch_l2), on the current
+        stream: issued where the stream would otherwise idle, a few tens of microseconds before a fused chain streams them (the
+        chain runs 62 us on warm weights and ~100 us on cold ones; in the rollout step they are always cold)."""
+        if _LAB_NO_PREFETCH:
+            return
+        eng = pol._engine()
+        flat = eng["flat"]
+        key = ("prefetch", prefixes)
+        plan = eng.get(key)
+        if plan is None:
+            offs = [flat.offsets[n] for n in flat.offsets if n.startswith(prefixes)]
+            if offs:
+                lo, hi = min(o for o, _ in offs), max(o + k for o, k in offs)
+                lo -= lo % 8                                 # 16-byte aligned in the 2-byte planes
+                planes = [flat.flat16] + ([flat.extra16[2]] if 2 in flat.extra16 and pol.uses_x3() else [])
+                n = len(planes)
+                plan = ((C.c_void_p * n)(*[t.data_ptr() + 2 * lo for t in planes]), (C.c_int64 * n)(*[2 * (hi - lo)] * n), n)
+            else:
+                plan = (None, None, 0)
+            eng[key] = plan
+        if plan[2]:
+            L.call("avlen_prefetch_l2", plan[0], plan[1], plan[2], L.stream())
 
     def _features_from_rows(self, pol, eng, obs, prev_actions, extra, stored):
         base, index = stored
@@ -1842,6 +1922,9 @@ class AudioNavDialogNet(_SMTBase):
                 cur.wait_stream(s_txt)
             if fork and pre is not None and getattr(pol, "_capture", None) is not None and _SPLIT:
                 pol._capture.split()                     # everything above does not need the text embedding
+                # the dialog half starts right behind the text tower, which has swept the caches: 10 us of prefetch buy ~40 us
+                # of the dialog encoder's fused chain
+                self.prefetch_weights(pol, ("net.dialog_state_encoder.",))
             # prefetch_text already applied dialog_layer inside the text graph; otherwise do it here
             d_emb = e if embedded else self._dialog_embed(pol, e)
         memd = _f32(ext_memory_dialog)

@@ -19,6 +19,7 @@ Nothing about the arithmetic changes: the same graphs, the same static buffers, 
 (tests/test_gpu_text_cache.py, tests/test_gpu_harness_parity.py hold the storage bit-equal).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -34,20 +35,24 @@ def _ev():
 
 class _Plan:
     __slots__ = ("B", "dev", "gq", "gg", "gl", "gt", "obs3", "grp_key", "key_q", "key_g", "key_l", "outs_q", "heads_q", "outs_g",
-                 "heads_g", "out_l1", "outs_l", "heads_l", "ah_q", "ah_g", "ah_l", "a_early", "a_full", "b_cmds", "emb", "keep",
-                 "tok_shape", "main")
+                 "heads_g", "out_l1", "outs_l", "heads_l", "ah_q", "ah_g", "ah_l", "a_early", "a_full", "b_text", "b_cmds", "emb", "keep",
+                 "tok_shape", "main", "aud_ev")
 
 
 class StepSequencer:
-    def __init__(self, pi_q, pi_g, pi_l, side_stream):
+    def __init__(self, pi_q, pi_g, pi_l):
         assert pi_q._enc_group is not None and pi_q._enc_group.leader is pi_q and pi_q._enc_group.members == [pi_q, pi_g, pi_l], \
             "the sequencer drives one EncoderGroup: share_encoders(pi_q, pi_g, pi_l) first"
-        self.q, self.g, self.l, self.S = pi_q, pi_g, pi_l, side_stream
+        self.q, self.g, self.l, self.S = pi_q, pi_g, pi_l, pi_q._enc_group.side_stream()
         self._plans = {}
         self._gen = None
         self._cur = None                   # the running step: ("fast", plan, l_args) or ("slow", key, args, templates)
         self.fast = self.slow = 0
         self.ev = None
+        # lab: the followers start behind pi_q's whole forward instead of behind the shared encoders (pi_q's fused chain, 8
+        # latency-bound workgroups, takes 110 us beside pi_g's GEMMs and ~60 us alone)
+        self.followers_after_q = bool(int(os.environ.get("AVLEN_LAB_FOLLOW_AFTER_Q", "0")))
+        self.l2_on_side = bool(int(os.environ.get("AVLEN_LAB_L2_SIDE", "0")))
 
     # ------------------------------------------------------------------------------------------------------------------
     def _events(self):
@@ -56,7 +61,7 @@ class StepSequencer:
             if grp.ready is None:
                 grp.ready = torch.cuda.Event()
             grp.ready.record(P._cur_stream())
-            self.ev = dict(ready=grp.ready, done_q=_ev(), done_g=_ev(), done_l=_ev(), text=_ev(), text_read=_ev())
+            self.ev = dict(ready=grp.ready, done_q=_ev(), done_g=_ev(), done_l=_ev(), l_half=_ev(), text_read=_ev(), text=_ev())
         return self.ev
 
     @staticmethod
@@ -104,6 +109,8 @@ class StepSequencer:
         l.net._sync_text_cache(l)
         early, q._enc_early = q._enc_early, None
         use_early = early is not None and early[0] is plan.gq and (early[1] is None or early[1] == plan.obs3)
+        if use_early and early[2] is not None and early[2] is not plan.aud_ev:
+            P._cur_stream().wait_event(early[2])
         B, dev = plan.B, plan.dev
         r0 = torch.get_rng_state()
         q._draw_noise("option", B, dev)                 # the reference's draw order: pi_q, pi_g (, pi_l in dialog_ready)
@@ -147,12 +154,15 @@ class StepSequencer:
         ev, net = self.ev, l.net
         if net._text_read is not None and net._text_read is not ev["text_read"]:
             P._cur_stream().wait_event(net._text_read)       # the embedding's last reader was enqueued by the slow path
+        # the text tower first: it is the step's critical path from here (the host has just read pi_q's actions); pi_l's draw -- third
+        # in the step, as in the reference -- and its dialog half go out while the tower runs
+        L.call("avlen_cmds_run", plan.b_text, len(plan.b_text))
         r0 = torch.get_rng_state()
         l._draw_noise("vln", plan.B, plan.dev)
         r1 = torch.get_rng_state()
         L.call("avlen_cmds_run", plan.b_cmds, len(plan.b_cmds))
         tok = l_args[7]
-        net._text = (tok.data_ptr(), plan.tok_shape, plan.emb, ev["text"])
+        net._text = (tok.data_ptr(), plan.tok_shape, plan.emb, ev["text_read"])
         net._text_key = ("pretext", plan.emb.data_ptr())
         net._text_read = ev["text_read"]
         l._later = l._deferred = None
@@ -230,29 +240,41 @@ class StepSequencer:
             keep.append(a)
             return copy(stream, a[0], a[1], a[2], n)
 
-        follow = ([(L.CMD_WAIT, 0, S, h(ev["ready"]), None, None)]
+        follow = ([(L.CMD_WAIT, 0, S, h(ev["done_q" if self.followers_after_q else "ready"]), None, None)]
                   + copy(S, mg.srcs, mg.dsts, mg.sizes, mg.n)
                   + [(L.CMD_GRAPH, 0, gg.exec1, S, None, None), (L.CMD_RECORD, 0, h(ev["done_g"]), S, None, None)]
                   + copy(S, ml.srcs, ml.dsts, ml.sizes, ml.n)
-                  + [(L.CMD_GRAPH, 0, gl.exec1, S, None, None)])
+                  + [(L.CMD_GRAPH, 0, gl.exec1, S, None, None), (L.CMD_RECORD, 0, h(ev["l_half"]), S, None, None)])
         tail = [(L.CMD_RECORD, 0, h(ev["ready"]), M, None, None), (L.CMD_GRAPH, 0, gq.exec2, M, None, None),
                 (L.CMD_RECORD, 0, h(ev["done_q"]), M, None, None)] + follow
-        a_early = copy(M, mq.late[0], mq.late[1], mq.late[2], mq.late[3]) + tail
-        a_full = copy(M, mq.srcs, mq.dsts, mq.sizes, mq.n) + [(L.CMD_GRAPH, 0, gq.exec1, M, None, None)] + tail
-        b = ([(L.CMD_WAIT, 0, M, h(ev["text_read"]), None, None)]
-             + pairs(M, [(gt.static[0], tok)])
-             + [(L.CMD_GRAPH, 0, gt.exec1, M, None, None), (L.CMD_RECORD, 0, h(ev["text"]), M, None, None),
-                (L.CMD_WAIT, 0, S, h(ev["text"]), None, None)]
-             + pairs(S, [(s8, astep)])
-             + [(L.CMD_GRAPH, 0, gl.exec2, S, None, None), (L.CMD_RECORD, 0, h(ev["text_read"]), S, None, None),
-                (L.CMD_RECORD, 0, h(ev["done_l"]), S, None, None)])
+        pl.aud_ev = q._enc_group.audio_events()[1] if gq.exec_a is not None else None
+        a_early = ([(L.CMD_WAIT, 0, M, h(pl.aud_ev), None, None)] if pl.aud_ev is not None else []) \
+            + copy(M, mq.late[0], mq.late[1], mq.late[2], mq.late[3]) + tail
+        a_full = copy(M, mq.srcs, mq.dsts, mq.sizes, mq.n) + [(L.CMD_GRAPH, 0, gq.exec1, M, None, None)] \
+            + ([(L.CMD_GRAPH, 0, gq.exec_a, M, None, None)] if gq.exec_a is not None else []) + tail
+        b_text = ([(L.CMD_WAIT, 0, M, h(ev["text_read"]), None, None)]
+                  + pairs(M, [(gt.static[0], tok)])
+                  + [(L.CMD_GRAPH, 0, gt.exec1, M, None, None)])
+        # pi_l's dialog half goes out on the CALLER's stream right behind the text tower (the Python flow puts it on the side stream
+        # behind an event: a queue that sits on a barrier packet until another queue's signal arrives starts ~20 us late, measured
+        # in profiles/r05_step_trace.txt); its state-encoder half finished on the side stream long before (l_half)
+        if self.l2_on_side:
+            b = ([(L.CMD_RECORD, 0, h(ev["text"]), M, None, None), (L.CMD_WAIT, 0, S, h(ev["text"]), None, None)]
+                 + pairs(S, [(s8, astep)])
+                 + [(L.CMD_GRAPH, 0, gl.exec2, S, None, None), (L.CMD_RECORD, 0, h(ev["text_read"]), S, None, None),
+                    (L.CMD_RECORD, 0, h(ev["done_l"]), S, None, None)])
+        else:
+          b = ([(L.CMD_WAIT, 0, M, h(ev["l_half"]), None, None)]
+             + pairs(M, [(s8, astep)])
+             + [(L.CMD_GRAPH, 0, gl.exec2, M, None, None), (L.CMD_RECORD, 0, h(ev["text_read"]), M, None, None),
+                (L.CMD_RECORD, 0, h(ev["done_l"]), M, None, None)])
 
         def arr(cmds):
             a = (L.Cmd * len(cmds))()
             for i, (op, n, x, y, z, w) in enumerate(cmds):
                 a[i].op, a[i].n, a[i].a, a[i].b, a[i].c, a[i].d = op, n, x, y, z, w
             return a
-        pl.a_early, pl.a_full, pl.b_cmds = arr(a_early), arr(a_full), arr(b)
+        pl.a_early, pl.a_full, pl.b_text, pl.b_cmds = arr(a_early), arr(a_full), arr(b_text), arr(b)
         pl.keep = (keep, mq, mg, ml)                      # the staging arrays the command lists point into
         pl.main = M
         while len(self._plans) >= 1024:

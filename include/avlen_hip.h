@@ -336,6 +336,10 @@ size_t avlen_clip_stream_bytes(const avlen_clip_text* p);
  * splits round later layers' fp16 operands at different points (2e-3 apart), so only the first two keep a dialog's embedding
  * independent of the other dialogs of the call. */
 void avlen_set_clip_tower_split4_wgs(int n);
+/* Fused row-batch chains (csrc/chain.hip: the single-token decoder / collapsed encoder / per-step tails of pi_q, pi_g, pi_l): 1
+ * (default) = batches of up to 32 blocks are launched with only every 8th block of the grid working, so that the working blocks
+ * share ONE XCD's L2 for the weights they all stream (speed only); 0 = plain grid. */
+void avlen_set_chain_one_xcd(int on);
 int avlen_clip_pack_stream(const avlen_clip_text* p, void* dst, int fmt, avlen_stream_t stream);
 
 /* ------------------------------------------------------------------ GRU ------------------------ */
@@ -484,6 +488,11 @@ int avlen_gather_rows(const float* src, int lds, const int* index, float* dst, i
 /* dst[i][0..nbytes[i]) = src[i][0..nbytes[i]) for i < n, in ONE launch per 32 pairs (host arrays of device pointers).
  * RolloutStorage.insert (rollout_storage.py:223-330 of the reference: ~25 `tensor[step].copy_()` calls per step). */
 int avlen_multi_copy(const void* const* src, void* const* dst, const int64_t* nbytes, int n, avlen_stream_t stream);
+
+/* Warm the L2 of every XCD with up to 8 byte ranges (16-byte aligned; whole 16-byte words are read) that a latency-bound kernel is
+ * about to stream -- the 16-bit weight planes of the fused state-encoder chains of pi_q / pi_l (smt_state_encoder.py:152-166,
+ * dialog_state_encoder.py:133-152 as one launch each): 62 us warm against ~100 us from HBM.  Reads only; speed only. */
+int avlen_prefetch_l2(const void* const* ptrs, const int64_t* nbytes, int n, avlen_stream_t stream);
 
 /* Step sequencer (csrc/sequencer.hip): a list of stream operations run by ONE call, in order.  The reference's rollout step has
  * two host round trips on its critical path (ppo_trainer.py:449-636: act_option -> host reads the option actions -> tokens ->
