@@ -18,6 +18,11 @@ $(LIB): $(OBJS)
 	@mkdir -p $(dir $(LIB))
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
 
+# kernels that issue loads / stores from inline asm with their own waits: walk the gfx950 ISA of exactly what is shipped (same
+# compiler, same flags) for a register the compiler touched too early (tools/asm_wait_check.py)
+asmcheck:
+	HIPCC="$(HIPCC)" HIPFLAGS="$(HIPFLAGS)" python3 tools/asm_wait_check.py $(SRC)/clip_tower.hip $(SRC)/tower_x3.hip $(SRC)/chain.hip
+
 clean:
 	rm -rf build $(LIB)
-.PHONY: all clean
+.PHONY: all clean asmcheck

@@ -5,3 +5,6 @@ models/rollout_storage.py; all arithmetic runs in hand-written HIP kernels behin
 include/avlen_hip.h (libavlen_hip.so).  There is no CPU or PyTorch fallback.
 """
 __version__ = "0.1.0"
+
+from . import config as _config
+_config.check_hw_queues()

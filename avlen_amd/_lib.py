@@ -194,6 +194,7 @@ SIGNATURES = {
     "avlen_clip_text_fwd": (i32, [C.POINTER(ClipText), vp, vp, i32, i32, vp, sz, vp]),
     "avlen_clip_text_cache_bytes": (sz, [C.POINTER(ClipText), i32]),
     "avlen_clip_text_cached_fwd": (i32, [C.POINTER(ClipText), vp, vp, sz, vp, i32, i32, vp, sz, vp]),
+    "avlen_clip_text_dialog_fwd": (i32, [C.POINTER(ClipText), C.POINTER(Linear), vp, vp, sz, vp, i32, i32, vp, sz, vp]),
     "avlen_clip_stream_bytes": (sz, [C.POINTER(ClipText)]),
     "avlen_clip_pack_stream": (i32, [C.POINTER(ClipText), vp, i32, vp]),
     "avlen_gru_workspace_bytes": (sz, [C.POINTER(Gru), i32, i32]),
@@ -225,6 +226,7 @@ SIGNATURES = {
     "avlen_set_big_m": (None, [C.c_long]),
     "avlen_set_x3_mixed_backward_rows": (None, [C.c_long]),
     "avlen_set_tower_x3_reserved_cus": (None, [i32]),
+    "avlen_tower_x3_timing": (i32, [vp, vp, i32]),
     "avlen_set_clip_tower_split4_wgs": (None, [i32]),
     "avlen_set_chain_one_xcd": (None, [i32]),
     "avlen_minibatch_gather": (i32, [vp, vp, vp, i32, i32, i32, sz, i32, vp]),

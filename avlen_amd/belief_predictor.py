@@ -9,7 +9,6 @@ copies the network outputs and every pose to the host and loops over environment
 """
 import ctypes as C
 import logging
-import os
 
 import torch
 import torch.nn as nn
@@ -24,7 +23,7 @@ _SHARED_CAPTURE = True
 # The two networks as TWO graphs replayed on two streams (classifier on a side stream, predictor + filter on the caller's): as two
 # branches of ONE captured graph they execute back to back (kernel trace of a replay: the predictor's first kernel starts when the
 # classifier's last one ends -- 350 + 435 us instead of max(350, 435)); separate graphs on separate streams do overlap.
-_TWO_GRAPHS = os.environ.get("AVLEN_BELIEF_TWO_GRAPHS", "1") != "0"
+_TWO_GRAPHS = True
 LABEL_PREDICTOR_PATH = "data/pretrained_weights/semantic_audionav/savi/label_predictor.pth"    # belief_predictor.py:96
 
 

@@ -2205,7 +2205,114 @@ __global__ __launch_bounds__(128) void text_cache_zero_rows_kernel(float* __rest
   for (int c = threadIdx.x * 4; c < wd; c += 512)
     *reinterpret_cast<float4*>(E + (long)r * wd + c) = *reinterpret_cast<const float4*>(E + (long)B * wd + c);
 }
+// The tail of the rollout's text graph as ONE launch: the shared embedding of the all-zero rows copied into the memo (what
+// text_cache_zero_rows_kernel does), ln_final of every row, the cast to the tower's 16-bit format and dialog_layer o text_projection
+// as one 16-row MFMA product (policy.py:847-849: dialog_layer(encode_text(x)); the projection is folded into the Linear's weight,
+// engine.Packed.proj_fold).  Was four launches of 5-9 us each behind the text tower, on the step's critical path.
+// Block = 16 rows, 4 waves; wave w owns output features 64 w .. 64 w + 63 (4 MFMA tiles), K = 512 in 16 steps; the A operand is the
+// weight fragment ([16 features][32 k], 16-byte loads from the row-major 16-bit weight), the B operand the rows' 16-bit image in
+// LDS -- the result tile is lane (c = lane & 15: row, q = lane >> 4: features 4 q .. 4 q + 3), as in chain.hip.
+typedef __attribute__((ext_vector_type(8))) _Float16 mf16x8;
+typedef __attribute__((ext_vector_type(4))) float mf32x4;
+template <bool F16>
+__global__ __launch_bounds__(256) void text_tail_kernel(float* __restrict__ E, const int* __restrict__ hdr, const int* __restrict__ zidx,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const unsigned short* __restrict__ w16, int ldw, const float* __restrict__ bias,
+                                                        float* __restrict__ out, int ldo, int B, int N) {
+  constexpr int WD = 512, XLD = WD + 8;
+  __shared__ __attribute__((aligned(16))) unsigned short xs[16 * XLD];
+  __shared__ int zrow[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r0 = blockIdx.x * 16;
+  if (tid < 16) zrow[tid] = 0;
+  __syncthreads();
+  const int nz = hdr ? hdr[2] : 0;
+  for (int i = tid; i < nz; i += 256) { const int r = zidx[i] - r0; if (r >= 0 && r < 16) zrow[r] = 1; }
+  __syncthreads();
+  // ---- ln_final of the block's rows (a wave per row, four rows per wave): ln_fwd_kernel<8>'s arithmetic -> 16-bit image
+  for (int rr = wave * 4; rr < wave * 4 + 4; rr++) {
+    const int row = r0 + rr;
+    unsigned short* xr = xs + rr * XLD;
+    if (row >= B) {
+      for (int i = 0; i < 8; i++) xr[lane + i * 64] = 0;
+      continue;
+    }
+    const float* src = E + (long)(zrow[rr] ? B : row) * WD;             // an all-zero dialog: the shared row (row B of the memo)
+    float v[8], s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { v[i] = src[lane + i * 64]; s += v[i]; }
+    if (zrow[rr]) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) E[(long)row * WD + lane + i * 64] = v[i];   // the memo keeps every row's tower output
+    }
+    const float mean = wave_sum(s) * (1.f / WD);
+    float qq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { const float t = v[i] - mean; qq += t * t; }
+    const float rstd = rsqrtf(wave_sum(qq) * (1.f / WD) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int c = lane + i * 64;
+      const float o = (v[i] - mean) * rstd * gamma[c] + beta[c];
+      if (F16) { const _Float16 hv = (_Float16)o; xr[c] = __builtin_bit_cast(unsigned short, hv); }
+      else { const __bf16 hv = (__bf16)o; xr[c] = __builtin_bit_cast(unsigned short, hv); }
+    }
+  }
+  __syncthreads();
+  // ---- out[row][n] = bias[n] + sum_k x16[row][k] * w16[n][k]
+  const int c = lane & 15, q = lane >> 4;
+  for (int nt = 0; nt < 4; nt++) {
+    const int n0 = wave * 64 + nt * 16;
+    if (n0 >= N) break;
+    mf32x4 acc = (mf32x4){0.f, 0.f, 0.f, 0.f};
+    const unsigned short* wr = w16 + (long)(n0 + c) * ldw + q * 8;
+    const unsigned short* xr = xs + c * XLD + q * 8;
+#pragma unroll 4
+    for (int k = 0; k < WD; k += 32) {
+      const uint4 wv = *reinterpret_cast<const uint4*>(wr + k);
+      const uint4 xv = *reinterpret_cast<const uint4*>(xr + k);
+      if (F16) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mf16x8, wv), __builtin_bit_cast(mf16x8, xv), acc, 0, 0, 0);
+      else acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv), __builtin_bit_cast(bf16x8, xv), acc, 0, 0, 0);
+    }
+    const int row = r0 + c;
+    if (row < B) {
+      const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + n0 + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(out + (long)row * ldo + n0 + q * 4) = make_float4(acc[0] + bv.x, acc[1] + bv.y, acc[2] + bv.z, acc[3] + bv.w);
+    }
+  }
+}
 }  // namespace
+// dialog_layer(CLIP.encode_text(tokens)) of the rollout (policy.py:844-851) on the memoised one-launch tower, the tail fused:
+// p = the tower WITHOUT its text projection (text_proj == NULL), fold = dialog_layer with the projection folded into its weight
+// ([out_f][width], 16-bit shadow in the tower's format).  out (B, fold->out_f) fp32.  16-bit modes and B + 1 <= 512 rows only
+// (AVLEN_ERR_ARG otherwise: the caller takes avlen_clip_text_cached_fwd + its own product).
+extern "C" int avlen_clip_text_dialog_fwd(const avlen_clip_text* p, const avlen_linear* fold, const int64_t* tokens, void* state,
+                                          size_t state_bytes, float* out, int B, int prec, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!p || !fold || !tokens || !state || !out || B <= 0) return AVLEN_ERR_ARG;
+  const int wd = p->width;
+  const bool f16 = prec == AVLEN_PREC_FP16;
+  const bool fast = ((prec == AVLEN_PREC_BF16 && p->half_fmt == 0) || (f16 && p->half_fmt == 1)) && B + 1 <= CLIP_PASS_ROWS &&
+                    p->wstream && avlen_clip_stream_bytes(p);
+  if (!fast || p->text_proj || wd != 512 || fold->in_f != wd || !fold->w16 || fold->ld16 % 8 || fold->out_f % 16 || fold->out_f > 256)
+    return AVLEN_ERR_ARG;
+  if (state_bytes < text_cache_bytes(B, p->ctx, wd) || ws_bytes < avlen_clip_text_workspace_bytes(p, B + 1)) return AVLEN_ERR_WS;
+  const TextCache c = text_cache_map(state, B, p->ctx, wd);
+  WsBump w(ws, ws_bytes);
+  w.take<float>((size_t)B * wd);
+  w.take<char>(GEMM_SCRATCH);
+  const size_t sb = avlen_clip_tower_stream_ws_bytes(B + 1);
+  void* sws = w.take<char>(sb);
+  if (!w.ok()) return AVLEN_ERR_WS;
+  const avlen_clip_memo memo{tokens, c.prev, c.hdr, c.zidx};
+  TRY(avlen_clip_tower_stream_fwd(p, c.prev, c.E, B + 1, f16 ? 1 : 0, sws, sb, st, &memo));
+  const dim3 grid((unsigned)((B + 15) / 16));
+  if (f16)
+    hipLaunchKernelGGL(text_tail_kernel<true>, grid, dim3(256), 0, st, c.E, c.hdr, c.zidx, p->ln_final.g, p->ln_final.b,
+                       (const unsigned short*)fold->w16, fold->ld16, fold->b, out, fold->out_f, B, fold->out_f);
+  else
+    hipLaunchKernelGGL(text_tail_kernel<false>, grid, dim3(256), 0, st, c.E, c.hdr, c.zidx, p->ln_final.g, p->ln_final.b,
+                       (const unsigned short*)fold->w16, fold->ld16, fold->b, out, fold->out_f, B, fold->out_f);
+  return avlen_launch_status();
+}
 extern "C" size_t avlen_clip_text_cache_bytes(const avlen_clip_text* p, int B) {
   return p && B > 0 ? text_cache_bytes(B, p->ctx, p->width) : 0;
 }

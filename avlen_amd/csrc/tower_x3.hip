@@ -1082,6 +1082,11 @@ constexpr int TOWER_LDS = QSLOT_OFF + 16;
 static_assert(TOWER_LDS <= 160 * 1024, "tower x3 LDS budget");
 typedef __attribute__((address_space(1))) unsigned gu32;
 
+// In-situ duration of the launch, for bench.py's roofline record (the kernel's time INSIDE the running rollout step, beside the
+// other streams' work, without a profiler): the workgroup that draws ticket 0 stamps the constant-rate wall clock, the last workgroup
+// to leave adds (its clock - that stamp) to a running sum.  Two atomics per workgroup and launch.
+__device__ unsigned long long g_x3_t0, g_x3_ticks, g_x3_launches;
+
 __global__ __launch_bounds__(RTH) void tower_x3_kernel(TowerArgs args) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x;
@@ -1093,7 +1098,15 @@ __global__ __launch_bounds__(RTH) void tower_x3_kernel(TowerArgs args) {
     __syncthreads();
     int item = __builtin_amdgcn_readfirstlane(*slot);
     __syncthreads();                                        // the slot is rewritten only after every wave has read it
-    if (item >= 2 * n) break;
+    if (item == 0 && tid == 0) __hip_atomic_store(&g_x3_t0, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (item >= 2 * n) {
+      if (tid == 0 && __hip_atomic_fetch_add(qw + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+        const unsigned long long t0 = __hip_atomic_load(&g_x3_t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&g_x3_ticks, (unsigned long long)wall_clock64() - t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&g_x3_launches, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      break;
+    }
     X3_WALL(29);
     if (item < n) {
       l1_body(args.l1, item / args.B, item % args.B, lds, args.prof, item);
@@ -1239,3 +1252,22 @@ int avlen_tower_x3_fwd(const avlen_resnet18* const* nets, const void* const* img
 // with every CU held by a tower workgroup it cannot start before the towers end; 64 reserved CUs cost the towers a fourth round
 // (0.50 -> 0.62 ms) and bring the step's text tower forward by more (step 1.97 -> 1.87 ms).
 extern "C" void avlen_set_tower_x3_reserved_cus(int n) { g_reserved_cus = n > 0 ? n : 0; }
+
+// Mean in-situ duration (microseconds) of the persistent tower launches since the last reset, and their count; reset != 0 clears
+// the counters afterwards.  SYNCHRONISES the device (a measurement call: bench.py, never the rollout).
+extern "C" int avlen_tower_x3_timing(double* mean_us, long long* launches, int reset) {
+  unsigned long long ticks = 0, n = 0;
+  if (hipDeviceSynchronize() != hipSuccess) return AVLEN_ERR_LAUNCH;
+  if (hipMemcpyFromSymbol(&ticks, HIP_SYMBOL(g_x3_ticks), 8) != hipSuccess || hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_x3_launches), 8) != hipSuccess)
+    return AVLEN_ERR_LAUNCH;
+  int dev = 0, khz = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;
+  if (mean_us) *mean_us = n ? (double)ticks / (double)n / ((double)khz * 1e-3) : 0.0;
+  if (launches) *launches = (long long)n;
+  if (reset) {
+    const unsigned long long z = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_x3_ticks), &z, 8) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(g_x3_launches), &z, 8) != hipSuccess)
+      return AVLEN_ERR_LAUNCH;
+  }
+  return AVLEN_OK;
+}

@@ -1,10 +1,10 @@
 """Host-side engine shared by the policies: flat parameter storage, packed weights, C-struct views of
 the parameters, workspaces.  PyTorch is used for device memory only."""
 import ctypes as C
-import os
 import torch
 
 from . import _lib as L
+from . import config as CFG
 
 ALIGN = 64          # floats
 
@@ -323,9 +323,14 @@ class Packed:
                        P(c), dims[0], dims[1], c16, st)
             elif kind == "pad16":
                 L.call("avlen_cast_h16", P(w), dims[1], P(buf16), c16, dims[0], dims[1], buf or 0, st)
-            elif kind == "projfold":                  # derived data: Linear weight x projection, then its 16-bit shadow
-                with torch.no_grad():
-                    torch.matmul(w[0].detach().float(), w[1].detach().float().t(), out=buf)
+            elif kind == "projfold":                  # derived data: Linear weight x projection (exact fp32 MFMA), then its 16-bit shadow
+                lw, pj = w                            # [out][k], [in][k]: folded[out][in] = sum_k lw[out][k] pj[in][k]
+                k = lw.shape[1]
+                nbg = L.lib.avlen_gemm_workspace_bytes(dims[0], dims[1], k, 1)
+                wsg = torch.empty(int(nbg), dtype=torch.uint8, device=self.device)
+                L.call("avlen_gemm", P(lw), k, 0, P(pj), pj.shape[1], 0, P(buf), dims[1], None, None, 0, dims[0], dims[1], k, 0,
+                       L.PREC_FP32, 1, 0.0, P(wsg), nbg, st)
+                self.bufs.append(wsg)                 # alive until the stream has run the product
                 L.call("avlen_cast_h16", P(buf), dims[1], P(buf16), dims[1], dims[0], dims[1], c16, st)
             elif kind == "t32":                       # derived data: a transposed fp32 copy
                 with torch.no_grad():
@@ -497,7 +502,7 @@ def clip_view(clip, flat=None, packed=None, fmt=0):
         packed.bufs.append(tp)
         packed.jobs.append(("t32", clip.text_projection, tp, None, None, 0))
         s.text_proj_t = P(tp)
-    if packed is not None and os.environ.get("AVLEN_CLIP_STREAM", "1") != "0":
+    if packed is not None and CFG.CLIP_STREAM:
         # per-wave weight streams of the one-launch sequence-stationary tower (csrc/clip_tower.hip): 0.76 ms for 64 dialogs against
         # 0.93 ms for the launch-per-GEMM tower (AVLEN_CLIP_STREAM=0 keeps that one).  0 bytes: shape not supported.
         nb = L.lib.avlen_clip_stream_bytes(C.byref(s))

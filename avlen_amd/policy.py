@@ -14,12 +14,12 @@ sampling="device" keeps everything on the GPU (like the reference would on a CUD
 """
 import contextlib
 import ctypes as C
-import os
 import time
 import torch
 import torch.nn as nn
 
 from . import _lib as L
+from . import config as CFG
 from . import engine as E
 from . import nets as N
 
@@ -77,9 +77,8 @@ def _i64(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-_LAB_NO_PREFETCH = os.environ.get("AVLEN_LAB_NO_PREFETCH", "0") != "0"
-_MAPPED_ACTIONS = os.environ.get("AVLEN_MAPPED_ACTIONS", "1") != "0"     # heads kernel stores the sampled actions into mapped pinned memory
-_FOLD_TEXT = os.environ.get("AVLEN_FOLD_TEXT", "1") != "0"     # A/B knob: text_projection folded into dialog_layer in the rollout's text graph
+_MAPPED_ACTIONS = CFG.MAPPED_ACTIONS     # heads kernel stores the sampled actions into mapped pinned memory
+_FOLD_TEXT = CFG.FOLD_TEXT               # text_projection folded into dialog_layer in the rollout's text graph
 _SPLIT = True        # pi_l's captured forward is cut in two around the text embedding (decided by measurement: DESIGN section 3)
 
 
@@ -433,7 +432,7 @@ class EncoderGroup:
         # on a side stream -- with the arguments the followers are about to be called with, predicted from their previous calls
         # (see auto_launch) -- and the followers' own calls pick the results up after validating every address.  AVLEN_AUTO_AHEAD=0
         # switches it off; explicit prefetch_* calls by the caller take precedence.
-        self.auto = os.environ.get("AVLEN_AUTO_AHEAD", "1") != "0"
+        self.auto = CFG.AUTO_AHEAD
         self._auto_stream = None
         self.auto_hits = self.auto_misses = 0
         self._side = None
@@ -645,6 +644,7 @@ class Policy(nn.Module):
         self._stash = None
         self._memos = {}                      # resolved launches per exact argument objects (see _Memo)
         self._capture = None                  # the _Graph being captured (lets a forward cut itself in two, see _Graph.split)
+        self._post = None                     # act* forwards: closures the net defers behind the heads kernel (see _forward.eager)
         self._between = None                  # host action between the two halves of a split graph
         self._mid = None                      # leader of an EncoderGroup: EncoderGroup.signal between the halves of its cut graph
         self._late_inputs = None              # (observation keys, event): see late_inputs()
@@ -971,8 +971,17 @@ class Policy(nn.Module):
         race = self.sampling == "race"
 
         def eager(*args):
-            outs = self.net.run(self, *args)
-            return outs, self._heads_first(which, outs[0], race=race)
+            # work of the forward that nothing on the step's critical path waits for (pi_q's memory row) is enqueued BEHIND the heads
+            # kernel, whose sampled actions the host is polling for
+            self._post = post = []
+            try:
+                outs = self.net.run(self, *args)
+            finally:
+                self._post = None
+            heads = self._heads_first(which, outs[0], race=race)
+            for fn in post:
+                fn()
+            return outs, heads
         st = self._stash
         if st is not None:
             self._stash = None
@@ -1096,7 +1105,7 @@ class Policy(nn.Module):
             grp = self._enc_group
             obs = net_args[0] if net_args and isinstance(net_args[0], dict) else None
             if (grp is not None and grp.leader is not self and obs is not None and grp.ready_key is not None
-                    and grp.ready_key == grp._key(obs) and os.environ.get("AVLEN_FOLLOW_EARLY", "1") != "0"):
+                    and grp.ready_key == grp._key(obs)):
                 # a follower of the marked observation: the shared encoders' event covers everything it reads (it was recorded on
                 # the current stream, behind every earlier write to the storage it reads)
                 stream.wait_event(grp.ready)
@@ -1612,8 +1621,6 @@ class _SMTBase(Net):
         """Warm every XCD's L2 with the 16-bit weight planes of the parameters under `prefixes` (avlen_prefetch_l2), on the current
         stream: issued where the stream would otherwise idle, a few tens of microseconds before a fused chain streams them (the
         chain runs 62 us on warm weights and ~100 us on cold ones; in the rollout step they are always cold)."""
-        if _LAB_NO_PREFETCH:
-            return
         eng = pol._engine()
         flat = eng["flat"]
         key = ("prefetch", prefixes)
@@ -1720,8 +1727,15 @@ class AudioNavOptionNet(_SMTBase):
         B = feats.shape[0]
         lqi = _f32(last_query_info)
         row = torch.empty(B, self._feature_size, device=feats.device)                          # [x | last_query_info]
-        L.call("avlen_concat_rows", E.P(feats), feats.shape[1], self._x_dims, E.P(lqi), lqi.shape[1], lqi.shape[1],
-               E.P(row), row.shape[1], B, L.stream())
+
+        def memory_row(feats=feats, lqi=lqi, row=row, B=B):
+            L.call("avlen_concat_rows", E.P(feats), feats.shape[1], self._x_dims, E.P(lqi), lqi.shape[1], lqi.shape[1],
+                   E.P(row), row.shape[1], B, L.stream())
+        post = getattr(pol, "_post", None)
+        if post is not None:
+            post.append(memory_row)                      # act_option: behind the heads (Policy._forward)
+        else:
+            memory_row()
         self._last = (feats, goal, saved)
         return x_att, rnn_hidden_states, row
 
@@ -1776,7 +1790,7 @@ class AudioNavDialogNet(_SMTBase):
     # previous step's.  What is kept is the tower's output BEFORE ln_final / text_projection / dialog_layer -- dialog_layer is
     # trained by update_dialog and is applied fresh every call.  Keyed on a row's tokens (content), one state block per batch size;
     # emptied when the weights change (mark_params_changed / load_state_dict bump pol._param_epoch).
-    text_cache = os.environ.get("AVLEN_TEXT_CACHE", "1") != "0"
+    text_cache = CFG.TEXT_CACHE
 
     def _text_state(self, pol, clip, B, dev):
         st = self.__dict__.setdefault("_text_states", {})
@@ -1817,7 +1831,22 @@ class AudioNavDialogNet(_SMTBase):
         eng = pol._engine()
         enc = self.encode_text_cached if self.text_cache else self.encode_text
         if "dialog_fold" in eng and pol.prec_of("clip") in (L.PREC_BF16, L.PREC_FP16):
-            return self._dialog_embed(pol, enc(pol, tokens, project=False), eng["dialog_fold"])
+            fold = eng["dialog_fold"]
+            if self.text_cache and tokens.shape[0] + 1 <= 512 and fold.out_f % 16 == 0 and fold.out_f <= 256 and fold.in_f == 512:
+                # memoised tower + ONE tail launch (memo rows, ln_final, 16-bit cast, the folded product): avlen_clip_text_dialog_fwd
+                tok = _i64(tokens)
+                B = tok.shape[0]
+                clip = eng["clip_noproj"]
+                if not torch.cuda.is_current_stream_capturing():
+                    self._sync_text_cache(pol)
+                state = self._text_state(pol, clip, B, tok.device)
+                out = torch.empty(B, fold.out_f, device=tok.device)
+                nb = L.lib.avlen_clip_text_workspace_bytes(C.byref(clip), B + 1)
+                ws = pol._ws.get("clip_cached", nb, tok.device)
+                L.call("avlen_clip_text_dialog_fwd", C.byref(clip), C.byref(fold), E.P(tok), E.P(state), state.numel(), E.P(out), B,
+                       pol.prec_of("clip"), E.P(ws), nb, L.stream())
+                return out
+            return self._dialog_embed(pol, enc(pol, tokens, project=False), fold)
         return self._dialog_embed(pol, enc(pol, tokens))
 
     text_encoder_override = None      # tests: callable(tokens)->(B,512) replacing the CLIP tower (unpinned)
@@ -2212,3 +2241,10 @@ class AudioNavOptionPolicy(_NetPolicy):
     def __init__(self, observation_space, action_space, hidden_size=128, **kwargs):
         ek = _split_engine_kwargs(kwargs)
         super().__init__(AudioNavOptionNet(observation_space, action_space, hidden_size=hidden_size, **kwargs), 2, **ek)
+
+
+# SURVEY section 5 (the reference keeps pth_time / env_time around these calls, ppo_trainer.py:326-328, 726-734, 896): roctx ranges for
+# rocprofv3 --marker-trace, installed only with AVLEN_ROCTX=1
+CFG.add_ranges(Policy, ("act", "act_option", "act_dialog", "get_value", "get_value_option", "evaluate_actions", "evaluate_actions_option",
+                        "evaluate_actions_dialog", "prefetch_act", "prefetch_act_option", "prefetch_act_dialog", "dialog_ready",
+                        "prefetch_encoders"))

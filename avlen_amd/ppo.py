@@ -14,6 +14,7 @@ import torch.nn as nn
 import torch.distributed as distrib
 
 from . import _lib as L
+from . import config as CFG
 from . import engine as E
 
 EPS_PPO = 1e-5
@@ -261,3 +262,6 @@ class DecentralizedDistributedMixin:
 
 class DDPPO(DecentralizedDistributedMixin, PPO):
     pass
+
+
+CFG.add_ranges(PPO, ('update', 'update_dialog'), "PPO.")

@@ -17,6 +17,7 @@ import ctypes as C
 import torch
 
 from . import _lib as L
+from . import config as CFG
 from .engine import P
 
 
@@ -498,3 +499,6 @@ class RolloutStorage:
                    g(self.ucnt_gt), mem(self.em), mem(self.em_option), mem(self.em_vln), mem(self.em_vln_dialog),
                    g(self.em_masks), g(self.em_vln_masks), g(self.all_dialog), g(self.query_state),
                    g(self.last_query_info), g(self.agent_step))
+
+
+CFG.add_ranges(RolloutStorage, ('insert', 'compute_returns', 'after_update'), "RolloutStorage.")

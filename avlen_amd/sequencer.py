@@ -19,11 +19,11 @@ Nothing about the arithmetic changes: the same graphs, the same static buffers, 
 (tests/test_gpu_text_cache.py, tests/test_gpu_harness_parity.py hold the storage bit-equal).
 """
 import ctypes as C
-import os
 
 import torch
 
 from . import _lib as L
+from . import config as CFG
 from . import policy as P
 
 
@@ -49,10 +49,12 @@ class StepSequencer:
         self._cur = None                   # the running step: ("fast", plan, l_args) or ("slow", key, args, templates)
         self.fast = self.slow = 0
         self.ev = None
-        # lab: the followers start behind pi_q's whole forward instead of behind the shared encoders (pi_q's fused chain, 8
-        # latency-bound workgroups, takes 110 us beside pi_g's GEMMs and ~60 us alone)
-        self.followers_after_q = bool(int(os.environ.get("AVLEN_LAB_FOLLOW_AFTER_Q", "0")))
-        self.l2_on_side = bool(int(os.environ.get("AVLEN_LAB_L2_SIDE", "0")))
+        # measured and settled (profiles/r05_sequencer_ab.txt): followers behind pi_q's WHOLE forward instead of behind the shared
+        # encoders -- pi_q's chain does not get faster (it is slow because its weights are cold, not because of pi_g beside it) and
+        # pi_g then crawls beside the text tower: 1.64 -> 1.89 ms per step; pi_l's dialog half on the side stream behind an event vs
+        # on the caller's stream behind the text tower: no difference (1.65 ms both), the caller's stream needs one event less
+        self.followers_after_q = False
+        self.l2_on_side = False
 
     # ------------------------------------------------------------------------------------------------------------------
     def _events(self):
@@ -280,3 +282,6 @@ class StepSequencer:
         while len(self._plans) >= 1024:
             self._plans.pop(next(iter(self._plans)))
         self._plans[key] = pl
+
+
+CFG.add_ranges(StepSequencer, ('launch', 'dialog_ready'), "StepSequencer.")

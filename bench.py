@@ -154,9 +154,20 @@ def kernel_roofline(prec_name, in_situ=None, towers=None):
                "achieved": towers["TFLOPs"], "peak": 2500.0, "unit": "TFLOP/s", "frac": towers["frac_of_bf16_peak"],
                "traffic": tpmc.get("traffic_bytes"), "mfma_util_pmc_percent": tpmc.get("MfmaUtil_percent"),
                "algorithmic_flops": towers["flops"], "algorithmic_bytes": towers["algorithmic_hbm_bytes"],
-               "us_per_launch": towers["us"], "measured": "in situ: the product's grouped call, HIP events on the launch stream"}
+               "us_per_launch": towers["us"], "measured": "the product's grouped call alone on its stream, HIP events on the launch stream"}
+        step = towers.get("in_step")
+        if step:
+            # THE figure: the kernel's duration inside the timed rollout steps (stamped by the kernel itself, avlen_tower_x3_timing:
+            # ticket-0 workgroup's start to the last workgroup's exit, device wall clock), beside the other streams' work; the
+            # stand-alone figure (grouped call incl. its fc GEMM, nothing else running) stays as `isolated`
+            tf = towers["flops"] / (step["us"] * 1e-6) / 1e12
+            top["isolated"] = {"achieved": top["achieved"], "frac": top["frac"], "us_per_launch": top["us_per_launch"],
+                               "measured": top["measured"]}
+            top.update(achieved=round(tf, 1), frac=round(tf / 2500.0, 4), us_per_launch=step["us"],
+                       measured="in situ: mean over the %d tower launches of the timed rollout steps, stamped by the kernel on the "
+                                "device wall clock (first ticket to last exit)" % step["launches"])
         if x3:
-            top["mfma_issue_frac"] = round(3 * towers["frac_of_bf16_peak"], 4)
+            top["mfma_issue_frac"] = round(3 * top["frac"], 4)
             try:                                     # per conv INSIDE the fused bodies: from the committed phase-stamp profile (a lab
                 import tower_x3_phase_table as tpt   # build of the same kernel, tools/x3_lab.hip), not re-measured by this run
                 t = tpt.table(os.path.join(ROOT, "profiles", "r04_tower_x3_phases.txt" if os.path.exists(os.path.join(ROOT, "profiles", "r04_tower_x3_phases.txt")) else "r03_tower_x3_phases.txt"))
@@ -588,6 +599,13 @@ def main():
     for _ in range(a.warmup):
         wl.cycle()
     barrier()
+    import ctypes
+    from avlen_amd import _lib as L
+    x3_us, x3_n = ctypes.c_double(0.0), ctypes.c_longlong(0)
+    step_us = step_n = 0.0
+    probe_x3 = rank == 0 and a.precision == "bf16x3" and a.config == "interactive" and not a.no_roofline
+    if probe_x3:
+        L.lib.avlen_tower_x3_timing(None, None, 1)
     t0 = time.perf_counter()
     t_roll = 0.0
     for _ in range(a.steps):
@@ -596,7 +614,13 @@ def main():
             wl.rollout_step()
         torch.cuda.synchronize()
         t_roll += time.perf_counter() - s0
+        if probe_x3:                                      # the rollout's tower launches only (the update's run 25x the images)
+            L.lib.avlen_tower_x3_timing(ctypes.byref(x3_us), ctypes.byref(x3_n), 1)
+            step_us += x3_us.value * x3_n.value
+            step_n += x3_n.value
         last = wl.update()
+        if probe_x3:
+            L.lib.avlen_tower_x3_timing(None, None, 1)
     barrier()
     dt = time.perf_counter() - t0
     # outside the timed region: the run must have produced numbers (a kernel race shows up as NaN losses / memories, not a crash)
@@ -630,6 +654,8 @@ def main():
         if not a.no_roofline:
             situ = text_tower_in_situ(wl) if (interactive and fast) else None
             tw = towers_fused(wl) if (interactive and fast) else None
+            if tw is not None and step_n:
+                tw["in_step"] = {"us": round(step_us / step_n, 1), "launches": int(step_n)}
             rl = kernel_roofline(a.precision, situ, tw)
             if rl is not None:
                 out["roofline"] = rl

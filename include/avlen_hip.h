@@ -310,6 +310,10 @@ void avlen_set_x3_mixed_backward_rows(long rows);
 /* Scheduling knob of the bf16x3 tower group (one persistent work-queue launch, one workgroup per CU): CUs it leaves free for the
  * other streams of the step (default 0 = every CU). */
 void avlen_set_tower_x3_reserved_cus(int n);
+/* Measurement (bench.py's roofline record): mean duration in microseconds of the persistent bf16x3 tower launches since the last
+ * reset, as they ran -- inside the rollout step, beside the other streams -- and how many there were; stamped by the kernel itself
+ * on the device's constant-rate wall clock.  Synchronises the device.  reset != 0 clears the counters. */
+int avlen_tower_x3_timing(double* mean_us, long long* launches, int reset);
 /* DialogStateEncoder.single_forward (dialog_state_encoder.py:114-155): x_att (B,d), memory_state (M,B,d),
  * masks (B,M), d_emb (B,d) or NULL, agent_step (B) float, goal (B,d) -> out (B,d). */
 size_t avlen_dialog_workspace_bytes(const avlen_dialog* p, int B, int M);
@@ -328,6 +332,12 @@ int avlen_clip_text_fwd(const avlen_clip_text* p, const int64_t* tokens, float* 
 size_t avlen_clip_text_cache_bytes(const avlen_clip_text* p, int B);
 int avlen_clip_text_cached_fwd(const avlen_clip_text* p, const int64_t* tokens, void* state, size_t state_bytes, float* out, int B,
                                int prec, void* ws, size_t ws_bytes, avlen_stream_t stream);
+/* dialog_layer(CLIP.encode_text(tokens)) of the rollout step (policy.py:844-851) on the memoised tower above with its tail as ONE
+ * launch (memo update of the all-zero rows + ln_final + 16-bit cast + the product): p = the tower with text_proj == NULL, fold =
+ * dialog_layer with text_projection folded into its weight ([out_f][width], 16-bit shadow in the tower's format; out_f % 16 == 0,
+ * <= 256).  out (B, fold->out_f).  16-bit modes, width 512, B + 1 <= 512 only: AVLEN_ERR_ARG otherwise. */
+int avlen_clip_text_dialog_fwd(const avlen_clip_text* p, const avlen_linear* fold, const int64_t* tokens, void* state, size_t state_bytes,
+                               float* out, int B, int prec, void* ws, size_t ws_bytes, avlen_stream_t stream);
 /* The one-launch tower's weight stream (csrc/clip_tower.hip): bytes for `p` (0: shape not supported -- width 512, 8 heads,
  * ctx <= 80, 4x MLP, biases present) and the packer (fmt 0 bf16, 1 fp16; from the fp32 weights; derived data). */
 size_t avlen_clip_stream_bytes(const avlen_clip_text* p);

@@ -24,7 +24,8 @@ def _tokens(n, gen):
 
 
 def _policy(mode, stream, sd=None):
-    os.environ["AVLEN_CLIP_STREAM"] = "1" if stream else "0"
+    from avlen_amd import config as CFG
+    keep, CFG.CLIP_STREAM = CFG.CLIP_STREAM, bool(stream)      # (AVLEN_CLIP_STREAM: read when the engine builds the tower's views)
     try:
         torch.manual_seed(3)
         pol = P.AudioNavDialogPolicy(savi_observation_space((65, 26, 2)), ActionSpace(4), pretraining=False, num_steps=3,
@@ -33,7 +34,7 @@ def _policy(mode, stream, sd=None):
             pol.load_state_dict(sd)
         pol._engine()
     finally:
-        os.environ.pop("AVLEN_CLIP_STREAM", None)
+        CFG.CLIP_STREAM = keep
     return pol
 
 

@@ -390,8 +390,12 @@ def test_replayed_graph_follows_a_clip_weight_change(mode):
     want = call(fresh)
     torch.cuda.synchronize()
     assert not torch.equal(moved[0], first[0])
+    # (the memoised path ends in one fused tail launch, the uncached one in ln_final + cast + product launches: same operands,
+    # another summation order in the last 512-long product)
     for a, b in zip(moved, want):
-        assert torch.equal(a, b), float((a.float() - b.float()).abs().max())
+        assert float((a.float() - b.float()).abs().max()) <= 2e-5 * max(1.0, float(b.float().abs().max())), (a, b)
+    old = max(float((a.float() - b.float()).abs().max()) for a, b in zip(first, want))
+    assert old > 1e-3, old                                       # ... whereas the stale embedding is far away
 
 
 def test_deterministic_follower_under_auto_ahead_keeps_the_host_generator_in_step():

@@ -83,9 +83,17 @@ def check_function(name, lines):
 def device_isa(src):
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "k.s")
-        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-ffp-contract=off", "-S",
-               "--cuda-device-only", src, "-o", out] + [a for a in sys.argv[1:] if a.startswith("-D")]
-        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        # compiler and flags of the shipped objects: `make asmcheck` hands the Makefile's HIPCC / HIPFLAGS over; stand-alone the same
+        # defaults are spelled out here
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        flags = os.environ.get("HIPFLAGS", "--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Iinclude -Wall -Wno-unused-function "
+                                           "-ffp-contract=off").split()
+        flags = [("-I" + os.path.join(ROOT, f[2:])) if f.startswith("-I") and not os.path.isabs(f[2:]) else f for f in flags]
+        cmd = [hipcc] + flags + ["-S", "--cuda-device-only", src, "-o", out] + [a for a in sys.argv[1:] if a.startswith("-D")]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stderr)
+            raise SystemExit(f"asm_wait_check: `{' '.join(cmd)}` failed ({r.returncode})")
         return open(out).read().splitlines()
 
 

@@ -10,7 +10,8 @@ wl = Workload(64, 2, precision="fp32", use_graphs=False, share_encoders=False, l
 tok = wl.dialog[0]
 ref = None
 for mode, stream in (("fp32", "0"), ("bf16x3", "0"), ("bf16x3", "1"), ("bf16", "0"), ("bf16", "1")):
-    os.environ["AVLEN_CLIP_STREAM"] = stream
+    from avlen_amd import config as CFG
+    CFG.CLIP_STREAM = stream != "0"
     torch.manual_seed(0)
     pol = P.AudioNavDialogPolicy(savi_observation_space((257, 101, 2)), ActionSpace(4), pretraining=False, num_steps=3,
                                  precision=mode, **SMT_KW).to("cuda")
