@@ -156,7 +156,7 @@ SIGNATURES = {
     "avlen_preprocess_image": (i32, [vp, i32, vp, i32, i32, i32, f32, vp]),
     "avlen_rgbd_concat": (i32, [vp, i32, vp, vp, i32, i32, vp]),
     "avlen_feature_assemble": (i32, [vp, i32, C.POINTER(Linear), vp, i32, vp, i32, vp, i32, vp, i32, i32, vp, vp, vp,
-                                     i32, i32, vp]),
+                                     i32, i32, vp, i32, i32, vp, i32, i32, i32, vp]),
     "avlen_concat_rows": (i32, [vp, i32, i32, vp, i32, i32, vp, i32, i32, vp]),
     "avlen_resnet18_workspace_bytes": (sz, [i32]),
     "avlen_resnet18_fwd": (i32, [C.POINTER(ResNet18), vp, i32, i32, i32, i32, f32, vp, i32, i32, vp, sz, vp]),

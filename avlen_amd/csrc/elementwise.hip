@@ -81,10 +81,14 @@ __global__ void assemble_kernel(float* __restrict__ feats, int ldf, const float*
                                 const float* __restrict__ category, int col_cat, const float* __restrict__ pose,
                                 int col_pose, const float* __restrict__ extra, int n_extra, int col_extra,
                                 const float* __restrict__ cbel, const float* __restrict__ lbel, float* __restrict__ goal,
-                                int d_goal, int B) {
+                                int d_goal, int B, const float* __restrict__ vis, int ld_vis, int n_vis,
+                                const float* __restrict__ aud, int ld_aud, int n_aud, int col_aud) {
   int b = blockIdx.x, t = threadIdx.x;
   if (b >= B) return;
   float* f = feats + (long)b * ldf;
+  // encoder columns computed elsewhere (an EncoderGroup's shared buffers): copied here instead of by two copy_rows launches
+  if (vis) for (int i = t; i < n_vis; i += blockDim.x) f[i] = vis[(long)b * ld_vis + i];
+  if (aud) for (int i = t; i < n_aud; i += blockDim.x) f[col_aud + i] = aud[(long)b * ld_aud + i];
   if (aw && t < n_act_out) {
     long a = prev_actions[b];
     float v = ab[t];
@@ -182,13 +186,14 @@ extern "C" int avlen_feature_assemble(float* feats, int ldf, const avlen_linear*
                                       int col_action, const float* category, int col_cat, const float* pose,
                                       int col_pose, const float* extra, int n_extra, int col_extra,
                                       const float* category_belief, const float* location_belief, float* goal,
-                                      int d_goal, int B, hipStream_t stream) {
+                                      int d_goal, int B, const float* vis, int ld_vis, int n_vis, const float* aud, int ld_aud,
+                                      int n_aud, int col_aud, hipStream_t stream) {
   if (B <= 0) return AVLEN_ERR_ARG;
   if (act && (act->out_f > 64 || !prev_actions)) return AVLEN_ERR_ARG;
   hipLaunchKernelGGL(assemble_kernel, dim3(B), dim3(64), 0, stream, feats, ldf, act ? act->w : nullptr,
                      act ? act->b : nullptr, act ? act->out_f : 0, act ? act->in_f : 0, prev_actions, col_action,
                      category, col_cat, pose, col_pose, extra, n_extra, col_extra, category_belief, location_belief,
-                     goal, d_goal, B);
+                     goal, d_goal, B, vis, ld_vis, n_vis, aud, ld_aud, n_aud, col_aud);
   return avlen_launch_status();
 }
 

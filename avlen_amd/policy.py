@@ -1515,6 +1515,7 @@ class _SMTBase(Net):
         fork = torch.cuda.is_current_stream_capturing()
         mode, grp = pol._shared_mode, pol._enc_group
         x3 = prec == L.PREC_BF16X3 and bool(eng["rgb"].conv1.w16lo)
+        vis = aud = None                                 # an EncoderGroup's shared feature buffers (copied into `feats` by the assemble launch)
         if prec == L.PREC_BF16 or x3:
             # bf16 fast path: the towers run as grouped launches (rgb+depth of this policy, or -- leader of an
             # EncoderGroup -- all towers of all member policies); the audio CNN is a parallel branch under capture
@@ -1548,8 +1549,7 @@ class _SMTBase(Net):
                     else:
                         L.call("avlen_cnn3_fwd", C.byref(eng["audio"]), E.P(spec), B, H, W, E.P(feats, 144), F, prec_a, E.P(ws2), nb2,
                                L.stream())
-                if aud is not None:
-                    L.call("avlen_copy_rows", E.P(aud), 128, E.P(feats, 144), F, B, 128, L.stream())
+                # (a group's audio / visual feature rows reach `feats` inside avlen_feature_assemble below)
             if mode == "follow":
                 vis = grp.buffers(B, dev)[grp.members.index(pol)]
             elif mode == "lead":
@@ -1583,8 +1583,6 @@ class _SMTBase(Net):
                                nbg, st)
                     else:
                         L.call("avlen_resnet18_group_fwd", nets, imgs, u8, chans, divs, outs, F, G, B, S, E.P(wsg), nbg, st)
-            if vis is not None:
-                L.call("avlen_copy_rows", E.P(vis), 128, E.P(feats), F, B, 128, st)
             s_rgb = s_dep = s_aud
         else:
             nb = L.lib.avlen_resnet18_workspace_bytes(B)
@@ -1610,7 +1608,8 @@ class _SMTBase(Net):
         L.call("avlen_feature_assemble", E.P(feats), F, C.byref(eng["action"]), E.P(pa), 128,
                E.P(cat) if cat is not None else None, self._col_cat, E.P(pose), pose_col,
                E.P(ex) if ex is not None else None, ex.shape[1] if ex is not None else 0, self._x_dims, E.P(cb), E.P(lb),
-               E.P(goal), self._hidden_size, B, st)
+               E.P(goal), self._hidden_size, B, E.P(vis) if vis is not None else None, 128, 128,
+               E.P(aud) if aud is not None else None, 128, 128, 144, st)
         if fork:
             for s_ in (s_rgb, s_dep):
                 if s_ is not cur:
@@ -1653,7 +1652,7 @@ class _SMTBase(Net):
         L.call("avlen_feature_assemble", E.P(feats), F, C.byref(eng["action"]), E.P(pa), 128,
                E.P(cat) if cat is not None else None, self._col_cat, E.P(pose), self._x_dims - 4,
                E.P(ex) if ex is not None else None, ex.shape[1] if ex is not None else 0, self._x_dims, E.P(cb), E.P(lb),
-               E.P(goal), self._hidden_size, B, st)
+               E.P(goal), self._hidden_size, B, None, 0, 0, None, 0, 0, 0, st)
         return feats, goal
 
     def smt(self, pol, feats, goal, ext_memory, ext_memory_masks, save_key="smt", mem_index=None, save=False):
@@ -1996,7 +1995,7 @@ class AudioNavDialogNet(_SMTBase):
         pa = _i64(prev_actions.view(R, -1)[:, :1])
         pose, cb, lb = _f32(obs[POSE]), _f32(obs[CATEGORY_BELIEF]), _f32(obs[LOCATION_BELIEF])
         L.call("avlen_feature_assemble", E.P(feats), F, C.byref(eng["action"]), E.P(pa), 128, None, self._col_cat, E.P(pose),
-               self._x_dims - 4, None, 0, self._x_dims, E.P(cb), E.P(lb), E.P(goal), self._hidden_size, R, st)
+               self._x_dims - 4, None, 0, self._x_dims, E.P(cb), E.P(lb), E.P(goal), self._hidden_size, R, None, 0, 0, None, 0, 0, 0, st)
         x_att, smt_saved = self.smt(pol, feats, goal, ext_memory, ext_memory_masks, "smt_train", mem_index, save=True)
         d_emb = e = None
         if all_dialog is not None:

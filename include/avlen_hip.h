@@ -197,11 +197,14 @@ int avlen_rgbd_concat(const void* rgb, int rgb_u8, const float* depth, float* y,
  *   feats[b, col_cat .. +21)      = category[b]              (only if category != NULL)
  *   feats[b, col_pose .. +4)      = pose[b]
  *   feats[b, col_extra .. +n_extra) = extra[b]               (query_state; only if extra != NULL)
- * and the belief/goal vector (policy.py:605-618): goal[b] = [category_belief(21) | location_belief(2) | 0...]. */
+ * and the belief/goal vector (policy.py:605-618): goal[b] = [category_belief(21) | location_belief(2) | 0...].
+ * vis / aud (optional): encoder feature rows computed into other buffers (the shared towers / AudioCNNs of several policies):
+ * feats[b, 0 .. n_vis) = vis[b], feats[b, col_aud .. +n_aud) = aud[b] -- policy.py:662-668's torch.cat as part of this launch. */
 int avlen_feature_assemble(float* feats, int ldf, const avlen_linear* action_encoder, const int64_t* prev_actions,
                            int col_action, const float* category, int col_cat, const float* pose, int col_pose,
                            const float* extra, int n_extra, int col_extra, const float* category_belief,
-                           const float* location_belief, float* goal, int d_goal, int B, avlen_stream_t stream);
+                           const float* location_belief, float* goal, int d_goal, int B, const float* vis, int ld_vis, int n_vis,
+                           const float* aud, int ld_aud, int n_aud, int col_aud, avlen_stream_t stream);
 /* rows[b] = [feats[b, 0:n_keep) | tail[b]]: the external-memory row of pi_q (policy.py:1062-1063). */
 int avlen_concat_rows(const float* a, int lda, int na, const float* b, int ldb, int nb, float* out, int ldo, int B,
                       avlen_stream_t stream);
