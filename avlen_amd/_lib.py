@@ -139,6 +139,7 @@ SIGNATURES = {
     "avlen_pack_fc_after_flatten_h16": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "avlen_resnet18_group_x3_workspace_bytes": (sz, [i32, i32]),
     "avlen_resnet18_group_fwd_x3": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, sz, vp]),
+    "avlen_resnet18_group_fwd_x3_phase": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp, sz, vp]),
     "avlen_gemm_h16": (i32, [vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     "avlen_pack_conv_weight_bf16": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "avlen_pack_conv_weight_frag": (i32, [vp, vp, i32, i32, vp]),
@@ -194,7 +195,7 @@ SIGNATURES = {
     "avlen_clip_text_fwd": (i32, [C.POINTER(ClipText), vp, vp, i32, i32, vp, sz, vp]),
     "avlen_clip_text_cache_bytes": (sz, [C.POINTER(ClipText), i32]),
     "avlen_clip_text_cached_fwd": (i32, [C.POINTER(ClipText), vp, vp, sz, vp, i32, i32, vp, sz, vp]),
-    "avlen_clip_text_dialog_fwd": (i32, [C.POINTER(ClipText), C.POINTER(Linear), vp, vp, sz, vp, i32, i32, vp, sz, vp]),
+    "avlen_clip_text_dialog_fwd": (i32, [C.POINTER(ClipText), C.POINTER(Linear), vp, vp, sz, vp, i32, i32, vp, sz, vp, vp, i32, vp]),
     "avlen_clip_stream_bytes": (sz, [C.POINTER(ClipText)]),
     "avlen_clip_pack_stream": (i32, [C.POINTER(ClipText), vp, i32, vp]),
     "avlen_gru_workspace_bytes": (sz, [C.POINTER(Gru), i32, i32]),

@@ -1130,10 +1130,13 @@ extern "C" int avlen_resnet18_group_fwd_indexed(const avlen_resnet18* const* net
 extern "C" size_t avlen_resnet18_group_x3_workspace_bytes(int groups, int B) {
   return avlen_tower_x3_workspace_bytes(groups, B) + (size_t)groups * ((size_t)B * 8192 * sizeof(float) + 256) + GEMM_SCRATCH + 4096;
 }
-extern "C" int avlen_resnet18_group_fwd_x3(const avlen_resnet18* const* nets, const void* const* imgs, const int* img_u8,
-                                           const int* channels, const float* divisors, float* const* outs, int ld_out, int groups,
-                                           int B, int S, const int32_t* row_index, void* ws, size_t ws_bytes, hipStream_t st) {
-  if (!nets || groups < 1 || groups > 8 || B <= 0) return AVLEN_ERR_ARG;
+// phase: 1 = the towers only (layer-4 outputs stay in the workspace), 2 = the fc only (on the workspace the same call with phase 1
+// filled), 3 = both.  The step sequencer replays the two as separate graph pieces: the fc beside the AudioCNNs, not in front of them.
+extern "C" int avlen_resnet18_group_fwd_x3_phase(const avlen_resnet18* const* nets, const void* const* imgs, const int* img_u8,
+                                                 const int* channels, const float* divisors, float* const* outs, int ld_out, int groups,
+                                                 int B, int S, const int32_t* row_index, int phase, void* ws, size_t ws_bytes,
+                                                 hipStream_t st) {
+  if (!nets || groups < 1 || groups > 8 || B <= 0 || phase < 1 || phase > 3) return AVLEN_ERR_ARG;
   if (ws_bytes < avlen_resnet18_group_x3_workspace_bytes(groups, B)) return AVLEN_ERR_WS;
   for (int g = 0; g < groups; g++)
     if (!avlen_tower_x3_supported(nets[g], S, channels[g])) return AVLEN_ERR_ARG;
@@ -1143,7 +1146,8 @@ extern "C" int avlen_resnet18_group_fwd_x3(const avlen_resnet18* const* nets, co
   void* gws = w.take<char>(GEMM_SCRATCH);
   const size_t tb = avlen_tower_x3_workspace_bytes(groups, B);
   void* tws = w.take<char>(tb);
-  TRY(avlen_tower_x3_fwd(nets, imgs, img_u8, channels, divisors, row_index, Y, groups, B, S, tws, tb, st));
+  if (phase & 1) TRY(avlen_tower_x3_fwd(nets, imgs, img_u8, channels, divisors, row_index, Y, groups, B, S, tws, tb, st));
+  if (!(phase & 2)) return AVLEN_OK;
   // fc (8192 -> 64) of all towers: one grouped compensated GEMM (the weights' low planes lie at one common distance)
   const void* FA[8]; const void* FB[8]; const float* FBI[8];
   const avlen_linear& fc = nets[0]->fc;
@@ -1154,6 +1158,12 @@ extern "C" int avlen_resnet18_group_fwd_x3(const avlen_resnet18* const* nets, co
     FA[g] = Y[g]; FB[g] = f.w16; FBI[g] = f.b;
   }
   return avlen_gemm_bf16_grouped(FA, 8192, FB, 8192, outs, ld_out, FBI, groups, B, fc.out_f, 8192, 0, gws, GEMM_SCRATCH, st, &o);
+}
+
+extern "C" int avlen_resnet18_group_fwd_x3(const avlen_resnet18* const* nets, const void* const* imgs, const int* img_u8,
+                                           const int* channels, const float* divisors, float* const* outs, int ld_out, int groups,
+                                           int B, int S, const int32_t* row_index, void* ws, size_t ws_bytes, hipStream_t st) {
+  return avlen_resnet18_group_fwd_x3_phase(nets, imgs, img_u8, channels, divisors, outs, ld_out, groups, B, S, row_index, 3, ws, ws_bytes, st);
 }
 
 extern "C" int avlen_resnet18_fwd(const avlen_resnet18* net, const void* img, int img_u8, int B, int S, int C, float divisor,
@@ -2209,20 +2219,40 @@ __global__ __launch_bounds__(128) void text_cache_zero_rows_kernel(float* __rest
 // text_cache_zero_rows_kernel does), ln_final of every row, the cast to the tower's 16-bit format and dialog_layer o text_projection
 // as one 16-row MFMA product (policy.py:847-849: dialog_layer(encode_text(x)); the projection is folded into the Linear's weight,
 // engine.Packed.proj_fold).  Was four launches of 5-9 us each behind the text tower, on the step's critical path.
-// Block = 16 rows, 4 waves; wave w owns output features 64 w .. 64 w + 63 (4 MFMA tiles), K = 512 in 16 steps; the A operand is the
-// weight fragment ([16 features][32 k], 16-byte loads from the row-major 16-bit weight), the B operand the rows' 16-bit image in
-// LDS -- the result tile is lane (c = lane & 15: row, q = lane >> 4: features 4 q .. 4 q + 3), as in chain.hip.
+// Block (x, y) = 16 rows x 64 output features, 4 waves; wave w owns features 64 y + 16 w .. + 15 (one MFMA tile), K = 512 in 16
+// steps; the A operand is the weight fragment ([16 features][32 k], 16-byte loads from the row-major 16-bit weight), the B operand
+// the rows' 16-bit image in LDS (every block of a row group normalises its 16 rows itself: 32 KB of reads against a launch of its
+// own) -- the result tile is lane (c = lane & 15: row, q = lane >> 4: features 4 q .. 4 q + 3), as in chain.hip.  Blocks with
+// x >= ceil(B / 16) do no arithmetic: they warm the L2s with the weight ranges in `pf` (the dialog state encoder's fused chain
+// runs right behind this launch and the text tower has just swept the caches: elementwise.hip, prefetch_l2_kernel).
+struct TailPrefetch { const char* p[4]; long n16[4]; int n; };
 typedef __attribute__((ext_vector_type(8))) _Float16 mf16x8;
 typedef __attribute__((ext_vector_type(4))) float mf32x4;
 template <bool F16>
 __global__ __launch_bounds__(256) void text_tail_kernel(float* __restrict__ E, const int* __restrict__ hdr, const int* __restrict__ zidx,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const unsigned short* __restrict__ w16, int ldw, const float* __restrict__ bias,
-                                                        float* __restrict__ out, int ldo, int B, int N) {
+                                                        float* __restrict__ out, int ldo, int B, int N, int row_blocks, TailPrefetch pf,
+                                                        unsigned* __restrict__ sink) {
   constexpr int WD = 512, XLD = WD + 8;
   __shared__ __attribute__((aligned(16))) unsigned short xs[16 * XLD];
   __shared__ int zrow[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r0 = blockIdx.x * 16;
+  if ((int)blockIdx.x >= row_blocks) {                     // prefetch role: block b serves XCD b % 8, slice b / 8
+    const int pb = (blockIdx.x - row_blocks) * gridDim.y + blockIdx.y, np = (gridDim.x - row_blocks) * gridDim.y;
+    const int slices = np >> 3, slice = pb >> 3;
+    unsigned acc = 0;
+    if (slices > 0 && slice < slices)
+      for (int r = 0; r < pf.n; r++) {
+        const uint4* src = reinterpret_cast<const uint4*>(pf.p[r]);
+        const long per = (pf.n16[r] + slices - 1) / slices, lo = per * slice, hi = lo + per < pf.n16[r] ? lo + per : pf.n16[r];
+        long i = lo + tid;
+        for (; i + 3 * 256 < hi; i += 4 * 256) { const uint4 v0 = src[i], v1 = src[i + 256], v2 = src[i + 512], v3 = src[i + 768]; acc ^= v0.x ^ v1.x ^ v2.x ^ v3.x; }
+        for (; i < hi; i += 256) acc ^= src[i].x;
+      }
+    if (acc == 0x9e3779b9u && sink) *sink = acc;
+    return;
+  }
   if (tid < 16) zrow[tid] = 0;
   __syncthreads();
   const int nz = hdr ? hdr[2] : 0;
@@ -2240,7 +2270,7 @@ __global__ __launch_bounds__(256) void text_tail_kernel(float* __restrict__ E, c
     float v[8], s = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; i++) { v[i] = src[lane + i * 64]; s += v[i]; }
-    if (zrow[rr]) {
+    if (zrow[rr] && blockIdx.y == 0) {
 #pragma unroll
       for (int i = 0; i < 8; i++) E[(long)row * WD + lane + i * 64] = v[i];   // the memo keeps every row's tower output
     }
@@ -2260,13 +2290,13 @@ __global__ __launch_bounds__(256) void text_tail_kernel(float* __restrict__ E, c
   __syncthreads();
   // ---- out[row][n] = bias[n] + sum_k x16[row][k] * w16[n][k]
   const int c = lane & 15, q = lane >> 4;
-  for (int nt = 0; nt < 4; nt++) {
-    const int n0 = wave * 64 + nt * 16;
-    if (n0 >= N) break;
+  {
+    const int n0 = blockIdx.y * 64 + wave * 16;
+    if (n0 >= N) return;
     mf32x4 acc = (mf32x4){0.f, 0.f, 0.f, 0.f};
     const unsigned short* wr = w16 + (long)(n0 + c) * ldw + q * 8;
     const unsigned short* xr = xs + c * XLD + q * 8;
-#pragma unroll 4
+#pragma unroll
     for (int k = 0; k < WD; k += 32) {
       const uint4 wv = *reinterpret_cast<const uint4*>(wr + k);
       const uint4 xv = *reinterpret_cast<const uint4*>(xr + k);
@@ -2286,7 +2316,8 @@ __global__ __launch_bounds__(256) void text_tail_kernel(float* __restrict__ E, c
 // ([out_f][width], 16-bit shadow in the tower's format).  out (B, fold->out_f) fp32.  16-bit modes and B + 1 <= 512 rows only
 // (AVLEN_ERR_ARG otherwise: the caller takes avlen_clip_text_cached_fwd + its own product).
 extern "C" int avlen_clip_text_dialog_fwd(const avlen_clip_text* p, const avlen_linear* fold, const int64_t* tokens, void* state,
-                                          size_t state_bytes, float* out, int B, int prec, void* ws, size_t ws_bytes, hipStream_t st) {
+                                          size_t state_bytes, float* out, int B, int prec, void* ws, size_t ws_bytes,
+                                          const void* const* warm_ptrs, const int64_t* warm_bytes, int n_warm, hipStream_t st) {
   if (!p || !fold || !tokens || !state || !out || B <= 0) return AVLEN_ERR_ARG;
   const int wd = p->width;
   const bool f16 = prec == AVLEN_PREC_FP16;
@@ -2304,13 +2335,22 @@ extern "C" int avlen_clip_text_dialog_fwd(const avlen_clip_text* p, const avlen_
   if (!w.ok()) return AVLEN_ERR_WS;
   const avlen_clip_memo memo{tokens, c.prev, c.hdr, c.zidx};
   TRY(avlen_clip_tower_stream_fwd(p, c.prev, c.E, B + 1, f16 ? 1 : 0, sws, sb, st, &memo));
-  const dim3 grid((unsigned)((B + 15) / 16));
+  TailPrefetch pf = {};
+  if (n_warm < 0 || n_warm > 4 || (n_warm > 0 && (!warm_ptrs || !warm_bytes))) return AVLEN_ERR_ARG;
+  for (int i = 0; i < n_warm; i++) {
+    if (!warm_ptrs[i] || warm_bytes[i] < 0 || ((uintptr_t)warm_ptrs[i] & 15)) return AVLEN_ERR_ARG;
+    pf.p[pf.n] = (const char*)warm_ptrs[i]; pf.n16[pf.n] = warm_bytes[i] >> 4; pf.n++;
+  }
+  const int rb = (B + 15) / 16, ny = (fold->out_f + 63) / 64;
+  // prefetch blocks: 8 XCDs x 32 slices as elementwise.hip's avlen_prefetch_l2, rounded up to whole grid columns
+  const int pcols = pf.n ? (256 + ny - 1) / ny : 0;
+  const dim3 grid((unsigned)(rb + pcols), (unsigned)ny);
   if (f16)
     hipLaunchKernelGGL(text_tail_kernel<true>, grid, dim3(256), 0, st, c.E, c.hdr, c.zidx, p->ln_final.g, p->ln_final.b,
-                       (const unsigned short*)fold->w16, fold->ld16, fold->b, out, fold->out_f, B, fold->out_f);
+                       (const unsigned short*)fold->w16, fold->ld16, fold->b, out, fold->out_f, B, fold->out_f, rb, pf, (unsigned*)nullptr);
   else
     hipLaunchKernelGGL(text_tail_kernel<false>, grid, dim3(256), 0, st, c.E, c.hdr, c.zidx, p->ln_final.g, p->ln_final.b,
-                       (const unsigned short*)fold->w16, fold->ld16, fold->b, out, fold->out_f, B, fold->out_f);
+                       (const unsigned short*)fold->w16, fold->ld16, fold->b, out, fold->out_f, B, fold->out_f, rb, pf, (unsigned*)nullptr);
   return avlen_launch_status();
 }
 extern "C" size_t avlen_clip_text_cache_bytes(const avlen_clip_text* p, int B) {

@@ -141,7 +141,9 @@ class _Graph:
             # EncoderGroup cuts a third, LINEAR piece out (`split_audio()`: the AudioCNNs, between the towers and the rest): a
             # forked branch inside one graph made its launch cost 54 us on the step's critical path (the towers' launch: 11 us as a
             # linear graph), and as a graph of its own the audio branch can be replayed on another stream.
-            self.graph, self.graph_a, self.graph2, self.between, self.mid = torch.cuda.CUDAGraph(), None, None, None, None
+            # A compensated-bf16 leader cuts a FOURTH piece (`split_fc()`): the towers' fc GEMM, so that the replay can run the
+            # AudioCNNs directly behind the towers on the caller's stream and the fc beside them on the side stream.
+            self.graph, self.graph_f, self.graph_a, self.graph2, self.between, self.mid = torch.cuda.CUDAGraph(), None, None, None, None, None
             cap = _capture_stream()
             cap.wait_stream(_cur_stream())
             pol._capture = self
@@ -160,6 +162,7 @@ class _Graph:
             self.ws = pol._ws
             # raw hipGraphExec_t handles: the step sequencer (sequencer.py) launches them from its recorded command lists
             self.exec1 = self.graph.raw_cuda_graph_exec()
+            self.exec_f = self.graph_f.raw_cuda_graph_exec() if self.graph_f is not None else None
             self.exec_a = self.graph_a.raw_cuda_graph_exec() if self.graph_a is not None else None
             self.exec2 = self.graph2.raw_cuda_graph_exec() if self.graph2 is not None else None
         finally:
@@ -179,13 +182,24 @@ class _Graph:
         AudioCNNs) becomes a graph of its own."""
         if self.graph_a is not None or self.graph2 is not None:
             return
-        self.graph.capture_end()
+        self._capturing.capture_end()
         self.graph_a = self._capturing = torch.cuda.CUDAGraph()
         self.graph_a.capture_begin(self.graph.pool())
+
+    def split_fc(self):
+        """Called by a compensated-bf16 leader right behind the tower launch: the towers' fc (and the weight prefetch behind it)
+        becomes a graph of its own, in front of the audio piece."""
+        if self.graph_f is not None or self.graph_a is not None or self.graph2 is not None:
+            return
+        self.graph.capture_end()
+        self.graph_f = self._capturing = torch.cuda.CUDAGraph()
+        self.graph_f.capture_begin(self.graph.pool())
 
     def replay_first(self):
         """Everything in front of the cut, on the current stream."""
         self.graph.replay()
+        if self.graph_f is not None:
+            self.graph_f.replay()
         if self.graph_a is not None:
             self.graph_a.replay()
 
@@ -572,7 +586,8 @@ class EncoderGroup:
         L.call("avlen_cnn3_group_fwd", nets, E.P(spec), G, B, H, W, outs, 128, E.P(ws), nb, L.stream())
         return bufs[0]
 
-    def run_all(self, pol, rgb, depth):
+    def run_all(self, pol, rgb, depth, phase=3):
+        """phase (compensated bf16 only): 1 = the tower launch, 2 = the fc on its outputs, 3 = both."""
         B, dev = rgb.shape[0], rgb.device
         bufs = self.buffers(B, dev)
         G = 2 * len(self.members)
@@ -590,9 +605,10 @@ class EncoderGroup:
         if pol.prec_of("towers") == L.PREC_BF16X3:
             nb = L.lib.avlen_resnet18_group_x3_workspace_bytes(G, B)
             ws = pol._ws.get("resnet_group_x3", nb, dev)
-            L.call("avlen_resnet18_group_fwd_x3", nets, imgs, u8, chans, divs, outs, 128, G, B, rgb.shape[1], None, E.P(ws), nb,
-                   L.stream())
+            L.call("avlen_resnet18_group_fwd_x3_phase", nets, imgs, u8, chans, divs, outs, 128, G, B, rgb.shape[1], None, phase,
+                   E.P(ws), nb, L.stream())
             return bufs[0]
+        assert phase == 3
         nb = L.lib.avlen_resnet18_group_workspace_bytes(G, B)
         ws = pol._ws.get("resnet_group", nb, dev)
         L.call("avlen_resnet18_group_fwd", nets, imgs, u8, chans, divs, outs, 128, G, B, rgb.shape[1], E.P(ws), nb, L.stream())
@@ -1331,7 +1347,14 @@ class Policy(nn.Module):
             # spectrogram only (stage event) and is waited for by the rest of the forward (audio event, checked in _graphed)
             side, (stage_ev, aud_ev) = grp.side_stream().cuda_stream, grp.audio_events()
             lst = [(L.CMD_MULTICOPY, n) + tuple(C.cast(x, C.c_void_p).value for x in arrs) + (raw,)]
-            if g.exec_a is not None:
+            if g.exec_f is not None and g.exec_a is not None:
+                # towers, then the audio piece on THIS stream; the fc piece on the side stream behind the towers' event (stage_ev);
+                # the rest of the forward waits for the fc's event (aud_ev: "what ran on the side stream is done")
+                lst += [(L.CMD_GRAPH, 0, g.exec1, raw, None, None), (L.CMD_RECORD, 0, stage_ev.cuda_event, raw, None, None),
+                        (L.CMD_GRAPH, 0, g.exec_a, raw, None, None),
+                        (L.CMD_WAIT, 0, side, stage_ev.cuda_event, None, None), (L.CMD_GRAPH, 0, g.exec_f, side, None, None),
+                        (L.CMD_RECORD, 0, aud_ev.cuda_event, side, None, None)]
+            elif g.exec_a is not None:
                 lst += [(L.CMD_RECORD, 0, stage_ev.cuda_event, raw, None, None), (L.CMD_GRAPH, 0, g.exec1, raw, None, None),
                         (L.CMD_WAIT, 0, side, stage_ev.cuda_event, None, None), (L.CMD_GRAPH, 0, g.exec_a, side, None, None),
                         (L.CMD_RECORD, 0, aud_ev.cuda_event, side, None, None)]
@@ -1531,9 +1554,16 @@ class _SMTBase(Net):
             if mode == "lead" and fork:
                 # capture order = submission order of the replay: the towers' persistent launch is the step's critical path and goes
                 # first; the audio piece runs behind / beside it
-                vis_early = grp.run_all(pol, rgb, depth)
+                if x3 and pol._capture is not None:
+                    # towers | fc + weight prefetch | audio: the replay runs the AudioCNNs right behind the towers and the fc (whose
+                    # 30 us sat between them) beside them on the side stream
+                    vis_early = grp.run_all(pol, rgb, depth, phase=1)
+                    pol._capture.split_fc()
+                    grp.run_all(pol, rgb, depth, phase=2)
+                else:
+                    vis_early = grp.run_all(pol, rgb, depth)
                 if pol._capture is not None:
-                    # the caller's stream now waits for the audio piece: the state encoder's weights come into the L2s meanwhile
+                    # the state encoder's weights come into the L2s while the audio piece runs
                     self.prefetch_weights(pol, ("net.smt_state_encoder.",))
                     pol._capture.split_audio()
             with torch.cuda.stream(s_aud):
@@ -1616,10 +1646,11 @@ class _SMTBase(Net):
                     cur.wait_stream(s_)
         return feats, goal
 
-    def prefetch_weights(self, pol, prefixes):
+    def prefetch_weights(self, pol, prefixes, plan_only=False):
         """Warm every XCD's L2 with the 16-bit weight planes of the parameters under `prefixes` (avlen_prefetch_l2), on the current
         stream: issued where the stream would otherwise idle, a few tens of microseconds before a fused chain streams them (the
-        chain runs 62 us on warm weights and ~100 us on cold ones; in the rollout step they are always cold)."""
+        chain runs 62 us on warm weights and ~100 us on cold ones; in the rollout step they are always cold).  plan_only: return
+        (pointer array, byte counts, n) for a launch that does the warming with its spare workgroups (the text tail)."""
         eng = pol._engine()
         flat = eng["flat"]
         key = ("prefetch", prefixes)
@@ -1635,6 +1666,8 @@ class _SMTBase(Net):
             else:
                 plan = (None, None, 0)
             eng[key] = plan
+        if plan_only:
+            return plan
         if plan[2]:
             L.call("avlen_prefetch_l2", plan[0], plan[1], plan[2], L.stream())
 
@@ -1831,7 +1864,7 @@ class AudioNavDialogNet(_SMTBase):
         enc = self.encode_text_cached if self.text_cache else self.encode_text
         if "dialog_fold" in eng and pol.prec_of("clip") in (L.PREC_BF16, L.PREC_FP16):
             fold = eng["dialog_fold"]
-            if self.text_cache and tokens.shape[0] + 1 <= 512 and fold.out_f % 16 == 0 and fold.out_f <= 256 and fold.in_f == 512:
+            if self._fused_tail(pol, tokens.shape[0]):
                 # memoised tower + ONE tail launch (memo rows, ln_final, 16-bit cast, the folded product): avlen_clip_text_dialog_fwd
                 tok = _i64(tokens)
                 B = tok.shape[0]
@@ -1842,11 +1875,20 @@ class AudioNavDialogNet(_SMTBase):
                 out = torch.empty(B, fold.out_f, device=tok.device)
                 nb = L.lib.avlen_clip_text_workspace_bytes(C.byref(clip), B + 1)
                 ws = pol._ws.get("clip_cached", nb, tok.device)
+                # ... whose spare workgroups warm the L2s with the dialog state encoder's weights: its chain is next
+                warm = self.prefetch_weights(pol, ("net.dialog_state_encoder.",), plan_only=True)
                 L.call("avlen_clip_text_dialog_fwd", C.byref(clip), C.byref(fold), E.P(tok), E.P(state), state.numel(), E.P(out), B,
-                       pol.prec_of("clip"), E.P(ws), nb, L.stream())
+                       pol.prec_of("clip"), E.P(ws), nb, warm[0], warm[1], warm[2], L.stream())
                 return out
             return self._dialog_embed(pol, enc(pol, tokens, project=False), fold)
         return self._dialog_embed(pol, enc(pol, tokens))
+
+    def _fused_tail(self, pol, B):
+        """The rollout's text graph ends in avlen_clip_text_dialog_fwd's one tail launch (which also warms the dialog chain's weights)."""
+        eng = pol._engine()
+        fold = eng.get("dialog_fold")
+        return (fold is not None and pol.prec_of("clip") in (L.PREC_BF16, L.PREC_FP16) and self.text_cache and B + 1 <= 512
+                and fold.out_f % 16 == 0 and fold.out_f <= 256 and fold.in_f == 512)
 
     text_encoder_override = None      # tests: callable(tokens)->(B,512) replacing the CLIP tower (unpinned, SURVEY §8c)
     _text = None                      # (tokens ptr, shape, static embedding, event) of the last prefetch_text
@@ -1950,9 +1992,11 @@ class AudioNavDialogNet(_SMTBase):
                 cur.wait_stream(s_txt)
             if fork and pre is not None and getattr(pol, "_capture", None) is not None and _SPLIT:
                 pol._capture.split()                     # everything above does not need the text embedding
-                # the dialog half starts right behind the text tower, which has swept the caches: 10 us of prefetch buy ~40 us
-                # of the dialog encoder's fused chain
-                self.prefetch_weights(pol, ("net.dialog_state_encoder.",))
+                # the dialog half starts right behind the text tower, which has swept the caches: the dialog encoder's fused chain
+                # wants its weights warm -- the text graph's tail launch has done that with its spare workgroups, or 10 us of
+                # prefetch here buy ~25 us of the chain
+                if not (self.text_encoder_override is None and self._fused_tail(pol, x_att.shape[0])):
+                    self.prefetch_weights(pol, ("net.dialog_state_encoder.",))
             # prefetch_text already applied dialog_layer inside the text graph; otherwise do it here
             d_emb = e if embedded else self._dialog_embed(pol, e)
         memd = _f32(ext_memory_dialog)

@@ -253,6 +253,7 @@ class StepSequencer:
         a_early = ([(L.CMD_WAIT, 0, M, h(pl.aud_ev), None, None)] if pl.aud_ev is not None else []) \
             + copy(M, mq.late[0], mq.late[1], mq.late[2], mq.late[3]) + tail
         a_full = copy(M, mq.srcs, mq.dsts, mq.sizes, mq.n) + [(L.CMD_GRAPH, 0, gq.exec1, M, None, None)] \
+            + ([(L.CMD_GRAPH, 0, gq.exec_f, M, None, None)] if gq.exec_f is not None else []) \
             + ([(L.CMD_GRAPH, 0, gq.exec_a, M, None, None)] if gq.exec_a is not None else []) + tail
         b_text = ([(L.CMD_WAIT, 0, M, h(ev["text_read"]), None, None)]
                   + pairs(M, [(gt.static[0], tok)])

@@ -219,6 +219,11 @@ size_t avlen_resnet18_group_x3_workspace_bytes(int groups, int B);
 int avlen_resnet18_group_fwd_x3(const avlen_resnet18* const* nets, const void* const* imgs, const int* img_u8, const int* channels,
                                 const float* divisors, float* const* outs, int ld_out, int groups, int B, int S,
                                 const int32_t* row_index, void* ws, size_t ws_bytes, avlen_stream_t stream);
+/* The same in two calls on ONE workspace: phase 1 = the towers (layer-4 outputs stay in `ws`), 2 = the fc on what phase 1 left
+ * there, 3 = both.  Lets a captured forward keep the fc off the path between the towers and the AudioCNNs. */
+int avlen_resnet18_group_fwd_x3_phase(const avlen_resnet18* const* nets, const void* const* imgs, const int* img_u8, const int* channels,
+                                      const float* divisors, float* const* outs, int ld_out, int groups, int B, int S,
+                                      const int32_t* row_index, int phase, void* ws, size_t ws_bytes, avlen_stream_t stream);
 /* avlen_pack_conv_weight_bf16 into 16-bit format fmt (0 = bf16, 1 = fp16, 2 = low plane of the compensated bf16 pair) */
 int avlen_pack_conv_weight_h16(const float* w_oihw, void* w_packed, int O, int I, int KH, int KW, int Cpad, int fmt,
                                avlen_stream_t stream);
@@ -338,9 +343,12 @@ int avlen_clip_text_cached_fwd(const avlen_clip_text* p, const int64_t* tokens, 
 /* dialog_layer(CLIP.encode_text(tokens)) of the rollout step (policy.py:844-851) on the memoised tower above with its tail as ONE
  * launch (memo update of the all-zero rows + ln_final + 16-bit cast + the product): p = the tower with text_proj == NULL, fold =
  * dialog_layer with text_projection folded into its weight ([out_f][width], 16-bit shadow in the tower's format; out_f % 16 == 0,
- * <= 256).  out (B, fold->out_f).  16-bit modes, width 512, B + 1 <= 512 only: AVLEN_ERR_ARG otherwise. */
+ * <= 256).  out (B, fold->out_f).  16-bit modes, width 512, B + 1 <= 512 only: AVLEN_ERR_ARG otherwise.
+ * warm_ptrs / warm_bytes (n_warm <= 4, optional): byte ranges (16-byte aligned) the tail launch's spare workgroups pull into the L2s
+ * while it runs -- the weights of the dialog state encoder's chain that follows (as avlen_prefetch_l2, without a launch of its own). */
 int avlen_clip_text_dialog_fwd(const avlen_clip_text* p, const avlen_linear* fold, const int64_t* tokens, void* state, size_t state_bytes,
-                               float* out, int B, int prec, void* ws, size_t ws_bytes, avlen_stream_t stream);
+                               float* out, int B, int prec, void* ws, size_t ws_bytes, const void* const* warm_ptrs,
+                               const int64_t* warm_bytes, int n_warm, avlen_stream_t stream);
 /* The one-launch tower's weight stream (csrc/clip_tower.hip): bytes for `p` (0: shape not supported -- width 512, 8 heads,
  * ctx <= 80, 4x MLP, biases present) and the packer (fmt 0 bf16, 1 fp16; from the fp32 weights; derived data). */
 size_t avlen_clip_stream_bytes(const avlen_clip_text* p);
