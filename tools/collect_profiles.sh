@@ -16,8 +16,10 @@ DB=$(find /tmp/ps -name "*.db" | head -1)
 python3 $R/tools/prof_summary.py $DB > $O/rocprof_summary_head.md || exit 1
 python3 $R/tools/step_breakdown.py $DB 150 > $O/step_breakdown.md || exit 1
 python3 $R/tools/update_breakdown.py $DB > $O/update_breakdown.md || exit 1
-python3 $R/tools/step_timeline.py 64 fresh 2>&1 | grep -E "^N=|times since|dialog stats" > $O/step_timeline.txt || exit 1
-python3 $R/tools/step_timeline.py 64 reference 2>&1 | grep -E "^N=|times since|dialog stats" >> $O/step_timeline.txt || exit 1
+python3 $R/tools/step_timeline.py 64 fresh 2>&1 | grep -E "^N=|median|sequencer|dialog stats" > $O/step_timeline.txt || exit 1
+python3 $R/tools/step_timeline.py 64 reference 2>&1 | grep -E "^N=|median|sequencer|dialog stats" >> $O/step_timeline.txt || exit 1
+python3 $R/tools/launch_cost.py 2>&1 | grep -E "phase|GRAPH|RECORD|WAIT|MULTICOPY|launch:|us$" > $O/launch_cost.txt || exit 1
+if [ -x $R/tools/bin/chain_lab1 ]; then ( echo "compensated-bf16 chain, pi_q-like program (16 Linear steps), warm / cold:"; $R/tools/bin/chain_lab1 1 | grep kernel ) > $O/chain_warm_cold.txt || exit 1; fi
 python3 $R/tools/step_trace.py $DB 150 40 > $O/step_trace.txt || exit 1
 # phase tables of the persistent tower launch and of the one-launch text tower (lab binaries built here: tools/bin is not tracked)
 if [ -x $R/tools/bin/x3_lab ]; then $R/tools/bin/x3_lab 64 6 > $O/tower_x3_phases.txt || exit 1; fi
