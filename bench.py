@@ -112,7 +112,7 @@ def kernel_roofline(prec_name, in_situ=None, towers=None):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import roofline_probe as rp
     pmc = {}
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             break
@@ -170,8 +170,10 @@ def kernel_roofline(prec_name, in_situ=None, towers=None):
             top["mfma_issue_frac"] = round(3 * top["frac"], 4)
             try:                                     # per conv INSIDE the fused bodies: from the committed phase-stamp profile (a lab
                 import tower_x3_phase_table as tpt   # build of the same kernel, tools/x3_lab.hip), not re-measured by this run
-                t = tpt.table(os.path.join(ROOT, "profiles", "r04_tower_x3_phases.txt" if os.path.exists(os.path.join(ROOT, "profiles", "r04_tower_x3_phases.txt")) else "r03_tower_x3_phases.txt"))
-                top["tower_convs_in_situ"] = {"source": "profiles/r0[34]_tower_x3_phases.txt, the newest (tools/x3_lab: phase stamps of the product kernel, "
+                ph = next(f for f in ("r05_tower_x3_phases.txt", "r04_tower_x3_phases.txt", "r03_tower_x3_phases.txt")
+                          if os.path.exists(os.path.join(ROOT, "profiles", f)))
+                t = tpt.table(os.path.join(ROOT, "profiles", ph))
+                top["tower_convs_in_situ"] = {"source": "profiles/" + ph + " (tools/x3_lab: phase stamps of the product kernel, "
                                                         "384 images; algorithmic FLOPs of a conv over its whole phase incl. GroupNorm "
                                                         "statistics and the normalise / split pass, per CU)",
                                               "whole_tower_frac_mfma_algorithmic": t["whole_tower_frac_mfma_algorithmic"],
