@@ -16,7 +16,7 @@ $(OBJ)/%.o: $(SRC)/%.hip $(SRC)/common.h $(SRC)/internal.h $(SRC)/tower_util.h i
 
 $(LIB): $(OBJS)
 	@mkdir -p $(dir $(LIB))
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -ldl
 
 # kernels that issue loads / stores from inline asm with their own waits: walk the gfx950 ISA of exactly what is shipped (same
 # compiler, same flags) for a register the compiler touched too early (tools/asm_wait_check.py)

@@ -234,6 +234,10 @@ SIGNATURES = {
     "avlen_copy_rows": (i32, [vp, i32, vp, i32, i32, i32, vp]),
     "avlen_gather_rows": (i32, [vp, i32, vp, vp, i32, i32, i32, vp]),
     "avlen_multi_copy": (i32, [vp, vp, vp, i32, vp]),
+    "avlen_comm_unique_id": (i32, [vp, sz]),
+    "avlen_comm_init_rank": (i32, [vp, i32, vp, i32]),
+    "avlen_comm_destroy": (i32, [vp]),
+    "avlen_grad_allreduce": (i32, [vp, sz, i32, vp, vp]),
     "avlen_cmds_run": (i32, [vp, i32]),
     "avlen_prefetch_l2": (i32, [vp, vp, i32, vp]),
     "avlen_ln_fold_weights": (i32, [vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, vp]),

@@ -10,6 +10,10 @@ nothing else in `avlen_amd/` reads `os.environ`.  Decisions that were measured a
                             the one-launch tower is tested against).  Default on.
     AVLEN_MAPPED_ACTIONS=0  sampled actions copied to the host by a copy launch instead of being stored into mapped pinned memory
                             by the heads kernel (host_actions then waits on an event instead of polling).  Default on.
+    AVLEN_NATIVE_ALLREDUCE=1  DDPPO's gradient all-reduce through the library's own RCCL binding (avlen_grad_allreduce: one in-place
+                            ncclAllReduce(avg) on the backward's stream, communicator bootstrapped over torch.distributed) instead of
+                            torch.distributed.all_reduce + a scaling launch.  Default off: the torch path is the one exercised on
+                            multi-GPU nodes so far.
     AVLEN_ROCTX=1           roctx ranges (rocprofv3 --marker-trace) around act* / dialog_ready / insert / update: the counterpart
                             of the reference trainer's pth_time / env_time bookkeeping (ppo_trainer.py:326-328, 726-734, 896).
                             Default off (a push / pop pair costs ~1 us per call).
@@ -33,6 +37,7 @@ FOLD_TEXT = _flag("AVLEN_FOLD_TEXT", True)
 CLIP_STREAM = _flag("AVLEN_CLIP_STREAM", True)
 MAPPED_ACTIONS = _flag("AVLEN_MAPPED_ACTIONS", True)
 ROCTX = _flag("AVLEN_ROCTX", False)
+NATIVE_ALLREDUCE = _flag("AVLEN_NATIVE_ALLREDUCE", False)
 
 
 def check_hw_queues():

@@ -238,8 +238,27 @@ class DecentralizedDistributedMixin:
         # a 1-rank group still goes through the collective (as DDP's reducer does): the RCCL path is the same code at any size
         self._distributed = distrib.is_available() and distrib.is_initialized()
         self.get_advantages = self._get_advantages_distributed
+        self._comm = None
         if self._distributed:
             self.broadcast_parameters()
+            if self.native_allreduce and next(self.actor_critic.parameters()).is_cuda and distrib.get_backend() == "nccl":
+                self._comm = self._native_comm()
+
+    native_allreduce = CFG.NATIVE_ALLREDUCE      # the C ABI's grad_allreduce instead of torch.distributed.all_reduce (config.py)
+
+    def _native_comm(self):
+        """An RCCL communicator of the library's own over the ranks of the default process group: rank 0 draws the unique id
+        (avlen_comm_unique_id), torch.distributed carries it to the others, every rank joins (avlen_comm_init_rank)."""
+        dev = next(self.actor_critic.parameters()).device
+        buf = (C.c_ubyte * 128)()
+        if distrib.get_rank() == 0:
+            L.call("avlen_comm_unique_id", buf, 128)
+        t = torch.tensor(list(buf), dtype=torch.uint8, device=dev)
+        distrib.broadcast(t, src=0)
+        buf = (C.c_ubyte * 128)(*t.cpu().tolist())
+        comm = C.c_void_p()
+        L.call("avlen_comm_init_rank", C.byref(comm), distrib.get_world_size(), buf, distrib.get_rank())
+        return comm
 
     def broadcast_parameters(self, src=0):
         pol = self.actor_critic
@@ -256,6 +275,9 @@ class DecentralizedDistributedMixin:
 
     def reduce_gradients(self, flat):
         if getattr(self, "_distributed", False):
+            if getattr(self, "_comm", None) is not None:       # one in-place ncclAllReduce(avg) on the backward's stream
+                L.call("avlen_grad_allreduce", E.P(flat.grad), flat.n_trained, L.PREC_FP32, self._comm, L.stream())
+                return
             distrib.all_reduce(flat.grad)
             flat.grad.mul_(1.0 / distrib.get_world_size())
 

@@ -515,6 +515,18 @@ int avlen_multi_copy(const void* const* src, void* const* dst, const int64_t* nb
  * dialog_state_encoder.py:133-152 as one launch each): 62 us warm against ~100 us from HBM.  Reads only; speed only. */
 int avlen_prefetch_l2(const void* const* ptrs, const int64_t* nbytes, int n, avlen_stream_t stream);
 
+/* The path's one collective: the mean over the ranks of the trained parameters' flat gradient, once per optimiser step --
+ * what DistributedDataParallel's reducer does for the reference (ss_baselines/savi/ddppo/algo/ddppo.py:75-96), as ONE in-place
+ * ncclAllReduce(avg) over RCCL (xGMI inside a node) on the stream the backward ran on.  RCCL is bound at run time (dlopen).
+ *   avlen_comm_unique_id: rank 0 draws the 128-byte id (HOST memory) and hands it to the others out of band (the host already has
+ *                         torch.distributed / a store for that);
+ *   avlen_comm_init_rank: every rank, collectively -> *comm;   avlen_comm_destroy at the end;
+ *   avlen_grad_allreduce: bucket (device, `count` elements of dtype AVLEN_PREC_FP32 | AVLEN_PREC_BF16) <- mean over the ranks. */
+int avlen_comm_unique_id(void* host_out, size_t bytes);
+int avlen_comm_init_rank(void** comm, int nranks, const void* host_unique_id, int rank);
+int avlen_comm_destroy(void* comm);
+int avlen_grad_allreduce(void* bucket, size_t count, int dtype, void* comm, avlen_stream_t stream);
+
 /* Step sequencer (csrc/sequencer.hip): a list of stream operations run by ONE call, in order.  The reference's rollout step has
  * two host round trips on its critical path (ppo_trainer.py:449-636: act_option -> host reads the option actions -> tokens ->
  * act_dialog -> envs.step); what the host enqueues after each of them is fixed once the argument buffers are known.

@@ -188,13 +188,25 @@ def test_fresh_dicts_and_tensors_every_call_with_graphs():
     assert torch.equal(v_new, v_ref) and not torch.allclose(v_new, outs[0])
 
 
-def test_ddppo_update_through_rccl_one_rank():
+@pytest.mark.parametrize("native", [False, True])
+def test_ddppo_update_through_rccl_one_rank(native):
     """A real DDPPO.update with an initialised `nccl` (= RCCL) process group of one rank: init_distributed broadcasts the flat
     parameter buffer, every optimiser step all-reduces the flat gradient ON THE DEVICE.  With one rank the reduction is the
-    identity, so the result must equal the same update without a process group."""
+    identity, so the result must equal the same update without a process group.  native: the reduction goes through the C ABI's own
+    RCCL binding (avlen_comm_unique_id / avlen_comm_init_rank / avlen_grad_allreduce) instead of torch.distributed.all_reduce."""
     import os
     import socket
     import torch.distributed as dist
+    from avlen_amd.ppo import DDPPO as _D
+    keep = _D.native_allreduce
+    _D.native_allreduce = native
+    try:
+        _rccl_one_rank(native, os, socket, dist)
+    finally:
+        _D.native_allreduce = keep
+
+
+def _rccl_one_rank(native, os, socket, dist):
     outs = []
     for with_group in (False, True):
         if with_group:
@@ -205,6 +217,7 @@ def test_ddppo_update_through_rccl_one_rank():
             wl = Workload(4, 3, spectrogram=(65, 26, 2), precision="fp32", pretraining=False, em_capacity=3, seed=2, use_graphs=False,
                           share_encoders=False, launch_ahead=False, with_goal_policy=False, with_dialog_policy=False)
             assert wl.agent._distributed == with_group
+            assert (wl.agent._comm is not None) == (with_group and native)
             torch.manual_seed(5)
             for _ in range(3):
                 wl.rollout_step()
