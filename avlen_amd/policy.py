@@ -451,6 +451,7 @@ class EncoderGroup:
         self.auto_hits = self.auto_misses = 0
         self._side = None
         self._aud_ev = self._stage_ev = None
+        self._seq = None                                 # the group's StepSequencer (auto_sequence), built on first use
 
     def side_stream(self):
         """The ONE side stream of the group: the followers' forwards (launched ahead by the trainer, by auto_launch or by the step
@@ -529,32 +530,64 @@ class EncoderGroup:
         if self._auto_stream is None:
             self._auto_stream = self.side_stream()
         for f in self.members[1:]:
-            h = f._call_hist
-            if len(h) < 2 or h[-1][0] != h[-2][0] or f._stash is not None or f._later is not None:
+            p = self._predict(f, lead_prev, lead_args)
+            if p is None:
                 continue
-            which, last, det = h[-1]                     # the follower is expected to pass the `deterministic` it passed last time
-            before = h[-2][1]
-            pred = []
-            for i, a in enumerate(last):
-                j = next((j for j, b in enumerate(lead_prev) if a is not None and self._same(a, b)), None)
-                if which == "vln" and i in (7, 8):
-                    pred.append(a)                       # dialog tokens / agent_step: placeholders, read by the second half only
-                elif j is not None and j < len(lead_args):
-                    pred.append(lead_args[j])
-                elif a is None or not torch.is_tensor(a):
-                    pred.append(a)
-                elif self._same(a, before[i]):
-                    pred.append(a)
-                else:
-                    pred.append(self._next_view(a, before[i]))
-                    if pred[-1] is None:
-                        pred = None
-                        break
-            if pred is None:
-                continue
+            which, pred, det = p
             f._auto_pending = True
             f._prefetch(which, *pred, stream=self._auto_stream, dialog_later=(which == "vln" and pred[7] is not None),
                         deterministic=det)
+
+    def _predict(self, f, lead_prev, lead_args):
+        """-> (head set, predicted argument list, predicted `deterministic`) of follower f's next call, or None (see auto_launch)."""
+        h = f._call_hist
+        if len(h) < 2 or h[-1][0] != h[-2][0] or f._stash is not None or f._later is not None:
+            return None
+        which, last, det = h[-1]                         # the follower is expected to pass the `deterministic` it passed last time
+        before = h[-2][1]
+        pred = []
+        for i, a in enumerate(last):
+            j = next((j for j, b in enumerate(lead_prev) if a is not None and self._same(a, b)), None)
+            if which == "vln" and i in (7, 8):
+                pred.append(a)                           # dialog tokens / agent_step: placeholders, read by the second half only
+            elif j is not None and j < len(lead_args):
+                pred.append(lead_args[j])
+            elif a is None or not torch.is_tensor(a):
+                pred.append(a)
+            elif self._same(a, before[i]):
+                pred.append(a)
+            else:
+                pred.append(self._next_view(a, before[i]))
+                if pred[-1] is None:
+                    return None
+        return which, pred, det
+
+    def sequencer(self):
+        if self._seq is None:
+            from .sequencer import StepSequencer
+            self._seq = StepSequencer(*self.members)
+        return self._seq
+
+    def auto_sequence(self, leader, lead_args):
+        """The automatic launch-ahead through the step sequencer (sequencer.py), tried BEFORE the leader's direct act_option enqueues
+        anything: with both followers' next calls predicted (as auto_launch predicts them) and all three sampling, the step's three
+        forwards go out as one recorded command list -- the leader's own call then picks its forward up like the followers do.
+        -> True if the step was launched."""
+        if not self.auto or len(self.members) != 3 or not leader._call_hist or leader._in_prefetch_explicit:
+            return False
+        if not all(m.use_graphs and m.sampling == "race" for m in self.members):
+            return False
+        lead_prev = leader._call_hist[-1][1]             # (this call has not been recorded yet)
+        if len(lead_prev) != len(lead_args):
+            return False
+        pg = self._predict(self.members[1], lead_prev, lead_args)
+        pl = self._predict(self.members[2], lead_prev, lead_args)
+        if pg is None or pl is None or pg[0] != "goal" or pl[0] != "vln" or pg[2] or pl[2] or pl[1][7] is None:
+            return False
+        self.sequencer().launch(tuple(lead_args), tuple(pg[1]), tuple(pl[1]), explicit=False)
+        for f in self.members[1:]:
+            f._auto_pending = True
+        return True
 
     def buffers(self, B, dev):
         if B not in self.out:
@@ -1104,7 +1137,8 @@ class Policy(nn.Module):
                 k.append(a)
         return tuple(k)
 
-    _in_prefetch_flow = False             # the caller issues prefetch_* itself: no automatic launch-ahead on top
+    _in_prefetch_flow = False             # prefetch_* calls are being issued for this policy: no automatic launch-ahead on top
+    _in_prefetch_explicit = False         # ... by the CALLER (the trainer / harness), not by the group's own sequencer
 
     def _prefetch(self, which, *net_args, stream=None, dialog_later=False, deterministic=False):
         """Enqueue the forward of a later act*/get_value* call now (no host synchronisation).  The matching call, made
@@ -1183,8 +1217,12 @@ class Policy(nn.Module):
                        query_state, last_query_info, stream=stream, deterministic=deterministic)
 
     def _mark_explicit(self):
-        for m in ([self] if self._enc_group is None else self._enc_group.members):
+        grp = self._enc_group
+        own = grp is not None and grp._seq is not None and grp._seq.auto_running
+        for m in ([self] if grp is None else grp.members):
             m._in_prefetch_flow = True
+            if not own:
+                m._in_prefetch_explicit = True
 
     def prefetch_text(self, all_dialog, stream, after_current=True):
         """pi_l only: start the frozen CLIP text tower for this step's dialog on `stream` right away (see net.prefetch_text).
@@ -1276,6 +1314,10 @@ class Policy(nn.Module):
     def act_option(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks,
                    query_state, last_query_info, deterministic=False):
         args = (observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks, query_state, last_query_info)
+        grp = self._enc_group
+        if grp is not None and grp.leader is self and not deterministic and self._stash is None and grp.auto \
+                and self.precision in ("bf16", "bf16x3"):
+            grp.auto_sequence(self, args)                # share_encoders alone: the whole step as one recorded command list
         (features, rnn_hidden_states, ext_memory_feats), h = self._forward("option", *args, sample=not deterministic)
         h = self._finish("option", features, h, deterministic=deterministic)
         self._after_act("option", args, deterministic)
@@ -1291,10 +1333,16 @@ class Policy(nn.Module):
         if lt is not None and self._auto_pending and lt[0] == "vln":
             # the first half was enqueued by EncoderGroup.auto_launch: if it ran on the tensors of THIS call, the text tower and the
             # second half follow now, on the call's own dialog tokens / agent_step
+            seq = self._enc_group._seq if self._enc_group is not None else None
             if all_dialog is not None and lt[1][:7] == self._arg_key(args[:7]):
                 self._later = (lt[0], self._arg_key(args), lt[2], lt[3], all_dialog, agent_step, deterministic)
-                self.dialog_ready()
+                if seq is not None and seq._cur is not None:
+                    seq.dialog_ready()                   # the step was launched by the group's sequencer: so is its second phase
+                else:
+                    self.dialog_ready()
             else:
+                if seq is not None:
+                    seq._cur = None
                 if lt[3] is not None:                    # the guessed first half may still be running in the graph this call replays
                     _cur_stream().wait_stream(lt[3])
                 if self._enc_group is not None:          # ... and it used up this follower's claim on the leader's encoders

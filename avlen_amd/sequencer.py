@@ -35,7 +35,7 @@ def _ev():
 
 class _Plan:
     __slots__ = ("B", "dev", "gq", "gg", "gl", "gt", "obs3", "grp_key", "key_q", "key_g", "key_l", "outs_q", "heads_q", "outs_g",
-                 "heads_g", "out_l1", "outs_l", "heads_l", "ah_q", "ah_g", "ah_l", "a_early", "a_full", "b_text", "b_cmds", "emb", "keep",
+                 "heads_g", "out_l1", "outs_l", "heads_l", "ah_q", "ah_g", "ah_l", "a_early", "a_full", "b_variants", "b_build", "emb", "keep",
                  "tok_shape", "main", "aud_ev")
 
 
@@ -55,6 +55,7 @@ class StepSequencer:
         # on the caller's stream behind the text tower: no difference (1.65 ms both), the caller's stream needs one event less
         self.followers_after_q = False
         self.l2_on_side = False
+        self.auto_running = False          # launch() was called by EncoderGroup.auto_sequence, not by the trainer
 
     # ------------------------------------------------------------------------------------------------------------------
     def _events(self):
@@ -83,7 +84,7 @@ class StepSequencer:
                 and not torch.cuda.is_current_stream_capturing())
 
     # ------------------------------------------------------------------------------------------------------------------
-    def launch(self, q_args, g_args, l_args):
+    def launch(self, q_args, g_args, l_args, explicit=True):
         """The three forwards of the step on their argument tuples (`act_option`'s, `act`'s, `act_dialog`'s positional arguments):
         pi_q's whole forward on the current stream, pi_g's and the half of pi_l's that reads neither the dialog tokens nor
         `agent_step` on the side stream.  Follow with `act_option(...)`, then -- once `all_dialog` / `agent_step` hold the step's
@@ -97,9 +98,13 @@ class StepSequencer:
         plan = self._plans.get(key) if key is not None else None
         if plan is None:
             self.slow += 1
-            q.prefetch_act_option(*q_args)
-            g.prefetch_act(*g_args, stream=self.S)
-            l.prefetch_act_dialog(*l_args, stream=self.S, dialog_later=True)
+            self.auto_running = not explicit
+            try:
+                q.prefetch_act_option(*q_args)
+                g.prefetch_act(*g_args, stream=self.S)
+                l.prefetch_act_dialog(*l_args, stream=self.S, dialog_later=True)
+            finally:
+                self.auto_running = False
             tmpl = None
             if key is not None and q._stash is not None and g._stash is not None and l._later is not None and l._later[0] == "vln":
                 tmpl = (q._stash, g._stash, l._later, l._deferred)
@@ -137,6 +142,8 @@ class StepSequencer:
         o1 = plan.out_l1
         l._later = ("vln", plan.key_l, ((o1[0][0], l_args[1], o1[0][2], o1[0][3]), dict(o1[1])), self.S, l_args[7], l_args[8], False)
         q._in_prefetch_flow = g._in_prefetch_flow = l._in_prefetch_flow = True
+        if explicit:
+            q._in_prefetch_explicit = g._in_prefetch_explicit = l._in_prefetch_explicit = True
         self._cur = ("fast", plan, l_args)
 
     def dialog_ready(self):
@@ -154,21 +161,30 @@ class StepSequencer:
             return
         _, plan, l_args = cur
         ev, net = self.ev, l.net
+        lt = l._later                                        # (act_dialog of the automatic flow has put the call's own tensors there)
+        if lt is None or lt[0] != "vln" or l._deferred is not plan.gl:
+            return l.dialog_ready()
+        key_l, tok, astep, det = lt[1], lt[4], lt[5], lt[6]
+        var = plan.b_variants.get((tok.data_ptr(), astep.data_ptr())) if torch.is_tensor(tok) and torch.is_tensor(astep) else None
+        if var is None and not det:
+            var = plan.b_build(tok, astep)
+        if var is None or det:
+            return l.dialog_ready()                          # the Python flow finishes what the command list started
+        b_text, b_cmds = var[0], var[1]
         if net._text_read is not None and net._text_read is not ev["text_read"]:
             P._cur_stream().wait_event(net._text_read)       # the embedding's last reader was enqueued by the slow path
         # the text tower first: it is the step's critical path from here (the host has just read pi_q's actions); pi_l's draw -- third
         # in the step, as in the reference -- and its dialog half go out while the tower runs
-        L.call("avlen_cmds_run", plan.b_text, len(plan.b_text))
+        L.call("avlen_cmds_run", b_text, len(b_text))
         r0 = torch.get_rng_state()
         l._draw_noise("vln", plan.B, plan.dev)
         r1 = torch.get_rng_state()
-        L.call("avlen_cmds_run", plan.b_cmds, len(plan.b_cmds))
-        tok = l_args[7]
+        L.call("avlen_cmds_run", b_cmds, len(b_cmds))
         net._text = (tok.data_ptr(), plan.tok_shape, plan.emb, ev["text_read"])
         net._text_key = ("pretext", plan.emb.data_ptr())
         net._text_read = ev["text_read"]
         l._later = l._deferred = None
-        l._stash = ("vln", plan.key_l, ((plan.outs_l[0], l_args[1], plan.outs_l[2], plan.outs_l[3]),
+        l._stash = ("vln", key_l, ((plan.outs_l[0], l_args[1], plan.outs_l[2], plan.outs_l[3]),
                                         dict(plan.heads_l, rng_spec=(r0, r1))), ev["done_l"])
         l._act_host["vln"] = (plan.ah_l, ev["done_l"], True)
 
@@ -255,29 +271,49 @@ class StepSequencer:
         a_full = copy(M, mq.srcs, mq.dsts, mq.sizes, mq.n) + [(L.CMD_GRAPH, 0, gq.exec1, M, None, None)] \
             + ([(L.CMD_GRAPH, 0, gq.exec_f, M, None, None)] if gq.exec_f is not None else []) \
             + ([(L.CMD_GRAPH, 0, gq.exec_a, M, None, None)] if gq.exec_a is not None else []) + tail
-        b_text = ([(L.CMD_WAIT, 0, M, h(ev["text_read"]), None, None)]
-                  + pairs(M, [(gt.static[0], tok)])
-                  + [(L.CMD_GRAPH, 0, gt.exec1, M, None, None)])
-        # pi_l's dialog half goes out on the CALLER's stream right behind the text tower (the Python flow puts it on the side stream
-        # behind an event: a queue that sits on a barrier packet until another queue's signal arrives starts ~20 us late, measured
-        # in profiles/r05_step_trace.txt); its state-encoder half finished on the side stream long before (l_half)
-        if self.l2_on_side:
-            b = ([(L.CMD_RECORD, 0, h(ev["text"]), M, None, None), (L.CMD_WAIT, 0, S, h(ev["text"]), None, None)]
-                 + pairs(S, [(s8, astep)])
-                 + [(L.CMD_GRAPH, 0, gl.exec2, S, None, None), (L.CMD_RECORD, 0, h(ev["text_read"]), S, None, None),
-                    (L.CMD_RECORD, 0, h(ev["done_l"]), S, None, None)])
-        else:
-          b = ([(L.CMD_WAIT, 0, M, h(ev["l_half"]), None, None)]
-             + pairs(M, [(s8, astep)])
-             + [(L.CMD_GRAPH, 0, gl.exec2, M, None, None), (L.CMD_RECORD, 0, h(ev["text_read"]), M, None, None),
-                (L.CMD_RECORD, 0, h(ev["done_l"]), M, None, None)])
-
         def arr(cmds):
             a = (L.Cmd * len(cmds))()
             for i, (op, n, x, y, z, w) in enumerate(cmds):
                 a[i].op, a[i].n, a[i].a, a[i].b, a[i].c, a[i].d = op, n, x, y, z, w
             return a
-        pl.a_early, pl.a_full, pl.b_text, pl.b_cmds = arr(a_early), arr(a_full), arr(b_text), arr(b)
+
+        def b_lists(tok, astep):
+            # the text tower first (the critical path once pi_q's actions are on the host) ...
+            b_text = ([(L.CMD_WAIT, 0, M, h(ev["text_read"]), None, None)]
+                      + pairs(M, [(gt.static[0], tok)])
+                      + [(L.CMD_GRAPH, 0, gt.exec1, M, None, None)])
+            # ... then pi_l's dialog half on the CALLER's stream right behind it (the Python flow puts it on the side stream behind an
+            # event; measured: no difference, one event less); its state-encoder half finished on the side stream long before (l_half)
+            if self.l2_on_side:
+                b = ([(L.CMD_RECORD, 0, h(ev["text"]), M, None, None), (L.CMD_WAIT, 0, S, h(ev["text"]), None, None)]
+                     + pairs(S, [(s8, astep)])
+                     + [(L.CMD_GRAPH, 0, gl.exec2, S, None, None), (L.CMD_RECORD, 0, h(ev["text_read"]), S, None, None),
+                        (L.CMD_RECORD, 0, h(ev["done_l"]), S, None, None)])
+            else:
+                b = ([(L.CMD_WAIT, 0, M, h(ev["l_half"]), None, None)]
+                     + pairs(M, [(s8, astep)])
+                     + [(L.CMD_GRAPH, 0, gl.exec2, M, None, None), (L.CMD_RECORD, 0, h(ev["text_read"]), M, None, None),
+                        (L.CMD_RECORD, 0, h(ev["done_l"]), M, None, None)])
+            return b_text, b
+
+        def b_build(tok, astep):
+            """The second phase's two lists for the dialog tokens / agent_step tensors of a call (the recorded ones, or -- automatic
+            flow -- whatever act_dialog was handed); None if a staging copy would need a conversion."""
+            if not (torch.is_tensor(tok) and tok.is_cuda and tok.dtype == torch.int64 and tok.is_contiguous()
+                    and tuple(tok.shape) == pl.tok_shape and torch.is_tensor(astep) and astep.is_cuda and astep.dtype == s8.dtype
+                    and astep.is_contiguous() and astep.numel() == s8.numel()):
+                return None
+            bt, bb = b_lists(tok, astep)
+            v = (arr(bt), arr(bb))
+            while len(pl.b_variants) >= 64:
+                pl.b_variants.pop(next(iter(pl.b_variants)))
+            pl.b_variants[(tok.data_ptr(), astep.data_ptr())] = v
+            return v
+
+        pl.a_early, pl.a_full = arr(a_early), arr(a_full)
+        pl.b_variants, pl.b_build = {}, b_build
+        if b_build(tok, astep) is None:
+            return
         pl.keep = (keep, mq, mg, ml)                      # the staging arrays the command lists point into
         pl.main = M
         while len(self._plans) >= 1024:

@@ -290,7 +290,8 @@ def test_storage_writes_on_the_side_stream_equal_the_plain_order():
         assert torch.equal(a[k], b[k]), k
 
 
-def test_sequencer_command_lists_equal_the_python_launch_ahead_flow():
+@pytest.mark.parametrize("process", ["fresh", "reference"])
+def test_sequencer_command_lists_equal_the_python_launch_ahead_flow(process):
     """avlen_amd/sequencer.py: after one pass through `prefetch_act_option` / `prefetch_act` / `prefetch_act_dialog` / `dialog_ready`
     per set of argument buffers, a step's launches are two recorded command lists run by `avlen_cmds_run`.  Scheduling only: the
     storage after two rollouts (the second one entirely on the recorded lists), the wrap-around in between, the sampled actions
@@ -298,7 +299,7 @@ def test_sequencer_command_lists_equal_the_python_launch_ahead_flow():
     N, T = 4, 5
     snaps = []
     for use_seq in (True, False):
-        wl = _run(N, T, precision="bf16x3")
+        wl = _run(N, T, precision="bf16x3", dialog_process=process)       # reference: tokens written by the host loop after a_q
         assert wl.seq is not None
         seq = wl.seq
         if not use_seq:

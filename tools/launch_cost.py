@@ -14,7 +14,8 @@ for _ in range(5):
 torch.cuda.synchronize()
 plan = next(iter(wl.seq._plans.values()))
 names = {1: "GRAPH", 2: "RECORD", 3: "WAIT", 4: "MULTICOPY"}
-for label, cmds in (("phase A (early)", plan.a_early), ("phase B", plan.b_cmds)):
+bt, bb = next(iter(plan.b_variants.values()))
+for label, cmds in (("phase A (early)", plan.a_early), ("phase B: text tower", bt), ("phase B: pi_l's dialog half", bb)):
     print(label)
     for i in range(len(cmds)):
         one = (L.Cmd * 1)(cmds[i])
