@@ -294,13 +294,17 @@ class BeliefPredictor(nn.Module):
         g["graph"].replay()
         L.multi_copy([(outs[k], g["out"][k]) for k in outs])
 
-    def update_async(self, observations, dones, stream):
-        """`update` on `stream` (ordered after everything enqueued so far on the caller's stream): the beliefs are written into
-        `observations[...]` -- pass the views of the rollout storage's slot, AFTER `rollouts.insert` -- while the caller goes on to
-        launch the next step's policies; `self.done` (an event) fires when they are in place: hand it to the leader policy
+    def update_async(self, observations, dones, stream, after=None):
+        """`update` on `stream`: the beliefs are written into `observations[...]` -- pass the views of the rollout storage's slot for
+        the two belief entries (the sensors may be the simulator's own tensors) -- while the caller goes on to launch the next
+        step's policies; `self.done` (an event) fires when they are in place: hand it to the leader policy
         (`policy.late_inputs((location_belief, category_belief), predictor.done)`), whose visual towers then run beside the two
-        belief networks instead of after them."""
-        stream.wait_stream(torch.cuda.current_stream())
+        belief networks instead of after them.  Ordered after `after` (an event: e.g. the storage's copy of the observation into
+        the slot, which must not overwrite the beliefs) or, without it, after everything enqueued so far on the caller's stream."""
+        if after is not None:
+            stream.wait_event(after)
+        else:
+            stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(stream):
             self.update(observations, dones)
             if getattr(self, "done", None) is None:

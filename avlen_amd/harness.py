@@ -58,7 +58,8 @@ class Workload:
         self.cached_views = cached_views
         self.distractor = distractor
         # Policy.prefetch_encoders on the new observation before `insert` copies it (the towers hide the storage bookkeeping)
-        self._early_enc = use_graphs and share_encoders and precision in ("bf16", "bf16x3") and not belief_predictor
+        # (with a BeliefPredictor too: its update of the new observation's beliefs is enqueued FIRST, the towers behind it)
+        self._early_enc = use_graphs and share_encoders and precision in ("bf16", "bf16x3")
         self._next_views = None
         self.trace = None                               # tools/step_timeline.py: a list collects (mark, host time) pairs of every step
         # ONE set of side streams per process (policy.process_stream): the runtime maps streams to its 4 hardware queues in creation
@@ -356,7 +357,7 @@ class Workload:
         if return_outs:                             # graph outputs are overwritten by the next replay
             o = {k: (x.clone() if torch.is_tensor(x) else x) for k, x in o.items()}
             o["actions"] = actions.clone()
-        small = self._small if (late_select and self._early_enc and self.launch_ahead and self.belief is None) else None
+        small = self._small if (late_select and self._early_enc and self.launch_ahead) else None
         if small is not None:
             self._fwd_ev.record(P._cur_stream())        # the three forwards of this step are complete behind this point
         started = False
@@ -388,8 +389,13 @@ class Workload:
             # asynchronous form: the new observation is stored first, the two belief networks then write their beliefs into the
             # storage slot on their own stream while the next step's visual towers already run (which leave them a few CUs:
             # avlen_set_tower_x3_reserved_cus); the rest of the next forward waits for the event (Policy.late_inputs)
-            slot = {k: x[ro.step] for k, x in ro.observations.items()}
-            ev = self.belief.update_async(slot, v["dones"], self._belief_stream)
+            # The networks read the SIMULATOR's tensors (no dependence on the storage's copy); only the beliefs go into the slot,
+            # behind the storage's own write of it (`_small_ev` when the writes ran on the side stream).
+            slot = dict(v["nxt"])
+            for k in ("location_belief", "category_belief"):
+                slot[k] = ro.observations[k][ro.step]
+            ev = self.belief.update_async(slot, v["dones"], self._belief_stream,
+                                          after=self._small_ev if (small is not None and started) else None)
             self.pi_q.late_inputs(("location_belief", "category_belief"), ev)
         return o if return_outs else None
 

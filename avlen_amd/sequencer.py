@@ -79,7 +79,7 @@ class StepSequencer:
     def _eligible(self, q_args, g_args, l_args):
         q, g, l = self.q, self.g, self.l
         return (all(p.sampling == "race" and p.use_graphs and p.precision in ("bf16", "bf16x3") for p in (q, g, l))
-                and q._late_inputs is None and l.net.text_encoder_override is None and l_args[7] is not None
+                and l.net.text_encoder_override is None and l_args[7] is not None
                 and g_args[0] is q_args[0] and l_args[0] is q_args[0] and isinstance(q_args[0], dict)
                 and not torch.cuda.is_current_stream_capturing())
 
@@ -124,6 +124,13 @@ class StepSequencer:
         r1 = torch.get_rng_state()
         g._draw_noise("goal", B, dev)
         r2 = torch.get_rng_state()
+        late = q._late_inputs
+        if late is not None:
+            # observation entries still being written when the towers started (Policy.late_inputs: the BeliefPredictor's beliefs, on
+            # its own stream): everything behind the encoders waits for their event -- the list's first staging copy re-reads them
+            P._cur_stream().wait_event(late[1])
+            if not use_early:
+                late = "full"
         cmds = plan.a_early if use_early else plan.a_full
         L.call("avlen_cmds_run", cmds, len(cmds))
         grp = q._enc_group

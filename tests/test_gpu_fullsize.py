@@ -21,6 +21,7 @@ def cycle(request):
         wl.rollout_step()
         if t in (0, 1, 77, 149):
             ro = wl.rollouts
+            wl._join_small()                             # the step's storage writes ran on the harness' side stream
             step_checks.append((t, ro.action_probs[t].clone(), ro.actions[t].clone(), ro.actions_option[t].clone(),
                                 ro.action_log_probs[t].clone(), ro.value_preds[t].clone()))
     return wl, before, step_checks, None
@@ -52,6 +53,7 @@ def test_external_memory_masks_count_inserted_steps(cycle):
 def test_gae_identity_and_update_touches_only_trained_parameters(cycle):
     wl, before, _, _ = cycle
     ro = wl.rollouts
+    wl._join_small()
     last = {k: v[ro.step] for k, v in ro.observations.items()}
     nv = wl.pi_q.get_value_option(last, ro.recurrent_hidden_states[ro.step], ro.prev_actions[ro.step], ro.masks[ro.step],
                                   ro.external_memory_option[:, ro.step], ro.external_memory_masks[ro.step],

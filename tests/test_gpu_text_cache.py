@@ -85,6 +85,7 @@ def test_memo_is_bit_equal_to_the_uncached_tower_over_a_query_scenario(mode):
 
 
 def _storage_snapshot(wl):
+    wl._join_small()                                        # the last step's storage writes ran on the harness' side stream
     ro = wl.rollouts
     keys = ("value_preds", "actions", "actions_option", "action_log_probs", "action_probs", "all_dialog", "agent_step")
     snap = {k: getattr(ro, k).clone() for k in keys}
@@ -213,6 +214,7 @@ def test_encoders_started_before_insert_equal_the_plain_order():
             for _ in range(T):
                 wl.rollout_step()
             ro = wl.rollouts
+            wl._join_small()
             last = {k: v[ro.step] for k, v in ro.observations.items()}
             nv = wl.pi_q.get_value_option(last, ro.recurrent_hidden_states[ro.step], ro.prev_actions[ro.step], ro.masks[ro.step],
                                           ro.external_memory_option[:, ro.step], ro.external_memory_masks[ro.step],
@@ -274,6 +276,7 @@ def test_storage_writes_on_the_side_stream_equal_the_plain_order():
             assert wl._small_pending == side
             wl._join_small()
             ro = wl.rollouts
+            wl._join_small()
             last = {k: v[ro.step] for k, v in ro.observations.items()}
             nv = wl.pi_q.get_value_option(last, ro.recurrent_hidden_states[ro.step], ro.prev_actions[ro.step], ro.masks[ro.step],
                                           ro.external_memory_option[:, ro.step], ro.external_memory_masks[ro.step],

@@ -93,6 +93,7 @@ def test_requeued_agent_continues_bit_for_bit(precision):
     for _ in range(T):
         wl.rollout_step()
     ro, s = wl.rollouts, wl.rollouts.step
+    wl._join_small()                                        # the last step's storage writes ran on the harness' side stream
     nv = wl.pi_q.get_value_option({k: v[s] for k, v in ro.observations.items()}, ro.recurrent_hidden_states[s], ro.prev_actions[s],
                                   ro.masks[s], ro.external_memory_option[:, s], ro.external_memory_masks[s], ro.query_state[s - 1],
                                   ro.last_query_info[s - 1])
