@@ -587,6 +587,7 @@ class EncoderGroup:
         self.sequencer().launch(tuple(lead_args), tuple(pg[1]), tuple(pl[1]), explicit=False)
         for f in self.members[1:]:
             f._auto_pending = True
+        leader._auto_seq_step = True                     # this step's followers are out: _after_act does not launch them again
         return True
 
     def buffers(self, B, dev):
@@ -1138,7 +1139,8 @@ class Policy(nn.Module):
         return tuple(k)
 
     _in_prefetch_flow = False             # prefetch_* calls are being issued for this policy: no automatic launch-ahead on top
-    _in_prefetch_explicit = False         # ... by the CALLER (the trainer / harness), not by the group's own sequencer
+    _in_prefetch_explicit = False         # (same; kept apart from the flag above for EncoderGroup.auto_sequence)
+    _auto_seq_step = False                # leader: EncoderGroup.auto_sequence launched this step's followers
 
     def _prefetch(self, which, *net_args, stream=None, dialog_later=False, deterministic=False):
         """Enqueue the forward of a later act*/get_value* call now (no host synchronisation).  The matching call, made
@@ -1218,11 +1220,11 @@ class Policy(nn.Module):
 
     def _mark_explicit(self):
         grp = self._enc_group
-        own = grp is not None and grp._seq is not None and grp._seq.auto_running
+        if grp is not None and grp._seq is not None and grp._seq.auto_running:
+            return                                       # the group's own sequencer is recording a step of the AUTOMATIC flow
         for m in ([self] if grp is None else grp.members):
             m._in_prefetch_flow = True
-            if not own:
-                m._in_prefetch_explicit = True
+            m._in_prefetch_explicit = True
 
     def prefetch_text(self, all_dialog, stream, after_current=True):
         """pi_l only: start the frozen CLIP text tower for this step's dialog on `stream` right away (see net.prefetch_text).
@@ -1440,7 +1442,10 @@ class Policy(nn.Module):
         if len(h) > 2:
             del h[0]
         if grp.leader is self and not self._in_prefetch_flow:
-            grp.auto_launch(self, args)
+            if self._auto_seq_step:
+                self._auto_seq_step = False
+            else:
+                grp.auto_launch(self, args)
 
     def get_value(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory, ext_memory_masks):
         features, _, _ = self.net.run(self, observations, rnn_hidden_states, prev_actions, masks, ext_memory,

@@ -148,8 +148,8 @@ class StepSequencer:
         l._deferred = plan.gl
         o1 = plan.out_l1
         l._later = ("vln", plan.key_l, ((o1[0][0], l_args[1], o1[0][2], o1[0][3]), dict(o1[1])), self.S, l_args[7], l_args[8], False)
-        q._in_prefetch_flow = g._in_prefetch_flow = l._in_prefetch_flow = True
         if explicit:
+            q._in_prefetch_flow = g._in_prefetch_flow = l._in_prefetch_flow = True
             q._in_prefetch_explicit = g._in_prefetch_explicit = l._in_prefetch_explicit = True
         self._cur = ("fast", plan, l_args)
 
