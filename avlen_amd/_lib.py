@@ -135,6 +135,8 @@ SIGNATURES = {
     "avlen_conv_direct_bf16": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "avlen_cast_bf16": (i32, [vp, i32, vp, i32, C.c_long, i32, vp]),
     "avlen_cast_h16": (i32, [vp, i32, vp, i32, C.c_long, i32, i32, vp]),
+    "avlen_gemm_tn_bf16_workspace_bytes": (sz, [C.c_long, i32, i32]),
+    "avlen_gemm_tn_bf16": (i32, [vp, C.c_long, vp, C.c_long, C.c_long, i32, i32, vp, i32, C.c_float, vp, sz, vp]),
     "avlen_pack_conv_weight_h16": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "avlen_pack_fc_after_flatten_h16": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "avlen_resnet18_group_x3_workspace_bytes": (sz, [i32, i32]),

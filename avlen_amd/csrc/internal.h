@@ -21,6 +21,10 @@ int avlen_i_linear(const avlen_ctx& c, const avlen_linear& L, const float* X, in
 int avlen_i_linear_dx(const avlen_ctx& c, const avlen_linear& L, const float* dY, int ldy, float* dX, int ldx, int M,
                       const float* add, int ldadd);
 int avlen_i_linear_dw(const avlen_ctx& c, const avlen_linear& G, const float* dY, int ldy, const float* X, int ldx, int M);
+// C [N1][N2] = beta C + A^T B over M rows, A / B row-major bf16 (gemm_tn.hip: the weight gradient without transposed operand copies)
+size_t avlen_i_gemm_tn_workspace_bytes(long M, int N1, int N2);
+int avlen_i_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb, long M, int N1, int N2, float* C, int ldc, float beta,
+                         void* ws, size_t ws_bytes, hipStream_t st);
 int avlen_i_colsum_acc(const avlen_ctx& c, const float* dY, int ld, float* out, int rows, int N);
 // conv weight gradient G.w[cout][KH*KW*C] += dY^T im2col(X) on the large-M bf16 route with the gather fused into the operand
 // cast; AVLEN_NOT_BIG = route not applicable (caller: im2col + avlen_i_linear_dw)

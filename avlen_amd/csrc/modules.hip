@@ -41,6 +41,11 @@ bool fused_dy_on() {             // AVLEN_FUSED_DY=0: the three separate passes 
   if (v < 0) v = (int)avlen_knob("AVLEN_FUSED_DY", 1);
   return v != 0;
 }
+bool tn_dw_on() {                // AVLEN_TN_DW=0: the weight gradient through transposed operand copies (A/B knob)
+  static int v = -1;
+  if (v < 0) v = (int)avlen_knob("AVLEN_TN_DW", 1);
+  return v != 0;
+}
 long g_big_m = -1;
 long g_mixed_rows = 65536;     // bf16x3: token rows from which avlen_smt_bwd runs its products on plain bf16 operands (0 = never)
 long big_m() {
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(256) void dy_prep_kernel(const float* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 2; j++) {                          // transposed: 64 columns x 8 chunks of 8 rows (rows past M were loaded as zero)
       const int idx = tid + 256 * j, col = idx >> 3, rch = (idx & 7) * 8;
-      if (c0 + col < N && r0 + rch < Mp) {
+      if (t16 && c0 + col < N && r0 + rch < Mp) {
         bf16x8 h, l;
 #pragma unroll
         for (int e = 0; e < 8; e++) { const float v = t[rch + e][col]; h[e] = (bf16)v; if (NP == 2) l[e] = (bf16)(v - (float)h[e]); }
@@ -236,6 +241,26 @@ int linear_bwd(const Ctx& c, const avlen_linear& L, const avlen_linear& G, const
     const int Np = pad8(L.out_f);
     const long Mp = pad8(M);
     const int np = c.prec == AVLEN_PREC_BF16X3 ? 2 : 1;
+    if (np == 1 && tn_dw_on() && avlen_i_gemm_tn_workspace_bytes(M, L.out_f, L.in_f) <= c.gws_bytes) {
+      // plain 16-bit operands (bf16 mode, and the compensated mode's backward at scale): NO transposed copies -- one pass over dY
+      // (row-major 16-bit operand + bias gradient), one cast of X, and the row-contracted product of gemm_tn.hip on both
+      const int Kp = pad8(L.in_f);
+      XsBump b(c);
+      bf16* dY16 = b.take((size_t)M * Np); bf16* X16 = b.take((size_t)M * Kp);
+      bf16* WT16 = dX ? b.take((size_t)L.in_f * Np) : nullptr;
+      if (b.good) {
+        const long rt = (Mp + 63) / 64;
+        const int tiles = (int)(rt / 64 < 1 ? 1 : (rt / 64 > 16 ? 16 : rt / 64));
+        const dim3 grid((unsigned)((rt + tiles - 1) / tiles), ceil_div(L.out_f, 64));
+        hipLaunchKernelGGL(dy_prep_kernel<1>, grid, dim3(256), 0, c.st, dY, ldy, dY16, Np, 0L, (bf16*)nullptr, Mp, 0L, G.b, (long)M, L.out_f, tiles);
+        TRY(avlen_launch_status());
+        TRY(cast_pair(c, X, ldx, X16, Kp, M, L.in_f, 0));
+        TRY(avlen_i_gemm_tn_bf16(dY16, Np, X16, Kp, M, L.out_f, L.in_f, G.w, L.in_f, 1.f, c.gws, c.gws_bytes, c.st));
+        if (!dX) return AVLEN_OK;
+        TRY(tcast(c, L.w, L.in_f, WT16, Np, L.out_f, L.in_f, 0));
+        return big_gemm(c, dY16, Np, 0, WT16, Np, 0, dX, lddx, nullptr, add, ldadd, M, L.in_f, Np, 0);
+      }
+    }
     XsBump b(c);
     bf16* dY16 = dX ? b.take((size_t)np * M * Np) : nullptr;
     bf16* dYT = b.take((size_t)np * L.out_f * Mp); bf16* XT = b.take((size_t)np * L.in_f * Mp);

@@ -134,6 +134,13 @@ int avlen_cast_bf16(const float* src, int ld_src, void* dst, int ld_dst, long ro
 /* The same cast into another 16-bit format: fmt 0 = bf16, 1 = fp16 (IEEE half), 2 = the LOW plane of the compensated bf16 pair,
  * bf16(x - bf16(x)) (AVLEN_PREC_BF16X3 operands are hi + lo planes of identical layout). */
 int avlen_cast_h16(const float* src, int ld_src, void* dst, int ld_dst, long rows, int cols, int fmt, avlen_stream_t stream);
+/* Weight gradient of a Linear over many rows without transposed operand copies (replaces the dW term of loss.backward(),
+ * ss_baselines/savi/ppo/ppo.py:207-270): C [N1][N2] (row stride ldc) = beta * C + A^T B with A [M][lda], B [M][ldb] ROW-major bf16
+ * (lda, ldb multiples of 8, >= the column count rounded up to 8; the pad columns must hold zeros).  Partial tiles are summed in a
+ * fixed order (bit-reproducible).  ws: avlen_gemm_tn_bf16_workspace_bytes(M, N1, N2). */
+size_t avlen_gemm_tn_bf16_workspace_bytes(long M, int N1, int N2);
+int avlen_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb, long M, int N1, int N2, float* C, int ldc, float beta,
+                       void* ws, size_t ws_bytes, avlen_stream_t stream);
 /* avlen_gemm_bf16 on 16-bit operands of format fmt (0 = bf16, 1 = fp16; C16 is written in the same format). */
 int avlen_gemm_h16(const void* A, int lda, const void* B, int ldb, float* C32, int ldc32, void* C16, int ldc16,
                    const float* bias, const float* residual, int ldr, int M, int N, int K, int act, int fmt, void* ws,

@@ -368,3 +368,28 @@ def test_multi_copy(L):
     torch.cuda.synchronize()
     for d, s_ in zip(dsts, srcs):
         assert torch.equal(d, s_)
+
+
+@pytest.mark.parametrize("M,N1,N2,lda,ldb,beta", [(1000, 256, 256, 256, 256, 0.0), (37, 256, 64, 256, 64, 0.0), (5, 21, 9, 24, 16, 1.0),
+                                                  (70001, 768, 268, 768, 272, 1.0), (4096, 512, 256, 520, 256, 0.0),
+                                                  (300 * 77, 300, 520, 304, 520, 0.5)])
+def test_gemm_tn_rows_contracted(L, M, N1, N2, lda, ldb, beta):
+    """avlen_gemm_tn_bf16: C = beta C + A^T B over the rows of two row-major bf16 operands (the weight gradient of the 2nd-stage
+    update) against the fp64 product of the same bf16 values; twice the same bits (fixed-order partial sums)."""
+    torch.manual_seed(3)
+    A = torch.zeros(M, lda); A[:, :N1] = torch.randn(M, N1)
+    B = torch.zeros(M, ldb); B[:, :N2] = torch.randn(M, N2)
+    A16, B16 = dev(A.bfloat16()), dev(B.bfloat16())
+    C0 = torch.randn(N1, N2)
+    ref = beta * C0.double() + A16.cpu().double()[:, :N1].t() @ B16.cpu().double()[:, :N2]
+    nb = L.lib.avlen_gemm_tn_bf16_workspace_bytes(M, N1, N2)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    outs = []
+    for _ in range(2):
+        out = dev(C0.clone())
+        L.call("avlen_gemm_tn_bf16", L.ptr(A16), lda, L.ptr(B16), ldb, M, N1, N2, L.ptr(out), N2, beta, L.ptr(ws), nb, L.stream())
+        torch.cuda.synchronize()
+        outs.append(out.cpu())
+    assert torch.equal(outs[0], outs[1])
+    scale = float(ref.abs().max())
+    assert float((outs[0].double() - ref).abs().max()) < 2e-5 * scale + 1e-4 * math.sqrt(M) * 1e-2, (float((outs[0].double() - ref).abs().max()), scale)

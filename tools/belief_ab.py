@@ -3,8 +3,11 @@ sys.path.insert(0, ".")
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
 from avlen_amd.harness import Workload
 from avlen_amd import _lib as L
-for name, kw, cus in (("no belief", dict(), 0), ("sync", dict(belief_predictor=True), 0), ("async cus32", dict(belief_predictor=True, belief_async=True), 32),
+from avlen_amd import belief_predictor as BP
+for name, kw, cus in (("no belief", dict(), 0), ("sync", dict(belief_predictor=True), 0), ("sync cls-first", dict(belief_predictor=True), 0),
+                      ("sync", dict(belief_predictor=True), 0), ("async cus0", dict(belief_predictor=True, belief_async=True), 0), ("async cus32", dict(belief_predictor=True, belief_async=True), 32),
                       ("async cus16", dict(belief_predictor=True, belief_async=True), 16), ("async cus64", dict(belief_predictor=True, belief_async=True), 64)):
+    BP._PRED_FIRST = "cls-first" not in name
     wl = Workload(64, 150, spectrogram=(65, 26, 2), **kw)
     L.lib.avlen_set_tower_x3_reserved_cus(cus)
     wl.cycle(); wl.cycle()
