@@ -460,11 +460,15 @@ __global__ __launch_bounds__(256) void attn_qkv16_kernel(const __bf16* __restric
 // Scene-memory self-attention straight from the packed bf16 projection [R][q | k | v] (D = 32, <= 160 tokens per sample,
 // key-padding mask): same scheme as attn_qkv16_kernel -- transposed scores so P stays in registers, V^T fragments by
 // ds_read_b64_tr_b16 from the row-major V tile -- with one MFMA k-step per score tile (K = D = 32) and up to 10 key tiles.
-template <int SKP, bool X3>        // max tokens per sample (160 or 320); X3: compensated bf16 pairs (low planes qkv_lo / o_lo elements behind)
-__global__ __launch_bounds__(256) void attn_smt16_kernel(const __bf16* __restrict__ QKV, int ld, int koff, int voff,
+template <int SKP, bool X3, int NTH = 256>   // max tokens per sample (160 or 320); X3: compensated bf16 pairs (low planes qkv_lo / o_lo elements
+// behind); NTH threads: the 320-token compensated instance holds 121 KB of LDS -- one block per CU -- and runs 8 waves so that two
+// waves per SIMD hide each other's LDS / MFMA / softmax latencies (4 waves: 3.9 ms for the 2nd-stage update's 2400 x 8 heads, slower
+// than the fp32 VALU kernel)
+__global__ __launch_bounds__(NTH) void attn_smt16_kernel(const __bf16* __restrict__ QKV, int ld, int koff, int voff,
                                                          __bf16* __restrict__ O16, int ldo16, int S, float scale,
                                                          const float* __restrict__ key_mask, const int* __restrict__ seg_off,
-                                                         long qkv_lo, long o_lo) {
+                                                         long qkv_lo, long o_lo, float* __restrict__ O32, int ldo32,
+                                                         float* __restrict__ lse) {
   constexpr int D = 32, KR = 48, NKT = SKP / 16;    // 96-byte LDS rows: conflict-free for both read kinds
   constexpr int NP = X3 ? 2 : 1;                    // planes: hi (, lo)
   __shared__ __attribute__((aligned(16))) __bf16 qs[X3 ? 1 : SKP * KR];     // X3: the Q fragments come straight from global memory
@@ -476,7 +480,7 @@ __global__ __launch_bounds__(256) void attn_smt16_kernel(const __bf16* __restric
   long row0 = (long)b * S;
   if (seg_off) { row0 = seg_off[b]; S = min(seg_off[b + 1] - seg_off[b], SKP); key_mask = nullptr; }   // ragged: all tokens live
   const int S32 = (S + 31) & ~31;
-  for (int i = tid; i < S32 * 4; i += 256) {                   // 4 x 16-byte chunks per 32-wide row
+  for (int i = tid; i < S32 * 4; i += NTH) {                   // 4 x 16-byte chunks per 32-wide row
     const int r = i >> 2, c = i & 3;
 #pragma unroll
     for (int pl = 0; pl < NP; pl++) {
@@ -492,10 +496,10 @@ __global__ __launch_bounds__(256) void attn_smt16_kernel(const __bf16* __restric
       *reinterpret_cast<uint4*>(&vs[pl][r * KR + c * 8]) = vv;
     }
   }
-  for (int i = tid; i < SKP; i += 256) km[i] = (i < S && (!key_mask || key_mask[(long)b * S + i] != 0.f)) ? 1.f : 0.f;
+  for (int i = tid; i < SKP; i += NTH) km[i] = (i < S && (!key_mask || key_mask[(long)b * S + i] != 0.f)) ? 1.f : 0.f;
   __syncthreads();
   const int n_kt = (S + 15) >> 4, n_kk = (S + 31) >> 5;
-  for (int mt = wave; mt * 16 < S; mt += 4) {
+  for (int mt = wave; mt * 16 < S; mt += NTH / 64) {
     af32x4 sacc[NKT];
 #pragma unroll
     for (int nt = 0; nt < NKT; nt++) sacc[nt] = (af32x4){0.f, 0.f, 0.f, 0.f};
@@ -584,7 +588,11 @@ __global__ __launch_bounds__(256) void attn_smt16_kernel(const __bf16* __restric
         for (int r = 0; r < 4; r++) { const float v = oacc[dt][r] * inv; o[r] = (__bf16)v; ol[r] = (__bf16)(v - (float)o[r]); }
         *reinterpret_cast<abf16x4*>(op + dt * 16) = o;
         if (X3) *reinterpret_cast<abf16x4*>(op + o_lo + dt * 16) = ol;
+        // training forward: the fp32 output and the row's log-sum-exp for the backward (same definitions as attn_fwd_kernel)
+        if (O32) *reinterpret_cast<float4*>(O32 + (row0 + qi) * ldo32 + h * D + q4 * 4 + dt * 16) =
+            make_float4(oacc[dt][0] * inv, oacc[dt][1] * inv, oacc[dt][2] * inv, oacc[dt][3] * inv);
       }
+      if (lse && q4 == 0) lse[((long)b * gridDim.x + h) * S + qi] = mx + __logf(sum);
     }
   }
 }
@@ -780,26 +788,28 @@ int avlen_attention_fwd16(const float* Q, int ldq, const float* K, int ldk, cons
 // SMT self-attention from the packed bf16 projection (D = 32): q | k | v at columns 0 | H*32 | 2*H*32; key_mask [B][S], or
 // seg_off [B+1] for a ragged batch of live tokens (S = upper bound of tokens per sample).
 int avlen_attention_smt16(const void* QKV16, int ld, void* O16, int ldo16, int B, int H, int S, float scale,
-                          const float* key_mask, const int* seg_off, hipStream_t stream, long qkv_lo, long o_lo) {
+                          const float* key_mask, const int* seg_off, hipStream_t stream, long qkv_lo, long o_lo, float* O32, int ldo32,
+                          float* lse) {
   if (!QKV16 || !O16 || B <= 0 || H <= 0 || S <= 0 || S > 320 || (ld & 7) || (ldo16 & 3)) return AVLEN_ERR_ARG;
+  if ((O32 && ((ldo32 & 3) || ((uintptr_t)O32 & 15))) || ((O32 || lse) && seg_off)) return AVLEN_ERR_ARG;
   if (qkv_lo || o_lo) {                 // compensated pairs: both planes of k and v in LDS, q fragments from global memory
     if (!qkv_lo || !o_lo) return AVLEN_ERR_ARG;
     if (S <= 160)
       hipLaunchKernelGGL((attn_smt16_kernel<160, true>), dim3(H, B), dim3(256), 0, stream, (const __bf16*)QKV16, ld, H * 32, 2 * H * 32,
-                         (__bf16*)O16, ldo16, S, scale, key_mask, seg_off, qkv_lo, o_lo);
+                         (__bf16*)O16, ldo16, S, scale, key_mask, seg_off, qkv_lo, o_lo, O32, ldo32, lse);
     else
-      hipLaunchKernelGGL((attn_smt16_kernel<320, true>), dim3(H, B), dim3(256), 0, stream, (const __bf16*)QKV16, ld, H * 32, 2 * H * 32,
-                         (__bf16*)O16, ldo16, S, scale, key_mask, seg_off, qkv_lo, o_lo);
+      hipLaunchKernelGGL((attn_smt16_kernel<320, true, 512>), dim3(H, B), dim3(512), 0, stream, (const __bf16*)QKV16, ld, H * 32, 2 * H * 32,
+                         (__bf16*)O16, ldo16, S, scale, key_mask, seg_off, qkv_lo, o_lo, O32, ldo32, lse);
     return avlen_launch_status();
   }
   if (S <= 160)
     hipLaunchKernelGGL((attn_smt16_kernel<160, false>), dim3(H, B), dim3(256), 0, stream, (const __bf16*)QKV16, ld, H * 32, 2 * H * 32,
-                       (__bf16*)O16, ldo16, S, scale, key_mask, seg_off, 0L, 0L);
+                       (__bf16*)O16, ldo16, S, scale, key_mask, seg_off, 0L, 0L, O32, ldo32, lse);
   else {
     static unsigned long long attr_done = 0;             // per-device bit mask (a process may drive several devices)
     if (avlen_set_dyn_lds(reinterpret_cast<const void*>(&attn_smt16_kernel<320, false>), 0, &attr_done) != AVLEN_OK) return AVLEN_ERR_LAUNCH;
     hipLaunchKernelGGL((attn_smt16_kernel<320, false>), dim3(H, B), dim3(256), 0, stream, (const __bf16*)QKV16, ld, H * 32, 2 * H * 32,
-                       (__bf16*)O16, ldo16, S, scale, key_mask, seg_off, 0L, 0L);
+                       (__bf16*)O16, ldo16, S, scale, key_mask, seg_off, 0L, 0L, O32, ldo32, lse);
   }
   return avlen_launch_status();
 }

@@ -97,7 +97,8 @@ int avlen_attention_qkv16(const void* QKV16, int ld, void* O16, int ldo16, int B
 // lo planes (elements; 0 = plain bf16): qkv_lo behind QKV16, o_lo behind O16 -- compensated bf16 (three MFMAs per product, P split
 // into hi + lo); only the <= 160-token instance exists in that mode
 int avlen_attention_smt16(const void* QKV16, int ld, void* O16, int ldo16, int B, int H, int S, float scale,
-                          const float* key_mask, const int* seg_off, hipStream_t stream, long qkv_lo = 0, long o_lo = 0);
+                          const float* key_mask, const int* seg_off, hipStream_t stream, long qkv_lo = 0, long o_lo = 0,
+                          float* O32 = nullptr, int ldo32 = 0, float* lse = nullptr);   // training forward: fp32 output + row log-sum-exp
 int avlen_attention_q1(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, void* O16, int ldo16, int B,
                        int H, int Sk, float scale, const float* key_mask, const int* seg_off, hipStream_t stream, long o_lo = 0);
 int avlen_gemm_bf16_dyn(const void* A, int lda, const void* B, int ldb, float* C32, int ldc32, void* C16, int ldc16,

@@ -235,8 +235,9 @@ int colsum_acc(const Ctx& c, const float* dY, int ld, float* out, int rows, int 
 // The whole backward of Y = X W^T + b for one upstream gradient: G.w += dY^T X, G.b += colsum(dY), dX = dY W (+ add) when dX is
 // given.  Large M (the 16-bit glds route): dY is read ONCE (dy_prep_kernel); otherwise -- or when the operand scratch cannot hold all
 // four operands at a time -- the three separate steps, in the order the call sites always used.
+// X16 (optional): the forward already holds X as a row-major 16-bit operand (row stride ldx16 >= pad8(in_f), pad columns zero).
 int linear_bwd(const Ctx& c, const avlen_linear& L, const avlen_linear& G, const float* dY, int ldy, const float* X, int ldx, float* dX,
-               int lddx, int M, const float* add, int ldadd) {
+               int lddx, int M, const float* add, int ldadd, const bf16* X16 = nullptr, int ldx16 = 0) {
   if (big_path(c, M) && !(ldy & 3) && !((uintptr_t)dY & 15) && fused_dy_on()) {
     const int Np = pad8(L.out_f);
     const long Mp = pad8(M);
@@ -246,7 +247,8 @@ int linear_bwd(const Ctx& c, const avlen_linear& L, const avlen_linear& G, const
       // (row-major 16-bit operand + bias gradient), one cast of X, and the row-contracted product of gemm_tn.hip on both
       const int Kp = pad8(L.in_f);
       XsBump b(c);
-      bf16* dY16 = b.take((size_t)M * Np); bf16* X16 = b.take((size_t)M * Kp);
+      const bool have_x = X16 != nullptr && ldx16 >= Kp;
+      bf16* dY16 = b.take((size_t)M * Np); bf16* Xc = have_x ? nullptr : b.take((size_t)M * Kp);
       bf16* WT16 = dX ? b.take((size_t)L.in_f * Np) : nullptr;
       if (b.good) {
         const long rt = (Mp + 63) / 64;
@@ -254,13 +256,15 @@ int linear_bwd(const Ctx& c, const avlen_linear& L, const avlen_linear& G, const
         const dim3 grid((unsigned)((rt + tiles - 1) / tiles), ceil_div(L.out_f, 64));
         hipLaunchKernelGGL(dy_prep_kernel<1>, grid, dim3(256), 0, c.st, dY, ldy, dY16, Np, 0L, (bf16*)nullptr, Mp, 0L, G.b, (long)M, L.out_f, tiles);
         TRY(avlen_launch_status());
-        TRY(cast_pair(c, X, ldx, X16, Kp, M, L.in_f, 0));
-        TRY(avlen_i_gemm_tn_bf16(dY16, Np, X16, Kp, M, L.out_f, L.in_f, G.w, L.in_f, 1.f, c.gws, c.gws_bytes, c.st));
+        if (!have_x) TRY(cast_pair(c, X, ldx, Xc, Kp, M, L.in_f, 0));
+        TRY(avlen_i_gemm_tn_bf16(dY16, Np, have_x ? X16 : Xc, have_x ? ldx16 : Kp, M, L.out_f, L.in_f, G.w, L.in_f, 1.f, c.gws, c.gws_bytes,
+                                 c.st));
         if (!dX) return AVLEN_OK;
         TRY(tcast(c, L.w, L.in_f, WT16, Np, L.out_f, L.in_f, 0));
         return big_gemm(c, dY16, Np, 0, WT16, Np, 0, dX, lddx, nullptr, add, ldadd, M, L.in_f, Np, 0);
       }
     }
+    if (X16) return AVLEN_ERR_WS;
     XsBump b(c);
     bf16* dY16 = dX ? b.take((size_t)np * M * Np) : nullptr;
     bf16* dYT = b.take((size_t)np * L.out_f * Mp); bf16* XT = b.take((size_t)np * L.in_f * Mp);
@@ -282,6 +286,7 @@ int linear_bwd(const Ctx& c, const avlen_linear& L, const avlen_linear& G, const
       return big_gemm(c, dY16, Np, yl, WT16, Np, wl, dX, lddx, nullptr, add, ldadd, M, L.in_f, Np, 0);
     }
   }
+  if (X16) return AVLEN_ERR_WS;        // the caller kept X only as a 16-bit plane: that route (above) must have been taken
   TRY(linear_dw(c, G, dY, ldy, X, ldx, M));
   TRY(colsum_acc(c, dY, ldy, G.b, M, L.out_f));
   return dX ? linear_dx(c, L, dY, ldy, dX, lddx, M, add, ldadd) : AVLEN_OK;
@@ -362,6 +367,14 @@ int colsum_acc(const Ctx& c, const float* dY, int ld, float* out, int rows, int 
 __global__ void relu_bwd_kernel(float* __restrict__ dx, const float* __restrict__ y, long n) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && y[i] <= 0.f) dx[i] = 0.f;
+}
+__global__ void relu_bwd16_kernel(float* __restrict__ dx, const bf16* __restrict__ y16, long n) {      // the sign survives the cast
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && (float)y16[i] <= 0.f) dx[i] = 0.f;
+}
+int relu_bwd16(const Ctx& c, float* dx, const bf16* y16, long n) {
+  hipLaunchKernelGGL(relu_bwd16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.st, dx, y16, n);
+  return avlen_launch_status();
 }
 int relu_bwd(const Ctx& c, float* dx, const float* y, long n) {
   hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.st, dx, y, n);
@@ -1371,6 +1384,13 @@ int transformer_fwd(const Ctx& c, const avlen_transformer& tr, TrWs& t, const fl
 }
 
 struct TrBwdWs { float *dA, *dB, *dC, *dD, *dE, *delta; };     // dA: [R,3d]; dB..dE: [R,d]
+// 16-bit activation planes of the training forward at scale ("big16": the 2nd-stage update, 722 k token rows): every producer emits the
+// operand of the next product (hi plane, and the lo plane right behind it in compensated mode), the hi planes stay for the backward's
+// weight gradients.  No per-product cast of an fp32 activation is left in the forward, none of X in the backward.
+struct Big16 { bf16 *XF = nullptr, *H1 = nullptr, *Z = nullptr, *QKV = nullptr, *AO = nullptr, *X1 = nullptr, *F1 = nullptr, *MEM = nullptr;
+               int ldxf = 0; };
+int g_big16 = 1;                 // avlen_set_big16(0): fp32-staged training forward at every size (tests compare the two)
+bool big16_enabled() { return g_big16 != 0; }
 
 void trb_layout(WsBump& w, TrBwdWs& b, long B, long S, int d, int H) {
   long R = B * S;
@@ -1381,7 +1401,7 @@ void trb_layout(WsBump& w, TrBwdWs& b, long B, long S, int d, int H) {
 // Gradients w.r.t. the transformer parameters (accumulated into g) and w.r.t. Z (written to dZ [R,d]).
 int transformer_bwd(const Ctx& c, const avlen_transformer& tr, const avlen_transformer& g, TrWs& t, TrBwdWs& s,
                     const float* Z, const float* maskx, const float* tgt, const float* d_out, float* dZ, int B, int S,
-                    bool cto) {
+                    bool cto, const Big16* h16 = nullptr) {
   const int d = tr.d, H = tr.nhead, D = d / H;
   const long R = (long)B * S;
   const float scale = 1.0f / sqrtf((float)D);
@@ -1418,7 +1438,7 @@ int transformer_bwd(const Ctx& c, const avlen_transformer& tr, const avlen_trans
     TRY(linear_bwd(c, wqp, gqp, dQc, d, t.Y1, d, dY1, d, B, dU2, d));                         // dY1 = dU2 + dQc Wq
     avlen_linear gkv = gin; gkv.w = gin.w + (size_t)d * d; gkv.b = gin.b + d; gkv.out_f = 2 * d;
     avlen_linear wkv = win; wkv.w = win.w + (size_t)d * d; wkv.out_f = 2 * d;
-    TRY(linear_bwd(c, wkv, gkv, dKVc, 2 * d, t.MEM, d, dMEM, d, (int)R, nullptr, 0));
+    TRY(linear_bwd(c, wkv, gkv, dKVc, 2 * d, t.MEM, d, dMEM, d, (int)R, nullptr, 0, h16 ? h16->MEM : nullptr, d));
   }
   // ---- decoder: norm1, self attention over the single target token
   float* dU1 = s.dB;
@@ -1435,14 +1455,16 @@ int transformer_bwd(const Ctx& c, const avlen_transformer& tr, const avlen_trans
   TRY(avlen_layernorm_bwd(dMEM, t.X2, tr.enc_norm.g, t.me, t.re, dX2, g.enc_norm.g, g.enc_norm.b, (int)R, d, c.st));
   TRY(avlen_layernorm_bwd(dX2, t.T2, e.norm2.g, t.m2, t.r2, dT2, ge.norm2.g, ge.norm2.b, (int)R, d, c.st));
   float* dF1 = s.dD; float* dX1 = s.dE;
-  TRY(linear_bwd(c, e.lin2, ge.lin2, dT2, d, t.F1, e.lin1.out_f, dF1, e.lin1.out_f, (int)R, nullptr, 0));
-  TRY(relu_bwd(c, dF1, t.F1, R * e.lin1.out_f));
-  TRY(linear_bwd(c, e.lin1, ge.lin1, dF1, e.lin1.out_f, t.X1, d, dX1, d, (int)R, dT2, d));          // dX1 = dT2 + dF1 W1
+  TRY(linear_bwd(c, e.lin2, ge.lin2, dT2, d, t.F1, e.lin1.out_f, dF1, e.lin1.out_f, (int)R, nullptr, 0, h16 ? h16->F1 : nullptr,
+                 e.lin1.out_f));
+  if (h16) TRY(relu_bwd16(c, dF1, h16->F1, R * e.lin1.out_f));
+  else TRY(relu_bwd(c, dF1, t.F1, R * e.lin1.out_f));
+  TRY(linear_bwd(c, e.lin1, ge.lin1, dF1, e.lin1.out_f, t.X1, d, dX1, d, (int)R, dT2, d, h16 ? h16->X1 : nullptr, d));   // dX1 = dT2 + dF1 W1
   // ---- encoder: norm1, self attention
   float* dT1 = s.dB;
   TRY(avlen_layernorm_bwd(dX1, t.T1, e.norm1.g, t.m1, t.r1, dT1, ge.norm1.g, ge.norm1.b, (int)R, d, c.st));
   float* dAO = s.dC;
-  TRY(linear_bwd(c, e.self_attn.out_proj, ge.self_attn.out_proj, dT1, d, t.AO, d, dAO, d, (int)R, nullptr, 0));
+  TRY(linear_bwd(c, e.self_attn.out_proj, ge.self_attn.out_proj, dT1, d, t.AO, d, dAO, d, (int)R, nullptr, 0, h16 ? h16->AO : nullptr, d));
   if (cto) {
     avlen_linear gv = ge.self_attn.in_proj; gv.w += (size_t)2 * d * d; gv.b += 2 * d; gv.out_f = d;
     avlen_linear wv = e.self_attn.in_proj; wv.w += (size_t)2 * d * d; wv.out_f = d;
@@ -1458,13 +1480,13 @@ int transformer_bwd(const Ctx& c, const avlen_transformer& tr, const avlen_trans
       rc = avlen_attention_bwd(t.QKV, 3 * d, t.QKV + d, 3 * d, t.QKV + 2 * d, 3 * d, t.AO, d, dAO, d, maskx, t.LSE, s.delta,
                                dQKV, 3 * d, dQKV + d, 3 * d, dQKV + 2 * d, 3 * d, B, H, S, S, D, 0, scale, c.st);
     TRY(rc);
-    TRY(linear_bwd(c, e.self_attn.in_proj, ge.self_attn.in_proj, dQKV, 3 * d, Z, d, dZ, d, (int)R, dT1, d));   // dZ = dT1 + dQKV Win
+    TRY(linear_bwd(c, e.self_attn.in_proj, ge.self_attn.in_proj, dQKV, 3 * d, Z, d, dZ, d, (int)R, dT1, d, h16 ? h16->Z : nullptr, d));   // dZ = dT1 + dQKV Win
   }
   return AVLEN_OK;
 }
 
 struct SmtWs { float *XF, *FMT, *maskx, *H1, *Z; TrWs tr; TrBwdWs tb; float *dZ, *dH1, *dPE, *dXc; void* gws; int ldxf;
-               void* xs; size_t xs_bytes; };
+               void* xs; size_t xs_bytes; Big16 h; };
 
 void smt_layout(WsBump& w, SmtWs& s, const avlen_smt* p, long B, long M, int F, bool cto) {
   long S = cto ? 1 : M + 1, R = B * S;
@@ -1481,7 +1503,67 @@ void smt_layout(WsBump& w, SmtWs& s, const avlen_smt* p, long B, long M, int F, 
   if (R >= big_m()) {            // operand scratch of the large-M bf16 products: two operands of up to 3d + ldxf columns
     s.xs_bytes = 2 * ((size_t)(R + 8) * (size_t)(4 * d + s.ldxf + 16) * 2 + ((size_t)4 << 20));     // x 2: hi + lo planes (bf16x3)
     s.xs = w.take<char>(s.xs_bytes);
+    if (!cto) {                    // big16 planes (hi + lo each)
+      const int ff = p->tr.enc.lin1.out_f;
+      s.h.ldxf = pad8(F + 12);
+      s.h.XF = w.take<bf16>(2 * R * s.h.ldxf); s.h.H1 = w.take<bf16>(2 * R * d); s.h.Z = w.take<bf16>(2 * R * d);
+      s.h.QKV = w.take<bf16>(2 * R * 3 * d); s.h.AO = w.take<bf16>(2 * R * d); s.h.X1 = w.take<bf16>(2 * R * d);
+      s.h.F1 = w.take<bf16>(2 * R * ff); s.h.MEM = w.take<bf16>(2 * R * d);
+    }
   }
+}
+// both directions decide alike: plain bf16, or the compensated mode where its backward runs on plain operands (R >= g_mixed_rows)
+bool big16_on(const avlen_smt* p, const SmtWs& s, int prec, long R, int S, bool cto) {
+  const int d = p->tr.d, H = p->tr.nhead;
+  if (cto || !s.xs || !s.h.XF || !big16_enabled() || R < big_m() || !tn_dw_on()) return false;
+  if (!(prec == AVLEN_PREC_BF16 || (prec == AVLEN_PREC_BF16X3 && g_mixed_rows > 0 && R >= g_mixed_rows))) return false;
+  return H > 0 && d / H == 32 && d % 8 == 0 && S <= 320 && (d == 256 || d == 512 || d == 128 || d == 64) && p->fus0.out_f == d &&
+         p->tr.enc.lin1.out_f % 8 == 0;
+}
+// Y = act(X16 W[r0 : r0 + n]^T + b) + res from 16-bit activation planes (xlo / ylo: ELEMENTS from the hi to the lo plane, compensated
+// mode) -> fp32 (Y32) and / or planes (Y16).  The weights are cast here, per call: they change with every optimiser step.
+int linear16t(const Ctx& c, const avlen_linear& L, int r0, int n, const bf16* X16, int ldx, long xlo, float* Y32, int ld32, bf16* Y16,
+              int ld16, long ylo, long M, int act, const float* res, int ldr) {
+  const int Kp = pad8(L.in_f);
+  const int np = c.prec == AVLEN_PREC_BF16X3 ? 2 : 1;
+  if (ldx < Kp || (np > 1 && (!xlo || (Y16 && !ylo)))) return AVLEN_ERR_ARG;
+  XsBump b(c);
+  bf16* W16 = b.take((size_t)np * n * Kp);
+  if (!b.good) return AVLEN_ERR_WS;
+  const long wl = np > 1 ? (long)n * Kp : 0;
+  TRY(cast_pair(c, L.w + (size_t)r0 * L.in_f, L.in_f, W16, Kp, n, L.in_f, wl));
+  avlen_g2_opts o;
+  if (np > 1) { o.x3 = 1; o.a_lo = xlo * 2; o.b_lo = wl * 2; o.c16_lo = ylo; }
+  return avlen_gemm_bf16_dyn(X16, ldx, W16, Kp, Y32, ld32, Y16, ld16, L.b ? L.b + r0 : nullptr, res, ldr, (int)M, nullptr, n, Kp, act,
+                             c.gws, c.gws_bytes, c.st, &o);
+}
+int dec_fwd(const Ctx& c, const avlen_transformer& tr, TrWs& t, const float* maskx, const float* tgt, float* out, int B, int S, bool cto);
+// The training forward at scale on 16-bit activation planes: same products, same formats as the fp32-staged forward (an operand plane
+// is the cast of the fp32 value either way), the self attention on the matrix cores (attn_smt16_kernel; it also leaves the fp32
+// output and the log-sum-exp the backward reads).  Fills what transformer_bwd / avlen_smt_bwd read: QKV, AO, LSE, T1, T2, X2, KVc, the
+// LayerNorm statistics and the planes of s.h.
+int smt_fwd_big16(const Ctx& c, const avlen_smt* p, SmtWs& s, const float* goal, float* out, int B, int S) {
+  const avlen_transformer& tr = p->tr; const avlen_enc_layer& e = tr.enc;
+  const int d = tr.d, H = tr.nhead, ff = e.lin1.out_f;
+  const long R = (long)B * S;
+  const float scale = 1.0f / sqrtf((float)(d / H));
+  const bool x3 = c.prec == AVLEN_PREC_BF16X3;
+  Big16& h = s.h; TrWs& t = s.tr;
+  const long lx = x3 ? R * h.ldxf : 0, l1 = x3 ? R * d : 0, l3 = x3 ? R * 3 * d : 0, lf = x3 ? R * ff : 0;      // hi -> lo plane
+  if (x3) TRY(cast_pair(c, s.XF, s.ldxf, h.XF, h.ldxf, R, p->fus0.in_f, lx));
+  else TRY(avlen_cast_h16(s.XF, s.ldxf, h.XF, h.ldxf, R, p->fus0.in_f, 0, c.st));
+  TRY(linear16t(c, p->fus0, 0, d, h.XF, h.ldxf, lx, nullptr, 0, h.H1, d, l1, R, AVLEN_ACT_RELU, nullptr, 0));
+  TRY(linear16t(c, p->fus2, 0, d, h.H1, d, l1, s.Z, d, h.Z, d, l1, R, 0, nullptr, 0));
+  TRY(linear16t(c, e.self_attn.in_proj, 0, 3 * d, h.Z, d, l1, t.QKV, 3 * d, h.QKV, 3 * d, l3, R, 0, nullptr, 0));
+  TRY(avlen_attention_smt16(h.QKV, 3 * d, h.AO, d, B, H, S, scale, s.maskx, nullptr, c.st, l3, l1, t.AO, d, t.LSE));
+  TRY(linear16t(c, e.self_attn.out_proj, 0, d, h.AO, d, l1, t.T1, d, nullptr, 0, 0, R, 0, s.Z, d));
+  TRY(avlen_layernorm_fwd16_dyn(t.T1, nullptr, e.norm1.g, e.norm1.b, t.X1, h.X1, t.m1, t.r1, (int)R, nullptr, d, 1e-5f, c.st, l1));
+  TRY(linear16t(c, e.lin1, 0, ff, h.X1, d, l1, nullptr, 0, h.F1, ff, lf, R, AVLEN_ACT_RELU, nullptr, 0));
+  TRY(linear16t(c, e.lin2, 0, d, h.F1, ff, lf, t.T2, d, nullptr, 0, 0, R, 0, t.X1, d));
+  TRY(avlen_layernorm_fwd(t.T2, nullptr, e.norm2.g, e.norm2.b, t.X2, t.m2, t.r2, (int)R, d, 1e-5f, c.st));
+  TRY(avlen_layernorm_fwd16_dyn(t.X2, nullptr, tr.enc_norm.g, tr.enc_norm.b, nullptr, h.MEM, t.me, t.re, (int)R, nullptr, d, 1e-5f, c.st, l1));
+  TRY(linear16t(c, tr.dec.cross_attn.in_proj, d, 2 * d, h.MEM, d, l1, t.KVc, 2 * d, nullptr, 0, 0, R, 0, nullptr, 0));
+  return dec_fwd(c, tr, t, s.maskx, goal, out, B, S, false);
 }
 
 }  // namespace
@@ -1822,6 +1904,7 @@ extern "C" int avlen_smt_fwd(const avlen_smt* p, const float* x, const float* me
   hipLaunchKernelGGL(smt_build_kernel, dim3((unsigned)R), dim3(128), 0, st, x, memory, mem_index, NC, masks, p->pose.w, p->pose.b, s.XF,
                      s.ldxf, s.FMT, s.maskx, B, M, F, pose_col, cto);
   TRY(avlen_launch_status());
+  if (save_for_backward && big16_on(p, s, prec, R, S, cto != 0)) return smt_fwd_big16(c, p, s, goal, out, B, S);
   TRY(linear(c, p->fus0, s.XF, s.ldxf, s.H1, d, (int)R, AVLEN_ACT_RELU, nullptr, 0));
   TRY(linear(c, p->fus2, s.H1, d, s.Z, d, (int)R, 0, nullptr, 0));
   return transformer_fwd(c, p->tr, s.tr, s.Z, s.maskx, goal, out, B, S, cto != 0);
@@ -1853,13 +1936,15 @@ extern "C" int avlen_smt_bwd(const avlen_smt* p, const avlen_smt* g, const float
   const bool mixed = prec == AVLEN_PREC_BF16X3 && g_mixed_rows > 0 && R >= g_mixed_rows;
   Ctx c{st, mixed ? AVLEN_PREC_BF16 : prec, s.gws, GEMM_SCRATCH};
   c.xs = s.xs; c.xs_bytes = s.xs_bytes;
-  TRY(transformer_bwd(c, p->tr, g->tr, s.tr, s.tb, s.Z, s.maskx, goal, d_out, s.dZ, B, S, cto != 0));
+  const Big16* h16 = big16_on(p, s, prec, R, S, cto != 0) ? &s.h : nullptr;      // the forward left 16-bit operand planes
+  TRY(transformer_bwd(c, p->tr, g->tr, s.tr, s.tb, s.Z, s.maskx, goal, d_out, s.dZ, B, S, cto != 0, h16));
   // fusion MLP
-  TRY(linear_bwd(c, p->fus2, g->fus2, s.dZ, d, s.H1, d, s.dH1, d, (int)R, nullptr, 0));
-  TRY(relu_bwd(c, s.dH1, s.H1, R * d));
+  TRY(linear_bwd(c, p->fus2, g->fus2, s.dZ, d, s.H1, d, s.dH1, d, (int)R, nullptr, 0, h16 ? h16->H1 : nullptr, d));
+  if (h16) TRY(relu_bwd16(c, s.dH1, h16->H1, R * d));
+  else TRY(relu_bwd(c, s.dH1, s.H1, R * d));
   {
     avlen_linear g0 = g->fus0;            // dW0[d][F+12] += dH1^T XF  (XF rows are ldxf apart)
-    TRY(linear_bwd(c, g0, g0, s.dH1, d, s.XF, s.ldxf, nullptr, 0, (int)R, nullptr, 0));
+    TRY(linear_bwd(c, g0, g0, s.dH1, d, s.XF, s.ldxf, nullptr, 0, (int)R, nullptr, 0, h16 ? h16->XF : nullptr, h16 ? h16->ldxf : 0));
   }
   // pose encoder: dPE[R,16] = dH1 * W0[:, pc:pc+16]
   TRY(avlen_gemm(s.dH1, d, 0, p->fus0.w + pose_col, p->fus0.in_f, 1, s.dPE, 16, nullptr, nullptr, 0, (int)R, 16, d, 0,
@@ -2456,4 +2541,5 @@ extern "C" int avlen_gru_fwd(const avlen_gru* p, const float* x, const float* h0
 extern "C" void avlen_set_big_m(long rows) { g_big_m = rows > 0 ? rows : 4096; }
 // bf16x3: token rows (B x (M + 1)) from which the SMT backward uses plain bf16 operands (forward stays compensated); 0 = never,
 // < 0 restores the default (65536).
+extern "C" void avlen_set_big16(int on) { g_big16 = on ? 1 : 0; }
 extern "C" void avlen_set_x3_mixed_backward_rows(long rows) { g_mixed_rows = rows < 0 ? 65536 : rows; }

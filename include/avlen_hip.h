@@ -322,6 +322,10 @@ void avlen_set_big_m(long rows);
  * backward's products and attention on plain bf16 operands with fp32 accumulation (mixed-precision training); the forward -- the
  * logits, the PPO ratio, the losses -- stays compensated at every size. */
 void avlen_set_x3_mixed_backward_rows(long rows);
+/* The training forward at scale (rows >= avlen_set_big_m; bf16 mode, and bf16x3 where its backward is mixed) keeps its activations
+ * as 16-bit operand planes emitted by their producers and runs the self attention on the matrix cores (default on).  0: every
+ * product casts its fp32 input (the layout the small-batch path uses); tests compare the two. */
+void avlen_set_big16(int on);
 /* Scheduling knob of the bf16x3 tower group (one persistent work-queue launch, one workgroup per CU): CUs it leaves free for the
  * other streams of the step (default 0 = every CU). */
 void avlen_set_tower_x3_reserved_cus(int n);
