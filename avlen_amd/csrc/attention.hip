@@ -885,7 +885,9 @@ __global__ __launch_bounds__(NTH) void attn_bwd16_kernel(const float* __restrict
                                                          const float* __restrict__ key_mask, const float* __restrict__ lse,
                                                          float* __restrict__ delta, float* __restrict__ dQ, int lddq,
                                                          float* __restrict__ dK, int lddk, float* __restrict__ dV, int lddv, int H,
-                                                         int S, float scale) {
+                                                         int S, float scale, const __bf16* __restrict__ QKV16, int ld16) {
+  // QKV16 (optional): q | k | v as the packed bf16 projection [R][ld16] (columns 0 | H*32 | 2*H*32) the forward kept -- the same
+  // values the fp32 -> bf16 staging below produces, without the fp32 copy (Q, K, V may then be null)
   constexpr int D = 32, KR = 48;                    // 96-byte LDS rows: conflict-free for both read kinds (as attn_smt16_kernel)
   __shared__ __attribute__((aligned(16))) __bf16 qs[SKP * KR];
   __shared__ __attribute__((aligned(16))) __bf16 ks[SKP * KR];
@@ -904,19 +906,32 @@ __global__ __launch_bounds__(NTH) void attn_bwd16_kernel(const float* __restrict
     for (int e = 0; e < 8; e++) { q8[e] = (__bf16)0.f; k8[e] = q8[e]; v8[e] = q8[e]; g8[e] = q8[e]; }
     float dl = 0.f;
     if (r < S) {
-      const float4* qp = reinterpret_cast<const float4*>(Q + (row0 + r) * ldq + h * D + c * 8);
-      const float4* kp = reinterpret_cast<const float4*>(K + (row0 + r) * ldk + h * D + c * 8);
-      const float4* vp = reinterpret_cast<const float4*>(V + (row0 + r) * ldv + h * D + c * 8);
       const float4* gp = reinterpret_cast<const float4*>(dO + (row0 + r) * lddo + h * D + c * 8);
       const float4* op = reinterpret_cast<const float4*>(O + (row0 + r) * ldo + h * D + c * 8);
+      if (QKV16) {
+        const __bf16* base = QKV16 + (row0 + r) * ld16 + h * D + c * 8;
+        q8 = *reinterpret_cast<const abf16x8*>(base);
+        k8 = *reinterpret_cast<const abf16x8*>(base + H * D);
+        v8 = *reinterpret_cast<const abf16x8*>(base + 2 * H * D);
 #pragma unroll
-      for (int u = 0; u < 2; u++) {
-        const float4 a = qp[u], bb = kp[u], cc = vp[u], g = gp[u], o = op[u];
-        q8[4 * u] = (__bf16)a.x; q8[4 * u + 1] = (__bf16)a.y; q8[4 * u + 2] = (__bf16)a.z; q8[4 * u + 3] = (__bf16)a.w;
-        k8[4 * u] = (__bf16)bb.x; k8[4 * u + 1] = (__bf16)bb.y; k8[4 * u + 2] = (__bf16)bb.z; k8[4 * u + 3] = (__bf16)bb.w;
-        v8[4 * u] = (__bf16)cc.x; v8[4 * u + 1] = (__bf16)cc.y; v8[4 * u + 2] = (__bf16)cc.z; v8[4 * u + 3] = (__bf16)cc.w;
-        g8[4 * u] = (__bf16)g.x; g8[4 * u + 1] = (__bf16)g.y; g8[4 * u + 2] = (__bf16)g.z; g8[4 * u + 3] = (__bf16)g.w;
-        dl += g.x * o.x + g.y * o.y + g.z * o.z + g.w * o.w;
+        for (int u = 0; u < 2; u++) {
+          const float4 g = gp[u], o = op[u];
+          g8[4 * u] = (__bf16)g.x; g8[4 * u + 1] = (__bf16)g.y; g8[4 * u + 2] = (__bf16)g.z; g8[4 * u + 3] = (__bf16)g.w;
+          dl += g.x * o.x + g.y * o.y + g.z * o.z + g.w * o.w;
+        }
+      } else {
+        const float4* qp = reinterpret_cast<const float4*>(Q + (row0 + r) * ldq + h * D + c * 8);
+        const float4* kp = reinterpret_cast<const float4*>(K + (row0 + r) * ldk + h * D + c * 8);
+        const float4* vp = reinterpret_cast<const float4*>(V + (row0 + r) * ldv + h * D + c * 8);
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const float4 a = qp[u], bb = kp[u], cc = vp[u], g = gp[u], o = op[u];
+          q8[4 * u] = (__bf16)a.x; q8[4 * u + 1] = (__bf16)a.y; q8[4 * u + 2] = (__bf16)a.z; q8[4 * u + 3] = (__bf16)a.w;
+          k8[4 * u] = (__bf16)bb.x; k8[4 * u + 1] = (__bf16)bb.y; k8[4 * u + 2] = (__bf16)bb.z; k8[4 * u + 3] = (__bf16)bb.w;
+          v8[4 * u] = (__bf16)cc.x; v8[4 * u + 1] = (__bf16)cc.y; v8[4 * u + 2] = (__bf16)cc.z; v8[4 * u + 3] = (__bf16)cc.w;
+          g8[4 * u] = (__bf16)g.x; g8[4 * u + 1] = (__bf16)g.y; g8[4 * u + 2] = (__bf16)g.z; g8[4 * u + 3] = (__bf16)g.w;
+          dl += g.x * o.x + g.y * o.y + g.z * o.z + g.w * o.w;
+        }
       }
     }
     *reinterpret_cast<abf16x8*>(&qs[r * KR + c * 8]) = q8;
@@ -1088,23 +1103,33 @@ extern "C" int avlen_attention_bwd_bf16(const float* Q, int ldq, const float* K,
                                         const float* lse, float* delta, float* dQ, int lddq, float* dK, int lddk, float* dV,
                                         int lddv, int B, int H, int Sq, int Sk, int D, int causal, float scale,
                                         hipStream_t stream) {
-  if (B <= 0 || H <= 0 || Sq != Sk || Sq <= 0 || Sq > 320 || D != 32 || causal || ((ldq | ldk | ldv | ldo | lddo | lddq | lddk | lddv) & 3))
+  return avlen_attention_bwd_p16(Q, ldq, K, ldk, V, ldv, O, ldo, dO, lddo, key_mask, lse, delta, dQ, lddq, dK, lddk, dV, lddv, B, H, Sq, Sk,
+                                 D, causal, scale, stream, nullptr, 0);
+}
+int avlen_attention_bwd_p16(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
+                            const float* O, int ldo, const float* dO, int lddo, const float* key_mask,
+                            const float* lse, float* delta, float* dQ, int lddq, float* dK, int lddk, float* dV,
+                            int lddv, int B, int H, int Sq, int Sk, int D, int causal, float scale,
+                            hipStream_t stream, const void* QKV16_, int ld16) {
+  const __bf16* QKV16 = (const __bf16*)QKV16_;
+  if (B <= 0 || H <= 0 || Sq != Sk || Sq <= 0 || Sq > 320 || D != 32 || causal || ((ldo | lddo | lddq | lddk | lddv) & 3))
     return AVLEN_ERR_ARG;
+  if (QKV16 ? ((ld16 & 7) || ((uintptr_t)QKV16 & 15)) : ((ldq | ldk | ldv) & 3) != 0) return AVLEN_ERR_ARG;
   if (Sq <= 160)
     hipLaunchKernelGGL((attn_bwd16_kernel<160, 256>), dim3(H, B), dim3(256), 0, stream, Q, ldq, K, ldk, V, ldv, O, ldo, dO, lddo, key_mask, lse,
-                       delta, dQ, lddq, dK, lddk, dV, lddv, H, Sq, scale);
+                       delta, dQ, lddq, dK, lddk, dV, lddv, H, Sq, scale, QKV16, ld16);
   else {
     static int nth = -1;                           // AVLEN_ATTN_BWD16_THREADS=256|512|1024 (A/B knob)
     if (nth < 0) nth = (int)avlen_knob("AVLEN_ATTN_BWD16_THREADS", 1024);
     if (nth == 256)
       hipLaunchKernelGGL((attn_bwd16_kernel<320, 256>), dim3(H, B), dim3(256), 0, stream, Q, ldq, K, ldk, V, ldv, O, ldo, dO, lddo, key_mask,
-                         lse, delta, dQ, lddq, dK, lddk, dV, lddv, H, Sq, scale);
+                         lse, delta, dQ, lddq, dK, lddk, dV, lddv, H, Sq, scale, QKV16, ld16);
     else if (nth == 512)
       hipLaunchKernelGGL((attn_bwd16_kernel<320, 512>), dim3(H, B), dim3(512), 0, stream, Q, ldq, K, ldk, V, ldv, O, ldo, dO, lddo, key_mask,
-                         lse, delta, dQ, lddq, dK, lddk, dV, lddv, H, Sq, scale);
+                         lse, delta, dQ, lddq, dK, lddk, dV, lddv, H, Sq, scale, QKV16, ld16);
     else      // 16 waves: measured 9.2 / 5.6 / 4.0 ms for 256 / 512 / 1024 threads at 2400 x 8 heads x 301 tokens (fp32 kernels: 17 ms)
       hipLaunchKernelGGL((attn_bwd16_kernel<320, 1024>), dim3(H, B), dim3(1024), 0, stream, Q, ldq, K, ldk, V, ldv, O, ldo, dO, lddo,
-                         key_mask, lse, delta, dQ, lddq, dK, lddk, dV, lddv, H, Sq, scale);
+                         key_mask, lse, delta, dQ, lddq, dK, lddk, dV, lddv, H, Sq, scale, QKV16, ld16);
   }
   return avlen_launch_status();
 }

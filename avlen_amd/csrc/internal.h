@@ -99,6 +99,11 @@ int avlen_attention_qkv16(const void* QKV16, int ld, void* O16, int ldo16, int B
 int avlen_attention_smt16(const void* QKV16, int ld, void* O16, int ldo16, int B, int H, int S, float scale,
                           const float* key_mask, const int* seg_off, hipStream_t stream, long qkv_lo = 0, long o_lo = 0,
                           float* O32 = nullptr, int ldo32 = 0, float* lse = nullptr);   // training forward: fp32 output + row log-sum-exp
+// avlen_attention_bwd_bf16 with q | k | v taken from the packed bf16 projection the forward kept (QKV16 [R][ld16]; Q, K, V unused)
+int avlen_attention_bwd_p16(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* O, int ldo,
+                            const float* dO, int lddo, const float* key_mask, const float* lse, float* delta, float* dQ, int lddq,
+                            float* dK, int lddk, float* dV, int lddv, int B, int H, int Sq, int Sk, int D, int causal, float scale,
+                            hipStream_t stream, const void* QKV16, int ld16);
 int avlen_attention_q1(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, void* O16, int ldo16, int B,
                        int H, int Sk, float scale, const float* key_mask, const int* seg_off, hipStream_t stream, long o_lo = 0);
 int avlen_gemm_bf16_dyn(const void* A, int lda, const void* B, int ldb, float* C32, int ldc32, void* C16, int ldc16,

@@ -86,9 +86,12 @@ int tcast(const Ctx& c, const float* src, int ld, bf16* dst, long ldt, long R, i
 // [M][Np] of dX = dY W (columns N .. Np-1 zero), the transposed operand [N][Mp] of dW = dY^T X (columns M .. Mp-1 zero) -- both with
 // the low plane of the compensated pair `*_lo` elements behind the high one when NP == 2 -- and the column sums (bias gradient,
 // added to `colsum`).  Replaces cast_pair + tcast + colsum_acc, i.e. three reads of dY (the 2nd-stage update's dY are 0.7 GB each).
+// relu16 (optional, row stride ldr): dY is the gradient w.r.t. a ReLU's OUTPUT y and relu16 holds y as 16-bit values: elements with
+// y <= 0 are taken as zero (the separate relu' pass over the fp32 gradient is skipped).
 template <int NP>
 __global__ __launch_bounds__(256) void dy_prep_kernel(const float* __restrict__ src, int ld, bf16* __restrict__ rows16, int Np, long rows_lo,
-                                                      bf16* __restrict__ t16, long Mp, long t_lo, float* __restrict__ colsum, long M, int N, int tiles) {
+                                                      bf16* __restrict__ t16, long Mp, long t_lo, float* __restrict__ colsum, long M, int N, int tiles,
+                                                      const bf16* __restrict__ relu16 = nullptr, int ldr = 0) {
   __shared__ float t[64][65];
   const int c0 = blockIdx.y * 64;
   const int tid = threadIdx.x;
@@ -105,6 +108,13 @@ __global__ __launch_bounds__(256) void dy_prep_kernel(const float* __restrict__ 
       if (r < M) {
         if (cc + 4 <= N) v = *reinterpret_cast<const float4*>(src + r * ld + cc);
         else { if (cc < N) v.x = src[r * ld + cc]; if (cc + 1 < N) v.y = src[r * ld + cc + 1]; if (cc + 2 < N) v.z = src[r * ld + cc + 2]; }
+        if (relu16) {
+          const bf16* y = relu16 + r * ldr + cc;
+          if (cc < N && (float)y[0] <= 0.f) v.x = 0.f;
+          if (cc + 1 < N && (float)y[1] <= 0.f) v.y = 0.f;
+          if (cc + 2 < N && (float)y[2] <= 0.f) v.z = 0.f;
+          if (cc + 3 < N && (float)y[3] <= 0.f) v.w = 0.f;
+        }
       }
       t[row][c4] = v.x; t[row][c4 + 1] = v.y; t[row][c4 + 2] = v.z; t[row][c4 + 3] = v.w;
     }
@@ -237,7 +247,8 @@ int colsum_acc(const Ctx& c, const float* dY, int ld, float* out, int rows, int 
 // four operands at a time -- the three separate steps, in the order the call sites always used.
 // X16 (optional): the forward already holds X as a row-major 16-bit operand (row stride ldx16 >= pad8(in_f), pad columns zero).
 int linear_bwd(const Ctx& c, const avlen_linear& L, const avlen_linear& G, const float* dY, int ldy, const float* X, int ldx, float* dX,
-               int lddx, int M, const float* add, int ldadd, const bf16* X16 = nullptr, int ldx16 = 0) {
+               int lddx, int M, const float* add, int ldadd, const bf16* X16 = nullptr, int ldx16 = 0, const bf16* relu16 = nullptr,
+               int ldr = 0) {     // relu16: dY still has to pass the ReLU whose 16-bit output this is (see dy_prep_kernel)
   if (big_path(c, M) && !(ldy & 3) && !((uintptr_t)dY & 15) && fused_dy_on()) {
     const int Np = pad8(L.out_f);
     const long Mp = pad8(M);
@@ -254,7 +265,8 @@ int linear_bwd(const Ctx& c, const avlen_linear& L, const avlen_linear& G, const
         const long rt = (Mp + 63) / 64;
         const int tiles = (int)(rt / 64 < 1 ? 1 : (rt / 64 > 16 ? 16 : rt / 64));
         const dim3 grid((unsigned)((rt + tiles - 1) / tiles), ceil_div(L.out_f, 64));
-        hipLaunchKernelGGL(dy_prep_kernel<1>, grid, dim3(256), 0, c.st, dY, ldy, dY16, Np, 0L, (bf16*)nullptr, Mp, 0L, G.b, (long)M, L.out_f, tiles);
+        hipLaunchKernelGGL(dy_prep_kernel<1>, grid, dim3(256), 0, c.st, dY, ldy, dY16, Np, 0L, (bf16*)nullptr, Mp, 0L, G.b, (long)M, L.out_f, tiles,
+                           relu16, ldr);
         TRY(avlen_launch_status());
         if (!have_x) TRY(cast_pair(c, X, ldx, Xc, Kp, M, L.in_f, 0));
         TRY(avlen_i_gemm_tn_bf16(dY16, Np, have_x ? X16 : Xc, have_x ? ldx16 : Kp, M, L.out_f, L.in_f, G.w, L.in_f, 1.f, c.gws, c.gws_bytes,
@@ -264,7 +276,7 @@ int linear_bwd(const Ctx& c, const avlen_linear& L, const avlen_linear& G, const
         return big_gemm(c, dY16, Np, 0, WT16, Np, 0, dX, lddx, nullptr, add, ldadd, M, L.in_f, Np, 0);
       }
     }
-    if (X16) return AVLEN_ERR_WS;
+    if (X16 || relu16) return AVLEN_ERR_WS;
     XsBump b(c);
     bf16* dY16 = dX ? b.take((size_t)np * M * Np) : nullptr;
     bf16* dYT = b.take((size_t)np * L.out_f * Mp); bf16* XT = b.take((size_t)np * L.in_f * Mp);
@@ -286,7 +298,7 @@ int linear_bwd(const Ctx& c, const avlen_linear& L, const avlen_linear& G, const
       return big_gemm(c, dY16, Np, yl, WT16, Np, wl, dX, lddx, nullptr, add, ldadd, M, L.in_f, Np, 0);
     }
   }
-  if (X16) return AVLEN_ERR_WS;        // the caller kept X only as a 16-bit plane: that route (above) must have been taken
+  if (X16 || relu16) return AVLEN_ERR_WS;        // the caller kept X only as a 16-bit plane: that route (above) must have been taken
   TRY(linear_dw(c, G, dY, ldy, X, ldx, M));
   TRY(colsum_acc(c, dY, ldy, G.b, M, L.out_f));
   return dX ? linear_dx(c, L, dY, ldy, dX, lddx, M, add, ldadd) : AVLEN_OK;
@@ -401,7 +413,10 @@ namespace {
 __global__ void smt_build_kernel(const float* __restrict__ x, const float* __restrict__ memory,
                                  const int32_t* __restrict__ mem_index, int NC, const float* __restrict__ masks, const float* __restrict__ pw,
                                  const float* __restrict__ pb, float* __restrict__ XF, int ldxf, float* __restrict__ FMT,
-                                 float* __restrict__ maskx, int B, int M, int F, int pc, int cto) {
+                                 float* __restrict__ maskx, int B, int M, int F, int pc, int cto,
+                                 bf16* __restrict__ XF16 = nullptr, int ld16 = 0, long lo16 = 0) {
+  // XF16 (training forward at scale): the row as the 16-bit operand of the first product (hi plane; lo plane lo16 elements behind when
+  // lo16 != 0; columns F + 12 .. ld16 - 1 zero); XF may then be null
   const int S = cto ? 1 : M + 1;
   const int row = blockIdx.x;                 // b * S + s
   const int b = row / S, s = cto ? M : row % S;
@@ -424,8 +439,10 @@ __global__ void smt_build_kernel(const float* __restrict__ x, const float* __res
     if (maskx) maskx[(long)b * S + (cto ? 0 : s)] = (s < M) ? masks[(long)b * M + s] : 1.f;
   }
   __syncthreads();
-  float* o = XF + (long)row * ldxf;
-  for (int i = t; i < F + 12; i += blockDim.x) {
+  float* o = XF ? XF + (long)row * ldxf : nullptr;
+  bf16* o16 = XF16 ? XF16 + (long)row * ld16 : nullptr;
+  const int ncol = XF16 && ld16 > F + 12 ? ld16 : F + 12;
+  for (int i = t; i < ncol; i += blockDim.x) {
     float v;
     if (i < pc) v = src[i];
     else if (i < pc + 16) {
@@ -433,23 +450,52 @@ __global__ void smt_build_kernel(const float* __restrict__ x, const float* __res
       v = pb[j];
 #pragma unroll
       for (int k = 0; k < 5; k++) v += pw[j * 5 + k] * fmt[k];
-    } else v = src[i - 12];
-    o[i] = v;
+    } else if (i < F + 12) v = src[i - 12];
+    else v = 0.f;
+    if (o && i < F + 12) o[i] = v;
+    if (o16) {
+      const bf16 hv = (bf16)v;
+      o16[i] = hv;
+      if (lo16) o16[lo16 + i] = (bf16)(v - (float)hv);
+    }
   }
   if (FMT && t < 5) FMT[(long)row * 8 + t] = fmt[t];
 }
 
 // dW_pose[16][5] += dPE^T FMT ; db_pose[16] += colsum(dPE)    (dPE: [R,16], FMT: [R,8])
-__global__ void pose_grad_kernel(const float* __restrict__ dPE, const float* __restrict__ FMT, float* __restrict__ gw,
-                                 float* __restrict__ gb, long R, int rows_per_block) {
-  __shared__ float acc[96];
-  const int t = threadIdx.x;            // 96 threads: t<80 -> (j=t/5,k=t%5) weight grads, t>=80 -> bias j=t-80
-  long r0 = (long)blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
-  float s = 0.f;
-  if (t < 80) { int j = t / 5, k = t % 5; for (long r = r0; r < r1; r++) s += dPE[r * 16 + j] * FMT[r * 8 + k]; }
-  else if (t < 96) { int j = t - 80; for (long r = r0; r < r1; r++) s += dPE[r * 16 + j]; }
-  (void)acc;
-  if (t < 80) atomicAdd(&gw[t], s); else if (t < 96) atomicAdd(&gb[t - 80], s);
+// A thread takes whole rows (64 + 32 contiguous bytes each), keeps the 96 sums in registers; one wave reduction + 96 atomics per
+// block.  (Until round 5: 96 threads, one output each, striding through the rows -- 0.8 ms per call at 722 k rows.)
+__global__ __launch_bounds__(256) void pose_grad_kernel(const float* __restrict__ dPE, const float* __restrict__ FMT, float* __restrict__ gw,
+                                                        float* __restrict__ gb, long R, int rows_per_block) {
+  __shared__ float red[4][96];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
+  float acc[96];
+#pragma unroll
+  for (int i = 0; i < 96; i++) acc[i] = 0.f;
+  for (long r = r0 + t; r < r1; r += 256) {
+    float pe[16], f[8];
+#pragma unroll
+    for (int u = 0; u < 4; u++) *reinterpret_cast<float4*>(&pe[4 * u]) = *reinterpret_cast<const float4*>(dPE + r * 16 + 4 * u);
+#pragma unroll
+    for (int u = 0; u < 2; u++) *reinterpret_cast<float4*>(&f[4 * u]) = *reinterpret_cast<const float4*>(FMT + r * 8 + 4 * u);
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+#pragma unroll
+      for (int k = 0; k < 5; k++) acc[j * 5 + k] += pe[j] * f[k];
+      acc[80 + j] += pe[j];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 96; i++) {
+    const float v = wave_sum(acc[i]);
+    if (lane == 0) red[wave][i] = v;
+  }
+  __syncthreads();
+  if (t < 96) {
+    const float v = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+    if (t < 80) atomicAdd(&gw[t], v); else atomicAdd(&gb[t - 80], v);
+  }
 }
 
 // dialog sequence rows: seq[b, s, :] = [ (s<M ? memory_state[s,b,:] : x_att[b,:]) | d_emb[b,:] (optional) ]
@@ -1457,9 +1503,9 @@ int transformer_bwd(const Ctx& c, const avlen_transformer& tr, const avlen_trans
   float* dF1 = s.dD; float* dX1 = s.dE;
   TRY(linear_bwd(c, e.lin2, ge.lin2, dT2, d, t.F1, e.lin1.out_f, dF1, e.lin1.out_f, (int)R, nullptr, 0, h16 ? h16->F1 : nullptr,
                  e.lin1.out_f));
-  if (h16) TRY(relu_bwd16(c, dF1, h16->F1, R * e.lin1.out_f));
-  else TRY(relu_bwd(c, dF1, t.F1, R * e.lin1.out_f));
-  TRY(linear_bwd(c, e.lin1, ge.lin1, dF1, e.lin1.out_f, t.X1, d, dX1, d, (int)R, dT2, d, h16 ? h16->X1 : nullptr, d));   // dX1 = dT2 + dF1 W1
+  if (!h16) TRY(relu_bwd(c, dF1, t.F1, R * e.lin1.out_f));          // (h16: relu' is applied where dF1 is cast for its two products)
+  TRY(linear_bwd(c, e.lin1, ge.lin1, dF1, e.lin1.out_f, t.X1, d, dX1, d, (int)R, dT2, d, h16 ? h16->X1 : nullptr, d,
+                 h16 ? h16->F1 : nullptr, e.lin1.out_f));                                            // dX1 = dT2 + dF1 W1
   // ---- encoder: norm1, self attention
   float* dT1 = s.dB;
   TRY(avlen_layernorm_bwd(dX1, t.T1, e.norm1.g, t.m1, t.r1, dT1, ge.norm1.g, ge.norm1.b, (int)R, d, c.st));
@@ -1473,7 +1519,12 @@ int transformer_bwd(const Ctx& c, const avlen_transformer& tr, const avlen_trans
     float* dQKV = s.dA;
     // bf16 mode: the matrix-core backward (P / dS in registers); shapes outside its envelope take the fp32 kernels
     int rc = AVLEN_ERR_ARG;
-    if (c.prec == AVLEN_PREC_BF16 && attn_bwd16_on())
+    if (h16) {
+      if (c.prec != AVLEN_PREC_BF16) return AVLEN_ERR_ARG;
+      TRY(avlen_attention_bwd_p16(nullptr, 0, nullptr, 0, nullptr, 0, t.AO, d, dAO, d, maskx, t.LSE, s.delta, dQKV, 3 * d, dQKV + d, 3 * d,
+                                  dQKV + 2 * d, 3 * d, B, H, S, S, D, 0, scale, c.st, h16->QKV, 3 * d));
+      rc = AVLEN_OK;
+    } else if (c.prec == AVLEN_PREC_BF16 && attn_bwd16_on())
       rc = avlen_attention_bwd_bf16(t.QKV, 3 * d, t.QKV + d, 3 * d, t.QKV + 2 * d, 3 * d, t.AO, d, dAO, d, maskx, t.LSE, s.delta,
                                     dQKV, 3 * d, dQKV + d, 3 * d, dQKV + 2 * d, 3 * d, B, H, S, S, D, 0, scale, c.st);
     if (rc == AVLEN_ERR_ARG)
@@ -1550,11 +1601,10 @@ int smt_fwd_big16(const Ctx& c, const avlen_smt* p, SmtWs& s, const float* goal,
   const bool x3 = c.prec == AVLEN_PREC_BF16X3;
   Big16& h = s.h; TrWs& t = s.tr;
   const long lx = x3 ? R * h.ldxf : 0, l1 = x3 ? R * d : 0, l3 = x3 ? R * 3 * d : 0, lf = x3 ? R * ff : 0;      // hi -> lo plane
-  if (x3) TRY(cast_pair(c, s.XF, s.ldxf, h.XF, h.ldxf, R, p->fus0.in_f, lx));
-  else TRY(avlen_cast_h16(s.XF, s.ldxf, h.XF, h.ldxf, R, p->fus0.in_f, 0, c.st));
   TRY(linear16t(c, p->fus0, 0, d, h.XF, h.ldxf, lx, nullptr, 0, h.H1, d, l1, R, AVLEN_ACT_RELU, nullptr, 0));
   TRY(linear16t(c, p->fus2, 0, d, h.H1, d, l1, s.Z, d, h.Z, d, l1, R, 0, nullptr, 0));
-  TRY(linear16t(c, e.self_attn.in_proj, 0, 3 * d, h.Z, d, l1, t.QKV, 3 * d, h.QKV, 3 * d, l3, R, 0, nullptr, 0));
+  TRY(linear16t(c, e.self_attn.in_proj, 0, 3 * d, h.Z, d, l1, nullptr, 0, h.QKV, 3 * d, l3, R, 0, nullptr, 0));   // (no fp32 q | k | v: the backward
+  // stages the hi plane -- the bf16 values it would round the fp32 ones to)
   TRY(avlen_attention_smt16(h.QKV, 3 * d, h.AO, d, B, H, S, scale, s.maskx, nullptr, c.st, l3, l1, t.AO, d, t.LSE));
   TRY(linear16t(c, e.self_attn.out_proj, 0, d, h.AO, d, l1, t.T1, d, nullptr, 0, 0, R, 0, s.Z, d));
   TRY(avlen_layernorm_fwd16_dyn(t.T1, nullptr, e.norm1.g, e.norm1.b, t.X1, h.X1, t.m1, t.r1, (int)R, nullptr, d, 1e-5f, c.st, l1));
@@ -1901,10 +1951,16 @@ extern "C" int avlen_smt_fwd(const avlen_smt* p, const float* x, const float* me
   const int S = cto ? 1 : M + 1, d = p->tr.d;
   const long R = (long)B * S;
   if (!mem_index) NC = B;
+  if (save_for_backward && big16_on(p, s, prec, R, S, cto != 0)) {       // the fusion input straight into its operand planes
+    hipLaunchKernelGGL(smt_build_kernel, dim3((unsigned)R), dim3(128), 0, st, x, memory, mem_index, NC, masks, p->pose.w, p->pose.b,
+                       (float*)nullptr, s.ldxf, s.FMT, s.maskx, B, M, F, pose_col, cto, s.h.XF, s.h.ldxf,
+                       prec == AVLEN_PREC_BF16X3 ? R * s.h.ldxf : 0L);
+    TRY(avlen_launch_status());
+    return smt_fwd_big16(c, p, s, goal, out, B, S);
+  }
   hipLaunchKernelGGL(smt_build_kernel, dim3((unsigned)R), dim3(128), 0, st, x, memory, mem_index, NC, masks, p->pose.w, p->pose.b, s.XF,
                      s.ldxf, s.FMT, s.maskx, B, M, F, pose_col, cto);
   TRY(avlen_launch_status());
-  if (save_for_backward && big16_on(p, s, prec, R, S, cto != 0)) return smt_fwd_big16(c, p, s, goal, out, B, S);
   TRY(linear(c, p->fus0, s.XF, s.ldxf, s.H1, d, (int)R, AVLEN_ACT_RELU, nullptr, 0));
   TRY(linear(c, p->fus2, s.H1, d, s.Z, d, (int)R, 0, nullptr, 0));
   return transformer_fwd(c, p->tr, s.tr, s.Z, s.maskx, goal, out, B, S, cto != 0);
@@ -1950,7 +2006,7 @@ extern "C" int avlen_smt_bwd(const avlen_smt* p, const avlen_smt* g, const float
   TRY(avlen_gemm(s.dH1, d, 0, p->fus0.w + pose_col, p->fus0.in_f, 1, s.dPE, 16, nullptr, nullptr, 0, (int)R, 16, d, 0,
                  c.prec, 1, 0.f, s.gws, GEMM_SCRATCH, st));
   int rpb = R >= 65536 ? 2048 : 256;
-  hipLaunchKernelGGL(pose_grad_kernel, dim3((unsigned)((R + rpb - 1) / rpb)), dim3(96), 0, st, s.dPE, s.FMT, g->pose.w,
+  hipLaunchKernelGGL(pose_grad_kernel, dim3((unsigned)((R + rpb - 1) / rpb)), dim3(256), 0, st, s.dPE, s.FMT, g->pose.w,
                      g->pose.b, R, rpb);
   if (d_x) {
     // gradient w.r.t. the CURRENT observation's features (pi_l under update_dialog: the encoders are trained through it; the
