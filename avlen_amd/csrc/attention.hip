@@ -885,7 +885,11 @@ __global__ __launch_bounds__(NTH) void attn_bwd16_kernel(const float* __restrict
                                                          const float* __restrict__ key_mask, const float* __restrict__ lse,
                                                          float* __restrict__ delta, float* __restrict__ dQ, int lddq,
                                                          float* __restrict__ dK, int lddk, float* __restrict__ dV, int lddv, int H,
-                                                         int S, float scale, const __bf16* __restrict__ QKV16, int ld16) {
+                                                         int S, float scale, const __bf16* __restrict__ QKV16, int ld16,
+                                                         __bf16* __restrict__ dQKV16, int ldd16, float* __restrict__ colsum) {
+  // dQKV16 (optional): the gradients ALSO as the packed bf16 rows [R][ldd16] (dq | dk | dv at columns 0 | H*32 | 2*H*32) -- the row-major
+  // operand of the in-projection's backward -- and their column sums added to colsum[3*H*32] (its bias gradient); dQ / dK / dV may
+  // then be null.  Saves the fp32 round trip of the 3d-wide gradient and the cast pass over it.
   // QKV16 (optional): q | k | v as the packed bf16 projection [R][ld16] (columns 0 | H*32 | 2*H*32) the forward kept -- the same
   // values the fp32 -> bf16 staging below produces, without the fp32 copy (Q, K, V may then be null)
   constexpr int D = 32, KR = 48;                    // 96-byte LDS rows: conflict-free for both read kinds (as attn_smt16_kernel)
@@ -894,10 +898,14 @@ __global__ __launch_bounds__(NTH) void attn_bwd16_kernel(const float* __restrict
   __shared__ __attribute__((aligned(16))) __bf16 vs[SKP * KR];
   __shared__ __attribute__((aligned(16))) __bf16 gs[SKP * KR];
   __shared__ float km[SKP], s_lse[SKP], s_del[SKP];
+  __shared__ float cred[NTH / 64][96];             // per-wave column sums of dq | dk | dv (this head's 32 dims each)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, q4 = lane >> 4;
   const int h = blockIdx.x, b = blockIdx.y;
   const long row0 = (long)b * S;
   const int S32 = (S + 31) & ~31;                   // rows S .. S32-1 are zero
+  af32x4 csq[2], csk[2], csv[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; dt++) { csq[dt] = (af32x4){0.f, 0.f, 0.f, 0.f}; csk[dt] = csq[dt]; csv[dt] = csq[dt]; }
   // ---- stage: 4 x 32-byte chunks (8 floats) per row and tensor; delta from the fp32 dO and O of the same chunk
   for (int i = tid; i < S32 * 4; i += NTH) {
     const int r = i >> 2, c = i & 3;
@@ -1019,10 +1027,23 @@ __global__ __launch_bounds__(NTH) void attn_bwd16_kernel(const float* __restrict
       }
     }
     if (qok) {
-      float* oq = dQ + (row0 + qi) * lddq + h * D + q4 * 4;
+      if (dQ) {
+        float* oq = dQ + (row0 + qi) * lddq + h * D + q4 * 4;
 #pragma unroll
-      for (int dt = 0; dt < 2; dt++)
-        *reinterpret_cast<float4*>(oq + dt * 16) = make_float4(dqa[dt][0], dqa[dt][1], dqa[dt][2], dqa[dt][3]);
+        for (int dt = 0; dt < 2; dt++)
+          *reinterpret_cast<float4*>(oq + dt * 16) = make_float4(dqa[dt][0], dqa[dt][1], dqa[dt][2], dqa[dt][3]);
+      }
+      if (dQKV16) {
+        __bf16* o16 = dQKV16 + (row0 + qi) * ldd16 + h * D + q4 * 4;
+#pragma unroll
+        for (int dt = 0; dt < 2; dt++) {
+          abf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; r++) o[r] = (__bf16)dqa[dt][r];
+          *reinterpret_cast<abf16x4*>(o16 + dt * 16) = o;
+          csq[dt] += dqa[dt];
+        }
+      }
     }
   }
   __syncthreads();
@@ -1078,13 +1099,48 @@ __global__ __launch_bounds__(NTH) void attn_bwd16_kernel(const float* __restrict
       }
     }
     if (key < S) {
-      float* ov = dV + (row0 + key) * lddv + h * D + q4 * 4;
-      float* ok = dK + (row0 + key) * lddk + h * D + q4 * 4;
+      if (dV) {
+        float* ov = dV + (row0 + key) * lddv + h * D + q4 * 4;
+        float* ok = dK + (row0 + key) * lddk + h * D + q4 * 4;
 #pragma unroll
-      for (int dt = 0; dt < 2; dt++) {
-        *reinterpret_cast<float4*>(ov + dt * 16) = make_float4(dva[dt][0], dva[dt][1], dva[dt][2], dva[dt][3]);
-        *reinterpret_cast<float4*>(ok + dt * 16) = make_float4(dka[dt][0], dka[dt][1], dka[dt][2], dka[dt][3]);
+        for (int dt = 0; dt < 2; dt++) {
+          *reinterpret_cast<float4*>(ov + dt * 16) = make_float4(dva[dt][0], dva[dt][1], dva[dt][2], dva[dt][3]);
+          *reinterpret_cast<float4*>(ok + dt * 16) = make_float4(dka[dt][0], dka[dt][1], dka[dt][2], dka[dt][3]);
+        }
       }
+      if (dQKV16) {
+        __bf16* o16 = dQKV16 + (row0 + key) * ldd16 + h * D + q4 * 4;
+#pragma unroll
+        for (int dt = 0; dt < 2; dt++) {
+          abf16x4 ok16, ov16;
+#pragma unroll
+          for (int r = 0; r < 4; r++) { ok16[r] = (__bf16)dka[dt][r]; ov16[r] = (__bf16)dva[dt][r]; }
+          *reinterpret_cast<abf16x4*>(o16 + H * D + dt * 16) = ok16;
+          *reinterpret_cast<abf16x4*>(o16 + 2 * H * D + dt * 16) = ov16;
+          csk[dt] += dka[dt]; csv[dt] += dva[dt];
+        }
+      }
+    }
+  }
+  if (colsum) {      // (uniform) column sums: over the 16 rows of a lane group, the waves, then one atomic per column and block
+#pragma unroll
+    for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        float a = csq[dt][r], bb = csk[dt][r], cc = csv[dt][r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); bb += __shfl_xor(bb, o, 64); cc += __shfl_xor(cc, o, 64); }
+        if (r16 == 0) {
+          const int dim = dt * 16 + q4 * 4 + r;
+          cred[wave][dim] = a; cred[wave][32 + dim] = bb; cred[wave][64 + dim] = cc;
+        }
+      }
+    __syncthreads();
+    if (tid < 96) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < NTH / 64; w++) v += cred[w][tid];
+      atomicAdd(&colsum[(tid >> 5) * H * D + h * D + (tid & 31)], v);
     }
   }
 }
@@ -1104,32 +1160,36 @@ extern "C" int avlen_attention_bwd_bf16(const float* Q, int ldq, const float* K,
                                         int lddv, int B, int H, int Sq, int Sk, int D, int causal, float scale,
                                         hipStream_t stream) {
   return avlen_attention_bwd_p16(Q, ldq, K, ldk, V, ldv, O, ldo, dO, lddo, key_mask, lse, delta, dQ, lddq, dK, lddk, dV, lddv, B, H, Sq, Sk,
-                                 D, causal, scale, stream, nullptr, 0);
+                                 D, causal, scale, stream, nullptr, 0, nullptr, 0, nullptr);
 }
 int avlen_attention_bwd_p16(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
                             const float* O, int ldo, const float* dO, int lddo, const float* key_mask,
                             const float* lse, float* delta, float* dQ, int lddq, float* dK, int lddk, float* dV,
                             int lddv, int B, int H, int Sq, int Sk, int D, int causal, float scale,
-                            hipStream_t stream, const void* QKV16_, int ld16) {
+                            hipStream_t stream, const void* QKV16_, int ld16, void* dQKV16_, int ldd16, float* colsum) {
   const __bf16* QKV16 = (const __bf16*)QKV16_;
-  if (B <= 0 || H <= 0 || Sq != Sk || Sq <= 0 || Sq > 320 || D != 32 || causal || ((ldo | lddo | lddq | lddk | lddv) & 3))
+  __bf16* dQKV16 = (__bf16*)dQKV16_;
+  if (B <= 0 || H <= 0 || Sq != Sk || Sq <= 0 || Sq > 320 || D != 32 || causal || ((ldo | lddo) & 3))
     return AVLEN_ERR_ARG;
+  if (dQKV16 ? ((ldd16 & 3) || ((uintptr_t)dQKV16 & 7) || !colsum) : (!dQ || !dK || !dV || colsum)) return AVLEN_ERR_ARG;
+  if (dQ && ((lddq | lddk | lddv) & 3)) return AVLEN_ERR_ARG;
+  if ((dQ != nullptr) != (dV != nullptr) || (dQ != nullptr) != (dK != nullptr)) return AVLEN_ERR_ARG;
   if (QKV16 ? ((ld16 & 7) || ((uintptr_t)QKV16 & 15)) : ((ldq | ldk | ldv) & 3) != 0) return AVLEN_ERR_ARG;
   if (Sq <= 160)
     hipLaunchKernelGGL((attn_bwd16_kernel<160, 256>), dim3(H, B), dim3(256), 0, stream, Q, ldq, K, ldk, V, ldv, O, ldo, dO, lddo, key_mask, lse,
-                       delta, dQ, lddq, dK, lddk, dV, lddv, H, Sq, scale, QKV16, ld16);
+                       delta, dQ, lddq, dK, lddk, dV, lddv, H, Sq, scale, QKV16, ld16, dQKV16, ldd16, colsum);
   else {
     static int nth = -1;                           // AVLEN_ATTN_BWD16_THREADS=256|512|1024 (A/B knob)
     if (nth < 0) nth = (int)avlen_knob("AVLEN_ATTN_BWD16_THREADS", 1024);
     if (nth == 256)
       hipLaunchKernelGGL((attn_bwd16_kernel<320, 256>), dim3(H, B), dim3(256), 0, stream, Q, ldq, K, ldk, V, ldv, O, ldo, dO, lddo, key_mask,
-                         lse, delta, dQ, lddq, dK, lddk, dV, lddv, H, Sq, scale, QKV16, ld16);
+                         lse, delta, dQ, lddq, dK, lddk, dV, lddv, H, Sq, scale, QKV16, ld16, dQKV16, ldd16, colsum);
     else if (nth == 512)
       hipLaunchKernelGGL((attn_bwd16_kernel<320, 512>), dim3(H, B), dim3(512), 0, stream, Q, ldq, K, ldk, V, ldv, O, ldo, dO, lddo, key_mask,
-                         lse, delta, dQ, lddq, dK, lddk, dV, lddv, H, Sq, scale, QKV16, ld16);
+                         lse, delta, dQ, lddq, dK, lddk, dV, lddv, H, Sq, scale, QKV16, ld16, dQKV16, ldd16, colsum);
     else      // 16 waves: measured 9.2 / 5.6 / 4.0 ms for 256 / 512 / 1024 threads at 2400 x 8 heads x 301 tokens (fp32 kernels: 17 ms)
       hipLaunchKernelGGL((attn_bwd16_kernel<320, 1024>), dim3(H, B), dim3(1024), 0, stream, Q, ldq, K, ldk, V, ldv, O, ldo, dO, lddo,
-                         key_mask, lse, delta, dQ, lddq, dK, lddk, dV, lddv, H, Sq, scale, QKV16, ld16);
+                         key_mask, lse, delta, dQ, lddq, dK, lddk, dV, lddv, H, Sq, scale, QKV16, ld16, dQKV16, ldd16, colsum);
   }
   return avlen_launch_status();
 }

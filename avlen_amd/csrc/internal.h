@@ -57,6 +57,9 @@ int avlen_groupnorm_nhwc_ws(const float* x, const float* gamma, const float* bet
 extern "C" size_t avlen_groupnorm_workspace_bytes(int B, int C);
 int avlen_groupnorm_apply_bf16(const float* x, const float* stats, const float* gamma, const float* beta, const void* res16,
                                void* y16, int B, int HW, int C, int G, int relu, float eps, hipStream_t stream);
+// avlen_layernorm_bwd that also leaves dx as bf16 rows [rows][d] (dx16) and adds its column sums to colsum[d] (both or neither)
+int avlen_layernorm_bwd16(const float* dy, const float* xsum, const float* gamma, const float* mean, const float* rstd, float* dx,
+                          float* dgamma, float* dbeta, int rows, int d, hipStream_t stream, void* dx16, float* colsum);
 int avlen_layernorm_fwd16(const float* x, const float* residual, const float* gamma, const float* beta, float* y,
                           void* y16, float* mean, float* rstd, int rows, int d, float eps, hipStream_t stream);
 int avlen_attention_fwd16(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
@@ -103,7 +106,8 @@ int avlen_attention_smt16(const void* QKV16, int ld, void* O16, int ldo16, int B
 int avlen_attention_bwd_p16(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* O, int ldo,
                             const float* dO, int lddo, const float* key_mask, const float* lse, float* delta, float* dQ, int lddq,
                             float* dK, int lddk, float* dV, int lddv, int B, int H, int Sq, int Sk, int D, int causal, float scale,
-                            hipStream_t stream, const void* QKV16, int ld16);
+                            hipStream_t stream, const void* QKV16, int ld16, void* dQKV16 = nullptr, int ldd16 = 0,
+                            float* colsum = nullptr);     // dQKV16: packed bf16 gradient rows + column sums instead of / beside fp32
 int avlen_attention_q1(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, void* O16, int ldo16, int B,
                        int H, int Sk, float scale, const float* key_mask, const int* seg_off, hipStream_t stream, long o_lo = 0);
 int avlen_gemm_bf16_dyn(const void* A, int lda, const void* B, int ldb, float* C32, int ldc32, void* C16, int ldc16,

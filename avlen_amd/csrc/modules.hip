@@ -174,6 +174,8 @@ struct XsBump {        // carve 256-byte aligned pieces out of the operand scrat
     return (bf16*)(base + o);
   }
 };
+// where linear_bwd's row-major dY operand will live (its first carve): a producer may write it there directly
+bf16* dy16_slot(const Ctx& c) { XsBump b(c); return b.take(8); }
 bool big_path(const Ctx& c, long M) { return (c.prec == AVLEN_PREC_BF16 || c.prec == AVLEN_PREC_BF16X3) && c.xs && M >= big_m(); }
 
 // Y[M, out_f] (ldy) = act(X[M, in_f] (ldx) * W^T + b) + res
@@ -248,7 +250,9 @@ int colsum_acc(const Ctx& c, const float* dY, int ld, float* out, int rows, int 
 // X16 (optional): the forward already holds X as a row-major 16-bit operand (row stride ldx16 >= pad8(in_f), pad columns zero).
 int linear_bwd(const Ctx& c, const avlen_linear& L, const avlen_linear& G, const float* dY, int ldy, const float* X, int ldx, float* dX,
                int lddx, int M, const float* add, int ldadd, const bf16* X16 = nullptr, int ldx16 = 0, const bf16* relu16 = nullptr,
-               int ldr = 0) {     // relu16: dY still has to pass the ReLU whose 16-bit output this is (see dy_prep_kernel)
+               int ldr = 0, bool dy16_ready = false) {     // relu16: dY still has to pass the ReLU whose 16-bit output this is (see dy_prep_kernel)
+  // dy16_ready: the PRODUCER of dY already left its row-major 16-bit operand [M][pad8(out_f)] at the head of the operand scratch
+  // (dy16_slot) and added the column sums to G.b; dY (fp32) is not read
   if (big_path(c, M) && !(ldy & 3) && !((uintptr_t)dY & 15) && fused_dy_on()) {
     const int Np = pad8(L.out_f);
     const long Mp = pad8(M);
@@ -265,9 +269,11 @@ int linear_bwd(const Ctx& c, const avlen_linear& L, const avlen_linear& G, const
         const long rt = (Mp + 63) / 64;
         const int tiles = (int)(rt / 64 < 1 ? 1 : (rt / 64 > 16 ? 16 : rt / 64));
         const dim3 grid((unsigned)((rt + tiles - 1) / tiles), ceil_div(L.out_f, 64));
-        hipLaunchKernelGGL(dy_prep_kernel<1>, grid, dim3(256), 0, c.st, dY, ldy, dY16, Np, 0L, (bf16*)nullptr, Mp, 0L, G.b, (long)M, L.out_f, tiles,
-                           relu16, ldr);
-        TRY(avlen_launch_status());
+        if (!dy16_ready) {
+          hipLaunchKernelGGL(dy_prep_kernel<1>, grid, dim3(256), 0, c.st, dY, ldy, dY16, Np, 0L, (bf16*)nullptr, Mp, 0L, G.b, (long)M, L.out_f, tiles,
+                             relu16, ldr);
+          TRY(avlen_launch_status());
+        }
         if (!have_x) TRY(cast_pair(c, X, ldx, Xc, Kp, M, L.in_f, 0));
         TRY(avlen_i_gemm_tn_bf16(dY16, Np, have_x ? X16 : Xc, have_x ? ldx16 : Kp, M, L.out_f, L.in_f, G.w, L.in_f, 1.f, c.gws, c.gws_bytes,
                                  c.st));
@@ -276,7 +282,7 @@ int linear_bwd(const Ctx& c, const avlen_linear& L, const avlen_linear& G, const
         return big_gemm(c, dY16, Np, 0, WT16, Np, 0, dX, lddx, nullptr, add, ldadd, M, L.in_f, Np, 0);
       }
     }
-    if (X16 || relu16) return AVLEN_ERR_WS;
+    if (X16 || relu16 || dy16_ready) return AVLEN_ERR_WS;
     XsBump b(c);
     bf16* dY16 = dX ? b.take((size_t)np * M * Np) : nullptr;
     bf16* dYT = b.take((size_t)np * L.out_f * Mp); bf16* XT = b.take((size_t)np * L.in_f * Mp);
@@ -298,7 +304,7 @@ int linear_bwd(const Ctx& c, const avlen_linear& L, const avlen_linear& G, const
       return big_gemm(c, dY16, Np, yl, WT16, Np, wl, dX, lddx, nullptr, add, ldadd, M, L.in_f, Np, 0);
     }
   }
-  if (X16 || relu16) return AVLEN_ERR_WS;        // the caller kept X only as a 16-bit plane: that route (above) must have been taken
+  if (X16 || relu16 || dy16_ready) return AVLEN_ERR_WS;        // the caller kept X only as a 16-bit plane: that route (above) must have been taken
   TRY(linear_dw(c, G, dY, ldy, X, ldx, M));
   TRY(colsum_acc(c, dY, ldy, G.b, M, L.out_f));
   return dX ? linear_dx(c, L, dY, ldy, dX, lddx, M, add, ldadd) : AVLEN_OK;
@@ -1499,18 +1505,23 @@ int transformer_bwd(const Ctx& c, const avlen_transformer& tr, const avlen_trans
   const avlen_enc_layer& e = tr.enc; const avlen_enc_layer& ge = g.enc;
   float* dX2 = s.dB; float* dT2 = s.dC;
   TRY(avlen_layernorm_bwd(dMEM, t.X2, tr.enc_norm.g, t.me, t.re, dX2, g.enc_norm.g, g.enc_norm.b, (int)R, d, c.st));
-  TRY(avlen_layernorm_bwd(dX2, t.T2, e.norm2.g, t.m2, t.r2, dT2, ge.norm2.g, ge.norm2.b, (int)R, d, c.st));
+  // (h16: the LayerNorm backward leaves its dx also as the next product's bf16 operand + bias gradient -- no cast pass over dT2 / dT1)
+  const bool lnf = h16 != nullptr && c.prec == AVLEN_PREC_BF16 && d % 8 == 0;
+  TRY(avlen_layernorm_bwd16(dX2, t.T2, e.norm2.g, t.m2, t.r2, dT2, ge.norm2.g, ge.norm2.b, (int)R, d, c.st, lnf ? dy16_slot(c) : nullptr,
+                            lnf ? ge.lin2.b : nullptr));
   float* dF1 = s.dD; float* dX1 = s.dE;
   TRY(linear_bwd(c, e.lin2, ge.lin2, dT2, d, t.F1, e.lin1.out_f, dF1, e.lin1.out_f, (int)R, nullptr, 0, h16 ? h16->F1 : nullptr,
-                 e.lin1.out_f));
+                 e.lin1.out_f, nullptr, 0, lnf));
   if (!h16) TRY(relu_bwd(c, dF1, t.F1, R * e.lin1.out_f));          // (h16: relu' is applied where dF1 is cast for its two products)
   TRY(linear_bwd(c, e.lin1, ge.lin1, dF1, e.lin1.out_f, t.X1, d, dX1, d, (int)R, dT2, d, h16 ? h16->X1 : nullptr, d,
                  h16 ? h16->F1 : nullptr, e.lin1.out_f));                                            // dX1 = dT2 + dF1 W1
   // ---- encoder: norm1, self attention
   float* dT1 = s.dB;
-  TRY(avlen_layernorm_bwd(dX1, t.T1, e.norm1.g, t.m1, t.r1, dT1, ge.norm1.g, ge.norm1.b, (int)R, d, c.st));
+  TRY(avlen_layernorm_bwd16(dX1, t.T1, e.norm1.g, t.m1, t.r1, dT1, ge.norm1.g, ge.norm1.b, (int)R, d, c.st, lnf ? dy16_slot(c) : nullptr,
+                            lnf ? ge.self_attn.out_proj.b : nullptr));
   float* dAO = s.dC;
-  TRY(linear_bwd(c, e.self_attn.out_proj, ge.self_attn.out_proj, dT1, d, t.AO, d, dAO, d, (int)R, nullptr, 0, h16 ? h16->AO : nullptr, d));
+  TRY(linear_bwd(c, e.self_attn.out_proj, ge.self_attn.out_proj, dT1, d, t.AO, d, dAO, d, (int)R, nullptr, 0, h16 ? h16->AO : nullptr, d,
+                 nullptr, 0, lnf));
   if (cto) {
     avlen_linear gv = ge.self_attn.in_proj; gv.w += (size_t)2 * d * d; gv.b += 2 * d; gv.out_f = d;
     avlen_linear wv = e.self_attn.in_proj; wv.w += (size_t)2 * d * d; wv.out_f = d;
@@ -1521,9 +1532,11 @@ int transformer_bwd(const Ctx& c, const avlen_transformer& tr, const avlen_trans
     int rc = AVLEN_ERR_ARG;
     if (h16) {
       if (c.prec != AVLEN_PREC_BF16) return AVLEN_ERR_ARG;
-      TRY(avlen_attention_bwd_p16(nullptr, 0, nullptr, 0, nullptr, 0, t.AO, d, dAO, d, maskx, t.LSE, s.delta, dQKV, 3 * d, dQKV + d, 3 * d,
-                                  dQKV + 2 * d, 3 * d, B, H, S, S, D, 0, scale, c.st, h16->QKV, 3 * d));
-      rc = AVLEN_OK;
+      // the 3d-wide gradient goes straight into the in-projection's operand slot as bf16 rows (+ its bias gradient): no fp32 copy
+      TRY(avlen_attention_bwd_p16(nullptr, 0, nullptr, 0, nullptr, 0, t.AO, d, dAO, d, maskx, t.LSE, s.delta, nullptr, 0, nullptr, 0,
+                                  nullptr, 0, B, H, S, S, D, 0, scale, c.st, h16->QKV, 3 * d, dy16_slot(c), 3 * d, ge.self_attn.in_proj.b));
+      return linear_bwd(c, e.self_attn.in_proj, ge.self_attn.in_proj, nullptr, 3 * d, Z, d, dZ, d, (int)R, dT1, d, h16->Z, d, nullptr, 0,
+                        true);                                                                      // dZ = dT1 + dQKV Win
     } else if (c.prec == AVLEN_PREC_BF16 && attn_bwd16_on())
       rc = avlen_attention_bwd_bf16(t.QKV, 3 * d, t.QKV + d, 3 * d, t.QKV + 2 * d, 3 * d, t.AO, d, dAO, d, maskx, t.LSE, s.delta,
                                     dQKV, 3 * d, dQKV + d, 3 * d, dQKV + 2 * d, 3 * d, B, H, S, S, D, 0, scale, c.st);

@@ -240,13 +240,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int rows,
-                                                     int rows_per_block) {
+                                                     int rows_per_block, __bf16* __restrict__ dx16, float* __restrict__ colsum) {
+  // dx16 / colsum (optional, together): dx also as row-major bf16 rows [rows][d] -- the operand of the NEXT Linear's backward -- and
+  // its column sums added to colsum[d] (that Linear's bias gradient): the cast pass over dx is skipped
   constexpr int d = NV * 64;
   __shared__ float sg[4][d], sb[4][d];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  float ag[NV], ab[NV];
+  float ag[NV], ab[NV], ac[NV];
 #pragma unroll
-  for (int i = 0; i < NV; i++) { ag[i] = 0.f; ab[i] = 0.f; }
+  for (int i = 0; i < NV; i++) { ag[i] = 0.f; ab[i] = 0.f; ac[i] = 0.f; }
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(rows, r0 + rows_per_block);
   for (int row = r0 + w; row < r1; row += 4) {
@@ -264,7 +266,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
     s1 = wave_sum(s1) * (1.f / d); s2 = wave_sum(s2) * (1.f / d);
 #pragma unroll
-    for (int i = 0; i < NV; i++) dx[(long)row * d + lane + i * 64] = rs * (g[i] - s1 - xh[i] * s2);
+    for (int i = 0; i < NV; i++) {
+      const float v = rs * (g[i] - s1 - xh[i] * s2);
+      dx[(long)row * d + lane + i * 64] = v;
+      if (dx16) { dx16[(long)row * d + lane + i * 64] = (__bf16)v; ac[i] += v; }
+    }
+  }
+  if (colsum) {
+#pragma unroll
+    for (int i = 0; i < NV; i++) sg[w][lane + i * 64] = ac[i];
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += 256) atomicAdd(&colsum[c], sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c]);
+    __syncthreads();
   }
   if (dgamma) {
 #pragma unroll
@@ -420,12 +433,17 @@ int avlen_groupnorm_apply_bf16(const float* x, const float* stats, const float* 
 extern "C" int avlen_layernorm_bwd(const float* dy, const float* xsum, const float* gamma, const float* mean,
                                    const float* rstd, float* dx, float* dgamma, float* dbeta, int rows, int d,
                                    hipStream_t stream) {
-  if (rows <= 0) return AVLEN_ERR_ARG;
+  return avlen_layernorm_bwd16(dy, xsum, gamma, mean, rstd, dx, dgamma, dbeta, rows, d, stream, nullptr, nullptr);
+}
+int avlen_layernorm_bwd16(const float* dy, const float* xsum, const float* gamma, const float* mean, const float* rstd, float* dx,
+                          float* dgamma, float* dbeta, int rows, int d, hipStream_t stream, void* dx16_, float* colsum) {
+  __bf16* dx16 = (__bf16*)dx16_;
+  if (rows <= 0 || (dx16 != nullptr) != (colsum != nullptr)) return AVLEN_ERR_ARG;
   int rpb = rows >= 65536 ? 256 : rows >= 4096 ? 64 : 16;
   dim3 grid(ceil_div(rows, rpb)), block(256);
   switch (d) {
-    case 256: hipLaunchKernelGGL((ln_bwd_kernel<4>), grid, block, 0, stream, dy, xsum, gamma, mean, rstd, dx, dgamma, dbeta, rows, rpb); break;
-    case 512: hipLaunchKernelGGL((ln_bwd_kernel<8>), grid, block, 0, stream, dy, xsum, gamma, mean, rstd, dx, dgamma, dbeta, rows, rpb); break;
+    case 256: hipLaunchKernelGGL((ln_bwd_kernel<4>), grid, block, 0, stream, dy, xsum, gamma, mean, rstd, dx, dgamma, dbeta, rows, rpb, dx16, colsum); break;
+    case 512: hipLaunchKernelGGL((ln_bwd_kernel<8>), grid, block, 0, stream, dy, xsum, gamma, mean, rstd, dx, dgamma, dbeta, rows, rpb, dx16, colsum); break;
     default: return AVLEN_ERR_ARG;
   }
   return avlen_launch_status();
