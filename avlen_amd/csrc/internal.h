@@ -21,6 +21,16 @@ int avlen_i_linear(const avlen_ctx& c, const avlen_linear& L, const float* X, in
 int avlen_i_linear_dx(const avlen_ctx& c, const avlen_linear& L, const float* dY, int ldy, float* dX, int ldx, int M,
                       const float* add, int ldadd);
 int avlen_i_linear_dw(const avlen_ctx& c, const avlen_linear& G, const float* dY, int ldy, const float* X, int ldx, int M);
+// single-query cross attention in memory space (cross1.hip; d = 256, 8 heads, S <= 320): per-head products against the rows of a
+// [d][d] projection slice, the forward (scores + softmax + weighted memory sum) and the backward (dA, d memory rows)
+bool avlen_i_cross1_ok(int d, int H, int S);
+int avlen_i_cross1_expand(const float* X, int ldx, const float* W, int ldw, float* out, int B, hipStream_t st);
+int avlen_i_cross1_reduce(const float* Z, const float* W, int ldw, const float* bias, float* Y, int ldy, int B, hipStream_t st);
+int avlen_i_cross1_dw(const float* X, int ldx, const float* Z, float* dW, int ldw, int B, hipStream_t st);
+int avlen_i_cross1_fwd(const float* A, const void* MEM16, long lo, const float* maskx, float* P, float* Mo, int B, int S, float scale,
+                       hipStream_t st);
+int avlen_i_cross1_bwd(const float* P, const float* DM, const float* A, const void* MEM16, long lo, float* dA, float* dMEM, int B, int S,
+                       float scale, hipStream_t st);
 // C [N1][N2] = beta C + A^T B over M rows, A / B row-major bf16 (gemm_tn.hip: the weight gradient without transposed operand copies)
 size_t avlen_i_gemm_tn_workspace_bytes(long M, int N1, int N2);
 int avlen_i_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb, long M, int N1, int N2, float* C, int ldc, float beta,

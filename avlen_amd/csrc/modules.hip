@@ -1358,6 +1358,7 @@ struct TrWs {          // forward activations kept for backward (R = B*S rows, d
   float *m1, *r1, *m2, *r2, *me, *re;
   float *V0, *U1, *Y1, *Qc, *KVc, *AOc, *LSEc, *U2, *Y2, *G1, *U3, *Y3;
   float *md1, *rd1, *md2, *rd2, *md3, *rd3, *mf, *rf;
+  float *cA, *cM, *cDM, *cDA, *cP;     // cross attention in memory space (cross1.hip): [B][H][d] x 4, probabilities [B][H][S]
 };
 
 void tr_layout(WsBump& w, TrWs& t, long B, long S, int d, int H, bool cto) {
@@ -1377,6 +1378,11 @@ void tr_layout(WsBump& w, TrWs& t, long B, long S, int d, int H, bool cto) {
   t.U3 = w.take<float>(B * d); t.Y3 = w.take<float>(B * d);
   t.md1 = w.take<float>(B); t.rd1 = w.take<float>(B); t.md2 = w.take<float>(B); t.rd2 = w.take<float>(B);
   t.md3 = w.take<float>(B); t.rd3 = w.take<float>(B); t.mf = w.take<float>(B); t.rf = w.take<float>(B);
+  t.cA = t.cM = t.cDM = t.cDA = t.cP = nullptr;
+  if (!cto) {
+    t.cA = w.take<float>(B * H * d); t.cM = w.take<float>(B * H * d); t.cDM = w.take<float>(B * H * d); t.cDA = w.take<float>(B * H * d);
+    t.cP = w.take<float>(B * H * S);
+  }
 }
 
 // Encoder layer + final encoder norm (fp32-staged kernels; keeps every activation for backward).
@@ -1406,9 +1412,11 @@ int enc_fwd(const Ctx& c, const avlen_transformer& tr, TrWs& t, const float* Z, 
   return linear_rows(c, q.cross_attn.in_proj, d, 2 * d, t.MEM, d, t.KVc, 2 * d, (int)R, 0, nullptr, 0);
 }
 
-// Decoder layer over ONE target token per sample, given t.KVc (K|V projections of the encoder memory).
+// Decoder layer over ONE target token per sample, given t.KVc (K|V projections of the encoder memory) -- or, mem16 given (training at
+// scale, cross1.hip), the encoder memory itself as 16-bit rows [B * S][d] (lo plane mem_lo elements behind; 0: none): the cross
+// attention then runs in memory space and t.KVc is never read.
 int dec_fwd(const Ctx& c, const avlen_transformer& tr, TrWs& t, const float* maskx, const float* tgt, float* out, int B,
-            int S, bool cto) {
+            int S, bool cto, const void* mem16 = nullptr, long mem_lo = 0) {
   const int d = tr.d, H = tr.nhead, D = d / H;
   const float scale = 1.0f / sqrtf((float)D);
   const avlen_dec_layer& q = tr.dec;
@@ -1417,8 +1425,14 @@ int dec_fwd(const Ctx& c, const avlen_transformer& tr, TrWs& t, const float* mas
   TRY(avlen_layernorm_fwd(t.U1, nullptr, q.norm1.g, q.norm1.b, t.Y1, t.md1, t.rd1, B, d, 1e-5f, c.st));
   if (!cto) {
     TRY(linear_rows(c, q.cross_attn.in_proj, 0, d, t.Y1, d, t.Qc, d, B, 0, nullptr, 0));
-    TRY(avlen_attention_fwd(t.Qc, d, t.KVc, 2 * d, t.KVc + d, 2 * d, t.AOc, d, maskx, t.LSEc, B, H, 1, S, D, 0, scale,
-                            c.st));
+    if (mem16) {
+      const avlen_linear& win = q.cross_attn.in_proj;
+      TRY(avlen_i_cross1_expand(t.Qc, d, win.w + (size_t)d * d, d, t.cA, B, c.st));                         // A = q_h W_k[h]
+      TRY(avlen_i_cross1_fwd(t.cA, mem16, mem_lo, maskx, t.cP, t.cM, B, S, scale, c.st));
+      TRY(avlen_i_cross1_reduce(t.cM, win.w + (size_t)2 * d * d, d, win.b ? win.b + 2 * d : nullptr, t.AOc, d, B, c.st));
+    } else
+      TRY(avlen_attention_fwd(t.Qc, d, t.KVc, 2 * d, t.KVc + d, 2 * d, t.AOc, d, maskx, t.LSEc, B, H, 1, S, D, 0, scale,
+                              c.st));
   }
   TRY(linear(c, q.cross_attn.out_proj, t.AOc, d, t.U2, d, B, 0, t.Y1, d));
   TRY(avlen_layernorm_fwd(t.U2, nullptr, q.norm2.g, q.norm2.b, t.Y2, t.md2, t.rd2, B, d, 1e-5f, c.st));
@@ -1440,9 +1454,10 @@ struct TrBwdWs { float *dA, *dB, *dC, *dD, *dE, *delta; };     // dA: [R,3d]; dB
 // operand of the next product (hi plane, and the lo plane right behind it in compensated mode), the hi planes stay for the backward's
 // weight gradients.  No per-product cast of an fp32 activation is left in the forward, none of X in the backward.
 struct Big16 { bf16 *XF = nullptr, *H1 = nullptr, *Z = nullptr, *QKV = nullptr, *AO = nullptr, *X1 = nullptr, *F1 = nullptr, *MEM = nullptr;
-               int ldxf = 0; };
+               int ldxf = 0; long lo1 = 0; };      // lo1: elements from the hi to the lo plane of the [R][d] buffers (0: plain bf16)
 int g_big16 = 1;                 // avlen_set_big16(0): fp32-staged training forward at every size (tests compare the two)
 bool big16_enabled() { return g_big16 != 0; }
+bool cross1_enabled() { return (g_big16 & 2) == 0; }       // avlen_set_big16(3): big16 with the K | V projection route (tests compare the two)
 
 void trb_layout(WsBump& w, TrBwdWs& b, long B, long S, int d, int H) {
   long R = B * S;
@@ -1480,6 +1495,19 @@ int transformer_bwd(const Ctx& c, const avlen_transformer& tr, const avlen_trans
     avlen_linear wv = win; wv.w = win.w + (size_t)2 * d * d; wv.out_f = d;
     TRY(linear_bwd(c, wv, gv, dAOc, d, t.MEM, d, dMEM, d, (int)R, nullptr, 0));
     TRY(avlen_copy_rows(dU2, d, dY1, d, B, d, c.st));                          // dY1 = dU2 (residual)
+  } else if (h16 && avlen_i_cross1_ok(d, H, S) && cross1_enabled()) {
+    // cross attention in memory space (cross1.hip): no K | V rows, no gradient rows of them, no backward of their projection
+    const float* Wk = win.w + (size_t)d * d; const float* Wv = win.w + (size_t)2 * d * d;
+    float* dQc = s.dA;                   // [B, d]
+    if (gin.b) TRY(colsum_acc(c, dAOc, d, gin.b + 2 * d, B, d));                                    // db_v (db_k = 0)
+    TRY(avlen_i_cross1_dw(dAOc, d, t.cM, gin.w + (size_t)2 * d * d, d, B, c.st));                      // dW_v[h] += dout_h^T m_h
+    TRY(avlen_i_cross1_expand(dAOc, d, Wv, d, t.cDM, B, c.st));                                        // dm = dout_h W_v[h]
+    TRY(avlen_i_cross1_bwd(t.cP, t.cDM, t.cA, h16->MEM, h16->lo1, t.cDA, dMEM, B, S, scale, c.st));
+    TRY(avlen_i_cross1_reduce(t.cDA, Wk, d, nullptr, dQc, d, B, c.st));                                // dq_h = dA W_k[h]^T
+    TRY(avlen_i_cross1_dw(t.Qc, d, t.cDA, gin.w + (size_t)d * d, d, B, c.st));                         // dW_k[h] += q_h^T dA
+    avlen_linear gqp = gin; gqp.out_f = d;
+    avlen_linear wqp = win; wqp.out_f = d;
+    TRY(linear_bwd(c, wqp, gqp, dQc, d, t.Y1, d, dY1, d, B, dU2, d));                         // dY1 = dU2 + dQc Wq
   } else {
     float* dQc = s.dA;                   // [B, d]
     float* dKVc = s.dA + (size_t)B * d;   // [R, 2d]
@@ -1601,7 +1629,6 @@ int linear16t(const Ctx& c, const avlen_linear& L, int r0, int n, const bf16* X1
   return avlen_gemm_bf16_dyn(X16, ldx, W16, Kp, Y32, ld32, Y16, ld16, L.b ? L.b + r0 : nullptr, res, ldr, (int)M, nullptr, n, Kp, act,
                              c.gws, c.gws_bytes, c.st, &o);
 }
-int dec_fwd(const Ctx& c, const avlen_transformer& tr, TrWs& t, const float* maskx, const float* tgt, float* out, int B, int S, bool cto);
 // The training forward at scale on 16-bit activation planes: same products, same formats as the fp32-staged forward (an operand plane
 // is the cast of the fp32 value either way), the self attention on the matrix cores (attn_smt16_kernel; it also leaves the fp32
 // output and the log-sum-exp the backward reads).  Fills what transformer_bwd / avlen_smt_bwd read: QKV, AO, LSE, T1, T2, X2, KVc, the
@@ -1625,6 +1652,8 @@ int smt_fwd_big16(const Ctx& c, const avlen_smt* p, SmtWs& s, const float* goal,
   TRY(linear16t(c, e.lin2, 0, d, h.F1, ff, lf, t.T2, d, nullptr, 0, 0, R, 0, t.X1, d));
   TRY(avlen_layernorm_fwd(t.T2, nullptr, e.norm2.g, e.norm2.b, t.X2, t.m2, t.r2, (int)R, d, 1e-5f, c.st));
   TRY(avlen_layernorm_fwd16_dyn(t.X2, nullptr, tr.enc_norm.g, tr.enc_norm.b, nullptr, h.MEM, t.me, t.re, (int)R, nullptr, d, 1e-5f, c.st, l1));
+  if (avlen_i_cross1_ok(d, H, S) && cross1_enabled())     // the decoder's single-query cross attention reads the memory rows themselves
+    return dec_fwd(c, tr, t, s.maskx, goal, out, B, S, false, h.MEM, l1);
   TRY(linear16t(c, tr.dec.cross_attn.in_proj, d, 2 * d, h.MEM, d, l1, t.KVc, 2 * d, nullptr, 0, 0, R, 0, nullptr, 0));
   return dec_fwd(c, tr, t, s.maskx, goal, out, B, S, false);
 }
@@ -1964,6 +1993,7 @@ extern "C" int avlen_smt_fwd(const avlen_smt* p, const float* x, const float* me
   const int S = cto ? 1 : M + 1, d = p->tr.d;
   const long R = (long)B * S;
   if (!mem_index) NC = B;
+  s.h.lo1 = prec == AVLEN_PREC_BF16X3 ? R * d : 0;
   if (save_for_backward && big16_on(p, s, prec, R, S, cto != 0)) {       // the fusion input straight into its operand planes
     hipLaunchKernelGGL(smt_build_kernel, dim3((unsigned)R), dim3(128), 0, st, x, memory, mem_index, NC, masks, p->pose.w, p->pose.b,
                        (float*)nullptr, s.ldxf, s.FMT, s.maskx, B, M, F, pose_col, cto, s.h.XF, s.h.ldxf,
@@ -2005,6 +2035,7 @@ extern "C" int avlen_smt_bwd(const avlen_smt* p, const avlen_smt* g, const float
   const bool mixed = prec == AVLEN_PREC_BF16X3 && g_mixed_rows > 0 && R >= g_mixed_rows;
   Ctx c{st, mixed ? AVLEN_PREC_BF16 : prec, s.gws, GEMM_SCRATCH};
   c.xs = s.xs; c.xs_bytes = s.xs_bytes;
+  s.h.lo1 = prec == AVLEN_PREC_BF16X3 ? R * d : 0;
   const Big16* h16 = big16_on(p, s, prec, R, S, cto != 0) ? &s.h : nullptr;      // the forward left 16-bit operand planes
   TRY(transformer_bwd(c, p->tr, g->tr, s.tr, s.tb, s.Z, s.maskx, goal, d_out, s.dZ, B, S, cto != 0, h16));
   // fusion MLP
@@ -2610,5 +2641,5 @@ extern "C" int avlen_gru_fwd(const avlen_gru* p, const float* x, const float* h0
 extern "C" void avlen_set_big_m(long rows) { g_big_m = rows > 0 ? rows : 4096; }
 // bf16x3: token rows (B x (M + 1)) from which the SMT backward uses plain bf16 operands (forward stays compensated); 0 = never,
 // < 0 restores the default (65536).
-extern "C" void avlen_set_big16(int on) { g_big16 = on ? 1 : 0; }
+extern "C" void avlen_set_big16(int on) { g_big16 = on; }
 extern "C" void avlen_set_x3_mixed_backward_rows(long rows) { g_mixed_rows = rows < 0 ? 65536 : rows; }

@@ -324,7 +324,8 @@ void avlen_set_big_m(long rows);
 void avlen_set_x3_mixed_backward_rows(long rows);
 /* The training forward at scale (rows >= avlen_set_big_m; bf16 mode, and bf16x3 where its backward is mixed) keeps its activations
  * as 16-bit operand planes emitted by their producers and runs the self attention on the matrix cores (default on).  0: every
- * product casts its fp32 input (the layout the small-batch path uses); tests compare the two. */
+ * product casts its fp32 input (the layout the small-batch path uses); 3: planes on, but the decoder's single-query cross attention
+ * through the K | V projection of the memory rows instead of in memory space (csrc/cross1.hip); tests compare the three. */
 void avlen_set_big16(int on);
 /* Scheduling knob of the bf16x3 tower group (one persistent work-queue launch, one workgroup per CU): CUs it leaves free for the
  * other streams of the step (default 0 = every CU). */

@@ -534,6 +534,10 @@ def test_gradients_bf16x3_mixed_backward_at_scale(specs):
         L.lib.avlen_set_x3_mixed_backward_rows(1)
         L.lib.avlen_set_big16(1)
         g_16 = _gradient_check(specs, "bf16x3", float("inf"), loss_rtol=2e-3)
+        # ... and with the decoder's cross attention through the K | V projection of the memory rows (the default absorbs the two
+        # projections into the query side and never forms K | V or their gradients: csrc/cross1.hip)
+        L.lib.avlen_set_big16(3)
+        g_kv = _gradient_check(specs, "bf16x3", float("inf"), loss_rtol=2e-3)
     finally:
         L.lib.avlen_set_big_m(0)
         L.lib.avlen_set_x3_mixed_backward_rows(-1)
@@ -558,6 +562,17 @@ def test_gradients_bf16x3_mixed_backward_at_scale(specs):
         worst = max(worst, err)
         print("   %-80s %.2e" % (k, err))
         assert err < 1e-2, (k, err)         # measured: <= 1e-3 but for the cancelling sums (pose encoder bias 5.2e-3)
+    worst_kv = 0.0
+    for k in g_16:
+        a, b = g_kv[k], g_16[k]
+        if float(a.norm()) == 0.0:
+            continue
+        err = float((a - b).norm() / a.norm())
+        worst_kv = max(worst_kv, err)
+        if "in_proj_bias" in k and "multihead_attn" in k:
+            continue                         # its K third is a zero-mean noise term on one side and exactly 0 on the other
+        assert err < 1e-2, (k, err)
+    print("bf16x3 mixed backward: cross attention in memory space vs through K | V, max relative L2 difference of a gradient tensor:", worst_kv)
     print("bf16x3 mixed backward: 16-bit-plane forward vs fp32-saved forward, max relative L2 difference of a gradient tensor:", worst)
 
 
