@@ -35,14 +35,32 @@ __device__ __forceinline__ void x_row(const bf16* p, long lo, float v[4]) {
   }
 }
 // sc[key][h][row of 16 lanes] = partial dot of vec[h] with memory row `key` (the wave's keys: wave, wave + 8, ...)
-__device__ __forceinline__ void x_dots(const bf16* rows, long lo, int S, const float (&vec)[XH][4], float (*sc)[XH][4], int wave, int lane) {
-  for (int k0 = wave; k0 < S; k0 += 4 * XW) {
-    float v[4][4];
+// four rows of the wave's key sequence (k0, k0 + 8, k0 + 16, k0 + 24; clamped: the extra loads are discarded)
+__device__ __forceinline__ void x_load4(const bf16* rows, long lo, int S, int k0, int lane, float (&v)[4][4]) {
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int key = k0 + u * XW < S ? k0 + u * XW : k0;
-      x_row(rows + (long)key * XD + 4 * lane, lo, v[u]);
-    }
+  for (int u = 0; u < 4; u++) {
+    const int key = k0 + u * XW < S ? k0 + u * XW : (k0 < S ? k0 : S - 1);
+    x_row(rows + (long)key * XD + 4 * lane, lo, v[u]);
+  }
+}
+// The loops over a sample's rows run the NEXT four loads under the arithmetic of the current four (two register sets, the loop
+// unrolled by two): a block has 8 waves and its CU two or three blocks -- without it every group of rows paid a full memory latency.
+#define X_ROWS_LOOP(BODY)                                                                             \
+  {                                                                                                   \
+    float va_[4][4], vb_[4][4];                                                                       \
+    x_load4(rows, lo, S, wave, lane, va_);                                                            \
+    for (int k0 = wave; k0 < S; k0 += 8 * XW) {                                                       \
+      if (k0 + 4 * XW < S) x_load4(rows, lo, S, k0 + 4 * XW, lane, vb_);                              \
+      BODY(va_, k0);                                                                                  \
+      if (k0 + 4 * XW < S) {                                                                          \
+        if (k0 + 8 * XW < S) x_load4(rows, lo, S, k0 + 8 * XW, lane, va_);                            \
+        BODY(vb_, k0 + 4 * XW);                                                                       \
+      }                                                                                               \
+    }                                                                                                 \
+  }
+// sc[key][h][row of 16 lanes] = partial dot of vec[h] with memory row `key` (the wave's keys: wave, wave + 8, ...)
+__device__ __forceinline__ void x_dots(const bf16* rows, long lo, int S, const float (&vec)[XH][4], float (*sc)[XH][4], int wave, int lane) {
+  auto body = [&](const float (&v)[4][4], int k0) {
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const int key = k0 + u * XW;
@@ -59,7 +77,8 @@ __device__ __forceinline__ void x_dots(const bf16* rows, long lo, int S, const f
         }
       }
     }
-  }
+  };
+  X_ROWS_LOOP(body)
 }
 
 // forward: A [B][H][d] -> P [B][H][S] (softmax over the valid keys), Mo [B][H][d] = sum_key p mem[key]
@@ -107,13 +126,7 @@ __global__ __launch_bounds__(XTH) void cross1_fwd_kernel(const float* __restrict
   for (int h = 0; h < XH; h++)
 #pragma unroll
     for (int e = 0; e < 4; e++) acc[h][e] = 0.f;
-  for (int k0 = wave; k0 < S; k0 += 4 * XW) {
-    float v[4][4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int key = k0 + u * XW < S ? k0 + u * XW : k0;
-      x_row(rows + (long)key * XD + 4 * lane, lo, v[u]);
-    }
+  auto mix = [&](const float (&v)[4][4], int k0) {
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const int key = k0 + u * XW;
@@ -126,7 +139,8 @@ __global__ __launch_bounds__(XTH) void cross1_fwd_kernel(const float* __restrict
           for (int e = 0; e < 4; e++) acc[h][e] = __builtin_fmaf(ph[h], v[u][e], acc[h][e]);
       }
     }
-  }
+  };
+  X_ROWS_LOOP(mix)
 #pragma unroll
   for (int h = 0; h < XH; h++)
 #pragma unroll
@@ -180,13 +194,7 @@ __global__ __launch_bounds__(XTH) void cross1_bwd_kernel(const float* __restrict
 #pragma unroll
     for (int e = 0; e < 4; e++) acc[h][e] = 0.f;
   }
-  for (int k0 = wave; k0 < S; k0 += 4 * XW) {
-    float v[4][4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int key = k0 + u * XW < S ? k0 + u * XW : k0;
-      x_row(rows + (long)key * XD + 4 * lane, lo, v[u]);
-    }
+  auto mix = [&](const float (&v)[4][4], int k0) {
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const int key = k0 + u * XW;
@@ -206,7 +214,8 @@ __global__ __launch_bounds__(XTH) void cross1_bwd_kernel(const float* __restrict
         *reinterpret_cast<float4*>(dMEM + (b * S + key) * XD + 4 * lane) = make_float4(o[0], o[1], o[2], o[3]);
       }
     }
-  }
+  };
+  X_ROWS_LOOP(mix)
 #pragma unroll
   for (int h = 0; h < XH; h++)
 #pragma unroll
@@ -223,10 +232,12 @@ __global__ __launch_bounds__(256) void hw_expand_kernel(const float* __restrict_
   const int c = threadIdx.x, b0 = blockIdx.x * 8;
   for (int i = threadIdx.x; i < 8 * XD; i += 256) { const int r = i >> 8, k = i & 255; xs[r][k] = b0 + r < B ? X[(long)(b0 + r) * ldx + k] : 0.f; }
   __syncthreads();
+#pragma unroll 1
   for (int h = 0; h < XH; h++) {
     float acc[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) acc[r] = 0.f;
+#pragma unroll 8
     for (int j = 0; j < 32; j++) {
       const float w = W[(long)(h * 32 + j) * ldw + c];
 #pragma unroll
@@ -247,6 +258,7 @@ __global__ __launch_bounds__(256) void hw_reduce_kernel(const float* __restrict_
   __syncthreads();
   const int r = t >> 5, j = t & 31;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 4
   for (int k = 0; k < XD; k += 4) {
     a0 = __builtin_fmaf(zs[r][k], ws[j][k], a0); a1 = __builtin_fmaf(zs[r][k + 1], ws[j][k + 1], a1);
     a2 = __builtin_fmaf(zs[r][k + 2], ws[j][k + 2], a2); a3 = __builtin_fmaf(zs[r][k + 3], ws[j][k + 3], a3);
@@ -261,6 +273,7 @@ __global__ __launch_bounds__(256) void hw_dw_kernel(const float* __restrict__ X,
   float acc[8];
 #pragma unroll
   for (int jj = 0; jj < 8; jj++) acc[jj] = 0.f;
+#pragma unroll 4
   for (int b = b0; b < b1; b++) {
     const float z = Z[((long)b * XH + h) * XD + c];
     const float4 x0 = *reinterpret_cast<const float4*>(X + (long)b * ldx + h * 32 + j0), x1 = *reinterpret_cast<const float4*>(X + (long)b * ldx + h * 32 + j0 + 4);

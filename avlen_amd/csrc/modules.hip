@@ -1502,7 +1502,8 @@ int transformer_bwd(const Ctx& c, const avlen_transformer& tr, const avlen_trans
     if (gin.b) TRY(colsum_acc(c, dAOc, d, gin.b + 2 * d, B, d));                                    // db_v (db_k = 0)
     TRY(avlen_i_cross1_dw(dAOc, d, t.cM, gin.w + (size_t)2 * d * d, d, B, c.st));                      // dW_v[h] += dout_h^T m_h
     TRY(avlen_i_cross1_expand(dAOc, d, Wv, d, t.cDM, B, c.st));                                        // dm = dout_h W_v[h]
-    TRY(avlen_i_cross1_bwd(t.cP, t.cDM, t.cA, h16->MEM, h16->lo1, t.cDA, dMEM, B, S, scale, c.st));
+    // (the mixed backward reads the memory rows as their hi plane: bf16 operands, as every other product of this backward)
+    TRY(avlen_i_cross1_bwd(t.cP, t.cDM, t.cA, h16->MEM, c.prec == AVLEN_PREC_BF16 ? 0L : h16->lo1, t.cDA, dMEM, B, S, scale, c.st));
     TRY(avlen_i_cross1_reduce(t.cDA, Wk, d, nullptr, dQc, d, B, c.st));                                // dq_h = dA W_k[h]^T
     TRY(avlen_i_cross1_dw(t.Qc, d, t.cDA, gin.w + (size_t)d * d, d, B, c.st));                         // dW_k[h] += q_h^T dA
     avlen_linear gqp = gin; gqp.out_f = d;
