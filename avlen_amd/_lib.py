@@ -229,6 +229,7 @@ SIGNATURES = {
     "avlen_set_big_m": (None, [C.c_long]),
     "avlen_set_x3_mixed_backward_rows": (None, [C.c_long]),
     "avlen_set_big16": (None, [i32]),
+    "avlen_set_audio3": (None, [i32]),
     "avlen_set_tower_x3_reserved_cus": (None, [i32]),
     "avlen_tower_x3_timing": (i32, [vp, vp, i32]),
     "avlen_set_clip_tower_split4_wgs": (None, [i32]),

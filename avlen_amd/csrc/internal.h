@@ -21,6 +21,10 @@ int avlen_i_linear(const avlen_ctx& c, const avlen_linear& L, const float* X, in
 int avlen_i_linear_dx(const avlen_ctx& c, const avlen_linear& L, const float* dY, int ldy, float* dX, int ldx, int M,
                       const float* add, int ldadd);
 int avlen_i_linear_dw(const avlen_ctx& c, const avlen_linear& G, const float* dY, int ldy, const float* X, int ldx, int M);
+// the AudioCNN's three convolutions as one launch, activations in LDS (audio3.hip); _ok: geometry / LDS budget covered
+bool avlen_i_audio3_ok(const avlen_cnn3* n, int H, int W);
+int avlen_i_audio3_fwd(const avlen_cnn3* const* nets, const float* x, const int* row_index, int groups, int B, int H, int W, void* const* outs,
+                       hipStream_t st);
 // single-query cross attention in memory space (cross1.hip; d = 256, 8 heads, S <= 320): per-head products against the rows of a
 // [d][d] projection slice, the forward (scores + softmax + weighted memory sum) and the backward (dA, d memory rows)
 bool avlen_i_cross1_ok(int d, int H, int S);

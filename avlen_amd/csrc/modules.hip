@@ -1024,6 +1024,8 @@ int resnet18_fwd_bf16(const avlen_resnet18* net, const void* img, int img_u8, in
 }
 
 // ---- 3-conv CNNs ----
+int g_audio3 = 1;                // avlen_set_audio3(0): cast + one implicit-GEMM launch per conv (tests compare the two)
+bool audio3_enabled() { return g_audio3 != 0; }
 void cnn3_dims2(const avlen_cnn3* n, int H, int W, int oh[3], int ow[3]) {
   for (int i = 0; i < 3; i++) {
     oh[i] = (H - n->conv[i].kh) / n->conv[i].stride + 1;
@@ -1064,6 +1066,12 @@ int cnn3_fwd_bf16(const avlen_cnn3* n, const float* x, int B, int H, int W, floa
     mx = zmax(mx, avlen_gemm_bf16_workspace_bytes(B * oh[i] * ow[i], n->conv[i].cout));
   }
   void* gws = w.take<char>(mx);
+  if (audio3_enabled() && avlen_i_audio3_ok(n, H, W) && n->fc.ld16 == oh[2] * ow[2] * n->conv[2].cout) {
+    void* co = a[2];
+    TRY(avlen_i_audio3_fwd(&n, x, row_index, 1, B, H, W, &co, st));
+    return avlen_gemm_bf16_dyn(a[2], n->fc.ld16, n->fc.w16, n->fc.ld16, out, ld_out, nullptr, 0, n->fc.b, nullptr, 0, B, nullptr,
+                               n->fc.out_f, n->fc.ld16, AVLEN_ACT_RELU, gws, mx, st, &go);
+  }
   const bool sp = cnn3_superpixel(n, W);
   const int wsp = sp ? ((ow[0] - 1) * n->conv[0].stride + n->conv[0].kw) / n->conv[0].stride : 0;   // super-pixels per row
   if (sp) TRY(avlen_cast_bf16_indexed(x, W * n->conv[0].cin, x16, wsp * 8, (long)B * H, wsp * 8, row_index, H, st, fmt));     // drop the unused columns
@@ -1145,6 +1153,15 @@ int cnn3_group_fwd_bf16(const avlen_cnn3* const* nets, const float* x, int G, in
   mx *= G;
   void* gws = w.take<char>(mx);
   if (!w.ok()) return AVLEN_ERR_WS;
+  bool fused = audio3_enabled() && n->fc.ld16 == oh[2] * ow[2] * n->conv[2].cout;
+  for (int g = 0; g < G; g++) fused = fused && avlen_i_audio3_ok(nets[g], H, W);
+  if (fused) {       // the three convs in one launch per (encoder, spectrogram): activations never leave LDS (audio3.hip)
+    void* co[8]; const void* FA[8]; const void* FB[8]; const float* FBI[8];
+    for (int g = 0; g < G; g++) { co[g] = a[2][g]; FA[g] = a[2][g]; FB[g] = nets[g]->fc.w16; FBI[g] = nets[g]->fc.b; }
+    TRY(avlen_i_audio3_fwd(nets, x, nullptr, G, B, H, W, co, st));
+    return avlen_gemm_bf16_grouped(FA, n->fc.ld16, FB, n->fc.ld16, outs, ld_out, FBI, G, B, n->fc.out_f, n->fc.ld16, AVLEN_ACT_RELU,
+                                   gws, mx, st, &go);
+  }
   bool sp = true;
   for (int g = 0; g < G; g++) sp = sp && cnn3_superpixel(nets[g], W);
   const int wsp = sp ? ((ow[0] - 1) * n->conv[0].stride + n->conv[0].kw) / n->conv[0].stride : 0;   // super-pixels per row
@@ -2643,4 +2660,5 @@ extern "C" void avlen_set_big_m(long rows) { g_big_m = rows > 0 ? rows : 4096; }
 // bf16x3: token rows (B x (M + 1)) from which the SMT backward uses plain bf16 operands (forward stays compensated); 0 = never,
 // < 0 restores the default (65536).
 extern "C" void avlen_set_big16(int on) { g_big16 = on; }
+extern "C" void avlen_set_audio3(int on) { g_audio3 = on ? 1 : 0; }
 extern "C" void avlen_set_x3_mixed_backward_rows(long rows) { g_mixed_rows = rows < 0 ? 65536 : rows; }

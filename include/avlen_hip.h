@@ -327,6 +327,9 @@ void avlen_set_x3_mixed_backward_rows(long rows);
  * product casts its fp32 input (the layout the small-batch path uses); 3: planes on, but the decoder's single-query cross attention
  * through the K | V projection of the memory rows instead of in memory space (csrc/cross1.hip); tests compare the three. */
 void avlen_set_big16(int on);
+/* The AudioCNN's three convolutions (audio_cnn.py: 8x8 s4, 4x4 s2, 3x3 s1 on a 2-channel spectrogram) run as ONE launch with the
+ * activations in LDS when the geometry fits (default on; csrc/audio3.hip).  0: a cast and one implicit-GEMM launch per conv. */
+void avlen_set_audio3(int on);
 /* Scheduling knob of the bf16x3 tower group (one persistent work-queue launch, one workgroup per CU): CUs it leaves free for the
  * other streams of the step (default 0 = every CU). */
 void avlen_set_tower_x3_reserved_cus(int n);

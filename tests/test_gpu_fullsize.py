@@ -128,3 +128,34 @@ def test_per_gpu_share_of_the_sharded_configs(stage, distractor, envs, precision
     # after_update carried the last step over; the rings hold the rollout's 150 inserted rows per environment
     assert int(ro.step) == 0 and ro.em_option.memory.shape == (300, envs, 329 if distractor else 308)
     assert float(ro.em_option.memory.abs().sum()) > 0
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_fused_audio_convs_match_the_per_layer_launches(precision):
+    """The AudioCNN's three convolutions as one LDS-resident launch (csrc/audio3.hip, the default) against the cast + one implicit-GEMM
+    launch per conv (`avlen_set_audio3(0)`): same 16-bit operands and activation formats (fp16 in bf16x3 mode, bf16 in bf16 mode), fp32
+    accumulation in another order.  First rollout step of two workloads built from the same seeds: the stored feature rows' audio
+    columns, the values and pi_l's probabilities."""
+    from avlen_amd.harness import Workload
+    from avlen_amd import _lib as L
+    got = []
+    try:
+        for fused in (0, 1):
+            L.lib.avlen_set_audio3(fused)
+            torch.manual_seed(123)
+            wl = Workload(64, 4, precision=precision)
+            wl.rollout_step()
+            wl._join_small()
+            torch.cuda.synchronize()
+            ro = wl.rollouts
+            got.append((ro.value_preds[0].clone(), ro.action_probs[0].clone(), ro.em_option.memory[0].clone()))   # slot 0: step 0's feature row
+            del wl
+    finally:
+        L.lib.avlen_set_audio3(1)
+    (v0, p0, m0), (v1, p1, m1) = got
+    tol = 2e-3 if precision == "bf16x3" else 2e-2          # fp16 / bf16 activations: one rounding flip of an intermediate moves an output by an ulp of it
+    assert float((v0 - v1).abs().max()) < tol * max(1.0, float(v0.abs().max())), float((v0 - v1).abs().max())
+    assert float((p0 - p1).abs().max()) < tol
+    if m0 is not None:
+        scale = float(m0.abs().max())
+        assert scale > 0 and float((m0 - m1).abs().max()) < tol * scale, (float((m0 - m1).abs().max()), scale)

@@ -11,3 +11,4 @@ rocprofv3 --kernel-trace --stats -d /tmp/p2 -o res -- python3 $R/bench.py --stag
 python3 $R/tools/update_sequence.py $(find /tmp/p2 -name "*.db" | head -1) > $O/update_sequence.txt
 cut -c1-400 $O/bench_stage2_envs32.log
 head -40 $O/update_stage2.md
+python3 $R/tools/step_trace.py $(find /tmp/p2 -name "*.db" | head -1) 150 40 > $O/step_trace_stage2.txt 2>&1
