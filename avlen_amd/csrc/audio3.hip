@@ -26,7 +26,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-constexpr int A3_TH = 512, A3_BAND = 16, A3_MAXG = 8;
+constexpr int A3_TH = 512, A3_BAND = 8, A3_MAXG = 8, A3_NLD = 12;     // A3_NLD: float2 loads per thread and band
 
 struct A3Args {
   const float* x; const int* row_index; int B, H, W;
@@ -58,7 +58,13 @@ __global__ __launch_bounds__(A3_TH) void audio3_kernel(A3Args a) {
   const long bs = a.row_index ? a.row_index[b] : b;
   char* a1 = lds; char* a2 = lds + a.a2_off;
   const int ow1 = a.ow1, ow2 = a.ow2, ow3 = a.ow3;
-  // ================= conv 1: bands of A3_BAND output rows =================
+  // conv 2's weights are requested first: they arrive under conv 1 (the registers are free until then)
+  const int cp = wave & 1, grp = wave >> 1;                 // convs 2 / 3: cout tiles 2 cp, 2 cp + 1; pixel tiles grp, grp + 4, ...
+  uint4 wf2[2][16];                                         // (half of them: all 128 registers beside conv 1's own spill)
+#pragma unroll
+  for (int tap = 0; tap < 16; tap++)
+    wf2[0][tap] = *reinterpret_cast<const uint4*>((const char*)a.w2[g] + ((long)((2 * cp) * 16 + r16) * 512 + 32 * tap + 8 * q) * 2);
+  // ================= conv 1: bands of A3_BAND output rows, double-buffered =================
   {
     uint4 wf[2][4];
     float bias[2][4];
@@ -71,20 +77,41 @@ __global__ __launch_bounds__(A3_TH) void audio3_kernel(A3Args a) {
       for (int r = 0; r < 4; r++) bias[nt][r] = a.b1[g][nt * 16 + 4 * q + r];
     }
     const float* img = a.x + bs * a.H * a.W * 2;
-    for (int oy0 = 0; oy0 < a.oh1; oy0 += A3_BAND) {
-      const int nb = min(A3_BAND, a.oh1 - oy0), nrows = 4 * nb + 4, y0 = 4 * oy0;
-      if (oy0) __syncthreads();                             // everyone has left the previous band
-      for (int i = tid; i < nrows * a.W; i += A3_TH) {
-        const int r = i / a.W, xx = i - r * a.W;
-        const float2 v = *reinterpret_cast<const float2*>(img + ((long)(y0 + r) * a.W + xx) * 2);
-        *reinterpret_cast<unsigned*>(a2 + r * a.row_bytes + xx * 4) = (unsigned)a3_cvt<F16>(v.x) | ((unsigned)a3_cvt<F16>(v.y) << 16);
+    const int band_bytes = (4 * A3_BAND + 4) * a.row_bytes;
+    float2 st[A3_NLD];
+    auto fetch = [&](int oy0) {                             // the band's input rows -> registers
+      const int nb = min(A3_BAND, a.oh1 - oy0), n = (4 * nb + 4) * a.W;
+#pragma unroll
+      for (int j = 0; j < A3_NLD; j++) {
+        const int i = tid + A3_TH * j;
+        if (i < n) st[j] = *reinterpret_cast<const float2*>(img + ((long)4 * oy0 * a.W + i) * 2);
       }
-      __syncthreads();
+    };
+    auto stash = [&](int oy0, char* band) {                 // registers -> the 16-bit band image
+      const int nb = min(A3_BAND, a.oh1 - oy0), n = (4 * nb + 4) * a.W;
+#pragma unroll
+      for (int j = 0; j < A3_NLD; j++) {
+        const int i = tid + A3_TH * j;
+        if (i < n) {
+          const int r = i / a.W, xx = i - r * a.W;
+          *reinterpret_cast<unsigned*>(band + r * a.row_bytes + xx * 4) = (unsigned)a3_cvt<F16>(st[j].x) | ((unsigned)a3_cvt<F16>(st[j].y) << 16);
+        }
+      }
+    };
+    fetch(0);
+    stash(0, a2);
+    __syncthreads();
+    int buf = 0;
+    for (int oy0 = 0; oy0 < a.oh1; oy0 += A3_BAND, buf ^= 1) {
+      const int nb = min(A3_BAND, a.oh1 - oy0);
+      const bool more = oy0 + A3_BAND < a.oh1;
+      if (more) fetch(oy0 + A3_BAND);                       // in flight under this band's MFMAs
+      const char* band = a2 + buf * band_bytes;
       const int npix = nb * ow1;
       for (int t = wave; t * 16 < npix; t += A3_TH / 64) {
         const int p = t * 16 + r16, pc = p < npix ? p : npix - 1;
         const int oyl = pc / ow1, ox = pc - oyl * ow1;
-        const char* src = a2 + (4 * oyl + (q >> 1)) * a.row_bytes + 16 * ox + 16 * (q & 1);
+        const char* src = band + (4 * oyl + (q >> 1)) * a.row_bytes + 16 * ox + 16 * (q & 1);
         f32x4 acc[2];
         acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[1] = acc[0];
 #pragma unroll
@@ -104,22 +131,21 @@ __global__ __launch_bounds__(A3_TH) void audio3_kernel(A3Args a) {
           }
         }
       }
+      if (more) stash(oy0 + A3_BAND, a2 + (buf ^ 1) * band_bytes);     // (that buffer's band was finished before the last barrier)
+      __syncthreads();
     }
   }
-  __syncthreads();
   // ================= conv 2: [oh1][ow1][32] -> [oh2][ow2][64], 16 taps =================
+#pragma unroll
+  for (int tap = 0; tap < 16; tap++)
+    wf2[1][tap] = *reinterpret_cast<const uint4*>((const char*)a.w2[g] + ((long)((2 * cp + 1) * 16 + r16) * 512 + 32 * tap + 8 * q) * 2);
   {
-    const int cp = wave & 1, grp = wave >> 1;               // cout tiles 2 cp, 2 cp + 1; pixel tiles grp, grp + 4, ...
-    uint4 wf[2][16];
+    uint4 (&wf)[2][16] = wf2;
     float bias[2][4];
 #pragma unroll
-    for (int nt = 0; nt < 2; nt++) {
-#pragma unroll
-      for (int tap = 0; tap < 16; tap++)
-        wf[nt][tap] = *reinterpret_cast<const uint4*>((const char*)a.w2[g] + ((long)((2 * cp + nt) * 16 + r16) * 512 + 32 * tap + 8 * q) * 2);
+    for (int nt = 0; nt < 2; nt++)
 #pragma unroll
       for (int r = 0; r < 4; r++) bias[nt][r] = a.b2[g][(2 * cp + nt) * 16 + 4 * q + r];
-    }
     const int npix = a.oh2 * ow2;
     for (int t = grp; t * 16 < npix; t += 4) {
       const int p = t * 16 + r16, pc = p < npix ? p : npix - 1;
@@ -147,25 +173,23 @@ __global__ __launch_bounds__(A3_TH) void audio3_kernel(A3Args a) {
       }
     }
   }
-  __syncthreads();
   // ================= conv 3: [oh2][ow2][64] -> [oh3][ow3][64] (no ReLU), 9 taps x 2 k-steps =================
+  // one cout tile per wave here (72 weight registers: with two, 144, the fragment reads of a tile could not be hoisted over its MFMAs)
   {
-    const int cp = wave & 1, grp = wave >> 1;               // cout tiles 2 cp, 2 cp + 1; pixel tiles grp, grp + 4, ...
-    uint4 wf[2][18];
-    float bias[2][4];
+    const int ct = wave & 3, grp3 = wave >> 2;              // pixel tiles grp3, grp3 + 2, ...
+    uint4 wf[18];
+    float bias[4];
 #pragma unroll
-    for (int nt = 0; nt < 2; nt++) {
+    for (int ks = 0; ks < 18; ks++)
+      wf[ks] = *reinterpret_cast<const uint4*>((const char*)a.w3[g] + ((long)(ct * 16 + r16) * 576 + 32 * ks + 8 * q) * 2);
 #pragma unroll
-      for (int ks = 0; ks < 18; ks++)
-        wf[nt][ks] = *reinterpret_cast<const uint4*>((const char*)a.w3[g] + ((long)((2 * cp + nt) * 16 + r16) * 576 + 32 * ks + 8 * q) * 2);
-#pragma unroll
-      for (int r = 0; r < 4; r++) bias[nt][r] = a.b3[g][(2 * cp + nt) * 16 + 4 * q + r];
-    }
+    for (int r = 0; r < 4; r++) bias[r] = a.b3[g][ct * 16 + 4 * q + r];
+    __syncthreads();                                        // conv 2's output is complete
     const int npix = a.oh3 * ow3;
-    for (int t = grp; t * 16 < npix; t += 4) {
+    for (int t = grp3; t * 16 < npix; t += 2) {
       const int p = t * 16 + r16, pc = p < npix ? p : npix - 1;
       const int oy = pc / ow3, ox = pc - oy * ow3;
-      f32x4 acc[2];
+      f32x4 acc[2];                                         // two accumulation chains (even / odd k-steps), added at the end
       acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[1] = acc[0];
 #pragma unroll
       for (int ky = 0; ky < 3; ky++)
@@ -176,16 +200,13 @@ __global__ __launch_bounds__(A3_TH) void audio3_kernel(A3Args a) {
 #pragma unroll
           for (int hh = 0; hh < 2; hh++) {
             const uint4 xf = *reinterpret_cast<const uint4*>(px + (((4 * hh + q) ^ (x & 7)) << 4));
-            acc[0] = a3_mma<F16>(wf[0][(ky * 3 + kx) * 2 + hh], xf, acc[0]);
-            acc[1] = a3_mma<F16>(wf[1][(ky * 3 + kx) * 2 + hh], xf, acc[1]);
+            acc[hh] = a3_mma<F16>(wf[(ky * 3 + kx) * 2 + hh], xf, acc[hh]);
           }
         }
       if (p < npix) {
-#pragma unroll
-        for (int nt = 0; nt < 2; nt++) {
-          const uint2 o = a3_pack4<F16>(acc[nt][0] + bias[nt][0], acc[nt][1] + bias[nt][1], acc[nt][2] + bias[nt][2], acc[nt][3] + bias[nt][3]);
-          *reinterpret_cast<uint2*>((char*)a.out[g] + (((long)b * npix + p) * 64 + (2 * cp + nt) * 16 + 4 * q) * 2) = o;
-        }
+        const uint2 o = a3_pack4<F16>((acc[0][0] + acc[1][0]) + bias[0], (acc[0][1] + acc[1][1]) + bias[1], (acc[0][2] + acc[1][2]) + bias[2],
+                                      (acc[0][3] + acc[1][3]) + bias[3]);
+        *reinterpret_cast<uint2*>((char*)a.out[g] + (((long)b * npix + p) * 64 + ct * 16 + 4 * q) * 2) = o;
       }
     }
   }
@@ -202,7 +223,8 @@ bool avlen_i_audio3_ok(const avlen_cnn3* n, int H, int W) {
   const int oh1 = (H - 8) / 4 + 1, ow1 = (W - 8) / 4 + 1, oh2 = (oh1 - 4) / 2 + 1, ow2 = (ow1 - 4) / 2 + 1, oh3 = oh2 - 2, ow3 = ow2 - 2;
   if (H < 8 || W < 8 || oh1 < 4 || ow1 < 4 || oh3 < 1 || ow3 < 1) return false;
   const int row_bytes = (W * 4 + 15) & ~15;
-  const long a1 = (long)oh1 * ow1 * 64, a2 = (long)oh2 * ow2 * 128, band = (long)(4 * A3_BAND + 4) * row_bytes;
+  const long a1 = (long)oh1 * ow1 * 64, a2 = (long)oh2 * ow2 * 128, band = 2L * (4 * A3_BAND + 4) * row_bytes;
+  if ((4 * A3_BAND + 4) * W > A3_TH * A3_NLD) return false;
   return a1 + (a2 > band ? a2 : band) <= 160 * 1024 - 512;
 }
 
@@ -218,7 +240,7 @@ int avlen_i_audio3_fwd(const avlen_cnn3* const* nets, const float* x, const int*
   a.oh1 = (H - 8) / 4 + 1; a.ow1 = (W - 8) / 4 + 1; a.oh2 = (a.oh1 - 4) / 2 + 1; a.ow2 = (a.ow1 - 4) / 2 + 1; a.oh3 = a.oh2 - 2; a.ow3 = a.ow2 - 2;
   a.row_bytes = (W * 4 + 15) & ~15;
   a.a2_off = (int)(((long)a.oh1 * a.ow1 * 64 + 255) & ~255L);
-  const long a2 = (long)a.oh2 * a.ow2 * 128, band = (long)(4 * A3_BAND + 4) * a.row_bytes;
+  const long a2 = (long)a.oh2 * a.ow2 * 128, band = 2L * (4 * A3_BAND + 4) * a.row_bytes;
   const int lds = a.a2_off + (int)(a2 > band ? a2 : band);
   for (int g = 0; g < groups; g++) {
     a.w1[g] = nets[g]->conv[0].w16c; a.w2[g] = nets[g]->conv[1].w16; a.w3[g] = nets[g]->conv[2].w16;
