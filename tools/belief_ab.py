@@ -1,5 +1,5 @@
 import os, time, torch, sys
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
 from avlen_amd.harness import Workload
 from avlen_amd import _lib as L

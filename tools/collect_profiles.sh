@@ -56,6 +56,11 @@ python3 $R/bench.py --stage 2 --envs 32 --steps 2 --no-roofline --no-cpu-baselin
 python3 $R/bench.py --stage 2 --envs 32 --steps 2 --no-roofline --no-cpu-baseline --no-extras --precision bf16 2>/dev/null | tail -1 > $O/bench_stage2_envs32_bf16.log
 rocprofv3 --kernel-trace --stats -d /tmp/p2 -o res -- python3 $R/bench.py --stage 2 --envs 32 --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-extras > /tmp/p2.log 2>&1 || exit 1
 ( echo "# 2nd stage (BASELINE configs[3] per-GPU share: 32 envs, M = 300 memory history), bf16x3: kernels of ONE PPO update (2 x 2)"; echo; echo '`rocprofv3 --kernel-trace --stats -- python bench.py --stage 2 --envs 32 --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-extras`, everything after the last `gae_kernel`:'; echo; python3 $R/tools/update_breakdown.py $(find /tmp/p2 -name "*.db" | head -1) ) > $O/update_stage2.md || exit 1
+python3 $R/tools/update_sequence.py $(find /tmp/p2 -name "*.db" | head -1) > $O/update_sequence.txt || exit 1
+python3 $R/tools/step_trace.py $(find /tmp/p2 -name "*.db" | head -1) 150 40 > $O/step_trace_stage2.txt 2>&1
+python3 $R/tools/gemm_tn_time.py 2>&1 | grep -E "dW|max" > $O/gemm_tn_time.txt || exit 1
+python3 $R/tools/audio3_ab.py 2>&1 | grep fused > $O/audio3_ab.txt || exit 1
+python3 $R/tools/belief_ab.py 2>&1 | grep -E "env-steps" > $O/belief_ab.txt || exit 1
 python3 $R/bench.py --precision bf16 --steps 3 --no-roofline --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/bench_bf16.log
 python3 $R/bench.py --belief --spectrogram 65x26 --steps 3 --no-roofline --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/bench_belief_65x26.log
 rocprofv3 --kernel-trace --stats -d /tmp/pg -o res -- python3 $R/bench.py --config gru --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > /tmp/pg.log 2>&1 || exit 1

@@ -1,7 +1,7 @@
 """Times the row-contracted weight-gradient product (avlen_gemm_tn_bf16) at the 2nd-stage update's shapes next to the route it
 replaces (two transposing casts + the row-times-row GEMM): python tools/gemm_tn_time.py"""
 import sys, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from avlen_amd import _lib as L
 
 M = 722400
