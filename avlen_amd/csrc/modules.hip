@@ -468,6 +468,60 @@ __global__ void smt_build_kernel(const float* __restrict__ x, const float* __res
   if (FMT && t < 5) FMT[(long)row * 8 + t] = fmt[t];
 }
 
+// smt_build_kernel for the training forward at scale (722 k rows): ONE WAVE per row, four rows per block, no LDS / barrier -- the
+// relative pose is computed by every lane (same values, no broadcast needed), a lane writes column pairs (4-byte stores of the hi
+// and lo planes).  Same values as smt_build_kernel; the fp32 row is not written.
+__global__ __launch_bounds__(256) void smt_build16w_kernel(const float* __restrict__ x, const float* __restrict__ memory,
+                                                           const int32_t* __restrict__ mem_index, int NC, const float* __restrict__ masks,
+                                                           const float* __restrict__ pw, const float* __restrict__ pb, float* __restrict__ FMT,
+                                                           float* __restrict__ maskx, long R, int B, int M, int F, int pc,
+                                                           bf16* __restrict__ XF16, int ld16, long lo16) {
+  const int S = M + 1, lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const int b = (int)(row / S), s = (int)(row % S);
+  const int col = mem_index ? mem_index[b] : b;
+  const float* src = (s < M) ? memory + ((long)s * NC + col) * F : x + (long)b * F;
+  const float* xp = x + (long)b * F + pc;
+  float fmt[5];
+  {
+    const float ax = xp[0], ay = xp[1], ah = xp[2];
+    const float bx = src[pc], by = src[pc + 1], bh = src[pc + 2], bt = src[pc + 3];
+    const float heading_a = -ah, heading_b = -bh;
+    const float dx = bx - ax, dy = by - ay;
+    const float r = sqrtf(dx * dx + dy * dy);
+    const float phi = atan2f(dy, dx) - heading_a;
+    float dh = heading_b - heading_a;
+    dh = -atan2f(sinf(dh), cosf(dh));
+    fmt[0] = r * cosf(phi); fmt[1] = r * sinf(phi); fmt[2] = cosf(dh); fmt[3] = sinf(dh); fmt[4] = expf(-bt);
+  }
+  if (lane == 0) maskx[(long)b * S + s] = (s < M) ? masks[(long)b * M + s] : 1.f;
+  if (lane < 5) FMT[row * 8 + lane] = fmt[lane];
+  bf16* o16 = XF16 + row * ld16;
+  for (int i = 2 * lane; i < ld16; i += 128) {
+    float v[2];
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      const int c = i + e;
+      if (c < pc) v[e] = src[c];
+      else if (c < pc + 16) {
+        const int j = c - pc;
+        float a = pb[j];
+#pragma unroll
+        for (int k = 0; k < 5; k++) a += pw[j * 5 + k] * fmt[k];
+        v[e] = a;
+      } else if (c < F + 12) v[e] = src[c - 12];
+      else v[e] = 0.f;
+    }
+    const bf16 h0 = (bf16)v[0], h1 = (bf16)v[1];
+    *reinterpret_cast<unsigned*>(o16 + i) = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+    if (lo16) {
+      const bf16 l0 = (bf16)(v[0] - (float)h0), l1 = (bf16)(v[1] - (float)h1);
+      *reinterpret_cast<unsigned*>(o16 + lo16 + i) = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+    }
+  }
+}
+
 // dW_pose[16][5] += dPE^T FMT ; db_pose[16] += colsum(dPE)    (dPE: [R,16], FMT: [R,8])
 // A thread takes whole rows (64 + 32 contiguous bytes each), keeps the 96 sums in registers; one wave reduction + 96 atomics per
 // block.  (Until round 5: 96 threads, one output each, striding through the rows -- 0.8 ms per call at 722 k rows.)
@@ -2013,9 +2067,8 @@ extern "C" int avlen_smt_fwd(const avlen_smt* p, const float* x, const float* me
   if (!mem_index) NC = B;
   s.h.lo1 = prec == AVLEN_PREC_BF16X3 ? R * d : 0;
   if (save_for_backward && big16_on(p, s, prec, R, S, cto != 0)) {       // the fusion input straight into its operand planes
-    hipLaunchKernelGGL(smt_build_kernel, dim3((unsigned)R), dim3(128), 0, st, x, memory, mem_index, NC, masks, p->pose.w, p->pose.b,
-                       (float*)nullptr, s.ldxf, s.FMT, s.maskx, B, M, F, pose_col, cto, s.h.XF, s.h.ldxf,
-                       prec == AVLEN_PREC_BF16X3 ? R * s.h.ldxf : 0L);
+    hipLaunchKernelGGL(smt_build16w_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, x, memory, mem_index, NC, masks, p->pose.w,
+                       p->pose.b, s.FMT, s.maskx, R, B, M, F, pose_col, s.h.XF, s.h.ldxf, prec == AVLEN_PREC_BF16X3 ? R * s.h.ldxf : 0L);
     TRY(avlen_launch_status());
     return smt_fwd_big16(c, p, s, goal, out, B, S);
   }
