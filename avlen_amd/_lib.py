@@ -136,6 +136,11 @@ SIGNATURES = {
     "avlen_cast_bf16": (i32, [vp, i32, vp, i32, C.c_long, i32, vp]),
     "avlen_cast_h16": (i32, [vp, i32, vp, i32, C.c_long, i32, i32, vp]),
     "avlen_gemm_tn_bf16_workspace_bytes": (sz, [C.c_long, i32, i32]),
+    "avlen_cross1_expand": (i32, [vp, i32, vp, i32, vp, i32, vp]),
+    "avlen_cross1_reduce": (i32, [vp, vp, i32, vp, vp, i32, i32, vp]),
+    "avlen_cross1_dw": (i32, [vp, i32, vp, vp, i32, i32, vp]),
+    "avlen_cross1_fwd": (i32, [vp, vp, C.c_long, vp, vp, vp, i32, i32, C.c_float, vp]),
+    "avlen_cross1_bwd": (i32, [vp, vp, vp, vp, C.c_long, vp, vp, i32, i32, C.c_float, vp]),
     "avlen_gemm_tn_bf16": (i32, [vp, C.c_long, vp, C.c_long, C.c_long, i32, i32, vp, i32, C.c_float, vp, sz, vp]),
     "avlen_pack_conv_weight_h16": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "avlen_pack_fc_after_flatten_h16": (i32, [vp, vp, i32, i32, i32, i32, vp]),

@@ -321,3 +321,22 @@ int avlen_i_cross1_bwd(const float* P, const float* DM, const float* A, const vo
   hipLaunchKernelGGL(cross1_bwd_kernel, dim3(B), dim3(XTH), 0, st, P, DM, A, (const bf16*)MEM16, lo, dA, dMEM, S, scale);
   return avlen_launch_status();
 }
+
+// ---- C ABI (tests/test_gpu_primitives.py drives the five steps against torch autograd of the K | V formulation) ----
+extern "C" int avlen_cross1_expand(const float* X, int ldx, const float* W, int ldw, float* out, int B, hipStream_t st) {
+  return avlen_i_cross1_expand(X, ldx, W, ldw, out, B, st);
+}
+extern "C" int avlen_cross1_reduce(const float* Z, const float* W, int ldw, const float* bias, float* Y, int ldy, int B, hipStream_t st) {
+  return avlen_i_cross1_reduce(Z, W, ldw, bias, Y, ldy, B, st);
+}
+extern "C" int avlen_cross1_dw(const float* X, int ldx, const float* Z, float* dW, int ldw, int B, hipStream_t st) {
+  return avlen_i_cross1_dw(X, ldx, Z, dW, ldw, B, st);
+}
+extern "C" int avlen_cross1_fwd(const float* A, const void* MEM16, long lo, const float* maskx, float* P, float* Mo, int B, int S, float scale,
+                                hipStream_t st) {
+  return avlen_i_cross1_fwd(A, MEM16, lo, maskx, P, Mo, B, S, scale, st);
+}
+extern "C" int avlen_cross1_bwd(const float* P, const float* DM, const float* A, const void* MEM16, long lo, float* dA, float* dMEM, int B,
+                                int S, float scale, hipStream_t st) {
+  return avlen_i_cross1_bwd(P, DM, A, MEM16, lo, dA, dMEM, B, S, scale, st);
+}

@@ -134,6 +134,22 @@ int avlen_cast_bf16(const float* src, int ld_src, void* dst, int ld_dst, long ro
 /* The same cast into another 16-bit format: fmt 0 = bf16, 1 = fp16 (IEEE half), 2 = the LOW plane of the compensated bf16 pair,
  * bf16(x - bf16(x)) (AVLEN_PREC_BF16X3 operands are hi + lo planes of identical layout). */
 int avlen_cast_h16(const float* src, int ld_src, void* dst, int ld_dst, long rows, int cols, int fmt, avlen_stream_t stream);
+/* Single-query cross attention in "memory space" (csrc/cross1.hip; the decoder layer of the scene-memory transformer, one target token
+ * per sample: ss_baselines/savi/models/smt_state_encoder.py:152-166), d = 256, 8 heads of 32, S <= 320 keys.  The K | V projections
+ * of the S memory rows are absorbed into the query side, so the training path at scale forms neither K | V nor their gradients:
+ *   expand : out[b][h][c] = sum_j X[b][32 h + j] W[32 h + j][c]          (A = q_h W_k[h];  dm = dout_h W_v[h])          W: rows of a [d][d] slice
+ *   fwd    : P [B][8][S] = masked softmax_key(scale * A[b][h] . mem[b][key]),  Mo[b][h] = sum_key P mem[b][key]            (mem: bf16 [B*S][256],
+ *            low plane `lo` elements behind the high one, 0 = none; maskx [B][S], 1 = valid)
+ *   reduce : Y[b][32 h + j] = sum_c Z[b][h][c] W[32 h + j][c] (+ bias)   (out = W_v[h] Mo + b_v;  dq = dA W_k[h]^T)
+ *   bwd    : dA[b][h] = sum_key g mem[key],  dMEM[b*S + key] = sum_h P dm_h + g A_h,   g = scale * P (dm . mem[key] - sum_key P dm . mem)
+ *   dw     : dW[32 h + j][c] += sum_b X[b][32 h + j] Z[b][h][c]          (dW_v += dout^T Mo;  dW_k += q^T dA) */
+int avlen_cross1_expand(const float* X, int ldx, const float* W, int ldw, float* out, int B, avlen_stream_t stream);
+int avlen_cross1_reduce(const float* Z, const float* W, int ldw, const float* bias, float* Y, int ldy, int B, avlen_stream_t stream);
+int avlen_cross1_dw(const float* X, int ldx, const float* Z, float* dW, int ldw, int B, avlen_stream_t stream);
+int avlen_cross1_fwd(const float* A, const void* MEM16, long lo, const float* maskx, float* P, float* Mo, int B, int S, float scale,
+                     avlen_stream_t stream);
+int avlen_cross1_bwd(const float* P, const float* DM, const float* A, const void* MEM16, long lo, float* dA, float* dMEM, int B, int S,
+                     float scale, avlen_stream_t stream);
 /* Weight gradient of a Linear over many rows without transposed operand copies (replaces the dW term of loss.backward(),
  * ss_baselines/savi/ppo/ppo.py:207-270): C [N1][N2] (row stride ldc) = beta * C + A^T B with A [M][lda], B [M][ldb] ROW-major bf16
  * (lda, ldb multiples of 8, >= the column count rounded up to 8; the pad columns must hold zeros).  Partial tiles are summed in a

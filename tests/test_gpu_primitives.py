@@ -393,3 +393,53 @@ def test_gemm_tn_rows_contracted(L, M, N1, N2, lda, ldb, beta):
     assert torch.equal(outs[0], outs[1])
     scale = float(ref.abs().max())
     assert float((outs[0].double() - ref).abs().max()) < 2e-5 * scale + 1e-4 * math.sqrt(M) * 1e-2, (float((outs[0].double() - ref).abs().max()), scale)
+
+
+@pytest.mark.parametrize("B,S,planes", [(5, 301, 2), (3, 17, 1), (9, 320, 2)])
+def test_single_query_cross_attention_in_memory_space(L, B, S, planes):
+    """csrc/cross1.hip (the decoder's cross attention of the 2nd-stage training path): expand -> fwd -> reduce and its backward
+    (dw, expand, bwd, reduce, dw) against torch autograd (fp64) of the textbook formulation -- K | V = mem W_kv^T + b_kv, one query
+    per (sample, head), key-padding mask -- on the same memory rows (the bf16 hi (+ lo) planes, added back)."""
+    torch.manual_seed(7)
+    d, H, D = 256, 8, 32
+    scale = 1.0 / math.sqrt(D)
+    mem = torch.randn(B * S, d)
+    hi = mem.bfloat16()
+    lo = (mem - hi.float()).bfloat16()
+    memv = (hi.float() + (lo.float() if planes == 2 else 0)).double().view(B, S, d).requires_grad_(True)
+    q = torch.randn(B, d, dtype=torch.float64, requires_grad=True)
+    Wk = (torch.randn(d, d, dtype=torch.float64) / 16).requires_grad_(True)
+    Wv = (torch.randn(d, d, dtype=torch.float64) / 16).requires_grad_(True)
+    bk = torch.randn(d, dtype=torch.float64, requires_grad=True)
+    bv = torch.randn(d, dtype=torch.float64, requires_grad=True)
+    mask = (torch.rand(B, S) > 0.3).float()
+    mask[:, -1] = 1.0                                        # the current token is always valid
+    K = memv @ Wk.t() + bk
+    V = memv @ Wv.t() + bv
+    sc = scale * torch.einsum("bhd,bshd->bhs", q.view(B, H, D), K.view(B, S, H, D))
+    sc = sc.masked_fill(mask.double()[:, None, :] == 0, float("-inf"))
+    p = torch.softmax(sc, -1)
+    out = torch.einsum("bhs,bshd->bhd", p, V.view(B, S, H, D)).reshape(B, d)
+    dout = torch.randn(B, d, dtype=torch.float64)
+    out.backward(dout)
+    planes16 = dev(torch.cat([hi, lo], 0) if planes == 2 else hi)
+    lo_off = B * S * d if planes == 2 else 0
+    f = lambda t: dev(t.detach().float())
+    qd, Wkd, Wvd, bvd, md, dod = f(q), f(Wk), f(Wv), f(bv), dev(mask), f(dout)
+    z = lambda *s: torch.zeros(*s, device="cuda")
+    A, P, Mo, o, DM, dA, dMEM, dq, dWk, dWv = z(B, H, d), z(B, H, S), z(B, H, d), z(B, d), z(B, H, d), z(B, H, d), z(B * S, d), z(B, d), z(d, d), z(d, d)
+    st = L.stream()
+    L.call("avlen_cross1_expand", L.ptr(qd), d, L.ptr(Wkd), d, L.ptr(A), B, st)
+    L.call("avlen_cross1_fwd", L.ptr(A), L.ptr(planes16), lo_off, L.ptr(md), L.ptr(P), L.ptr(Mo), B, S, scale, st)
+    L.call("avlen_cross1_reduce", L.ptr(Mo), L.ptr(Wvd), d, L.ptr(bvd), L.ptr(o), d, B, st)
+    L.call("avlen_cross1_dw", L.ptr(dod), d, L.ptr(Mo), L.ptr(dWv), d, B, st)
+    L.call("avlen_cross1_expand", L.ptr(dod), d, L.ptr(Wvd), d, L.ptr(DM), B, st)
+    L.call("avlen_cross1_bwd", L.ptr(P), L.ptr(DM), L.ptr(A), L.ptr(planes16), lo_off, L.ptr(dA), L.ptr(dMEM), B, S, scale, st)
+    L.call("avlen_cross1_reduce", L.ptr(dA), L.ptr(Wkd), d, None, L.ptr(dq), d, B, st)
+    L.call("avlen_cross1_dw", L.ptr(qd), d, L.ptr(dA), L.ptr(dWk), d, B, st)
+    torch.cuda.synchronize()
+    assert rel_err(P, p.detach()) < 2e-5 and rel_err(o, out.detach()) < 2e-5
+    assert rel_err(dq, q.grad) < 5e-5 and rel_err(dWk, Wk.grad) < 5e-5 and rel_err(dWv, Wv.grad) < 5e-5
+    assert rel_err(dMEM, memv.grad.reshape(B * S, d)) < 5e-5
+    assert float(bk.grad.abs().max()) < 1e-9 * max(1.0, float(Wk.grad.abs().max()))   # the shift invariance the kernel relies on (db_k = 0)
+    assert rel_err(dod.sum(0), bv.grad) < 1e-5                                        # db_v = column sums of dout
