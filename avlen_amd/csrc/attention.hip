@@ -527,14 +527,18 @@ __global__ __launch_bounds__(NTH) void attn_smt16_kernel(const __bf16* __restric
         sacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, sacc[nt], 0, 0, 0);      // S^T: rows = keys, cols = queries
       }
     const int qi = mt * 16 + r16;
-    float mx = -INFINITY;
+    // the softmax in the base-2 domain: scores scaled by scale * log2(e) once, p = exp2(s - max) is ONE v_exp_f32 per element (a
+    // masked key's -inf gives 0 by itself: the maximum is finite, the current token is always a valid key) -- this loop is what
+    // bounds the kernel at 301 keys (VALU, not MFMA)
+    const float scale2 = scale * 1.44269504088896340736f;
+    float mx = -3.0e38f;
 #pragma unroll
     for (int nt = 0; nt < NKT; nt++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int key = nt * 16 + q4 * 4 + r;
         const bool ok = nt < n_kt && km[key] != 0.f;
-        const float v = ok ? sacc[nt][r] * scale : -INFINITY;
+        const float v = ok ? sacc[nt][r] * scale2 : -INFINITY;
         sacc[nt][r] = v;
         mx = fmaxf(mx, v);
       }
@@ -544,7 +548,7 @@ __global__ __launch_bounds__(NTH) void attn_smt16_kernel(const __bf16* __restric
     for (int nt = 0; nt < NKT; nt++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const float pv = (sacc[nt][r] == -INFINITY) ? 0.f : __expf(sacc[nt][r] - mx);
+        const float pv = __builtin_amdgcn_exp2f(sacc[nt][r] - mx);
         sum += pv; sacc[nt][r] = pv;
       }
     sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
@@ -592,7 +596,7 @@ __global__ __launch_bounds__(NTH) void attn_smt16_kernel(const __bf16* __restric
         if (O32) *reinterpret_cast<float4*>(O32 + (row0 + qi) * ldo32 + h * D + q4 * 4 + dt * 16) =
             make_float4(oacc[dt][0] * inv, oacc[dt][1] * inv, oacc[dt][2] * inv, oacc[dt][3] * inv);
       }
-      if (lse && q4 == 0) lse[((long)b * gridDim.x + h) * S + qi] = mx + __logf(sum);
+      if (lse && q4 == 0) lse[((long)b * gridDim.x + h) * S + qi] = (mx + __log2f(sum)) * 0.69314718055994530942f;   // natural units
     }
   }
 }
